@@ -1,0 +1,237 @@
+/*
+ * optiland_hip.h -- C ABI of the MI355X-native sequential ray-trace hot path.
+ *
+ * This is the drop-in boundary for Optiland's batched real-ray trace
+ * (reference: optiland/surfaces/surface_group.py:245-257 `SurfaceGroup.trace`,
+ * optiland/surfaces/standard_surface.py:200-274 `Surface.trace/_trace_real/
+ * _record_real`, driven by optiland/raytrace/real_ray_tracer.py:58-154).
+ * The reference has no native interface (it is pure Python); these entry points
+ * are what a ctypes binding inside `optiland.backend` would call -- see
+ * INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - plain C, POD structs, no exceptions cross the boundary;
+ *   - every function returns 0 on success or a negative OL_E* code and leaves a
+ *     thread-local message readable through ol_last_error();
+ *   - the library NEVER owns ray memory: every ray / record / PRT buffer is a
+ *     caller-allocated DEVICE pointer (e.g. torch tensor .data_ptr());
+ *   - the library owns only the opaque `ol_system` (surface table in HBM);
+ *   - all launches go to the caller's stream (`hipStream_t` passed as void*).
+ */
+#ifndef OPTILAND_HIP_H
+#define OPTILAND_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OL_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------- */
+#define OL_OK 0
+#define OL_EINVAL (-1)      /* bad argument                                  */
+#define OL_EUNSUPPORTED (-2)/* surface/coating kind the fast path refuses     */
+#define OL_EHIP (-3)        /* HIP runtime error (message has hipGetErrorString) */
+#define OL_ENOMEM (-4)
+
+/* ---- arithmetic type of the ray buffers -------------------------------- */
+typedef enum ol_dtype { OL_F32 = 0, OL_F64 = 1 } ol_dtype;
+
+/* ---- geometry kinds (reference class -> enum) ---------------------------
+ * PLANE         optiland/geometries/plane.py:72-109
+ * STANDARD      optiland/geometries/standard.py:97-175 (conic; |R|=inf allowed)
+ * EVEN_ASPHERE  optiland/geometries/even_asphere.py:93-140 (+ Newton-Raphson,
+ *               optiland/geometries/newton_raphson.py:119-168)
+ * ZERNIKE       optiland/geometries/zernike.py:153-266
+ * ODD_ASPHERE   optiland/geometries/odd_asphere.py:86-143
+ * POLYNOMIAL    optiland/geometries/polynomial.py:105-155 (x^i y^j freeform)
+ */
+typedef enum ol_geom_kind {
+  OL_GEOM_PLANE = 0,
+  OL_GEOM_STANDARD = 1,
+  OL_GEOM_EVEN_ASPHERE = 2,
+  OL_GEOM_ZERNIKE = 3,
+  OL_GEOM_ODD_ASPHERE = 4,
+  OL_GEOM_POLYNOMIAL = 5
+} ol_geom_kind;
+
+/* ---- what happens at the surface ----------------------------------------
+ * RECORD_ONLY  ObjectSurface.trace, optiland/surfaces/object_surface.py:56-93
+ * REFRACT      RealRays.refract,    optiland/rays/real_rays.py:163-187
+ * REFLECT      RealRays.reflect,    optiland/rays/real_rays.py:189-205
+ */
+typedef enum ol_interaction {
+  OL_INTERACT_RECORD_ONLY = 0,
+  OL_INTERACT_REFRACT = 1,
+  OL_INTERACT_REFLECT = 2
+} ol_interaction;
+
+/* ---- physical apertures (optiland/physical_apertures/ *.py) --------------
+ * aperture[] meaning per kind:
+ *   RADIAL         r_min, r_max                        radial.py:56-70
+ *   OFFSET_RADIAL  r_min, r_max, offset_x, offset_y    offset_radial.py:48-61
+ *   RECTANGULAR    x_min, x_max, y_min, y_max          rectangular.py:42-59
+ *   ELLIPTICAL     a, b, offset_x, offset_y            elliptical.py:42-56
+ */
+typedef enum ol_aperture_kind {
+  OL_AP_NONE = 0,
+  OL_AP_RADIAL = 1,
+  OL_AP_OFFSET_RADIAL = 2,
+  OL_AP_RECTANGULAR = 3,
+  OL_AP_ELLIPTICAL = 4
+} ol_aperture_kind;
+
+/* ---- coatings (optiland/coatings.py) --------------------------------------
+ *   SIMPLE   i *= T (refract) | R (reflect)            coatings.py:164-237
+ *   FRESNEL  Jones diag(s,p,1) from Fresnel equations  coatings.py:362-386,
+ *            jones.py:71-117 (needs a PRT buffer, i.e. polarized rays)
+ */
+typedef enum ol_coating_kind {
+  OL_COAT_NONE = 0,
+  OL_COAT_SIMPLE = 1,
+  OL_COAT_FRESNEL = 2
+} ol_coating_kind;
+
+#define OL_SURF_ROTATED 0x1u /* rot[] is not the identity */
+
+/* One traced surface.  All lengths in mm, angles already folded into rot[]. */
+typedef struct ol_surface_desc {
+  int32_t geom_kind;     /* ol_geom_kind                                      */
+  int32_t interaction;   /* ol_interaction                                    */
+  int32_t aperture_kind; /* ol_aperture_kind                                  */
+  int32_t coating_kind;  /* ol_coating_kind                                   */
+  int32_t coeff_offset;  /* first element of this surface's block in coeffs[] */
+  int32_t n_coeff;       /* EVEN/ODD_ASPHERE: number of C_i;
+                            ZERNIKE: number of terms (4 doubles per term:
+                            c_j, n_j, m_j, N_j -- coefficient, radial order,
+                            azimuthal order, normalisation constant);
+                            POLYNOMIAL: rows*cols of the c[i][j] grid (cols in
+                            poly_cols)                                         */
+  int32_t max_iter;      /* Newton-Raphson iteration cap (geometry.max_iter)  */
+  uint32_t flags;        /* OL_SURF_*                                         */
+  int32_t poly_cols;     /* POLYNOMIAL only: number of columns (y powers)     */
+  int32_t reserved_;
+  double radius;         /* radius of curvature (may be +-inf)                */
+  double conic;          /* conic constant k                                  */
+  double tol;            /* Newton-Raphson tolerance (geometry.tol)           */
+  double norm_radius;    /* ZERNIKE normalisation radius                      */
+  double origin[3];      /* global position of the local origin               */
+  double rot[9];         /* row-major R: local = R * (global - origin)
+                            (= Rx(-rx) Ry(-ry) Rz(-rz), with parent frames
+                            folded in; coordinate_system.py:73-107)           */
+  double aperture[4];
+  double coat[2];        /* SIMPLE: transmittance, reflectance                */
+} ol_surface_desc;
+
+/* Per (surface, wavelength) optical constants, laid out [surface][wavelength].
+ *   n1      = material_pre.n(lambda)   standard_surface.py:244, real_rays.py:175
+ *   n2      = material_post.n(lambda)
+ *   absorb  = 4*pi*k_pre(lambda)/lambda * 1e3  [1/mm]; 0 => no Beer-Lambert
+ *             step (propagation/homogeneous.py:44-53)
+ */
+typedef struct ol_surface_optics {
+  double n1;
+  double n2;
+  double absorb;
+} ol_surface_optics;
+
+typedef struct ol_system ol_system; /* opaque */
+
+/* ---- status bits written (OR-ed) into the device status word -------------
+ * Data-dependent conditions the reference turns into Python exceptions.   */
+#define OL_STATUS_ZERNIKE_RANGE 0x1u /* |x/norm|>1 or |y/norm|>1
+                                        (geometries/zernike.py:254-266)       */
+#define OL_STATUS_K_PARALLEL_X 0x2u  /* initial k parallel to x-hat
+                                        (rays/polarized_rays.py:221-222)      */
+
+/* ---- trace flags --------------------------------------------------------- */
+#define OL_TRACE_WRITE_RAYS 0x1u   /* write the final ray state back into rays[] */
+#define OL_TRACE_COMPACT 0x2u      /* enable wavefront straggler compaction in
+                                      the Newton loop (default on via 0x2)    */
+
+/* Polarisation state for the update_intensity epilogue
+ * (rays/polarized_rays.py:122-133, rays/polarization_state.py:29-56).      */
+typedef struct ol_polarization_state {
+  int32_t is_polarized; /* 0 => unpolarised: mean of the x and y states      */
+  int32_t reserved_;
+  double Ex, Ey, phase_x, phase_y;
+} ol_polarization_state;
+
+/* Build the device-resident surface table.
+ *   surf[n_surf]                  traced surfaces in order (object first)
+ *   coeffs[n_coeffs]              flat coefficient buffer (may be NULL if 0)
+ *   optics[n_surf*n_wavelengths]  per-surface, per-wavelength constants
+ * Replaces: the per-call walk over Surface objects in SurfaceGroup.trace
+ * (surfaces/surface_group.py:245-257).                                      */
+int ol_system_create(const ol_surface_desc* surf, int32_t n_surf,
+                     const double* coeffs, int32_t n_coeffs,
+                     const ol_surface_optics* optics, int32_t n_wavelengths,
+                     ol_system** out);
+void ol_system_destroy(ol_system* sys);
+int32_t ol_system_num_surfaces(const ol_system* sys);
+
+/* Trace n_rays through surfaces [first_surface, last_surface] (inclusive).
+ *   rays[8]  device pointers x,y,z,L,M,N,i,opd (each n_rays elements of dt);
+ *            read as the initial state; rewritten iff OL_TRACE_WRITE_RAYS.
+ *   record   nullable; (last-first+1) rows x 8 planes x record_stride
+ *            elements: row s, plane k at record + ((s*8+k)*record_stride).
+ *            Planes are x,y,z,L,M,N,intensity,opd in the GLOBAL frame, as
+ *            Surface._record_real stores them (standard_surface.py:260-274).
+ *   prt      nullable; 9 planes x n_rays (row-major 3x3 polarisation
+ *            ray-tracing matrix, real part) read-modify-write:
+ *            PolarizedRays.update (rays/polarized_rays.py:180-202).
+ *   status   nullable device uint32; OL_STATUS_* bits are OR-ed in.
+ * Replaces: SurfaceGroup.trace(rays, skip) -- `first_surface` generalises
+ * `skip`.                                                                    */
+int ol_trace(const ol_system* sys, ol_dtype dt, int64_t n_rays,
+             void* const rays[8], int32_t wavelength_index,
+             void* record, int64_t record_stride, void* prt,
+             int32_t first_surface, int32_t last_surface, uint32_t flags,
+             uint32_t* status, void* stream);
+
+/* Generate rays on device from normalised field/pupil coordinates for the case
+ * every config uses: angle field, object at infinity or finite, paraxial aiming
+ * (rays/ray_generator.py:47-99, rays/ray_aiming/paraxial.py:33-106,
+ * fields/field_types/angle.py:17-58).  See ol_raygen_params.               */
+typedef struct ol_raygen_params {
+  int32_t object_infinite; /* obj.is_infinite                                 */
+  int32_t reserved_;
+  double EPL, EPD;         /* paraxial entrance pupil location / diameter     */
+  double max_field;        /* degrees                                          */
+  double offset;           /* AngleField._get_starting_z_offset               */
+  double z_first;          /* surfaces.positions[1] (infinite) or [0] (finite)*/
+} ol_raygen_params;
+
+/* hx,hy,px,py: device arrays of n elements (dt); vx,vy: 1 - vignetting factor,
+ * device arrays of n elements or NULL (=> 1).  out[7]: x,y,z,L,M,N,i (i = 1). */
+int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n,
+                     const void* hx, const void* hy, const void* px,
+                     const void* py, const void* vx, const void* vy,
+                     void* const out[7], void* stream);
+
+/* update_intensity epilogue for polarised traces (trace() only):
+ * i = sum_fields |P E0|^2 * i0 / n_fields.  k0[3]: initial direction planes.  */
+int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt,
+                           const void* const k0[3], const void* i0,
+                           const ol_polarization_state* state, void* intensity,
+                           uint32_t* status, void* stream);
+
+/* Image-plane reductions for one ray block (analysis/spot_diagram/core.py:
+ * 329-372): out[0..5] += {sum w, sum w x, sum w y, sum w x^2, sum w y^2,
+ * count} with w = (i>0 ? 1 : 0) -- the masked centroid / RMS building blocks;
+ * out[6] = max r^2 about (cx,cy) is filled by ol_spot_max_r2.  Device doubles. */
+int ol_spot_moments(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
+                    const void* intensity, double* out6, void* stream);
+int ol_spot_max_r2(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
+                   const void* intensity, double cx, double cy, double* out1,
+                   void* stream);
+
+const char* ol_last_error(void);
+int32_t ol_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPTILAND_HIP_H */

@@ -1,0 +1,300 @@
+"""Pack a live reference `Optic` into a `SystemTable`.
+
+This is the only module that touches reference objects.  It reads exactly the
+attributes the reference's own trace reads (citations inline) and refuses --
+raising `UnsupportedSystem` -- anything the fused kernel does not implement, so
+the caller can leave such systems on the reference's own array path
+(SURVEY.md section 8b "must-not-intercept cases").
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import system as S
+from .system import SystemTable
+
+
+class UnsupportedSystem(Exception):
+    """The optic contains something the fused HIP path does not implement."""
+
+
+def _f(v) -> float:
+    """Backend scalar / 0-d array / python number -> float."""
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return float(np.asarray(v).reshape(-1)[0]) if np.ndim(v) else float(v)
+
+
+def _rot_x(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=np.float64)
+
+
+def _rot_y(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=np.float64)
+
+
+def _rot_z(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float64)
+
+
+def cs_to_affine(cs):
+    """Fold a (possibly nested) reference CoordinateSystem into (R, origin).
+
+    Reference: `CoordinateSystem.localize` (optiland/coordinate_system.py:73-89)
+    translates by (-x,-y,-z) then applies rotate_z(-rz), rotate_y(-ry),
+    rotate_x(-rx) (rays/real_rays.py:112-152), each only when the angle is
+    non-zero; a parent `reference_cs` is localized first.  Hence
+    local = R (global - origin), R = Rx(-rx) Ry(-ry) Rz(-rz) R_parent.
+    """
+    rx, ry, rz = _f(cs.rx), _f(cs.ry), _f(cs.rz)
+    t = np.array([_f(cs.x), _f(cs.y), _f(cs.z)], dtype=np.float64)
+    R = np.eye(3)
+    if rz:
+        R = _rot_z(-rz) @ R
+    if ry:
+        R = _rot_y(-ry) @ R
+    if rx:
+        R = _rot_x(-rx) @ R
+    if cs.reference_cs is not None:
+        Rp, tp = cs_to_affine(cs.reference_cs)
+        # child origin expressed in the global frame
+        with np.errstate(invalid="ignore"):
+            t = tp + Rp.T @ t
+        R = R @ Rp
+    return R, t
+
+
+def _pack_geometry(geom, row, coeffs: list):
+    name = type(geom).__name__
+    row["coeff_offset"] = len(coeffs)
+    row["n_coeff"] = 0
+    row["radius"] = math.inf
+    row["conic"] = 0.0
+    row["tol"] = 0.0
+    row["max_iter"] = 0
+    row["norm_radius"] = 1.0
+    if name == "Plane":
+        row["geom_kind"] = S.GEOM_PLANE
+        return
+    if name == "StandardGeometry":
+        row["geom_kind"] = S.GEOM_STANDARD
+        row["radius"] = _f(geom.radius)
+        row["conic"] = _f(geom.k)
+        return
+    if name in ("EvenAsphere", "OddAsphere"):
+        row["geom_kind"] = (
+            S.GEOM_EVEN_ASPHERE if name == "EvenAsphere" else S.GEOM_ODD_ASPHERE
+        )
+        row["radius"] = _f(geom.radius)
+        row["conic"] = _f(geom.k)
+        row["tol"] = float(geom.tol)
+        row["max_iter"] = int(geom.max_iter)
+        cs_ = [_f(c) for c in geom.coefficients]
+        row["n_coeff"] = len(cs_)
+        coeffs.extend(cs_)
+        return
+    if name == "PolynomialGeometry":
+        row["geom_kind"] = S.GEOM_POLYNOMIAL
+        row["radius"] = _f(geom.radius)
+        row["conic"] = _f(geom.k)
+        row["tol"] = float(geom.tol)
+        row["max_iter"] = int(geom.max_iter)
+        c = np.atleast_2d(np.asarray(_to_np(geom.coefficients), dtype=np.float64))
+        row["n_coeff"] = c.size
+        row["poly_cols"] = c.shape[1]
+        coeffs.extend(c.reshape(-1).tolist())
+        return
+    if name == "ZernikePolynomialGeometry":
+        row["geom_kind"] = S.GEOM_ZERNIKE
+        row["radius"] = _f(geom.radius)
+        row["conic"] = _f(geom.k)
+        row["tol"] = float(geom.tol)
+        row["max_iter"] = int(geom.max_iter)
+        row["norm_radius"] = _f(geom.norm_radius)
+        z = geom.zernike
+        cj = np.asarray(_to_np(z.coeffs), dtype=np.float64).reshape(-1)
+        row["n_coeff"] = cj.size
+        # (n, m) come from the scheme's own index table and N_j from its
+        # _norm_constant (optiland/zernike/base.py:42-68, 145-193).
+        for c, (n, m) in zip(cj, z.indices):
+            coeffs.extend([float(c), float(n), float(m), _f(z._norm_constant(n, m))])
+        return
+    raise UnsupportedSystem(f"geometry {name} is not on the fused path")
+
+
+def _to_np(v):
+    if hasattr(v, "detach"):
+        return v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+def _pack_aperture(ap, row):
+    row["aperture_kind"] = S.AP_NONE
+    if ap is None:
+        return
+    name = type(ap).__name__
+    if name == "RadialAperture":
+        row["aperture_kind"] = S.AP_RADIAL
+        row["aperture"] = [_f(ap.r_min), _f(ap.r_max), 0.0, 0.0]
+    elif name == "OffsetRadialAperture":
+        row["aperture_kind"] = S.AP_OFFSET_RADIAL
+        row["aperture"] = [_f(ap.r_min), _f(ap.r_max), _f(ap.offset_x), _f(ap.offset_y)]
+    elif name == "RectangularAperture":
+        row["aperture_kind"] = S.AP_RECTANGULAR
+        row["aperture"] = [_f(ap.x_min), _f(ap.x_max), _f(ap.y_min), _f(ap.y_max)]
+    elif name == "EllipticalAperture":
+        row["aperture_kind"] = S.AP_ELLIPTICAL
+        row["aperture"] = [_f(ap.a), _f(ap.b), _f(ap.offset_x), _f(ap.offset_y)]
+    else:
+        raise UnsupportedSystem(f"aperture {name} is not on the fused path")
+
+
+def _pack_coating(coating, row):
+    row["coating_kind"] = S.COAT_NONE
+    if coating is None:
+        return
+    name = type(coating).__name__
+    if name == "SimpleCoating":
+        row["coating_kind"] = S.COAT_SIMPLE
+        row["coat"] = [_f(coating.transmittance), _f(coating.reflectance)]
+    elif name == "FresnelCoating":
+        row["coating_kind"] = S.COAT_FRESNEL
+    else:
+        raise UnsupportedSystem(f"coating {name} is not on the fused path")
+
+
+def _scalar_index(material, w: float, which: str) -> float:
+    """material.n(lambda) / material.k(lambda) with a *scalar* wavelength.
+
+    The reference calls these with the whole N-vector `rays.w` and builds a
+    cache key out of all N values (optiland/materials/base.py:73-79), the
+    dominant CPU cost in its profile; per trace every ray shares one wavelength
+    (rays/ray_generator.py:87), so a scalar call returns the same number.
+    """
+    v = getattr(material, which)(w)
+    return _f(v)
+
+
+def pack_optic(optic, wavelengths=None, name: str | None = None) -> SystemTable:
+    """Flatten `optic` (a reference `Optic`) for the given wavelengths (microns).
+
+    Raises `UnsupportedSystem` for anything outside the fused path.
+    """
+    surfaces = list(optic.surfaces)
+    if wavelengths is None:
+        wavelengths = [_f(w.value) for w in optic.wavelengths.wavelengths]
+    wl = np.array([float(w) for w in np.atleast_1d(wavelengths)], dtype=np.float64)
+    n_s = len(surfaces)
+    desc = np.zeros(n_s, dtype=S.SURFACE_DESC_DTYPE)
+    optics = np.zeros((n_s, wl.size), dtype=S.SURFACE_OPTICS_DTYPE)
+    coeffs: list = []
+
+    for i, surf in enumerate(surfaces):
+        row = desc[i]
+        geom = surf.geometry
+        R, t = cs_to_affine(geom.cs)
+        row["origin"] = t
+        row["rot"] = R.reshape(-1)
+        row["flags"] = 0 if np.array_equal(R, np.eye(3)) else S.SURF_ROTATED
+        im = surf.interaction_model
+        if type(im).__name__ != "RefractiveReflectiveModel":
+            raise UnsupportedSystem(
+                f"interaction model {type(im).__name__} is not on the fused path"
+            )
+        if getattr(im, "bsdf", None) is not None:
+            raise UnsupportedSystem("BSDF scatter is not on the fused path")
+        _pack_geometry(geom, row, coeffs)
+        _pack_aperture(surf.aperture, row)
+        _pack_coating(surf.coating, row)
+        if i == 0:
+            # ObjectSurface.trace only records (surfaces/object_surface.py:56-93)
+            row["interaction"] = S.INTERACT_RECORD_ONLY
+            optics[i, :] = (1.0, 1.0, 0.0)
+            optics[i, :]["n2"] = [
+                _scalar_index(surf.material_post, float(w), "n") for w in wl
+            ]
+            continue
+        row["interaction"] = (
+            S.INTERACT_REFLECT if im.is_reflective else S.INTERACT_REFRACT
+        )
+        pre, post = surf.material_pre, surf.material_post
+        for m in (pre, post):
+            pm = type(m.propagation_model).__name__
+            if pm != "HomogeneousPropagation":
+                raise UnsupportedSystem(f"propagation model {pm} is not on the fused path")
+        for j, w in enumerate(wl):
+            w = float(w)
+            n1 = _scalar_index(pre, w, "n")
+            n2 = _scalar_index(post, w, "n")
+            k1 = _scalar_index(pre, w, "k")
+            # propagation/homogeneous.py:44-53: alpha = 4 pi k / lambda, applied
+            # as exp(-alpha * t * 1e3) only when k > 0.
+            absorb = (4.0 * math.pi * k1 / w) * 1e3 if k1 > 0 else 0.0
+            optics[i, j] = (n1, n2, absorb)
+
+    table = SystemTable(
+        surfaces=desc,
+        coeffs=np.asarray(coeffs, dtype=np.float64),
+        optics=optics,
+        wavelengths=wl,
+        name=name or (optic.name or type(optic).__name__),
+    )
+    table.last_thickness = _f(surfaces[-1].thickness) if n_s else 0.0
+    _pack_raygen(optic, table)
+    pol = optic.polarization
+    if pol != "ignore":
+        st = optic.polarization_state
+        table.polarization = {
+            "is_polarized": bool(st.is_polarized),
+            "Ex": None if st.Ex is None else _f(st.Ex),
+            "Ey": None if st.Ey is None else _f(st.Ey),
+            "phase_x": None if st.phase_x is None else _f(st.phase_x),
+            "phase_y": None if st.phase_y is None else _f(st.phase_y),
+        }
+    return table
+
+
+def _pack_raygen(optic, table: SystemTable) -> None:
+    """Scalars for on-device ray generation.
+
+    Only the case every config uses is packed: AngleField, paraxial aiming, not
+    object-space telecentric, no apodization (rays/ray_aiming/paraxial.py:33-106,
+    fields/field_types/angle.py:17-58).  Otherwise `table.raygen` stays empty and
+    callers generate rays with the reference's own RayGenerator.
+    """
+    fd = optic.fields.field_definition
+    if type(fd).__name__ != "AngleField":
+        return
+    if optic.obj_space_telecentric or optic.apodization is not None:
+        return
+    mode = getattr(optic.ray_tracer, "ray_aiming_config", {}).get("mode", "paraxial")
+    if mode != "paraxial":
+        return
+    obj = optic.object_surface
+    EPL = _f(optic.paraxial.EPL())
+    EPD = _f(optic.paraxial.EPD())
+    infinite = bool(obj.is_infinite)
+    pos = np.asarray(_to_np(optic.surfaces.positions), dtype=np.float64).reshape(-1)
+    if infinite:
+        offset = _f(fd._get_starting_z_offset(optic))
+        z_first = float(pos[1])
+    else:
+        offset = 0.0
+        z_first = float(pos[0])
+    table.raygen = {
+        "object_infinite": 1.0 if infinite else 0.0,
+        "EPL": EPL,
+        "EPD": EPD,
+        "max_field": _f(optic.fields.max_field),
+        "offset": offset,
+        "z_first": z_first,
+    }
+    table.fields = [
+        (_f(f.x), _f(f.y), _f(f.vx), _f(f.vy)) for f in optic.fields.fields
+    ]

@@ -1,0 +1,215 @@
+"""Packed description of a sequential optical system (the "surface table").
+
+`SystemTable` is the host-side POD image of what `ol_system_create`
+(include/optiland_hip.h) consumes: one `ol_surface_desc` per traced surface, a
+flat coefficient buffer and per-(surface, wavelength) optical constants.  It is
+what `SurfaceGroup.trace` walks in the reference
+(optiland/surfaces/surface_group.py:245-257), flattened once instead of being
+re-discovered through Python attribute access on every call.
+
+The table can be produced from a live reference `Optic` (see
+`optiland_amd.packer.pack_optic`) or loaded from a JSON fixture, which is how the
+GPU box -- where the reference package does not exist -- gets its systems.
+"""
+
+from __future__ import annotations
+
+import json
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# ---- enums (mirror include/optiland_hip.h) ---------------------------------
+GEOM_PLANE, GEOM_STANDARD, GEOM_EVEN_ASPHERE, GEOM_ZERNIKE = 0, 1, 2, 3
+GEOM_ODD_ASPHERE, GEOM_POLYNOMIAL = 4, 5
+INTERACT_RECORD_ONLY, INTERACT_REFRACT, INTERACT_REFLECT = 0, 1, 2
+AP_NONE, AP_RADIAL, AP_OFFSET_RADIAL, AP_RECTANGULAR, AP_ELLIPTICAL = 0, 1, 2, 3, 4
+COAT_NONE, COAT_SIMPLE, COAT_FRESNEL = 0, 1, 2
+SURF_ROTATED = 0x1
+
+STATUS_ZERNIKE_RANGE = 0x1
+STATUS_K_PARALLEL_X = 0x2
+
+TRACE_WRITE_RAYS = 0x1
+TRACE_COMPACT = 0x2
+
+GEOM_NAMES = {
+    GEOM_PLANE: "plane",
+    GEOM_STANDARD: "standard",
+    GEOM_EVEN_ASPHERE: "even_asphere",
+    GEOM_ZERNIKE: "zernike",
+    GEOM_ODD_ASPHERE: "odd_asphere",
+    GEOM_POLYNOMIAL: "polynomial",
+}
+
+# numpy image of `ol_surface_desc`; align=True reproduces the C layout.
+SURFACE_DESC_DTYPE = np.dtype(
+    [
+        ("geom_kind", np.int32),
+        ("interaction", np.int32),
+        ("aperture_kind", np.int32),
+        ("coating_kind", np.int32),
+        ("coeff_offset", np.int32),
+        ("n_coeff", np.int32),
+        ("max_iter", np.int32),
+        ("flags", np.uint32),
+        ("poly_cols", np.int32),
+        ("reserved_", np.int32),
+        ("radius", np.float64),
+        ("conic", np.float64),
+        ("tol", np.float64),
+        ("norm_radius", np.float64),
+        ("origin", np.float64, (3,)),
+        ("rot", np.float64, (9,)),
+        ("aperture", np.float64, (4,)),
+        ("coat", np.float64, (2,)),
+    ],
+    align=True,
+)
+
+SURFACE_OPTICS_DTYPE = np.dtype(
+    [("n1", np.float64), ("n2", np.float64), ("absorb", np.float64)], align=True
+)
+
+RAYGEN_DTYPE = np.dtype(
+    [
+        ("object_infinite", np.int32),
+        ("reserved_", np.int32),
+        ("EPL", np.float64),
+        ("EPD", np.float64),
+        ("max_field", np.float64),
+        ("offset", np.float64),
+        ("z_first", np.float64),
+    ],
+    align=True,
+)
+
+
+def _enc(v: float):
+    """JSON-safe float (JSON has no inf/nan literals that every parser takes)."""
+    v = float(v)
+    if math.isinf(v):
+        return "inf" if v > 0 else "-inf"
+    if math.isnan(v):
+        return "nan"
+    return v
+
+
+def _dec(v) -> float:
+    return float(v)
+
+
+@dataclass
+class SystemTable:
+    """POD surface table + the scalars ray generation needs."""
+
+    surfaces: np.ndarray  # SURFACE_DESC_DTYPE, shape (S+1,)  (object surface first)
+    coeffs: np.ndarray  # float64, flat
+    optics: np.ndarray  # SURFACE_OPTICS_DTYPE, shape (S+1, W)
+    wavelengths: np.ndarray  # float64 (W,) microns
+    raygen: dict = field(default_factory=dict)  # EPL, EPD, max_field, offset, ...
+    fields: list = field(default_factory=list)  # [(x, y, vx, vy), ...] field points
+    polarization: dict | None = None  # None => "ignore"; else PolarizationState
+    name: str = ""
+    last_thickness: float = 0.0  # optic.surfaces[-1].thickness
+
+    # ------------------------------------------------------------------ info
+    @property
+    def num_surfaces(self) -> int:
+        """Number of table rows (object + traced surfaces)."""
+        return int(self.surfaces.shape[0])
+
+    @property
+    def num_traced(self) -> int:
+        """S: ray-surface intersections per ray (every non-object surface)."""
+        return self.num_surfaces - 1
+
+    @property
+    def uses_polarization(self) -> bool:
+        return bool(np.any(self.surfaces["coating_kind"] == COAT_FRESNEL))
+
+    def wavelength_index(self, wavelength: float) -> int:
+        """Index of `wavelength` in the table (exact match on the packed value)."""
+        w = float(wavelength)
+        idx = np.nonzero(np.isclose(self.wavelengths, w, rtol=0.0, atol=1e-12))[0]
+        if idx.size == 0:
+            raise KeyError(
+                f"wavelength {w} not packed in this SystemTable "
+                f"(have {self.wavelengths.tolist()})"
+            )
+        return int(idx[0])
+
+    # ------------------------------------------------------------------ json
+    def to_json(self) -> str:
+        surf = []
+        for s in self.surfaces:
+            surf.append(
+                {
+                    k: (
+                        [_enc(x) for x in np.atleast_1d(s[k])]
+                        if SURFACE_DESC_DTYPE[k].shape
+                        else (
+                            _enc(s[k])
+                            if SURFACE_DESC_DTYPE[k].kind == "f"
+                            else int(s[k])
+                        )
+                    )
+                    for k in SURFACE_DESC_DTYPE.names
+                    if k != "reserved_"
+                }
+            )
+        doc = {
+            "name": self.name,
+            "surfaces": surf,
+            "coeffs": [_enc(c) for c in self.coeffs],
+            "wavelengths": [float(w) for w in self.wavelengths],
+            "optics": [
+                [[_enc(o["n1"]), _enc(o["n2"]), _enc(o["absorb"])] for o in row]
+                for row in self.optics
+            ],
+            "raygen": {k: _enc(v) for k, v in self.raygen.items()},
+            "fields": [[float(v) for v in f] for f in self.fields],
+            "polarization": self.polarization,
+            "last_thickness": _enc(self.last_thickness),
+        }
+        return json.dumps(doc, indent=1)
+
+    @classmethod
+    def from_json(cls, text: str) -> "SystemTable":
+        doc = json.loads(text)
+        surfaces = np.zeros(len(doc["surfaces"]), dtype=SURFACE_DESC_DTYPE)
+        for i, s in enumerate(doc["surfaces"]):
+            for k, v in s.items():
+                if isinstance(v, list):
+                    surfaces[i][k] = [_dec(x) for x in v]
+                elif SURFACE_DESC_DTYPE[k].kind == "f":
+                    surfaces[i][k] = _dec(v)
+                else:
+                    surfaces[i][k] = int(v)
+        optics = np.zeros(
+            (len(doc["optics"]), len(doc["wavelengths"])), dtype=SURFACE_OPTICS_DTYPE
+        )
+        for i, row in enumerate(doc["optics"]):
+            for j, (n1, n2, ab) in enumerate(row):
+                optics[i, j] = (_dec(n1), _dec(n2), _dec(ab))
+        return cls(
+            surfaces=surfaces,
+            coeffs=np.array([_dec(c) for c in doc["coeffs"]], dtype=np.float64),
+            optics=optics,
+            wavelengths=np.array(doc["wavelengths"], dtype=np.float64),
+            raygen={k: _dec(v) for k, v in doc.get("raygen", {}).items()},
+            fields=[tuple(f) for f in doc.get("fields", [])],
+            polarization=doc.get("polarization"),
+            name=doc.get("name", ""),
+            last_thickness=_dec(doc.get("last_thickness", 0.0)),
+        )
+
+    def save(self, path) -> None:
+        with open(path, "w") as f:
+            f.write(self.to_json())
+
+    @classmethod
+    def load(cls, path) -> "SystemTable":
+        with open(path) as f:
+            return cls.from_json(f.read())

@@ -1,0 +1,156 @@
+"""ctypes wrapper around oracle/liboracle.so (TEST INFRASTRUCTURE ONLY).
+
+May be imported by tests/, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+bench.py -- never by anything under optiland_amd/.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc (seconds)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "trace_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "optiland_hip.h")
+    stale = (
+        force
+        or not os.path.exists(so)
+        or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+    )
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.oracle_trace.restype = C.c_uint32
+        _LIB.oracle_polarized_intensity.restype = C.c_uint32
+        _LIB.oracle_sag.restype = C.c_double
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class PolState(C.Structure):
+    _fields_ = [
+        ("is_polarized", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("Ex", C.c_double),
+        ("Ey", C.c_double),
+        ("phase_x", C.c_double),
+        ("phase_y", C.c_double),
+    ]
+
+
+def pol_state(polarization: dict | None) -> PolState:
+    if not polarization or not polarization.get("is_polarized"):
+        return PolState(0, 0, 0.0, 0.0, 0.0, 0.0)
+    return PolState(1, 0, polarization["Ex"], polarization["Ey"],
+                    polarization["phase_x"], polarization["phase_y"])
+
+
+def trace(table, rays, wavelength_index=0, record=True, polarized=False,
+          first=0, last=None):
+    """Trace `rays` (dict of float64 arrays x,y,z,L,M,N,i[,opd]) through `table`.
+
+    Returns dict(final rays..., record=(rows,8,n) or None, prt=(n,3,3) complex or
+    None, pre_dir=(3,n), status=int).  Inputs are not modified.
+    """
+    n = int(np.asarray(rays["x"]).size)
+    last = table.num_surfaces - 1 if last is None else last
+    planes = []
+    for k in ("x", "y", "z", "L", "M", "N", "i", "opd"):
+        if k == "opd" and k not in rays:
+            planes.append(np.zeros(n))
+        else:
+            planes.append(np.ascontiguousarray(np.array(rays[k], dtype=np.float64)).copy())
+    arr = (C.c_void_p * 8)(*[_ptr(p) for p in planes])
+    rows = last - first + 1
+    rec = np.zeros((rows, 8, n)) if record else None
+    prt = None
+    if polarized:
+        prt = np.tile(np.eye(3, dtype=np.complex128), (n, 1, 1))
+    pre = np.zeros((3, n))
+    surf = np.ascontiguousarray(table.surfaces)
+    optics = np.ascontiguousarray(table.optics)
+    coeffs = np.ascontiguousarray(table.coeffs, dtype=np.float64)
+    status = lib().oracle_trace(
+        _ptr(surf), C.c_int32(table.num_surfaces), _ptr(coeffs), _ptr(optics),
+        C.c_int32(optics.shape[1]), C.c_int32(wavelength_index), C.c_int64(n), arr,
+        _ptr(rec) if rec is not None else None,
+        _ptr(prt) if prt is not None else None, _ptr(pre),
+        C.c_int32(first), C.c_int32(last),
+    )
+    out = dict(zip(("x", "y", "z", "L", "M", "N", "i", "opd"), planes))
+    out.update(record=rec, prt=prt, pre_dir=pre, status=int(status))
+    return out
+
+
+def generate_rays(raygen: dict, hx, hy, px, py, vx=None, vy=None):
+    from optiland_amd.system import RAYGEN_DTYPE
+
+    p = np.zeros(1, dtype=RAYGEN_DTYPE)
+    p["object_infinite"] = int(raygen["object_infinite"])
+    for k in ("EPL", "EPD", "max_field", "offset", "z_first"):
+        p[k] = raygen[k]
+    hx, hy, px, py = (np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64),
+                      np.broadcast(hx, hy, px, py).shape)).reshape(-1).copy()
+                      for a in (hx, hy, px, py))
+    n = hx.size
+    outs = [np.zeros(n) for _ in range(7)]
+    arr = (C.c_void_p * 7)(*[_ptr(o) for o in outs])
+    vxp = _ptr(np.ascontiguousarray(vx, dtype=np.float64)) if vx is not None else None
+    vyp = _ptr(np.ascontiguousarray(vy, dtype=np.float64)) if vy is not None else None
+    lib().oracle_generate_rays(_ptr(p), C.c_int64(n), _ptr(hx), _ptr(hy), _ptr(px),
+                               _ptr(py), vxp, vyp, arr)
+    return dict(zip(("x", "y", "z", "L", "M", "N", "i"), outs))
+
+
+def polarized_intensity(prt, L0, M0, N0, i0, polarization):
+    n = int(np.asarray(L0).size)
+    prt = np.ascontiguousarray(prt, dtype=np.complex128)
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (L0, M0, N0, i0)]
+    out = np.zeros(n)
+    st = pol_state(polarization)
+    status = lib().oracle_polarized_intensity(C.c_int64(n), _ptr(prt), *[_ptr(v) for v in a],
+                                              C.byref(st), _ptr(out))
+    return out, int(status)
+
+
+def sag(table, surface_index, x, y):
+    surf = np.ascontiguousarray(table.surfaces[surface_index:surface_index + 1])
+    coeffs = np.ascontiguousarray(table.coeffs, dtype=np.float64)
+    return lib().oracle_sag(_ptr(surf), _ptr(coeffs), C.c_double(x), C.c_double(y))
+
+
+def normal(table, surface_index, x, y):
+    surf = np.ascontiguousarray(table.surfaces[surface_index:surface_index + 1])
+    coeffs = np.ascontiguousarray(table.coeffs, dtype=np.float64)
+    out = np.zeros(3)
+    lib().oracle_normal(_ptr(surf), _ptr(coeffs), C.c_double(x), C.c_double(y), _ptr(out))
+    return out
+
+
+def distance(table, surface_index, x, y, z, L, M, N):
+    surf = np.ascontiguousarray(table.surfaces[surface_index:surface_index + 1])
+    coeffs = np.ascontiguousarray(table.coeffs, dtype=np.float64)
+    a = [np.ascontiguousarray(np.atleast_1d(v), dtype=np.float64) for v in (x, y, z, L, M, N)]
+    t = np.zeros(a[0].size)
+    lib().oracle_distance(_ptr(surf), _ptr(coeffs), C.c_int64(a[0].size),
+                          *[_ptr(v) for v in a], _ptr(t))
+    return t

@@ -1,0 +1,622 @@
+/*
+ * trace_oracle.c -- CPU restatement (fp64, plain C99) of Optiland's batched
+ * sequential real-ray trace.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this file's shared object; the product path (optiland_amd/) never
+ * imports, links or executes anything under oracle/.
+ *
+ * Parity status: PINNED.  tests/test_oracle_*.py check this restatement against
+ *  (1) the known-answer scalars hard-coded in the reference's own unit tests
+ *      (tests/test_geometries.py, tests/test_rays.py, tests/test_coatings.py),
+ *  (2) golden traces generated in the build container by importing the
+ *      reference itself with its NumPy backend (tools/make_golden.py ->
+ *      tests/golden/*.npz).
+ *
+ * The structure mirrors the reference: an outer loop over surfaces and, per
+ * surface, whole-batch passes -- so batch-global decisions (the Newton-Raphson
+ * stop rule, `any(k > 0)`) are reproduced exactly.  Every function cites the
+ * reference lines it follows (paths relative to /root/reference/optiland).
+ */
+#include <complex.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/optiland_hip.h"
+
+/* plane indices in rays[] / record rows */
+enum { PX = 0, PY, PZ, PL, PM, PN, PI_, POPD };
+
+typedef struct {
+  int64_t n;
+  double *x, *y, *z, *L, *M, *N, *i, *opd;
+  double *L0, *M0, *N0;       /* pre-interaction cosines (real_rays.py:170-172) */
+  double complex* p;          /* n x 3 x 3 PRT matrices or NULL                 */
+} rays_t;
+
+/* ---- coordinate_system.py:73-89 (localize) / 91-107 (globalize) -----------
+ * The packed descriptor carries the composed rotation R and origin; see
+ * optiland_amd/packer.py:cs_to_affine for the composition.                   */
+static void localize(const ol_surface_desc* s, rays_t* r) {
+  const double* R = s->rot;
+  const int rotated = (s->flags & OL_SURF_ROTATED) != 0;
+  for (int64_t j = 0; j < r->n; ++j) {
+    double x = r->x[j] - s->origin[0]; /* rays/base.py:51-65 translate */
+    double y = r->y[j] - s->origin[1];
+    double z = r->z[j] - s->origin[2];
+    if (rotated) {
+      double L = r->L[j], M = r->M[j], N = r->N[j];
+      r->x[j] = R[0] * x + R[1] * y + R[2] * z;
+      r->y[j] = R[3] * x + R[4] * y + R[5] * z;
+      r->z[j] = R[6] * x + R[7] * y + R[8] * z;
+      r->L[j] = R[0] * L + R[1] * M + R[2] * N;
+      r->M[j] = R[3] * L + R[4] * M + R[5] * N;
+      r->N[j] = R[6] * L + R[7] * M + R[8] * N;
+    } else {
+      r->x[j] = x; r->y[j] = y; r->z[j] = z;
+    }
+  }
+}
+
+static void globalize(const ol_surface_desc* s, rays_t* r) {
+  const double* R = s->rot;
+  const int rotated = (s->flags & OL_SURF_ROTATED) != 0;
+  for (int64_t j = 0; j < r->n; ++j) {
+    double x = r->x[j], y = r->y[j], z = r->z[j];
+    if (rotated) { /* inverse rotation = transpose */
+      double L = r->L[j], M = r->M[j], N = r->N[j];
+      double gx = R[0] * x + R[3] * y + R[6] * z;
+      double gy = R[1] * x + R[4] * y + R[7] * z;
+      double gz = R[2] * x + R[5] * y + R[8] * z;
+      x = gx; y = gy; z = gz;
+      r->L[j] = R[0] * L + R[3] * M + R[6] * N;
+      r->M[j] = R[1] * L + R[4] * M + R[7] * N;
+      r->N[j] = R[2] * L + R[5] * M + R[8] * N;
+    }
+    r->x[j] = x + s->origin[0];
+    r->y[j] = y + s->origin[1];
+    r->z[j] = z + s->origin[2];
+  }
+}
+
+/* ---- geometries/standard.py:81-95 (sag of the base conic) ----------------- */
+static double conic_sag(double R, double k, double x, double y) {
+  double r2 = x * x + y * y;
+  return r2 / (R * (1.0 + sqrt(1.0 - (1.0 + k) * r2 / (R * R))));
+}
+
+/* ---- zernike/base.py:216-239 (_radial_term) / 260-299 (_radial_derivative) */
+static double factorial_d(int n) {
+  double f = 1.0;
+  for (int i = 2; i <= n; ++i) f *= (double)i;
+  return f;
+}
+
+static double zern_radial(int n, int m, double r) {
+  int ma = m < 0 ? -m : m;
+  int s_max = (n - ma) / 2 + 1;
+  double value = 0.0;
+  for (int k = 0; k < s_max; ++k) {
+    double num = factorial_d(n - k);
+    double den = factorial_d(k) * factorial_d((n + ma) / 2 - k) *
+                 factorial_d((n - ma) / 2 - k);
+    double coeff = ((k & 1) ? -1.0 : 1.0) * num / den;
+    value += coeff * pow(r, (double)(n - 2 * k));
+  }
+  return value;
+}
+
+static double zern_radial_deriv(int n, int m, double r) { /* m >= 0 here */
+  int s_max = (n - m) / 2 + 1;
+  double value = 0.0;
+  for (int k = 0; k < s_max; ++k) {
+    double num = factorial_d(n - k);
+    double den = factorial_d(k) * factorial_d((n + m) / 2 - k) *
+                 factorial_d((n - m) / 2 - k);
+    int factor = n - 2 * k;
+    if (factor < 0) continue;
+    double power_term = (n - 2 * k - 1) >= 0 ? pow(r, (double)(n - 2 * k - 1)) : 0.0;
+    value += ((k & 1) ? -1.0 : 1.0) * (num / den) * (double)factor * power_term;
+  }
+  return value;
+}
+
+/* ---- sag(x, y) per geometry -------------------------------------------------
+ * even_asphere.py:93-109, odd_asphere.py:86-104, polynomial.py:105-126,
+ * zernike.py:153-180 (+ zernike/base.py:42-98 get_term/poly)                 */
+static double geom_sag(const ol_surface_desc* s, const double* coeffs, double x,
+                       double y, uint32_t* status) {
+  const double* c = coeffs + s->coeff_offset;
+  double r2 = x * x + y * y;
+  double z = conic_sag(s->radius, s->conic, x, y);
+  switch (s->geom_kind) {
+    case OL_GEOM_EVEN_ASPHERE:
+      for (int i = 0; i < s->n_coeff; ++i) z = z + c[i] * pow(r2, (double)(i + 1));
+      return z;
+    case OL_GEOM_ODD_ASPHERE: {
+      double r = sqrt(r2);
+      for (int i = 0; i < s->n_coeff; ++i) z = z + c[i] * pow(r, (double)(i + 1));
+      return z;
+    }
+    case OL_GEOM_POLYNOMIAL: {
+      int cols = s->poly_cols, rows = cols ? s->n_coeff / cols : 0;
+      for (int i = 0; i < rows; ++i)
+        for (int j = 0; j < cols; ++j)
+          z = z + c[i * cols + j] * pow(x, (double)i) * pow(y, (double)j);
+      return z;
+    }
+    case OL_GEOM_ZERNIKE: {
+      double xn = x / s->norm_radius, yn = y / s->norm_radius;
+      if (fabs(xn) > 1.0 || fabs(yn) > 1.0) *status |= OL_STATUS_ZERNIKE_RANGE;
+      double rho = sqrt(xn * xn + yn * yn);
+      double phi = atan2(yn, xn);
+      double sum = 0.0;
+      for (int j = 0; j < s->n_coeff; ++j) {
+        double cj = c[4 * j];
+        int n = (int)c[4 * j + 1], m = (int)c[4 * j + 2];
+        double Nj = c[4 * j + 3];
+        double az = m >= 0 ? cos(m * phi) : sin(-m * phi); /* base.py:241-258 */
+        sum += cj * Nj * zern_radial(n, m, rho) * az;
+      }
+      return z + sum;
+    }
+    default:
+      return z;
+  }
+}
+
+/* ---- _surface_normal(x, y) per Newton-Raphson geometry ----------------------
+ * even_asphere.py:111-140, odd_asphere.py:106-143, polynomial.py:128-155,
+ * zernike.py:182-252                                                          */
+static void geom_normal_nr(const ol_surface_desc* s, const double* coeffs, double x,
+                           double y, int all_rho_zero, double* nx, double* ny,
+                           double* nz) {
+  const double* c = coeffs + s->coeff_offset;
+  const double R = s->radius, k = s->conic;
+  double r2 = x * x + y * y;
+  double denom = R * sqrt(1.0 - (1.0 + k) * r2 / (R * R));
+  double dfdx = x / denom, dfdy = y / denom;
+  switch (s->geom_kind) {
+    case OL_GEOM_EVEN_ASPHERE:
+      for (int i = 0; i < s->n_coeff; ++i) {
+        dfdx = dfdx + 2 * (i + 1) * x * c[i] * pow(r2, (double)i);
+        dfdy = dfdy + 2 * (i + 1) * y * c[i] * pow(r2, (double)i);
+      }
+      break;
+    case OL_GEOM_ODD_ASPHERE: {
+      /* odd_asphere.py:120-134: non-finite terms (r == 0, i == 0) are zeroed */
+      double r = sqrt(r2);
+      for (int i = 0; i < s->n_coeff; ++i) {
+        double x_term = (i + 1) * x * c[i] * pow(r, (double)(i - 1));
+        double y_term = (i + 1) * y * c[i] * pow(r, (double)(i - 1));
+        if (!isfinite(x_term)) x_term = 0.0;
+        if (!isfinite(y_term)) y_term = 0.0;
+        dfdx = dfdx + x_term;
+        dfdy = dfdy + y_term;
+      }
+      break;
+    }
+    case OL_GEOM_POLYNOMIAL: {
+      int cols = s->poly_cols, rows = cols ? s->n_coeff / cols : 0;
+      for (int i = 1; i < rows; ++i)
+        for (int j = 0; j < cols; ++j)
+          dfdx = dfdx + i * c[i * cols + j] * pow(x, (double)(i - 1)) * pow(y, (double)j);
+      for (int i = 0; i < rows; ++i)
+        for (int j = 1; j < cols; ++j)
+          dfdy = dfdy + j * c[i * cols + j] * pow(x, (double)i) * pow(y, (double)(j - 1));
+      break;
+    }
+    case OL_GEOM_ZERNIKE: {
+      const double eps = 1e-14, nr = s->norm_radius;
+      double xn = x / nr, yn = y / nr;
+      double rho = sqrt(xn * xn + yn * yn);
+      double phi = atan2(yn, xn);
+      double drho_dx = all_rho_zero ? 0.0 : ((x / (nr * nr)) / (rho + eps));
+      double drho_dy = all_rho_zero ? 0.0 : ((y / (nr * nr)) / (rho + eps));
+      double dphi_dx = -(yn) / (rho * rho + eps) * (1.0 / nr);
+      double dphi_dy = +(xn) / (rho * rho + eps) * (1.0 / nr);
+      for (int j = 0; j < s->n_coeff; ++j) {
+        double cj = c[4 * j];
+        if (cj == 0.0) continue;
+        int n = (int)c[4 * j + 1], m = (int)c[4 * j + 2];
+        int ma = m < 0 ? -m : m;
+        /* zernike/base.py:100-137 get_derivative (no norm constant!) */
+        double Rt = zern_radial(n, ma, rho);
+        double Rd = zern_radial_deriv(n, ma, rho);
+        double dZdrho, dZdphi;
+        if (m == 0) { dZdrho = Rd; dZdphi = 0.0; }
+        else if (m > 0) { dZdrho = Rd * cos(m * phi); dZdphi = -m * Rt * sin(m * phi); }
+        else { dZdrho = Rd * sin(ma * phi); dZdphi = ma * Rt * cos(ma * phi); }
+        dfdx += cj * (dZdrho * drho_dx + dZdphi * dphi_dx);
+        dfdy += cj * (dZdrho * drho_dy + dZdphi * dphi_dy);
+      }
+      double norm = sqrt(dfdx * dfdx + dfdy * dfdy + 1.0);
+      if (norm < eps) norm = 1.0;
+      *nx = dfdx / norm; *ny = dfdy / norm; *nz = -1.0 / norm;
+      return;
+    }
+    default:
+      break;
+  }
+  double mag = sqrt(dfdx * dfdx + dfdy * dfdy + 1.0);
+  *nx = dfdx / mag; *ny = dfdy / mag; *nz = -1.0 / mag;
+}
+
+/* ---- standard.py:97-148 (conic distance) ----------------------------------- */
+static double conic_distance(double R, double k, double x, double y, double z,
+                             double L, double M, double N) {
+  if (isinf(R)) {
+    double N_safe = fabs(N) > 1e-14 ? N : 1e-14;
+    return -z / N_safe;
+  }
+  double a = k * N * N + L * L + M * M + N * N;
+  double b = 2 * k * N * z + 2 * L * x + 2 * M * y - 2 * N * R + 2 * N * z;
+  double c = k * z * z - 2 * R * z + x * x + y * y + z * z;
+  double d = b * b - 4 * a * c;
+  double sq = sqrt(d); /* NaN for d < 0, silently (standard.py:132-137) */
+  double t1 = (-b + sq) / (2 * a);
+  double t2 = (-b - sq) / (2 * a);
+  double z1 = z + t1 * N, z2 = z + t2 * N;
+  double t = (fabs(z1) <= fabs(z2)) ? t1 : t2; /* NaN compare false -> t2 */
+  if (a == 0) t = -c / b;
+  return t;
+}
+
+/* distance for the whole batch; Newton loop with the GLOBAL stop rule of
+ * newton_raphson.py:119-168.                                                  */
+static void batch_distance(const ol_surface_desc* s, const double* coeffs,
+                           const rays_t* r, double* t, uint32_t* status) {
+  const int64_t n = r->n;
+  if (s->geom_kind == OL_GEOM_PLANE) { /* plane.py:72-88 */
+    for (int64_t j = 0; j < n; ++j) t[j] = -r->z[j] / r->N[j];
+    return;
+  }
+  for (int64_t j = 0; j < n; ++j)
+    t[j] = conic_distance(s->radius, s->conic, r->x[j], r->y[j], r->z[j], r->L[j],
+                          r->M[j], r->N[j]);
+  if (s->geom_kind == OL_GEOM_STANDARD) return;
+
+  double* f = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+  for (int it = 0; it < s->max_iter; ++it) {
+    double fmax = 0.0; /* numpy max propagates NaN */
+    int has_nan = 0, all_rho_zero = 1;
+    for (int64_t j = 0; j < n; ++j) {
+      double xi = r->x[j] + t[j] * r->L[j];
+      double yi = r->y[j] + t[j] * r->M[j];
+      double zi = r->z[j] + t[j] * r->N[j];
+      f[j] = geom_sag(s, coeffs, xi, yi, status) - zi;
+      double af = fabs(f[j]);
+      if (isnan(af)) has_nan = 1;
+      else if (af > fmax) fmax = af;
+      if (!(xi == 0.0 && yi == 0.0)) all_rho_zero = 0;
+    }
+    if (n == 0) break;
+    if (!has_nan && fmax < s->tol) break;
+    for (int64_t j = 0; j < n; ++j) {
+      double xi = r->x[j] + t[j] * r->L[j];
+      double yi = r->y[j] + t[j] * r->M[j];
+      double nx, ny, nz;
+      geom_normal_nr(s, coeffs, xi, yi, all_rho_zero, &nx, &ny, &nz);
+      double nz_safe = fabs(nz) > 1e-14 ? nz : 1e-14;
+      double fx = -nx / nz_safe, fy = -ny / nz_safe;
+      double df = fx * r->L[j] + fy * r->M[j] - r->N[j];
+      double df_safe = fabs(df) > 1e-14 ? df : 1e-14;
+      t[j] = t[j] - f[j] / df_safe;
+    }
+  }
+  free(f);
+}
+
+/* surface normal at the hit point, per geometry (interact step) */
+static void hit_normal(const ol_surface_desc* s, const double* coeffs, double x,
+                       double y, int all_rho_zero, double* nx, double* ny,
+                       double* nz) {
+  if (s->geom_kind == OL_GEOM_PLANE) { /* plane.py:90-109 */
+    *nx = 0.0; *ny = 0.0; *nz = 1.0;
+    return;
+  }
+  if (s->geom_kind == OL_GEOM_STANDARD) { /* standard.py:150-175 */
+    double R = s->radius, k = s->conic;
+    double r2 = x * x + y * y;
+    double denom = R * sqrt(1.0 - (1.0 + k) * r2 / (R * R));
+    double dfdx = x / denom, dfdy = y / denom, dfdz = -1.0;
+    double mag = sqrt(dfdx * dfdx + dfdy * dfdy + dfdz * dfdz);
+    *nx = dfdx / mag; *ny = dfdy / mag; *nz = dfdz / mag;
+    return;
+  }
+  geom_normal_nr(s, coeffs, x, y, all_rho_zero, nx, ny, nz);
+}
+
+/* ---- physical_apertures/ contains() ------------------------------------ */
+static int aperture_contains(const ol_surface_desc* s, double x, double y) {
+  const double* a = s->aperture;
+  switch (s->aperture_kind) {
+    case OL_AP_RADIAL: { /* radial.py:56-70 */
+      double r2 = x * x + y * y;
+      return (r2 <= a[1] * a[1]) && (r2 >= a[0] * a[0]);
+    }
+    case OL_AP_OFFSET_RADIAL: { /* offset_radial.py:48-61 */
+      double r2 = (x - a[2]) * (x - a[2]) + (y - a[3]) * (y - a[3]);
+      return (r2 <= a[1] * a[1]) && (r2 >= a[0] * a[0]);
+    }
+    case OL_AP_RECTANGULAR: /* rectangular.py:42-59 */
+      return (a[0] <= x) && (x <= a[1]) && (a[2] <= y) && (y <= a[3]);
+    case OL_AP_ELLIPTICAL: { /* elliptical.py:42-56 */
+      double xx = x - a[2], yy = y - a[3];
+      return (xx * xx / (a[0] * a[0]) + yy * yy / (a[1] * a[1])) <= 1.0;
+    }
+    default:
+      return 1;
+  }
+}
+
+/* ---- rays/polarized_rays.py:136-202 (get_local_basis + update) ------------- */
+static void cross3(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static double norm3(const double* a) {
+  return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+}
+
+static void prt_update(rays_t* r, int64_t j, const double complex* jones /*3 diag or NULL*/) {
+  double k0[3] = {r->L0[j], r->M0[j], r->N0[j]};
+  double k1[3] = {r->L[j], r->M[j], r->N[j]};
+  double s[3], p0[3], p1[3];
+  cross3(k0, k1, s);
+  double mag = norm3(s);
+  if (mag == 0.0) { /* k0 parallel k1 (NaN != 0, falls through like numpy) */
+    double xh[3] = {1, 0, 0}, yh[3] = {0, 1, 0}, pf[3];
+    cross3(k0, xh, pf);
+    if (norm3(pf) == 0.0) cross3(k0, yh, pf);
+    cross3(pf, k0, s);
+    mag = norm3(s);
+  }
+  for (int a = 0; a < 3; ++a) s[a] /= mag;
+  cross3(k0, s, p0);
+  cross3(k1, s, p1);
+  /* o_in rows (s, p0, k0); o_out columns (s, p1, k1) */
+  double oin[3][3], oout[3][3];
+  for (int a = 0; a < 3; ++a) {
+    oin[0][a] = s[a]; oin[1][a] = p0[a]; oin[2][a] = k0[a];
+    oout[a][0] = s[a]; oout[a][1] = p1[a]; oout[a][2] = k1[a];
+  }
+  double complex P[3][3];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      double complex acc = 0;
+      for (int c = 0; c < 3; ++c) {
+        double complex jc = jones ? jones[c] : 1.0;
+        acc += oout[a][c] * jc * oin[c][b];
+      }
+      P[a][b] = acc;
+    }
+  double complex* p = r->p + 9 * j;
+  double complex q[9];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      double complex acc = 0;
+      for (int c = 0; c < 3; ++c) acc += P[a][c] * p[3 * c + b];
+      q[3 * a + b] = acc;
+    }
+  memcpy(p, q, sizeof(q));
+}
+
+/* ---- one surface, whole batch: standard_surface.py:200-274 ----------------- */
+static void trace_surface(const ol_surface_desc* s, const double* coeffs,
+                          const ol_surface_optics* o, rays_t* r, double* t,
+                          uint32_t* status) {
+  const int64_t n = r->n;
+  if (s->interaction == OL_INTERACT_RECORD_ONLY) return; /* object_surface.py:56-93 */
+  localize(s, r);
+  batch_distance(s, coeffs, r, t, status);
+  /* propagation/homogeneous.py:30-57 */
+  for (int64_t j = 0; j < n; ++j) {
+    r->x[j] = r->x[j] + t[j] * r->L[j];
+    r->y[j] = r->y[j] + t[j] * r->M[j];
+    r->z[j] = r->z[j] + t[j] * r->N[j];
+  }
+  if (o->absorb > 0.0) /* == any(k > 0) for a scalar k */
+    for (int64_t j = 0; j < n; ++j) r->i[j] = r->i[j] * exp(-o->absorb * t[j]);
+  /* standard_surface.py:244 */
+  for (int64_t j = 0; j < n; ++j) r->opd[j] = r->opd[j] + fabs(t[j] * o->n1);
+  /* clip: physical_apertures/base.py:71-82, real_rays.py:154-161 */
+  if (s->aperture_kind != OL_AP_NONE)
+    for (int64_t j = 0; j < n; ++j)
+      if (!aperture_contains(s, r->x[j], r->y[j])) r->i[j] = 0.0;
+
+  /* interactions/refractive_reflective_model.py:32-55 */
+  int all_rho_zero = 1;
+  for (int64_t j = 0; j < n; ++j)
+    if (!(r->x[j] == 0.0 && r->y[j] == 0.0)) { all_rho_zero = 0; break; }
+  const double u = o->n1 / o->n2;
+  for (int64_t j = 0; j < n; ++j) {
+    double nx, ny, nz;
+    hit_normal(s, coeffs, r->x[j], r->y[j], all_rho_zero, &nx, &ny, &nz);
+    double L0 = r->L[j], M0 = r->M[j], N0 = r->N[j];
+    r->L0[j] = L0; r->M0[j] = M0; r->N0[j] = N0;
+    /* real_rays.py:535-571 _align_surface_normal */
+    double dot = L0 * nx + M0 * ny + N0 * nz;
+    double sgn = (dot > 0) - (dot < 0);
+    if (isnan(dot)) sgn = NAN;
+    double ax = nx * sgn, ay = ny * sgn, az = nz * sgn;
+    dot = fabs(dot);
+    if (s->interaction == OL_INTERACT_REFLECT) { /* real_rays.py:189-205 */
+      r->L[j] = L0 - 2 * dot * ax;
+      r->M[j] = M0 - 2 * dot * ay;
+      r->N[j] = N0 - 2 * dot * az;
+    } else { /* real_rays.py:163-187 */
+      double root = sqrt(1 - u * u * (1 - dot * dot));
+      r->L[j] = u * L0 + ax * root - u * ax * dot;
+      r->M[j] = u * M0 + ay * root - u * ay * dot;
+      r->N[j] = u * N0 + az * root - u * az * dot;
+    }
+    /* interactions/base.py:111-128 _apply_coating_and_bsdf */
+    if (s->coating_kind == OL_COAT_SIMPLE) { /* coatings.py:213,236 */
+      r->i[j] = r->i[j] *
+                (s->interaction == OL_INTERACT_REFLECT ? s->coat[1] : s->coat[0]);
+    } else if (s->coating_kind == OL_COAT_FRESNEL && r->p) {
+      /* coatings.py:72-92 _compute_aoi uses the un-aligned normal */
+      double d = fabs(nx * L0 + ny * M0 + nz * N0);
+      if (d > 1.0) d = 1.0;
+      if (d < -1.0) d = -1.0;
+      double aoi = acos(d);
+      /* jones.py:71-117 */
+      double cosi = cos(aoi);
+      double nn = o->n2 / o->n1;
+      double complex root = csqrt((double complex)(nn * nn - sin(aoi) * sin(aoi)));
+      double complex J[3];
+      if (s->interaction == OL_INTERACT_REFLECT) {
+        double complex sj = (cosi - root) / (cosi + root);
+        double complex pj = (nn * nn * cosi - root) / (nn * nn * cosi + root);
+        J[0] = sj; J[1] = -pj; J[2] = -1.0;
+      } else {
+        double complex sj = 2 * cosi / (cosi + root);
+        double complex pj = 2 * nn * cosi / (nn * nn * cosi + root);
+        J[0] = sj; J[1] = pj; J[2] = 1.0;
+      }
+      prt_update(r, j, J);
+    } else if (r->p) {
+      prt_update(r, j, NULL); /* rays.update() with no Jones matrix */
+    }
+  }
+  globalize(s, r);
+}
+
+/* ===========================================================================
+ * Exported entry points (loaded with ctypes by tests/ and bench.py only)
+ * ========================================================================= */
+
+/* SurfaceGroup.trace(rays, skip=first) -- surfaces/surface_group.py:245-257.
+ * rays[8]: x,y,z,L,M,N,i,opd (updated in place).  record: rows x 8 x n or NULL.
+ * prt: n x 9 complex128 (interleaved) or NULL.  Returns OL_STATUS_* bits.     */
+uint32_t oracle_trace(const ol_surface_desc* surf, int32_t n_surf,
+                      const double* coeffs, const ol_surface_optics* optics,
+                      int32_t n_wl, int32_t wl_index, int64_t n, double* const rays[8],
+                      double* record, double* prt, double* pre_dir /*3 x n or NULL*/,
+                      int32_t first, int32_t last) {
+  (void)n_surf;
+  uint32_t status = 0;
+  rays_t r;
+  r.n = n;
+  r.x = rays[PX]; r.y = rays[PY]; r.z = rays[PZ];
+  r.L = rays[PL]; r.M = rays[PM]; r.N = rays[PN];
+  r.i = rays[PI_]; r.opd = rays[POPD];
+  size_t nn = (size_t)(n > 0 ? n : 1);
+  double* scratch = (double*)malloc(sizeof(double) * nn * 4);
+  r.L0 = scratch; r.M0 = scratch + nn; r.N0 = scratch + 2 * nn;
+  double* t = scratch + 3 * nn;
+  for (int64_t j = 0; j < n; ++j) { r.L0[j] = r.L[j]; r.M0[j] = r.M[j]; r.N0[j] = r.N[j]; }
+  r.p = (double complex*)prt;
+  for (int32_t s = first; s <= last; ++s) {
+    trace_surface(&surf[s], coeffs, &optics[(size_t)s * n_wl + wl_index], &r, t, &status);
+    if (record) { /* standard_surface.py:260-274 */
+      double* row = record + (size_t)(s - first) * 8 * (size_t)n;
+      for (int k = 0; k < 8; ++k) memcpy(row + (size_t)k * n, rays[k], sizeof(double) * (size_t)n);
+    }
+  }
+  if (pre_dir) {
+    memcpy(pre_dir, r.L0, sizeof(double) * (size_t)n);
+    memcpy(pre_dir + n, r.M0, sizeof(double) * (size_t)n);
+    memcpy(pre_dir + 2 * n, r.N0, sizeof(double) * (size_t)n);
+  }
+  free(scratch);
+  return status;
+}
+
+/* rays/ray_generator.py:47-99 + rays/ray_aiming/paraxial.py:33-106 +
+ * fields/field_types/angle.py:17-58.  out[7] = x,y,z,L,M,N,i.                */
+void oracle_generate_rays(const ol_raygen_params* p, int64_t n, const double* hx,
+                          const double* hy, const double* px, const double* py,
+                          const double* vx, const double* vy, double* const out[7]) {
+  const double d2r = M_PI / 180.0;
+  for (int64_t j = 0; j < n; ++j) {
+    double vxx = vx ? vx[j] : 1.0, vyy = vy ? vy[j] : 1.0;
+    double field_x = p->max_field * hx[j], field_y = p->max_field * hy[j];
+    double x0, y0, z0;
+    if (p->object_infinite) {
+      double x = -tan(field_x * d2r) * (p->offset + p->EPL);
+      double y = -tan(field_y * d2r) * (p->offset + p->EPL);
+      z0 = p->z_first - p->offset;
+      x0 = px[j] * p->EPD / 2 * vxx + x;
+      y0 = py[j] * p->EPD / 2 * vyy + y;
+    } else {
+      z0 = p->z_first;
+      x0 = -tan(field_x * d2r) * (p->EPL - z0);
+      y0 = -tan(field_y * d2r) * (p->EPL - z0);
+    }
+    double x1 = px[j] * p->EPD * vxx / 2;
+    double y1 = py[j] * p->EPD * vyy / 2;
+    double z1 = p->EPL;
+    double mag = sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0) + (z1 - z0) * (z1 - z0));
+    int is_zero = mag < 1e-9;
+    if (is_zero) mag = 1.0;
+    out[0][j] = x0; out[1][j] = y0; out[2][j] = z0;
+    out[3][j] = is_zero ? 0.0 : (x1 - x0) / mag;
+    out[4][j] = is_zero ? 0.0 : (y1 - y0) / mag;
+    out[5][j] = is_zero ? 1.0 : (z1 - z0) / mag;
+    out[6][j] = 1.0;
+  }
+}
+
+/* rays/polarized_rays.py:68-133, 204-233: update_intensity.
+ * prt: n x 9 complex128.  Returns status bits.                               */
+uint32_t oracle_polarized_intensity(int64_t n, const double* prt, const double* L0,
+                                    const double* M0, const double* N0, const double* i0,
+                                    const ol_polarization_state* st, double* intensity) {
+  uint32_t status = 0;
+  const double complex* P = (const double complex*)prt;
+  int nf = st->is_polarized ? 1 : 2;
+  for (int64_t j = 0; j < n; ++j) {
+    double k[3] = {L0[j], M0[j], N0[j]}, xh[3] = {1, 0, 0}, p[3], s[3];
+    cross3(k, xh, p);
+    double nrm = norm3(p);
+    if (nrm == 0.0) status |= OL_STATUS_K_PARALLEL_X;
+    for (int a = 0; a < 3; ++a) p[a] /= nrm;
+    cross3(p, k, s);
+    double acc = 0.0;
+    for (int f = 0; f < nf; ++f) {
+      double Ex, Ey, phx, phy;
+      if (st->is_polarized) { Ex = st->Ex; Ey = st->Ey; phx = st->phase_x; phy = st->phase_y; }
+      else { Ex = f == 0 ? 1.0 : 0.0; Ey = f == 0 ? 0.0 : 1.0; phx = phy = 0.0; }
+      double complex E0[3], E1[3];
+      for (int a = 0; a < 3; ++a)
+        E0[a] = Ex * cexp(I * phx) * s[a] + Ey * cexp(I * phy) * p[a];
+      for (int a = 0; a < 3; ++a) {
+        E1[a] = 0;
+        for (int b = 0; b < 3; ++b) E1[a] += P[9 * j + 3 * a + b] * E0[b];
+        acc += cabs(E1[a]) * cabs(E1[a]);
+      }
+    }
+    intensity[j] = acc * i0[j] / nf;
+  }
+  return status;
+}
+
+/* single-point helpers for the reference's known-answer unit tests */
+double oracle_sag(const ol_surface_desc* s, const double* coeffs, double x, double y) {
+  uint32_t st = 0;
+  if (s->geom_kind == OL_GEOM_PLANE) return 0.0;
+  if (s->geom_kind == OL_GEOM_STANDARD) return conic_sag(s->radius, s->conic, x, y);
+  return geom_sag(s, coeffs, x, y, &st);
+}
+
+void oracle_normal(const ol_surface_desc* s, const double* coeffs, double x, double y,
+                   double* out3) {
+  hit_normal(s, coeffs, x, y, (x == 0.0 && y == 0.0), &out3[0], &out3[1], &out3[2]);
+}
+
+void oracle_distance(const ol_surface_desc* s, const double* coeffs, int64_t n,
+                     const double* x, const double* y, const double* z, const double* L,
+                     const double* M, const double* N, double* t) {
+  rays_t r;
+  memset(&r, 0, sizeof(r));
+  r.n = n;
+  r.x = (double*)x; r.y = (double*)y; r.z = (double*)z;
+  r.L = (double*)L; r.M = (double*)M; r.N = (double*)N;
+  uint32_t st = 0;
+  batch_distance(s, coeffs, &r, t, &st);
+}

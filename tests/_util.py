@@ -1,0 +1,69 @@
+"""Shared helpers for the test-suite (golden loading, tolerances)."""
+
+from __future__ import annotations
+
+import glob
+import os
+
+import numpy as np
+
+from optiland_amd.system import SystemTable
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+PLANES = ("x", "y", "z", "L", "M", "N", "i", "opd")
+
+
+def golden_cases():
+    return sorted(
+        os.path.splitext(os.path.basename(p))[0]
+        for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
+    )
+
+
+def load_case(name):
+    table = SystemTable.load(os.path.join(GOLDEN, f"{name}.json"))
+    data = dict(np.load(os.path.join(GOLDEN, f"{name}.npz")))
+    return table, data
+
+
+def rays_in_dict(data):
+    r = data["rays_in"]
+    return {k: r[j].copy() for j, k in enumerate(PLANES[:7])}
+
+
+def assert_close_planes(got, want, rtol, atol_scale, label=""):
+    """Compare (..., 8, N) plane stacks.
+
+    Tolerance model (stated here once, used by every parity test): for each plane
+    |got - want| <= rtol * |want| + atol_scale * scale, where `scale` is the
+    largest finite |want| over the plane's GROUP -- positions (x, y, z) share one
+    scale (the size of the system: a focused spot near the axis is compared
+    relative to the path lengths that produced it, not to itself), direction
+    cosines (L, M, N) share one, intensity and opd have their own.  NaN masks must match
+    exactly, and so must the `i == 0` (clipped) mask of the intensity plane.
+    """
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (label, got.shape, want.shape)
+    nan_g, nan_w = np.isnan(got), np.isnan(want)
+    assert np.array_equal(nan_g, nan_w), f"{label}: NaN masks differ ({nan_g.sum()} vs {nan_w.sum()})"
+    groups = {0: (0, 1, 2), 1: (0, 1, 2), 2: (0, 1, 2), 3: (3, 4, 5), 4: (3, 4, 5),
+              5: (3, 4, 5), 6: (6,), 7: (7,)}
+    for k in range(want.shape[-2]):
+        w = want[..., k, :]
+        g = got[..., k, :]
+        fin = np.isfinite(w)
+        if not fin.any():
+            continue
+        grp = want[..., list(groups.get(k, (k,))), :]
+        scale = np.max(np.abs(grp[np.isfinite(grp)]))
+        err = np.abs(g[fin] - w[fin])
+        tol = rtol * np.abs(w[fin]) + atol_scale * scale
+        bad = err > tol
+        assert not bad.any(), (
+            f"{label}: plane {PLANES[k] if k < 8 else k}: max err {err.max():.3e} "
+            f"(scale {scale:.3e}, worst tol {tol[np.argmax(err)]:.3e}, {bad.sum()} bad)"
+        )
+        # +-inf entries must match exactly
+        assert np.array_equal(np.isinf(g), np.isinf(w)), f"{label}: inf masks differ"

@@ -1,0 +1,288 @@
+#!/usr/bin/env python
+"""Generate golden fixtures by importing the REFERENCE (NumPy backend, fp64).
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    python tools/make_golden.py            # writes tests/golden/*.json|*.npz
+                                           # and optiland_amd/data/*.json
+
+For every case it (1) builds the reference `Optic`, (2) packs it with
+`optiland_amd.packer.pack_optic` into a JSON surface table, (3) generates rays and
+traces them with the reference's own `SurfaceGroup.trace`, and (4) stores inputs,
+the per-surface recorded arrays and the final ray state.  The fixtures pin the
+oracle (tests/test_oracle_golden.py) and the HIP path (tests/test_gpu_parity.py).
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("OPTILAND_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path[:0] = [os.path.join(ROOT, "tests", "refshim"), REF, ROOT]
+
+import numpy as np  # noqa: E402
+
+import optiland.backend as be  # noqa: E402
+from optiland import optic as optic_mod  # noqa: E402
+from optiland import physical_apertures  # noqa: E402
+from optiland.coatings import SimpleCoating  # noqa: E402
+from optiland.rays import PolarizationState  # noqa: E402
+from optiland.samples.objectives import CookeTriplet, DoubleGauss  # noqa: E402
+from optiland.samples.simple import AsphericSinglet  # noqa: E402
+from optiland.samples.telescopes import HubbleTelescope  # noqa: E402
+
+from optiland_amd.packer import pack_optic  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(ROOT, "optiland_amd", "data")
+
+be.set_backend("numpy")
+
+
+# ----------------------------------------------------------------- systems
+def rc_asphere():
+    """Config C4: Ritchey-Chretien (Hubble mirrors) + even-asphere corrector plate
+    (SURVEY.md section 8d)."""
+    lens = optic_mod.Optic(name="RCAsphere")
+    lens.surfaces.add(index=0, radius=be.inf, thickness=be.inf)
+    lens.surfaces.add(index=1, thickness=4910.01016)
+    obsc = physical_apertures.RadialAperture(r_max=be.inf, r_min=177.80035)
+    lens.surfaces.add(index=2, radius=-11040.02286, thickness=-4910.01016,
+                      material="mirror", is_stop=True, conic=-1.001152, aperture=obsc)
+    lens.surfaces.add(index=3, radius=-1349.31166, thickness=6265.20955,
+                      material="mirror", conic=-1.483014)
+    lens.surfaces.add(index=4, surface_type="even_asphere", radius=be.inf, thickness=5.0,
+                      material="N-BK7", conic=0.0, coefficients=[0.0, 1e-12, -1e-18])
+    lens.surfaces.add(index=5, thickness=96.7)
+    lens.surfaces.add(index=6)
+    lens.set_aperture(aperture_type="EPD", value=2400)
+    lens.fields.set_type(field_type="angle")
+    lens.fields.add(y=0)
+    lens.fields.add(y=0.1)
+    lens.wavelengths.add(value=0.55, is_primary=True)
+    return lens
+
+
+def zernike_fresnel(polarization="unpolarized", zernike_type="fringe"):
+    """Config C5: Zernike freeform singlet + Fresnel coatings."""
+    lens = optic_mod.Optic(name=f"ZernikeFresnel_{zernike_type}")
+    coeffs = [0.0, 2e-4, -3e-4, 5e-4, 1e-3, -4e-4, 2.5e-4, -1.5e-4, 3e-4, 1e-4,
+              -2e-4, 1.2e-4]
+    lens.surfaces.add(index=0, radius=be.inf, thickness=be.inf)
+    lens.surfaces.add(index=1, surface_type="zernike", radius=50.0, thickness=5.0,
+                      material="N-BK7", is_stop=True, zernike_type=zernike_type,
+                      norm_radius=15.0, coefficients=coeffs)
+    lens.surfaces.add(index=2, radius=-200.0, thickness=75.0)
+    lens.surfaces.add(index=3)
+    lens.set_aperture(aperture_type="EPD", value=20)
+    lens.fields.set_type(field_type="angle")
+    lens.fields.add(y=0)
+    lens.fields.add(y=3)
+    lens.wavelengths.add(value=0.55, is_primary=True)
+    if polarization is not None:
+        lens.surfaces.set_fresnel_coatings()
+        if polarization == "unpolarized":
+            st = PolarizationState(is_polarized=False)
+        else:
+            st = PolarizationState(is_polarized=True, Ex=1.0, Ey=0.5, phase_x=0.0,
+                                   phase_y=0.7)
+        lens.updater.set_polarization(st)
+    return lens
+
+
+def tilted_fold():
+    """Edge case: decentered + tilted surfaces, a fold mirror, rectangular and
+    elliptical apertures, a SimpleCoating, finite object distance."""
+    lens = optic_mod.Optic(name="TiltedFold")
+    lens.surfaces.add(index=0, radius=be.inf, thickness=80.0)
+    lens.surfaces.add(index=1, radius=40.0, thickness=6.0, material="N-BK7", is_stop=True,
+                      aperture=physical_apertures.EllipticalAperture(a=5.5, b=4.5),
+                      coating=SimpleCoating(transmittance=0.97, reflectance=0.02))
+    lens.surfaces.add(index=2, radius=-60.0, thickness=20.0, dx=0.3, dy=-0.2, rx=0.02,
+                      ry=-0.015)
+    lens.surfaces.add(index=3, radius=be.inf, thickness=-25.0, material="mirror",
+                      rx=0.35, rz=0.1,
+                      aperture=physical_apertures.RectangularAperture(-6, 6, -5, 7),
+                      coating=SimpleCoating(transmittance=0.0, reflectance=0.9))
+    lens.surfaces.add(index=4, radius=be.inf, rx=0.7, conic=0.0)
+    lens.set_aperture(aperture_type="EPD", value=12)
+    lens.fields.set_type(field_type="angle")
+    lens.fields.add(y=0)
+    lens.fields.add(y=2.0)
+    lens.wavelengths.add(value=0.6328, is_primary=True)
+    return lens
+
+
+def nr_family():
+    """f3 geometries: odd asphere + x^i y^j polynomial freeform + offset aperture."""
+    lens = optic_mod.Optic(name="NRFamily")
+    lens.surfaces.add(index=0, radius=be.inf, thickness=be.inf)
+    lens.surfaces.add(index=1, surface_type="odd_asphere", radius=35.0, thickness=4.0,
+                      material="N-SF11", is_stop=True, conic=-0.3,
+                      coefficients=[0.0, 1e-4, -2e-5, 1e-6])
+    lens.surfaces.add(index=2, surface_type="polynomial", radius=-90.0, thickness=30.0,
+                      conic=0.1,
+                      coefficients=[[0.0, 1e-3, 2e-4], [-5e-4, 1e-4, 1e-6], [3e-4, -1e-5, 0]],
+                      aperture=physical_apertures.OffsetRadialAperture(
+                          r_max=9.0, r_min=0.5, offset_x=0.4, offset_y=-0.3))
+    lens.surfaces.add(index=3)
+    lens.set_aperture(aperture_type="EPD", value=16)
+    lens.fields.set_type(field_type="angle")
+    lens.fields.add(y=0)
+    lens.fields.add(y=5)
+    lens.wavelengths.add(value=0.5876, is_primary=True)
+    return lens
+
+
+def tir_prism():
+    """Edge case: steep glass->air exit so part of the bundle is totally internally
+    reflected (NaN directions, real_rays.py:179-180) and part misses a small
+    sphere (NaN distance, standard.py:132-137)."""
+    lens = optic_mod.Optic(name="TIRMiss")
+    lens.surfaces.add(index=0, radius=be.inf, thickness=be.inf)
+    lens.surfaces.add(index=1, radius=be.inf, thickness=10.0, material="N-SF11", is_stop=True)
+    lens.surfaces.add(index=2, radius=-7.4, thickness=1.5)
+    lens.surfaces.add(index=3, radius=2.6, thickness=5.0, material="N-BK7")
+    lens.surfaces.add(index=4)
+    lens.set_aperture(aperture_type="EPD", value=10)
+    lens.fields.set_type(field_type="angle")
+    lens.fields.add(y=0)
+    lens.fields.add(y=4)
+    lens.wavelengths.add(value=0.55, is_primary=True)
+    return lens
+
+
+# ------------------------------------------------------------------ helpers
+def disc_points(n, seed):
+    rng = np.random.default_rng(seed)
+    r = np.sqrt(rng.random(n))
+    th = 2 * np.pi * rng.random(n)
+    return r * np.cos(th), r * np.sin(th)
+
+
+def stack_record(optic):
+    sg = optic.surfaces
+    return np.stack([np.asarray(a, dtype=np.float64) for a in
+                     (sg.x, sg.y, sg.z, sg.L, sg.M, sg.N, sg.intensity, sg.opd)], axis=1)
+
+
+def run_case(name, optic, Hx, Hy, Px, Py, wavelength, use_trace=None, save_json_to=(GOLD,)):
+    """Trace and dump.  `use_trace`: dict(num_rays=, distribution=) to go through
+    Optic.trace() (fields x pupil expansion) instead of trace_generic."""
+    table = pack_optic(optic, wavelengths=[wavelength], name=name)
+    for d in save_json_to:
+        table.save(os.path.join(d, f"{name}.json"))
+
+    tracer = optic.ray_tracer
+    if use_trace is not None:
+        from optiland.distribution import create_distribution
+        dist = create_distribution(use_trace["distribution"])
+        dist.generate_points(use_trace["num_rays"])
+        Px, Py = np.asarray(dist.x, dtype=float), np.asarray(dist.y, dtype=float)
+        Hx = np.atleast_1d(np.asarray(Hx, dtype=float))
+        Hy = np.atleast_1d(np.asarray(Hy, dtype=float))
+        nf, npup = len(Hx), len(Px)
+        Hx_full, Hy_full = np.repeat(Hx, npup), np.repeat(Hy, npup)
+        Px_full, Py_full = np.tile(Px, nf), np.tile(Py, nf)
+    else:
+        Hx_full, Hy_full, Px_full, Py_full = (np.broadcast_to(
+            np.asarray(a, dtype=float), np.broadcast(Hx, Hy, Px, Py).shape).copy()
+            for a in (Hx, Hy, Px, Py))
+    # what trace_generic does before generate_rays (real_ray_tracer.py:134-137)
+    vx, vy = optic.fields.get_vig_factor(Hx_full, Hy_full)
+    if use_trace is None:
+        Px_gen, Py_gen = Px_full * (1 - vx), Py_full * (1 - vy)
+    else:
+        Px_gen, Py_gen = Px_full, Py_full
+    rays = tracer.ray_generator.generate_rays(Hx_full, Hy_full, Px_gen, Py_gen, wavelength)
+    rays_in = np.stack([np.array(getattr(rays, k), dtype=np.float64)
+                        for k in ("x", "y", "z", "L", "M", "N", "i")])
+    optic.surfaces.trace(rays)
+    record = stack_record(optic)
+    last = optic.surfaces[-1]
+    last.material_post.propagation_model.propagate(rays, last.thickness)
+    out = dict(Hx=Hx_full, Hy=Hy_full, Px=Px_full, Py=Py_full,
+               vx=np.asarray(vx, dtype=float) * np.ones_like(Px_full),
+               vy=np.asarray(vy, dtype=float) * np.ones_like(Px_full),
+               wavelength=np.float64(wavelength), rays_in=rays_in, record=record,
+               via_trace=np.bool_(use_trace is not None))
+    polarized = hasattr(rays, "p")
+    if polarized:
+        out["prt"] = np.array(rays.p, dtype=np.complex128)
+        out["i_before_update"] = np.array(rays.i, dtype=np.float64)
+        rays.update_intensity(optic.polarization_state)
+        out["i_updated"] = np.array(rays.i, dtype=np.float64)
+    out["final"] = np.stack([np.array(getattr(rays, k), dtype=np.float64)
+                             for k in ("x", "y", "z", "L", "M", "N", "i", "opd")])
+    out["pre_dir"] = np.stack([np.array(rays.L0), np.array(rays.M0), np.array(rays.N0)])
+
+    # cross-check against the reference's public entry point on a fresh optic state
+    if use_trace is None:
+        chk = optic.trace_generic(Hx_full, Hy_full, Px_full, Py_full, wavelength)
+    else:
+        chk = optic.trace(Hx, Hy, wavelength, use_trace["num_rays"], use_trace["distribution"])
+    for k, row in zip(("x", "y", "z", "L", "M", "N", "opd"), (0, 1, 2, 3, 4, 5, 7)):
+        a, b = np.asarray(getattr(chk, k)), out["final"][row]
+        assert np.array_equal(a, b, equal_nan=True), (name, k)
+    if polarized and use_trace is not None:
+        assert np.array_equal(np.asarray(chk.i), out["i_updated"], equal_nan=True)
+
+    np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
+    nan_frac = float(np.mean(np.isnan(out["final"][0])))
+    clip_frac = float(np.mean(out["final"][6] == 0))
+    print(f"{name:28s} N={rays_in.shape[1]:6d} S={record.shape[0]-1:2d} "
+          f"nan={nan_frac:.3f} clipped={clip_frac:.3f}")
+    return table
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    os.makedirs(DATA, exist_ok=True)
+
+    # C1: Cooke triplet through Optic.trace (fields x hexapolar pupil)
+    run_case("cooke_trace_hexapolar6", CookeTriplet(), [0.0, 0.0, 0.0], [0.0, 0.7, 1.0],
+             None, None, 0.55, use_trace=dict(num_rays=6, distribution="hexapolar"))
+    px, py = disc_points(1500, 0)
+    run_case("cooke_generic", CookeTriplet(), 0.0, 1.0, px, py, 0.55,
+             save_json_to=(GOLD, DATA))
+    # full-size C1 system JSON for the plumbing run is the same table.
+
+    # C2/C3: double Gauss
+    px, py = disc_points(2000, 0)
+    run_case("double_gauss", DoubleGauss(), 0.0, 0.7, px, py, 0.5876,
+             save_json_to=(GOLD, DATA))
+    hx = np.repeat([0.0, 0.3, -0.5], 300)
+    hy = np.repeat([0.0, 1.0, 0.6], 300)
+    px, py = disc_points(900, 3)
+    run_case("double_gauss_multifield", DoubleGauss(), hx, hy, px, py, 0.4861)
+
+    # C4: RC + even asphere corrector; pure-NR singlet
+    px, py = disc_points(2000, 1)
+    run_case("rc_asphere", rc_asphere(), 0.0, 1.0, px, py, 0.55, save_json_to=(GOLD, DATA))
+    run_case("hubble", HubbleTelescope(), 0.0, 0.5, px, py, 0.55)
+    px, py = disc_points(1500, 2)
+    run_case("aspheric_singlet", AsphericSinglet(), 0.0, 0.0, px, py, 0.587)
+
+    # C5: Zernike + Fresnel, unpolarised, through Optic.trace (update_intensity)
+    for zt in ("fringe", "standard", "noll"):
+        run_case(f"zernike_fresnel_{zt}", zernike_fresnel("unpolarized", zt), [0.0, 0.0],
+                 [0.0, 1.0], None, None, 0.55,
+                 use_trace=dict(num_rays=24, distribution="uniform"),
+                 save_json_to=(GOLD, DATA) if zt == "fringe" else (GOLD,))
+    px, py = disc_points(1200, 5)
+    run_case("zernike_fresnel_polarized", zernike_fresnel("polarized"), 0.0, 1.0, px, py, 0.55)
+    run_case("zernike_nopol", zernike_fresnel(None), 0.0, 0.5, px, py, 0.55)
+
+    # edge cases
+    px, py = disc_points(1500, 7)
+    run_case("tilted_fold", tilted_fold(), 0.0, 1.0, px, py, 0.6328)
+    run_case("nr_family", nr_family(), 0.0, 1.0, px * 0.9, py * 0.9, 0.5876)
+    run_case("tir_miss", tir_prism(), 0.0, 1.0, px, py, 0.55)
+
+
+if __name__ == "__main__":
+    main()
