@@ -1,0 +1,144 @@
+"""ctypes binding of include/optiland_hip.h (the drop-in boundary).
+
+There is deliberately NO fallback: if the HIP extension is missing or cannot be
+loaded every entry point raises -- a silent CPU path would void parity claims.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+
+class HipExtensionError(RuntimeError):
+    """The HIP shared library is missing / failed to load / returned an error."""
+
+
+class SurfaceDesc(C.Structure):
+    _fields_ = [
+        ("geom_kind", C.c_int32),
+        ("interaction", C.c_int32),
+        ("aperture_kind", C.c_int32),
+        ("coating_kind", C.c_int32),
+        ("coeff_offset", C.c_int32),
+        ("n_coeff", C.c_int32),
+        ("max_iter", C.c_int32),
+        ("flags", C.c_uint32),
+        ("poly_cols", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("radius", C.c_double),
+        ("conic", C.c_double),
+        ("tol", C.c_double),
+        ("norm_radius", C.c_double),
+        ("origin", C.c_double * 3),
+        ("rot", C.c_double * 9),
+        ("aperture", C.c_double * 4),
+        ("coat", C.c_double * 2),
+    ]
+
+
+class SurfaceOptics(C.Structure):
+    _fields_ = [("n1", C.c_double), ("n2", C.c_double), ("absorb", C.c_double)]
+
+
+class RaygenParams(C.Structure):
+    _fields_ = [
+        ("object_infinite", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("EPL", C.c_double),
+        ("EPD", C.c_double),
+        ("max_field", C.c_double),
+        ("offset", C.c_double),
+        ("z_first", C.c_double),
+    ]
+
+
+class PolarizationStateC(C.Structure):
+    _fields_ = [
+        ("is_polarized", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("Ex", C.c_double),
+        ("Ey", C.c_double),
+        ("phase_x", C.c_double),
+        ("phase_y", C.c_double),
+    ]
+
+
+EXPORTS = (
+    "ol_abi_version",
+    "ol_last_error",
+    "ol_system_create",
+    "ol_system_destroy",
+    "ol_system_num_surfaces",
+    "ol_trace",
+    "ol_generate_rays",
+    "ol_polarized_intensity",
+    "ol_spot_moments",
+    "ol_spot_max_r2",
+)
+
+F32, F64 = 0, 1
+ABI_VERSION = 1
+
+
+def library_path() -> str:
+    return os.environ.get("OPTILAND_HIP_LIBRARY", _build.library_path())
+
+
+def load():
+    """Load liboptiland_hip.so (once).  Raises HipExtensionError when absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise HipExtensionError(
+            f"HIP extension not built: {path} is missing. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "optiland_amd has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(path)
+    except OSError as exc:  # e.g. libamdhip64 missing
+        raise HipExtensionError(f"cannot load {path}: {exc}") from exc
+    vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
+    lib.ol_abi_version.restype = i32
+    lib.ol_abi_version.argtypes = []
+    lib.ol_last_error.restype = C.c_char_p
+    lib.ol_last_error.argtypes = []
+    lib.ol_system_create.restype = C.c_int
+    lib.ol_system_create.argtypes = [vp, i32, vp, i32, vp, i32, C.POINTER(vp)]
+    lib.ol_system_destroy.restype = None
+    lib.ol_system_destroy.argtypes = [vp]
+    lib.ol_system_num_surfaces.restype = i32
+    lib.ol_system_num_surfaces.argtypes = [vp]
+    lib.ol_trace.restype = C.c_int
+    lib.ol_trace.argtypes = [vp, C.c_int, i64, C.POINTER(vp), i32, vp, i64, vp, i32, i32, u32,
+                             vp, vp]
+    lib.ol_generate_rays.restype = C.c_int
+    lib.ol_generate_rays.argtypes = [vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, C.POINTER(vp), vp]
+    lib.ol_polarized_intensity.restype = C.c_int
+    lib.ol_polarized_intensity.argtypes = [C.c_int, i64, vp, C.POINTER(vp), vp, vp, vp, vp, vp]
+    lib.ol_spot_moments.restype = C.c_int
+    lib.ol_spot_moments.argtypes = [C.c_int, i64, vp, vp, vp, vp, vp]
+    lib.ol_spot_max_r2.restype = C.c_int
+    lib.ol_spot_max_r2.argtypes = [C.c_int, i64, vp, vp, vp, C.c_double, C.c_double, vp, vp]
+    if lib.ol_abi_version() != ABI_VERSION:
+        raise HipExtensionError(
+            f"{path}: ABI version {lib.ol_abi_version()} != expected {ABI_VERSION}; rebuild"
+        )
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ol_last_error().decode("utf-8", "replace")
+        if "Polarization must be set" in msg:
+            # same exception type/text as rays/ray_generator.py:89-94
+            raise ValueError(msg)
+        raise HipExtensionError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,68 @@
+"""Compile the HIP kernels + C ABI into optiland_amd/lib/liboptiland_hip.so.
+
+`hipcc --offload-arch=gfx950` cross-compiles without a GPU, so this runs in the
+build container; the resulting .so is git-ignored but travels with the tree to
+the GPU box.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIBNAME = "liboptiland_hip.so"
+SOURCES = ("trace_kernel.hip", "aux_kernels.hip", "capi.hip")
+HEADERS = ("device_table.h", "trace_launch.h")
+ARCH = "gfx950"
+
+
+def library_path() -> str:
+    return os.path.join(LIBDIR, LIBNAME)
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (need ROCm's hipcc to build the HIP extension)")
+    return exe
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Build (if stale) and return the path of the shared library."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    pub = os.path.join(HERE, "..", "include", "optiland_hip.h")
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [pub]
+    objs = []
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
+             "-fno-math-errno", "-Wall"]
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + hdrs):
+            cmd = [_hipcc(), *flags, "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(o)
+    so = library_path()
+    if force or _stale(so, objs):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", so]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return so
+
+
+if __name__ == "__main__":
+    print(build_library(force=False, verbose=True))

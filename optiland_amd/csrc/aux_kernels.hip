@@ -1,0 +1,257 @@
+// aux_kernels.hip -- the steps either side of the trace kernel:
+// on-device ray generation, the polarised update_intensity epilogue and the
+// image-plane spot reductions.  All are streaming elementwise / reduction
+// kernels (HBM-bound, grid-stride, coalesced SoA).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "trace_launch.h"
+
+namespace ol {
+
+namespace {
+constexpr int kBlock = 256;
+
+inline unsigned grid_for(int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  const int64_t cap = 256 * 8;  // 256 CUs x 8 blocks, grid-stride beyond that
+  return (unsigned)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+template <typename T>
+__device__ __forceinline__ T tan_deg(T deg);
+template <>
+__device__ __forceinline__ float tan_deg<float>(float deg) {
+  // formed in double: the field angle is a per-field constant in practice and
+  // fp32 tanf of a degree->radian product would cost 1e-7 of a 20 mm offset.
+  return (float)tan((double)deg * 0.017453292519943295);
+}
+template <>
+__device__ __forceinline__ double tan_deg<double>(double deg) {
+  return tan(deg * 0.017453292519943295);
+}
+}  // namespace
+
+// rays/ray_generator.py:47-99, rays/ray_aiming/paraxial.py:33-106,
+// fields/field_types/angle.py:17-58
+template <typename T>
+__global__ __launch_bounds__(kBlock) void raygen_kernel(RaygenDev p, int64_t n,
+                                                        const T* __restrict__ hx,
+                                                        const T* __restrict__ hy,
+                                                        const T* __restrict__ px,
+                                                        const T* __restrict__ py,
+                                                        const T* __restrict__ vx,
+                                                        const T* __restrict__ vy, T* ox, T* oy,
+                                                        T* oz, T* oL, T* oM, T* oN, T* oi) {
+  const T EPL = (T)p.EPL, EPD = (T)p.EPD, maxf = (T)p.max_field;
+  const T off_epl = (T)(p.offset + p.EPL);
+  const T z_inf = (T)(p.z_first - p.offset), z_fin = (T)p.z_first;
+  const T epl_z = (T)(p.EPL - p.z_first);
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * kBlock) {
+    const T vxx = vx ? vx[j] : T(1), vyy = vy ? vy[j] : T(1);
+    const T tx = tan_deg<T>(maxf * hx[j]), ty = tan_deg<T>(maxf * hy[j]);
+    const T pxx = px[j], pyy = py[j];
+    T x0, y0, z0;
+    if (p.object_infinite) {
+      x0 = pxx * EPD / T(2) * vxx + (-tx * off_epl);
+      y0 = pyy * EPD / T(2) * vyy + (-ty * off_epl);
+      z0 = z_inf;
+    } else {
+      x0 = -tx * epl_z;
+      y0 = -ty * epl_z;
+      z0 = z_fin;
+    }
+    const T x1 = pxx * EPD * vxx / T(2), y1 = pyy * EPD * vyy / T(2), z1 = EPL;
+    const T dx = x1 - x0, dy = y1 - y0, dz = z1 - z0;
+    T mag = sqrt(dx * dx + dy * dy + dz * dz);
+    const bool is_zero = mag < T(1e-9);
+    mag = is_zero ? T(1) : mag;
+    ox[j] = x0;
+    oy[j] = y0;
+    oz[j] = z0;
+    oL[j] = is_zero ? T(0) : dx / mag;
+    oM[j] = is_zero ? T(0) : dy / mag;
+    oN[j] = is_zero ? T(1) : dz / mag;
+    oi[j] = T(1);
+  }
+}
+
+template <typename T>
+hipError_t launch_raygen(const RaygenDev& p, int64_t n, const T* hx, const T* hy, const T* px,
+                         const T* py, const T* vx, const T* vy, T* const out[7],
+                         hipStream_t stream) {
+  hipLaunchKernelGGL((raygen_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, stream, p, n, hx, hy,
+                     px, py, vx, vy, out[0], out[1], out[2], out[3], out[4], out[5], out[6]);
+  return hipGetLastError();
+}
+
+// rays/polarized_rays.py:68-133, 204-233 with a real PRT matrix:
+// |P E0|^2 = |P Re E0|^2 + |P Im E0|^2.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pol_intensity_kernel(int64_t n, const T* __restrict__ prt,
+                                                               const T* __restrict__ k0x,
+                                                               const T* __restrict__ k0y,
+                                                               const T* __restrict__ k0z,
+                                                               const T* __restrict__ i0,
+                                                               PolStateDev st, T* intensity,
+                                                               uint32_t* status) {
+  // field amplitudes: E0 = Ex e^{i phx} s_hat + Ey e^{i phy} p_hat
+  T ar[2], ai[2], br[2], bi[2];
+  int nf;
+  if (st.is_polarized) {
+    nf = 1;
+    ar[0] = (T)(st.Ex * cos(st.phase_x));
+    ai[0] = (T)(st.Ex * sin(st.phase_x));
+    br[0] = (T)(st.Ey * cos(st.phase_y));
+    bi[0] = (T)(st.Ey * sin(st.phase_y));
+  } else {
+    nf = 2;
+    ar[0] = T(1); ai[0] = T(0); br[0] = T(0); bi[0] = T(0);
+    ar[1] = T(0); ai[1] = T(0); br[1] = T(1); bi[1] = T(0);
+  }
+  uint32_t flag = 0;
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * kBlock) {
+    const T kx = k0x[j], ky = k0y[j], kz = k0z[j];
+    // p = k x x_hat = (0, kz, -ky), normalised; s = p x k
+    T nrm = sqrt(kz * kz + ky * ky);
+    if (nrm == T(0)) flag |= 0x2u;  // OL_STATUS_K_PARALLEL_X
+    const T px = T(0), py = kz / nrm, pz = -ky / nrm;
+    const T sx = py * kz - pz * ky, sy = pz * kx - px * kz, sz = px * ky - py * kx;
+    T P[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) P[e] = prt[(int64_t)e * n + j];
+    T acc = T(0);
+    for (int f = 0; f < nf; ++f) {
+      const T er[3] = {ar[f] * sx + br[f] * px, ar[f] * sy + br[f] * py, ar[f] * sz + br[f] * pz};
+      const T ei[3] = {ai[f] * sx + bi[f] * px, ai[f] * sy + bi[f] * py, ai[f] * sz + bi[f] * pz};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const T vr = P[3 * a] * er[0] + P[3 * a + 1] * er[1] + P[3 * a + 2] * er[2];
+        const T vi = P[3 * a] * ei[0] + P[3 * a + 1] * ei[1] + P[3 * a + 2] * ei[2];
+        acc += vr * vr + vi * vi;
+      }
+    }
+    intensity[j] = acc * i0[j] / T(nf);
+  }
+  if (flag && status) atomicOr(status, flag);
+}
+
+template <typename T>
+hipError_t launch_pol_intensity(int64_t n, const T* prt, const T* const k0[3], const T* i0,
+                                const PolStateDev& st, T* intensity, uint32_t* status,
+                                hipStream_t stream) {
+  hipLaunchKernelGGL((pol_intensity_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, stream, n,
+                     prt, k0[0], k0[1], k0[2], i0, st, intensity, status);
+  return hipGetLastError();
+}
+
+// wave-level sum via DPP-free shuffles (64 lanes), then one atomic per wave
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double o = __shfl_down(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// analysis/spot_diagram/core.py:329-372, 440-481 building blocks: rays with
+// intensity > 0 only (mask at :470-476).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void spot_moments_kernel(int64_t n, const T* __restrict__ x,
+                                                              const T* __restrict__ y,
+                                                              const T* __restrict__ inten,
+                                                              double* out6) {
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * kBlock) {
+    const double xv = (double)x[j], yv = (double)y[j];
+    if (inten[j] > T(0)) {
+      s[0] += 1.0;
+      s[1] += xv;
+      s[2] += yv;
+      s[3] += xv * xv;
+      s[4] += yv * yv;
+      s[5] += 1.0;
+    }
+  }
+  __shared__ double part[kBlock / 64][6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double v = wave_sum(s[k]);
+    if (lane == 0) part[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double v = 0;
+    for (int w = 0; w < kBlock / 64; ++w) v += part[w][threadIdx.x];
+    atomicAdd(&out6[threadIdx.x], v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void spot_max_r2_kernel(int64_t n, const T* __restrict__ x,
+                                                             const T* __restrict__ y,
+                                                             const T* __restrict__ inten,
+                                                             double cx, double cy, double* out1) {
+  double best = 0.0;
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * kBlock) {
+    if (inten[j] > T(0)) {
+      const double dx = (double)x[j] - cx, dy = (double)y[j] - cy;
+      const double r2 = dx * dx + dy * dy;
+      best = r2 > best ? r2 : best;
+    }
+  }
+  best = wave_max(best);
+  __shared__ double part[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) part[wave] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = part[0];
+    for (int w = 1; w < kBlock / 64; ++w) v = part[w] > v ? part[w] : v;
+    // non-negative doubles order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long*>(out1),
+              (unsigned long long)__double_as_longlong(v));
+  }
+}
+
+template <typename T>
+hipError_t launch_spot_moments(int64_t n, const T* x, const T* y, const T* inten, double* out6,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL((spot_moments_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, stream, n, x,
+                     y, inten, out6);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten, double cx,
+                              double cy, double* out1, hipStream_t stream) {
+  hipLaunchKernelGGL((spot_max_r2_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, stream, n, x, y,
+                     inten, cx, cy, out1);
+  return hipGetLastError();
+}
+
+#define OL_INST(T)                                                                             \
+  template hipError_t launch_raygen<T>(const RaygenDev&, int64_t, const T*, const T*, const T*, \
+                                       const T*, const T*, const T*, T* const[7], hipStream_t); \
+  template hipError_t launch_pol_intensity<T>(int64_t, const T*, const T* const[3], const T*,  \
+                                              const PolStateDev&, T*, uint32_t*, hipStream_t); \
+  template hipError_t launch_spot_moments<T>(int64_t, const T*, const T*, const T*, double*,   \
+                                             hipStream_t);                                     \
+  template hipError_t launch_spot_max_r2<T>(int64_t, const T*, const T*, const T*, double,     \
+                                            double, double*, hipStream_t);
+OL_INST(float)
+OL_INST(double)
+#undef OL_INST
+
+}  // namespace ol

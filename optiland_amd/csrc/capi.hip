@@ -1,0 +1,487 @@
+// capi.hip -- the C ABI declared in include/optiland_hip.h.
+//
+// Host-side only: validates arguments, re-expresses the public surface table as
+// DevSurf<T>/DevOptics<T> for T in {float, double} (device_table.h) and launches
+// the kernels on the caller's stream.  No ray memory is ever allocated here.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/optiland_hip.h"
+#include "device_table.h"
+#include "trace_launch.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define OL_HIP_CHECK(expr)                                                        \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess)                                                         \
+      return fail(OL_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));        \
+  } while (0)
+
+void mat3_mul_abt(const double* A, const double* B, double* out) {  // A * B^T
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double acc = 0;
+      for (int k = 0; k < 3; ++k) acc += A[3 * i + k] * B[3 * j + k];
+      out[3 * i + j] = acc;
+    }
+}
+
+bool is_identity(const double* R) {
+  static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  return std::memcmp(R, I, sizeof(I)) == 0 ||
+         std::equal(R, R + 9, I);  // -0.0 == 0.0
+}
+
+double factorial(int n) {
+  double f = 1.0;
+  for (int i = 2; i <= n; ++i) f *= i;
+  return f;
+}
+
+// Regroup Zernike terms (c_j, n_j, m_j, N_j) into per-(|m|, cos|sin) radial
+// polynomials in u = rho^2 with the factor rho^|m| removed:
+//   R_n^m(rho) = sum_k (-1)^k (n-k)! / (k! ((n+m)/2-k)! ((n-m)/2-k)!) rho^(n-2k)
+// (zernike/base.py:216-239), rho^(n-2k) = rho^m u^((n-m)/2-k).
+// Layout per group: [m, kind, K, a_0..a_{K-1}, b_0..b_{K-1}] (device_table.h).
+int build_zernike_block(const double* terms, int n_terms, std::vector<double>& out,
+                        int* n_groups) {
+  std::map<std::pair<int, int>, std::pair<std::vector<double>, std::vector<double>>> groups;
+  for (int j = 0; j < n_terms; ++j) {
+    const double c = terms[4 * j];
+    const int n = (int)terms[4 * j + 1];
+    const int m = (int)terms[4 * j + 2];
+    const double N = terms[4 * j + 3];
+    if (c == 0.0) continue;  // zernike.py:234 (and contributes 0 to the sag)
+    const int ma = std::abs(m);
+    if (n < ma || ((n - ma) & 1) || n > 60) return -1;
+    const int K = (n - ma) / 2 + 1;
+    auto& g = groups[{ma, m < 0 ? 1 : 0}];
+    if ((int)g.first.size() < K) {
+      g.first.resize(K, 0.0);
+      g.second.resize(K, 0.0);
+    }
+    for (int k = 0; k < K; ++k) {
+      double coef = ((k & 1) ? -1.0 : 1.0) * factorial(n - k) /
+                    (factorial(k) * factorial((n + ma) / 2 - k) * factorial((n - ma) / 2 - k));
+      const int p = (n - ma) / 2 - k;
+      g.first[p] += c * N * coef;
+      g.second[p] += c * coef;
+    }
+  }
+  *n_groups = (int)groups.size();
+  for (auto& kv : groups) {  // std::map iterates in ascending (m, kind)
+    out.push_back((double)kv.first.first);
+    out.push_back((double)kv.first.second);
+    out.push_back((double)kv.second.first.size());
+    out.insert(out.end(), kv.second.first.begin(), kv.second.first.end());
+    out.insert(out.end(), kv.second.second.begin(), kv.second.second.end());
+  }
+  return 0;
+}
+
+template <typename T>
+struct DeviceTable {
+  ol::DevSurf<T>* surf = nullptr;
+  ol::DevOptics<T>* optics = nullptr;
+  T* coeffs = nullptr;
+};
+
+}  // namespace
+
+struct ol_system {
+  int32_t n_surf = 0;
+  int32_t n_wl = 0;
+  int device = 0;
+  DeviceTable<float> f32;
+  DeviceTable<double> f64;
+  std::vector<int32_t> interaction;  // host copy for validation
+  std::vector<int32_t> coating;
+};
+
+namespace {
+
+template <typename T>
+int upload(const std::vector<ol::DevSurf<double>>& surf64,
+           const std::vector<ol::DevOptics<double>>& opt64, const std::vector<double>& coef64,
+           DeviceTable<T>& dst) {
+  std::vector<ol::DevSurf<T>> surf(surf64.size());
+  for (size_t i = 0; i < surf64.size(); ++i) {
+    const auto& a = surf64[i];
+    auto& b = surf[i];
+    std::memset(&b, 0, sizeof(b));
+    b.geom = a.geom; b.interaction = a.interaction; b.aperture_kind = a.aperture_kind;
+    b.coating_kind = a.coating_kind; b.coeff_off = a.coeff_off; b.n_coeff = a.n_coeff;
+    b.max_iter = a.max_iter; b.flags = a.flags; b.poly_cols = a.poly_cols;
+    b.coeff_len = a.coeff_len;
+    b.cv = (T)a.cv; b.kp1 = (T)a.kp1; b.tol = (T)a.tol; b.inv_norm = (T)a.inv_norm;
+    for (int k = 0; k < 3; ++k) { b.origin[k] = (T)a.origin[k]; b.rel_off[k] = (T)a.rel_off[k]; }
+    for (int k = 0; k < 9; ++k) { b.rot[k] = (T)a.rot[k]; b.rel_rot[k] = (T)a.rel_rot[k]; }
+    for (int k = 0; k < 4; ++k) b.ap[k] = (T)a.ap[k];
+    for (int k = 0; k < 2; ++k) b.coat[k] = (T)a.coat[k];
+  }
+  std::vector<ol::DevOptics<T>> opt(opt64.size());
+  for (size_t i = 0; i < opt64.size(); ++i) {
+    std::memset(&opt[i], 0, sizeof(opt[i]));
+    opt[i].n1 = (T)opt64[i].n1; opt[i].n2 = (T)opt64[i].n2; opt[i].u = (T)opt64[i].u;
+    opt[i].nn = (T)opt64[i].nn; opt[i].absorb = (T)opt64[i].absorb;
+  }
+  std::vector<T> coef(coef64.size() ? coef64.size() : 1, T(0));
+  for (size_t i = 0; i < coef64.size(); ++i) coef[i] = (T)coef64[i];
+
+  OL_HIP_CHECK(hipMalloc((void**)&dst.surf, surf.size() * sizeof(ol::DevSurf<T>)));
+  OL_HIP_CHECK(hipMalloc((void**)&dst.optics, opt.size() * sizeof(ol::DevOptics<T>)));
+  OL_HIP_CHECK(hipMalloc((void**)&dst.coeffs, coef.size() * sizeof(T)));
+  OL_HIP_CHECK(hipMemcpy(dst.surf, surf.data(), surf.size() * sizeof(ol::DevSurf<T>),
+                         hipMemcpyHostToDevice));
+  OL_HIP_CHECK(hipMemcpy(dst.optics, opt.data(), opt.size() * sizeof(ol::DevOptics<T>),
+                         hipMemcpyHostToDevice));
+  OL_HIP_CHECK(hipMemcpy(dst.coeffs, coef.data(), coef.size() * sizeof(T),
+                         hipMemcpyHostToDevice));
+  return OL_OK;
+}
+
+template <typename T>
+void release(DeviceTable<T>& t) {
+  if (t.surf) (void)hipFree(t.surf);
+  if (t.optics) (void)hipFree(t.optics);
+  if (t.coeffs) (void)hipFree(t.coeffs);
+  t = DeviceTable<T>();
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T>
+int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* const rays[8],
+             int32_t wl, void* record, int64_t record_stride, void* prt, int32_t first,
+             int32_t last, uint32_t flags, uint32_t* status, hipStream_t stream) {
+  ol::TraceArgs<T> a;
+  a.surf = tab.surf;
+  a.optics = tab.optics;
+  a.coeffs = tab.coeffs;
+  bool vec = true;
+  constexpr int64_t kVec = 16 / sizeof(T);
+  for (int k = 0; k < 8; ++k) {
+    a.rays[k] = static_cast<T*>(rays[k]);
+    vec = vec && aligned16(rays[k]);
+  }
+  a.record = static_cast<T*>(record);
+  a.prt = static_cast<T*>(prt);
+  if (record) vec = vec && aligned16(record) && (record_stride % kVec == 0);
+  if (prt) vec = vec && aligned16(prt) && (n % kVec == 0);
+  a.status = status;
+  a.n = n;
+  a.record_stride = record_stride;
+  a.first = first;
+  a.last = last;
+  a.n_wl = sys->n_wl;
+  a.wl = wl;
+  a.flags = flags;
+  hipError_t e = ol::launch_trace<T>(a, vec, stream);
+  if (e != hipSuccess) return fail(OL_EHIP, "trace launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ol_last_error(void) { return g_err.c_str(); }
+int32_t ol_abi_version(void) { return OL_ABI_VERSION; }
+
+int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* coeffs,
+                     int32_t n_coeffs, const ol_surface_optics* optics, int32_t n_wavelengths,
+                     ol_system** out) {
+  if (!out) return fail(OL_EINVAL, "ol_system_create: out is NULL");
+  *out = nullptr;
+  if (!surf || n_surf <= 0) return fail(OL_EINVAL, "ol_system_create: no surfaces");
+  if (!optics || n_wavelengths <= 0) return fail(OL_EINVAL, "ol_system_create: no optics table");
+  if (n_coeffs < 0 || (n_coeffs > 0 && !coeffs))
+    return fail(OL_EINVAL, "ol_system_create: bad coefficient buffer");
+
+  std::vector<ol::DevSurf<double>> dev(n_surf);
+  std::vector<double> dcoef;
+  for (int32_t i = 0; i < n_surf; ++i) {
+    const ol_surface_desc& s = surf[i];
+    ol::DevSurf<double>& d = dev[i];
+    std::memset(&d, 0, sizeof(d));
+    if (s.geom_kind < OL_GEOM_PLANE || s.geom_kind > OL_GEOM_POLYNOMIAL)
+      return fail(OL_EUNSUPPORTED, "surface %d: geometry kind %d", i, s.geom_kind);
+    if (s.interaction < OL_INTERACT_RECORD_ONLY || s.interaction > OL_INTERACT_REFLECT)
+      return fail(OL_EUNSUPPORTED, "surface %d: interaction %d", i, s.interaction);
+    if (s.aperture_kind < OL_AP_NONE || s.aperture_kind > OL_AP_ELLIPTICAL)
+      return fail(OL_EUNSUPPORTED, "surface %d: aperture kind %d", i, s.aperture_kind);
+    if (s.coating_kind < OL_COAT_NONE || s.coating_kind > OL_COAT_FRESNEL)
+      return fail(OL_EUNSUPPORTED, "surface %d: coating kind %d", i, s.coating_kind);
+    if (s.n_coeff < 0 || s.coeff_offset < 0)
+      return fail(OL_EINVAL, "surface %d: negative coefficient range", i);
+    const int per = s.geom_kind == OL_GEOM_ZERNIKE ? 4 : 1;
+    if ((int64_t)s.coeff_offset + (int64_t)s.n_coeff * per > n_coeffs)
+      return fail(OL_EINVAL, "surface %d: coefficient block exceeds the buffer", i);
+
+    d.geom = s.geom_kind;
+    d.interaction = s.interaction;
+    d.aperture_kind = s.aperture_kind;
+    d.coating_kind = s.coating_kind;
+    d.max_iter = s.max_iter;
+    d.poly_cols = s.poly_cols;
+    d.flags = (s.flags & OL_SURF_ROTATED) ? ol::kSurfRotated : 0u;
+    const bool inf_r = std::isinf(s.radius) || s.geom_kind == OL_GEOM_PLANE;
+    if (inf_r) d.flags |= ol::kSurfRadiusInf;
+    d.cv = inf_r ? 0.0 : 1.0 / s.radius;
+    d.kp1 = 1.0 + s.conic;
+    d.tol = s.tol;
+    d.inv_norm = s.norm_radius != 0.0 ? 1.0 / s.norm_radius : 0.0;
+    for (int k = 0; k < 3; ++k) d.origin[k] = s.origin[k];
+    for (int k = 0; k < 9; ++k) d.rot[k] = s.rot[k];
+    if (!(d.flags & ol::kSurfRotated)) {
+      static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      std::memcpy(d.rot, I, sizeof(I));
+    }
+    // relative transform from the previous surface's local frame
+    static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::memcpy(d.rel_rot, I, sizeof(I));
+    if (i > 0) {
+      const ol::DevSurf<double>& p = dev[i - 1];
+      mat3_mul_abt(d.rot, p.rot, d.rel_rot);
+      double dv[3] = {p.origin[0] - d.origin[0], p.origin[1] - d.origin[1],
+                      p.origin[2] - d.origin[2]};
+      for (int r = 0; r < 3; ++r) {
+        double v = d.rot[3 * r] * dv[0] + d.rot[3 * r + 1] * dv[1] + d.rot[3 * r + 2] * dv[2];
+        d.rel_off[r] = std::isfinite(v) ? v : 0.0;
+      }
+      if (!is_identity(d.rel_rot)) d.flags |= ol::kSurfRelRotated;
+    }
+    // apertures: pre-square / pre-invert in double
+    switch (s.aperture_kind) {
+      case OL_AP_RADIAL:
+      case OL_AP_OFFSET_RADIAL:
+        d.ap[0] = s.aperture[0] * s.aperture[0];
+        d.ap[1] = s.aperture[1] * s.aperture[1];
+        d.ap[2] = s.aperture[2];
+        d.ap[3] = s.aperture[3];
+        break;
+      case OL_AP_RECTANGULAR:
+        for (int k = 0; k < 4; ++k) d.ap[k] = s.aperture[k];
+        break;
+      case OL_AP_ELLIPTICAL:
+        d.ap[0] = 1.0 / (s.aperture[0] * s.aperture[0]);
+        d.ap[1] = 1.0 / (s.aperture[1] * s.aperture[1]);
+        d.ap[2] = s.aperture[2];
+        d.ap[3] = s.aperture[3];
+        break;
+      default:
+        break;
+    }
+    d.coat[0] = s.coat[0];
+    d.coat[1] = s.coat[1];
+
+    // coefficient block
+    d.coeff_off = (int32_t)dcoef.size();
+    const double* src = coeffs ? coeffs + s.coeff_offset : nullptr;
+    if (s.geom_kind == OL_GEOM_ZERNIKE) {
+      int ng = 0;
+      if (build_zernike_block(src, s.n_coeff, dcoef, &ng) != 0)
+        return fail(OL_EINVAL, "surface %d: invalid Zernike (n, m) index", i);
+      d.n_coeff = ng;
+    } else if (s.geom_kind == OL_GEOM_EVEN_ASPHERE || s.geom_kind == OL_GEOM_ODD_ASPHERE ||
+               s.geom_kind == OL_GEOM_POLYNOMIAL) {
+      if (s.geom_kind == OL_GEOM_POLYNOMIAL &&
+          (s.poly_cols <= 0 || s.n_coeff % s.poly_cols != 0))
+        return fail(OL_EINVAL, "surface %d: polynomial grid %d x ? cols %d", i, s.n_coeff,
+                    s.poly_cols);
+      d.n_coeff = s.n_coeff;
+      dcoef.insert(dcoef.end(), src, src + s.n_coeff);
+    } else {
+      d.n_coeff = 0;
+    }
+    d.coeff_len = (int32_t)dcoef.size() - d.coeff_off;
+  }
+
+  std::vector<ol::DevOptics<double>> dopt((size_t)n_surf * n_wavelengths);
+  for (size_t i = 0; i < dopt.size(); ++i) {
+    const ol_surface_optics& o = optics[i];
+    std::memset(&dopt[i], 0, sizeof(dopt[i]));
+    dopt[i].n1 = o.n1;
+    dopt[i].n2 = o.n2;
+    dopt[i].u = o.n1 / o.n2;
+    dopt[i].nn = o.n2 / o.n1;
+    dopt[i].absorb = o.absorb > 0.0 ? o.absorb : 0.0;
+  }
+
+  ol_system* sys = new (std::nothrow) ol_system();
+  if (!sys) return fail(OL_ENOMEM, "ol_system_create: out of host memory");
+  sys->n_surf = n_surf;
+  sys->n_wl = n_wavelengths;
+  for (int32_t i = 0; i < n_surf; ++i) {
+    sys->interaction.push_back(surf[i].interaction);
+    sys->coating.push_back(surf[i].coating_kind);
+  }
+  if (hipGetDevice(&sys->device) != hipSuccess) {
+    delete sys;
+    return fail(OL_EHIP, "ol_system_create: no HIP device (hipGetDevice failed)");
+  }
+  int rc = upload<float>(dev, dopt, dcoef, sys->f32);
+  if (rc == OL_OK) rc = upload<double>(dev, dopt, dcoef, sys->f64);
+  if (rc != OL_OK) {
+    release(sys->f32);
+    release(sys->f64);
+    delete sys;
+    return rc;
+  }
+  *out = sys;
+  return OL_OK;
+}
+
+void ol_system_destroy(ol_system* sys) {
+  if (!sys) return;
+  release(sys->f32);
+  release(sys->f64);
+  delete sys;
+}
+
+int32_t ol_system_num_surfaces(const ol_system* sys) { return sys ? sys->n_surf : 0; }
+
+int ol_trace(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const rays[8],
+             int32_t wavelength_index, void* record, int64_t record_stride, void* prt,
+             int32_t first_surface, int32_t last_surface, uint32_t flags, uint32_t* status,
+             void* stream) {
+  if (!sys) return fail(OL_EINVAL, "ol_trace: system is NULL");
+  if (dt != OL_F32 && dt != OL_F64) return fail(OL_EINVAL, "ol_trace: bad dtype %d", (int)dt);
+  if (n_rays < 0) return fail(OL_EINVAL, "ol_trace: negative ray count");
+  if (first_surface < 0 || last_surface >= sys->n_surf || first_surface > last_surface)
+    return fail(OL_EINVAL, "ol_trace: surface range [%d, %d] outside [0, %d)", first_surface,
+                last_surface, sys->n_surf);
+  if (wavelength_index < 0 || wavelength_index >= sys->n_wl)
+    return fail(OL_EINVAL, "ol_trace: wavelength index %d outside [0, %d)", wavelength_index,
+                sys->n_wl);
+  if (n_rays == 0) return OL_OK;
+  if (!rays) return fail(OL_EINVAL, "ol_trace: rays is NULL");
+  for (int k = 0; k < 8; ++k)
+    if (!rays[k]) return fail(OL_EINVAL, "ol_trace: rays[%d] is NULL", k);
+  if (record && record_stride < n_rays)
+    return fail(OL_EINVAL, "ol_trace: record_stride %lld < n_rays %lld", (long long)record_stride,
+                (long long)n_rays);
+  if (!record && !(flags & OL_TRACE_WRITE_RAYS) && !prt)
+    return fail(OL_EINVAL, "ol_trace: nothing to write (no record, no OL_TRACE_WRITE_RAYS)");
+  if (!prt) {
+    // rays/ray_generator.py:89-94: polarization-dependent coatings need polarized rays
+    for (int32_t s = first_surface; s <= last_surface; ++s)
+      if (sys->coating[s] == OL_COAT_FRESNEL)
+        return fail(OL_EINVAL,
+                    "Polarization must be set when surfaces have polarization-dependent "
+                    "coatings.");
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dt == OL_F32)
+    return do_trace<float>(sys, sys->f32, n_rays, rays, wavelength_index, record, record_stride,
+                           prt, first_surface, last_surface, flags, status, st);
+  return do_trace<double>(sys, sys->f64, n_rays, rays, wavelength_index, record, record_stride,
+                          prt, first_surface, last_surface, flags, status, st);
+}
+
+int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n, const void* hx,
+                     const void* hy, const void* px, const void* py, const void* vx,
+                     const void* vy, void* const out[7], void* stream) {
+  if (!p || !hx || !hy || !px || !py || !out)
+    return fail(OL_EINVAL, "ol_generate_rays: NULL argument");
+  if (n < 0) return fail(OL_EINVAL, "ol_generate_rays: negative count");
+  if (n == 0) return OL_OK;
+  for (int k = 0; k < 7; ++k)
+    if (!out[k]) return fail(OL_EINVAL, "ol_generate_rays: out[%d] is NULL", k);
+  ol::RaygenDev d{p->object_infinite, p->EPL, p->EPD, p->max_field, p->offset, p->z_first};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (dt == OL_F32) {
+    float* o[7];
+    for (int k = 0; k < 7; ++k) o[k] = static_cast<float*>(out[k]);
+    e = ol::launch_raygen<float>(d, n, (const float*)hx, (const float*)hy, (const float*)px,
+                                 (const float*)py, (const float*)vx, (const float*)vy, o, st);
+  } else if (dt == OL_F64) {
+    double* o[7];
+    for (int k = 0; k < 7; ++k) o[k] = static_cast<double*>(out[k]);
+    e = ol::launch_raygen<double>(d, n, (const double*)hx, (const double*)hy, (const double*)px,
+                                  (const double*)py, (const double*)vx, (const double*)vy, o, st);
+  } else {
+    return fail(OL_EINVAL, "ol_generate_rays: bad dtype %d", (int)dt);
+  }
+  if (e != hipSuccess) return fail(OL_EHIP, "raygen launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
+int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt, const void* const k0[3],
+                           const void* i0, const ol_polarization_state* state, void* intensity,
+                           uint32_t* status, void* stream) {
+  if (!prt || !k0 || !k0[0] || !k0[1] || !k0[2] || !i0 || !state || !intensity)
+    return fail(OL_EINVAL, "ol_polarized_intensity: NULL argument");
+  if (n_rays < 0) return fail(OL_EINVAL, "ol_polarized_intensity: negative count");
+  if (n_rays == 0) return OL_OK;
+  ol::PolStateDev s{state->is_polarized, state->Ex, state->Ey, state->phase_x, state->phase_y};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (dt == OL_F32) {
+    const float* k[3] = {(const float*)k0[0], (const float*)k0[1], (const float*)k0[2]};
+    e = ol::launch_pol_intensity<float>(n_rays, (const float*)prt, k, (const float*)i0, s,
+                                        (float*)intensity, status, st);
+  } else if (dt == OL_F64) {
+    const double* k[3] = {(const double*)k0[0], (const double*)k0[1], (const double*)k0[2]};
+    e = ol::launch_pol_intensity<double>(n_rays, (const double*)prt, k, (const double*)i0, s,
+                                         (double*)intensity, status, st);
+  } else {
+    return fail(OL_EINVAL, "ol_polarized_intensity: bad dtype %d", (int)dt);
+  }
+  if (e != hipSuccess) return fail(OL_EHIP, "launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
+int ol_spot_moments(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
+                    const void* intensity, double* out6, void* stream) {
+  if (!x || !y || !intensity || !out6) return fail(OL_EINVAL, "ol_spot_moments: NULL argument");
+  if (n_rays <= 0) return n_rays == 0 ? OL_OK : fail(OL_EINVAL, "ol_spot_moments: negative count");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = dt == OL_F32
+                     ? ol::launch_spot_moments<float>(n_rays, (const float*)x, (const float*)y,
+                                                      (const float*)intensity, out6, st)
+                     : ol::launch_spot_moments<double>(n_rays, (const double*)x, (const double*)y,
+                                                       (const double*)intensity, out6, st);
+  if (e != hipSuccess) return fail(OL_EHIP, "launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
+int ol_spot_max_r2(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
+                   const void* intensity, double cx, double cy, double* out1, void* stream) {
+  if (!x || !y || !intensity || !out1) return fail(OL_EINVAL, "ol_spot_max_r2: NULL argument");
+  if (n_rays <= 0) return n_rays == 0 ? OL_OK : fail(OL_EINVAL, "ol_spot_max_r2: negative count");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = dt == OL_F32
+                     ? ol::launch_spot_max_r2<float>(n_rays, (const float*)x, (const float*)y,
+                                                     (const float*)intensity, cx, cy, out1, st)
+                     : ol::launch_spot_max_r2<double>(n_rays, (const double*)x, (const double*)y,
+                                                      (const double*)intensity, cx, cy, out1, st);
+  if (e != hipSuccess) return fail(OL_EHIP, "launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// device_table.h -- device-resident image of the surface table (gfx950).
+//
+// The public `ol_surface_desc` (include/optiland_hip.h) is what the boundary
+// accepts; at ol_system_create time it is re-expressed per arithmetic type T as
+// `DevSurf<T>`: curvature instead of radius, squared aperture bounds, the
+// surface-to-surface relative transform (so fp32 never adds a 6 m vertex offset
+// to a 10 um spot coordinate), Zernike terms regrouped into per-|m| radial
+// polynomials.  Every field is wave-uniform at run time: the kernel indexes the
+// table with the (uniform) surface counter, so the compiler emits scalar loads
+// (s_load_dwordx8/x16 through the scalar cache) and the values live in SGPRs --
+// they cost no VGPRs and no LDS traffic.  Variable-length coefficient blocks
+// (aspheres, polynomials, Zernike groups) are staged per block into LDS.
+#pragma once
+#include <stdint.h>
+
+namespace ol {
+
+enum : int {
+  kGeomPlane = 0,
+  kGeomStandard = 1,
+  kGeomEvenAsphere = 2,
+  kGeomZernike = 3,
+  kGeomOddAsphere = 4,
+  kGeomPolynomial = 5
+};
+enum : int { kRecordOnly = 0, kRefract = 1, kReflect = 2 };
+enum : int { kApNone = 0, kApRadial = 1, kApOffsetRadial = 2, kApRect = 3, kApElliptical = 4 };
+enum : int { kCoatNone = 0, kCoatSimple = 1, kCoatFresnel = 2 };
+
+constexpr uint32_t kSurfRotated = 0x1u;     // this surface's own frame is rotated
+constexpr uint32_t kSurfRelRotated = 0x2u;  // transform from the previous frame rotates
+constexpr uint32_t kSurfRadiusInf = 0x4u;   // |R| = inf (standard.py:108-111 branch)
+
+template <typename T>
+struct DevSurf {
+  int32_t geom;
+  int32_t interaction;
+  int32_t aperture_kind;
+  int32_t coating_kind;
+  int32_t coeff_off;   // offset into the T coefficient buffer
+  int32_t n_coeff;     // asphere: #C_i; polynomial: rows*cols; zernike: #groups
+  int32_t max_iter;
+  uint32_t flags;
+  int32_t poly_cols;
+  int32_t coeff_len;   // number of T elements of this surface's coefficient block
+  int32_t pad0, pad1;
+  T cv;                // curvature 1/R (0 for |R| = inf)
+  T kp1;               // 1 + conic
+  T tol;
+  T inv_norm;          // 1 / norm_radius (zernike)
+  T origin[3];         // global position of the local origin
+  T rot[9];            // local = rot * (global - origin)
+  T rel_off[3];        // local_s = rel_rot * local_{s-1} + rel_off
+  T rel_rot[9];
+  T ap[4];             // radial: rmin^2, rmax^2, ox, oy; rect: xmin,xmax,ymin,ymax;
+                       // elliptical: 1/a^2, 1/b^2, ox, oy
+  T coat[2];           // simple coating: T, R
+};
+
+template <typename T>
+struct DevOptics {
+  T n1;      // material_pre.n(lambda)
+  T n2;      // material_post.n(lambda)
+  T u;       // n1 / n2 (formed in double)
+  T nn;      // n2 / n1 (Fresnel: jones.py:95)
+  T absorb;  // 4 pi k1 / lambda * 1e3, 0 => skip
+  T pad[3];
+};
+
+// Zernike group header inside the coefficient block (all stored as T):
+//   [0] m  (>= 0)   [1] trig kind: 0 = cos / m == 0, 1 = sin   [2] K = #coeffs
+//   then K sag coefficients  a_k  (sum_j c_j N_j R_n^m, ascending powers of rho^2,
+//        the common factor rho^m taken out),
+//   then K normal coefficients b_k (same without N_j).
+constexpr int kZernGroupHeader = 3;
+
+}  // namespace ol

@@ -1,0 +1,773 @@
+// trace_kernel.hip -- fused whole-system sequential ray trace for gfx950 (MI355X).
+//
+// One launch replaces the reference's Python loop over surfaces
+// (optiland/surfaces/surface_group.py:245-257) and the ~100 N-element array
+// operations it runs per surface.  Each thread owns RPT rays
+// (struct-of-arrays in HBM, RPT consecutive rays = one 16-byte vector per plane
+// per lane), keeps their state in VGPRs across ALL surfaces and streams the
+// recorded per-surface state out with 16 B/lane stores.  Surface constants are
+// wave-uniform -> scalar loads / SGPR operands.  No MFMA: this is a streaming
+// vector-ALU path bounded by HBM write bandwidth in record-all mode.
+//
+// Per-surface arithmetic follows SURVEY.md Appendix A; each device function
+// cites the reference lines it implements.  Differences that are deliberate:
+//   * conic intersection uses the cancellation-free root  t = C / q  (the
+//     reference's (-b +- sqrt(d)) / 2a loses digits for near-flat surfaces;
+//     same root selection rule, see conic_distance());
+//   * ray state is carried in the LOCAL frame of the last surface and moved to
+//     the next frame with a host-precomputed relative transform; the global
+//     coordinates the reference records are formed only for the store;
+//   * the Newton-Raphson stop test is per ray (the reference's is a global max
+//     over the batch, newton_raphson.py:148), followed by one more update --
+//     see newton_distance().
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_table.h"
+#include "trace_launch.h"
+
+namespace ol {
+
+// --------------------------------------------------------------------------
+// arithmetic helpers
+// --------------------------------------------------------------------------
+template <typename T>
+struct Math;
+
+template <>
+struct Math<float> {
+  // v_rcp_f32 / v_sqrt_f32 / v_rsq_f32: 1 ulp, quarter rate, no denormal
+  // fix-up sequences -- well inside the 1e-4 fp32 parity budget.
+  static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+  static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+  static __device__ __forceinline__ float div(float a, float b) { return a * rcp(b); }
+  static __device__ __forceinline__ float exp(float x) { return __expf(x); }
+  static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
+  static __device__ __forceinline__ float copysign(float a, float b) {
+    return __builtin_copysignf(a, b);
+  }
+  static __device__ __forceinline__ float fma(float a, float b, float c) {
+    return __builtin_fmaf(a, b, c);
+  }
+  static __device__ __forceinline__ float eps() { return 1.1920929e-7f; }
+  static __device__ __forceinline__ float guard() { return 1e-14f; }
+};
+
+template <>
+struct Math<double> {
+  static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+  static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }
+  static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / __builtin_sqrt(x); }
+  static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+  static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+  static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
+  static __device__ __forceinline__ double copysign(double a, double b) {
+    return __builtin_copysign(a, b);
+  }
+  static __device__ __forceinline__ double fma(double a, double b, double c) {
+    return __builtin_fma(a, b, c);
+  }
+  static __device__ __forceinline__ double eps() { return 2.220446049250313e-16; }
+  static __device__ __forceinline__ double guard() { return 1e-14; }
+};
+
+template <typename T>
+struct Ray {
+  T x, y, z, L, M, N, i, opd;
+};
+
+// 3x3 real polarisation ray-tracing matrix (the imaginary part
+// is identically zero for uncoated / Fresnel surfaces unless the ray is already
+// NaN through total internal reflection).
+template <typename T>
+struct Prt {
+  T m[9];
+};
+
+// --------------------------------------------------------------------------
+// geometry: conic
+// --------------------------------------------------------------------------
+// standard.py:97-148.  Reference quadratic a t^2 + b t + c with
+//   a = R*A, b = R*B, c = R*C;  A = cv(L^2+M^2+(1+k)N^2),
+//   B/2 = E = cv(xL+yM+(1+k)zN) - N,  C = cv(x^2+y^2+(1+k)z^2) - 2z.
+// Roots: t_a = C/q (no cancellation), t_b = q/A with q = -(E + sgn(E) sqrt(E^2-AC)).
+// Reference picks t1 if |z+t1 N| <= |z+t2 N| else t2 where
+//   t1 = (-E + sgn(R) sqrt(disc))/A, t2 = (-E - sgn(R) sqrt(disc))/A;
+// a == 0 -> -c/b which is exactly t_a.
+template <typename T>
+__device__ __forceinline__ T conic_distance(const DevSurf<T>& s, T x, T y, T z, T L, T M, T N) {
+  using m = Math<T>;
+  if (s.flags & kSurfRadiusInf) {
+    T Ns = m::abs(N) > m::guard() ? N : m::guard();
+    return -m::div(z, Ns);
+  }
+  const T cv = s.cv, kp1 = s.kp1;
+  const T kz = kp1 * z, kN = kp1 * N;
+  T E = m::fma(cv, m::fma(x, L, m::fma(y, M, kz * N)), -N);
+  T A = cv * m::fma(L, L, m::fma(M, M, kN * N));
+  T C = m::fma(cv, m::fma(x, x, m::fma(y, y, kz * z)), T(-2) * z);
+  T disc = m::fma(E, E, -A * C);
+  T sq = m::sqrt(disc);  // NaN when the ray misses (standard.py:132-137)
+  T q = -(E + m::copysign(sq, E));
+  T ta = m::div(C, q);
+  T tb = m::div(q, A);
+  T za = m::abs(m::fma(ta, N, z));
+  T zb = m::abs(m::fma(tb, N, z));
+  // t_b is the reference's t1 iff -sgn(E) == sgn(R)
+  bool b_is_t1 = (E < T(0)) == (cv > T(0));
+  bool take_b = b_is_t1 ? (zb <= za) : !(za <= zb);
+  T t = take_b ? tb : ta;
+  t = (A == T(0)) ? ta : t;
+  return t;
+}
+
+// standard.py:150-175: gradient of the conic; returns (fx, fy) = (x, y)/denom.
+template <typename T>
+__device__ __forceinline__ void conic_gradient(const DevSurf<T>& s, T x, T y, T& fx, T& fy) {
+  using m = Math<T>;
+  T r2 = m::fma(x, x, y * y);
+  T g = m::rsqrt(m::fma(-s.kp1 * s.cv * s.cv, r2, T(1)));  // 1/sqrt(1-(1+k) r^2/R^2)
+  T f = s.cv * g;
+  fx = x * f;
+  fy = y * f;
+}
+
+// conic part of the sag, standard.py:81-95
+template <typename T>
+__device__ __forceinline__ T conic_sag(const DevSurf<T>& s, T r2) {
+  using m = Math<T>;
+  T g = m::sqrt(m::fma(-s.kp1 * s.cv * s.cv, r2, T(1)));
+  return m::div(s.cv * r2, T(1) + g);
+}
+
+// --------------------------------------------------------------------------
+// Newton-Raphson geometries: sag + gradient at (x, y)
+// --------------------------------------------------------------------------
+// even_asphere.py:93-140 (Horner in r^2 instead of r2**(i+1))
+template <typename T>
+__device__ __forceinline__ void even_asphere_eval(const DevSurf<T>& s, const T* __restrict__ c,
+                                                  T x, T y, T& sag, T& fx, T& fy) {
+  using m = Math<T>;
+  T r2 = m::fma(x, x, y * y);
+  T g = m::sqrt(m::fma(-s.kp1 * s.cv * s.cv, r2, T(1)));
+  sag = m::div(s.cv * r2, T(1) + g);
+  T f = m::div(s.cv, g);
+  // P(r2) = sum C_i r2^(i+1);  P'(r2) = sum (i+1) C_i r2^i
+  T p = T(0), dp = T(0);
+  for (int i = s.n_coeff - 1; i >= 0; --i) {
+    T ci = c[i];
+    dp = m::fma(dp, r2, T(i + 1) * ci);
+    p = m::fma(p, r2, ci);
+  }
+  sag = m::fma(p, r2, sag);
+  f = m::fma(T(2), dp, f);
+  fx = x * f;
+  fy = y * f;
+}
+
+// odd_asphere.py:86-143: sum C_i r^(i+1); gradient terms (i+1) x C_i r^(i-1),
+// non-finite terms (i == 0 at r == 0) zeroed.
+template <typename T>
+__device__ __forceinline__ void odd_asphere_eval(const DevSurf<T>& s, const T* __restrict__ c,
+                                                 T x, T y, T& sag, T& fx, T& fy) {
+  using m = Math<T>;
+  T r2 = m::fma(x, x, y * y);
+  T r = m::sqrt(r2);
+  T g = m::sqrt(m::fma(-s.kp1 * s.cv * s.cv, r2, T(1)));
+  sag = m::div(s.cv * r2, T(1) + g);
+  T f = m::div(s.cv, g);
+  // Q(r) = sum_{i>=1} (i+1) C_i r^(i-1);  P(r) = sum C_i r^(i+1)
+  T p = T(0), q = T(0);
+  for (int i = s.n_coeff - 1; i >= 0; --i) {
+    T ci = c[i];
+    p = m::fma(p, r, ci);
+    if (i >= 1) q = m::fma(q, r, T(i + 1) * ci);
+  }
+  sag = m::fma(p, r, sag);
+  T c0 = s.n_coeff > 0 ? c[0] : T(0);
+  T t0 = r > T(0) ? m::div(c0, r) : T(0);  // i = 0 term: x C_0 / r, 0 at r == 0
+  f = f + q + t0;
+  fx = x * f;
+  fy = y * f;
+}
+
+// polynomial.py:105-155: sum c[i][j] x^i y^j (row i = x power), nested Horner.
+template <typename T>
+__device__ __forceinline__ void polynomial_eval(const DevSurf<T>& s, const T* __restrict__ c,
+                                                T x, T y, T& sag, T& fx, T& fy) {
+  using m = Math<T>;
+  T r2 = m::fma(x, x, y * y);
+  T g = m::sqrt(m::fma(-s.kp1 * s.cv * s.cv, r2, T(1)));
+  sag = m::div(s.cv * r2, T(1) + g);
+  T f = m::div(s.cv, g);
+  fx = x * f;
+  fy = y * f;
+  const int cols = s.poly_cols;
+  const int rows = cols > 0 ? s.n_coeff / cols : 0;
+  // outer Horner in x over rows; inner Horner in y gives q_i(y) and q_i'(y)
+  T P = T(0), dPdx = T(0), dPdy = T(0);
+  for (int i = rows - 1; i >= 0; --i) {
+    T qi = T(0), dqi = T(0);
+    for (int j = cols - 1; j >= 0; --j) {
+      T cij = c[i * cols + j];
+      dqi = m::fma(dqi, y, qi);
+      qi = m::fma(qi, y, cij);
+    }
+    dPdx = m::fma(dPdx, x, P);
+    P = m::fma(P, x, qi);
+    dPdy = m::fma(dPdy, x, dqi);
+  }
+  sag += P;
+  fx += dPdx;
+  fy += dPdy;
+}
+
+// zernike.py:153-252 + zernike/base.py:42-137.  Terms regrouped on the host per
+// (|m|, cos/sin) into radial polynomials rho^m * Q(rho^2); cos(m phi) / sin(m phi)
+// come from the Chebyshev recurrence on (x_n/rho, y_n/rho) -- (1, 0) at rho == 0,
+// matching atan2(0, 0) = 0 -- instead of atan2 + cos/sin per term.  The chain-rule
+// regularisers eps = 1e-14 of zernike.py:206-231 are kept.
+template <typename T>
+__device__ __forceinline__ void zernike_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
+                                             T y, T& sag, T& fx, T& fy, uint32_t& status) {
+  using m = Math<T>;
+  T r2 = m::fma(x, x, y * y);
+  T g = m::sqrt(m::fma(-s.kp1 * s.cv * s.cv, r2, T(1)));
+  sag = m::div(s.cv * r2, T(1) + g);
+  T f = m::div(s.cv, g);
+  fx = x * f;
+  fy = y * f;
+  const T inv = s.inv_norm;
+  const T xn = x * inv, yn = y * inv;
+  if (m::abs(xn) > T(1) || m::abs(yn) > T(1)) status |= 0x1u;  // OL_STATUS_ZERNIKE_RANGE
+  const T u = m::fma(xn, xn, yn * yn);
+  const T rho = m::sqrt(u);
+  const T eps = m::guard();
+  const T irho = rho > T(0) ? m::rcp(rho) : T(0);
+  const T c1 = rho > T(0) ? xn * irho : T(1);
+  const T s1 = rho > T(0) ? yn * irho : T(0);
+  // drho/dx = (x/norm^2)/(rho+eps), dphi/dx = -(y_n)/(rho^2+eps)/norm
+  const T ir_e = m::rcp(rho + eps);
+  const T iu_e = m::rcp(u + eps);
+  const T drho_dx = xn * inv * ir_e, drho_dy = yn * inv * ir_e;
+  const T dphi_dx = -yn * iu_e * inv, dphi_dy = xn * iu_e * inv;
+
+  T zsum = T(0), gx = T(0), gy = T(0);
+  // running cos(m phi), sin(m phi), rho^m across groups (sorted by ascending m)
+  T cm = T(1), sm = T(0), rm = T(1), rm1 = T(0);  // rm1 = rho^(m-1) (0 for m = 0)
+  int mcur = 0;
+  int off = 0;
+  for (int gi = 0; gi < s.n_coeff; ++gi) {
+    const int mg = (int)c[off];
+    const int kind = (int)c[off + 1];
+    const int K = (int)c[off + 2];
+    const T* a = c + off + kZernGroupHeader;
+    const T* b = a + K;
+    off += kZernGroupHeader + 2 * K;
+    while (mcur < mg) {  // advance the recurrences (uniform trip count)
+      T cn = cm * c1 - sm * s1;
+      T sn = sm * c1 + cm * s1;
+      cm = cn;
+      sm = sn;
+      rm1 = rm;
+      rm = rm * rho;
+      ++mcur;
+    }
+    T qs = T(0), qn = T(0), dqn = T(0);
+    for (int k = K - 1; k >= 0; --k) {
+      qs = m::fma(qs, u, a[k]);
+      dqn = m::fma(dqn, u, qn);
+      qn = m::fma(qn, u, b[k]);
+    }
+    const T trig = kind ? sm : cm;
+    // d/dphi: cos -> -m sin, sin -> +m cos
+    const T dtrig = kind ? T(mg) * cm : -T(mg) * sm;
+    zsum = m::fma(rm * qs, trig, zsum);
+    // d/drho [rho^m Qn(rho^2)] = m rho^(m-1) Qn + 2 rho^(m+1) Qn'
+    const T dR = m::fma(T(mg) * rm1, qn, T(2) * rm * rho * dqn);
+    const T Rn = rm * qn;
+    const T dZdrho = dR * trig;
+    const T dZdphi = Rn * dtrig;
+    gx = m::fma(dZdrho, drho_dx, m::fma(dZdphi, dphi_dx, gx));
+    gy = m::fma(dZdrho, drho_dy, m::fma(dZdphi, dphi_dy, gy));
+  }
+  sag += zsum;
+  fx += gx;
+  fy += gy;
+}
+
+template <typename T>
+__device__ __forceinline__ void nr_eval(const DevSurf<T>& s, const T* __restrict__ c, T x, T y,
+                                        T& sag, T& fx, T& fy, uint32_t& status) {
+  switch (s.geom) {
+    case kGeomEvenAsphere: even_asphere_eval(s, c, x, y, sag, fx, fy); break;
+    case kGeomOddAsphere: odd_asphere_eval(s, c, x, y, sag, fx, fy); break;
+    case kGeomPolynomial: polynomial_eval(s, c, x, y, sag, fx, fy); break;
+    default: zernike_eval(s, c, x, y, sag, fx, fy, status); break;
+  }
+}
+
+// newton_raphson.py:119-168.  f(t) = sag(x(t), y(t)) - z(t); with the unit
+// normal n = (fx, fy, -1)/|.| the reference's  -nx/nz, -ny/nz  are just (fx, fy),
+// so f'(t) = fx L + fy M - N (guards on nz and f' kept: |nz| > 1e-14 always holds
+// for finite gradients).  Per-ray stop rule: the reference stops the whole batch
+// when max |f| < tol; here a ray that sees |f| < tol takes ONE more Newton update
+// and leaves (quadratic convergence => its residual is far below the reference's),
+// NaN rays leave at once.  `floor` keeps fp32 from spinning when tol is below the
+// rounding noise of sag - z.
+template <typename T>
+__device__ __forceinline__ T newton_distance(const DevSurf<T>& s, const T* __restrict__ c, T x,
+                                             T y, T z, T L, T M, T N, uint32_t& status) {
+  using m = Math<T>;
+  T t = conic_distance(s, x, y, z, L, M, N);
+  bool active = true;
+  for (int it = 0; it < s.max_iter; ++it) {
+    if (!__any(active)) break;
+    if (active) {
+      T xi = m::fma(t, L, x), yi = m::fma(t, M, y), zi = m::fma(t, N, z);
+      T sag, fx, fy;
+      nr_eval(s, c, xi, yi, sag, fx, fy, status);
+      T f = sag - zi;
+      T floor = T(4) * m::eps() * (m::abs(sag) + m::abs(zi));
+      T thr = s.tol > floor ? s.tol : floor;
+      bool last = !(m::abs(f) >= thr);  // converged, or NaN
+      T df = m::fma(fx, L, m::fma(fy, M, -N));
+      T dfs = m::abs(df) > m::guard() ? df : m::guard();
+      t = t - m::div(f, dfs);
+      active = !last;
+    }
+  }
+  return t;
+}
+
+// --------------------------------------------------------------------------
+// apertures: physical_apertures/{radial,offset_radial,rectangular,elliptical}.py
+// --------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ bool aperture_contains(const DevSurf<T>& s, T x, T y) {
+  using m = Math<T>;
+  switch (s.aperture_kind) {
+    case kApRadial: {
+      T r2 = m::fma(x, x, y * y);
+      return (r2 <= s.ap[1]) && (r2 >= s.ap[0]);
+    }
+    case kApOffsetRadial: {
+      T dx = x - s.ap[2], dy = y - s.ap[3];
+      T r2 = m::fma(dx, dx, dy * dy);
+      return (r2 <= s.ap[1]) && (r2 >= s.ap[0]);
+    }
+    case kApRect:
+      return (s.ap[0] <= x) && (x <= s.ap[1]) && (s.ap[2] <= y) && (y <= s.ap[3]);
+    case kApElliptical: {
+      T dx = x - s.ap[2], dy = y - s.ap[3];
+      return m::fma(dx * dx, s.ap[0], dy * dy * s.ap[1]) <= T(1);
+    }
+    default:
+      return true;
+  }
+}
+
+// --------------------------------------------------------------------------
+// polarisation: rays/polarized_rays.py:136-202 with J = diag(j0, j1, j2)
+// --------------------------------------------------------------------------
+// The s-vector (normal to the plane of incidence) is formed as k0 x n instead of
+// the reference's k0 x k1: both are parallel (k1 = u k0 + w n for refraction,
+// k0 - 2 dot n for reflection; the sign cancels in O_out J O_in), but k0 x k1
+// degenerates to rounding noise whenever the surface barely deviates the ray
+// (image plane with n1 == n2, near-vertex rays), where the reference only works
+// because numpy's un-fused arithmetic happens to return exact zeros.  One
+// Gram-Schmidt step keeps s orthogonal to k0 to rounding, so the residual noise
+// in its azimuth only couples through the Jones anisotropy |ts - tp| ~ aoi^2.
+template <typename T>
+__device__ __forceinline__ void prt_update(Prt<T>& P, T k0x, T k0y, T k0z, T k1x, T k1y, T k1z,
+                                           T nx, T ny, T nz, T j0, T j1, T j2) {
+  using m = Math<T>;
+  T sx = k0y * nz - k0z * ny, sy = k0z * nx - k0x * nz, sz = k0x * ny - k0y * nx;
+  {
+    T proj = m::fma(sx, k0x, m::fma(sy, k0y, sz * k0z));
+    sx = m::fma(-proj, k0x, sx);
+    sy = m::fma(-proj, k0y, sy);
+    sz = m::fma(-proj, k0z, sz);
+  }
+  T mag2 = m::fma(sx, sx, m::fma(sy, sy, sz * sz));
+  if (mag2 == T(0)) {
+    // normal incidence: polarized_rays.py:153-166 fallback axes
+    // p_f = k0 x x_hat = (0, k0z, -k0y); if zero, k0 x y_hat = (-k0z, 0, k0x)
+    T px = T(0), py = k0z, pz = -k0y;
+    if (py == T(0) && pz == T(0)) {
+      px = -k0z;
+      py = T(0);
+      pz = k0x;
+    }
+    // s = p_f x k0
+    sx = py * k0z - pz * k0y;
+    sy = pz * k0x - px * k0z;
+    sz = px * k0y - py * k0x;
+    mag2 = m::fma(sx, sx, m::fma(sy, sy, sz * sz));
+  }
+  T im = m::rsqrt(mag2);
+  sx *= im;
+  sy *= im;
+  sz *= im;
+  // p0 = k0 x s, p1 = k1 x s
+  T p0x = k0y * sz - k0z * sy, p0y = k0z * sx - k0x * sz, p0z = k0x * sy - k0y * sx;
+  T p1x = k1y * sz - k1z * sy, p1y = k1z * sx - k1x * sz, p1z = k1x * sy - k1y * sx;
+  // v = O_in * P  (rows of O_in: s, p0, k0), scaled by the Jones diagonal
+  T v0[3], v1[3], v2[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    v0[b] = j0 * (sx * P.m[b] + sy * P.m[3 + b] + sz * P.m[6 + b]);
+    v1[b] = j1 * (p0x * P.m[b] + p0y * P.m[3 + b] + p0z * P.m[6 + b]);
+    v2[b] = j2 * (k0x * P.m[b] + k0y * P.m[3 + b] + k0z * P.m[6 + b]);
+  }
+  // P <- O_out * v  (columns of O_out: s, p1, k1)
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    P.m[b] = sx * v0[b] + p1x * v1[b] + k1x * v2[b];
+    P.m[3 + b] = sy * v0[b] + p1y * v1[b] + k1y * v2[b];
+    P.m[6 + b] = sz * v0[b] + p1z * v1[b] + k1z * v2[b];
+  }
+}
+
+// --------------------------------------------------------------------------
+// one surface for one ray: standard_surface.py:200-248 (minus record)
+// --------------------------------------------------------------------------
+template <typename T, bool POL>
+__device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptics<T>& o,
+                                             const T* __restrict__ coeffs, bool from_global,
+                                             Ray<T>& r, Prt<T>& P, uint32_t& status) {
+  using m = Math<T>;
+  // ---- into the local frame (coordinate_system.py:73-89)
+  if (from_global) {
+    T x = r.x - s.origin[0], y = r.y - s.origin[1], z = r.z - s.origin[2];
+    if (s.flags & kSurfRotated) {
+      const T* R = s.rot;
+      T L = r.L, M = r.M, N = r.N;
+      r.x = R[0] * x + R[1] * y + R[2] * z;
+      r.y = R[3] * x + R[4] * y + R[5] * z;
+      r.z = R[6] * x + R[7] * y + R[8] * z;
+      r.L = R[0] * L + R[1] * M + R[2] * N;
+      r.M = R[3] * L + R[4] * M + R[5] * N;
+      r.N = R[6] * L + R[7] * M + R[8] * N;
+    } else {
+      r.x = x;
+      r.y = y;
+      r.z = z;
+    }
+  } else {
+    if (s.flags & kSurfRelRotated) {
+      const T* R = s.rel_rot;
+      T x = r.x, y = r.y, z = r.z, L = r.L, M = r.M, N = r.N;
+      r.x = m::fma(R[0], x, m::fma(R[1], y, m::fma(R[2], z, s.rel_off[0])));
+      r.y = m::fma(R[3], x, m::fma(R[4], y, m::fma(R[5], z, s.rel_off[1])));
+      r.z = m::fma(R[6], x, m::fma(R[7], y, m::fma(R[8], z, s.rel_off[2])));
+      r.L = R[0] * L + R[1] * M + R[2] * N;
+      r.M = R[3] * L + R[4] * M + R[5] * N;
+      r.N = R[6] * L + R[7] * M + R[8] * N;
+    } else {
+      r.x += s.rel_off[0];
+      r.y += s.rel_off[1];
+      r.z += s.rel_off[2];
+    }
+  }
+
+  // ---- distance to the surface
+  const T* c = coeffs + s.coeff_off;
+  T t;
+  if (s.geom == kGeomPlane) {
+    t = -m::div(r.z, r.N);  // plane.py:72-88
+  } else if (s.geom == kGeomStandard) {
+    t = conic_distance(s, r.x, r.y, r.z, r.L, r.M, r.N);
+  } else {
+    t = newton_distance(s, c, r.x, r.y, r.z, r.L, r.M, r.N, status);
+  }
+
+  // ---- propagate + absorb + opd (homogeneous.py:30-57, standard_surface.py:244)
+  r.x = m::fma(t, r.L, r.x);
+  r.y = m::fma(t, r.M, r.y);
+  r.z = m::fma(t, r.N, r.z);
+  if (o.absorb > T(0)) r.i = r.i * m::exp(-o.absorb * t);
+  r.opd = r.opd + m::abs(t * o.n1);
+
+  // ---- clip (physical_apertures/base.py:71-82, real_rays.py:154-161)
+  if (s.aperture_kind != kApNone) {
+    if (!aperture_contains(s, r.x, r.y)) r.i = T(0);
+  }
+
+  // ---- surface normal at the hit point
+  T nx, ny, nz;
+  if (s.geom == kGeomPlane) {
+    nx = T(0);
+    ny = T(0);
+    nz = T(1);  // plane.py:90-109
+  } else {
+    T fx, fy;
+    if (s.geom == kGeomStandard) {
+      conic_gradient(s, r.x, r.y, fx, fy);
+    } else {
+      T sag;
+      uint32_t st = 0;  // range already flagged inside the Newton loop
+      nr_eval(s, c, r.x, r.y, sag, fx, fy, st);
+    }
+    T im = m::rsqrt(m::fma(fx, fx, m::fma(fy, fy, T(1))));
+    nx = fx * im;
+    ny = fy * im;
+    nz = -im;
+  }
+
+  // ---- refract / reflect (real_rays.py:163-205, 535-571)
+  const T L0 = r.L, M0 = r.M, N0 = r.N;
+  T dot = m::fma(L0, nx, m::fma(M0, ny, N0 * nz));
+  const T sgn = dot > T(0) ? T(1) : (dot < T(0) ? T(-1) : (dot == T(0) ? T(0) : dot));
+  const T ax = nx * sgn, ay = ny * sgn, az = nz * sgn;
+  const T adot = m::abs(dot);
+  if (s.interaction == kReflect) {
+    T k2 = T(-2) * adot;
+    r.L = m::fma(k2, ax, L0);
+    r.M = m::fma(k2, ay, M0);
+    r.N = m::fma(k2, az, N0);
+  } else {
+    const T u = o.u;
+    T root = m::sqrt(m::fma(-u * u, m::fma(-adot, adot, T(1)), T(1)));  // NaN on TIR
+    T w = m::fma(-u, adot, root);
+    r.L = m::fma(u, L0, ax * w);
+    r.M = m::fma(u, M0, ay * w);
+    r.N = m::fma(u, N0, az * w);
+  }
+
+  // ---- coating (interactions/base.py:111-128)
+  if (s.coating_kind == kCoatSimple) {
+    r.i = r.i * (s.interaction == kReflect ? s.coat[1] : s.coat[0]);
+  }
+  if constexpr (POL) {
+    T j0 = T(1), j1 = T(1), j2 = T(1);
+    if (s.coating_kind == kCoatFresnel) {
+      // coatings.py:72-92 + jones.py:71-117 with cos(aoi) = min(|n.k0|, 1):
+      // root = sqrt(nn^2 - sin^2) is real unless TIR, where k1 is NaN already.
+      T ci = adot < T(1) ? adot : (adot >= T(1) ? T(1) : adot);
+      T nn = o.nn;
+      T root = m::sqrt(m::fma(nn, nn, m::fma(ci, ci, T(-1))));
+      if (s.interaction == kReflect) {
+        j0 = m::div(ci - root, ci + root);
+        j1 = -m::div(m::fma(nn * nn, ci, -root), m::fma(nn * nn, ci, root));
+        j2 = T(-1);
+      } else {
+        j0 = m::div(T(2) * ci, ci + root);
+        j1 = m::div(T(2) * nn * ci, m::fma(nn * nn, ci, root));
+        j2 = T(1);
+      }
+    }
+    prt_update(P, L0, M0, N0, r.L, r.M, r.N, nx, ny, nz, j0, j1, j2);
+  }
+}
+
+// local -> global for the recorded state (coordinate_system.py:91-107)
+template <typename T>
+__device__ __forceinline__ Ray<T> to_global(const DevSurf<T>& s, const Ray<T>& r) {
+  Ray<T> g = r;
+  if (s.flags & kSurfRotated) {
+    const T* R = s.rot;  // inverse = transpose
+    g.x = R[0] * r.x + R[3] * r.y + R[6] * r.z;
+    g.y = R[1] * r.x + R[4] * r.y + R[7] * r.z;
+    g.z = R[2] * r.x + R[5] * r.y + R[8] * r.z;
+    g.L = R[0] * r.L + R[3] * r.M + R[6] * r.N;
+    g.M = R[1] * r.L + R[4] * r.M + R[7] * r.N;
+    g.N = R[2] * r.L + R[5] * r.M + R[8] * r.N;
+  }
+  g.x += s.origin[0];
+  g.y += s.origin[1];
+  g.z += s.origin[2];
+  return g;
+}
+
+// --------------------------------------------------------------------------
+// vector load / store of RPT consecutive rays of one plane
+// --------------------------------------------------------------------------
+template <typename T, int RPT>
+struct VecOf {
+  typedef T type __attribute__((ext_vector_type(RPT)));
+};
+
+template <typename T, int RPT>
+__device__ __forceinline__ void load_plane(const T* __restrict__ p, int64_t base, int cnt,
+                                           T (&out)[RPT]) {
+  if constexpr (RPT == 1) {
+    out[0] = p[base];
+  } else {
+    using V = typename VecOf<T, RPT>::type;
+    if (cnt == RPT) {
+      V v = *reinterpret_cast<const V*>(p + base);
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) out[k] = v[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) out[k] = k < cnt ? p[base + k] : T(0);
+    }
+  }
+}
+
+template <typename T, int RPT>
+__device__ __forceinline__ void store_plane(T* __restrict__ p, int64_t base, int cnt,
+                                            const T (&in)[RPT]) {
+  // streaming (non-temporal) stores: recorded rows are written once and never
+  // re-read by this kernel, so they should not displace anything in L2.
+  if constexpr (RPT == 1) {
+    __builtin_nontemporal_store(in[0], p + base);
+  } else {
+    using V = typename VecOf<T, RPT>::type;
+    if (cnt == RPT) {
+      V v;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) v[k] = in[k];
+      __builtin_nontemporal_store(v, reinterpret_cast<V*>(p + base));
+    } else {
+#pragma unroll
+      for (int k = 0; k < RPT; ++k)
+        if (k < cnt) p[base + k] = in[k];
+    }
+  }
+}
+
+template <typename T, int RPT>
+__device__ __forceinline__ void store_rays(T* __restrict__ row, int64_t stride, int64_t base,
+                                           int cnt, const Ray<T> (&g)[RPT]) {
+  T tmp[RPT];
+#define OL_STORE_FIELD(idx, fld)                         \
+  _Pragma("unroll") for (int k = 0; k < RPT; ++k) tmp[k] = g[k].fld; \
+  store_plane<T, RPT>(row + (int64_t)(idx) * stride, base, cnt, tmp);
+  OL_STORE_FIELD(0, x)
+  OL_STORE_FIELD(1, y)
+  OL_STORE_FIELD(2, z)
+  OL_STORE_FIELD(3, L)
+  OL_STORE_FIELD(4, M)
+  OL_STORE_FIELD(5, N)
+  OL_STORE_FIELD(6, i)
+  OL_STORE_FIELD(7, opd)
+#undef OL_STORE_FIELD
+}
+
+// --------------------------------------------------------------------------
+// the kernel
+// --------------------------------------------------------------------------
+template <typename T, int RPT, bool RECORD, bool POL>
+__global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceArgs<T> a) {
+  const int64_t base = ((int64_t)blockIdx.x * kTraceBlock + threadIdx.x) * RPT;
+  if (base >= a.n) return;
+  const int64_t left = a.n - base;
+  const int cnt = left >= RPT ? RPT : (int)left;
+
+  Ray<T> r[RPT];
+  Prt<T> P[POL ? RPT : 1];
+  {
+    T tmp[RPT];
+#define OL_LOAD_FIELD(idx, fld)                      \
+  load_plane<T, RPT>(a.rays[idx], base, cnt, tmp);   \
+  _Pragma("unroll") for (int k = 0; k < RPT; ++k) r[k].fld = tmp[k];
+    OL_LOAD_FIELD(0, x)
+    OL_LOAD_FIELD(1, y)
+    OL_LOAD_FIELD(2, z)
+    OL_LOAD_FIELD(3, L)
+    OL_LOAD_FIELD(4, M)
+    OL_LOAD_FIELD(5, N)
+    OL_LOAD_FIELD(6, i)
+    OL_LOAD_FIELD(7, opd)
+#undef OL_LOAD_FIELD
+    if constexpr (POL) {
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        load_plane<T, RPT>(a.prt + (int64_t)e * a.n, base, cnt, tmp);
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) P[k].m[e] = tmp[k];
+      }
+    }
+  }
+
+  uint32_t status = 0;
+  bool is_global = true;  // frame of the state held in r[]
+  const DevSurf<T>* last_traced = nullptr;
+  for (int s = a.first; s <= a.last; ++s) {
+    const DevSurf<T>& S = a.surf[s];
+    if (S.interaction != kRecordOnly) {
+      const DevOptics<T>& O = a.optics[s * a.n_wl + a.wl];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) surface_step<T, POL>(S, O, a.coeffs, is_global, r[k], P[POL ? k : 0], status);
+      is_global = false;
+      last_traced = &S;
+    }
+    if constexpr (RECORD) {
+      T* row = a.record + (int64_t)(s - a.first) * 8 * a.record_stride;
+      if (is_global) {
+        store_rays<T, RPT>(row, a.record_stride, base, cnt, r);
+      } else {
+        Ray<T> g[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) g[k] = to_global(*last_traced, r[k]);
+        store_rays<T, RPT>(row, a.record_stride, base, cnt, g);
+      }
+    }
+  }
+
+  if (a.flags & kTraceWriteRays) {
+    Ray<T> g[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) g[k] = is_global ? r[k] : to_global(*last_traced, r[k]);
+    T tmp[RPT];
+#define OL_WB_FIELD(idx, fld)                                        \
+  _Pragma("unroll") for (int k = 0; k < RPT; ++k) tmp[k] = g[k].fld; \
+  store_plane<T, RPT>(a.rays[idx], base, cnt, tmp);
+    OL_WB_FIELD(0, x)
+    OL_WB_FIELD(1, y)
+    OL_WB_FIELD(2, z)
+    OL_WB_FIELD(3, L)
+    OL_WB_FIELD(4, M)
+    OL_WB_FIELD(5, N)
+    OL_WB_FIELD(6, i)
+    OL_WB_FIELD(7, opd)
+#undef OL_WB_FIELD
+  }
+  if constexpr (POL) {
+    T tmp[RPT];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) tmp[k] = P[k].m[e];
+      store_plane<T, RPT>(a.prt + (int64_t)e * a.n, base, cnt, tmp);
+    }
+  }
+  if (status && a.status) atomicOr(a.status, status);
+}
+
+// --------------------------------------------------------------------------
+// host-side launcher
+// --------------------------------------------------------------------------
+template <typename T, int RPT>
+static hipError_t launch_rpt(const TraceArgs<T>& a, hipStream_t stream) {
+  const int64_t threads = (a.n + RPT - 1) / RPT;
+  const int64_t blocks = (threads + kTraceBlock - 1) / kTraceBlock;
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  dim3 grid((unsigned)blocks), block(kTraceBlock);
+  const bool rec = a.record != nullptr, pol = a.prt != nullptr;
+  if (rec && pol)
+    hipLaunchKernelGGL((trace_kernel<T, RPT, true, true>), grid, block, 0, stream, a);
+  else if (rec)
+    hipLaunchKernelGGL((trace_kernel<T, RPT, true, false>), grid, block, 0, stream, a);
+  else if (pol)
+    hipLaunchKernelGGL((trace_kernel<T, RPT, false, true>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((trace_kernel<T, RPT, false, false>), grid, block, 0, stream, a);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, hipStream_t stream) {
+  constexpr int kVec = 16 / sizeof(T);  // rays per 16-byte lane vector
+  if (vector_ok) return launch_rpt<T, kVec>(a, stream);
+  return launch_rpt<T, 1>(a, stream);
+}
+
+template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, hipStream_t);
+template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, hipStream_t);
+
+}  // namespace ol

@@ -1,0 +1,61 @@
+// trace_launch.h -- kernel argument block shared by the kernels and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_table.h"
+
+namespace ol {
+
+constexpr int kTraceBlock = 256;           // 4 waves of 64 lanes
+constexpr uint32_t kTraceWriteRays = 0x1u; // OL_TRACE_WRITE_RAYS
+constexpr uint32_t kTraceCompact = 0x2u;   // OL_TRACE_COMPACT
+
+template <typename T>
+struct TraceArgs {
+  const DevSurf<T>* surf;      // [n_surf]
+  const DevOptics<T>* optics;  // [n_surf][n_wl]
+  const T* coeffs;             // coefficient blocks
+  T* rays[8];                  // x,y,z,L,M,N,i,opd planes
+  T* record;                   // rows x 8 x record_stride or nullptr
+  T* prt;                      // 9 x n or nullptr
+  uint32_t* status;            // device word or nullptr
+  int64_t n;
+  int64_t record_stride;
+  int32_t first, last;
+  int32_t n_wl, wl;
+  uint32_t flags;
+};
+
+template <typename T>
+hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, hipStream_t stream);
+
+// ray generation / epilogue / reductions (aux_kernels.hip)
+struct RaygenDev {
+  int32_t object_infinite;
+  double EPL, EPD, max_field, offset, z_first;
+};
+
+template <typename T>
+hipError_t launch_raygen(const RaygenDev& p, int64_t n, const T* hx, const T* hy, const T* px,
+                         const T* py, const T* vx, const T* vy, T* const out[7],
+                         hipStream_t stream);
+
+struct PolStateDev {
+  int32_t is_polarized;
+  double Ex, Ey, phase_x, phase_y;
+};
+
+template <typename T>
+hipError_t launch_pol_intensity(int64_t n, const T* prt, const T* const k0[3], const T* i0,
+                                const PolStateDev& st, T* intensity, uint32_t* status,
+                                hipStream_t stream);
+
+template <typename T>
+hipError_t launch_spot_moments(int64_t n, const T* x, const T* y, const T* inten, double* out6,
+                               hipStream_t stream);
+template <typename T>
+hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten, double cx,
+                              double cy, double* out1, hipStream_t stream);
+
+}  // namespace ol

@@ -1,0 +1,223 @@
+"""Device-side engine: owns an `ol_system` handle and launches traces.
+
+PyTorch is used only as the device-memory container and stream provider; all
+arithmetic happens in the hand-written HIP kernels behind the C ABI.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from . import system as S
+from .system import SystemTable
+
+PLANES = ("x", "y", "z", "L", "M", "N", "i", "opd")
+_DT = {torch.float32: _capi.F32, torch.float64: _capi.F64}
+_VEC_PAD = 64  # record row stride padded to 64 elements (256 B fp32 / 512 B fp64)
+
+
+def _require_gpu(device) -> torch.device:
+    if not torch.cuda.is_available():
+        raise _capi.HipExtensionError(
+            "no HIP device visible (torch.cuda.is_available() is False); the fused "
+            "trace has no CPU fallback"
+        )
+    dev = torch.device(device if device is not None else "cuda")
+    if dev.type != "cuda":
+        raise ValueError(f"HipSystem needs a cuda (HIP) device, got {dev}")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def _stream_ptr(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+class TraceResult:
+    """Outputs of one launch.  `record` is (rows, 8, stride) with [:, :, :n] valid."""
+
+    __slots__ = ("n", "rays", "record", "prt", "status", "first", "last")
+
+    def __init__(self, n, rays, record, prt, status, first, last):
+        self.n, self.rays, self.record, self.prt = n, rays, record, prt
+        self.status, self.first, self.last = status, first, last
+
+    def row(self, s: int, plane: str | int) -> torch.Tensor:
+        k = PLANES.index(plane) if isinstance(plane, str) else plane
+        return self.record[s - self.first, k, : self.n]
+
+    def stack(self, plane: str | int) -> torch.Tensor:
+        """(rows, n) view of one plane for all recorded surfaces (no copy)."""
+        k = PLANES.index(plane) if isinstance(plane, str) else plane
+        return self.record[:, k, : self.n]
+
+
+class HipSystem:
+    """A surface table resident on one GPU (wraps `ol_system`)."""
+
+    def __init__(self, table: SystemTable, device=None):
+        self.lib = _capi.load()
+        self.device = _require_gpu(device)
+        self.table = table
+        surf = np.ascontiguousarray(table.surfaces)
+        assert surf.dtype.itemsize == C.sizeof(_capi.SurfaceDesc), "ABI struct mismatch"
+        optics = np.ascontiguousarray(table.optics)
+        coeffs = np.ascontiguousarray(table.coeffs, dtype=np.float64)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.ol_system_create(
+                surf.ctypes.data, surf.shape[0],
+                coeffs.ctypes.data if coeffs.size else None, coeffs.size,
+                optics.ctypes.data, optics.shape[1], C.byref(handle))
+        _capi.check(rc, "ol_system_create")
+        self._handle = handle
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self.lib.ol_system_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_surfaces(self) -> int:
+        return self.table.num_surfaces
+
+    # ------------------------------------------------------------------ trace
+    def alloc_record(self, n: int, dtype, rows: int | None = None) -> torch.Tensor:
+        rows = self.num_surfaces if rows is None else rows
+        stride = (n + _VEC_PAD - 1) // _VEC_PAD * _VEC_PAD
+        return torch.empty((rows, 8, max(stride, _VEC_PAD)), dtype=dtype, device=self.device)
+
+    def trace(self, rays, wavelength_index: int = 0, record=True, prt: torch.Tensor | None = None,
+              first: int = 0, last: int | None = None, write_rays: bool | None = None,
+              check_status: bool = True) -> TraceResult:
+        """Launch the fused trace.
+
+        rays: sequence of 8 contiguous 1-D device tensors (x,y,z,L,M,N,i,opd) of one
+        dtype -- the initial state.  record: True (allocate), False/None, or a
+        preallocated (rows, 8, stride) tensor.  prt: (9, n) tensor, read-modify-write.
+        With write_rays (default: only when nothing is recorded) the final state is
+        written back into `rays` in place, like SurfaceGroup.trace mutates its rays.
+        """
+        rays = list(rays)
+        if len(rays) != 8:
+            raise ValueError("rays must be 8 planes: x,y,z,L,M,N,i,opd")
+        n = int(rays[0].numel())
+        dtype = rays[0].dtype
+        if dtype not in _DT:
+            raise TypeError(f"unsupported ray dtype {dtype}")
+        for t in rays:
+            if t.device != self.device or t.dtype != dtype or t.numel() != n or not t.is_contiguous():
+                raise ValueError("ray planes must be contiguous, same dtype/size, on the system's device")
+        last = self.num_surfaces - 1 if last is None else last
+        rows = last - first + 1
+        rec = None
+        if record is True:
+            rec = self.alloc_record(n, dtype, rows)
+        elif isinstance(record, torch.Tensor):
+            rec = record
+            if rec.dtype != dtype or rec.dim() != 3 or rec.shape[0] < rows or rec.shape[1] != 8 \
+                    or rec.shape[2] < n or not rec.is_contiguous():
+                raise ValueError("record must be a contiguous (rows, 8, stride>=n) tensor")
+        if write_rays is None:
+            write_rays = rec is None
+        flags = (S.TRACE_WRITE_RAYS if write_rays else 0) | S.TRACE_COMPACT
+        if prt is not None:
+            if prt.dtype != dtype or tuple(prt.shape) != (9, n) or not prt.is_contiguous():
+                raise ValueError("prt must be a contiguous (9, n) tensor of the ray dtype")
+        ptrs = (C.c_void_p * 8)(*[t.data_ptr() for t in rays])
+        if check_status:
+            self._status.zero_()
+        with torch.cuda.device(self.device):
+            rc = self.lib.ol_trace(
+                self._handle, _DT[dtype], n, ptrs, int(wavelength_index),
+                rec.data_ptr() if rec is not None else None,
+                int(rec.shape[2]) if rec is not None else 0,
+                prt.data_ptr() if prt is not None else None,
+                int(first), int(last), flags,
+                self._status.data_ptr() if check_status else None,
+                _stream_ptr(self.device))
+        _capi.check(rc, "ol_trace")
+        status = int(self._status.item()) if check_status else 0
+        if status & S.STATUS_ZERNIKE_RANGE:
+            # same text as optiland/geometries/zernike.py:262-266
+            raise ValueError(
+                "Zernike coordinates must be normalized "
+                "to [-1, 1]. Consider updating the normalization "
+                "radius to 1.1x the surface aperture."
+            )
+        return TraceResult(n, rays, rec, prt, status, first, last)
+
+    # ------------------------------------------------------------- ray source
+    def generate_rays(self, hx, hy, px, py, vx=None, vy=None):
+        """On-device ray generation (paraxial aiming, angle fields).  Returns 7 planes."""
+        rg = self.table.raygen
+        if not rg:
+            raise ValueError("this SystemTable carries no ray-generation scalars")
+        n = int(px.numel())
+        dtype = px.dtype
+        p = _capi.RaygenParams(int(rg["object_infinite"]), 0, rg["EPL"], rg["EPD"],
+                               rg["max_field"], rg["offset"], rg["z_first"])
+        out = torch.empty((7, max(n, 1)), dtype=dtype, device=self.device)
+        ptrs = (C.c_void_p * 7)(*[out[k].data_ptr() for k in range(7)])
+        args = [t.contiguous() for t in (hx, hy, px, py)]
+        vxc = vx.contiguous() if vx is not None else None
+        vyc = vy.contiguous() if vy is not None else None
+        with torch.cuda.device(self.device):
+            rc = self.lib.ol_generate_rays(
+                C.byref(p), _DT[dtype], n, *[a.data_ptr() for a in args],
+                vxc.data_ptr() if vxc is not None else None,
+                vyc.data_ptr() if vyc is not None else None, ptrs, _stream_ptr(self.device))
+        _capi.check(rc, "ol_generate_rays")
+        return [out[k, :n] for k in range(7)]
+
+    def polarized_intensity(self, prt, k0, i0, polarization: dict | None):
+        n = int(i0.numel())
+        dtype = i0.dtype
+        if polarization and polarization.get("is_polarized"):
+            st = _capi.PolarizationStateC(1, 0, polarization["Ex"], polarization["Ey"],
+                                          polarization["phase_x"], polarization["phase_y"])
+        else:
+            st = _capi.PolarizationStateC(0, 0, 0.0, 0.0, 0.0, 0.0)
+        out = torch.empty(n, dtype=dtype, device=self.device)
+        kp = (C.c_void_p * 3)(*[t.data_ptr() for t in k0])
+        self._status.zero_()
+        with torch.cuda.device(self.device):
+            rc = self.lib.ol_polarized_intensity(
+                _DT[dtype], n, prt.data_ptr(), kp, i0.data_ptr(), C.byref(st), out.data_ptr(),
+                self._status.data_ptr(), _stream_ptr(self.device))
+        _capi.check(rc, "ol_polarized_intensity")
+        if int(self._status.item()) & S.STATUS_K_PARALLEL_X:
+            # rays/polarized_rays.py:221-222
+            raise ValueError("k-vector parallel to x-axis is not currently supported.")
+        return out
+
+    def spot_moments(self, x, y, intensity):
+        """Device reduction: returns float64 tensor [count, sx, sy, sxx, syy, count]."""
+        out = torch.zeros(6, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.ol_spot_moments(_DT[x.dtype], int(x.numel()), x.data_ptr(),
+                                          y.data_ptr(), intensity.data_ptr(), out.data_ptr(),
+                                          _stream_ptr(self.device))
+        _capi.check(rc, "ol_spot_moments")
+        return out
+
+    def spot_max_r2(self, x, y, intensity, cx: float, cy: float):
+        out = torch.zeros(1, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.ol_spot_max_r2(_DT[x.dtype], int(x.numel()), x.data_ptr(),
+                                         y.data_ptr(), intensity.data_ptr(), float(cx),
+                                         float(cy), out.data_ptr(), _stream_ptr(self.device))
+        _capi.check(rc, "ol_spot_max_r2")
+        return out

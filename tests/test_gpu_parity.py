@@ -1,0 +1,199 @@
+"""HIP path vs the reference goldens and vs the CPU oracle (needs an MI355X).
+
+Tolerances (the contract stated in BASELINE.json `north_star`):
+    fp64: 1e-6 relative      fp32: 1e-4 relative
+applied with the group-scale model documented in tests/_util.assert_close_planes
+(|err| <= rtol*|want| + rtol*scale_of_group).  fp64 is additionally held to 1e-9
+on every fixture -- the kernel's Newton loop converges further than the
+reference's, so the only systematic difference is the reference's own residual.
+NaN masks (missed surfaces, TIR) and clipped (i == 0) masks must match exactly.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from tests._util import PLANES, assert_close_planes, golden_cases, load_case
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float64: 1e-6, torch.float32: 1e-4}
+TIGHT64 = 1e-9
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from optiland_amd.engine import HipSystem
+
+    cache = {}
+
+    def get(case):
+        if case not in cache:
+            table, data = load_case(case)
+            cache[case] = (HipSystem(table, "cuda:0"), table, data)
+        return cache[case]
+
+    yield get
+    for sysm, _, _ in cache.values():
+        sysm.close()
+
+
+def _device_rays(data, dtype):
+    r = data["rays_in"]
+    planes = [torch.tensor(r[k], dtype=dtype, device="cuda:0") for k in range(7)]
+    planes.append(torch.zeros_like(planes[0]))
+    return planes
+
+
+def _fp32_nan_ok(case):
+    # in fp32 a ray within rounding of grazing/TIR may flip its NaN status
+    return False
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("case", golden_cases())
+def test_record_matches_reference(hip, case, dtype):
+    sysm, table, data = hip(case)
+    polarized = "prt" in data
+    rays = _device_rays(data, dtype)
+    n = rays[0].numel()
+    prt = None
+    if polarized:
+        prt = torch.eye(3, dtype=dtype, device="cuda:0").reshape(9, 1).repeat(1, n).contiguous()
+    res = sysm.trace(rays, 0, record=True, prt=prt)
+    got = res.record[:, :, :n].double().cpu().numpy()
+    tol = TOL[dtype]
+    assert_close_planes(got, data["record"], tol, tol, f"{case}:{dtype}")
+    if dtype == torch.float64:
+        assert_close_planes(got, data["record"], TIGHT64, TIGHT64, f"{case}:tight")
+        assert np.array_equal(got[:, 6, :] == 0, data["record"][:, 6, :] == 0)
+    if polarized:
+        p = prt.double().cpu().numpy().T.reshape(n, 3, 3)
+        want = data["prt"]
+        assert np.abs(want.imag).max() == 0.0 or np.isnan(want.imag).any()
+        np.testing.assert_allclose(p, want.real, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("case", ["double_gauss", "rc_asphere", "tilted_fold"])
+def test_writeback_equals_last_row_and_partial_ranges(hip, case, dtype):
+    """OL_TRACE_WRITE_RAYS output == last recorded row; tracing [0,k] then [k+1,S]
+    (the `skip` generalisation) == one full trace, bit for bit."""
+    sysm, table, data = hip(case)
+    n = data["rays_in"].shape[1]
+    full = sysm.trace(_device_rays(data, dtype), 0, record=True)
+    rays = _device_rays(data, dtype)
+    sysm.trace(rays, 0, record=False)  # in-place final state
+    for k in range(8):
+        assert torch.equal(rays[k].nan_to_num(nan=-7.0), full.row(full.last, k).nan_to_num(nan=-7.0))
+    # split trace
+    S = table.num_surfaces - 1
+    k = S // 2
+    rays = _device_rays(data, dtype)
+    sysm.trace(rays, 0, record=False, first=0, last=k)
+    sysm.trace(rays, 0, record=False, first=k + 1, last=S)
+    tol = TOL[dtype]
+    got = torch.stack(rays).double().cpu().numpy()
+    want = full.record[-1, :, :n].double().cpu().numpy()
+    # not bit-identical: the split hands over GLOBAL coordinates (one extra rounding)
+    assert_close_planes(got[None], want[None], tol * 1e-2, tol * 1e-2, f"{case}:split")
+
+
+@pytest.mark.parametrize("case", [c for c in golden_cases() if "fresnel" in c])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_polarized_intensity_epilogue(hip, case, dtype):
+    sysm, table, data = hip(case)
+    rays = _device_rays(data, dtype)
+    n = rays[0].numel()
+    k0 = [rays[3].clone(), rays[4].clone(), rays[5].clone()]
+    i0 = rays[6].clone()
+    prt = torch.eye(3, dtype=dtype, device="cuda:0").reshape(9, 1).repeat(1, n).contiguous()
+    sysm.trace(rays, 0, record=False, prt=prt)
+    got = sysm.polarized_intensity(prt, k0, i0, table.polarization).double().cpu().numpy()
+    tol = TOL[dtype]
+    np.testing.assert_allclose(got, data["i_updated"], rtol=tol, atol=tol * 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("case", golden_cases())
+def test_ray_generation(hip, case, dtype):
+    sysm, table, data = hip(case)
+    if not table.raygen:
+        pytest.skip("no ray-generation scalars")
+    generic = not bool(data["via_trace"])
+    vx, vy = 1.0 - data["vx"], 1.0 - data["vy"]
+    px = data["Px"] * (vx if generic else 1.0)
+    py = data["Py"] * (vy if generic else 1.0)
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda:0")
+    out = sysm.generate_rays(dev(data["Hx"]), dev(data["Hy"]), dev(px), dev(py), dev(vx), dev(vy))
+    tol = 1e-12 if dtype == torch.float64 else 2e-6
+    for j in range(7):
+        want = data["rays_in"][j]
+        scale = max(1.0, np.abs(data["rays_in"][:3]).max()) if j < 3 else 1.0
+        np.testing.assert_allclose(out[j].double().cpu().numpy(), want, rtol=tol, atol=tol * scale,
+                                   err_msg=f"{case}:{PLANES[j]}")
+
+
+def test_empty_and_ragged_sizes(hip):
+    sysm, table, data = hip("double_gauss")
+    from oracle import oracle
+    for n in (0, 1, 3, 63, 64, 65, 257, 1023):
+        for dtype in (torch.float64, torch.float32):
+            r = data["rays_in"][:, :n]
+            planes = [torch.tensor(np.ascontiguousarray(r[k]), dtype=dtype, device="cuda:0")
+                      for k in range(7)]
+            planes.append(torch.zeros(n, dtype=dtype, device="cuda:0"))
+            res = sysm.trace(planes, 0, record=True)
+            if n == 0:
+                continue
+            want = data["record"][:, :, :n]
+            tol = TOL[dtype]
+            assert_close_planes(res.record[:, :, :n].double().cpu().numpy(), want, tol, tol,
+                                f"n={n}")
+
+
+def test_unaligned_views_take_the_scalar_path(hip):
+    """Ray planes that are views at odd offsets (not 16-byte aligned) still work."""
+    sysm, table, data = hip("cooke_generic")
+    n = 777
+    dtype = torch.float32
+    big = torch.zeros(8, n + 1, dtype=dtype, device="cuda:0")
+    planes = [big[k, 1:] for k in range(8)]  # 4-byte offset -> unaligned for dwordx4
+    for k in range(7):
+        planes[k].copy_(torch.tensor(data["rays_in"][k, :n], dtype=dtype))
+    res = sysm.trace(planes, 0, record=True)
+    assert_close_planes(res.record[:, :, :n].double().cpu().numpy(), data["record"][:, :, :n],
+                        1e-4, 1e-4, "unaligned")
+
+
+def test_zernike_range_raises(hip):
+    sysm, table, data = hip("zernike_nopol")
+    dtype = torch.float64
+    rays = _device_rays(data, dtype)
+    rays[0] += 40.0  # far outside norm_radius = 15
+    with pytest.raises(ValueError, match="Zernike coordinates must be normalized"):
+        sysm.trace(rays, 0, record=False)
+
+
+def test_fresnel_without_polarized_rays_raises(hip):
+    sysm, table, data = hip("zernike_fresnel_fringe")
+    with pytest.raises(ValueError, match="Polarization must be set"):
+        sysm.trace(_device_rays(data, torch.float64), 0, record=False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_oracle_side_by_side_large(hip, dtype):
+    """Seeded 2e5-ray bundle on the double Gauss: HIP vs the CPU oracle directly."""
+    from oracle import oracle
+    sysm, table, data = hip("double_gauss")
+    rng = np.random.default_rng(11)
+    n = 200_000
+    r, th = np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
+    rays = oracle.generate_rays(table.raygen, np.zeros(n), rng.uniform(-1, 1, n),
+                                r * np.cos(th), r * np.sin(th))
+    want = oracle.trace(table, rays, 0, record=True)["record"]
+    planes = [torch.tensor(rays[k], dtype=dtype, device="cuda:0") for k in PLANES[:7]]
+    planes.append(torch.zeros(n, dtype=dtype, device="cuda:0"))
+    res = sysm.trace(planes, 0, record=True)
+    tol = TOL[dtype]
+    assert_close_planes(res.record[:, :, :n].double().cpu().numpy(), want, tol, tol, "oracle-2e5")
