@@ -1,0 +1,283 @@
+#!/usr/bin/env python
+"""Benchmark of the fused sequential ray-trace hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic rays already
+resident in HBM: the whole-system trace of `--rays` rays (default 1e7, fp32)
+through the double Gauss (BASELINE.json configs[1]) in record-all mode, i.e. what
+`Optic.trace()` observably produces (8 recorded planes for each of the S+1
+surfaces).  For N > 1 every rank traces its own `--rays` rays (weak scaling) and
+the step ends with the image-plane exchange: per-rank spot moments reduced with
+one RCCL all-reduce (default) or the raw all-gather of image-plane hits
+(`--exchange gather`).
+
+Rank 0 prints ONE JSON line (metric = ray-surface intersections/s, whole job).
+`roofline` refers to the trace kernel in the mode that was run; `cpu_baseline`
+times the CPU oracle (oracle/, a C port of the reference's algorithm) on a
+bounded sample of the same workload -- the reference itself is pure Python and
+does not exist on the GPU box.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (system json, Hy, description)
+    "double_gauss": ("double_gauss", 0.7, "DoubleGauss"),
+    "cooke": ("cooke_generic", 1.0, "CookeTriplet"),
+    "rc_asphere": ("rc_asphere", 1.0, "RC + even-asphere corrector (Newton-Raphson)"),
+    "zernike_fresnel": ("zernike_fresnel_fringe", 1.0, "Zernike freeform + Fresnel/polarized"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=float, default=1e7, help="rays per GPU per step")
+    ap.add_argument("--dtype", choices=("f32", "f64"), default="f32")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="double_gauss")
+    ap.add_argument("--mode", choices=("record", "last"), default="record",
+                    help="record: all surfaces (drop-in semantics); last: image plane only")
+    ap.add_argument("--exchange", choices=("reduce", "gather", "none"), default="reduce",
+                    help="image-plane exchange when --gpus > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def init_dist(n_gpus):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    if n_gpus != world:
+        if rank == 0:
+            print(f"warning: --gpus {n_gpus} but WORLD_SIZE={world}; using {world}",
+                  file=sys.stderr)
+    return rank, local, world
+
+
+def make_rays(hip, n, dtype, hy, seed, device):
+    """Seeded uniform-disc pupil sampling on device -> rays via ol_generate_rays."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    r = torch.rand(n, generator=g, device=device, dtype=torch.float32).sqrt()
+    th = 2 * np.pi * torch.rand(n, generator=g, device=device, dtype=torch.float32)
+    px, py = (r * th.cos()).to(dtype), (r * th.sin()).to(dtype)
+    del r, th
+    hx = torch.zeros(n, dtype=dtype, device=device)
+    hyt = torch.full((n,), hy, dtype=dtype, device=device)
+    planes = hip.generate_rays(hx, hyt, px, py)
+    rays = [p.contiguous().clone() for p in planes]
+    rays.append(torch.zeros(n, dtype=dtype, device=device))
+    return rays
+
+
+def cpu_baseline(table, hy, mode, budget_s):
+    """Time the CPU oracle (C port, 1 thread) on a bounded sample, same mode."""
+    from oracle import oracle
+    n = 1_000_000
+    rng = np.random.default_rng(0)
+    r, th = np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
+    rays = oracle.generate_rays(table.raygen, np.zeros(n), np.full(n, hy),
+                                r * np.cos(th), r * np.sin(th))
+    pol = table.uses_polarization
+    S = table.num_traced
+    reps, t_total = 0, 0.0
+    oracle.trace(table, {k: v[:1000] for k, v in rays.items()}, 0, record=(mode == "record"),
+                 polarized=pol)  # warm (build + page in)
+    while t_total < budget_s and reps < 64:
+        t0 = time.perf_counter()
+        oracle.trace(table, rays, 0, record=(mode == "record"), polarized=pol)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    return {
+        "value": n * S * reps / t_total,
+        "unit": "ray-surfaces/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{reps} x {n} rays x {S} surfaces, fp64, oracle/trace_oracle.c (gcc -O2), "
+                  f"mode={mode}, {t_total:.1f} s on {os.cpu_count()} logical host cores available",
+    }
+
+
+def load_traffic(workload, dtype, mode):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary, if any."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+        return doc.get(f"{workload}:{dtype}:{mode}")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse_args()
+    rank, local, world = init_dist(args.gpus)
+    device = torch.device("cuda", local)
+    from optiland_amd import load_system
+    from optiland_amd.engine import HipSystem
+
+    sys_name, hy, desc = WORKLOADS[args.workload]
+    table = load_system(sys_name)
+    hip = HipSystem(table, device)
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    b = 4 if args.dtype == "f32" else 8
+    n = int(args.rays)
+    S = table.num_traced
+    pol = table.uses_polarization
+
+    rays = make_rays(hip, n, dtype, hy, seed=1234 + rank, device=device)
+    record = hip.alloc_record(n, dtype) if args.mode == "record" else None
+    prt0 = prt = None
+    if pol:
+        prt0 = torch.eye(3, dtype=dtype, device=device).reshape(9, 1).repeat(1, n).contiguous()
+        prt = torch.empty_like(prt0)
+    scratch = [torch.empty_like(t) for t in rays] if args.mode == "last" else None
+
+    exchange = args.exchange if world > 1 else "none"
+    if exchange != "none":
+        import torch.distributed as dist
+        gather_buf = None
+        if exchange == "gather":
+            gather_buf = torch.empty((world, 3, n), dtype=dtype, device=device)
+            hits = torch.empty((3, n), dtype=dtype, device=device)
+
+    def step(ev0=None, ev1=None):
+        if pol:
+            prt.copy_(prt0)
+        if args.mode == "record":
+            src = rays
+        else:  # last-surface mode mutates the rays in place: refresh from the source
+            for d, s_ in zip(scratch, rays):
+                d.copy_(s_)
+            src = scratch
+        if ev0 is not None:
+            ev0.record()
+        res = hip.trace(src, 0, record=record if record is not None else False, prt=prt,
+                        check_status=False)
+        if ev1 is not None:
+            ev1.record()
+        if exchange != "none":
+            if args.mode == "record":
+                x, y, inten = res.row(res.last, 0), res.row(res.last, 1), res.row(res.last, 6)
+            else:
+                x, y, inten = src[0], src[1], src[6]
+            if exchange == "reduce":
+                mom = hip.spot_moments(x, y, inten)
+                dist.all_reduce(mom)
+            else:
+                hits[0].copy_(x)
+                hits[1].copy_(y)
+                hits[2].copy_(inten)
+                dist.all_gather_into_tensor(gather_buf.view(-1), hits.view(-1))
+        return res
+
+    for _ in range(args.warmup):
+        step()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)]
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(*evs[k])
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    kern_ms = float(np.mean([a.elapsed_time(bb) for a, bb in evs])) if args.steps else float("nan")
+
+    if rank == 0:
+        total_rs = float(n) * S * world * args.steps
+        value = total_rs / elapsed
+        # algorithmic bytes per launch: record-all reads 8 planes and
+        # writes 8 planes for each of the S+1 surfaces; record-last reads 8, writes 8.
+        if args.mode == "record":
+            alg_bytes = 8 * b * (S + 2) * n
+        else:
+            alg_bytes = 16 * b * n
+        if pol:
+            alg_bytes += 2 * 9 * b * n  # PRT read-modify-write
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = load_traffic(args.workload, args.dtype, args.mode)
+        out = {
+            "metric": "ray-surface intersections/s",
+            "value": value,
+            "unit": "ray-surfaces/s",
+            "rays_per_s": value / S,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"{desc} ({S} traced surfaces incl. image plane), "
+                            f"{n:.3g} rays/GPU {args.dtype}, uniform-disc pupil, Hy={hy}, "
+                            f"mode={'record-all' if args.mode == 'record' else 'record-last'}",
+                "rays_per_gpu": n,
+                "surfaces": S,
+                "mode": args.mode,
+                "exchange": exchange,
+                "parallelism": f"ray-shard x{world}",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "trace_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel_ms": kern_ms,
+                "algorithmic_bytes": alg_bytes,
+                "bytes_per_ray_surface": alg_bytes / (float(n) * S),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(table, hy, args.mode, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    hip.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,6 +22,7 @@
 //     see newton_distance().
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "device_table.h"
 #include "trace_launch.h"
@@ -584,6 +585,12 @@ __device__ __forceinline__ Ray<T> to_global(const DevSurf<T>& s, const Ray<T>& r
 // --------------------------------------------------------------------------
 // vector load / store of RPT consecutive rays of one plane
 // --------------------------------------------------------------------------
+#ifdef OL_NT_STORES
+#define OL_STORE(v, ptr) __builtin_nontemporal_store(v, ptr)
+#else
+#define OL_STORE(v, ptr) (*(ptr) = (v))
+#endif
+
 template <typename T, int RPT>
 struct VecOf {
   typedef T type __attribute__((ext_vector_type(RPT)));
@@ -610,17 +617,17 @@ __device__ __forceinline__ void load_plane(const T* __restrict__ p, int64_t base
 template <typename T, int RPT>
 __device__ __forceinline__ void store_plane(T* __restrict__ p, int64_t base, int cnt,
                                             const T (&in)[RPT]) {
-  // streaming (non-temporal) stores: recorded rows are written once and never
-  // re-read by this kernel, so they should not displace anything in L2.
+  // plain stores: measured 1-2 % faster than non-temporal ones for this 104-plane
+  // pattern on MI355X (tools/microbench/stream_write.hip; OL_NT_STORES flips it).
   if constexpr (RPT == 1) {
-    __builtin_nontemporal_store(in[0], p + base);
+    OL_STORE(in[0], p + base);
   } else {
     using V = typename VecOf<T, RPT>::type;
     if (cnt == RPT) {
       V v;
 #pragma unroll
       for (int k = 0; k < RPT; ++k) v[k] = in[k];
-      __builtin_nontemporal_store(v, reinterpret_cast<V*>(p + base));
+      OL_STORE(v, reinterpret_cast<V*>(p + base));
     } else {
 #pragma unroll
       for (int k = 0; k < RPT; ++k)
@@ -650,8 +657,17 @@ __device__ __forceinline__ void store_rays(T* __restrict__ row, int64_t stride, 
 // --------------------------------------------------------------------------
 // the kernel
 // --------------------------------------------------------------------------
+// The three table pointers are separate `const __restrict__` kernel arguments on
+// purpose: only then can the compiler prove that the record stores never clobber
+// the table and fetch it with scalar loads (s_load_dwordx*, lgkmcnt).  As fields of
+// the by-value argument struct they were fetched with per-lane global_load_dword +
+// v_readfirstlane, and -- vmcnt being in-order on gfx9-family parts -- every
+// surface's table read then waited for ALL outstanding record stores to retire,
+// serialising compute behind HBM writes (measured: 1.00 ms -> see DESIGN.md).
 template <typename T, int RPT, bool RECORD, bool POL>
-__global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceArgs<T> a) {
+__global__ __launch_bounds__(kTraceBlock) void trace_kernel(
+    const DevSurf<T>* __restrict__ surf_tab, const DevOptics<T>* __restrict__ optics_tab,
+    const T* __restrict__ coeff_tab, TraceArgs<T> a) {
   const int64_t base = ((int64_t)blockIdx.x * kTraceBlock + threadIdx.x) * RPT;
   if (base >= a.n) return;
   const int64_t left = a.n - base;
@@ -687,11 +703,11 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(TraceArgs<T> a) {
   bool is_global = true;  // frame of the state held in r[]
   const DevSurf<T>* last_traced = nullptr;
   for (int s = a.first; s <= a.last; ++s) {
-    const DevSurf<T>& S = a.surf[s];
+    const DevSurf<T>& S = surf_tab[s];
     if (S.interaction != kRecordOnly) {
-      const DevOptics<T>& O = a.optics[s * a.n_wl + a.wl];
+      const DevOptics<T>& O = optics_tab[s * a.n_wl + a.wl];
 #pragma unroll
-      for (int k = 0; k < RPT; ++k) surface_step<T, POL>(S, O, a.coeffs, is_global, r[k], P[POL ? k : 0], status);
+      for (int k = 0; k < RPT; ++k) surface_step<T, POL>(S, O, coeff_tab, is_global, r[k], P[POL ? k : 0], status);
       is_global = false;
       last_traced = &S;
     }
@@ -750,21 +766,36 @@ static hipError_t launch_rpt(const TraceArgs<T>& a, hipStream_t stream) {
   dim3 grid((unsigned)blocks), block(kTraceBlock);
   const bool rec = a.record != nullptr, pol = a.prt != nullptr;
   if (rec && pol)
-    hipLaunchKernelGGL((trace_kernel<T, RPT, true, true>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((trace_kernel<T, RPT, true, true>), grid, block, 0, stream, a.surf, a.optics,
+                       a.coeffs, a);
   else if (rec)
-    hipLaunchKernelGGL((trace_kernel<T, RPT, true, false>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((trace_kernel<T, RPT, true, false>), grid, block, 0, stream, a.surf, a.optics,
+                       a.coeffs, a);
   else if (pol)
-    hipLaunchKernelGGL((trace_kernel<T, RPT, false, true>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((trace_kernel<T, RPT, false, true>), grid, block, 0, stream, a.surf, a.optics,
+                       a.coeffs, a);
   else
-    hipLaunchKernelGGL((trace_kernel<T, RPT, false, false>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((trace_kernel<T, RPT, false, false>), grid, block, 0, stream, a.surf, a.optics,
+                       a.coeffs, a);
   return hipGetLastError();
 }
 
 template <typename T>
 hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, hipStream_t stream) {
   constexpr int kVec = 16 / sizeof(T);  // rays per 16-byte lane vector
-  if (vector_ok) return launch_rpt<T, kVec>(a, stream);
-  return launch_rpt<T, 1>(a, stream);
+  if (!vector_ok) return launch_rpt<T, 1>(a, stream);
+  // tuning hook (profiling only): OL_TRACE_RPT=1|2|4|8 overrides rays per thread
+  static const int forced = [] {
+    const char* e = getenv("OL_TRACE_RPT");
+    return e ? atoi(e) : 0;
+  }();
+  switch (forced) {
+    case 1: return launch_rpt<T, 1>(a, stream);
+    case 2: return launch_rpt<T, 2>(a, stream);
+    case 4: if (sizeof(T) == 4) return launch_rpt<T, 4>(a, stream); break;
+    default: break;
+  }
+  return launch_rpt<T, kVec>(a, stream);
 }
 
 template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, hipStream_t);
