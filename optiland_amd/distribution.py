@@ -1,0 +1,100 @@
+"""Pupil samplers (host side, tiny) mirroring the reference's sampler names.
+
+Interface parity with optiland/distribution.py:415-446: `create_distribution(name)`
+returns an object with `generate_points(n)` that fills `.x` / `.y` (normalised pupil
+coordinates), and an unknown name raises ValueError("Invalid distribution type.").
+Point ORDER matches the reference for every deterministic sampler, because ray
+order is observable (`repeat`/`tile` in raytrace/real_ray_tracer.py:95-98).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def _line(n, positive):
+    return np.linspace(0.0 if positive else -1.0, 1.0, n)
+
+
+def _hexapolar(rings):
+    # distribution.py:201-220: centre + 6(i+1) points on ring i, radius linspace
+    xs, ys = [np.zeros(1)], [np.zeros(1)]
+    radii = np.linspace(0.0, 1.0, rings + 1)
+    for i in range(rings):
+        theta = np.linspace(0.0, 2.0 * np.pi, 6 * (i + 1) + 1)[:-1]
+        xs.append(radii[i + 1] * np.cos(theta))
+        ys.append(radii[i + 1] * np.sin(theta))
+    return np.concatenate(xs), np.concatenate(ys)
+
+
+def _uniform(n):
+    # distribution.py:161-186: n x n grid masked to the unit disc (row-major order)
+    g = np.linspace(-1.0, 1.0, n)
+    x, y = np.meshgrid(g, g)
+    keep = x**2 + y**2 <= 1
+    return x[keep], y[keep]
+
+
+def _cross(n):
+    # distribution.py:235-262: vertical arm first, horizontal arm without its
+    # duplicate origin when n is odd
+    arm = np.linspace(-1.0, 1.0, n)
+    hx = arm
+    if n % 2 == 1:
+        hx = np.delete(arm, n // 2)
+    return (np.concatenate([np.zeros(n), hx]), np.concatenate([arm, np.zeros(hx.size)]))
+
+
+def _ring(n):
+    theta = np.linspace(0.0, 2.0 * np.pi, n + 1)[:-1]
+    return np.cos(theta), np.sin(theta)
+
+
+class Distribution:
+    """One named sampler; `generate_points` stores float64 arrays in .x/.y."""
+
+    def __init__(self, kind: str, seed=None):
+        self.kind = kind
+        self.seed = seed
+        self.x = np.zeros(0)
+        self.y = np.zeros(0)
+
+    def generate_points(self, num_points: int = 6):
+        k = self.kind
+        if k in ("line_x", "positive_line_x"):
+            self.x, self.y = _line(num_points, k.startswith("positive")), np.zeros(num_points)
+        elif k in ("line_y", "positive_line_y"):
+            self.x, self.y = np.zeros(num_points), _line(num_points, k.startswith("positive"))
+        elif k == "hexapolar":
+            self.x, self.y = _hexapolar(num_points)
+        elif k == "uniform":
+            self.x, self.y = _uniform(num_points)
+        elif k == "cross":
+            self.x, self.y = _cross(num_points)
+        elif k == "ring":
+            self.x, self.y = _ring(num_points)
+        elif k in ("random", "sobol"):
+            # stochastic samplers: same law (uniform over the unit disc) as
+            # distribution.py:137-158 / 381-412; the stream differs from NumPy's
+            if k == "sobol":
+                from scipy.stats import qmc
+                u = qmc.Sobol(d=2, scramble=True, seed=self.seed).random(num_points)
+                u1, u2 = u[:, 0], u[:, 1]
+            else:
+                rng = np.random.default_rng(self.seed)
+                u1, u2 = rng.random(num_points), rng.random(num_points)
+            r, th = np.sqrt(u1), 2.0 * np.pi * u2
+            self.x, self.y = r * np.cos(th), r * np.sin(th)
+        else:  # pragma: no cover - guarded in create_distribution
+            raise ValueError("Invalid distribution type.")
+        return self
+
+
+_KINDS = ("line_x", "line_y", "positive_line_x", "positive_line_y", "random", "uniform",
+          "hexapolar", "cross", "ring", "sobol")
+
+
+def create_distribution(distribution_type: str) -> Distribution:
+    if distribution_type not in _KINDS:
+        raise ValueError("Invalid distribution type.")
+    return Distribution(distribution_type)

@@ -1,0 +1,246 @@
+"""Plug the fused HIP trace in behind a live reference installation.
+
+Two seams of the reference are used:
+
+1. the backend registry -- `optiland.backend._backends` (backend/__init__.py:
+   100-112); `register_backend()` adds a `"hip"` entry, a `TorchBackend` pinned
+   to the HIP device so every un-accelerated `be.*` call keeps working on the
+   same device tensors (the reference's own test does the same with a "dummy"
+   backend, tests/test_backend.py:79-85);
+2. the tracer attribute -- `Optic.ray_tracer` (optic/optic.py:121,740,763);
+   `install(optic)` replaces it with `OptilandHipRayTracer`, a subclass of the
+   reference's `RealRayTracer` whose `trace` / `trace_generic` run the HIP path
+   and then populate exactly what the reference leaves behind: the returned
+   `RealRays` / `PolarizedRays` object and every `Surface`'s recorded
+   x, y, z, L, M, N, intensity, opd (surfaces/standard_surface.py:260-274).
+
+Anything the fused path does not implement (autograd, BSDF, GRIN, NURBS, thin
+films, non-paraxial aiming ...) raises `UnsupportedSystem` inside the packer
+and the call is forwarded, untouched, to the reference implementation.
+
+This module imports the reference lazily; it is inert where `optiland` is not
+installed (e.g. the GPU test box).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import tracer as _tracer
+from .packer import UnsupportedSystem, pack_optic
+from .rays import _state_dict
+
+BACKEND_NAME = "hip"
+
+
+def register_backend(name: str = BACKEND_NAME):
+    """Insert the HIP backend into the reference's registry and return it."""
+    import optiland.backend as be
+    from optiland.backend.torch_backend import TorchBackend
+
+    if name in be._backends:
+        return be._backends[name]
+
+    class HipBackend(TorchBackend):
+        """TorchBackend on the ROCm device (+ the fused trace via install())."""
+
+        @property
+        def name(self) -> str:  # noqa: D401
+            return name
+
+        def __init__(self):
+            super().__init__()
+            if torch.cuda.is_available():
+                self._config.set_device("cuda")
+
+    be._backends[name] = HipBackend()
+    return be._backends[name]
+
+
+def _table_key(table):
+    return (table.surfaces.tobytes(), table.coeffs.tobytes(), table.optics.tobytes(),
+            table.wavelengths.tobytes(), repr(sorted(table.raygen.items())),
+            repr(table.fields), repr(table.polarization))
+
+
+def _make_tracer_class():
+    import optiland.backend as be
+    from optiland.distribution import create_distribution
+    from optiland.raytrace.real_ray_tracer import RealRayTracer
+    from optiland.rays import PolarizedRays as RefPolarizedRays
+    from optiland.rays import RealRays as RefRealRays
+
+    class OptilandHipRayTracer(RealRayTracer):
+        """`RealRayTracer` whose surface loop runs in one HIP kernel."""
+
+        def __init__(self, optic, device=None, force=False):
+            super().__init__(optic)
+            self._hip_device = device
+            self._hip_force = force  # tests: intercept regardless of backend/device
+            self._hip_key = None
+            self._hip_engine = None
+            self._hip_table = None
+            self.last_path = None  # "hip" | "reference" (introspection for tests)
+
+        # ---------------------------------------------------------- eligibility
+        def _eligible(self) -> bool:
+            if self._hip_force:
+                return True
+            if be.get_backend() not in (BACKEND_NAME, "torch"):
+                return False
+            inst = be._backends[be.get_backend()]
+            if inst._config.get_device() != "cuda":
+                return False
+            if inst._config.grad_mode.requires_grad:  # autograd stays on torch ops
+                return False
+            return True
+
+        def _dtype(self):
+            if be.get_backend() in (BACKEND_NAME, "torch"):
+                return be._backends[be.get_backend()]._config.get_precision()
+            return torch.float64
+
+        def _engine_for(self, wavelength):
+            w = float(wavelength.item()) if hasattr(wavelength, "item") else float(wavelength)
+            table = pack_optic(self.optic, wavelengths=[w])
+            key = _table_key(table)
+            if key != self._hip_key:
+                if self._hip_engine is not None and hasattr(self._hip_engine, "close"):
+                    self._hip_engine.close()
+                self._hip_engine = _tracer._make_engine(table, self._hip_device)
+                self._hip_key, self._hip_table = key, table
+            return self._hip_engine, self._hip_table
+
+        # ---------------------------------------------------------------- trace
+        def _hip_trace(self, Hx, Hy, Px, Py, wavelength, update_intensity, vig_scaled):
+            eng, table = self._engine_for(wavelength)
+            dtype, dev = self._dtype(), eng.device
+            as_dev = lambda a: torch.as_tensor(  # noqa: E731
+                np.array(be.to_numpy(a), dtype=np.float64) if not isinstance(a, torch.Tensor) else a,
+                dtype=dtype, device=dev).reshape(-1).contiguous()
+            if table.raygen:
+                hx, hy, px, py = (as_dev(a) for a in (Hx, Hy, Px, Py))
+                vxf, vyf = self.optic.fields.get_vig_factor(Hx, Hy)
+                vx = as_dev(1 - np.asarray(be.to_numpy(vxf), dtype=np.float64)
+                            * np.ones(hx.numel()))
+                vy = as_dev(1 - np.asarray(be.to_numpy(vyf), dtype=np.float64)
+                            * np.ones(hx.numel()))
+                planes = eng.generate_rays(hx, hy, px, py, vx, vy)
+            else:  # aiming/field type the device generator does not cover
+                r = self.ray_generator.generate_rays(Hx, Hy, Px, Py, wavelength)
+                planes = [as_dev(getattr(r, k)) for k in ("x", "y", "z", "L", "M", "N", "i")]
+            n = int(planes[0].numel())
+            rays = [p.contiguous() for p in planes] + [torch.zeros(n, dtype=dtype, device=dev)]
+            polarized = self.optic.polarization != "ignore"
+            if not polarized and self.optic.surfaces.uses_polarization:
+                raise ValueError("Polarization must be set when surfaces have "
+                                 "polarization-dependent coatings.")
+            prt = k_init = i0 = None
+            if polarized:
+                prt = torch.zeros((9, n), dtype=dtype, device=dev)
+                prt[0].fill_(1), prt[4].fill_(1), prt[8].fill_(1)
+                k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
+                i0 = rays[6].clone()
+            res = eng.trace(rays, 0, record=True, prt=prt)
+
+            # every Surface gets its recorded vectors (views, no copies)
+            for s, surf in enumerate(self.optic.surfaces):
+                surf.reset()
+                surf.x, surf.y, surf.z = res.row(s, 0), res.row(s, 1), res.row(s, 2)
+                surf.L, surf.M, surf.N = res.row(s, 3), res.row(s, 4), res.row(s, 5)
+                surf.intensity, surf.opd = res.row(s, 6), res.row(s, 7)
+
+            last = res.last
+            w = torch.full((n,), float(wavelength), dtype=dtype, device=dev)
+            fin = [res.row(last, k) for k in range(8)]
+            cls = RefPolarizedRays if polarized else RefRealRays
+            out = cls.__new__(cls)  # fill attributes directly: no be.* round trip
+            out.x, out.y, out.z, out.L, out.M, out.N = fin[:6]
+            out.i, out.opd, out.w = fin[6], fin[7], w
+            out.is_normalized = True
+            if last > 0:
+                out.L0, out.M0, out.N0 = res.row(last - 1, 3), res.row(last - 1, 4), \
+                    res.row(last - 1, 5)
+            else:
+                out.L0 = out.M0 = out.N0 = None
+            if polarized:
+                real = prt.t().reshape(n, 3, 3)
+                cd = torch.complex64 if dtype == torch.float32 else torch.complex128
+                out.p = real.to(cd)
+                out._i0, out._L0, out._M0, out._N0 = i0, *k_init
+                if update_intensity:  # real_ray_tracer.py:112-113
+                    out.i = eng.polarized_intensity(prt, k_init, i0,
+                                                    _state_dict(self.optic.polarization_state))
+            # final propagation by the image thickness (0 in every sample):
+            # real_ray_tracer.py:106-110 -- identity for t == 0
+            thick = float(table.last_thickness)
+            if thick != 0.0:
+                last_surface = self.optic.surfaces[-1]
+                last_surface.material_post.propagation_model.propagate(out, thick)
+            return out
+
+        def trace(self, Hx, Hy, wavelength, num_rays=100, distribution="hexapolar"):
+            if not self._eligible():
+                self.last_path = "reference"
+                return super().trace(Hx, Hy, wavelength, num_rays, distribution)
+            self._validate_normalized_coordinates(Hx, Hy, "field")
+            try:
+                if isinstance(distribution, str):
+                    distribution = create_distribution(distribution)
+                    distribution.generate_points(num_rays)
+                Px, Py = be.to_numpy(distribution.x), be.to_numpy(distribution.y)
+                Hxa = np.atleast_1d(np.asarray(be.to_numpy(Hx), dtype=np.float64))
+                Hya = np.atleast_1d(np.asarray(be.to_numpy(Hy), dtype=np.float64))
+                nf, npup = Hxa.size, Px.size
+                out = self._hip_trace(np.repeat(Hxa, npup), np.repeat(Hya, npup),
+                                      np.tile(Px, nf), np.tile(Py, nf), wavelength,
+                                      update_intensity=True, vig_scaled=False)
+            except UnsupportedSystem:
+                self.last_path = "reference"
+                return super().trace(Hx, Hy, wavelength, num_rays, distribution)
+            self.last_path = "hip"
+            return out
+
+        def trace_generic(self, Hx, Hy, Px, Py, wavelength):
+            if not self._eligible():
+                self.last_path = "reference"
+                return super().trace_generic(Hx, Hy, Px, Py, wavelength)
+            self._validate_normalized_coordinates(Hx, Hy, "field")
+            self._validate_normalized_coordinates(Px, Py, "pupil")
+            try:
+                vx, vy = self.optic.fields.get_vig_factor(Hx, Hy)
+                arrs = [np.atleast_1d(np.asarray(be.to_numpy(a), dtype=np.float64))
+                        for a in (Hx, Hy, Px, Py)]
+                n = max(a.size for a in arrs)
+                Hxa, Hya, Pxa, Pya = (np.broadcast_to(a, (n,)) if a.size == 1 else a
+                                      for a in arrs)
+                Pxa = Pxa * (1 - np.asarray(be.to_numpy(vx), dtype=np.float64))
+                Pya = Pya * (1 - np.asarray(be.to_numpy(vy), dtype=np.float64))
+                out = self._hip_trace(Hxa, Hya, Pxa, Pya, wavelength, update_intensity=False,
+                                      vig_scaled=True)
+            except UnsupportedSystem:
+                self.last_path = "reference"
+                return super().trace_generic(Hx, Hy, Px, Py, wavelength)
+            self.last_path = "hip"
+            return out
+
+    return OptilandHipRayTracer
+
+
+def install(optic, device=None, force=False):
+    """Replace `optic.ray_tracer` with the HIP tracer (keeps the aiming config)."""
+    cls = _make_tracer_class()
+    old = optic.ray_tracer
+    new = cls(optic, device=device, force=force)
+    new.ray_aiming_config = dict(getattr(old, "ray_aiming_config", new.ray_aiming_config))
+    optic.ray_tracer = new
+    return new
+
+
+def uninstall(optic):
+    from optiland.raytrace.real_ray_tracer import RealRayTracer
+
+    cfg = dict(optic.ray_tracer.ray_aiming_config)
+    optic.ray_tracer = RealRayTracer(optic)
+    optic.ray_tracer.ray_aiming_config = cfg

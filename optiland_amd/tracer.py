@@ -1,0 +1,199 @@
+"""Host-side mirror of the reference's real-ray tracer for the fused HIP path.
+
+`HipRayTracer` exposes the interface of `RealRayTracer`
+(optiland/raytrace/real_ray_tracer.py:36-173): `trace(Hx, Hy, wavelength,
+num_rays, distribution)`, `trace_generic(Hx, Hy, Px, Py, wavelength)`,
+`set_aiming(...)`, `ray_aiming_config` -- same argument meaning, same
+`ValueError` texts -- but runs ray generation, the whole surface sequence and
+the recording in HIP kernels behind the C ABI.  The per-surface recorded state
+(`SurfaceGroup.x/.y/.../.intensity/.opd`, surfaces/surface_group.py:108-153) is
+exposed without copies as views of one (S+1, 8, N) device block.
+
+It works from a `SystemTable` alone (the GPU box has no reference package) or
+from a live reference `Optic` through `optiland_amd.integration`.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .distribution import Distribution, create_distribution
+from .rays import PolarizedRays, RealRays, _state_dict
+from .system import SystemTable
+
+
+def _make_engine(table: SystemTable, device):
+    """Engine factory (tests substitute an oracle-backed stand-in here; the
+    product path has no CPU fallback)."""
+    from .engine import HipSystem
+
+    return HipSystem(table, device)
+
+
+class RecordedSurfaces:
+    """Stacked per-surface state of the last trace: `(S+1, N)` views (no copy).
+
+    Mirrors the read side of `SurfaceGroup` (surfaces/surface_group.py:108-153).
+    """
+
+    _PLANES = {"x": 0, "y": 1, "z": 2, "L": 3, "M": 4, "N": 5, "intensity": 6, "opd": 7}
+
+    def __init__(self):
+        self._res = None
+
+    def _bind(self, res):
+        self._res = res
+
+    def __getattr__(self, name):
+        planes = object.__getattribute__(self, "_PLANES")
+        if name in planes:
+            res = object.__getattribute__(self, "_res")
+            if res is None or res.record is None:
+                return torch.empty((0, 0))
+            return res.stack(planes[name])
+        raise AttributeError(name)
+
+    @property
+    def num_surfaces(self):
+        return 0 if self._res is None else self._res.last - self._res.first + 1
+
+
+class HipRayTracer:
+    """Drop-in for `RealRayTracer` on a packed system."""
+
+    def __init__(self, table: SystemTable, device=None, dtype=torch.float32, engine=None):
+        self.table = table
+        self.dtype = dtype
+        self.engine = engine if engine is not None else _make_engine(table, device)
+        self.device = self.engine.device
+        self.surfaces = RecordedSurfaces()
+        self.ray_aiming_config = {"mode": "paraxial", "max_iter": 10, "tol": 1e-6}
+        self.record_all = True  # drop-in semantics; False = image plane only
+        f = np.asarray(table.fields, dtype=np.float64).reshape(-1, 4)
+        self._fields = f
+
+    # ------------------------------------------------------------ configuration
+    def set_aiming(self, mode: str, max_iter: int = 10, tol: float = 1e-6, **kwargs):
+        """real_ray_tracer.py:42-56.  Only paraxial aiming runs on device."""
+        if mode != "paraxial":
+            raise NotImplementedError(
+                f"ray aiming mode {mode!r} is a host-side Newton loop in the reference "
+                "(rays/ray_aiming/iterative.py) and is outside the fused path")
+        self.ray_aiming_config = {"mode": mode, "max_iter": max_iter, "tol": tol, **kwargs}
+
+    # ------------------------------------------------------------------ helpers
+    def _dev(self, v):
+        if isinstance(v, torch.Tensor):
+            return v.to(device=self.device, dtype=self.dtype).reshape(-1)
+        return torch.as_tensor(np.atleast_1d(np.asarray(v, dtype=np.float64)),
+                               dtype=self.dtype, device=self.device).reshape(-1)
+
+    @staticmethod
+    def _validate_normalized_coordinates(x, y, coord_type="field"):
+        """real_ray_tracer.py:156-173 (same message)."""
+        def ok(v):
+            if isinstance(v, torch.Tensor):
+                return bool(((v >= -1) & (v <= 1)).all())
+            a = np.asarray(v, dtype=np.float64)
+            return bool(np.all((a >= -1) & (a <= 1)))
+        if not (ok(x) and ok(y)):
+            raise ValueError(f"Normalized {coord_type} coordinates must be within (-1, 1)")
+
+    def _vig_factor(self, hx, hy):
+        """FieldGroup.get_vig_factor (fields/field_group.py:93-122): nearest field
+        point in normalised field coordinates -> (vx, vy)."""
+        f = self._fields
+        if f.shape[0] == 0 or not np.any(f[:, 2:]):
+            return None, None
+        max_field = self.table.raygen.get("max_field", 0.0)
+        pts = f[:, :2] / max_field if max_field != 0 else f[:, :2]
+        P = torch.as_tensor(pts, dtype=self.dtype, device=self.device)
+        d2 = (hx[:, None] - P[None, :, 0]) ** 2 + (hy[:, None] - P[None, :, 1]) ** 2
+        idx = torch.argmin(d2, dim=1)
+        V = torch.as_tensor(f[:, 2:], dtype=self.dtype, device=self.device)
+        return V[idx, 0], V[idx, 1]
+
+    def _wavelength_index(self, wavelength):
+        w = float(wavelength.item()) if hasattr(wavelength, "item") else float(wavelength)
+        return self.table.wavelength_index(w), w
+
+    # -------------------------------------------------------------------- trace
+    def _run(self, hx, hy, px, py, one_minus_v, wavelength, update_intensity):
+        wl, w = self._wavelength_index(wavelength)
+        eng = self.engine
+        vx, vy = one_minus_v
+        planes = eng.generate_rays(hx, hy, px, py, vx, vy)
+        n = int(px.numel())
+        rays = [p if p.is_contiguous() else p.contiguous() for p in planes]
+        rays.append(torch.zeros(n, dtype=self.dtype, device=self.device))
+        polarized = self.table.polarization is not None
+        if not polarized and self.table.uses_polarization:
+            # rays/ray_generator.py:89-94
+            raise ValueError("Polarization must be set when surfaces have "
+                             "polarization-dependent coatings.")
+        prt = None
+        k_init = i0 = None
+        if polarized:
+            prt = torch.zeros((9, n), dtype=self.dtype, device=self.device)
+            prt[0].fill_(1), prt[4].fill_(1), prt[8].fill_(1)
+            k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
+            i0 = rays[6].clone()
+        res = eng.trace(rays, wl, record=self.record_all, prt=prt)
+        self.surfaces._bind(res)
+        wt = torch.full((n,), w, dtype=self.dtype, device=self.device)
+        if res.record is not None:
+            fin = [res.row(res.last, k) for k in range(8)]
+        else:
+            fin = rays
+        if polarized:
+            out = PolarizedRays(*fin[:7], wt, fin[7], engine=eng, prt=prt, i0=i0, k_init=k_init)
+            if update_intensity:  # real_ray_tracer.py:112-113 -- trace() only
+                out.update_intensity(_state_dict(self.table.polarization))
+        else:
+            out = RealRays(*fin[:7], wt, fin[7])
+        # pre-interaction cosines at the last surface = directions recorded on the
+        # previous one, expressed in the last surface's frame (real_rays.py:170-172)
+        if res.record is not None and res.last > res.first:
+            L0, M0, N0 = (res.row(res.last - 1, k) for k in (3, 4, 5))
+            s = self.table.surfaces[res.last]
+            if s["flags"] & 1:
+                R = torch.as_tensor(np.asarray(s["rot"]).reshape(3, 3), dtype=self.dtype,
+                                    device=self.device)
+                k = torch.stack([L0, M0, N0])
+                L0, M0, N0 = R @ k
+            out.L0, out.M0, out.N0 = L0, M0, N0
+        return out
+
+    def trace(self, Hx, Hy, wavelength, num_rays=100, distribution="hexapolar"):
+        """real_ray_tracer.py:58-118: every field point x every pupil point."""
+        self._validate_normalized_coordinates(Hx, Hy, "field")
+        if isinstance(distribution, str):
+            distribution = create_distribution(distribution)
+            distribution.generate_points(num_rays)
+        Px, Py = self._dev(distribution.x), self._dev(distribution.y)
+        Hx, Hy = self._dev(Hx), self._dev(Hy)
+        nf, npup = Hx.numel(), Px.numel()
+        hx, hy = Hx.repeat_interleave(npup), Hy.repeat_interleave(npup)
+        px, py = Px.repeat(nf), Py.repeat(nf)
+        vxf, vyf = self._vig_factor(hx, hy)
+        omv = (None, None) if vxf is None else (1 - vxf, 1 - vyf)
+        return self._run(hx, hy, px, py, omv, wavelength, update_intensity=True)
+
+    def trace_generic(self, Hx, Hy, Px, Py, wavelength):
+        """real_ray_tracer.py:120-154: caller-supplied per-ray coordinates; the
+        pupil is pre-scaled by (1 - v) (:134-137) and the polarised
+        update_intensity epilogue is NOT applied."""
+        self._validate_normalized_coordinates(Hx, Hy, "field")
+        self._validate_normalized_coordinates(Px, Py, "pupil")
+        arrs = [self._dev(a) for a in (Hx, Hy, Px, Py)]
+        n = max(a.numel() for a in arrs)
+        hx, hy, px, py = (a.expand(n).contiguous() if a.numel() == 1 else a for a in arrs)
+        if any(a.numel() != n for a in (hx, hy, px, py)):
+            raise ValueError("Hx, Hy, Px, Py must be scalars or arrays of one common size")
+        vxf, vyf = self._vig_factor(hx, hy)
+        omv = (None, None)
+        if vxf is not None:
+            px, py = px * (1 - vxf), py * (1 - vyf)
+            omv = (1 - vxf, 1 - vyf)
+        return self._run(hx, hy, px, py, omv, wavelength, update_intensity=False)

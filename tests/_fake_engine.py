@@ -1,0 +1,89 @@
+"""Oracle-backed stand-in for `optiland_amd.engine.HipSystem` (tests only).
+
+Lets the `-m "not gpu"` suite exercise the HOST logic (tracer mirror, reference
+integration, sharding) on CPU tensors.  It lives under tests/ and is injected by
+monkeypatching `optiland_amd.tracer._make_engine`; the product has no such path.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from optiland_amd import system as S
+from optiland_amd.engine import PLANES, TraceResult
+from oracle import oracle
+
+
+class OracleEngine:
+    def __init__(self, table, device=None):
+        self.table = table
+        self.device = torch.device("cpu")
+        self.calls = 0
+
+    @property
+    def num_surfaces(self):
+        return self.table.num_surfaces
+
+    def close(self):
+        pass
+
+    def trace(self, rays, wavelength_index=0, record=True, prt=None, first=0, last=None,
+              write_rays=None, check_status=True):
+        self.calls += 1
+        rays = list(rays)
+        n = int(rays[0].numel())
+        dtype = rays[0].dtype
+        last = self.num_surfaces - 1 if last is None else last
+        if prt is None and any(self.table.surfaces["coating_kind"][first:last + 1] == S.COAT_FRESNEL):
+            raise ValueError("Polarization must be set when surfaces have "
+                             "polarization-dependent coatings.")
+        d = {k: rays[j].double().numpy() for j, k in enumerate(PLANES)}
+        out = oracle.trace(self.table, d, wavelength_index, record=bool(record is not False
+                           and record is not None), polarized=prt is not None,
+                           first=first, last=last)
+        if out["status"] & S.STATUS_ZERNIKE_RANGE:
+            raise ValueError(
+                "Zernike coordinates must be normalized "
+                "to [-1, 1]. Consider updating the normalization "
+                "radius to 1.1x the surface aperture.")
+        rec = None
+        if out["record"] is not None:
+            rec = torch.as_tensor(out["record"], dtype=dtype)
+        if write_rays is None:
+            write_rays = rec is None
+        if write_rays:
+            for j, k in enumerate(PLANES):
+                rays[j].copy_(torch.as_tensor(out[k], dtype=dtype))
+        if prt is not None:
+            p = out["prt"]  # (n,3,3) complex; started from identity -> multiply in
+            start = prt.t().reshape(n, 3, 3).double().numpy()
+            newp = np.einsum("nij,njk->nik", p.real, start)
+            prt.copy_(torch.as_tensor(newp.reshape(n, 9).T.copy(), dtype=dtype))
+        return TraceResult(n, rays, rec, prt, out["status"], first, last)
+
+    def generate_rays(self, hx, hy, px, py, vx=None, vy=None):
+        f = lambda t: None if t is None else t.double().numpy()  # noqa: E731
+        g = oracle.generate_rays(self.table.raygen, f(hx), f(hy), f(px), f(py), f(vx), f(vy))
+        return [torch.as_tensor(g[k], dtype=px.dtype) for k in ("x", "y", "z", "L", "M", "N", "i")]
+
+    def polarized_intensity(self, prt, k0, i0, polarization):
+        n = int(i0.numel())
+        p = prt.t().reshape(n, 3, 3).double().numpy().astype(np.complex128)
+        out, status = oracle.polarized_intensity(p, *[k.double().numpy() for k in k0],
+                                                 i0.double().numpy(), polarization)
+        if status & S.STATUS_K_PARALLEL_X:
+            raise ValueError("k-vector parallel to x-axis is not currently supported.")
+        return torch.as_tensor(out, dtype=i0.dtype)
+
+    def spot_moments(self, x, y, intensity):
+        m = intensity > 0
+        xd, yd = x[m].double(), y[m].double()
+        c = float(m.sum())
+        return torch.tensor([c, xd.sum(), yd.sum(), (xd * xd).sum(), (yd * yd).sum(), c],
+                            dtype=torch.float64)
+
+    def spot_max_r2(self, x, y, intensity, cx, cy):
+        m = intensity > 0
+        r2 = (x[m].double() - cx) ** 2 + (y[m].double() - cy) ** 2
+        return r2.max().reshape(1) if r2.numel() else torch.zeros(1, dtype=torch.float64)

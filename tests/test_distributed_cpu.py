@@ -1,0 +1,98 @@
+"""World-size-2 gloo test of the sharding + image-plane exchange (CPU)."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from optiland_amd.distributed import shard_bounds
+
+
+def test_shard_bounds_cover_exactly():
+    for n in (0, 1, 7, 8, 9, 1000, 10**7 + 3):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import optiland_amd.tracer as tr
+        from optiland_amd.distributed import ShardedTracer
+        from tests._fake_engine import OracleEngine
+        from tests._util import load_case
+        tr._make_engine = lambda table, device: OracleEngine(table, device)
+        table, data = load_case("double_gauss_multifield")
+        n = 899  # ragged on purpose
+        args = [data[k][:n] for k in ("Hx", "Hy", "Px", "Py")]
+        t = tr.HipRayTracer(table, dtype=torch.float64)
+        st = ShardedTracer(t)
+        g = st.trace_generic(*args, 0.4861, exchange="gather")
+        r = st.trace_generic(*args, 0.4861, exchange="reduce")
+        q.put((rank, g["lo"], g["hi"], g["rays"].x.numpy(), [h.numpy() for h in g["hits"]],
+               r["spot"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_shards_equal_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+
+    # single-process result on the same inputs
+    import optiland_amd.tracer as tr
+    from tests._fake_engine import OracleEngine
+    from tests._util import load_case
+    table, data = load_case("double_gauss_multifield")
+    n = 899
+    eng = OracleEngine(table)
+    t = tr.HipRayTracer(table, dtype=torch.float64, engine=eng)
+    full = t.trace_generic(*[data[k][:n] for k in ("Hx", "Hy", "Px", "Py")], 0.4861)
+    fx, fy, fi = full.x.numpy(), full.y.numpy(), full.i.numpy()
+
+    # shards tile the input order and concatenate to the single-device result, bit for bit
+    assert results[0][1] == 0 and results[0][2] == results[1][1] and results[1][2] == n
+    cat = np.concatenate([results[0][3], results[1][3]])
+    assert np.array_equal(cat, fx)
+    # every rank's all-gather output equals the single-device image-plane arrays
+    for _, _, _, _, hits, _ in results:
+        assert np.array_equal(hits[0], fx) and np.array_equal(hits[1], fy)
+        assert np.array_equal(hits[2], fi)
+    # reduced spot statistics agree with the definition on the full set
+    m = fi > 0
+    cx, cy = fx[m].mean(), fy[m].mean()
+    rms = np.sqrt(np.mean((fx[m] - cx) ** 2 + (fy[m] - cy) ** 2))
+    geo = np.sqrt(np.max((fx[m] - cx) ** 2 + (fy[m] - cy) ** 2))
+    for _, _, _, _, _, spot in results:
+        assert spot["count"] == m.sum()
+        np.testing.assert_allclose(spot["centroid"], (cx, cy), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(spot["rms_radius"], rms, rtol=1e-6)
+        np.testing.assert_allclose(spot["geometric_radius"], geo, rtol=1e-10)
