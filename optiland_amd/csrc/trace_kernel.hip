@@ -17,9 +17,9 @@
 //   * ray state is carried in the LOCAL frame of the last surface and moved to
 //     the next frame with a host-precomputed relative transform; the global
 //     coordinates the reference records are formed only for the store;
-//   * the Newton-Raphson stop test is per ray (the reference's is a global max
-//     over the batch, newton_raphson.py:148), followed by one more update --
-//     see newton_distance().
+//   * the Newton-Raphson loop is re-based on the conic hit, stops per ray (the
+//     reference's test is a global max over the batch, newton_raphson.py:148)
+//     and hands its last gradient to the normal -- see newton_iterate().
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -311,35 +311,47 @@ __device__ __forceinline__ void nr_eval(const DevSurf<T>& s, const T* __restrict
 
 // newton_raphson.py:119-168.  f(t) = sag(x(t), y(t)) - z(t); with the unit
 // normal n = (fx, fy, -1)/|.| the reference's  -nx/nz, -ny/nz  are just (fx, fy),
-// so f'(t) = fx L + fy M - N (guards on nz and f' kept: |nz| > 1e-14 always holds
-// for finite gradients).  Per-ray stop rule: the reference stops the whole batch
-// when max |f| < tol; here a ray that sees |f| < tol takes ONE more Newton update
-// and leaves (quadratic convergence => its residual is far below the reference's),
-// NaN rays leave at once.  `floor` keeps fp32 from spinning when tol is below the
-// rounding noise of sag - z.
+// so f'(t) = fx L + fy M - N (guard on f' kept; |nz| > 1e-14 always holds for
+// finite gradients).  Differences from the reference, all deliberate:
+//  * re-based iteration: the ray is first moved to the conic/plane hit
+//    P_b = P + t0 D and Newton runs on the small correction dt, so that
+//    z_b + dt N does not cancel a metres-long path against itself (fp32 on
+//    a telescope: ulp(6265 mm) = 5e-4 mm >> tol = 1e-6 mm);
+//  * per-ray stop rule: the reference stops the whole batch when max |f| < tol
+//    (newton_raphson.py:148); here a ray that sees |f| < tol takes ONE more
+//    update and leaves (quadratic convergence => its residual is far below the
+//    reference's own), NaN rays leave at once, and a ray whose residual no longer
+//    halves (rounding floor reached -- fp32 with tol below the noise of sag - z)
+//    leaves too instead of spinning to max_iter;
+//  * the gradient of the LAST evaluation is returned and reused for the surface
+//    normal: the hit point moved by |f|/|f'| < tol since, which changes the
+//    normal by < curvature * tol.
+// Returns t = t0 + dt and leaves the hit point in (x, y, z).
 template <typename T>
-__device__ __forceinline__ T newton_distance(const DevSurf<T>& s, const T* __restrict__ c, T x,
-                                             T y, T z, T L, T M, T N, uint32_t& status) {
+struct NewtonRay {
+  T xb, yb, zb, dt, fprev, gx, gy;
+  bool active;
+};
+
+template <typename T>
+__device__ __forceinline__ void newton_iterate(const DevSurf<T>& s, const T* __restrict__ c,
+                                               NewtonRay<T>& q, T L, T M, T N, int it,
+                                               uint32_t& status) {
   using m = Math<T>;
-  T t = conic_distance(s, x, y, z, L, M, N);
-  bool active = true;
-  for (int it = 0; it < s.max_iter; ++it) {
-    if (!__any(active)) break;
-    if (active) {
-      T xi = m::fma(t, L, x), yi = m::fma(t, M, y), zi = m::fma(t, N, z);
-      T sag, fx, fy;
-      nr_eval(s, c, xi, yi, sag, fx, fy, status);
-      T f = sag - zi;
-      T floor = T(4) * m::eps() * (m::abs(sag) + m::abs(zi));
-      T thr = s.tol > floor ? s.tol : floor;
-      bool last = !(m::abs(f) >= thr);  // converged, or NaN
-      T df = m::fma(fx, L, m::fma(fy, M, -N));
-      T dfs = m::abs(df) > m::guard() ? df : m::guard();
-      t = t - m::div(f, dfs);
-      active = !last;
-    }
-  }
-  return t;
+  T xi = m::fma(q.dt, L, q.xb), yi = m::fma(q.dt, M, q.yb), zi = m::fma(q.dt, N, q.zb);
+  T sag, fx, fy;
+  nr_eval(s, c, xi, yi, sag, fx, fy, status);
+  T f = sag - zi;
+  T af = m::abs(f);
+  bool done = !(af >= s.tol);                       // converged, or NaN
+  done = done || (it > 0 && !(af < T(0.5) * q.fprev));  // residual stopped halving
+  T df = m::fma(fx, L, m::fma(fy, M, -N));
+  T dfs = m::abs(df) > m::guard() ? df : m::guard();
+  q.dt = q.dt - m::div(f, dfs);
+  q.fprev = af;
+  q.gx = fx;
+  q.gy = fy;
+  q.active = !done;
 }
 
 // --------------------------------------------------------------------------
@@ -432,14 +444,15 @@ __device__ __forceinline__ void prt_update(Prt<T>& P, T k0x, T k0y, T k0z, T k1x
 }
 
 // --------------------------------------------------------------------------
-// one surface for one ray: standard_surface.py:200-248 (minus record)
+// one surface for the RPT rays of a thread: standard_surface.py:200-248 (minus
+// record).  Phases run across the thread's rays so that independent chains
+// interleave (ILP) and the Newton loop can look at all of them together.
 // --------------------------------------------------------------------------
-template <typename T, bool POL>
-__device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptics<T>& o,
-                                             const T* __restrict__ coeffs, bool from_global,
-                                             Ray<T>& r, Prt<T>& P, uint32_t& status) {
+template <typename T>
+__device__ __forceinline__ void into_local_frame(const DevSurf<T>& s, bool from_global,
+                                                 Ray<T>& r) {
   using m = Math<T>;
-  // ---- into the local frame (coordinate_system.py:73-89)
+  // coordinate_system.py:73-89
   if (from_global) {
     T x = r.x - s.origin[0], y = r.y - s.origin[1], z = r.z - s.origin[2];
     if (s.flags & kSurfRotated) {
@@ -472,52 +485,37 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
       r.z += s.rel_off[2];
     }
   }
+}
 
-  // ---- distance to the surface
-  const T* c = coeffs + s.coeff_off;
-  T t;
-  if (s.geom == kGeomPlane) {
-    t = -m::div(r.z, r.N);  // plane.py:72-88
-  } else if (s.geom == kGeomStandard) {
-    t = conic_distance(s, r.x, r.y, r.z, r.L, r.M, r.N);
-  } else {
-    t = newton_distance(s, c, r.x, r.y, r.z, r.L, r.M, r.N, status);
-  }
-
-  // ---- propagate + absorb + opd (homogeneous.py:30-57, standard_surface.py:244)
-  r.x = m::fma(t, r.L, r.x);
-  r.y = m::fma(t, r.M, r.y);
-  r.z = m::fma(t, r.N, r.z);
+// everything after the hit point is known: absorb, opd, clip, refract/reflect,
+// coating, PRT.  (fx, fy) is the sag gradient at the hit (unused for planes).
+template <typename T, bool POL>
+__device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>& o, T t, T fx,
+                                         T fy, Ray<T>& r, Prt<T>& P) {
+  using m = Math<T>;
+  // homogeneous.py:44-53, standard_surface.py:244
   if (o.absorb > T(0)) r.i = r.i * m::exp(-o.absorb * t);
   r.opd = r.opd + m::abs(t * o.n1);
 
-  // ---- clip (physical_apertures/base.py:71-82, real_rays.py:154-161)
+  // clip (physical_apertures/base.py:71-82, real_rays.py:154-161)
   if (s.aperture_kind != kApNone) {
     if (!aperture_contains(s, r.x, r.y)) r.i = T(0);
   }
 
-  // ---- surface normal at the hit point
+  // surface normal at the hit point
   T nx, ny, nz;
   if (s.geom == kGeomPlane) {
     nx = T(0);
     ny = T(0);
     nz = T(1);  // plane.py:90-109
   } else {
-    T fx, fy;
-    if (s.geom == kGeomStandard) {
-      conic_gradient(s, r.x, r.y, fx, fy);
-    } else {
-      T sag;
-      uint32_t st = 0;  // range already flagged inside the Newton loop
-      nr_eval(s, c, r.x, r.y, sag, fx, fy, st);
-    }
     T im = m::rsqrt(m::fma(fx, fx, m::fma(fy, fy, T(1))));
     nx = fx * im;
     ny = fy * im;
     nz = -im;
   }
 
-  // ---- refract / reflect (real_rays.py:163-205, 535-571)
+  // refract / reflect (real_rays.py:163-205, 535-571)
   const T L0 = r.L, M0 = r.M, N0 = r.N;
   T dot = m::fma(L0, nx, m::fma(M0, ny, N0 * nz));
   const T sgn = dot > T(0) ? T(1) : (dot < T(0) ? T(-1) : (dot == T(0) ? T(0) : dot));
@@ -537,7 +535,7 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
     r.N = m::fma(u, N0, az * w);
   }
 
-  // ---- coating (interactions/base.py:111-128)
+  // coating (interactions/base.py:111-128)
   if (s.coating_kind == kCoatSimple) {
     r.i = r.i * (s.interaction == kReflect ? s.coat[1] : s.coat[0]);
   }
@@ -561,6 +559,83 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
     }
     prt_update(P, L0, M0, N0, r.L, r.M, r.N, nx, ny, nz, j0, j1, j2);
   }
+}
+
+template <typename T, int RPT, bool POL>
+__device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptics<T>& o,
+                                             const T* __restrict__ coeffs, bool from_global,
+                                             Ray<T> (&r)[RPT], Prt<T> (&P)[POL ? RPT : 1],
+                                             uint32_t& status) {
+  using m = Math<T>;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) into_local_frame(s, from_global, r[k]);
+
+  const T* c = coeffs + s.coeff_off;
+  T t[RPT], fx[RPT], fy[RPT];
+  if (s.geom == kGeomPlane) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      t[k] = -m::div(r[k].z, r[k].N);  // plane.py:72-88
+      fx[k] = fy[k] = T(0);
+      r[k].x = m::fma(t[k], r[k].L, r[k].x);
+      r[k].y = m::fma(t[k], r[k].M, r[k].y);
+      r[k].z = m::fma(t[k], r[k].N, r[k].z);
+    }
+  } else if (s.geom == kGeomStandard) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      t[k] = conic_distance(s, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M, r[k].N);
+      r[k].x = m::fma(t[k], r[k].L, r[k].x);
+      r[k].y = m::fma(t[k], r[k].M, r[k].y);
+      r[k].z = m::fma(t[k], r[k].N, r[k].z);
+      conic_gradient(s, r[k].x, r[k].y, fx[k], fy[k]);
+    }
+  } else {
+    NewtonRay<T> q[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      t[k] = conic_distance(s, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M, r[k].N);
+      q[k].xb = m::fma(t[k], r[k].L, r[k].x);
+      q[k].yb = m::fma(t[k], r[k].M, r[k].y);
+      q[k].zb = m::fma(t[k], r[k].N, r[k].z);
+      q[k].dt = T(0);
+      q[k].fprev = T(0);
+      q[k].gx = q[k].gy = T(0);
+      q[k].active = true;
+    }
+    int it = 0;
+    for (; it < s.max_iter; ++it) {
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        if (q[k].active) newton_iterate(s, c, q[k], r[k].L, r[k].M, r[k].N, it, status);
+        any = any || q[k].active;
+      }
+      if (!__any(any)) {
+        ++it;
+        break;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      r[k].x = m::fma(q[k].dt, r[k].L, q[k].xb);
+      r[k].y = m::fma(q[k].dt, r[k].M, q[k].yb);
+      r[k].z = m::fma(q[k].dt, r[k].N, q[k].zb);
+      t[k] = t[k] + q[k].dt;
+      fx[k] = q[k].gx;
+      fy[k] = q[k].gy;
+    }
+    if (it == 0) {  // max_iter == 0: no evaluation happened, take the gradient here
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        T sag;
+        uint32_t st = 0;
+        nr_eval(s, c, r[k].x, r[k].y, sag, fx[k], fy[k], st);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) interact<T, POL>(s, o, t[k], fx[k], fy[k], r[k], P[POL ? k : 0]);
 }
 
 // local -> global for the recorded state (coordinate_system.py:91-107)
@@ -706,8 +781,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
     const DevSurf<T>& S = surf_tab[s];
     if (S.interaction != kRecordOnly) {
       const DevOptics<T>& O = optics_tab[s * a.n_wl + a.wl];
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) surface_step<T, POL>(S, O, coeff_tab, is_global, r[k], P[POL ? k : 0], status);
+      surface_step<T, RPT, POL>(S, O, coeff_tab, is_global, r, P, status);
       is_global = false;
       last_traced = &S;
     }
