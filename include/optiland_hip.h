@@ -148,8 +148,8 @@ typedef struct ol_system ol_system; /* opaque */
 
 /* ---- trace flags --------------------------------------------------------- */
 #define OL_TRACE_WRITE_RAYS 0x1u   /* write the final ray state back into rays[] */
-#define OL_TRACE_COMPACT 0x2u      /* enable wavefront straggler compaction in
-                                      the Newton loop (default on via 0x2)    */
+#define OL_TRACE_COMPACT 0x2u      /* allow wavefront straggler compaction in the
+                                      Newton loop (only if OL_TUNE_COMPACT=1) */
 
 /* Polarisation state for the update_intensity epilogue
  * (rays/polarized_rays.py:122-133, rays/polarization_state.py:29-56).      */
@@ -227,6 +227,17 @@ int ol_spot_moments(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
 int ol_spot_max_r2(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
                    const void* intensity, double cx, double cy, double* out1,
                    void* stream);
+
+/* Profiling knobs (process-wide, not part of the trace semantics).
+ *   OL_TUNE_RAYS_PER_THREAD  0 = auto (16-byte vector of rays per lane for conic-only
+ *                            ranges, one ray per lane when Newton surfaces are
+ *                            present), 1 = one ray per lane, 2 = force the vector
+ *   OL_TUNE_COMPACT          1 = wavefront straggler compaction in the Newton loop
+ *                            (needs the vector layout; default 0, measured slower)
+ * The environment variable OL_TRACE_RPT seeds OL_TUNE_RAYS_PER_THREAD.           */
+#define OL_TUNE_RAYS_PER_THREAD 0
+#define OL_TUNE_COMPACT 1
+int ol_set_tuning(int32_t knob, int32_t value);
 
 const char* ol_last_error(void);
 int32_t ol_abi_version(void);

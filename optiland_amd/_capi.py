@@ -79,9 +79,11 @@ EXPORTS = (
     "ol_polarized_intensity",
     "ol_spot_moments",
     "ol_spot_max_r2",
+    "ol_set_tuning",
 )
 
 F32, F64 = 0, 1
+TUNE_RAYS_PER_THREAD, TUNE_COMPACT = 0, 1
 ABI_VERSION = 1
 
 
@@ -127,6 +129,8 @@ def load():
     lib.ol_spot_moments.argtypes = [C.c_int, i64, vp, vp, vp, vp, vp]
     lib.ol_spot_max_r2.restype = C.c_int
     lib.ol_spot_max_r2.argtypes = [C.c_int, i64, vp, vp, vp, C.c_double, C.c_double, vp, vp]
+    lib.ol_set_tuning.restype = C.c_int
+    lib.ol_set_tuning.argtypes = [i32, i32]
     if lib.ol_abi_version() != ABI_VERSION:
         raise HipExtensionError(
             f"{path}: ABI version {lib.ol_abi_version()} != expected {ABI_VERSION}; rebuild"

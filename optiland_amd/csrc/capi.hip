@@ -119,6 +119,7 @@ struct ol_system {
   DeviceTable<double> f64;
   std::vector<int32_t> interaction;  // host copy for validation
   std::vector<int32_t> coating;
+  std::vector<int32_t> geom;
 };
 
 namespace {
@@ -199,7 +200,10 @@ int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* c
   a.n_wl = sys->n_wl;
   a.wl = wl;
   a.flags = flags;
-  hipError_t e = ol::launch_trace<T>(a, vec, stream);
+  bool has_newton = false;  // any Newton-Raphson geometry in the traced range?
+  for (int32_t s = first; s <= last; ++s)
+    has_newton = has_newton || (sys->geom[s] != OL_GEOM_PLANE && sys->geom[s] != OL_GEOM_STANDARD);
+  hipError_t e = ol::launch_trace<T>(a, vec, has_newton, stream);
   if (e != hipSuccess) return fail(OL_EHIP, "trace launch failed: %s", hipGetErrorString(e));
   return OL_OK;
 }
@@ -210,6 +214,21 @@ extern "C" {
 
 const char* ol_last_error(void) { return g_err.c_str(); }
 int32_t ol_abi_version(void) { return OL_ABI_VERSION; }
+
+int ol_set_tuning(int32_t knob, int32_t value) {
+  switch (knob) {
+    case OL_TUNE_RAYS_PER_THREAD:
+      if (value < 0 || value > 2)
+        return fail(OL_EINVAL, "ol_set_tuning: rays per thread must be 0 (auto), 1 or 2 (vector)");
+      ol::tuning().rays_per_thread = value;
+      return OL_OK;
+    case OL_TUNE_COMPACT:
+      ol::tuning().compact = value ? 1 : 0;
+      return OL_OK;
+    default:
+      return fail(OL_EINVAL, "ol_set_tuning: unknown knob %d", knob);
+  }
+}
 
 int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* coeffs,
                      int32_t n_coeffs, const ol_surface_optics* optics, int32_t n_wavelengths,
@@ -338,6 +357,7 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
   for (int32_t i = 0; i < n_surf; ++i) {
     sys->interaction.push_back(surf[i].interaction);
     sys->coating.push_back(surf[i].coating_kind);
+    sys->geom.push_back(surf[i].geom_kind);
   }
   if (hipGetDevice(&sys->device) != hipSuccess) {
     delete sys;

@@ -354,6 +354,92 @@ __device__ __forceinline__ void newton_iterate(const DevSurf<T>& s, const T* __r
   q.active = !done;
 }
 
+// Wavefront straggler compaction (RPT > 1).  After the common iterations most
+// rays of the wave's 64 x RPT pool are done, but the slot-by-slot loop still pays
+// a full wave pass for every slot that holds ONE unfinished ray.  Here the
+// stragglers are densely re-packed onto lanes: ballots give per-slot masks,
+// v_mbcnt prefix counts give every unfinished ray a dense id, the executing lane
+// finds its source (slot, lane) as the rank-th set bit of that slot's mask and
+// pulls the ray's state with ds_bpermute (__shfl); ceil(total/64) passes iterate
+// the packed rays to completion and the results are shuffled back.  No LDS
+// allocation, no barriers; only used when every lane of the wave is alive.
+__device__ __forceinline__ int nth_set_bit(uint64_t mask, int rank) {
+  int pos = 0;
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    const uint64_t low = (w == 32) ? 0xffffffffull : ((1ull << w) - 1ull);
+    const int cnt = __popcll((mask >> pos) & low);
+    if (rank >= cnt) {
+      rank -= cnt;
+      pos += w;
+    }
+  }
+  return pos;
+}
+
+template <typename T, int RPT>
+__device__ __forceinline__ void newton_compacted(const DevSurf<T>& s, const T* __restrict__ c,
+                                                 NewtonRay<T> (&q)[RPT], const Ray<T> (&r)[RPT],
+                                                 const uint64_t (&ballots)[RPT], int total,
+                                                 int it_start, uint32_t& status) {
+  const int lane = (int)__lane_id();
+  int base[RPT], acc = 0;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    base[k] = acc;
+    acc += __popcll(ballots[k]);
+  }
+  const int passes = (total + 63) >> 6;
+  for (int p = 0; p < passes; ++p) {
+    const int id = p * 64 + lane;
+    const bool have = id < total;
+    int slot = 0, rank = 0;
+    uint64_t mask = ballots[0];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      if (id >= base[k]) {  // last slot whose base <= id
+        slot = k;
+        rank = id - base[k];
+        mask = ballots[k];
+      }
+    }
+    const int src = have ? nth_set_bit(mask, rank) : lane;
+    NewtonRay<T> g;
+    T L = T(0), M = T(0), N = T(1);
+    g.xb = g.yb = g.zb = g.dt = g.fprev = g.gx = g.gy = T(0);
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const T xb = __shfl(q[k].xb, src), yb = __shfl(q[k].yb, src), zb = __shfl(q[k].zb, src);
+      const T dt = __shfl(q[k].dt, src), fp = __shfl(q[k].fprev, src);
+      const T l = __shfl(r[k].L, src), mm = __shfl(r[k].M, src), n = __shfl(r[k].N, src);
+      if (slot == k) {
+        g.xb = xb; g.yb = yb; g.zb = zb; g.dt = dt; g.fprev = fp;
+        L = l; M = mm; N = n;
+      }
+    }
+    g.active = have;
+    for (int it = it_start; it < s.max_iter; ++it) {
+      if (!__any(g.active)) break;
+      if (g.active) newton_iterate(s, c, g, L, M, N, it, status);
+    }
+    // hand the results back to the owning (lane, slot)
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int myid = base[k] + (int)__builtin_amdgcn_mbcnt_hi(
+                                     (uint32_t)(ballots[k] >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)ballots[k], 0u));
+      const int from = myid & 63;
+      const T dt = __shfl(g.dt, from), gx = __shfl(g.gx, from), gy = __shfl(g.gy, from);
+      if (q[k].active && (myid >> 6) == p) {
+        q[k].dt = dt;
+        q[k].gx = gx;
+        q[k].gy = gy;
+        q[k].active = false;
+      }
+    }
+  }
+}
+
 // --------------------------------------------------------------------------
 // apertures: physical_apertures/{radial,offset_radial,rectangular,elliptical}.py
 // --------------------------------------------------------------------------
@@ -561,7 +647,10 @@ __device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>
   }
 }
 
-template <typename T, int RPT, bool POL>
+// NR: 0 = the surface range holds no Newton-Raphson geometry (lean kernel: none of
+// that code, or its registers, is compiled in), 1 = Newton loop, 2 = Newton loop
+// with wavefront straggler compaction.
+template <typename T, int RPT, bool POL, int NR>
 __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptics<T>& o,
                                              const T* __restrict__ coeffs, bool from_global,
                                              Ray<T> (&r)[RPT], Prt<T> (&P)[POL ? RPT : 1],
@@ -590,7 +679,8 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
       r[k].z = m::fma(t[k], r[k].N, r[k].z);
       conic_gradient(s, r[k].x, r[k].y, fx[k], fy[k]);
     }
-  } else {
+  } else if constexpr (NR != 0) {
+    constexpr bool COMPACT = NR == 2;
     NewtonRay<T> q[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -604,6 +694,7 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
       q[k].active = true;
     }
     int it = 0;
+    const bool can_compact = COMPACT && RPT > 1 && __popcll(__ballot(true)) == 64;
     for (; it < s.max_iter; ++it) {
       bool any = false;
 #pragma unroll
@@ -611,9 +702,29 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
         if (q[k].active) newton_iterate(s, c, q[k], r[k].L, r[k].M, r[k].N, it, status);
         any = any || q[k].active;
       }
-      if (!__any(any)) {
-        ++it;
-        break;
+      if constexpr (COMPACT && RPT > 1) {
+        uint64_t ballots[RPT];
+        int total = 0, nonempty = 0;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          ballots[k] = __ballot(q[k].active);
+          total += __popcll(ballots[k]);
+          nonempty += ballots[k] != 0;
+        }
+        if (total == 0) {
+          ++it;
+          break;
+        }
+        if (can_compact && ((total + 63) >> 6) < nonempty) {
+          newton_compacted<T, RPT>(s, c, q, r, ballots, total, it + 1, status);
+          ++it;
+          break;
+        }
+      } else {
+        if (!__any(any)) {
+          ++it;
+          break;
+        }
       }
     }
 #pragma unroll
@@ -633,6 +744,10 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
         nr_eval(s, c, r[k].x, r[k].y, sag, fx[k], fy[k], st);
       }
     }
+  } else {
+    // unreachable: the host only selects NR == 0 for ranges without such surfaces
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) t[k] = fx[k] = fy[k] = T(0);
   }
 #pragma unroll
   for (int k = 0; k < RPT; ++k) interact<T, POL>(s, o, t[k], fx[k], fy[k], r[k], P[POL ? k : 0]);
@@ -739,7 +854,7 @@ __device__ __forceinline__ void store_rays(T* __restrict__ row, int64_t stride, 
 // v_readfirstlane, and -- vmcnt being in-order on gfx9-family parts -- every
 // surface's table read then waited for ALL outstanding record stores to retire,
 // serialising compute behind HBM writes (measured: 1.00 ms -> see DESIGN.md).
-template <typename T, int RPT, bool RECORD, bool POL>
+template <typename T, int RPT, bool RECORD, bool POL, int NR>
 __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
     const DevSurf<T>* __restrict__ surf_tab, const DevOptics<T>* __restrict__ optics_tab,
     const T* __restrict__ coeff_tab, TraceArgs<T> a) {
@@ -781,7 +896,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
     const DevSurf<T>& S = surf_tab[s];
     if (S.interaction != kRecordOnly) {
       const DevOptics<T>& O = optics_tab[s * a.n_wl + a.wl];
-      surface_step<T, RPT, POL>(S, O, coeff_tab, is_global, r, P, status);
+      surface_step<T, RPT, POL, NR>(S, O, coeff_tab, is_global, r, P, status);
       is_global = false;
       last_traced = &S;
     }
@@ -831,48 +946,62 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
 // --------------------------------------------------------------------------
 // host-side launcher
 // --------------------------------------------------------------------------
-template <typename T, int RPT>
-static hipError_t launch_rpt(const TraceArgs<T>& a, hipStream_t stream) {
+template <typename T, int RPT, int NR>
+static hipError_t launch_nr(const TraceArgs<T>& a, hipStream_t stream) {
   const int64_t threads = (a.n + RPT - 1) / RPT;
   const int64_t blocks = (threads + kTraceBlock - 1) / kTraceBlock;
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)blocks), block(kTraceBlock);
   const bool rec = a.record != nullptr, pol = a.prt != nullptr;
-  if (rec && pol)
-    hipLaunchKernelGGL((trace_kernel<T, RPT, true, true>), grid, block, 0, stream, a.surf, a.optics,
-                       a.coeffs, a);
-  else if (rec)
-    hipLaunchKernelGGL((trace_kernel<T, RPT, true, false>), grid, block, 0, stream, a.surf, a.optics,
-                       a.coeffs, a);
-  else if (pol)
-    hipLaunchKernelGGL((trace_kernel<T, RPT, false, true>), grid, block, 0, stream, a.surf, a.optics,
-                       a.coeffs, a);
-  else
-    hipLaunchKernelGGL((trace_kernel<T, RPT, false, false>), grid, block, 0, stream, a.surf, a.optics,
-                       a.coeffs, a);
+#define OL_LAUNCH(R, P)                                                                      \
+  hipLaunchKernelGGL((trace_kernel<T, RPT, R, P, NR>), grid, block, 0, stream, a.surf,       \
+                     a.optics, a.coeffs, a)
+  if (rec && pol) OL_LAUNCH(true, true);
+  else if (rec) OL_LAUNCH(true, false);
+  else if (pol) OL_LAUNCH(false, true);
+  else OL_LAUNCH(false, false);
+#undef OL_LAUNCH
   return hipGetLastError();
 }
 
-template <typename T>
-hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, hipStream_t stream) {
-  constexpr int kVec = 16 / sizeof(T);  // rays per 16-byte lane vector
-  if (!vector_ok) return launch_rpt<T, 1>(a, stream);
-  // tuning hook (profiling only): OL_TRACE_RPT=1|2|4|8 overrides rays per thread
-  static const int forced = [] {
-    const char* e = getenv("OL_TRACE_RPT");
-    return e ? atoi(e) : 0;
-  }();
-  switch (forced) {
-    case 1: return launch_rpt<T, 1>(a, stream);
-    case 2: return launch_rpt<T, 2>(a, stream);
-    case 4: if (sizeof(T) == 4) return launch_rpt<T, 4>(a, stream); break;
-    default: break;
+template <typename T, int RPT>
+static hipError_t launch_rpt(const TraceArgs<T>& a, int nr, hipStream_t stream) {
+  if (nr == 0) return launch_nr<T, RPT, 0>(a, stream);
+  if constexpr (RPT > 1) {
+    if (nr == 2) return launch_nr<T, RPT, 2>(a, stream);
   }
-  return launch_rpt<T, kVec>(a, stream);
+  return launch_nr<T, RPT, 1>(a, stream);
 }
 
-template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, hipStream_t);
-template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, hipStream_t);
+Tuning& tuning() {
+  static Tuning t = [] {
+    Tuning v;
+    if (const char* e = getenv("OL_TRACE_RPT")) v.rays_per_thread = atoi(e);
+    return v;
+  }();
+  return t;
+}
+
+template <typename T>
+hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
+                        hipStream_t stream) {
+  constexpr int kVec = 16 / sizeof(T);  // rays per 16-byte lane vector
+  const int nr = !has_newton ? 0 : ((a.flags & kTraceCompact) && tuning().compact ? 2 : 1);
+  if (!vector_ok) return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
+  // Defaults from interleaved A/B runs on MI355X (tools/ab_bench.py, profiles/):
+  //  * conic-only ranges: one 16-byte vector of rays per lane (== 1 ray/lane within 1 %);
+  //  * ranges with Newton-Raphson surfaces: ONE ray per lane -- the iteration loop
+  //    then diverges per ray instead of per slot, registers drop (fp32: 118 -> 70)
+  //    and occupancy rises; 15-30 % faster on the asphere / Zernike configs;
+  //  * compaction only on request (measured slower on every surface tried: Newton
+  //    iteration counts are nearly uniform across a wave once the stop rule is per ray).
+  const int want = tuning().rays_per_thread;
+  if (want == 1 || (want == 0 && nr == 1)) return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
+  return launch_rpt<T, kVec>(a, nr, stream);
+}
+
+template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, bool, hipStream_t);
+template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, bool, hipStream_t);
 
 }  // namespace ol

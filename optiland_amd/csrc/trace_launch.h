@@ -28,7 +28,15 @@ struct TraceArgs {
 };
 
 template <typename T>
-hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, hipStream_t stream);
+hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
+                        hipStream_t stream);
+
+// process-wide tuning knobs (ol_set_tuning)
+struct Tuning {
+  int rays_per_thread = 0;  // 0 = default, 1 = one ray per lane, 2 = force vector
+  int compact = 0;          // measured slower; opt-in (OL_TUNE_COMPACT)
+};
+Tuning& tuning();
 
 // ray generation / epilogue / reductions (aux_kernels.hip)
 struct RaygenDev {
