@@ -1,0 +1,157 @@
+"""Full-size GPU checks (BASELINE.json sizes) through size-independent properties,
+plus the reductions and the C1 plumbing configuration at its real size."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests._util import PLANES, assert_close_planes, load_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def dg():
+    from optiland_amd import load_system
+    from optiland_amd.engine import HipSystem
+    table = load_system("double_gauss")
+    hip = HipSystem(table, DEV)
+    yield hip, table
+    hip.close()
+
+
+def _pupil(n, seed, dtype):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    r = torch.rand(n, generator=g, device=DEV, dtype=torch.float64).sqrt()
+    th = 2 * np.pi * torch.rand(n, generator=g, device=DEV, dtype=torch.float64)
+    return (r * th.cos()).to(dtype), (r * th.sin()).to(dtype)
+
+
+def _rays(hip, n, dtype, hy, seed=5, px=None, py=None):
+    if px is None:
+        px, py = _pupil(n, seed, dtype)
+    hx = torch.zeros(n, dtype=dtype, device=DEV)
+    hyt = torch.full((n,), hy, dtype=dtype, device=DEV)
+    planes = [p.contiguous().clone() for p in hip.generate_rays(hx, hyt, px, py)]
+    planes.append(torch.zeros(n, dtype=dtype, device=DEV))
+    return planes
+
+
+@pytest.mark.parametrize("dtype,n", [(torch.float32, 10_000_000), (torch.float64, 5_000_000)],
+                         ids=["f32-1e7", "f64-5e6"])
+def test_fullsize_properties(dg, dtype, n):
+    hip, table = dg
+    S = table.num_traced
+    rays = _rays(hip, n, dtype, 0.7)
+    res = hip.trace(rays, 0, record=True)
+    rec = res.record
+    # (1) record-last == last row of record-all, bit for bit
+    r2 = [t.clone() for t in rays]
+    hip.trace(r2, 0, record=False)
+    for k in range(8):
+        assert torch.equal(r2[k], res.row(S, k)), PLANES[k]
+    # (2) shard invariance: two half traces == one full trace, bit for bit
+    h = n // 2 + 3  # ragged on purpose (vector tail + unaligned second half)
+    for lo, hi in ((0, h), (h, n)):
+        part = [t[lo:hi].clone() for t in rays]
+        pr = hip.trace(part, 0, record=True)
+        for s in (1, S // 2, S):
+            for k in (0, 1, 5, 6, 7):
+                assert torch.equal(pr.row(s, k), res.row(s, k)[lo:hi]), (s, k)
+    # (3) physics invariants on every ray
+    L, M, N = (res.stack(k) for k in (3, 4, 5))
+    norm = L * L + M * M + N * N
+    tol = 1e-5 if dtype == torch.float32 else 1e-12
+    assert float((norm - 1).abs().max()) < tol          # Snell keeps |k| = 1
+    opd = res.stack(7)
+    assert bool((opd[1:] >= opd[:-1]).all())            # opd accumulates |t n|
+    inten = res.stack(6)
+    assert bool((inten[1:] <= inten[:-1] + 0).all())    # absorption only removes energy
+    assert not bool(torch.isnan(rec[:, :, :n]).any())
+    # (4) strided subsample against the CPU oracle (every 997th ray)
+    from oracle import oracle
+    idx = torch.arange(0, n, 997, device=DEV)
+    sub = {k: rays[j][idx].double().cpu().numpy() for j, k in enumerate(PLANES[:7])}
+    want = oracle.trace(table, sub, 0, record=True)["record"]
+    got = rec[:, :, :n][:, :, idx].double().cpu().numpy()
+    t = 1e-4 if dtype == torch.float32 else 1e-9
+    assert_close_planes(got, want, t, t, f"subsample {dtype}")
+
+
+def test_mirror_symmetry_is_exact(dg):
+    """On-axis field of a rotationally symmetric lens: (Px, Py) -> (-Px, Py) mirrors
+    x and L exactly (IEEE arithmetic is sign-symmetric; no op order depends on sign)."""
+    hip, table = dg
+    n = 1_000_000
+    for dtype in (torch.float32, torch.float64):
+        px, py = _pupil(n, 9, dtype)
+        a = hip.trace(_rays(hip, n, dtype, 0.0, px=px, py=py), 0, record=True)
+        b = hip.trace(_rays(hip, n, dtype, 0.0, px=-px, py=py), 0, record=True)
+        S = table.num_traced
+        assert torch.equal(a.row(S, 0), -b.row(S, 0))
+        assert torch.equal(a.row(S, 1), b.row(S, 1))
+        assert torch.equal(a.row(S, 3), -b.row(S, 3))
+        assert torch.equal(a.row(S, 7), b.row(S, 7))
+
+
+def test_config1_cooke_full_size_vs_oracle():
+    """C1: Cooke triplet, 3 fields x 64-ring hexapolar (37 443 rays), fp64 + fp32."""
+    from optiland_amd import load_system, tracer as tr
+    from optiland_amd.distribution import create_distribution
+    from oracle import oracle
+    table = load_system("cooke_generic")
+    d = create_distribution("hexapolar").generate_points(64)
+    assert d.x.size == 12481
+    for dtype, t in ((torch.float64, 1e-9), (torch.float32, 1e-4)):
+        trc = tr.HipRayTracer(table, DEV, dtype=dtype)
+        rays = trc.trace([0.0, 0.0, 0.0], [0.0, 0.7, 1.0], 0.55, 64, "hexapolar")
+        assert len(rays) == 37443 and trc.surfaces.x.shape == (8, 37443)
+        hx = np.zeros(37443)
+        hy = np.repeat([0.0, 0.7, 1.0], 12481)
+        rin = oracle.generate_rays(table.raygen, hx, hy, np.tile(d.x, 3), np.tile(d.y, 3))
+        want = oracle.trace(table, rin, 0, record=True)["record"]
+        got = torch.stack([getattr(trc.surfaces, k) for k in
+                           ("x", "y", "z", "L", "M", "N", "intensity", "opd")], 1)
+        assert_close_planes(got.double().cpu().numpy(), want, t, t, f"C1 {dtype}")
+        trc.engine.close()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_spot_reductions(dg, dtype):
+    hip, table = dg
+    n = 3_000_001
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(n, generator=g, device=DEV, dtype=torch.float64).to(dtype) * 0.01 + 17.2
+    y = torch.randn(n, generator=g, device=DEV, dtype=torch.float64).to(dtype) * 0.02 - 0.3
+    inten = (torch.rand(n, generator=g, device=DEV) > 0.1).to(dtype)
+    inten[::7] = 0
+    mom = hip.spot_moments(x, y, inten).cpu().numpy()
+    m = (inten > 0).cpu().numpy()
+    xd, yd = x.double().cpu().numpy()[m], y.double().cpu().numpy()[m]
+    want = np.array([m.sum(), xd.sum(), yd.sum(), (xd * xd).sum(), (yd * yd).sum(), m.sum()])
+    np.testing.assert_allclose(mom, want, rtol=1e-12)
+    cx, cy = xd.mean(), yd.mean()
+    r2 = float(hip.spot_max_r2(x, y, inten, cx, cy).item())
+    np.testing.assert_allclose(r2, np.max((xd - cx) ** 2 + (yd - cy) ** 2), rtol=1e-12)
+    # empty selection
+    z = torch.zeros(5, dtype=dtype, device=DEV)
+    assert float(hip.spot_moments(z, z, z).sum()) == 0.0
+
+
+def test_sharded_spot_statistics_single_rank(dg):
+    """distributed.spot_statistics with no process group == direct definition."""
+    from optiland_amd.distributed import spot_statistics
+    hip, table = dg
+    n = 1_000_000
+    res = hip.trace(_rays(hip, n, torch.float64, 0.7), 0, record=True)
+    S = table.num_traced
+    x, y, i = res.row(S, 0), res.row(S, 1), res.row(S, 6)
+    st = spot_statistics(hip, x, y, i)
+    xd, yd = x.cpu().numpy(), y.cpu().numpy()
+    cx, cy = xd.mean(), yd.mean()
+    np.testing.assert_allclose(st["centroid"], (cx, cy), rtol=1e-12)
+    np.testing.assert_allclose(st["rms_radius"], np.sqrt(np.mean((xd - cx) ** 2 + (yd - cy) ** 2)),
+                               rtol=1e-6)
+    np.testing.assert_allclose(st["geometric_radius"],
+                               np.sqrt(np.max((xd - cx) ** 2 + (yd - cy) ** 2)), rtol=1e-9)
