@@ -74,14 +74,28 @@ typedef enum ol_interaction {
  *   OFFSET_RADIAL  r_min, r_max, offset_x, offset_y    offset_radial.py:48-61
  *   RECTANGULAR    x_min, x_max, y_min, y_max          rectangular.py:42-59
  *   ELLIPTICAL     a, b, offset_x, offset_y            elliptical.py:42-56
+ *   COMPOSITE      boolean tree of the above (Union / Intersection / Difference,
+ *                  base.py:259-340) flattened to reverse-Polish tokens stored in
+ *                  coeffs[]: aperture[0] = first token's index in coeffs[],
+ *                  aperture[1] = token count; a token is 5 doubles
+ *                  {op, p0, p1, p2, p3}: op = a leaf kind above (p = its
+ *                  parameters) or OL_AP_OP_UNION / _INTERSECTION / _DIFFERENCE
+ *                  (pops b then a, pushes a|b, a&b, a&~b).
  */
 typedef enum ol_aperture_kind {
   OL_AP_NONE = 0,
   OL_AP_RADIAL = 1,
   OL_AP_OFFSET_RADIAL = 2,
   OL_AP_RECTANGULAR = 3,
-  OL_AP_ELLIPTICAL = 4
+  OL_AP_ELLIPTICAL = 4,
+  OL_AP_COMPOSITE = 5
 } ol_aperture_kind;
+
+#define OL_AP_OP_UNION 10
+#define OL_AP_OP_INTERSECTION 11
+#define OL_AP_OP_DIFFERENCE 12
+#define OL_AP_TOKEN_DOUBLES 5
+#define OL_AP_MAX_DEPTH 16
 
 /* ---- coatings (optiland/coatings.py) --------------------------------------
  *   SIMPLE   i *= T (refract) | R (reflect)            coatings.py:164-237

@@ -55,6 +55,31 @@ bool is_identity(const double* R) {
          std::equal(R, R + 9, I);  // -0.0 == 0.0
 }
 
+// device form of a leaf aperture: squared radii, inverse squared semi-axes
+void convert_aperture(int kind, const double* a, double* out) {
+  out[0] = out[1] = out[2] = out[3] = 0.0;
+  switch (kind) {
+    case OL_AP_RADIAL:
+    case OL_AP_OFFSET_RADIAL:
+      out[0] = a[0] * a[0];
+      out[1] = a[1] * a[1];
+      out[2] = a[2];
+      out[3] = a[3];
+      break;
+    case OL_AP_RECTANGULAR:
+      for (int k = 0; k < 4; ++k) out[k] = a[k];
+      break;
+    case OL_AP_ELLIPTICAL:
+      out[0] = 1.0 / (a[0] * a[0]);
+      out[1] = 1.0 / (a[1] * a[1]);
+      out[2] = a[2];
+      out[3] = a[3];
+      break;
+    default:
+      break;
+  }
+}
+
 double factorial(int n) {
   double f = 1.0;
   for (int i = 2; i <= n; ++i) f *= i;
@@ -136,7 +161,7 @@ int upload(const std::vector<ol::DevSurf<double>>& surf64,
     b.geom = a.geom; b.interaction = a.interaction; b.aperture_kind = a.aperture_kind;
     b.coating_kind = a.coating_kind; b.coeff_off = a.coeff_off; b.n_coeff = a.n_coeff;
     b.max_iter = a.max_iter; b.flags = a.flags; b.poly_cols = a.poly_cols;
-    b.coeff_len = a.coeff_len;
+    b.coeff_len = a.coeff_len; b.ap_off = a.ap_off; b.ap_len = a.ap_len;
     b.cv = (T)a.cv; b.kp1 = (T)a.kp1; b.tol = (T)a.tol; b.inv_norm = (T)a.inv_norm;
     for (int k = 0; k < 3; ++k) { b.origin[k] = (T)a.origin[k]; b.rel_off[k] = (T)a.rel_off[k]; }
     for (int k = 0; k < 9; ++k) { b.rot[k] = (T)a.rot[k]; b.rel_rot[k] = (T)a.rel_rot[k]; }
@@ -250,7 +275,7 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
       return fail(OL_EUNSUPPORTED, "surface %d: geometry kind %d", i, s.geom_kind);
     if (s.interaction < OL_INTERACT_RECORD_ONLY || s.interaction > OL_INTERACT_REFLECT)
       return fail(OL_EUNSUPPORTED, "surface %d: interaction %d", i, s.interaction);
-    if (s.aperture_kind < OL_AP_NONE || s.aperture_kind > OL_AP_ELLIPTICAL)
+    if (s.aperture_kind < OL_AP_NONE || s.aperture_kind > OL_AP_COMPOSITE)
       return fail(OL_EUNSUPPORTED, "surface %d: aperture kind %d", i, s.aperture_kind);
     if (s.coating_kind < OL_COAT_NONE || s.coating_kind > OL_COAT_FRESNEL)
       return fail(OL_EUNSUPPORTED, "surface %d: coating kind %d", i, s.coating_kind);
@@ -294,25 +319,33 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
       if (!is_identity(d.rel_rot)) d.flags |= ol::kSurfRelRotated;
     }
     // apertures: pre-square / pre-invert in double
-    switch (s.aperture_kind) {
-      case OL_AP_RADIAL:
-      case OL_AP_OFFSET_RADIAL:
-        d.ap[0] = s.aperture[0] * s.aperture[0];
-        d.ap[1] = s.aperture[1] * s.aperture[1];
-        d.ap[2] = s.aperture[2];
-        d.ap[3] = s.aperture[3];
-        break;
-      case OL_AP_RECTANGULAR:
-        for (int k = 0; k < 4; ++k) d.ap[k] = s.aperture[k];
-        break;
-      case OL_AP_ELLIPTICAL:
-        d.ap[0] = 1.0 / (s.aperture[0] * s.aperture[0]);
-        d.ap[1] = 1.0 / (s.aperture[1] * s.aperture[1]);
-        d.ap[2] = s.aperture[2];
-        d.ap[3] = s.aperture[3];
-        break;
-      default:
-        break;
+    if (s.aperture_kind == OL_AP_COMPOSITE) {
+      const int64_t off = (int64_t)s.aperture[0], cnt = (int64_t)s.aperture[1];
+      if (off < 0 || cnt <= 0 || off + cnt * OL_AP_TOKEN_DOUBLES > n_coeffs)
+        return fail(OL_EINVAL, "surface %d: aperture token list outside the buffer", i);
+      d.ap_off = (int32_t)dcoef.size();
+      d.ap_len = (int32_t)cnt;
+      int depth = 0;
+      for (int64_t t = 0; t < cnt; ++t) {
+        const double* tok = coeffs + off + t * OL_AP_TOKEN_DOUBLES;
+        const int op = (int)tok[0];
+        double q[4];
+        if (op >= OL_AP_RADIAL && op <= OL_AP_ELLIPTICAL) {
+          convert_aperture(op, tok + 1, q);
+          if (++depth > OL_AP_MAX_DEPTH)
+            return fail(OL_EUNSUPPORTED, "surface %d: aperture tree too deep", i);
+        } else if (op >= OL_AP_OP_UNION && op <= OL_AP_OP_DIFFERENCE) {
+          q[0] = q[1] = q[2] = q[3] = 0.0;
+          if (--depth < 1) return fail(OL_EINVAL, "surface %d: malformed aperture tokens", i);
+        } else {
+          return fail(OL_EUNSUPPORTED, "surface %d: aperture token op %d", i, op);
+        }
+        dcoef.push_back((double)op);
+        dcoef.insert(dcoef.end(), q, q + 4);
+      }
+      if (depth != 1) return fail(OL_EINVAL, "surface %d: malformed aperture tokens", i);
+    } else {
+      convert_aperture(s.aperture_kind, s.aperture, d.ap);
     }
     d.coat[0] = s.coat[0];
     d.coat[1] = s.coat[1];

@@ -24,7 +24,11 @@ enum : int {
   kGeomPolynomial = 5
 };
 enum : int { kRecordOnly = 0, kRefract = 1, kReflect = 2 };
-enum : int { kApNone = 0, kApRadial = 1, kApOffsetRadial = 2, kApRect = 3, kApElliptical = 4 };
+enum : int {
+  kApNone = 0, kApRadial = 1, kApOffsetRadial = 2, kApRect = 3, kApElliptical = 4,
+  kApComposite = 5, kApOpUnion = 10, kApOpIntersection = 11, kApOpDifference = 12
+};
+constexpr int kApTokenLen = 5;   // {op, p0..p3} per reverse-Polish token
 enum : int { kCoatNone = 0, kCoatSimple = 1, kCoatFresnel = 2 };
 
 constexpr uint32_t kSurfRotated = 0x1u;     // this surface's own frame is rotated
@@ -43,7 +47,8 @@ struct DevSurf {
   uint32_t flags;
   int32_t poly_cols;
   int32_t coeff_len;   // number of T elements of this surface's coefficient block
-  int32_t pad0, pad1;
+  int32_t ap_off;      // composite aperture: first token in the coefficient buffer
+  int32_t ap_len;      // composite aperture: number of tokens
   T cv;                // curvature 1/R (0 for |R| = inf)
   T kp1;               // 1 + conic
   T tol;

@@ -444,27 +444,49 @@ __device__ __forceinline__ void newton_compacted(const DevSurf<T>& s, const T* _
 // apertures: physical_apertures/{radial,offset_radial,rectangular,elliptical}.py
 // --------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ bool aperture_contains(const DevSurf<T>& s, T x, T y) {
+__device__ __forceinline__ bool leaf_contains(int kind, const T* __restrict__ ap, T x, T y) {
   using m = Math<T>;
-  switch (s.aperture_kind) {
+  switch (kind) {
     case kApRadial: {
       T r2 = m::fma(x, x, y * y);
-      return (r2 <= s.ap[1]) && (r2 >= s.ap[0]);
+      return (r2 <= ap[1]) && (r2 >= ap[0]);
     }
     case kApOffsetRadial: {
-      T dx = x - s.ap[2], dy = y - s.ap[3];
+      T dx = x - ap[2], dy = y - ap[3];
       T r2 = m::fma(dx, dx, dy * dy);
-      return (r2 <= s.ap[1]) && (r2 >= s.ap[0]);
+      return (r2 <= ap[1]) && (r2 >= ap[0]);
     }
     case kApRect:
-      return (s.ap[0] <= x) && (x <= s.ap[1]) && (s.ap[2] <= y) && (y <= s.ap[3]);
+      return (ap[0] <= x) && (x <= ap[1]) && (ap[2] <= y) && (y <= ap[3]);
     case kApElliptical: {
-      T dx = x - s.ap[2], dy = y - s.ap[3];
-      return m::fma(dx * dx, s.ap[0], dy * dy * s.ap[1]) <= T(1);
+      T dx = x - ap[2], dy = y - ap[3];
+      return m::fma(dx * dx, ap[0], dy * dy * ap[1]) <= T(1);
     }
     default:
       return true;
   }
+}
+
+// Boolean trees (physical_apertures/base.py:259-340) arrive as reverse-Polish
+// tokens; the evaluation stack is one bit per entry in a 32-bit register
+// (depth <= 16 checked on the host).  Token stream and op codes are wave-uniform.
+template <typename T>
+__device__ __forceinline__ bool aperture_contains(const DevSurf<T>& s,
+                                                  const T* __restrict__ coeffs, T x, T y) {
+  if (s.aperture_kind != kApComposite) return leaf_contains<T>(s.aperture_kind, s.ap, x, y);
+  const T* tok = coeffs + s.ap_off;
+  uint32_t stack = 0;  // bit 0 = top of stack
+  for (int i = 0; i < s.ap_len; ++i, tok += kApTokenLen) {
+    const int op = (int)tok[0];
+    if (op < kApOpUnion) {
+      stack = (stack << 1) | (leaf_contains<T>(op, tok + 1, x, y) ? 1u : 0u);
+    } else {
+      const uint32_t b = stack & 1u, a = (stack >> 1) & 1u;
+      const uint32_t v = op == kApOpUnion ? (a | b) : (op == kApOpIntersection ? (a & b) : (a & ~b & 1u));
+      stack = ((stack >> 2) << 1) | v;
+    }
+  }
+  return (stack & 1u) != 0;
 }
 
 // --------------------------------------------------------------------------
@@ -576,8 +598,9 @@ __device__ __forceinline__ void into_local_frame(const DevSurf<T>& s, bool from_
 // everything after the hit point is known: absorb, opd, clip, refract/reflect,
 // coating, PRT.  (fx, fy) is the sag gradient at the hit (unused for planes).
 template <typename T, bool POL>
-__device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>& o, T t, T fx,
-                                         T fy, Ray<T>& r, Prt<T>& P) {
+__device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>& o,
+                                         const T* __restrict__ coeffs, T t, T fx, T fy,
+                                         Ray<T>& r, Prt<T>& P) {
   using m = Math<T>;
   // homogeneous.py:44-53, standard_surface.py:244
   if (o.absorb > T(0)) r.i = r.i * m::exp(-o.absorb * t);
@@ -585,7 +608,7 @@ __device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>
 
   // clip (physical_apertures/base.py:71-82, real_rays.py:154-161)
   if (s.aperture_kind != kApNone) {
-    if (!aperture_contains(s, r.x, r.y)) r.i = T(0);
+    if (!aperture_contains(s, coeffs, r.x, r.y)) r.i = T(0);
   }
 
   // surface normal at the hit point
@@ -750,7 +773,8 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
     for (int k = 0; k < RPT; ++k) t[k] = fx[k] = fy[k] = T(0);
   }
 #pragma unroll
-  for (int k = 0; k < RPT; ++k) interact<T, POL>(s, o, t[k], fx[k], fy[k], r[k], P[POL ? k : 0]);
+  for (int k = 0; k < RPT; ++k)
+    interact<T, POL>(s, o, coeffs, t[k], fx[k], fy[k], r[k], P[POL ? k : 0]);
 }
 
 // local -> global for the recorded state (coordinate_system.py:91-107)

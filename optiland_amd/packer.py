@@ -134,25 +134,56 @@ def _to_np(v):
     return np.asarray(v)
 
 
-def _pack_aperture(ap, row):
+def _leaf_token(ap):
+    name = type(ap).__name__
+    if name == "RadialAperture":
+        return [S.AP_RADIAL, _f(ap.r_min), _f(ap.r_max), 0.0, 0.0]
+    if name == "OffsetRadialAperture":
+        return [S.AP_OFFSET_RADIAL, _f(ap.r_min), _f(ap.r_max), _f(ap.offset_x), _f(ap.offset_y)]
+    if name == "RectangularAperture":
+        return [S.AP_RECTANGULAR, _f(ap.x_min), _f(ap.x_max), _f(ap.y_min), _f(ap.y_max)]
+    if name == "EllipticalAperture":
+        return [S.AP_ELLIPTICAL, _f(ap.a), _f(ap.b), _f(ap.offset_x), _f(ap.offset_y)]
+    return None
+
+
+_BOOL_OPS = {"UnionAperture": S.AP_OP_UNION, "IntersectionAperture": S.AP_OP_INTERSECTION,
+             "DifferenceAperture": S.AP_OP_DIFFERENCE}
+
+
+def _flatten_aperture(ap, out: list, depth=1):
+    """Boolean aperture tree (physical_apertures/base.py:259-340) -> reverse-Polish
+    tokens.  Returns the stack depth needed."""
+    leaf = _leaf_token(ap)
+    if leaf is not None:
+        out.append(leaf)
+        return 1
+    name = type(ap).__name__
+    if name in _BOOL_OPS:
+        da = _flatten_aperture(ap.a, out)
+        db = _flatten_aperture(ap.b, out)
+        out.append([_BOOL_OPS[name], 0.0, 0.0, 0.0, 0.0])
+        return max(da, 1 + db)
+    raise UnsupportedSystem(f"aperture {name} is not on the fused path")
+
+
+def _pack_aperture(ap, row, coeffs: list):
     row["aperture_kind"] = S.AP_NONE
     if ap is None:
         return
-    name = type(ap).__name__
-    if name == "RadialAperture":
-        row["aperture_kind"] = S.AP_RADIAL
-        row["aperture"] = [_f(ap.r_min), _f(ap.r_max), 0.0, 0.0]
-    elif name == "OffsetRadialAperture":
-        row["aperture_kind"] = S.AP_OFFSET_RADIAL
-        row["aperture"] = [_f(ap.r_min), _f(ap.r_max), _f(ap.offset_x), _f(ap.offset_y)]
-    elif name == "RectangularAperture":
-        row["aperture_kind"] = S.AP_RECTANGULAR
-        row["aperture"] = [_f(ap.x_min), _f(ap.x_max), _f(ap.y_min), _f(ap.y_max)]
-    elif name == "EllipticalAperture":
-        row["aperture_kind"] = S.AP_ELLIPTICAL
-        row["aperture"] = [_f(ap.a), _f(ap.b), _f(ap.offset_x), _f(ap.offset_y)]
-    else:
-        raise UnsupportedSystem(f"aperture {name} is not on the fused path")
+    leaf = _leaf_token(ap)
+    if leaf is not None:
+        row["aperture_kind"] = int(leaf[0])
+        row["aperture"] = leaf[1:]
+        return
+    tokens: list = []
+    depth = _flatten_aperture(ap, tokens)
+    if depth > 16:
+        raise UnsupportedSystem("boolean aperture nesting deeper than 16")
+    row["aperture_kind"] = S.AP_COMPOSITE
+    row["aperture"] = [float(len(coeffs)), float(len(tokens)), 0.0, 0.0]
+    for t in tokens:
+        coeffs.extend(float(v) for v in t)
 
 
 def _pack_coating(coating, row):
@@ -210,7 +241,7 @@ def pack_optic(optic, wavelengths=None, name: str | None = None) -> SystemTable:
         if getattr(im, "bsdf", None) is not None:
             raise UnsupportedSystem("BSDF scatter is not on the fused path")
         _pack_geometry(geom, row, coeffs)
-        _pack_aperture(surf.aperture, row)
+        _pack_aperture(surf.aperture, row, coeffs)
         _pack_coating(surf.coating, row)
         if i == 0:
             # ObjectSurface.trace only records (surfaces/object_surface.py:56-93)

@@ -25,6 +25,8 @@ GEOM_PLANE, GEOM_STANDARD, GEOM_EVEN_ASPHERE, GEOM_ZERNIKE = 0, 1, 2, 3
 GEOM_ODD_ASPHERE, GEOM_POLYNOMIAL = 4, 5
 INTERACT_RECORD_ONLY, INTERACT_REFRACT, INTERACT_REFLECT = 0, 1, 2
 AP_NONE, AP_RADIAL, AP_OFFSET_RADIAL, AP_RECTANGULAR, AP_ELLIPTICAL = 0, 1, 2, 3, 4
+AP_COMPOSITE = 5
+AP_OP_UNION, AP_OP_INTERSECTION, AP_OP_DIFFERENCE = 10, 11, 12
 COAT_NONE, COAT_SIMPLE, COAT_FRESNEL = 0, 1, 2
 SURF_ROTATED = 0x1
 

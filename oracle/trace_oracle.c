@@ -330,9 +330,8 @@ static void hit_normal(const ol_surface_desc* s, const double* coeffs, double x,
 }
 
 /* ---- physical_apertures/ contains() ------------------------------------ */
-static int aperture_contains(const ol_surface_desc* s, double x, double y) {
-  const double* a = s->aperture;
-  switch (s->aperture_kind) {
+static int leaf_contains(int kind, const double* a, double x, double y) {
+  switch (kind) {
     case OL_AP_RADIAL: { /* radial.py:56-70 */
       double r2 = x * x + y * y;
       return (r2 <= a[1] * a[1]) && (r2 >= a[0] * a[0]);
@@ -350,6 +349,28 @@ static int aperture_contains(const ol_surface_desc* s, double x, double y) {
     default:
       return 1;
   }
+}
+
+/* base.py:259-340: Union / Intersection / Difference, evaluated from the
+ * reverse-Polish token list the packer emits.                                */
+static int aperture_contains(const ol_surface_desc* s, const double* coeffs, double x,
+                             double y) {
+  if (s->aperture_kind != OL_AP_COMPOSITE)
+    return leaf_contains(s->aperture_kind, s->aperture, x, y);
+  const double* tok = coeffs + (int)s->aperture[0];
+  int n_tok = (int)s->aperture[1];
+  int stack[OL_AP_MAX_DEPTH], sp = 0;
+  for (int i = 0; i < n_tok; ++i, tok += OL_AP_TOKEN_DOUBLES) {
+    int op = (int)tok[0];
+    if (op < OL_AP_OP_UNION) {
+      stack[sp++] = leaf_contains(op, tok + 1, x, y);
+    } else {
+      int b = stack[--sp], a = stack[--sp];
+      stack[sp++] = op == OL_AP_OP_UNION ? (a || b)
+                    : op == OL_AP_OP_INTERSECTION ? (a && b) : (a && !b);
+    }
+  }
+  return sp > 0 ? stack[sp - 1] : 1;
 }
 
 /* ---- rays/polarized_rays.py:136-202 (get_local_basis + update) ------------- */
@@ -426,7 +447,7 @@ static void trace_surface(const ol_surface_desc* s, const double* coeffs,
   /* clip: physical_apertures/base.py:71-82, real_rays.py:154-161 */
   if (s->aperture_kind != OL_AP_NONE)
     for (int64_t j = 0; j < n; ++j)
-      if (!aperture_contains(s, r->x[j], r->y[j])) r->i[j] = 0.0;
+      if (!aperture_contains(s, coeffs, r->x[j], r->y[j])) r->i[j] = 0.0;
 
   /* interactions/refractive_reflective_model.py:32-55 */
   int all_rho_zero = 1;

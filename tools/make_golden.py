@@ -138,6 +138,33 @@ def nr_family():
     return lens
 
 
+def boolean_apertures():
+    """Edge case: nested Union / Intersection / Difference apertures
+    (physical_apertures/base.py:259-340) on two surfaces."""
+    pa = physical_apertures
+    lens = optic_mod.Optic(name="BooleanApertures")
+    d_shape = pa.IntersectionAperture(pa.RadialAperture(r_max=7.0),
+                                      pa.RectangularAperture(-5.0, 5.5, -8.0, 8.0))
+    spider = pa.UnionAperture(pa.RectangularAperture(-0.4, 0.4, -9.0, 9.0),
+                              pa.OffsetRadialAperture(r_max=1.5, r_min=0.0, offset_x=1.0,
+                                                      offset_y=-0.5))
+    ap1 = pa.DifferenceAperture(d_shape, spider)
+    ap2 = pa.UnionAperture(pa.EllipticalAperture(a=3.0, b=2.0, offset_x=-1.0),
+                           pa.DifferenceAperture(pa.RadialAperture(r_max=6.0, r_min=0.0),
+                                                 pa.RadialAperture(r_max=4.5, r_min=0.0)))
+    lens.surfaces.add(index=0, radius=be.inf, thickness=be.inf)
+    lens.surfaces.add(index=1, radius=60.0, thickness=5.0, material="N-BK7", is_stop=True,
+                      aperture=ap1)
+    lens.surfaces.add(index=2, radius=-80.0, thickness=40.0, aperture=ap2)
+    lens.surfaces.add(index=3)
+    lens.set_aperture(aperture_type="EPD", value=16)
+    lens.fields.set_type(field_type="angle")
+    lens.fields.add(y=0)
+    lens.fields.add(y=3)
+    lens.wavelengths.add(value=0.55, is_primary=True)
+    return lens
+
+
 def tir_prism():
     """Edge case: steep glass->air exit so part of the bundle is totally internally
     reflected (NaN directions, real_rays.py:179-180) and part misses a small
@@ -282,6 +309,7 @@ def main():
     run_case("tilted_fold", tilted_fold(), 0.0, 1.0, px, py, 0.6328)
     run_case("nr_family", nr_family(), 0.0, 1.0, px * 0.9, py * 0.9, 0.5876)
     run_case("tir_miss", tir_prism(), 0.0, 1.0, px, py, 0.55)
+    run_case("boolean_apertures", boolean_apertures(), 0.0, 0.5, px, py, 0.55)
 
 
 if __name__ == "__main__":
