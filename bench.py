@@ -57,6 +57,8 @@ def parse_args():
                     help="record: all surfaces (drop-in semantics); last: image plane only")
     ap.add_argument("--exchange", choices=("reduce", "gather", "none"), default="reduce",
                     help="image-plane exchange when --gpus > 1")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the image-plane exchange even with one rank (RCCL path check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -67,7 +69,7 @@ def init_dist(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -158,9 +160,10 @@ def main():
         prt = torch.empty_like(prt0)
     scratch = [torch.empty_like(t) for t in rays] if args.mode == "last" else None
 
-    exchange = args.exchange if world > 1 else "none"
+    import torch.distributed as dist
+    have_pg = dist.is_available() and dist.is_initialized()
+    exchange = args.exchange if (world > 1 or (args.force_exchange and have_pg)) else "none"
     if exchange != "none":
-        import torch.distributed as dist
         gather_buf = None
         if exchange == "gather":
             gather_buf = torch.empty((world, 3, n), dtype=dtype, device=device)
@@ -201,18 +204,18 @@ def main():
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
            for _ in range(args.steps)]
     torch.cuda.synchronize(device)
-    if world > 1:
+    if have_pg:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(*evs[k])
     torch.cuda.synchronize(device)
-    if world > 1:
+    if have_pg:
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if have_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -275,7 +278,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     hip.close()
-    if world > 1:
+    if have_pg:
         dist.destroy_process_group()
 
 
