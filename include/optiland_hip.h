@@ -47,6 +47,14 @@ typedef enum ol_dtype { OL_F32 = 0, OL_F64 = 1 } ol_dtype;
  * ZERNIKE       optiland/geometries/zernike.py:153-266
  * ODD_ASPHERE   optiland/geometries/odd_asphere.py:86-143
  * POLYNOMIAL    optiland/geometries/polynomial.py:105-155 (x^i y^j freeform)
+ * CHEBYSHEV     optiland/geometries/chebyshev.py:126-241; coefficient block =
+ *               {norm_x, norm_y, c[0][0], c[0][1], ...}: n_coeff = rows*cols,
+ *               poly_cols = cols
+ * BICONIC       optiland/geometries/biconic.py:69-158; radius/conic = Rx/kx,
+ *               coefficient block = {Ry, ky} (n_coeff = 2)
+ * TOROIDAL      optiland/geometries/toroidal.py:86-242; radius = YZ radius (base
+ *               conic of the Newton start, conic = 0), coefficient block =
+ *               {R_rot, k_yz, a_1, a_2, ...} (n_coeff = 2 + number of y^2i terms)
  */
 typedef enum ol_geom_kind {
   OL_GEOM_PLANE = 0,
@@ -54,7 +62,10 @@ typedef enum ol_geom_kind {
   OL_GEOM_EVEN_ASPHERE = 2,
   OL_GEOM_ZERNIKE = 3,
   OL_GEOM_ODD_ASPHERE = 4,
-  OL_GEOM_POLYNOMIAL = 5
+  OL_GEOM_POLYNOMIAL = 5,
+  OL_GEOM_CHEBYSHEV = 6,
+  OL_GEOM_BICONIC = 7,
+  OL_GEOM_TOROIDAL = 8
 } ol_geom_kind;
 
 /* ---- what happens at the surface ----------------------------------------
@@ -159,6 +170,8 @@ typedef struct ol_system ol_system; /* opaque */
                                         (geometries/zernike.py:254-266)       */
 #define OL_STATUS_K_PARALLEL_X 0x2u  /* initial k parallel to x-hat
                                         (rays/polarized_rays.py:221-222)      */
+#define OL_STATUS_CHEBYSHEV_RANGE 0x4u /* |x/norm_x|>1 or |y/norm_y|>1
+                                        (geometries/chebyshev.py:227-240)     */
 
 /* ---- trace flags --------------------------------------------------------- */
 #define OL_TRACE_WRITE_RAYS 0x1u   /* write the final ray state back into rays[] */

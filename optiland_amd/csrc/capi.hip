@@ -271,7 +271,7 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
     const ol_surface_desc& s = surf[i];
     ol::DevSurf<double>& d = dev[i];
     std::memset(&d, 0, sizeof(d));
-    if (s.geom_kind < OL_GEOM_PLANE || s.geom_kind > OL_GEOM_POLYNOMIAL)
+    if (s.geom_kind < OL_GEOM_PLANE || s.geom_kind > OL_GEOM_TOROIDAL)
       return fail(OL_EUNSUPPORTED, "surface %d: geometry kind %d", i, s.geom_kind);
     if (s.interaction < OL_INTERACT_RECORD_ONLY || s.interaction > OL_INTERACT_REFLECT)
       return fail(OL_EUNSUPPORTED, "surface %d: interaction %d", i, s.interaction);
@@ -282,7 +282,8 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
     if (s.n_coeff < 0 || s.coeff_offset < 0)
       return fail(OL_EINVAL, "surface %d: negative coefficient range", i);
     const int per = s.geom_kind == OL_GEOM_ZERNIKE ? 4 : 1;
-    if ((int64_t)s.coeff_offset + (int64_t)s.n_coeff * per > n_coeffs)
+    const int extra = s.geom_kind == OL_GEOM_CHEBYSHEV ? 2 : 0;
+    if ((int64_t)s.coeff_offset + (int64_t)s.n_coeff * per + extra > n_coeffs)
       return fail(OL_EINVAL, "surface %d: coefficient block exceeds the buffer", i);
 
     d.geom = s.geom_kind;
@@ -366,6 +367,31 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
                     s.poly_cols);
       d.n_coeff = s.n_coeff;
       dcoef.insert(dcoef.end(), src, src + s.n_coeff);
+    } else if (s.geom_kind == OL_GEOM_CHEBYSHEV) {
+      if (s.poly_cols <= 0 || s.n_coeff % s.poly_cols != 0)
+        return fail(OL_EINVAL, "surface %d: chebyshev grid %d, cols %d", i, s.n_coeff,
+                    s.poly_cols);
+      d.n_coeff = s.n_coeff;
+      dcoef.push_back(1.0 / src[0]);
+      dcoef.push_back(1.0 / src[1]);
+      dcoef.insert(dcoef.end(), src + 2, src + 2 + s.n_coeff);
+    } else if (s.geom_kind == OL_GEOM_BICONIC) {
+      // biconic.py:57-66: cx/cy = 0 for infinite or zero radii
+      if (s.n_coeff != 2) return fail(OL_EINVAL, "surface %d: biconic needs {Ry, ky}", i);
+      const double Rx = s.radius, Ry = src[0];
+      d.cv = (std::isinf(Rx) || Rx == 0.0) ? 0.0 : 1.0 / Rx;
+      d.n_coeff = 2;
+      dcoef.push_back((std::isinf(Ry) || Ry == 0.0) ? 0.0 : 1.0 / Ry);
+      dcoef.push_back(1.0 + src[1]);
+    } else if (s.geom_kind == OL_GEOM_TOROIDAL) {
+      if (s.n_coeff < 2) return fail(OL_EINVAL, "surface %d: toroidal needs {R_rot, k_yz}", i);
+      const double Rr = src[0], Ryz = s.radius;
+      d.n_coeff = s.n_coeff - 2;  // number of y^(2i) terms
+      dcoef.push_back(Rr);
+      dcoef.push_back(std::isinf(Rr) ? 0.0 : 1.0 / Rr);
+      dcoef.push_back(1.0 + src[1]);
+      dcoef.push_back((std::isfinite(Ryz) && Ryz != 0.0) ? 1.0 / Ryz : 0.0);
+      dcoef.insert(dcoef.end(), src + 2, src + s.n_coeff);
     } else {
       d.n_coeff = 0;
     }

@@ -21,7 +21,10 @@ enum : int {
   kGeomEvenAsphere = 2,
   kGeomZernike = 3,
   kGeomOddAsphere = 4,
-  kGeomPolynomial = 5
+  kGeomPolynomial = 5,
+  kGeomChebyshev = 6,  // block: {1/norm_x, 1/norm_y, c[i][j]...}
+  kGeomBiconic = 7,    // block: {cy, 1 + ky}; cv/kp1 hold cx, 1 + kx
+  kGeomToroidal = 8    // block: {R_rot (or inf), 1/R_rot, 1 + k_yz, c_yz, a_1, a_2, ...}
 };
 enum : int { kRecordOnly = 0, kRefract = 1, kReflect = 2 };
 enum : int {

@@ -298,6 +298,127 @@ __device__ __forceinline__ void zernike_eval(const DevSurf<T>& s, const T* __res
   fy += gy;
 }
 
+// chebyshev.py:126-225.  T_n by the three-term recurrence instead of
+// cos(n acos x); T_n'(x) = n U_{n-1}(x) instead of n sin(n acos x)/sqrt(1-x^2)
+// (identical for |x| < 1; at |x| == 1 the reference divides by zero).  As in the
+// reference the derivative is taken w.r.t. the NORMALISED coordinate and is not
+// divided by norm_x / norm_y (chebyshev.py:176-186).
+template <typename T>
+__device__ __forceinline__ void chebyshev_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
+                                               T y, T& sag, T& fx, T& fy, uint32_t& status) {
+  using m = Math<T>;
+  T r2 = m::fma(x, x, y * y);
+  T g = m::sqrt(m::fma(-s.kp1 * s.cv * s.cv, r2, T(1)));
+  sag = m::div(s.cv * r2, T(1) + g);
+  T f = m::div(s.cv, g);
+  fx = x * f;
+  fy = y * f;
+  const T xn = x * c[0], yn = y * c[1];
+  if (m::abs(xn) > T(1) || m::abs(yn) > T(1)) status |= 0x4u;  // OL_STATUS_CHEBYSHEV_RANGE
+  const int cols = s.poly_cols;
+  const int rows = cols > 0 ? s.n_coeff / cols : 0;
+  const T* grid = c + 2;
+  // Ti, Ui1 = T_i(xn), U_{i-1}(xn)
+  T Ti = T(1), Tim = T(0), Ui1 = T(0), Ui2 = T(0);
+  T S = T(0), Sx = T(0), Sy = T(0);
+  for (int i = 0; i < rows; ++i) {
+    // row polynomial in y: sum_j c_ij T_j(yn) and sum_j c_ij j U_{j-1}(yn)
+    T Tj = T(1), Tjm = T(0), Uj1 = T(0), Uj2 = T(0);
+    T q = T(0), dq = T(0);
+    for (int j = 0; j < cols; ++j) {
+      const T cij = grid[i * cols + j];
+      q = m::fma(cij, Tj, q);
+      dq = m::fma(cij * T(j), Uj1, dq);
+      // advance: T_{j+1} = 2 y T_j - T_{j-1};  U_j = 2 y U_{j-1} - U_{j-2}
+      const T Tn = j == 0 ? yn : m::fma(T(2) * yn, Tj, -Tjm);
+      const T Un = j == 0 ? T(1) : m::fma(T(2) * yn, Uj1, -Uj2);
+      Tjm = Tj; Tj = Tn; Uj2 = Uj1; Uj1 = Un;
+    }
+    S = m::fma(Ti, q, S);
+    Sx = m::fma(T(i) * Ui1, q, Sx);
+    Sy = m::fma(Ti, dq, Sy);
+    const T Tn = i == 0 ? xn : m::fma(T(2) * xn, Ti, -Tim);
+    const T Un = i == 0 ? T(1) : m::fma(T(2) * xn, Ui1, -Ui2);
+    Tim = Ti; Ti = Tn; Ui2 = Ui1; Ui1 = Un;
+  }
+  sag += S;
+  fx += Sx;
+  fy += Sy;
+}
+
+// biconic.py:69-158: z = zx(x) + zy(y), each a conic profile; clamps kept.
+template <typename T>
+__device__ __forceinline__ void biconic_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
+                                             T y, T& sag, T& fx, T& fy) {
+  using m = Math<T>;
+  const T cx = s.cv, kx1 = s.kp1, cy = c[0], ky1 = c[1];
+  const T lim = m::guard();
+  T zx = T(0), zy = T(0);
+  fx = T(0);
+  fy = T(0);
+  if (cx != T(0)) {
+    T v = m::fma(-kx1 * cx * cx, x * x, T(1));
+    T st0 = v < lim ? T(0) : v;   // sag: clamp to 0
+    T st1 = v < lim ? lim : v;    // gradient: clamp to 1e-14
+    zx = m::div(cx * x * x, T(1) + m::sqrt(st0));
+    fx = m::div(cx * x, m::sqrt(st1));
+  }
+  if (cy != T(0)) {
+    T v = m::fma(-ky1 * cy * cy, y * y, T(1));
+    T st0 = v < lim ? T(0) : v;
+    T st1 = v < lim ? lim : v;
+    zy = m::div(cy * y * y, T(1) + m::sqrt(st0));
+    fy = m::div(cy * y, m::sqrt(st1));
+  }
+  sag = zx + zy;
+}
+
+// toroidal.py:86-242: Y-Z profile z_y(y) (conic + even polynomial) rotated about an
+// axis parallel to Y at distance R_rot.  Invalid domain ((R - z_y)^2 < x^2): sag is
+// NaN and the reference's normal is (0, 0, -1), i.e. zero gradient.
+template <typename T>
+__device__ __forceinline__ void toroidal_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
+                                              T y, T& sag, T& fx, T& fy) {
+  using m = Math<T>;
+  const T R = c[0], invR = c[1], k1 = c[2], cyz = c[3];
+  const T* a = c + 4;
+  const T y2 = y * y;
+  const T lim = m::guard();
+  T zy = T(0), dzy = T(0);
+  if (cyz != T(0)) {
+    T v = m::fma(-k1 * cyz * cyz, y2, T(1));
+    T r0 = v < T(0) ? T(0) : v;
+    T r1 = v < lim ? lim : v;
+    zy = m::div(cyz * y2, T(1) + m::sqrt(r0));
+    dzy = m::div(cyz * y, m::sqrt(r1));
+  }
+  T p = T(0), dp = T(0);  // sum a_i y2^(i+1), sum 2(i+1) a_i y^(2i+1)
+  for (int i = s.n_coeff - 1; i >= 0; --i) {
+    dp = m::fma(dp, y2, T(2 * (i + 1)) * a[i]);
+    p = m::fma(p, y2, a[i]);
+  }
+  zy = m::fma(p, y2, zy);
+  dzy = m::fma(dp, y, dzy);
+  if (invR == T(0)) {  // cylinder extruded along x
+    sag = zy;
+    fx = T(0);
+    fy = dzy;
+    return;
+  }
+  const T d = R - zy;
+  const T term = m::fma(d, d, -x * x);
+  const bool valid = term >= T(0);
+  const T sq = m::sqrt(valid ? term : lim);
+  const T ssq = m::abs(sq) < lim ? lim : sq;
+  const T sgd = d > T(0) ? T(1) : (d < T(0) ? T(-1) : T(0));
+  const T sgR = R > T(0) ? T(1) : T(-1);
+  // z_y + (d - sign(d) sqrt(term)) = R - sign(d) sqrt(term)
+  sag = valid ? zy + (d - sgd * sq) : (term < T(0) ? T(__builtin_nanf("")) : term);
+  const T isq = m::rcp(ssq);
+  fx = valid ? sgR * x * isq : T(0);
+  fy = valid ? sgR * d * dzy * isq : T(0);
+}
+
 template <typename T>
 __device__ __forceinline__ void nr_eval(const DevSurf<T>& s, const T* __restrict__ c, T x, T y,
                                         T& sag, T& fx, T& fy, uint32_t& status) {
@@ -305,6 +426,9 @@ __device__ __forceinline__ void nr_eval(const DevSurf<T>& s, const T* __restrict
     case kGeomEvenAsphere: even_asphere_eval(s, c, x, y, sag, fx, fy); break;
     case kGeomOddAsphere: odd_asphere_eval(s, c, x, y, sag, fx, fy); break;
     case kGeomPolynomial: polynomial_eval(s, c, x, y, sag, fx, fy); break;
+    case kGeomChebyshev: chebyshev_eval(s, c, x, y, sag, fx, fy, status); break;
+    case kGeomBiconic: biconic_eval(s, c, x, y, sag, fx, fy); break;
+    case kGeomToroidal: toroidal_eval(s, c, x, y, sag, fx, fy); break;
     default: zernike_eval(s, c, x, y, sag, fx, fy, status); break;
   }
 }

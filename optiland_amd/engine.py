@@ -157,6 +157,13 @@ class HipSystem:
                 "to [-1, 1]. Consider updating the normalization "
                 "radius to 1.1x the surface aperture."
             )
+        if status & S.STATUS_CHEBYSHEV_RANGE:
+            # same text as optiland/geometries/chebyshev.py:235-240
+            raise ValueError(
+                "Chebyshev input coordinates must be normalized "
+                "to [-1, 1]. Consider updating the normalization "
+                "factors."
+            )
         return TraceResult(n, rays, rec, prt, status, first, last)
 
     # ------------------------------------------------------------- ray source

@@ -110,6 +110,37 @@ def _pack_geometry(geom, row, coeffs: list):
         row["poly_cols"] = c.shape[1]
         coeffs.extend(c.reshape(-1).tolist())
         return
+    if name == "ChebyshevPolynomialGeometry":
+        row["geom_kind"] = S.GEOM_CHEBYSHEV
+        row["radius"] = _f(geom.radius)
+        row["conic"] = _f(geom.k)
+        row["tol"] = float(geom.tol)
+        row["max_iter"] = int(geom.max_iter)
+        c = np.atleast_2d(np.asarray(_to_np(geom.coefficients), dtype=np.float64))
+        row["n_coeff"] = c.size
+        row["poly_cols"] = c.shape[1]
+        coeffs.extend([_f(geom.norm_x), _f(geom.norm_y)])
+        coeffs.extend(c.reshape(-1).tolist())
+        return
+    if name == "BiconicGeometry":
+        row["geom_kind"] = S.GEOM_BICONIC
+        row["radius"] = _f(geom.Rx)
+        row["conic"] = _f(geom.kx)
+        row["tol"] = float(geom.tol)
+        row["max_iter"] = int(geom.max_iter)
+        row["n_coeff"] = 2
+        coeffs.extend([_f(geom.Ry), _f(geom.ky)])
+        return
+    if name == "ToroidalGeometry":
+        row["geom_kind"] = S.GEOM_TOROIDAL
+        row["radius"] = _f(geom.R_yz)
+        row["conic"] = 0.0  # base conic handed to NewtonRaphsonGeometry (toroidal.py:67-69)
+        row["tol"] = float(geom.tol)
+        row["max_iter"] = int(geom.max_iter)
+        poly = [float(v) for v in np.asarray(_to_np(geom.coeffs_poly_y), dtype=np.float64)]
+        row["n_coeff"] = 2 + len(poly)
+        coeffs.extend([_f(geom.R_rot), _f(geom.k_yz)] + poly)
+        return
     if name == "ZernikePolynomialGeometry":
         row["geom_kind"] = S.GEOM_ZERNIKE
         row["radius"] = _f(geom.radius)

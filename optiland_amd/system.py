@@ -23,6 +23,7 @@ import numpy as np
 # ---- enums (mirror include/optiland_hip.h) ---------------------------------
 GEOM_PLANE, GEOM_STANDARD, GEOM_EVEN_ASPHERE, GEOM_ZERNIKE = 0, 1, 2, 3
 GEOM_ODD_ASPHERE, GEOM_POLYNOMIAL = 4, 5
+GEOM_CHEBYSHEV, GEOM_BICONIC, GEOM_TOROIDAL = 6, 7, 8
 INTERACT_RECORD_ONLY, INTERACT_REFRACT, INTERACT_REFLECT = 0, 1, 2
 AP_NONE, AP_RADIAL, AP_OFFSET_RADIAL, AP_RECTANGULAR, AP_ELLIPTICAL = 0, 1, 2, 3, 4
 AP_COMPOSITE = 5
@@ -32,6 +33,7 @@ SURF_ROTATED = 0x1
 
 STATUS_ZERNIKE_RANGE = 0x1
 STATUS_K_PARALLEL_X = 0x2
+STATUS_CHEBYSHEV_RANGE = 0x4
 
 TRACE_WRITE_RAYS = 0x1
 TRACE_COMPACT = 0x2
@@ -43,6 +45,9 @@ GEOM_NAMES = {
     GEOM_ZERNIKE: "zernike",
     GEOM_ODD_ASPHERE: "odd_asphere",
     GEOM_POLYNOMIAL: "polynomial",
+    GEOM_CHEBYSHEV: "chebyshev",
+    GEOM_BICONIC: "biconic",
+    GEOM_TOROIDAL: "toroidal",
 }
 
 # numpy image of `ol_surface_desc`; align=True reproduces the C layout.

@@ -123,6 +123,52 @@ static double zern_radial_deriv(int n, int m, double r) { /* m >= 0 here */
   return value;
 }
 
+/* ---- toroidal.py:86-160: Y-Z profile and its derivative -------------------- */
+static double tor_zy(const ol_surface_desc* s, const double* c, double y) {
+  double y2 = y * y, z_y = 0.0;
+  double R_yz = s->radius, k = c[1];
+  if (isfinite(R_yz) && R_yz != 0.0) {
+    double cv = 1.0 / R_yz;
+    double root_val = 1.0 - (1.0 + k) * cv * cv * y2;
+    double root = root_val < 0 ? 0.0 : root_val;
+    double denom = 1.0 + sqrt(root);
+    double safe = fabs(denom) < 1e-14 ? 1e-14 : denom;
+    z_y = (cv * y2) / safe;
+  }
+  if (s->n_coeff > 2) {
+    double poly = 0.0, pw = y2;
+    for (int i = 2; i < s->n_coeff; ++i) { poly = poly + c[i] * pw; pw = pw * y2; }
+    z_y = z_y + poly;
+  }
+  return z_y;
+}
+
+static double tor_dzy(const ol_surface_desc* s, const double* c, double y) {
+  double y2 = y * y, d = 0.0;
+  double R_yz = s->radius, k = c[1];
+  if (isfinite(R_yz) && R_yz != 0.0) {
+    double cv = 1.0 / R_yz;
+    double root_val = 1.0 - (1.0 + k) * cv * cv * y2;
+    double root = root_val < 1e-14 ? 1e-14 : root_val;
+    double sq = sqrt(root);
+    double safe = fabs(sq) < 1e-14 ? 1e-14 : sq;
+    d = (cv * y) / safe;
+  }
+  if (s->n_coeff > 2) {
+    double poly = 0.0, pw = y;
+    for (int i = 2; i < s->n_coeff; ++i) {
+      poly = poly + c[i] * (2.0 * ((i - 2) + 1.0)) * pw;
+      pw = pw * y2;
+    }
+    d = d + poly;
+  }
+  return d;
+}
+
+/* chebyshev.py:197-225 */
+static double cheb_T(int n, double x) { return cos(n * acos(x)); }
+static double cheb_dT(int n, double x) { return n * sin(n * acos(x)) / sqrt(1 - x * x); }
+
 /* ---- sag(x, y) per geometry -------------------------------------------------
  * even_asphere.py:93-109, odd_asphere.py:86-104, polynomial.py:105-126,
  * zernike.py:153-180 (+ zernike/base.py:42-98 get_term/poly)                 */
@@ -147,6 +193,48 @@ static double geom_sag(const ol_surface_desc* s, const double* coeffs, double x,
           z = z + c[i * cols + j] * pow(x, (double)i) * pow(y, (double)j);
       return z;
     }
+    case OL_GEOM_CHEBYSHEV: { /* chebyshev.py:126-152 */
+      double xn = x / c[0], yn = y / c[1];
+      if (fabs(xn) > 1.0 || fabs(yn) > 1.0) *status |= OL_STATUS_CHEBYSHEV_RANGE;
+      int cols = s->poly_cols, rows = cols ? s->n_coeff / cols : 0;
+      for (int i = 0; i < rows; ++i)
+        for (int j = 0; j < cols; ++j) {
+          double cij = c[2 + i * cols + j];
+          if (cij != 0.0) z = z + cij * cheb_T(i, xn) * cheb_T(j, yn);
+        }
+      return z;
+    }
+    case OL_GEOM_BICONIC: { /* biconic.py:69-103 (radius/conic = Rx/kx, c = {Ry, ky}) */
+      double Rx = s->radius, kx = s->conic, Ry = c[0], ky = c[1];
+      double cx = (isinf(Rx) || Rx == 0) ? 0.0 : 1.0 / Rx;
+      double cy = (isinf(Ry) || Ry == 0) ? 0.0 : 1.0 / Ry;
+      double zx = 0.0, zy = 0.0;
+      if (cx != 0.0) {
+        double v = 1.0 - (1.0 + kx) * cx * cx * x * x;
+        double st = v < 1e-14 ? 0.0 : v;
+        double den = 1.0 + sqrt(st);
+        double sd = fabs(den) < 1e-14 ? 1e-14 : den;
+        zx = (cx * x * x) / sd;
+      }
+      if (cy != 0.0) {
+        double v = 1.0 - (1.0 + ky) * cy * cy * y * y;
+        double st = v < 1e-14 ? 0.0 : v;
+        double den = 1.0 + sqrt(st);
+        double sd = fabs(den) < 1e-14 ? 1e-14 : den;
+        zy = (cy * y * y) / sd;
+      }
+      return zx + zy;
+    }
+    case OL_GEOM_TOROIDAL: { /* toroidal.py:162-190 */
+      double R = c[0];
+      double z_y = tor_zy(s, c, y);
+      if (isinf(R)) return z_y;
+      double term = (R - z_y) * (R - z_y) - x * x;
+      if (term < 0) return NAN;
+      double d = R - z_y;
+      double sg = (d > 0) - (d < 0);
+      return z_y + (d - sg * sqrt(term));
+    }
     case OL_GEOM_ZERNIKE: {
       double xn = x / s->norm_radius, yn = y / s->norm_radius;
       if (fabs(xn) > 1.0 || fabs(yn) > 1.0) *status |= OL_STATUS_ZERNIKE_RANGE;
@@ -170,11 +258,60 @@ static double geom_sag(const ol_surface_desc* s, const double* coeffs, double x,
 /* ---- _surface_normal(x, y) per Newton-Raphson geometry ----------------------
  * even_asphere.py:111-140, odd_asphere.py:106-143, polynomial.py:128-155,
  * zernike.py:182-252                                                          */
+static uint32_t g_normal_status; /* chebyshev validates inside _surface_normal too */
+
 static void geom_normal_nr(const ol_surface_desc* s, const double* coeffs, double x,
                            double y, int all_rho_zero, double* nx, double* ny,
                            double* nz) {
   const double* c = coeffs + s->coeff_offset;
   const double R = s->radius, k = s->conic;
+  if (s->geom_kind == OL_GEOM_BICONIC) { /* biconic.py:105-158 */
+    double Rx = s->radius, kx = s->conic, Ry = c[0], ky = c[1];
+    double cx = (isinf(Rx) || Rx == 0) ? 0.0 : 1.0 / Rx;
+    double cy = (isinf(Ry) || Ry == 0) ? 0.0 : 1.0 / Ry;
+    double dfdx = 0.0, dfdy = 0.0;
+    if (cx != 0.0) {
+      double v = 1.0 - (1.0 + kx) * cx * cx * x * x;
+      double st = v < 1e-14 ? 1e-14 : v;
+      double sq = sqrt(st);
+      double sd = fabs(sq) < 1e-14 ? 1e-14 : sq;
+      dfdx = (cx * x) / sd;
+    }
+    if (cy != 0.0) {
+      double v = 1.0 - (1.0 + ky) * cy * cy * y * y;
+      double st = v < 1e-14 ? 1e-14 : v;
+      double sq = sqrt(st);
+      double sd = fabs(sq) < 1e-14 ? 1e-14 : sq;
+      dfdy = (cy * y) / sd;
+    }
+    double mag = sqrt(dfdx * dfdx + dfdy * dfdy + 1.0);
+    double sm = mag < 1e-14 ? 1.0 : mag;
+    *nx = dfdx / sm; *ny = dfdy / sm; *nz = -1.0 / sm;
+    return;
+  }
+  if (s->geom_kind == OL_GEOM_TOROIDAL) { /* toroidal.py:192-242 */
+    const double eps = 1e-14;
+    double Rr = c[0];
+    double z_y = tor_zy(s, c, y), dz_dy = tor_dzy(s, c, y);
+    double fx, fy, term;
+    if (isinf(Rr)) {
+      fx = 0.0; fy = dz_dy; term = INFINITY;
+    } else {
+      term = (Rr - z_y) * (Rr - z_y) - x * x;
+      int valid = term >= 0;
+      double safe_term = valid ? term : eps;
+      double sq = sqrt(safe_term);
+      double ssq = fabs(sq) < eps ? eps : sq;
+      double sg = (Rr > 0) - (Rr < 0);
+      fx = valid ? sg * x / ssq : 0.0;
+      fy = valid ? sg * (Rr - z_y) * dz_dy / ssq : 0.0;
+    }
+    double mag = sqrt(fx * fx + fy * fy + 1.0);
+    double sm = mag < eps ? 1.0 : mag;
+    if (term >= 0) { *nx = fx / sm; *ny = fy / sm; *nz = -1.0 / sm; }
+    else { *nx = 0.0; *ny = 0.0; *nz = -1.0; }
+    return;
+  }
   double r2 = x * x + y * y;
   double denom = R * sqrt(1.0 - (1.0 + k) * r2 / (R * R));
   double dfdx = x / denom, dfdy = y / denom;
@@ -206,6 +343,19 @@ static void geom_normal_nr(const ol_surface_desc* s, const double* coeffs, doubl
       for (int i = 0; i < rows; ++i)
         for (int j = 1; j < cols; ++j)
           dfdy = dfdy + j * c[i * cols + j] * pow(x, (double)i) * pow(y, (double)(j - 1));
+      break;
+    }
+    case OL_GEOM_CHEBYSHEV: { /* chebyshev.py:154-195: no 1/norm on the derivative */
+      double xn = x / c[0], yn = y / c[1];
+      if (fabs(xn) > 1.0 || fabs(yn) > 1.0) g_normal_status |= OL_STATUS_CHEBYSHEV_RANGE;
+      int cols = s->poly_cols, rows = cols ? s->n_coeff / cols : 0;
+      for (int i = 0; i < rows; ++i)
+        for (int j = 0; j < cols; ++j) {
+          double cij = c[2 + i * cols + j];
+          if (cij == 0.0) continue;
+          dfdx = dfdx + (cheb_dT(i, xn) * cij * cheb_T(j, yn));
+          dfdy = dfdy + (cheb_dT(j, yn) * cij * cheb_T(i, xn));
+        }
       break;
     }
     case OL_GEOM_ZERNIKE: {
@@ -521,6 +671,7 @@ uint32_t oracle_trace(const ol_surface_desc* surf, int32_t n_surf,
                       int32_t first, int32_t last) {
   (void)n_surf;
   uint32_t status = 0;
+  g_normal_status = 0;
   rays_t r;
   r.n = n;
   r.x = rays[PX]; r.y = rays[PY]; r.z = rays[PZ];
@@ -545,7 +696,7 @@ uint32_t oracle_trace(const ol_surface_desc* surf, int32_t n_surf,
     memcpy(pre_dir + 2 * n, r.N0, sizeof(double) * (size_t)n);
   }
   free(scratch);
-  return status;
+  return status | g_normal_status;
 }
 
 /* rays/ray_generator.py:47-99 + rays/ray_aiming/paraxial.py:33-106 +

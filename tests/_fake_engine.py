@@ -47,6 +47,11 @@ class OracleEngine:
                 "Zernike coordinates must be normalized "
                 "to [-1, 1]. Consider updating the normalization "
                 "radius to 1.1x the surface aperture.")
+        if out["status"] & S.STATUS_CHEBYSHEV_RANGE:
+            raise ValueError(
+                "Chebyshev input coordinates must be normalized "
+                "to [-1, 1]. Consider updating the normalization "
+                "factors.")
         rec = None
         if out["record"] is not None:
             rec = torch.as_tensor(out["record"], dtype=dtype)

@@ -165,6 +165,30 @@ def boolean_apertures():
     return lens
 
 
+def f3_family():
+    """f3 geometries: biconic, toroidal (with y^2i terms) and Chebyshev."""
+    lens = optic_mod.Optic(name="F3Family")
+    lens.surfaces.add(index=0, radius=be.inf, thickness=be.inf)
+    lens.surfaces.add(index=1, surface_type="biconic", radius_x=40.0, radius_y=55.0,
+                      conic_x=-0.5, conic_y=0.2, thickness=4.0, material="N-BK7", is_stop=True)
+    lens.surfaces.add(index=2, surface_type="toroidal", radius_x=-70.0, radius_y=-45.0,
+                      conic=0.3, toroidal_coeffs_poly_y=[1e-5, -2e-8], thickness=6.0)
+    lens.surfaces.add(index=3, surface_type="chebyshev", radius=80.0, conic=-0.2,
+                      coefficients=[[0.0, 1e-3, -2e-3], [5e-4, 2e-3, 0.0], [-1e-3, 0.0, 4e-4]],
+                      norm_x=12.0, norm_y=12.0, thickness=3.0, material="N-SF11")
+    lens.surfaces.add(index=4, surface_type="biconic", radius_x=be.inf, radius_y=-30.0,
+                      thickness=25.0)
+    lens.surfaces.add(index=5, surface_type="toroidal", radius_x=be.inf, radius_y=60.0,
+                      thickness=0.0)
+    lens.surfaces.add(index=6)
+    lens.set_aperture(aperture_type="EPD", value=12)
+    lens.fields.set_type(field_type="angle")
+    lens.fields.add(y=0)
+    lens.fields.add(y=4)
+    lens.wavelengths.add(value=0.5876, is_primary=True)
+    return lens
+
+
 def tir_prism():
     """Edge case: steep glass->air exit so part of the bundle is totally internally
     reflected (NaN directions, real_rays.py:179-180) and part misses a small
@@ -310,6 +334,7 @@ def main():
     run_case("nr_family", nr_family(), 0.0, 1.0, px * 0.9, py * 0.9, 0.5876)
     run_case("tir_miss", tir_prism(), 0.0, 1.0, px, py, 0.55)
     run_case("boolean_apertures", boolean_apertures(), 0.0, 0.5, px, py, 0.55)
+    run_case("f3_family", f3_family(), 0.0, 1.0, px, py, 0.5876)
 
 
 if __name__ == "__main__":
