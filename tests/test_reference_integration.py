@@ -155,7 +155,7 @@ def test_unsupported_system_falls_back_to_reference(hip_on_cpu):
     from optiland.samples.objectives import CookeTriplet
     from optiland_amd.integration import install
     lens = CookeTriplet()
-    lens.surfaces[3].geometry.__class__ = type("BiconicGeometry", (lens.surfaces[3].geometry.__class__,), {})
+    lens.surfaces[3].geometry.__class__ = type("ForbesQbfsGeometry", (lens.surfaces[3].geometry.__class__,), {})
     tracer = install(lens, force=True)
     r = lens.trace(0.0, 0.0, 0.55, 4, "hexapolar")
     assert tracer.last_path == "reference"
