@@ -37,11 +37,12 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 WORKLOADS = {
-    # name: (system json, Hy, description)
-    "double_gauss": ("double_gauss", 0.7, "DoubleGauss"),
-    "cooke": ("cooke_generic", 1.0, "CookeTriplet"),
-    "rc_asphere": ("rc_asphere", 1.0, "RC + even-asphere corrector (Newton-Raphson)"),
-    "zernike_fresnel": ("zernike_fresnel_fringe", 1.0, "Zernike freeform + Fresnel/polarized"),
+    # name: (system json, Hy, description, wavelength in um)
+    "double_gauss": ("double_gauss", 0.7, "DoubleGauss", 0.5876),
+    "cooke": ("cooke_generic", 1.0, "CookeTriplet", 0.55),
+    "rc_asphere": ("rc_asphere", 1.0, "RC + even-asphere corrector (Newton-Raphson)", 0.55),
+    "zernike_fresnel": ("zernike_fresnel_fringe", 1.0, "Zernike freeform + Fresnel/polarized",
+                        0.55),
 }
 
 
@@ -97,7 +98,7 @@ def make_rays(hip, n, dtype, hy, seed, device):
     return rays
 
 
-def cpu_baseline(table, hy, mode, budget_s):
+def cpu_baseline(table, hy, mode, budget_s, wl=0):
     """Time the CPU oracle (C port, 1 thread) on a bounded sample, same mode."""
     from oracle import oracle
     n = 1_000_000
@@ -108,11 +109,11 @@ def cpu_baseline(table, hy, mode, budget_s):
     pol = table.uses_polarization
     S = table.num_traced
     reps, t_total = 0, 0.0
-    oracle.trace(table, {k: v[:1000] for k, v in rays.items()}, 0, record=(mode == "record"),
+    oracle.trace(table, {k: v[:1000] for k, v in rays.items()}, wl, record=(mode == "record"),
                  polarized=pol)  # warm (build + page in)
     while t_total < budget_s and reps < 64:
         t0 = time.perf_counter()
-        oracle.trace(table, rays, 0, record=(mode == "record"), polarized=pol)
+        oracle.trace(table, rays, wl, record=(mode == "record"), polarized=pol)
         t_total += time.perf_counter() - t0
         reps += 1
     return {
@@ -143,8 +144,9 @@ def main():
     from optiland_amd import load_system
     from optiland_amd.engine import HipSystem
 
-    sys_name, hy, desc = WORKLOADS[args.workload]
+    sys_name, hy, desc, wavelength = WORKLOADS[args.workload]
     table = load_system(sys_name)
+    wl = table.wavelength_index(wavelength)
     hip = HipSystem(table, device)
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     b = 4 if args.dtype == "f32" else 8
@@ -180,7 +182,7 @@ def main():
             src = scratch
         if ev0 is not None:
             ev0.record()
-        res = hip.trace(src, 0, record=record if record is not None else False, prt=prt,
+        res = hip.trace(src, wl, record=record if record is not None else False, prt=prt,
                         check_status=False)
         if ev1 is not None:
             ev1.record()
@@ -251,7 +253,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{desc} ({S} traced surfaces incl. image plane), "
-                            f"{n:.3g} rays/GPU {args.dtype}, uniform-disc pupil, Hy={hy}, "
+                            f"{n:.3g} rays/GPU {args.dtype}, lambda={wavelength} um, "
+                            f"uniform-disc pupil, Hy={hy}, "
                             f"mode={'record-all' if args.mode == 'record' else 'record-last'}",
                 "rays_per_gpu": n,
                 "surfaces": S,
@@ -273,7 +276,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(table, hy, args.mode, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(table, hy, args.mode, args.cpu_seconds, wl)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -110,7 +110,7 @@ def test_config1_cooke_full_size_vs_oracle():
         hx = np.zeros(37443)
         hy = np.repeat([0.0, 0.7, 1.0], 12481)
         rin = oracle.generate_rays(table.raygen, hx, hy, np.tile(d.x, 3), np.tile(d.y, 3))
-        want = oracle.trace(table, rin, 0, record=True)["record"]
+        want = oracle.trace(table, rin, table.wavelength_index(0.55), record=True)["record"]
         got = torch.stack([getattr(trc.surfaces, k) for k in
                            ("x", "y", "z", "L", "M", "N", "intensity", "opd")], 1)
         assert_close_planes(got.double().cpu().numpy(), want, t, t, f"C1 {dtype}")
@@ -155,3 +155,18 @@ def test_sharded_spot_statistics_single_rank(dg):
                                rtol=1e-6)
     np.testing.assert_allclose(st["geometric_radius"],
                                np.sqrt(np.max((xd - cx) ** 2 + (yd - cy) ** 2)), rtol=1e-9)
+
+
+def test_spot_diagram_goldens_on_device():
+    """Reference goldens tests/test_analysis.py:76-102 through the HIP path + the
+    device reductions, fp64 (1e-5, the reference's own tolerance) and fp32."""
+    from optiland_amd import load_system, tracer as tr
+    from optiland_amd.analysis import SpotDiagram
+    from tests.test_host_tracer import COOKE_GEO, COOKE_RMS
+    table = load_system("cooke_generic")
+    for dtype, tol in ((torch.float64, 1e-5), (torch.float32, 2e-3)):
+        t = tr.HipRayTracer(table, DEV, dtype=dtype)
+        spot = SpotDiagram(t)
+        np.testing.assert_allclose(spot.rms_spot_radius(), COOKE_RMS, rtol=tol)
+        np.testing.assert_allclose(spot.geometric_spot_radius(), COOKE_GEO, rtol=tol)
+        t.engine.close()

@@ -119,3 +119,25 @@ def test_distributions_match_reference_counts_and_order():
     assert create_distribution("ring").generate_points(7).x.size == 7
     r = create_distribution("random").generate_points(1000)
     assert np.all(r.x**2 + r.y**2 <= 1)
+
+
+# reference goldens: tests/test_analysis.py:76-102 (CookeTriplet, fields 0/14/20 deg,
+# wavelengths 0.48/0.55/0.65 um, 6 hexapolar rings, chief-ray centred)
+COOKE_GEO = [[0.00597244087781, 0.00628645771124, 0.00931911440064],
+             [0.03928464835617618, 0.04075295155639047, 0.04772194200606705],
+             [0.018909146395329878, 0.022501847359635008, 0.036545592330568866]]
+COOKE_RMS = [[0.003791335461448, 0.004293689564257, 0.006195618755672],
+             [0.01582480029344623, 0.016918412809703662, 0.019221165873836682],
+             [0.013236232767092956, 0.012116688566406967, 0.013648684944411313]]
+
+
+def test_spot_diagram_reproduces_reference_goldens_host_logic():
+    from optiland_amd import load_system
+    from optiland_amd.analysis import SpotDiagram
+    table = load_system("cooke_generic")
+    t = tr.HipRayTracer(table, dtype=torch.float64)
+    spot = SpotDiagram(t)
+    np.testing.assert_allclose(spot.rms_spot_radius(), COOKE_RMS, rtol=1e-5)
+    np.testing.assert_allclose(spot.geometric_spot_radius(), COOKE_GEO, rtol=1e-5)
+    c = SpotDiagram(t, reference="centroid")
+    assert np.all(np.array(c.rms_spot_radius()) <= np.array(spot.rms_spot_radius()) + 1e-12)

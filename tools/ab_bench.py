@@ -35,7 +35,7 @@ args = ap.parse_args()
 if args.system_json:
     table, hy = SystemTable.load(args.system_json), (args.hy if args.hy is not None else 0.0)
 else:
-    name, hy, _ = WORKLOADS[args.workload]
+    name, hy, _, _wl = WORKLOADS[args.workload]
     table = load_system(name)
     if args.hy is not None:
         hy = args.hy

@@ -226,7 +226,10 @@ def run_case(name, optic, Hx, Hy, Px, Py, wavelength, use_trace=None, save_json_
     Optic.trace() (fields x pupil expansion) instead of trace_generic."""
     table = pack_optic(optic, wavelengths=[wavelength], name=name)
     for d in save_json_to:
-        table.save(os.path.join(d, f"{name}.json"))
+        if d == GOLD:
+            table.save(os.path.join(d, f"{name}.json"))
+        else:  # shipped sample systems carry every wavelength of the optic
+            pack_optic(optic, wavelengths=None, name=name).save(os.path.join(d, f"{name}.json"))
 
     tracer = optic.ray_tracer
     if use_trace is not None:
