@@ -64,7 +64,14 @@ def _table_key(table):
             repr(table.fields), repr(table.polarization))
 
 
+_TRACER_CLASS = None
+_ORIGINALS = {}
+
+
 def _make_tracer_class():
+    global _TRACER_CLASS
+    if _TRACER_CLASS is not None:
+        return _TRACER_CLASS
     import optiland.backend as be
     from optiland.distribution import create_distribution
     from optiland.raytrace.real_ray_tracer import RealRayTracer
@@ -183,7 +190,7 @@ def _make_tracer_class():
         def trace(self, Hx, Hy, wavelength, num_rays=100, distribution="hexapolar"):
             if not self._eligible():
                 self.last_path = "reference"
-                return super().trace(Hx, Hy, wavelength, num_rays, distribution)
+                return _ORIGINALS["trace"](self, Hx, Hy, wavelength, num_rays, distribution)
             self._validate_normalized_coordinates(Hx, Hy, "field")
             try:
                 if isinstance(distribution, str):
@@ -198,14 +205,14 @@ def _make_tracer_class():
                                       update_intensity=True, vig_scaled=False)
             except UnsupportedSystem:
                 self.last_path = "reference"
-                return super().trace(Hx, Hy, wavelength, num_rays, distribution)
+                return _ORIGINALS["trace"](self, Hx, Hy, wavelength, num_rays, distribution)
             self.last_path = "hip"
             return out
 
         def trace_generic(self, Hx, Hy, Px, Py, wavelength):
             if not self._eligible():
                 self.last_path = "reference"
-                return super().trace_generic(Hx, Hy, Px, Py, wavelength)
+                return _ORIGINALS["trace_generic"](self, Hx, Hy, Px, Py, wavelength)
             self._validate_normalized_coordinates(Hx, Hy, "field")
             self._validate_normalized_coordinates(Px, Py, "pupil")
             try:
@@ -221,11 +228,65 @@ def _make_tracer_class():
                                       vig_scaled=True)
             except UnsupportedSystem:
                 self.last_path = "reference"
-                return super().trace_generic(Hx, Hy, Px, Py, wavelength)
+                return _ORIGINALS["trace_generic"](self, Hx, Hy, Px, Py, wavelength)
             self.last_path = "hip"
             return out
 
+    # the reference's own implementations, captured before enable() can patch them
+    _ORIGINALS["trace"] = RealRayTracer.trace
+    _ORIGINALS["trace_generic"] = RealRayTracer.trace_generic
+    _TRACER_CLASS = OptilandHipRayTracer
     return OptilandHipRayTracer
+
+
+def enable(device=None, force=False):
+    """Route EVERY `Optic` (existing and future) through the HIP path.
+
+    Patches `RealRayTracer.trace / trace_generic` (raytrace/real_ray_tracer.py:58-154)
+    in place; each tracer instance lazily gets an `OptilandHipRayTracer` companion.
+    Ineligible calls (numpy backend, autograd, unsupported systems) run the original
+    methods.  `disable()` restores them.  This is the activation to prefer with the
+    stock `"torch"` backend: about thirty sites of the reference branch on
+    `be.get_backend() == "torch"` (Forbes, NURBS, optimisers ...), which a backend
+    registered under another name does not satisfy.
+    """
+    cls = _make_tracer_class()
+    from optiland.raytrace.real_ray_tracer import RealRayTracer
+
+    if getattr(RealRayTracer, "_hip_enabled", False):
+        return
+
+    def _companion(self):
+        comp = self.__dict__.get("_hip_companion")
+        if comp is None:
+            comp = cls(self.optic, device=device, force=force)
+            comp.ray_generator = self.ray_generator
+            self.__dict__["_hip_companion"] = comp
+        comp.ray_aiming_config = self.ray_aiming_config
+        return comp
+
+    def trace(self, Hx, Hy, wavelength, num_rays=100, distribution="hexapolar"):
+        if isinstance(self, cls):
+            return cls.trace(self, Hx, Hy, wavelength, num_rays, distribution)
+        return _companion(self).trace(Hx, Hy, wavelength, num_rays, distribution)
+
+    def trace_generic(self, Hx, Hy, Px, Py, wavelength):
+        if isinstance(self, cls):
+            return cls.trace_generic(self, Hx, Hy, Px, Py, wavelength)
+        return _companion(self).trace_generic(Hx, Hy, Px, Py, wavelength)
+
+    RealRayTracer.trace = trace
+    RealRayTracer.trace_generic = trace_generic
+    RealRayTracer._hip_enabled = True
+
+
+def disable():
+    from optiland.raytrace.real_ray_tracer import RealRayTracer
+
+    if getattr(RealRayTracer, "_hip_enabled", False):
+        RealRayTracer.trace = _ORIGINALS["trace"]
+        RealRayTracer.trace_generic = _ORIGINALS["trace_generic"]
+        RealRayTracer._hip_enabled = False
 
 
 def install(optic, device=None, force=False):

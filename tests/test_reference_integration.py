@@ -185,3 +185,66 @@ def test_packer_matches_committed_tables(ref):
     assert fresh.surfaces.tobytes() == table.surfaces.tobytes()
     np.testing.assert_array_equal(fresh.optics, table.optics)
     assert fresh.raygen == table.raygen
+
+
+def test_enable_routes_every_optic_and_disable_restores(hip_on_cpu):
+    be = hip_on_cpu
+    from optiland.raytrace.real_ray_tracer import RealRayTracer
+    from optiland.samples.objectives import CookeTriplet
+    from optiland_amd import integration
+    orig = RealRayTracer.trace
+    be.set_backend("numpy")
+    want = np.array(CookeTriplet().trace(0.0, 1.0, 0.55, 5, "hexapolar").y)
+    be.set_backend("torch")
+    integration.enable(force=True)
+    try:
+        lens = CookeTriplet()  # created AFTER enable(), never touched by install()
+        r = lens.trace(0.0, 1.0, 0.55, 5, "hexapolar")
+        comp = lens.ray_tracer._hip_companion
+        assert comp.last_path == "hip"
+        np.testing.assert_allclose(_np(be, r.y), want, rtol=1e-9, atol=1e-10)
+        g = lens.trace_generic(0.0, 0.5, be.array([0.1, 0.2]), be.array([0.0, -0.3]), 0.55)
+        assert comp.last_path == "hip" and _np(be, g.x).shape == (2,)
+    finally:
+        integration.disable()
+    assert RealRayTracer.trace is orig
+    lens = CookeTriplet()
+    lens.trace(0.0, 1.0, 0.55, 5, "hexapolar")
+    assert "_hip_companion" not in lens.ray_tracer.__dict__
+
+
+def test_reference_suite_sweeps_the_hip_backend(tmp_path):
+    """The reference's conftest parametrises every test over
+    `be.list_available_backends()` (tests/conftest.py:8-23): registering "hip" before
+    collection makes its own suite sweep the new backend.  Run its backend-contract
+    tests and the hot-path unit tests that way (CPU, fp64).  One test is
+    deselected: `test__process_input` checks `be.ndarray`, which the reference picks
+    by backend NAME."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dst = tmp_path / "tests"
+    shutil.copytree(os.path.join(REF, "tests"), dst,
+                    ignore=shutil.ignore_patterns("__pycache__", "zemax_files", "*.zmx"))
+    conf = (dst / "conftest.py").read_text()
+    conf = conf.replace(
+        "import optiland.backend as be\n",
+        "import optiland.backend as be\nimport sys\nsys.path.insert(0, %r)\n"
+        "from optiland_amd.integration import register_backend\nregister_backend()\n" % root, 1)
+    conf = conf.replace('if backend_name == "torch":', 'if backend_name in ("torch", "hip"):')
+    (dst / "conftest.py").write_text(conf)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1",
+               PYTHONPATH=os.pathsep.join([os.path.join(root, "tests", "refshim"), REF]))
+    files = ["tests/test_backend_contract.py", "tests/test_rays.py",
+             "tests/test_coordinate_system.py", "tests/test_physical_apertures.py",
+             "tests/test_coatings.py", "tests/test_jones.py", "tests/test_standard_surface.py",
+             "tests/test_surface_group.py", "tests/test_zernike.py"]
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider",
+                          "-k", "hip and not test__process_input", *files],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    tail = out.stdout.strip().splitlines()[-1]
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert " passed" in tail and "failed" not in tail, tail
+    n = int(tail.split(" passed")[0].split()[-1])
+    assert n > 300, tail
