@@ -127,9 +127,19 @@ int build_zernike_block(const double* terms, int n_terms, std::vector<double>& o
   return 0;
 }
 
+// host-side staging record: every field of both device blocks, in double
+struct HostSurf {
+  int32_t geom, interaction, aperture_kind, coating_kind, coeff_off, n_coeff, max_iter;
+  uint32_t flags;
+  int32_t poly_cols, coeff_len, ap_off, ap_len;
+  double cv, kp1, tol, inv_norm;
+  double origin[3], rot[9], rel_off[3], rel_rot[9], ap[4], coat[2];
+};
+
 template <typename T>
 struct DeviceTable {
-  ol::DevSurf<T>* surf = nullptr;
+  ol::DevSurfHot<T>* surf = nullptr;
+  ol::DevSurfCold<T>* cold = nullptr;
   ol::DevOptics<T>* optics = nullptr;
   T* coeffs = nullptr;
 };
@@ -150,23 +160,27 @@ struct ol_system {
 namespace {
 
 template <typename T>
-int upload(const std::vector<ol::DevSurf<double>>& surf64,
+int upload(const std::vector<HostSurf>& surf64,
            const std::vector<ol::DevOptics<double>>& opt64, const std::vector<double>& coef64,
            DeviceTable<T>& dst) {
-  std::vector<ol::DevSurf<T>> surf(surf64.size());
+  std::vector<ol::DevSurfHot<T>> surf(surf64.size());
+  std::vector<ol::DevSurfCold<T>> cold(surf64.size());
   for (size_t i = 0; i < surf64.size(); ++i) {
     const auto& a = surf64[i];
     auto& b = surf[i];
+    auto& c = cold[i];
     std::memset(&b, 0, sizeof(b));
+    std::memset(&c, 0, sizeof(c));
     b.geom = a.geom; b.interaction = a.interaction; b.aperture_kind = a.aperture_kind;
     b.coating_kind = a.coating_kind; b.coeff_off = a.coeff_off; b.n_coeff = a.n_coeff;
-    b.max_iter = a.max_iter; b.flags = a.flags; b.poly_cols = a.poly_cols;
-    b.coeff_len = a.coeff_len; b.ap_off = a.ap_off; b.ap_len = a.ap_len;
-    b.cv = (T)a.cv; b.kp1 = (T)a.kp1; b.tol = (T)a.tol; b.inv_norm = (T)a.inv_norm;
+    b.max_iter = a.max_iter; b.flags = a.flags;
+    b.cv = (T)a.cv; b.kp1 = (T)a.kp1;
+    c.poly_cols = a.poly_cols; c.coeff_len = a.coeff_len; c.ap_off = a.ap_off;
+    c.ap_len = a.ap_len; c.tol = (T)a.tol; c.inv_norm = (T)a.inv_norm;
     for (int k = 0; k < 3; ++k) { b.origin[k] = (T)a.origin[k]; b.rel_off[k] = (T)a.rel_off[k]; }
-    for (int k = 0; k < 9; ++k) { b.rot[k] = (T)a.rot[k]; b.rel_rot[k] = (T)a.rel_rot[k]; }
-    for (int k = 0; k < 4; ++k) b.ap[k] = (T)a.ap[k];
-    for (int k = 0; k < 2; ++k) b.coat[k] = (T)a.coat[k];
+    for (int k = 0; k < 9; ++k) { c.rot[k] = (T)a.rot[k]; c.rel_rot[k] = (T)a.rel_rot[k]; }
+    for (int k = 0; k < 4; ++k) c.ap[k] = (T)a.ap[k];
+    for (int k = 0; k < 2; ++k) c.coat[k] = (T)a.coat[k];
   }
   std::vector<ol::DevOptics<T>> opt(opt64.size());
   for (size_t i = 0; i < opt64.size(); ++i) {
@@ -177,10 +191,13 @@ int upload(const std::vector<ol::DevSurf<double>>& surf64,
   std::vector<T> coef(coef64.size() ? coef64.size() : 1, T(0));
   for (size_t i = 0; i < coef64.size(); ++i) coef[i] = (T)coef64[i];
 
-  OL_HIP_CHECK(hipMalloc((void**)&dst.surf, surf.size() * sizeof(ol::DevSurf<T>)));
+  OL_HIP_CHECK(hipMalloc((void**)&dst.surf, surf.size() * sizeof(ol::DevSurfHot<T>)));
+  OL_HIP_CHECK(hipMalloc((void**)&dst.cold, cold.size() * sizeof(ol::DevSurfCold<T>)));
+  OL_HIP_CHECK(hipMemcpy(dst.cold, cold.data(), cold.size() * sizeof(ol::DevSurfCold<T>),
+                         hipMemcpyHostToDevice));
   OL_HIP_CHECK(hipMalloc((void**)&dst.optics, opt.size() * sizeof(ol::DevOptics<T>)));
   OL_HIP_CHECK(hipMalloc((void**)&dst.coeffs, coef.size() * sizeof(T)));
-  OL_HIP_CHECK(hipMemcpy(dst.surf, surf.data(), surf.size() * sizeof(ol::DevSurf<T>),
+  OL_HIP_CHECK(hipMemcpy(dst.surf, surf.data(), surf.size() * sizeof(ol::DevSurfHot<T>),
                          hipMemcpyHostToDevice));
   OL_HIP_CHECK(hipMemcpy(dst.optics, opt.data(), opt.size() * sizeof(ol::DevOptics<T>),
                          hipMemcpyHostToDevice));
@@ -192,6 +209,7 @@ int upload(const std::vector<ol::DevSurf<double>>& surf64,
 template <typename T>
 void release(DeviceTable<T>& t) {
   if (t.surf) (void)hipFree(t.surf);
+  if (t.cold) (void)hipFree(t.cold);
   if (t.optics) (void)hipFree(t.optics);
   if (t.coeffs) (void)hipFree(t.coeffs);
   t = DeviceTable<T>();
@@ -205,6 +223,7 @@ int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* c
              int32_t last, uint32_t flags, uint32_t* status, hipStream_t stream) {
   ol::TraceArgs<T> a;
   a.surf = tab.surf;
+  a.cold = tab.cold;
   a.optics = tab.optics;
   a.coeffs = tab.coeffs;
   bool vec = true;
@@ -265,11 +284,11 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
   if (n_coeffs < 0 || (n_coeffs > 0 && !coeffs))
     return fail(OL_EINVAL, "ol_system_create: bad coefficient buffer");
 
-  std::vector<ol::DevSurf<double>> dev(n_surf);
+  std::vector<HostSurf> dev(n_surf);
   std::vector<double> dcoef;
   for (int32_t i = 0; i < n_surf; ++i) {
     const ol_surface_desc& s = surf[i];
-    ol::DevSurf<double>& d = dev[i];
+    HostSurf& d = dev[i];
     std::memset(&d, 0, sizeof(d));
     if (s.geom_kind < OL_GEOM_PLANE || s.geom_kind > OL_GEOM_TOROIDAL)
       return fail(OL_EUNSUPPORTED, "surface %d: geometry kind %d", i, s.geom_kind);
@@ -309,7 +328,7 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
     static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     std::memcpy(d.rel_rot, I, sizeof(I));
     if (i > 0) {
-      const ol::DevSurf<double>& p = dev[i - 1];
+      const HostSurf& p = dev[i - 1];
       mat3_mul_abt(d.rot, p.rot, d.rel_rot);
       double dv[3] = {p.origin[0] - d.origin[0], p.origin[1] - d.origin[1],
                       p.origin[2] - d.origin[2]};

@@ -38,31 +38,46 @@ constexpr uint32_t kSurfRotated = 0x1u;     // this surface's own frame is rotat
 constexpr uint32_t kSurfRelRotated = 0x2u;  // transform from the previous frame rotates
 constexpr uint32_t kSurfRadiusInf = 0x4u;   // |R| = inf (standard.py:108-111 branch)
 
+// Hot part: everything a plain conic surface needs, exactly 16 elements so the
+// kernel fetches it with ONE s_load_dwordx16 (fp32) / two (fp64) per surface and
+// can prefetch the next surface's block while it works on the current one.
 template <typename T>
-struct DevSurf {
+struct alignas(16) DevSurfHot {
   int32_t geom;
   int32_t interaction;
   int32_t aperture_kind;
   int32_t coating_kind;
+  uint32_t flags;
   int32_t coeff_off;   // offset into the T coefficient buffer
   int32_t n_coeff;     // asphere: #C_i; polynomial: rows*cols; zernike: #groups
   int32_t max_iter;
-  uint32_t flags;
+  T cv;                // curvature 1/R (0 for |R| = inf)
+  T kp1;               // 1 + conic
+  T rel_off[3];        // local_s = rel_rot * local_{s-1} + rel_off
+  T origin[3];         // global position of the local origin
+};
+
+// Cold part: only touched when a flag / kind in the hot part says so.
+template <typename T>
+struct DevSurfCold {
   int32_t poly_cols;
   int32_t coeff_len;   // number of T elements of this surface's coefficient block
   int32_t ap_off;      // composite aperture: first token in the coefficient buffer
   int32_t ap_len;      // composite aperture: number of tokens
-  T cv;                // curvature 1/R (0 for |R| = inf)
-  T kp1;               // 1 + conic
   T tol;
   T inv_norm;          // 1 / norm_radius (zernike)
-  T origin[3];         // global position of the local origin
   T rot[9];            // local = rot * (global - origin)
-  T rel_off[3];        // local_s = rel_rot * local_{s-1} + rel_off
   T rel_rot[9];
   T ap[4];             // radial: rmin^2, rmax^2, ox, oy; rect: xmin,xmax,ymin,ymax;
                        // elliptical: 1/a^2, 1/b^2, ox, oy
   T coat[2];           // simple coating: T, R
+};
+
+// What the device functions see: the hot block BY VALUE (SGPRs) + a pointer to
+// the cold block.
+template <typename T>
+struct DevSurf : DevSurfHot<T> {
+  const DevSurfCold<T>* cold;
 };
 
 template <typename T>

@@ -204,7 +204,7 @@ __device__ __forceinline__ void polynomial_eval(const DevSurf<T>& s, const T* __
   T f = m::div(s.cv, g);
   fx = x * f;
   fy = y * f;
-  const int cols = s.poly_cols;
+  const int cols = s.cold->poly_cols;
   const int rows = cols > 0 ? s.n_coeff / cols : 0;
   // outer Horner in x over rows; inner Horner in y gives q_i(y) and q_i'(y)
   T P = T(0), dPdx = T(0), dPdy = T(0);
@@ -239,7 +239,7 @@ __device__ __forceinline__ void zernike_eval(const DevSurf<T>& s, const T* __res
   T f = m::div(s.cv, g);
   fx = x * f;
   fy = y * f;
-  const T inv = s.inv_norm;
+  const T inv = s.cold->inv_norm;
   const T xn = x * inv, yn = y * inv;
   if (m::abs(xn) > T(1) || m::abs(yn) > T(1)) status |= 0x1u;  // OL_STATUS_ZERNIKE_RANGE
   const T u = m::fma(xn, xn, yn * yn);
@@ -315,7 +315,7 @@ __device__ __forceinline__ void chebyshev_eval(const DevSurf<T>& s, const T* __r
   fy = y * f;
   const T xn = x * c[0], yn = y * c[1];
   if (m::abs(xn) > T(1) || m::abs(yn) > T(1)) status |= 0x4u;  // OL_STATUS_CHEBYSHEV_RANGE
-  const int cols = s.poly_cols;
+  const int cols = s.cold->poly_cols;
   const int rows = cols > 0 ? s.n_coeff / cols : 0;
   const T* grid = c + 2;
   // Ti, Ui1 = T_i(xn), U_{i-1}(xn)
@@ -467,7 +467,7 @@ __device__ __forceinline__ void newton_iterate(const DevSurf<T>& s, const T* __r
   nr_eval(s, c, xi, yi, sag, fx, fy, status);
   T f = sag - zi;
   T af = m::abs(f);
-  bool done = !(af >= s.tol);                       // converged, or NaN
+  bool done = !(af >= s.cold->tol);                       // converged, or NaN
   done = done || (it > 0 && !(af < T(0.5) * q.fprev));  // residual stopped halving
   T df = m::fma(fx, L, m::fma(fy, M, -N));
   T dfs = m::abs(df) > m::guard() ? df : m::guard();
@@ -597,10 +597,10 @@ __device__ __forceinline__ bool leaf_contains(int kind, const T* __restrict__ ap
 template <typename T>
 __device__ __forceinline__ bool aperture_contains(const DevSurf<T>& s,
                                                   const T* __restrict__ coeffs, T x, T y) {
-  if (s.aperture_kind != kApComposite) return leaf_contains<T>(s.aperture_kind, s.ap, x, y);
-  const T* tok = coeffs + s.ap_off;
+  if (s.aperture_kind != kApComposite) return leaf_contains<T>(s.aperture_kind, s.cold->ap, x, y);
+  const T* tok = coeffs + s.cold->ap_off;
   uint32_t stack = 0;  // bit 0 = top of stack
-  for (int i = 0; i < s.ap_len; ++i, tok += kApTokenLen) {
+  for (int i = 0; i < s.cold->ap_len; ++i, tok += kApTokenLen) {
     const int op = (int)tok[0];
     if (op < kApOpUnion) {
       stack = (stack << 1) | (leaf_contains<T>(op, tok + 1, x, y) ? 1u : 0u);
@@ -688,7 +688,7 @@ __device__ __forceinline__ void into_local_frame(const DevSurf<T>& s, bool from_
   if (from_global) {
     T x = r.x - s.origin[0], y = r.y - s.origin[1], z = r.z - s.origin[2];
     if (s.flags & kSurfRotated) {
-      const T* R = s.rot;
+      const T* R = s.cold->rot;
       T L = r.L, M = r.M, N = r.N;
       r.x = R[0] * x + R[1] * y + R[2] * z;
       r.y = R[3] * x + R[4] * y + R[5] * z;
@@ -703,7 +703,7 @@ __device__ __forceinline__ void into_local_frame(const DevSurf<T>& s, bool from_
     }
   } else {
     if (s.flags & kSurfRelRotated) {
-      const T* R = s.rel_rot;
+      const T* R = s.cold->rel_rot;
       T x = r.x, y = r.y, z = r.z, L = r.L, M = r.M, N = r.N;
       r.x = m::fma(R[0], x, m::fma(R[1], y, m::fma(R[2], z, s.rel_off[0])));
       r.y = m::fma(R[3], x, m::fma(R[4], y, m::fma(R[5], z, s.rel_off[1])));
@@ -770,7 +770,7 @@ __device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>
 
   // coating (interactions/base.py:111-128)
   if (s.coating_kind == kCoatSimple) {
-    r.i = r.i * (s.interaction == kReflect ? s.coat[1] : s.coat[0]);
+    r.i = r.i * (s.interaction == kReflect ? s.cold->coat[1] : s.cold->coat[0]);
   }
   if constexpr (POL) {
     T j0 = T(1), j1 = T(1), j2 = T(1);
@@ -906,7 +906,7 @@ template <typename T>
 __device__ __forceinline__ Ray<T> to_global(const DevSurf<T>& s, const Ray<T>& r) {
   Ray<T> g = r;
   if (s.flags & kSurfRotated) {
-    const T* R = s.rot;  // inverse = transpose
+    const T* R = s.cold->rot;  // inverse = transpose
     g.x = R[0] * r.x + R[3] * r.y + R[6] * r.z;
     g.y = R[1] * r.x + R[4] * r.y + R[7] * r.z;
     g.z = R[2] * r.x + R[5] * r.y + R[8] * r.z;
@@ -933,6 +933,11 @@ template <typename T, int RPT>
 struct VecOf {
   typedef T type __attribute__((ext_vector_type(RPT)));
 };
+
+template <typename T, int RPT>
+__device__ __forceinline__ T vec_get(const typename VecOf<T, RPT>::type& v, int k) {
+  return v[k];  // ext_vector_type(1) is still a vector
+}
 
 template <typename T, int RPT>
 __device__ __forceinline__ void load_plane(const T* __restrict__ p, int64_t base, int cnt,
@@ -1004,8 +1009,9 @@ __device__ __forceinline__ void store_rays(T* __restrict__ row, int64_t stride, 
 // serialising compute behind HBM writes (measured: 1.00 ms -> see DESIGN.md).
 template <typename T, int RPT, bool RECORD, bool POL, int NR>
 __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
-    const DevSurf<T>* __restrict__ surf_tab, const DevOptics<T>* __restrict__ optics_tab,
-    const T* __restrict__ coeff_tab, TraceArgs<T> a) {
+    const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
+    const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
+    TraceArgs<T> a) {
   const int64_t base = ((int64_t)blockIdx.x * kTraceBlock + threadIdx.x) * RPT;
   if (base >= a.n) return;
   const int64_t left = a.n - base;
@@ -1014,39 +1020,72 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
   Ray<T> r[RPT];
   Prt<T> P[POL ? RPT : 1];
   {
-    T tmp[RPT];
-#define OL_LOAD_FIELD(idx, fld)                      \
-  load_plane<T, RPT>(a.rays[idx], base, cnt, tmp);   \
-  _Pragma("unroll") for (int k = 0; k < RPT; ++k) r[k].fld = tmp[k];
-    OL_LOAD_FIELD(0, x)
-    OL_LOAD_FIELD(1, y)
-    OL_LOAD_FIELD(2, z)
-    OL_LOAD_FIELD(3, L)
-    OL_LOAD_FIELD(4, M)
-    OL_LOAD_FIELD(5, N)
-    OL_LOAD_FIELD(6, i)
-    OL_LOAD_FIELD(7, opd)
-#undef OL_LOAD_FIELD
-    if constexpr (POL) {
+    // All plane loads are issued back to back under ONE branch (full vector vs
+    // ragged tail): with the branch inside each plane's load the compiler placed
+    // an s_waitcnt vmcnt(0) after every load, serialising 8 (+9) HBM round trips.
+    T in[8][RPT];
+    T pin[POL ? 9 : 1][RPT];
+    if (RPT > 1 && cnt == RPT) {
+      using V = typename VecOf<T, RPT>::type;
+      V v[8];
 #pragma unroll
-      for (int e = 0; e < 9; ++e) {
-        load_plane<T, RPT>(a.prt + (int64_t)e * a.n, base, cnt, tmp);
+      for (int f = 0; f < 8; ++f) v[f] = *reinterpret_cast<const V*>(a.rays[f] + base);
+      if constexpr (POL) {
+        V pv[9];
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) P[k].m[e] = tmp[k];
+        for (int e = 0; e < 9; ++e)
+          pv[e] = *reinterpret_cast<const V*>(a.prt + (int64_t)e * a.n + base);
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+#pragma unroll
+          for (int k = 0; k < RPT; ++k) pin[e][k] = vec_get<T, RPT>(pv[e], k);
+      }
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) in[f][k] = vec_get<T, RPT>(v[f], k);
+    } else {
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) in[f][k] = k < cnt ? a.rays[f][base + k] : T(0);
+      if constexpr (POL) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+#pragma unroll
+          for (int k = 0; k < RPT; ++k)
+            pin[e][k] = k < cnt ? a.prt[(int64_t)e * a.n + base + k] : T(0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      r[k].x = in[0][k]; r[k].y = in[1][k]; r[k].z = in[2][k];
+      r[k].L = in[3][k]; r[k].M = in[4][k]; r[k].N = in[5][k];
+      r[k].i = in[6][k]; r[k].opd = in[7][k];
+      if constexpr (POL) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) P[k].m[e] = pin[e][k];
       }
     }
   }
 
   uint32_t status = 0;
   bool is_global = true;  // frame of the state held in r[]
-  const DevSurf<T>* last_traced = nullptr;
+  DevSurf<T> last_traced;
+  last_traced.cold = cold_tab;
+  // hot block of the current surface by value (one s_load_dwordx16 for fp32); the
+  // next surface's block is requested before the current one is worked on.
+  DevSurfHot<T> cur = surf_tab[a.first];
   for (int s = a.first; s <= a.last; ++s) {
-    const DevSurf<T>& S = surf_tab[s];
+    DevSurf<T> S;
+    static_cast<DevSurfHot<T>&>(S) = cur;
+    S.cold = cold_tab + s;
+    if (s < a.last) cur = surf_tab[s + 1];
     if (S.interaction != kRecordOnly) {
-      const DevOptics<T>& O = optics_tab[s * a.n_wl + a.wl];
+      const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
       surface_step<T, RPT, POL, NR>(S, O, coeff_tab, is_global, r, P, status);
       is_global = false;
-      last_traced = &S;
+      last_traced = S;
     }
     if constexpr (RECORD) {
       T* row = a.record + (int64_t)(s - a.first) * 8 * a.record_stride;
@@ -1055,7 +1094,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
       } else {
         Ray<T> g[RPT];
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) g[k] = to_global(*last_traced, r[k]);
+        for (int k = 0; k < RPT; ++k) g[k] = to_global(last_traced, r[k]);
         store_rays<T, RPT>(row, a.record_stride, base, cnt, g);
       }
     }
@@ -1064,7 +1103,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
   if (a.flags & kTraceWriteRays) {
     Ray<T> g[RPT];
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) g[k] = is_global ? r[k] : to_global(*last_traced, r[k]);
+    for (int k = 0; k < RPT; ++k) g[k] = is_global ? r[k] : to_global(last_traced, r[k]);
     T tmp[RPT];
 #define OL_WB_FIELD(idx, fld)                                        \
   _Pragma("unroll") for (int k = 0; k < RPT; ++k) tmp[k] = g[k].fld; \
@@ -1104,7 +1143,7 @@ static hipError_t launch_nr(const TraceArgs<T>& a, hipStream_t stream) {
   const bool rec = a.record != nullptr, pol = a.prt != nullptr;
 #define OL_LAUNCH(R, P)                                                                      \
   hipLaunchKernelGGL((trace_kernel<T, RPT, R, P, NR>), grid, block, 0, stream, a.surf,       \
-                     a.optics, a.coeffs, a)
+                     a.cold, a.optics, a.coeffs, a)
   if (rec && pol) OL_LAUNCH(true, true);
   else if (rec) OL_LAUNCH(true, false);
   else if (pol) OL_LAUNCH(false, true);
@@ -1138,14 +1177,17 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
   const int nr = !has_newton ? 0 : ((a.flags & kTraceCompact) && tuning().compact ? 2 : 1);
   if (!vector_ok) return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
   // Defaults from interleaved A/B runs on MI355X (tools/ab_bench.py, profiles/):
-  //  * conic-only ranges: one 16-byte vector of rays per lane (== 1 ray/lane within 1 %);
-  //  * ranges with Newton-Raphson surfaces: ONE ray per lane -- the iteration loop
-  //    then diverges per ray instead of per slot, registers drop (fp32: 118 -> 70)
-  //    and occupancy rises; 15-30 % faster on the asphere / Zernike configs;
+  //  * fp32 conic-only ranges: one 16-byte vector of rays per lane (equal to 1 ray/lane
+  //    in record-all mode, 20 % faster in record-last mode where ALU/ILP decides);
+  //  * fp64, and any range with Newton-Raphson surfaces: ONE ray per lane -- fewer
+  //    registers, more waves; the iteration loop diverges per ray instead of per
+  //    slot; 5 % (fp64 conic) to 15-30 % (asphere / Zernike) faster;
   //  * compaction only on request (measured slower on every surface tried: Newton
   //    iteration counts are nearly uniform across a wave once the stop rule is per ray).
   const int want = tuning().rays_per_thread;
-  if (want == 1 || (want == 0 && nr == 1)) return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
+  const bool prefer_one = nr == 1 || sizeof(T) == 8;
+  if (want == 1 || (want == 0 && prefer_one && nr != 2))
+    return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
   return launch_rpt<T, kVec>(a, nr, stream);
 }
 

@@ -13,7 +13,8 @@ constexpr uint32_t kTraceCompact = 0x2u;   // OL_TRACE_COMPACT
 
 template <typename T>
 struct TraceArgs {
-  const DevSurf<T>* surf;      // [n_surf]
+  const DevSurfHot<T>* surf;   // [n_surf] hot blocks
+  const DevSurfCold<T>* cold;  // [n_surf] cold blocks
   const DevOptics<T>* optics;  // [n_surf][n_wl]
   const T* coeffs;             // coefficient blocks
   T* rays[8];                  // x,y,z,L,M,N,i,opd planes
