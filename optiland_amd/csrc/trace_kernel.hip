@@ -97,13 +97,15 @@ struct Prt {
 //   t1 = (-E + sgn(R) sqrt(disc))/A, t2 = (-E - sgn(R) sqrt(disc))/A;
 // a == 0 -> -c/b which is exactly t_a.
 template <typename T>
-__device__ __forceinline__ T conic_distance(const DevSurf<T>& s, T x, T y, T z, T L, T M, T N) {
+__device__ __forceinline__ T flat_distance(T z, T N) {  // standard.py:108-111
   using m = Math<T>;
-  if (s.flags & kSurfRadiusInf) {
-    T Ns = m::abs(N) > m::guard() ? N : m::guard();
-    return -m::div(z, Ns);
-  }
-  const T cv = s.cv, kp1 = s.kp1;
+  T Ns = m::abs(N) > m::guard() ? N : m::guard();
+  return -m::div(z, Ns);
+}
+
+template <typename T>
+__device__ __forceinline__ T curved_distance(T cv, T kp1, T x, T y, T z, T L, T M, T N) {
+  using m = Math<T>;
   const T kz = kp1 * z, kN = kp1 * N;
   T E = m::fma(cv, m::fma(x, L, m::fma(y, M, kz * N)), -N);
   T A = cv * m::fma(L, L, m::fma(M, M, kN * N));
@@ -121,6 +123,12 @@ __device__ __forceinline__ T conic_distance(const DevSurf<T>& s, T x, T y, T z, 
   T t = take_b ? tb : ta;
   t = (A == T(0)) ? ta : t;
   return t;
+}
+
+template <typename T>
+__device__ __forceinline__ T conic_distance(const DevSurf<T>& s, T x, T y, T z, T L, T M, T N) {
+  if (s.flags & kSurfRadiusInf) return flat_distance(z, N);
+  return curved_distance(s.cv, s.kp1, x, y, z, L, M, N);
 }
 
 // standard.py:150-175: gradient of the conic; returns (fx, fy) = (x, y)/denom.
@@ -680,117 +688,168 @@ __device__ __forceinline__ void prt_update(Prt<T>& P, T k0x, T k0y, T k0z, T k1x
 // record).  Phases run across the thread's rays so that independent chains
 // interleave (ILP) and the Newton loop can look at all of them together.
 // --------------------------------------------------------------------------
-template <typename T>
+// Uniform (per-surface) branches are hoisted OUTSIDE the per-ray loops everywhere
+// below: each branch body is then one basic block holding the arithmetic of all
+// RPT rays, which is what lets their independent dependency chains interleave.
+template <typename T, int RPT>
 __device__ __forceinline__ void into_local_frame(const DevSurf<T>& s, bool from_global,
-                                                 Ray<T>& r) {
+                                                 Ray<T> (&r)[RPT]) {
   using m = Math<T>;
   // coordinate_system.py:73-89
   if (from_global) {
-    T x = r.x - s.origin[0], y = r.y - s.origin[1], z = r.z - s.origin[2];
+    const T ox = s.origin[0], oy = s.origin[1], oz = s.origin[2];
     if (s.flags & kSurfRotated) {
       const T* R = s.cold->rot;
-      T L = r.L, M = r.M, N = r.N;
-      r.x = R[0] * x + R[1] * y + R[2] * z;
-      r.y = R[3] * x + R[4] * y + R[5] * z;
-      r.z = R[6] * x + R[7] * y + R[8] * z;
-      r.L = R[0] * L + R[1] * M + R[2] * N;
-      r.M = R[3] * L + R[4] * M + R[5] * N;
-      r.N = R[6] * L + R[7] * M + R[8] * N;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        T x = r[k].x - ox, y = r[k].y - oy, z = r[k].z - oz;
+        T L = r[k].L, M = r[k].M, N = r[k].N;
+        r[k].x = R[0] * x + R[1] * y + R[2] * z;
+        r[k].y = R[3] * x + R[4] * y + R[5] * z;
+        r[k].z = R[6] * x + R[7] * y + R[8] * z;
+        r[k].L = R[0] * L + R[1] * M + R[2] * N;
+        r[k].M = R[3] * L + R[4] * M + R[5] * N;
+        r[k].N = R[6] * L + R[7] * M + R[8] * N;
+      }
     } else {
-      r.x = x;
-      r.y = y;
-      r.z = z;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        r[k].x -= ox;
+        r[k].y -= oy;
+        r[k].z -= oz;
+      }
+    }
+  } else if (s.flags & kSurfRelRotated) {
+    const T* R = s.cold->rel_rot;
+    const T ox = s.rel_off[0], oy = s.rel_off[1], oz = s.rel_off[2];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      T x = r[k].x, y = r[k].y, z = r[k].z, L = r[k].L, M = r[k].M, N = r[k].N;
+      r[k].x = m::fma(R[0], x, m::fma(R[1], y, m::fma(R[2], z, ox)));
+      r[k].y = m::fma(R[3], x, m::fma(R[4], y, m::fma(R[5], z, oy)));
+      r[k].z = m::fma(R[6], x, m::fma(R[7], y, m::fma(R[8], z, oz)));
+      r[k].L = R[0] * L + R[1] * M + R[2] * N;
+      r[k].M = R[3] * L + R[4] * M + R[5] * N;
+      r[k].N = R[6] * L + R[7] * M + R[8] * N;
     }
   } else {
-    if (s.flags & kSurfRelRotated) {
-      const T* R = s.cold->rel_rot;
-      T x = r.x, y = r.y, z = r.z, L = r.L, M = r.M, N = r.N;
-      r.x = m::fma(R[0], x, m::fma(R[1], y, m::fma(R[2], z, s.rel_off[0])));
-      r.y = m::fma(R[3], x, m::fma(R[4], y, m::fma(R[5], z, s.rel_off[1])));
-      r.z = m::fma(R[6], x, m::fma(R[7], y, m::fma(R[8], z, s.rel_off[2])));
-      r.L = R[0] * L + R[1] * M + R[2] * N;
-      r.M = R[3] * L + R[4] * M + R[5] * N;
-      r.N = R[6] * L + R[7] * M + R[8] * N;
-    } else {
-      r.x += s.rel_off[0];
-      r.y += s.rel_off[1];
-      r.z += s.rel_off[2];
+    const T ox = s.rel_off[0], oy = s.rel_off[1], oz = s.rel_off[2];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      r[k].x += ox;
+      r[k].y += oy;
+      r[k].z += oz;
     }
   }
 }
 
 // everything after the hit point is known: absorb, opd, clip, refract/reflect,
 // coating, PRT.  (fx, fy) is the sag gradient at the hit (unused for planes).
-template <typename T, bool POL>
+template <typename T, int RPT, bool POL>
 __device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>& o,
-                                         const T* __restrict__ coeffs, T t, T fx, T fy,
-                                         Ray<T>& r, Prt<T>& P) {
+                                         const T* __restrict__ coeffs, const T (&t)[RPT],
+                                         const T (&fx)[RPT], const T (&fy)[RPT],
+                                         Ray<T> (&r)[RPT], Prt<T> (&P)[POL ? RPT : 1]) {
   using m = Math<T>;
   // homogeneous.py:44-53, standard_surface.py:244
-  if (o.absorb > T(0)) r.i = r.i * m::exp(-o.absorb * t);
-  r.opd = r.opd + m::abs(t * o.n1);
+  if (o.absorb > T(0)) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) r[k].i = r[k].i * m::exp(-o.absorb * t[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) r[k].opd = r[k].opd + m::abs(t[k] * o.n1);
 
   // clip (physical_apertures/base.py:71-82, real_rays.py:154-161)
   if (s.aperture_kind != kApNone) {
-    if (!aperture_contains(s, coeffs, r.x, r.y)) r.i = T(0);
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+      if (!aperture_contains(s, coeffs, r[k].x, r[k].y)) r[k].i = T(0);
   }
 
   // surface normal at the hit point
-  T nx, ny, nz;
+  T nx[RPT], ny[RPT], nz[RPT];
   if (s.geom == kGeomPlane) {
-    nx = T(0);
-    ny = T(0);
-    nz = T(1);  // plane.py:90-109
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      nx[k] = T(0);
+      ny[k] = T(0);
+      nz[k] = T(1);  // plane.py:90-109
+    }
   } else {
-    T im = m::rsqrt(m::fma(fx, fx, m::fma(fy, fy, T(1))));
-    nx = fx * im;
-    ny = fy * im;
-    nz = -im;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      T im = m::rsqrt(m::fma(fx[k], fx[k], m::fma(fy[k], fy[k], T(1))));
+      nx[k] = fx[k] * im;
+      ny[k] = fy[k] * im;
+      nz[k] = -im;
+    }
   }
 
   // refract / reflect (real_rays.py:163-205, 535-571)
-  const T L0 = r.L, M0 = r.M, N0 = r.N;
-  T dot = m::fma(L0, nx, m::fma(M0, ny, N0 * nz));
-  const T sgn = dot > T(0) ? T(1) : (dot < T(0) ? T(-1) : (dot == T(0) ? T(0) : dot));
-  const T ax = nx * sgn, ay = ny * sgn, az = nz * sgn;
-  const T adot = m::abs(dot);
+  T L0[RPT], M0[RPT], N0[RPT], adot[RPT], ax[RPT], ay[RPT], az[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    L0[k] = r[k].L;
+    M0[k] = r[k].M;
+    N0[k] = r[k].N;
+    T dot = m::fma(L0[k], nx[k], m::fma(M0[k], ny[k], N0[k] * nz[k]));
+    const T sgn = dot > T(0) ? T(1) : (dot < T(0) ? T(-1) : (dot == T(0) ? T(0) : dot));
+    ax[k] = nx[k] * sgn;
+    ay[k] = ny[k] * sgn;
+    az[k] = nz[k] * sgn;
+    adot[k] = m::abs(dot);
+  }
   if (s.interaction == kReflect) {
-    T k2 = T(-2) * adot;
-    r.L = m::fma(k2, ax, L0);
-    r.M = m::fma(k2, ay, M0);
-    r.N = m::fma(k2, az, N0);
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      T k2 = T(-2) * adot[k];
+      r[k].L = m::fma(k2, ax[k], L0[k]);
+      r[k].M = m::fma(k2, ay[k], M0[k]);
+      r[k].N = m::fma(k2, az[k], N0[k]);
+    }
   } else {
     const T u = o.u;
-    T root = m::sqrt(m::fma(-u * u, m::fma(-adot, adot, T(1)), T(1)));  // NaN on TIR
-    T w = m::fma(-u, adot, root);
-    r.L = m::fma(u, L0, ax * w);
-    r.M = m::fma(u, M0, ay * w);
-    r.N = m::fma(u, N0, az * w);
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      T root = m::sqrt(m::fma(-u * u, m::fma(-adot[k], adot[k], T(1)), T(1)));  // NaN on TIR
+      T w = m::fma(-u, adot[k], root);
+      r[k].L = m::fma(u, L0[k], ax[k] * w);
+      r[k].M = m::fma(u, M0[k], ay[k] * w);
+      r[k].N = m::fma(u, N0[k], az[k] * w);
+    }
   }
 
   // coating (interactions/base.py:111-128)
   if (s.coating_kind == kCoatSimple) {
-    r.i = r.i * (s.interaction == kReflect ? s.cold->coat[1] : s.cold->coat[0]);
+    const T f = s.interaction == kReflect ? s.cold->coat[1] : s.cold->coat[0];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) r[k].i = r[k].i * f;
   }
   if constexpr (POL) {
-    T j0 = T(1), j1 = T(1), j2 = T(1);
-    if (s.coating_kind == kCoatFresnel) {
-      // coatings.py:72-92 + jones.py:71-117 with cos(aoi) = min(|n.k0|, 1):
-      // root = sqrt(nn^2 - sin^2) is real unless TIR, where k1 is NaN already.
-      T ci = adot < T(1) ? adot : (adot >= T(1) ? T(1) : adot);
-      T nn = o.nn;
-      T root = m::sqrt(m::fma(nn, nn, m::fma(ci, ci, T(-1))));
-      if (s.interaction == kReflect) {
-        j0 = m::div(ci - root, ci + root);
-        j1 = -m::div(m::fma(nn * nn, ci, -root), m::fma(nn * nn, ci, root));
-        j2 = T(-1);
-      } else {
-        j0 = m::div(T(2) * ci, ci + root);
-        j1 = m::div(T(2) * nn * ci, m::fma(nn * nn, ci, root));
-        j2 = T(1);
+    const bool fresnel = s.coating_kind == kCoatFresnel;
+    const bool reflect = s.interaction == kReflect;
+    const T nn = o.nn;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      T j0 = T(1), j1 = T(1), j2 = T(1);
+      if (fresnel) {
+        // coatings.py:72-92 + jones.py:71-117 with cos(aoi) = min(|n.k0|, 1):
+        // root = sqrt(nn^2 - sin^2) is real unless TIR, where k1 is NaN already.
+        T ci = adot[k] < T(1) ? adot[k] : (adot[k] >= T(1) ? T(1) : adot[k]);
+        T root = m::sqrt(m::fma(nn, nn, m::fma(ci, ci, T(-1))));
+        if (reflect) {
+          j0 = m::div(ci - root, ci + root);
+          j1 = -m::div(m::fma(nn * nn, ci, -root), m::fma(nn * nn, ci, root));
+          j2 = T(-1);
+        } else {
+          j0 = m::div(T(2) * ci, ci + root);
+          j1 = m::div(T(2) * nn * ci, m::fma(nn * nn, ci, root));
+          j2 = T(1);
+        }
       }
+      prt_update(P[k], L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, nx[k], ny[k], nz[k], j0, j1,
+                 j2);
     }
-    prt_update(P, L0, M0, N0, r.L, r.M, r.N, nx, ny, nz, j0, j1, j2);
   }
 }
 
@@ -803,8 +862,7 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
                                              Ray<T> (&r)[RPT], Prt<T> (&P)[POL ? RPT : 1],
                                              uint32_t& status) {
   using m = Math<T>;
-#pragma unroll
-  for (int k = 0; k < RPT; ++k) into_local_frame(s, from_global, r[k]);
+  into_local_frame<T, RPT>(s, from_global, r);
 
   const T* c = coeffs + s.coeff_off;
   T t[RPT], fx[RPT], fy[RPT];
@@ -818,13 +876,27 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
       r[k].z = m::fma(t[k], r[k].N, r[k].z);
     }
   } else if (s.geom == kGeomStandard) {
+    if (s.flags & kSurfRadiusInf) {
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      t[k] = conic_distance(s, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M, r[k].N);
-      r[k].x = m::fma(t[k], r[k].L, r[k].x);
-      r[k].y = m::fma(t[k], r[k].M, r[k].y);
-      r[k].z = m::fma(t[k], r[k].N, r[k].z);
-      conic_gradient(s, r[k].x, r[k].y, fx[k], fy[k]);
+      for (int k = 0; k < RPT; ++k) {
+        t[k] = flat_distance(r[k].z, r[k].N);
+        r[k].x = m::fma(t[k], r[k].L, r[k].x);
+        r[k].y = m::fma(t[k], r[k].M, r[k].y);
+        r[k].z = m::fma(t[k], r[k].N, r[k].z);
+        fx[k] = fy[k] = T(0);  // conic_gradient with cv = 0
+      }
+    } else {
+      const T cv = s.cv, kp1 = s.kp1;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k)
+        t[k] = curved_distance(cv, kp1, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M, r[k].N);
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        r[k].x = m::fma(t[k], r[k].L, r[k].x);
+        r[k].y = m::fma(t[k], r[k].M, r[k].y);
+        r[k].z = m::fma(t[k], r[k].N, r[k].z);
+        conic_gradient(s, r[k].x, r[k].y, fx[k], fy[k]);
+      }
     }
   } else if constexpr (NR != 0) {
     constexpr bool COMPACT = NR == 2;
@@ -896,9 +968,7 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
 #pragma unroll
     for (int k = 0; k < RPT; ++k) t[k] = fx[k] = fy[k] = T(0);
   }
-#pragma unroll
-  for (int k = 0; k < RPT; ++k)
-    interact<T, POL>(s, o, coeffs, t[k], fx[k], fy[k], r[k], P[POL ? k : 0]);
+  interact<T, RPT, POL>(s, o, coeffs, t, fx, fy, r, P);
 }
 
 // local -> global for the recorded state (coordinate_system.py:91-107)
@@ -1176,16 +1246,18 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
   constexpr int kVec = 16 / sizeof(T);  // rays per 16-byte lane vector
   const int nr = !has_newton ? 0 : ((a.flags & kTraceCompact) && tuning().compact ? 2 : 1);
   if (!vector_ok) return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
-  // Defaults from interleaved A/B runs on MI355X (tools/ab_bench.py, profiles/):
-  //  * fp32 conic-only ranges: one 16-byte vector of rays per lane (equal to 1 ray/lane
-  //    in record-all mode, 20 % faster in record-last mode where ALU/ILP decides);
-  //  * fp64, and any range with Newton-Raphson surfaces: ONE ray per lane -- fewer
-  //    registers, more waves; the iteration loop diverges per ray instead of per
-  //    slot; 5 % (fp64 conic) to 15-30 % (asphere / Zernike) faster;
+  // Defaults from interleaved A/B runs on MI355X (tools/ab_bench.py):
+  //  * record-all (HBM-write bound), fp32 and fp64: ONE ray per lane -- 36 / 81 VGPRs,
+  //    8 / 5 waves per SIMD keep more stores in flight (fp32 +2 %, fp64 +6 % over the
+  //    16-byte vector layout);
+  //  * record-last on conic-only ranges (ALU bound): one 16-byte vector of rays per
+  //    lane, whose independent chains interleave (fp32 0.205 vs 0.259 ms);
+  //  * any range with Newton-Raphson surfaces: one ray per lane -- the iteration loop
+  //    diverges per ray instead of per slot; 7-30 % faster on asphere / Zernike;
   //  * compaction only on request (measured slower on every surface tried: Newton
   //    iteration counts are nearly uniform across a wave once the stop rule is per ray).
   const int want = tuning().rays_per_thread;
-  const bool prefer_one = nr == 1 || sizeof(T) == 8;
+  const bool prefer_one = nr == 1 || a.record != nullptr;
   if (want == 1 || (want == 0 && prefer_one && nr != 2))
     return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
   return launch_rpt<T, kVec>(a, nr, stream);
