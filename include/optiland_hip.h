@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OL_ABI_VERSION 1
+#define OL_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------- */
 #define OL_OK 0
@@ -112,11 +112,19 @@ typedef enum ol_aperture_kind {
  *   SIMPLE   i *= T (refract) | R (reflect)            coatings.py:164-237
  *   FRESNEL  Jones diag(s,p,1) from Fresnel equations  coatings.py:362-386,
  *            jones.py:71-117 (needs a PRT buffer, i.e. polarized rays)
+ *   POLARIZER linear polarizer, transmission axis a    coatings.py:418-447,
+ *            jones.py:120-181; coat[0] = index in coeffs[] of {ax, ay, az}
+ *            (normalised, as JonesLinearPolarizer stores it)
+ *   RETARDER linear retarder, fast axis a, retardance d coatings.py:450-485,
+ *            jones.py:331-393; coat[0] = index in coeffs[] of {ax, ay, az, d};
+ *            its Jones matrix is complex: needs OL_TRACE_PRT_COMPLEX
  */
 typedef enum ol_coating_kind {
   OL_COAT_NONE = 0,
   OL_COAT_SIMPLE = 1,
-  OL_COAT_FRESNEL = 2
+  OL_COAT_FRESNEL = 2,
+  OL_COAT_POLARIZER = 3,
+  OL_COAT_RETARDER = 4
 } ol_coating_kind;
 
 #define OL_SURF_ROTATED 0x1u /* rot[] is not the identity */
@@ -175,6 +183,7 @@ typedef struct ol_system ol_system; /* opaque */
 
 /* ---- trace flags --------------------------------------------------------- */
 #define OL_TRACE_WRITE_RAYS 0x1u   /* write the final ray state back into rays[] */
+#define OL_TRACE_PRT_COMPLEX 0x4u  /* prt holds 18 planes: 9 real then 9 imaginary */
 #define OL_TRACE_COMPACT 0x2u      /* allow wavefront straggler compaction in the
                                       Newton loop (only if OL_TUNE_COMPACT=1) */
 
@@ -208,7 +217,9 @@ int32_t ol_system_num_surfaces(const ol_system* sys);
  *            Surface._record_real stores them (standard_surface.py:260-274).
  *   prt      nullable; 9 planes x n_rays (row-major 3x3 polarisation
  *            ray-tracing matrix, real part) read-modify-write:
- *            PolarizedRays.update (rays/polarized_rays.py:180-202).
+ *            PolarizedRays.update (rays/polarized_rays.py:180-202).  With
+ *            OL_TRACE_PRT_COMPLEX: 18 planes, real part then imaginary part
+ *            (required when the range holds a RETARDER coating).
  *   status   nullable device uint32; OL_STATUS_* bits are OR-ed in.
  * Replaces: SurfaceGroup.trace(rays, skip) -- `first_surface` generalises
  * `skip`.                                                                    */
@@ -241,6 +252,7 @@ int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n,
 /* update_intensity epilogue for polarised traces (trace() only):
  * i = sum_fields |P E0|^2 * i0 / n_fields.  k0[3]: initial direction planes.  */
 int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt,
+                           int32_t prt_complex /* 0: 9 planes, 1: 18 planes */,
                            const void* const k0[3], const void* i0,
                            const ol_polarization_state* state, void* intensity,
                            uint32_t* status, void* stream);

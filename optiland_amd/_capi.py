@@ -84,7 +84,7 @@ EXPORTS = (
 
 F32, F64 = 0, 1
 TUNE_RAYS_PER_THREAD, TUNE_COMPACT = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 def library_path() -> str:
@@ -124,7 +124,8 @@ def load():
     lib.ol_generate_rays.restype = C.c_int
     lib.ol_generate_rays.argtypes = [vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, C.POINTER(vp), vp]
     lib.ol_polarized_intensity.restype = C.c_int
-    lib.ol_polarized_intensity.argtypes = [C.c_int, i64, vp, C.POINTER(vp), vp, vp, vp, vp, vp]
+    lib.ol_polarized_intensity.argtypes = [C.c_int, i64, vp, i32, C.POINTER(vp), vp, vp, vp, vp,
+                                           vp]
     lib.ol_spot_moments.restype = C.c_int
     lib.ol_spot_moments.argtypes = [C.c_int, i64, vp, vp, vp, vp, vp]
     lib.ol_spot_max_r2.restype = C.c_int

@@ -86,9 +86,9 @@ hipError_t launch_raygen(const RaygenDev& p, int64_t n, const T* hx, const T* hy
   return hipGetLastError();
 }
 
-// rays/polarized_rays.py:68-133, 204-233 with a real PRT matrix:
-// |P E0|^2 = |P Re E0|^2 + |P Im E0|^2.
-template <typename T>
+// rays/polarized_rays.py:68-133, 204-233.  Real PRT: |P E0|^2 = |P Re E0|^2 +
+// |P Im E0|^2; complex PRT (CPLX, 18 planes): full complex product.
+template <typename T, bool CPLX>
 __global__ __launch_bounds__(kBlock) void pol_intensity_kernel(int64_t n, const T* __restrict__ prt,
                                                                const T* __restrict__ k0x,
                                                                const T* __restrict__ k0y,
@@ -119,17 +119,24 @@ __global__ __launch_bounds__(kBlock) void pol_intensity_kernel(int64_t n, const 
     if (nrm == T(0)) flag |= 0x2u;  // OL_STATUS_K_PARALLEL_X
     const T px = T(0), py = kz / nrm, pz = -ky / nrm;
     const T sx = py * kz - pz * ky, sy = pz * kx - px * kz, sz = px * ky - py * kx;
-    T P[9];
+    T P[9], Q[9];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) P[e] = prt[(int64_t)e * n + j];
+    for (int e = 0; e < 9; ++e) {
+      P[e] = prt[(int64_t)e * n + j];
+      Q[e] = CPLX ? prt[(int64_t)(9 + e) * n + j] : T(0);
+    }
     T acc = T(0);
     for (int f = 0; f < nf; ++f) {
       const T er[3] = {ar[f] * sx + br[f] * px, ar[f] * sy + br[f] * py, ar[f] * sz + br[f] * pz};
       const T ei[3] = {ai[f] * sx + bi[f] * px, ai[f] * sy + bi[f] * py, ai[f] * sz + bi[f] * pz};
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const T vr = P[3 * a] * er[0] + P[3 * a + 1] * er[1] + P[3 * a + 2] * er[2];
-        const T vi = P[3 * a] * ei[0] + P[3 * a + 1] * ei[1] + P[3 * a + 2] * ei[2];
+        T vr = P[3 * a] * er[0] + P[3 * a + 1] * er[1] + P[3 * a + 2] * er[2];
+        T vi = P[3 * a] * ei[0] + P[3 * a + 1] * ei[1] + P[3 * a + 2] * ei[2];
+        if (CPLX) {
+          vr -= Q[3 * a] * ei[0] + Q[3 * a + 1] * ei[1] + Q[3 * a + 2] * ei[2];
+          vi += Q[3 * a] * er[0] + Q[3 * a + 1] * er[1] + Q[3 * a + 2] * er[2];
+        }
         acc += vr * vr + vi * vi;
       }
     }
@@ -139,11 +146,15 @@ __global__ __launch_bounds__(kBlock) void pol_intensity_kernel(int64_t n, const 
 }
 
 template <typename T>
-hipError_t launch_pol_intensity(int64_t n, const T* prt, const T* const k0[3], const T* i0,
-                                const PolStateDev& st, T* intensity, uint32_t* status,
-                                hipStream_t stream) {
-  hipLaunchKernelGGL((pol_intensity_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, stream, n,
-                     prt, k0[0], k0[1], k0[2], i0, st, intensity, status);
+hipError_t launch_pol_intensity(int64_t n, const T* prt, bool prt_complex, const T* const k0[3],
+                                const T* i0, const PolStateDev& st, T* intensity,
+                                uint32_t* status, hipStream_t stream) {
+  if (prt_complex)
+    hipLaunchKernelGGL((pol_intensity_kernel<T, true>), dim3(grid_for(n)), dim3(kBlock), 0,
+                       stream, n, prt, k0[0], k0[1], k0[2], i0, st, intensity, status);
+  else
+    hipLaunchKernelGGL((pol_intensity_kernel<T, false>), dim3(grid_for(n)), dim3(kBlock), 0,
+                       stream, n, prt, k0[0], k0[1], k0[2], i0, st, intensity, status);
   return hipGetLastError();
 }
 
@@ -244,8 +255,9 @@ hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten,
 #define OL_INST(T)                                                                             \
   template hipError_t launch_raygen<T>(const RaygenDev&, int64_t, const T*, const T*, const T*, \
                                        const T*, const T*, const T*, T* const[7], hipStream_t); \
-  template hipError_t launch_pol_intensity<T>(int64_t, const T*, const T* const[3], const T*,  \
-                                              const PolStateDev&, T*, uint32_t*, hipStream_t); \
+  template hipError_t launch_pol_intensity<T>(int64_t, const T*, bool, const T* const[3],      \
+                                              const T*, const PolStateDev&, T*, uint32_t*,     \
+                                              hipStream_t);                                    \
   template hipError_t launch_spot_moments<T>(int64_t, const T*, const T*, const T*, double*,   \
                                              hipStream_t);                                     \
   template hipError_t launch_spot_max_r2<T>(int64_t, const T*, const T*, const T*, double,     \

@@ -133,7 +133,7 @@ struct HostSurf {
   uint32_t flags;
   int32_t poly_cols, coeff_len, ap_off, ap_len;
   double cv, kp1, tol, inv_norm;
-  double origin[3], rot[9], rel_off[3], rel_rot[9], ap[4], coat[2];
+  double origin[3], rot[9], rel_off[3], rel_rot[9], ap[4], coat[2], axis[3], ret_cos, ret_sin;
 };
 
 template <typename T>
@@ -181,6 +181,8 @@ int upload(const std::vector<HostSurf>& surf64,
     for (int k = 0; k < 9; ++k) { c.rot[k] = (T)a.rot[k]; c.rel_rot[k] = (T)a.rel_rot[k]; }
     for (int k = 0; k < 4; ++k) c.ap[k] = (T)a.ap[k];
     for (int k = 0; k < 2; ++k) c.coat[k] = (T)a.coat[k];
+    for (int k = 0; k < 3; ++k) c.axis[k] = (T)a.axis[k];
+    c.ret_cos = (T)a.ret_cos; c.ret_sin = (T)a.ret_sin;
   }
   std::vector<ol::DevOptics<T>> opt(opt64.size());
   for (size_t i = 0; i < opt64.size(); ++i) {
@@ -296,7 +298,7 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
       return fail(OL_EUNSUPPORTED, "surface %d: interaction %d", i, s.interaction);
     if (s.aperture_kind < OL_AP_NONE || s.aperture_kind > OL_AP_COMPOSITE)
       return fail(OL_EUNSUPPORTED, "surface %d: aperture kind %d", i, s.aperture_kind);
-    if (s.coating_kind < OL_COAT_NONE || s.coating_kind > OL_COAT_FRESNEL)
+    if (s.coating_kind < OL_COAT_NONE || s.coating_kind > OL_COAT_RETARDER)
       return fail(OL_EUNSUPPORTED, "surface %d: coating kind %d", i, s.coating_kind);
     if (s.n_coeff < 0 || s.coeff_offset < 0)
       return fail(OL_EINVAL, "surface %d: negative coefficient range", i);
@@ -369,6 +371,17 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
     }
     d.coat[0] = s.coat[0];
     d.coat[1] = s.coat[1];
+    if (s.coating_kind == OL_COAT_POLARIZER || s.coating_kind == OL_COAT_RETARDER) {
+      const int need = s.coating_kind == OL_COAT_RETARDER ? 4 : 3;
+      const int64_t off = (int64_t)s.coat[0];
+      if (off < 0 || off + need > n_coeffs)
+        return fail(OL_EINVAL, "surface %d: coating axis block outside the buffer", i);
+      for (int k = 0; k < 3; ++k) d.axis[k] = coeffs[off + k];
+      if (s.coating_kind == OL_COAT_RETARDER) {
+        d.ret_cos = std::cos(coeffs[off + 3] / 2);
+        d.ret_sin = std::sin(coeffs[off + 3] / 2);
+      }
+    }
 
     // coefficient block
     d.coeff_off = (int32_t)dcoef.size();
@@ -487,10 +500,16 @@ int ol_trace(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const rays
   if (!prt) {
     // rays/ray_generator.py:89-94: polarization-dependent coatings need polarized rays
     for (int32_t s = first_surface; s <= last_surface; ++s)
-      if (sys->coating[s] == OL_COAT_FRESNEL)
+      if (sys->coating[s] >= OL_COAT_FRESNEL)
         return fail(OL_EINVAL,
                     "Polarization must be set when surfaces have polarization-dependent "
                     "coatings.");
+  }
+  if (prt && !(flags & OL_TRACE_PRT_COMPLEX)) {
+    for (int32_t s = first_surface; s <= last_surface; ++s)
+      if (sys->coating[s] == OL_COAT_RETARDER)
+        return fail(OL_EINVAL, "ol_trace: surface %d is a retarder (complex Jones matrix): "
+                               "pass an 18-plane prt with OL_TRACE_PRT_COMPLEX", s);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dt == OL_F32)
@@ -529,8 +548,9 @@ int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n, const vo
   return OL_OK;
 }
 
-int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt, const void* const k0[3],
-                           const void* i0, const ol_polarization_state* state, void* intensity,
+int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt, int32_t prt_complex,
+                           const void* const k0[3], const void* i0,
+                           const ol_polarization_state* state, void* intensity,
                            uint32_t* status, void* stream) {
   if (!prt || !k0 || !k0[0] || !k0[1] || !k0[2] || !i0 || !state || !intensity)
     return fail(OL_EINVAL, "ol_polarized_intensity: NULL argument");
@@ -541,11 +561,13 @@ int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt, const v
   hipError_t e;
   if (dt == OL_F32) {
     const float* k[3] = {(const float*)k0[0], (const float*)k0[1], (const float*)k0[2]};
-    e = ol::launch_pol_intensity<float>(n_rays, (const float*)prt, k, (const float*)i0, s,
+    e = ol::launch_pol_intensity<float>(n_rays, (const float*)prt, prt_complex != 0, k,
+                                        (const float*)i0, s,
                                         (float*)intensity, status, st);
   } else if (dt == OL_F64) {
     const double* k[3] = {(const double*)k0[0], (const double*)k0[1], (const double*)k0[2]};
-    e = ol::launch_pol_intensity<double>(n_rays, (const double*)prt, k, (const double*)i0, s,
+    e = ol::launch_pol_intensity<double>(n_rays, (const double*)prt, prt_complex != 0, k,
+                                         (const double*)i0, s,
                                          (double*)intensity, status, st);
   } else {
     return fail(OL_EINVAL, "ol_polarized_intensity: bad dtype %d", (int)dt);

@@ -32,7 +32,9 @@ enum : int {
   kApComposite = 5, kApOpUnion = 10, kApOpIntersection = 11, kApOpDifference = 12
 };
 constexpr int kApTokenLen = 5;   // {op, p0..p3} per reverse-Polish token
-enum : int { kCoatNone = 0, kCoatSimple = 1, kCoatFresnel = 2 };
+enum : int {
+  kCoatNone = 0, kCoatSimple = 1, kCoatFresnel = 2, kCoatPolarizer = 3, kCoatRetarder = 4
+};
 
 constexpr uint32_t kSurfRotated = 0x1u;     // this surface's own frame is rotated
 constexpr uint32_t kSurfRelRotated = 0x2u;  // transform from the previous frame rotates
@@ -71,6 +73,8 @@ struct DevSurfCold {
   T ap[4];             // radial: rmin^2, rmax^2, ox, oy; rect: xmin,xmax,ymin,ymax;
                        // elliptical: 1/a^2, 1/b^2, ox, oy
   T coat[2];           // simple coating: T, R
+  T axis[3];           // polarizer / retarder axis (normalised)
+  T ret_cos, ret_sin;  // retarder: cos(d/2), sin(d/2)
 };
 
 // What the device functions see: the hot block BY VALUE (SGPRs) + a pointer to

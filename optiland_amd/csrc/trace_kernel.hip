@@ -81,9 +81,18 @@ struct Ray {
 // 3x3 real polarisation ray-tracing matrix (the imaginary part
 // is identically zero for uncoated / Fresnel surfaces unless the ray is already
 // NaN through total internal reflection).
-template <typename T>
+// POLK: 0 = no polarisation, 1 = real PRT (9 values), 2 = complex PRT (18 values:
+// real part then imaginary part; needed only behind a retarder, jones.py:331-393).
+template <typename T, int POLK>
 struct Prt {
-  T m[9];
+  T m[POLK == 2 ? 18 : 9];
+};
+
+// Surface Jones matrix in the local (s, p) basis: 2x2 block A + iB, and the
+// k-component factor j22 (jones.py:109-117: +-1).
+template <typename T>
+struct Jones {
+  T a00, a01, a10, a11, b00, b01, b10, b11, j22;
 };
 
 // --------------------------------------------------------------------------
@@ -633,8 +642,13 @@ __device__ __forceinline__ bool aperture_contains(const DevSurf<T>& s,
 // Gram-Schmidt step keeps s orthogonal to k0 to rounding, so the residual noise
 // in its azimuth only couples through the Jones anisotropy |ts - tp| ~ aoi^2.
 template <typename T>
-__device__ __forceinline__ void prt_update(Prt<T>& P, T k0x, T k0y, T k0z, T k1x, T k1y, T k1z,
-                                           T nx, T ny, T nz, T j0, T j1, T j2) {
+struct PolBasis {
+  T sx, sy, sz, p0x, p0y, p0z, p1x, p1y, p1z;
+};
+
+template <typename T>
+__device__ __forceinline__ PolBasis<T> pol_basis(T k0x, T k0y, T k0z, T k1x, T k1y, T k1z, T nx,
+                                                 T ny, T nz) {
   using m = Math<T>;
   T sx = k0y * nz - k0z * ny, sy = k0z * nx - k0x * nz, sz = k0x * ny - k0y * nx;
   {
@@ -660,27 +674,87 @@ __device__ __forceinline__ void prt_update(Prt<T>& P, T k0x, T k0y, T k0z, T k1x
     mag2 = m::fma(sx, sx, m::fma(sy, sy, sz * sz));
   }
   T im = m::rsqrt(mag2);
-  sx *= im;
-  sy *= im;
-  sz *= im;
+  PolBasis<T> b;
+  b.sx = sx * im;
+  b.sy = sy * im;
+  b.sz = sz * im;
   // p0 = k0 x s, p1 = k1 x s
-  T p0x = k0y * sz - k0z * sy, p0y = k0z * sx - k0x * sz, p0z = k0x * sy - k0y * sx;
-  T p1x = k1y * sz - k1z * sy, p1y = k1z * sx - k1x * sz, p1z = k1x * sy - k1y * sx;
-  // v = O_in * P  (rows of O_in: s, p0, k0), scaled by the Jones diagonal
-  T v0[3], v1[3], v2[3];
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    v0[b] = j0 * (sx * P.m[b] + sy * P.m[3 + b] + sz * P.m[6 + b]);
-    v1[b] = j1 * (p0x * P.m[b] + p0y * P.m[3 + b] + p0z * P.m[6 + b]);
-    v2[b] = j2 * (k0x * P.m[b] + k0y * P.m[3 + b] + k0z * P.m[6 + b]);
+  b.p0x = k0y * b.sz - k0z * b.sy; b.p0y = k0z * b.sx - k0x * b.sz; b.p0z = k0x * b.sy - k0y * b.sx;
+  b.p1x = k1y * b.sz - k1z * b.sy; b.p1y = k1z * b.sx - k1x * b.sz; b.p1z = k1x * b.sy - k1y * b.sx;
+  return b;
+}
+
+// jones.py:120-181 (polarizer: J = u_out u_in^T) and jones.py:331-393 (retarder:
+// J = cos(d/2) I - i sin(d/2) (2 u u^T - I)), u = the axis projected on (s, p).
+template <typename T>
+__device__ __forceinline__ Jones<T> axis_jones(const PolBasis<T>& b, const T* __restrict__ axis,
+                                               bool retarder, T rc, T rs) {
+  using m = Math<T>;
+  const T ax = axis[0], ay = axis[1], az = axis[2];
+  T ts = ax * b.sx + ay * b.sy + az * b.sz;
+  T tpi = ax * b.p0x + ay * b.p0y + az * b.p0z;
+  T ni = m::sqrt(m::fma(ts, ts, tpi * tpi));
+  ni = ni == T(0) ? T(1) : ni;
+  const T usi = m::div(ts, ni), upi = m::div(tpi, ni);
+  Jones<T> J;
+  J.j22 = T(1);
+  if (retarder) {
+    // e^{-id/2} us^2 + e^{id/2} up^2 = c (us^2+up^2) - i s (us^2 - up^2)
+    const T q0 = usi * usi, q1 = upi * upi, q01 = usi * upi;
+    J.a00 = rc * (q0 + q1); J.b00 = -rs * (q0 - q1);
+    J.a11 = rc * (q0 + q1); J.b11 = rs * (q0 - q1);
+    J.a01 = J.a10 = T(0);
+    J.b01 = J.b10 = T(-2) * rs * q01;
+  } else {
+    T tpo = ax * b.p1x + ay * b.p1y + az * b.p1z;
+    T no = m::sqrt(m::fma(ts, ts, tpo * tpo));
+    no = no == T(0) ? T(1) : no;
+    const T uso = m::div(ts, no), upo = m::div(tpo, no);
+    J.a00 = uso * usi; J.a01 = uso * upi; J.a10 = upo * usi; J.a11 = upo * upi;
+    J.b00 = J.b01 = J.b10 = J.b11 = T(0);
   }
-  // P <- O_out * v  (columns of O_out: s, p1, k1)
+  return J;
+}
+
+// P <- O_out J O_in P  (polarized_rays.py:180-202); O_in rows (s, p0, k0), O_out
+// columns (s, p1, k1).  POLK == 2 carries the imaginary part too.
+template <typename T, int POLK>
+__device__ __forceinline__ void prt_apply(Prt<T, POLK>& P, const PolBasis<T>& b, T k0x, T k0y,
+                                          T k0z, T k1x, T k1y, T k1z, const Jones<T>& J) {
+  constexpr int NP = POLK == 2 ? 2 : 1;
+  T v0[NP][3], v1[NP][3], v2[NP][3];
+  T w0[NP][3], w1[NP][3], w2[NP][3];
 #pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    P.m[b] = sx * v0[b] + p1x * v1[b] + k1x * v2[b];
-    P.m[3 + b] = sy * v0[b] + p1y * v1[b] + k1y * v2[b];
-    P.m[6 + b] = sz * v0[b] + p1z * v1[b] + k1z * v2[b];
+  for (int c = 0; c < NP; ++c)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const T* Q = P.m + 9 * c;
+      w0[c][e] = b.sx * Q[e] + b.sy * Q[3 + e] + b.sz * Q[6 + e];
+      w1[c][e] = b.p0x * Q[e] + b.p0y * Q[3 + e] + b.p0z * Q[6 + e];
+      w2[c][e] = k0x * Q[e] + k0y * Q[3 + e] + k0z * Q[6 + e];
+    }
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    v0[0][e] = J.a00 * w0[0][e] + J.a01 * w1[0][e];
+    v1[0][e] = J.a10 * w0[0][e] + J.a11 * w1[0][e];
+    v2[0][e] = J.j22 * w2[0][e];
+    if constexpr (POLK == 2) {
+      v0[0][e] -= J.b00 * w0[1][e] + J.b01 * w1[1][e];
+      v1[0][e] -= J.b10 * w0[1][e] + J.b11 * w1[1][e];
+      v0[1][e] = J.a00 * w0[1][e] + J.a01 * w1[1][e] + J.b00 * w0[0][e] + J.b01 * w1[0][e];
+      v1[1][e] = J.a10 * w0[1][e] + J.a11 * w1[1][e] + J.b10 * w0[0][e] + J.b11 * w1[0][e];
+      v2[1][e] = J.j22 * w2[1][e];
+    }
   }
+#pragma unroll
+  for (int c = 0; c < NP; ++c)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      T* Q = P.m + 9 * c;
+      Q[e] = b.sx * v0[c][e] + b.p1x * v1[c][e] + k1x * v2[c][e];
+      Q[3 + e] = b.sy * v0[c][e] + b.p1y * v1[c][e] + k1y * v2[c][e];
+      Q[6 + e] = b.sz * v0[c][e] + b.p1z * v1[c][e] + k1z * v2[c][e];
+    }
 }
 
 // --------------------------------------------------------------------------
@@ -745,11 +819,12 @@ __device__ __forceinline__ void into_local_frame(const DevSurf<T>& s, bool from_
 
 // everything after the hit point is known: absorb, opd, clip, refract/reflect,
 // coating, PRT.  (fx, fy) is the sag gradient at the hit (unused for planes).
-template <typename T, int RPT, bool POL>
+template <typename T, int RPT, int POLK>
 __device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>& o,
                                          const T* __restrict__ coeffs, const T (&t)[RPT],
                                          const T (&fx)[RPT], const T (&fy)[RPT],
-                                         Ray<T> (&r)[RPT], Prt<T> (&P)[POL ? RPT : 1]) {
+                                         Ray<T> (&r)[RPT],
+                                         Prt<T, POLK> (&P)[POLK ? RPT : 1]) {
   using m = Math<T>;
   // homogeneous.py:44-53, standard_surface.py:244
   if (o.absorb > T(0)) {
@@ -825,30 +900,36 @@ __device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>
 #pragma unroll
     for (int k = 0; k < RPT; ++k) r[k].i = r[k].i * f;
   }
-  if constexpr (POL) {
-    const bool fresnel = s.coating_kind == kCoatFresnel;
+  if constexpr (POLK != 0) {
+    const int ck = s.coating_kind;
     const bool reflect = s.interaction == kReflect;
     const T nn = o.nn;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-      T j0 = T(1), j1 = T(1), j2 = T(1);
-      if (fresnel) {
+      const PolBasis<T> b = pol_basis(L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, nx[k], ny[k],
+                                      nz[k]);
+      Jones<T> J;
+      J.a00 = J.a11 = J.j22 = T(1);
+      J.a01 = J.a10 = J.b00 = J.b01 = J.b10 = J.b11 = T(0);
+      if (ck == kCoatFresnel) {
         // coatings.py:72-92 + jones.py:71-117 with cos(aoi) = min(|n.k0|, 1):
         // root = sqrt(nn^2 - sin^2) is real unless TIR, where k1 is NaN already.
         T ci = adot[k] < T(1) ? adot[k] : (adot[k] >= T(1) ? T(1) : adot[k]);
         T root = m::sqrt(m::fma(nn, nn, m::fma(ci, ci, T(-1))));
         if (reflect) {
-          j0 = m::div(ci - root, ci + root);
-          j1 = -m::div(m::fma(nn * nn, ci, -root), m::fma(nn * nn, ci, root));
-          j2 = T(-1);
+          J.a00 = m::div(ci - root, ci + root);
+          J.a11 = -m::div(m::fma(nn * nn, ci, -root), m::fma(nn * nn, ci, root));
+          J.j22 = T(-1);
         } else {
-          j0 = m::div(T(2) * ci, ci + root);
-          j1 = m::div(T(2) * nn * ci, m::fma(nn * nn, ci, root));
-          j2 = T(1);
+          J.a00 = m::div(T(2) * ci, ci + root);
+          J.a11 = m::div(T(2) * nn * ci, m::fma(nn * nn, ci, root));
         }
+      } else if (ck == kCoatPolarizer) {
+        J = axis_jones(b, s.cold->axis, false, T(0), T(0));
+      } else if (ck == kCoatRetarder) {
+        J = axis_jones(b, s.cold->axis, true, s.cold->ret_cos, s.cold->ret_sin);
       }
-      prt_update(P[k], L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, nx[k], ny[k], nz[k], j0, j1,
-                 j2);
+      prt_apply<T, POLK>(P[k], b, L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, J);
     }
   }
 }
@@ -856,10 +937,11 @@ __device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>
 // NR: 0 = the surface range holds no Newton-Raphson geometry (lean kernel: none of
 // that code, or its registers, is compiled in), 1 = Newton loop, 2 = Newton loop
 // with wavefront straggler compaction.
-template <typename T, int RPT, bool POL, int NR>
+template <typename T, int RPT, int POLK, int NR>
 __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptics<T>& o,
                                              const T* __restrict__ coeffs, bool from_global,
-                                             Ray<T> (&r)[RPT], Prt<T> (&P)[POL ? RPT : 1],
+                                             Ray<T> (&r)[RPT],
+                                             Prt<T, POLK> (&P)[POLK ? RPT : 1],
                                              uint32_t& status) {
   using m = Math<T>;
   into_local_frame<T, RPT>(s, from_global, r);
@@ -968,7 +1050,7 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
 #pragma unroll
     for (int k = 0; k < RPT; ++k) t[k] = fx[k] = fy[k] = T(0);
   }
-  interact<T, RPT, POL>(s, o, coeffs, t, fx, fy, r, P);
+  interact<T, RPT, POLK>(s, o, coeffs, t, fx, fy, r, P);
 }
 
 // local -> global for the recorded state (coordinate_system.py:91-107)
@@ -1077,7 +1159,7 @@ __device__ __forceinline__ void store_rays(T* __restrict__ row, int64_t stride, 
 // v_readfirstlane, and -- vmcnt being in-order on gfx9-family parts -- every
 // surface's table read then waited for ALL outstanding record stores to retire,
 // serialising compute behind HBM writes (measured: 1.00 ms -> see DESIGN.md).
-template <typename T, int RPT, bool RECORD, bool POL, int NR>
+template <typename T, int RPT, bool RECORD, int POLK, int NR>
 __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
     const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
@@ -1088,25 +1170,26 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
   const int cnt = left >= RPT ? RPT : (int)left;
 
   Ray<T> r[RPT];
-  Prt<T> P[POL ? RPT : 1];
+  constexpr int NPRT = POLK == 2 ? 18 : 9;  // PRT planes (real, then imaginary)
+  Prt<T, POLK> P[POLK ? RPT : 1];
   {
     // All plane loads are issued back to back under ONE branch (full vector vs
     // ragged tail): with the branch inside each plane's load the compiler placed
     // an s_waitcnt vmcnt(0) after every load, serialising 8 (+9) HBM round trips.
     T in[8][RPT];
-    T pin[POL ? 9 : 1][RPT];
+    T pin[POLK ? NPRT : 1][RPT];
     if (RPT > 1 && cnt == RPT) {
       using V = typename VecOf<T, RPT>::type;
       V v[8];
 #pragma unroll
       for (int f = 0; f < 8; ++f) v[f] = *reinterpret_cast<const V*>(a.rays[f] + base);
-      if constexpr (POL) {
-        V pv[9];
+      if constexpr (POLK != 0) {
+        V pv[NPRT];
 #pragma unroll
-        for (int e = 0; e < 9; ++e)
+        for (int e = 0; e < NPRT; ++e)
           pv[e] = *reinterpret_cast<const V*>(a.prt + (int64_t)e * a.n + base);
 #pragma unroll
-        for (int e = 0; e < 9; ++e)
+        for (int e = 0; e < NPRT; ++e)
 #pragma unroll
           for (int k = 0; k < RPT; ++k) pin[e][k] = vec_get<T, RPT>(pv[e], k);
       }
@@ -1119,9 +1202,9 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
       for (int f = 0; f < 8; ++f)
 #pragma unroll
         for (int k = 0; k < RPT; ++k) in[f][k] = k < cnt ? a.rays[f][base + k] : T(0);
-      if constexpr (POL) {
+      if constexpr (POLK != 0) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e)
+        for (int e = 0; e < NPRT; ++e)
 #pragma unroll
           for (int k = 0; k < RPT; ++k)
             pin[e][k] = k < cnt ? a.prt[(int64_t)e * a.n + base + k] : T(0);
@@ -1132,9 +1215,9 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
       r[k].x = in[0][k]; r[k].y = in[1][k]; r[k].z = in[2][k];
       r[k].L = in[3][k]; r[k].M = in[4][k]; r[k].N = in[5][k];
       r[k].i = in[6][k]; r[k].opd = in[7][k];
-      if constexpr (POL) {
+      if constexpr (POLK != 0) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e) P[k].m[e] = pin[e][k];
+        for (int e = 0; e < NPRT; ++e) P[k].m[e] = pin[e][k];
       }
     }
   }
@@ -1153,7 +1236,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
     if (s < a.last) cur = surf_tab[s + 1];
     if (S.interaction != kRecordOnly) {
       const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
-      surface_step<T, RPT, POL, NR>(S, O, coeff_tab, is_global, r, P, status);
+      surface_step<T, RPT, POLK, NR>(S, O, coeff_tab, is_global, r, P, status);
       is_global = false;
       last_traced = S;
     }
@@ -1188,10 +1271,10 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
     OL_WB_FIELD(7, opd)
 #undef OL_WB_FIELD
   }
-  if constexpr (POL) {
+  if constexpr (POLK != 0) {
     T tmp[RPT];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) {
+    for (int e = 0; e < NPRT; ++e) {
 #pragma unroll
       for (int k = 0; k < RPT; ++k) tmp[k] = P[k].m[e];
       store_plane<T, RPT>(a.prt + (int64_t)e * a.n, base, cnt, tmp);
@@ -1210,14 +1293,22 @@ static hipError_t launch_nr(const TraceArgs<T>& a, hipStream_t stream) {
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)blocks), block(kTraceBlock);
-  const bool rec = a.record != nullptr, pol = a.prt != nullptr;
+  const bool rec = a.record != nullptr;
+  const int polk = a.prt == nullptr ? 0 : ((a.flags & kTracePrtComplex) ? 2 : 1);
 #define OL_LAUNCH(R, P)                                                                      \
   hipLaunchKernelGGL((trace_kernel<T, RPT, R, P, NR>), grid, block, 0, stream, a.surf,       \
                      a.cold, a.optics, a.coeffs, a)
-  if (rec && pol) OL_LAUNCH(true, true);
-  else if (rec) OL_LAUNCH(true, false);
-  else if (pol) OL_LAUNCH(false, true);
-  else OL_LAUNCH(false, false);
+  if (polk == 2) {
+    // the complex-PRT variant exists for one ray per lane only (register budget)
+    if constexpr (RPT == 1) {
+      if (rec) OL_LAUNCH(true, 2); else OL_LAUNCH(false, 2);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  } else if (rec && polk == 1) OL_LAUNCH(true, 1);
+  else if (rec) OL_LAUNCH(true, 0);
+  else if (polk == 1) OL_LAUNCH(false, 1);
+  else OL_LAUNCH(false, 0);
 #undef OL_LAUNCH
   return hipGetLastError();
 }
@@ -1245,7 +1336,8 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
                         hipStream_t stream) {
   constexpr int kVec = 16 / sizeof(T);  // rays per 16-byte lane vector
   const int nr = !has_newton ? 0 : ((a.flags & kTraceCompact) && tuning().compact ? 2 : 1);
-  if (!vector_ok) return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
+  if (!vector_ok || (a.prt && (a.flags & kTracePrtComplex)))
+    return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
   // Defaults from interleaved A/B runs on MI355X (tools/ab_bench.py):
   //  * record-all (HBM-write bound), fp32 and fp64: ONE ray per lane -- 36 / 81 VGPRs,
   //    8 / 5 waves per SIMD keep more stores in flight (fp32 +2 %, fp64 +6 % over the

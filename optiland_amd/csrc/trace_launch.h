@@ -10,6 +10,7 @@ namespace ol {
 constexpr int kTraceBlock = 256;           // 4 waves of 64 lanes
 constexpr uint32_t kTraceWriteRays = 0x1u; // OL_TRACE_WRITE_RAYS
 constexpr uint32_t kTraceCompact = 0x2u;   // OL_TRACE_COMPACT
+constexpr uint32_t kTracePrtComplex = 0x4u;  // OL_TRACE_PRT_COMPLEX
 
 template <typename T>
 struct TraceArgs {
@@ -19,7 +20,7 @@ struct TraceArgs {
   const T* coeffs;             // coefficient blocks
   T* rays[8];                  // x,y,z,L,M,N,i,opd planes
   T* record;                   // rows x 8 x record_stride or nullptr
-  T* prt;                      // 9 x n or nullptr
+  T* prt;                      // 9 x n (18 x n with kTracePrtComplex) or nullptr
   uint32_t* status;            // device word or nullptr
   int64_t n;
   int64_t record_stride;
@@ -56,7 +57,8 @@ struct PolStateDev {
 };
 
 template <typename T>
-hipError_t launch_pol_intensity(int64_t n, const T* prt, const T* const k0[3], const T* i0,
+hipError_t launch_pol_intensity(int64_t n, const T* prt, bool prt_complex, const T* const k0[3],
+                                const T* i0,
                                 const PolStateDev& st, T* intensity, uint32_t* status,
                                 hipStream_t stream);
 

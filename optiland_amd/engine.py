@@ -106,7 +106,8 @@ class HipSystem:
 
         rays: sequence of 8 contiguous 1-D device tensors (x,y,z,L,M,N,i,opd) of one
         dtype -- the initial state.  record: True (allocate), False/None, or a
-        preallocated (rows, 8, stride) tensor.  prt: (9, n) tensor, read-modify-write.
+        preallocated (rows, 8, stride) tensor.  prt: (9, n) real or (18, n) real+imaginary
+        tensor (the latter is required behind retarder coatings), read-modify-write.
         With write_rays (default: only when nothing is recorded) the final state is
         written back into `rays` in place, like SurfaceGroup.trace mutates its rays.
         """
@@ -134,8 +135,12 @@ class HipSystem:
             write_rays = rec is None
         flags = (S.TRACE_WRITE_RAYS if write_rays else 0) | S.TRACE_COMPACT
         if prt is not None:
-            if prt.dtype != dtype or tuple(prt.shape) != (9, n) or not prt.is_contiguous():
-                raise ValueError("prt must be a contiguous (9, n) tensor of the ray dtype")
+            if prt.dtype != dtype or prt.dim() != 2 or prt.shape[0] not in (9, 18) \
+                    or prt.shape[1] != n or not prt.is_contiguous():
+                raise ValueError("prt must be a contiguous (9, n) [real] or (18, n) "
+                                 "[real + imaginary] tensor of the ray dtype")
+            if prt.shape[0] == 18:
+                flags |= S.TRACE_PRT_COMPLEX
         ptrs = (C.c_void_p * 8)(*[t.data_ptr() for t in rays])
         if check_status:
             self._status.zero_()
@@ -202,7 +207,8 @@ class HipSystem:
         self._status.zero_()
         with torch.cuda.device(self.device):
             rc = self.lib.ol_polarized_intensity(
-                _DT[dtype], n, prt.data_ptr(), kp, i0.data_ptr(), C.byref(st), out.data_ptr(),
+                _DT[dtype], n, prt.data_ptr(), 1 if prt.shape[0] == 18 else 0, kp,
+                i0.data_ptr(), C.byref(st), out.data_ptr(),
                 self._status.data_ptr(), _stream_ptr(self.device))
         _capi.check(rc, "ol_polarized_intensity")
         if int(self._status.item()) & S.STATUS_K_PARALLEL_X:

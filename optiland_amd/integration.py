@@ -29,7 +29,7 @@ import torch
 
 from . import tracer as _tracer
 from .packer import UnsupportedSystem, pack_optic
-from .rays import _state_dict
+from .rays import _state_dict, new_prt, prt_to_complex
 
 BACKEND_NAME = "hip"
 
@@ -145,8 +145,7 @@ def _make_tracer_class():
                                  "polarization-dependent coatings.")
             prt = k_init = i0 = None
             if polarized:
-                prt = torch.zeros((9, n), dtype=dtype, device=dev)
-                prt[0].fill_(1), prt[4].fill_(1), prt[8].fill_(1)
+                prt = new_prt(n, dtype, dev, table.needs_complex_prt)
                 k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
                 i0 = rays[6].clone()
             res = eng.trace(rays, 0, record=True, prt=prt)
@@ -172,9 +171,7 @@ def _make_tracer_class():
             else:
                 out.L0 = out.M0 = out.N0 = None
             if polarized:
-                real = prt.t().reshape(n, 3, 3)
-                cd = torch.complex64 if dtype == torch.float32 else torch.complex128
-                out.p = real.to(cd)
+                out.p = prt_to_complex(prt)
                 out._i0, out._L0, out._M0, out._N0 = i0, *k_init
                 if update_intensity:  # real_ray_tracer.py:112-113
                     out.i = eng.polarized_intensity(prt, k_init, i0,

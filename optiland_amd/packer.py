@@ -217,11 +217,22 @@ def _pack_aperture(ap, row, coeffs: list):
         coeffs.extend(float(v) for v in t)
 
 
-def _pack_coating(coating, row):
+def _pack_coating(coating, row, coeffs: list):
     row["coating_kind"] = S.COAT_NONE
     if coating is None:
         return
     name = type(coating).__name__
+    if name == "PolarizerCoating":
+        row["coating_kind"] = S.COAT_POLARIZER
+        row["coat"] = [float(len(coeffs)), 0.0]
+        coeffs.extend(float(v) for v in _to_np(coating.jones.axis).reshape(-1))
+        return
+    if name == "RetarderCoating":
+        row["coating_kind"] = S.COAT_RETARDER
+        row["coat"] = [float(len(coeffs)), 0.0]
+        coeffs.extend(float(v) for v in _to_np(coating.jones.axis).reshape(-1))
+        coeffs.append(_f(coating.jones.retardance))
+        return
     if name == "SimpleCoating":
         row["coating_kind"] = S.COAT_SIMPLE
         row["coat"] = [_f(coating.transmittance), _f(coating.reflectance)]
@@ -273,7 +284,7 @@ def pack_optic(optic, wavelengths=None, name: str | None = None) -> SystemTable:
             raise UnsupportedSystem("BSDF scatter is not on the fused path")
         _pack_geometry(geom, row, coeffs)
         _pack_aperture(surf.aperture, row, coeffs)
-        _pack_coating(surf.coating, row)
+        _pack_coating(surf.coating, row, coeffs)
         if i == 0:
             # ObjectSurface.trace only records (surfaces/object_surface.py:56-93)
             row["interaction"] = S.INTERACT_RECORD_ONLY

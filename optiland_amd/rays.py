@@ -36,10 +36,11 @@ class RealRays:
 class PolarizedRays(RealRays):
     """Rays carrying the 3x3 polarisation ray-tracing matrix.
 
-    On device the matrix is REAL, stored as nine planes (9, N) (for
-    uncoated / Fresnel surfaces the imaginary part is identically zero unless the
-    ray already went NaN through total internal reflection).  `.p` materialises
-    the reference's (N, 3, 3) complex layout on demand.
+    On device the matrix is stored as planes: nine REAL ones (9, N) for uncoated /
+    Fresnel / simple / polarizer surfaces (the imaginary part is
+    identically zero unless the ray already went NaN through total internal
+    reflection), eighteen (real then imaginary) when the system holds a retarder.
+    `.p` materialises the reference's (N, 3, 3) complex layout on demand.
     """
 
     def __init__(self, x, y, z, L, M, N, intensity, wavelength, opd=None, *, engine=None,
@@ -52,21 +53,35 @@ class PolarizedRays(RealRays):
 
     @property
     def p(self) -> torch.Tensor:
-        n = self._prt.shape[1]
-        real = self._prt.t().reshape(n, 3, 3)
-        cdtype = torch.complex64 if real.dtype == torch.float32 else torch.complex128
-        out = real.to(cdtype)
-        # a NaN real part means the reference's complex entry is NaN+NaNj
-        nanmask = torch.isnan(real)
-        if nanmask.any():
-            out[nanmask] = complex(float("nan"), float("nan"))
-        return out
+        return prt_to_complex(self._prt)
 
     def update_intensity(self, state) -> None:
         """rays/polarized_rays.py:122-133 on device (`state`: dict, reference
         PolarizationState, or None for unpolarised)."""
         self.i = self._engine.polarized_intensity(
             self._prt, (self._L0, self._M0, self._N0), self._i0, _state_dict(state))
+
+
+def new_prt(n: int, dtype, device, complex_: bool) -> torch.Tensor:
+    """Identity PRT planes: (9, n) real, or (18, n) real + imaginary."""
+    prt = torch.zeros((18 if complex_ else 9, n), dtype=dtype, device=device)
+    prt[0].fill_(1), prt[4].fill_(1), prt[8].fill_(1)
+    return prt
+
+
+def prt_to_complex(prt: torch.Tensor) -> torch.Tensor:
+    """(9|18, n) device planes -> the reference's (n, 3, 3) complex layout."""
+    n = prt.shape[1]
+    real = prt[:9].t().reshape(n, 3, 3)
+    cdtype = torch.complex64 if real.dtype == torch.float32 else torch.complex128
+    if prt.shape[0] == 18:
+        return torch.complex(real.contiguous(), prt[9:].t().reshape(n, 3, 3).contiguous())
+    out = real.to(cdtype)
+    # a NaN real part means the reference's complex entry is NaN+NaNj
+    nanmask = torch.isnan(real)
+    if nanmask.any():
+        out[nanmask] = complex(float("nan"), float("nan"))
+    return out
 
 
 def _state_dict(state):

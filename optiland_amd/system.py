@@ -28,7 +28,7 @@ INTERACT_RECORD_ONLY, INTERACT_REFRACT, INTERACT_REFLECT = 0, 1, 2
 AP_NONE, AP_RADIAL, AP_OFFSET_RADIAL, AP_RECTANGULAR, AP_ELLIPTICAL = 0, 1, 2, 3, 4
 AP_COMPOSITE = 5
 AP_OP_UNION, AP_OP_INTERSECTION, AP_OP_DIFFERENCE = 10, 11, 12
-COAT_NONE, COAT_SIMPLE, COAT_FRESNEL = 0, 1, 2
+COAT_NONE, COAT_SIMPLE, COAT_FRESNEL, COAT_POLARIZER, COAT_RETARDER = 0, 1, 2, 3, 4
 SURF_ROTATED = 0x1
 
 STATUS_ZERNIKE_RANGE = 0x1
@@ -37,6 +37,7 @@ STATUS_CHEBYSHEV_RANGE = 0x4
 
 TRACE_WRITE_RAYS = 0x1
 TRACE_COMPACT = 0x2
+TRACE_PRT_COMPLEX = 0x4
 
 GEOM_NAMES = {
     GEOM_PLANE: "plane",
@@ -134,7 +135,13 @@ class SystemTable:
 
     @property
     def uses_polarization(self) -> bool:
-        return bool(np.any(self.surfaces["coating_kind"] == COAT_FRESNEL))
+        """Any polarization-dependent coating (SurfaceGroup.uses_polarization)."""
+        return bool(np.any(self.surfaces["coating_kind"] >= COAT_FRESNEL))
+
+    @property
+    def needs_complex_prt(self) -> bool:
+        """Retarder coatings have a complex Jones matrix (jones.py:331-393)."""
+        return bool(np.any(self.surfaces["coating_kind"] == COAT_RETARDER))
 
     def wavelength_index(self, wavelength: float) -> int:
         """Index of `wavelength` in the table (exact match on the packed value)."""

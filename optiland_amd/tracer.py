@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from .distribution import Distribution, create_distribution
-from .rays import PolarizedRays, RealRays, _state_dict
+from .rays import PolarizedRays, RealRays, _state_dict, new_prt
 from .system import SystemTable
 
 
@@ -135,8 +135,7 @@ class HipRayTracer:
         prt = None
         k_init = i0 = None
         if polarized:
-            prt = torch.zeros((9, n), dtype=self.dtype, device=self.device)
-            prt[0].fill_(1), prt[4].fill_(1), prt[8].fill_(1)
+            prt = new_prt(n, self.dtype, self.device, self.table.needs_complex_prt)
             k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
             i0 = rays[6].clone()
         res = eng.trace(rays, wl, record=self.record_all, prt=prt)

@@ -533,10 +533,11 @@ static double norm3(const double* a) {
   return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
 }
 
-static void prt_update(rays_t* r, int64_t j, const double complex* jones /*3 diag or NULL*/) {
-  double k0[3] = {r->L0[j], r->M0[j], r->N0[j]};
-  double k1[3] = {r->L[j], r->M[j], r->N[j]};
-  double s[3], p0[3], p1[3];
+/* local basis of rays/polarized_rays.py:136-178 for ray j */
+static void local_basis(const rays_t* r, int64_t j, double* s, double* p0, double* p1,
+                        double* k0, double* k1) {
+  k0[0] = r->L0[j]; k0[1] = r->M0[j]; k0[2] = r->N0[j];
+  k1[0] = r->L[j]; k1[1] = r->M[j]; k1[2] = r->N[j];
   cross3(k0, k1, s);
   double mag = norm3(s);
   if (mag == 0.0) { /* k0 parallel k1 (NaN != 0, falls through like numpy) */
@@ -549,20 +550,30 @@ static void prt_update(rays_t* r, int64_t j, const double complex* jones /*3 dia
   for (int a = 0; a < 3; ++a) s[a] /= mag;
   cross3(k0, s, p0);
   cross3(k1, s, p1);
+}
+
+/* PolarizedRays.update (polarized_rays.py:180-202) with a full 3x3 Jones matrix
+ * J (row-major) or J = NULL for the identity.                                 */
+static void prt_update(rays_t* r, int64_t j, const double complex* J) {
+  double s[3], p0[3], p1[3], k0[3], k1[3];
+  local_basis(r, j, s, p0, p1, k0, k1);
   /* o_in rows (s, p0, k0); o_out columns (s, p1, k1) */
   double oin[3][3], oout[3][3];
   for (int a = 0; a < 3; ++a) {
     oin[0][a] = s[a]; oin[1][a] = p0[a]; oin[2][a] = k0[a];
     oout[a][0] = s[a]; oout[a][1] = p1[a]; oout[a][2] = k1[a];
   }
-  double complex P[3][3];
+  double complex JO[3][3], P[3][3];
   for (int a = 0; a < 3; ++a)
     for (int b = 0; b < 3; ++b) {
       double complex acc = 0;
-      for (int c = 0; c < 3; ++c) {
-        double complex jc = jones ? jones[c] : 1.0;
-        acc += oout[a][c] * jc * oin[c][b];
-      }
+      for (int c = 0; c < 3; ++c) acc += (J ? J[3 * a + c] : (a == c ? 1.0 : 0.0)) * oin[c][b];
+      JO[a][b] = acc;
+    }
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      double complex acc = 0;
+      for (int c = 0; c < 3; ++c) acc += oout[a][c] * JO[c][b];
       P[a][b] = acc;
     }
   double complex* p = r->p + 9 * j;
@@ -574,6 +585,35 @@ static void prt_update(rays_t* r, int64_t j, const double complex* jones /*3 dia
       q[3 * a + b] = acc;
     }
   memcpy(p, q, sizeof(q));
+}
+
+/* jones.py:120-181 (linear polarizer) and jones.py:331-393 (linear retarder) */
+static void axis_jones(const rays_t* r, int64_t j, const double* axis, int retarder,
+                       double d, double complex* J) {
+  double s[3], p0[3], p1[3], k0[3], k1[3];
+  local_basis(r, j, s, p0, p1, k0, k1);
+  double ts_in = axis[0] * s[0] + axis[1] * s[1] + axis[2] * s[2];
+  double tp_in = axis[0] * p0[0] + axis[1] * p0[1] + axis[2] * p0[2];
+  double norm_in = sqrt(ts_in * ts_in + tp_in * tp_in);
+  if (norm_in == 0) norm_in = 1.0;
+  double us_in = ts_in / norm_in, up_in = tp_in / norm_in;
+  for (int a = 0; a < 9; ++a) J[a] = 0;
+  if (retarder) {
+    double complex em = cexp(-I * d / 2), ep = cexp(I * d / 2);
+    J[0] = em * us_in * us_in + ep * up_in * up_in;
+    J[1] = -2.0 * I * sin(d / 2) * us_in * up_in;
+    J[3] = J[1];
+    J[4] = ep * us_in * us_in + em * up_in * up_in;
+  } else {
+    double ts_out = ts_in;
+    double tp_out = axis[0] * p1[0] + axis[1] * p1[1] + axis[2] * p1[2];
+    double norm_out = sqrt(ts_out * ts_out + tp_out * tp_out);
+    if (norm_out == 0) norm_out = 1.0;
+    double us_out = ts_out / norm_out, up_out = tp_out / norm_out;
+    J[0] = us_out * us_in; J[1] = us_out * up_in;
+    J[3] = up_out * us_in; J[4] = up_out * up_in;
+  }
+  J[8] = 1.0;
 }
 
 /* ---- one surface, whole batch: standard_surface.py:200-274 ----------------- */
@@ -639,16 +679,23 @@ static void trace_surface(const ol_surface_desc* s, const double* coeffs,
       double cosi = cos(aoi);
       double nn = o->n2 / o->n1;
       double complex root = csqrt((double complex)(nn * nn - sin(aoi) * sin(aoi)));
-      double complex J[3];
+      double complex J[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       if (s->interaction == OL_INTERACT_REFLECT) {
         double complex sj = (cosi - root) / (cosi + root);
         double complex pj = (nn * nn * cosi - root) / (nn * nn * cosi + root);
-        J[0] = sj; J[1] = -pj; J[2] = -1.0;
+        J[0] = sj; J[4] = -pj; J[8] = -1.0;
       } else {
         double complex sj = 2 * cosi / (cosi + root);
         double complex pj = 2 * nn * cosi / (nn * nn * cosi + root);
-        J[0] = sj; J[1] = pj; J[2] = 1.0;
+        J[0] = sj; J[4] = pj; J[8] = 1.0;
       }
+      prt_update(r, j, J);
+    } else if ((s->coating_kind == OL_COAT_POLARIZER || s->coating_kind == OL_COAT_RETARDER) &&
+               r->p) {
+      const double* ax = coeffs + (int)s->coat[0];
+      double complex J[9];
+      axis_jones(r, j, ax, s->coating_kind == OL_COAT_RETARDER,
+                 s->coating_kind == OL_COAT_RETARDER ? ax[3] : 0.0, J);
       prt_update(r, j, J);
     } else if (r->p) {
       prt_update(r, j, NULL); /* rays.update() with no Jones matrix */

@@ -35,7 +35,7 @@ class OracleEngine:
         n = int(rays[0].numel())
         dtype = rays[0].dtype
         last = self.num_surfaces - 1 if last is None else last
-        if prt is None and any(self.table.surfaces["coating_kind"][first:last + 1] == S.COAT_FRESNEL):
+        if prt is None and any(self.table.surfaces["coating_kind"][first:last + 1] >= S.COAT_FRESNEL):
             raise ValueError("Polarization must be set when surfaces have "
                              "polarization-dependent coatings.")
         d = {k: rays[j].double().numpy() for j, k in enumerate(PLANES)}
@@ -61,10 +61,14 @@ class OracleEngine:
             for j, k in enumerate(PLANES):
                 rays[j].copy_(torch.as_tensor(out[k], dtype=dtype))
         if prt is not None:
-            p = out["prt"]  # (n,3,3) complex; started from identity -> multiply in
-            start = prt.t().reshape(n, 3, 3).double().numpy()
-            newp = np.einsum("nij,njk->nik", p.real, start)
-            prt.copy_(torch.as_tensor(newp.reshape(n, 9).T.copy(), dtype=dtype))
+            p = out["prt"]  # (n,3,3) complex; oracle started from identity -> multiply in
+            start = prt[:9].t().reshape(n, 3, 3).double().numpy().astype(np.complex128)
+            if prt.shape[0] == 18:
+                start = start + 1j * prt[9:].t().reshape(n, 3, 3).double().numpy()
+            newp = np.einsum("nij,njk->nik", p, start)
+            prt[:9].copy_(torch.as_tensor(newp.real.reshape(n, 9).T.copy(), dtype=dtype))
+            if prt.shape[0] == 18:
+                prt[9:].copy_(torch.as_tensor(newp.imag.reshape(n, 9).T.copy(), dtype=dtype))
         return TraceResult(n, rays, rec, prt, out["status"], first, last)
 
     def generate_rays(self, hx, hy, px, py, vx=None, vy=None):
@@ -74,7 +78,9 @@ class OracleEngine:
 
     def polarized_intensity(self, prt, k0, i0, polarization):
         n = int(i0.numel())
-        p = prt.t().reshape(n, 3, 3).double().numpy().astype(np.complex128)
+        p = prt[:9].t().reshape(n, 3, 3).double().numpy().astype(np.complex128)
+        if prt.shape[0] == 18:
+            p = p + 1j * prt[9:].t().reshape(n, 3, 3).double().numpy()
         out, status = oracle.polarized_intensity(p, *[k.double().numpy() for k in k0],
                                                  i0.double().numpy(), polarization)
         if status & S.STATUS_K_PARALLEL_X:

@@ -63,7 +63,8 @@ def test_record_matches_reference(hip, case, dtype):
     n = rays[0].numel()
     prt = None
     if polarized:
-        prt = torch.eye(3, dtype=dtype, device="cuda:0").reshape(9, 1).repeat(1, n).contiguous()
+        from optiland_amd.rays import new_prt
+        prt = new_prt(n, dtype, "cuda:0", table.needs_complex_prt)
     res = sysm.trace(rays, 0, record=True, prt=prt)
     got = res.record[:, :, :n].double().cpu().numpy()
     tol = TOL[dtype]
@@ -84,10 +85,12 @@ def test_record_matches_reference(hip, case, dtype):
         assert_close_planes(got, conv, tight, tight, f"{case}:tight-vs-converged-oracle")
         assert np.array_equal(got[:, 6, :] == 0, data["record"][:, 6, :] == 0)
     if polarized:
-        p = prt.double().cpu().numpy().T.reshape(n, 3, 3)
+        from optiland_amd.rays import prt_to_complex
+        p = prt_to_complex(prt).cpu().numpy().astype(np.complex128)
         want = data["prt"]
-        assert np.abs(want.imag).max() == 0.0 or np.isnan(want.imag).any()
-        np.testing.assert_allclose(p, want.real, rtol=tol, atol=tol)
+        if not table.needs_complex_prt:
+            assert np.abs(want.imag).max() == 0.0 or np.isnan(want.imag).any()
+        np.testing.assert_allclose(p, want, rtol=tol, atol=tol)
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
@@ -115,15 +118,18 @@ def test_writeback_equals_last_row_and_partial_ranges(hip, case, dtype):
     assert_close_planes(got[None], want[None], tol * 1e-2, tol * 1e-2, f"{case}:split")
 
 
-@pytest.mark.parametrize("case", [c for c in golden_cases() if "fresnel" in c])
+@pytest.mark.parametrize("case", golden_cases())
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 def test_polarized_intensity_epilogue(hip, case, dtype):
     sysm, table, data = hip(case)
+    if "prt" not in data:
+        pytest.skip("not a polarised case")
+    from optiland_amd.rays import new_prt
     rays = _device_rays(data, dtype)
     n = rays[0].numel()
     k0 = [rays[3].clone(), rays[4].clone(), rays[5].clone()]
     i0 = rays[6].clone()
-    prt = torch.eye(3, dtype=dtype, device="cuda:0").reshape(9, 1).repeat(1, n).contiguous()
+    prt = new_prt(n, dtype, "cuda:0", table.needs_complex_prt)
     sysm.trace(rays, 0, record=False, prt=prt)
     got = sysm.polarized_intensity(prt, k0, i0, table.polarization).double().cpu().numpy()
     tol = TOL[dtype]
@@ -189,6 +195,16 @@ def test_zernike_range_raises(hip):
     rays[0] += 40.0  # far outside norm_radius = 15
     with pytest.raises(ValueError, match="Zernike coordinates must be normalized"):
         sysm.trace(rays, 0, record=False)
+
+
+def test_retarder_needs_complex_prt(hip):
+    from optiland_amd._capi import HipExtensionError
+    from optiland_amd.rays import new_prt
+    sysm, table, data = hip("polarizer_retarder")
+    rays = _device_rays(data, torch.float64)
+    prt = new_prt(rays[0].numel(), torch.float64, "cuda:0", False)  # 9 planes only
+    with pytest.raises(HipExtensionError, match="retarder"):
+        sysm.trace(rays, 0, record=False, prt=prt)
 
 
 def test_fresnel_without_polarized_rays_raises(hip):

@@ -141,3 +141,13 @@ def test_spot_diagram_reproduces_reference_goldens_host_logic():
     np.testing.assert_allclose(spot.geometric_spot_radius(), COOKE_GEO, rtol=1e-5)
     c = SpotDiagram(t, reference="centroid")
     assert np.all(np.array(c.rms_spot_radius()) <= np.array(spot.rms_spot_radius()) + 1e-12)
+
+
+def test_polarizer_and_retarder_system_through_the_tracer():
+    """Host logic with a complex PRT (18 planes): trace() applies update_intensity."""
+    table, data = load_case("polarizer_retarder")
+    assert table.needs_complex_prt
+    t = tr.HipRayTracer(table, dtype=torch.float64)
+    rays = t.trace([0.0, 0.0], [0.0, 1.0], 0.55, num_rays=20, distribution="uniform")
+    np.testing.assert_allclose(rays.p.numpy(), data["prt"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(rays.i.numpy(), data["i_updated"], rtol=1e-10)

@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Print the measured parity margins of the HIP path on every golden case:
+max |got - want| / scale per plane group, fp32 and fp64 (needs a GPU)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from optiland_amd.engine import HipSystem  # noqa: E402
+from tests._util import golden_cases, load_case  # noqa: E402
+
+GROUPS = {"pos": (0, 1, 2), "dir": (3, 4, 5), "i": (6,), "opd": (7,)}
+print(f"{'case':28s} {'dtype':5s} " + " ".join(f"{g:>9s}" for g in GROUPS))
+for case in golden_cases():
+    table, data = load_case(case)
+    hip = HipSystem(table, "cuda:0")
+    want = data["record"]
+    n = want.shape[2]
+    for dtype in (torch.float32, torch.float64):
+        rays = [torch.tensor(data["rays_in"][k], dtype=dtype, device="cuda:0") for k in range(7)]
+        rays.append(torch.zeros(n, dtype=dtype, device="cuda:0"))
+        prt = None
+        if "prt" in data:
+            prt = torch.eye(3, dtype=dtype, device="cuda:0").reshape(9, 1).repeat(1, n).contiguous()
+        got = hip.trace(rays, 0, record=True, prt=prt).record[:, :, :n].double().cpu().numpy()
+        errs = []
+        for g, idx in GROUPS.items():
+            w, o = want[:, idx, :], got[:, idx, :]
+            fin = np.isfinite(w)
+            scale = np.abs(w[fin]).max() if fin.any() else 1.0
+            errs.append(np.abs(o[fin] - w[fin]).max() / scale if fin.any() else 0.0)
+        print(f"{case:28s} {'f32' if dtype == torch.float32 else 'f64':5s} "
+              + " ".join(f"{e:9.2e}" for e in errs))
+    hip.close()

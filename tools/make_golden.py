@@ -29,7 +29,8 @@ import numpy as np  # noqa: E402
 import optiland.backend as be  # noqa: E402
 from optiland import optic as optic_mod  # noqa: E402
 from optiland import physical_apertures  # noqa: E402
-from optiland.coatings import SimpleCoating  # noqa: E402
+from optiland.coatings import (FresnelCoating, PolarizerCoating, RetarderCoating,  # noqa: E402
+                               SimpleCoating)
 from optiland.rays import PolarizationState  # noqa: E402
 from optiland.samples.objectives import CookeTriplet, DoubleGauss  # noqa: E402
 from optiland.samples.simple import AsphericSinglet  # noqa: E402
@@ -189,6 +190,38 @@ def f3_family():
     return lens
 
 
+def polarizer_retarder(with_retarder=True):
+    """f3 Jones elements: linear polarizer plate, (tilted) quarter-wave-ish retarder
+    plate, then a Fresnel-coated singlet; fully polarised input state."""
+    lens = optic_mod.Optic(name="PolarizerRetarder")
+    lens.surfaces.add(index=0, radius=be.inf, thickness=be.inf)
+    lens.surfaces.add(index=1, radius=be.inf, thickness=2.0, is_stop=True,
+                      coating=PolarizerCoating(axis=(1.0, 0.6, 0.0)))
+    if with_retarder:
+        lens.surfaces.add(index=2, radius=be.inf, thickness=3.0, rx=0.12, material="N-BK7",
+                          coating=RetarderCoating(retardance=1.3, axis=(0.2, 1.0, 0.1)))
+        lens.surfaces.add(index=3, radius=be.inf, thickness=2.0, rx=0.12,
+                          coating=PolarizerCoating(axis=(0.0, 1.0, 0.0)))
+    else:
+        lens.surfaces.add(index=2, radius=be.inf, thickness=3.0, rx=0.12, material="N-BK7")
+        lens.surfaces.add(index=3, radius=be.inf, thickness=2.0, rx=0.12,
+                          coating=PolarizerCoating(axis=(0.3, 1.0, 0.0)))
+    lens.surfaces.add(index=4, radius=35.0, thickness=5.0, material="N-SF11")
+    lens.surfaces.add(index=5, radius=-80.0, thickness=30.0)
+    lens.surfaces.add(index=6)
+    for i in (4, 5):
+        s_ = lens.surfaces[i]
+        s_.coating = FresnelCoating(s_.material_pre, s_.material_post)
+    lens.set_aperture(aperture_type="EPD", value=12)
+    lens.fields.set_type(field_type="angle")
+    lens.fields.add(y=0)
+    lens.fields.add(y=5)
+    lens.wavelengths.add(value=0.55, is_primary=True)
+    lens.updater.set_polarization(PolarizationState(is_polarized=True, Ex=1.0, Ey=0.3,
+                                                    phase_x=0.0, phase_y=0.4))
+    return lens
+
+
 def tir_prism():
     """Edge case: steep glass->air exit so part of the bundle is totally internally
     reflected (NaN directions, real_rays.py:179-180) and part misses a small
@@ -338,6 +371,9 @@ def main():
     run_case("tir_miss", tir_prism(), 0.0, 1.0, px, py, 0.55)
     run_case("boolean_apertures", boolean_apertures(), 0.0, 0.5, px, py, 0.55)
     run_case("f3_family", f3_family(), 0.0, 1.0, px, py, 0.5876)
+    run_case("polarizer_retarder", polarizer_retarder(True), [0.0, 0.0], [0.0, 1.0], None, None,
+             0.55, use_trace=dict(num_rays=20, distribution="uniform"))
+    run_case("polarizer_only", polarizer_retarder(False), 0.0, 1.0, px, py, 0.55)
 
 
 if __name__ == "__main__":
