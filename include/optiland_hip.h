@@ -267,6 +267,29 @@ int ol_spot_max_r2(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
                    const void* intensity, double cx, double cy, double* out1,
                    void* stream);
 
+/* Wavefront OPD against a spherical reference centred on the chief-ray image point
+ * (wavefront/strategy.py:163-215 ChiefRayStrategy.
+ * compute_wavefront_data, wavefront/reference_geometry.py:41-79
+ * SphericalReference.path_length, strategy.py:83-139 _correct_tilt).  Per ray:
+ *   t       = back-propagation distance from the image point to the sphere,
+ *   opd_img = n_image * t,  opd = ray_opd - opd_img + (ux X + uy Y),
+ *             X = px * half_epd, Y = py * half_epd,
+ *   opd_waves = (opd_ref - opd) / (wavelength_um * 1e-3),
+ *   pupil    = r - t * k  (optional).
+ * rays[7]: x,y,z,L,M,N,opd at the image surface.  Meant for fp64 traces.       */
+typedef struct ol_wavefront_params {
+  double xc, yc, zc, R;  /* reference sphere                                      */
+  double n_image;        /* index of image space at the primary wavelength       */
+  double opd_ref;        /* chief-ray OPD to the sphere (tilt-corrected)          */
+  double ux, uy;         /* launch-plane tilt direction cosines (0 when n/a)      */
+  double half_epd;
+  double wavelength_um;
+} ol_wavefront_params;
+
+int ol_wavefront_opd(const ol_wavefront_params* p, ol_dtype dt, int64_t n_rays,
+                     const void* const rays[7], const void* px, const void* py,
+                     void* opd_waves, void* const pupil[3], void* stream);
+
 /* Profiling knobs (process-wide, not part of the trace semantics).
  *   OL_TUNE_RAYS_PER_THREAD  0 = auto (16-byte vector of rays per lane for conic-only
  *                            ranges, one ray per lane when Newton surfaces are

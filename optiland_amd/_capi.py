@@ -57,6 +57,11 @@ class RaygenParams(C.Structure):
     ]
 
 
+class WavefrontParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("xc", "yc", "zc", "R", "n_image", "opd_ref", "ux",
+                                          "uy", "half_epd", "wavelength_um")]
+
+
 class PolarizationStateC(C.Structure):
     _fields_ = [
         ("is_polarized", C.c_int32),
@@ -80,6 +85,7 @@ EXPORTS = (
     "ol_spot_moments",
     "ol_spot_max_r2",
     "ol_set_tuning",
+    "ol_wavefront_opd",
 )
 
 F32, F64 = 0, 1
@@ -130,6 +136,8 @@ def load():
     lib.ol_spot_moments.argtypes = [C.c_int, i64, vp, vp, vp, vp, vp]
     lib.ol_spot_max_r2.restype = C.c_int
     lib.ol_spot_max_r2.argtypes = [C.c_int, i64, vp, vp, vp, C.c_double, C.c_double, vp, vp]
+    lib.ol_wavefront_opd.restype = C.c_int
+    lib.ol_wavefront_opd.argtypes = [vp, C.c_int, i64, C.POINTER(vp), vp, vp, vp, vp, vp]
     lib.ol_set_tuning.restype = C.c_int
     lib.ol_set_tuning.argtypes = [i32, i32]
     if lib.ol_abi_version() != ABI_VERSION:

@@ -158,6 +158,52 @@ hipError_t launch_pol_intensity(int64_t n, const T* prt, bool prt_complex, const
   return hipGetLastError();
 }
 
+// wavefront/strategy.py:163-215 + reference_geometry.py:41-79: OPD in waves against
+// the chief-ray reference sphere.  Streaming elementwise (9 planes in, 1-4 out).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void wavefront_kernel(
+    WavefrontDev p, int64_t n, const T* __restrict__ x, const T* __restrict__ y,
+    const T* __restrict__ z, const T* __restrict__ Ld, const T* __restrict__ Md,
+    const T* __restrict__ Nd, const T* __restrict__ opd_in, const T* __restrict__ px,
+    const T* __restrict__ py, T* opd_waves, T* pux, T* puy, T* puz) {
+  const T xc = (T)p.xc, yc = (T)p.yc, zc = (T)p.zc, R = (T)p.R, ni = (T)p.n_image;
+  const T inv_w = (T)(1.0 / (p.wavelength_um * 1e-3));
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * kBlock) {
+    const T xr = x[j], yr = y[j], zr = z[j];
+    const T L = -Ld[j], M = -Md[j], N = -Nd[j];  // trace backwards from the image
+    const T a = L * L + M * M + N * N;
+    const T b = T(2) * (L * (xr - xc) + M * (yr - yc) + N * (zr - zc));
+    const T c = xr * xr + yr * yr + zr * zr - T(2) * (xr * xc + yr * yc + zr * zc) + xc * xc +
+                yc * yc + zc * zc - R * R;
+    T d = b * b - T(4) * a * c;
+    d = d < T(0) ? T(0) : d;
+    const T sq = sqrt(d);
+    const T t1 = (-b - sq) / (T(2) * a), t2 = (-b + sq) / (T(2) * a);
+    const T t = t1 < T(0) ? t2 : t1;
+    const T opd_img = ni * t;
+    const T tilt = (T)p.ux * (px[j] * (T)p.half_epd) + (T)p.uy * (py[j] * (T)p.half_epd);
+    const T opd = opd_in[j] - opd_img + tilt;
+    opd_waves[j] = ((T)p.opd_ref - opd) * inv_w;
+    if (pux) {
+      const T tt = opd_img / ni;
+      pux[j] = xr - tt * Ld[j];
+      puy[j] = yr - tt * Md[j];
+      puz[j] = zr - tt * Nd[j];
+    }
+  }
+}
+
+template <typename T>
+hipError_t launch_wavefront(const WavefrontDev& p, int64_t n, const T* const rays[7], const T* px,
+                            const T* py, T* opd_waves, T* const pupil[3], hipStream_t stream) {
+  hipLaunchKernelGGL((wavefront_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, stream, p, n,
+                     rays[0], rays[1], rays[2], rays[3], rays[4], rays[5], rays[6], px, py,
+                     opd_waves, pupil ? pupil[0] : nullptr, pupil ? pupil[1] : nullptr,
+                     pupil ? pupil[2] : nullptr);
+  return hipGetLastError();
+}
+
 // wave-level sum via DPP-free shuffles (64 lanes), then one atomic per wave
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -258,6 +304,8 @@ hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten,
   template hipError_t launch_pol_intensity<T>(int64_t, const T*, bool, const T* const[3],      \
                                               const T*, const PolStateDev&, T*, uint32_t*,     \
                                               hipStream_t);                                    \
+  template hipError_t launch_wavefront<T>(const WavefrontDev&, int64_t, const T* const[7],     \
+                                          const T*, const T*, T*, T* const[3], hipStream_t);   \
   template hipError_t launch_spot_moments<T>(int64_t, const T*, const T*, const T*, double*,   \
                                              hipStream_t);                                     \
   template hipError_t launch_spot_max_r2<T>(int64_t, const T*, const T*, const T*, double,     \

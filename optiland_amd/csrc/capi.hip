@@ -576,6 +576,42 @@ int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt, int32_t
   return OL_OK;
 }
 
+int ol_wavefront_opd(const ol_wavefront_params* p, ol_dtype dt, int64_t n_rays,
+                     const void* const rays[7], const void* px, const void* py,
+                     void* opd_waves, void* const pupil[3], void* stream) {
+  if (!p || !rays || !px || !py || !opd_waves)
+    return fail(OL_EINVAL, "ol_wavefront_opd: NULL argument");
+  if (n_rays < 0) return fail(OL_EINVAL, "ol_wavefront_opd: negative count");
+  if (n_rays == 0) return OL_OK;
+  for (int k = 0; k < 7; ++k)
+    if (!rays[k]) return fail(OL_EINVAL, "ol_wavefront_opd: rays[%d] is NULL", k);
+  if (pupil && (!pupil[0] || !pupil[1] || !pupil[2]))
+    return fail(OL_EINVAL, "ol_wavefront_opd: pupil planes must all be given or pupil = NULL");
+  ol::WavefrontDev d{p->xc, p->yc, p->zc, p->R, p->n_image, p->opd_ref,
+                     p->ux, p->uy, p->half_epd, p->wavelength_um};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (dt == OL_F32) {
+    const float* r[7];
+    for (int k = 0; k < 7; ++k) r[k] = static_cast<const float*>(rays[k]);
+    float* pu[3] = {pupil ? (float*)pupil[0] : nullptr, pupil ? (float*)pupil[1] : nullptr,
+                    pupil ? (float*)pupil[2] : nullptr};
+    e = ol::launch_wavefront<float>(d, n_rays, r, (const float*)px, (const float*)py,
+                                    (float*)opd_waves, pupil ? pu : nullptr, st);
+  } else if (dt == OL_F64) {
+    const double* r[7];
+    for (int k = 0; k < 7; ++k) r[k] = static_cast<const double*>(rays[k]);
+    double* pu[3] = {pupil ? (double*)pupil[0] : nullptr, pupil ? (double*)pupil[1] : nullptr,
+                     pupil ? (double*)pupil[2] : nullptr};
+    e = ol::launch_wavefront<double>(d, n_rays, r, (const double*)px, (const double*)py,
+                                     (double*)opd_waves, pupil ? pu : nullptr, st);
+  } else {
+    return fail(OL_EINVAL, "ol_wavefront_opd: bad dtype %d", (int)dt);
+  }
+  if (e != hipSuccess) return fail(OL_EHIP, "launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
 int ol_spot_moments(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
                     const void* intensity, double* out6, void* stream) {
   if (!x || !y || !intensity || !out6) return fail(OL_EINVAL, "ol_spot_moments: NULL argument");

@@ -62,6 +62,14 @@ hipError_t launch_pol_intensity(int64_t n, const T* prt, bool prt_complex, const
                                 const PolStateDev& st, T* intensity, uint32_t* status,
                                 hipStream_t stream);
 
+struct WavefrontDev {
+  double xc, yc, zc, R, n_image, opd_ref, ux, uy, half_epd, wavelength_um;
+};
+
+template <typename T>
+hipError_t launch_wavefront(const WavefrontDev& p, int64_t n, const T* const rays[7], const T* px,
+                            const T* py, T* opd_waves, T* const pupil[3], hipStream_t stream);
+
 template <typename T>
 hipError_t launch_spot_moments(int64_t n, const T* x, const T* y, const T* inten, double* out6,
                                hipStream_t stream);

@@ -216,6 +216,23 @@ class HipSystem:
             raise ValueError("k-vector parallel to x-axis is not currently supported.")
         return out
 
+    def wavefront_opd(self, params: dict, rays7, px, py, want_pupil: bool = True):
+        """OPD in waves (+ pupil coordinates) against the chief-ray reference sphere."""
+        n = int(px.numel())
+        dtype = px.dtype
+        p = _capi.WavefrontParams(**{k: float(params[k]) for k, _ in
+                                     _capi.WavefrontParams._fields_})
+        opd = torch.empty(n, dtype=dtype, device=self.device)
+        pupil = torch.empty((3, n), dtype=dtype, device=self.device) if want_pupil else None
+        rp = (C.c_void_p * 7)(*[t.data_ptr() for t in rays7])
+        pp = (C.c_void_p * 3)(*[pupil[k].data_ptr() for k in range(3)]) if want_pupil else None
+        with torch.cuda.device(self.device):
+            rc = self.lib.ol_wavefront_opd(C.byref(p), _DT[dtype], n, rp, px.data_ptr(),
+                                           py.data_ptr(), opd.data_ptr(), pp,
+                                           _stream_ptr(self.device))
+        _capi.check(rc, "ol_wavefront_opd")
+        return opd, pupil
+
     def spot_moments(self, x, y, intensity):
         """Device reduction: returns float64 tensor [count, sx, sy, sxx, syy, count]."""
         out = torch.zeros(6, dtype=torch.float64, device=self.device)

@@ -371,3 +371,10 @@ def _pack_raygen(optic, table: SystemTable) -> None:
     table.fields = [
         (_f(f.x), _f(f.y), _f(f.vx), _f(f.vy)) for f in optic.fields.fields
     ]
+    # wavefront analysis (wavefront/strategy.py:157-160, 63): exit pupil z and the
+    # image-space index at the PRIMARY wavelength
+    try:
+        table.raygen["pupil_z"] = _f(optic.paraxial.XPL()) + float(pos[-1])
+        table.raygen["n_image"] = _f(optic.surfaces.n(optic.primary_wavelength)[-1])
+    except Exception:  # systems without a well-defined exit pupil: no wavefront data
+        pass

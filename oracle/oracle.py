@@ -154,3 +154,22 @@ def distance(table, surface_index, x, y, z, L, M, N):
     lib().oracle_distance(_ptr(surf), _ptr(coeffs), C.c_int64(a[0].size),
                           *[_ptr(v) for v in a], _ptr(t))
     return t
+
+
+class WavefrontParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("xc", "yc", "zc", "R", "n_image", "opd_ref", "ux",
+                                          "uy", "half_epd", "wavelength_um")]
+
+
+def wavefront_opd(params: dict, rays7, px, py):
+    """rays7: x,y,z,L,M,N,opd at the image surface.  Returns (opd_waves, pupil(3,n))."""
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in rays7]
+    px, py = (np.ascontiguousarray(v, dtype=np.float64) for v in (px, py))
+    n = a[0].size
+    p = WavefrontParams(**{k: float(params[k]) for k, _ in WavefrontParams._fields_})
+    out = np.zeros(n)
+    pupil = np.zeros((3, n))
+    rp = (C.c_void_p * 7)(*[_ptr(v) for v in a])
+    pp = (C.c_void_p * 3)(*[_ptr(pupil[k]) for k in range(3)])
+    lib().oracle_wavefront_opd(C.byref(p), C.c_int64(n), rp, _ptr(px), _ptr(py), _ptr(out), pp)
+    return out, pupil

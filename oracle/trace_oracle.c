@@ -815,6 +815,37 @@ uint32_t oracle_polarized_intensity(int64_t n, const double* prt, const double* 
   return status;
 }
 
+/* wavefront/strategy.py:163-215 (steps 4-5), reference_geometry.py:41-79,
+ * strategy.py:83-139.  rays[7]: x,y,z,L,M,N,opd at the image surface.           */
+void oracle_wavefront_opd(const ol_wavefront_params* p, int64_t n, double* const rays[7],
+                          const double* px, const double* py, double* opd_waves,
+                          double* const pupil[3]) {
+  for (int64_t j = 0; j < n; ++j) {
+    double xr = rays[0][j], yr = rays[1][j], zr = rays[2][j];
+    double L = -rays[3][j], M = -rays[4][j], N = -rays[5][j];
+    double xc = p->xc, yc = p->yc, zc = p->zc, R = p->R;
+    double a = L * L + M * M + N * N;
+    double b = 2 * (L * (xr - xc) + M * (yr - yc) + N * (zr - zc));
+    double c = xr * xr + yr * yr + zr * zr - 2 * (xr * xc + yr * yc + zr * zc) + xc * xc +
+               yc * yc + zc * zc - R * R;
+    double d = b * b - 4 * a * c;
+    if (d < 0) d = 0;
+    double t1 = (-b - sqrt(d)) / (2 * a), t2 = (-b + sqrt(d)) / (2 * a);
+    double t = t1 < 0 ? t2 : t1;
+    double opd_img = p->n_image * t;
+    double opd = rays[6][j] - opd_img;
+    double X_m = px[j] * p->half_epd, Y_m = py[j] * p->half_epd;
+    opd = opd + (p->ux * X_m + p->uy * Y_m);
+    opd_waves[j] = (p->opd_ref - opd) / (p->wavelength_um * 1e-3);
+    if (pupil) {
+      double tt = opd_img / p->n_image;
+      pupil[0][j] = xr - tt * rays[3][j];
+      pupil[1][j] = yr - tt * rays[4][j];
+      pupil[2][j] = zr - tt * rays[5][j];
+    }
+  }
+}
+
 /* single-point helpers for the reference's known-answer unit tests */
 double oracle_sag(const ol_surface_desc* s, const double* coeffs, double x, double y) {
   uint32_t st = 0;

@@ -87,6 +87,12 @@ class OracleEngine:
             raise ValueError("k-vector parallel to x-axis is not currently supported.")
         return torch.as_tensor(out, dtype=i0.dtype)
 
+    def wavefront_opd(self, params, rays7, px, py, want_pupil=True):
+        out, pupil = oracle.wavefront_opd(params, [t.double().numpy() for t in rays7],
+                                          px.double().numpy(), py.double().numpy())
+        return (torch.as_tensor(out, dtype=px.dtype),
+                torch.as_tensor(pupil, dtype=px.dtype) if want_pupil else None)
+
     def spot_moments(self, x, y, intensity):
         m = intensity > 0
         xd, yd = x[m].double(), y[m].double()

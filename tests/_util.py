@@ -18,6 +18,7 @@ def golden_cases():
     return sorted(
         os.path.splitext(os.path.basename(p))[0]
         for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
+        if os.path.exists(p[:-4] + ".json")  # trace cases only (wavefront.npz has no table)
     )
 
 

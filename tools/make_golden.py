@@ -326,6 +326,32 @@ def run_case(name, optic, Hx, Hy, Px, Py, wavelength, use_trace=None, save_json_
     return table
 
 
+def wavefront_goldens():
+    """f4: the reference's own OPD / FFT PSF numbers for two sample lenses."""
+    from optiland.psf import FFTPSF
+    from optiland.wavefront import OPD
+    out = {}
+    for tag, optic, field, wl in (("cooke", CookeTriplet(), (0.0, 1.0), 0.55),
+                                  ("dgauss", DoubleGauss(), (0.0, 0.7), 0.5876)):
+        opd = OPD(optic, field, wl)  # 15 hexapolar rings, chief-ray sphere
+        d = opd.get_data(field, wl)
+        out[f"{tag}_opd"] = np.asarray(d.opd, dtype=np.float64)
+        out[f"{tag}_pupil"] = np.stack([np.asarray(v, dtype=np.float64)
+                                        for v in (d.pupil_x, d.pupil_y, d.pupil_z)])
+        out[f"{tag}_radius"] = np.float64(d.radius)
+        out[f"{tag}_rms"] = np.float64(opd.rms())
+        psf = FFTPSF(optic, field, wl, num_rays=64)
+        full = np.asarray(psf.psf, dtype=np.float64)
+        c = full.shape[0] // 2
+        out[f"{tag}_psf_center"] = full[c - 16:c + 16, c - 16:c + 16]
+        out[f"{tag}_psf_sum"] = np.float64(full.sum())
+        out[f"{tag}_strehl"] = np.float64(psf.strehl_ratio())
+        out[f"{tag}_grid"] = np.array([psf.num_rays, psf.grid_size])
+        print(f"wavefront {tag}: rms={out[tag + '_rms']:.6f} waves strehl={out[tag + '_strehl']:.5f} "
+              f"grid={psf.num_rays}/{psf.grid_size}")
+    np.savez_compressed(os.path.join(GOLD, "wavefront.npz"), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     os.makedirs(DATA, exist_ok=True)
@@ -374,6 +400,7 @@ def main():
     run_case("polarizer_retarder", polarizer_retarder(True), [0.0, 0.0], [0.0, 1.0], None, None,
              0.55, use_trace=dict(num_rays=20, distribution="uniform"))
     run_case("polarizer_only", polarizer_retarder(False), 0.0, 1.0, px, py, 0.55)
+    wavefront_goldens()
 
 
 if __name__ == "__main__":
