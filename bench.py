@@ -58,6 +58,9 @@ def parse_args():
                     help="record: all surfaces (drop-in semantics); last: image plane only")
     ap.add_argument("--exchange", choices=("reduce", "gather", "none"), default="reduce",
                     help="image-plane exchange when --gpus > 1")
+    ap.add_argument("--object-row", choices=("alias", "copy"), default="alias",
+                    help="record mode: generate the rays straight into row 0 of the record "
+                         "block (zero-copy object row) or keep separate ray planes")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the image-plane exchange even with one rank (RCCL path check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -83,8 +86,9 @@ def init_dist(n_gpus):
     return rank, local, world
 
 
-def make_rays(hip, n, dtype, hy, seed, device):
-    """Seeded uniform-disc pupil sampling on device -> rays via ol_generate_rays."""
+def make_rays(hip, n, dtype, hy, seed, device, out=None):
+    """Seeded uniform-disc pupil sampling on device -> rays via ol_generate_rays.
+    `out`: 8 preallocated planes (row 0 of the record block) to generate into."""
     g = torch.Generator(device=device).manual_seed(seed)
     r = torch.rand(n, generator=g, device=device, dtype=torch.float32).sqrt()
     th = 2 * np.pi * torch.rand(n, generator=g, device=device, dtype=torch.float32)
@@ -92,6 +96,10 @@ def make_rays(hip, n, dtype, hy, seed, device):
     del r, th
     hx = torch.zeros(n, dtype=dtype, device=device)
     hyt = torch.full((n,), hy, dtype=dtype, device=device)
+    if out is not None:
+        hip.generate_rays(hx, hyt, px, py, out=out)
+        out[7].zero_()
+        return list(out)
     planes = hip.generate_rays(hx, hyt, px, py)
     rays = [p.contiguous().clone() for p in planes]
     rays.append(torch.zeros(n, dtype=dtype, device=device))
@@ -154,8 +162,10 @@ def main():
     S = table.num_traced
     pol = table.uses_polarization
 
-    rays = make_rays(hip, n, dtype, hy, seed=1234 + rank, device=device)
     record = hip.alloc_record(n, dtype) if args.mode == "record" else None
+    alias = record is not None and args.object_row == "alias"
+    rays = make_rays(hip, n, dtype, hy, seed=1234 + rank, device=device,
+                     out=hip.row0_planes(record, n) if alias else None)
     prt0 = prt = None
     if pol:
         prt0 = torch.eye(3, dtype=dtype, device=device).reshape(9, 1).repeat(1, n).contiguous()
@@ -230,13 +240,15 @@ def main():
         # algorithmic bytes per launch: record-all reads 8 planes and
         # writes 8 planes for each of the S+1 surfaces; record-last reads 8, writes 8.
         if args.mode == "record":
-            alg_bytes = 8 * b * (S + 2) * n
+            # zero-copy object row: row 0 IS the input, so S rows are written, not S+1
+            alg_bytes = 8 * b * (S + 1) * n if alias else 8 * b * (S + 2) * n
         else:
             alg_bytes = 16 * b * n
         if pol:
             alg_bytes += 2 * 9 * b * n  # PRT read-modify-write
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = load_traffic(args.workload, args.dtype, args.mode)
+        traffic = load_traffic(args.workload, args.dtype,
+                               args.mode + (":alias" if alias else ""))
         out = {
             "metric": "ray-surface intersections/s",
             "value": value,
@@ -259,6 +271,8 @@ def main():
                 "rays_per_gpu": n,
                 "surfaces": S,
                 "mode": args.mode,
+                "object_row": ("zero-copy (rays generated into record row 0)" if alias
+                               else "copied") if args.mode == "record" else None,
                 "exchange": exchange,
                 "parallelism": f"ray-shard x{world}",
             },
@@ -273,6 +287,8 @@ def main():
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes": alg_bytes,
                 "bytes_per_ray_surface": alg_bytes / (float(n) * S),
+                "survey_formula_bytes": (8 * b * (S + 2) * n + (2 * 9 * b * n if pol else 0))
+                if args.mode == "record" else alg_bytes,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

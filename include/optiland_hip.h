@@ -215,6 +215,9 @@ int32_t ol_system_num_surfaces(const ol_system* sys);
  *            elements: row s, plane k at record + ((s*8+k)*record_stride).
  *            Planes are x,y,z,L,M,N,intensity,opd in the GLOBAL frame, as
  *            Surface._record_real stores them (standard_surface.py:260-274).
+ *            Zero-copy object row: if rays[k] == record + k*record_stride for all
+ *            k (the rays were generated straight into row 0) and the first
+ *            surface is RECORD_ONLY, row 0 is left as is instead of rewritten.
  *   prt      nullable; 9 planes x n_rays (row-major 3x3 polarisation
  *            ray-tracing matrix, real part) read-modify-write:
  *            PolarizedRays.update (rays/polarized_rays.py:180-202).  With

@@ -245,7 +245,16 @@ int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* c
   a.last = last;
   a.n_wl = sys->n_wl;
   a.wl = wl;
-  a.flags = flags;
+  a.flags = flags & 0xffu;  // public flags only
+  // Zero-copy object row: when the caller's ray planes ARE row 0 of the record
+  // block and the first surface only records (ObjectSurface.trace,
+  // surfaces/object_surface.py:56-69), the kernel skips that row's stores.
+  if (record && sys->interaction[first] == OL_INTERACT_RECORD_ONLY) {
+    bool alias = true;
+    for (int k = 0; k < 8; ++k)
+      alias = alias && (static_cast<T*>(rays[k]) == static_cast<T*>(record) + k * record_stride);
+    if (alias) a.flags |= ol::kTraceRow0IsInput;
+  }
   bool has_newton = false;  // any Newton-Raphson geometry in the traced range?
   for (int32_t s = first; s <= last; ++s)
     has_newton = has_newton || (sys->geom[s] != OL_GEOM_PLANE && sys->geom[s] != OL_GEOM_STANDARD);

@@ -1242,7 +1242,10 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
     }
     if constexpr (RECORD) {
       T* row = a.record + (int64_t)(s - a.first) * 8 * a.record_stride;
-      if (is_global) {
+      if (s == a.first && (a.flags & kTraceRow0IsInput)) {
+        // the caller generated the rays straight into row 0 of the record block
+        // (the object surface only records its input): nothing to write
+      } else if (is_global) {
         store_rays<T, RPT>(row, a.record_stride, base, cnt, r);
       } else {
         Ray<T> g[RPT];

@@ -11,6 +11,7 @@ constexpr int kTraceBlock = 256;           // 4 waves of 64 lanes
 constexpr uint32_t kTraceWriteRays = 0x1u; // OL_TRACE_WRITE_RAYS
 constexpr uint32_t kTraceCompact = 0x2u;   // OL_TRACE_COMPACT
 constexpr uint32_t kTracePrtComplex = 0x4u;  // OL_TRACE_PRT_COMPLEX
+constexpr uint32_t kTraceRow0IsInput = 0x100u;  // internal: rays[] ARE record row 0
 
 template <typename T>
 struct TraceArgs {

@@ -171,9 +171,15 @@ class HipSystem:
             )
         return TraceResult(n, rays, rec, prt, status, first, last)
 
+    def row0_planes(self, record: torch.Tensor, n: int):
+        """The 8 planes of record row 0 as ray planes (zero-copy object row)."""
+        return [record[0, k, :n] for k in range(8)]
+
     # ------------------------------------------------------------- ray source
-    def generate_rays(self, hx, hy, px, py, vx=None, vy=None):
-        """On-device ray generation (paraxial aiming, angle fields).  Returns 7 planes."""
+    def generate_rays(self, hx, hy, px, py, vx=None, vy=None, out=None):
+        """On-device ray generation (paraxial aiming, angle fields).  Returns 7 planes.
+        `out`: optional list of >= 7 preallocated planes to generate into (e.g. row 0 of
+        a record block, so that the trace need not copy the object-surface row)."""
         rg = self.table.raygen
         if not rg:
             raise ValueError("this SystemTable carries no ray-generation scalars")
@@ -181,8 +187,12 @@ class HipSystem:
         dtype = px.dtype
         p = _capi.RaygenParams(int(rg["object_infinite"]), 0, rg["EPL"], rg["EPD"],
                                rg["max_field"], rg["offset"], rg["z_first"])
-        out = torch.empty((7, max(n, 1)), dtype=dtype, device=self.device)
-        ptrs = (C.c_void_p * 7)(*[out[k].data_ptr() for k in range(7)])
+        if out is None:
+            buf = torch.empty((7, max(n, 1)), dtype=dtype, device=self.device)
+            planes = [buf[k, :n] for k in range(7)]
+        else:
+            planes = list(out[:7])
+        ptrs = (C.c_void_p * 7)(*[p_.data_ptr() for p_ in planes])
         args = [t.contiguous() for t in (hx, hy, px, py)]
         vxc = vx.contiguous() if vx is not None else None
         vyc = vy.contiguous() if vy is not None else None
@@ -192,7 +202,7 @@ class HipSystem:
                 vxc.data_ptr() if vxc is not None else None,
                 vyc.data_ptr() if vyc is not None else None, ptrs, _stream_ptr(self.device))
         _capi.check(rc, "ol_generate_rays")
-        return [out[k, :n] for k in range(7)]
+        return planes
 
     def polarized_intensity(self, prt, k0, i0, polarization: dict | None):
         n = int(i0.numel())

@@ -126,19 +126,26 @@ def _make_tracer_class():
             as_dev = lambda a: torch.as_tensor(  # noqa: E731
                 np.array(be.to_numpy(a), dtype=np.float64) if not isinstance(a, torch.Tensor) else a,
                 dtype=dtype, device=dev).reshape(-1).contiguous()
+            # the rays are generated (or copied) straight into row 0 of the record
+            # block: the object surface only records its input (zero-copy object row)
             if table.raygen:
                 hx, hy, px, py = (as_dev(a) for a in (Hx, Hy, Px, Py))
+                n = int(hx.numel())
+                record = eng.alloc_record(n, dtype)
+                rays = eng.row0_planes(record, n)
                 vxf, vyf = self.optic.fields.get_vig_factor(Hx, Hy)
-                vx = as_dev(1 - np.asarray(be.to_numpy(vxf), dtype=np.float64)
-                            * np.ones(hx.numel()))
-                vy = as_dev(1 - np.asarray(be.to_numpy(vyf), dtype=np.float64)
-                            * np.ones(hx.numel()))
-                planes = eng.generate_rays(hx, hy, px, py, vx, vy)
+                vx = as_dev(1 - np.asarray(be.to_numpy(vxf), dtype=np.float64) * np.ones(n))
+                vy = as_dev(1 - np.asarray(be.to_numpy(vyf), dtype=np.float64) * np.ones(n))
+                eng.generate_rays(hx, hy, px, py, vx, vy, out=rays)
             else:  # aiming/field type the device generator does not cover
                 r = self.ray_generator.generate_rays(Hx, Hy, Px, Py, wavelength)
-                planes = [as_dev(getattr(r, k)) for k in ("x", "y", "z", "L", "M", "N", "i")]
-            n = int(planes[0].numel())
-            rays = [p.contiguous() for p in planes] + [torch.zeros(n, dtype=dtype, device=dev)]
+                src = [as_dev(getattr(r, k)) for k in ("x", "y", "z", "L", "M", "N", "i")]
+                n = int(src[0].numel())
+                record = eng.alloc_record(n, dtype)
+                rays = eng.row0_planes(record, n)
+                for dst, s_ in zip(rays, src):
+                    dst.copy_(s_)
+            rays[7].zero_()
             polarized = self.optic.polarization != "ignore"
             if not polarized and self.optic.surfaces.uses_polarization:
                 raise ValueError("Polarization must be set when surfaces have "
@@ -148,7 +155,7 @@ def _make_tracer_class():
                 prt = new_prt(n, dtype, dev, table.needs_complex_prt)
                 k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
                 i0 = rays[6].clone()
-            res = eng.trace(rays, 0, record=True, prt=prt)
+            res = eng.trace(rays, 0, record=record, prt=prt)
 
             # every Surface gets its recorded vectors (views, no copies)
             for s, surf in enumerate(self.optic.surfaces):

@@ -123,10 +123,19 @@ class HipRayTracer:
         wl, w = self._wavelength_index(wavelength)
         eng = self.engine
         vx, vy = one_minus_v
-        planes = eng.generate_rays(hx, hy, px, py, vx, vy)
         n = int(px.numel())
-        rays = [p if p.is_contiguous() else p.contiguous() for p in planes]
-        rays.append(torch.zeros(n, dtype=self.dtype, device=self.device))
+        record = self.record_all
+        if self.record_all:
+            # rays are generated straight into row 0 of the record block: the object
+            # surface only records its input, so the trace need not copy that row
+            record = eng.alloc_record(n, self.dtype)
+            rays = eng.row0_planes(record, n)
+            eng.generate_rays(hx, hy, px, py, vx, vy, out=rays)
+            rays[7].zero_()
+        else:
+            planes = eng.generate_rays(hx, hy, px, py, vx, vy)
+            rays = [p if p.is_contiguous() else p.contiguous() for p in planes]
+            rays.append(torch.zeros(n, dtype=self.dtype, device=self.device))
         polarized = self.table.polarization is not None
         if not polarized and self.table.uses_polarization:
             # rays/ray_generator.py:89-94
@@ -138,7 +147,7 @@ class HipRayTracer:
             prt = new_prt(n, self.dtype, self.device, self.table.needs_complex_prt)
             k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
             i0 = rays[6].clone()
-        res = eng.trace(rays, wl, record=self.record_all, prt=prt)
+        res = eng.trace(rays, wl, record=record, prt=prt)
         self.surfaces._bind(res)
         wt = torch.full((n,), w, dtype=self.dtype, device=self.device)
         if res.record is not None:

@@ -54,7 +54,11 @@ class OracleEngine:
                 "factors.")
         rec = None
         if out["record"] is not None:
-            rec = torch.as_tensor(out["record"], dtype=dtype)
+            if isinstance(record, torch.Tensor):
+                rec = record
+                rec[: out["record"].shape[0], :, :n].copy_(torch.as_tensor(out["record"], dtype=dtype))
+            else:
+                rec = torch.as_tensor(out["record"], dtype=dtype)
         if write_rays is None:
             write_rays = rec is None
         if write_rays:
@@ -71,10 +75,22 @@ class OracleEngine:
                 prt[9:].copy_(torch.as_tensor(newp.imag.reshape(n, 9).T.copy(), dtype=dtype))
         return TraceResult(n, rays, rec, prt, out["status"], first, last)
 
-    def generate_rays(self, hx, hy, px, py, vx=None, vy=None):
+    def row0_planes(self, record, n):
+        return [record[0, k, :n] for k in range(8)]
+
+    def alloc_record(self, n, dtype, rows=None):
+        rows = self.num_surfaces if rows is None else rows
+        return torch.empty((rows, 8, max(n, 1)), dtype=dtype)
+
+    def generate_rays(self, hx, hy, px, py, vx=None, vy=None, out=None):
         f = lambda t: None if t is None else t.double().numpy()  # noqa: E731
         g = oracle.generate_rays(self.table.raygen, f(hx), f(hy), f(px), f(py), f(vx), f(vy))
-        return [torch.as_tensor(g[k], dtype=px.dtype) for k in ("x", "y", "z", "L", "M", "N", "i")]
+        planes = [torch.as_tensor(g[k], dtype=px.dtype) for k in ("x", "y", "z", "L", "M", "N", "i")]
+        if out is not None:
+            for dst, src in zip(out, planes):
+                dst.copy_(src)
+            return list(out[:7])
+        return planes
 
     def polarized_intensity(self, prt, k0, i0, polarization):
         n = int(i0.numel())

@@ -229,3 +229,21 @@ def test_oracle_side_by_side_large(hip, dtype):
     res = sysm.trace(planes, 0, record=True)
     tol = TOL[dtype]
     assert_close_planes(res.record[:, :, :n].double().cpu().numpy(), want, tol, tol, "oracle-2e5")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_zero_copy_object_row(hip, dtype):
+    """Rays generated straight into record row 0: the trace leaves that row untouched
+    and every other row is bit-identical to the copying path."""
+    sysm, table, data = hip("double_gauss")
+    rays = _device_rays(data, dtype)
+    n = rays[0].numel()
+    ref = sysm.trace(rays, 0, record=True)
+    rec = sysm.alloc_record(n, dtype)
+    row0 = sysm.row0_planes(rec, n)
+    for dst, src in zip(row0, rays):
+        dst.copy_(src)
+    sentinel = rec[0, :, :n].clone()
+    res = sysm.trace(row0, 0, record=rec)
+    assert torch.equal(rec[0, :, :n], sentinel)
+    assert torch.equal(res.record[:, :, :n], ref.record[:, :, :n])

@@ -47,30 +47,37 @@ dtype = torch.float32 if args.dtype == "f32" else torch.float64
 n = int(args.rays)
 rays = make_rays(hip, n, dtype, hy, 1234, dev)
 rec = hip.alloc_record(n, dtype) if args.mode == "record" else None
+rec2 = hip.alloc_record(n, dtype) if args.mode == "record" else None
+alias_rays = None
+if rec2 is not None:
+    alias_rays = make_rays(hip, n, dtype, hy, 1234, dev, out=hip.row0_planes(rec2, n))
 pol = table.uses_polarization
 prt0 = torch.eye(3, dtype=dtype, device=dev).reshape(9, 1).repeat(1, n).contiguous() if pol else None
 prt = torch.empty_like(prt0) if pol else None
 scratch = [torch.empty_like(t) for t in rays]
 lib = _capi.load()
 variants = [("vec,compact", 2, 1), ("vec,plain", 2, 0), ("rpt1", 1, 0), ("auto", 0, 0)]
+if alias_rays is not None:
+    variants.append(("auto,row0-alias", 0, 0))
 times = {v[0]: [] for v in variants}
 
 
-def one(rpt, compact):
+def one(rpt, compact, alias=False):
     lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, rpt)
     lib.ol_set_tuning(_capi.TUNE_COMPACT, compact)
     ms = []
     for _ in range(args.steps):
         if pol:
             prt.copy_(prt0)
-        src = rays
+        src = alias_rays if alias else rays
         if args.mode != "record":
             for d, s_ in zip(scratch, rays):
                 d.copy_(s_)
             src = scratch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        hip.trace(src, 0, record=rec if rec is not None else False, prt=prt, check_status=False)
+        hip.trace(src, 0, record=(rec2 if alias else rec) if rec is not None else False, prt=prt,
+                  check_status=False)
         e1.record()
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
@@ -78,10 +85,10 @@ def one(rpt, compact):
 
 
 for name, rpt, comp in variants:
-    one(rpt, comp)  # warm
+    one(rpt, comp, "alias" in name)  # warm
 for _ in range(args.rounds):
     for name, rpt, comp in variants:
-        times[name].append(one(rpt, comp))
+        times[name].append(one(rpt, comp, "alias" in name))
 S = table.num_traced
 print(f"# {args.workload if not args.system_json else args.system_json} {args.dtype} {args.mode} "
       f"n={n:.3g} S={S} tol={args.tol}")

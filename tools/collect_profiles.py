@@ -19,11 +19,13 @@ OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
 TAGS = {  # tag -> traffic key
-    "dg_f32": "double_gauss:f32:record",
-    "dg_f64": "double_gauss:f64:record",
-    "rc_f32": "rc_asphere:f32:record",
-    "zf_f32": "zernike_fresnel:f32:record",
+    # record-mode bench runs use the zero-copy object row by default (":alias")
+    "dg_f32": "double_gauss:f32:record:alias",
+    "dg_f64": "double_gauss:f64:record:alias",
+    "rc_f32": "rc_asphere:f32:record:alias",
+    "zf_f32": "zernike_fresnel:f32:record:alias",
     "dg_f32_last": "double_gauss:f32:last",
+    "dg_f32_copy": "double_gauss:f32:record",
 }
 
 
