@@ -3,11 +3,13 @@
 // One launch replaces the reference's Python loop over surfaces
 // (optiland/surfaces/surface_group.py:245-257) and the ~100 N-element array
 // operations it runs per surface.  Each thread owns RPT rays
-// (struct-of-arrays in HBM, RPT consecutive rays = one 16-byte vector per plane
-// per lane), keeps their state in VGPRs across ALL surfaces and streams the
-// recorded per-surface state out with 16 B/lane stores.  Surface constants are
-// wave-uniform -> scalar loads / SGPR operands.  No MFMA: this is a streaming
-// vector-ALU path bounded by HBM write bandwidth in record-all mode.
+// (struct-of-arrays in HBM; RPT = 1, or the 16-byte vector of consecutive rays per
+// plane per lane -- chosen per mode from measurements, see launch_trace()), keeps
+// their state in VGPRs across ALL surfaces and streams the recorded per-surface
+// state out.  Surface constants are wave-uniform -> scalar loads / SGPR operands
+// (one s_load_dwordx16 per surface, prefetched one surface ahead).  No MFMA, no
+// LDS: this is a streaming vector-ALU path bounded by HBM write bandwidth in
+// record-all mode.
 //
 // Per-surface arithmetic follows SURVEY.md Appendix A; each device function
 // cites the reference lines it implements.  Differences that are deliberate:
@@ -149,14 +151,6 @@ __device__ __forceinline__ void conic_gradient(const DevSurf<T>& s, T x, T y, T&
   T f = s.cv * g;
   fx = x * f;
   fy = y * f;
-}
-
-// conic part of the sag, standard.py:81-95
-template <typename T>
-__device__ __forceinline__ T conic_sag(const DevSurf<T>& s, T r2) {
-  using m = Math<T>;
-  T g = m::sqrt(m::fma(-s.kp1 * s.cv * s.cv, r2, T(1)));
-  return m::div(s.cv * r2, T(1) + g);
 }
 
 // --------------------------------------------------------------------------
@@ -1089,24 +1083,6 @@ struct VecOf {
 template <typename T, int RPT>
 __device__ __forceinline__ T vec_get(const typename VecOf<T, RPT>::type& v, int k) {
   return v[k];  // ext_vector_type(1) is still a vector
-}
-
-template <typename T, int RPT>
-__device__ __forceinline__ void load_plane(const T* __restrict__ p, int64_t base, int cnt,
-                                           T (&out)[RPT]) {
-  if constexpr (RPT == 1) {
-    out[0] = p[base];
-  } else {
-    using V = typename VecOf<T, RPT>::type;
-    if (cnt == RPT) {
-      V v = *reinterpret_cast<const V*>(p + base);
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) out[k] = v[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) out[k] = k < cnt ? p[base + k] : T(0);
-    }
-  }
 }
 
 template <typename T, int RPT>
