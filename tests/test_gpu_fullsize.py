@@ -170,3 +170,30 @@ def test_spot_diagram_goldens_on_device():
         np.testing.assert_allclose(spot.rms_spot_radius(), COOKE_RMS, rtol=tol)
         np.testing.assert_allclose(spot.geometric_spot_radius(), COOKE_GEO, rtol=tol)
         t.engine.close()
+
+
+def test_sixty_million_rays_64bit_offsets(dg):
+    """6e7 rays fp32 record-all: the record block is 25 GB, element offsets exceed
+    2^32.  The tail of the batch must equal a separate small trace bit for bit."""
+    hip, table = dg
+    n = 60_000_000
+    dtype = torch.float32
+    S = table.num_traced
+    rec = hip.alloc_record(n, dtype)
+    assert rec.numel() > 2**32
+    rays = hip.row0_planes(rec, n)
+    px, py = _pupil(n, 21, dtype)
+    hx = torch.zeros(n, dtype=dtype, device=DEV)
+    hy = torch.full((n,), 0.7, dtype=dtype, device=DEV)
+    hip.generate_rays(hx, hy, px, py, out=rays)
+    rays[7].zero_()
+    del px, py, hx, hy
+    res = hip.trace(rays, 0, record=rec)
+    tail = [t[-1000:].clone() for t in rays]
+    small = hip.trace(tail, 0, record=True)
+    for s in (1, S):
+        for k in range(8):
+            assert torch.equal(small.row(s, k), res.row(s, k)[-1000:]), (s, k)
+    assert not bool(torch.isnan(res.row(S, 0)).any())
+    del rec, res
+    torch.cuda.empty_cache()
