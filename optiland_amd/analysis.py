@@ -12,7 +12,6 @@ to seven doubles.
 from __future__ import annotations
 
 import numpy as np
-import torch
 
 
 class SpotDiagram:

@@ -120,7 +120,7 @@ def _make_tracer_class():
             return self._hip_engine, self._hip_table
 
         # ---------------------------------------------------------------- trace
-        def _hip_trace(self, Hx, Hy, Px, Py, wavelength, update_intensity, vig_scaled):
+        def _hip_trace(self, Hx, Hy, Px, Py, wavelength, update_intensity):
             eng, table = self._engine_for(wavelength)
             dtype, dev = self._dtype(), eng.device
             as_dev = lambda a: torch.as_tensor(  # noqa: E731
@@ -206,7 +206,7 @@ def _make_tracer_class():
                 nf, npup = Hxa.size, Px.size
                 out = self._hip_trace(np.repeat(Hxa, npup), np.repeat(Hya, npup),
                                       np.tile(Px, nf), np.tile(Py, nf), wavelength,
-                                      update_intensity=True, vig_scaled=False)
+                                      update_intensity=True)
             except UnsupportedSystem:
                 self.last_path = "reference"
                 return _ORIGINALS["trace"](self, Hx, Hy, wavelength, num_rays, distribution)
@@ -228,8 +228,7 @@ def _make_tracer_class():
                                       for a in arrs)
                 Pxa = Pxa * (1 - np.asarray(be.to_numpy(vx), dtype=np.float64))
                 Pya = Pya * (1 - np.asarray(be.to_numpy(vy), dtype=np.float64))
-                out = self._hip_trace(Hxa, Hya, Pxa, Pya, wavelength, update_intensity=False,
-                                      vig_scaled=True)
+                out = self._hip_trace(Hxa, Hya, Pxa, Pya, wavelength, update_intensity=False)
             except UnsupportedSystem:
                 self.last_path = "reference"
                 return _ORIGINALS["trace_generic"](self, Hx, Hy, Px, Py, wavelength)

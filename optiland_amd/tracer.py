@@ -18,7 +18,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from .distribution import Distribution, create_distribution
+from .distribution import create_distribution
 from .rays import PolarizedRays, RealRays, _state_dict, new_prt
 from .system import SystemTable
 

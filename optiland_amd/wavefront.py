@@ -21,7 +21,7 @@ import math
 import numpy as np
 import torch
 
-from .distribution import Distribution, create_distribution
+from .distribution import create_distribution
 
 
 class WavefrontData:
