@@ -1069,10 +1069,16 @@ __device__ __forceinline__ Ray<T> to_global(const DevSurf<T>& s, const Ray<T>& r
 // --------------------------------------------------------------------------
 // vector load / store of RPT consecutive rays of one plane
 // --------------------------------------------------------------------------
-#ifdef OL_NT_STORES
-#define OL_STORE(v, ptr) __builtin_nontemporal_store(v, ptr)
-#else
-#define OL_STORE(v, ptr) (*(ptr) = (v))
+// Store flavour, measured on MI355X with the 2 MiB-aligned record block
+// (tools/microbench/rw_scope.hip, stream_write.hip): for ONE ray per lane (4/8-byte
+// stores) non-temporal stores are ~2 % faster than plain ones (0.777 vs 0.792 ms on
+// the record-all pattern; agent/system-scope write-through stores 0.795); for the
+// 16-byte vector layout plain stores win by 1-2 %.
+#ifndef OL_NT_SCALAR
+#define OL_NT_SCALAR 1
+#endif
+#ifndef OL_NT_VECTOR
+#define OL_NT_VECTOR 0
 #endif
 
 template <typename T, int RPT>
@@ -1088,17 +1094,23 @@ __device__ __forceinline__ T vec_get(const typename VecOf<T, RPT>::type& v, int 
 template <typename T, int RPT>
 __device__ __forceinline__ void store_plane(T* __restrict__ p, int64_t base, int cnt,
                                             const T (&in)[RPT]) {
-  // plain stores: measured 1-2 % faster than non-temporal ones for this 104-plane
-  // pattern on MI355X (tools/microbench/stream_write.hip; OL_NT_STORES flips it).
   if constexpr (RPT == 1) {
-    OL_STORE(in[0], p + base);
+#if OL_NT_SCALAR
+    __builtin_nontemporal_store(in[0], p + base);
+#else
+    p[base] = in[0];
+#endif
   } else {
     using V = typename VecOf<T, RPT>::type;
     if (cnt == RPT) {
       V v;
 #pragma unroll
       for (int k = 0; k < RPT; ++k) v[k] = in[k];
-      OL_STORE(v, reinterpret_cast<V*>(p + base));
+#if OL_NT_VECTOR
+      __builtin_nontemporal_store(v, reinterpret_cast<V*>(p + base));
+#else
+      *reinterpret_cast<V*>(p + base) = v;
+#endif
     } else {
 #pragma unroll
       for (int k = 0; k < RPT; ++k)
