@@ -7,7 +7,10 @@
 
 namespace ol {
 
-constexpr int kTraceBlock = 256;           // 4 waves of 64 lanes
+#ifndef OL_TRACE_BLOCK
+#define OL_TRACE_BLOCK 256
+#endif
+constexpr int kTraceBlock = OL_TRACE_BLOCK;  // threads per workgroup (waves of 64 lanes)
 constexpr uint32_t kTraceWriteRays = 0x1u; // OL_TRACE_WRITE_RAYS
 constexpr uint32_t kTraceCompact = 0x2u;   // OL_TRACE_COMPACT
 constexpr uint32_t kTracePrtComplex = 0x4u;  // OL_TRACE_PRT_COMPLEX
