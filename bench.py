@@ -166,10 +166,9 @@ def main():
     alias = record is not None and args.object_row == "alias"
     rays = make_rays(hip, n, dtype, hy, seed=1234 + rank, device=device,
                      out=hip.row0_planes(record, n) if alias else None)
-    prt0 = prt = None
-    if pol:
-        prt0 = torch.eye(3, dtype=dtype, device=device).reshape(9, 1).repeat(1, n).contiguous()
-        prt = torch.empty_like(prt0)
+    prt = None
+    if pol:  # write-only: every step starts a fresh PRT from the identity in-kernel
+        prt = torch.empty((18 if table.needs_complex_prt else 9, n), dtype=dtype, device=device)
     scratch = [torch.empty_like(t) for t in rays] if args.mode == "last" else None
 
     import torch.distributed as dist
@@ -182,8 +181,6 @@ def main():
             hits = torch.empty((3, n), dtype=dtype, device=device)
 
     def step(ev0=None, ev1=None):
-        if pol:
-            prt.copy_(prt0)
         if args.mode == "record":
             src = rays
         else:  # last-surface mode mutates the rays in place: refresh from the source
@@ -193,7 +190,7 @@ def main():
         if ev0 is not None:
             ev0.record()
         res = hip.trace(src, wl, record=record if record is not None else False, prt=prt,
-                        check_status=False)
+                        check_status=False, prt_identity=pol)
         if ev1 is not None:
             ev1.record()
         if exchange != "none":
@@ -244,10 +241,10 @@ def main():
         else:
             alg_bytes = 16 * b * n
         if pol:
-            alg_bytes += 2 * 9 * b * n  # PRT read-modify-write
+            alg_bytes += 2 * 9 * b * n  # PRT read-modify-write (SURVEY figure)
         # bytes this launch really has to move: with the zero-copy object row, row 0
         # of the record block IS the input, so only S rows are written
-        moved_bytes = alg_bytes - (8 * b * n if alias else 0)
+        moved_bytes = alg_bytes - (8 * b * n if alias else 0) - (9 * b * n if pol else 0)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = load_traffic(args.workload, args.dtype,
                                args.mode + (":alias" if alias else ""))

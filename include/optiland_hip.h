@@ -184,6 +184,10 @@ typedef struct ol_system ol_system; /* opaque */
 /* ---- trace flags --------------------------------------------------------- */
 #define OL_TRACE_WRITE_RAYS 0x1u   /* write the final ray state back into rays[] */
 #define OL_TRACE_PRT_COMPLEX 0x4u  /* prt holds 18 planes: 9 real then 9 imaginary */
+#define OL_TRACE_PRT_IDENTITY 0x8u /* prt is write-only: start from the identity instead
+                                      of reading it (PolarizedRays.__init__,
+                                      rays/polarized_rays.py:50) -- saves 9 plane reads
+                                      and the caller's fill                          */
 #define OL_TRACE_COMPACT 0x2u      /* allow wavefront straggler compaction in the
                                       Newton loop (only if OL_TUNE_COMPACT=1) */
 

@@ -246,6 +246,7 @@ int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* c
   a.n_wl = sys->n_wl;
   a.wl = wl;
   a.flags = flags & 0xffu;  // public flags only
+  if (!prt) a.flags &= ~ol::kTracePrtIdentity;
   // Zero-copy object row: when the caller's ray planes ARE row 0 of the record
   // block and the first surface only records (ObjectSurface.trace,
   // surfaces/object_surface.py:56-69), the kernel skips that row's stores.

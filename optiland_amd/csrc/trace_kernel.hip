@@ -1172,14 +1172,16 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
 #pragma unroll
       for (int f = 0; f < 8; ++f) v[f] = *reinterpret_cast<const V*>(a.rays[f] + base);
       if constexpr (POLK != 0) {
-        V pv[NPRT];
+        if (!(a.flags & kTracePrtIdentity)) {
+          V pv[NPRT];
 #pragma unroll
-        for (int e = 0; e < NPRT; ++e)
-          pv[e] = *reinterpret_cast<const V*>(a.prt + (int64_t)e * a.n + base);
+          for (int e = 0; e < NPRT; ++e)
+            pv[e] = *reinterpret_cast<const V*>(a.prt + (int64_t)e * a.n + base);
 #pragma unroll
-        for (int e = 0; e < NPRT; ++e)
+          for (int e = 0; e < NPRT; ++e)
 #pragma unroll
-          for (int k = 0; k < RPT; ++k) pin[e][k] = vec_get<T, RPT>(pv[e], k);
+            for (int k = 0; k < RPT; ++k) pin[e][k] = vec_get<T, RPT>(pv[e], k);
+        }
       }
 #pragma unroll
       for (int f = 0; f < 8; ++f)
@@ -1191,11 +1193,13 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
 #pragma unroll
         for (int k = 0; k < RPT; ++k) in[f][k] = k < cnt ? a.rays[f][base + k] : T(0);
       if constexpr (POLK != 0) {
+        if (!(a.flags & kTracePrtIdentity)) {
 #pragma unroll
-        for (int e = 0; e < NPRT; ++e)
+          for (int e = 0; e < NPRT; ++e)
 #pragma unroll
-          for (int k = 0; k < RPT; ++k)
-            pin[e][k] = k < cnt ? a.prt[(int64_t)e * a.n + base + k] : T(0);
+            for (int k = 0; k < RPT; ++k)
+              pin[e][k] = k < cnt ? a.prt[(int64_t)e * a.n + base + k] : T(0);
+        }
       }
     }
 #pragma unroll
@@ -1204,8 +1208,10 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
       r[k].L = in[3][k]; r[k].M = in[4][k]; r[k].N = in[5][k];
       r[k].i = in[6][k]; r[k].opd = in[7][k];
       if constexpr (POLK != 0) {
+        const bool ident = (a.flags & kTracePrtIdentity) != 0;  // PRT starts as I
 #pragma unroll
-        for (int e = 0; e < NPRT; ++e) P[k].m[e] = pin[e][k];
+        for (int e = 0; e < NPRT; ++e)
+          P[k].m[e] = ident ? ((e == 0 || e == 4 || e == 8) ? T(1) : T(0)) : pin[e][k];
       }
     }
   }

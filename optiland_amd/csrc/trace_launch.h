@@ -14,6 +14,7 @@ constexpr int kTraceBlock = OL_TRACE_BLOCK;  // threads per workgroup (waves of 
 constexpr uint32_t kTraceWriteRays = 0x1u; // OL_TRACE_WRITE_RAYS
 constexpr uint32_t kTraceCompact = 0x2u;   // OL_TRACE_COMPACT
 constexpr uint32_t kTracePrtComplex = 0x4u;  // OL_TRACE_PRT_COMPLEX
+constexpr uint32_t kTracePrtIdentity = 0x8u;  // OL_TRACE_PRT_IDENTITY
 constexpr uint32_t kTraceRow0IsInput = 0x100u;  // internal: rays[] ARE record row 0
 
 template <typename T>

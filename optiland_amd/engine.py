@@ -125,13 +125,15 @@ class HipSystem:
 
     def trace(self, rays, wavelength_index: int = 0, record=True, prt: torch.Tensor | None = None,
               first: int = 0, last: int | None = None, write_rays: bool | None = None,
-              check_status: bool = True) -> TraceResult:
+              check_status: bool = True, prt_identity: bool = False) -> TraceResult:
         """Launch the fused trace.
 
         rays: sequence of 8 contiguous 1-D device tensors (x,y,z,L,M,N,i,opd) of one
         dtype -- the initial state.  record: True (allocate), False/None, or a
         preallocated (rows, 8, stride) tensor.  prt: (9, n) real or (18, n) real+imaginary
         tensor (the latter is required behind retarder coatings), read-modify-write.
+        prt_identity: the PRT buffer is uninitialised and the trace starts from the
+        identity (a fresh PolarizedRays) -- no fill, no read.
         With write_rays (default: only when nothing is recorded) the final state is
         written back into `rays` in place, like SurfaceGroup.trace mutates its rays.
         """
@@ -165,6 +167,8 @@ class HipSystem:
                                  "[real + imaginary] tensor of the ray dtype")
             if prt.shape[0] == 18:
                 flags |= S.TRACE_PRT_COMPLEX
+            if prt_identity:  # write-only PRT: starts from I inside the kernel
+                flags |= S.TRACE_PRT_IDENTITY
         ptrs = (C.c_void_p * 8)(*[t.data_ptr() for t in rays])
         if check_status:
             self._status.zero_()

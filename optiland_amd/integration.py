@@ -29,7 +29,7 @@ import torch
 
 from . import tracer as _tracer
 from .packer import UnsupportedSystem, pack_optic
-from .rays import _state_dict, new_prt, prt_to_complex
+from .rays import _state_dict, prt_to_complex
 
 BACKEND_NAME = "hip"
 
@@ -152,10 +152,11 @@ def _make_tracer_class():
                                  "polarization-dependent coatings.")
             prt = k_init = i0 = None
             if polarized:
-                prt = new_prt(n, dtype, dev, table.needs_complex_prt)
+                prt = torch.empty((18 if table.needs_complex_prt else 9, n), dtype=dtype,
+                                  device=dev)  # written by the kernel (starts from I)
                 k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
                 i0 = rays[6].clone()
-            res = eng.trace(rays, 0, record=record, prt=prt)
+            res = eng.trace(rays, 0, record=record, prt=prt, prt_identity=prt is not None)
 
             # every Surface gets its recorded vectors (views, no copies)
             for s, surf in enumerate(self.optic.surfaces):

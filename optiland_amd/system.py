@@ -38,6 +38,7 @@ STATUS_CHEBYSHEV_RANGE = 0x4
 TRACE_WRITE_RAYS = 0x1
 TRACE_COMPACT = 0x2
 TRACE_PRT_COMPLEX = 0x4
+TRACE_PRT_IDENTITY = 0x8
 
 GEOM_NAMES = {
     GEOM_PLANE: "plane",

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from .distribution import create_distribution
-from .rays import PolarizedRays, RealRays, _state_dict, new_prt
+from .rays import PolarizedRays, RealRays, _state_dict
 from .system import SystemTable
 
 
@@ -144,10 +144,11 @@ class HipRayTracer:
         prt = None
         k_init = i0 = None
         if polarized:
-            prt = new_prt(n, self.dtype, self.device, self.table.needs_complex_prt)
+            prt = torch.empty((18 if self.table.needs_complex_prt else 9, n), dtype=self.dtype,
+                              device=self.device)  # written by the kernel (starts from I)
             k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
             i0 = rays[6].clone()
-        res = eng.trace(rays, wl, record=record, prt=prt)
+        res = eng.trace(rays, wl, record=record, prt=prt, prt_identity=prt is not None)
         self.surfaces._bind(res)
         wt = torch.full((n,), w, dtype=self.dtype, device=self.device)
         if res.record is not None:

@@ -29,7 +29,7 @@ class OracleEngine:
         pass
 
     def trace(self, rays, wavelength_index=0, record=True, prt=None, first=0, last=None,
-              write_rays=None, check_status=True):
+              write_rays=None, check_status=True, prt_identity=False):
         self.calls += 1
         rays = list(rays)
         n = int(rays[0].numel())
@@ -65,6 +65,9 @@ class OracleEngine:
             for j, k in enumerate(PLANES):
                 rays[j].copy_(torch.as_tensor(out[k], dtype=dtype))
         if prt is not None:
+            if prt_identity:
+                prt.zero_()
+                prt[0].fill_(1), prt[4].fill_(1), prt[8].fill_(1)
             p = out["prt"]  # (n,3,3) complex; oracle started from identity -> multiply in
             start = prt[:9].t().reshape(n, 3, 3).double().numpy().astype(np.complex128)
             if prt.shape[0] == 18:

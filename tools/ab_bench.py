@@ -52,8 +52,7 @@ alias_rays = None
 if rec2 is not None:
     alias_rays = make_rays(hip, n, dtype, hy, 1234, dev, out=hip.row0_planes(rec2, n))
 pol = table.uses_polarization
-prt0 = torch.eye(3, dtype=dtype, device=dev).reshape(9, 1).repeat(1, n).contiguous() if pol else None
-prt = torch.empty_like(prt0) if pol else None
+prt = torch.empty((9, n), dtype=dtype, device=dev) if pol else None
 scratch = [torch.empty_like(t) for t in rays]
 lib = _capi.load()
 variants = [("vec,compact", 2, 1), ("vec,plain", 2, 0), ("rpt1", 1, 0), ("auto", 0, 0)]
@@ -67,8 +66,6 @@ def one(rpt, compact, alias=False):
     lib.ol_set_tuning(_capi.TUNE_COMPACT, compact)
     ms = []
     for _ in range(args.steps):
-        if pol:
-            prt.copy_(prt0)
         src = alias_rays if alias else rays
         if args.mode != "record":
             for d, s_ in zip(scratch, rays):
@@ -77,7 +74,7 @@ def one(rpt, compact, alias=False):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         hip.trace(src, 0, record=(rec2 if alias else rec) if rec is not None else False, prt=prt,
-                  check_status=False)
+                  check_status=False, prt_identity=pol)
         e1.record()
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
