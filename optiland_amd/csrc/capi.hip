@@ -298,6 +298,7 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
 
   std::vector<HostSurf> dev(n_surf);
   std::vector<double> dcoef;
+  int32_t prev_traced = -1;
   for (int32_t i = 0; i < n_surf; ++i) {
     const ol_surface_desc& s = surf[i];
     HostSurf& d = dev[i];
@@ -336,11 +337,12 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
       static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
       std::memcpy(d.rot, I, sizeof(I));
     }
-    // relative transform from the previous surface's local frame
+    // relative transform from the local frame of the previous TRACED surface (the
+    // kernel keeps its state in that frame; record-only surfaces do not move it)
     static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     std::memcpy(d.rel_rot, I, sizeof(I));
-    if (i > 0) {
-      const HostSurf& p = dev[i - 1];
+    if (prev_traced >= 0) {
+      const HostSurf& p = dev[prev_traced];
       mat3_mul_abt(d.rot, p.rot, d.rel_rot);
       double dv[3] = {p.origin[0] - d.origin[0], p.origin[1] - d.origin[1],
                       p.origin[2] - d.origin[2]};
@@ -350,6 +352,7 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
       }
       if (!is_identity(d.rel_rot)) d.flags |= ol::kSurfRelRotated;
     }
+    if (s.interaction != OL_INTERACT_RECORD_ONLY) prev_traced = i;
     // apertures: pre-square / pre-invert in double
     if (s.aperture_kind == OL_AP_COMPOSITE) {
       const int64_t off = (int64_t)s.aperture[0], cnt = (int64_t)s.aperture[1];

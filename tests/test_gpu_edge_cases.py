@@ -198,3 +198,27 @@ def test_polarised_partial_traces_continue_the_prt(case):
     for a, b in zip(rays, rays_full):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-9, atol=1e-9)
     hip.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-4)],
+                         ids=["f64", "f32"])
+def test_record_only_surface_in_the_middle(dtype, tol):
+    """A RECORD_ONLY (dummy) surface between tilted traced surfaces: it must record the
+    state without moving it, and the next surface must start from the right frame."""
+    table, data = load_case("tilted_fold")
+    import copy
+    t2 = copy.deepcopy(table)
+    # insert a copy of surface 2 as a record-only dummy after it (same frame)
+    surf = np.insert(t2.surfaces, 3, t2.surfaces[2])
+    surf[3]["interaction"] = S.INTERACT_RECORD_ONLY
+    surf[3]["origin"] = (0.3, -0.4, 11.0)          # its own frame is irrelevant
+    opt = np.insert(t2.optics, 3, t2.optics[2], axis=0)
+    t2.surfaces, t2.optics = surf, opt
+    rays = {k: data["rays_in"][j] for j, k in enumerate(PLANES[:7])}
+    got, want, _ = run_both(t2, rays, dtype)
+    w = want["record"]
+    assert_close_planes(got, w, tol, tol, "dummy surface")
+    # the dummy row repeats the previous row; later rows equal the original system's
+    assert np.array_equal(np.nan_to_num(got[3]), np.nan_to_num(got[2]))
+    assert_close_planes(np.delete(got, 3, axis=0), data["record"], max(tol, 1e-9), max(tol, 1e-9),
+                        "rows after the dummy")
