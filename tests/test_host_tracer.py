@@ -151,3 +151,18 @@ def test_polarizer_and_retarder_system_through_the_tracer():
     rays = t.trace([0.0, 0.0], [0.0, 1.0], 0.55, num_rays=20, distribution="uniform")
     np.testing.assert_allclose(rays.p.numpy(), data["prt"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(rays.i.numpy(), data["i_updated"], rtol=1e-10)
+
+
+def test_vignetting_factors_trace_and_trace_generic():
+    """Nearest-field vignetting (fields/field_group.py:93-122) through both entry
+    points; trace_generic applies (1 - v) twice like the reference
+    (real_ray_tracer.py:134-137 + ray_aiming/paraxial.py:60-62,90-91)."""
+    table, data = load_case("vignetted_trace")
+    t = tr.HipRayTracer(table, dtype=torch.float64)
+    t.trace([0.0, 0.0, 0.25], [0.0, 0.7, 1.0], 0.55, num_rays=5, distribution="hexapolar")
+    assert_close_planes(_stack(t.surfaces), data["record"], 1e-10, 1e-11, "vignetted trace()")
+    table, data = load_case("vignetted_generic")
+    t = tr.HipRayTracer(table, dtype=torch.float64)
+    t.trace_generic(data["Hx"], data["Hy"], data["Px"], data["Py"], 0.55)
+    assert_close_planes(_stack(t.surfaces), data["record"], 1e-10, 1e-11,
+                        "vignetted trace_generic()")

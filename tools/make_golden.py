@@ -222,6 +222,28 @@ def polarizer_retarder(with_retarder=True):
     return lens
 
 
+def vignetted_cooke():
+    """Cooke triplet with vignetting factors on the off-axis fields and an x field:
+    exercises FieldGroup.get_vig_factor (nearest field) in trace() and the double
+    (1 - v) scaling of trace_generic (real_ray_tracer.py:134-137)."""
+    lens = optic_mod.Optic(name="VignettedCooke")
+    lens.surfaces.add(index=0, radius=be.inf, thickness=be.inf)
+    lens.surfaces.add(index=1, radius=22.01359, thickness=3.25896, material="SK16")
+    lens.surfaces.add(index=2, radius=-435.76044, thickness=6.00755)
+    lens.surfaces.add(index=3, radius=-22.21328, thickness=0.99997, material=("F2", "schott"))
+    lens.surfaces.add(index=4, radius=20.29192, thickness=4.75041, is_stop=True)
+    lens.surfaces.add(index=5, radius=79.68360, thickness=2.95208, material="SK16")
+    lens.surfaces.add(index=6, radius=-18.39533, thickness=42.20778)
+    lens.surfaces.add(index=7)
+    lens.set_aperture(aperture_type="EPD", value=10)
+    lens.fields.set_type(field_type="angle")
+    lens.fields.add(y=0)
+    lens.fields.add(y=14, vx=0.05, vy=0.15)
+    lens.fields.add(y=20, x=5, vx=0.1, vy=0.3)
+    lens.wavelengths.add(value=0.55, is_primary=True)
+    return lens
+
+
 def tir_prism():
     """Edge case: steep glass->air exit so part of the bundle is totally internally
     reflected (NaN directions, real_rays.py:179-180) and part misses a small
@@ -400,6 +422,12 @@ def main():
     run_case("polarizer_retarder", polarizer_retarder(True), [0.0, 0.0], [0.0, 1.0], None, None,
              0.55, use_trace=dict(num_rays=20, distribution="uniform"))
     run_case("polarizer_only", polarizer_retarder(False), 0.0, 1.0, px, py, 0.55)
+    run_case("vignetted_trace", vignetted_cooke(), [0.0, 0.0, 0.25], [0.0, 0.7, 1.0], None, None,
+             0.55, use_trace=dict(num_rays=5, distribution="hexapolar"))
+    hx = np.repeat([0.0, 0.05, 0.25, 0.2], 200)
+    hy = np.repeat([0.1, 0.6, 1.0, 0.9], 200)
+    px8, py8 = disc_points(800, 11)
+    run_case("vignetted_generic", vignetted_cooke(), hx, hy, px8, py8, 0.55)
     wavefront_goldens()
 
 
