@@ -222,3 +222,40 @@ def test_record_only_surface_in_the_middle(dtype, tol):
     assert np.array_equal(np.nan_to_num(got[3]), np.nan_to_num(got[2]))
     assert_close_planes(np.delete(got, 3, axis=0), data["record"], max(tol, 1e-9), max(tol, 1e-9),
                         "rows after the dummy")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("n", [1, 63, 257, 1000, 4099])
+def test_no_write_outside_the_callers_buffers(dtype, n):
+    """Memory safety: sentinels around the ray planes, in the stride padding of every
+    record plane, in a spare record row and around the PRT must survive the trace
+    (vector path, ragged tail and scalar path all covered by the sizes)."""
+    from optiland_amd.engine import HipSystem
+    table, data = load_case("zernike_fresnel_fringe")
+    hip = HipSystem(table, DEV)
+    reps = -(-n // data["rays_in"].shape[1])
+    src = np.tile(data["rays_in"], (1, reps))[:, :n]
+    SENT = 12345.0
+    pad = 8
+    big = torch.full((8, n + 2 * pad), SENT, dtype=dtype, device=DEV)
+    rays = [big[k, pad:pad + n] for k in range(8)]
+    for k in range(7):
+        rays[k].copy_(torch.tensor(src[k], dtype=dtype))
+    rays[7].zero_()
+    rows = table.num_surfaces
+    stride = n + 64
+    rec = torch.full((rows + 1, 8, stride), SENT, dtype=dtype, device=DEV)
+    prt_big = torch.full((9, n), SENT, dtype=dtype, device=DEV)
+    guard = torch.full((2, 64), SENT, dtype=dtype, device=DEV)  # neighbours of small allocs
+    res = hip.trace(rays, 0, record=rec, prt=prt_big, prt_identity=True, write_rays=True)
+    torch.cuda.synchronize()
+    assert bool((big[:, :pad] == SENT).all()) and bool((big[:, pad + n:] == SENT).all())
+    assert bool((rec[:rows, :, n:] == SENT).all()), "stride padding was written"
+    assert bool((rec[rows] == SENT).all()), "spare record row was written"
+    assert bool((guard == SENT).all())
+    assert not bool((rec[:rows, :, :n] == SENT).any())
+    assert not bool((prt_big == SENT).any())
+    # final state written back == last recorded row
+    for k in range(8):
+        assert torch.equal(rays[k].nan_to_num(nan=-1.0), res.row(rows - 1, k).nan_to_num(nan=-1.0))
+    hip.close()
