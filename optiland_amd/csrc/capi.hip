@@ -502,6 +502,12 @@ int ol_trace(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const rays
     return fail(OL_EINVAL, "ol_trace: wavelength index %d outside [0, %d)", wavelength_index,
                 sys->n_wl);
   if (n_rays == 0) return OL_OK;
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != sys->device)
+      return fail(OL_EINVAL, "ol_trace: current HIP device %d is not the system's device %d",
+                  cur, sys->device);
+  }
   if (!rays) return fail(OL_EINVAL, "ol_trace: rays is NULL");
   for (int k = 0; k < 8; ++k)
     if (!rays[k]) return fail(OL_EINVAL, "ol_trace: rays[%d] is NULL", k);

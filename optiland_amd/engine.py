@@ -125,7 +125,8 @@ class HipSystem:
 
     def trace(self, rays, wavelength_index: int = 0, record=True, prt: torch.Tensor | None = None,
               first: int = 0, last: int | None = None, write_rays: bool | None = None,
-              check_status: bool = True, prt_identity: bool = False) -> TraceResult:
+              check_status: bool = True, prt_identity: bool = False,
+              defer_status: bool = False) -> TraceResult:
         """Launch the fused trace.
 
         rays: sequence of 8 contiguous 1-D device tensors (x,y,z,L,M,N,i,opd) of one
@@ -182,26 +183,33 @@ class HipSystem:
                 self._status.data_ptr() if check_status else None,
                 _stream_ptr(self.device))
         _capi.check(rc, "ol_trace")
-        status = int(self._status.item()) if check_status else 0
+        # defer_status: the kernel still ORs its bits into self._status, but the caller
+        # reads them back later (together with other device-side checks)
+        status = int(self._status.item()) if (check_status and not defer_status) else 0
+        self.raise_for_status(status)
+        return TraceResult(n, rays, rec, prt, status, first, last)
+
+    def row0_planes(self, record: torch.Tensor, n: int):
+        """The 8 planes of record row 0 as ray planes (zero-copy object row)."""
+        return [record[0, k, :n] for k in range(8)]
+
+    @staticmethod
+    def raise_for_status(status: int) -> None:
+        """Device status bits -> the reference's exceptions (same texts)."""
         if status & S.STATUS_ZERNIKE_RANGE:
-            # same text as optiland/geometries/zernike.py:262-266
+            # optiland/geometries/zernike.py:262-266
             raise ValueError(
                 "Zernike coordinates must be normalized "
                 "to [-1, 1]. Consider updating the normalization "
                 "radius to 1.1x the surface aperture."
             )
         if status & S.STATUS_CHEBYSHEV_RANGE:
-            # same text as optiland/geometries/chebyshev.py:235-240
+            # optiland/geometries/chebyshev.py:235-240
             raise ValueError(
                 "Chebyshev input coordinates must be normalized "
                 "to [-1, 1]. Consider updating the normalization "
                 "factors."
             )
-        return TraceResult(n, rays, rec, prt, status, first, last)
-
-    def row0_planes(self, record: torch.Tensor, n: int):
-        """The 8 planes of record row 0 as ray planes (zero-copy object row)."""
-        return [record[0, k, :n] for k in range(8)]
 
     # ------------------------------------------------------------- ray source
     def generate_rays(self, hx, hy, px, py, vx=None, vy=None, out=None):

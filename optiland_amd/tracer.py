@@ -70,6 +70,7 @@ class HipRayTracer:
         self.surfaces = RecordedSurfaces()
         self.ray_aiming_config = {"mode": "paraxial", "max_iter": 10, "tol": 1e-6}
         self.record_all = True  # drop-in semantics; False = image plane only
+        self._pending = []      # deferred on-device argument checks
         f = np.asarray(table.fields, dtype=np.float64).reshape(-1, 4)
         self._fields = f
 
@@ -89,16 +90,37 @@ class HipRayTracer:
         return torch.as_tensor(np.atleast_1d(np.asarray(v, dtype=np.float64)),
                                dtype=self.dtype, device=self.device).reshape(-1)
 
-    @staticmethod
-    def _validate_normalized_coordinates(x, y, coord_type="field"):
-        """real_ray_tracer.py:156-173 (same message)."""
-        def ok(v):
-            if isinstance(v, torch.Tensor):
-                return bool(((v >= -1) & (v <= 1)).all())
-            a = np.asarray(v, dtype=np.float64)
-            return bool(np.all((a >= -1) & (a <= 1)))
-        if not (ok(x) and ok(y)):
-            raise ValueError(f"Normalized {coord_type} coordinates must be within (-1, 1)")
+    def _validate_normalized_coordinates(self, x, y, coord_type="field"):
+        """real_ray_tracer.py:156-173 (same message).  Host values are checked at once;
+        device tensors are checked ON DEVICE and the verdict is read back together with
+        the trace's status word (one synchronisation per call instead of one per
+        argument)."""
+        for v in (x, y):
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                self._pending.append((((v < -1) | (v > 1)).any(), coord_type))
+            else:
+                a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else \
+                    np.asarray(v, dtype=np.float64)
+                if not bool(np.all((a >= -1) & (a <= 1))):
+                    self._pending.clear()
+                    raise ValueError(
+                        f"Normalized {coord_type} coordinates must be within (-1, 1)")
+
+    def _finish_checks(self, eng):
+        """One read-back: deferred range checks + the kernel's status word."""
+        pending, self._pending = self._pending, []
+        status_t = getattr(eng, "_status", None)
+        if status_t is None:  # engines that raise eagerly (tests' oracle stand-in)
+            for bad, kind in pending:
+                if bool(bad):
+                    raise ValueError(f"Normalized {kind} coordinates must be within (-1, 1)")
+            return
+        words = [status_t[0].to(torch.int64)] + [b.to(torch.int64) for b, _ in pending]
+        vals = torch.stack(words).tolist()
+        for (_, kind), bad in zip(pending, vals[1:]):
+            if bad:
+                raise ValueError(f"Normalized {kind} coordinates must be within (-1, 1)")
+        eng.raise_for_status(int(vals[0]))
 
     def _vig_factor(self, hx, hy):
         """FieldGroup.get_vig_factor (fields/field_group.py:93-122): nearest field
@@ -148,7 +170,10 @@ class HipRayTracer:
                               device=self.device)  # written by the kernel (starts from I)
             k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
             i0 = rays[6].clone()
-        res = eng.trace(rays, wl, record=record, prt=prt, prt_identity=prt is not None)
+        deferred = hasattr(eng, "_status")
+        kw = {"defer_status": True} if deferred else {}
+        res = eng.trace(rays, wl, record=record, prt=prt, prt_identity=prt is not None, **kw)
+        self._finish_checks(eng)
         self.surfaces._bind(res)
         wt = torch.full((n,), w, dtype=self.dtype, device=self.device)
         if res.record is not None:
