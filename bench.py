@@ -174,11 +174,13 @@ def main():
     import torch.distributed as dist
     have_pg = dist.is_available() and dist.is_initialized()
     exchange = args.exchange if (world > 1 or (args.force_exchange and have_pg)) else "none"
-    if exchange != "none":
-        gather_buf = None
-        if exchange == "gather":
-            gather_buf = torch.empty((world, 3, n), dtype=dtype, device=device)
-            hits = torch.empty((3, n), dtype=dtype, device=device)
+    pending = [None, None]  # in-flight all-gathers (double-buffered)
+    if exchange == "gather":
+        # two buffer pairs: the all-gather of step k runs on RCCL's stream while step
+        # k+1 traces; a buffer is only reused after its collective has completed
+        gather_buf = [torch.empty((world, 3, n), dtype=dtype, device=device) for _ in range(2)]
+        hits = [torch.empty((3, n), dtype=dtype, device=device) for _ in range(2)]
+    step_no = [0]
 
     def step(ev0=None, ev1=None):
         if args.mode == "record":
@@ -202,10 +204,15 @@ def main():
                 mom = hip.spot_moments(x, y, inten)
                 dist.all_reduce(mom)
             else:
-                hits[0].copy_(x)
-                hits[1].copy_(y)
-                hits[2].copy_(inten)
-                dist.all_gather_into_tensor(gather_buf.view(-1), hits.view(-1))
+                k = step_no[0] & 1
+                step_no[0] += 1
+                if pending[k] is not None:
+                    pending[k].wait()  # stream-level wait: this pair is free again
+                hits[k][0].copy_(x)
+                hits[k][1].copy_(y)
+                hits[k][2].copy_(inten)
+                pending[k] = dist.all_gather_into_tensor(gather_buf[k].view(-1),
+                                                         hits[k].view(-1), async_op=True)
         return res
 
     for _ in range(args.warmup):
@@ -219,6 +226,9 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(*evs[k])
+    for w in pending:
+        if w is not None:
+            w.wait()
     torch.cuda.synchronize(device)
     if have_pg:
         dist.barrier()
