@@ -29,6 +29,10 @@
 #include "device_table.h"
 #include "trace_launch.h"
 
+#ifndef OL_TABLE_IN_LDS
+#define OL_TABLE_IN_LDS 0  // 1: stage the surface table in LDS (measured slower)
+#endif
+
 namespace ol {
 
 // --------------------------------------------------------------------------
@@ -1152,6 +1156,28 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
     const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
     TraceArgs<T> a) {
+#if OL_TABLE_IN_LDS
+  // Experiment (BASELINE.json: "surface coefficients staged in LDS"): stage the hot
+  // blocks and the optics of the traced range into LDS once per workgroup and read
+  // them back with wave-uniform ds_reads.  Measured against the scalar-load path in
+  // DESIGN.md 4.1; off by default.
+  constexpr int kMaxLdsSurf = 64;
+  __shared__ DevSurfHot<T> lds_hot[kMaxLdsSurf];
+  __shared__ DevOptics<T> lds_opt[kMaxLdsSurf];
+  {
+    const int ns = a.last - a.first + 1;
+    constexpr int HW = sizeof(DevSurfHot<T>) / 4, OW = sizeof(DevOptics<T>) / 4;
+    const uint32_t* gh = reinterpret_cast<const uint32_t*>(surf_tab + a.first);
+    uint32_t* lh = reinterpret_cast<uint32_t*>(lds_hot);
+    for (int i = threadIdx.x; i < ns * HW; i += kTraceBlock) lh[i] = gh[i];
+    uint32_t* lo = reinterpret_cast<uint32_t*>(lds_opt);
+    for (int i = threadIdx.x; i < ns * OW; i += kTraceBlock) {
+      const int sidx = i / OW, w = i % OW;
+      lo[i] = reinterpret_cast<const uint32_t*>(optics_tab + (a.first + sidx) * a.n_wl + a.wl)[w];
+    }
+    __syncthreads();
+  }
+#endif
   const int64_t base = ((int64_t)blockIdx.x * kTraceBlock + threadIdx.x) * RPT;
   if (base >= a.n) return;
   const int64_t left = a.n - base;
@@ -1222,14 +1248,26 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
   last_traced.cold = cold_tab;
   // hot block of the current surface by value (one s_load_dwordx16 for fp32); the
   // next surface's block is requested before the current one is worked on.
+#if OL_TABLE_IN_LDS
+  DevSurfHot<T> cur = lds_hot[0];
+#else
   DevSurfHot<T> cur = surf_tab[a.first];
+#endif
   for (int s = a.first; s <= a.last; ++s) {
     DevSurf<T> S;
     static_cast<DevSurfHot<T>&>(S) = cur;
     S.cold = cold_tab + s;
+#if OL_TABLE_IN_LDS
+    if (s < a.last) cur = lds_hot[s + 1 - a.first];
+#else
     if (s < a.last) cur = surf_tab[s + 1];
+#endif
     if (S.interaction != kRecordOnly) {
+#if OL_TABLE_IN_LDS
+      const DevOptics<T> O = lds_opt[s - a.first];
+#else
       const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
+#endif
       surface_step<T, RPT, POLK, NR>(S, O, coeff_tab, is_global, r, P, status);
       is_global = false;
       last_traced = S;
