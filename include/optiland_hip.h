@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OL_ABI_VERSION 2
+#define OL_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------- */
 #define OL_OK 0
@@ -273,6 +273,39 @@ int ol_spot_moments(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
 int ol_spot_max_r2(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
                    const void* intensity, double cx, double cy, double* out1,
                    void* stream);
+
+/* Fused spot pipeline for one ray block: generate -> trace the whole sequence ->
+ * reduce, in ONE kernel (SURVEY.md 8 f1 + f2).  The rays never exist in HBM: each
+ * lane builds its rays from the normalised coordinates exactly like
+ * ol_generate_rays, walks surfaces [0, num_surfaces) like ol_trace and folds the
+ * image-plane hit into masked sums about (cx, cy).  Replaces, for unpolarised
+ * systems, the chain Optic.trace -> surface_group.x/y/intensity[-1] ->
+ * SpotDiagram.centroid / rms_spot_radius / geometric_spot_radius
+ * (raytrace/real_ray_tracer.py:58-118, analysis/spot_diagram/core.py:329-372,
+ * 440-481).
+ *   hx,hy    per-ray normalised field planes, or both NULL -> p->hx, p->hy
+ *   px,py    per-ray normalised pupil planes (required)
+ *   vx,vy    per-ray (1 - vignetting factor) planes, or both NULL -> p->vx, p->vy
+ *   hits     NULL, or 3 planes receiving the global x, y and intensity at the last
+ *            surface (what surface_group.x[-1], .y[-1], .intensity[-1] hold)
+ *   out7     device doubles, ACCUMULATED (zero them first), rays with i > 0 only:
+ *            {count, sum dx, sum dy, sum dx^2, sum dy^2, sum i, max(dx^2+dy^2)}
+ *            with dx = x - p->cx, dy = y - p->cy
+ *   status   as ol_trace.
+ * Systems with polarization-dependent coatings are refused (OL_EINVAL) like
+ * ol_trace without a prt.                                                       */
+typedef struct ol_spot_params {
+  ol_raygen_params raygen;
+  double hx, hy;  /* launch-uniform normalised field (used when hx == NULL)     */
+  double vx, vy;  /* launch-uniform 1 - vignetting factor (used when vx == NULL)*/
+  double cx, cy;  /* centre of the moments, global image-plane coordinates      */
+} ol_spot_params;
+
+int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays,
+                  const ol_spot_params* p, const void* hx, const void* hy,
+                  const void* px, const void* py, const void* vx, const void* vy,
+                  int32_t wavelength_index, void* const hits[3], double* out7,
+                  uint32_t* status, void* stream);
 
 /* Wavefront OPD against a spherical reference centred on the chief-ray image point
  * (wavefront/strategy.py:163-215 ChiefRayStrategy.

@@ -57,6 +57,11 @@ class RaygenParams(C.Structure):
     ]
 
 
+class SpotParams(C.Structure):
+    _fields_ = [("raygen", RaygenParams)] + [(k, C.c_double) for k in
+                                             ("hx", "hy", "vx", "vy", "cx", "cy")]
+
+
 class WavefrontParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("xc", "yc", "zc", "R", "n_image", "opd_ref", "ux",
                                           "uy", "half_epd", "wavelength_um")]
@@ -86,11 +91,12 @@ EXPORTS = (
     "ol_spot_max_r2",
     "ol_set_tuning",
     "ol_wavefront_opd",
+    "ol_trace_spot",
 )
 
 F32, F64 = 0, 1
 TUNE_RAYS_PER_THREAD, TUNE_COMPACT = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def library_path() -> str:
@@ -138,6 +144,9 @@ def load():
     lib.ol_spot_max_r2.argtypes = [C.c_int, i64, vp, vp, vp, C.c_double, C.c_double, vp, vp]
     lib.ol_wavefront_opd.restype = C.c_int
     lib.ol_wavefront_opd.argtypes = [vp, C.c_int, i64, C.POINTER(vp), vp, vp, vp, vp, vp]
+    lib.ol_trace_spot.restype = C.c_int
+    lib.ol_trace_spot.argtypes = [vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, vp, i32,
+                                  C.POINTER(vp), vp, vp, vp]
     lib.ol_set_tuning.restype = C.c_int
     lib.ol_set_tuning.argtypes = [i32, i32]
     if lib.ol_abi_version() != ABI_VERSION:

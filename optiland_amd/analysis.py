@@ -4,9 +4,10 @@ Mirrors the numeric part of the reference's `SpotDiagram`
 (optiland/analysis/spot_diagram/core.py:329-372, 420-481 and reference.py:60-105):
 for every (field, wavelength) trace `num_rings` hexapolar rings, keep rays with
 intensity > 0, centre on the chief ray of the reference wavelength (default) or on
-the centroid, and report RMS and geometric (maximum) radius.  The image-plane hits
-never leave the GPU: each spot is reduced by `ol_spot_moments` / `ol_spot_max_r2`
-to seven doubles.
+the centroid, and report RMS and geometric (maximum) radius.  For unpolarised
+systems each spot is ONE fused kernel (`ol_trace_spot`: generate -> trace -> reduce)
+that returns seven doubles -- no ray or hit plane is ever written; polarised systems
+trace into planes and reduce them with `ol_spot_moments` / `ol_spot_max_r2`.
 """
 
 from __future__ import annotations
@@ -38,58 +39,93 @@ class SpotDiagram:
         self.ref_index = primary_index
         self._moments = None
         self._centers = None
-        self._geo = None
         self._run()
 
-    # image-plane local coordinates: global minus the image vertex (untilted)
+    # Internal form: per [field][wavelength] seven doubles ABOUT the field's centre
+    # (cx, cy): {count, sum dx, sum dy, sum dx^2, sum dy^2, sum i, max r^2}.
     def _run(self):
+        t = self.tracer
+        fused = t.table.polarization is None and not t.table.uses_polarization
+        self.fused = fused
+        if fused:
+            self._run_fused()
+        else:
+            self._run_planes()
+
+    def _chief_center(self, hx, hy):
+        r = self.tracer.trace_generic(hx, hy, 0.0, 0.0, self.wavelengths[self.ref_index])
+        return float(r.x[0]), float(r.y[0])
+
+    def _run_fused(self):
+        """One `ol_trace_spot` launch per (field, wavelength): generate -> trace ->
+        reduce in a single kernel; no ray or hit planes are materialised."""
+        t = self.tracer
+        centers, mom = [], []
+        for hx, hy in self.fields:
+            if self.reference == "chief_ray":
+                c = self._chief_center(hx, hy)
+            else:  # centroid of the reference wavelength: one extra reduction pass
+                m0, _ = t.trace_spot(hx, hy, self.wavelengths[self.ref_index], self.num_rings,
+                                     self.distribution)
+                m0 = m0.cpu().numpy()
+                c = (m0[1] / m0[0], m0[2] / m0[0])
+            centers.append(c)
+            row = [t.trace_spot(hx, hy, w, self.num_rings, self.distribution, center=c)[0]
+                   for w in self.wavelengths]
+            mom.append([m.cpu().numpy() for m in row])
+        self._moments, self._centers = mom, centers
+
+    def _run_planes(self):
+        """Polarised systems: trace() (with its update_intensity epilogue) into planes,
+        then the two reduction kernels."""
         t, eng = self.tracer, self.tracer.engine
         old = t.record_all
         t.record_all = True
         try:
-            mom = [[None] * len(self.wavelengths) for _ in self.fields]
+            raw = [[None] * len(self.wavelengths) for _ in self.fields]
             hits = [[None] * len(self.wavelengths) for _ in self.fields]
             for fi, (hx, hy) in enumerate(self.fields):
                 for wi, w in enumerate(self.wavelengths):
                     t.trace(hx, hy, w, self.num_rings, self.distribution)
-                    x, y, inten = (t.surfaces.x[-1], t.surfaces.y[-1], t.surfaces.intensity[-1])
-                    x, y, inten = x.contiguous().clone(), y.contiguous().clone(), inten.contiguous().clone()
-                    mom[fi][wi] = eng.spot_moments(x, y, inten).cpu().numpy()
+                    # core.py:455-459 reads the RECORDED image-plane state
+                    x, y, inten = (v[-1].contiguous().clone() for v in
+                                   (t.surfaces.x, t.surfaces.y, t.surfaces.intensity))
+                    raw[fi][wi] = eng.spot_moments(x, y, inten).cpu().numpy()
                     hits[fi][wi] = (x, y, inten)
-            centers = []
+            centers, mom = [], []
             for fi, (hx, hy) in enumerate(self.fields):
                 if self.reference == "chief_ray":
-                    r = t.trace_generic(hx, hy, 0.0, 0.0, self.wavelengths[self.ref_index])
-                    centers.append((float(r.x[0]), float(r.y[0])))
+                    cx, cy = self._chief_center(hx, hy)
                 else:
-                    m = mom[fi][self.ref_index]
-                    centers.append((m[1] / m[0], m[2] / m[0]))
-            geo = [[float(eng.spot_max_r2(*hits[fi][wi], *centers[fi])[0]) ** 0.5
-                    for wi in range(len(self.wavelengths))] for fi in range(len(self.fields))]
+                    m = raw[fi][self.ref_index]
+                    cx, cy = m[1] / m[0], m[2] / m[0]
+                centers.append((cx, cy))
+                row = []
+                for wi in range(len(self.wavelengths)):
+                    m = raw[fi][wi]
+                    n = m[0]
+                    r2 = float(eng.spot_max_r2(*hits[fi][wi], cx, cy)[0])
+                    row.append(np.array([n, m[1] - n * cx, m[2] - n * cy,
+                                         m[3] - 2 * cx * m[1] + n * cx * cx,
+                                         m[4] - 2 * cy * m[2] + n * cy * cy, n, r2]))
+                mom.append(row)
         finally:
             t.record_all = old
-        self._moments, self._centers, self._geo = mom, centers, geo
+        self._moments, self._centers = mom, centers
 
     def centroid(self):
         """(x, y) centroid per field at the reference wavelength, image-local."""
         out = []
-        for fi in range(len(self.fields)):
+        for fi, (cx, cy) in enumerate(self._centers):
             m = self._moments[fi][self.ref_index]
-            out.append((m[1] / m[0] - self._origin[0], m[2] / m[0] - self._origin[1]))
+            out.append((cx + m[1] / m[0] - self._origin[0], cy + m[2] / m[0] - self._origin[1]))
         return out
 
     def rms_spot_radius(self):
         """sqrt(mean((x-cx)^2 + (y-cy)^2)) per [field][wavelength]."""
-        out = []
-        for fi, (cx, cy) in enumerate(self._centers):
-            row = []
-            for m in self._moments[fi]:
-                n = m[0]
-                v = (m[3] - 2 * cx * m[1] + n * cx * cx + m[4] - 2 * cy * m[2] + n * cy * cy) / n
-                row.append(float(max(v, 0.0)) ** 0.5)
-            out.append(row)
-        return out
+        return [[float(max((m[3] + m[4]) / m[0], 0.0)) ** 0.5 for m in row]
+                for row in self._moments]
 
     def geometric_spot_radius(self):
         """max sqrt((x-cx)^2 + (y-cy)^2) per [field][wavelength]."""
-        return [list(r) for r in self._geo]
+        return [[float(m[6]) ** 0.5 for m in row] for row in self._moments]

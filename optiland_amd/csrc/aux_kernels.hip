@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "raygen_device.h"
 #include "trace_launch.h"
 
 namespace ol {
@@ -18,18 +19,6 @@ inline unsigned grid_for(int64_t n) {
   return (unsigned)(b < cap ? (b > 0 ? b : 1) : cap);
 }
 
-template <typename T>
-__device__ __forceinline__ T tan_deg(T deg);
-template <>
-__device__ __forceinline__ float tan_deg<float>(float deg) {
-  // formed in double: the field angle is a per-field constant in practice and
-  // fp32 tanf of a degree->radian product would cost 1e-7 of a 20 mm offset.
-  return (float)tan((double)deg * 0.017453292519943295);
-}
-template <>
-__device__ __forceinline__ double tan_deg<double>(double deg) {
-  return tan(deg * 0.017453292519943295);
-}
 }  // namespace
 
 // rays/ray_generator.py:47-99, rays/ray_aiming/paraxial.py:33-106,
@@ -43,36 +32,18 @@ __global__ __launch_bounds__(kBlock) void raygen_kernel(RaygenDev p, int64_t n,
                                                         const T* __restrict__ vx,
                                                         const T* __restrict__ vy, T* ox, T* oy,
                                                         T* oz, T* oL, T* oM, T* oN, T* oi) {
-  const T EPL = (T)p.EPL, EPD = (T)p.EPD, maxf = (T)p.max_field;
-  const T off_epl = (T)(p.offset + p.EPL);
-  const T z_inf = (T)(p.z_first - p.offset), z_fin = (T)p.z_first;
-  const T epl_z = (T)(p.EPL - p.z_first);
+  const RaygenConsts<T> c(p);
   for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
        j += (int64_t)gridDim.x * kBlock) {
-    const T vxx = vx ? vx[j] : T(1), vyy = vy ? vy[j] : T(1);
-    const T tx = tan_deg<T>(maxf * hx[j]), ty = tan_deg<T>(maxf * hy[j]);
-    const T pxx = px[j], pyy = py[j];
-    T x0, y0, z0;
-    if (p.object_infinite) {
-      x0 = pxx * EPD / T(2) * vxx + (-tx * off_epl);
-      y0 = pyy * EPD / T(2) * vyy + (-ty * off_epl);
-      z0 = z_inf;
-    } else {
-      x0 = -tx * epl_z;
-      y0 = -ty * epl_z;
-      z0 = z_fin;
-    }
-    const T x1 = pxx * EPD * vxx / T(2), y1 = pyy * EPD * vyy / T(2), z1 = EPL;
-    const T dx = x1 - x0, dy = y1 - y0, dz = z1 - z0;
-    T mag = sqrt(dx * dx + dy * dy + dz * dz);
-    const bool is_zero = mag < T(1e-9);
-    mag = is_zero ? T(1) : mag;
-    ox[j] = x0;
-    oy[j] = y0;
-    oz[j] = z0;
-    oL[j] = is_zero ? T(0) : dx / mag;
-    oM[j] = is_zero ? T(0) : dy / mag;
-    oN[j] = is_zero ? T(1) : dz / mag;
+    T tx, ty, o[6];
+    raygen_field<T>(c, hx[j], hy[j], tx, ty);
+    raygen_one<T>(c, tx, ty, px[j], py[j], vx ? vx[j] : T(1), vy ? vy[j] : T(1), o);
+    ox[j] = o[0];
+    oy[j] = o[1];
+    oz[j] = o[2];
+    oL[j] = o[3];
+    oM[j] = o[4];
+    oN[j] = o[5];
     oi[j] = T(1);
   }
 }

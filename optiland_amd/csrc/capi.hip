@@ -264,6 +264,51 @@ int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* c
   return OL_OK;
 }
 
+template <typename T>
+int do_trace_spot(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
+                  const ol_spot_params* p, const void* hx, const void* hy, const void* px,
+                  const void* py, const void* vx, const void* vy, int32_t wl, void* const hits[3],
+                  double* out7, uint32_t* status, hipStream_t stream) {
+  ol::SpotArgs<T> a;
+  a.surf = tab.surf;
+  a.cold = tab.cold;
+  a.optics = tab.optics;
+  a.coeffs = tab.coeffs;
+  a.hx = static_cast<const T*>(hx);
+  a.hy = static_cast<const T*>(hy);
+  a.px = static_cast<const T*>(px);
+  a.py = static_cast<const T*>(py);
+  a.vx = static_cast<const T*>(vx);
+  a.vy = static_cast<const T*>(vy);
+  a.hx0 = (T)p->hx;
+  a.hy0 = (T)p->hy;
+  a.vx0 = (T)p->vx;
+  a.vy0 = (T)p->vy;
+  const ol_raygen_params& g = p->raygen;
+  a.rg = ol::RaygenDev{g.object_infinite, g.EPL, g.EPD, g.max_field, g.offset, g.z_first};
+  a.cx = p->cx;
+  a.cy = p->cy;
+  bool vec = aligned16(px) && aligned16(py) && aligned16(hx) && aligned16(hy) && aligned16(vx) &&
+             aligned16(vy);  // NULL counts as aligned
+  for (int k = 0; k < 3; ++k) {
+    a.hits[k] = hits ? static_cast<T*>(hits[k]) : nullptr;
+    vec = vec && aligned16(a.hits[k]);
+  }
+  a.out = out7;
+  a.status = status;
+  a.n = n;
+  a.first = 0;
+  a.last = sys->n_surf - 1;
+  a.n_wl = sys->n_wl;
+  a.wl = wl;
+  bool has_newton = false;
+  for (int32_t s = 0; s < sys->n_surf; ++s)
+    has_newton = has_newton || (sys->geom[s] != OL_GEOM_PLANE && sys->geom[s] != OL_GEOM_STANDARD);
+  hipError_t e = ol::launch_spot_trace<T>(a, vec, has_newton, stream);
+  if (e != hipSuccess) return fail(OL_EHIP, "spot launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -565,6 +610,41 @@ int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n, const vo
   }
   if (e != hipSuccess) return fail(OL_EHIP, "raygen launch failed: %s", hipGetErrorString(e));
   return OL_OK;
+}
+
+int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_spot_params* p,
+                  const void* hx, const void* hy, const void* px, const void* py, const void* vx,
+                  const void* vy, int32_t wavelength_index, void* const hits[3], double* out7,
+                  uint32_t* status, void* stream) {
+  if (!sys) return fail(OL_EINVAL, "ol_trace_spot: system is NULL");
+  if (dt != OL_F32 && dt != OL_F64) return fail(OL_EINVAL, "ol_trace_spot: bad dtype %d", (int)dt);
+  if (!p || !px || !py || !out7) return fail(OL_EINVAL, "ol_trace_spot: NULL argument");
+  if ((hx == nullptr) != (hy == nullptr) || (vx == nullptr) != (vy == nullptr))
+    return fail(OL_EINVAL, "ol_trace_spot: hx/hy (and vx/vy) must be given together");
+  if (hits && (!hits[0] || !hits[1] || !hits[2]))
+    return fail(OL_EINVAL, "ol_trace_spot: hits needs three planes");
+  if (n_rays < 0) return fail(OL_EINVAL, "ol_trace_spot: negative ray count");
+  if (wavelength_index < 0 || wavelength_index >= sys->n_wl)
+    return fail(OL_EINVAL, "ol_trace_spot: wavelength index %d outside [0, %d)", wavelength_index,
+                sys->n_wl);
+  for (int32_t s = 0; s < sys->n_surf; ++s)
+    if (sys->coating[s] >= OL_COAT_FRESNEL)
+      return fail(OL_EINVAL,
+                  "Polarization must be set when surfaces have polarization-dependent "
+                  "coatings.");
+  if (n_rays == 0) return OL_OK;
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != sys->device)
+      return fail(OL_EINVAL, "ol_trace_spot: current HIP device %d is not the system's device %d",
+                  cur, sys->device);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dt == OL_F32)
+    return do_trace_spot<float>(sys, sys->f32, n_rays, p, hx, hy, px, py, vx, vy,
+                                wavelength_index, hits, out7, status, st);
+  return do_trace_spot<double>(sys, sys->f64, n_rays, p, hx, hy, px, py, vx, vy,
+                               wavelength_index, hits, out7, status, st);
 }
 
 int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt, int32_t prt_complex,

@@ -1,0 +1,71 @@
+// raygen_device.h -- per-ray launch state from normalised field / pupil coordinates.
+// ONE definition shared by the stand-alone ray generator (aux_kernels.hip) and the
+// fused generate -> trace -> reduce spot kernel (trace_kernel.hip), so both produce
+// the same rays.  Reference: rays/ray_generator.py:47-99,
+// rays/ray_aiming/paraxial.py:33-106, fields/field_types/angle.py:17-58.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "trace_launch.h"
+
+namespace ol {
+
+template <typename T>
+__device__ __forceinline__ T tan_deg(T deg);
+template <>
+__device__ __forceinline__ float tan_deg<float>(float deg) {
+  // formed in double: the field angle is a per-field constant in practice and
+  // fp32 tanf of a degree->radian product would cost 1e-7 of a 20 mm offset.
+  return (float)tan((double)deg * 0.017453292519943295);
+}
+template <>
+__device__ __forceinline__ double tan_deg<double>(double deg) {
+  return tan(deg * 0.017453292519943295);
+}
+
+// launch-invariant scalars, converted to the working precision once
+template <typename T>
+struct RaygenConsts {
+  T EPL, EPD, maxf, off_epl, z_inf, z_fin, epl_z;
+  bool infinite;
+  __device__ __forceinline__ explicit RaygenConsts(const RaygenDev& p)
+      : EPL((T)p.EPL), EPD((T)p.EPD), maxf((T)p.max_field), off_epl((T)(p.offset + p.EPL)),
+        z_inf((T)(p.z_first - p.offset)), z_fin((T)p.z_first), epl_z((T)(p.EPL - p.z_first)),
+        infinite(p.object_infinite != 0) {}
+};
+
+// field tangents (angle.py:40-47); hoistable when the field is launch-uniform
+template <typename T>
+__device__ __forceinline__ void raygen_field(const RaygenConsts<T>& c, T hx, T hy, T& tx, T& ty) {
+  tx = tan_deg<T>(c.maxf * hx);
+  ty = tan_deg<T>(c.maxf * hy);
+}
+
+// o[0..5] = x, y, z, L, M, N  (intensity is 1, ray_generator.py:81-85)
+template <typename T>
+__device__ __forceinline__ void raygen_one(const RaygenConsts<T>& c, T tx, T ty, T px, T py, T vx,
+                                           T vy, T (&o)[6]) {
+  T x0, y0, z0;
+  if (c.infinite) {
+    x0 = px * c.EPD / T(2) * vx + (-tx * c.off_epl);
+    y0 = py * c.EPD / T(2) * vy + (-ty * c.off_epl);
+    z0 = c.z_inf;
+  } else {
+    x0 = -tx * c.epl_z;
+    y0 = -ty * c.epl_z;
+    z0 = c.z_fin;
+  }
+  const T x1 = px * c.EPD * vx / T(2), y1 = py * c.EPD * vy / T(2), z1 = c.EPL;
+  const T dx = x1 - x0, dy = y1 - y0, dz = z1 - z0;
+  T mag = sqrt(dx * dx + dy * dy + dz * dz);
+  const bool is_zero = mag < T(1e-9);  // paraxial.py:96-104
+  mag = is_zero ? T(1) : mag;
+  o[0] = x0;
+  o[1] = y0;
+  o[2] = z0;
+  o[3] = is_zero ? T(0) : dx / mag;
+  o[4] = is_zero ? T(0) : dy / mag;
+  o[5] = is_zero ? T(1) : dz / mag;
+}
+
+}  // namespace ol

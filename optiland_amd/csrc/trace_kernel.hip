@@ -24,9 +24,11 @@
 //     and hands its last gradient to the normal -- see newton_iterate().
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include <stdlib.h>
 
 #include "device_table.h"
+#include "raygen_device.h"
 #include "trace_launch.h"
 
 #ifndef OL_TABLE_IN_LDS
@@ -1392,5 +1394,234 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
 
 template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, bool, hipStream_t);
 template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, bool, hipStream_t);
+
+// --------------------------------------------------------------------------
+// fused spot kernel: generate -> trace -> reduce, nothing but the pupil read
+// --------------------------------------------------------------------------
+// SURVEY.md 8 f1 + f2: the spot statistics of one (field, wavelength) need only
+// sum / max reductions over the image-plane hits, so the rays never have to exist in
+// HBM.  Each lane generates its rays from (Hx, Hy, Px, Py) (raygen_device.h, the same
+// code as ol_generate_rays), walks the surface table exactly like trace_kernel and
+// folds the hit into per-lane fp64 partial sums about the caller's centre (cx, cy):
+//   out[0] += #{i > 0}        out[1] += sum dx      out[2] += sum dy
+//   out[3] += sum dx^2        out[4] += sum dy^2    out[5] += sum i
+//   out[6]  = max(out[6], max(dx^2 + dy^2))         (dx = x - cx, dy = y - cy)
+// the mask i > 0 is analysis/spot_diagram/core.py:470-476.  HBM traffic: 2 planes
+// read (+3 written when the caller asks for the hits); the kernel is ALU-bound.
+// A workgroup walks `tiles_per_block` consecutive tiles (chosen by the launcher): few
+// enough workgroups that the 7 same-address atomics per workgroup stay far below the
+// L2 atomic rate, many enough (>= ~8 rounds of resident workgroups) that the last
+// round's partial occupancy does not show.
+
+__device__ __forceinline__ double spot_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double spot_wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+template <typename T, int RPT, int NR, bool FIELDP>
+__global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
+    const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
+    const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
+    SpotArgs<T> a) {
+  const RaygenConsts<T> c(a.rg);
+  // FIELDP: per-ray field planes.  A template parameter because the per-ray
+  // double-precision tangent (tan_deg) would otherwise set the register budget of
+  // the common launch-uniform-field case as well.
+  constexpr bool field_planes = FIELDP;
+  const bool vig_planes = a.vx != nullptr;
+  // launch-uniform field: the two tangents come from the host (launch_spot_nr) --
+  // evaluated per lane the double-precision tan() cost ~15 % of the whole kernel
+  const T tx0 = a.tx0, ty0 = a.ty0;
+
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  double rmax = 0.0;
+  uint32_t status = 0;
+  constexpr int64_t kTileRays = (int64_t)kTraceBlock * RPT;
+  const int64_t ntiles = (a.n + kTileRays - 1) / kTileRays;
+
+  for (int tt = 0; tt < a.tiles_per_block; ++tt) {
+    const int64_t tile = (int64_t)blockIdx.x * a.tiles_per_block + tt;
+    if (tile >= ntiles) break;  // workgroup-uniform
+    const int64_t base = (tile * kTraceBlock + threadIdx.x) * RPT;
+    const int64_t left = a.n - base;
+    const int cnt = left >= RPT ? RPT : (left > 0 ? (int)left : 0);
+
+    // pupil (and optional per-ray field / vignetting) planes; lanes past the end
+    // trace the on-axis pupil point and are masked out of the sums
+    T in[6][RPT];
+    if (RPT > 1 && cnt == RPT) {
+      using V = typename VecOf<T, RPT>::type;
+      V v[6];
+      v[0] = *reinterpret_cast<const V*>(a.px + base);
+      v[1] = *reinterpret_cast<const V*>(a.py + base);
+      if constexpr (FIELDP) {
+        v[2] = *reinterpret_cast<const V*>(a.hx + base);
+        v[3] = *reinterpret_cast<const V*>(a.hy + base);
+      }
+      if (vig_planes) {
+        v[4] = *reinterpret_cast<const V*>(a.vx + base);
+        v[5] = *reinterpret_cast<const V*>(a.vy + base);
+      }
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        in[0][k] = vec_get<T, RPT>(v[0], k);
+        in[1][k] = vec_get<T, RPT>(v[1], k);
+        in[2][k] = field_planes ? vec_get<T, RPT>(v[2], k) : T(0);
+        in[3][k] = field_planes ? vec_get<T, RPT>(v[3], k) : T(0);
+        in[4][k] = vig_planes ? vec_get<T, RPT>(v[4], k) : a.vx0;
+        in[5][k] = vig_planes ? vec_get<T, RPT>(v[5], k) : a.vy0;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const bool ok = k < cnt;
+        in[0][k] = ok ? a.px[base + k] : T(0);
+        in[1][k] = ok ? a.py[base + k] : T(0);
+        in[2][k] = (ok && field_planes) ? a.hx[base + k] : T(0);
+        in[3][k] = (ok && field_planes) ? a.hy[base + k] : T(0);
+        in[4][k] = (ok && vig_planes) ? a.vx[base + k] : a.vx0;
+        in[5][k] = (ok && vig_planes) ? a.vy[base + k] : a.vy0;
+      }
+    }
+
+    Ray<T> r[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      T tx = tx0, ty = ty0, o[6];
+      if constexpr (FIELDP) raygen_field<T>(c, in[2][k], in[3][k], tx, ty);
+      raygen_one<T>(c, tx, ty, in[0][k], in[1][k], in[4][k], in[5][k], o);
+      r[k].x = o[0]; r[k].y = o[1]; r[k].z = o[2];
+      r[k].L = o[3]; r[k].M = o[4]; r[k].N = o[5];
+      r[k].i = T(1); r[k].opd = T(0);
+    }
+
+    bool is_global = true;
+    DevSurf<T> last_traced;
+    last_traced.cold = cold_tab;
+    Prt<T, 0> P[1];
+    DevSurfHot<T> cur = surf_tab[a.first];
+    for (int s = a.first; s <= a.last; ++s) {
+      DevSurf<T> S;
+      static_cast<DevSurfHot<T>&>(S) = cur;
+      S.cold = cold_tab + s;
+      if (s < a.last) cur = surf_tab[s + 1];
+      if (S.interaction != kRecordOnly) {
+        const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
+        surface_step<T, RPT, 0, NR>(S, O, coeff_tab, is_global, r, P, status);
+        is_global = false;
+        last_traced = S;
+      }
+    }
+
+    T hx_[RPT], hy_[RPT], hi_[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const Ray<T> g = is_global ? r[k] : to_global(last_traced, r[k]);
+      hx_[k] = g.x; hy_[k] = g.y; hi_[k] = g.i;
+      if (k < cnt && g.i > T(0)) {
+        const double dx = (double)g.x - a.cx, dy = (double)g.y - a.cy;
+        const double dx2 = dx * dx, dy2 = dy * dy;
+        acc[0] += 1.0;
+        acc[1] += dx;
+        acc[2] += dy;
+        acc[3] += dx2;
+        acc[4] += dy2;
+        acc[5] += (double)g.i;
+        const double r2 = dx2 + dy2;
+        rmax = r2 > rmax ? r2 : rmax;  // NaN hits compare false and are skipped
+      }
+    }
+    if (a.hits[0] != nullptr && cnt > 0) {
+      store_plane<T, RPT>(a.hits[0], base, cnt, hx_);
+      store_plane<T, RPT>(a.hits[1], base, cnt, hy_);
+      store_plane<T, RPT>(a.hits[2], base, cnt, hi_);
+    }
+  }
+
+  __shared__ double part[kTraceBlock / 64][7];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double v = spot_wave_sum(acc[k]);
+    if (lane == 0) part[wave][k] = v;
+  }
+  {
+    const double v = spot_wave_max(rmax);
+    if (lane == 0) part[wave][6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double v = 0;
+    for (int w = 0; w < kTraceBlock / 64; ++w) v += part[w][threadIdx.x];
+    // hardware fp64 atomic add (the output lives in ordinary coarse-grained HBM)
+    if (v != 0.0) unsafeAtomicAdd(&a.out[threadIdx.x], v);
+  } else if (threadIdx.x == 6) {
+    double v = part[0][6];
+    for (int w = 1; w < kTraceBlock / 64; ++w) v = part[w][6] > v ? part[w][6] : v;
+    // non-negative doubles order like their bit patterns
+    if (v > 0.0)
+      atomicMax(reinterpret_cast<unsigned long long*>(&a.out[6]),
+                (unsigned long long)__double_as_longlong(v));
+  }
+  if (status && a.status) atomicOr(a.status, status);
+}
+
+template <typename T, int RPT, int NR>
+static hipError_t launch_spot_nr(const SpotArgs<T>& a_in, hipStream_t stream) {
+  SpotArgs<T> a = a_in;
+  const int64_t tile_rays = (int64_t)kTraceBlock * RPT;
+  const int64_t ntiles = (a.n + tile_rays - 1) / tile_rays;
+  static const int forced = [] {
+    const char* e = getenv("OL_SPOT_TILES");
+    return e ? atoi(e) : 0;
+  }();
+  constexpr int64_t kTargetBlocks = 8192;  // ~8 rounds of 256 CUs x 4 resident workgroups
+  int64_t tpb = forced > 0 ? forced : (ntiles + kTargetBlocks - 1) / kTargetBlocks;
+  if (tpb < 1) tpb = 1;
+  if (tpb > 1024) tpb = 1024;
+  a.tiles_per_block = (int32_t)tpb;
+  if (a.hx == nullptr) {
+    // same expression as raygen_field / tan_deg: product in T, tangent in double
+    const T maxf = (T)a.rg.max_field;
+    a.tx0 = (T)tan((double)(maxf * a.hx0) * 0.017453292519943295);
+    a.ty0 = (T)tan((double)(maxf * a.hy0) * 0.017453292519943295);
+  }
+  const int64_t blocks = (ntiles + tpb - 1) / tpb;
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (a.hx != nullptr)
+    hipLaunchKernelGGL((spot_trace_kernel<T, RPT, NR, true>), dim3((unsigned)blocks),
+                       dim3(kTraceBlock), 0, stream, a.surf, a.cold, a.optics, a.coeffs, a);
+  else
+    hipLaunchKernelGGL((spot_trace_kernel<T, RPT, NR, false>), dim3((unsigned)blocks),
+                       dim3(kTraceBlock), 0, stream, a.surf, a.cold, a.optics, a.coeffs, a);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_spot_trace(const SpotArgs<T>& a, bool vector_ok, bool has_newton,
+                             hipStream_t stream) {
+  constexpr int kVec = 16 / sizeof(T);
+  // same defaults as record-last traces (launch_trace): conic-only ranges are ALU
+  // bound and want the 16-byte vector of rays per lane; Newton ranges one ray
+  const int want = tuning().rays_per_thread;
+  if (has_newton)
+    return (vector_ok && want == 2) ? launch_spot_nr<T, kVec, 1>(a, stream)
+                                    : launch_spot_nr<T, 1, 1>(a, stream);
+  if (!vector_ok || want == 1) return launch_spot_nr<T, 1, 0>(a, stream);
+  return launch_spot_nr<T, kVec, 0>(a, stream);
+}
+
+template hipError_t launch_spot_trace<float>(const SpotArgs<float>&, bool, bool, hipStream_t);
+template hipError_t launch_spot_trace<double>(const SpotArgs<double>&, bool, bool, hipStream_t);
 
 }  // namespace ol

@@ -56,6 +56,33 @@ hipError_t launch_raygen(const RaygenDev& p, int64_t n, const T* hx, const T* hy
                          const T* py, const T* vx, const T* vy, T* const out[7],
                          hipStream_t stream);
 
+// fused generate -> trace -> reduce spot kernel (trace_kernel.hip, SURVEY.md 8 f1+f2)
+template <typename T>
+struct SpotArgs {
+  const DevSurfHot<T>* surf;
+  const DevSurfCold<T>* cold;
+  const DevOptics<T>* optics;
+  const T* coeffs;
+  const T *hx, *hy;  // per-ray normalised field, or nullptr -> hx0, hy0
+  const T *px, *py;  // per-ray normalised pupil
+  const T *vx, *vy;  // per-ray (1 - vignetting), or nullptr -> vx0, vy0
+  T hx0, hy0, vx0, vy0;
+  T tx0, ty0;        // tan(field angle) for the launch-uniform field (set by the launcher)
+  RaygenDev rg;
+  double cx, cy;     // centre the moments are taken about (global image coordinates)
+  T* hits[3];        // optional image-plane x, y, intensity planes (all or none)
+  double* out;       // 7 doubles, accumulated
+  uint32_t* status;
+  int64_t n;
+  int32_t first, last;
+  int32_t n_wl, wl;
+  int32_t tiles_per_block;  // set by the launcher
+};
+
+template <typename T>
+hipError_t launch_spot_trace(const SpotArgs<T>& a, bool vector_ok, bool has_newton,
+                             hipStream_t stream);
+
 struct PolStateDev {
   int32_t is_polarized;
   double Ex, Ey, phase_x, phase_y;

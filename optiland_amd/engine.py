@@ -279,9 +279,59 @@ class HipSystem:
         _capi.check(rc, "ol_wavefront_opd")
         return opd, pupil
 
-    def spot_moments(self, x, y, intensity):
-        """Device reduction: returns float64 tensor [count, sx, sy, sxx, syy, count]."""
-        out = torch.zeros(6, dtype=torch.float64, device=self.device)
+    def trace_spot(self, px, py, wl_index: int, *, field=None, hx=None, hy=None, vig=(1.0, 1.0),
+                   vx=None, vy=None, center=(0.0, 0.0), hits=None, out=None,
+                   check_status: bool = True):
+        """Fused generate -> trace -> reduce (`ol_trace_spot`): one kernel, no ray planes.
+
+        `field` = (Hx, Hy) launch-uniform, or per-ray `hx`, `hy` tensors; `vig` =
+        launch-uniform (1 - vx, 1 - vy) or per-ray `vx`, `vy`; `center` = (cx, cy) the
+        moments are taken about (global image coordinates); `hits` = optional list of 3
+        preallocated planes for the image-plane x, y, intensity.  Returns a float64
+        tensor {count, sum dx, sum dy, sum dx^2, sum dy^2, sum i, max r^2} (`out`, if
+        given, is ACCUMULATED into -- zero it to start a new spot)."""
+        rg = self.table.raygen
+        if not rg:
+            raise ValueError("this SystemTable carries no ray-generation scalars")
+        if (field is None) == (hx is None):
+            raise ValueError("give either field=(Hx, Hy) or per-ray hx, hy")
+        n = int(px.numel())
+        dtype = px.dtype
+        f = (0.0, 0.0) if field is None else (float(field[0]), float(field[1]))
+        p = _capi.SpotParams(
+            _capi.RaygenParams(int(rg["object_infinite"]), 0, rg["EPL"], rg["EPD"],
+                               rg["max_field"], rg["offset"], rg["z_first"]),
+            f[0], f[1], float(vig[0]), float(vig[1]), float(center[0]), float(center[1]))
+        if out is None:
+            out = torch.zeros(7, dtype=torch.float64, device=self.device)
+        if n == 0:  # nothing to add (an empty tensor has no device pointer to hand over)
+            return out
+        keep = [t.contiguous() if t is not None else None for t in (hx, hy, px, py, vx, vy)]
+        for t in keep:
+            if t is not None and (t.dtype != dtype or t.numel() != n):
+                raise ValueError("trace_spot: coordinate planes must share dtype and length")
+        ptr = [t.data_ptr() if t is not None else None for t in keep]
+        hp = None
+        if hits is not None:
+            hp = (C.c_void_p * 3)(*[h.data_ptr() for h in hits])
+        if check_status:
+            self._status.zero_()
+        with torch.cuda.device(self.device):
+            rc = self.lib.ol_trace_spot(self._handle, _DT[dtype], n, C.byref(p), *ptr,
+                                        int(wl_index), hp, out.data_ptr(),
+                                        self._status.data_ptr(), _stream_ptr(self.device))
+        _capi.check(rc, "ol_trace_spot")
+        if check_status:
+            self.raise_for_status(int(self._status.item()))
+        return out
+
+    def spot_moments(self, x, y, intensity, out=None):
+        """Device reduction: returns float64 tensor [count, sx, sy, sxx, syy, count]
+        (`out`: optional preallocated 6-element float64 tensor, zeroed here)."""
+        if out is None:
+            out = torch.zeros(6, dtype=torch.float64, device=self.device)
+        else:
+            out.zero_()
         with torch.cuda.device(self.device):
             rc = self.lib.ol_spot_moments(_DT[x.dtype], int(x.numel()), x.data_ptr(),
                                           y.data_ptr(), intensity.data_ptr(), out.data_ptr(),

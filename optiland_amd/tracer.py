@@ -136,6 +136,16 @@ class HipRayTracer:
         V = torch.as_tensor(f[:, 2:], dtype=self.dtype, device=self.device)
         return V[idx, 0], V[idx, 1]
 
+    def _vig_scalar(self, hx: float, hy: float):
+        """`_vig_factor` for one field point, on the host: (1 - vx, 1 - vy)."""
+        f = self._fields
+        if f.shape[0] == 0 or not np.any(f[:, 2:]):
+            return 1.0, 1.0
+        max_field = self.table.raygen.get("max_field", 0.0)
+        pts = f[:, :2] / max_field if max_field != 0 else f[:, :2]
+        idx = int(np.argmin((hx - pts[:, 0]) ** 2 + (hy - pts[:, 1]) ** 2))
+        return 1.0 - float(f[idx, 2]), 1.0 - float(f[idx, 3])
+
     def _wavelength_index(self, wavelength):
         w = float(wavelength.item()) if hasattr(wavelength, "item") else float(wavelength)
         return self.table.wavelength_index(w), w
@@ -213,6 +223,34 @@ class HipRayTracer:
         vxf, vyf = self._vig_factor(hx, hy)
         omv = (None, None) if vxf is None else (1 - vxf, 1 - vyf)
         return self._run(hx, hy, px, py, omv, wavelength, update_intensity=True)
+
+    def trace_spot(self, Hx: float, Hy: float, wavelength, num_rays=100,
+                   distribution="hexapolar", center=(0.0, 0.0), hits: bool = False):
+        """`trace(Hx, Hy, ...)` for ONE field point fused with the image-plane
+        reduction (`ol_trace_spot`): rays are generated, traced and folded into masked
+        moments about `center` in one kernel and never exist in HBM.  Returns
+        (moments7, hits) with moments7 = {count, sum dx, sum dy, sum dx^2, sum dy^2,
+        sum i, max r^2} (float64 device tensor) and hits = (x, y, intensity) at the last
+        surface or None.  Unpolarised systems only (the polarised `update_intensity`
+        epilogue needs the PRT planes); the masks are those of
+        analysis/spot_diagram/core.py:470-476."""
+        Hx, Hy = float(Hx), float(Hy)
+        self._validate_normalized_coordinates(Hx, Hy, "field")
+        if self.table.polarization is not None or self.table.uses_polarization:
+            raise ValueError("trace_spot: fused spot reduction needs an unpolarised system")
+        if isinstance(distribution, str):
+            distribution = create_distribution(distribution)
+            distribution.generate_points(num_rays)
+        px, py = self._dev(distribution.x), self._dev(distribution.y)
+        wl, _ = self._wavelength_index(wavelength)
+        out3 = None
+        if hits:
+            n = int(px.numel())
+            buf = torch.empty((3, max(n, 1)), dtype=self.dtype, device=self.device)
+            out3 = [buf[k, :n] for k in range(3)]
+        mom = self.engine.trace_spot(px, py, wl, field=(Hx, Hy), vig=self._vig_scalar(Hx, Hy),
+                                     center=center, hits=out3)
+        return mom, out3
 
     def trace_generic(self, Hx, Hy, Px, Py, wavelength):
         """real_ray_tracer.py:120-154: caller-supplied per-ray coordinates; the

@@ -112,6 +112,33 @@ class OracleEngine:
         return (torch.as_tensor(out, dtype=px.dtype),
                 torch.as_tensor(pupil, dtype=px.dtype) if want_pupil else None)
 
+    def trace_spot(self, px, py, wl_index, *, field=None, hx=None, hy=None, vig=(1.0, 1.0),
+                   vx=None, vy=None, center=(0.0, 0.0), hits=None, out=None, check_status=True):
+        n = int(px.numel())
+        dtype = px.dtype
+        full = lambda v: torch.full((n,), float(v), dtype=dtype)  # noqa: E731
+        if field is not None:
+            hx, hy = full(field[0]), full(field[1])
+        if vx is None:
+            vx, vy = full(vig[0]), full(vig[1])
+        rays = self.generate_rays(hx, hy, px, py, vx, vy) + [torch.zeros(n, dtype=dtype)]
+        self.trace(rays, wl_index, record=False)
+        x, y, i = rays[0].double(), rays[1].double(), rays[6].double()
+        if hits is not None:
+            for dst, src in zip(hits, (rays[0], rays[1], rays[6])):
+                dst.copy_(src)
+        m = i > 0
+        dx, dy = x[m] - center[0], y[m] - center[1]
+        r2 = dx * dx + dy * dy
+        r2 = r2[~torch.isnan(r2)]
+        got = torch.tensor([float(m.sum()), dx.sum(), dy.sum(), (dx * dx).sum(), (dy * dy).sum(),
+                            i[m].sum(), r2.max() if r2.numel() else 0.0], dtype=torch.float64)
+        if out is None:
+            return got
+        out[:6] += got[:6]
+        out[6] = torch.maximum(out[6], got[6])
+        return out
+
     def spot_moments(self, x, y, intensity):
         m = intensity > 0
         xd, yd = x[m].double(), y[m].double()

@@ -26,6 +26,8 @@ TAGS = {  # tag -> traffic key
     "zf_f32": "zernike_fresnel:f32:record:alias",
     "dg_f32_last": "double_gauss:f32:last",
     "dg_f32_copy": "double_gauss:f32:record",
+    "dg_f32_spot": "double_gauss:f32:spot",
+    "dg_f64_spot": "double_gauss:f64:spot",
 }
 
 

@@ -11,4 +11,6 @@ bash tools/gpu_prof.sh rc_f32 --workload rc_asphere > /dev/null 2>&1
 bash tools/gpu_prof.sh zf_f32 --workload zernike_fresnel > /dev/null 2>&1
 bash tools/gpu_prof.sh dg_f32_last --mode last > /dev/null 2>&1
 bash tools/gpu_prof.sh dg_f32_copy --object-row copy > /dev/null 2>&1
-for t in dg_f32 dg_f64 rc_f32 zf_f32 dg_f32_last dg_f32_copy; do echo "=== $t"; grep '^{' gpurun_out/prof_$t/stats.log | tail -1 | cut -c1-400; grep -E "trace_kernel" gpurun_out/prof_$t/summary.txt | cut -c1-260; done
+bash tools/gpu_prof.sh dg_f32_spot --mode spot > /dev/null 2>&1
+bash tools/gpu_prof.sh dg_f64_spot --mode spot --dtype f64 > /dev/null 2>&1
+for t in dg_f32 dg_f64 rc_f32 zf_f32 dg_f32_last dg_f32_copy dg_f32_spot dg_f64_spot; do echo "=== $t"; grep '^{' gpurun_out/prof_$t/stats.log | tail -1 | cut -c1-400; grep -E "trace_kernel|spot" gpurun_out/prof_$t/summary.txt | cut -c1-260; done
