@@ -96,6 +96,28 @@ def spot_statistics(engine, x, y, intensity, group=None) -> dict:
             "geometric_radius": float(mx[0]) ** 0.5}
 
 
+def allreduce_spot7(mom7: torch.Tensor, group=None) -> torch.Tensor:
+    """Combine the seven doubles of `ol_trace_spot` across ranks (in place): the six
+    sums with one SUM all-reduce, the max r^2 with one MAX all-reduce."""
+    world, _ = _world(group)
+    if world > 1:
+        dist.all_reduce(mom7[:6], op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(mom7[6:], op=dist.ReduceOp.MAX, group=group)
+    return mom7
+
+
+def spot7_statistics(mom7, center) -> dict:
+    """Centroid / RMS / geometric radius from moments taken about `center`."""
+    m = [float(v) for v in mom7]
+    cnt = m[0]
+    if cnt == 0:
+        return {"count": 0.0, "centroid": (float("nan"),) * 2, "rms_radius": float("nan"),
+                "geometric_radius": float("nan"), "center": tuple(center)}
+    return {"count": cnt, "centroid": (center[0] + m[1] / cnt, center[1] + m[2] / cnt),
+            "rms_radius": max((m[3] + m[4]) / cnt, 0.0) ** 0.5,
+            "geometric_radius": m[6] ** 0.5, "center": tuple(center)}
+
+
 class ShardedTracer:
     """Trace this rank's shard of a global ray list and exchange image-plane hits."""
 
@@ -103,6 +125,22 @@ class ShardedTracer:
         self.tracer = tracer
         self.group = group
         self.world, self.rank = _world(group)
+
+    def trace_spot(self, Hx: float, Hy: float, Px, Py, wavelength, center=(0.0, 0.0)):
+        """Fused spot of ONE field point over a GLOBAL pupil list: this rank runs
+        `ol_trace_spot` on its shard of (Px, Py); the seven doubles are all-reduced.
+        No ray plane is written and 56 bytes cross the wire.  RMS / geometric radius
+        are about `center` (e.g. the chief-ray hit); the centroid is absolute."""
+        t = self.tracer
+        if t.table.polarization is not None or t.table.uses_polarization:
+            raise ValueError("trace_spot: fused spot reduction needs an unpolarised system")
+        px, py = t._dev(Px), t._dev(Py)
+        lo, hi = shard_bounds(px.numel(), self.world, self.rank)
+        wl, _ = t._wavelength_index(wavelength)
+        hx, hy = float(Hx), float(Hy)
+        mom = t.engine.trace_spot(px[lo:hi].contiguous(), py[lo:hi].contiguous(), wl,
+                                  field=(hx, hy), vig=t._vig_scalar(hx, hy), center=center)
+        return spot7_statistics(allreduce_spot7(mom, self.group).cpu(), center)
 
     def trace_generic(self, Hx, Hy, Px, Py, wavelength, exchange: str = "reduce"):
         """Global per-ray arrays in; local rays + exchanged image-plane data out."""

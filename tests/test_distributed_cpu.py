@@ -47,8 +47,10 @@ def _worker(rank, world, port, q):
         st = ShardedTracer(t)
         g = st.trace_generic(*args, 0.4861, exchange="gather")
         r = st.trace_generic(*args, 0.4861, exchange="reduce")
+        # fused spot of one field over the global pupil list (7 doubles all-reduced)
+        fs = st.trace_spot(0.0, 0.7, data["Px"][:n], data["Py"][:n], 0.4861, center=(0.0, 17.0))
         q.put((rank, g["lo"], g["hi"], g["rays"].x.numpy(), [h.numpy() for h in g["hits"]],
-               r["spot"]))
+               r["spot"], fs))
     finally:
         dist.destroy_process_group()
 
@@ -83,7 +85,7 @@ def test_two_rank_shards_equal_single_process():
     cat = np.concatenate([results[0][3], results[1][3]])
     assert np.array_equal(cat, fx)
     # every rank's all-gather output equals the single-device image-plane arrays
-    for _, _, _, _, hits, _ in results:
+    for _, _, _, _, hits, _, _ in results:
         assert np.array_equal(hits[0], fx) and np.array_equal(hits[1], fy)
         assert np.array_equal(hits[2], fi)
     # reduced spot statistics agree with the definition on the full set
@@ -91,7 +93,21 @@ def test_two_rank_shards_equal_single_process():
     cx, cy = fx[m].mean(), fy[m].mean()
     rms = np.sqrt(np.mean((fx[m] - cx) ** 2 + (fy[m] - cy) ** 2))
     geo = np.sqrt(np.max((fx[m] - cx) ** 2 + (fy[m] - cy) ** 2))
-    for _, _, _, _, _, spot in results:
+    # sharded fused spot == single-process definition about the same centre
+    one = t.trace_generic(0.0, 0.7, data["Px"][:n], data["Py"][:n], 0.4861)
+    ox, oy, oi = one.x.numpy(), one.y.numpy(), one.i.numpy()
+    om = oi > 0
+    for res in results:
+        fs = res[6]
+        assert fs["count"] == om.sum()
+        np.testing.assert_allclose(fs["centroid"], (ox[om].mean(), oy[om].mean()), rtol=1e-12,
+                                   atol=1e-13)
+        np.testing.assert_allclose(
+            fs["rms_radius"], np.sqrt(np.mean(ox[om] ** 2 + (oy[om] - 17.0) ** 2)), rtol=1e-12)
+        np.testing.assert_allclose(
+            fs["geometric_radius"], np.sqrt(np.max(ox[om] ** 2 + (oy[om] - 17.0) ** 2)),
+            rtol=1e-12)
+    for _, _, _, _, _, spot, _ in results:
         assert spot["count"] == m.sum()
         np.testing.assert_allclose(spot["centroid"], (cx, cy), rtol=1e-12, atol=1e-13)
         np.testing.assert_allclose(spot["rms_radius"], rms, rtol=1e-6)
