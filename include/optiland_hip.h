@@ -178,6 +178,9 @@ typedef struct ol_system ol_system; /* opaque */
                                         (geometries/zernike.py:254-266)       */
 #define OL_STATUS_K_PARALLEL_X 0x2u  /* initial k parallel to x-hat
                                         (rays/polarized_rays.py:221-222)      */
+#define OL_STATUS_FIELD_RANGE 0x8u   /* a normalised field coordinate outside [-1, 1]
+                                        (real_ray_tracer.py:156-173)             */
+#define OL_STATUS_PUPIL_RANGE 0x10u  /* a normalised pupil coordinate outside [-1, 1] */
 #define OL_STATUS_CHEBYSHEV_RANGE 0x4u /* |x/norm_x|>1 or |y/norm_y|>1
                                         (geometries/chebyshev.py:227-240)     */
 
@@ -249,12 +252,38 @@ typedef struct ol_raygen_params {
   double z_first;          /* surfaces.positions[1] (infinite) or [0] (finite)*/
 } ol_raygen_params;
 
-/* hx,hy,px,py: device arrays of n elements (dt); vx,vy: 1 - vignetting factor,
- * device arrays of n elements or NULL (=> 1).  out[7]: x,y,z,L,M,N,i (i = 1). */
+/* Normalised coordinates of one ray block.  Each of the pairs (hx,hy) and (vx,vy)
+ * is either two device planes of n elements or both NULL, in which case the
+ * launch-uniform scalars are used (one field point per launch is the common case:
+ * Optic.trace(Hx, Hy, ...) with scalar Hx, Hy).                                  */
+typedef struct ol_raygen_inputs {
+  const void *hx, *hy;  /* normalised field, per ray, or NULL -> hx0, hy0          */
+  const void *px, *py;  /* normalised pupil, per ray (required)                    */
+  const void *vx, *vy;  /* 1 - vignetting factor, per ray, or NULL -> vx0, vy0     */
+  double hx0, hy0;
+  double vx0, vy0;      /* 1 when unvignetted                                       */
+  uint32_t flags;       /* OL_RAYGEN_*                                              */
+  uint32_t reserved_;
+} ol_raygen_inputs;
+
+#define OL_RAYGEN_CHECK_FIELD 0x1u /* OR OL_STATUS_FIELD_RANGE into *status when a field
+                                      coordinate lies outside [-1, 1]
+                                      (RealRayTracer._validate_normalized_coordinates,
+                                      real_ray_tracer.py:156-173) -- checked where the
+                                      kernel reads the value anyway                 */
+#define OL_RAYGEN_CHECK_PUPIL 0x2u /* same for the pupil coordinates
+                                      (OL_STATUS_PUPIL_RANGE); trace_generic only   */
+#define OL_RAYGEN_PRESCALE_PUPIL 0x4u /* trace_generic semantics: the pupil is scaled
+                                      by (1 - v) BEFORE ray generation
+                                      (real_ray_tracer.py:134-137) and the aimer
+                                      scales it again (ray_aiming/paraxial.py:60-62,
+                                      90-91) -- SURVEY.md Appendix D                */
+
+/* out[0..6]: x,y,z,L,M,N,i planes (i = 1); out[7]: optional opd plane, zero-filled
+ * (NULL to skip).  status: nullable unless a CHECK flag is set.                 */
 int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n,
-                     const void* hx, const void* hy, const void* px,
-                     const void* py, const void* vx, const void* vy,
-                     void* const out[7], void* stream);
+                     const ol_raygen_inputs* in, void* const out[8],
+                     uint32_t* status, void* stream);
 
 /* update_intensity epilogue for polarised traces (trace() only):
  * i = sum_fields |P E0|^2 * i0 / n_fields.  k0[3]: initial direction planes.  */
@@ -283,29 +312,20 @@ int ol_spot_max_r2(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
  * SpotDiagram.centroid / rms_spot_radius / geometric_spot_radius
  * (raytrace/real_ray_tracer.py:58-118, analysis/spot_diagram/core.py:329-372,
  * 440-481).
- *   hx,hy    per-ray normalised field planes, or both NULL -> p->hx, p->hy
- *   px,py    per-ray normalised pupil planes (required)
- *   vx,vy    per-ray (1 - vignetting factor) planes, or both NULL -> p->vx, p->vy
+ *   in       normalised coordinates as for ol_generate_rays (flags honoured)
  *   hits     NULL, or 3 planes receiving the global x, y and intensity at the last
  *            surface (what surface_group.x[-1], .y[-1], .intensity[-1] hold)
  *   out7     device doubles, ACCUMULATED (zero them first), rays with i > 0 only:
  *            {count, sum dx, sum dy, sum dx^2, sum dy^2, sum i, max(dx^2+dy^2)}
- *            with dx = x - p->cx, dy = y - p->cy
- *   status   as ol_trace.
+ *            with dx = x - cx, dy = y - cy; (cx, cy) = centre in global image-plane
+ *            coordinates (e.g. the chief-ray hit)
+ *   status   as ol_trace / ol_generate_rays.
  * Systems with polarization-dependent coatings are refused (OL_EINVAL) like
  * ol_trace without a prt.                                                       */
-typedef struct ol_spot_params {
-  ol_raygen_params raygen;
-  double hx, hy;  /* launch-uniform normalised field (used when hx == NULL)     */
-  double vx, vy;  /* launch-uniform 1 - vignetting factor (used when vx == NULL)*/
-  double cx, cy;  /* centre of the moments, global image-plane coordinates      */
-} ol_spot_params;
-
 int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays,
-                  const ol_spot_params* p, const void* hx, const void* hy,
-                  const void* px, const void* py, const void* vx, const void* vy,
-                  int32_t wavelength_index, void* const hits[3], double* out7,
-                  uint32_t* status, void* stream);
+                  const ol_raygen_params* p, const ol_raygen_inputs* in,
+                  double cx, double cy, int32_t wavelength_index,
+                  void* const hits[3], double* out7, uint32_t* status, void* stream);
 
 /* Wavefront OPD against a spherical reference centred on the chief-ray image point
  * (wavefront/strategy.py:163-215 ChiefRayStrategy.

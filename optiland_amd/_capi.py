@@ -57,9 +57,13 @@ class RaygenParams(C.Structure):
     ]
 
 
-class SpotParams(C.Structure):
-    _fields_ = [("raygen", RaygenParams)] + [(k, C.c_double) for k in
-                                             ("hx", "hy", "vx", "vy", "cx", "cy")]
+class RaygenInputs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("hx", "hy", "px", "py", "vx", "vy")] + \
+               [(k, C.c_double) for k in ("hx0", "hy0", "vx0", "vy0")] + \
+               [("flags", C.c_uint32), ("reserved_", C.c_uint32)]
+
+
+RAYGEN_CHECK_FIELD, RAYGEN_CHECK_PUPIL, RAYGEN_PRESCALE_PUPIL = 0x1, 0x2, 0x4
 
 
 class WavefrontParams(C.Structure):
@@ -134,7 +138,7 @@ def load():
     lib.ol_trace.argtypes = [vp, C.c_int, i64, C.POINTER(vp), i32, vp, i64, vp, i32, i32, u32,
                              vp, vp]
     lib.ol_generate_rays.restype = C.c_int
-    lib.ol_generate_rays.argtypes = [vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, C.POINTER(vp), vp]
+    lib.ol_generate_rays.argtypes = [vp, C.c_int, i64, vp, C.POINTER(vp), vp, vp]
     lib.ol_polarized_intensity.restype = C.c_int
     lib.ol_polarized_intensity.argtypes = [C.c_int, i64, vp, i32, C.POINTER(vp), vp, vp, vp, vp,
                                            vp]
@@ -145,7 +149,7 @@ def load():
     lib.ol_wavefront_opd.restype = C.c_int
     lib.ol_wavefront_opd.argtypes = [vp, C.c_int, i64, C.POINTER(vp), vp, vp, vp, vp, vp]
     lib.ol_trace_spot.restype = C.c_int
-    lib.ol_trace_spot.argtypes = [vp, C.c_int, i64, vp, vp, vp, vp, vp, vp, vp, i32,
+    lib.ol_trace_spot.argtypes = [vp, C.c_int, i64, vp, vp, C.c_double, C.c_double, i32,
                                   C.POINTER(vp), vp, vp, vp]
     lib.ol_set_tuning.restype = C.c_int
     lib.ol_set_tuning.argtypes = [i32, i32]
@@ -160,7 +164,8 @@ def load():
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().ol_last_error().decode("utf-8", "replace")
-        if "Polarization must be set" in msg:
-            # same exception type/text as rays/ray_generator.py:89-94
+        if "Polarization must be set" in msg or msg.startswith("Normalized "):
+            # same exception type/text as rays/ray_generator.py:89-94 and
+            # raytrace/real_ray_tracer.py:170-173
             raise ValueError(msg)
         raise HipExtensionError(f"{what} failed (code {rc}): {msg}")

@@ -22,22 +22,27 @@ inline unsigned grid_for(int64_t n) {
 }  // namespace
 
 // rays/ray_generator.py:47-99, rays/ray_aiming/paraxial.py:33-106,
-// fields/field_types/angle.py:17-58
+// fields/field_types/angle.py:17-58; range validation real_ray_tracer.py:156-173
 template <typename T>
-__global__ __launch_bounds__(kBlock) void raygen_kernel(RaygenDev p, int64_t n,
-                                                        const T* __restrict__ hx,
-                                                        const T* __restrict__ hy,
-                                                        const T* __restrict__ px,
-                                                        const T* __restrict__ py,
-                                                        const T* __restrict__ vx,
-                                                        const T* __restrict__ vy, T* ox, T* oy,
-                                                        T* oz, T* oL, T* oM, T* oN, T* oi) {
+__global__ __launch_bounds__(kBlock) void raygen_kernel(RaygenDev p, RaygenIn<T> in, int64_t n,
+                                                        T* ox, T* oy, T* oz, T* oL, T* oM, T* oN,
+                                                        T* oi, T* oopd, uint32_t* status) {
   const RaygenConsts<T> c(p);
+  const bool field_planes = in.hx != nullptr, vig_planes = in.vx != nullptr;
+  uint32_t st = 0;
   for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
        j += (int64_t)gridDim.x * kBlock) {
-    T tx, ty, o[6];
-    raygen_field<T>(c, hx[j], hy[j], tx, ty);
-    raygen_one<T>(c, tx, ty, px[j], py[j], vx ? vx[j] : T(1), vy ? vy[j] : T(1), o);
+    T tx = in.tx0, ty = in.ty0, o[6];
+    if (field_planes) {
+      const T hx = in.hx[j], hy = in.hy[j];
+      if ((in.flags & kRaygenCheckField) && (outside_unit(hx) || outside_unit(hy)))
+        st |= kStatusFieldRange;
+      raygen_field<T>(c, hx, hy, tx, ty);
+    }
+    T px = in.px[j], py = in.py[j];
+    const T vx = vig_planes ? in.vx[j] : in.vx0, vy = vig_planes ? in.vy[j] : in.vy0;
+    raygen_pupil<T>(in.flags, vx, vy, px, py, st);
+    raygen_one<T>(c, tx, ty, px, py, vx, vy, o);
     ox[j] = o[0];
     oy[j] = o[1];
     oz[j] = o[2];
@@ -45,15 +50,18 @@ __global__ __launch_bounds__(kBlock) void raygen_kernel(RaygenDev p, int64_t n,
     oM[j] = o[4];
     oN[j] = o[5];
     oi[j] = T(1);
+    if (oopd) oopd[j] = T(0);
   }
+  if (st && status) atomicOr(status, st);
 }
 
 template <typename T>
-hipError_t launch_raygen(const RaygenDev& p, int64_t n, const T* hx, const T* hy, const T* px,
-                         const T* py, const T* vx, const T* vy, T* const out[7],
-                         hipStream_t stream) {
-  hipLaunchKernelGGL((raygen_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, stream, p, n, hx, hy,
-                     px, py, vx, vy, out[0], out[1], out[2], out[3], out[4], out[5], out[6]);
+hipError_t launch_raygen(const RaygenDev& p, const RaygenIn<T>& in_, int64_t n, T* const out[8],
+                         uint32_t* status, hipStream_t stream) {
+  RaygenIn<T> in = in_;
+  if (in.hx == nullptr) uniform_field_tangents<T>(p, in);
+  hipLaunchKernelGGL((raygen_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, stream, p, in, n,
+                     out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], status);
   return hipGetLastError();
 }
 
@@ -270,8 +278,8 @@ hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten,
 }
 
 #define OL_INST(T)                                                                             \
-  template hipError_t launch_raygen<T>(const RaygenDev&, int64_t, const T*, const T*, const T*, \
-                                       const T*, const T*, const T*, T* const[7], hipStream_t); \
+  template hipError_t launch_raygen<T>(const RaygenDev&, const RaygenIn<T>&, int64_t,            \
+                                       T* const[8], uint32_t*, hipStream_t);                    \
   template hipError_t launch_pol_intensity<T>(int64_t, const T*, bool, const T* const[3],      \
                                               const T*, const PolStateDev&, T*, uint32_t*,     \
                                               hipStream_t);                                    \

@@ -264,32 +264,72 @@ int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* c
   return OL_OK;
 }
 
+// ol_raygen_inputs -> working precision; host-side part of the range validation
+// (launch-uniform scalars are checked here, planes in the kernel)
+template <typename T>
+int convert_inputs(const char* who, const ol_raygen_inputs* in, uint32_t* status,
+                   ol::RaygenIn<T>& o, bool& aligned) {
+  if (!in || !in->px || !in->py) return fail(OL_EINVAL, "%s: NULL argument", who);
+  if ((in->hx == nullptr) != (in->hy == nullptr) || (in->vx == nullptr) != (in->vy == nullptr))
+    return fail(OL_EINVAL, "%s: hx/hy (and vx/vy) must be given together", who);
+  if ((in->flags & (OL_RAYGEN_CHECK_FIELD | OL_RAYGEN_CHECK_PUPIL)) && !status)
+    return fail(OL_EINVAL, "%s: a CHECK flag needs a status word", who);
+  if ((in->flags & OL_RAYGEN_CHECK_FIELD) && !in->hx) {
+    auto bad = [](double v) { return !(v >= -1.0 && v <= 1.0); };
+    if (bad(in->hx0) || bad(in->hy0))  // real_ray_tracer.py:156-173, same text
+      return fail(OL_EINVAL, "Normalized field coordinates must be within (-1, 1)");
+  }
+  o.hx = static_cast<const T*>(in->hx);
+  o.hy = static_cast<const T*>(in->hy);
+  o.px = static_cast<const T*>(in->px);
+  o.py = static_cast<const T*>(in->py);
+  o.vx = static_cast<const T*>(in->vx);
+  o.vy = static_cast<const T*>(in->vy);
+  o.hx0 = (T)in->hx0;
+  o.hy0 = (T)in->hy0;
+  o.vx0 = (T)in->vx0;
+  o.vy0 = (T)in->vy0;
+  o.tx0 = o.ty0 = T(0);
+  o.flags = in->flags;
+  aligned = aligned16(in->px) && aligned16(in->py) && aligned16(in->hx) && aligned16(in->hy) &&
+            aligned16(in->vx) && aligned16(in->vy);  // NULL counts as aligned
+  return OL_OK;
+}
+
+ol::RaygenDev raygen_dev(const ol_raygen_params* g) {
+  return ol::RaygenDev{g->object_infinite, g->EPL, g->EPD, g->max_field, g->offset, g->z_first};
+}
+
+template <typename T>
+int do_generate_rays(const ol_raygen_params* p, int64_t n, const ol_raygen_inputs* in,
+                     void* const out[8], uint32_t* status, hipStream_t stream) {
+  ol::RaygenIn<T> ri;
+  bool al = true;
+  if (int rc = convert_inputs<T>("ol_generate_rays", in, status, ri, al)) return rc;
+  if (n == 0) return OL_OK;
+  T* o[8];
+  for (int k = 0; k < 8; ++k) o[k] = static_cast<T*>(out[k]);
+  hipError_t e = ol::launch_raygen<T>(raygen_dev(p), ri, n, o, status, stream);
+  if (e != hipSuccess) return fail(OL_EHIP, "raygen launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
 template <typename T>
 int do_trace_spot(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
-                  const ol_spot_params* p, const void* hx, const void* hy, const void* px,
-                  const void* py, const void* vx, const void* vy, int32_t wl, void* const hits[3],
-                  double* out7, uint32_t* status, hipStream_t stream) {
+                  const ol_raygen_params* p, const ol_raygen_inputs* in, double cx, double cy,
+                  int32_t wl, void* const hits[3], double* out7, uint32_t* status,
+                  hipStream_t stream) {
   ol::SpotArgs<T> a;
+  bool vec = true;
+  if (int rc = convert_inputs<T>("ol_trace_spot", in, status, a.in, vec)) return rc;
+  if (n == 0) return OL_OK;
   a.surf = tab.surf;
   a.cold = tab.cold;
   a.optics = tab.optics;
   a.coeffs = tab.coeffs;
-  a.hx = static_cast<const T*>(hx);
-  a.hy = static_cast<const T*>(hy);
-  a.px = static_cast<const T*>(px);
-  a.py = static_cast<const T*>(py);
-  a.vx = static_cast<const T*>(vx);
-  a.vy = static_cast<const T*>(vy);
-  a.hx0 = (T)p->hx;
-  a.hy0 = (T)p->hy;
-  a.vx0 = (T)p->vx;
-  a.vy0 = (T)p->vy;
-  const ol_raygen_params& g = p->raygen;
-  a.rg = ol::RaygenDev{g.object_infinite, g.EPL, g.EPD, g.max_field, g.offset, g.z_first};
-  a.cx = p->cx;
-  a.cy = p->cy;
-  bool vec = aligned16(px) && aligned16(py) && aligned16(hx) && aligned16(hy) && aligned16(vx) &&
-             aligned16(vy);  // NULL counts as aligned
+  a.rg = raygen_dev(p);
+  a.cx = cx;
+  a.cy = cy;
   for (int k = 0; k < 3; ++k) {
     a.hits[k] = hits ? static_cast<T*>(hits[k]) : nullptr;
     vec = vec && aligned16(a.hits[k]);
@@ -301,6 +341,7 @@ int do_trace_spot(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
   a.last = sys->n_surf - 1;
   a.n_wl = sys->n_wl;
   a.wl = wl;
+  a.tiles_per_block = 1;
   bool has_newton = false;
   for (int32_t s = 0; s < sys->n_surf; ++s)
     has_newton = has_newton || (sys->geom[s] != OL_GEOM_PLANE && sys->geom[s] != OL_GEOM_STANDARD);
@@ -583,44 +624,25 @@ int ol_trace(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const rays
                           prt, first_surface, last_surface, flags, status, st);
 }
 
-int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n, const void* hx,
-                     const void* hy, const void* px, const void* py, const void* vx,
-                     const void* vy, void* const out[7], void* stream) {
-  if (!p || !hx || !hy || !px || !py || !out)
-    return fail(OL_EINVAL, "ol_generate_rays: NULL argument");
+int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n,
+                     const ol_raygen_inputs* in, void* const out[8], uint32_t* status,
+                     void* stream) {
+  if (!p || !in || !out) return fail(OL_EINVAL, "ol_generate_rays: NULL argument");
   if (n < 0) return fail(OL_EINVAL, "ol_generate_rays: negative count");
-  if (n == 0) return OL_OK;
   for (int k = 0; k < 7; ++k)
-    if (!out[k]) return fail(OL_EINVAL, "ol_generate_rays: out[%d] is NULL", k);
-  ol::RaygenDev d{p->object_infinite, p->EPL, p->EPD, p->max_field, p->offset, p->z_first};
+    if (!out[k] && n > 0) return fail(OL_EINVAL, "ol_generate_rays: out[%d] is NULL", k);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipError_t e;
-  if (dt == OL_F32) {
-    float* o[7];
-    for (int k = 0; k < 7; ++k) o[k] = static_cast<float*>(out[k]);
-    e = ol::launch_raygen<float>(d, n, (const float*)hx, (const float*)hy, (const float*)px,
-                                 (const float*)py, (const float*)vx, (const float*)vy, o, st);
-  } else if (dt == OL_F64) {
-    double* o[7];
-    for (int k = 0; k < 7; ++k) o[k] = static_cast<double*>(out[k]);
-    e = ol::launch_raygen<double>(d, n, (const double*)hx, (const double*)hy, (const double*)px,
-                                  (const double*)py, (const double*)vx, (const double*)vy, o, st);
-  } else {
-    return fail(OL_EINVAL, "ol_generate_rays: bad dtype %d", (int)dt);
-  }
-  if (e != hipSuccess) return fail(OL_EHIP, "raygen launch failed: %s", hipGetErrorString(e));
-  return OL_OK;
+  if (dt == OL_F32) return do_generate_rays<float>(p, n, in, out, status, st);
+  if (dt == OL_F64) return do_generate_rays<double>(p, n, in, out, status, st);
+  return fail(OL_EINVAL, "ol_generate_rays: bad dtype %d", (int)dt);
 }
 
-int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_spot_params* p,
-                  const void* hx, const void* hy, const void* px, const void* py, const void* vx,
-                  const void* vy, int32_t wavelength_index, void* const hits[3], double* out7,
-                  uint32_t* status, void* stream) {
+int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_raygen_params* p,
+                  const ol_raygen_inputs* in, double cx, double cy, int32_t wavelength_index,
+                  void* const hits[3], double* out7, uint32_t* status, void* stream) {
   if (!sys) return fail(OL_EINVAL, "ol_trace_spot: system is NULL");
   if (dt != OL_F32 && dt != OL_F64) return fail(OL_EINVAL, "ol_trace_spot: bad dtype %d", (int)dt);
-  if (!p || !px || !py || !out7) return fail(OL_EINVAL, "ol_trace_spot: NULL argument");
-  if ((hx == nullptr) != (hy == nullptr) || (vx == nullptr) != (vy == nullptr))
-    return fail(OL_EINVAL, "ol_trace_spot: hx/hy (and vx/vy) must be given together");
+  if (!p || !in || !out7) return fail(OL_EINVAL, "ol_trace_spot: NULL argument");
   if (hits && (!hits[0] || !hits[1] || !hits[2]))
     return fail(OL_EINVAL, "ol_trace_spot: hits needs three planes");
   if (n_rays < 0) return fail(OL_EINVAL, "ol_trace_spot: negative ray count");
@@ -632,8 +654,7 @@ int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_sp
       return fail(OL_EINVAL,
                   "Polarization must be set when surfaces have polarization-dependent "
                   "coatings.");
-  if (n_rays == 0) return OL_OK;
-  {
+  if (n_rays > 0) {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != sys->device)
       return fail(OL_EINVAL, "ol_trace_spot: current HIP device %d is not the system's device %d",
@@ -641,10 +662,10 @@ int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_sp
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dt == OL_F32)
-    return do_trace_spot<float>(sys, sys->f32, n_rays, p, hx, hy, px, py, vx, vy,
-                                wavelength_index, hits, out7, status, st);
-  return do_trace_spot<double>(sys, sys->f64, n_rays, p, hx, hy, px, py, vx, vy,
-                               wavelength_index, hits, out7, status, st);
+    return do_trace_spot<float>(sys, sys->f32, n_rays, p, in, cx, cy, wavelength_index, hits,
+                                out7, status, st);
+  return do_trace_spot<double>(sys, sys->f64, n_rays, p, in, cx, cy, wavelength_index, hits,
+                               out7, status, st);
 }
 
 int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt, int32_t prt_complex,

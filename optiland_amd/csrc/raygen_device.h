@@ -41,6 +41,22 @@ __device__ __forceinline__ void raygen_field(const RaygenConsts<T>& c, T hx, T h
   ty = tan_deg<T>(c.maxf * hy);
 }
 
+// range checks (real_ray_tracer.py:156-173: all((v >= -1) & (v <= 1)); NaN fails) and
+// the trace_generic pre-scaling of the pupil (real_ray_tracer.py:134-137)
+template <typename T>
+__device__ __forceinline__ bool outside_unit(T v) { return !(v >= T(-1) && v <= T(1)); }
+
+template <typename T>
+__device__ __forceinline__ void raygen_pupil(uint32_t flags, T vx, T vy, T& px, T& py,
+                                             uint32_t& status) {
+  if ((flags & kRaygenCheckPupil) && (outside_unit(px) || outside_unit(py)))
+    status |= kStatusPupilRange;
+  if (flags & kRaygenPrescalePupil) {
+    px *= vx;
+    py *= vy;
+  }
+}
+
 // o[0..5] = x, y, z, L, M, N  (intensity is 1, ray_generator.py:81-85)
 template <typename T>
 __device__ __forceinline__ void raygen_one(const RaygenConsts<T>& c, T tx, T ty, T px, T py, T vx,

@@ -1437,10 +1437,10 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
   // double-precision tangent (tan_deg) would otherwise set the register budget of
   // the common launch-uniform-field case as well.
   constexpr bool field_planes = FIELDP;
-  const bool vig_planes = a.vx != nullptr;
-  // launch-uniform field: the two tangents come from the host (launch_spot_nr) --
-  // evaluated per lane the double-precision tan() cost ~15 % of the whole kernel
-  const T tx0 = a.tx0, ty0 = a.ty0;
+  const RaygenIn<T>& in_ = a.in;
+  const bool vig_planes = in_.vx != nullptr;
+  // launch-uniform field: the two tangents come from the host (uniform_field_tangents)
+  const T tx0 = in_.tx0, ty0 = in_.ty0;
 
   double acc[6] = {0, 0, 0, 0, 0, 0};
   double rmax = 0.0;
@@ -1461,15 +1461,15 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
     if (RPT > 1 && cnt == RPT) {
       using V = typename VecOf<T, RPT>::type;
       V v[6];
-      v[0] = *reinterpret_cast<const V*>(a.px + base);
-      v[1] = *reinterpret_cast<const V*>(a.py + base);
+      v[0] = *reinterpret_cast<const V*>(in_.px + base);
+      v[1] = *reinterpret_cast<const V*>(in_.py + base);
       if constexpr (FIELDP) {
-        v[2] = *reinterpret_cast<const V*>(a.hx + base);
-        v[3] = *reinterpret_cast<const V*>(a.hy + base);
+        v[2] = *reinterpret_cast<const V*>(in_.hx + base);
+        v[3] = *reinterpret_cast<const V*>(in_.hy + base);
       }
       if (vig_planes) {
-        v[4] = *reinterpret_cast<const V*>(a.vx + base);
-        v[5] = *reinterpret_cast<const V*>(a.vy + base);
+        v[4] = *reinterpret_cast<const V*>(in_.vx + base);
+        v[5] = *reinterpret_cast<const V*>(in_.vy + base);
       }
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
@@ -1477,19 +1477,19 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
         in[1][k] = vec_get<T, RPT>(v[1], k);
         in[2][k] = field_planes ? vec_get<T, RPT>(v[2], k) : T(0);
         in[3][k] = field_planes ? vec_get<T, RPT>(v[3], k) : T(0);
-        in[4][k] = vig_planes ? vec_get<T, RPT>(v[4], k) : a.vx0;
-        in[5][k] = vig_planes ? vec_get<T, RPT>(v[5], k) : a.vy0;
+        in[4][k] = vig_planes ? vec_get<T, RPT>(v[4], k) : in_.vx0;
+        in[5][k] = vig_planes ? vec_get<T, RPT>(v[5], k) : in_.vy0;
       }
     } else {
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         const bool ok = k < cnt;
-        in[0][k] = ok ? a.px[base + k] : T(0);
-        in[1][k] = ok ? a.py[base + k] : T(0);
-        in[2][k] = (ok && field_planes) ? a.hx[base + k] : T(0);
-        in[3][k] = (ok && field_planes) ? a.hy[base + k] : T(0);
-        in[4][k] = (ok && vig_planes) ? a.vx[base + k] : a.vx0;
-        in[5][k] = (ok && vig_planes) ? a.vy[base + k] : a.vy0;
+        in[0][k] = ok ? in_.px[base + k] : T(0);
+        in[1][k] = ok ? in_.py[base + k] : T(0);
+        in[2][k] = (ok && field_planes) ? in_.hx[base + k] : T(0);
+        in[3][k] = (ok && field_planes) ? in_.hy[base + k] : T(0);
+        in[4][k] = (ok && vig_planes) ? in_.vx[base + k] : in_.vx0;
+        in[5][k] = (ok && vig_planes) ? in_.vy[base + k] : in_.vy0;
       }
     }
 
@@ -1497,7 +1497,12 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       T tx = tx0, ty = ty0, o[6];
-      if constexpr (FIELDP) raygen_field<T>(c, in[2][k], in[3][k], tx, ty);
+      if constexpr (FIELDP) {
+        if ((in_.flags & kRaygenCheckField) && (outside_unit(in[2][k]) || outside_unit(in[3][k])))
+          status |= kStatusFieldRange;
+        raygen_field<T>(c, in[2][k], in[3][k], tx, ty);
+      }
+      raygen_pupil<T>(in_.flags, in[4][k], in[5][k], in[0][k], in[1][k], status);
       raygen_one<T>(c, tx, ty, in[0][k], in[1][k], in[4][k], in[5][k], o);
       r[k].x = o[0]; r[k].y = o[1]; r[k].z = o[2];
       r[k].L = o[3]; r[k].M = o[4]; r[k].N = o[5];
@@ -1589,16 +1594,11 @@ static hipError_t launch_spot_nr(const SpotArgs<T>& a_in, hipStream_t stream) {
   if (tpb < 1) tpb = 1;
   if (tpb > 1024) tpb = 1024;
   a.tiles_per_block = (int32_t)tpb;
-  if (a.hx == nullptr) {
-    // same expression as raygen_field / tan_deg: product in T, tangent in double
-    const T maxf = (T)a.rg.max_field;
-    a.tx0 = (T)tan((double)(maxf * a.hx0) * 0.017453292519943295);
-    a.ty0 = (T)tan((double)(maxf * a.hy0) * 0.017453292519943295);
-  }
+  if (a.in.hx == nullptr) uniform_field_tangents<T>(a.rg, a.in);
   const int64_t blocks = (ntiles + tpb - 1) / tpb;
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  if (a.hx != nullptr)
+  if (a.in.hx != nullptr)
     hipLaunchKernelGGL((spot_trace_kernel<T, RPT, NR, true>), dim3((unsigned)blocks),
                        dim3(kTraceBlock), 0, stream, a.surf, a.cold, a.optics, a.coeffs, a);
   else

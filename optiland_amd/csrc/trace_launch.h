@@ -1,6 +1,7 @@
 // trace_launch.h -- kernel argument block shared by the kernels and the C ABI.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "device_table.h"
@@ -51,10 +52,36 @@ struct RaygenDev {
   double EPL, EPD, max_field, offset, z_first;
 };
 
+constexpr uint32_t kRaygenCheckField = 0x1u;    // OL_RAYGEN_CHECK_FIELD
+constexpr uint32_t kRaygenCheckPupil = 0x2u;    // OL_RAYGEN_CHECK_PUPIL
+constexpr uint32_t kRaygenPrescalePupil = 0x4u; // OL_RAYGEN_PRESCALE_PUPIL
+constexpr uint32_t kStatusFieldRange = 0x8u;    // OL_STATUS_FIELD_RANGE
+constexpr uint32_t kStatusPupilRange = 0x10u;   // OL_STATUS_PUPIL_RANGE
+
+// normalised coordinates of one ray block (ol_raygen_inputs in working precision)
 template <typename T>
-hipError_t launch_raygen(const RaygenDev& p, int64_t n, const T* hx, const T* hy, const T* px,
-                         const T* py, const T* vx, const T* vy, T* const out[7],
-                         hipStream_t stream);
+struct RaygenIn {
+  const T *hx, *hy;  // per-ray field or nullptr -> hx0, hy0 (tangents tx0, ty0)
+  const T *px, *py;  // per-ray pupil
+  const T *vx, *vy;  // per-ray 1 - vignetting or nullptr -> vx0, vy0
+  T hx0, hy0, vx0, vy0;
+  T tx0, ty0;        // tan(field angle) of the launch-uniform field, formed on the host
+  uint32_t flags;
+};
+
+// tangents of a launch-uniform field: same expression as raygen_field() / tan_deg()
+// on the device (product in T, tangent in double) -- evaluated per lane the
+// double-precision tan() cost ~15 % of the fused spot kernel.
+template <typename T>
+inline void uniform_field_tangents(const RaygenDev& rg, RaygenIn<T>& in) {
+  const T maxf = (T)rg.max_field;
+  in.tx0 = (T)tan((double)(maxf * in.hx0) * 0.017453292519943295);
+  in.ty0 = (T)tan((double)(maxf * in.hy0) * 0.017453292519943295);
+}
+
+template <typename T>
+hipError_t launch_raygen(const RaygenDev& p, const RaygenIn<T>& in, int64_t n, T* const out[8],
+                         uint32_t* status, hipStream_t stream);
 
 // fused generate -> trace -> reduce spot kernel (trace_kernel.hip, SURVEY.md 8 f1+f2)
 template <typename T>
@@ -63,11 +90,7 @@ struct SpotArgs {
   const DevSurfCold<T>* cold;
   const DevOptics<T>* optics;
   const T* coeffs;
-  const T *hx, *hy;  // per-ray normalised field, or nullptr -> hx0, hy0
-  const T *px, *py;  // per-ray normalised pupil
-  const T *vx, *vy;  // per-ray (1 - vignetting), or nullptr -> vx0, vy0
-  T hx0, hy0, vx0, vy0;
-  T tx0, ty0;        // tan(field angle) for the launch-uniform field (set by the launcher)
+  RaygenIn<T> in;
   RaygenDev rg;
   double cx, cy;     // centre the moments are taken about (global image coordinates)
   T* hits[3];        // optional image-plane x, y, intensity planes (all or none)

@@ -126,7 +126,7 @@ class HipSystem:
     def trace(self, rays, wavelength_index: int = 0, record=True, prt: torch.Tensor | None = None,
               first: int = 0, last: int | None = None, write_rays: bool | None = None,
               check_status: bool = True, prt_identity: bool = False,
-              defer_status: bool = False) -> TraceResult:
+              defer_status: bool = False, zero_status: bool = True) -> TraceResult:
         """Launch the fused trace.
 
         rays: sequence of 8 contiguous 1-D device tensors (x,y,z,L,M,N,i,opd) of one
@@ -171,7 +171,7 @@ class HipSystem:
             if prt_identity:  # write-only PRT: starts from I inside the kernel
                 flags |= S.TRACE_PRT_IDENTITY
         ptrs = (C.c_void_p * 8)(*[t.data_ptr() for t in rays])
-        if check_status:
+        if check_status and zero_status:  # zero_status=False: keep bits set by ray generation
             self._status.zero_()
         with torch.cuda.device(self.device):
             rc = self.lib.ol_trace(
@@ -196,6 +196,11 @@ class HipSystem:
     @staticmethod
     def raise_for_status(status: int) -> None:
         """Device status bits -> the reference's exceptions (same texts)."""
+        # raytrace/real_ray_tracer.py:156-173 (field is validated before the pupil)
+        if status & S.STATUS_FIELD_RANGE:
+            raise ValueError("Normalized field coordinates must be within (-1, 1)")
+        if status & S.STATUS_PUPIL_RANGE:
+            raise ValueError("Normalized pupil coordinates must be within (-1, 1)")
         if status & S.STATUS_ZERNIKE_RANGE:
             # optiland/geometries/zernike.py:262-266
             raise ValueError(
@@ -212,33 +217,65 @@ class HipSystem:
             )
 
     # ------------------------------------------------------------- ray source
-    def generate_rays(self, hx, hy, px, py, vx=None, vy=None, out=None):
-        """On-device ray generation (paraxial aiming, angle fields).  Returns 7 planes.
-        `out`: optional list of >= 7 preallocated planes to generate into (e.g. row 0 of
-        a record block, so that the trace need not copy the object-surface row)."""
+    def _raygen_params(self):
         rg = self.table.raygen
         if not rg:
             raise ValueError("this SystemTable carries no ray-generation scalars")
+        return _capi.RaygenParams(int(rg["object_infinite"]), 0, rg["EPL"], rg["EPD"],
+                                  rg["max_field"], rg["offset"], rg["z_first"])
+
+    @staticmethod
+    def _raygen_inputs(hx, hy, px, py, vx, vy, flags):
+        """`ol_raygen_inputs` from tensors (per-ray planes) or floats (launch-uniform).
+        Returns (struct, keep-alive list)."""
+        n, dtype = int(px.numel()), px.dtype
+        keep, ptr, scal = [], {}, {"hx": 0.0, "hy": 0.0, "vx": 1.0, "vy": 1.0}
+        for name, v in (("hx", hx), ("hy", hy), ("px", px), ("py", py), ("vx", vx), ("vy", vy)):
+            if isinstance(v, torch.Tensor):
+                if v.dtype != dtype or v.numel() != n:
+                    raise ValueError("ray generation: coordinate planes must share dtype and "
+                                     "length")
+                v = v.contiguous()
+                keep.append(v)
+                ptr[name] = v.data_ptr()
+            else:
+                ptr[name] = None
+                if v is not None:
+                    scal[name] = float(v)
+        for a, b in (("hx", "hy"), ("vx", "vy")):
+            if (ptr[a] is None) != (ptr[b] is None):
+                raise ValueError(f"ray generation: {a} and {b} must both be planes or both scalars")
+        st = _capi.RaygenInputs(ptr["hx"], ptr["hy"], ptr["px"], ptr["py"], ptr["vx"], ptr["vy"],
+                                scal["hx"], scal["hy"], scal["vx"], scal["vy"], int(flags), 0)
+        return st, keep
+
+    def generate_rays(self, hx, hy, px, py, vx=None, vy=None, out=None, *, flags: int = 0,
+                      zero_status: bool = True):
+        """On-device ray generation (paraxial aiming, angle fields).  `hx, hy` and
+        `vx, vy` are per-ray tensors or floats (launch-uniform; None = unvignetted).
+        Returns 7 planes.  `out`: optional list of >= 7 preallocated planes (an 8th, if
+        present, is zero-filled as the opd plane) -- e.g. row 0 of a record block, so
+        that the trace need not copy the object-surface row.  `flags`: `_capi.RAYGEN_*`
+        (range checks land in the status word read by `raise_for_status`)."""
+        p = self._raygen_params()
         n = int(px.numel())
         dtype = px.dtype
-        p = _capi.RaygenParams(int(rg["object_infinite"]), 0, rg["EPL"], rg["EPD"],
-                               rg["max_field"], rg["offset"], rg["z_first"])
         if out is None:
             buf = torch.empty((7, max(n, 1)), dtype=dtype, device=self.device)
             planes = [buf[k, :n] for k in range(7)]
         else:
-            planes = list(out[:7])
-        ptrs = (C.c_void_p * 7)(*[p_.data_ptr() for p_ in planes])
-        args = [t.contiguous() for t in (hx, hy, px, py)]
-        vxc = vx.contiguous() if vx is not None else None
-        vyc = vy.contiguous() if vy is not None else None
+            planes = list(out[:8])
+        if n == 0:
+            return planes[:7]
+        inp, keep = self._raygen_inputs(hx, hy, px, py, vx, vy, flags)
+        ptrs = (C.c_void_p * 8)(*([p_.data_ptr() for p_ in planes] + [None] * (8 - len(planes))))
+        if zero_status and flags & (_capi.RAYGEN_CHECK_FIELD | _capi.RAYGEN_CHECK_PUPIL):
+            self._status.zero_()
         with torch.cuda.device(self.device):
-            rc = self.lib.ol_generate_rays(
-                C.byref(p), _DT[dtype], n, *[a.data_ptr() for a in args],
-                vxc.data_ptr() if vxc is not None else None,
-                vyc.data_ptr() if vyc is not None else None, ptrs, _stream_ptr(self.device))
+            rc = self.lib.ol_generate_rays(C.byref(p), _DT[dtype], n, C.byref(inp), ptrs,
+                                           self._status.data_ptr(), _stream_ptr(self.device))
         _capi.check(rc, "ol_generate_rays")
-        return planes
+        return planes[:7]
 
     def polarized_intensity(self, prt, k0, i0, polarization: dict | None):
         n = int(i0.numel())
@@ -281,7 +318,7 @@ class HipSystem:
 
     def trace_spot(self, px, py, wl_index: int, *, field=None, hx=None, hy=None, vig=(1.0, 1.0),
                    vx=None, vy=None, center=(0.0, 0.0), hits=None, out=None,
-                   check_status: bool = True):
+                   check_status: bool = True, flags: int = 0):
         """Fused generate -> trace -> reduce (`ol_trace_spot`): one kernel, no ray planes.
 
         `field` = (Hx, Hy) launch-uniform, or per-ray `hx`, `hy` tensors; `vig` =
@@ -290,36 +327,30 @@ class HipSystem:
         preallocated planes for the image-plane x, y, intensity.  Returns a float64
         tensor {count, sum dx, sum dy, sum dx^2, sum dy^2, sum i, max r^2} (`out`, if
         given, is ACCUMULATED into -- zero it to start a new spot)."""
-        rg = self.table.raygen
-        if not rg:
-            raise ValueError("this SystemTable carries no ray-generation scalars")
+        p = self._raygen_params()
         if (field is None) == (hx is None):
             raise ValueError("give either field=(Hx, Hy) or per-ray hx, hy")
         n = int(px.numel())
         dtype = px.dtype
-        f = (0.0, 0.0) if field is None else (float(field[0]), float(field[1]))
-        p = _capi.SpotParams(
-            _capi.RaygenParams(int(rg["object_infinite"]), 0, rg["EPL"], rg["EPD"],
-                               rg["max_field"], rg["offset"], rg["z_first"]),
-            f[0], f[1], float(vig[0]), float(vig[1]), float(center[0]), float(center[1]))
         if out is None:
             out = torch.zeros(7, dtype=torch.float64, device=self.device)
         if n == 0:  # nothing to add (an empty tensor has no device pointer to hand over)
             return out
-        keep = [t.contiguous() if t is not None else None for t in (hx, hy, px, py, vx, vy)]
-        for t in keep:
-            if t is not None and (t.dtype != dtype or t.numel() != n):
-                raise ValueError("trace_spot: coordinate planes must share dtype and length")
-        ptr = [t.data_ptr() if t is not None else None for t in keep]
+        if field is not None:
+            hx, hy = float(field[0]), float(field[1])
+        if vx is None:
+            vx, vy = float(vig[0]), float(vig[1])
+        inp, keep = self._raygen_inputs(hx, hy, px, py, vx, vy, flags)
         hp = None
         if hits is not None:
             hp = (C.c_void_p * 3)(*[h.data_ptr() for h in hits])
         if check_status:
             self._status.zero_()
         with torch.cuda.device(self.device):
-            rc = self.lib.ol_trace_spot(self._handle, _DT[dtype], n, C.byref(p), *ptr,
-                                        int(wl_index), hp, out.data_ptr(),
-                                        self._status.data_ptr(), _stream_ptr(self.device))
+            rc = self.lib.ol_trace_spot(self._handle, _DT[dtype], n, C.byref(p), C.byref(inp),
+                                        float(center[0]), float(center[1]), int(wl_index), hp,
+                                        out.data_ptr(), self._status.data_ptr(),
+                                        _stream_ptr(self.device))
         _capi.check(rc, "ol_trace_spot")
         if check_status:
             self.raise_for_status(int(self._status.item()))

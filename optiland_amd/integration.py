@@ -136,7 +136,7 @@ def _make_tracer_class():
                 vxf, vyf = self.optic.fields.get_vig_factor(Hx, Hy)
                 vx = as_dev(1 - np.asarray(be.to_numpy(vxf), dtype=np.float64) * np.ones(n))
                 vy = as_dev(1 - np.asarray(be.to_numpy(vyf), dtype=np.float64) * np.ones(n))
-                eng.generate_rays(hx, hy, px, py, vx, vy, out=rays)
+                eng.generate_rays(hx, hy, px, py, vx, vy, out=rays)  # zero-fills the opd plane
             else:  # aiming/field type the device generator does not cover
                 r = self.ray_generator.generate_rays(Hx, Hy, Px, Py, wavelength)
                 src = [as_dev(getattr(r, k)) for k in ("x", "y", "z", "L", "M", "N", "i")]
@@ -145,7 +145,7 @@ def _make_tracer_class():
                 rays = eng.row0_planes(record, n)
                 for dst, s_ in zip(rays, src):
                     dst.copy_(s_)
-            rays[7].zero_()
+                rays[7].zero_()
             polarized = self.optic.polarization != "ignore"
             if not polarized and self.optic.surfaces.uses_polarization:
                 raise ValueError("Polarization must be set when surfaces have "

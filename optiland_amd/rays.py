@@ -19,12 +19,23 @@ class RealRays:
         self.x, self.y, self.z = x, y, z
         self.L, self.M, self.N = L, M, N
         self.i = intensity
-        self.w = wavelength
+        self._w = wavelength  # tensor, or a float materialised on first use
         self.opd = opd if opd is not None else torch.zeros_like(x)
         self.L0 = None
         self.M0 = None
         self.N0 = None
         self.is_normalized = True
+
+    @property
+    def w(self):
+        """Per-ray wavelength array (real_rays.py:68); built on first access."""
+        if not isinstance(self._w, torch.Tensor):
+            self._w = torch.full_like(self.x, float(self._w))
+        return self._w
+
+    @w.setter
+    def w(self, value):
+        self._w = value
 
     def __len__(self):
         return int(self.x.numel())

@@ -34,6 +34,8 @@ SURF_ROTATED = 0x1
 STATUS_ZERNIKE_RANGE = 0x1
 STATUS_K_PARALLEL_X = 0x2
 STATUS_CHEBYSHEV_RANGE = 0x4
+STATUS_FIELD_RANGE = 0x8
+STATUS_PUPIL_RANGE = 0x10
 
 TRACE_WRITE_RAYS = 0x1
 TRACE_COMPACT = 0x2

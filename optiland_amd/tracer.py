@@ -18,6 +18,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from . import _capi
 from .distribution import create_distribution
 from .rays import PolarizedRays, RealRays, _state_dict
 from .system import SystemTable
@@ -70,7 +71,7 @@ class HipRayTracer:
         self.surfaces = RecordedSurfaces()
         self.ray_aiming_config = {"mode": "paraxial", "max_iter": 10, "tol": 1e-6}
         self.record_all = True  # drop-in semantics; False = image plane only
-        self._pending = []      # deferred on-device argument checks
+        self._pupil_cache = {}  # (distribution name, num_rays) -> device planes
         f = np.asarray(table.fields, dtype=np.float64).reshape(-1, 4)
         self._fields = f
 
@@ -90,41 +91,44 @@ class HipRayTracer:
         return torch.as_tensor(np.atleast_1d(np.asarray(v, dtype=np.float64)),
                                dtype=self.dtype, device=self.device).reshape(-1)
 
+    @staticmethod
+    def _as_scalar(v):
+        """float(v) when `v` is a host scalar / one-element host array, else None."""
+        if isinstance(v, torch.Tensor):
+            return None if (v.is_cuda or v.numel() != 1) else float(v)
+        if isinstance(v, (int, float, np.floating, np.integer)):
+            return float(v)
+        a = np.asarray(v)
+        return float(a.reshape(-1)[0]) if a.size == 1 else None
+
     def _validate_normalized_coordinates(self, x, y, coord_type="field"):
-        """real_ray_tracer.py:156-173 (same message).  Host values are checked at once;
-        device tensors are checked ON DEVICE and the verdict is read back together with
-        the trace's status word (one synchronisation per call instead of one per
-        argument)."""
+        """real_ray_tracer.py:156-173 (same message) for values that live on the HOST.
+        Device planes are validated inside the ray-generation kernel, which reads them
+        anyway (`OL_RAYGEN_CHECK_*` -> status bits, surfaced by `_finish_checks`)."""
         for v in (x, y):
             if isinstance(v, torch.Tensor) and v.is_cuda:
-                self._pending.append((((v < -1) | (v > 1)).any(), coord_type))
+                continue
+            s = self._as_scalar(v)
+            if s is not None:
+                ok = -1.0 <= s <= 1.0
             else:
-                a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else \
+                a = v.detach().numpy() if isinstance(v, torch.Tensor) else \
                     np.asarray(v, dtype=np.float64)
-                if not bool(np.all((a >= -1) & (a <= 1))):
-                    self._pending.clear()
-                    raise ValueError(
-                        f"Normalized {coord_type} coordinates must be within (-1, 1)")
+                ok = bool(np.all((a >= -1) & (a <= 1)))
+            if not ok:
+                raise ValueError(f"Normalized {coord_type} coordinates must be within (-1, 1)")
 
     def _finish_checks(self, eng):
-        """One read-back: deferred range checks + the kernel's status word."""
-        pending, self._pending = self._pending, []
+        """One read-back of the device status word (range checks of the ray generator +
+        the trace kernel's own bits)."""
         status_t = getattr(eng, "_status", None)
         if status_t is None:  # engines that raise eagerly (tests' oracle stand-in)
-            for bad, kind in pending:
-                if bool(bad):
-                    raise ValueError(f"Normalized {kind} coordinates must be within (-1, 1)")
             return
-        words = [status_t[0].to(torch.int64)] + [b.to(torch.int64) for b, _ in pending]
-        vals = torch.stack(words).tolist()
-        for (_, kind), bad in zip(pending, vals[1:]):
-            if bad:
-                raise ValueError(f"Normalized {kind} coordinates must be within (-1, 1)")
-        eng.raise_for_status(int(vals[0]))
+        eng.raise_for_status(int(status_t.item()))
 
     def _vig_factor(self, hx, hy):
         """FieldGroup.get_vig_factor (fields/field_group.py:93-122): nearest field
-        point in normalised field coordinates -> (vx, vy)."""
+        point in normalised field coordinates -> (vx, vy), per ray, on device."""
         f = self._fields
         if f.shape[0] == 0 or not np.any(f[:, 2:]):
             return None, None
@@ -150,24 +154,38 @@ class HipRayTracer:
         w = float(wavelength.item()) if hasattr(wavelength, "item") else float(wavelength)
         return self.table.wavelength_index(w), w
 
+    def _pupil_planes(self, distribution, num_rays):
+        """Device planes of a pupil distribution; named distributions are cached per
+        (name, num_rays) so that repeated traces do not re-sample / re-upload them."""
+        if isinstance(distribution, str):
+            key = (distribution, int(num_rays) if num_rays is not None else None)
+            hit = self._pupil_cache.get(key)
+            if hit is None:
+                d = create_distribution(distribution)
+                d.generate_points(num_rays)
+                hit = (self._dev(d.x), self._dev(d.y))
+                if distribution != "random":  # a fresh sample per call, like the reference
+                    self._pupil_cache[key] = hit
+            return hit
+        return self._dev(distribution.x), self._dev(distribution.y)
+
     # -------------------------------------------------------------------- trace
-    def _run(self, hx, hy, px, py, one_minus_v, wavelength, update_intensity):
+    def _run(self, hx, hy, px, py, vig, wavelength, update_intensity, flags):
+        """hx, hy: floats (launch-uniform field) or device planes; px, py: device planes;
+        vig: (1 - vx, 1 - vy) as floats or planes; flags: OL_RAYGEN_*."""
         wl, w = self._wavelength_index(wavelength)
         eng = self.engine
-        vx, vy = one_minus_v
         n = int(px.numel())
-        record = self.record_all
         if self.record_all:
             # rays are generated straight into row 0 of the record block: the object
             # surface only records its input, so the trace need not copy that row
             record = eng.alloc_record(n, self.dtype)
             rays = eng.row0_planes(record, n)
-            eng.generate_rays(hx, hy, px, py, vx, vy, out=rays)
-            rays[7].zero_()
         else:
-            planes = eng.generate_rays(hx, hy, px, py, vx, vy)
-            rays = [p if p.is_contiguous() else p.contiguous() for p in planes]
-            rays.append(torch.zeros(n, dtype=self.dtype, device=self.device))
+            record = False
+            buf = torch.empty((8, max(n, 1)), dtype=self.dtype, device=self.device)
+            rays = [buf[k, :n] for k in range(8)]
+        eng.generate_rays(hx, hy, px, py, vig[0], vig[1], out=rays, flags=flags)
         polarized = self.table.polarization is not None
         if not polarized and self.table.uses_polarization:
             # rays/ray_generator.py:89-94
@@ -181,21 +199,20 @@ class HipRayTracer:
             k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
             i0 = rays[6].clone()
         deferred = hasattr(eng, "_status")
-        kw = {"defer_status": True} if deferred else {}
+        kw = {"defer_status": True, "zero_status": False} if deferred else {}
         res = eng.trace(rays, wl, record=record, prt=prt, prt_identity=prt is not None, **kw)
         self._finish_checks(eng)
         self.surfaces._bind(res)
-        wt = torch.full((n,), w, dtype=self.dtype, device=self.device)
         if res.record is not None:
             fin = [res.row(res.last, k) for k in range(8)]
         else:
             fin = rays
         if polarized:
-            out = PolarizedRays(*fin[:7], wt, fin[7], engine=eng, prt=prt, i0=i0, k_init=k_init)
+            out = PolarizedRays(*fin[:7], w, fin[7], engine=eng, prt=prt, i0=i0, k_init=k_init)
             if update_intensity:  # real_ray_tracer.py:112-113 -- trace() only
                 out.update_intensity(_state_dict(self.table.polarization))
         else:
-            out = RealRays(*fin[:7], wt, fin[7])
+            out = RealRays(*fin[:7], w, fin[7])
         # pre-interaction cosines at the last surface = directions recorded on the
         # previous one, expressed in the last surface's frame (real_rays.py:170-172)
         if res.record is not None and res.last > res.first:
@@ -212,17 +229,19 @@ class HipRayTracer:
     def trace(self, Hx, Hy, wavelength, num_rays=100, distribution="hexapolar"):
         """real_ray_tracer.py:58-118: every field point x every pupil point."""
         self._validate_normalized_coordinates(Hx, Hy, "field")
-        if isinstance(distribution, str):
-            distribution = create_distribution(distribution)
-            distribution.generate_points(num_rays)
-        Px, Py = self._dev(distribution.x), self._dev(distribution.y)
+        Px, Py = self._pupil_planes(distribution, num_rays)
+        sx, sy = self._as_scalar(Hx), self._as_scalar(Hy)
+        if sx is not None and sy is not None:  # one field point: launch-uniform scalars
+            return self._run(sx, sy, Px, Py, self._vig_scalar(sx, sy), wavelength,
+                             update_intensity=True, flags=0)
         Hx, Hy = self._dev(Hx), self._dev(Hy)
         nf, npup = Hx.numel(), Px.numel()
         hx, hy = Hx.repeat_interleave(npup), Hy.repeat_interleave(npup)
         px, py = Px.repeat(nf), Py.repeat(nf)
         vxf, vyf = self._vig_factor(hx, hy)
-        omv = (None, None) if vxf is None else (1 - vxf, 1 - vyf)
-        return self._run(hx, hy, px, py, omv, wavelength, update_intensity=True)
+        vig = (None, None) if vxf is None else (1 - vxf, 1 - vyf)
+        return self._run(hx, hy, px, py, vig, wavelength, update_intensity=True,
+                         flags=_capi.RAYGEN_CHECK_FIELD)
 
     def trace_spot(self, Hx: float, Hy: float, wavelength, num_rays=100,
                    distribution="hexapolar", center=(0.0, 0.0), hits: bool = False):
@@ -238,10 +257,7 @@ class HipRayTracer:
         self._validate_normalized_coordinates(Hx, Hy, "field")
         if self.table.polarization is not None or self.table.uses_polarization:
             raise ValueError("trace_spot: fused spot reduction needs an unpolarised system")
-        if isinstance(distribution, str):
-            distribution = create_distribution(distribution)
-            distribution.generate_points(num_rays)
-        px, py = self._dev(distribution.x), self._dev(distribution.y)
+        px, py = self._pupil_planes(distribution, num_rays)
         wl, _ = self._wavelength_index(wavelength)
         out3 = None
         if hits:
@@ -254,18 +270,31 @@ class HipRayTracer:
 
     def trace_generic(self, Hx, Hy, Px, Py, wavelength):
         """real_ray_tracer.py:120-154: caller-supplied per-ray coordinates; the
-        pupil is pre-scaled by (1 - v) (:134-137) and the polarised
-        update_intensity epilogue is NOT applied."""
+        pupil is pre-scaled by (1 - v) (:134-137, `OL_RAYGEN_PRESCALE_PUPIL`) and the
+        polarised update_intensity epilogue is NOT applied."""
         self._validate_normalized_coordinates(Hx, Hy, "field")
         self._validate_normalized_coordinates(Px, Py, "pupil")
-        arrs = [self._dev(a) for a in (Hx, Hy, Px, Py)]
-        n = max(a.numel() for a in arrs)
-        hx, hy, px, py = (a.expand(n).contiguous() if a.numel() == 1 else a for a in arrs)
-        if any(a.numel() != n for a in (hx, hy, px, py)):
+        sx, sy = self._as_scalar(Hx), self._as_scalar(Hy)
+        px, py = self._dev(Px), self._dev(Py)
+        flags = _capi.RAYGEN_CHECK_PUPIL
+        if sx is not None and sy is not None:
+            n = max(px.numel(), py.numel())
+            hx, hy = sx, sy
+            vig = self._vig_scalar(sx, sy)
+            vignetted = vig != (1.0, 1.0)
+        else:
+            hx, hy = self._dev(Hx), self._dev(Hy)
+            n = max(a.numel() for a in (hx, hy, px, py))
+            hx, hy = (a.expand(n).contiguous() if a.numel() == 1 else a for a in (hx, hy))
+            if hx.numel() != n or hy.numel() != n:
+                raise ValueError("Hx, Hy, Px, Py must be scalars or arrays of one common size")
+            vxf, vyf = self._vig_factor(hx, hy)
+            vignetted = vxf is not None
+            vig = (1 - vxf, 1 - vyf) if vignetted else (None, None)
+            flags |= _capi.RAYGEN_CHECK_FIELD
+        px, py = (a.expand(n).contiguous() if a.numel() == 1 else a for a in (px, py))
+        if px.numel() != n or py.numel() != n:
             raise ValueError("Hx, Hy, Px, Py must be scalars or arrays of one common size")
-        vxf, vyf = self._vig_factor(hx, hy)
-        omv = (None, None)
-        if vxf is not None:
-            px, py = px * (1 - vxf), py * (1 - vyf)
-            omv = (1 - vxf, 1 - vyf)
-        return self._run(hx, hy, px, py, omv, wavelength, update_intensity=False)
+        if vignetted:
+            flags |= _capi.RAYGEN_PRESCALE_PUPIL
+        return self._run(hx, hy, px, py, vig, wavelength, update_intensity=False, flags=flags)

@@ -85,13 +85,34 @@ class OracleEngine:
         rows = self.num_surfaces if rows is None else rows
         return torch.empty((rows, 8, max(n, 1)), dtype=dtype)
 
-    def generate_rays(self, hx, hy, px, py, vx=None, vy=None, out=None):
-        f = lambda t: None if t is None else t.double().numpy()  # noqa: E731
-        g = oracle.generate_rays(self.table.raygen, f(hx), f(hy), f(px), f(py), f(vx), f(vy))
+    def generate_rays(self, hx, hy, px, py, vx=None, vy=None, out=None, *, flags=0,
+                      zero_status=True):
+        n = int(px.numel())
+
+        def plane(v, default):
+            if v is None:
+                v = default
+            if isinstance(v, torch.Tensor):
+                return v.double().numpy()
+            return np.full(n, float(v))
+
+        H = [plane(hx, 0.0), plane(hy, 0.0)]
+        P = [plane(px, 0.0), plane(py, 0.0)]
+        V = [plane(vx, 1.0), plane(vy, 1.0)]
+        bad = lambda a: not bool(np.all((a >= -1) & (a <= 1)))  # noqa: E731
+        if flags & 0x1 and (bad(H[0]) or bad(H[1])):
+            raise ValueError("Normalized field coordinates must be within (-1, 1)")
+        if flags & 0x2 and (bad(P[0]) or bad(P[1])):
+            raise ValueError("Normalized pupil coordinates must be within (-1, 1)")
+        if flags & 0x4:  # trace_generic: pupil pre-scaled by (1 - v)
+            P = [P[0] * V[0], P[1] * V[1]]
+        g = oracle.generate_rays(self.table.raygen, H[0], H[1], P[0], P[1], V[0], V[1])
         planes = [torch.as_tensor(g[k], dtype=px.dtype) for k in ("x", "y", "z", "L", "M", "N", "i")]
         if out is not None:
             for dst, src in zip(out, planes):
                 dst.copy_(src)
+            if len(out) > 7:
+                out[7].zero_()
             return list(out[:7])
         return planes
 
@@ -113,14 +134,14 @@ class OracleEngine:
                 torch.as_tensor(pupil, dtype=px.dtype) if want_pupil else None)
 
     def trace_spot(self, px, py, wl_index, *, field=None, hx=None, hy=None, vig=(1.0, 1.0),
-                   vx=None, vy=None, center=(0.0, 0.0), hits=None, out=None, check_status=True):
+                   vx=None, vy=None, center=(0.0, 0.0), hits=None, out=None, check_status=True,
+                   flags=0):
         n = int(px.numel())
         dtype = px.dtype
-        full = lambda v: torch.full((n,), float(v), dtype=dtype)  # noqa: E731
         if field is not None:
-            hx, hy = full(field[0]), full(field[1])
+            hx, hy = float(field[0]), float(field[1])
         if vx is None:
-            vx, vy = full(vig[0]), full(vig[1])
+            vx, vy = float(vig[0]), float(vig[1])
         rays = self.generate_rays(hx, hy, px, py, vx, vy) + [torch.zeros(n, dtype=dtype)]
         self.trace(rays, wl_index, record=False)
         x, y, i = rays[0].double(), rays[1].double(), rays[6].double()

@@ -81,12 +81,27 @@ def test_argument_validation_without_a_device(lib):
     handle = C.c_void_p()
     rc = lib.ol_system_create(None, 0, None, 0, None, 0, C.byref(handle))
     assert rc == -1 and b"no surfaces" in lib.ol_last_error()
-    rc = lib.ol_generate_rays(None, 0, 1, None, None, None, None, None, None, None, None)
+    rc = lib.ol_generate_rays(None, 0, 1, None, None, None, None)
     assert rc == -1
+    # host-side part of the range validation (launch-uniform field scalars) and the
+    # argument rules of ol_raygen_inputs need no device
+    from optiland_amd._capi import RaygenInputs, RaygenParams
+    par = RaygenParams(1, 0, 10.0, 5.0, 20.0, 5.0, 0.0)
+    outp = (C.c_void_p * 8)(*([8] * 7 + [None]))  # never dereferenced: the call must fail first
+    status = C.c_uint32(0)
+    inp = RaygenInputs(None, None, 16, 16, None, None, 0.0, 1.5, 1.0, 1.0, 0x1, 0)
+    rc = lib.ol_generate_rays(C.byref(par), 0, 4, C.byref(inp), outp, C.byref(status), None)
+    assert rc == -1
+    assert lib.ol_last_error() == b"Normalized field coordinates must be within (-1, 1)"
+    inp = RaygenInputs(16, None, 16, 16, None, None, 0.0, 0.0, 1.0, 1.0, 0, 0)
+    rc = lib.ol_generate_rays(C.byref(par), 0, 4, C.byref(inp), outp, None, None)
+    assert rc == -1 and b"must be given together" in lib.ol_last_error()
+    inp = RaygenInputs(None, None, 16, 16, None, None, 0.0, 0.0, 1.0, 1.0, 0x2, 0)
+    rc = lib.ol_generate_rays(C.byref(par), 0, 4, C.byref(inp), outp, None, None)
+    assert rc == -1 and b"needs a status word" in lib.ol_last_error()
     rc = lib.ol_spot_moments(0, 4, None, None, None, None, None)
     assert rc == -1
-    rc = lib.ol_trace_spot(None, 0, 4, None, None, None, None, None, None, None, 0, None, None,
-                           None, None)
+    rc = lib.ol_trace_spot(None, 0, 4, None, None, 0.0, 0.0, 0, None, None, None, None)
     assert rc == -1 and b"system is NULL" in lib.ol_last_error()
     assert lib.ol_system_num_surfaces(None) == 0
     lib.ol_system_destroy(None)  # no-op

@@ -259,3 +259,64 @@ def test_no_write_outside_the_callers_buffers(dtype, n):
     for k in range(8):
         assert torch.equal(rays[k].nan_to_num(nan=-1.0), res.row(rows - 1, k).nan_to_num(nan=-1.0))
     hip.close()
+
+
+def test_range_validation_happens_in_the_raygen_kernel():
+    """Device-resident Hx/Hy/Px/Py are validated by the ray-generation kernel
+    (OL_RAYGEN_CHECK_* -> status bits) with the reference's messages
+    (real_ray_tracer.py:156-173); host scalars are validated on the host."""
+    from optiland_amd import load_system, tracer as tr
+    t = tr.HipRayTracer(load_system("double_gauss"), DEV, dtype=torch.float32)
+    n = 1000
+    ok = torch.linspace(-1, 1, n, device=DEV)
+    bad = ok.clone()
+    bad[n // 2] = 1.0001
+    nan = ok.clone()
+    nan[3] = float("nan")
+    t.trace_generic(ok * 0.5, ok, ok * 0.1, ok * 0.1, 0.5876)  # passes
+    with pytest.raises(ValueError, match="Normalized field coordinates"):
+        t.trace_generic(bad, ok, ok, ok, 0.5876)
+    with pytest.raises(ValueError, match="Normalized field coordinates"):
+        t.trace_generic(ok, nan, ok, ok, 0.5876)
+    with pytest.raises(ValueError, match="Normalized pupil coordinates"):
+        t.trace_generic(ok, ok, ok, bad, 0.5876)
+    with pytest.raises(ValueError, match="Normalized pupil coordinates"):
+        t.trace_generic(0.0, 0.5, bad, ok, 0.5876)
+    with pytest.raises(ValueError, match="Normalized field coordinates"):  # field first
+        t.trace_generic(bad, ok, bad, ok, 0.5876)
+    with pytest.raises(ValueError, match="Normalized field coordinates"):
+        t.trace_generic(0.0, 1.5, ok, ok, 0.5876)
+    with pytest.raises(ValueError, match="Normalized field coordinates"):
+        t.trace(torch.tensor([0.0, 2.0], device=DEV), torch.tensor([0.0, 0.0], device=DEV),
+                0.5876, 3, "hexapolar")
+    # trace() does not validate the pupil (a distribution may exceed the unit disc)
+    r = t.trace_generic(0.0, 0.0, ok * 0.2, ok * 0.2, 0.5876)
+    assert len(r) == n
+    t.engine.close()
+
+
+def test_uniform_field_scalars_equal_field_planes():
+    """Launch-uniform (Hx, Hy) scalars and constant per-ray planes give the same rays,
+    with and without vignetting (trace and trace_generic)."""
+    from optiland_amd import load_system, tracer as tr
+    from tests._util import load_case
+    for dtype in (torch.float32, torch.float64):
+        table, _ = load_case("vignetted_trace")
+        t = tr.HipRayTracer(table, DEV, dtype=dtype)
+        n = 515
+        g = torch.Generator(device=DEV).manual_seed(3)
+        px = (torch.rand(n, generator=g, device=DEV, dtype=torch.float64) - 0.5).to(dtype)
+        py = (torch.rand(n, generator=g, device=DEV, dtype=torch.float64) - 0.5).to(dtype)
+        mf = table.raygen["max_field"]
+        hy0 = float(np.asarray(table.fields)[-1][1] / mf)
+        a = t.trace_generic(0.0, hy0, px, py, float(table.wavelengths[0]))
+        ax = [v.clone() for v in (a.x, a.y, a.L, a.i, a.opd)]
+        hx = torch.zeros(n, dtype=dtype, device=DEV)
+        hy = torch.full((n,), hy0, dtype=dtype, device=DEV)
+        b = t.trace_generic(hx, hy, px, py, float(table.wavelengths[0]))
+        eps = 1e-6 if dtype == torch.float32 else 1e-14
+        for u, v in zip(ax, (b.x, b.y, b.L, b.i, b.opd)):
+            assert torch.equal(torch.isnan(u), torch.isnan(v))
+            scale = float(v.abs().nan_to_num().max()) + 1.0
+            assert float((u - v).abs().nan_to_num().max()) <= 20 * eps * scale
+        t.engine.close()
