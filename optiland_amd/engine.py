@@ -52,6 +52,10 @@ class TraceResult:
         k = PLANES.index(plane) if isinstance(plane, str) else plane
         return self.record[s - self.first, k, : self.n]
 
+    def rows(self, s: int):
+        """All 8 plane views of recorded surface `s` (two tensor ops instead of 8)."""
+        return self.record[s - self.first, :, : self.n].unbind(0)
+
     def stack(self, plane: str | int) -> torch.Tensor:
         """(rows, n) view of one plane for all recorded surfaces (no copy)."""
         k = PLANES.index(plane) if isinstance(plane, str) else plane
@@ -191,7 +195,7 @@ class HipSystem:
 
     def row0_planes(self, record: torch.Tensor, n: int):
         """The 8 planes of record row 0 as ray planes (zero-copy object row)."""
-        return [record[0, k, :n] for k in range(8)]
+        return list(record[0, :, :n].unbind(0))
 
     @staticmethod
     def raise_for_status(status: int) -> None:

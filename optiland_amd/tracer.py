@@ -204,7 +204,7 @@ class HipRayTracer:
         self._finish_checks(eng)
         self.surfaces._bind(res)
         if res.record is not None:
-            fin = [res.row(res.last, k) for k in range(8)]
+            fin = res.rows(res.last)
         else:
             fin = rays
         if polarized:
@@ -216,7 +216,7 @@ class HipRayTracer:
         # pre-interaction cosines at the last surface = directions recorded on the
         # previous one, expressed in the last surface's frame (real_rays.py:170-172)
         if res.record is not None and res.last > res.first:
-            L0, M0, N0 = (res.row(res.last - 1, k) for k in (3, 4, 5))
+            L0, M0, N0 = res.rows(res.last - 1)[3:6]
             s = self.table.surfaces[res.last]
             if s["flags"] & 1:
                 R = torch.as_tensor(np.asarray(s["rot"]).reshape(3, 3), dtype=self.dtype,
