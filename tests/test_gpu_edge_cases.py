@@ -320,3 +320,41 @@ def test_uniform_field_scalars_equal_field_planes():
             scale = float(v.abs().nan_to_num().max()) + 1.0
             assert float((u - v).abs().nan_to_num().max()) <= 20 * eps * scale
         t.engine.close()
+
+
+def test_graphed_trace_replays_the_eager_kernels_bit_for_bit():
+    """hipGraph capture of (status zero -> ol_generate_rays -> ol_trace): replays with
+    new inputs equal eager traces bit for bit; range errors still surface."""
+    from optiland_amd import load_system
+    from optiland_amd.engine import HipSystem
+    from optiland_amd.graph import GraphedTrace
+    table = load_system("double_gauss")
+    hip = HipSystem(table, DEV)
+    try:
+        for dtype, record_all in ((torch.float32, True), (torch.float64, True),
+                                  (torch.float32, False)):
+            n = 300
+            g = GraphedTrace(hip, n, dtype, wavelength_index=1, record_all=record_all)
+            gen = torch.Generator(device=DEV).manual_seed(5)
+            for rep in range(3):
+                c = [(torch.rand(n, generator=gen, device=DEV, dtype=torch.float64) * 1.2 - 0.6)
+                     .to(dtype) for _ in range(4)]
+                for dst, src in zip((g.hx, g.hy, g.px, g.py), c):
+                    dst.copy_(src)
+                res = g.replay()
+                planes = hip.generate_rays(*c)
+                eager = [p.contiguous().clone() for p in planes] + \
+                    [torch.zeros(n, dtype=dtype, device=DEV)]
+                er = hip.trace(eager, 1, record=record_all)
+                if record_all:
+                    assert torch.equal(res.record[:, :, :n].nan_to_num(), er.record[:, :, :n].nan_to_num())
+                else:
+                    for a, b in zip(g.rays, eager):
+                        assert torch.equal(a.nan_to_num(), b.nan_to_num())
+            g.px[7] = 1.5
+            with pytest.raises(ValueError, match="Normalized pupil coordinates"):
+                g.replay()
+            g.px[7] = 0.0
+            g.replay()  # status word is re-zeroed inside the graph
+    finally:
+        hip.close()
