@@ -27,6 +27,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "device_table.h"
 #include "raygen_device.h"
 #include "trace_launch.h"
@@ -42,6 +44,27 @@ namespace ol {
 // --------------------------------------------------------------------------
 template <typename T>
 struct Math;
+
+// lane-wise compare / select vocabulary shared by the scalar types and the packed
+// pair (Math<f32x2>): the lean (conic-only, unpolarised) path is written once in these
+// terms and instantiated for T and for f32x2.
+#define OL_SCALAR_LANE_OPS(T)                                                             \
+  using scalar = T;                                                                       \
+  using mask = bool;                                                                      \
+  static constexpr int lanes = 1;                                                         \
+  static __device__ __forceinline__ T splat(T v) { return v; }                            \
+  static __device__ __forceinline__ bool lt(T a, T b) { return a < b; }                   \
+  static __device__ __forceinline__ bool le(T a, T b) { return a <= b; }                  \
+  static __device__ __forceinline__ bool gt(T a, T b) { return a > b; }                   \
+  static __device__ __forceinline__ bool ge(T a, T b) { return a >= b; }                  \
+  static __device__ __forceinline__ bool eq(T a, T b) { return a == b; }                  \
+  static __device__ __forceinline__ bool ne(T a, T b) { return a != b; }                  \
+  static __device__ __forceinline__ bool all(bool v) { return v; }                        \
+  static __device__ __forceinline__ bool mnot(bool m) { return !m; }                      \
+  static __device__ __forceinline__ bool mand(bool p, bool q) { return p && q; }          \
+  static __device__ __forceinline__ bool same(bool p, bool q) { return p == q; }          \
+  static __device__ __forceinline__ T select(bool m, T a, T b) { return m ? a : b; }      \
+  static __device__ __forceinline__ bool mselect(bool m, bool a, bool b) { return m ? a : b; }
 
 template <>
 struct Math<float> {
@@ -61,6 +84,7 @@ struct Math<float> {
   }
   static __device__ __forceinline__ float eps() { return 1.1920929e-7f; }
   static __device__ __forceinline__ float guard() { return 1e-14f; }
+  OL_SCALAR_LANE_OPS(float)
 };
 
 template <>
@@ -79,6 +103,66 @@ struct Math<double> {
   }
   static __device__ __forceinline__ double eps() { return 2.220446049250313e-16; }
   static __device__ __forceinline__ double guard() { return 1e-14; }
+  OL_SCALAR_LANE_OPS(double)
+};
+
+// Two fp32 rays in one 64-bit register pair.  add / mul / fma on this type compile to
+// the packed instructions v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, which issue at
+// the same rate as their scalar forms and so do two rays' worth of arithmetic per
+// issue slot -- the only way to the full fp32 vector rate on CDNA3/4.  sqrt / rcp /
+// compares / selects stay one instruction per ray (there are no packed forms), and a
+// mask is a pair of bools so that a compare still lands in an SGPR pair and feeds
+// v_cndmask directly, exactly like the scalar code.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct Mask2 {
+  bool a, b;
+};
+
+template <>
+struct Math<f32x2> {
+  using scalar = float;
+  using mask = Mask2;
+  static constexpr int lanes = 2;
+  using V = f32x2;
+  static __device__ __forceinline__ V rcp(V x) {
+    return V{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
+  }
+  static __device__ __forceinline__ V sqrt(V x) {
+    return V{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
+  }
+  static __device__ __forceinline__ V rsqrt(V x) {
+    return V{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)};
+  }
+  static __device__ __forceinline__ V div(V a, V b) { return a * rcp(b); }
+  static __device__ __forceinline__ V exp(V x) { return V{__expf(x.x), __expf(x.y)}; }
+  static __device__ __forceinline__ V abs(V x) {
+    return V{__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
+  }
+  static __device__ __forceinline__ V copysign(V a, V b) {
+    return V{__builtin_copysignf(a.x, b.x), __builtin_copysignf(a.y, b.y)};
+  }
+  static __device__ __forceinline__ V fma(V a, V b, V c) {
+    return __builtin_elementwise_fma(a, b, c);
+  }
+  static __device__ __forceinline__ float eps() { return 1.1920929e-7f; }
+  static __device__ __forceinline__ float guard() { return 1e-14f; }
+  static __device__ __forceinline__ V splat(float v) { return V{v, v}; }
+  static __device__ __forceinline__ mask lt(V a, V b) { return {a.x < b.x, a.y < b.y}; }
+  static __device__ __forceinline__ mask le(V a, V b) { return {a.x <= b.x, a.y <= b.y}; }
+  static __device__ __forceinline__ mask gt(V a, V b) { return {a.x > b.x, a.y > b.y}; }
+  static __device__ __forceinline__ mask ge(V a, V b) { return {a.x >= b.x, a.y >= b.y}; }
+  static __device__ __forceinline__ mask eq(V a, V b) { return {a.x == b.x, a.y == b.y}; }
+  static __device__ __forceinline__ mask ne(V a, V b) { return {a.x != b.x, a.y != b.y}; }
+  static __device__ __forceinline__ mask all(bool v) { return {v, v}; }
+  static __device__ __forceinline__ mask mnot(mask m) { return {!m.a, !m.b}; }
+  static __device__ __forceinline__ mask mand(mask p, mask q) { return {p.a && q.a, p.b && q.b}; }
+  static __device__ __forceinline__ mask same(mask p, mask q) { return {p.a == q.a, p.b == q.b}; }
+  static __device__ __forceinline__ V select(mask m, V a, V b) {
+    return V{m.a ? a.x : b.x, m.b ? a.y : b.y};
+  }
+  static __device__ __forceinline__ mask mselect(mask m, mask a, mask b) {
+    return {m.a ? a.a : b.a, m.b ? a.b : b.b};
+  }
 };
 
 template <typename T>
@@ -113,32 +197,36 @@ struct Jones {
 // Reference picks t1 if |z+t1 N| <= |z+t2 N| else t2 where
 //   t1 = (-E + sgn(R) sqrt(disc))/A, t2 = (-E - sgn(R) sqrt(disc))/A;
 // a == 0 -> -c/b which is exactly t_a.
-template <typename T>
-__device__ __forceinline__ T flat_distance(T z, T N) {  // standard.py:108-111
-  using m = Math<T>;
-  T Ns = m::abs(N) > m::guard() ? N : m::guard();
+template <typename V>
+__device__ __forceinline__ V flat_distance(V z, V N) {  // standard.py:108-111
+  using m = Math<V>;
+  const V g = m::splat(m::guard());
+  V Ns = m::select(m::gt(m::abs(N), g), N, g);
   return -m::div(z, Ns);
 }
 
-template <typename T>
-__device__ __forceinline__ T curved_distance(T cv, T kp1, T x, T y, T z, T L, T M, T N) {
-  using m = Math<T>;
-  const T kz = kp1 * z, kN = kp1 * N;
-  T E = m::fma(cv, m::fma(x, L, m::fma(y, M, kz * N)), -N);
-  T A = cv * m::fma(L, L, m::fma(M, M, kN * N));
-  T C = m::fma(cv, m::fma(x, x, m::fma(y, y, kz * z)), T(-2) * z);
-  T disc = m::fma(E, E, -A * C);
-  T sq = m::sqrt(disc);  // NaN when the ray misses (standard.py:132-137)
-  T q = -(E + m::copysign(sq, E));
-  T ta = m::div(C, q);
-  T tb = m::div(q, A);
-  T za = m::abs(m::fma(ta, N, z));
-  T zb = m::abs(m::fma(tb, N, z));
-  // t_b is the reference's t1 iff -sgn(E) == sgn(R)
-  bool b_is_t1 = (E < T(0)) == (cv > T(0));
-  bool take_b = b_is_t1 ? (zb <= za) : !(za <= zb);
-  T t = take_b ? tb : ta;
-  t = (A == T(0)) ? ta : t;
+template <typename V>
+__device__ __forceinline__ V curved_distance(typename Math<V>::scalar cv,
+                                             typename Math<V>::scalar kp1, V x, V y, V z, V L, V M,
+                                             V N) {
+  using m = Math<V>;
+  const V zero = m::splat(0);
+  const V kz = kp1 * z, kN = kp1 * N;
+  V E = m::fma(m::splat(cv), m::fma(x, L, m::fma(y, M, kz * N)), -N);
+  V A = cv * m::fma(L, L, m::fma(M, M, kN * N));
+  V C = m::fma(m::splat(cv), m::fma(x, x, m::fma(y, y, kz * z)), m::splat(-2) * z);
+  V disc = m::fma(E, E, -A * C);
+  V sq = m::sqrt(disc);  // NaN when the ray misses (standard.py:132-137)
+  V q = -(E + m::copysign(sq, E));
+  V ta = m::div(C, q);
+  V tb = m::div(q, A);
+  // t_b is the reference's t1 iff -sgn(E) == sgn(R); the reference keeps t1 when
+  // |z + t1 N| <= |z + t2 N| and t2 otherwise (also when the comparison is NaN)
+  const auto b_is_t1 = m::same(m::lt(E, zero), m::all(cv > 0));
+  const V t1 = m::select(b_is_t1, tb, ta), t2 = m::select(b_is_t1, ta, tb);
+  const V z1 = m::abs(m::fma(t1, N, z)), z2 = m::abs(m::fma(t2, N, z));
+  V t = m::select(m::le(z1, z2), t1, t2);
+  t = m::select(m::eq(A, zero), ta, t);
   return t;
 }
 
@@ -148,15 +236,31 @@ __device__ __forceinline__ T conic_distance(const DevSurf<T>& s, T x, T y, T z, 
   return curved_distance(s.cv, s.kp1, x, y, z, L, M, N);
 }
 
-// standard.py:150-175: gradient of the conic; returns (fx, fy) = (x, y)/denom.
-template <typename T>
-__device__ __forceinline__ void conic_gradient(const DevSurf<T>& s, T x, T y, T& fx, T& fy) {
-  using m = Math<T>;
-  T r2 = m::fma(x, x, y * y);
-  T g = m::rsqrt(m::fma(-s.kp1 * s.cv * s.cv, r2, T(1)));  // 1/sqrt(1-(1+k) r^2/R^2)
-  T f = s.cv * g;
-  fx = x * f;
-  fy = y * f;
+// Unit normal of the conic at the hit point (x, y, z).
+// Reference (standard.py:150-175): (fx, fy) = cv (x, y) / sqrt(D), D = 1 - (1+k) cv^2 r^2,
+// n = (fx, fy, -1) / sqrt(fx^2 + fy^2 + 1) -- two reciprocal square roots.  Multiplying
+// through by sqrt(D):  n = (cv x, cv y, -sqrt(D)) / sqrt(cv^2 r^2 + D), and ON the
+// surface sqrt(D) = |1 - cv (1+k) z|  (z = cv r^2 / (1 + sqrt(D))), so the hit point's
+// own z replaces the first square root.  For a sphere (k = 0) the denominator is
+// cv^2 (x^2 + y^2 + z^2) - 2 cv z + 1 = 1 identically: NO transcendental at all; other
+// conics keep one rsq.  |.| keeps the reference's sign when the selected root lies on
+// the far sheet.  (v_rsq / v_sqrt are quarter rate: on the VALU-bound record-last and
+// fused-spot kernels the two removed rsq were 11 % of the issue cycles.)
+template <typename V>
+__device__ __forceinline__ void conic_normal(typename Math<V>::scalar cv,
+                                             typename Math<V>::scalar kp1, V x, V y, V z, V& nx,
+                                             V& ny, V& nz) {
+  using m = Math<V>;
+  const V w = m::abs(m::fma(m::splat(-cv * kp1), z, m::splat(1)));
+  nx = cv * x;
+  ny = cv * y;
+  nz = -w;
+  if (kp1 != typename m::scalar(1)) {  // surface-uniform
+    const V h = m::rsqrt(m::fma(nx, nx, m::fma(ny, ny, w * w)));
+    nx = nx * h;
+    ny = ny * h;
+    nz = nz * h;
+  }
 }
 
 // --------------------------------------------------------------------------
@@ -765,10 +869,11 @@ __device__ __forceinline__ void prt_apply(Prt<T, POLK>& P, const PolBasis<T>& b,
 // Uniform (per-surface) branches are hoisted OUTSIDE the per-ray loops everywhere
 // below: each branch body is then one basic block holding the arithmetic of all
 // RPT rays, which is what lets their independent dependency chains interleave.
-template <typename T, int RPT>
-__device__ __forceinline__ void into_local_frame(const DevSurf<T>& s, bool from_global,
-                                                 Ray<T> (&r)[RPT]) {
-  using m = Math<T>;
+template <typename V, int RPT>
+__device__ __forceinline__ void into_local_frame(const DevSurf<typename Math<V>::scalar>& s,
+                                                 bool from_global, Ray<V> (&r)[RPT]) {
+  using m = Math<V>;
+  using T = typename m::scalar;
   // coordinate_system.py:73-89
   if (from_global) {
     const T ox = s.origin[0], oy = s.origin[1], oz = s.origin[2];
@@ -776,8 +881,8 @@ __device__ __forceinline__ void into_local_frame(const DevSurf<T>& s, bool from_
       const T* R = s.cold->rot;
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
-        T x = r[k].x - ox, y = r[k].y - oy, z = r[k].z - oz;
-        T L = r[k].L, M = r[k].M, N = r[k].N;
+        V x = r[k].x - ox, y = r[k].y - oy, z = r[k].z - oz;
+        V L = r[k].L, M = r[k].M, N = r[k].N;
         r[k].x = R[0] * x + R[1] * y + R[2] * z;
         r[k].y = R[3] * x + R[4] * y + R[5] * z;
         r[k].z = R[6] * x + R[7] * y + R[8] * z;
@@ -798,10 +903,10 @@ __device__ __forceinline__ void into_local_frame(const DevSurf<T>& s, bool from_
     const T ox = s.rel_off[0], oy = s.rel_off[1], oz = s.rel_off[2];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-      T x = r[k].x, y = r[k].y, z = r[k].z, L = r[k].L, M = r[k].M, N = r[k].N;
-      r[k].x = m::fma(R[0], x, m::fma(R[1], y, m::fma(R[2], z, ox)));
-      r[k].y = m::fma(R[3], x, m::fma(R[4], y, m::fma(R[5], z, oy)));
-      r[k].z = m::fma(R[6], x, m::fma(R[7], y, m::fma(R[8], z, oz)));
+      V x = r[k].x, y = r[k].y, z = r[k].z, L = r[k].L, M = r[k].M, N = r[k].N;
+      r[k].x = m::fma(m::splat(R[0]), x, m::fma(m::splat(R[1]), y, m::fma(m::splat(R[2]), z, m::splat(ox))));
+      r[k].y = m::fma(m::splat(R[3]), x, m::fma(m::splat(R[4]), y, m::fma(m::splat(R[5]), z, m::splat(oy))));
+      r[k].z = m::fma(m::splat(R[6]), x, m::fma(m::splat(R[7]), y, m::fma(m::splat(R[8]), z, m::splat(oz))));
       r[k].L = R[0] * L + R[1] * M + R[2] * N;
       r[k].M = R[3] * L + R[4] * M + R[5] * N;
       r[k].N = R[6] * L + R[7] * M + R[8] * N;
@@ -818,14 +923,30 @@ __device__ __forceinline__ void into_local_frame(const DevSurf<T>& s, bool from_
 }
 
 // everything after the hit point is known: absorb, opd, clip, refract/reflect,
-// coating, PRT.  (fx, fy) is the sag gradient at the hit (unused for planes).
-template <typename T, int RPT, int POLK>
-__device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>& o,
-                                         const T* __restrict__ coeffs, const T (&t)[RPT],
-                                         const T (&fx)[RPT], const T (&fy)[RPT],
-                                         Ray<T> (&r)[RPT],
-                                         Prt<T, POLK> (&P)[POLK ? RPT : 1]) {
-  using m = Math<T>;
+// coating, PRT.  (nx, ny, nz) is the unit surface normal at the hit.
+// lane-wise aperture test: the scalar predicate per ray of the pack
+template <typename V>
+__device__ __forceinline__ typename Math<V>::mask aperture_mask(
+    const DevSurf<typename Math<V>::scalar>& s, const typename Math<V>::scalar* __restrict__ coeffs,
+    V x, V y) {
+  if constexpr (Math<V>::lanes == 1) {
+    return aperture_contains(s, coeffs, x, y);
+  } else {
+    return {aperture_contains(s, coeffs, x.x, y.x), aperture_contains(s, coeffs, x.y, y.y)};
+  }
+}
+
+template <typename V, int RPT, int POLK>
+__device__ __forceinline__ void interact(const DevSurf<typename Math<V>::scalar>& s,
+                                         const DevOptics<typename Math<V>::scalar>& o,
+                                         const typename Math<V>::scalar* __restrict__ coeffs,
+                                         const V (&t)[RPT], const V (&nx)[RPT], const V (&ny)[RPT],
+                                         const V (&nz)[RPT], Ray<V> (&r)[RPT],
+                                         Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1]) {
+  using m = Math<V>;
+  using T = typename m::scalar;
+  static_assert(POLK == 0 || m::lanes == 1, "the polarised path is scalar");
+  const V zero = m::splat(0), one = m::splat(1);
   // homogeneous.py:44-53, standard_surface.py:244
   if (o.absorb > T(0)) {
 #pragma unroll
@@ -838,37 +959,20 @@ __device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>
   if (s.aperture_kind != kApNone) {
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
-      if (!aperture_contains(s, coeffs, r[k].x, r[k].y)) r[k].i = T(0);
-  }
-
-  // surface normal at the hit point
-  T nx[RPT], ny[RPT], nz[RPT];
-  if (s.geom == kGeomPlane) {
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      nx[k] = T(0);
-      ny[k] = T(0);
-      nz[k] = T(1);  // plane.py:90-109
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      T im = m::rsqrt(m::fma(fx[k], fx[k], m::fma(fy[k], fy[k], T(1))));
-      nx[k] = fx[k] * im;
-      ny[k] = fy[k] * im;
-      nz[k] = -im;
-    }
+      r[k].i = m::select(aperture_mask<V>(s, coeffs, r[k].x, r[k].y), r[k].i, zero);
   }
 
   // refract / reflect (real_rays.py:163-205, 535-571)
-  T L0[RPT], M0[RPT], N0[RPT], adot[RPT], ax[RPT], ay[RPT], az[RPT];
+  V L0[RPT], M0[RPT], N0[RPT], adot[RPT], ax[RPT], ay[RPT], az[RPT];
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
     L0[k] = r[k].L;
     M0[k] = r[k].M;
     N0[k] = r[k].N;
-    T dot = m::fma(L0[k], nx[k], m::fma(M0[k], ny[k], N0[k] * nz[k]));
-    const T sgn = dot > T(0) ? T(1) : (dot < T(0) ? T(-1) : (dot == T(0) ? T(0) : dot));
+    V dot = m::fma(L0[k], nx[k], m::fma(M0[k], ny[k], N0[k] * nz[k]));
+    // be.sign(dot): +-1, and 0 at 0.  (A NaN dot still poisons the new direction
+    // through adot below, whatever sign it is given here.)
+    const V sgn = m::select(m::ne(dot, zero), m::copysign(one, dot), zero);
     ax[k] = nx[k] * sgn;
     ay[k] = ny[k] * sgn;
     az[k] = nz[k] * sgn;
@@ -877,7 +981,7 @@ __device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>
   if (s.interaction == kReflect) {
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-      T k2 = T(-2) * adot[k];
+      V k2 = m::splat(-2) * adot[k];
       r[k].L = m::fma(k2, ax[k], L0[k]);
       r[k].M = m::fma(k2, ay[k], M0[k]);
       r[k].N = m::fma(k2, az[k], N0[k]);
@@ -886,11 +990,11 @@ __device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>
     const T u = o.u;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-      T root = m::sqrt(m::fma(-u * u, m::fma(-adot[k], adot[k], T(1)), T(1)));  // NaN on TIR
-      T w = m::fma(-u, adot[k], root);
-      r[k].L = m::fma(u, L0[k], ax[k] * w);
-      r[k].M = m::fma(u, M0[k], ay[k] * w);
-      r[k].N = m::fma(u, N0[k], az[k] * w);
+      V root = m::sqrt(m::fma(m::splat(-u * u), m::fma(-adot[k], adot[k], one), one));  // NaN on TIR
+      V w = m::fma(m::splat(-u), adot[k], root);
+      r[k].L = m::fma(m::splat(u), L0[k], ax[k] * w);
+      r[k].M = m::fma(m::splat(u), M0[k], ay[k] * w);
+      r[k].N = m::fma(m::splat(u), N0[k], az[k] * w);
     }
   }
 
@@ -937,22 +1041,26 @@ __device__ __forceinline__ void interact(const DevSurf<T>& s, const DevOptics<T>
 // NR: 0 = the surface range holds no Newton-Raphson geometry (lean kernel: none of
 // that code, or its registers, is compiled in), 1 = Newton loop, 2 = Newton loop
 // with wavefront straggler compaction.
-template <typename T, int RPT, int POLK, int NR>
-__device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptics<T>& o,
-                                             const T* __restrict__ coeffs, bool from_global,
-                                             Ray<T> (&r)[RPT],
-                                             Prt<T, POLK> (&P)[POLK ? RPT : 1],
+template <typename V, int RPT, int POLK, int NR>
+__device__ __forceinline__ void surface_step(const DevSurf<typename Math<V>::scalar>& s,
+                                             const DevOptics<typename Math<V>::scalar>& o,
+                                             const typename Math<V>::scalar* __restrict__ coeffs,
+                                             bool from_global, Ray<V> (&r)[RPT],
+                                             Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
                                              uint32_t& status) {
-  using m = Math<T>;
-  into_local_frame<T, RPT>(s, from_global, r);
+  using m = Math<V>;
+  using T = typename m::scalar;
+  static_assert(NR == 0 || m::lanes == 1, "the Newton-Raphson path is scalar");
+  into_local_frame<V, RPT>(s, from_global, r);
 
   const T* c = coeffs + s.coeff_off;
-  T t[RPT], fx[RPT], fy[RPT];
+  V t[RPT], nx[RPT], ny[RPT], nz[RPT];  // distance, unit normal at the hit
   if (s.geom == kGeomPlane) {
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       t[k] = -m::div(r[k].z, r[k].N);  // plane.py:72-88
-      fx[k] = fy[k] = T(0);
+      nx[k] = ny[k] = m::splat(0);
+      nz[k] = m::splat(1);  // plane.py:90-109
       r[k].x = m::fma(t[k], r[k].L, r[k].x);
       r[k].y = m::fma(t[k], r[k].M, r[k].y);
       r[k].z = m::fma(t[k], r[k].N, r[k].z);
@@ -961,23 +1069,24 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
     if (s.flags & kSurfRadiusInf) {
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
-        t[k] = flat_distance(r[k].z, r[k].N);
+        t[k] = flat_distance<V>(r[k].z, r[k].N);
         r[k].x = m::fma(t[k], r[k].L, r[k].x);
         r[k].y = m::fma(t[k], r[k].M, r[k].y);
         r[k].z = m::fma(t[k], r[k].N, r[k].z);
-        fx[k] = fy[k] = T(0);  // conic_gradient with cv = 0
+        nx[k] = ny[k] = m::splat(0);  // the conic normal with cv = 0
+        nz[k] = m::splat(-1);
       }
     } else {
       const T cv = s.cv, kp1 = s.kp1;
 #pragma unroll
       for (int k = 0; k < RPT; ++k)
-        t[k] = curved_distance(cv, kp1, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M, r[k].N);
+        t[k] = curved_distance<V>(cv, kp1, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M, r[k].N);
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         r[k].x = m::fma(t[k], r[k].L, r[k].x);
         r[k].y = m::fma(t[k], r[k].M, r[k].y);
         r[k].z = m::fma(t[k], r[k].N, r[k].z);
-        conic_gradient(s, r[k].x, r[k].y, fx[k], fy[k]);
+        conic_normal<V>(cv, kp1, r[k].x, r[k].y, r[k].z, nx[k], ny[k], nz[k]);
       }
     }
   } else if constexpr (NR != 0) {
@@ -1034,29 +1143,37 @@ __device__ __forceinline__ void surface_step(const DevSurf<T>& s, const DevOptic
       r[k].y = m::fma(q[k].dt, r[k].M, q[k].yb);
       r[k].z = m::fma(q[k].dt, r[k].N, q[k].zb);
       t[k] = t[k] + q[k].dt;
-      fx[k] = q[k].gx;
-      fy[k] = q[k].gy;
     }
     if (it == 0) {  // max_iter == 0: no evaluation happened, take the gradient here
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         T sag;
         uint32_t st = 0;
-        nr_eval(s, c, r[k].x, r[k].y, sag, fx[k], fy[k], st);
+        nr_eval(s, c, r[k].x, r[k].y, sag, q[k].gx, q[k].gy, st);
       }
+    }
+    // n = (fx, fy, -1) / |.| from the sag gradient (newton_raphson.py:80-98)
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const T im = m::rsqrt(m::fma(q[k].gx, q[k].gx, m::fma(q[k].gy, q[k].gy, T(1))));
+      nx[k] = q[k].gx * im;
+      ny[k] = q[k].gy * im;
+      nz[k] = -im;
     }
   } else {
     // unreachable: the host only selects NR == 0 for ranges without such surfaces
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) t[k] = fx[k] = fy[k] = T(0);
+    for (int k = 0; k < RPT; ++k) t[k] = nx[k] = ny[k] = nz[k] = m::splat(0);
   }
-  interact<T, RPT, POLK>(s, o, coeffs, t, fx, fy, r, P);
+  interact<V, RPT, POLK>(s, o, coeffs, t, nx, ny, nz, r, P);
 }
 
 // local -> global for the recorded state (coordinate_system.py:91-107)
-template <typename T>
-__device__ __forceinline__ Ray<T> to_global(const DevSurf<T>& s, const Ray<T>& r) {
-  Ray<T> g = r;
+template <typename V>
+__device__ __forceinline__ Ray<V> to_global(const DevSurf<typename Math<V>::scalar>& s,
+                                            const Ray<V>& r) {
+  using T = typename Math<V>::scalar;
+  Ray<V> g = r;
   if (s.flags & kSurfRotated) {
     const T* R = s.cold->rot;  // inverse = transpose
     g.x = R[0] * r.x + R[3] * r.y + R[6] * r.z;
@@ -1071,6 +1188,45 @@ __device__ __forceinline__ Ray<T> to_global(const DevSurf<T>& s, const Ray<T>& r
   g.z += s.origin[2];
   return g;
 }
+
+// The lean fp32 configuration -- four rays per lane, conic-only range, no
+// polarisation -- runs on packed pairs: two f32x2 rays instead of four scalar ones.
+// Everything else keeps V = T.
+template <typename T, int RPT, int POLK, int NR>
+struct LanePack {
+#ifndef OL_PACKED_F32
+#define OL_PACKED_F32 1
+#endif
+  static constexpr bool packed =
+      OL_PACKED_F32 && sizeof(T) == 4 && RPT == 4 && POLK == 0 && NR == 0;
+  using V = typename std::conditional<packed, f32x2, T>::type;
+  static constexpr int NV = packed ? RPT / 2 : RPT;
+  // ray k of the thread: element (k % lanes) of pack (k / lanes)
+  static __device__ __forceinline__ T get(const V& v, int e) {
+    if constexpr (packed) return v[e]; else return v;
+  }
+  static __device__ __forceinline__ void set(V& v, int e, T x) {
+    if constexpr (packed) v[e] = x; else v = x;
+  }
+  static __device__ __forceinline__ Ray<T> ray(const Ray<V> (&r)[NV], int k) {
+    constexpr int L = packed ? 2 : 1;
+    const Ray<V>& p = r[k / L];
+    const int e = k % L;
+    Ray<T> o;
+    o.x = get(p.x, e); o.y = get(p.y, e); o.z = get(p.z, e);
+    o.L = get(p.L, e); o.M = get(p.M, e); o.N = get(p.N, e);
+    o.i = get(p.i, e); o.opd = get(p.opd, e);
+    return o;
+  }
+  static __device__ __forceinline__ void put(Ray<V> (&r)[NV], int k, const Ray<T>& o) {
+    constexpr int L = packed ? 2 : 1;
+    Ray<V>& p = r[k / L];
+    const int e = k % L;
+    set(p.x, e, o.x); set(p.y, e, o.y); set(p.z, e, o.z);
+    set(p.L, e, o.L); set(p.M, e, o.M); set(p.N, e, o.N);
+    set(p.i, e, o.i); set(p.opd, e, o.opd);
+  }
+};
 
 // --------------------------------------------------------------------------
 // vector load / store of RPT consecutive rays of one plane
@@ -1185,7 +1341,10 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
   const int64_t left = a.n - base;
   const int cnt = left >= RPT ? RPT : (int)left;
 
-  Ray<T> r[RPT];
+  using LP = LanePack<T, RPT, POLK, NR>;  // fp32 lean kernel: packed pairs of rays
+  using V = typename LP::V;
+  constexpr int NV = LP::NV;
+  Ray<V> r[NV];
   constexpr int NPRT = POLK == 2 ? 18 : 9;  // PRT planes (real, then imaginary)
   Prt<T, POLK> P[POLK ? RPT : 1];
   {
@@ -1232,9 +1391,11 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-      r[k].x = in[0][k]; r[k].y = in[1][k]; r[k].z = in[2][k];
-      r[k].L = in[3][k]; r[k].M = in[4][k]; r[k].N = in[5][k];
-      r[k].i = in[6][k]; r[k].opd = in[7][k];
+      Ray<T> o;
+      o.x = in[0][k]; o.y = in[1][k]; o.z = in[2][k];
+      o.L = in[3][k]; o.M = in[4][k]; o.N = in[5][k];
+      o.i = in[6][k]; o.opd = in[7][k];
+      LP::put(r, k, o);
       if constexpr (POLK != 0) {
         const bool ident = (a.flags & kTracePrtIdentity) != 0;  // PRT starts as I
 #pragma unroll
@@ -1270,7 +1431,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
 #else
       const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
 #endif
-      surface_step<T, RPT, POLK, NR>(S, O, coeff_tab, is_global, r, P, status);
+      surface_step<V, NV, POLK, NR>(S, O, coeff_tab, is_global, r, P, status);
       is_global = false;
       last_traced = S;
     }
@@ -1279,21 +1440,25 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
       if (s == a.first && (a.flags & kTraceRow0IsInput)) {
         // the caller generated the rays straight into row 0 of the record block
         // (the object surface only records its input): nothing to write
-      } else if (is_global) {
-        store_rays<T, RPT>(row, a.record_stride, base, cnt, r);
       } else {
+        Ray<V> gv[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(last_traced, r[j]);
         Ray<T> g[RPT];
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) g[k] = to_global(last_traced, r[k]);
+        for (int k = 0; k < RPT; ++k) g[k] = LP::ray(gv, k);
         store_rays<T, RPT>(row, a.record_stride, base, cnt, g);
       }
     }
   }
 
   if (a.flags & kTraceWriteRays) {
+    Ray<V> gv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(last_traced, r[j]);
     Ray<T> g[RPT];
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) g[k] = is_global ? r[k] : to_global(last_traced, r[k]);
+    for (int k = 0; k < RPT; ++k) g[k] = LP::ray(gv, k);
     T tmp[RPT];
 #define OL_WB_FIELD(idx, fld)                                        \
   _Pragma("unroll") for (int k = 0; k < RPT; ++k) tmp[k] = g[k].fld; \
@@ -1493,7 +1658,10 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
       }
     }
 
-    Ray<T> r[RPT];
+    using LP = LanePack<T, RPT, 0, NR>;  // fp32 lean kernel: packed pairs of rays
+    using V = typename LP::V;
+    constexpr int NV = LP::NV;
+    Ray<V> r[NV];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       T tx = tx0, ty = ty0, o[6];
@@ -1504,9 +1672,11 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
       }
       raygen_pupil<T>(in_.flags, in[4][k], in[5][k], in[0][k], in[1][k], status);
       raygen_one<T>(c, tx, ty, in[0][k], in[1][k], in[4][k], in[5][k], o);
-      r[k].x = o[0]; r[k].y = o[1]; r[k].z = o[2];
-      r[k].L = o[3]; r[k].M = o[4]; r[k].N = o[5];
-      r[k].i = T(1); r[k].opd = T(0);
+      Ray<T> q;
+      q.x = o[0]; q.y = o[1]; q.z = o[2];
+      q.L = o[3]; q.M = o[4]; q.N = o[5];
+      q.i = T(1); q.opd = T(0);
+      LP::put(r, k, q);
     }
 
     bool is_global = true;
@@ -1521,16 +1691,19 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
       if (s < a.last) cur = surf_tab[s + 1];
       if (S.interaction != kRecordOnly) {
         const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
-        surface_step<T, RPT, 0, NR>(S, O, coeff_tab, is_global, r, P, status);
+        surface_step<V, NV, 0, NR>(S, O, coeff_tab, is_global, r, P, status);
         is_global = false;
         last_traced = S;
       }
     }
 
+    Ray<V> gv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(last_traced, r[j]);
     T hx_[RPT], hy_[RPT], hi_[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-      const Ray<T> g = is_global ? r[k] : to_global(last_traced, r[k]);
+      const Ray<T> g = LP::ray(gv, k);
       hx_[k] = g.x; hy_[k] = g.y; hi_[k] = g.i;
       if (k < cnt && g.i > T(0)) {
         const double dx = (double)g.x - a.cx, dy = (double)g.y - a.cy;
