@@ -10,6 +10,7 @@ the caller can leave such systems on the reference's own array path
 from __future__ import annotations
 
 import math
+import weakref
 
 import numpy as np
 
@@ -333,7 +334,51 @@ def pack_optic(optic, wavelengths=None, name: str | None = None) -> SystemTable:
     return table
 
 
+# The paraxial scalars below are produced by the REFERENCE's own paraxial tracer
+# (Paraxial.EPL / EPD / XPL: three paraxial traces, each walking every surface through
+# `position_in_gcs`); on the drop-in path they cost more than the whole GPU trace of a
+# small ray batch.  They only depend on the first-order layout at the PRIMARY
+# wavelength, so they are memoised per optic against a fingerprint of everything they
+# can depend on -- analyses that call Optic.trace() per field and per wavelength
+# (spot diagrams, ray fans) then pay for them once.
+_RAYGEN_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _raygen_fingerprint(optic, table: SystemTable):
+    prim = _f(optic.primary_wavelength)
+    ap = optic.aperture
+    fd = optic.fields.field_definition
+    surfaces = list(optic.surfaces)
+    idx = tuple(_scalar_index(s.material_post, prim, "n") for s in surfaces)
+    stop = tuple(bool(getattr(s, "is_stop", False)) for s in surfaces)
+    fields = tuple((_f(f.x), _f(f.y), _f(f.vx), _f(f.vy)) for f in optic.fields.fields)
+    mode = getattr(optic.ray_tracer, "ray_aiming_config", {}).get("mode", "paraxial")
+    return hash((
+        table.surfaces.tobytes(), table.coeffs.tobytes(), prim, idx, stop,
+        type(ap).__name__, None if ap is None else _f(ap.value),
+        type(fd).__name__, fields, bool(optic.object_surface.is_infinite),
+        bool(optic.obj_space_telecentric), optic.apodization is None, mode,
+    ))
+
+
 def _pack_raygen(optic, table: SystemTable) -> None:
+    try:
+        key = _raygen_fingerprint(optic, table)
+        hit = _RAYGEN_CACHE.get(optic)
+    except TypeError:  # an unhashable / non-weakref-able Optic subclass: no memo
+        key, hit = None, None
+    if hit is not None and hit[0] == key:
+        table.raygen, table.fields = dict(hit[1]), list(hit[2])
+        return
+    _compute_raygen(optic, table)
+    if key is not None:
+        try:
+            _RAYGEN_CACHE[optic] = (key, dict(table.raygen), list(table.fields))
+        except TypeError:
+            pass
+
+
+def _compute_raygen(optic, table: SystemTable) -> None:
     """Scalars for on-device ray generation.
 
     Only the case every config uses is packed: AngleField, paraxial aiming, not
@@ -353,7 +398,9 @@ def _pack_raygen(optic, table: SystemTable) -> None:
     EPL = _f(optic.paraxial.EPL())
     EPD = _f(optic.paraxial.EPD())
     infinite = bool(obj.is_infinite)
-    pos = np.asarray(_to_np(optic.surfaces.positions), dtype=np.float64).reshape(-1)
+    # SurfaceGroup.positions (surface_group.py:155-161) = z of every vertex in the
+    # global frame = the origins already folded by cs_to_affine
+    pos = np.asarray(table.surfaces["origin"][:, 2], dtype=np.float64).reshape(-1)
     if infinite:
         offset = _f(fd._get_starting_z_offset(optic))
         z_first = float(pos[1])

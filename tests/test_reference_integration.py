@@ -248,3 +248,44 @@ def test_reference_suite_sweeps_the_hip_backend(tmp_path):
     assert " passed" in tail and "failed" not in tail, tail
     n = int(tail.split(" passed")[0].split()[-1])
     assert n > 300, tail
+
+
+def test_packer_memoises_paraxial_scalars_and_invalidates(ref, monkeypatch):
+    """The reference's paraxial traces (EPL / EPD / XPL) are memoised per optic against
+    a fingerprint of the first-order layout: repeated packs (one per field / wavelength
+    of an analysis) call them once; any change that moves them recomputes."""
+    be = ref
+    be.set_backend("numpy")
+    from optiland.paraxial import Paraxial
+    from optiland.samples.objectives import CookeTriplet
+    from optiland_amd.packer import pack_optic
+    calls = {"EPL": 0}
+    orig = Paraxial.EPL
+
+    def counted(self):
+        calls["EPL"] += 1
+        return orig(self)
+
+    monkeypatch.setattr(Paraxial, "EPL", counted)
+    lens = CookeTriplet()
+    a = pack_optic(lens, wavelengths=[0.55])
+    n0 = calls["EPL"]
+    assert n0 >= 1
+    for w in (0.48, 0.55, 0.65):
+        b = pack_optic(lens, wavelengths=[w])
+        assert b.raygen == a.raygen and b.fields == a.fields
+    assert calls["EPL"] == n0                        # memo hit: no paraxial trace
+    # the packed positions are SurfaceGroup.positions
+    pos = np.asarray(be.to_numpy(lens.surfaces.positions), dtype=np.float64).reshape(-1)
+    assert np.array_equal(a.surfaces["origin"][1:, 2], pos[1:])
+    # a first-order change invalidates: radius, thickness (position), aperture value
+    lens.surfaces[2].geometry.radius = float(lens.surfaces[2].geometry.radius) * 1.01
+    c = pack_optic(lens, wavelengths=[0.55])
+    assert calls["EPL"] > n0 and c.raygen["EPL"] != a.raygen["EPL"]
+    n1 = calls["EPL"]
+    lens.set_aperture(aperture_type="EPD", value=8.0)
+    d = pack_optic(lens, wavelengths=[0.55])
+    assert calls["EPL"] > n1 and d.raygen["EPD"] == pytest.approx(8.0)
+    # against a fresh computation
+    monkeypatch.setattr(Paraxial, "EPL", orig)
+    assert d.raygen["EPL"] == pytest.approx(float(np.asarray(lens.paraxial.EPL()).reshape(-1)[0]))
