@@ -247,3 +247,46 @@ def test_zero_copy_object_row(hip, dtype):
     res = sysm.trace(row0, 0, record=rec)
     assert torch.equal(rec[0, :, :n], sentinel)
     assert torch.equal(res.record[:, :, :n], ref.record[:, :, :n])
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("case", golden_cases())
+def test_every_kernel_variant_is_bit_identical(hip, case, dtype):
+    """One source, several instantiations: one ray per lane, a 16-byte vector of rays
+    per lane, and -- fp32, conic-only, unpolarised -- packed f32x2 pairs
+    (v_pk_*_f32).  On every golden system they must agree BIT FOR BIT: record-last
+    (vector / packed by default) against the last row of record-all (one ray per
+    lane), and record-all forced onto the vector layout against the default."""
+    from optiland_amd import _capi
+    sysm, table, data = hip(case)
+    if "prt" in data:
+        pytest.skip("polarised systems run one ray per lane only for the complex PRT")
+    lib = _capi.load()
+    n = data["rays_in"].shape[1]
+    pad = (-n) % 4  # make the batch vector-eligible and keep a ragged tail elsewhere
+    def rays_padded():
+        r = _device_rays(data, dtype)
+        if pad:
+            r = [torch.cat([t, t[:pad]]).contiguous() for t in r]
+        return r
+    ref = sysm.trace(rays_padded(), 0, record=True)             # default: 1 ray / lane
+    m = n + pad
+    last = rays_padded()
+    sysm.trace(last, 0, record=False)                            # vector / packed
+    for k in range(8):
+        a, b = last[k], ref.row(ref.last, k)
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), (case, k)
+        assert torch.equal(a.nan_to_num(), b.nan_to_num()), (case, PLANES[k])
+    try:
+        assert lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, 2) == 0   # force vector
+        vec = sysm.trace(rays_padded(), 0, record=True)
+        assert lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, 1) == 0   # force scalar
+        one = rays_padded()
+        sysm.trace(one, 0, record=False)
+    finally:
+        lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, 0)
+    a, b = vec.record[:, :, :m], ref.record[:, :, :m]
+    assert torch.equal(torch.isnan(a), torch.isnan(b))
+    assert torch.equal(a.nan_to_num(), b.nan_to_num())
+    for k in range(8):
+        assert torch.equal(one[k].nan_to_num(), last[k].nan_to_num()), (case, PLANES[k])
