@@ -1008,6 +1008,21 @@ __device__ __forceinline__ void interact(const DevSurf<typename Math<V>::scalar>
     const int ck = s.coating_kind;
     const bool reflect = s.interaction == kReflect;
     const T nn = o.nn;
+    // An uncoated refracting surface between equal indices (every image plane, dummy
+    // surfaces) leaves the direction unchanged (u = 1 => k1 = k0), its Jones matrix is
+    // the identity and O_out O_in = I for ANY orthonormal basis: P' = P.  The
+    // reference still multiplies it out (and its s = k0 x k1 there is rounding noise);
+    // here the update is skipped and only the NaN state of a lost ray is carried into
+    // the matrix, as the reference's product would.
+    if (ck == kCoatNone && !reflect && o.u == T(1)) {
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const T poison = (r[k].L + r[k].M + r[k].N) * T(0);  // 0, or NaN for a lost ray
+#pragma unroll
+        for (int e = 0; e < (POLK == 2 ? 18 : 9); ++e) P[k].m[e] += poison;
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       const PolBasis<T> b = pol_basis(L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, nx[k], ny[k],
