@@ -65,11 +65,13 @@ def pol_state(polarization: dict | None) -> PolState:
 
 
 def trace(table, rays, wavelength_index=0, record=True, polarized=False,
-          first=0, last=None):
+          first=0, last=None, record_out=None):
     """Trace `rays` (dict of float64 arrays x,y,z,L,M,N,i[,opd]) through `table`.
 
     Returns dict(final rays..., record=(rows,8,n) or None, prt=(n,3,3) complex or
-    None, pre_dir=(3,n), status=int).  Inputs are not modified.
+    None, pre_dir=(3,n), status=int).  Inputs are not modified.  `record_out`: an
+    optional preallocated C-contiguous float64 (rows, 8, n) array to record into (the
+    timing harness reuses one so that it measures the trace, not page faults).
     """
     n = int(np.asarray(rays["x"]).size)
     last = table.num_surfaces - 1 if last is None else last
@@ -81,7 +83,14 @@ def trace(table, rays, wavelength_index=0, record=True, polarized=False,
             planes.append(np.ascontiguousarray(np.array(rays[k], dtype=np.float64)).copy())
     arr = (C.c_void_p * 8)(*[_ptr(p) for p in planes])
     rows = last - first + 1
-    rec = np.zeros((rows, 8, n)) if record else None
+    rec = None
+    if record:
+        if record_out is not None:
+            assert record_out.shape == (rows, 8, n) and record_out.dtype == np.float64 \
+                and record_out.flags.c_contiguous
+            rec = record_out
+        else:
+            rec = np.zeros((rows, 8, n))
     prt = None
     if polarized:
         prt = np.tile(np.eye(3, dtype=np.complex128), (n, 1, 1))

@@ -258,7 +258,7 @@ static double geom_sag(const ol_surface_desc* s, const double* coeffs, double x,
 /* ---- _surface_normal(x, y) per Newton-Raphson geometry ----------------------
  * even_asphere.py:111-140, odd_asphere.py:106-143, polynomial.py:128-155,
  * zernike.py:182-252                                                          */
-static uint32_t g_normal_status; /* chebyshev validates inside _surface_normal too */
+static __thread uint32_t g_normal_status; /* chebyshev validates inside _surface_normal too */
 
 static void geom_normal_nr(const ol_surface_desc* s, const double* coeffs, double x,
                            double y, int all_rho_zero, double* nx, double* ny,
