@@ -52,28 +52,47 @@ class SpotDiagram:
         else:
             self._run_planes()
 
-    def _chief_center(self, hx, hy):
-        r = self.tracer.trace_generic(hx, hy, 0.0, 0.0, self.wavelengths[self.ref_index])
-        return float(r.x[0]), float(r.y[0])
+    def _chief_centers(self):
+        """Chief-ray image points of ALL fields at the reference wavelength: one
+        trace_generic launch (Px = Py = 0 per field), one read-back."""
+        import torch
+        t = self.tracer
+        hx = torch.tensor([f[0] for f in self.fields], dtype=t.dtype, device=t.device)
+        hy = torch.tensor([f[1] for f in self.fields], dtype=t.dtype, device=t.device)
+        z = torch.zeros_like(hx)
+        r = t.trace_generic(hx, hy, z, z, self.wavelengths[self.ref_index])
+        xy = torch.stack([r.x, r.y]).double().cpu().numpy()
+        return [(float(xy[0, i]), float(xy[1, i])) for i in range(len(self.fields))]
 
     def _run_fused(self):
         """One `ol_trace_spot` launch per (field, wavelength): generate -> trace ->
-        reduce in a single kernel; no ray or hit planes are materialised."""
+        reduce in a single kernel; no ray or hit planes are materialised.  All launches
+        are queued back to back; the 7-double results and the status word are read
+        back once at the end."""
+        import torch
         t = self.tracer
-        centers, mom = [], []
-        for hx, hy in self.fields:
-            if self.reference == "chief_ray":
-                c = self._chief_center(hx, hy)
-            else:  # centroid of the reference wavelength: one extra reduction pass
-                m0, _ = t.trace_spot(hx, hy, self.wavelengths[self.ref_index], self.num_rings,
-                                     self.distribution)
-                m0 = m0.cpu().numpy()
-                c = (m0[1] / m0[0], m0[2] / m0[0])
-            centers.append(c)
-            row = [t.trace_spot(hx, hy, w, self.num_rings, self.distribution, center=c)[0]
-                   for w in self.wavelengths]
-            mom.append([m.cpu().numpy() for m in row])
-        self._moments, self._centers = mom, centers
+        if self.reference == "chief_ray":
+            centers = self._chief_centers()
+            t.reset_status()
+        else:
+            t.reset_status()  # centroid of the reference wavelength: one extra reduction pass per field
+            first = [t.trace_spot(hx, hy, self.wavelengths[self.ref_index], self.num_rings,
+                                  self.distribution, check_status=False)[0]
+                     for hx, hy in self.fields]
+            m0 = torch.stack(first).cpu().numpy()
+            centers = [(m[1] / m[0], m[2] / m[0]) for m in m0]
+        dev = [t.trace_spot(hx, hy, w, self.num_rings, self.distribution, center=c,
+                            check_status=False)[0]
+               for (hx, hy), c in zip(self.fields, centers) for w in self.wavelengths]
+        mom = torch.stack(dev).cpu().numpy().reshape(len(self.fields), len(self.wavelengths), 7)
+        t.check_status()
+        self._moments = [[mom[fi, wi] for wi in range(len(self.wavelengths))]
+                         for fi in range(len(self.fields))]
+        self._centers = centers
+
+    def _chief_center(self, hx, hy):
+        r = self.tracer.trace_generic(hx, hy, 0.0, 0.0, self.wavelengths[self.ref_index])
+        return float(r.x[0]), float(r.y[0])
 
     def _run_planes(self):
         """Polarised systems: trace() (with its update_intensity epilogue) into planes,

@@ -243,8 +243,21 @@ class HipRayTracer:
         return self._run(hx, hy, px, py, vig, wavelength, update_intensity=True,
                          flags=_capi.RAYGEN_CHECK_FIELD)
 
+    def reset_status(self):
+        """Clear the device status word before queueing launches with
+        check_status=False (they OR their bits in and never clear it)."""
+        st = getattr(self.engine, "_status", None)
+        if st is not None:
+            st.zero_()
+
+    def check_status(self):
+        """Read the device status word back and raise what it holds (for callers that
+        queued launches with check_status=False)."""
+        self._finish_checks(self.engine)
+
     def trace_spot(self, Hx: float, Hy: float, wavelength, num_rays=100,
-                   distribution="hexapolar", center=(0.0, 0.0), hits: bool = False):
+                   distribution="hexapolar", center=(0.0, 0.0), hits: bool = False,
+                   check_status: bool = True):
         """`trace(Hx, Hy, ...)` for ONE field point fused with the image-plane
         reduction (`ol_trace_spot`): rays are generated, traced and folded into masked
         moments about `center` in one kernel and never exist in HBM.  Returns
@@ -265,7 +278,7 @@ class HipRayTracer:
             buf = torch.empty((3, max(n, 1)), dtype=self.dtype, device=self.device)
             out3 = [buf[k, :n] for k in range(3)]
         mom = self.engine.trace_spot(px, py, wl, field=(Hx, Hy), vig=self._vig_scalar(Hx, Hy),
-                                     center=center, hits=out3)
+                                     center=center, hits=out3, check_status=check_status)
         return mom, out3
 
     def trace_generic(self, Hx, Hy, Px, Py, wavelength):
