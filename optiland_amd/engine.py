@@ -228,17 +228,23 @@ class HipSystem:
         return _capi.RaygenParams(int(rg["object_infinite"]), 0, rg["EPL"], rg["EPD"],
                                   rg["max_field"], rg["offset"], rg["z_first"])
 
-    @staticmethod
-    def _raygen_inputs(hx, hy, px, py, vx, vy, flags):
+    def _check_out_planes(self, planes, n, dtype, what):
+        for t in planes:
+            if t.device != self.device or t.dtype != dtype or t.numel() != n \
+                    or not t.is_contiguous():
+                raise ValueError(f"{what}: output planes must be contiguous, of the ray dtype, "
+                                 f"{n} long and on the system's device")
+
+    def _raygen_inputs(self, hx, hy, px, py, vx, vy, flags):
         """`ol_raygen_inputs` from tensors (per-ray planes) or floats (launch-uniform).
         Returns (struct, keep-alive list)."""
         n, dtype = int(px.numel()), px.dtype
         keep, ptr, scal = [], {}, {"hx": 0.0, "hy": 0.0, "vx": 1.0, "vy": 1.0}
         for name, v in (("hx", hx), ("hy", hy), ("px", px), ("py", py), ("vx", vx), ("vy", vy)):
             if isinstance(v, torch.Tensor):
-                if v.dtype != dtype or v.numel() != n:
+                if v.dtype != dtype or v.numel() != n or v.device != self.device:
                     raise ValueError("ray generation: coordinate planes must share dtype and "
-                                     "length")
+                                     "length and live on the system's device")
                 v = v.contiguous()
                 keep.append(v)
                 ptr[name] = v.data_ptr()
@@ -269,6 +275,7 @@ class HipSystem:
             planes = [buf[k, :n] for k in range(7)]
         else:
             planes = list(out[:8])
+            self._check_out_planes(planes, n, dtype, "generate_rays")
         if n == 0:
             return planes[:7]
         inp, keep = self._raygen_inputs(hx, hy, px, py, vx, vy, flags)
@@ -347,6 +354,7 @@ class HipSystem:
         inp, keep = self._raygen_inputs(hx, hy, px, py, vx, vy, flags)
         hp = None
         if hits is not None:
+            self._check_out_planes(hits, n, dtype, "trace_spot")
             hp = (C.c_void_p * 3)(*[h.data_ptr() for h in hits])
         if check_status:
             self._status.zero_()
