@@ -255,12 +255,18 @@ __device__ __forceinline__ void conic_normal(typename Math<V>::scalar cv,
   nx = cv * x;
   ny = cv * y;
   nz = -w;
+  const V n2 = m::fma(nx, nx, m::fma(ny, ny, w * w));
+  V h;
   if (kp1 != typename m::scalar(1)) {  // surface-uniform
-    const V h = m::rsqrt(m::fma(nx, nx, m::fma(ny, ny, w * w)));
-    nx = nx * h;
-    ny = ny * h;
-    nz = nz * h;
+    h = m::rsqrt(n2);
+  } else {
+    // sphere: |n|^2 = 1 + e with e = O(rounding of the hit point); one Newton step of
+    // 1/sqrt at 1 (1 - e/2) restores the unit length to O(e^2) without a transcendental
+    h = m::fma(m::splat(-0.5), n2, m::splat(1.5));
   }
+  nx = nx * h;
+  ny = ny * h;
+  nz = nz * h;
 }
 
 // --------------------------------------------------------------------------

@@ -24,7 +24,8 @@ for case in golden_cases():
         rays.append(torch.zeros(n, dtype=dtype, device="cuda:0"))
         prt = None
         if "prt" in data:
-            prt = torch.eye(3, dtype=dtype, device="cuda:0").reshape(9, 1).repeat(1, n).contiguous()
+            from optiland_amd.rays import new_prt
+            prt = new_prt(n, dtype, "cuda:0", table.needs_complex_prt)
         got = hip.trace(rays, 0, record=True, prt=prt).record[:, :, :n].double().cpu().numpy()
         errs = []
         for g, idx in GROUPS.items():

@@ -374,7 +374,39 @@ def wavefront_goldens():
     np.savez_compressed(os.path.join(GOLD, "wavefront.npz"), **out)
 
 
+def sample_goldens():
+    """EVERY lens of optiland.samples (29 systems, 3 to 43 surfaces: photographic
+    objectives, microscopes, eyepieces, IR triplets, wide-angle projection lenses,
+    telescopes, an eye model, a UV lithography lens): 3 field points x 2 hexapolar
+    rings at the primary wavelength through the reference's ray generator and
+    SurfaceGroup.trace.  Small on purpose -- breadth over real prescriptions (glass
+    catalogue indices, stops in odd places, steep fields), not ray count."""
+    import importlib
+    import inspect
+    from optiland.distribution import create_distribution
+    dist = create_distribution("hexapolar")
+    dist.generate_points(2)
+    px1, py1 = np.asarray(dist.x, dtype=float) * 0.95, np.asarray(dist.y, dtype=float) * 0.95
+    n_ok = 0
+    for m in ("eyepieces", "infrared", "lithography", "microscopes", "miscellaneous",
+              "objectives", "simple", "telescopes"):
+        mod = importlib.import_module("optiland.samples." + m)
+        for cname, cls in inspect.getmembers(mod, inspect.isclass):
+            if cls.__module__ != mod.__name__ or not issubclass(cls, optic_mod.Optic):
+                continue
+            lens = cls()
+            hy = np.repeat([0.0, 0.7, 1.0], px1.size)
+            hx = np.zeros_like(hy)
+            w = float(np.asarray(lens.primary_wavelength).reshape(-1)[0])
+            run_case(f"sample_{cname}", lens, hx, hy, np.tile(px1, 3), np.tile(py1, 3), w)
+            n_ok += 1
+    print(f"{n_ok} sample systems")
+
+
 def main():
+    if "--samples-only" in sys.argv:
+        sample_goldens()
+        return
     os.makedirs(GOLD, exist_ok=True)
     os.makedirs(DATA, exist_ok=True)
 
@@ -429,6 +461,7 @@ def main():
     px8, py8 = disc_points(800, 11)
     run_case("vignetted_generic", vignetted_cooke(), hx, hy, px8, py8, 0.55)
     wavefront_goldens()
+    sample_goldens()
 
 
 if __name__ == "__main__":
