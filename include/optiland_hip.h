@@ -239,17 +239,25 @@ int ol_trace(const ol_system* sys, ol_dtype dt, int64_t n_rays,
              int32_t first_surface, int32_t last_surface, uint32_t flags,
              uint32_t* status, void* stream);
 
-/* Generate rays on device from normalised field/pupil coordinates for the case
- * every config uses: angle field, object at infinity or finite, paraxial aiming
- * (rays/ray_generator.py:47-99, rays/ray_aiming/paraxial.py:33-106,
- * fields/field_types/angle.py:17-58).  See ol_raygen_params.               */
+/* Generate rays on device from normalised field/pupil coordinates: angle fields
+ * (object at infinity or finite, fields/field_types/angle.py:17-58) and object-height
+ * fields on a planar object (fields/field_types/object_height.py:19-47), paraxial
+ * aiming incl. the object-space-telecentric branch (rays/ray_generator.py:47-99,
+ * rays/ray_aiming/paraxial.py:33-106).  See ol_raygen_params.                   */
+#define OL_FIELD_ANGLE 0
+#define OL_FIELD_OBJECT_HEIGHT 1
 typedef struct ol_raygen_params {
   int32_t object_infinite; /* obj.is_infinite                                 */
-  int32_t reserved_;
+  int32_t field_kind;      /* OL_FIELD_ANGLE | OL_FIELD_OBJECT_HEIGHT          */
   double EPL, EPD;         /* paraxial entrance pupil location / diameter     */
-  double max_field;        /* degrees                                          */
+  double max_field;        /* degrees (angle) or lens units (object height)    */
   double offset;           /* AngleField._get_starting_z_offset               */
   double z_first;          /* surfaces.positions[1] (infinite) or [0] (finite)*/
+  double tele_dz;          /* 0: aim at the paraxial entrance pupil
+                              (ray_aiming/paraxial.py:88-94); > 0: object-space
+                              telecentric, sqrt(1 - sin^2)/sin of the object NA
+                              (:82-87): the target plane sits tele_dz behind the
+                              object point and the pupil offsets are ABSOLUTE     */
 } ol_raygen_params;
 
 /* Normalised coordinates of one ray block.  Each of the pairs (hx,hy) and (vx,vy)

@@ -48,12 +48,13 @@ class SurfaceOptics(C.Structure):
 class RaygenParams(C.Structure):
     _fields_ = [
         ("object_infinite", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("field_kind", C.c_int32),
         ("EPL", C.c_double),
         ("EPD", C.c_double),
         ("max_field", C.c_double),
         ("offset", C.c_double),
         ("z_first", C.c_double),
+        ("tele_dz", C.c_double),
     ]
 
 

@@ -297,7 +297,8 @@ int convert_inputs(const char* who, const ol_raygen_inputs* in, uint32_t* status
 }
 
 ol::RaygenDev raygen_dev(const ol_raygen_params* g) {
-  return ol::RaygenDev{g->object_infinite, g->EPL, g->EPD, g->max_field, g->offset, g->z_first};
+  return ol::RaygenDev{g->object_infinite, g->field_kind, g->EPL,     g->EPD,
+                       g->max_field,       g->offset,     g->z_first, g->tele_dz};
 }
 
 template <typename T>

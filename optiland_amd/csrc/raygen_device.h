@@ -26,19 +26,26 @@ __device__ __forceinline__ double tan_deg<double>(double deg) {
 // launch-invariant scalars, converted to the working precision once
 template <typename T>
 struct RaygenConsts {
-  T EPL, EPD, maxf, off_epl, z_inf, z_fin, epl_z;
-  bool infinite;
+  T EPL, EPD, maxf, off_epl, z_inf, z_fin, epl_z, tele_dz;
+  bool infinite, height, telecentric;
   __device__ __forceinline__ explicit RaygenConsts(const RaygenDev& p)
       : EPL((T)p.EPL), EPD((T)p.EPD), maxf((T)p.max_field), off_epl((T)(p.offset + p.EPL)),
         z_inf((T)(p.z_first - p.offset)), z_fin((T)p.z_first), epl_z((T)(p.EPL - p.z_first)),
-        infinite(p.object_infinite != 0) {}
+        tele_dz((T)p.tele_dz), infinite(p.object_infinite != 0), height(p.field_kind == 1),
+        telecentric(p.tele_dz > 0.0) {}
 };
 
-// field tangents (angle.py:40-47); hoistable when the field is launch-uniform
+// field quantity per axis: tan(field angle) (angle.py:40-47) or the object height
+// (object_height.py:38-41); hoistable when the field is launch-uniform
 template <typename T>
 __device__ __forceinline__ void raygen_field(const RaygenConsts<T>& c, T hx, T hy, T& tx, T& ty) {
-  tx = tan_deg<T>(c.maxf * hx);
-  ty = tan_deg<T>(c.maxf * hy);
+  if (c.height) {
+    tx = c.maxf * hx;
+    ty = c.maxf * hy;
+  } else {
+    tx = tan_deg<T>(c.maxf * hx);
+    ty = tan_deg<T>(c.maxf * hy);
+  }
 }
 
 // range checks (real_ray_tracer.py:156-173: all((v >= -1) & (v <= 1)); NaN fails) and
@@ -62,7 +69,11 @@ template <typename T>
 __device__ __forceinline__ void raygen_one(const RaygenConsts<T>& c, T tx, T ty, T px, T py, T vx,
                                            T vy, T (&o)[6]) {
   T x0, y0, z0;
-  if (c.infinite) {
+  if (c.height) {  // object_height.py:36-47 (planar object surface)
+    x0 = tx;
+    y0 = ty;
+    z0 = c.z_fin;
+  } else if (c.infinite) {
     x0 = px * c.EPD / T(2) * vx + (-tx * c.off_epl);
     y0 = py * c.EPD / T(2) * vy + (-ty * c.off_epl);
     z0 = c.z_inf;
@@ -71,7 +82,16 @@ __device__ __forceinline__ void raygen_one(const RaygenConsts<T>& c, T tx, T ty,
     y0 = -ty * c.epl_z;
     z0 = c.z_fin;
   }
-  const T x1 = px * c.EPD * vx / T(2), y1 = py * c.EPD * vy / T(2), z1 = c.EPL;
+  T x1, y1, z1;
+  if (c.telecentric) {  // ray_aiming/paraxial.py:82-87
+    x1 = px * vx + x0;
+    y1 = py * vy + y0;
+    z1 = c.tele_dz + z0;
+  } else {              // :88-94
+    x1 = px * c.EPD * vx / T(2);
+    y1 = py * c.EPD * vy / T(2);
+    z1 = c.EPL;
+  }
   const T dx = x1 - x0, dy = y1 - y0, dz = z1 - z0;
   T mag = sqrt(dx * dx + dy * dy + dz * dz);
   const bool is_zero = mag < T(1e-9);  // paraxial.py:96-104

@@ -49,7 +49,8 @@ Tuning& tuning();
 // ray generation / epilogue / reductions (aux_kernels.hip)
 struct RaygenDev {
   int32_t object_infinite;
-  double EPL, EPD, max_field, offset, z_first;
+  int32_t field_kind;  // 0 angle, 1 object height
+  double EPL, EPD, max_field, offset, z_first, tele_dz;
 };
 
 constexpr uint32_t kRaygenCheckField = 0x1u;    // OL_RAYGEN_CHECK_FIELD
@@ -65,18 +66,24 @@ struct RaygenIn {
   const T *px, *py;  // per-ray pupil
   const T *vx, *vy;  // per-ray 1 - vignetting or nullptr -> vx0, vy0
   T hx0, hy0, vx0, vy0;
-  T tx0, ty0;        // tan(field angle) of the launch-uniform field, formed on the host
+  T tx0, ty0;        // tan(field angle) / object height of the launch-uniform field (host)
   uint32_t flags;
 };
 
-// tangents of a launch-uniform field: same expression as raygen_field() / tan_deg()
-// on the device (product in T, tangent in double) -- evaluated per lane the
-// double-precision tan() cost ~15 % of the fused spot kernel.
+// field quantity of a launch-uniform field (tan of the field angle, or the object
+// height): same expression as raygen_field() / tan_deg() on the device (product in
+// T, tangent in double) -- evaluated per lane the double-precision tan() cost ~15 %
+// of the fused spot kernel.
 template <typename T>
 inline void uniform_field_tangents(const RaygenDev& rg, RaygenIn<T>& in) {
   const T maxf = (T)rg.max_field;
-  in.tx0 = (T)tan((double)(maxf * in.hx0) * 0.017453292519943295);
-  in.ty0 = (T)tan((double)(maxf * in.hy0) * 0.017453292519943295);
+  if (rg.field_kind == 1) {
+    in.tx0 = maxf * in.hx0;
+    in.ty0 = maxf * in.hy0;
+  } else {
+    in.tx0 = (T)tan((double)(maxf * in.hx0) * 0.017453292519943295);
+    in.ty0 = (T)tan((double)(maxf * in.hy0) * 0.017453292519943295);
+  }
 }
 
 template <typename T>

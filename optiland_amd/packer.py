@@ -381,23 +381,39 @@ def _pack_raygen(optic, table: SystemTable) -> None:
 def _compute_raygen(optic, table: SystemTable) -> None:
     """Scalars for on-device ray generation.
 
-    Only the case every config uses is packed: AngleField, paraxial aiming, not
-    object-space telecentric, no apodization (rays/ray_aiming/paraxial.py:33-106,
-    fields/field_types/angle.py:17-58).  Otherwise `table.raygen` stays empty and
-    callers generate rays with the reference's own RayGenerator.
+    Packed: paraxial aiming without apodization for AngleField (object at infinity or
+    finite, fields/field_types/angle.py:17-58) and ObjectHeightField on a planar object
+    (object_height.py:19-47), incl. the object-space-telecentric branch of the aimer
+    (rays/ray_aiming/paraxial.py:33-106).  Otherwise (iterative / robust aiming, image
+    height fields, apodization) `table.raygen` stays empty and callers generate rays
+    with the reference's own RayGenerator.
     """
     fd = optic.fields.field_definition
-    if type(fd).__name__ != "AngleField":
-        return
-    if optic.obj_space_telecentric or optic.apodization is not None:
+    kind = {"AngleField": S.FIELD_ANGLE, "ObjectHeightField": S.FIELD_OBJECT_HEIGHT}.get(
+        type(fd).__name__)
+    if kind is None or optic.apodization is not None:
         return
     mode = getattr(optic.ray_tracer, "ray_aiming_config", {}).get("mode", "paraxial")
     if mode != "paraxial":
         return
     obj = optic.object_surface
+    infinite = bool(obj.is_infinite)
+    if kind == S.FIELD_OBJECT_HEIGHT:
+        # object_height.py:36-47: z0 = obj.geometry.sag(x0, y0) + obj z -- planar objects only
+        if infinite or table.surfaces[0]["geom_kind"] != S.GEOM_PLANE:
+            return
+    tele_dz = 0.0
+    if optic.obj_space_telecentric:
+        # ray_aiming/paraxial.py:82-87, 108-123: object-height fields with an
+        # object-NA aperture only; z1 - z0 = sqrt(1 - sin^2) / sin
+        if kind != S.FIELD_OBJECT_HEIGHT or type(optic.aperture).__name__ != "ObjectNAAperture":
+            return
+        sin = _f(optic.aperture.value)
+        if not 0.0 < sin < 1.0:
+            return
+        tele_dz = math.sqrt(1.0 - sin * sin) / sin
     EPL = _f(optic.paraxial.EPL())
     EPD = _f(optic.paraxial.EPD())
-    infinite = bool(obj.is_infinite)
     # SurfaceGroup.positions (surface_group.py:155-161) = z of every vertex in the
     # global frame = the origins already folded by cs_to_affine
     pos = np.asarray(table.surfaces["origin"][:, 2], dtype=np.float64).reshape(-1)
@@ -409,11 +425,13 @@ def _compute_raygen(optic, table: SystemTable) -> None:
         z_first = float(pos[0])
     table.raygen = {
         "object_infinite": 1.0 if infinite else 0.0,
+        "field_kind": float(kind),
         "EPL": EPL,
         "EPD": EPD,
         "max_field": _f(optic.fields.max_field),
         "offset": offset,
         "z_first": z_first,
+        "tele_dz": tele_dz,
     }
     table.fields = [
         (_f(f.x), _f(f.y), _f(f.vx), _f(f.vy)) for f in optic.fields.fields

@@ -34,6 +34,7 @@ SURF_ROTATED = 0x1
 STATUS_ZERNIKE_RANGE = 0x1
 STATUS_K_PARALLEL_X = 0x2
 STATUS_CHEBYSHEV_RANGE = 0x4
+FIELD_ANGLE, FIELD_OBJECT_HEIGHT = 0, 1
 STATUS_FIELD_RANGE = 0x8
 STATUS_PUPIL_RANGE = 0x10
 
@@ -86,12 +87,13 @@ SURFACE_OPTICS_DTYPE = np.dtype(
 RAYGEN_DTYPE = np.dtype(
     [
         ("object_infinite", np.int32),
-        ("reserved_", np.int32),
+        ("field_kind", np.int32),
         ("EPL", np.float64),
         ("EPD", np.float64),
         ("max_field", np.float64),
         ("offset", np.float64),
         ("z_first", np.float64),
+        ("tele_dz", np.float64),
     ],
     align=True,
 )

@@ -747,7 +747,8 @@ uint32_t oracle_trace(const ol_surface_desc* surf, int32_t n_surf,
 }
 
 /* rays/ray_generator.py:47-99 + rays/ray_aiming/paraxial.py:33-106 +
- * fields/field_types/angle.py:17-58.  out[7] = x,y,z,L,M,N,i.                */
+ * fields/field_types/angle.py:17-58 + fields/field_types/object_height.py:19-47
+ * (planar object).  out[7] = x,y,z,L,M,N,i.                                      */
 void oracle_generate_rays(const ol_raygen_params* p, int64_t n, const double* hx,
                           const double* hy, const double* px, const double* py,
                           const double* vx, const double* vy, double* const out[7]) {
@@ -756,7 +757,13 @@ void oracle_generate_rays(const ol_raygen_params* p, int64_t n, const double* hx
     double vxx = vx ? vx[j] : 1.0, vyy = vy ? vy[j] : 1.0;
     double field_x = p->max_field * hx[j], field_y = p->max_field * hy[j];
     double x0, y0, z0;
-    if (p->object_infinite) {
+    if (p->field_kind == OL_FIELD_OBJECT_HEIGHT) {
+      /* object_height.py:36-47: x0 = field_x, y0 = field_y, z0 = sag(x0,y0) + obj z
+       * (sag = 0: only planar object surfaces are packed)                         */
+      x0 = field_x;
+      y0 = field_y;
+      z0 = p->z_first;
+    } else if (p->object_infinite) {
       double x = -tan(field_x * d2r) * (p->offset + p->EPL);
       double y = -tan(field_y * d2r) * (p->offset + p->EPL);
       z0 = p->z_first - p->offset;
@@ -767,9 +774,16 @@ void oracle_generate_rays(const ol_raygen_params* p, int64_t n, const double* hx
       x0 = -tan(field_x * d2r) * (p->EPL - z0);
       y0 = -tan(field_y * d2r) * (p->EPL - z0);
     }
-    double x1 = px[j] * p->EPD * vxx / 2;
-    double y1 = py[j] * p->EPD * vyy / 2;
-    double z1 = p->EPL;
+    double x1, y1, z1;
+    if (p->tele_dz > 0.0) { /* paraxial.py:82-87: object-space telecentric */
+      z1 = p->tele_dz + z0;
+      x1 = px[j] * vxx + x0;
+      y1 = py[j] * vyy + y0;
+    } else { /* :88-94 */
+      x1 = px[j] * p->EPD * vxx / 2;
+      y1 = py[j] * p->EPD * vyy / 2;
+      z1 = p->EPL;
+    }
     double mag = sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0) + (z1 - z0) * (z1 - z0));
     int is_zero = mag < 1e-9;
     if (is_zero) mag = 1.0;

@@ -244,6 +244,46 @@ def vignetted_cooke():
     return lens
 
 
+def finite_conjugate(field_type="object_height", telecentric=False):
+    """Cooke triplet used at finite conjugates (object 150 mm in front): object-height
+    fields on a planar object (fields/field_types/object_height.py), optionally
+    object-space telecentric with an object-NA aperture (ray_aiming/paraxial.py:82-87);
+    the same layout with angle fields covers AngleField's finite-object branch
+    (angle.py:48-58).  Vignetting on the outer field exercises the (1 - v) factors of
+    both aiming branches."""
+    lens = optic_mod.Optic(name=f"FiniteCooke_{field_type}{'_tele' if telecentric else ''}")
+    lens.surfaces.add(index=0, radius=be.inf, thickness=150.0)
+    lens.surfaces.add(index=1, radius=22.01359, thickness=3.25896, material="SK16")
+    lens.surfaces.add(index=2, radius=-435.76044, thickness=6.00755)
+    lens.surfaces.add(index=3, radius=-22.21328, thickness=0.99997, material=("F2", "schott"))
+    lens.surfaces.add(index=4, radius=20.29192, thickness=4.75041, is_stop=True)
+    lens.surfaces.add(index=5, radius=79.68360, thickness=2.95208, material="SK16")
+    lens.surfaces.add(index=6, radius=-18.39533, thickness=62.0)
+    lens.surfaces.add(index=7)
+    if telecentric:
+        lens.set_aperture(aperture_type="objectNA", value=0.03)
+        lens.obj_space_telecentric = True
+    else:
+        lens.set_aperture(aperture_type="EPD", value=8)
+    lens.fields.set_type(field_type=field_type)
+    if field_type == "angle":
+        lens.fields.add(y=0)
+        lens.fields.add(y=4, vx=0.05, vy=0.1)
+        lens.fields.add(y=6, x=2)
+    elif telecentric:
+        # chief rays leave parallel to the axis: keep the object small enough that the
+        # bundle still clears the (non-telecentric) triplet without grazing its rims
+        lens.fields.add(y=0)
+        lens.fields.add(y=2, vx=0.05, vy=0.1)
+        lens.fields.add(y=3, x=1)
+    else:
+        lens.fields.add(y=0)
+        lens.fields.add(y=10, vx=0.05, vy=0.1)
+        lens.fields.add(y=15, x=5)
+    lens.wavelengths.add(value=0.55, is_primary=True)
+    return lens
+
+
 def tir_prism():
     """Edge case: steep glass->air exit so part of the bundle is totally internally
     reflected (NaN directions, real_rays.py:179-180) and part misses a small
@@ -460,6 +500,20 @@ def main():
     hy = np.repeat([0.1, 0.6, 1.0, 0.9], 200)
     px8, py8 = disc_points(800, 11)
     run_case("vignetted_generic", vignetted_cooke(), hx, hy, px8, py8, 0.55)
+    # finite conjugates: object-height fields (plain and telecentric), finite angle field
+    hx = np.repeat([0.0, 0.1, 1 / 3, -0.2], 150)
+    hy = np.repeat([0.0, 0.6, 1.0, 0.9], 150)
+    px6, py6 = disc_points(600, 13)
+    for nm, lens in (("finite_object_height", finite_conjugate("object_height")),
+                     ("finite_object_height_telecentric", finite_conjugate("object_height", True)),
+                     ("finite_angle", finite_conjugate("angle"))):
+        run_case(nm + "_generic", lens, hx, hy, px6, py6, 0.55)
+    run_case("finite_object_height_trace", finite_conjugate("object_height"),
+             [0.0, 0.0, 1 / 3], [0.0, 0.7, 1.0], None, None, 0.55,
+             use_trace=dict(num_rays=4, distribution="hexapolar"))
+    run_case("finite_telecentric_trace", finite_conjugate("object_height", True),
+             [0.0, 0.0, 1 / 3], [0.0, 0.7, 1.0], None, None, 0.55,
+             use_trace=dict(num_rays=4, distribution="hexapolar"))
     wavefront_goldens()
     sample_goldens()
 
