@@ -262,7 +262,10 @@ __device__ __forceinline__ void conic_normal(typename Math<V>::scalar cv,
   } else {
     // sphere: |n|^2 = 1 + e with e = O(rounding of the hit point); one Newton step of
     // 1/sqrt at 1 (1 - e/2) restores the unit length to O(e^2) without a transcendental
-    h = m::fma(m::splat(-0.5), n2, m::splat(1.5));
+#ifndef OL_SPHERE_RENORM
+#define OL_SPHERE_RENORM 1
+#endif
+    h = OL_SPHERE_RENORM ? m::fma(m::splat(-0.5), n2, m::splat(1.5)) : m::splat(1);
   }
   nx = nx * h;
   ny = ny * h;
