@@ -238,7 +238,14 @@ def main():
         gather_buf = [torch.empty((world, 3, n), dtype=dtype, device=device) for _ in range(2)]
         hits = [torch.empty((3, n), dtype=dtype, device=device) for _ in range(2)]
     if exchange == "reduce":
-        moms = [torch.zeros(6, dtype=torch.float64, device=device) for _ in range(2)]
+        # spot moments come out of the trace launch itself (epilogue of the same kernel,
+        # ol_trace_ex): slotted partial sums -> 7 doubles -> one small all-reduce
+        # Per step: zero 4 KB, trace (+ epilogue), ONE async all-gather of the 4 KB slot
+        # block; the slots of all ranks are folded (sum / max) only when the statistics
+        # are read -- no per-step reduction launches on the critical stream.
+        slots = [hip.alloc_spot_slots() for _ in range(2)]
+        all_slots = [torch.zeros((world,) + tuple(slots[0].shape), dtype=torch.float64,
+                                 device=device) for _ in range(2)]
     step_no = [0]
 
     def spot_step(ev0=None, ev1=None):
@@ -270,27 +277,31 @@ def main():
             for d, s_ in zip(scratch, rays):
                 d.copy_(s_)
             src = scratch
+        k = step_no[0] & 1
+        step_no[0] += 1
+        if exchange != "none" and pending[k] is not None:
+            for w in (pending[k] if isinstance(pending[k], tuple) else (pending[k],)):
+                w.wait()  # stream-level wait: this buffer pair is free again
+            pending[k] = None
+        spot_arg = None
+        if exchange == "reduce":
+            slots[k].zero_()
+            spot_arg = (slots[k], 0.0, 0.0)
         if ev0 is not None:
             ev0.record()
         res = hip.trace(src, wl, record=record if record is not None else False, prt=prt,
-                        check_status=False, prt_identity=pol)
+                        check_status=False, prt_identity=pol, spot=spot_arg)
         if ev1 is not None:
             ev1.record()
         if exchange != "none":
-            if args.mode == "record":
-                x, y, inten = res.row(res.last, 0), res.row(res.last, 1), res.row(res.last, 6)
-            else:
-                x, y, inten = src[0], src[1], src[6]
-            k = step_no[0] & 1
-            step_no[0] += 1
-            if pending[k] is not None:
-                pending[k].wait()  # stream-level wait: this buffer pair is free again
             if exchange == "reduce":
-                # per-rank masked moments (6 doubles) -> one small all-reduce, issued
-                # asynchronously so that its latency overlaps the next step's trace
-                hip.spot_moments(x, y, inten, out=moms[k])
-                pending[k] = dist.all_reduce(moms[k], async_op=True)
+                pending[k] = dist.all_gather_into_tensor(all_slots[k].view(-1),
+                                                         slots[k].view(-1), async_op=True)
             else:
+                if args.mode == "record":
+                    x, y, inten = res.row(res.last, 0), res.row(res.last, 1), res.row(res.last, 6)
+                else:
+                    x, y, inten = src[0], src[1], src[6]
                 hits[k][0].copy_(x)
                 hits[k][1].copy_(y)
                 hits[k][2].copy_(inten)
@@ -318,6 +329,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    if exchange == "reduce" and not spot and args.steps:
+        # fold the gathered slots of the last step: whole-job spot statistics
+        tot = hip.reduce_spot_slots(all_slots[(step_no[0] - 1) & 1].view(-1, 8)).cpu().numpy()
+        assert tot[0] > 0, "no ray reached the image plane"
     if have_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -239,6 +239,25 @@ int ol_trace(const ol_system* sys, ol_dtype dt, int64_t n_rays,
              int32_t first_surface, int32_t last_surface, uint32_t flags,
              uint32_t* status, void* stream);
 
+/* ol_trace with optional extras.  `spot_slots` (nullable): the launch also reduces the
+ * FINAL ray state (global frame, last traced surface) to the masked spot moments of
+ * ol_trace_spot about (cx, cy), as an epilogue of the same kernel -- no second pass
+ * over the image-plane planes.  Layout: OL_SPOT_SLOTS x 8 device doubles, ACCUMULATED
+ * (zero them first); workgroups spread their atomics over the slots, the consumer
+ * adds slots up: elements 0..5 = {count, sum dx, sum dy, sum dx^2, sum dy^2, sum i}
+ * (sum over slots), element 6 = max r^2 (max over slots), element 7 unused.      */
+#define OL_SPOT_SLOTS 64
+typedef struct ol_trace_extras {
+  double* spot_slots;
+  double cx, cy;
+} ol_trace_extras;
+
+int ol_trace_ex(const ol_system* sys, ol_dtype dt, int64_t n_rays,
+                void* const rays[8], int32_t wavelength_index,
+                void* record, int64_t record_stride, void* prt,
+                int32_t first_surface, int32_t last_surface, uint32_t flags,
+                uint32_t* status, const ol_trace_extras* extras, void* stream);
+
 /* Generate rays on device from normalised field/pupil coordinates: angle fields
  * (object at infinity or finite, fields/field_types/angle.py:17-58) and object-height
  * fields on a planar object (fields/field_types/object_height.py:19-47), paraxial

@@ -67,6 +67,13 @@ class RaygenInputs(C.Structure):
 RAYGEN_CHECK_FIELD, RAYGEN_CHECK_PUPIL, RAYGEN_PRESCALE_PUPIL = 0x1, 0x2, 0x4
 
 
+class TraceExtras(C.Structure):
+    _fields_ = [("spot_slots", C.c_void_p), ("cx", C.c_double), ("cy", C.c_double)]
+
+
+SPOT_SLOTS = 64
+
+
 class WavefrontParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("xc", "yc", "zc", "R", "n_image", "opd_ref", "ux",
                                           "uy", "half_epd", "wavelength_um")]
@@ -97,6 +104,7 @@ EXPORTS = (
     "ol_set_tuning",
     "ol_wavefront_opd",
     "ol_trace_spot",
+    "ol_trace_ex",
 )
 
 F32, F64 = 0, 1
@@ -138,6 +146,9 @@ def load():
     lib.ol_trace.restype = C.c_int
     lib.ol_trace.argtypes = [vp, C.c_int, i64, C.POINTER(vp), i32, vp, i64, vp, i32, i32, u32,
                              vp, vp]
+    lib.ol_trace_ex.restype = C.c_int
+    lib.ol_trace_ex.argtypes = [vp, C.c_int, i64, C.POINTER(vp), i32, vp, i64, vp, i32, i32, u32,
+                                vp, vp, vp]
     lib.ol_generate_rays.restype = C.c_int
     lib.ol_generate_rays.argtypes = [vp, C.c_int, i64, vp, C.POINTER(vp), vp, vp]
     lib.ol_polarized_intensity.restype = C.c_int

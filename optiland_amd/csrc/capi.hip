@@ -222,8 +222,13 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 template <typename T>
 int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* const rays[8],
              int32_t wl, void* record, int64_t record_stride, void* prt, int32_t first,
-             int32_t last, uint32_t flags, uint32_t* status, hipStream_t stream) {
+             int32_t last, uint32_t flags, uint32_t* status, const ol_trace_extras* extras,
+             hipStream_t stream) {
   ol::TraceArgs<T> a;
+  a.spot = extras ? extras->spot_slots : nullptr;
+  a.cx = extras ? extras->cx : 0.0;
+  a.cy = extras ? extras->cy : 0.0;
+  a.spot_slots = OL_SPOT_SLOTS;
   a.surf = tab.surf;
   a.cold = tab.cold;
   a.optics = tab.optics;
@@ -579,6 +584,14 @@ int ol_trace(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const rays
              int32_t wavelength_index, void* record, int64_t record_stride, void* prt,
              int32_t first_surface, int32_t last_surface, uint32_t flags, uint32_t* status,
              void* stream) {
+  return ol_trace_ex(sys, dt, n_rays, rays, wavelength_index, record, record_stride, prt,
+                     first_surface, last_surface, flags, status, nullptr, stream);
+}
+
+int ol_trace_ex(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const rays[8],
+                int32_t wavelength_index, void* record, int64_t record_stride, void* prt,
+                int32_t first_surface, int32_t last_surface, uint32_t flags, uint32_t* status,
+                const ol_trace_extras* extras, void* stream) {
   if (!sys) return fail(OL_EINVAL, "ol_trace: system is NULL");
   if (dt != OL_F32 && dt != OL_F64) return fail(OL_EINVAL, "ol_trace: bad dtype %d", (int)dt);
   if (n_rays < 0) return fail(OL_EINVAL, "ol_trace: negative ray count");
@@ -601,8 +614,11 @@ int ol_trace(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const rays
   if (record && record_stride < n_rays)
     return fail(OL_EINVAL, "ol_trace: record_stride %lld < n_rays %lld", (long long)record_stride,
                 (long long)n_rays);
-  if (!record && !(flags & OL_TRACE_WRITE_RAYS) && !prt)
+  if (!record && !(flags & OL_TRACE_WRITE_RAYS) && !prt && !(extras && extras->spot_slots))
     return fail(OL_EINVAL, "ol_trace: nothing to write (no record, no OL_TRACE_WRITE_RAYS)");
+  if (prt && extras && extras->spot_slots)
+    return fail(OL_EINVAL, "ol_trace_ex: the spot epilogue is for unpolarised traces (the "
+                           "polarised intensity needs ol_polarized_intensity first)");
   if (!prt) {
     // rays/ray_generator.py:89-94: polarization-dependent coatings need polarized rays
     for (int32_t s = first_surface; s <= last_surface; ++s)
@@ -620,9 +636,9 @@ int ol_trace(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const rays
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dt == OL_F32)
     return do_trace<float>(sys, sys->f32, n_rays, rays, wavelength_index, record, record_stride,
-                           prt, first_surface, last_surface, flags, status, st);
+                           prt, first_surface, last_surface, flags, status, extras, st);
   return do_trace<double>(sys, sys->f64, n_rays, rays, wavelength_index, record, record_stride,
-                          prt, first_surface, last_surface, flags, status, st);
+                          prt, first_surface, last_surface, flags, status, extras, st);
 }
 
 int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n,

@@ -1324,6 +1324,88 @@ __device__ __forceinline__ void store_rays(T* __restrict__ row, int64_t stride, 
 }
 
 // --------------------------------------------------------------------------
+// image-plane spot moments (analysis/spot_diagram/core.py:329-372, mask :470-476):
+// shared by the fused spot kernel and the optional epilogue of trace_kernel
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double spot_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double spot_wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+struct SpotAcc {
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  double rmax = 0.0;
+  template <typename T>
+  __device__ __forceinline__ void add(T x, T y, T i, double cx, double cy) {
+    if (i > T(0)) {
+      const double dx = (double)x - cx, dy = (double)y - cy;
+      const double dx2 = dx * dx, dy2 = dy * dy;
+      s[0] += 1.0;
+      s[1] += dx;
+      s[2] += dy;
+      s[3] += dx2;
+      s[4] += dy2;
+      s[5] += (double)i;
+      const double r2 = dx2 + dy2;
+      rmax = r2 > rmax ? r2 : rmax;  // NaN hits compare false and are skipped
+    }
+  }
+  // workgroup reduction -> 7 atomics into out[0..6]; EVERY thread of the workgroup
+  // must call it (barrier inside)
+  __device__ __forceinline__ void flush(double* __restrict__ out) {
+    __shared__ double part[kTraceBlock / 64][7];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave reduction, STEP-major: the seven values move together, so each of the six
+    // steps has 14 independent ds_bpermute in flight and one wait -- chain-major (one
+    // value after the other) was 42 serialised LDS-crossbar round trips per wave and
+    // cost the record-all kernel 20 % when this ran as its epilogue
+    double v[7] = {s[0], s[1], s[2], s[3], s[4], s[5], rmax};
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      double o[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) o[k] = __shfl_down(v[k], off, 64);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v[k] += o[k];
+      v[6] = o[6] > v[6] ? o[6] : v[6];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) part[wave][k] = v[k];
+    }
+    // Workgroup barrier that orders LDS only.  __syncthreads() is a release/acquire
+    // fence over ALL address spaces: in the epilogue of the record-all kernel it made
+    // every wave drain its ~100 outstanding record stores (s_waitcnt vmcnt(0)) before
+    // the barrier instead of retiring with them in flight -- 0.78 -> 0.94 ms.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    if (threadIdx.x < 6) {
+      double v = 0;
+      for (int w = 0; w < kTraceBlock / 64; ++w) v += part[w][threadIdx.x];
+      // hardware fp64 atomic add (the output lives in ordinary coarse-grained HBM)
+      if (v != 0.0) unsafeAtomicAdd(&out[threadIdx.x], v);
+    } else if (threadIdx.x == 6) {
+      double v = part[0][6];
+      for (int w = 1; w < kTraceBlock / 64; ++w) v = part[w][6] > v ? part[w][6] : v;
+      // non-negative doubles order like their bit patterns
+      if (v > 0.0)
+        atomicMax(reinterpret_cast<unsigned long long*>(&out[6]),
+                  (unsigned long long)__double_as_longlong(v));
+    }
+  }
+};
+
+// --------------------------------------------------------------------------
 // the kernel
 // --------------------------------------------------------------------------
 // The three table pointers are separate `const __restrict__` kernel arguments on
@@ -1333,7 +1415,7 @@ __device__ __forceinline__ void store_rays(T* __restrict__ row, int64_t stride, 
 // v_readfirstlane, and -- vmcnt being in-order on gfx9-family parts -- every
 // surface's table read then waited for ALL outstanding record stores to retire,
 // serialising compute behind HBM writes (measured: 1.00 ms -> see DESIGN.md).
-template <typename T, int RPT, bool RECORD, int POLK, int NR>
+template <typename T, int RPT, bool RECORD, int POLK, int NR, bool SPOT>
 __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
     const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
@@ -1360,10 +1442,22 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
     __syncthreads();
   }
 #endif
-  const int64_t base = ((int64_t)blockIdx.x * kTraceBlock + threadIdx.x) * RPT;
-  if (base >= a.n) return;
+  // Lanes past the end leave at once.  With the spot epilogue (SPOT: a workgroup
+  // reduction with a barrier) they have to stay: one-ray lanes then re-trace the LAST
+  // ray (identical values to identical addresses, no predicate anywhere in the hot
+  // loop -- a per-lane "live" guard around the stores cost 20 %), vector lanes take
+  // the ragged-tail path with zero rays; either way they are masked out of the sums.
+  int64_t base = ((int64_t)blockIdx.x * kTraceBlock + threadIdx.x) * RPT;
+  const bool live = base < a.n;
+  if constexpr (!SPOT) {
+    if (!live) return;
+  } else if (RPT == 1 && !live) {
+    base = a.n - 1;
+  }
   const int64_t left = a.n - base;
-  const int cnt = left >= RPT ? RPT : (int)left;
+  // (one ray per lane: always exactly one ray -- said outright, so that the SPOT
+  // variant's loads and stores stay as unpredicated as the plain kernel's)
+  const int cnt = RPT == 1 ? 1 : (left >= RPT ? RPT : (left > 0 ? (int)left : 0));
 
   using LP = LanePack<T, RPT, POLK, NR>;  // fp32 lean kernel: packed pairs of rays
   using V = typename LP::V;
@@ -1476,7 +1570,25 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
     }
   }
 
-  if (a.flags & kTraceWriteRays) {
+  if constexpr (SPOT) {
+    // epilogue: masked moments of the final (global) state about (cx, cy),
+    // into slot (workgroup % slots) of the caller's [slots][8] buffer -- the slots keep
+    // the ~4e4 workgroups of a 1e7-ray launch off one address (7 x 39 k same-address
+    // atomics were measured at 0.95 ms); the consumer adds the slots up
+    Ray<V> gv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(last_traced, r[j]);
+    SpotAcc acc;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const Ray<T> g = LP::ray(gv, k);
+      if (live && k < cnt) acc.add(g.x, g.y, g.i, a.cx, a.cy);
+    }
+    acc.flush(a.spot + 8 * (blockIdx.x % (unsigned)a.spot_slots));
+  }
+  // (SPOT: a lane that re-traced the last ray must not write it back -- its owner may
+  // already have, and then this lane started from the final state)
+  if ((a.flags & kTraceWriteRays) && (!SPOT || live)) {
     Ray<V> gv[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(last_traced, r[j]);
@@ -1521,9 +1633,17 @@ static hipError_t launch_nr(const TraceArgs<T>& a, hipStream_t stream) {
   dim3 grid((unsigned)blocks), block(kTraceBlock);
   const bool rec = a.record != nullptr;
   const int polk = a.prt == nullptr ? 0 : ((a.flags & kTracePrtComplex) ? 2 : 1);
-#define OL_LAUNCH(R, P)                                                                      \
-  hipLaunchKernelGGL((trace_kernel<T, RPT, R, P, NR>), grid, block, 0, stream, a.surf,       \
+#define OL_LAUNCH_S(R, P, S)                                                                 \
+  hipLaunchKernelGGL((trace_kernel<T, RPT, R, P, NR, S>), grid, block, 0, stream, a.surf,    \
                      a.cold, a.optics, a.coeffs, a)
+#define OL_LAUNCH(R, P) OL_LAUNCH_S(R, P, false)
+  if (a.spot != nullptr) {
+    // the spot epilogue exists for unpolarised traces (the polarised intensity needs
+    // the update_intensity epilogue first)
+    if (polk != 0) return hipErrorInvalidValue;
+    if (rec) OL_LAUNCH_S(true, 0, true); else OL_LAUNCH_S(false, 0, true);
+    return hipGetLastError();
+  }
   if (polk == 2) {
     // the complex-PRT variant exists for one ray per lane only (register budget)
     if constexpr (RPT == 1) {
@@ -1535,6 +1655,7 @@ static hipError_t launch_nr(const TraceArgs<T>& a, hipStream_t stream) {
   else if (rec) OL_LAUNCH(true, 0);
   else if (polk == 1) OL_LAUNCH(false, 1);
   else OL_LAUNCH(false, 0);
+#undef OL_LAUNCH_S
 #undef OL_LAUNCH
   return hipGetLastError();
 }
@@ -1602,20 +1723,6 @@ template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, bool, h
 // L2 atomic rate, many enough (>= ~8 rounds of resident workgroups) that the last
 // round's partial occupancy does not show.
 
-__device__ __forceinline__ double spot_wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ double spot_wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_down(v, off, 64);
-    v = o > v ? o : v;
-  }
-  return v;
-}
-
 template <typename T, int RPT, int NR, bool FIELDP>
 __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
@@ -1631,8 +1738,7 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
   // launch-uniform field: the two tangents come from the host (uniform_field_tangents)
   const T tx0 = in_.tx0, ty0 = in_.ty0;
 
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  double rmax = 0.0;
+  SpotAcc acc;
   uint32_t status = 0;
   constexpr int64_t kTileRays = (int64_t)kTraceBlock * RPT;
   const int64_t ntiles = (a.n + kTileRays - 1) / kTileRays;
@@ -1729,18 +1835,7 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
     for (int k = 0; k < RPT; ++k) {
       const Ray<T> g = LP::ray(gv, k);
       hx_[k] = g.x; hy_[k] = g.y; hi_[k] = g.i;
-      if (k < cnt && g.i > T(0)) {
-        const double dx = (double)g.x - a.cx, dy = (double)g.y - a.cy;
-        const double dx2 = dx * dx, dy2 = dy * dy;
-        acc[0] += 1.0;
-        acc[1] += dx;
-        acc[2] += dy;
-        acc[3] += dx2;
-        acc[4] += dy2;
-        acc[5] += (double)g.i;
-        const double r2 = dx2 + dy2;
-        rmax = r2 > rmax ? r2 : rmax;  // NaN hits compare false and are skipped
-      }
+      if (k < cnt) acc.add(g.x, g.y, g.i, a.cx, a.cy);
     }
     if (a.hits[0] != nullptr && cnt > 0) {
       store_plane<T, RPT>(a.hits[0], base, cnt, hx_);
@@ -1749,31 +1844,7 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
     }
   }
 
-  __shared__ double part[kTraceBlock / 64][7];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const double v = spot_wave_sum(acc[k]);
-    if (lane == 0) part[wave][k] = v;
-  }
-  {
-    const double v = spot_wave_max(rmax);
-    if (lane == 0) part[wave][6] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    double v = 0;
-    for (int w = 0; w < kTraceBlock / 64; ++w) v += part[w][threadIdx.x];
-    // hardware fp64 atomic add (the output lives in ordinary coarse-grained HBM)
-    if (v != 0.0) unsafeAtomicAdd(&a.out[threadIdx.x], v);
-  } else if (threadIdx.x == 6) {
-    double v = part[0][6];
-    for (int w = 1; w < kTraceBlock / 64; ++w) v = part[w][6] > v ? part[w][6] : v;
-    // non-negative doubles order like their bit patterns
-    if (v > 0.0)
-      atomicMax(reinterpret_cast<unsigned long long*>(&a.out[6]),
-                (unsigned long long)__double_as_longlong(v));
-  }
+  acc.flush(a.out);
   if (status && a.status) atomicOr(a.status, status);
 }
 

@@ -28,6 +28,9 @@ struct TraceArgs {
   T* record;                   // rows x 8 x record_stride or nullptr
   T* prt;                      // 9 x n (18 x n with kTracePrtComplex) or nullptr
   uint32_t* status;            // device word or nullptr
+  double* spot;                // [spot_slots][8] doubles (epilogue moments) or nullptr
+  double cx, cy;               // centre of the epilogue moments
+  int32_t spot_slots;
   int64_t n;
   int64_t record_stride;
   int32_t first, last;

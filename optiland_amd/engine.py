@@ -130,7 +130,8 @@ class HipSystem:
     def trace(self, rays, wavelength_index: int = 0, record=True, prt: torch.Tensor | None = None,
               first: int = 0, last: int | None = None, write_rays: bool | None = None,
               check_status: bool = True, prt_identity: bool = False,
-              defer_status: bool = False, zero_status: bool = True) -> TraceResult:
+              defer_status: bool = False, zero_status: bool = True,
+              spot=None) -> TraceResult:
         """Launch the fused trace.
 
         rays: sequence of 8 contiguous 1-D device tensors (x,y,z,L,M,N,i,opd) of one
@@ -141,6 +142,10 @@ class HipSystem:
         identity (a fresh PolarizedRays) -- no fill, no read.
         With write_rays (default: only when nothing is recorded) the final state is
         written back into `rays` in place, like SurfaceGroup.trace mutates its rays.
+        spot: optional (slots, cx, cy) -- `slots` from `alloc_spot_slots()`; the launch
+        then also accumulates the masked spot moments of the final state about
+        (cx, cy) as an epilogue of the same kernel (`ol_trace_ex`); read them with
+        `reduce_spot_slots(slots)`.
         """
         rays = list(rays)
         if len(rays) != 8:
@@ -175,23 +180,43 @@ class HipSystem:
             if prt_identity:  # write-only PRT: starts from I inside the kernel
                 flags |= S.TRACE_PRT_IDENTITY
         ptrs = (C.c_void_p * 8)(*[t.data_ptr() for t in rays])
+        extras = None
+        if spot is not None:
+            slots, cx, cy = spot
+            if slots.dtype != torch.float64 or slots.numel() != 8 * _capi.SPOT_SLOTS \
+                    or slots.device != self.device or not slots.is_contiguous():
+                raise ValueError("spot slots must come from alloc_spot_slots()")
+            extras = C.byref(_capi.TraceExtras(slots.data_ptr(), float(cx), float(cy)))
         if check_status and zero_status:  # zero_status=False: keep bits set by ray generation
             self._status.zero_()
         with torch.cuda.device(self.device):
-            rc = self.lib.ol_trace(
+            rc = self.lib.ol_trace_ex(
                 self._handle, _DT[dtype], n, ptrs, int(wavelength_index),
                 rec.data_ptr() if rec is not None else None,
                 int(rec.shape[2]) if rec is not None else 0,
                 prt.data_ptr() if prt is not None else None,
                 int(first), int(last), flags,
                 self._status.data_ptr() if check_status else None,
-                _stream_ptr(self.device))
+                extras, _stream_ptr(self.device))
         _capi.check(rc, "ol_trace")
         # defer_status: the kernel still ORs its bits into self._status, but the caller
         # reads them back later (together with other device-side checks)
         status = int(self._status.item()) if (check_status and not defer_status) else 0
         self.raise_for_status(status)
         return TraceResult(n, rays, rec, prt, status, first, last)
+
+    def alloc_spot_slots(self) -> torch.Tensor:
+        """Zeroed [OL_SPOT_SLOTS, 8] float64 buffer for the spot epilogue of `trace`."""
+        return torch.zeros((_capi.SPOT_SLOTS, 8), dtype=torch.float64, device=self.device)
+
+    @staticmethod
+    def reduce_spot_slots(slots: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """[slots, 8] -> the seven doubles of `ol_trace_spot` (sum of 0..5, max of 6)."""
+        if out is None:
+            out = torch.empty(7, dtype=torch.float64, device=slots.device)
+        torch.sum(slots[:, :6], dim=0, out=out[:6])
+        torch.amax(slots[:, 6], dim=0, out=out[6])
+        return out
 
     def row0_planes(self, record: torch.Tensor, n: int):
         """The 8 planes of record row 0 as ray planes (zero-copy object row)."""

@@ -224,3 +224,38 @@ def test_fused_spot_fullsize_against_planes(dtype, n):
         assert abs(got[1] / got[0]) < tol * 20 and abs(got[2] / got[0]) < tol * 20
     finally:
         hip.close()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("mode", ["record", "last"])
+@pytest.mark.parametrize("n", [1, 255, 100_003])
+def test_trace_epilogue_moments_equal_plane_reductions(system, dtype, mode, n):
+    """`ol_trace_ex` spot epilogue (slotted atomics inside the trace kernel) == the
+    separate reductions of the traced image-plane planes; the traced state itself is
+    unchanged by asking for it (ragged sizes: lanes past the end stay for the barrier)."""
+    hip, table, wl, field = system
+    px, py = _pupil(n, 17, dtype)
+    planes = [p.contiguous().clone() for p in hip.generate_rays(field[0], field[1], px, py)]
+    planes.append(torch.zeros(n, dtype=dtype, device=DEV))
+    ref_in = [p.clone() for p in planes]
+    slots = hip.alloc_spot_slots()
+    cx, cy = 0.0, 0.25
+    res = hip.trace(planes, wl, record=(mode == "record"), spot=(slots, cx, cy))
+    got = hip.reduce_spot_slots(slots).cpu().numpy()
+    plain = hip.trace(ref_in, wl, record=(mode == "record"))
+    if mode == "record":
+        assert torch.equal(res.record[:, :, :n].nan_to_num(), plain.record[:, :, :n].nan_to_num())
+        x, y, i = (plain.row(plain.last, k) for k in (0, 1, 6))
+    else:
+        for a, b in zip(planes, ref_in):
+            assert torch.equal(a.nan_to_num(), b.nan_to_num())
+        x, y, i = ref_in[0], ref_in[1], ref_in[6]
+    m = i > 0
+    dx, dy = x[m].double() - cx, y[m].double() - cy
+    ok = ~(torch.isnan(dx) | torch.isnan(dy))
+    want = np.array([float(m.sum()), float(dx.sum()), float(dy.sum()), float((dx * dx).sum()),
+                     float((dy * dy).sum()), float(i[m].double().sum()),
+                     float((dx * dx + dy * dy)[ok].max()) if bool(ok.any()) else 0.0])
+    assert got[0] == want[0]
+    np.testing.assert_allclose(got[1:6], want[1:6], rtol=1e-10, atol=1e-9)
+    assert got[6] == want[6]

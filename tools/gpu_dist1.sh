@@ -1,7 +1,12 @@
 #!/bin/bash
+# torchrun path on ONE rank with the image-plane exchange forced (RCCL path check + overhead)
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
-for ex in reduce gather; do
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline --force-exchange --exchange $ex 2>&1 | tail -2 | cut -c1-600
-done
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline --dtype f64 --rays 1.25e7 --force-exchange 2>&1 | tail -1 | cut -c1-400
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29535 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline --mode spot --force-exchange 2>&1 | tail -1 | cut -c1-300
+show() { grep "^{" | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('  ', d['config']['mode'], d['dtype'], 'exchange='+d['config']['exchange'], 'ms/step=%.4f kernel_ms=%.4f value=%.4g' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['value']))"; }
+run() { python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $1 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline "${@:2}" 2>&1 | show; }
+echo "plain (no process group)"; python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | show
+run 29531 --exchange none
+run 29532 --force-exchange --exchange reduce
+run 29533 --force-exchange --exchange gather
+run 29534 --force-exchange --dtype f64 --rays 1.25e7
+run 29535 --force-exchange --mode spot
+run 29536 --force-exchange --mode last
