@@ -183,12 +183,7 @@ hipError_t launch_wavefront(const WavefrontDev& p, int64_t n, const T* const ray
   return hipGetLastError();
 }
 
-// wave-level sum via DPP-free shuffles (64 lanes), then one atomic per wave
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
+// wave-level max via shuffles (64 lanes)
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -220,10 +215,19 @@ __global__ __launch_bounds__(kBlock) void spot_moments_kernel(int64_t n, const T
   }
   __shared__ double part[kBlock / 64][6];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // step-major wave reduction: the six values move together (12 independent
+  // ds_bpermute per step) instead of six serial chains -- see SpotAcc::flush
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    double v = wave_sum(s[k]);
-    if (lane == 0) part[wave][k] = v;
+  for (int off = 32; off > 0; off >>= 1) {
+    double o[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = __shfl_down(s[k], off, 64);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] += o[k];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) part[wave][k] = s[k];
   }
   __syncthreads();
   if (threadIdx.x < 6) {
