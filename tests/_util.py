@@ -28,6 +28,11 @@ def load_case(name):
     return table, data
 
 
+def load_case_table(name):
+    """Table-only fixtures (no recorded arrays), e.g. the Zemax known-answer lenses."""
+    return SystemTable.load(os.path.join(GOLDEN, f"{name}.json"))
+
+
 def rays_in_dict(data):
     r = data["rays_in"]
     return {k: r[j].copy() for j, k in enumerate(PLANES[:7])}

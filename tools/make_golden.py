@@ -414,6 +414,32 @@ def wavefront_goldens():
     np.savez_compressed(os.path.join(GOLD, "wavefront.npz"), **out)
 
 
+def zemax_toroid_tables():
+    """System tables (no traces) of the two single-toroid lenses whose Zemax ray data the
+    reference's own tests hard-code (tests/test_geometries.py:1483-1840); the Zemax
+    numbers themselves live in tests/test_zemax_known_answers.py."""
+    from optiland.materials import IdealMaterial
+    for name, kw, t1, t2, mat, epd in (
+            ("zemax_toroid_posRx", dict(radius_x=100.0, radius_y=50.0, conic=-0.5,
+                                        toroidal_coeffs_poly_y=[0.05, 0.0002]), 5.0, 10.0,
+             IdealMaterial(n=1.5, k=0), 10.0),
+            ("zemax_toroid_negRx", dict(radius_x=-50.0, radius_y=40.0, conic=-0.5,
+                                        toroidal_coeffs_poly_y=[5e-5, 5e-6]), 7.0, 70.0,
+             "N-BK7", 20.0)):
+        lens = optic_mod.Optic(name=name)
+        lens.surfaces.add(index=0, thickness=be.inf)
+        lens.surfaces.add(index=1, surface_type="toroidal", thickness=t1, material=mat,
+                          is_stop=True, **kw)
+        lens.surfaces.add(index=2, thickness=t2, material="air")
+        lens.surfaces.add(index=3)
+        lens.set_aperture(aperture_type="EPD", value=epd)
+        lens.wavelengths.add(value=0.550, is_primary=True)
+        lens.fields.set_type("angle")
+        lens.fields.add(y=0)
+        pack_optic(lens, wavelengths=[0.55], name=name).save(os.path.join(GOLD, f"{name}.json"))
+        print(f"{name}: table only")
+
+
 def sample_goldens():
     """EVERY lens of optiland.samples (29 systems, 3 to 43 surfaces: photographic
     objectives, microscopes, eyepieces, IR triplets, wide-angle projection lenses,
@@ -446,6 +472,9 @@ def sample_goldens():
 def main():
     if "--samples-only" in sys.argv:
         sample_goldens()
+        return
+    if "--zemax-only" in sys.argv:
+        zemax_toroid_tables()
         return
     os.makedirs(GOLD, exist_ok=True)
     os.makedirs(DATA, exist_ok=True)
@@ -515,6 +544,7 @@ def main():
              [0.0, 0.0, 1 / 3], [0.0, 0.7, 1.0], None, None, 0.55,
              use_trace=dict(num_rays=4, distribution="hexapolar"))
     wavefront_goldens()
+    zemax_toroid_tables()
     sample_goldens()
 
 
