@@ -106,3 +106,49 @@ def test_hip_reproduces_zemax_ray_data(case, dtype):
         _check(case, out, fp32=dtype == torch.float32)
     finally:
         hip.close()
+
+
+# --- ray generator known answers (reference tests/test_rays.py:686-735) -----------------
+RAYGEN_CASES = {
+    # TessarLens, angle field at infinity: Hx = Hy = 0.5, Px = Py = [0.1, 0.2]
+    "tessar": ("sample_TessarLens", 0.5, 0.5, [0.1, 0.2], [0.1, 0.2],
+               dict(x=[-0.23535066, -0.1909309], y=[-0.23535066, -0.1909309],
+                    z=[-0.88839505, -0.88839505], L=[0.17519154, 0.17519154],
+                    M=[0.17519154, 0.17519154], N=[0.96882189, 0.96882189], i=[1.0, 1.0])),
+    # UVProjectionLens, object-height field, object-space telecentric: Hy = 1, Px = 0.8
+    "uv_telecentric": ("sample_UVProjectionLens", 0.0, 1.0, [0.8], [0.0],
+                       dict(x=[0.0], y=[48.0], z=[-110.85883544], L=[0.10674041], M=[0.0],
+                            N=[0.99428692], i=[1.0])),
+}
+
+
+@pytest.mark.parametrize("case", sorted(RAYGEN_CASES))
+def test_oracle_reproduces_raygen_known_answers(case):
+    from oracle import oracle
+    name, hx, hy, px, py, want = RAYGEN_CASES[case]
+    table = load_case_table(name)
+    n = len(px)
+    got = oracle.generate_rays(table.raygen, np.full(n, hx), np.full(n, hy), np.array(px),
+                               np.array(py))
+    for k, v in want.items():
+        np.testing.assert_allclose(got[k], v, rtol=0, atol=1e-8, err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("case", sorted(RAYGEN_CASES))
+def test_hip_reproduces_raygen_known_answers(case, dtype):
+    from optiland_amd.engine import HipSystem
+    name, hx, hy, px, py, want = RAYGEN_CASES[case]
+    table = load_case_table(name)
+    hip = HipSystem(table, "cuda:0")
+    try:
+        tx = torch.tensor(px, dtype=dtype, device="cuda:0")
+        ty = torch.tensor(py, dtype=dtype, device="cuda:0")
+        planes = hip.generate_rays(hx, hy, tx, ty)  # launch-uniform field scalars
+        atol = 1e-8 if dtype == torch.float64 else 2e-5  # fp32: ulp(110 mm) = 7.6e-6
+        for k, p in zip(("x", "y", "z", "L", "M", "N", "i"), planes):
+            np.testing.assert_allclose(p.double().cpu().numpy(), want[k], rtol=0, atol=atol,
+                                       err_msg=k)
+    finally:
+        hip.close()

@@ -417,7 +417,7 @@ def wavefront_goldens():
 def zemax_toroid_tables():
     """System tables (no traces) of the two single-toroid lenses whose Zemax ray data the
     reference's own tests hard-code (tests/test_geometries.py:1483-1840); the Zemax
-    numbers themselves live in tests/test_zemax_known_answers.py."""
+    numbers themselves live in tests/test_external_known_answers.py."""
     from optiland.materials import IdealMaterial
     for name, kw, t1, t2, mat, epd in (
             ("zemax_toroid_posRx", dict(radius_x=100.0, radius_y=50.0, conic=-0.5,
