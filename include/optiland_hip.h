@@ -277,7 +277,21 @@ typedef struct ol_raygen_params {
                               telecentric, sqrt(1 - sin^2)/sin of the object NA
                               (:82-87): the target plane sits tele_dz behind the
                               object point and the pupil offsets are ABSOLUTE     */
+  double apod_a, apod_b;   /* apodization parameters, see OL_APOD_*                */
+  int32_t apod_kind;       /* initial intensity i = A(Px, Py), ray_generator.py:81-85 */
+  int32_t reserved_;
 } ol_raygen_params;
+
+/* optiland/apodization/: r = sqrt(Px^2 + Py^2) of the pupil coordinates handed to the
+ * ray generator (after trace_generic's pre-scaling)                                */
+#define OL_APOD_NONE 0           /* 1 (uniform.py)                                 */
+#define OL_APOD_GAUSSIAN 1       /* exp(-r^2 / (2 a^2)),            a = sigma      */
+#define OL_APOD_COSINE_SQUARED 2 /* cos^2(pi r / (2 a)) for r < a else 0, a = R    */
+#define OL_APOD_HANN 3           /* (1 - cos(2 pi r / a)) / 2 for r < a/2 else 0, a = D */
+#define OL_APOD_POLYNOMIAL 4     /* (1 - (r/a)^2)^b for r < a else 0, a = R, b = p */
+#define OL_APOD_SUPER_GAUSSIAN 5 /* exp(-(r / a)^b),                a = w, b = n   */
+#define OL_APOD_TUKEY 6          /* 1 for r <= a(1 - b/2); (1 + cos(pi (r - a(1-b/2)) /
+                                    (a b / 2))) / 2 up to r < a; else 0; a = R, b = alpha */
 
 /* Normalised coordinates of one ray block.  Each of the pairs (hx,hy) and (vx,vy)
  * is either two device planes of n elements or both NULL, in which case the

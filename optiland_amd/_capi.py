@@ -55,6 +55,10 @@ class RaygenParams(C.Structure):
         ("offset", C.c_double),
         ("z_first", C.c_double),
         ("tele_dz", C.c_double),
+        ("apod_a", C.c_double),
+        ("apod_b", C.c_double),
+        ("apod_kind", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 

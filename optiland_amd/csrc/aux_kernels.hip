@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void raygen_kernel(RaygenDev p, RaygenIn<T>
     oL[j] = o[3];
     oM[j] = o[4];
     oN[j] = o[5];
-    oi[j] = T(1);
+    oi[j] = raygen_apodize<T>(c, px, py);
     if (oopd) oopd[j] = T(0);
   }
   if (st && status) atomicOr(status, st);

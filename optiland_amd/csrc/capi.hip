@@ -302,8 +302,9 @@ int convert_inputs(const char* who, const ol_raygen_inputs* in, uint32_t* status
 }
 
 ol::RaygenDev raygen_dev(const ol_raygen_params* g) {
-  return ol::RaygenDev{g->object_infinite, g->field_kind, g->EPL,     g->EPD,
-                       g->max_field,       g->offset,     g->z_first, g->tele_dz};
+  return ol::RaygenDev{g->object_infinite, g->field_kind, g->EPL,     g->EPD,    g->max_field,
+                       g->offset,          g->z_first,    g->tele_dz, g->apod_a, g->apod_b,
+                       g->apod_kind};
 }
 
 template <typename T>

@@ -26,14 +26,46 @@ __device__ __forceinline__ double tan_deg<double>(double deg) {
 // launch-invariant scalars, converted to the working precision once
 template <typename T>
 struct RaygenConsts {
-  T EPL, EPD, maxf, off_epl, z_inf, z_fin, epl_z, tele_dz;
+  T EPL, EPD, maxf, off_epl, z_inf, z_fin, epl_z, tele_dz, apod_a, apod_b;
+  int apod_kind;
   bool infinite, height, telecentric;
   __device__ __forceinline__ explicit RaygenConsts(const RaygenDev& p)
       : EPL((T)p.EPL), EPD((T)p.EPD), maxf((T)p.max_field), off_epl((T)(p.offset + p.EPL)),
         z_inf((T)(p.z_first - p.offset)), z_fin((T)p.z_first), epl_z((T)(p.EPL - p.z_first)),
-        tele_dz((T)p.tele_dz), infinite(p.object_infinite != 0), height(p.field_kind == 1),
+        tele_dz((T)p.tele_dz), apod_a((T)p.apod_a), apod_b((T)p.apod_b),
+        apod_kind(p.apod_kind), infinite(p.object_infinite != 0), height(p.field_kind == 1),
         telecentric(p.tele_dz > 0.0) {}
 };
+
+// initial intensity from the pupil apodization (ray_generator.py:81-85,
+// optiland/apodization/*.py); launch-uniform switch
+template <typename T>
+__device__ __forceinline__ T raygen_apodize(const RaygenConsts<T>& c, T px, T py) {
+  if (c.apod_kind == 0) return T(1);
+  const T pi = T(3.14159265358979323846);
+  const T r2 = px * px + py * py;
+  const T r = sqrt(r2);
+  const T a = c.apod_a, b = c.apod_b;
+  switch (c.apod_kind) {
+    case 1: return exp(-r2 / (T(2) * a * a));                                  // gaussian.py
+    case 2: {                                                                  // cosine_squared.py
+      const T cs = cos(pi * r / (T(2) * a));
+      return r < a ? cs * cs : T(0);
+    }
+    case 3: return r < a / T(2) ? T(0.5) * (T(1) - cos(T(2) * pi * r / a)) : T(0);  // hann.py
+    case 4: {                                                                  // polynomial.py
+      const T q = r / a;
+      return r < a ? pow(T(1) - q * q, b) : T(0);
+    }
+    case 5: return exp(-pow(r / a, b));                                        // super_gaussian.py
+    default: {                                                                 // tukey.py
+      const T flat = a * (T(1) - b / T(2));
+      const T taper = T(0.5) * (T(1) + cos(pi * (r - flat) / (a * b / T(2))));
+      T i = r <= flat ? T(1) : T(0);
+      return (r > flat && r < a) ? taper : i;
+    }
+  }
+}
 
 // field quantity per axis: tan(field angle) (angle.py:40-47) or the object height
 // (object_height.py:38-41); hoistable when the field is launch-uniform

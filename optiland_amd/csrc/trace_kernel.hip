@@ -1805,7 +1805,7 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
       Ray<T> q;
       q.x = o[0]; q.y = o[1]; q.z = o[2];
       q.L = o[3]; q.M = o[4]; q.N = o[5];
-      q.i = T(1); q.opd = T(0);
+      q.i = raygen_apodize<T>(c, in[0][k], in[1][k]); q.opd = T(0);
       LP::put(r, k, q);
     }
 

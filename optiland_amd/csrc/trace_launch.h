@@ -54,6 +54,8 @@ struct RaygenDev {
   int32_t object_infinite;
   int32_t field_kind;  // 0 angle, 1 object height
   double EPL, EPD, max_field, offset, z_first, tele_dz;
+  double apod_a, apod_b;
+  int32_t apod_kind;
 };
 
 constexpr uint32_t kRaygenCheckField = 0x1u;    // OL_RAYGEN_CHECK_FIELD

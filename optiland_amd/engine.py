@@ -252,7 +252,9 @@ class HipSystem:
             raise ValueError("this SystemTable carries no ray-generation scalars")
         return _capi.RaygenParams(int(rg["object_infinite"]), int(rg.get("field_kind", 0)),
                                   rg["EPL"], rg["EPD"], rg["max_field"], rg["offset"],
-                                  rg["z_first"], float(rg.get("tele_dz", 0.0)))
+                                  rg["z_first"], float(rg.get("tele_dz", 0.0)),
+                                  float(rg.get("apod_a", 0.0)), float(rg.get("apod_b", 0.0)),
+                                  int(rg.get("apod_kind", 0)), 0)
 
     def _check_out_planes(self, planes, n, dtype, what):
         for t in planes:

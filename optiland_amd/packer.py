@@ -357,7 +357,7 @@ def _raygen_fingerprint(optic, table: SystemTable):
         table.surfaces.tobytes(), table.coeffs.tobytes(), prim, idx, stop,
         type(ap).__name__, None if ap is None else _f(ap.value),
         type(fd).__name__, fields, bool(optic.object_surface.is_infinite),
-        bool(optic.obj_space_telecentric), optic.apodization is None, mode,
+        bool(optic.obj_space_telecentric), _pack_apodization(optic.apodization), mode,
     ))
 
 
@@ -378,20 +378,46 @@ def _pack_raygen(optic, table: SystemTable) -> None:
             pass
 
 
+def _pack_apodization(ap):
+    """(kind, a, b) of optiland/apodization/*.py, or None for a class the device
+    generator does not know."""
+    if ap is None:
+        return S.APOD_NONE, 0.0, 0.0
+    name = type(ap).__name__
+    if name == "UniformApodization":
+        return S.APOD_NONE, 0.0, 0.0
+    if name == "GaussianApodization":
+        return S.APOD_GAUSSIAN, _f(ap.sigma), 0.0
+    if name == "CosineSquaredApodization":
+        return S.APOD_COSINE_SQUARED, _f(ap.R), 0.0
+    if name == "HannApodization":
+        return S.APOD_HANN, _f(ap.D), 0.0
+    if name == "PolynomialApodization":
+        return S.APOD_POLYNOMIAL, _f(ap.R), _f(ap.p)
+    if name == "SuperGaussianApodization":
+        return S.APOD_SUPER_GAUSSIAN, _f(ap.w), _f(ap.n)
+    if name == "TukeyApodization":
+        return S.APOD_TUKEY, _f(ap.R), _f(ap.alpha)
+    return None
+
+
 def _compute_raygen(optic, table: SystemTable) -> None:
     """Scalars for on-device ray generation.
 
-    Packed: paraxial aiming without apodization for AngleField (object at infinity or
+    Packed: paraxial aiming, any apodization of optiland/apodization/, for AngleField (object at infinity or
     finite, fields/field_types/angle.py:17-58) and ObjectHeightField on a planar object
     (object_height.py:19-47), incl. the object-space-telecentric branch of the aimer
     (rays/ray_aiming/paraxial.py:33-106).  Otherwise (iterative / robust aiming, image
-    height fields, apodization) `table.raygen` stays empty and callers generate rays
+    height fields) `table.raygen` stays empty and callers generate rays
     with the reference's own RayGenerator.
     """
     fd = optic.fields.field_definition
     kind = {"AngleField": S.FIELD_ANGLE, "ObjectHeightField": S.FIELD_OBJECT_HEIGHT}.get(
         type(fd).__name__)
-    if kind is None or optic.apodization is not None:
+    if kind is None:
+        return
+    apod = _pack_apodization(optic.apodization)
+    if apod is None:
         return
     mode = getattr(optic.ray_tracer, "ray_aiming_config", {}).get("mode", "paraxial")
     if mode != "paraxial":
@@ -432,6 +458,9 @@ def _compute_raygen(optic, table: SystemTable) -> None:
         "offset": offset,
         "z_first": z_first,
         "tele_dz": tele_dz,
+        "apod_kind": float(apod[0]),
+        "apod_a": apod[1],
+        "apod_b": apod[2],
     }
     table.fields = [
         (_f(f.x), _f(f.y), _f(f.vx), _f(f.vy)) for f in optic.fields.fields

@@ -35,6 +35,8 @@ STATUS_ZERNIKE_RANGE = 0x1
 STATUS_K_PARALLEL_X = 0x2
 STATUS_CHEBYSHEV_RANGE = 0x4
 FIELD_ANGLE, FIELD_OBJECT_HEIGHT = 0, 1
+(APOD_NONE, APOD_GAUSSIAN, APOD_COSINE_SQUARED, APOD_HANN, APOD_POLYNOMIAL, APOD_SUPER_GAUSSIAN,
+ APOD_TUKEY) = range(7)
 STATUS_FIELD_RANGE = 0x8
 STATUS_PUPIL_RANGE = 0x10
 
@@ -94,6 +96,10 @@ RAYGEN_DTYPE = np.dtype(
         ("offset", np.float64),
         ("z_first", np.float64),
         ("tele_dz", np.float64),
+        ("apod_a", np.float64),
+        ("apod_b", np.float64),
+        ("apod_kind", np.int32),
+        ("reserved_", np.int32),
     ],
     align=True,
 )

@@ -117,6 +117,9 @@ def generate_rays(raygen: dict, hx, hy, px, py, vx=None, vy=None):
     p["object_infinite"] = int(raygen["object_infinite"])
     p["field_kind"] = int(raygen.get("field_kind", 0))
     p["tele_dz"] = float(raygen.get("tele_dz", 0.0))
+    p["apod_kind"] = int(raygen.get("apod_kind", 0))
+    p["apod_a"] = float(raygen.get("apod_a", 0.0))
+    p["apod_b"] = float(raygen.get("apod_b", 0.0))
     for k in ("EPL", "EPD", "max_field", "offset", "z_first"):
         p[k] = raygen[k]
     hx, hy, px, py = (np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64),

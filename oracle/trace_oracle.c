@@ -746,6 +746,34 @@ uint32_t oracle_trace(const ol_surface_desc* surf, int32_t n_surf,
   return status | g_normal_status;
 }
 
+/* optiland/apodization/{uniform,gaussian,cosine_squared,hann,polynomial,
+ * super_gaussian,tukey}.py get_intensity, applied at rays/ray_generator.py:81-85     */
+static double apodization(const ol_raygen_params* p, double Px, double Py) {
+  const double a = p->apod_a, b = p->apod_b;
+  const double r2 = Px * Px + Py * Py;
+  const double r = sqrt(r2);
+  switch (p->apod_kind) {
+    case OL_APOD_GAUSSIAN: return exp(-r2 / (2 * a * a));
+    case OL_APOD_COSINE_SQUARED: {
+      double c = cos(M_PI * r / (2 * a));
+      return r < a ? c * c : 0.0;
+    }
+    case OL_APOD_HANN: return r < a / 2 ? 0.5 * (1 - cos(2 * M_PI * r / a)) : 0.0;
+    case OL_APOD_POLYNOMIAL: {
+      double q = (r / a) * (r / a);
+      return r < a ? pow(1 - q, b) : 0.0;
+    }
+    case OL_APOD_SUPER_GAUSSIAN: return exp(-pow(r / a, b));
+    case OL_APOD_TUKEY: {
+      double flat = a * (1 - b / 2);
+      double taper = 0.5 * (1 + cos(M_PI * (r - flat) / (a * b / 2)));
+      double i = r <= flat ? 1.0 : 0.0;
+      return (r > flat && r < a) ? taper : i;
+    }
+    default: return 1.0;
+  }
+}
+
 /* rays/ray_generator.py:47-99 + rays/ray_aiming/paraxial.py:33-106 +
  * fields/field_types/angle.py:17-58 + fields/field_types/object_height.py:19-47
  * (planar object).  out[7] = x,y,z,L,M,N,i.                                      */
@@ -791,7 +819,7 @@ void oracle_generate_rays(const ol_raygen_params* p, int64_t n, const double* hx
     out[3][j] = is_zero ? 0.0 : (x1 - x0) / mag;
     out[4][j] = is_zero ? 0.0 : (y1 - y0) / mag;
     out[5][j] = is_zero ? 1.0 : (z1 - z0) / mag;
-    out[6][j] = 1.0;
+    out[6][j] = apodization(p, px[j], py[j]);
   }
 }
 

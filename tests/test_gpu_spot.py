@@ -259,3 +259,42 @@ def test_trace_epilogue_moments_equal_plane_reductions(system, dtype, mode, n):
     assert got[0] == want[0]
     np.testing.assert_allclose(got[1:6], want[1:6], rtol=1e-10, atol=1e-9)
     assert got[6] == want[6]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("case,field", [("apodized_tukey_trace", (0.0, 0.7)),
+                                        ("apodized_hann_trace", (0.0, 0.0)),
+                                        ("finite_object_height_generic", (1 / 3, 1.0)),
+                                        ("finite_object_height_telecentric_generic", (0.1, 0.6)),
+                                        ("finite_angle_generic", (-0.2, 0.9)),
+                                        ("sample_UVProjectionLens", (0.0, 1.0))])
+def test_fused_spot_field_kinds_and_apodization(case, field, dtype):
+    """The fused kernel shares the ray generator: object-height / telecentric / finite
+    angle fields and pupil apodization (initial intensities feed the i > 0 mask and
+    sum i) against the oracle pipeline."""
+    from optiland_amd.engine import HipSystem
+    from tests._util import load_case
+    table, _ = load_case(case)
+    hip = HipSystem(table, DEV)
+    try:
+        n = 5003
+        px, py = _pupil(n, 23, dtype)
+        hx = torch.full((n,), field[0], dtype=dtype, device=DEV)
+        hy = torch.full((n,), field[1], dtype=dtype, device=DEV)
+        vig = (0.95, 0.9)
+        vx = torch.full((n,), vig[0], dtype=dtype, device=DEV)
+        vy = torch.full((n,), vig[1], dtype=dtype, device=DEV)
+        want, (wx, wy, wi) = _oracle_spot(table, 0, hx, hy, px, py, vx, vy, (0.0, 0.0))
+        got = hip.trace_spot(px, py, 0, field=field, vig=vig).cpu().numpy()
+        # a pupil point within rounding of an apodization edge (r = R) may fall on either
+        # side in fp32: allow the count to differ by what sits inside 1e-6 of an edge
+        if dtype == torch.float64:
+            _check_moments(got, want, _scale(table, wx, wy), 1e-10)
+        else:
+            assert abs(got[0] - want[0]) <= 2
+            np.testing.assert_allclose(got[5], want[5], rtol=1e-4)
+            nrm = max(want[0], 1.0)
+            sc = _scale(table, wx, wy)
+            np.testing.assert_allclose(got[1:3] / nrm, want[1:3] / nrm, atol=2e-5 * sc)
+    finally:
+        hip.close()

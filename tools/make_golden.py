@@ -543,6 +543,24 @@ def main():
     run_case("finite_telecentric_trace", finite_conjugate("object_height", True),
              [0.0, 0.0, 1 / 3], [0.0, 0.7, 1.0], None, None, 0.55,
              use_trace=dict(num_rays=4, distribution="hexapolar"))
+    # pupil apodization (ray_generator.py:81-85): every class of optiland/apodization
+    from optiland import apodization as apod_mod
+    for nm, ap in (("gaussian", apod_mod.GaussianApodization(sigma=0.7)),
+                   ("cosine_squared", apod_mod.CosineSquaredApodization(R=0.9)),
+                   ("hann", apod_mod.HannApodization(D=1.8)),
+                   ("polynomial", apod_mod.PolynomialApodization(R=0.95, p=1.5)),
+                   ("super_gaussian", apod_mod.SuperGaussianApodization(w=0.8, n=4.0)),
+                   ("tukey", apod_mod.TukeyApodization(R=0.9, alpha=0.4))):
+        lens = vignetted_cooke()
+        lens.updater.set_apodization(ap)
+        run_case(f"apodized_{nm}_trace", lens, [0.0, 0.0], [0.0, 0.7], None, None, 0.55,
+                 use_trace=dict(num_rays=4, distribution="hexapolar"))
+    lens = vignetted_cooke()
+    lens.updater.set_apodization(apod_mod.GaussianApodization(sigma=0.7))
+    hx = np.repeat([0.0, 0.25], 150)
+    hy = np.repeat([0.6, 1.0], 150)
+    px3, py3 = disc_points(300, 17)
+    run_case("apodized_gaussian_generic", lens, hx, hy, px3, py3, 0.55)
     wavefront_goldens()
     zemax_toroid_tables()
     sample_goldens()
