@@ -99,7 +99,12 @@ typedef enum ol_aperture_kind {
   OL_AP_OFFSET_RADIAL = 2,
   OL_AP_RECTANGULAR = 3,
   OL_AP_ELLIPTICAL = 4,
-  OL_AP_COMPOSITE = 5
+  OL_AP_COMPOSITE = 5,
+  OL_AP_POLYGON = 6   /* PolygonAperture / FileAperture (physical_apertures/polygon.py):
+                         parameters {first vertex index in the coefficient buffer,
+                         vertex count}; vertices stored x0, y0, x1, y1, ...; inside =
+                         matplotlib's crossings test (Path.contains_points, radius 0),
+                         which is what the NumPy backend calls                      */
 } ol_aperture_kind;
 
 #define OL_AP_OP_UNION 10

@@ -400,7 +400,7 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
       return fail(OL_EUNSUPPORTED, "surface %d: geometry kind %d", i, s.geom_kind);
     if (s.interaction < OL_INTERACT_RECORD_ONLY || s.interaction > OL_INTERACT_REFLECT)
       return fail(OL_EUNSUPPORTED, "surface %d: interaction %d", i, s.interaction);
-    if (s.aperture_kind < OL_AP_NONE || s.aperture_kind > OL_AP_COMPOSITE)
+    if (s.aperture_kind < OL_AP_NONE || s.aperture_kind > OL_AP_POLYGON)
       return fail(OL_EUNSUPPORTED, "surface %d: aperture kind %d", i, s.aperture_kind);
     if (s.coating_kind < OL_COAT_NONE || s.coating_kind > OL_COAT_RETARDER)
       return fail(OL_EUNSUPPORTED, "surface %d: coating kind %d", i, s.coating_kind);
@@ -446,13 +446,24 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
       if (!is_identity(d.rel_rot)) d.flags |= ol::kSurfRelRotated;
     }
     if (s.interaction != OL_INTERACT_RECORD_ONLY) prev_traced = i;
-    // apertures: pre-square / pre-invert in double
+    // apertures: pre-square / pre-invert in double; polygon vertex blocks move into the
+    // device coefficient buffer and their token / descriptor offsets are rewritten
+    auto stage_polygon = [&](const double* a, double* q) -> int {
+      const int64_t voff = (int64_t)a[0], nv = (int64_t)a[1];
+      if (voff < 0 || nv < 1 || voff + 2 * nv > n_coeffs)
+        return fail(OL_EINVAL, "surface %d: polygon vertex block outside the buffer", i);
+      q[0] = (double)dcoef.size();
+      q[1] = (double)nv;
+      q[2] = q[3] = 0.0;
+      dcoef.insert(dcoef.end(), coeffs + voff, coeffs + voff + 2 * nv);
+      return OL_OK;
+    };
     if (s.aperture_kind == OL_AP_COMPOSITE) {
       const int64_t off = (int64_t)s.aperture[0], cnt = (int64_t)s.aperture[1];
       if (off < 0 || cnt <= 0 || off + cnt * OL_AP_TOKEN_DOUBLES > n_coeffs)
         return fail(OL_EINVAL, "surface %d: aperture token list outside the buffer", i);
-      d.ap_off = (int32_t)dcoef.size();
-      d.ap_len = (int32_t)cnt;
+      // pass 1: converted tokens (polygon vertices are appended to dcoef as they come)
+      std::vector<double> toks;
       int depth = 0;
       for (int64_t t = 0; t < cnt; ++t) {
         const double* tok = coeffs + off + t * OL_AP_TOKEN_DOUBLES;
@@ -462,16 +473,26 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
           convert_aperture(op, tok + 1, q);
           if (++depth > OL_AP_MAX_DEPTH)
             return fail(OL_EUNSUPPORTED, "surface %d: aperture tree too deep", i);
+        } else if (op == OL_AP_POLYGON) {
+          if (int rc = stage_polygon(tok + 1, q)) return rc;
+          if (++depth > OL_AP_MAX_DEPTH)
+            return fail(OL_EUNSUPPORTED, "surface %d: aperture tree too deep", i);
         } else if (op >= OL_AP_OP_UNION && op <= OL_AP_OP_DIFFERENCE) {
           q[0] = q[1] = q[2] = q[3] = 0.0;
           if (--depth < 1) return fail(OL_EINVAL, "surface %d: malformed aperture tokens", i);
         } else {
           return fail(OL_EUNSUPPORTED, "surface %d: aperture token op %d", i, op);
         }
-        dcoef.push_back((double)op);
-        dcoef.insert(dcoef.end(), q, q + 4);
+        toks.push_back((double)op);
+        toks.insert(toks.end(), q, q + 4);
       }
       if (depth != 1) return fail(OL_EINVAL, "surface %d: malformed aperture tokens", i);
+      // pass 2: the token list itself, contiguous
+      d.ap_off = (int32_t)dcoef.size();
+      d.ap_len = (int32_t)cnt;
+      dcoef.insert(dcoef.end(), toks.begin(), toks.end());
+    } else if (s.aperture_kind == OL_AP_POLYGON) {
+      if (int rc = stage_polygon(s.aperture, d.ap)) return rc;
     } else {
       convert_aperture(s.aperture_kind, s.aperture, d.ap);
     }

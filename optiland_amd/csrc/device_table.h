@@ -29,7 +29,7 @@ enum : int {
 enum : int { kRecordOnly = 0, kRefract = 1, kReflect = 2 };
 enum : int {
   kApNone = 0, kApRadial = 1, kApOffsetRadial = 2, kApRect = 3, kApElliptical = 4,
-  kApComposite = 5, kApOpUnion = 10, kApOpIntersection = 11, kApOpDifference = 12
+  kApComposite = 5, kApPolygon = 6, kApOpUnion = 10, kApOpIntersection = 11, kApOpDifference = 12
 };
 constexpr int kApTokenLen = 5;   // {op, p0..p3} per reverse-Polish token
 enum : int {

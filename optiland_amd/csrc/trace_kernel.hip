@@ -697,10 +697,35 @@ __device__ __forceinline__ void newton_compacted(const DevSurf<T>& s, const T* _
 // --------------------------------------------------------------------------
 // apertures: physical_apertures/{radial,offset_radial,rectangular,elliptical}.py
 // --------------------------------------------------------------------------
+// physical_apertures/polygon.py:54-71: matplotlib's crossings test over the implicitly
+// closed polygon (see oracle/trace_oracle.c:polygon_contains, checked against
+// matplotlib itself); vertices x0, y0, x1, y1, ... in the coefficient buffer.
 template <typename T>
-__device__ __forceinline__ bool leaf_contains(int kind, const T* __restrict__ ap, T x, T y) {
+__device__ __forceinline__ bool polygon_contains(const T* __restrict__ v, int nv, T tx, T ty) {
+  if (!(tx - tx == T(0) && ty - ty == T(0))) return false;  // non-finite points are outside
+  bool inside = false;
+  T x0 = v[0], y0 = v[1];
+  bool yflag0 = y0 >= ty;
+  for (int k = 1; k <= nv; ++k) {
+    const int j = k == nv ? 0 : k;  // k == nv closes the polygon
+    const T x1 = v[2 * j], y1 = v[2 * j + 1];
+    const bool yflag1 = y1 >= ty;
+    if (yflag0 != yflag1 && (((y1 - ty) * (x0 - x1) >= (x1 - tx) * (y0 - y1)) == yflag1))
+      inside = !inside;
+    yflag0 = yflag1;
+    x0 = x1;
+    y0 = y1;
+  }
+  return inside;
+}
+
+template <typename T>
+__device__ __forceinline__ bool leaf_contains(int kind, const T* __restrict__ ap,
+                                              const T* __restrict__ coeffs, T x, T y) {
   using m = Math<T>;
   switch (kind) {
+    case kApPolygon:
+      return polygon_contains<T>(coeffs + (int)ap[0], (int)ap[1], x, y);
     case kApRadial: {
       T r2 = m::fma(x, x, y * y);
       return (r2 <= ap[1]) && (r2 >= ap[0]);
@@ -727,13 +752,14 @@ __device__ __forceinline__ bool leaf_contains(int kind, const T* __restrict__ ap
 template <typename T>
 __device__ __forceinline__ bool aperture_contains(const DevSurf<T>& s,
                                                   const T* __restrict__ coeffs, T x, T y) {
-  if (s.aperture_kind != kApComposite) return leaf_contains<T>(s.aperture_kind, s.cold->ap, x, y);
+  if (s.aperture_kind != kApComposite)
+    return leaf_contains<T>(s.aperture_kind, s.cold->ap, coeffs, x, y);
   const T* tok = coeffs + s.cold->ap_off;
   uint32_t stack = 0;  // bit 0 = top of stack
   for (int i = 0; i < s.cold->ap_len; ++i, tok += kApTokenLen) {
     const int op = (int)tok[0];
     if (op < kApOpUnion) {
-      stack = (stack << 1) | (leaf_contains<T>(op, tok + 1, x, y) ? 1u : 0u);
+      stack = (stack << 1) | (leaf_contains<T>(op, tok + 1, coeffs, x, y) ? 1u : 0u);
     } else {
       const uint32_t b = stack & 1u, a = (stack >> 1) & 1u;
       const uint32_t v = op == kApOpUnion ? (a | b) : (op == kApOpIntersection ? (a & b) : (a & ~b & 1u));

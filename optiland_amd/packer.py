@@ -166,8 +166,14 @@ def _to_np(v):
     return np.asarray(v)
 
 
-def _leaf_token(ap):
+def _leaf_token(ap, coeffs: list):
     name = type(ap).__name__
+    if name in ("PolygonAperture", "FileAperture"):
+        # polygon.py:37-41: vertices (n, 2); stored x0, y0, x1, y1, ... in the coefficients
+        v = np.asarray(_to_np(ap.vertices), dtype=np.float64).reshape(-1, 2)
+        off = len(coeffs)
+        coeffs.extend(float(c) for c in v.reshape(-1))
+        return [S.AP_POLYGON, float(off), float(v.shape[0]), 0.0, 0.0]
     if name == "RadialAperture":
         return [S.AP_RADIAL, _f(ap.r_min), _f(ap.r_max), 0.0, 0.0]
     if name == "OffsetRadialAperture":
@@ -183,17 +189,17 @@ _BOOL_OPS = {"UnionAperture": S.AP_OP_UNION, "IntersectionAperture": S.AP_OP_INT
              "DifferenceAperture": S.AP_OP_DIFFERENCE}
 
 
-def _flatten_aperture(ap, out: list, depth=1):
+def _flatten_aperture(ap, out: list, coeffs: list):
     """Boolean aperture tree (physical_apertures/base.py:259-340) -> reverse-Polish
     tokens.  Returns the stack depth needed."""
-    leaf = _leaf_token(ap)
+    leaf = _leaf_token(ap, coeffs)
     if leaf is not None:
         out.append(leaf)
         return 1
     name = type(ap).__name__
     if name in _BOOL_OPS:
-        da = _flatten_aperture(ap.a, out)
-        db = _flatten_aperture(ap.b, out)
+        da = _flatten_aperture(ap.a, out, coeffs)
+        db = _flatten_aperture(ap.b, out, coeffs)
         out.append([_BOOL_OPS[name], 0.0, 0.0, 0.0, 0.0])
         return max(da, 1 + db)
     raise UnsupportedSystem(f"aperture {name} is not on the fused path")
@@ -203,13 +209,13 @@ def _pack_aperture(ap, row, coeffs: list):
     row["aperture_kind"] = S.AP_NONE
     if ap is None:
         return
-    leaf = _leaf_token(ap)
+    leaf = _leaf_token(ap, coeffs)
     if leaf is not None:
         row["aperture_kind"] = int(leaf[0])
         row["aperture"] = leaf[1:]
         return
     tokens: list = []
-    depth = _flatten_aperture(ap, tokens)
+    depth = _flatten_aperture(ap, tokens, coeffs)
     if depth > 16:
         raise UnsupportedSystem("boolean aperture nesting deeper than 16")
     row["aperture_kind"] = S.AP_COMPOSITE

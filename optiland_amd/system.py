@@ -27,6 +27,7 @@ GEOM_CHEBYSHEV, GEOM_BICONIC, GEOM_TOROIDAL = 6, 7, 8
 INTERACT_RECORD_ONLY, INTERACT_REFRACT, INTERACT_REFLECT = 0, 1, 2
 AP_NONE, AP_RADIAL, AP_OFFSET_RADIAL, AP_RECTANGULAR, AP_ELLIPTICAL = 0, 1, 2, 3, 4
 AP_COMPOSITE = 5
+AP_POLYGON = 6
 AP_OP_UNION, AP_OP_INTERSECTION, AP_OP_DIFFERENCE = 10, 11, 12
 COAT_NONE, COAT_SIMPLE, COAT_FRESNEL, COAT_POLARIZER, COAT_RETARDER = 0, 1, 2, 3, 4
 SURF_ROTATED = 0x1

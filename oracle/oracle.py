@@ -146,6 +146,16 @@ def polarized_intensity(prt, L0, M0, N0, i0, polarization):
     return out, int(status)
 
 
+def polygon_contains(vertices, x, y):
+    """Restated matplotlib crossings test for an (n, 2) vertex array and point arrays."""
+    v = np.ascontiguousarray(np.asarray(vertices, dtype=np.float64).reshape(-1, 2))
+    f = lib().oracle_polygon_contains
+    f.restype = C.c_int
+    xs, ys = np.atleast_1d(np.asarray(x, float)), np.atleast_1d(np.asarray(y, float))
+    return np.array([bool(f(_ptr(v), C.c_int(v.shape[0]), C.c_double(a), C.c_double(b)))
+                     for a, b in zip(xs, ys)])
+
+
 def sag(table, surface_index, x, y):
     surf = np.ascontiguousarray(table.surfaces[surface_index:surface_index + 1])
     coeffs = np.ascontiguousarray(table.coeffs, dtype=np.float64)

@@ -480,8 +480,33 @@ static void hit_normal(const ol_surface_desc* s, const double* coeffs, double x,
 }
 
 /* ---- physical_apertures/ contains() ------------------------------------ */
-static int leaf_contains(int kind, const double* a, double x, double y) {
+/* polygon.py:54-71 -> backend/numpy_backend.py:1125-1137 ->
+ * matplotlib.path.Path(vertices).contains_points(points) (radius 0): matplotlib's
+ * point_in_path_impl (src/_path.h), the crossings test of Graphics Gems IV over the
+ * implicitly closed polygon; non-finite points are outside.  (matplotlib is a pinned
+ * dependency of the reference, not vendored; tests/test_oracle_polygon.py checks this
+ * restatement against the installed matplotlib where it is importable.)            */
+static int polygon_contains(const double* v, int nv, double tx, double ty) {
+  if (!(isfinite(tx) && isfinite(ty)) || nv < 1) return 0;
+  int inside = 0;
+  double x0 = v[0], y0 = v[1]; /* edge start; the first "edge" is degenerate */
+  int yflag0 = y0 >= ty;
+  for (int k = 1; k <= nv; ++k) {
+    const double x1 = v[2 * (k % nv)], y1 = v[2 * (k % nv) + 1]; /* k == nv closes */
+    const int yflag1 = y1 >= ty;
+    if (yflag0 != yflag1 &&
+        (((y1 - ty) * (x0 - x1) >= (x1 - tx) * (y0 - y1)) == yflag1))
+      inside ^= 1;
+    yflag0 = yflag1;
+    x0 = x1;
+    y0 = y1;
+  }
+  return inside;
+}
+
+static int leaf_contains(int kind, const double* a, const double* coeffs, double x, double y) {
   switch (kind) {
+    case OL_AP_POLYGON: return polygon_contains(coeffs + (int)a[0], (int)a[1], x, y);
     case OL_AP_RADIAL: { /* radial.py:56-70 */
       double r2 = x * x + y * y;
       return (r2 <= a[1] * a[1]) && (r2 >= a[0] * a[0]);
@@ -506,14 +531,14 @@ static int leaf_contains(int kind, const double* a, double x, double y) {
 static int aperture_contains(const ol_surface_desc* s, const double* coeffs, double x,
                              double y) {
   if (s->aperture_kind != OL_AP_COMPOSITE)
-    return leaf_contains(s->aperture_kind, s->aperture, x, y);
+    return leaf_contains(s->aperture_kind, s->aperture, coeffs, x, y);
   const double* tok = coeffs + (int)s->aperture[0];
   int n_tok = (int)s->aperture[1];
   int stack[OL_AP_MAX_DEPTH], sp = 0;
   for (int i = 0; i < n_tok; ++i, tok += OL_AP_TOKEN_DOUBLES) {
     int op = (int)tok[0];
     if (op < OL_AP_OP_UNION) {
-      stack[sp++] = leaf_contains(op, tok + 1, x, y);
+      stack[sp++] = leaf_contains(op, tok + 1, coeffs, x, y);
     } else {
       int b = stack[--sp], a = stack[--sp];
       stack[sp++] = op == OL_AP_OP_UNION ? (a || b)
@@ -889,6 +914,10 @@ void oracle_wavefront_opd(const ol_wavefront_params* p, int64_t n, double* const
 }
 
 /* single-point helpers for the reference's known-answer unit tests */
+int oracle_polygon_contains(const double* vertices, int nv, double x, double y) {
+  return polygon_contains(vertices, nv, x, y);
+}
+
 double oracle_sag(const ol_surface_desc* s, const double* coeffs, double x, double y) {
   uint32_t st = 0;
   if (s->geom_kind == OL_GEOM_PLANE) return 0.0;

@@ -166,6 +166,30 @@ def boolean_apertures():
     return lens
 
 
+def polygon_apertures():
+    """PolygonAperture (physical_apertures/polygon.py; matplotlib point-in-polygon on the
+    NumPy backend): a concave L-shaped stop, and a hexagon minus a triangle inside a
+    boolean tree on the second surface."""
+    pa = physical_apertures
+    lens = optic_mod.Optic(name="PolygonApertures")
+    ell = pa.PolygonAperture(x=[-6.0, 6.0, 6.0, 1.5, 1.5, -6.0], y=[-6.0, -6.0, -1.0, -1.0, 6.0, 6.0])
+    th = np.linspace(0, 2 * np.pi, 7)[:-1] + 0.2
+    hexa = pa.PolygonAperture(x=5.5 * np.cos(th), y=5.5 * np.sin(th))
+    tri = pa.PolygonAperture(x=[-1.0, 2.0, 0.5], y=[-1.0, -0.5, 2.0])
+    ap2 = pa.DifferenceAperture(pa.IntersectionAperture(hexa, pa.RadialAperture(r_max=5.2)), tri)
+    lens.surfaces.add(index=0, radius=be.inf, thickness=be.inf)
+    lens.surfaces.add(index=1, radius=60.0, thickness=5.0, material="N-BK7", is_stop=True,
+                      aperture=ell)
+    lens.surfaces.add(index=2, radius=-80.0, thickness=40.0, aperture=ap2)
+    lens.surfaces.add(index=3)
+    lens.set_aperture(aperture_type="EPD", value=16)
+    lens.fields.set_type(field_type="angle")
+    lens.fields.add(y=0)
+    lens.fields.add(y=3)
+    lens.wavelengths.add(value=0.55, is_primary=True)
+    return lens
+
+
 def f3_family():
     """f3 geometries: biconic, toroidal (with y^2i terms) and Chebyshev."""
     lens = optic_mod.Optic(name="F3Family")
@@ -519,6 +543,7 @@ def main():
     run_case("nr_family", nr_family(), 0.0, 1.0, px * 0.9, py * 0.9, 0.5876)
     run_case("tir_miss", tir_prism(), 0.0, 1.0, px, py, 0.55)
     run_case("boolean_apertures", boolean_apertures(), 0.0, 0.5, px, py, 0.55)
+    run_case("polygon_apertures", polygon_apertures(), 0.0, 0.5, px, py, 0.55)
     run_case("f3_family", f3_family(), 0.0, 1.0, px, py, 0.5876)
     run_case("polarizer_retarder", polarizer_retarder(True), [0.0, 0.0], [0.0, 1.0], None, None,
              0.55, use_trace=dict(num_rays=20, distribution="uniform"))
