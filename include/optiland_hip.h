@@ -270,11 +270,19 @@ int ol_trace_ex(const ol_system* sys, ol_dtype dt, int64_t n_rays,
  * rays/ray_aiming/paraxial.py:33-106).  See ol_raygen_params.                   */
 #define OL_FIELD_ANGLE 0
 #define OL_FIELD_OBJECT_HEIGHT 1
+#define OL_FIELD_PARAXIAL_IMAGE_HEIGHT 2 /* fields/field_types/paraxial_image_height.py:
+                                            the normalised field maps LINEARLY to the
+                                            object-space chief-ray slope (object at
+                                            infinity) or to the object height (finite
+                                            object); `max_field` then carries that
+                                            host-computed scale: u_obj_unit (or
+                                            y_obj_unit) * max_field / y_img_unit        */
 typedef struct ol_raygen_params {
   int32_t object_infinite; /* obj.is_infinite                                 */
-  int32_t field_kind;      /* OL_FIELD_ANGLE | OL_FIELD_OBJECT_HEIGHT          */
+  int32_t field_kind;      /* OL_FIELD_ANGLE | _OBJECT_HEIGHT | _PARAXIAL_IMAGE_HEIGHT */
   double EPL, EPD;         /* paraxial entrance pupil location / diameter     */
-  double max_field;        /* degrees (angle) or lens units (object height)    */
+  double max_field;        /* degrees (angle), lens units (object height), or the
+                              slope / height scale of a paraxial image height field */
   double offset;           /* AngleField._get_starting_z_offset               */
   double z_first;          /* surfaces.positions[1] (infinite) or [0] (finite)*/
   double tele_dz;          /* 0: aim at the paraxial entrance pupil

@@ -28,13 +28,16 @@ template <typename T>
 struct RaygenConsts {
   T EPL, EPD, maxf, off_epl, z_inf, z_fin, epl_z, tele_dz, apod_a, apod_b;
   int apod_kind;
-  bool infinite, height, telecentric;
+  bool infinite, height, linear, telecentric;
   __device__ __forceinline__ explicit RaygenConsts(const RaygenDev& p)
       : EPL((T)p.EPL), EPD((T)p.EPD), maxf((T)p.max_field), off_epl((T)(p.offset + p.EPL)),
         z_inf((T)(p.z_first - p.offset)), z_fin((T)p.z_first), epl_z((T)(p.EPL - p.z_first)),
         tele_dz((T)p.tele_dz), apod_a((T)p.apod_a), apod_b((T)p.apod_b),
-        apod_kind(p.apod_kind), infinite(p.object_infinite != 0), height(p.field_kind == 1),
-        telecentric(p.tele_dz > 0.0) {}
+        apod_kind(p.apod_kind), infinite(p.object_infinite != 0),
+        // the field quantity is a POSITION on the object for object-height fields and
+        // for paraxial-image-height fields with a finite object; otherwise a slope
+        height(p.field_kind == 1 || (p.field_kind == 2 && p.object_infinite == 0)),
+        linear(p.field_kind != 0), telecentric(p.tele_dz > 0.0) {}
 };
 
 // initial intensity from the pupil apodization (ray_generator.py:81-85,
@@ -67,11 +70,12 @@ __device__ __forceinline__ T raygen_apodize(const RaygenConsts<T>& c, T px, T py
   }
 }
 
-// field quantity per axis: tan(field angle) (angle.py:40-47) or the object height
-// (object_height.py:38-41); hoistable when the field is launch-uniform
+// field quantity per axis: tan(field angle) (angle.py:40-47), the object height
+// (object_height.py:38-41), or the paraxially scaled slope / height of an image-height
+// field (paraxial_image_height.py:36-60); hoistable when the field is launch-uniform
 template <typename T>
 __device__ __forceinline__ void raygen_field(const RaygenConsts<T>& c, T hx, T hy, T& tx, T& ty) {
-  if (c.height) {
+  if (c.linear) {  // object height, or paraxial image height (slope or height scale)
     tx = c.maxf * hx;
     ty = c.maxf * hy;
   } else {

@@ -82,7 +82,7 @@ struct RaygenIn {
 template <typename T>
 inline void uniform_field_tangents(const RaygenDev& rg, RaygenIn<T>& in) {
   const T maxf = (T)rg.max_field;
-  if (rg.field_kind == 1) {
+  if (rg.field_kind != 0) {
     in.tx0 = maxf * in.hx0;
     in.ty0 = maxf * in.hy0;
   } else {

@@ -251,7 +251,8 @@ class HipSystem:
         if not rg:
             raise ValueError("this SystemTable carries no ray-generation scalars")
         return _capi.RaygenParams(int(rg["object_infinite"]), int(rg.get("field_kind", 0)),
-                                  rg["EPL"], rg["EPD"], rg["max_field"], rg["offset"],
+                                  rg["EPL"], rg["EPD"],
+                                  float(rg.get("field_scale", rg["max_field"])), rg["offset"],
                                   rg["z_first"], float(rg.get("tele_dz", 0.0)),
                                   float(rg.get("apod_a", 0.0)), float(rg.get("apod_b", 0.0)),
                                   int(rg.get("apod_kind", 0)), 0)

@@ -410,16 +410,17 @@ def _pack_apodization(ap):
 def _compute_raygen(optic, table: SystemTable) -> None:
     """Scalars for on-device ray generation.
 
-    Packed: paraxial aiming, any apodization of optiland/apodization/, for AngleField (object at infinity or
-    finite, fields/field_types/angle.py:17-58) and ObjectHeightField on a planar object
-    (object_height.py:19-47), incl. the object-space-telecentric branch of the aimer
-    (rays/ray_aiming/paraxial.py:33-106).  Otherwise (iterative / robust aiming, image
-    height fields) `table.raygen` stays empty and callers generate rays
-    with the reference's own RayGenerator.
+    Packed: paraxial aiming, any apodization of optiland/apodization/, for AngleField
+    (object at infinity or finite, fields/field_types/angle.py:17-58), ObjectHeightField
+    on a planar object (object_height.py:19-47) and ParaxialImageHeightField
+    (paraxial_image_height.py:19-60), incl. the object-space-telecentric branch of the
+    aimer (rays/ray_aiming/paraxial.py:33-106).  Otherwise (iterative / robust aiming,
+    real image height fields) `table.raygen` stays empty and callers generate rays with
+    the reference's own RayGenerator.
     """
     fd = optic.fields.field_definition
-    kind = {"AngleField": S.FIELD_ANGLE, "ObjectHeightField": S.FIELD_OBJECT_HEIGHT}.get(
-        type(fd).__name__)
+    kind = {"AngleField": S.FIELD_ANGLE, "ObjectHeightField": S.FIELD_OBJECT_HEIGHT,
+            "ParaxialImageHeightField": S.FIELD_PARAXIAL_IMAGE_HEIGHT}.get(type(fd).__name__)
     if kind is None:
         return
     apod = _pack_apodization(optic.apodization)
@@ -430,7 +431,7 @@ def _compute_raygen(optic, table: SystemTable) -> None:
         return
     obj = optic.object_surface
     infinite = bool(obj.is_infinite)
-    if kind == S.FIELD_OBJECT_HEIGHT:
+    if kind == S.FIELD_OBJECT_HEIGHT or (kind == S.FIELD_PARAXIAL_IMAGE_HEIGHT and not infinite):
         # object_height.py:36-47: z0 = obj.geometry.sag(x0, y0) + obj z -- planar objects only
         if infinite or table.surfaces[0]["geom_kind"] != S.GEOM_PLANE:
             return
@@ -438,7 +439,7 @@ def _compute_raygen(optic, table: SystemTable) -> None:
     if optic.obj_space_telecentric:
         # ray_aiming/paraxial.py:82-87, 108-123: object-height fields with an
         # object-NA aperture only; z1 - z0 = sqrt(1 - sin^2) / sin
-        if kind != S.FIELD_OBJECT_HEIGHT or type(optic.aperture).__name__ != "ObjectNAAperture":
+        if kind == S.FIELD_ANGLE or type(optic.aperture).__name__ != "ObjectNAAperture":
             return
         sin = _f(optic.aperture.value)
         if not 0.0 < sin < 1.0:
@@ -455,12 +456,21 @@ def _compute_raygen(optic, table: SystemTable) -> None:
     else:
         offset = 0.0
         z_first = float(pos[0])
+    max_field = _f(optic.fields.max_field)
+    field_scale = max_field
+    if kind == S.FIELD_PARAXIAL_IMAGE_HEIGHT:
+        # paraxial_image_height.py:36-60: two unit paraxial chief-ray traces from the stop
+        # give the linear map from image height to object slope (infinite) / height
+        y_img_unit = _f(fd._trace_unit_chief_ray(optic, plane="image")[0])
+        y_obj_unit, u_obj_unit = (_f(v) for v in fd._trace_unit_chief_ray(optic, plane="object"))
+        field_scale = (u_obj_unit if infinite else y_obj_unit) * max_field / y_img_unit
     table.raygen = {
         "object_infinite": 1.0 if infinite else 0.0,
         "field_kind": float(kind),
+        "field_scale": field_scale,
         "EPL": EPL,
         "EPD": EPD,
-        "max_field": _f(optic.fields.max_field),
+        "max_field": max_field,
         "offset": offset,
         "z_first": z_first,
         "tele_dz": tele_dz,

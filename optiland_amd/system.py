@@ -35,7 +35,7 @@ SURF_ROTATED = 0x1
 STATUS_ZERNIKE_RANGE = 0x1
 STATUS_K_PARALLEL_X = 0x2
 STATUS_CHEBYSHEV_RANGE = 0x4
-FIELD_ANGLE, FIELD_OBJECT_HEIGHT = 0, 1
+FIELD_ANGLE, FIELD_OBJECT_HEIGHT, FIELD_PARAXIAL_IMAGE_HEIGHT = 0, 1, 2
 (APOD_NONE, APOD_GAUSSIAN, APOD_COSINE_SQUARED, APOD_HANN, APOD_POLYNOMIAL, APOD_SUPER_GAUSSIAN,
  APOD_TUKEY) = range(7)
 STATUS_FIELD_RANGE = 0x8

@@ -55,7 +55,9 @@ class Wavefront:
     # strategy.py:83-139: tilt of the launch plane for angle fields at infinity
     def _tilt_cosines(self):
         rg = self.tracer.table.raygen
-        if not rg.get("object_infinite"):
+        # only AngleField at infinity is corrected (strategy.py:113-117); other field
+        # types keep their launch-plane tilt, as in the reference
+        if not rg.get("object_infinite") or int(rg.get("field_kind", 0)) != 0:
             return 0.0, 0.0
         fx = self.field[0] * rg["max_field"]
         fy = self.field[1] * rg["max_field"]

@@ -122,6 +122,7 @@ def generate_rays(raygen: dict, hx, hy, px, py, vx=None, vy=None):
     p["apod_b"] = float(raygen.get("apod_b", 0.0))
     for k in ("EPL", "EPD", "max_field", "offset", "z_first"):
         p[k] = raygen[k]
+    p["max_field"] = float(raygen.get("field_scale", raygen["max_field"]))
     hx, hy, px, py = (np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64),
                       np.broadcast(hx, hy, px, py).shape)).reshape(-1).copy()
                       for a in (hx, hy, px, py))

@@ -810,15 +810,23 @@ void oracle_generate_rays(const ol_raygen_params* p, int64_t n, const double* hx
     double vxx = vx ? vx[j] : 1.0, vyy = vy ? vy[j] : 1.0;
     double field_x = p->max_field * hx[j], field_y = p->max_field * hy[j];
     double x0, y0, z0;
-    if (p->field_kind == OL_FIELD_OBJECT_HEIGHT) {
+    const int linear = p->field_kind != OL_FIELD_ANGLE;
+    if (p->field_kind == OL_FIELD_OBJECT_HEIGHT ||
+        (p->field_kind == OL_FIELD_PARAXIAL_IMAGE_HEIGHT && !p->object_infinite)) {
       /* object_height.py:36-47: x0 = field_x, y0 = field_y, z0 = sag(x0,y0) + obj z
-       * (sag = 0: only planar object surfaces are packed)                         */
+       * (sag = 0: only planar object surfaces are packed); paraxial_image_height.py:
+       * 50-60: the same with field = y_obj_unit * (max_field H / y_img_unit), the
+       * scale folded into max_field by the packer                                 */
       x0 = field_x;
       y0 = field_y;
       z0 = p->z_first;
     } else if (p->object_infinite) {
-      double x = -tan(field_x * d2r) * (p->offset + p->EPL);
-      double y = -tan(field_y * d2r) * (p->offset + p->EPL);
+      /* angle.py:40-47; paraxial_image_height.py:39-49 with the slope
+       * u_obj = u_obj_unit * (max_field H / y_img_unit) in place of the tangent   */
+      double sx = linear ? field_x : tan(field_x * d2r);
+      double sy = linear ? field_y : tan(field_y * d2r);
+      double x = -sx * (p->offset + p->EPL);
+      double y = -sy * (p->offset + p->EPL);
       z0 = p->z_first - p->offset;
       x0 = px[j] * p->EPD / 2 * vxx + x;
       y0 = py[j] * p->EPD / 2 * vyy + y;

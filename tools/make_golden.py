@@ -565,6 +565,22 @@ def main():
     run_case("finite_object_height_trace", finite_conjugate("object_height"),
              [0.0, 0.0, 1 / 3], [0.0, 0.7, 1.0], None, None, 0.55,
              use_trace=dict(num_rays=4, distribution="hexapolar"))
+    # paraxial image height fields: object at infinity (slope scale) and finite (height scale)
+    lens = CookeTriplet()
+    lens.fields.set_type(field_type="paraxial_image_height")
+    lens.fields.fields.clear()
+    lens.fields.add(y=0)
+    lens.fields.add(y=12.0, vx=0.05, vy=0.1)
+    lens.fields.add(y=18.0, x=4.0)
+    run_case("image_height_infinite_generic", lens, hx, hy, px6, py6, 0.55)
+    lens = finite_conjugate("object_height")
+    lens.fields.set_type(field_type="paraxial_image_height")
+    lens.fields.fields.clear()
+    lens.fields.add(y=0)
+    lens.fields.add(y=3.0, vx=0.05, vy=0.1)
+    lens.fields.add(y=5.0, x=1.5)
+    run_case("image_height_finite_trace", lens, [0.0, 0.0, 0.3], [0.0, 0.6, 1.0], None, None, 0.55,
+             use_trace=dict(num_rays=4, distribution="hexapolar"))
     run_case("finite_telecentric_trace", finite_conjugate("object_height", True),
              [0.0, 0.0, 1 / 3], [0.0, 0.7, 1.0], None, None, 0.55,
              use_trace=dict(num_rays=4, distribution="hexapolar"))
