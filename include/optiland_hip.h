@@ -357,6 +357,17 @@ int ol_spot_max_r2(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
                    const void* intensity, double cx, double cy, double* out1,
                    void* stream);
 
+/* Encircled-energy building block (analysis/encircled_energy.py:147-160): for the radii
+ * r_step[0..n_steps) (ascending, device doubles) accumulate
+ *   bins[j] += sum of intensity over rays whose radius about (cx, cy) satisfies
+ *              r_step[j-1] < r <= r_step[j]        (r <= r_step[0] for j = 0),
+ * so that cumsum(bins)[j] = nansum(energy[radii <= r_step[j]]) -- the reference's
+ * curve.  Rays with NaN radius or NaN intensity are skipped (nansum / `<=`), rays
+ * beyond r_step[n_steps-1] fall outside.  bins: n_steps device doubles, accumulated. */
+int ol_radial_energy(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
+                     const void* intensity, double cx, double cy, const double* r_step,
+                     int32_t n_steps, double* bins, void* stream);
+
 /* Fused spot pipeline for one ray block: generate -> trace the whole sequence ->
  * reduce, in ONE kernel (SURVEY.md 8 f1 + f2).  The rays never exist in HBM: each
  * lane builds its rays from the normalised coordinates exactly like

@@ -109,6 +109,7 @@ EXPORTS = (
     "ol_wavefront_opd",
     "ol_trace_spot",
     "ol_trace_ex",
+    "ol_radial_energy",
 )
 
 F32, F64 = 0, 1
@@ -167,6 +168,9 @@ def load():
     lib.ol_trace_spot.restype = C.c_int
     lib.ol_trace_spot.argtypes = [vp, C.c_int, i64, vp, vp, C.c_double, C.c_double, i32,
                                   C.POINTER(vp), vp, vp, vp]
+    lib.ol_radial_energy.restype = C.c_int
+    lib.ol_radial_energy.argtypes = [C.c_int, i64, vp, vp, vp, C.c_double, C.c_double, vp, i32,
+                                     vp, vp]
     lib.ol_set_tuning.restype = C.c_int
     lib.ol_set_tuning.argtypes = [i32, i32]
     if lib.ol_abi_version() != ABI_VERSION:

@@ -265,6 +265,51 @@ __global__ __launch_bounds__(kBlock) void spot_max_r2_kernel(int64_t n, const T*
   }
 }
 
+// analysis/encircled_energy.py:147-160: energy per radius step.  Each workgroup bins
+// its rays into an LDS histogram (binary search over the caller's r_step array, so the
+// `radii <= r` comparisons are the reference's own), then adds its non-empty bins to
+// the global ones.
+constexpr int kMaxEeSteps = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void radial_energy_kernel(
+    int64_t n, const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ inten,
+    double cx, double cy, const double* __restrict__ r_step, int n_steps, double* bins) {
+  __shared__ double hist[kMaxEeSteps];
+  __shared__ double steps[kMaxEeSteps];
+  for (int k = threadIdx.x; k < n_steps; k += kBlock) {
+    hist[k] = 0.0;
+    steps[k] = r_step[k];
+  }
+  __syncthreads();
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * kBlock) {
+    const double e = (double)inten[j];
+    const double dx = (double)x[j] - cx, dy = (double)y[j] - cy;
+    const double r = sqrt(dx * dx + dy * dy);
+    if (!(e == e) || !(r <= steps[n_steps - 1])) continue;  // NaN energy / NaN or far radius
+    int lo = 0, hi = n_steps - 1;  // first index with r <= steps[idx]
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (r <= steps[mid]) hi = mid; else lo = mid + 1;
+    }
+    if (e != 0.0) unsafeAtomicAdd(&hist[lo], e);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < n_steps; k += kBlock)
+    if (hist[k] != 0.0) unsafeAtomicAdd(&bins[k], hist[k]);
+}
+
+template <typename T>
+hipError_t launch_radial_energy(int64_t n, const T* x, const T* y, const T* inten, double cx,
+                                double cy, const double* r_step, int n_steps, double* bins,
+                                hipStream_t stream) {
+  if (n_steps < 1 || n_steps > kMaxEeSteps) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((radial_energy_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, stream, n, x,
+                     y, inten, cx, cy, r_step, n_steps, bins);
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_spot_moments(int64_t n, const T* x, const T* y, const T* inten, double* out6,
                                hipStream_t stream) {
@@ -291,6 +336,9 @@ hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten,
                                           const T*, const T*, T*, T* const[3], hipStream_t);   \
   template hipError_t launch_spot_moments<T>(int64_t, const T*, const T*, const T*, double*,   \
                                              hipStream_t);                                     \
+  template hipError_t launch_radial_energy<T>(int64_t, const T*, const T*, const T*, double,   \
+                                              double, const double*, int, double*,             \
+                                              hipStream_t);                                    \
   template hipError_t launch_spot_max_r2<T>(int64_t, const T*, const T*, const T*, double,     \
                                             double, double*, hipStream_t);
 OL_INST(float)

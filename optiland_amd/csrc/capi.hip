@@ -707,6 +707,30 @@ int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_ra
                                out7, status, st);
 }
 
+int ol_radial_energy(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
+                     const void* intensity, double cx, double cy, const double* r_step,
+                     int32_t n_steps, double* bins, void* stream) {
+  if (!x || !y || !intensity || !r_step || !bins)
+    return fail(OL_EINVAL, "ol_radial_energy: NULL argument");
+  if (n_rays < 0) return fail(OL_EINVAL, "ol_radial_energy: negative count");
+  if (n_steps < 1 || n_steps > 1024)
+    return fail(OL_EINVAL, "ol_radial_energy: n_steps %d outside [1, 1024]", n_steps);
+  if (n_rays == 0) return OL_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (dt == OL_F32)
+    e = ol::launch_radial_energy<float>(n_rays, (const float*)x, (const float*)y,
+                                        (const float*)intensity, cx, cy, r_step, n_steps, bins, st);
+  else if (dt == OL_F64)
+    e = ol::launch_radial_energy<double>(n_rays, (const double*)x, (const double*)y,
+                                         (const double*)intensity, cx, cy, r_step, n_steps, bins,
+                                         st);
+  else
+    return fail(OL_EINVAL, "ol_radial_energy: bad dtype %d", (int)dt);
+  if (e != hipSuccess) return fail(OL_EHIP, "launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
 int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt, int32_t prt_complex,
                            const void* const k0[3], const void* i0,
                            const ol_polarization_state* state, void* intensity,

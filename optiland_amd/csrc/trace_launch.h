@@ -141,6 +141,10 @@ template <typename T>
 hipError_t launch_spot_moments(int64_t n, const T* x, const T* y, const T* inten, double* out6,
                                hipStream_t stream);
 template <typename T>
+hipError_t launch_radial_energy(int64_t n, const T* x, const T* y, const T* inten, double cx,
+                                double cy, const double* r_step, int n_steps, double* bins,
+                                hipStream_t stream);
+template <typename T>
 hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten, double cx,
                               double cy, double* out1, hipStream_t stream);
 

@@ -411,6 +411,25 @@ class HipSystem:
         _capi.check(rc, "ol_spot_moments")
         return out
 
+    def radial_energy(self, x, y, intensity, cx: float, cy: float, r_step: torch.Tensor,
+                      out: torch.Tensor | None = None):
+        """Energy per radius step about (cx, cy) (`ol_radial_energy`); `torch.cumsum` of
+        the result is the reference's encircled-energy curve
+        (analysis/encircled_energy.py:147-160).  `r_step`: ascending float64 device
+        tensor; `out` (accumulated) or a new zeroed tensor of the same length."""
+        if r_step.dtype != torch.float64 or r_step.device != self.device:
+            raise ValueError("r_step must be a float64 tensor on the system's device")
+        r_step = r_step.contiguous()
+        if out is None:
+            out = torch.zeros_like(r_step)
+        with torch.cuda.device(self.device):
+            rc = self.lib.ol_radial_energy(_DT[x.dtype], int(x.numel()), x.data_ptr(),
+                                           y.data_ptr(), intensity.data_ptr(), float(cx),
+                                           float(cy), r_step.data_ptr(), int(r_step.numel()),
+                                           out.data_ptr(), _stream_ptr(self.device))
+        _capi.check(rc, "ol_radial_energy")
+        return out
+
     def spot_max_r2(self, x, y, intensity, cx: float, cy: float):
         out = torch.zeros(1, dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):

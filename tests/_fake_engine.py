@@ -167,6 +167,17 @@ class OracleEngine:
         return torch.tensor([c, xd.sum(), yd.sum(), (xd * xd).sum(), (yd * yd).sum(), c],
                             dtype=torch.float64)
 
+    def radial_energy(self, x, y, intensity, cx, cy, r_step, out=None):
+        r = torch.sqrt((x.double() - cx) ** 2 + (y.double() - cy) ** 2).numpy()
+        e = intensity.double().numpy()
+        rs = r_step.numpy()
+        cum = np.array([np.nansum(e[r <= v]) for v in rs])
+        bins = torch.as_tensor(np.diff(cum, prepend=0.0))
+        if out is None:
+            return bins
+        out += bins
+        return out
+
     def spot_max_r2(self, x, y, intensity, cx, cy):
         m = intensity > 0
         r2 = (x[m].double() - cx) ** 2 + (y[m].double() - cy) ** 2

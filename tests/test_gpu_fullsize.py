@@ -197,3 +197,54 @@ def test_sixty_million_rays_64bit_offsets(dg):
     assert not bool(torch.isnan(res.row(S, 0)).any())
     del rec, res
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_radial_energy_kernel_equals_definition(dg, dtype):
+    """ol_radial_energy: cumsum(bins)[j] == nansum(energy[radii <= r_step[j]])
+    (analysis/encircled_energy.py:147-160) incl. NaN radii / energies, rays exactly on a
+    step and rays beyond the last step."""
+    hip, _ = dg
+    n = 1_000_003
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = (torch.randn(n, generator=g, device=DEV, dtype=torch.float64) * 0.02 + 3.0).to(dtype)
+    y = (torch.randn(n, generator=g, device=DEV, dtype=torch.float64) * 0.03 - 1.0).to(dtype)
+    e = torch.rand(n, generator=g, device=DEV, dtype=torch.float64).to(dtype)
+    e[::11] = 0
+    e[5::1001] = float("nan")
+    x[7::997] = float("nan")
+    cx, cy = 3.0, -1.0
+    r_step = torch.linspace(0, 0.08, 256, dtype=torch.float64, device=DEV)
+    x[:4], y[:4] = cx, cy
+    y[1] = cy + float(r_step[10])   # exactly on a step (fp64 case)
+    bins = hip.radial_energy(x, y, e, cx, cy, r_step)
+    got = torch.cumsum(bins, 0).cpu().numpy()
+    xd, yd, ed = x.double().cpu().numpy(), y.double().cpu().numpy(), e.double().cpu().numpy()
+    r = np.sqrt((xd - cx) ** 2 + (yd - cy) ** 2)
+    order = np.argsort(np.where(np.isnan(r), np.inf, r))
+    rs, es = r[order], np.where(np.isnan(ed[order]), 0.0, ed[order])
+    cum = np.concatenate([[0.0], np.cumsum(es)])
+    want = cum[np.searchsorted(rs, r_step.cpu().numpy(), side="right")]
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-9)
+    # accumulation into a caller buffer
+    out = bins.clone()
+    hip.radial_energy(x, y, e, cx, cy, r_step, out=out)
+    np.testing.assert_allclose(out.cpu().numpy(), 2 * bins.cpu().numpy(), rtol=1e-12)
+
+
+def test_encircled_energy_analysis_on_device():
+    from optiland_amd import load_system, tracer as tr
+    from optiland_amd.analysis import EncircledEnergy
+    table = load_system("cooke_generic")
+    for dtype in (torch.float64, torch.float32):
+        t = tr.HipRayTracer(table, DEV, dtype=dtype)
+        ee = EncircledEnergy(t, wavelength=0.55, num_rays=20_000, distribution="random",
+                             num_points=128)
+        assert ee.ee.shape == (3, 128)
+        for k, (h, c) in enumerate(zip(ee._hits, ee._centers)):
+            x, y, e = (v.double().cpu().numpy() for v in h)
+            r = np.sqrt((x - c[0]) ** 2 + (y - c[1]) ** 2)
+            want = np.array([np.nansum(e[r <= v]) for v in ee.r_step])
+            np.testing.assert_allclose(ee.ee[k], want, rtol=1e-9, atol=1e-9)
+            assert ee.ee[k][-1] == pytest.approx(np.nansum(e), rel=1e-12)
+        t.engine.close()

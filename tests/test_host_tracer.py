@@ -166,3 +166,21 @@ def test_vignetting_factors_trace_and_trace_generic():
     t.trace_generic(data["Hx"], data["Hy"], data["Px"], data["Py"], 0.55)
     assert_close_planes(_stack(t.surfaces), data["record"], 1e-10, 1e-11,
                         "vignetted trace_generic()")
+
+
+def test_encircled_energy_host_logic():
+    """EncircledEnergy on the oracle-backed engine == the reference's definition
+    (analysis/encircled_energy.py:147-160) evaluated with numpy on the same hits."""
+    from optiland_amd import load_system
+    from optiland_amd.analysis import EncircledEnergy
+    table = load_system("cooke_generic")
+    t = tr.HipRayTracer(table, dtype=torch.float64)
+    ee = EncircledEnergy(t, wavelength=0.55, num_rays=8, distribution="hexapolar", num_points=64)
+    assert ee.ee.shape == (len(ee.fields), 64) and ee.r_step[0] == 0.0
+    for k, (h, c) in enumerate(zip(ee._hits, ee._centers)):
+        x, y, e = (v.double().numpy() for v in h)
+        r = np.sqrt((x - c[0]) ** 2 + (y - c[1]) ** 2)
+        want = np.array([np.nansum(e[r <= v]) for v in ee.r_step])
+        np.testing.assert_allclose(ee.ee[k], want, rtol=1e-12, atol=1e-12)
+        assert ee.ee[k][-1] == pytest.approx(np.nansum(e))  # everything inside 1.2 r_max
+    assert np.all(np.diff(ee.ee, axis=1) >= 0)
