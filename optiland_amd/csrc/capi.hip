@@ -155,6 +155,7 @@ struct ol_system {
   std::vector<int32_t> interaction;  // host copy for validation
   std::vector<int32_t> coating;
   std::vector<int32_t> geom;
+  std::vector<uint8_t> polygon;  // surface uses a polygon aperture (top level or in a tree)
 };
 
 namespace {
@@ -263,7 +264,8 @@ int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* c
   }
   bool has_newton = false;  // any Newton-Raphson geometry in the traced range?
   for (int32_t s = first; s <= last; ++s)
-    has_newton = has_newton || (sys->geom[s] != OL_GEOM_PLANE && sys->geom[s] != OL_GEOM_STANDARD);
+    has_newton = has_newton || sys->polygon[s] ||  // polygons live in the full kernels only
+                 (sys->geom[s] != OL_GEOM_PLANE && sys->geom[s] != OL_GEOM_STANDARD);
   hipError_t e = ol::launch_trace<T>(a, vec, has_newton, stream);
   if (e != hipSuccess) return fail(OL_EHIP, "trace launch failed: %s", hipGetErrorString(e));
   return OL_OK;
@@ -351,7 +353,8 @@ int do_trace_spot(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
   a.tiles_per_block = 1;
   bool has_newton = false;
   for (int32_t s = 0; s < sys->n_surf; ++s)
-    has_newton = has_newton || (sys->geom[s] != OL_GEOM_PLANE && sys->geom[s] != OL_GEOM_STANDARD);
+    has_newton = has_newton || sys->polygon[s] ||
+                 (sys->geom[s] != OL_GEOM_PLANE && sys->geom[s] != OL_GEOM_STANDARD);
   hipError_t e = ol::launch_spot_trace<T>(a, vec, has_newton, stream);
   if (e != hipSuccess) return fail(OL_EHIP, "spot launch failed: %s", hipGetErrorString(e));
   return OL_OK;
@@ -576,6 +579,15 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
     sys->interaction.push_back(surf[i].interaction);
     sys->coating.push_back(surf[i].coating_kind);
     sys->geom.push_back(surf[i].geom_kind);
+    {
+      bool poly = surf[i].aperture_kind == OL_AP_POLYGON;
+      if (surf[i].aperture_kind == OL_AP_COMPOSITE) {
+        const int64_t off = (int64_t)surf[i].aperture[0], cnt = (int64_t)surf[i].aperture[1];
+        for (int64_t t = 0; t < cnt; ++t)
+          poly = poly || (int)coeffs[off + t * OL_AP_TOKEN_DOUBLES] == OL_AP_POLYGON;
+      }
+      sys->polygon.push_back(poly ? 1 : 0);
+    }
   }
   if (hipGetDevice(&sys->device) != hipSuccess) {
     delete sys;

@@ -706,6 +706,7 @@ __device__ __forceinline__ bool polygon_contains(const T* __restrict__ v, int nv
   bool inside = false;
   T x0 = v[0], y0 = v[1];
   bool yflag0 = y0 >= ty;
+#pragma nounroll  // rare path: keep it out of the register budget of every kernel
   for (int k = 1; k <= nv; ++k) {
     const int j = k == nv ? 0 : k;  // k == nv closes the polygon
     const T x1 = v[2 * j], y1 = v[2 * j + 1];
@@ -719,13 +720,17 @@ __device__ __forceinline__ bool polygon_contains(const T* __restrict__ v, int nv
   return inside;
 }
 
-template <typename T>
+// FULL: the polygon test is compiled only into the "full" (NR != 0) kernel variants --
+// the host routes systems with polygon apertures there; in the lean conic-only kernels
+// it cost 12 VGPRs (46 -> 58) for a case that almost never occurs
+template <typename T, bool FULL>
 __device__ __forceinline__ bool leaf_contains(int kind, const T* __restrict__ ap,
                                               const T* __restrict__ coeffs, T x, T y) {
   using m = Math<T>;
+  if constexpr (FULL) {
+    if (kind == kApPolygon) return polygon_contains<T>(coeffs + (int)ap[0], (int)ap[1], x, y);
+  }
   switch (kind) {
-    case kApPolygon:
-      return polygon_contains<T>(coeffs + (int)ap[0], (int)ap[1], x, y);
     case kApRadial: {
       T r2 = m::fma(x, x, y * y);
       return (r2 <= ap[1]) && (r2 >= ap[0]);
@@ -749,17 +754,17 @@ __device__ __forceinline__ bool leaf_contains(int kind, const T* __restrict__ ap
 // Boolean trees (physical_apertures/base.py:259-340) arrive as reverse-Polish
 // tokens; the evaluation stack is one bit per entry in a 32-bit register
 // (depth <= 16 checked on the host).  Token stream and op codes are wave-uniform.
-template <typename T>
+template <typename T, bool FULL>
 __device__ __forceinline__ bool aperture_contains(const DevSurf<T>& s,
                                                   const T* __restrict__ coeffs, T x, T y) {
   if (s.aperture_kind != kApComposite)
-    return leaf_contains<T>(s.aperture_kind, s.cold->ap, coeffs, x, y);
+    return leaf_contains<T, FULL>(s.aperture_kind, s.cold->ap, coeffs, x, y);
   const T* tok = coeffs + s.cold->ap_off;
   uint32_t stack = 0;  // bit 0 = top of stack
   for (int i = 0; i < s.cold->ap_len; ++i, tok += kApTokenLen) {
     const int op = (int)tok[0];
     if (op < kApOpUnion) {
-      stack = (stack << 1) | (leaf_contains<T>(op, tok + 1, coeffs, x, y) ? 1u : 0u);
+      stack = (stack << 1) | (leaf_contains<T, FULL>(op, tok + 1, coeffs, x, y) ? 1u : 0u);
     } else {
       const uint32_t b = stack & 1u, a = (stack >> 1) & 1u;
       const uint32_t v = op == kApOpUnion ? (a | b) : (op == kApOpIntersection ? (a & b) : (a & ~b & 1u));
@@ -960,18 +965,19 @@ __device__ __forceinline__ void into_local_frame(const DevSurf<typename Math<V>:
 // everything after the hit point is known: absorb, opd, clip, refract/reflect,
 // coating, PRT.  (nx, ny, nz) is the unit surface normal at the hit.
 // lane-wise aperture test: the scalar predicate per ray of the pack
-template <typename V>
+template <typename V, bool FULL>
 __device__ __forceinline__ typename Math<V>::mask aperture_mask(
     const DevSurf<typename Math<V>::scalar>& s, const typename Math<V>::scalar* __restrict__ coeffs,
     V x, V y) {
   if constexpr (Math<V>::lanes == 1) {
-    return aperture_contains(s, coeffs, x, y);
+    return aperture_contains<typename Math<V>::scalar, FULL>(s, coeffs, x, y);
   } else {
-    return {aperture_contains(s, coeffs, x.x, y.x), aperture_contains(s, coeffs, x.y, y.y)};
+    return {aperture_contains<typename Math<V>::scalar, FULL>(s, coeffs, x.x, y.x),
+            aperture_contains<typename Math<V>::scalar, FULL>(s, coeffs, x.y, y.y)};
   }
 }
 
-template <typename V, int RPT, int POLK>
+template <typename V, int RPT, int POLK, bool FULL>
 __device__ __forceinline__ void interact(const DevSurf<typename Math<V>::scalar>& s,
                                          const DevOptics<typename Math<V>::scalar>& o,
                                          const typename Math<V>::scalar* __restrict__ coeffs,
@@ -994,7 +1000,7 @@ __device__ __forceinline__ void interact(const DevSurf<typename Math<V>::scalar>
   if (s.aperture_kind != kApNone) {
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
-      r[k].i = m::select(aperture_mask<V>(s, coeffs, r[k].x, r[k].y), r[k].i, zero);
+      r[k].i = m::select(aperture_mask<V, FULL>(s, coeffs, r[k].x, r[k].y), r[k].i, zero);
   }
 
   // refract / reflect (real_rays.py:163-205, 535-571)
@@ -1215,7 +1221,7 @@ __device__ __forceinline__ void surface_step(const DevSurf<typename Math<V>::sca
 #pragma unroll
     for (int k = 0; k < RPT; ++k) t[k] = nx[k] = ny[k] = nz[k] = m::splat(0);
   }
-  interact<V, RPT, POLK>(s, o, coeffs, t, nx, ny, nz, r, P);
+  interact<V, RPT, POLK, NR != 0>(s, o, coeffs, t, nx, ny, nz, r, P);
 }
 
 // local -> global for the recorded state (coordinate_system.py:91-107)
