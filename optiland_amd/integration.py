@@ -28,6 +28,7 @@ import numpy as np
 import torch
 
 from . import tracer as _tracer
+from . import _capi
 from .packer import UnsupportedSystem, pack_optic
 from .rays import _state_dict, prt_to_complex
 
@@ -120,24 +121,54 @@ def _make_tracer_class():
             return self._hip_engine, self._hip_table
 
         # ---------------------------------------------------------------- trace
-        def _hip_trace(self, Hx, Hy, Px, Py, wavelength, update_intensity):
+        @staticmethod
+        def _scalar(v):
+            """float(v) for scalar-like field coordinates (python / numpy / 0-d or
+            one-element backend values), else None."""
+            try:
+                a = np.asarray(be.to_numpy(v), dtype=np.float64)
+            except Exception:
+                return None
+            return float(a.reshape(-1)[0]) if a.size == 1 else None
+
+        def _hip_trace(self, Hx, Hy, Px, Py, wavelength, update_intensity, prescale=False):
+            """Hx, Hy: two floats (ONE field point: launch-uniform scalars, no field or
+            vignetting planes are built) or per-ray arrays; Px, Py: per-ray arrays.
+            prescale: trace_generic's (1 - v) pre-scaling of the pupil, done in-kernel."""
             eng, table = self._engine_for(wavelength)
             dtype, dev = self._dtype(), eng.device
             as_dev = lambda a: torch.as_tensor(  # noqa: E731
                 np.array(be.to_numpy(a), dtype=np.float64) if not isinstance(a, torch.Tensor) else a,
                 dtype=dtype, device=dev).reshape(-1).contiguous()
+            uniform = isinstance(Hx, float) and isinstance(Hy, float)
             # the rays are generated (or copied) straight into row 0 of the record
             # block: the object surface only records its input (zero-copy object row)
             if table.raygen:
-                hx, hy, px, py = (as_dev(a) for a in (Hx, Hy, Px, Py))
-                n = int(hx.numel())
+                px, py = as_dev(Px), as_dev(Py)
+                n = int(px.numel())
                 record = eng.alloc_record(n, dtype)
                 rays = eng.row0_planes(record, n)
                 vxf, vyf = self.optic.fields.get_vig_factor(Hx, Hy)
-                vx = as_dev(1 - np.asarray(be.to_numpy(vxf), dtype=np.float64) * np.ones(n))
-                vy = as_dev(1 - np.asarray(be.to_numpy(vyf), dtype=np.float64) * np.ones(n))
-                eng.generate_rays(hx, hy, px, py, vx, vy, out=rays)  # zero-fills the opd plane
+                flags = _capi.RAYGEN_PRESCALE_PUPIL if prescale else 0
+                if uniform:
+                    vx = 1.0 - float(np.asarray(be.to_numpy(vxf), dtype=np.float64).reshape(-1)[0])
+                    vy = 1.0 - float(np.asarray(be.to_numpy(vyf), dtype=np.float64).reshape(-1)[0])
+                    eng.generate_rays(Hx, Hy, px, py, vx, vy, out=rays, flags=flags)
+                else:
+                    hx, hy = as_dev(Hx), as_dev(Hy)
+                    vx = as_dev(1 - np.asarray(be.to_numpy(vxf), dtype=np.float64) * np.ones(n))
+                    vy = as_dev(1 - np.asarray(be.to_numpy(vyf), dtype=np.float64) * np.ones(n))
+                    eng.generate_rays(hx, hy, px, py, vx, vy, out=rays, flags=flags)
             else:  # aiming/field type the device generator does not cover
+                if uniform:
+                    Hx = np.full(np.size(be.to_numpy(Px)), Hx)
+                    Hy = np.full(np.size(be.to_numpy(Px)), Hy)
+                if prescale:  # real_ray_tracer.py:134-137
+                    vxf, vyf = self.optic.fields.get_vig_factor(Hx, Hy)
+                    Px = np.asarray(be.to_numpy(Px), dtype=np.float64) * \
+                        (1 - np.asarray(be.to_numpy(vxf), dtype=np.float64))
+                    Py = np.asarray(be.to_numpy(Py), dtype=np.float64) * \
+                        (1 - np.asarray(be.to_numpy(vyf), dtype=np.float64))
                 r = self.ray_generator.generate_rays(Hx, Hy, Px, Py, wavelength)
                 src = [as_dev(getattr(r, k)) for k in ("x", "y", "z", "L", "M", "N", "i")]
                 n = int(src[0].numel())
@@ -202,12 +233,16 @@ def _make_tracer_class():
                     distribution = create_distribution(distribution)
                     distribution.generate_points(num_rays)
                 Px, Py = be.to_numpy(distribution.x), be.to_numpy(distribution.y)
-                Hxa = np.atleast_1d(np.asarray(be.to_numpy(Hx), dtype=np.float64))
-                Hya = np.atleast_1d(np.asarray(be.to_numpy(Hy), dtype=np.float64))
-                nf, npup = Hxa.size, Px.size
-                out = self._hip_trace(np.repeat(Hxa, npup), np.repeat(Hya, npup),
-                                      np.tile(Px, nf), np.tile(Py, nf), wavelength,
-                                      update_intensity=True)
+                sx, sy = self._scalar(Hx), self._scalar(Hy)
+                if sx is not None and sy is not None:  # one field point
+                    out = self._hip_trace(sx, sy, Px, Py, wavelength, update_intensity=True)
+                else:
+                    Hxa = np.atleast_1d(np.asarray(be.to_numpy(Hx), dtype=np.float64))
+                    Hya = np.atleast_1d(np.asarray(be.to_numpy(Hy), dtype=np.float64))
+                    nf, npup = Hxa.size, Px.size
+                    out = self._hip_trace(np.repeat(Hxa, npup), np.repeat(Hya, npup),
+                                          np.tile(Px, nf), np.tile(Py, nf), wavelength,
+                                          update_intensity=True)
             except UnsupportedSystem:
                 self.last_path = "reference"
                 return _ORIGINALS["trace"](self, Hx, Hy, wavelength, num_rays, distribution)
@@ -221,15 +256,18 @@ def _make_tracer_class():
             self._validate_normalized_coordinates(Hx, Hy, "field")
             self._validate_normalized_coordinates(Px, Py, "pupil")
             try:
-                vx, vy = self.optic.fields.get_vig_factor(Hx, Hy)
+                sx, sy = self._scalar(Hx), self._scalar(Hy)
                 arrs = [np.atleast_1d(np.asarray(be.to_numpy(a), dtype=np.float64))
                         for a in (Hx, Hy, Px, Py)]
                 n = max(a.size for a in arrs)
                 Hxa, Hya, Pxa, Pya = (np.broadcast_to(a, (n,)) if a.size == 1 else a
                                       for a in arrs)
-                Pxa = Pxa * (1 - np.asarray(be.to_numpy(vx), dtype=np.float64))
-                Pya = Pya * (1 - np.asarray(be.to_numpy(vy), dtype=np.float64))
-                out = self._hip_trace(Hxa, Hya, Pxa, Pya, wavelength, update_intensity=False)
+                if sx is not None and sy is not None:
+                    out = self._hip_trace(sx, sy, Pxa, Pya, wavelength, update_intensity=False,
+                                          prescale=True)
+                else:
+                    out = self._hip_trace(Hxa, Hya, Pxa, Pya, wavelength,
+                                          update_intensity=False, prescale=True)
             except UnsupportedSystem:
                 self.last_path = "reference"
                 return _ORIGINALS["trace_generic"](self, Hx, Hy, Px, Py, wavelength)
