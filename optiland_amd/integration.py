@@ -24,6 +24,8 @@ installed (e.g. the GPU test box).
 
 from __future__ import annotations
 
+import collections
+
 import numpy as np
 import torch
 
@@ -67,6 +69,7 @@ def _table_key(table):
 
 _TRACER_CLASS = None
 _ORIGINALS = {}
+_MAX_ENGINES = 8  # device tables kept per tracer (a few kB each)
 
 
 def _make_tracer_class():
@@ -86,8 +89,11 @@ def _make_tracer_class():
             super().__init__(optic)
             self._hip_device = device
             self._hip_force = force  # tests: intercept regardless of backend/device
-            self._hip_key = None
-            self._hip_engine = None
+            # packed-table fingerprint -> (engine, table): analyses alternate between the
+            # optic's wavelengths call by call, so the last few device tables stay alive
+            # instead of being re-created for every (field, wavelength) trace
+            self._hip_engines = collections.OrderedDict()
+            self._hip_engine = None  # most recently used (introspection)
             self._hip_table = None
             self.last_path = None  # "hip" | "reference" (introspection for tests)
 
@@ -113,12 +119,18 @@ def _make_tracer_class():
             w = float(wavelength.item()) if hasattr(wavelength, "item") else float(wavelength)
             table = pack_optic(self.optic, wavelengths=[w])
             key = _table_key(table)
-            if key != self._hip_key:
-                if self._hip_engine is not None and hasattr(self._hip_engine, "close"):
-                    self._hip_engine.close()
-                self._hip_engine = _tracer._make_engine(table, self._hip_device)
-                self._hip_key, self._hip_table = key, table
-            return self._hip_engine, self._hip_table
+            hit = self._hip_engines.get(key)
+            if hit is None:
+                hit = (_tracer._make_engine(table, self._hip_device), table)
+                self._hip_engines[key] = hit
+                while len(self._hip_engines) > _MAX_ENGINES:  # evict least recently used
+                    _, (old, _t) = self._hip_engines.popitem(last=False)
+                    if hasattr(old, "close"):
+                        old.close()
+            else:
+                self._hip_engines.move_to_end(key)
+            self._hip_engine, self._hip_table = hit
+            return hit
 
         # ---------------------------------------------------------------- trace
         @staticmethod

@@ -289,3 +289,24 @@ def test_packer_memoises_paraxial_scalars_and_invalidates(ref, monkeypatch):
     # against a fresh computation
     monkeypatch.setattr(Paraxial, "EPL", orig)
     assert d.raygen["EPL"] == pytest.approx(float(np.asarray(lens.paraxial.EPL()).reshape(-1)[0]))
+
+
+def test_dropin_keeps_device_tables_per_wavelength(hip_on_cpu):
+    """Alternating wavelengths (what SpotDiagram does per field) reuses the device tables
+    instead of re-creating one per call; a change of the prescription makes a new one."""
+    from optiland.samples.objectives import CookeTriplet
+    from optiland_amd import integration
+    lens = CookeTriplet()
+    integration.install(lens, force=True)
+    t = lens.ray_tracer
+    for _ in range(3):
+        for w in (0.48, 0.55, 0.65):
+            lens.trace(0.0, 0.7, w, num_rays=3, distribution="hexapolar")
+    assert len(t._hip_engines) == 3
+    engines = {id(e) for e, _ in t._hip_engines.values()}
+    for w in (0.48, 0.55, 0.65):
+        lens.trace(0.0, 0.0, w, num_rays=3, distribution="hexapolar")
+    assert {id(e) for e, _ in t._hip_engines.values()} == engines
+    lens.surfaces[2].geometry.radius = float(lens.surfaces[2].geometry.radius) * 1.02
+    lens.trace(0.0, 0.0, 0.55, num_rays=3, distribution="hexapolar")
+    assert len(t._hip_engines) == 4
