@@ -418,7 +418,9 @@ int ol_wavefront_opd(const ol_wavefront_params* p, ol_dtype dt, int64_t n_rays,
 /* Profiling knobs (process-wide, not part of the trace semantics).
  *   OL_TUNE_RAYS_PER_THREAD  0 = auto (16-byte vector of rays per lane for conic-only
  *                            ranges, one ray per lane when Newton surfaces are
- *                            present), 1 = one ray per lane, 2 = force the vector
+ *                            present), 1 = one ray per lane, 2 = force the vector,
+ *                            3 = fp32 lean ranges: one packed PAIR of rays per lane
+ *                            (8-byte loads / stores; measured slower, kept for A/B)
  *   OL_TUNE_COMPACT          1 = wavefront straggler compaction in the Newton loop
  *                            (needs the vector layout; default 0, measured slower)
  * The environment variable OL_TRACE_RPT seeds OL_TUNE_RAYS_PER_THREAD.           */

@@ -370,8 +370,9 @@ int32_t ol_abi_version(void) { return OL_ABI_VERSION; }
 int ol_set_tuning(int32_t knob, int32_t value) {
   switch (knob) {
     case OL_TUNE_RAYS_PER_THREAD:
-      if (value < 0 || value > 2)
-        return fail(OL_EINVAL, "ol_set_tuning: rays per thread must be 0 (auto), 1 or 2 (vector)");
+      if (value < 0 || value > 3)
+        return fail(OL_EINVAL, "ol_set_tuning: rays per thread must be 0 (auto), 1, 2 (vector) "
+                               "or 3 (fp32 pair)");
       ol::tuning().rays_per_thread = value;
       return OL_OK;
     case OL_TUNE_COMPACT:

@@ -1254,7 +1254,7 @@ struct LanePack {
 #define OL_PACKED_F32 1
 #endif
   static constexpr bool packed =
-      OL_PACKED_F32 && sizeof(T) == 4 && RPT == 4 && POLK == 0 && NR == 0;
+      OL_PACKED_F32 && sizeof(T) == 4 && (RPT == 4 || RPT == 2) && POLK == 0 && NR == 0;
   using V = typename std::conditional<packed, f32x2, T>::type;
   static constexpr int NV = packed ? RPT / 2 : RPT;
   // ray k of the thread: element (k % lanes) of pack (k / lanes)
@@ -1324,11 +1324,12 @@ __device__ __forceinline__ void store_plane(T* __restrict__ p, int64_t base, int
       V v;
 #pragma unroll
       for (int k = 0; k < RPT; ++k) v[k] = in[k];
-#if OL_NT_VECTOR
-      __builtin_nontemporal_store(v, reinterpret_cast<V*>(p + base));
-#else
-      *reinterpret_cast<V*>(p + base) = v;
-#endif
+      // 8-byte lane vectors behave like the scalar fp64 stores (non-temporal wins);
+      // 16-byte ones prefer plain stores
+      if constexpr (OL_NT_VECTOR || sizeof(V) <= 8)
+        __builtin_nontemporal_store(v, reinterpret_cast<V*>(p + base));
+      else
+        *reinterpret_cast<V*>(p + base) = v;
     } else {
 #pragma unroll
       for (int k = 0; k < RPT; ++k)
@@ -1701,6 +1702,24 @@ static hipError_t launch_rpt(const TraceArgs<T>& a, int nr, hipStream_t stream) 
   return launch_nr<T, RPT, 1>(a, stream);
 }
 
+// fp32, two rays per lane = ONE packed pair, 8-byte loads / stores (lean unpolarised
+// ranges only)
+template <typename T>
+static hipError_t launch_pair(const TraceArgs<T>& a, hipStream_t stream) {
+  const int64_t threads = (a.n + 1) / 2;
+  const int64_t blocks = (threads + kTraceBlock - 1) / kTraceBlock;
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  dim3 grid((unsigned)blocks), block(kTraceBlock);
+  if (a.record != nullptr)
+    hipLaunchKernelGGL((trace_kernel<T, 2, true, 0, 0, false>), grid, block, 0, stream, a.surf,
+                       a.cold, a.optics, a.coeffs, a);
+  else
+    hipLaunchKernelGGL((trace_kernel<T, 2, false, 0, 0, false>), grid, block, 0, stream, a.surf,
+                       a.cold, a.optics, a.coeffs, a);
+  return hipGetLastError();
+}
+
 Tuning& tuning() {
   static Tuning t = [] {
     Tuning v;
@@ -1728,6 +1747,10 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
   //  * compaction only on request (measured slower on every surface tried: Newton
   //    iteration counts are nearly uniform across a wave once the stop rule is per ray).
   const int want = tuning().rays_per_thread;
+  if constexpr (sizeof(T) == 4) {
+    if (want == 3 && nr == 0 && a.prt == nullptr && a.spot == nullptr)
+      return launch_pair<T>(a, stream);
+  }
   const bool prefer_one = nr == 1 || a.record != nullptr;
   if (want == 1 || (want == 0 && prefer_one && nr != 2))
     return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
