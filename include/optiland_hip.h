@@ -368,6 +368,20 @@ int ol_radial_energy(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
                      const void* intensity, double cx, double cy, const double* r_step,
                      int32_t n_steps, double* bins, void* stream);
 
+/* Detector irradiance building block (analysis/irradiance.py:341-353): numpy.histogram2d
+ * of the ray hits weighted by power, with explicit edges:
+ *   hist[ix * ny + iy] += power  for rays with power > 0 and
+ *   x_edges[ix] <= x < x_edges[ix+1], y_edges[iy] <= y < y_edges[iy+1]
+ * (the LAST bin of each axis also takes its right edge, as numpy does); rays outside
+ * the edges, with non-finite coordinates or with power <= 0 / NaN are dropped.
+ * x_edges: nx + 1, y_edges: ny + 1 ascending device doubles; hist: nx * ny device
+ * doubles, accumulated (so ray shards -- and ranks, through an all-reduce of the
+ * bins -- add up: the reduction that replaces the all-gather of hits for imaging
+ * consumers).                                                        */
+int ol_irradiance(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
+                  const void* power, const double* x_edges, int32_t nx,
+                  const double* y_edges, int32_t ny, double* hist, void* stream);
+
 /* Fused spot pipeline for one ray block: generate -> trace the whole sequence ->
  * reduce, in ONE kernel (SURVEY.md 8 f1 + f2).  The rays never exist in HBM: each
  * lane builds its rays from the normalised coordinates exactly like

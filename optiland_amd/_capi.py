@@ -110,6 +110,7 @@ EXPORTS = (
     "ol_trace_spot",
     "ol_trace_ex",
     "ol_radial_energy",
+    "ol_irradiance",
 )
 
 F32, F64 = 0, 1
@@ -168,6 +169,8 @@ def load():
     lib.ol_trace_spot.restype = C.c_int
     lib.ol_trace_spot.argtypes = [vp, C.c_int, i64, vp, vp, C.c_double, C.c_double, i32,
                                   C.POINTER(vp), vp, vp, vp]
+    lib.ol_irradiance.restype = C.c_int
+    lib.ol_irradiance.argtypes = [C.c_int, i64, vp, vp, vp, vp, i32, vp, i32, vp, vp]
     lib.ol_radial_energy.restype = C.c_int
     lib.ol_radial_energy.argtypes = [C.c_int, i64, vp, vp, vp, C.c_double, C.c_double, vp, i32,
                                      vp, vp]

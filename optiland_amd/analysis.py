@@ -206,3 +206,46 @@ class EncircledEnergy:
     def centroid(self):
         """encircled_energy.py:117-131: plain mean of the hit coordinates per field."""
         return [(float(h[0].double().mean()), float(h[1].double().mean())) for h in self._hits]
+
+
+class IncoherentIrradiance:
+    """Detector irradiance map on device (analysis/irradiance.py:251-353, the
+    non-differentiable path): trace `num_rays` pupil points of `distribution` for one
+    field and wavelength, bin the detector-plane hits with `numpy.histogram2d` semantics
+    weighted by the ray power (rays with power > 0 only), divide by the pixel area.
+
+    `extent` = (x_min, x_max, y_min, y_max) of the detector in its local frame (the
+    reference takes it from the detector surface's aperture); `res` = (npix_x, npix_y).
+    The hits stay on the GPU: one trace + one `ol_irradiance` histogram pass; sharded
+    runs add their `power_map`s (an all-reduce of H x W bins instead of an all-gather of
+    hits)."""
+
+    def __init__(self, tracer, field, wavelength, extent, res=(128, 128), num_rays: int = 100,
+                 distribution: str = "uniform"):
+        import torch
+        table = tracer.table
+        s = table.surfaces[-1]
+        if s["flags"] & 1:
+            raise NotImplementedError("irradiance on a tilted detector surface")
+        ox, oy = float(s["origin"][0]), float(s["origin"][1])
+        self.npix_x, self.npix_y = int(res[0]), int(res[1])
+        x_min, x_max, y_min, y_max = (float(v) for v in extent)
+        self.x_edges = np.linspace(x_min, x_max, self.npix_x + 1, dtype=float)
+        self.y_edges = np.linspace(y_min, y_max, self.npix_y + 1, dtype=float)
+        self.pixel_area = (self.x_edges[1] - self.x_edges[0]) * (self.y_edges[1] - self.y_edges[0])
+        old = tracer.record_all
+        tracer.record_all = False
+        try:
+            rays = tracer.trace(field[0], field[1], wavelength, num_rays, distribution)
+        finally:
+            tracer.record_all = old
+        dev = tracer.device
+        # detector-local = global - vertex (untilted): shift the EDGES instead of the hits
+        xe = torch.as_tensor(self.x_edges + ox, dtype=torch.float64, device=dev)
+        ye = torch.as_tensor(self.y_edges + oy, dtype=torch.float64, device=dev)
+        self.power_map = tracer.engine.irradiance(rays.x.contiguous(), rays.y.contiguous(),
+                                                  rays.i.contiguous(), xe, ye)
+        self.irradiance = self.power_map / self.pixel_area   # (npix_x, npix_y), device
+
+    def peak_irradiance(self) -> float:
+        return float(self.irradiance.max())

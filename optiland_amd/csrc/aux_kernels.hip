@@ -310,6 +310,64 @@ hipError_t launch_radial_energy(int64_t n, const T* x, const T* y, const T* inte
   return hipGetLastError();
 }
 
+// analysis/irradiance.py:341-353: numpy.histogram2d(x, y, bins=[x_edges, y_edges],
+// weights=power) for rays with power > 0.  Bin search = numpy's
+// searchsorted(edges, v, "right") - 1 with the right-most edge folded into the last bin.
+__device__ __forceinline__ int edge_bin(const double* __restrict__ e, int nb, double v) {
+  if (!(v >= e[0]) || !(v <= e[nb])) return -1;  // outside, or NaN
+  if (v == e[nb]) return nb - 1;
+  int lo = 0, hi = nb;  // invariant: e[lo] <= v < e[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (e[mid] <= v) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+constexpr int kMaxLdsBins = 4096;  // 32 KB of LDS doubles: small detectors are privatised
+
+template <typename T, bool LDS>
+__global__ __launch_bounds__(kBlock) void irradiance_kernel(
+    int64_t n, const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ power,
+    const double* __restrict__ xe, int nx, const double* __restrict__ ye, int ny, double* hist) {
+  __shared__ double lh[LDS ? kMaxLdsBins : 1];
+  const int nb = nx * ny;
+  if constexpr (LDS) {
+    for (int k = threadIdx.x; k < nb; k += kBlock) lh[k] = 0.0;
+    __syncthreads();
+  }
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * kBlock) {
+    const double p = (double)power[j];
+    if (!(p > 0.0)) continue;  // irradiance.py:346 (NaN power fails the test too)
+    const int ix = edge_bin(xe, nx, (double)x[j]);
+    if (ix < 0) continue;
+    const int iy = edge_bin(ye, ny, (double)y[j]);
+    if (iy < 0) continue;
+    if constexpr (LDS) unsafeAtomicAdd(&lh[ix * ny + iy], p);
+    else unsafeAtomicAdd(&hist[(int64_t)ix * ny + iy], p);
+  }
+  if constexpr (LDS) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < nb; k += kBlock)
+      if (lh[k] != 0.0) unsafeAtomicAdd(&hist[k], lh[k]);
+  }
+}
+
+template <typename T>
+hipError_t launch_irradiance(int64_t n, const T* x, const T* y, const T* power,
+                             const double* x_edges, int nx, const double* y_edges, int ny,
+                             double* hist, hipStream_t stream) {
+  if (nx < 1 || ny < 1) return hipErrorInvalidValue;
+  if ((int64_t)nx * ny <= kMaxLdsBins)
+    hipLaunchKernelGGL((irradiance_kernel<T, true>), dim3(grid_for(n)), dim3(kBlock), 0, stream,
+                       n, x, y, power, x_edges, nx, y_edges, ny, hist);
+  else
+    hipLaunchKernelGGL((irradiance_kernel<T, false>), dim3(grid_for(n)), dim3(kBlock), 0, stream,
+                       n, x, y, power, x_edges, nx, y_edges, ny, hist);
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_spot_moments(int64_t n, const T* x, const T* y, const T* inten, double* out6,
                                hipStream_t stream) {
@@ -336,6 +394,9 @@ hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten,
                                           const T*, const T*, T*, T* const[3], hipStream_t);   \
   template hipError_t launch_spot_moments<T>(int64_t, const T*, const T*, const T*, double*,   \
                                              hipStream_t);                                     \
+  template hipError_t launch_irradiance<T>(int64_t, const T*, const T*, const T*,              \
+                                           const double*, int, const double*, int, double*,    \
+                                           hipStream_t);                                       \
   template hipError_t launch_radial_energy<T>(int64_t, const T*, const T*, const T*, double,   \
                                               double, const double*, int, double*,             \
                                               hipStream_t);                                    \

@@ -720,6 +720,29 @@ int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_ra
                                out7, status, st);
 }
 
+int ol_irradiance(ol_dtype dt, int64_t n_rays, const void* x, const void* y, const void* power,
+                  const double* x_edges, int32_t nx, const double* y_edges, int32_t ny,
+                  double* hist, void* stream) {
+  if (!x || !y || !power || !x_edges || !y_edges || !hist)
+    return fail(OL_EINVAL, "ol_irradiance: NULL argument");
+  if (n_rays < 0) return fail(OL_EINVAL, "ol_irradiance: negative count");
+  if (nx < 1 || ny < 1 || (int64_t)nx * ny > (int64_t)1 << 28)
+    return fail(OL_EINVAL, "ol_irradiance: %d x %d bins", nx, ny);
+  if (n_rays == 0) return OL_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (dt == OL_F32)
+    e = ol::launch_irradiance<float>(n_rays, (const float*)x, (const float*)y,
+                                     (const float*)power, x_edges, nx, y_edges, ny, hist, st);
+  else if (dt == OL_F64)
+    e = ol::launch_irradiance<double>(n_rays, (const double*)x, (const double*)y,
+                                      (const double*)power, x_edges, nx, y_edges, ny, hist, st);
+  else
+    return fail(OL_EINVAL, "ol_irradiance: bad dtype %d", (int)dt);
+  if (e != hipSuccess) return fail(OL_EHIP, "launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
 int ol_radial_energy(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
                      const void* intensity, double cx, double cy, const double* r_step,
                      int32_t n_steps, double* bins, void* stream) {

@@ -145,6 +145,10 @@ hipError_t launch_radial_energy(int64_t n, const T* x, const T* y, const T* inte
                                 double cy, const double* r_step, int n_steps, double* bins,
                                 hipStream_t stream);
 template <typename T>
+hipError_t launch_irradiance(int64_t n, const T* x, const T* y, const T* power,
+                             const double* x_edges, int nx, const double* y_edges, int ny,
+                             double* hist, hipStream_t stream);
+template <typename T>
 hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten, double cx,
                               double cy, double* out1, hipStream_t stream);
 

@@ -411,6 +411,25 @@ class HipSystem:
         _capi.check(rc, "ol_spot_moments")
         return out
 
+    def irradiance(self, x, y, power, x_edges: torch.Tensor, y_edges: torch.Tensor,
+                   out: torch.Tensor | None = None) -> torch.Tensor:
+        """numpy.histogram2d(x, y, [x_edges, y_edges], weights=power) over rays with
+        power > 0 (`ol_irradiance`, analysis/irradiance.py:341-353).  Edges: ascending
+        float64 device tensors; returns (nx, ny) float64 (`out` is accumulated into)."""
+        for e in (x_edges, y_edges):
+            if e.dtype != torch.float64 or e.device != self.device or e.numel() < 2:
+                raise ValueError("edges must be float64 tensors on the system's device")
+        xe, ye = x_edges.contiguous(), y_edges.contiguous()
+        nx, ny = xe.numel() - 1, ye.numel() - 1
+        if out is None:
+            out = torch.zeros((nx, ny), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.ol_irradiance(_DT[x.dtype], int(x.numel()), x.data_ptr(), y.data_ptr(),
+                                        power.data_ptr(), xe.data_ptr(), nx, ye.data_ptr(), ny,
+                                        out.data_ptr(), _stream_ptr(self.device))
+        _capi.check(rc, "ol_irradiance")
+        return out
+
     def radial_energy(self, x, y, intensity, cx: float, cy: float, r_step: torch.Tensor,
                       out: torch.Tensor | None = None):
         """Energy per radius step about (cx, cy) (`ol_radial_energy`); `torch.cumsum` of

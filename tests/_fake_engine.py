@@ -167,6 +167,18 @@ class OracleEngine:
         return torch.tensor([c, xd.sum(), yd.sum(), (xd * xd).sum(), (yd * yd).sum(), c],
                             dtype=torch.float64)
 
+    def irradiance(self, x, y, power, x_edges, y_edges, out=None):
+        xn, yn, pn = (v.double().numpy() for v in (x, y, power))
+        valid = pn > 0.0
+        with np.errstate(invalid="ignore"):
+            h, _, _ = np.histogram2d(xn[valid], yn[valid], bins=[x_edges.numpy(), y_edges.numpy()],
+                                     weights=pn[valid])
+        h = torch.as_tensor(h)
+        if out is None:
+            return h
+        out += h
+        return out
+
     def radial_energy(self, x, y, intensity, cx, cy, r_step, out=None):
         r = torch.sqrt((x.double() - cx) ** 2 + (y.double() - cy) ** 2).numpy()
         e = intensity.double().numpy()

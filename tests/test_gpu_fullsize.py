@@ -248,3 +248,55 @@ def test_encircled_energy_analysis_on_device():
             np.testing.assert_allclose(ee.ee[k], want, rtol=1e-9, atol=1e-9)
             assert ee.ee[k][-1] == pytest.approx(np.nansum(e), rel=1e-12)
         t.engine.close()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("res", [(16, 24), (300, 200)], ids=["lds", "global"])
+def test_irradiance_kernel_equals_numpy_histogram2d(dg, dtype, res):
+    """ol_irradiance == numpy.histogram2d(x, y, bins=[xe, ye], weights=power) over rays
+    with power > 0 (analysis/irradiance.py:341-353): half-open bins, closed last edge,
+    NaN / out-of-range rays dropped; both the LDS-privatised and the global path."""
+    hip, _ = dg
+    n = 700_001
+    g = torch.Generator(device=DEV).manual_seed(21)
+    x = (torch.randn(n, generator=g, device=DEV, dtype=torch.float64) * 0.4 + 0.1).to(dtype)
+    y = (torch.randn(n, generator=g, device=DEV, dtype=torch.float64) * 0.3 - 0.2).to(dtype)
+    p = torch.rand(n, generator=g, device=DEV, dtype=torch.float64).to(dtype)
+    p[::9] = 0
+    p[3::777] = float("nan")
+    p[4::555] = -1.0
+    x[5::333] = float("nan")
+    xe = torch.linspace(-1.0, 1.0, res[0] + 1, dtype=torch.float64, device=DEV)
+    ye = torch.linspace(-0.8, 0.9, res[1] + 1, dtype=torch.float64, device=DEV)
+    # rays exactly on inner edges, on the outer edges, and just outside
+    x[0], y[0] = float(xe[3]), float(ye[5])
+    x[1], y[1] = float(xe[-1]), float(ye[-1])
+    x[2], y[2] = float(xe[0]), float(ye[0])
+    x[6], y[6] = float(xe[-1]) + 1e-3, 0.0
+    p[:8] = 1.0
+    got = hip.irradiance(x, y, p, xe, ye).cpu().numpy()
+    xn, yn, pn = (v.double().cpu().numpy() for v in (x, y, p))
+    valid = pn > 0.0
+    want, _, _ = np.histogram2d(xn[valid], yn[valid], bins=[xe.cpu().numpy(), ye.cpu().numpy()],
+                                weights=pn[valid])
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-9)
+    assert got.sum() > 0
+    twice = hip.irradiance(x, y, p, xe, ye, out=torch.as_tensor(got, device=DEV).clone())
+    np.testing.assert_allclose(twice.cpu().numpy(), 2 * got, rtol=1e-12)
+
+
+def test_incoherent_irradiance_analysis_on_device():
+    from optiland_amd import load_system, tracer as tr
+    from optiland_amd.analysis import IncoherentIrradiance
+    t = tr.HipRayTracer(load_system("cooke_generic"), DEV, dtype=torch.float64)
+    rays = t.trace(0.0, 0.7, 0.55, 200, "uniform")
+    x, y, i = (v.double().cpu().numpy() for v in (rays.x, rays.y, rays.i))
+    cx, cy = np.nanmean(x), np.nanmean(y)
+    ext = (cx - 0.05, cx + 0.05, cy - 0.06, cy + 0.06)
+    irr = IncoherentIrradiance(t, (0.0, 0.7), 0.55, ext, res=(40, 48), num_rays=200)
+    valid = i > 0
+    want, _, _ = np.histogram2d(x[valid], y[valid], bins=[irr.x_edges, irr.y_edges],
+                                weights=i[valid])
+    np.testing.assert_allclose(irr.power_map.cpu().numpy(), want, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(irr.peak_irradiance(), want.max() / irr.pixel_area, rtol=1e-10)
+    t.engine.close()
