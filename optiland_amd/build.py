@@ -15,8 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "liboptiland_hip.so"
-SOURCES = ("trace_kernel.hip", "aux_kernels.hip", "capi.hip")
-HEADERS = ("device_table.h", "trace_launch.h")
+# trace_kernel.hip is compiled twice -- fp32 and fp64 instantiations in separate
+# translation units -- so that the two halves (the bulk of the build) run in parallel
+SOURCES = ("trace_kernel_f32.hip", "trace_kernel_f64.hip", "aux_kernels.hip", "capi.hip")
+HEADERS = ("device_table.h", "trace_launch.h", "raygen_device.h", "trace_kernel.hip")
 ARCH = "gfx950"
 
 
@@ -43,18 +45,22 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     pub = os.path.join(HERE, "..", "include", "optiland_hip.h")
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [pub]
-    objs = []
+    objs, jobs = [], []
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
              "-fno-math-errno", "-Wall"]
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [_hipcc(), *flags, "-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append([_hipcc(), *flags, "-c", s, "-o", o])
         objs.append(o)
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        if verbose:
+            for cmd in jobs:
+                print(" ".join(cmd))
+        with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
+            list(pool.map(subprocess.check_call, jobs))
     so = library_path()
     if force or _stale(so, objs):
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", so]

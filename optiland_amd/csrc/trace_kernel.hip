@@ -1720,6 +1720,7 @@ static hipError_t launch_pair(const TraceArgs<T>& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+#if OL_TRACE_TU != 2
 Tuning& tuning() {
   static Tuning t = [] {
     Tuning v;
@@ -1728,6 +1729,7 @@ Tuning& tuning() {
   }();
   return t;
 }
+#endif
 
 template <typename T>
 hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
@@ -1757,8 +1759,18 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
   return launch_rpt<T, kVec>(a, nr, stream);
 }
 
+// OL_TRACE_TU: 0 = everything in this translation unit; 1 / 2 = the fp32 / fp64
+// instantiations only (trace_kernel_f32.hip / trace_kernel_f64.hip include this file so
+// that the two halves compile in parallel)
+#ifndef OL_TRACE_TU
+#define OL_TRACE_TU 0
+#endif
+#if OL_TRACE_TU != 2
 template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, bool, hipStream_t);
+#endif
+#if OL_TRACE_TU != 1
 template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, bool, hipStream_t);
+#endif
 
 // --------------------------------------------------------------------------
 // fused spot kernel: generate -> trace -> reduce, nothing but the pupil read
@@ -1951,7 +1963,11 @@ hipError_t launch_spot_trace(const SpotArgs<T>& a, bool vector_ok, bool has_newt
   return launch_spot_nr<T, kVec, 0>(a, stream);
 }
 
+#if OL_TRACE_TU != 2
 template hipError_t launch_spot_trace<float>(const SpotArgs<float>&, bool, bool, hipStream_t);
+#endif
+#if OL_TRACE_TU != 1
 template hipError_t launch_spot_trace<double>(const SpotArgs<double>&, bool, bool, hipStream_t);
+#endif
 
 }  // namespace ol
