@@ -286,7 +286,8 @@ def main():
         spot_arg = None
         if exchange == "reduce":
             slots[k].zero_()
-            spot_arg = (slots[k], 0.0, 0.0)
+            if not pol:  # polarised traces reduce after the launch (see below)
+                spot_arg = (slots[k], 0.0, 0.0)
         if ev0 is not None:
             ev0.record()
         res = hip.trace(src, wl, record=record if record is not None else False, prt=prt,
@@ -295,6 +296,12 @@ def main():
             ev1.record()
         if exchange != "none":
             if exchange == "reduce":
+                if pol:
+                    # the epilogue is for unpolarised traces: reduce the image-plane planes
+                    # with the stand-alone kernel into slot 0 of the same block
+                    xi, yi, ii = ((res.row(res.last, q) for q in (0, 1, 6))
+                                  if args.mode == "record" else (src[0], src[1], src[6]))
+                    hip.spot_moments(xi, yi, ii, out=slots[k].view(-1)[:6])
                 pending[k] = dist.all_gather_into_tensor(all_slots[k].view(-1),
                                                          slots[k].view(-1), async_op=True)
             else:

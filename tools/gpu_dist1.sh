@@ -10,3 +10,4 @@ run 29533 --force-exchange --exchange gather
 run 29534 --force-exchange --dtype f64 --rays 1.25e7
 run 29535 --force-exchange --mode spot
 run 29536 --force-exchange --mode last
+run 29537 --force-exchange --workload zernike_fresnel
