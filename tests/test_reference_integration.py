@@ -250,6 +250,55 @@ def test_reference_suite_sweeps_the_hip_backend(tmp_path):
     assert n > 300, tail
 
 
+def test_reference_consumers_run_on_the_replaced_tracer(tmp_path):
+    """The reference's OWN tests of the consumers of the path -- Optic.trace /
+    trace_generic, spot diagrams, encircled energy, irradiance, ray fans, wavefront / OPD /
+    Zernike fits -- executed with `integration.enable(force=True)`: every real-ray trace
+    inside them goes through the drop-in tracer (packer -> C-ABI-shaped engine, here the
+    oracle-backed stand-in) and their hard-coded expectations still hold.  Autograd tests
+    are deselected: the drop-in must not intercept differentiable traces."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dst = tmp_path / "tests"
+    shutil.copytree(os.path.join(REF, "tests"), dst,
+                    ignore=shutil.ignore_patterns("__pycache__"))
+    counter = tmp_path / "hip_engines.txt"
+    conf = (dst / "conftest.py").read_text()
+    conf = conf.replace(
+        "import optiland.backend as be\n",
+        "import optiland.backend as be\n"
+        "import atexit, importlib.util, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "_spec = importlib.util.spec_from_file_location('_ol_fake_engine', %r)\n"
+        "_fake = importlib.util.module_from_spec(_spec)\n"
+        "_spec.loader.exec_module(_fake)\n"
+        "import optiland_amd.tracer as _tr\n"
+        "_made = [0]\n"
+        "def _mk(table, device):\n"
+        "    _made[0] += 1\n"
+        "    return _fake.OracleEngine(table, device)\n"
+        "_tr._make_engine = _mk\n"
+        "atexit.register(lambda: open(%r, 'w').write(str(_made[0])))\n"
+        "from optiland_amd import integration as _integ\n"
+        "_integ.enable(force=True)\n"
+        % (root, os.path.join(root, "tests", "_fake_engine.py"), str(counter)), 1)
+    conf = conf.replace("be.grad_mode.enable()", "be.grad_mode.disable()")
+    (dst / "conftest.py").write_text(conf)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1",
+               PYTHONPATH=os.pathsep.join([os.path.join(root, "tests", "refshim"), REF]))
+    files = ["tests/test_optic.py", "tests/test_analysis.py", "tests/test_wavefront.py"]
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider",
+                          "-k", "torch and not autodiff", *files],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    tail = out.stdout.strip().splitlines()[-1]
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert " passed" in tail and "failed" not in tail, tail
+    assert int(tail.split(" passed")[0].split()[-1]) > 140, tail
+    assert int(counter.read_text()) > 50  # the traces really went through the drop-in
+
+
 def test_packer_memoises_paraxial_scalars_and_invalidates(ref, monkeypatch):
     """The reference's paraxial traces (EPL / EPD / XPL) are memoised per optic against
     a fingerprint of the first-order layout: repeated packs (one per field / wavelength
