@@ -24,6 +24,8 @@ class UnsupportedSystem(Exception):
 
 def _f(v) -> float:
     """Backend scalar / 0-d array / python number -> float."""
+    if type(v) is float or type(v) is int:  # the common case, ~160 calls per pack
+        return float(v)
     if hasattr(v, "detach"):
         v = v.detach().cpu().numpy()
     return float(np.asarray(v).reshape(-1)[0]) if np.ndim(v) else float(v)
@@ -44,6 +46,10 @@ def _rot_z(a):
     return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float64)
 
 
+_EYE3 = np.eye(3)
+_EYE3.setflags(write=False)
+
+
 def cs_to_affine(cs):
     """Fold a (possibly nested) reference CoordinateSystem into (R, origin).
 
@@ -55,6 +61,8 @@ def cs_to_affine(cs):
     """
     rx, ry, rz = _f(cs.rx), _f(cs.ry), _f(cs.rz)
     t = np.array([_f(cs.x), _f(cs.y), _f(cs.z)], dtype=np.float64)
+    if not (rx or ry or rz) and cs.reference_cs is None:
+        return _EYE3, t  # the common untilted, un-nested surface
     R = np.eye(3)
     if rz:
         R = _rot_z(-rz) @ R
@@ -249,6 +257,9 @@ def _pack_coating(coating, row, coeffs: list):
         raise UnsupportedSystem(f"coating {name} is not on the fused path")
 
 
+_INDEX_MEMO: dict = {}  # (id(material), wavelength, which) -> value; cleared per pack
+
+
 def _scalar_index(material, w: float, which: str) -> float:
     """material.n(lambda) / material.k(lambda) with a *scalar* wavelength.
 
@@ -257,8 +268,11 @@ def _scalar_index(material, w: float, which: str) -> float:
     dominant CPU cost in its profile; per trace every ray shares one wavelength
     (rays/ray_generator.py:87), so a scalar call returns the same number.
     """
-    v = getattr(material, which)(w)
-    return _f(v)
+    key = (id(material), w, which)
+    hit = _INDEX_MEMO.get(key)
+    if hit is None:  # consecutive surfaces share materials (pre of one = post of the last)
+        hit = _INDEX_MEMO[key] = _f(getattr(material, which)(w))
+    return hit
 
 
 def pack_optic(optic, wavelengths=None, name: str | None = None) -> SystemTable:
@@ -266,6 +280,7 @@ def pack_optic(optic, wavelengths=None, name: str | None = None) -> SystemTable:
 
     Raises `UnsupportedSystem` for anything outside the fused path.
     """
+    _INDEX_MEMO.clear()
     surfaces = list(optic.surfaces)
     if wavelengths is None:
         wavelengths = [_f(w.value) for w in optic.wavelengths.wavelengths]
@@ -281,7 +296,7 @@ def pack_optic(optic, wavelengths=None, name: str | None = None) -> SystemTable:
         R, t = cs_to_affine(geom.cs)
         row["origin"] = t
         row["rot"] = R.reshape(-1)
-        row["flags"] = 0 if np.array_equal(R, np.eye(3)) else S.SURF_ROTATED
+        row["flags"] = 0 if (R is _EYE3 or np.array_equal(R, _EYE3)) else S.SURF_ROTATED
         im = surf.interaction_model
         if type(im).__name__ != "RefractiveReflectiveModel":
             raise UnsupportedSystem(
