@@ -991,7 +991,16 @@ __device__ __forceinline__ void interact(const DevSurf<typename Math<V>::scalar>
   // homogeneous.py:44-53, standard_surface.py:244
   if (o.absorb > T(0)) {
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) r[k].i = r[k].i * m::exp(-o.absorb * t[k]);
+    for (int k = 0; k < RPT; ++k) {
+      // i * exp(-alpha t).  A clipped ray (i = 0) that then runs a long NEGATIVE distance
+      // through an absorbing medium has exp(+x) overflow fp32 (x > 88.7) long before it
+      // overflows the reference's fp64 (x > 709.78): keep the reference's 0 * finite = 0
+      // there instead of fp32's 0 * inf = NaN.
+      const V arg = -o.absorb * t[k];
+      const V prod = r[k].i * m::exp(arg);
+      r[k].i = m::select(m::mand(m::eq(r[k].i, zero), m::lt(arg, m::splat(T(709.78)))), zero,
+                         prod);
+    }
   }
 #pragma unroll
   for (int k = 0; k < RPT; ++k) r[k].opd = r[k].opd + m::abs(t[k] * o.n1);

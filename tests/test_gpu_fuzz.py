@@ -3,7 +3,8 @@
 Forty seeded random systems of 2-6 surfaces -- planes, conics of either sign and any
 conic constant, even aspheres, mirrors, decentred and tilted frames, radial / rectangular /
 elliptical apertures, index steps up and down, absorbing media -- traced with ray bundles
-wide enough to produce misses, clipping and total internal reflection.  fp64 must agree
+wide enough to produce misses, clipping and total internal reflection (conic-only systems;
+aspheres get bundles inside the region where their Newton iteration has a unique root).  fp64 must agree
 with the oracle to 1e-9 of the position scale with IDENTICAL NaN and clip masks (the
 Newton surfaces to 1e-7: gradient reuse, see test_gpu_parity).  fp32 is checked on the
 rays the oracle itself finds well away from every branch point (fp32 inputs alone move a
@@ -88,9 +89,16 @@ def random_system(seed):
     table = SystemTable(surfaces=surf, coeffs=np.array(coeffs, dtype=np.float64), optics=optics,
                         wavelengths=np.array([0.55]), name=f"fuzz{seed}")
     n = 4000
-    rays = {"x": rng.uniform(-7, 7, n), "y": rng.uniform(-7, 7, n), "z": np.full(n, -20.0)}
-    L, M = rng.uniform(-0.12, 0.12, n), rng.uniform(-0.12, 0.12, n)
-    rays.update(L=L, M=M, N=np.sqrt(1 - L * L - M * M), i=np.ones(n))
+    # half the bundle is tame, half is wild (steep, far off axis): misses and TIR.  Systems
+    # with an even asphere keep the whole bundle tame: 40 mm off axis the random r^4 / r^6
+    # terms fold the surface over, the Newton iteration turns chaotic (several roots, or
+    # none) and where it ends after the reference's batch-wide 100 iterations is decided by
+    # rounding noise -- not something any second implementation can reproduce ray by ray.
+    half = n if has_nr else n // 2
+    xy = np.concatenate([rng.uniform(-7, 7, (2, half)), rng.uniform(-40, 40, (2, n - half))], 1)
+    lm = np.concatenate([rng.uniform(-0.12, 0.12, (2, half)), rng.uniform(-0.55, 0.55, (2, n - half))], 1)
+    rays = {"x": xy[0], "y": xy[1], "z": np.full(n, -20.0), "L": lm[0], "M": lm[1]}
+    rays.update(N=np.sqrt(1 - lm[0] ** 2 - lm[1] ** 2), i=np.ones(n))
     return table, rays, has_nr
 
 
@@ -121,22 +129,24 @@ def test_random_system_fp32_on_well_conditioned_rays(seed):
     r32 = {k: v.astype(np.float32).astype(np.float64) for k, v in rays.items()}
     want = oracle.trace(table, r32, 0, record=True)["record"]
     # well-conditioned = the oracle's verdict (hit / miss / clipped pattern) survives a
-    # 1e-5 perturbation of the launch state in every direction tried
+    # 1e-3 mm / 1e-4 rad perturbation of the launch state in every direction tried
     stable = np.ones(n, dtype=bool)
     rng = np.random.default_rng(1000 + seed)
-    for _ in range(4):
+    for _ in range(10):
         pert = {k: v.copy() for k, v in r32.items()}
         for k in ("x", "y"):
-            pert[k] += rng.uniform(-2e-4, 2e-4, n)
+            pert[k] += rng.uniform(-1e-3, 1e-3, n)
         for k in ("L", "M"):
-            pert[k] += rng.uniform(-2e-5, 2e-5, n)
+            pert[k] += rng.uniform(-1e-4, 1e-4, n)
         pert["N"] = np.sqrt(1 - pert["L"] ** 2 - pert["M"] ** 2)
         alt = oracle.trace(table, pert, 0, record=True)["record"]
-        stable &= np.all(np.isnan(alt[:, 0, :]) == np.isnan(want[:, 0, :]), axis=0)
+        # (every plane: total internal reflection leaves the hit finite and kills only
+        # the direction)
+        stable &= np.all(np.isnan(alt) == np.isnan(want), axis=(0, 1))
         stable &= np.all((alt[:, 6, :] == 0) == (want[:, 6, :] == 0), axis=0)
         # near total internal reflection / grazing: directions move a lot under the nudge
         with np.errstate(invalid="ignore"):
-            stable &= np.all(np.nan_to_num(np.abs(alt[:, 3:6, :] - want[:, 3:6, :])) < 2e-3,
+            stable &= np.all(np.nan_to_num(np.abs(alt[:, 3:6, :] - want[:, 3:6, :])) < 1e-2,
                              axis=(0, 1))
     assert stable.sum() > 0.3 * n
     hip = HipSystem(table, DEV)
