@@ -1058,6 +1058,11 @@ __device__ __forceinline__ void interact(const DevSurf<typename Math<V>::scalar>
     const int ck = s.coating_kind;
     const bool reflect = s.interaction == kReflect;
     const T nn = o.nn;
+    // SimpleCoating.reflect / transmit only scale the intensity (coatings.py:199-237): they
+    // never call rays.update(), so the PRT matrix passes through unchanged -- unlike an
+    // UNCOATED surface, whose interaction model calls rays.update() with the identity
+    // Jones matrix (interactions/base.py:124-125).
+    if (ck == kCoatSimple) return;
     // An uncoated refracting surface between equal indices (every image plane, dummy
     // surfaces) leaves the direction unchanged (u = 1 => k1 = k0), its Jones matrix is
     // the identity and O_out O_in = I for ANY orthonormal basis: P' = P.  The

@@ -157,3 +157,105 @@ def test_random_system_fp32_on_well_conditioned_rays(seed):
     finally:
         hip.close()
     assert_close_planes(got[:, :, stable], want[:, :, stable], 1e-4, 1e-4, f"fuzz{seed}:f32")
+
+
+def random_polarised_system(seed):
+    """Conic / plane surfaces with random Simple / Fresnel / Polarizer / Retarder coatings,
+    tilts and mirrors; tame bundle (the PRT of a lost ray is NaN in both)."""
+    rng = np.random.default_rng(5000 + seed)
+    ns = int(rng.integers(2, 6))
+    surf = np.zeros(ns + 1, dtype=S.SURFACE_DESC_DTYPE)
+    optics = np.zeros((ns + 1, 1), dtype=S.SURFACE_OPTICS_DTYPE)
+    coeffs = []
+    surf["rot"] = np.eye(3).reshape(-1)
+    surf["norm_radius"] = 1.0
+    surf[0]["geom_kind"], surf[0]["interaction"] = S.GEOM_PLANE, S.INTERACT_RECORD_ONLY
+    surf[0]["origin"] = (0.0, 0.0, -20.0)
+    optics[0, 0] = (1.0, 1.0, 0.0)
+    n_prev, z, direction = 1.0, 0.0, 1.0
+    for i in range(1, ns + 1):
+        row = surf[i]
+        row["geom_kind"] = rng.choice([S.GEOM_PLANE, S.GEOM_STANDARD, S.GEOM_STANDARD])
+        row["radius"] = (rng.choice([-1, 1]) * rng.uniform(30.0, 300.0)
+                         if row["geom_kind"] == S.GEOM_STANDARD else np.inf)
+        row["conic"] = (rng.choice([0.0, -1.0, rng.uniform(-2.0, 1.0)])
+                        if row["geom_kind"] == S.GEOM_STANDARD else 0.0)
+        mirror = rng.random() < 0.2
+        row["interaction"] = S.INTERACT_REFLECT if mirror else S.INTERACT_REFRACT
+        n_next = n_prev if mirror else float(rng.choice([1.0, rng.uniform(1.3, 1.9)]))
+        if not mirror and abs(n_next - n_prev) < 0.05:
+            # an undeviated ray at a CURVED surface leaves the reference's s = k0 x k1 as
+            # pure rounding noise (no longer orthogonal to k0): its PRT there is garbage
+            # that no implementation can reproduce -- always step the index
+            n_next = n_prev + 0.3 if n_prev < 1.5 else 1.0
+        if i == ns:  # image plane: same medium, like every real system
+            row["geom_kind"], row["radius"], row["interaction"] = S.GEOM_PLANE, np.inf, S.INTERACT_REFRACT
+            n_next = n_prev
+        optics[i, 0] = (n_prev, n_next, 0.0)
+        n_prev = n_next
+        z += direction * rng.uniform(3.0, 20.0)
+        if mirror and i != ns:
+            direction = -direction
+        row["origin"] = (rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), z)
+        if rng.random() < 0.3:
+            row["rot"] = _rot(rng, 5.0).reshape(-1)
+            row["flags"] = S.SURF_ROTATED
+        ck = rng.choice([S.COAT_NONE, S.COAT_SIMPLE, S.COAT_FRESNEL, S.COAT_FRESNEL,
+                         S.COAT_POLARIZER, S.COAT_RETARDER]) if i != ns else S.COAT_NONE
+        row["coating_kind"] = ck
+        if ck == S.COAT_SIMPLE:
+            row["coat"] = (rng.uniform(0.5, 1.0), rng.uniform(0.0, 0.5))
+        elif ck in (S.COAT_POLARIZER, S.COAT_RETARDER):
+            ax = rng.normal(size=3)
+            ax[2] *= 0.2
+            ax /= np.linalg.norm(ax)
+            row["coat"] = (float(len(coeffs)), 0.0)
+            coeffs.extend(ax.tolist())
+            if ck == S.COAT_RETARDER:
+                coeffs.append(float(rng.uniform(0.2, 3.0)))
+    table = SystemTable(surfaces=surf, coeffs=np.array(coeffs, dtype=np.float64), optics=optics,
+                        wavelengths=np.array([0.55]), name=f"polfuzz{seed}")
+    table.polarization = {"is_polarized": True, "Ex": 1.0, "Ey": 0.5, "phase_x": 0.0, "phase_y": 0.7}
+    n = 1500
+    rays = {"x": rng.uniform(-5, 5, n), "y": rng.uniform(-5, 5, n), "z": np.full(n, -20.0)}
+    L, M = rng.uniform(-0.1, 0.1, n), rng.uniform(-0.1, 0.1, n)
+    rays.update(L=L, M=M, N=np.sqrt(1 - L * L - M * M), i=np.ones(n))
+    return table, rays
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("seed", range(25))
+def test_random_polarised_system(seed, dtype):
+    """Rays, PRT matrices (real or complex planes) and the update_intensity epilogue of
+    random coated systems against the oracle: fp64 1e-9, fp32 1e-4."""
+    from oracle import oracle
+    from optiland_amd.engine import HipSystem
+    from optiland_amd.rays import prt_to_complex
+    table, rays = random_polarised_system(seed)
+    if dtype == torch.float32:
+        rays = {k: v.astype(np.float32).astype(np.float64) for k, v in rays.items()}
+    n = rays["x"].size
+    out = oracle.trace(table, rays, 0, record=True, polarized=True)
+    hip = HipSystem(table, DEV)
+    try:
+        planes = [torch.tensor(rays[k], dtype=dtype, device=DEV) for k in PLANES[:7]]
+        planes.append(torch.zeros_like(planes[0]))
+        k0 = [planes[3].clone(), planes[4].clone(), planes[5].clone()]
+        i0 = planes[6].clone()
+        prt = torch.empty((18 if table.needs_complex_prt else 9, n), dtype=dtype, device=DEV)
+        res = hip.trace(planes, 0, record=True, prt=prt, prt_identity=True)
+        got = res.record[:, :, :n].double().cpu().numpy()
+        p = prt_to_complex(prt).cpu().numpy().astype(np.complex128)
+        iu = hip.polarized_intensity(prt, k0, i0, table.polarization).double().cpu().numpy()
+    finally:
+        hip.close()
+    tol = 1e-9 if dtype == torch.float64 else 1e-4
+    assert_close_planes(got, out["record"], tol, tol, f"polfuzz{seed}")
+    assert np.array_equal(np.isnan(p.real), np.isnan(out["prt"].real))
+    np.testing.assert_allclose(np.nan_to_num(p), np.nan_to_num(out["prt"]), rtol=0,
+                               atol=tol * 10)
+    r = rays
+    want_i, status = oracle.polarized_intensity(out["prt"], r["L"], r["M"], r["N"], r["i"],
+                                                table.polarization)
+    assert status == 0
+    np.testing.assert_allclose(np.nan_to_num(iu), np.nan_to_num(want_i), rtol=0, atol=tol * 10)
