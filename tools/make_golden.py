@@ -246,6 +246,38 @@ def polarizer_retarder(with_retarder=True):
     return lens
 
 
+def coated_mirror_polarised():
+    """Polarised rays through every way a surface can (not) touch the PRT: an UNCOATED
+    curved refractor (rays.update() with the identity Jones matrix), a SimpleCoating
+    refractor (intensity only -- SimpleCoating never calls rays.update()), a
+    Fresnel-coated tilted MIRROR (reflection Jones, j22 = -1), a SimpleCoating mirror, a
+    Fresnel refractor and the image plane."""
+    lens = optic_mod.Optic(name="CoatedMirrorPolarised")
+    lens.surfaces.add(index=0, radius=be.inf, thickness=be.inf)
+    lens.surfaces.add(index=1, radius=60.0, thickness=4.0, material="N-BK7", is_stop=True)
+    lens.surfaces.add(index=2, radius=-90.0, thickness=12.0,
+                      coating=SimpleCoating(transmittance=0.9, reflectance=0.05))
+    lens.surfaces.add(index=3, radius=-150.0, thickness=-10.0, material="mirror", rx=0.08)
+    lens.surfaces.add(index=4, radius=be.inf, thickness=10.0, material="mirror", rx=0.08,
+                      coating=SimpleCoating(transmittance=0.0, reflectance=0.8))
+    lens.surfaces.add(index=5, radius=45.0, thickness=3.0, material="SF6")
+    lens.surfaces.add(index=6, radius=be.inf, thickness=25.0)
+    lens.surfaces.add(index=7)
+    m3 = lens.surfaces[3]
+    m3.coating = FresnelCoating(m3.material_pre, m3.material_post)
+    for i in (5, 6):
+        s_ = lens.surfaces[i]
+        s_.coating = FresnelCoating(s_.material_pre, s_.material_post)
+    lens.set_aperture(aperture_type="EPD", value=8)
+    lens.fields.set_type(field_type="angle")
+    lens.fields.add(y=0)
+    lens.fields.add(y=2)
+    lens.wavelengths.add(value=0.55, is_primary=True)
+    lens.updater.set_polarization(PolarizationState(is_polarized=True, Ex=0.8, Ey=0.6,
+                                                    phase_x=0.1, phase_y=-0.5))
+    return lens
+
+
 def vignetted_cooke():
     """Cooke triplet with vignetting factors on the off-axis fields and an x field:
     exercises FieldGroup.get_vig_factor (nearest field) in trace() and the double
@@ -548,6 +580,8 @@ def main():
     run_case("polarizer_retarder", polarizer_retarder(True), [0.0, 0.0], [0.0, 1.0], None, None,
              0.55, use_trace=dict(num_rays=20, distribution="uniform"))
     run_case("polarizer_only", polarizer_retarder(False), 0.0, 1.0, px, py, 0.55)
+    run_case("coated_mirror_polarised", coated_mirror_polarised(), [0.0, 0.0], [0.0, 1.0], None,
+             None, 0.55, use_trace=dict(num_rays=12, distribution="uniform"))
     run_case("vignetted_trace", vignetted_cooke(), [0.0, 0.0, 0.25], [0.0, 0.7, 1.0], None, None,
              0.55, use_trace=dict(num_rays=5, distribution="hexapolar"))
     hx = np.repeat([0.0, 0.05, 0.25, 0.2], 200)
