@@ -259,3 +259,114 @@ def test_random_polarised_system(seed, dtype):
                                                 table.polarization)
     assert status == 0
     np.testing.assert_allclose(np.nan_to_num(iu), np.nan_to_num(want_i), rtol=0, atol=tol * 10)
+
+
+def random_nr_system(seed):
+    """Every Newton-Raphson geometry kind with random (mild) coefficients: odd / even
+    asphere, XY polynomial, Chebyshev, biconic, toroidal, Zernike; decentres, tilts,
+    apertures; bundle inside the region where the iteration has a unique root."""
+    rng = np.random.default_rng(9000 + seed)
+    ns = int(rng.integers(2, 5))
+    surf = np.zeros(ns + 1, dtype=S.SURFACE_DESC_DTYPE)
+    optics = np.zeros((ns + 1, 1), dtype=S.SURFACE_OPTICS_DTYPE)
+    coeffs = []
+    surf["rot"] = np.eye(3).reshape(-1)
+    surf["norm_radius"] = 1.0
+    surf[0]["geom_kind"], surf[0]["interaction"] = S.GEOM_PLANE, S.INTERACT_RECORD_ONLY
+    surf[0]["origin"] = (0.0, 0.0, -20.0)
+    optics[0, 0] = (1.0, 1.0, 0.0)
+    kinds = [S.GEOM_EVEN_ASPHERE, S.GEOM_ODD_ASPHERE, S.GEOM_POLYNOMIAL, S.GEOM_CHEBYSHEV,
+             S.GEOM_BICONIC, S.GEOM_TOROIDAL, S.GEOM_ZERNIKE]
+    n_prev, z = 1.0, 0.0
+    for i in range(1, ns + 1):
+        row = surf[i]
+        kind = int(kinds[(seed + i) % len(kinds)]) if i < ns else S.GEOM_PLANE
+        row["geom_kind"] = kind
+        row["radius"] = rng.choice([-1, 1]) * rng.uniform(40.0, 300.0) if kind != S.GEOM_PLANE else np.inf
+        row["conic"] = rng.choice([0.0, -1.0, rng.uniform(-1.5, 0.8)]) if kind != S.GEOM_PLANE else 0.0
+        if kind != S.GEOM_PLANE:
+            row["max_iter"], row["tol"] = 100, 1e-12
+            row["coeff_offset"] = len(coeffs)
+        if kind == S.GEOM_EVEN_ASPHERE:
+            c = [rng.uniform(-1e-4, 1e-4), rng.uniform(-1e-6, 1e-6), rng.uniform(-1e-8, 1e-8)]
+        elif kind == S.GEOM_ODD_ASPHERE:
+            c = [rng.uniform(-1e-3, 1e-3), rng.uniform(-1e-4, 1e-4), rng.uniform(-1e-5, 1e-5),
+                 rng.uniform(-1e-6, 1e-6)]
+        elif kind == S.GEOM_POLYNOMIAL:
+            g = (rng.uniform(-1, 1, (3, 4)) * np.array([[1e-3, 1e-3, 1e-4, 1e-5]])
+                 * np.array([[1.0], [1.0], [0.1]]))
+            g[0, 0] = 0.0
+            row["poly_cols"] = 4
+            c = g.reshape(-1).tolist()
+        elif kind == S.GEOM_CHEBYSHEV:
+            g = rng.uniform(-1, 1, (3, 3)) * 2e-3
+            g[0, 0] = 0.0
+            row["poly_cols"] = 3
+            coeffs.extend([12.0, 14.0])  # norm_x, norm_y (bundle stays inside)
+            c = g.reshape(-1).tolist()
+        elif kind == S.GEOM_BICONIC:
+            c = [float(rng.choice([-1, 1]) * rng.uniform(40.0, 300.0)), float(rng.uniform(-1.2, 0.5))]
+        elif kind == S.GEOM_TOROIDAL:
+            c = [float(rng.choice([-1, 1]) * rng.uniform(40.0, 300.0)), float(rng.uniform(-1.0, 0.5)),
+                 rng.uniform(-1e-4, 1e-4), rng.uniform(-1e-6, 1e-6)]
+            row["conic"] = 0.0
+        elif kind == S.GEOM_ZERNIKE:
+            row["norm_radius"] = 12.0
+            terms = [(1, 1), (1, -1), (2, 0), (2, 2), (2, -2), (3, 1), (3, -1), (4, 0), (3, 3)]
+            c = []
+            for (nn, mm) in terms:
+                c.extend([float(rng.uniform(-5e-4, 5e-4)), float(nn), float(mm),
+                          float(rng.choice([1.0, np.sqrt(2.0 * (nn + 1))]))])
+        else:
+            c = []
+        if kind == S.GEOM_ZERNIKE:
+            row["n_coeff"] = len(c) // 4
+        elif kind == S.GEOM_CHEBYSHEV:
+            row["n_coeff"] = len(c)
+        else:
+            row["n_coeff"] = len(c)
+        coeffs.extend(c)
+        row["interaction"] = S.INTERACT_REFRACT
+        n_next = float(rng.uniform(1.3, 1.9)) if n_prev == 1.0 else 1.0
+        if i == ns:
+            n_next = n_prev
+        optics[i, 0] = (n_prev, n_next, 0.0)
+        n_prev = n_next
+        z += rng.uniform(4.0, 15.0)
+        row["origin"] = (rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), z)
+        if rng.random() < 0.3:
+            row["rot"] = _rot(rng, 3.0).reshape(-1)
+            row["flags"] = S.SURF_ROTATED
+        if rng.random() < 0.4:
+            row["aperture_kind"] = S.AP_RADIAL
+            row["aperture"] = (0.0, rng.uniform(4.0, 7.0), 0, 0)
+    table = SystemTable(surfaces=surf, coeffs=np.array(coeffs, dtype=np.float64), optics=optics,
+                        wavelengths=np.array([0.55]), name=f"nrfuzz{seed}")
+    n = 2000
+    rays = {"x": rng.uniform(-5, 5, n), "y": rng.uniform(-5, 5, n), "z": np.full(n, -20.0)}
+    L, M = rng.uniform(-0.08, 0.08, n), rng.uniform(-0.08, 0.08, n)
+    rays.update(L=L, M=M, N=np.sqrt(1 - L * L - M * M), i=np.ones(n))
+    return table, rays
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("seed", range(28))
+def test_random_newton_raphson_system(seed, dtype):
+    from oracle import oracle
+    from optiland_amd.engine import HipSystem
+    table, rays = random_nr_system(seed)
+    if dtype == torch.float32:
+        rays = {k: v.astype(np.float32).astype(np.float64) for k, v in rays.items()}
+    n = rays["x"].size
+    want = oracle.trace(table, rays, 0, record=True)
+    assert want["status"] == 0
+    hip = HipSystem(table, DEV)
+    try:
+        planes = [torch.tensor(rays[k], dtype=dtype, device=DEV) for k in PLANES[:7]]
+        planes.append(torch.zeros_like(planes[0]))
+        got = hip.trace(planes, 0, record=True).record[:, :, :n].double().cpu().numpy()
+    finally:
+        hip.close()
+    assert not np.isnan(want["record"]).all()
+    tol = 1e-7 if dtype == torch.float64 else 1e-4
+    assert_close_planes(got, want["record"], tol, tol, f"nrfuzz{seed}")
