@@ -370,3 +370,143 @@ def test_random_newton_raphson_system(seed, dtype):
     assert not np.isnan(want["record"]).all()
     tol = 1e-7 if dtype == torch.float64 else 1e-4
     assert_close_planes(got, want["record"], tol, tol, f"nrfuzz{seed}")
+
+
+def _random_aperture_tokens(rng, coeffs, depth=0):
+    """Random boolean aperture tree -> reverse-Polish token list (packer._flatten_aperture)."""
+    if depth >= 3 or rng.random() < 0.45:
+        kind = rng.choice([S.AP_RADIAL, S.AP_OFFSET_RADIAL, S.AP_RECTANGULAR, S.AP_ELLIPTICAL,
+                           S.AP_POLYGON])
+        if kind == S.AP_RADIAL:
+            return [[kind, rng.choice([0.0, 1.5]), rng.uniform(3.0, 8.0), 0.0, 0.0]]
+        if kind == S.AP_OFFSET_RADIAL:
+            return [[kind, 0.0, rng.uniform(2.0, 6.0), rng.uniform(-2, 2), rng.uniform(-2, 2)]]
+        if kind == S.AP_RECTANGULAR:
+            return [[kind, -rng.uniform(1, 7), rng.uniform(1, 7), -rng.uniform(1, 7), rng.uniform(1, 7)]]
+        if kind == S.AP_ELLIPTICAL:
+            return [[kind, rng.uniform(2, 8), rng.uniform(2, 8), rng.uniform(-1, 1), rng.uniform(-1, 1)]]
+        nv = int(rng.integers(3, 9))
+        th = np.sort(rng.uniform(0, 2 * np.pi, nv))
+        rr = rng.uniform(2.0, 8.0, nv)
+        off = len(coeffs)
+        for a, b in zip(rr * np.cos(th), rr * np.sin(th)):
+            coeffs.extend([float(a), float(b)])
+        return [[kind, float(off), float(nv), 0.0, 0.0]]
+    op = rng.choice([S.AP_OP_UNION, S.AP_OP_INTERSECTION, S.AP_OP_DIFFERENCE])
+    return (_random_aperture_tokens(rng, coeffs, depth + 1)
+            + _random_aperture_tokens(rng, coeffs, depth + 1) + [[op, 0.0, 0.0, 0.0, 0.0]])
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_aperture_trees_clip_exactly(seed):
+    """Random boolean trees over every leaf kind (incl. polygons) on a two-surface lens:
+    the clipped mask (i == 0) must equal the oracle's ray for ray, fp64; hit coordinates
+    to 1e-9."""
+    from oracle import oracle
+    from optiland_amd.engine import HipSystem
+    rng = np.random.default_rng(20_000 + seed)
+    surf = np.zeros(4, dtype=S.SURFACE_DESC_DTYPE)
+    optics = np.zeros((4, 1), dtype=S.SURFACE_OPTICS_DTYPE)
+    surf["rot"] = np.eye(3).reshape(-1)
+    surf["norm_radius"] = 1.0
+    coeffs = []
+    surf[0]["interaction"] = S.INTERACT_RECORD_ONLY
+    surf[0]["origin"] = (0, 0, -10.0)
+    optics[0, 0] = (1.0, 1.0, 0.0)
+    for i, (R, n1, n2, z) in enumerate(((60.0, 1.0, 1.6, 0.0), (-70.0, 1.6, 1.0, 5.0)), start=1):
+        surf[i]["geom_kind"], surf[i]["radius"] = S.GEOM_STANDARD, R
+        surf[i]["interaction"] = S.INTERACT_REFRACT
+        surf[i]["origin"] = (0, 0, z)
+        optics[i, 0] = (n1, n2, 0.0)
+        toks = _random_aperture_tokens(rng, coeffs)
+        if len(toks) == 1:
+            surf[i]["aperture_kind"] = int(toks[0][0])
+            surf[i]["aperture"] = toks[0][1:]
+        else:
+            surf[i]["aperture_kind"] = S.AP_COMPOSITE
+            surf[i]["aperture"] = (float(len(coeffs)), float(len(toks)), 0.0, 0.0)
+            for t in toks:
+                coeffs.extend(float(v) for v in t)
+    surf[3]["geom_kind"], surf[3]["interaction"] = S.GEOM_PLANE, S.INTERACT_REFRACT
+    surf[3]["origin"] = (0, 0, 40.0)
+    optics[3, 0] = (1.0, 1.0, 0.0)
+    table = SystemTable(surfaces=surf, coeffs=np.array(coeffs, dtype=np.float64), optics=optics,
+                        wavelengths=np.array([0.55]), name=f"apfuzz{seed}")
+    n = 6000
+    rays = {"x": rng.uniform(-9, 9, n), "y": rng.uniform(-9, 9, n), "z": np.full(n, -10.0),
+            "L": np.zeros(n), "M": np.zeros(n), "N": np.ones(n), "i": np.ones(n)}
+    want = oracle.trace(table, rays, 0, record=True)["record"]
+    hip = HipSystem(table, DEV)
+    try:
+        planes = [torch.tensor(rays[k], dtype=torch.float64, device=DEV) for k in PLANES[:7]]
+        planes.append(torch.zeros_like(planes[0]))
+        got = hip.trace(planes, 0, record=True).record[:, :, :n].cpu().numpy()
+        # the fused spot kernel shares the aperture code through a different instantiation
+    finally:
+        hip.close()
+    assert np.array_equal(got[:, 6, :] == 0, want[:, 6, :] == 0)
+    assert_close_planes(got, want, 1e-9, 1e-9, f"apfuzz{seed}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("seed", range(30))
+def test_random_ray_generation(seed, dtype):
+    """ol_generate_rays against the oracle over random generator scalars: the three field
+    kinds, object at infinity or finite, telecentric, every apodization, per-ray planes
+    and launch-uniform scalars, vignetting factors and trace_generic's pupil pre-scale."""
+    from oracle import oracle
+    from optiland_amd import _capi
+    from optiland_amd.engine import HipSystem
+    from optiland_amd import load_system
+    rng = np.random.default_rng(30_000 + seed)
+    table = load_system("double_gauss")
+    kind = int(rng.integers(0, 3))
+    infinite = bool(rng.random() < 0.5) if kind != 1 else False
+    rg = {"object_infinite": 1.0 if infinite else 0.0, "field_kind": float(kind),
+          "EPL": float(rng.uniform(5, 60)), "EPD": float(rng.uniform(4, 25)),
+          "max_field": float(rng.uniform(2, 25)), "offset": float(rng.uniform(5, 30)) if infinite else 0.0,
+          "z_first": float(rng.uniform(-200, -20)) if not infinite else 0.0,
+          "tele_dz": float(rng.uniform(5, 40)) if (kind != 0 and not infinite and rng.random() < 0.4) else 0.0,
+          "apod_kind": float(rng.integers(0, 7)), "apod_a": float(rng.uniform(0.6, 1.2)),
+          "apod_b": float(rng.uniform(0.3, 0.9))}
+    if kind == 2:
+        rg["field_scale"] = float(rng.uniform(0.05, 0.6))
+    if int(rg["apod_kind"]) == 5:
+        rg["apod_b"] = float(rng.uniform(2.0, 6.0))   # super-Gaussian order n >= 2
+    if int(rg["apod_kind"]) == 4:
+        rg["apod_b"] = float(rng.uniform(0.5, 3.0))   # polynomial power
+    table.raygen = rg
+    hip = HipSystem(table, DEV)
+    try:
+        n = 3001
+        r, th = np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
+        px, py = r * np.cos(th), r * np.sin(th)
+        hx, hy = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        vx, vy = rng.uniform(0.7, 1.0, n), rng.uniform(0.7, 1.0, n)
+        dev = lambda a: torch.as_tensor(a, dtype=dtype, device=DEV)  # noqa: E731
+        seen = lambda a: dev(a).double().cpu().numpy()  # noqa: E731
+        prescale = bool(rng.random() < 0.5)
+        flags = _capi.RAYGEN_PRESCALE_PUPIL if prescale else 0
+        got = hip.generate_rays(dev(hx), dev(hy), dev(px), dev(py), dev(vx), dev(vy), flags=flags)
+        pxs, pys = (seen(px) * seen(vx), seen(py) * seen(vy)) if prescale else (seen(px), seen(py))
+        want = oracle.generate_rays(rg, seen(hx), seen(hy), pxs, pys, seen(vx), seen(vy))
+        scale = max(1.0, abs(rg["z_first"]), rg["EPD"], rg["offset"] + rg["EPL"])
+        tol = 1e-12 if dtype == torch.float64 else 2e-6
+        for k, g in zip(("x", "y", "z", "L", "M", "N", "i"), got):
+            gv = g.double().cpu().numpy()
+            s_ = scale if k in "xyz" else 1.0
+            if dtype == torch.float32 and k == "i":
+                # a pupil point within fp32 rounding of an apodization edge may fall on
+                # either side of it: compare away from the edges
+                ok = np.abs(gv - want[k]) < 1e-3
+                assert ok.mean() > 0.995
+                continue
+            np.testing.assert_allclose(gv, want[k], rtol=0, atol=tol * s_ * 10, err_msg=k)
+        # launch-uniform scalars == constant planes
+        c = np.ones(n)
+        a = hip.generate_rays(0.3, -0.4, dev(px), dev(py), 0.9, 0.8)
+        b = hip.generate_rays(dev(0.3 * c), dev(-0.4 * c), dev(px), dev(py), dev(0.9 * c), dev(0.8 * c))
+        for u, v in zip(a, b):
+            assert float((u - v).abs().max()) <= (1e-5 if dtype == torch.float32 else 1e-12) * scale
+    finally:
+        hip.close()
