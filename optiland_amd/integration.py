@@ -14,6 +14,12 @@ Two seams of the reference are used:
    `RealRays` / `PolarizedRays` object and every `Surface`'s recorded
    x, y, z, L, M, N, intensity, opd (surfaces/standard_surface.py:260-274).
 
+`enable()` also patches the third seam of SURVEY.md section 8b, the one that covers
+direct callers: `SurfaceGroup.trace(rays, skip)` (surfaces/surface_group.py:245-257),
+reached with caller-built rays by `IncoherentIrradiance` / `RadiantIntensity` with
+`user_initial_rays`, `ExtendedSourceOptic.trace` and `RealImageHeightField` -- the
+rays are traced IN PLACE through surfaces[skip:] by one `ol_trace` launch.
+
 Anything the fused path does not implement (autograd, BSDF, GRIN, NURBS, thin
 films, non-paraxial aiming ...) raises `UnsupportedSystem` inside the packer
 and the call is forwarded, untouched, to the reference implementation.
@@ -31,7 +37,7 @@ import torch
 
 from . import tracer as _tracer
 from . import _capi
-from .packer import UnsupportedSystem, pack_optic
+from .packer import UnsupportedSystem, pack_optic, pack_surfaces
 from .rays import _state_dict, prt_to_complex
 
 BACKEND_NAME = "hip"
@@ -291,6 +297,102 @@ def _make_tracer_class():
     return OptilandHipRayTracer
 
 
+# --------------------------------------------------------------------------------------
+# SurfaceGroup.trace(rays, skip) -- the seam for callers that bring their own rays
+# --------------------------------------------------------------------------------------
+_SG = {"device": None, "force": False, "count": 0, "fallbacks": 0}
+_PLANE_ATTRS = ("x", "y", "z", "L", "M", "N", "i", "opd")
+
+
+def _sg_backend_ok(be) -> bool:
+    if be.get_backend() not in (BACKEND_NAME, "torch"):
+        return False
+    cfg = be._backends[be.get_backend()]._config
+    if cfg.grad_mode.requires_grad:
+        return False
+    return True if _SG["force"] else cfg.get_device() == "cuda"
+
+
+def _sg_engine(group, wavelength: float):
+    """(engine, table) for this SurfaceGroup at one wavelength, LRU-cached on the group
+    against the packed bytes (a changed surface re-packs and misses)."""
+    table = pack_surfaces(group.surfaces, [wavelength], name="SurfaceGroup")
+    cache = group.__dict__.setdefault("_hip_engines", collections.OrderedDict())
+    key = _table_key(table)
+    hit = cache.get(key)
+    if hit is None:
+        hit = cache[key] = (_tracer._make_engine(table, _SG["device"]), table)
+        while len(cache) > _MAX_ENGINES:
+            _, (old, _t) = cache.popitem(last=False)
+            if hasattr(old, "close"):
+                old.close()
+    else:
+        cache.move_to_end(key)
+    return hit
+
+
+def _hip_surface_group_trace(group, rays, skip):
+    """SurfaceGroup.trace on the HIP path, or None when the call is not eligible (the
+    caller then runs the reference's own loop).  Mirrors surface_group.py:245-257:
+    `reset()`, trace surfaces[skip:] in order, every traced Surface records
+    x,y,z,L,M,N,intensity,opd (standard_surface.py:260-274), `rays` is mutated in place
+    and returned; L0/M0/N0 are the direction cosines before the last interaction
+    (interactions/refractive_reflective_model.py:41) and PolarizedRays.p is advanced
+    from its CURRENT value (rays/polarized_rays.py:180-202)."""
+    import optiland.backend as be
+    from optiland.rays import PolarizedRays as RefPolarizedRays
+    from optiland.rays import RealRays as RefRealRays
+
+    if type(rays) not in (RefRealRays, RefPolarizedRays) or not _sg_backend_ok(be):
+        return None
+    n_s = len(group.surfaces)
+    skip = int(skip)
+    if not (0 <= skip < n_s) or not getattr(rays, "is_normalized", True):
+        return None
+    planes = [getattr(rays, k, None) for k in _PLANE_ATTRS]
+    w = getattr(rays, "w", None)
+    if any(not isinstance(t, torch.Tensor) for t in planes + [w]):
+        return None
+    dtype, dev, n = planes[0].dtype, planes[0].device, planes[0].numel()
+    if dtype not in (torch.float32, torch.float64) or n == 0 or w.numel() == 0 \
+            or any(t.dtype != dtype or t.device != dev or t.numel() != n or t.requires_grad
+                   for t in planes):
+        return None
+    if not _SG["force"] and dev.type != "cuda":
+        return None
+    lo, hi = (float(v) for v in torch.stack(torch.aminmax(w.detach())).tolist())  # one sync
+    if not (lo == hi and lo > 0.0):
+        return None  # per-ray wavelengths: per-ray n(w), not a launch constant
+    polarized = type(rays) is RefPolarizedRays
+    try:
+        eng, table = _sg_engine(group, lo)
+    except UnsupportedSystem:
+        return None
+    if table.uses_polarization and not polarized:
+        return None  # RealRays.update() ignores Jones matrices; keep that on the reference
+    if getattr(eng, "device", dev) != dev and not _SG["force"]:
+        return None
+    planes = [t.detach().reshape(-1).contiguous() for t in planes]
+    prt = None
+    if polarized:
+        p = rays.p.reshape(n, 9)
+        prt = torch.cat([p.real.t(), p.imag.t()]).to(dtype).contiguous()  # (18, n)
+    res = eng.trace(planes, 0, record=True, prt=prt, first=skip, last=n_s - 1)
+
+    group.reset()
+    for s in range(skip, n_s):
+        surf = group.surfaces[s]
+        surf.x, surf.y, surf.z, surf.L, surf.M, surf.N, surf.intensity, surf.opd = res.rows(s)
+    last = n_s - 1
+    pre = res.rows(last - 1)[3:6] if last > skip else planes[3:6]
+    if not (skip == 0 and last == 0):  # an object surface alone interacts with nothing
+        rays.L0, rays.M0, rays.N0 = pre
+    rays.x, rays.y, rays.z, rays.L, rays.M, rays.N, rays.i, rays.opd = res.rows(last)
+    if polarized:
+        rays.p = prt_to_complex(prt)
+    return rays
+
+
 def enable(device=None, force=False):
     """Route EVERY `Optic` (existing and future) through the HIP path.
 
@@ -331,6 +433,21 @@ def enable(device=None, force=False):
     RealRayTracer.trace_generic = trace_generic
     RealRayTracer._hip_enabled = True
 
+    from optiland.surfaces.surface_group import SurfaceGroup
+
+    _ORIGINALS.setdefault("sg_trace", SurfaceGroup.trace)
+    _SG.update(device=device, force=force)
+
+    def sg_trace(self, rays, skip=0):
+        out = _hip_surface_group_trace(self, rays, skip)
+        if out is None:
+            _SG["fallbacks"] += 1
+            return _ORIGINALS["sg_trace"](self, rays, skip)
+        _SG["count"] += 1
+        return out
+
+    SurfaceGroup.trace = sg_trace
+
 
 def disable():
     from optiland.raytrace.real_ray_tracer import RealRayTracer
@@ -339,6 +456,9 @@ def disable():
         RealRayTracer.trace = _ORIGINALS["trace"]
         RealRayTracer.trace_generic = _ORIGINALS["trace_generic"]
         RealRayTracer._hip_enabled = False
+        from optiland.surfaces.surface_group import SurfaceGroup
+
+        SurfaceGroup.trace = _ORIGINALS["sg_trace"]
 
 
 def install(optic, device=None, force=False):

@@ -275,15 +275,16 @@ def _scalar_index(material, w: float, which: str) -> float:
     return hit
 
 
-def pack_optic(optic, wavelengths=None, name: str | None = None) -> SystemTable:
-    """Flatten `optic` (a reference `Optic`) for the given wavelengths (microns).
+def pack_surfaces(surfaces, wavelengths, name: str = "surfaces") -> SystemTable:
+    """Flatten a sequence of reference `Surface` objects (a `SurfaceGroup`'s list) for
+    the given wavelengths (microns): everything `SurfaceGroup.trace`
+    (surfaces/surface_group.py:245-257) needs -- no ray-generator scalars, no
+    polarisation state (those belong to the `Optic`, see `pack_optic`).
 
     Raises `UnsupportedSystem` for anything outside the fused path.
     """
     _INDEX_MEMO.clear()
-    surfaces = list(optic.surfaces)
-    if wavelengths is None:
-        wavelengths = [_f(w.value) for w in optic.wavelengths.wavelengths]
+    surfaces = list(surfaces)
     wl = np.array([float(w) for w in np.atleast_1d(wavelengths)], dtype=np.float64)
     n_s = len(surfaces)
     desc = np.zeros(n_s, dtype=S.SURFACE_DESC_DTYPE)
@@ -338,9 +339,22 @@ def pack_optic(optic, wavelengths=None, name: str | None = None) -> SystemTable:
         coeffs=np.asarray(coeffs, dtype=np.float64),
         optics=optics,
         wavelengths=wl,
-        name=name or (optic.name or type(optic).__name__),
+        name=name,
     )
     table.last_thickness = _f(surfaces[-1].thickness) if n_s else 0.0
+    return table
+
+
+def pack_optic(optic, wavelengths=None, name: str | None = None) -> SystemTable:
+    """Flatten `optic` (a reference `Optic`) for the given wavelengths (microns):
+    `pack_surfaces` + the ray-generator scalars + the polarisation state.
+
+    Raises `UnsupportedSystem` for anything outside the fused path.
+    """
+    if wavelengths is None:
+        wavelengths = [_f(w.value) for w in optic.wavelengths.wavelengths]
+    table = pack_surfaces(optic.surfaces, wavelengths,
+                          name or (optic.name or type(optic).__name__))
     _pack_raygen(optic, table)
     pol = optic.polarization
     if pol != "ignore":

@@ -359,3 +359,163 @@ def test_dropin_keeps_device_tables_per_wavelength(hip_on_cpu):
     lens.surfaces[2].geometry.radius = float(lens.surfaces[2].geometry.radius) * 1.02
     lens.trace(0.0, 0.0, 0.55, num_rays=3, distribution="hexapolar")
     assert len(t._hip_engines) == 4
+
+
+# ------------------------------------------------------------------------------------
+# the SurfaceGroup.trace(rays, skip) seam (SURVEY.md 8b "covers direct callers")
+# ------------------------------------------------------------------------------------
+@pytest.fixture()
+def sg_seam(hip_on_cpu):
+    from optiland_amd import integration
+    integration.enable(force=True)
+    integration._SG.update(count=0, fallbacks=0)
+    yield integration
+    integration.disable()
+
+
+def _clone_rays(be, rays):
+    import copy
+    out = copy.copy(rays)
+    for k, v in vars(rays).items():
+        if hasattr(v, "clone"):
+            setattr(out, k, v.clone())
+    return out
+
+
+@pytest.mark.parametrize("skip", [0, 1, 3])
+def test_surface_group_seam_matches_reference_loop(sg_seam, skip):
+    """Caller-built RealRays through `optic.surfaces.trace(rays, skip)`: in-place ray
+    state, L0/M0/N0, and every traced surface's record equal the reference's own loop;
+    surfaces before `skip` stay reset (empty)."""
+    import optiland.backend as be
+    from optiland.samples.objectives import CookeTriplet
+    lens = CookeTriplet()
+    gen = lens.ray_tracer.ray_generator
+    px, py = be.array(np.linspace(-0.8, 0.8, 41)), be.array(np.linspace(0.7, -0.5, 41))
+    start = gen.generate_rays(be.zeros_like(px), be.ones_like(px) * 0.6, px, py, 0.55)
+    if skip:  # walk the first surfaces with the reference so the start state is mid-system
+        for s in lens.surfaces.surfaces[:skip]:
+            s.trace(start)
+    a, b = _clone_rays(be, start), _clone_rays(be, start)
+    want = sg_seam._ORIGINALS["sg_trace"](lens.surfaces, a, skip)
+    rec_want = {k: [_np(be, getattr(s, k)) for s in lens.surfaces.surfaces]
+                for k in ("x", "y", "z", "L", "M", "N", "intensity", "opd")}
+    got = lens.surfaces.trace(b, skip=skip)
+    assert got is b and sg_seam._SG["count"] == 1 and sg_seam._SG["fallbacks"] == 0
+    for k in ("x", "y", "z", "L", "M", "N", "i", "opd", "L0", "M0", "N0", "w"):
+        np.testing.assert_allclose(_np(be, getattr(got, k)), _np(be, getattr(want, k)),
+                                   rtol=1e-10, atol=1e-11, err_msg=k)
+    for k, rows in rec_want.items():
+        for s, (surf, w_) in enumerate(zip(lens.surfaces.surfaces, rows)):
+            g_ = _np(be, getattr(surf, k))
+            assert g_.shape == w_.shape, (k, s)
+            np.testing.assert_allclose(g_, w_, rtol=1e-10, atol=1e-10, err_msg=f"{k}[{s}]")
+    assert _np(be, lens.surfaces.x).shape == (len(lens.surfaces.surfaces) - skip, 41) or skip == 0
+
+
+def test_surface_group_seam_advances_an_existing_prt(sg_seam):
+    """PolarizedRays whose `p` is no longer the identity (traced half way by the
+    reference) continue through surfaces[skip:] on the seam: p, i, and the record match
+    the reference loop.
+
+    The reference side runs on its NumPy backend (the parity target): on the torch
+    backend `cross(k0, k0)` is not exactly zero (fused multiply-adds), so the
+    `mag == 0` branch of PolarizedRays.get_local_basis (rays/polarized_rays.py:154-166)
+    is never taken and every undeviated ray -- every ray at the image plane -- gets an
+    s-vector made of rounding noise and a non-unitary PRT."""
+    import torch
+    import optiland.backend as be
+    from optiland.rays import PolarizationState
+    from optiland.samples.objectives import CookeTriplet
+
+    def build():
+        lens = CookeTriplet()
+        lens.surfaces.set_fresnel_coatings()
+        lens.updater.set_polarization(PolarizationState(is_polarized=False))
+        return lens
+
+    def start_rays(lens):
+        px, py = be.array(np.linspace(-0.7, 0.7, 29)), be.array(np.linspace(0.6, -0.6, 29))
+        return lens.ray_tracer.ray_generator.generate_rays(
+            be.zeros_like(px), be.ones_like(px) * 0.5, px, py, 0.55)
+
+    be.set_backend("numpy")
+    lens_np = build()
+    a = start_rays(lens_np)
+    assert type(a).__name__ == "PolarizedRays"
+    for s in lens_np.surfaces.surfaces[:4]:
+        s.trace(a)
+    assert float(abs(a.p.real[:, 0, 0] - 1).max()) > 1e-3   # not the identity any more
+    snap = {k: np.array(v) for k, v in vars(a).items() if isinstance(v, np.ndarray)}
+    want = lens_np.surfaces.trace(a, skip=4)                 # NumPy backend: seam declines
+    assert sg_seam._SG["count"] == 0
+    be.set_backend("torch")
+    lens_t = build()
+    b = start_rays(lens_t)
+    for k, v in snap.items():
+        setattr(b, k, torch.as_tensor(v))
+    got = lens_t.surfaces.trace(b, skip=4)
+    assert sg_seam._SG["count"] == 1
+    for k in ("x", "y", "z", "L", "M", "N", "i", "opd"):
+        np.testing.assert_allclose(_np(be, getattr(got, k)), np.asarray(getattr(want, k)),
+                                   rtol=1e-10, atol=1e-11, err_msg=k)
+    np.testing.assert_allclose(be.to_numpy(got.p), want.p, rtol=1e-9, atol=1e-10)
+    mk = lambda: PolarizationState(is_polarized=True, Ex=1.0, Ey=0.0,  # noqa: E731
+                                   phase_x=0.0, phase_y=0.0)
+    got.update_intensity(mk())
+    be.set_backend("numpy")
+    want.update_intensity(mk())
+    be.set_backend("torch")
+    np.testing.assert_allclose(_np(be, got.i), np.asarray(want.i), rtol=1e-9, atol=1e-12)
+
+
+def test_surface_group_seam_declines_what_it_must(sg_seam):
+    """Paraxial rays, per-ray wavelengths, polarised coatings with plain RealRays and the
+    NumPy backend all run the reference's loop untouched."""
+    import optiland.backend as be
+    from optiland.samples.objectives import CookeTriplet
+    lens = CookeTriplet()
+    gen = lens.ray_tracer.ray_generator
+    px = be.array(np.linspace(-0.5, 0.5, 7))
+    rays = gen.generate_rays(be.zeros_like(px), be.zeros_like(px), px, px, 0.55)
+    rays.w = rays.w * be.array(np.linspace(0.9, 1.1, 7))      # per-ray wavelengths
+    lens.surfaces.trace(rays)
+    assert (sg_seam._SG["count"], sg_seam._SG["fallbacks"]) == (0, 1)
+    lens.paraxial._ray_tracer.trace(0.0, 1.0, 0.55)              # ParaxialRays walk the same method
+    assert sg_seam._SG["count"] == 0 and sg_seam._SG["fallbacks"] >= 2
+    before = sg_seam._SG["fallbacks"]
+    be.set_backend("numpy")
+    lens2 = CookeTriplet()
+    r2 = lens2.ray_tracer.ray_generator.generate_rays(0.0, 0.0, np.zeros(3), np.zeros(3), 0.55)
+    lens2.surfaces.trace(r2)
+    assert sg_seam._SG["count"] == 0 and sg_seam._SG["fallbacks"] == before + 1
+    be.set_backend("torch")
+
+
+def test_irradiance_with_user_rays_runs_on_the_seam(sg_seam):
+    """IncoherentIrradiance(user_initial_rays=...) calls optic.surfaces.trace(rays)
+    directly (analysis/irradiance.py:279): with the seam enabled that trace is the HIP
+    launch, and the irradiance map equals the reference's."""
+    import optiland.backend as be
+    from optiland import analysis
+    from optiland.physical_apertures import RectangularAperture
+    from optiland.samples.objectives import CookeTriplet
+
+    def build():
+        lens = CookeTriplet()
+        lens.surfaces.surfaces[-1].aperture = RectangularAperture(-2.0, 2.0, -2.0, 2.0)
+        return lens
+    lens = build()
+    px, py = np.meshgrid(np.linspace(-0.9, 0.9, 31), np.linspace(-0.9, 0.9, 31))
+    px, py = be.array(px.ravel()), be.array(py.ravel())
+    rays = lens.ray_tracer.ray_generator.generate_rays(be.zeros_like(px), be.zeros_like(px),
+                                                       px, py, 0.55)
+    irr = analysis.IncoherentIrradiance(lens, res=(16, 16), user_initial_rays=_clone_rays(be, rays))
+    assert sg_seam._SG["count"] >= 1
+    got = _np(be, irr.data[0][0][0])
+    sg_seam.disable()
+    ref_irr = analysis.IncoherentIrradiance(build(), res=(16, 16),
+                                            user_initial_rays=_clone_rays(be, rays))
+    want = _np(be, ref_irr.data[0][0][0])
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
+    assert want.sum() > 0
