@@ -300,7 +300,7 @@ def _make_tracer_class():
 # --------------------------------------------------------------------------------------
 # SurfaceGroup.trace(rays, skip) -- the seam for callers that bring their own rays
 # --------------------------------------------------------------------------------------
-_SG = {"device": None, "force": False, "count": 0, "fallbacks": 0}
+_SG = {"device": None, "force": False, "count": 0, "fallbacks": 0, "foreign": 0}
 _PLANE_ATTRS = ("x", "y", "z", "L", "M", "N", "i", "opd")
 
 
@@ -313,15 +313,16 @@ def _sg_backend_ok(be) -> bool:
     return True if _SG["force"] else cfg.get_device() == "cuda"
 
 
-def _sg_engine(group, wavelength: float):
-    """(engine, table) for this SurfaceGroup at one wavelength, LRU-cached on the group
-    against the packed bytes (a changed surface re-packs and misses)."""
-    table = pack_surfaces(group.surfaces, [wavelength], name="SurfaceGroup")
+def _sg_engine(group, table, dev):
+    """(engine, table) for this SurfaceGroup's packed table on the rays' device,
+    LRU-cached on the group against the packed bytes (a changed surface re-packs and
+    misses)."""
     cache = group.__dict__.setdefault("_hip_engines", collections.OrderedDict())
-    key = _table_key(table)
+    dev = dev if dev.type == "cuda" else _SG["device"]
+    key = (_table_key(table), str(dev))
     hit = cache.get(key)
     if hit is None:
-        hit = cache[key] = (_tracer._make_engine(table, _SG["device"]), table)
+        hit = cache[key] = (_tracer._make_engine(table, dev), table)
         while len(cache) > _MAX_ENGINES:
             _, (old, _t) = cache.popitem(last=False)
             if hasattr(old, "close"):
@@ -331,6 +332,42 @@ def _sg_engine(group, wavelength: float):
     return hit
 
 
+def _sg_planes(rays):
+    """The 8 state planes of a reference ray bundle as they must be for a launch, or
+    None (not device tensors of one floating dtype / size, autograd attached)."""
+    planes = [getattr(rays, k, None) for k in _PLANE_ATTRS]
+    if any(not isinstance(t, torch.Tensor) for t in planes):
+        return None
+    dtype, dev, n = planes[0].dtype, planes[0].device, planes[0].numel()
+    if dtype not in (torch.float32, torch.float64) or n == 0 \
+            or any(t.dtype != dtype or t.device != dev or t.numel() != n or t.requires_grad
+                   for t in planes):
+        return None
+    if not _SG["force"] and dev.type != "cuda":
+        return None
+    return planes
+
+
+def _sg_run(group, eng, rays, planes, first, last, polarized):
+    """One fused launch over surfaces[first..last]; rays and surfaces updated in place."""
+    n, dtype = planes[0].numel(), planes[0].dtype
+    planes = [t.detach().reshape(-1).contiguous() for t in planes]
+    prt = None
+    if polarized:
+        p = rays.p.reshape(n, 9)
+        prt = torch.cat([p.real.t(), p.imag.t()]).to(dtype).contiguous()  # (18, n)
+    res = eng.trace(planes, 0, record=True, prt=prt, first=first, last=last)
+    for s in range(first, last + 1):
+        surf = group.surfaces[s]
+        surf.x, surf.y, surf.z, surf.L, surf.M, surf.N, surf.intensity, surf.opd = res.rows(s)
+    pre = res.rows(last - 1)[3:6] if last > first else planes[3:6]
+    if not (first == 0 and last == 0):  # an object surface alone interacts with nothing
+        rays.L0, rays.M0, rays.N0 = pre
+    rays.x, rays.y, rays.z, rays.L, rays.M, rays.N, rays.i, rays.opd = res.rows(last)
+    if polarized:
+        rays.p = prt_to_complex(prt)
+
+
 def _hip_surface_group_trace(group, rays, skip):
     """SurfaceGroup.trace on the HIP path, or None when the call is not eligible (the
     caller then runs the reference's own loop).  Mirrors surface_group.py:245-257:
@@ -338,7 +375,16 @@ def _hip_surface_group_trace(group, rays, skip):
     x,y,z,L,M,N,intensity,opd (standard_surface.py:260-274), `rays` is mutated in place
     and returned; L0/M0/N0 are the direction cosines before the last interaction
     (interactions/refractive_reflective_model.py:41) and PolarizedRays.p is advanced
-    from its CURRENT value (rays/polarized_rays.py:180-202)."""
+    from its CURRENT value (rays/polarized_rays.py:180-202).
+
+    Surfaces the fused path does not implement (thin lens, grating, phase, Forbes / NURBS
+    / grid-sag geometry, GRIN media, BSDF, thin-film coating ...) do not disqualify the
+    whole system: they are traced by their own `Surface.trace(rays)` on the same device
+    tensors, and the runs of supported surfaces between them are one launch each
+    (`ol_trace`'s [first, last] range; SURVEY.md section 8b "split the system into supported
+    segments").  A bundle a thin lens left un-normalised (`is_normalized == False`) takes
+    one more reference surface, whose propagation renormalises it
+    (propagation/homogeneous.py:55-56)."""
     import optiland.backend as be
     from optiland.rays import PolarizedRays as RefPolarizedRays
     from optiland.rays import RealRays as RefRealRays
@@ -347,49 +393,40 @@ def _hip_surface_group_trace(group, rays, skip):
         return None
     n_s = len(group.surfaces)
     skip = int(skip)
-    if not (0 <= skip < n_s) or not getattr(rays, "is_normalized", True):
+    if not (0 <= skip < n_s) or _sg_planes(rays) is None:
         return None
-    planes = [getattr(rays, k, None) for k in _PLANE_ATTRS]
     w = getattr(rays, "w", None)
-    if any(not isinstance(t, torch.Tensor) for t in planes + [w]):
-        return None
-    dtype, dev, n = planes[0].dtype, planes[0].device, planes[0].numel()
-    if dtype not in (torch.float32, torch.float64) or n == 0 or w.numel() == 0 \
-            or any(t.dtype != dtype or t.device != dev or t.numel() != n or t.requires_grad
-                   for t in planes):
-        return None
-    if not _SG["force"] and dev.type != "cuda":
+    if not isinstance(w, torch.Tensor) or w.numel() == 0:
         return None
     lo, hi = (float(v) for v in torch.stack(torch.aminmax(w.detach())).tolist())  # one sync
     if not (lo == hi and lo > 0.0):
         return None  # per-ray wavelengths: per-ray n(w), not a launch constant
     polarized = type(rays) is RefPolarizedRays
     try:
-        eng, table = _sg_engine(group, lo)
+        table = pack_surfaces(group.surfaces, [lo], name="SurfaceGroup", tolerate=True)
     except UnsupportedSystem:
         return None
+    foreign = set(table.unsupported)
+    if len(foreign) >= n_s - skip - (1 if skip == 0 else 0):
+        return None  # nothing but the object row would run fused
     if table.uses_polarization and not polarized:
         return None  # RealRays.update() ignores Jones matrices; keep that on the reference
-    if getattr(eng, "device", dev) != dev and not _SG["force"]:
-        return None
-    planes = [t.detach().reshape(-1).contiguous() for t in planes]
-    prt = None
-    if polarized:
-        p = rays.p.reshape(n, 9)
-        prt = torch.cat([p.real.t(), p.imag.t()]).to(dtype).contiguous()  # (18, n)
-    res = eng.trace(planes, 0, record=True, prt=prt, first=skip, last=n_s - 1)
+    eng, table = _sg_engine(group, table, rays.x.device)
 
     group.reset()
-    for s in range(skip, n_s):
-        surf = group.surfaces[s]
-        surf.x, surf.y, surf.z, surf.L, surf.M, surf.N, surf.intensity, surf.opd = res.rows(s)
-    last = n_s - 1
-    pre = res.rows(last - 1)[3:6] if last > skip else planes[3:6]
-    if not (skip == 0 and last == 0):  # an object surface alone interacts with nothing
-        rays.L0, rays.M0, rays.N0 = pre
-    rays.x, rays.y, rays.z, rays.L, rays.M, rays.N, rays.i, rays.opd = res.rows(last)
-    if polarized:
-        rays.p = prt_to_complex(prt)
+    s = skip
+    while s < n_s:
+        planes = _sg_planes(rays) if getattr(rays, "is_normalized", True) else None
+        if s in foreign or planes is None:
+            group.surfaces[s].trace(rays)  # the reference's own surface, same tensors
+            _SG["foreign"] += 1
+            s += 1
+            continue
+        e = s
+        while e + 1 < n_s and (e + 1) not in foreign:
+            e += 1
+        _sg_run(group, eng, rays, planes, s, e, polarized)
+        s = e + 1
     return rays
 
 

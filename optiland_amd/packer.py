@@ -275,23 +275,29 @@ def _scalar_index(material, w: float, which: str) -> float:
     return hit
 
 
-def pack_surfaces(surfaces, wavelengths, name: str = "surfaces") -> SystemTable:
+def pack_surfaces(surfaces, wavelengths, name: str = "surfaces",
+                  tolerate: bool = False) -> SystemTable:
     """Flatten a sequence of reference `Surface` objects (a `SurfaceGroup`'s list) for
     the given wavelengths (microns): everything `SurfaceGroup.trace`
     (surfaces/surface_group.py:245-257) needs -- no ray-generator scalars, no
     polarisation state (those belong to the `Optic`, see `pack_optic`).
 
-    Raises `UnsupportedSystem` for anything outside the fused path.
+    Raises `UnsupportedSystem` for anything outside the fused path -- or, with
+    `tolerate`, packs a never-traced placeholder row for every such surface (except the
+    object surface) and lists their indices in `table.unsupported`: the caller then
+    launches the fused trace on the `[first, last]` runs between them and leaves those
+    surfaces to the reference (integration._hip_surface_group_trace).
     """
     _INDEX_MEMO.clear()
     surfaces = list(surfaces)
+    unsupported: list = []
     wl = np.array([float(w) for w in np.atleast_1d(wavelengths)], dtype=np.float64)
     n_s = len(surfaces)
     desc = np.zeros(n_s, dtype=S.SURFACE_DESC_DTYPE)
     optics = np.zeros((n_s, wl.size), dtype=S.SURFACE_OPTICS_DTYPE)
     coeffs: list = []
 
-    for i, surf in enumerate(surfaces):
+    def pack_one(i, surf):
         row = desc[i]
         geom = surf.geometry
         R, t = cs_to_affine(geom.cs)
@@ -315,7 +321,7 @@ def pack_surfaces(surfaces, wavelengths, name: str = "surfaces") -> SystemTable:
             optics[i, :]["n2"] = [
                 _scalar_index(surf.material_post, float(w), "n") for w in wl
             ]
-            continue
+            return
         row["interaction"] = (
             S.INTERACT_REFLECT if im.is_reflective else S.INTERACT_REFRACT
         )
@@ -334,6 +340,20 @@ def pack_surfaces(surfaces, wavelengths, name: str = "surfaces") -> SystemTable:
             absorb = (4.0 * math.pi * k1 / w) * 1e3 if k1 > 0 else 0.0
             optics[i, j] = (n1, n2, absorb)
 
+    for i, surf in enumerate(surfaces):
+        mark = len(coeffs)
+        try:
+            pack_one(i, surf)
+        except UnsupportedSystem:
+            if not tolerate or i == 0:
+                raise
+            del coeffs[mark:]
+            desc[i] = np.zeros((), dtype=S.SURFACE_DESC_DTYPE)  # placeholder, never traced
+            desc[i]["rot"] = _EYE3.reshape(-1)
+            desc[i]["interaction"] = S.INTERACT_RECORD_ONLY
+            optics[i, :] = (1.0, 1.0, 0.0)
+            unsupported.append(i)
+
     table = SystemTable(
         surfaces=desc,
         coeffs=np.asarray(coeffs, dtype=np.float64),
@@ -342,6 +362,7 @@ def pack_surfaces(surfaces, wavelengths, name: str = "surfaces") -> SystemTable:
         name=name,
     )
     table.last_thickness = _f(surfaces[-1].thickness) if n_s else 0.0
+    table.unsupported = tuple(unsupported)
     return table
 
 

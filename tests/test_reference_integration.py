@@ -519,3 +519,71 @@ def test_irradiance_with_user_rays_runs_on_the_seam(sg_seam):
     want = _np(be, ref_irr.data[0][0][0])
     np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
     assert want.sum() > 0
+
+
+def _grating_lens(be):
+    """tests/test_grating.py:13-44 with a curved lens after the grating."""
+    from optiland.optic import Optic
+    lens = Optic()
+    lens.surfaces.add(index=0, radius=be.inf, thickness=be.inf)
+    lens.surfaces.add(index=1, radius=80.0, thickness=4, material="N-BK7")
+    lens.surfaces.add(index=2, radius=-90.0, thickness=5)
+    lens.surfaces.add(index=3, radius=be.inf, thickness=3, surface_type="grating", grating_order=-1,
+                      grating_period=5.0, groove_orientation_angle=0.0, is_stop=True,
+                      material="N-BK7")
+    lens.surfaces.add(index=4, radius=-60.0, thickness=6)
+    lens.surfaces.add(index=5, radius=50.0, thickness=3, material="SF6")
+    lens.surfaces.add(index=6, radius=be.inf, thickness=30)
+    lens.surfaces.add(index=7)
+    lens.set_aperture(aperture_type="EPD", value=12)
+    lens.fields.set_type(field_type="angle")
+    lens.fields.add(y=0)
+    lens.fields.add(y=5)
+    lens.wavelengths.add(value=0.587, is_primary=True)
+    lens.updater.update_paraxial()
+    return lens
+
+
+def _thin_lens_system(be):
+    from optiland.optic import Optic
+    lens = Optic()
+    lens.surfaces.add(index=0, radius=be.inf, thickness=be.inf)
+    lens.surfaces.add(index=1, radius=70.0, thickness=4, material="N-BK7", is_stop=True)
+    lens.surfaces.add(index=2, radius=-120.0, thickness=6)
+    lens.surfaces.add(index=3, surface_type="paraxial", f=80, thickness=5)
+    lens.surfaces.add(index=4, radius=40.0, thickness=3, material="N-SF11")
+    lens.surfaces.add(index=5, radius=-300.0, thickness=25)
+    lens.surfaces.add(index=6)
+    lens.set_aperture(aperture_type="EPD", value=10)
+    lens.fields.set_type(field_type="angle")
+    lens.fields.add(y=0)
+    lens.fields.add(y=4)
+    lens.wavelengths.add(value=0.55, is_primary=True)
+    lens.updater.update_paraxial()
+    return lens
+
+
+@pytest.mark.parametrize("build", [_grating_lens, _thin_lens_system], ids=["grating", "thin_lens"])
+def test_unsupported_surface_is_bridged_by_the_reference(sg_seam, build):
+    """A grating / thin lens in the middle of a system is left to the reference's own
+    Surface.trace; the runs of supported surfaces on either side are fused launches.
+    Whole-trace results (Optic.trace -> reference ray generation -> patched
+    SurfaceGroup.trace) equal the unpatched reference."""
+    import optiland.backend as be
+    lens = build(be)
+    got = lens.trace(0.0, 1.0, lens.primary_wavelength, 8, "hexapolar")
+    c = dict(sg_seam._SG)
+    assert c["count"] == 1 and c["foreign"] >= 1 and c["fallbacks"] == 0
+    rec_got = {k: _np(be, getattr(lens.surfaces, k)) for k in ("x", "y", "z", "L", "M", "N",
+                                                                "intensity", "opd")}
+    sg_seam.disable()
+    lens2 = build(be)
+    want = lens2.trace(0.0, 1.0, lens2.primary_wavelength, 8, "hexapolar")
+    for k in ("x", "y", "z", "L", "M", "N", "i", "opd"):
+        np.testing.assert_allclose(_np(be, getattr(got, k)), _np(be, getattr(want, k)),
+                                   rtol=1e-9, atol=1e-10, err_msg=k)
+    assert np.isfinite(_np(be, want.x)).mean() > 0.9
+    for k, a in rec_got.items():
+        b = _np(be, getattr(lens2.surfaces, k))
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9, err_msg=k)
