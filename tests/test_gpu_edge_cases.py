@@ -358,3 +358,42 @@ def test_graphed_trace_replays_the_eager_kernels_bit_for_bit():
             g.replay()  # status word is re-zeroed inside the graph
     finally:
         hip.close()
+
+
+@pytest.mark.parametrize("case", ["tilted_fold", "double_gauss", "rc_asphere"])
+def test_segments_around_a_placeholder_row(case):
+    """What the SurfaceGroup seam does around a surface the fused path does not implement
+    (integration._hip_surface_group_trace): its row is a never-traced placeholder, the
+    runs [0, k-1] and [k+1, S] are separate launches and the caller moves the rays across
+    surface k itself.  Here the 'foreign' surface is traced by a second handle holding the
+    ORIGINAL table, so the chain must reproduce the one-launch trace: the run after the
+    gap starts from the global frame, not from a frame relative to the placeholder."""
+    import copy
+    from optiland_amd.engine import HipSystem
+    table, data = load_case(case)
+    S_ = table.num_surfaces - 1
+    k = max(2, S_ // 2)
+    holed = copy.deepcopy(table)
+    holed.surfaces[k] = np.zeros((), dtype=S.SURFACE_DESC_DTYPE)
+    holed.surfaces[k]["rot"] = np.eye(3).reshape(-1)
+    holed.surfaces[k]["interaction"] = S.INTERACT_RECORD_ONLY
+    holed.optics[k, :] = (1.0, 1.0, 0.0)
+    dtype = torch.float64
+    r = data["rays_in"]
+    n = r.shape[1]
+    mk = lambda: [torch.tensor(r[j], dtype=dtype, device=DEV) for j in range(7)] + \
+        [torch.zeros(n, dtype=dtype, device=DEV)]  # noqa: E731
+    whole, gap = HipSystem(table, DEV), HipSystem(holed, DEV)
+    try:
+        full = whole.trace(mk(), 0, record=True)
+        rays = mk()
+        a = gap.trace(rays, 0, record=True, first=0, last=k - 1, write_rays=True)
+        b = whole.trace(rays, 0, record=True, first=k, last=k, write_rays=True)
+        c = gap.trace(rays, 0, record=True, first=k + 1, last=S_, write_rays=True)
+        got = torch.cat([a.record[:, :, :n], b.record[:, :, :n], c.record[:, :, :n]])
+        assert_close_planes(got.cpu().numpy(), full.record[:, :, :n].cpu().numpy(),
+                            1e-10, 1e-10, case)
+        for u, v in zip(rays, full.rows(S_)):
+            np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-10, atol=1e-10)
+    finally:
+        whole.close(), gap.close()
