@@ -510,3 +510,49 @@ def test_random_ray_generation(seed, dtype):
             assert float((u - v).abs().max()) <= (1e-5 if dtype == torch.float32 else 1e-12) * scale
     finally:
         hip.close()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("seed", range(28))
+def test_random_newton_raphson_system_polarised(seed, dtype):
+    """The Newton-Raphson family with Fresnel / Simple coatings and a polarised state
+    (the POLK x NR kernel instantiations of configuration C5): rays, PRT and the
+    update_intensity epilogue against the oracle."""
+    from oracle import oracle
+    from optiland_amd.engine import HipSystem
+    from optiland_amd.rays import prt_to_complex
+    table, rays = random_nr_system(seed)
+    rng = np.random.default_rng(40_000 + seed)
+    for i in range(1, table.num_surfaces - 1):
+        ck = rng.choice([S.COAT_FRESNEL, S.COAT_FRESNEL, S.COAT_SIMPLE, S.COAT_NONE])
+        table.surfaces[i]["coating_kind"] = ck
+        if ck == S.COAT_SIMPLE:
+            table.surfaces[i]["coat"] = (rng.uniform(0.6, 1.0), rng.uniform(0.0, 0.4))
+    table.polarization = {"is_polarized": bool(seed % 2), "Ex": 0.8, "Ey": 0.6, "phase_x": 0.3,
+                          "phase_y": -0.4}
+    if dtype == torch.float32:
+        rays = {k: v.astype(np.float32).astype(np.float64) for k, v in rays.items()}
+    n = rays["x"].size
+    out = oracle.trace(table, rays, 0, record=True, polarized=True)
+    assert out["status"] == 0
+    hip = HipSystem(table, DEV)
+    try:
+        planes = [torch.tensor(rays[k], dtype=dtype, device=DEV) for k in PLANES[:7]]
+        planes.append(torch.zeros_like(planes[0]))
+        k0 = [planes[3].clone(), planes[4].clone(), planes[5].clone()]
+        i0 = planes[6].clone()
+        prt = torch.empty((9, n), dtype=dtype, device=DEV)
+        res = hip.trace(planes, 0, record=True, prt=prt, prt_identity=True)
+        got = res.record[:, :, :n].double().cpu().numpy()
+        p = prt_to_complex(prt).cpu().numpy().astype(np.complex128)
+        iu = hip.polarized_intensity(prt, k0, i0, table.polarization).double().cpu().numpy()
+    finally:
+        hip.close()
+    tol = 1e-7 if dtype == torch.float64 else 1e-4
+    assert_close_planes(got, out["record"], tol, tol, f"nrpol{seed}")
+    assert np.array_equal(np.isnan(p.real), np.isnan(out["prt"].real))
+    np.testing.assert_allclose(np.nan_to_num(p), np.nan_to_num(out["prt"]), rtol=0, atol=tol * 10)
+    want_i, status = oracle.polarized_intensity(out["prt"], rays["L"], rays["M"], rays["N"],
+                                                rays["i"], table.polarization)
+    assert status == 0
+    np.testing.assert_allclose(np.nan_to_num(iu), np.nan_to_num(want_i), rtol=0, atol=tol * 10)
