@@ -556,3 +556,78 @@ def test_random_newton_raphson_system_polarised(seed, dtype):
                                                 rays["i"], table.polarization)
     assert status == 0
     np.testing.assert_allclose(np.nan_to_num(iu), np.nan_to_num(want_i), rtol=0, atol=tol * 10)
+
+
+def _random_raygen(rng, table):
+    """Generator scalars that put a tame bundle onto a `random_nr_system` lens."""
+    z1 = float(table.surfaces[1]["origin"][2])
+    infinite = bool(rng.random() < 0.5)
+    kind = int(rng.integers(0, 2)) if not infinite else int(rng.choice([0, 2]))
+    rg = {"object_infinite": 1.0 if infinite else 0.0, "field_kind": float(kind),
+          "EPL": z1 + float(rng.uniform(0.0, 6.0)), "EPD": float(rng.uniform(3.0, 7.0)),
+          "offset": float(rng.uniform(5, 30)) if infinite else 0.0,
+          "z_first": z1 if infinite else z1 - float(rng.uniform(40, 120)),
+          "tele_dz": 0.0, "apod_kind": float(rng.integers(0, 7)),
+          "apod_a": float(rng.uniform(0.6, 1.2)), "apod_b": float(rng.uniform(0.3, 0.9))}
+    rg["max_field"] = float(rng.uniform(0.5, 3.0))          # degrees or mm
+    if kind == 2:
+        rg["field_scale"] = float(rng.uniform(0.005, 0.04))  # slope per unit H
+    if kind == 1 and rng.random() < 0.5:
+        rg["tele_dz"] = float(rng.uniform(20, 60))           # object-space telecentric
+    if int(rg["apod_kind"]) == 5:
+        rg["apod_b"] = float(rng.uniform(2.0, 6.0))
+    if int(rg["apod_kind"]) == 4:
+        rg["apod_b"] = float(rng.uniform(0.5, 3.0))
+    return rg
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("seed", range(28))
+def test_random_fused_spot(seed, dtype):
+    """generate -> trace -> reduce in ONE kernel (`ol_trace_spot`: its own instantiations
+    per Newton-Raphson class, field planes / uniform field, apodization on / off) on random
+    Newton-Raphson-family lenses with random generator scalars, against the oracle's
+    generate + trace + numpy moments; per-ray hits as well as the seven moments."""
+    from tests.test_gpu_spot import _check_moments, _oracle_spot, _scale
+    from optiland_amd.engine import HipSystem
+    table, _ = random_nr_system(seed)
+    rng = np.random.default_rng(50_000 + seed)
+    table.raygen = _random_raygen(rng, table)
+    n = 20_011
+    r, th = np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
+    dev = lambda a: torch.as_tensor(a, dtype=dtype, device=DEV)  # noqa: E731
+    px, py = dev(r * np.cos(th)), dev(r * np.sin(th))
+    planes = bool(seed % 2)              # per-ray field planes or one launch-uniform field
+    if planes:
+        hx, hy = dev(rng.uniform(-1, 1, n)), dev(rng.uniform(-1, 1, n))
+        vx, vy = dev(rng.uniform(0.8, 1.0, n)), dev(rng.uniform(0.8, 1.0, n))
+    else:
+        f, v = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))), (0.95, 0.9)
+        one = torch.ones(n, dtype=dtype, device=DEV)
+        hx, hy, vx, vy = one * f[0], one * f[1], one * v[0], one * v[1]
+    center = (float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2)))
+    want, (wx, wy, wi) = _oracle_spot(table, 0, hx, hy, px, py, vx, vy, center)
+    hits = [torch.empty(n, dtype=dtype, device=DEV) for _ in range(3)]
+    hip = HipSystem(table, DEV)
+    try:
+        if planes:
+            got = hip.trace_spot(px, py, 0, hx=hx, hy=hy, vx=vx, vy=vy, center=center, hits=hits)
+        else:
+            got = hip.trace_spot(px, py, 0, field=f, vig=v, center=center, hits=hits)
+        got = got.cpu().numpy()
+    finally:
+        hip.close()
+    gx, gy, gi = (h.double().cpu().numpy() for h in hits)
+    scale = _scale(table, wx, wy)
+    assert want[0] > 0.05 * n, "bundle lost: the fuzz case tests nothing"
+    if dtype == torch.float64:
+        assert np.array_equal(gi > 0, wi > 0)
+        _check_moments(got, want, scale, 1e-7)
+        tol = 1e-7
+    else:
+        assert ((gi > 0) == (wi > 0)).mean() > 0.998   # rim rays may round either way
+        tol = 1e-4
+    both = (gi > 0) & (wi > 0)
+    np.testing.assert_allclose(gx[both], wx[both], rtol=0, atol=tol * scale)
+    np.testing.assert_allclose(gy[both], wy[both], rtol=0, atol=tol * scale)
+    np.testing.assert_allclose(gi[both], wi[both], rtol=0, atol=max(tol, 1e-9) * 10)
