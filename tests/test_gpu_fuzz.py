@@ -631,3 +631,39 @@ def test_random_fused_spot(seed, dtype):
     np.testing.assert_allclose(gx[both], wx[both], rtol=0, atol=tol * scale)
     np.testing.assert_allclose(gy[both], wy[both], rtol=0, atol=tol * scale)
     np.testing.assert_allclose(gi[both], wi[both], rtol=0, atol=max(tol, 1e-9) * 10)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_wavefront_opd(seed):
+    """`ol_wavefront_opd` (reference-sphere path length + tilt removal, wavefront/
+    strategy.py:83-139,163-215) against the oracle on random image-plane bundles and
+    random reference spheres, fp64: OPD to 1e-9 waves (relative to its magnitude),
+    pupil coordinates to 1e-10 of the sphere radius."""
+    from oracle import oracle
+    from optiland_amd.engine import HipSystem
+    from optiland_amd import load_system
+    rng = np.random.default_rng(60_000 + seed)
+    n = 5003
+    R = float(rng.uniform(30, 400)) * (1 if rng.random() < 0.8 else -1)
+    zc = float(rng.uniform(50, 150))
+    params = {"xc": float(rng.uniform(-2, 2)), "yc": float(rng.uniform(-2, 2)), "zc": zc - R,
+              "R": R, "n_image": float(rng.choice([1.0, 1.33])), "opd_ref": float(rng.uniform(90, 110)),
+              "ux": float(rng.uniform(-0.05, 0.05)) if seed % 2 else 0.0,
+              "uy": float(rng.uniform(-0.05, 0.05)) if seed % 2 else 0.0,
+              "half_epd": float(rng.uniform(3, 12)), "wavelength_um": float(rng.uniform(0.4, 1.6))}
+    L, M = rng.uniform(-0.15, 0.15, n), rng.uniform(-0.15, 0.15, n)
+    rays7 = [rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n), np.full(n, zc),
+             L, M, np.sqrt(1 - L * L - M * M), rng.uniform(95, 105, n)]
+    r, th = np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
+    px, py = r * np.cos(th), r * np.sin(th)
+    want, want_pupil = oracle.wavefront_opd(params, rays7, px, py)
+    hip = HipSystem(load_system("cooke_generic"), DEV)
+    try:
+        dev = lambda a: torch.as_tensor(a, dtype=torch.float64, device=DEV).contiguous()  # noqa: E731
+        got, pupil = hip.wavefront_opd(params, [dev(a) for a in rays7], dev(px), dev(py))
+        got, pupil = got.cpu().numpy(), pupil.cpu().numpy()
+    finally:
+        hip.close()
+    assert np.isfinite(want).all()
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(want).max()))
+    np.testing.assert_allclose(pupil, want_pupil, rtol=0, atol=1e-10 * abs(R))
