@@ -94,6 +94,13 @@ class HipSystem:
         except Exception:
             pass
 
+    def __reduce__(self):
+        """copy.deepcopy / pickle: a device handle cannot be copied bit for bit, so the
+        copy is a fresh `ol_system` built from the same table on the same device.  The
+        drop-in caches engines on reference objects (tracer, SurfaceGroup) that the
+        reference deep-copies (tolerancing, optimisation, paraxial_to_thick ...)."""
+        return (HipSystem, (self.table, str(self.device)))
+
     @property
     def num_surfaces(self) -> int:
         return self.table.num_surfaces

@@ -293,6 +293,9 @@ def _make_tracer_class():
     # the reference's own implementations, captured before enable() can patch them
     _ORIGINALS["trace"] = RealRayTracer.trace
     _ORIGINALS["trace_generic"] = RealRayTracer.trace_generic
+    from optiland.surfaces.surface_group import SurfaceGroup
+
+    _ORIGINALS["sg_trace"] = SurfaceGroup.trace
     _TRACER_CLASS = OptilandHipRayTracer
     return OptilandHipRayTracer
 
@@ -304,13 +307,17 @@ _SG = {"device": None, "force": False, "count": 0, "fallbacks": 0, "foreign": 0}
 _PLANE_ATTRS = ("x", "y", "z", "L", "M", "N", "i", "opd")
 
 
-def _sg_backend_ok(be) -> bool:
+def _sg_force(group) -> bool:
+    return bool(_SG["force"] or group.__dict__.get("_hip_force", False))
+
+
+def _sg_backend_ok(be, force: bool) -> bool:
     if be.get_backend() not in (BACKEND_NAME, "torch"):
         return False
     cfg = be._backends[be.get_backend()]._config
     if cfg.grad_mode.requires_grad:
         return False
-    return True if _SG["force"] else cfg.get_device() == "cuda"
+    return True if force else cfg.get_device() == "cuda"
 
 
 def _sg_engine(group, table, dev):
@@ -318,7 +325,7 @@ def _sg_engine(group, table, dev):
     LRU-cached on the group against the packed bytes (a changed surface re-packs and
     misses)."""
     cache = group.__dict__.setdefault("_hip_engines", collections.OrderedDict())
-    dev = dev if dev.type == "cuda" else _SG["device"]
+    dev = dev if dev.type == "cuda" else (group.__dict__.get("_hip_device") or _SG["device"])
     key = (_table_key(table), str(dev))
     hit = cache.get(key)
     if hit is None:
@@ -332,7 +339,7 @@ def _sg_engine(group, table, dev):
     return hit
 
 
-def _sg_planes(rays):
+def _sg_planes(rays, force: bool):
     """The 8 state planes of a reference ray bundle as they must be for a launch, or
     None (not device tensors of one floating dtype / size, autograd attached)."""
     planes = [getattr(rays, k, None) for k in _PLANE_ATTRS]
@@ -343,7 +350,7 @@ def _sg_planes(rays):
             or any(t.dtype != dtype or t.device != dev or t.numel() != n or t.requires_grad
                    for t in planes):
         return None
-    if not _SG["force"] and dev.type != "cuda":
+    if not force and dev.type != "cuda":
         return None
     return planes
 
@@ -389,11 +396,12 @@ def _hip_surface_group_trace(group, rays, skip):
     from optiland.rays import PolarizedRays as RefPolarizedRays
     from optiland.rays import RealRays as RefRealRays
 
-    if type(rays) not in (RefRealRays, RefPolarizedRays) or not _sg_backend_ok(be):
+    force = _sg_force(group)
+    if type(rays) not in (RefRealRays, RefPolarizedRays) or not _sg_backend_ok(be, force):
         return None
     n_s = len(group.surfaces)
     skip = int(skip)
-    if not (0 <= skip < n_s) or _sg_planes(rays) is None:
+    if not (0 <= skip < n_s) or _sg_planes(rays, force) is None:
         return None
     w = getattr(rays, "w", None)
     if not isinstance(w, torch.Tensor) or w.numel() == 0:
@@ -416,7 +424,7 @@ def _hip_surface_group_trace(group, rays, skip):
     group.reset()
     s = skip
     while s < n_s:
-        planes = _sg_planes(rays) if getattr(rays, "is_normalized", True) else None
+        planes = _sg_planes(rays, force) if getattr(rays, "is_normalized", True) else None
         if s in foreign or planes is None:
             group.surfaces[s].trace(rays)  # the reference's own surface, same tensors
             _SG["foreign"] += 1
@@ -428,6 +436,17 @@ def _hip_surface_group_trace(group, rays, skip):
         _sg_run(group, eng, rays, planes, s, e, polarized)
         s = e + 1
     return rays
+
+
+def _sg_trace(self, rays, skip=0):
+    """Replacement for SurfaceGroup.trace (class-wide under enable(), on one group under
+    install())."""
+    out = _hip_surface_group_trace(self, rays, skip)
+    if out is None:
+        _SG["fallbacks"] += 1
+        return _ORIGINALS["sg_trace"](self, rays, skip)
+    _SG["count"] += 1
+    return out
 
 
 def enable(device=None, force=False):
@@ -475,15 +494,7 @@ def enable(device=None, force=False):
     _ORIGINALS.setdefault("sg_trace", SurfaceGroup.trace)
     _SG.update(device=device, force=force)
 
-    def sg_trace(self, rays, skip=0):
-        out = _hip_surface_group_trace(self, rays, skip)
-        if out is None:
-            _SG["fallbacks"] += 1
-            return _ORIGINALS["sg_trace"](self, rays, skip)
-        _SG["count"] += 1
-        return out
-
-    SurfaceGroup.trace = sg_trace
+    SurfaceGroup.trace = _sg_trace
 
 
 def disable():
@@ -496,6 +507,7 @@ def disable():
         from optiland.surfaces.surface_group import SurfaceGroup
 
         SurfaceGroup.trace = _ORIGINALS["sg_trace"]
+        _SG.update(device=None, force=False)
 
 
 def install(optic, device=None, force=False):
@@ -505,6 +517,16 @@ def install(optic, device=None, force=False):
     new = cls(optic, device=device, force=force)
     new.ray_aiming_config = dict(getattr(old, "ray_aiming_config", new.ray_aiming_config))
     optic.ray_tracer = new
+    # this optic's SurfaceGroup too: caller-built rays, and the surface loop of traces whose
+    # ray generation stays on the reference (aiming modes, unsupported surfaces bridged)
+    import types
+
+    from optiland.surfaces.surface_group import SurfaceGroup
+
+    _ORIGINALS.setdefault("sg_trace", SurfaceGroup.trace)
+    group = optic.surfaces
+    group.__dict__["_hip_force"], group.__dict__["_hip_device"] = bool(force), device
+    group.__dict__["trace"] = types.MethodType(_sg_trace, group)
     return new
 
 
@@ -514,3 +536,5 @@ def uninstall(optic):
     cfg = dict(optic.ray_tracer.ray_aiming_config)
     optic.ray_tracer = RealRayTracer(optic)
     optic.ray_tracer.ray_aiming_config = cfg
+    for k in ("trace", "_hip_force", "_hip_device"):
+        optic.surfaces.__dict__.pop(k, None)

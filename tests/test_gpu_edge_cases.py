@@ -397,3 +397,26 @@ def test_segments_around_a_placeholder_row(case):
             np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-10, atol=1e-10)
     finally:
         whole.close(), gap.close()
+
+
+def test_engine_survives_deepcopy_and_pickle():
+    """The drop-in caches engines on reference objects the reference deep-copies; a
+    HipSystem copy is a fresh handle on the same table, and traces identically."""
+    import copy
+    import pickle
+    from optiland_amd.engine import HipSystem
+    table, data = load_case("double_gauss")
+    r = data["rays_in"]
+    n = r.shape[1]
+    mk = lambda: [torch.tensor(r[j], dtype=torch.float64, device=DEV) for j in range(7)] + \
+        [torch.zeros(n, dtype=torch.float64, device=DEV)]  # noqa: E731
+    a = HipSystem(table, DEV)
+    holder = {"engines": {"k": (a, table)}, "tag": 3}
+    b = copy.deepcopy(holder)["engines"]["k"][0]
+    c = pickle.loads(pickle.dumps(a))
+    assert b is not a and len({a._handle.value, b._handle.value, c._handle.value}) == 3
+    want = a.trace(mk(), 0, record=True).record
+    a.close()                                   # the copies do not depend on the original
+    for other in (b, c):
+        assert torch.equal(other.trace(mk(), 0, record=True).record, want)
+        other.close()

@@ -587,3 +587,29 @@ def test_unsupported_surface_is_bridged_by_the_reference(sg_seam, build):
         b = _np(be, getattr(lens2.surfaces, k))
         assert a.shape == b.shape
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9, err_msg=k)
+
+
+def test_install_alone_also_bridges_on_its_own_surface_group(hip_on_cpu):
+    """install(optic) patches that optic's SurfaceGroup instance only: its grating system
+    runs fused around the grating, another optic's SurfaceGroup is untouched, and
+    uninstall() removes the instance patch."""
+    be = hip_on_cpu
+    from optiland_amd import integration
+    integration._SG.update(count=0, fallbacks=0, foreign=0)
+    lens, other = _grating_lens(be), _grating_lens(be)
+    tracer = integration.install(lens, force=True)
+    got = lens.trace(0.0, 1.0, lens.primary_wavelength, 8, "hexapolar")
+    assert tracer.last_path == "reference"            # ray generation + driver: reference
+    assert integration._SG["count"] == 1 and integration._SG["foreign"] >= 1
+    want = other.trace(0.0, 1.0, other.primary_wavelength, 8, "hexapolar")
+    assert integration._SG["count"] == 1              # the other optic never entered the seam
+    for k in ("x", "y", "z", "L", "M", "N", "i", "opd"):
+        np.testing.assert_allclose(_np(be, getattr(got, k)), _np(be, getattr(want, k)),
+                                   rtol=1e-9, atol=1e-10, err_msg=k)
+    import copy
+    clone = copy.deepcopy(lens)                        # engines cached on the group survive
+    clone.trace(0.0, 0.5, clone.primary_wavelength, 6, "hexapolar")
+    assert integration._SG["count"] == 2
+    integration.uninstall(lens)
+    lens.trace(0.0, 1.0, lens.primary_wavelength, 8, "hexapolar")
+    assert integration._SG["count"] == 2 and "trace" not in lens.surfaces.__dict__
