@@ -420,3 +420,40 @@ def test_engine_survives_deepcopy_and_pickle():
     for other in (b, c):
         assert torch.equal(other.trace(mk(), 0, record=True).record, want)
         other.close()
+
+
+@pytest.mark.parametrize("case", ["zernike_fresnel_fringe", "coated_mirror_polarised"])
+def test_complex_prt_planes_on_a_real_prt_system(case):
+    """The SurfaceGroup seam always hands over 18 PRT planes (a caller's PolarizedRays.p
+    is complex whatever the coatings).  On a system whose own PRT is real the complex
+    kernel must (a) reproduce the 9-plane result with a zero imaginary part from the
+    identity, and (b) advance an arbitrary complex start matrix p0 to P @ p0."""
+    from optiland_amd.engine import HipSystem
+    from optiland_amd.rays import prt_to_complex
+    table, data = load_case(case)
+    assert not table.needs_complex_prt
+    dtype = torch.float64
+    r = data["rays_in"]
+    n = r.shape[1]
+    mk = lambda: [torch.tensor(r[j], dtype=dtype, device=DEV) for j in range(7)] + \
+        [torch.zeros(n, dtype=dtype, device=DEV)]  # noqa: E731
+    hip = HipSystem(table, DEV)
+    try:
+        p9 = torch.empty((9, n), dtype=dtype, device=DEV)
+        hip.trace(mk(), 0, record=False, prt=p9, prt_identity=True)
+        p18 = torch.empty((18, n), dtype=dtype, device=DEV)
+        hip.trace(mk(), 0, record=False, prt=p18, prt_identity=True)
+        ok = ~torch.isnan(p9).any(0)
+        assert ok.float().mean() > 0.5
+        assert torch.equal(p18[:9, ok], p9[:, ok]) and float(p18[9:, ok].abs().max()) == 0.0
+        g = torch.Generator(device="cpu").manual_seed(5)
+        p0 = torch.complex(torch.randn(n, 3, 3, generator=g, dtype=dtype),
+                           torch.randn(n, 3, 3, generator=g, dtype=dtype)).to(DEV)
+        start = torch.cat([p0.real.reshape(n, 9).t(), p0.imag.reshape(n, 9).t()]).contiguous()
+        hip.trace(mk(), 0, record=False, prt=start)
+        got = prt_to_complex(start)
+        want = prt_to_complex(p18) @ p0
+        np.testing.assert_allclose(got[ok].cpu().numpy(), want[ok].cpu().numpy(),
+                                   rtol=1e-10, atol=1e-11)
+    finally:
+        hip.close()
