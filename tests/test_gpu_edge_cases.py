@@ -415,10 +415,10 @@ def test_engine_survives_deepcopy_and_pickle():
     b = copy.deepcopy(holder)["engines"]["k"][0]
     c = pickle.loads(pickle.dumps(a))
     assert b is not a and len({a._handle.value, b._handle.value, c._handle.value}) == 3
-    want = a.trace(mk(), 0, record=True).record
+    want = a.trace(mk(), 0, record=True).record[:, :, :n].clone()
     a.close()                                   # the copies do not depend on the original
     for other in (b, c):
-        assert torch.equal(other.trace(mk(), 0, record=True).record, want)
+        assert torch.equal(other.trace(mk(), 0, record=True).record[:, :, :n], want)
         other.close()
 
 
