@@ -1,0 +1,245 @@
+"""Differential fuzz of the LIVE reference against packer + oracle (build container only).
+
+The golden fixtures pin 66 hand-picked systems.  Here random lenses are built through the
+reference's own public API (`Optic.surfaces.add(surface_type=..., dx/dy/rx/ry/rz, aperture,
+coating, material)`), traced by the reference's NumPy backend, and compared with
+`pack_optic` -> `oracle.generate_rays` -> `oracle.trace` on the same field and pupil
+points: every surface's recorded x, y, z, L, M, N, intensity, opd.  What this catches that
+the goldens cannot: a parameter convention of some surface type / decentre / tilt / aperture
+/ coating that the packer reads correctly only for the values the goldens happen to use.
+
+CPU only, skipped where /root/reference does not exist.  The HIP kernel is held to the
+oracle on the GPU box (tests/test_gpu_fuzz.py), which closes the chain reference -> packer
+-> oracle -> kernel for random systems.
+"""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REF = os.environ.get("OPTILAND_REFERENCE", "/root/reference")
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "optiland")),
+                                reason="reference package not present")
+
+GLASSES = ["N-BK7", "N-SF11", "SF6", "N-LAK9", "N-F2"]
+
+
+@pytest.fixture(scope="module")
+def ref():
+    shim = os.path.join(os.path.dirname(os.path.abspath(__file__)), "refshim")
+    sys.dont_write_bytecode = True
+    added = [p for p in (shim, REF) if p not in sys.path]
+    sys.path[:0] = added
+    import optiland.backend as be
+    be.set_backend("numpy")
+    yield be
+    for p in added:
+        sys.path.remove(p)
+
+
+def _surface_kwargs(rng, kind, be):
+    R = float(rng.uniform(25, 120)) * (1 if rng.random() < 0.5 else -1)
+    k = float(rng.uniform(-1.2, 0.6))
+    if kind == "standard":
+        return dict(radius=R if rng.random() < 0.85 else be.inf, conic=k)
+    if kind == "even_asphere":
+        return dict(surface_type="even_asphere", radius=R, conic=k,
+                    coefficients=[float(rng.normal(0, 2e-4)), float(rng.normal(0, 2e-6)),
+                                  float(rng.normal(0, 2e-8))])
+    if kind == "odd_asphere":
+        return dict(surface_type="odd_asphere", radius=R, conic=k,
+                    coefficients=[0.0, float(rng.normal(0, 1e-4)), float(rng.normal(0, 1e-5)),
+                                  float(rng.normal(0, 1e-6))])
+    if kind == "polynomial":
+        c = rng.normal(0, 1, (3, 3)) * np.array([[0, 1e-3, 2e-4], [1e-3, 2e-4, 1e-5],
+                                                 [2e-4, 1e-5, 1e-6]])
+        return dict(surface_type="polynomial", radius=R, conic=k, coefficients=c.tolist())
+    if kind == "chebyshev":
+        c = rng.normal(0, 1, (3, 3)) * 1e-3
+        c[0, 0] = 0.0
+        return dict(surface_type="chebyshev", radius=R, conic=k, coefficients=c.tolist(),
+                    norm_x=float(rng.uniform(12, 16)), norm_y=float(rng.uniform(12, 16)))
+    if kind == "zernike":
+        nterm = int(rng.integers(4, 13))
+        c = (rng.normal(0, 3e-4, nterm)).tolist()
+        c[0] = 0.0
+        return dict(surface_type="zernike", radius=R, conic=k, coefficients=c,
+                    zernike_type=str(rng.choice(["fringe", "standard", "noll"])),
+                    norm_radius=float(rng.uniform(12, 18)))
+    if kind == "biconic":
+        return dict(surface_type="biconic", radius_x=R, radius_y=R * float(rng.uniform(0.7, 1.5)),
+                    conic_x=k, conic_y=float(rng.uniform(-1.0, 0.5)))
+    if kind == "toroidal":
+        return dict(surface_type="toroidal", radius_x=R, radius_y=R * float(rng.uniform(0.7, 1.5)),
+                    conic=k, toroidal_coeffs_poly_y=[float(rng.normal(0, 1e-5)),
+                                                     float(rng.normal(0, 1e-8))])
+    raise AssertionError(kind)
+
+
+KINDS = ["standard", "standard", "even_asphere", "odd_asphere", "polynomial", "chebyshev",
+         "zernike", "biconic", "toroidal"]
+
+
+def _random_aperture(rng, pa):
+    c = rng.integers(0, 6)
+    if c == 0:
+        return pa.RadialAperture(r_max=float(rng.uniform(4.5, 8)), r_min=float(rng.choice([0, 0.8])))
+    if c == 1:
+        return pa.RectangularAperture(-float(rng.uniform(4, 8)), float(rng.uniform(4, 8)),
+                                      -float(rng.uniform(4, 8)), float(rng.uniform(4, 8)))
+    if c == 2:
+        return pa.EllipticalAperture(a=float(rng.uniform(4, 8)), b=float(rng.uniform(4, 8)),
+                                     offset_x=float(rng.uniform(-0.5, 0.5)))
+    if c == 3:
+        return pa.OffsetRadialAperture(r_max=float(rng.uniform(5, 8)), r_min=0.0,
+                                       offset_x=float(rng.uniform(-0.5, 0.5)),
+                                       offset_y=float(rng.uniform(-0.5, 0.5)))
+    if c == 4:
+        return pa.DifferenceAperture(pa.RadialAperture(r_max=float(rng.uniform(5, 8))),
+                                     pa.RectangularAperture(-0.3, 0.3, -9.0, 9.0))
+    th = np.sort(rng.uniform(0, 2 * np.pi, int(rng.integers(3, 8))))
+    rr = rng.uniform(4.5, 8.0, th.size)
+    return pa.PolygonAperture(x=(rr * np.cos(th)).tolist(), y=(rr * np.sin(th)).tolist())
+
+
+def build_random_lens(seed, be):
+    from optiland import optic as optic_mod
+    from optiland import physical_apertures as pa
+    from optiland.coatings import FresnelCoating, SimpleCoating
+    from optiland.rays import PolarizationState
+    rng = np.random.default_rng(70_000 + seed)
+    lens = optic_mod.Optic(name=f"fuzz{seed}")
+    finite = rng.random() < 0.3
+    lens.surfaces.add(index=0, radius=be.inf, thickness=float(rng.uniform(60, 200)) if finite else be.inf)
+    ns = int(rng.integers(2, 7))
+    in_glass = False
+    polarised = rng.random() < 0.35
+    stop = int(rng.integers(1, ns + 1))
+    mirror_done = False
+    sign = 1.0
+    for i in range(1, ns + 1):
+        kw = _surface_kwargs(rng, str(rng.choice(KINDS)), be)
+        mat = None
+        if not in_glass and not mirror_done and i < ns and rng.random() < 0.12:
+            mat = "mirror"
+            mirror_done = True
+        elif not in_glass:
+            # an air-to-air surface does not deviate the ray: fine for the ray data, but the
+            # reference's PRT there is rounding noise -- polarised
+            # lenses get no such surface
+            mat = str(rng.choice(GLASSES)) if (polarised or rng.random() < 0.8) else None
+        thick = float(rng.uniform(2.0, 6.0) if (mat not in (None, "mirror")) else rng.uniform(4, 14))
+        if mat == "mirror":
+            sign = -sign
+        kw.update(thickness=sign * thick, is_stop=(i == stop))
+        if mat == "mirror":
+            kw["material"] = "mirror"
+        elif mat is not None:
+            kw["material"] = mat
+        in_glass = mat not in (None, "mirror")
+        if rng.random() < 0.3:
+            kw.update(dx=float(rng.uniform(-0.3, 0.3)), dy=float(rng.uniform(-0.3, 0.3)))
+        if rng.random() < 0.3:
+            kw.update(rx=float(rng.uniform(-0.04, 0.04)), ry=float(rng.uniform(-0.04, 0.04)))
+        if rng.random() < 0.15:
+            kw.update(rz=float(rng.uniform(-0.5, 0.5)))
+        if rng.random() < 0.35:
+            kw["aperture"] = _random_aperture(rng, pa)
+        if not polarised and rng.random() < 0.2:
+            kw["coating"] = SimpleCoating(transmittance=float(rng.uniform(0.6, 1.0)),
+                                          reflectance=float(rng.uniform(0.0, 0.4)))
+        lens.surfaces.add(index=i, **kw)
+    lens.surfaces.add(index=ns + 1)
+    if polarised:
+        for i in range(1, ns + 1):
+            if rng.random() < 0.7:
+                s_ = lens.surfaces[i]
+                s_.coating = FresnelCoating(s_.material_pre, s_.material_post)
+    lens.set_aperture(aperture_type="EPD", value=float(rng.uniform(4, 9)))
+    if finite and rng.random() < 0.5:
+        lens.fields.set_type(field_type="object_height")
+        lens.fields.add(y=0)
+        lens.fields.add(y=float(rng.uniform(1, 4)), x=float(rng.uniform(0, 2)))
+    else:
+        lens.fields.set_type(field_type="angle")
+        lens.fields.add(y=0)
+        lens.fields.add(y=float(rng.uniform(1, 5)), x=float(rng.uniform(0, 3)))
+    lens.wavelengths.add(value=float(rng.uniform(0.45, 0.9)), is_primary=True)
+    if polarised:
+        if rng.random() < 0.5:
+            lens.updater.set_polarization(PolarizationState(is_polarized=False))
+        else:
+            lens.updater.set_polarization(PolarizationState(
+                is_polarized=True, Ex=1.0, Ey=float(rng.uniform(0, 1)), phase_x=0.0,
+                phase_y=float(rng.uniform(-1, 1))))
+    return lens, rng
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_random_reference_lens_equals_packer_plus_oracle(ref, seed):
+    be = ref
+    from oracle import oracle
+    from optiland_amd.packer import UnsupportedSystem, pack_optic
+    from optiland_amd.rays import _state_dict
+    try:
+        lens, rng = build_random_lens(seed, be)
+        w = float(lens.primary_wavelength)
+        table = pack_optic(lens, wavelengths=[w])
+    except UnsupportedSystem as e:  # must not happen: every generated feature is on the path
+        pytest.fail(f"packer refused a supported system: {e}")
+    assert table.raygen, "device ray generation must cover angle / object-height fields"
+    n = 400
+    r, th = np.sqrt(rng.random(n)) * 0.9, 2 * np.pi * rng.random(n)
+    px, py = r * np.cos(th), r * np.sin(th)
+    hx, hy = float(rng.uniform(-0.6, 0.6)), float(rng.uniform(-1, 1))
+    with np.errstate(all="ignore"):
+        try:
+            out = lens.trace_generic(hx, hy, px, py, w)
+        except ValueError as e:   # Zernike / Chebyshev range errors: the oracle must flag the same
+            g = oracle.generate_rays(table.raygen, np.full(n, hx), np.full(n, hy), px, py)
+            g["opd"] = np.zeros(n)
+            got = oracle.trace(table, g, 0, record=True,
+                               polarized=table.polarization is not None)
+            assert got["status"] != 0, f"reference raised {e!r}, oracle status 0"
+            return
+    want = {k: np.asarray(getattr(lens.surfaces, k), dtype=np.float64)
+            for k in ("x", "y", "z", "L", "M", "N", "intensity", "opd")}
+    g = oracle.generate_rays(table.raygen, np.full(n, hx), np.full(n, hy), px, py)
+    g["opd"] = np.zeros(n)
+    polarised = table.polarization is not None
+    got = oracle.trace(table, g, 0, record=True, polarized=polarised)
+    assert got["status"] == 0
+    rec = got["record"]
+    scale = max(1.0, float(np.nanmax(np.abs(want["z"][1:][np.isfinite(want["z"][1:])]))))
+    for j, k in enumerate(("x", "y", "z", "L", "M", "N", "intensity", "opd")):
+        a, b = rec[:, j, :], want[k]
+        assert a.shape == b.shape, k
+        if k in "xyz" and not np.isfinite(b[0]).all():   # object at infinity: row 0 z = -inf etc.
+            a, b = a[1:], b[1:]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f"{k}: NaN masks differ"
+        tol = 1e-7 * (scale if k in ("x", "y", "z", "opd") else 1.0)
+        np.testing.assert_allclose(np.nan_to_num(a, posinf=0, neginf=0),
+                                   np.nan_to_num(b, posinf=0, neginf=0), rtol=0, atol=tol,
+                                   err_msg=f"seed {seed} plane {k}")
+    if polarised:
+        np.testing.assert_allclose(np.nan_to_num(got["prt"]), np.nan_to_num(np.asarray(out.p)),
+                                   rtol=0, atol=1e-7)
+        r0 = lens.trace(hx, hy, w, 5, "hexapolar")       # Optic.trace: + update_intensity
+        g2 = {k: np.asarray(getattr(lens.surfaces, k))[0].astype(np.float64)
+              for k in ("x", "y", "z", "L", "M", "N")}
+        g2["i"] = np.asarray(lens.surfaces.intensity)[0].astype(np.float64)
+        g2["opd"] = np.zeros_like(g2["x"])
+        if not np.isfinite(g2["z"]).all():               # object at infinity: regenerate
+            from optiland.distribution import create_distribution
+            d = create_distribution("hexapolar")
+            d.generate_points(5)
+            g2 = oracle.generate_rays(table.raygen, np.full(d.x.size, hx), np.full(d.x.size, hy),
+                                      np.asarray(d.x), np.asarray(d.y))
+            g2["opd"] = np.zeros(d.x.size)
+        o2 = oracle.trace(table, g2, 0, record=False, polarized=True)
+        wi, st = oracle.polarized_intensity(o2["prt"], g2["L"], g2["M"], g2["N"], g2["i"],
+                                            _state_dict(lens.polarization_state))
+        np.testing.assert_allclose(np.nan_to_num(wi), np.nan_to_num(np.asarray(r0.i)),
+                                   rtol=0, atol=1e-7)
