@@ -139,6 +139,10 @@ def build_random_lens(seed, be):
         elif mat is not None:
             kw["material"] = mat
         in_glass = mat not in (None, "mirror")
+        if in_glass and rng.random() < 0.15:   # absorbing medium (homogeneous.py:44-53)
+            from optiland.materials import IdealMaterial
+            kw["material"] = IdealMaterial(n=float(rng.uniform(1.4, 1.8)),
+                                           k=float(rng.uniform(1e-7, 3e-6)))
         if rng.random() < 0.3:
             kw.update(dx=float(rng.uniform(-0.3, 0.3)), dy=float(rng.uniform(-0.3, 0.3)))
         if rng.random() < 0.3:
@@ -153,19 +157,50 @@ def build_random_lens(seed, be):
         lens.surfaces.add(index=i, **kw)
     lens.surfaces.add(index=ns + 1)
     if polarised:
+        from optiland.coatings import PolarizerCoating, RetarderCoating
         for i in range(1, ns + 1):
-            if rng.random() < 0.7:
-                s_ = lens.surfaces[i]
+            s_ = lens.surfaces[i]
+            u = rng.random()
+            if u < 0.65:
                 s_.coating = FresnelCoating(s_.material_pre, s_.material_post)
-    lens.set_aperture(aperture_type="EPD", value=float(rng.uniform(4, 9)))
-    if finite and rng.random() < 0.5:
+            elif u < 0.75:
+                s_.coating = PolarizerCoating(axis=(float(rng.normal()), float(rng.normal()),
+                                                    float(rng.normal()) * 0.1))
+            elif u < 0.85:
+                s_.coating = RetarderCoating(retardance=float(rng.uniform(0.2, 3.0)),
+                                             axis=(float(rng.normal()), float(rng.normal()), 0.0))
+    vig = dict(vx=float(rng.uniform(0, 0.2)), vy=float(rng.uniform(0, 0.3))) \
+        if rng.random() < 0.5 else {}
+    u = rng.random()
+    if finite and u < 0.2:       # object-space telecentric (ray_aiming/paraxial.py:82-87)
+        lens.set_aperture(aperture_type="objectNA", value=float(rng.uniform(0.01, 0.04)))
+        lens.obj_space_telecentric = True
         lens.fields.set_type(field_type="object_height")
         lens.fields.add(y=0)
-        lens.fields.add(y=float(rng.uniform(1, 4)), x=float(rng.uniform(0, 2)))
+        lens.fields.add(y=float(rng.uniform(0.5, 2)), x=float(rng.uniform(0, 1)), **vig)
     else:
-        lens.fields.set_type(field_type="angle")
-        lens.fields.add(y=0)
-        lens.fields.add(y=float(rng.uniform(1, 5)), x=float(rng.uniform(0, 3)))
+        lens.set_aperture(aperture_type="EPD", value=float(rng.uniform(4, 9)))
+        if finite and u < 0.55:
+            lens.fields.set_type(field_type="object_height")
+            lens.fields.add(y=0)
+            lens.fields.add(y=float(rng.uniform(1, 4)), x=float(rng.uniform(0, 2)), **vig)
+        elif u > 0.85:
+            lens.fields.set_type(field_type="paraxial_image_height")
+            lens.fields.add(y=0)
+            lens.fields.add(y=float(rng.uniform(0.5, 3)), x=float(rng.uniform(0, 1)), **vig)
+        else:
+            lens.fields.set_type(field_type="angle")
+            lens.fields.add(y=0)
+            lens.fields.add(y=float(rng.uniform(1, 5)), x=float(rng.uniform(0, 3)), **vig)
+    if rng.random() < 0.35:
+        from optiland import apodization as apod
+        lens.updater.set_apodization(rng.choice([
+            apod.GaussianApodization(sigma=float(rng.uniform(0.5, 1.2))),
+            apod.CosineSquaredApodization(R=float(rng.uniform(0.8, 1.2))),
+            apod.HannApodization(D=float(rng.uniform(1.6, 2.4))),
+            apod.PolynomialApodization(R=float(rng.uniform(0.8, 1.2)), p=float(rng.uniform(0.5, 3))),
+            apod.SuperGaussianApodization(w=float(rng.uniform(0.6, 1.1)), n=float(rng.uniform(2, 6))),
+            apod.TukeyApodization(R=float(rng.uniform(0.8, 1.1)), alpha=float(rng.uniform(0.1, 0.9)))]))
     lens.wavelengths.add(value=float(rng.uniform(0.45, 0.9)), is_primary=True)
     if polarised:
         if rng.random() < 0.5:
@@ -189,7 +224,7 @@ def test_random_reference_lens_equals_packer_plus_oracle(ref, seed):
         table = pack_optic(lens, wavelengths=[w])
     except UnsupportedSystem as e:  # must not happen: every generated feature is on the path
         pytest.fail(f"packer refused a supported system: {e}")
-    assert table.raygen, "device ray generation must cover angle / object-height fields"
+    assert table.raygen, "device ray generation must cover every generated field type"
     n = 400
     r, th = np.sqrt(rng.random(n)) * 0.9, 2 * np.pi * rng.random(n)
     px, py = r * np.cos(th), r * np.sin(th)
@@ -206,7 +241,12 @@ def test_random_reference_lens_equals_packer_plus_oracle(ref, seed):
             return
     want = {k: np.asarray(getattr(lens.surfaces, k), dtype=np.float64)
             for k in ("x", "y", "z", "L", "M", "N", "intensity", "opd")}
-    g = oracle.generate_rays(table.raygen, np.full(n, hx), np.full(n, hy), px, py)
+    # trace_generic pre-scales the pupil by (1 - v) and the generator applies the factors
+    # once more (real_ray_tracer.py:134-137 + ray_generator.py:62-66)
+    vxf, vyf = lens.fields.get_vig_factor(hx, hy)
+    vx, vy = 1.0 - float(np.asarray(vxf)), 1.0 - float(np.asarray(vyf))
+    g = oracle.generate_rays(table.raygen, np.full(n, hx), np.full(n, hy), px * vx, py * vy,
+                             np.full(n, vx), np.full(n, vy))
     g["opd"] = np.zeros(n)
     polarised = table.polarization is not None
     got = oracle.trace(table, g, 0, record=True, polarized=polarised)
@@ -236,7 +276,8 @@ def test_random_reference_lens_equals_packer_plus_oracle(ref, seed):
             d = create_distribution("hexapolar")
             d.generate_points(5)
             g2 = oracle.generate_rays(table.raygen, np.full(d.x.size, hx), np.full(d.x.size, hy),
-                                      np.asarray(d.x), np.asarray(d.y))
+                                      np.asarray(d.x), np.asarray(d.y), np.full(d.x.size, vx),
+                                      np.full(d.x.size, vy))
             g2["opd"] = np.zeros(d.x.size)
         o2 = oracle.trace(table, g2, 0, record=False, polarized=True)
         wi, st = oracle.polarized_intensity(o2["prt"], g2["L"], g2["M"], g2["N"], g2["i"],
