@@ -525,9 +525,35 @@ def sample_goldens():
     print(f"{n_ok} sample systems")
 
 
+def fuzz_goldens(count=24):
+    """Random lenses of the differential fuzz (tests/test_reference_fuzz.py:
+    `build_random_lens`, seeds 0..count-1) frozen as fixtures, so that the GPU box -- where
+    the reference does not exist -- holds the KERNEL to reference results on random
+    systems too (tests/test_gpu_parity.py picks every *.npz up)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "_ref_fuzz", os.path.join(HERE, "..", "tests", "test_reference_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for seed in range(count):
+        lens, rng = mod.build_random_lens(seed, be)
+        n = 160
+        r, th = np.sqrt(rng.random(n)) * 0.9, 2 * np.pi * rng.random(n)
+        hx, hy = float(rng.uniform(-0.6, 0.6)), float(rng.uniform(-1, 1))
+        try:
+            with np.errstate(all="ignore"):
+                run_case(f"fuzz_{seed:02d}", lens, hx, hy, r * np.cos(th), r * np.sin(th),
+                         float(lens.primary_wavelength))
+        except ValueError as e:   # Zernike / Chebyshev range error: not a trace fixture
+            print(f"fuzz_{seed:02d}: skipped ({e})")
+
+
 def main():
     if "--samples-only" in sys.argv:
         sample_goldens()
+        return
+    if "--fuzz-only" in sys.argv:
+        fuzz_goldens()
         return
     if "--zemax-only" in sys.argv:
         zemax_toroid_tables()
@@ -639,6 +665,7 @@ def main():
     wavefront_goldens()
     zemax_toroid_tables()
     sample_goldens()
+    fuzz_goldens()
 
 
 if __name__ == "__main__":
