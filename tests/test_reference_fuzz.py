@@ -338,3 +338,39 @@ def test_standalone_tracer_on_random_lenses(ref, seed):
     assert rec1.shape == rec0.shape
     np.testing.assert_allclose(np.nan_to_num(rec1[1:]), np.nan_to_num(rec0[1:]), rtol=0,
                                atol=1e-7 * scale)
+
+
+@pytest.mark.parametrize("reference", ["chief_ray", "centroid"])
+@pytest.mark.parametrize("seed", range(30))
+def test_standalone_spot_diagram_on_random_lenses(ref, seed, reference):
+    """`analysis.SpotDiagram` (fused generate-trace-reduce per spot, moments about the
+    chief ray / the centroid) against the reference's `SpotDiagram` on random lenses:
+    centroid, RMS and geometric radius of every field."""
+    be = ref
+    import torch
+    from optiland import analysis as ref_analysis
+    from optiland_amd.analysis import SpotDiagram
+    from optiland_amd.packer import pack_optic
+    from optiland_amd.tracer import HipRayTracer
+    from tests._fake_engine import OracleEngine
+    lens, rng = build_random_lens(seed, be)
+    table = pack_optic(lens)
+    try:
+        with np.errstate(all="ignore"):
+            want = ref_analysis.SpotDiagram(lens, num_rings=4, reference=reference)
+            w_rms = np.array(want.rms_spot_radius(), dtype=np.float64)
+            w_geo = np.array(want.geometric_spot_radius(), dtype=np.float64)
+            w_cen = np.array(want.centroid(), dtype=np.float64)
+    except ValueError:
+        pytest.skip("reference raises a coordinate-range error for this lens")
+    if not (np.isfinite(w_rms).all() and np.isfinite(w_cen).all()):
+        pytest.skip("rays miss a surface: the reference's statistics are NaN")
+    t = HipRayTracer(table, "cpu", dtype=torch.float64, engine=OracleEngine(table, "cpu"))
+    with np.errstate(all="ignore"):
+        got = SpotDiagram(t, num_rings=4, reference=reference)
+    scale = max(1.0, float(np.abs(w_cen).max()))
+    np.testing.assert_allclose(np.array(got.rms_spot_radius()), w_rms, rtol=1e-7, atol=1e-9 * scale)
+    np.testing.assert_allclose(np.array(got.geometric_spot_radius()), w_geo, rtol=1e-7,
+                               atol=1e-9 * scale)
+    np.testing.assert_allclose(np.array(got.centroid(), dtype=np.float64), w_cen, rtol=0,
+                               atol=1e-8 * scale)
