@@ -92,11 +92,14 @@ class Wavefront:
 
 
 class OPD(Wavefront):
-    """wavefront/opd.py: OPD wavefront, `num_rings` hexapolar rings (default 15)."""
+    """wavefront/opd.py:72-93: OPD wavefront; `num_rays` = number of hexapolar rings for
+    the default distribution (15), as in the reference (`num_rings` is kept as an alias)."""
 
-    def __init__(self, tracer, field, wavelength, num_rings: int = 15):
-        super().__init__(tracer, field, wavelength, num_rays=num_rings,
-                         distribution="hexapolar")
+    def __init__(self, tracer, field, wavelength, num_rays: int = 15,
+                 distribution="hexapolar", num_rings: int | None = None):
+        super().__init__(tracer, field, wavelength,
+                         num_rays=num_rays if num_rings is None else num_rings,
+                         distribution=distribution)
 
     def rms(self) -> float:
         """opd.py:145-159."""

@@ -374,3 +374,83 @@ def test_standalone_spot_diagram_on_random_lenses(ref, seed, reference):
                                atol=1e-9 * scale)
     np.testing.assert_allclose(np.array(got.centroid(), dtype=np.float64), w_cen, rtol=0,
                                atol=1e-8 * scale)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_standalone_opd_on_random_lenses(ref, seed):
+    """`wavefront.OPD` (chief-ray reference sphere, exit-pupil data from the packer, tilt
+    removal for angle fields at infinity only) against the reference's `OPD` on random
+    lenses and a random field: reference-sphere radius, pupil coordinates, the OPD map in
+    waves and its RMS."""
+    be = ref
+    import torch
+    from optiland.wavefront import OPD as RefOPD
+    from optiland_amd.packer import pack_optic
+    from optiland_amd.tracer import HipRayTracer
+    from optiland_amd.wavefront import OPD
+    from tests._fake_engine import OracleEngine
+    lens, rng = build_random_lens(seed, be)
+    if lens.polarization != "ignore":
+        pytest.skip("wavefront of polarised systems is not part of the fuzz")
+    w = float(lens.primary_wavelength)
+    field = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-1, 1)))
+    try:
+        with np.errstate(all="ignore"):
+            want = RefOPD(lens, field, w, num_rays=5)
+            d0 = want.get_data(field, w)
+            w_opd = np.asarray(d0.opd, dtype=np.float64)
+            w_rms = float(want.rms())
+    except ValueError:
+        pytest.skip("reference raises for this lens")
+    if not np.isfinite(w_opd).all():
+        pytest.skip("rays miss a surface: the reference's OPD map has NaNs")
+    table = pack_optic(lens, wavelengths=[w])
+    t = HipRayTracer(table, "cpu", dtype=torch.float64, engine=OracleEngine(table, "cpu"))
+    with np.errstate(all="ignore"):
+        got = OPD(t, field, w, num_rays=5)
+    d1 = got.data
+    np.testing.assert_allclose(d1.radius, float(d0.radius), rtol=1e-9)
+    pupil1 = torch.stack([d1.pupil_x, d1.pupil_y, d1.pupil_z]).numpy()
+    pupil0 = np.stack([np.asarray(v, dtype=np.float64) for v in (d0.pupil_x, d0.pupil_y, d0.pupil_z)])
+    np.testing.assert_allclose(pupil1, pupil0, rtol=0, atol=1e-8 * max(1.0, abs(float(d0.radius))))
+    # OPD in waves: absolute error scaled by the optical path (mm / lambda) it is the small
+    # difference of
+    waves = max(1.0, float(np.abs(w_opd).max()))
+    np.testing.assert_allclose(d1.opd.numpy(), w_opd, rtol=0, atol=2e-6 * waves + 1e-6)
+    np.testing.assert_allclose(got.rms(), w_rms, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_standalone_fft_psf_on_random_lenses(ref, seed):
+    """`wavefront.FFTPSF` (uniform pupil grid -> complex pupil function -> padded FFT,
+    psf/fft.py) against the reference's `FFTPSF` on random unpolarised lenses: the whole
+    normalised PSF array and the Strehl ratio."""
+    be = ref
+    import torch
+    from optiland.psf import FFTPSF as RefFFTPSF
+    from optiland_amd.packer import pack_optic
+    from optiland_amd.tracer import HipRayTracer
+    from optiland_amd.wavefront import FFTPSF
+    from tests._fake_engine import OracleEngine
+    lens, rng = build_random_lens(seed, be)
+    if lens.polarization != "ignore":
+        pytest.skip("wavefront of polarised systems is not part of the fuzz")
+    w = float(lens.primary_wavelength)
+    field = (0.0, float(rng.uniform(0, 1)))
+    try:
+        with np.errstate(all="ignore"):
+            want = RefFFTPSF(lens, field, w, num_rays=32)
+            w_psf = np.asarray(want.psf, dtype=np.float64)
+            w_strehl = float(want.strehl_ratio())
+    except ValueError:
+        pytest.skip("reference raises for this lens")
+    if not np.isfinite(w_psf).all():
+        pytest.skip("rays miss a surface: the reference's PSF has NaNs")
+    table = pack_optic(lens, wavelengths=[w])
+    t = HipRayTracer(table, "cpu", dtype=torch.float64, engine=OracleEngine(table, "cpu"))
+    with np.errstate(all="ignore"):
+        got = FFTPSF(t, field, w, num_rays=32)
+    g_psf = got.psf.numpy()
+    assert g_psf.shape == w_psf.shape
+    np.testing.assert_allclose(g_psf, w_psf, rtol=0, atol=2e-5 * w_psf.max())
+    np.testing.assert_allclose(got.strehl_ratio(), w_strehl, rtol=1e-4, atol=1e-6)
