@@ -17,16 +17,22 @@ import numpy as np
 
 class SpotDiagram:
     def __init__(self, tracer, fields="all", wavelengths="all", num_rings: int = 6,
-                 distribution: str = "hexapolar", reference: str = "chief_ray",
-                 primary_index: int | None = None):
+                 distribution: str = "hexapolar", coordinates: str = "local",
+                 reference: str = "chief_ray", primary_index: int | None = None):
+        if coordinates not in ("global", "local"):  # core.py:105-106
+            raise ValueError("Coordinates must be 'global' or 'local'.")
         if reference not in ("chief_ray", "centroid"):
             raise ValueError(f"Invalid reference '{reference}'. Must be 'chief_ray' or 'centroid'.")
         self.tracer = tracer
+        self.coordinates = coordinates
         table = tracer.table
         s = table.surfaces[-1]
-        if s["flags"] & 1:
-            raise NotImplementedError("spot statistics on a tilted image surface")
-        self._origin = np.asarray(s["origin"], dtype=np.float64)
+        if s["flags"] & 1 and coordinates == "local":
+            raise NotImplementedError("local spot coordinates on a tilted image surface")
+        # radii are frame-independent for an untilted image surface; only the centroid
+        # moves by the surface origin between the two coordinate systems
+        self._origin = (np.asarray(s["origin"], dtype=np.float64) if coordinates == "local"
+                        else np.zeros(3))
         mf = table.raygen.get("max_field", 0.0) or 1.0
         if fields == "all":
             fields = [(f[0] / mf, f[1] / mf) for f in table.fields]

@@ -36,7 +36,12 @@ class Wavefront:
     """OPD map for ONE field and wavelength (chief-ray strategy, spherical reference)."""
 
     def __init__(self, tracer, field, wavelength, num_rays: int = 12,
-                 distribution="hexapolar"):
+                 distribution="hexapolar", strategy: str = "chief_ray",
+                 remove_tilt: bool = False):
+        if strategy != "chief_ray" or remove_tilt:
+            raise NotImplementedError(
+                "only the reference's default wavefront strategy (chief-ray reference "
+                "sphere, no tilt removal: wavefront/strategy.py:163-215) runs on device")
         if tracer.dtype != torch.float64:
             raise ValueError("wavefront analysis needs an fp64 tracer (OPD in waves)")
         rg = tracer.table.raygen
@@ -96,10 +101,11 @@ class OPD(Wavefront):
     the default distribution (15), as in the reference (`num_rings` is kept as an alias)."""
 
     def __init__(self, tracer, field, wavelength, num_rays: int = 15,
-                 distribution="hexapolar", num_rings: int | None = None):
+                 distribution="hexapolar", strategy: str = "chief_ray",
+                 remove_tilt: bool = False, num_rings: int | None = None):
         super().__init__(tracer, field, wavelength,
                          num_rays=num_rays if num_rings is None else num_rings,
-                         distribution=distribution)
+                         distribution=distribution, strategy=strategy, remove_tilt=remove_tilt)
 
     def rms(self) -> float:
         """opd.py:145-159."""
@@ -120,7 +126,8 @@ def calculate_grid_size(num_rays: int) -> tuple[int, int]:
 class FFTPSF:
     """Scalar FFT PSF (psf/fft.py:42-262) for one field and wavelength."""
 
-    def __init__(self, tracer, field, wavelength, num_rays: int = 128, grid_size=None):
+    def __init__(self, tracer, field, wavelength, num_rays: int = 128, grid_size=None,
+                 strategy: str = "chief_ray", remove_tilt: bool = False):
         if grid_size is None:
             if num_rays < 32:
                 raise ValueError("num_rays must be at least 32 if grid_size is not specified.")
@@ -129,7 +136,8 @@ class FFTPSF:
             raise ValueError(f"Grid size ({grid_size}) must be greater than or equal to the "
                              f"number of rays ({num_rays}).")
         self.num_rays, self.grid_size = num_rays, grid_size
-        self.wavefront = Wavefront(tracer, field, wavelength, num_rays, "uniform")
+        self.wavefront = Wavefront(tracer, field, wavelength, num_rays, "uniform",
+                                   strategy=strategy, remove_tilt=remove_tilt)
         self.pupil = self._generate_pupil()
         self.psf = self._compute_psf()
 

@@ -184,3 +184,37 @@ def test_encircled_energy_host_logic():
         np.testing.assert_allclose(ee.ee[k], want, rtol=1e-12, atol=1e-12)
         assert ee.ee[k][-1] == pytest.approx(np.nansum(e))  # everything inside 1.2 r_max
     assert np.all(np.diff(ee.ee, axis=1) >= 0)
+
+
+def test_analysis_signatures_follow_the_reference(monkeypatch):
+    """Argument names and error behaviour of the stand-alone analyses mirror the
+    reference's: SpotDiagram(coordinates=, reference=) (analysis/spot_diagram/core.py:
+    69-121), OPD(num_rays=, distribution=, strategy=, remove_tilt=) (wavefront/opd.py:72-93),
+    FFTPSF(num_rays=, grid_size=, strategy=, remove_tilt=) (psf/fft.py:87-110)."""
+    import inspect
+    import torch
+    import optiland_amd.tracer as tr
+    from optiland_amd import load_system
+    from optiland_amd.analysis import SpotDiagram
+    from optiland_amd.wavefront import FFTPSF, OPD
+    from tests._fake_engine import OracleEngine
+    monkeypatch.setattr(tr, "_make_engine", lambda table, device: OracleEngine(table, device))
+    names = lambda f: list(inspect.signature(f).parameters)[1:]  # noqa: E731
+    assert names(SpotDiagram.__init__)[:7] == ["tracer", "fields", "wavelengths", "num_rings",
+                                               "distribution", "coordinates", "reference"]
+    assert names(OPD.__init__)[:7] == ["tracer", "field", "wavelength", "num_rays", "distribution",
+                                       "strategy", "remove_tilt"]
+    assert names(FFTPSF.__init__)[:7] == ["tracer", "field", "wavelength", "num_rays", "grid_size",
+                                          "strategy", "remove_tilt"]
+    t = tr.HipRayTracer(load_system("cooke_generic"), dtype=torch.float64)
+    with pytest.raises(ValueError, match="Coordinates must be 'global' or 'local'"):
+        SpotDiagram(t, coordinates="polar")
+    with pytest.raises(ValueError, match="Invalid reference"):
+        SpotDiagram(t, reference="nowhere")
+    with pytest.raises(NotImplementedError):
+        OPD(t, (0, 0), 0.55, strategy="centroid_sphere")
+    loc, glo = SpotDiagram(t, num_rings=3), SpotDiagram(t, num_rings=3, coordinates="global")
+    np.testing.assert_allclose(loc.rms_spot_radius(), glo.rms_spot_radius(), rtol=1e-12)
+    oz = np.asarray(t.table.surfaces[-1]["origin"], dtype=np.float64)
+    for (a, b), (c, d) in zip(loc.centroid(), glo.centroid()):
+        np.testing.assert_allclose([c - a, d - b], oz[:2], atol=1e-12)
