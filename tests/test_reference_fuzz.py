@@ -454,3 +454,58 @@ def test_standalone_fft_psf_on_random_lenses(ref, seed):
     assert g_psf.shape == w_psf.shape
     np.testing.assert_allclose(g_psf, w_psf, rtol=0, atol=2e-5 * w_psf.max())
     np.testing.assert_allclose(got.strehl_ratio(), w_strehl, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_standalone_encircled_energy_on_random_lenses(ref, seed):
+    """`analysis.EncircledEnergy` (fused trace with hit planes + `ol_radial_energy`
+    histogram + cumsum) against the numbers the reference's `EncircledEnergy.view()` plots
+    (analysis/encircled_energy.py:74-160: spots centred on the chief ray, radius steps
+    linspace(0, 1.2 max geometric radius, num_points), ee(r) = nansum(energy[radii <= r]))
+    on random unpolarised lenses; a deterministic pupil distribution so both sides trace
+    the same rays."""
+    be = ref
+    import torch
+    from optiland import analysis as ref_analysis
+    from optiland_amd.analysis import EncircledEnergy
+    from optiland_amd.packer import pack_optic
+    from optiland_amd.tracer import HipRayTracer
+    from tests._fake_engine import OracleEngine
+    lens, rng = build_random_lens(seed, be)
+    if lens.polarization != "ignore":
+        pytest.skip("encircled energy of polarised systems is not on the device path")
+    npts = 48
+    try:
+        with np.errstate(all="ignore"):
+            want = ref_analysis.EncircledEnergy(lens, num_rays=7, distribution="hexapolar",
+                                                num_points=npts)
+            data = want._center_spots(want.data)
+            axis_lim = float(np.max(np.asarray(want.geometric_spot_radius(), dtype=np.float64)))
+            r_step = np.linspace(0, axis_lim * 1.2, npts)
+            curves = []
+            for field_data in data:
+                p = field_data[0]
+                x, y, e = (np.asarray(v, dtype=np.float64) for v in (p.x, p.y, p.intensity))
+                radii = np.sqrt(x * x + y * y)
+                curves.append([np.nansum(e[radii <= r]) for r in r_step])
+            w_cen = np.array(want.centroid(), dtype=np.float64)
+    except ValueError:
+        pytest.skip("reference raises for this lens")
+    if not np.isfinite(axis_lim):
+        pytest.skip("rays miss a surface: the reference's axis limit is NaN")
+    table = pack_optic(lens)
+    t = HipRayTracer(table, "cpu", dtype=torch.float64, engine=OracleEngine(table, "cpu"))
+    with np.errstate(all="ignore"):
+        got = EncircledEnergy(t, num_rays=7, distribution="hexapolar", num_points=npts)
+    np.testing.assert_allclose(got.r_step, r_step, rtol=1e-7, atol=1e-12)  # Newton stop tolerance
+    want_ee = np.array(curves)
+    # a hit within rounding of a radius step may fall on either side of it: allow one
+    # ray's energy of slack on at most a few steps, exact elsewhere
+    diff = np.abs(got.ee - want_ee)
+    assert (diff > 1e-9 * max(1.0, want_ee.max())).mean() < 0.02
+    assert diff.max() <= 1.0 + 1e-9
+    np.testing.assert_allclose(got.ee[:, -1], want_ee[:, -1], rtol=1e-12)
+    # image-local vs global centroid: the reference's EE centroid is of the local hits
+    oz = np.asarray(table.surfaces[-1]["origin"], dtype=np.float64)
+    np.testing.assert_allclose(np.array(got.centroid()) - oz[:2], w_cen, rtol=0,
+                               atol=1e-8 * max(1.0, np.abs(w_cen).max()))
