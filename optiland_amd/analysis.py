@@ -214,44 +214,108 @@ class EncircledEnergy:
         return [(float(h[0].double().mean()), float(h[1].double().mean())) for h in self._hits]
 
 
+def _aperture_extent(row):
+    """`aperture.extent` of the reference's leaf apertures (physical_apertures/
+    radial.py:47-54, offset_radial.py:34-46, rectangular.py:33-40, elliptical.py:33-40)
+    from a packed surface row, or None."""
+    from . import system as S
+    k, a = int(row["aperture_kind"]), [float(v) for v in row["aperture"]]
+    if k == S.AP_RECTANGULAR:
+        return a[0], a[1], a[2], a[3]
+    if k == S.AP_RADIAL:
+        return -a[1], a[1], -a[1], a[1]
+    if k == S.AP_OFFSET_RADIAL:
+        return a[2] - a[1], a[2] + a[1], a[3] - a[1], a[3] + a[1]
+    if k == S.AP_ELLIPTICAL:
+        return -a[0], a[0], -a[1], a[1]
+    return None
+
+
 class IncoherentIrradiance:
-    """Detector irradiance map on device (analysis/irradiance.py:251-353, the
-    non-differentiable path): trace `num_rays` pupil points of `distribution` for one
-    field and wavelength, bin the detector-plane hits with `numpy.histogram2d` semantics
-    weighted by the ray power (rays with power > 0 only), divide by the pixel area.
+    """Detector irradiance maps on device (analysis/irradiance.py:79-353, the
+    non-differentiable path), same arguments as the reference: for every field and
+    wavelength trace `num_rays` pupil points of `distribution`, bin the detector-plane
+    hits with `numpy.histogram2d` semantics weighted by the ray power (rays with power > 0
+    only), divide by the pixel area.  `data[field][wavelength] = (irradiance, x_edges,
+    y_edges)` as in the reference, `irradiance` a device tensor of shape (npix_x, npix_y).
 
-    `extent` = (x_min, x_max, y_min, y_max) of the detector in its local frame (the
-    reference takes it from the detector surface's aperture); `res` = (npix_x, npix_y).
-    The hits stay on the GPU: one trace + one `ol_irradiance` histogram pass; sharded
-    runs add their `power_map`s (an all-reduce of H x W bins instead of an all-gather of
-    hits)."""
+    The detector must be the image surface and carry a physical aperture whose `extent`
+    gives the pixel grid (irradiance.py:136-145); `extent=(x_min, x_max, y_min, y_max)`
+    overrides it (boolean / polygon apertures have no packed extent).  `px_size=(dx, dy)`
+    derives the resolution from the pixel size like the reference (:302-313).  Not taken
+    over: `user_initial_rays` / `source` / `skip_trace` (caller-built bundles enter at
+    `engine.trace` / the `SurfaceGroup.trace` seam) and the autograd branch.
+    The hits stay on the GPU: one trace + one `ol_irradiance` histogram pass per map;
+    sharded runs add their `power_map`s (an all-reduce of H x W bins instead of an
+    all-gather of hits)."""
 
-    def __init__(self, tracer, field, wavelength, extent, res=(128, 128), num_rays: int = 100,
-                 distribution: str = "uniform"):
-        import torch
+    def __init__(self, tracer, num_rays: int = 5, res=(128, 128), px_size=None,
+                 detector_surface: int = -1, *, fields="all", wavelengths="all",
+                 distribution: str = "random", extent=None):
         table = tracer.table
+        n_s = table.num_surfaces
+        if int(detector_surface) not in (-1, n_s - 1):
+            raise NotImplementedError("the detector must be the image surface")
         s = table.surfaces[-1]
         if s["flags"] & 1:
             raise NotImplementedError("irradiance on a tilted detector surface")
-        ox, oy = float(s["origin"][0]), float(s["origin"][1])
+        if extent is None:
+            from . import system as S
+            if int(s["aperture_kind"]) == S.AP_NONE:
+                raise ValueError("Detector surface has no physical aperture - set one "
+                                 "(e.g. RectangularAperture) so that the irradiance "
+                                 "grid can be defined.")
+            extent = _aperture_extent(s)
+            if extent is None:
+                raise NotImplementedError("pass extent= for a boolean / polygon detector aperture")
+        self.tracer = tracer
+        self.num_rays, self.distribution = num_rays, distribution
         self.npix_x, self.npix_y = int(res[0]), int(res[1])
+        self.px_size = None if px_size is None else (float(px_size[0]), float(px_size[1]))
+        self.detector_surface = int(detector_surface)
+        mf = table.raygen.get("max_field", 0.0) or 1.0
+        if fields == "all":
+            fields = [(f[0] / mf, f[1] / mf) for f in table.fields]
+        self.fields = [tuple(map(float, f)) for f in fields]
+        self.wavelengths = (list(map(float, table.wavelengths)) if wavelengths == "all"
+                            else [float(w) for w in wavelengths])
         x_min, x_max, y_min, y_max = (float(v) for v in extent)
-        self.x_edges = np.linspace(x_min, x_max, self.npix_x + 1, dtype=float)
-        self.y_edges = np.linspace(y_min, y_max, self.npix_y + 1, dtype=float)
-        self.pixel_area = (self.x_edges[1] - self.x_edges[0]) * (self.y_edges[1] - self.y_edges[0])
+        if self.px_size is None:
+            self.x_edges = np.linspace(x_min, x_max, self.npix_x + 1, dtype=float)
+            self.y_edges = np.linspace(y_min, y_max, self.npix_y + 1, dtype=float)
+            self.pixel_area = ((self.x_edges[1] - self.x_edges[0])
+                               * (self.y_edges[1] - self.y_edges[0]))
+        else:
+            dx, dy = self.px_size
+            self.x_edges = np.arange(x_min, x_max + 0.5 * dx, dx, dtype=float)
+            self.y_edges = np.arange(y_min, y_max + 0.5 * dy, dy, dtype=float)
+            self.pixel_area = dx * dy
+            self.npix_x, self.npix_y = len(self.x_edges) - 1, len(self.y_edges) - 1
+        self.power_maps = [[self._power_map(f, w) for w in self.wavelengths] for f in self.fields]
+        self.data = [[(pm / self.pixel_area, self.x_edges, self.y_edges) for pm in row]
+                     for row in self.power_maps]
+        # first field / wavelength, for the single-map case
+        self.power_map = self.power_maps[0][0]
+        self.irradiance = self.data[0][0][0]
+
+    def _power_map(self, field, wavelength):
+        import torch
+        tracer = self.tracer
+        s = tracer.table.surfaces[-1]
+        ox, oy = float(s["origin"][0]), float(s["origin"][1])
         old = tracer.record_all
         tracer.record_all = False
         try:
-            rays = tracer.trace(field[0], field[1], wavelength, num_rays, distribution)
+            rays = tracer.trace(field[0], field[1], wavelength, self.num_rays, self.distribution)
         finally:
             tracer.record_all = old
         dev = tracer.device
         # detector-local = global - vertex (untilted): shift the EDGES instead of the hits
         xe = torch.as_tensor(self.x_edges + ox, dtype=torch.float64, device=dev)
         ye = torch.as_tensor(self.y_edges + oy, dtype=torch.float64, device=dev)
-        self.power_map = tracer.engine.irradiance(rays.x.contiguous(), rays.y.contiguous(),
-                                                  rays.i.contiguous(), xe, ye)
-        self.irradiance = self.power_map / self.pixel_area   # (npix_x, npix_y), device
+        return tracer.engine.irradiance(rays.x.contiguous(), rays.y.contiguous(),
+                                        rays.i.contiguous(), xe, ye)
 
-    def peak_irradiance(self) -> float:
-        return float(self.irradiance.max())
+    def peak_irradiance(self):
+        """irradiance.py: maximum of every map, per [field][wavelength]."""
+        return [[float(irr.max()) for irr, _, _ in row] for row in self.data]

@@ -293,10 +293,11 @@ def test_incoherent_irradiance_analysis_on_device():
     x, y, i = (v.double().cpu().numpy() for v in (rays.x, rays.y, rays.i))
     cx, cy = np.nanmean(x), np.nanmean(y)
     ext = (cx - 0.05, cx + 0.05, cy - 0.06, cy + 0.06)
-    irr = IncoherentIrradiance(t, (0.0, 0.7), 0.55, ext, res=(40, 48), num_rays=200)
+    irr = IncoherentIrradiance(t, 200, (40, 48), fields=[(0.0, 0.7)], wavelengths=[0.55],
+                               distribution="uniform", extent=ext)
     valid = i > 0
     want, _, _ = np.histogram2d(x[valid], y[valid], bins=[irr.x_edges, irr.y_edges],
                                 weights=i[valid])
     np.testing.assert_allclose(irr.power_map.cpu().numpy(), want, rtol=1e-10, atol=1e-12)
-    np.testing.assert_allclose(irr.peak_irradiance(), want.max() / irr.pixel_area, rtol=1e-10)
+    np.testing.assert_allclose(irr.peak_irradiance()[0][0], want.max() / irr.pixel_area, rtol=1e-10)
     t.engine.close()

@@ -509,3 +509,74 @@ def test_standalone_encircled_energy_on_random_lenses(ref, seed):
     oz = np.asarray(table.surfaces[-1]["origin"], dtype=np.float64)
     np.testing.assert_allclose(np.array(got.centroid()) - oz[:2], w_cen, rtol=0,
                                atol=1e-8 * max(1.0, np.abs(w_cen).max()))
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_standalone_irradiance_on_random_lenses(ref, seed):
+    """`analysis.IncoherentIrradiance` -- same arguments as the reference's -- on random
+    lenses whose image surface carries a detector aperture of a random leaf class: every
+    (field, wavelength) map, the pixel edges (from `res` or from `px_size`) and the peak
+    irradiance equal the reference's (analysis/irradiance.py:251-353)."""
+    be = ref
+    import torch
+    from optiland import analysis as ref_analysis
+    from optiland import physical_apertures as pa
+    from optiland_amd.analysis import IncoherentIrradiance
+    from optiland_amd.packer import pack_optic
+    from optiland_amd.tracer import HipRayTracer
+    from tests._fake_engine import OracleEngine
+    lens, rng = build_random_lens(seed, be)
+    w = float(lens.primary_wavelength)
+    with np.errstate(all="ignore"):
+        try:
+            chief = lens.trace_generic(0.0, 0.0, 0.0, 0.0, w)
+        except ValueError:
+            pytest.skip("reference raises for this lens")
+    cx = float(np.asarray(chief.x)[0]) - float(np.asarray(lens.image_surface.geometry.cs.x))
+    cy = float(np.asarray(chief.y)[0]) - float(np.asarray(lens.image_surface.geometry.cs.y))
+    if not (np.isfinite(cx) and np.isfinite(cy)):
+        pytest.skip("the chief ray misses a surface")
+    half = float(rng.uniform(0.5, 3.0))
+    kind = int(rng.integers(0, 3))
+    if kind == 0:
+        # (edges chosen so that no pixel boundary passes through the bundle's symmetry axes)
+        ap = pa.RectangularAperture(cx - 0.9713 * half, cx + 1.3 * half, cy - 0.8171 * half,
+                                    cy + half)
+    elif kind == 1:
+        ap = pa.RadialAperture(r_max=float(np.hypot(cx, cy)) + half)
+    else:
+        ap = pa.OffsetRadialAperture(r_max=half, r_min=0.0, offset_x=cx, offset_y=cy)
+    lens.image_surface.aperture = ap
+    use_px = bool(seed % 3 == 0)
+    kw = dict(px_size=(half / 7.3, half / 5.1)) if use_px else {}
+    res = (int(rng.integers(8, 24)), int(rng.integers(8, 24)))
+    try:
+        with np.errstate(all="ignore"):
+            want = ref_analysis.IncoherentIrradiance(lens, num_rays=9, res=res,
+                                                     distribution="hexapolar", **kw)
+    except ValueError:
+        pytest.skip("reference raises for this lens")
+    table = pack_optic(lens)
+    t = HipRayTracer(table, "cpu", dtype=torch.float64, engine=OracleEngine(table, "cpu"))
+    with np.errstate(all="ignore"):
+        got = IncoherentIrradiance(t, num_rays=9, res=res, distribution="hexapolar", **kw)
+    assert len(got.data) == len(want.data) and len(got.data[0]) == len(want.data[0])
+    total = 0.0
+    for grow, wrow in zip(got.data, want.data):
+        for (gi, gx, gy), (wi, wx, wy) in zip(grow, wrow):
+            np.testing.assert_allclose(gx, wx, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(gy, wy, rtol=1e-12, atol=1e-12)
+            g, w_ = gi.numpy(), np.asarray(wi, dtype=np.float64)
+            assert g.shape == w_.shape
+            # a hit within rounding of a pixel edge may land in the neighbouring pixel
+            # powers below 1e-12 of a ray are rounding noise on both sides (e.g. crossed
+            # polarizers: 1e-40 vs 1e-34)
+            floor = 1e-12 / got.pixel_area
+            bad = np.abs(g - w_) > 1e-9 * w_.max() + floor
+            assert bad.sum() <= max(4, 0.02 * bad.size), f"{bad.sum()} of {bad.size} pixels differ"
+            np.testing.assert_allclose(g.sum(), w_.sum(), rtol=1e-9, atol=floor)
+            total += w_.sum() * got.pixel_area
+    if total < 1e-6:
+        pytest.skip("no power reaches the detector of this lens")
+    gp, wp = np.array(got.peak_irradiance()), np.array(want.peak_irradiance(), dtype=np.float64)
+    np.testing.assert_allclose(gp, wp, rtol=0.02, atol=1e-12 / got.pixel_area)
