@@ -40,8 +40,8 @@ class SpotDiagram:
         self.wavelengths = (list(map(float, table.wavelengths)) if wavelengths == "all"
                             else [float(w) for w in wavelengths])
         self.num_rings, self.distribution, self.reference = num_rings, distribution, reference
-        if primary_index is None:
-            primary_index = len(self.wavelengths) // 2
+        if primary_index is None:  # core.py:114-119: the optic's primary wavelength, else 0
+            primary_index = table.reference_wavelength_index(self.wavelengths)
         self.ref_index = primary_index
         self._moments = None
         self._centers = None
@@ -178,7 +178,8 @@ class EncircledEnergy:
         if isinstance(wavelength, (int, float)):
             w = float(wavelength)
         elif wavelength == "primary":
-            w = float(table.wavelengths[len(table.wavelengths) // 2])
+            w = (float(table.primary_wavelength) if table.primary_wavelength is not None
+                 else float(table.wavelengths[len(table.wavelengths) // 2]))
         else:
             raise TypeError(f"Unsupported wavelength: {wavelength}. Expected 'primary' or a number.")
         mf = table.raygen.get("max_field", 0.0) or 1.0

@@ -377,6 +377,7 @@ def pack_optic(optic, wavelengths=None, name: str | None = None) -> SystemTable:
     table = pack_surfaces(optic.surfaces, wavelengths,
                           name or (optic.name or type(optic).__name__))
     _pack_raygen(optic, table)
+    table.primary_wavelength = _f(optic.primary_wavelength)
     pol = optic.polarization
     if pol != "ignore":
         st = optic.polarization_state

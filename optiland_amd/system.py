@@ -133,8 +133,21 @@ class SystemTable:
     polarization: dict | None = None  # None => "ignore"; else PolarizationState
     name: str = ""
     last_thickness: float = 0.0  # optic.surfaces[-1].thickness
+    primary_wavelength: float | None = None  # optic.primary_wavelength (microns), if known
 
     # ------------------------------------------------------------------ info
+    def reference_wavelength_index(self, wavelengths=None) -> int:
+        """Index, within `wavelengths` (default: the table's), of the optic's primary
+        wavelength, 0 if it is not among them -- the reference wavelength of the
+        reference's analyses (analysis/spot_diagram/core.py:114-119).  Tables written
+        before the primary wavelength was recorded fall back to the middle entry (true for
+        every shipped sample)."""
+        wl = [float(w) for w in (self.wavelengths if wavelengths is None else wavelengths)]
+        if self.primary_wavelength is None:
+            return len(wl) // 2
+        p = float(self.primary_wavelength)
+        return wl.index(p) if p in wl else 0
+
     @property
     def num_surfaces(self) -> int:
         """Number of table rows (object + traced surfaces)."""
@@ -199,6 +212,8 @@ class SystemTable:
             "polarization": self.polarization,
             "last_thickness": _enc(self.last_thickness),
         }
+        if self.primary_wavelength is not None:
+            doc["primary_wavelength"] = float(self.primary_wavelength)
         return json.dumps(doc, indent=1)
 
     @classmethod
@@ -229,6 +244,7 @@ class SystemTable:
             polarization=doc.get("polarization"),
             name=doc.get("name", ""),
             last_thickness=_dec(doc.get("last_thickness", 0.0)),
+            primary_wavelength=doc.get("primary_wavelength"),
         )
 
     def save(self, path) -> None:

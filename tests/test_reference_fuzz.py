@@ -201,7 +201,16 @@ def build_random_lens(seed, be):
             apod.PolynomialApodization(R=float(rng.uniform(0.8, 1.2)), p=float(rng.uniform(0.5, 3))),
             apod.SuperGaussianApodization(w=float(rng.uniform(0.6, 1.1)), n=float(rng.uniform(2, 6))),
             apod.TukeyApodization(R=float(rng.uniform(0.8, 1.1)), alpha=float(rng.uniform(0.1, 0.9)))]))
-    lens.wavelengths.add(value=float(rng.uniform(0.45, 0.9)), is_primary=True)
+    # 1-3 wavelengths, the primary one anywhere in the list (its own generator: the lens
+    # geometry of a seed does not depend on it)
+    wrng = np.random.default_rng(80_000 + seed)
+    nw, prim = int(wrng.integers(1, 4)), float(rng.uniform(0.45, 0.9))
+    ip = int(wrng.integers(0, nw))
+    for j in range(nw):
+        if j == ip:
+            lens.wavelengths.add(value=prim, is_primary=True)
+        else:
+            lens.wavelengths.add(value=float(wrng.uniform(0.45, 0.9)), is_primary=False)
     if polarised:
         if rng.random() < 0.5:
             lens.updater.set_polarization(PolarizationState(is_polarized=False))
