@@ -510,7 +510,9 @@ def test_standalone_encircled_energy_on_random_lenses(ref, seed):
     want_ee = np.array(curves)
     # a hit within rounding of a radius step may fall on either side of it: allow one
     # ray's energy of slack on at most a few steps, exact elsewhere
-    diff = np.abs(got.ee - want_ee)
+    # (the r = 0 sample is left out: it holds the chief ray's own energy if and only if that
+    # ray's hit equals the separately traced centre to the last bit)
+    diff = np.abs(got.ee - want_ee)[:, 1:]
     assert (diff > 1e-9 * max(1.0, want_ee.max())).mean() < 0.02
     assert diff.max() <= 1.0 + 1e-9
     np.testing.assert_allclose(got.ee[:, -1], want_ee[:, -1], rtol=1e-12)
@@ -570,7 +572,7 @@ def test_standalone_irradiance_on_random_lenses(ref, seed):
     with np.errstate(all="ignore"):
         got = IncoherentIrradiance(t, num_rays=9, res=res, distribution="hexapolar", **kw)
     assert len(got.data) == len(want.data) and len(got.data[0]) == len(want.data[0])
-    total = 0.0
+    total, any_edge_hit = 0.0, False
     for grow, wrow in zip(got.data, want.data):
         for (gi, gx, gy), (wi, wx, wy) in zip(grow, wrow):
             np.testing.assert_allclose(gx, wx, rtol=1e-12, atol=1e-12)
@@ -583,9 +585,12 @@ def test_standalone_irradiance_on_random_lenses(ref, seed):
             floor = 1e-12 / got.pixel_area
             bad = np.abs(g - w_) > 1e-9 * w_.max() + floor
             assert bad.sum() <= max(4, 0.02 * bad.size), f"{bad.sum()} of {bad.size} pixels differ"
+            any_edge_hit = any_edge_hit or bool(bad.any())
             np.testing.assert_allclose(g.sum(), w_.sum(), rtol=1e-9, atol=floor)
             total += w_.sum() * got.pixel_area
     if total < 1e-6:
         pytest.skip("no power reaches the detector of this lens")
-    gp, wp = np.array(got.peak_irradiance()), np.array(want.peak_irradiance(), dtype=np.float64)
-    np.testing.assert_allclose(gp, wp, rtol=0.02, atol=1e-12 / got.pixel_area)
+    if not any_edge_hit:   # a spot sitting on a pixel edge moves its peak with the rounding
+        gp = np.array(got.peak_irradiance())
+        wp = np.array(want.peak_irradiance(), dtype=np.float64)
+        np.testing.assert_allclose(gp, wp, rtol=1e-9, atol=1e-12 / got.pixel_area)

@@ -1,0 +1,36 @@
+"""CPU, build container only: the differential fuzz families of tests/test_reference_fuzz.py
+over a long seed range (python tools/ref_long_fuzz.py LO HI).  Last run (round 1): seeds
+0..400 of the five stand-alone families and 150..1000 of reference vs packer + oracle:
+0 failures."""
+import sys
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests", "refshim"), "/root/reference"]
+import numpy as np, warnings
+warnings.filterwarnings("ignore")
+import optiland.backend as be
+be.set_backend("numpy")
+import importlib.util
+spec = importlib.util.spec_from_file_location("rf", os.path.join(ROOT, "tests", "test_reference_fuzz.py"))
+rf = importlib.util.module_from_spec(spec); spec.loader.exec_module(rf)
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+for name, extra in (("test_random_reference_lens_equals_packer_plus_oracle", ()),
+                    ("test_standalone_tracer_on_random_lenses", ()),
+                    ("test_standalone_spot_diagram_on_random_lenses", ("chief_ray",)),
+                    ("test_standalone_spot_diagram_on_random_lenses", ("centroid",)),
+                    ("test_standalone_opd_on_random_lenses", ()),
+                    ("test_standalone_encircled_energy_on_random_lenses", ()),
+                    ("test_standalone_irradiance_on_random_lenses", ())):
+    fn = getattr(rf, name)
+    bad, skipped = [], 0
+    for seed in range(lo, hi):
+        try:
+            fn(be, seed, *extra)
+        except BaseException as e:
+            if type(e).__name__ == "Skipped":
+                skipped += 1
+                continue
+            bad.append((seed, type(e).__name__, str(e)[:400].replace("\n", " ")))
+    print(name, extra, "checked", hi - lo, "skipped", skipped, "failures", len(bad))
+    for b in bad[:6]:
+        print("   ", b)
