@@ -1,0 +1,80 @@
+"""GPU box: kernel vs oracle on every table under fuzz_tables/ (tools/make_fuzz_tables.py):
+device ray generation + record-all trace (+ PRT and update_intensity when polarised), fp64
+and fp32.  Prints the worst margins and every case over the contract (fp64 1e-6, fp32 1e-4
+of the position scale; direction / intensity absolute)."""
+import glob
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle  # noqa: E402
+from optiland_amd.engine import HipSystem  # noqa: E402
+from optiland_amd.rays import prt_to_complex  # noqa: E402
+from optiland_amd.system import SystemTable  # noqa: E402
+
+DEV = "cuda:0"
+worst = {torch.float64: 0.0, torch.float32: 0.0}
+over, checked, flagged = [], 0, 0
+for path in sorted(glob.glob(os.path.join(ROOT, "fuzz_tables", "*.json"))):
+    table = SystemTable.load(path)
+    seed = int(os.path.basename(path)[5:9])
+    rng = np.random.default_rng(90_000 + seed)
+    n = 3000
+    r, th = np.sqrt(rng.random(n)) * 0.9, 2 * np.pi * rng.random(n)
+    px, py = r * np.cos(th), r * np.sin(th)
+    hx, hy = np.full(n, rng.uniform(-0.6, 0.6)), np.full(n, rng.uniform(-1, 1))
+    pol = table.polarization is not None
+    for dtype, tol in ((torch.float64, 1e-6), (torch.float32, 1e-4)):
+        f = lambda a: torch.as_tensor(a, dtype=dtype, device=DEV)  # noqa: E731
+        seen = lambda a: f(a).double().cpu().numpy()  # noqa: E731
+        g = oracle.generate_rays(table.raygen, seen(hx), seen(hy), seen(px), seen(py))
+        g["opd"] = np.zeros(n)
+        want = oracle.trace(table, g, 0, record=True, polarized=pol)
+        hip = HipSystem(table, DEV)
+        try:
+            rays = hip.generate_rays(f(hx), f(hy), f(px), f(py), torch.ones(n, dtype=dtype, device=DEV),
+                                     torch.ones(n, dtype=dtype, device=DEV))
+            rays = list(rays) + [torch.zeros(n, dtype=dtype, device=DEV)] if len(rays) == 7 else list(rays)
+            prt = torch.empty((18 if table.needs_complex_prt else 9, n), dtype=dtype, device=DEV) if pol else None
+            try:
+                res = hip.trace(rays, 0, record=True, prt=prt, prt_identity=pol)
+            except ValueError:
+                assert want["status"] != 0, path
+                flagged += 1
+                continue
+            assert want["status"] == 0, (path, "oracle flags a range error, kernel does not")
+            got = res.record[:, :, :n].double().cpu().numpy()
+        finally:
+            hip.close()
+        rec = want["record"]
+        z = rec[1:, 2][np.isfinite(rec[1:, 2])]
+        scale = max(1.0, float(np.abs(z).max()) if z.size else 1.0)
+        # rays the oracle finishes; fp32: away from clip / TIR decisions
+        ok = np.isfinite(rec[-1, 0]) & np.isfinite(got[-1, 0])
+        if dtype == torch.float32:
+            ok &= (rec[-1, 6] > 0) == (got[-1, 6] > 0)
+        if dtype == torch.float64:
+            assert np.array_equal(np.isnan(rec[1:]), np.isnan(got[1:])), path
+        err = 0.0
+        for k in range(8):
+            s_ = scale if k in (0, 1, 2, 7) else 1.0
+            a, b = got[1:, k][:, ok], rec[1:, k][:, ok]
+            if a.size:
+                err = max(err, float(np.nanmax(np.abs(a - b)) / s_))
+        if pol:
+            p = prt_to_complex(prt).cpu().numpy()[ok]
+            err = max(err, float(np.nanmax(np.abs(np.nan_to_num(p) - np.nan_to_num(want["prt"][ok]))))
+                      if ok.any() else 0.0)
+        worst[dtype] = max(worst[dtype], err)
+        if err > tol:
+            over.append((os.path.basename(path), str(dtype), err, float(ok.mean())))
+        checked += 1
+print(f"checked {checked} (table, dtype) pairs, {flagged} range-flagged on both sides")
+print("worst fp64 margin %.3e   worst fp32 margin %.3e" % (worst[torch.float64], worst[torch.float32]))
+print("over the contract:", len(over))
+for o in over[:20]:
+    print("   ", o)
