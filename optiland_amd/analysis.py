@@ -160,7 +160,8 @@ class EncircledEnergy:
     """Encircled-energy curves on device (analysis/encircled_energy.py:20-160).
 
     Mirrors the reference's numerics: per field `num_rays` pupil points of `distribution`
-    (default 100 000 random points) at ONE wavelength, image-plane hits WITHOUT the
+    (default 100 000 random points) at one wavelength (a number / 'primary') or at every
+    wavelength ('all'), image-plane hits WITHOUT the
     intensity mask (its `_generate_field_data`, :163-185), centred on the chief ray of
     that wavelength (the inherited `SpotDiagram` reference), radius steps
     `linspace(0, 1.2 * max geometric radius over all fields, num_points)` and
@@ -175,40 +176,54 @@ class EncircledEnergy:
         table = tracer.table
         if table.polarization is not None or table.uses_polarization:
             raise NotImplementedError("encircled energy of polarised systems")
+        # encircled_energy.py:53-64: a number, 'primary' or 'all'
         if isinstance(wavelength, (int, float)):
-            w = float(wavelength)
+            wls = [float(wavelength)]
         elif wavelength == "primary":
-            w = (float(table.primary_wavelength) if table.primary_wavelength is not None
-                 else float(table.wavelengths[len(table.wavelengths) // 2]))
+            wls = [float(table.primary_wavelength) if table.primary_wavelength is not None
+                   else float(table.wavelengths[len(table.wavelengths) // 2])]
+        elif wavelength == "all":
+            wls = [float(w) for w in table.wavelengths]
         else:
-            raise TypeError(f"Unsupported wavelength: {wavelength}. Expected 'primary' or a number.")
+            raise TypeError(f"Unsupported wavelength: {wavelength}. "
+                            "Expected 'primary', 'all', or a number.")
         mf = table.raygen.get("max_field", 0.0) or 1.0
         if fields == "all":
             fields = [(f[0] / mf, f[1] / mf) for f in table.fields]
         self.fields = [tuple(map(float, f)) for f in fields]
-        self.wavelength, self.num_points = w, int(num_points)
+        self.wavelengths, self.num_points = wls, int(num_points)
+        self.ref_index = table.reference_wavelength_index(wls)
+        self.wavelength = wls[0]  # the curve `view()` titles / `centroid()` reads
         t, eng = tracer, tracer.engine
         hx = torch.tensor([f[0] for f in self.fields], dtype=t.dtype, device=t.device)
         hy = torch.tensor([f[1] for f in self.fields], dtype=t.dtype, device=t.device)
         z = torch.zeros_like(hx)
-        chief = t.trace_generic(hx, hy, z, z, w)
+        chief = t.trace_generic(hx, hy, z, z, wls[self.ref_index])
         cxy = torch.stack([chief.x, chief.y]).double().cpu().numpy()
         self._centers = [(float(cxy[0, i]), float(cxy[1, i])) for i in range(len(self.fields))]
         hits, rmax2 = [], []
         for (fx, fy), c in zip(self.fields, self._centers):
-            _, h = t.trace_spot(fx, fy, w, num_rays, distribution, center=c, hits=True,
-                                check_status=False)
-            hits.append(h)
-            dx, dy = h[0].double() - c[0], h[1].double() - c[1]
-            rmax2.append(torch.max(dx * dx + dy * dy))  # NaN-propagating, like be.max
+            row = []
+            for w in wls:
+                _, h = t.trace_spot(fx, fy, w, num_rays, distribution, center=c, hits=True,
+                                    check_status=False)
+                row.append(h)
+                dx, dy = h[0].double() - c[0], h[1].double() - c[1]
+                rmax2.append(torch.max(dx * dx + dy * dy))  # NaN-propagating, like be.max
+            hits.append(row)
         t.check_status()
-        self._hits = hits
+        self._hits_all = hits
+        self._hits = [row[0] for row in hits]
         axis_lim = float(torch.sqrt(torch.stack(rmax2).max()))
         self.r_step = np.linspace(0.0, axis_lim * 1.2, self.num_points)
         r_dev = torch.as_tensor(self.r_step, dtype=torch.float64, device=t.device)
-        curves = [torch.cumsum(eng.radial_energy(h[0], h[1], h[2], c[0], c[1], r_dev), 0)
-                  for h, c in zip(hits, self._centers)]
-        self.ee = torch.stack(curves).cpu().numpy()  # (n_fields, num_points)
+        curves = [torch.stack([torch.cumsum(eng.radial_energy(h[0], h[1], h[2], c[0], c[1], r_dev), 0)
+                               for h in row])
+                  for row, c in zip(hits, self._centers)]
+        # (n_fields, n_wavelengths, num_points): every curve `view()` draws; `ee` = the first
+        # wavelength's, the only one when `wavelength` is a number or 'primary'
+        self.ee_all = torch.stack(curves).cpu().numpy()
+        self.ee = self.ee_all[:, 0, :]
 
     def centroid(self):
         """encircled_energy.py:117-131: plain mean of the hit coordinates per field."""
