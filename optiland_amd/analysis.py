@@ -258,17 +258,22 @@ class IncoherentIrradiance:
     The detector must be the image surface and carry a physical aperture whose `extent`
     gives the pixel grid (irradiance.py:136-145); `extent=(x_min, x_max, y_min, y_max)`
     overrides it (boolean / polygon apertures have no packed extent).  `px_size=(dx, dy)`
-    derives the resolution from the pixel size like the reference (:302-313).  Not taken
-    over: `user_initial_rays` / `source` / `skip_trace` (caller-built bundles enter at
-    `engine.trace` / the `SurfaceGroup.trace` seam) and the autograd branch.
+    derives the resolution from the pixel size like the reference (:302-313);
+    `user_initial_rays` (a `rays.RealRays` of one wavelength) is traced instead of a field's
+    pupil sampling (:276-280).  Not taken over: `source` / `skip_trace` and the autograd
+    branch.
     The hits stay on the GPU: one trace + one `ol_irradiance` histogram pass per map;
     sharded runs add their `power_map`s (an all-reduce of H x W bins instead of an
     all-gather of hits)."""
 
     def __init__(self, tracer, num_rays: int = 5, res=(128, 128), px_size=None,
                  detector_surface: int = -1, *, fields="all", wavelengths="all",
-                 distribution: str = "random", extent=None):
+                 distribution: str = "random", user_initial_rays=None, extent=None):
+        from .rays import RealRays
         table = tracer.table
+        if user_initial_rays is not None and not isinstance(user_initial_rays, RealRays):
+            raise TypeError("user_initial_rays must be a RealRays object.")  # irradiance.py:121
+        self.user_initial_rays = user_initial_rays
         n_s = table.num_surfaces
         if int(detector_surface) not in (-1, n_s - 1):
             raise NotImplementedError("the detector must be the image surface")
@@ -319,12 +324,24 @@ class IncoherentIrradiance:
         tracer = self.tracer
         s = tracer.table.surfaces[-1]
         ox, oy = float(s["origin"][0]), float(s["origin"][1])
-        old = tracer.record_all
-        tracer.record_all = False
-        try:
-            rays = tracer.trace(field[0], field[1], wavelength, self.num_rays, self.distribution)
-        finally:
-            tracer.record_all = old
+        if self.user_initial_rays is not None:
+            # irradiance.py:276-280: the caller's bundle (copied: traced in place), straight
+            # through the surface loop -- field and pupil sampling play no part
+            u = self.user_initial_rays
+            planes = [p.detach().to(device=tracer.device, dtype=tracer.dtype).reshape(-1).clone()
+                      for p in (u.x, u.y, u.z, u.L, u.M, u.N, u.i)]
+            planes.append(torch.zeros_like(planes[0]))
+            wi = tracer.table.wavelength_index(float(u.w.reshape(-1)[0]))
+            tracer.engine.trace(planes, wi, record=False)
+            rays = type("Hits", (), dict(x=planes[0], y=planes[1], i=planes[6]))
+        else:
+            old = tracer.record_all
+            tracer.record_all = False
+            try:
+                rays = tracer.trace(field[0], field[1], wavelength, self.num_rays,
+                                    self.distribution)
+            finally:
+                tracer.record_all = old
         dev = tracer.device
         # detector-local = global - vertex (untilted): shift the EDGES instead of the hits
         xe = torch.as_tensor(self.x_edges + ox, dtype=torch.float64, device=dev)

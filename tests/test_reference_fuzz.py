@@ -601,3 +601,58 @@ def test_standalone_irradiance_on_random_lenses(ref, seed):
         gp = np.array(got.peak_irradiance())
         wp = np.array(want.peak_irradiance(), dtype=np.float64)
         np.testing.assert_allclose(gp, wp, rtol=1e-9, atol=1e-12 / got.pixel_area)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_standalone_irradiance_with_user_rays(ref, seed):
+    """`IncoherentIrradiance(user_initial_rays=...)`: the caller's bundle is traced instead
+    of a field's pupil sampling (analysis/irradiance.py:276-280), on random lenses."""
+    be = ref
+    import copy
+    import torch
+    from optiland import analysis as ref_analysis
+    from optiland import physical_apertures as pa
+    from optiland_amd.analysis import IncoherentIrradiance
+    from optiland_amd.packer import pack_optic
+    from optiland_amd.rays import RealRays
+    from optiland_amd.tracer import HipRayTracer
+    from tests._fake_engine import OracleEngine
+    lens, rng = build_random_lens(seed, be)
+    if lens.polarization != "ignore":
+        pytest.skip("user bundles are plain RealRays")
+    w = float(lens.primary_wavelength)
+    n = 300
+    r, th = np.sqrt(rng.random(n)) * 0.8, 2 * np.pi * rng.random(n)
+    with np.errstate(all="ignore"):
+        try:
+            start = lens.ray_tracer.ray_generator.generate_rays(
+                np.zeros(n), np.full(n, 0.3), r * np.cos(th), r * np.sin(th), w)
+            probe = lens.surfaces.trace(copy.deepcopy(start))
+        except ValueError:
+            pytest.skip("reference raises for this lens")
+    px_, py_ = np.asarray(probe.x, dtype=np.float64), np.asarray(probe.y, dtype=np.float64)
+    if not np.isfinite(px_).any():
+        pytest.skip("no ray reaches the image surface")
+    cx, cy = float(np.nanmedian(px_)), float(np.nanmedian(py_))
+    half = 1.7 * max(float(np.nanmax(np.abs(px_ - cx))), float(np.nanmax(np.abs(py_ - cy))), 1e-3)
+    lens.image_surface.aperture = pa.RectangularAperture(cx - 0.97 * half, cx + half,
+                                                         cy - half, cy + 0.93 * half)
+    with np.errstate(all="ignore"):
+        want = ref_analysis.IncoherentIrradiance(lens, res=(12, 10),
+                                                 user_initial_rays=copy.deepcopy(start))
+    table = pack_optic(lens)
+    t = HipRayTracer(table, "cpu", dtype=torch.float64, engine=OracleEngine(table, "cpu"))
+    mine = RealRays(*[torch.as_tensor(np.asarray(getattr(start, k), dtype=np.float64))
+                      for k in ("x", "y", "z", "L", "M", "N", "i")], w)
+    before = mine.x.clone()
+    with np.errstate(all="ignore"):
+        got = IncoherentIrradiance(t, res=(12, 10), user_initial_rays=mine)
+    assert torch.equal(mine.x, before), "the caller's bundle must not be traced in place"
+    with pytest.raises(TypeError, match="must be a RealRays object"):
+        IncoherentIrradiance(t, res=(12, 10), user_initial_rays={"x": 1})
+    g, w_ = got.data[0][0][0].numpy(), np.asarray(want.data[0][0][0], dtype=np.float64)
+    bad = np.abs(g - w_) > 1e-9 * max(1.0, w_.max())
+    assert bad.sum() <= 4, f"{bad.sum()} pixels differ"
+    np.testing.assert_allclose(g.sum(), w_.sum(), rtol=1e-9, atol=1e-12)
+    if w_.sum() == 0:
+        pytest.skip("every ray of the bundle is clipped in this lens")
