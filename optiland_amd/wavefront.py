@@ -38,10 +38,11 @@ class Wavefront:
     def __init__(self, tracer, field, wavelength, num_rays: int = 12,
                  distribution="hexapolar", strategy: str = "chief_ray",
                  remove_tilt: bool = False):
-        if strategy != "chief_ray" or remove_tilt:
+        if strategy != "chief_ray":
             raise NotImplementedError(
                 "only the reference's default wavefront strategy (chief-ray reference "
-                "sphere, no tilt removal: wavefront/strategy.py:163-215) runs on device")
+                "sphere, wavefront/strategy.py:163-215) runs on device")
+        self.remove_tilt = bool(remove_tilt)
         if tracer.dtype != torch.float64:
             raise ValueError("wavefront analysis needs an fp64 tracer (OPD in waves)")
         rg = tracer.table.raygen
@@ -56,6 +57,24 @@ class Wavefront:
             distribution.generate_points(num_rays)
         self.distribution = distribution
         self.data = self._compute()
+        if self.remove_tilt:  # wavefront.py:173-174
+            self.data.opd = self.fit_and_remove_tilt(self.data)
+
+    @staticmethod
+    def fit_and_remove_tilt(data, remove_piston: bool = False, ridge: float = 1e-12):
+        """wavefront.py:103-148: intensity-weighted least-squares plane a + b x + c y over
+        the pupil coordinates, subtracted from the OPD (the piston term a only when
+        `remove_piston`).  Six moments and a 3x3 solve -- plain tensor ops on the device."""
+        x, y, wgt, opd = data.pupil_x, data.pupil_y, data.intensity, data.opd
+        X = torch.stack([torch.ones_like(x), x, y], dim=1)
+        sw = torch.sqrt(wgt)
+        Xw, yw = X * sw[:, None], opd * sw
+        A = Xw.T @ Xw + ridge * torch.eye(3, dtype=X.dtype, device=X.device)
+        coeffs = torch.linalg.solve(A, Xw.T @ yw)
+        if not remove_piston:
+            coeffs = coeffs.clone()
+            coeffs[0] = 0.0
+        return opd - X @ coeffs
 
     # strategy.py:83-139: tilt of the launch plane for angle fields at infinity
     def _tilt_cosines(self):

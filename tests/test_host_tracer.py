@@ -213,6 +213,9 @@ def test_analysis_signatures_follow_the_reference(monkeypatch):
         SpotDiagram(t, reference="nowhere")
     with pytest.raises(NotImplementedError):
         OPD(t, (0, 0), 0.55, strategy="centroid_sphere")
+    flat = OPD(t, (0, 1), 0.55, num_rays=4, remove_tilt=True)
+    raw = OPD(t, (0, 1), 0.55, num_rays=4)
+    assert flat.rms() <= raw.rms() + 1e-12
     loc, glo = SpotDiagram(t, num_rings=3), SpotDiagram(t, num_rings=3, coordinates="global")
     np.testing.assert_allclose(loc.rms_spot_radius(), glo.rms_spot_radius(), rtol=1e-12)
     oz = np.asarray(t.table.surfaces[-1]["origin"], dtype=np.float64)
