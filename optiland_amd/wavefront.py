@@ -37,11 +37,14 @@ class Wavefront:
 
     def __init__(self, tracer, field, wavelength, num_rays: int = 12,
                  distribution="hexapolar", strategy: str = "chief_ray",
-                 remove_tilt: bool = False):
-        if strategy != "chief_ray":
-            raise NotImplementedError(
-                "only the reference's default wavefront strategy (chief-ray reference "
-                "sphere, wavefront/strategy.py:163-215) runs on device")
+                 remove_tilt: bool = False, robust_trim_std: float = 3.0):
+        # wavefront/strategy.py:606-616 (incl. the backward-compatible aliases)
+        strategy = {"centroid_sphere": "centroid", "best_fit_sphere": "best_fit"}.get(strategy,
+                                                                                       strategy)
+        if strategy not in ("chief_ray", "centroid", "best_fit"):
+            raise ValueError(f"Unknown wavefront strategy: {strategy}")
+        self.strategy = strategy
+        self.robust_trim_std = float(robust_trim_std)
         self.remove_tilt = bool(remove_tilt)
         if tracer.dtype != torch.float64:
             raise ValueError("wavefront analysis needs an fp64 tracer (OPD in waves)")
@@ -90,6 +93,8 @@ class Wavefront:
         return tx * uz, ty * uz
 
     def _compute(self) -> WavefrontData:
+        if self.strategy != "chief_ray":
+            return self._compute_fitted()
         t, rg = self.tracer, self.tracer.table.raygen
         hx, hy = self.field
         # 1. chief ray alone -> reference sphere (strategy.py:176-184, 228-243)
@@ -115,16 +120,77 @@ class Wavefront:
         return WavefrontData(pupil[0], pupil[1], pupil[2], opd, intensity, R)
 
 
+    def _compute_fitted(self) -> WavefrontData:
+        """CentroidStrategy / BestFitStrategy with a spherical reference
+        (wavefront/strategy.py:287-582): the reference sphere comes from the traced bundle
+        itself -- centred on the intensity-weighted (3-sigma trimmed) centroid of the image
+        points with the weighted mean wavefront distance as radius, or the least-squares
+        sphere through the wavefront points -- and the piston is the mean OPD of the rays
+        with intensity > 0.  A handful of device reductions around the same
+        `ol_wavefront_opd` launch."""
+        t, rg = self.tracer, self.tracer.table.raygen
+        hx, hy = self.field
+        rays = t.trace(hx, hy, self.wavelength, None, self.distribution)
+        px, py = t._dev(self.distribution.x), t._dev(self.distribution.y)
+        ux, uy = self._tilt_cosines()
+        half = rg["EPD"] / 2.0
+        opd_c = rays.opd + ux * (px * half) + uy * (py * half)          # strategy.py:88-139
+        inten = rays.i
+        P = torch.stack([rays.x, rays.y, rays.z], dim=1)
+        D = torch.stack([rays.L, rays.M, rays.N], dim=1)
+        valid = (torch.isfinite(P).all(1) & torch.isfinite(D).all(1) & torch.isfinite(opd_c)
+                 & (inten != 0))                                         # :367-393
+        if not bool(valid.any()):
+            raise ValueError("No valid ray samples found for best-fit geometry.")
+        img = P[valid]
+        pts = img - (opd_c[valid] / rg["n_image"])[:, None] * D[valid]
+        if self.strategy == "centroid":
+            w = inten[valid].clamp(min=0.0)                              # :395-431
+            total = w.sum()
+            if float(total) == 0.0:
+                w = torch.ones_like(w)
+                total = w.sum()
+            if self.robust_trim_std > 0:
+                c0 = (img * w[:, None]).sum(0) / total
+                dist = torch.linalg.norm(img - c0, dim=1)
+                mean_d, std_d = dist.mean(), dist.std(unbiased=False)
+                if float(std_d) > 0:
+                    keep = dist <= mean_d + self.robust_trim_std * std_d
+                    if int(keep.sum()) >= 4:
+                        w = w * keep
+            center = (img * w[:, None]).sum(0) / w.sum()                 # :433-474
+            R = float((w * torch.linalg.norm(pts - center, dim=1)).sum() / w.sum())
+        else:
+            if pts.shape[0] < 4:
+                raise ValueError("Need at least 4 valid ray samples for best-fit.")
+            A = torch.cat([pts, torch.ones_like(pts[:, :1])], dim=1)     # :556-582
+            b = (pts * pts).sum(1)
+            c = torch.linalg.lstsq(A.cpu(), b.cpu()[:, None], driver="gelsd").solution[:, 0].to(A)
+            center = c[:3] / 2
+            R = float(torch.sqrt(c[3] + (center * center).sum()))
+        xc, yc, zc = (float(v) for v in center)
+        params = dict(xc=xc, yc=yc, zc=zc, R=R, n_image=rg["n_image"], opd_ref=0.0, ux=ux,
+                      uy=uy, half_epd=half, wavelength_um=self.wavelength)
+        r7 = [v.contiguous() for v in (rays.x, rays.y, rays.z, rays.L, rays.M, rays.N, rays.opd)]
+        neg, pupil = t.engine.wavefront_opd(params, r7, px, py, want_pupil=True)
+        alive = inten > 0                                                # :331-340
+        if not bool(alive.any()):
+            raise ValueError("No valid rays with non-zero intensity for OPD calculation.")
+        opd = neg - neg[alive].mean()       # (mean_opd - opd) / lambda
+        return WavefrontData(pupil[0], pupil[1], pupil[2], opd, inten.clone(), R)
+
+
 class OPD(Wavefront):
     """wavefront/opd.py:72-93: OPD wavefront; `num_rays` = number of hexapolar rings for
     the default distribution (15), as in the reference (`num_rings` is kept as an alias)."""
 
     def __init__(self, tracer, field, wavelength, num_rays: int = 15,
                  distribution="hexapolar", strategy: str = "chief_ray",
-                 remove_tilt: bool = False, num_rings: int | None = None):
+                 remove_tilt: bool = False, num_rings: int | None = None, **kwargs):
         super().__init__(tracer, field, wavelength,
                          num_rays=num_rays if num_rings is None else num_rings,
-                         distribution=distribution, strategy=strategy, remove_tilt=remove_tilt)
+                         distribution=distribution, strategy=strategy, remove_tilt=remove_tilt,
+                         **kwargs)
 
     def rms(self) -> float:
         """opd.py:145-159."""
@@ -146,7 +212,7 @@ class FFTPSF:
     """Scalar FFT PSF (psf/fft.py:42-262) for one field and wavelength."""
 
     def __init__(self, tracer, field, wavelength, num_rays: int = 128, grid_size=None,
-                 strategy: str = "chief_ray", remove_tilt: bool = False):
+                 strategy: str = "chief_ray", remove_tilt: bool = False, **kwargs):
         if grid_size is None:
             if num_rays < 32:
                 raise ValueError("num_rays must be at least 32 if grid_size is not specified.")
@@ -156,7 +222,7 @@ class FFTPSF:
                              f"number of rays ({num_rays}).")
         self.num_rays, self.grid_size = num_rays, grid_size
         self.wavefront = Wavefront(tracer, field, wavelength, num_rays, "uniform",
-                                   strategy=strategy, remove_tilt=remove_tilt)
+                                   strategy=strategy, remove_tilt=remove_tilt, **kwargs)
         self.pupil = self._generate_pupil()
         self.psf = self._compute_psf()
 

@@ -211,8 +211,8 @@ def test_analysis_signatures_follow_the_reference(monkeypatch):
         SpotDiagram(t, coordinates="polar")
     with pytest.raises(ValueError, match="Invalid reference"):
         SpotDiagram(t, reference="nowhere")
-    with pytest.raises(NotImplementedError):
-        OPD(t, (0, 0), 0.55, strategy="centroid_sphere")
+    with pytest.raises(ValueError, match="Unknown wavefront strategy"):
+        OPD(t, (0, 0), 0.55, strategy="nearest_sphere")
     flat = OPD(t, (0, 1), 0.55, num_rays=4, remove_tilt=True)
     raw = OPD(t, (0, 1), 0.55, num_rays=4)
     assert flat.rms() <= raw.rms() + 1e-12

@@ -385,8 +385,9 @@ def test_standalone_spot_diagram_on_random_lenses(ref, seed, reference):
                                atol=1e-8 * scale)
 
 
+@pytest.mark.parametrize("strategy", ["chief_ray", "centroid_sphere", "best_fit_sphere"])
 @pytest.mark.parametrize("seed", range(40))
-def test_standalone_opd_on_random_lenses(ref, seed):
+def test_standalone_opd_on_random_lenses(ref, seed, strategy):
     """`wavefront.OPD` (chief-ray reference sphere, exit-pupil data from the packer, tilt
     removal for angle fields at infinity only) against the reference's `OPD` on random
     lenses and a random field: reference-sphere radius, pupil coordinates, the OPD map in
@@ -406,7 +407,7 @@ def test_standalone_opd_on_random_lenses(ref, seed):
     detrend = bool(seed % 2)     # wavefront.py:103-148: weighted tilt removal
     try:
         with np.errstate(all="ignore"):
-            want = RefOPD(lens, field, w, num_rays=5, remove_tilt=detrend)
+            want = RefOPD(lens, field, w, num_rays=5, strategy=strategy, remove_tilt=detrend)
             d0 = want.get_data(field, w)
             w_opd = np.asarray(d0.opd, dtype=np.float64)
             w_rms = float(want.rms())
@@ -417,12 +418,16 @@ def test_standalone_opd_on_random_lenses(ref, seed):
     table = pack_optic(lens, wavelengths=[w])
     t = HipRayTracer(table, "cpu", dtype=torch.float64, engine=OracleEngine(table, "cpu"))
     with np.errstate(all="ignore"):
-        got = OPD(t, field, w, num_rays=5, remove_tilt=detrend)
+        got = OPD(t, field, w, num_rays=5, strategy=strategy, remove_tilt=detrend)
     d1 = got.data
-    np.testing.assert_allclose(d1.radius, float(d0.radius), rtol=1e-9)
+    # (the least-squares sphere is an ill-conditioned fit: SVD here and there agree to ~1e-8)
+    np.testing.assert_allclose(d1.radius, float(d0.radius),
+                               rtol=1e-6 if strategy.startswith("best_fit") else 1e-9)
     pupil1 = torch.stack([d1.pupil_x, d1.pupil_y, d1.pupil_z]).numpy()
     pupil0 = np.stack([np.asarray(v, dtype=np.float64) for v in (d0.pupil_x, d0.pupil_y, d0.pupil_z)])
-    np.testing.assert_allclose(pupil1, pupil0, rtol=0, atol=1e-8 * max(1.0, abs(float(d0.radius))))
+    np.testing.assert_allclose(pupil1, pupil0, rtol=0,
+                               atol=(1e-6 if strategy.startswith("best_fit") else 1e-8)
+                               * max(1.0, abs(float(d0.radius))))
     # OPD in waves: absolute error scaled by the optical path (mm / lambda) it is the small
     # difference of
     waves = max(1.0, float(np.abs(w_opd).max()))

@@ -77,3 +77,29 @@ def test_wavefront_and_psf_on_device(tag):
     if tag == "cooke":
         np.testing.assert_allclose(opd.rms(), 0.9709788038168692, rtol=1e-5)
     t.engine.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strategy", ["centroid_sphere", "best_fit_sphere"])
+@pytest.mark.parametrize("tag", list(CASES))
+def test_fitted_reference_spheres_on_device(tag, strategy):
+    """Centroid / best-fit reference spheres (wavefront/strategy.py:287-582) and the
+    weighted tilt removal on the real engine against the same host code on the
+    oracle-backed engine (itself held to the live reference by tests/test_reference_fuzz.py)."""
+    from tests._fake_engine import OracleEngine
+    name, field, wl = CASES[tag]
+    table = load_system(name)
+    real = tr.HipRayTracer(table, "cuda:0", dtype=torch.float64)
+    fake = tr.HipRayTracer(table, "cpu", dtype=torch.float64, engine=OracleEngine(table, "cpu"))
+    try:
+        for detrend in (False, True):
+            a = OPD(real, field, wl, num_rays=8, strategy=strategy, remove_tilt=detrend)
+            b = OPD(fake, field, wl, num_rays=8, strategy=strategy, remove_tilt=detrend)
+            np.testing.assert_allclose(a.data.radius, b.data.radius, rtol=1e-6)
+            np.testing.assert_allclose(a.data.opd.cpu().numpy(), b.data.opd.numpy(), rtol=0,
+                                       atol=1e-6 * max(1.0, float(b.data.opd.abs().max())))
+            np.testing.assert_allclose(a.rms(), b.rms(), rtol=1e-5, atol=1e-7)
+        psf = FFTPSF(real, field, wl, num_rays=32, strategy=strategy)
+        assert 0.0 < psf.strehl_ratio() <= 1.0 + 1e-9
+    finally:
+        real.engine.close()

@@ -18,7 +18,9 @@ for name, extra in (("test_random_reference_lens_equals_packer_plus_oracle", ())
                     ("test_standalone_tracer_on_random_lenses", ()),
                     ("test_standalone_spot_diagram_on_random_lenses", ("chief_ray",)),
                     ("test_standalone_spot_diagram_on_random_lenses", ("centroid",)),
-                    ("test_standalone_opd_on_random_lenses", ()),
+                    ("test_standalone_opd_on_random_lenses", ("chief_ray",)),
+                    ("test_standalone_opd_on_random_lenses", ("centroid_sphere",)),
+                    ("test_standalone_opd_on_random_lenses", ("best_fit_sphere",)),
                     ("test_standalone_encircled_energy_on_random_lenses", ()),
                     ("test_standalone_irradiance_on_random_lenses", ())):
     fn = getattr(rf, name)
