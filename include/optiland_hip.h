@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OL_ABI_VERSION 3
+#define OL_ABI_VERSION 4
 
 /* ---- error codes ------------------------------------------------------- */
 #define OL_OK 0
@@ -423,6 +423,11 @@ typedef struct ol_wavefront_params {
   double ux, uy;         /* launch-plane tilt direction cosines (0 when n/a)      */
   double half_epd;
   double wavelength_um;
+  /* ABI 4: planar reference for afocal systems (wavefront/reference_geometry.py:87-128
+   * PlanarReference.path_length).  All zero = the sphere above; otherwise the reference is
+   * the plane through (xc, yc, zc) with this normal, R is ignored and
+   *   t = -((r - c) . n) / (k_back . n),  |k_back . n| < 1e-12 replaced by 1e-12.       */
+  double nx, ny, nz;
 } ol_wavefront_params;
 
 int ol_wavefront_opd(const ol_wavefront_params* p, ol_dtype dt, int64_t n_rays,

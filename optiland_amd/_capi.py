@@ -80,7 +80,7 @@ SPOT_SLOTS = 64
 
 class WavefrontParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("xc", "yc", "zc", "R", "n_image", "opd_ref", "ux",
-                                          "uy", "half_epd", "wavelength_um")]
+                                          "uy", "half_epd", "wavelength_um", "nx", "ny", "nz")]
 
 
 class PolarizationStateC(C.Structure):
@@ -115,7 +115,7 @@ EXPORTS = (
 
 F32, F64 = 0, 1
 TUNE_RAYS_PER_THREAD, TUNE_COMPACT = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def library_path() -> str:

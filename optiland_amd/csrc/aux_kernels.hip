@@ -147,19 +147,29 @@ __global__ __launch_bounds__(kBlock) void wavefront_kernel(
     const T* __restrict__ py, T* opd_waves, T* pux, T* puy, T* puz) {
   const T xc = (T)p.xc, yc = (T)p.yc, zc = (T)p.zc, R = (T)p.R, ni = (T)p.n_image;
   const T inv_w = (T)(1.0 / (p.wavelength_um * 1e-3));
+  const bool planar = p.nx != 0.0 || p.ny != 0.0 || p.nz != 0.0;  // launch-uniform
+  const T nx = (T)p.nx, ny = (T)p.ny, nz = (T)p.nz;
   for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
        j += (int64_t)gridDim.x * kBlock) {
     const T xr = x[j], yr = y[j], zr = z[j];
     const T L = -Ld[j], M = -Md[j], N = -Nd[j];  // trace backwards from the image
-    const T a = L * L + M * M + N * N;
-    const T b = T(2) * (L * (xr - xc) + M * (yr - yc) + N * (zr - zc));
-    const T c = xr * xr + yr * yr + zr * zr - T(2) * (xr * xc + yr * yc + zr * zc) + xc * xc +
-                yc * yc + zc * zc - R * R;
-    T d = b * b - T(4) * a * c;
-    d = d < T(0) ? T(0) : d;
-    const T sq = sqrt(d);
-    const T t1 = (-b - sq) / (T(2) * a), t2 = (-b + sq) / (T(2) * a);
-    const T t = t1 < T(0) ? t2 : t1;
+    T t;
+    if (planar) {  // reference_geometry.py:104-124
+      const T num = (xr - xc) * nx + (yr - yc) * ny + (zr - zc) * nz;
+      T den = L * nx + M * ny + N * nz;
+      den = fabs(den) < T(1e-12) ? T(1e-12) : den;
+      t = -num / den;
+    } else {
+      const T a = L * L + M * M + N * N;
+      const T b = T(2) * (L * (xr - xc) + M * (yr - yc) + N * (zr - zc));
+      const T c = xr * xr + yr * yr + zr * zr - T(2) * (xr * xc + yr * yc + zr * zc) +
+                  xc * xc + yc * yc + zc * zc - R * R;
+      T d = b * b - T(4) * a * c;
+      d = d < T(0) ? T(0) : d;
+      const T sq = sqrt(d);
+      const T t1 = (-b - sq) / (T(2) * a), t2 = (-b + sq) / (T(2) * a);
+      t = t1 < T(0) ? t2 : t1;
+    }
     const T opd_img = ni * t;
     const T tilt = (T)p.ux * (px[j] * (T)p.half_epd) + (T)p.uy * (py[j] * (T)p.half_epd);
     const T opd = opd_in[j] - opd_img + tilt;

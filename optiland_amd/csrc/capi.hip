@@ -807,7 +807,7 @@ int ol_wavefront_opd(const ol_wavefront_params* p, ol_dtype dt, int64_t n_rays,
   if (pupil && (!pupil[0] || !pupil[1] || !pupil[2]))
     return fail(OL_EINVAL, "ol_wavefront_opd: pupil planes must all be given or pupil = NULL");
   ol::WavefrontDev d{p->xc, p->yc, p->zc, p->R, p->n_image, p->opd_ref,
-                     p->ux, p->uy, p->half_epd, p->wavelength_um};
+                     p->ux, p->uy, p->half_epd, p->wavelength_um, p->nx, p->ny, p->nz};
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipError_t e;
   if (dt == OL_F32) {

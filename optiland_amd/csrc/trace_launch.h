@@ -131,6 +131,7 @@ hipError_t launch_pol_intensity(int64_t n, const T* prt, bool prt_complex, const
 
 struct WavefrontDev {
   double xc, yc, zc, R, n_image, opd_ref, ux, uy, half_epd, wavelength_um;
+  double nx, ny, nz;  // all zero: spherical reference; else planar reference normal
 };
 
 template <typename T>

@@ -350,8 +350,8 @@ class HipSystem:
         """OPD in waves (+ pupil coordinates) against the chief-ray reference sphere."""
         n = int(px.numel())
         dtype = px.dtype
-        p = _capi.WavefrontParams(**{k: float(params[k]) for k, _ in
-                                     _capi.WavefrontParams._fields_})
+        p = _capi.WavefrontParams(**{k: float(params.get(k, 0.0)) for k, _ in
+                                     _capi.WavefrontParams._fields_})  # nx,ny,nz default 0
         opd = torch.empty(n, dtype=dtype, device=self.device)
         pupil = torch.empty((3, n), dtype=dtype, device=self.device) if want_pupil else None
         rp = (C.c_void_p * 7)(*[t.data_ptr() for t in rays7])

@@ -37,7 +37,7 @@ class Wavefront:
 
     def __init__(self, tracer, field, wavelength, num_rays: int = 12,
                  distribution="hexapolar", strategy: str = "chief_ray",
-                 remove_tilt: bool = False, robust_trim_std: float = 3.0):
+                 remove_tilt: bool = False, robust_trim_std: float = 3.0, afocal: bool = False):
         # wavefront/strategy.py:606-616 (incl. the backward-compatible aliases)
         strategy = {"centroid_sphere": "centroid", "best_fit_sphere": "best_fit"}.get(strategy,
                                                                                        strategy)
@@ -46,6 +46,8 @@ class Wavefront:
         self.strategy = strategy
         self.robust_trim_std = float(robust_trim_std)
         self.remove_tilt = bool(remove_tilt)
+        # wavefront.py:74: afocal systems measure against a PLANE (reference_geometry.py:87-128)
+        self.afocal = bool(afocal)
         if tracer.dtype != torch.float64:
             raise ValueError("wavefront analysis needs an fp64 tracer (OPD in waves)")
         rg = tracer.table.raygen
@@ -100,10 +102,15 @@ class Wavefront:
         # 1. chief ray alone -> reference sphere (strategy.py:176-184, 228-243)
         chief = t.trace_generic(hx, hy, 0.0, 0.0, self.wavelength)
         xc, yc, zc = (float(v[0]) for v in (chief.x, chief.y, chief.z))
-        R = math.sqrt(xc * xc + yc * yc + (zc - rg["pupil_z"]) ** 2)
         ux, uy = self._tilt_cosines()
-        params = dict(xc=xc, yc=yc, zc=zc, R=R, n_image=rg["n_image"], opd_ref=0.0, ux=ux,
+        params = dict(xc=xc, yc=yc, zc=zc, n_image=rg["n_image"], opd_ref=0.0, ux=ux,
                       uy=uy, half_epd=rg["EPD"] / 2.0, wavelength_um=self.wavelength)
+        if self.afocal:  # strategy.py:260-284: plane through the chief-ray hit, normal to it
+            R = math.inf
+            params.update(R=0.0, nx=float(chief.L[0]), ny=float(chief.M[0]), nz=float(chief.N[0]))
+        else:
+            R = math.sqrt(xc * xc + yc * yc + (zc - rg["pupil_z"]) ** 2)
+            params.update(R=R)
         zero = torch.zeros(1, dtype=t.dtype, device=t.device)
         # with opd_ref = 0 the kernel returns -opd/lambda for the chief ray
         c7 = [v.contiguous() for v in (chief.x, chief.y, chief.z, chief.L, chief.M, chief.N,
@@ -144,6 +151,7 @@ class Wavefront:
             raise ValueError("No valid ray samples found for best-fit geometry.")
         img = P[valid]
         pts = img - (opd_c[valid] / rg["n_image"])[:, None] * D[valid]
+        normal = None
         if self.strategy == "centroid":
             w = inten[valid].clamp(min=0.0)                              # :395-431
             total = w.sum()
@@ -159,7 +167,19 @@ class Wavefront:
                     if int(keep.sum()) >= 4:
                         w = w * keep
             center = (img * w[:, None]).sum(0) / w.sum()                 # :433-474
-            R = float((w * torch.linalg.norm(pts - center, dim=1)).sum() / w.sum())
+            if self.afocal:                                              # :485-517
+                normal = (D[valid] * w[:, None]).sum(0) / w.sum()
+                nrm = torch.linalg.norm(normal)
+                normal = normal / nrm if float(nrm) > 0 else normal
+                R = math.inf
+            else:
+                R = float((w * torch.linalg.norm(pts - center, dim=1)).sum() / w.sum())
+        elif self.afocal:                                                # :584-605
+            if pts.shape[0] < 4:
+                raise ValueError("Need at least 4 valid ray samples for best-fit.")
+            center = pts.mean(0)
+            normal = torch.linalg.svd((pts - center).cpu(), full_matrices=False).Vh[-1].to(pts)
+            R = math.inf
         else:
             if pts.shape[0] < 4:
                 raise ValueError("Need at least 4 valid ray samples for best-fit.")
@@ -169,8 +189,11 @@ class Wavefront:
             center = c[:3] / 2
             R = float(torch.sqrt(c[3] + (center * center).sum()))
         xc, yc, zc = (float(v) for v in center)
-        params = dict(xc=xc, yc=yc, zc=zc, R=R, n_image=rg["n_image"], opd_ref=0.0, ux=ux,
+        params = dict(xc=xc, yc=yc, zc=zc, R=0.0 if normal is not None else R,
+                      n_image=rg["n_image"], opd_ref=0.0, ux=ux,
                       uy=uy, half_epd=half, wavelength_um=self.wavelength)
+        if normal is not None:
+            params.update(nx=float(normal[0]), ny=float(normal[1]), nz=float(normal[2]))
         r7 = [v.contiguous() for v in (rays.x, rays.y, rays.z, rays.L, rays.M, rays.N, rays.opd)]
         neg, pupil = t.engine.wavefront_opd(params, r7, px, py, want_pupil=True)
         alive = inten > 0                                                # :331-340

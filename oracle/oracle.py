@@ -183,7 +183,7 @@ def distance(table, surface_index, x, y, z, L, M, N):
 
 class WavefrontParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("xc", "yc", "zc", "R", "n_image", "opd_ref", "ux",
-                                          "uy", "half_epd", "wavelength_um")]
+                                          "uy", "half_epd", "wavelength_um", "nx", "ny", "nz")]
 
 
 def wavefront_opd(params: dict, rays7, px, py):
@@ -191,7 +191,7 @@ def wavefront_opd(params: dict, rays7, px, py):
     a = [np.ascontiguousarray(v, dtype=np.float64) for v in rays7]
     px, py = (np.ascontiguousarray(v, dtype=np.float64) for v in (px, py))
     n = a[0].size
-    p = WavefrontParams(**{k: float(params[k]) for k, _ in WavefrontParams._fields_})
+    p = WavefrontParams(**{k: float(params.get(k, 0.0)) for k, _ in WavefrontParams._fields_})
     out = np.zeros(n)
     pupil = np.zeros((3, n))
     rp = (C.c_void_p * 7)(*[_ptr(v) for v in a])

@@ -911,6 +911,13 @@ void oracle_wavefront_opd(const ol_wavefront_params* p, int64_t n, double* const
     if (d < 0) d = 0;
     double t1 = (-b - sqrt(d)) / (2 * a), t2 = (-b + sqrt(d)) / (2 * a);
     double t = t1 < 0 ? t2 : t1;
+    if (p->nx != 0.0 || p->ny != 0.0 || p->nz != 0.0) {
+      /* wavefront/reference_geometry.py:104-124 PlanarReference.path_length */
+      double num = (xr - xc) * p->nx + (yr - yc) * p->ny + (zr - zc) * p->nz;
+      double den = L * p->nx + M * p->ny + N * p->nz;
+      if (fabs(den) < 1e-12) den = 1e-12;
+      t = -num / den;
+    }
     double opd_img = p->n_image * t;
     double opd = rays[6][j] - opd_img;
     double X_m = px[j] * p->half_epd, Y_m = py[j] * p->half_epd;

@@ -41,7 +41,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.ol_abi_version() == _capi.ABI_VERSION == 3
+    assert lib.ol_abi_version() == _capi.ABI_VERSION == 4
 
 
 def test_struct_layouts_agree_with_the_c_compiler():
@@ -56,6 +56,8 @@ int main(void) {
          offsetof(ol_surface_desc, rot), offsetof(ol_surface_desc, aperture),
          offsetof(ol_surface_desc, coat), sizeof(ol_surface_optics), sizeof(ol_raygen_params));
   printf("%zu %zu\n", sizeof(ol_polarization_state), offsetof(ol_raygen_params, EPL));
+  printf("%zu %zu %zu\n", sizeof(ol_wavefront_params), offsetof(ol_wavefront_params, wavelength_um),
+         offsetof(ol_wavefront_params, nx));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -72,6 +74,10 @@ int main(void) {
     assert nums[7] == S.RAYGEN_DTYPE.itemsize == C.sizeof(_capi.RaygenParams)
     assert nums[8] == C.sizeof(_capi.PolarizationStateC)
     assert nums[9] == S.RAYGEN_DTYPE.fields["EPL"][1]
+    from oracle.oracle import WavefrontParams as OracleWavefrontParams
+    for cls in (_capi.WavefrontParams, OracleWavefrontParams):
+        assert nums[10] == C.sizeof(cls)
+        assert nums[11] == cls.wavelength_um.offset and nums[12] == cls.nx.offset
 
 
 def test_argument_validation_without_a_device(lib):

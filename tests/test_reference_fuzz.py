@@ -405,9 +405,11 @@ def test_standalone_opd_on_random_lenses(ref, seed, strategy):
     w = float(lens.primary_wavelength)
     field = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-1, 1)))
     detrend = bool(seed % 2)     # wavefront.py:103-148: weighted tilt removal
+    afocal = bool(seed % 3 == 0)  # planar reference (reference_geometry.py:87-128)
     try:
         with np.errstate(all="ignore"):
-            want = RefOPD(lens, field, w, num_rays=5, strategy=strategy, remove_tilt=detrend)
+            want = RefOPD(lens, field, w, num_rays=5, strategy=strategy, remove_tilt=detrend,
+                          afocal=afocal)
             d0 = want.get_data(field, w)
             w_opd = np.asarray(d0.opd, dtype=np.float64)
             w_rms = float(want.rms())
@@ -418,16 +420,20 @@ def test_standalone_opd_on_random_lenses(ref, seed, strategy):
     table = pack_optic(lens, wavelengths=[w])
     t = HipRayTracer(table, "cpu", dtype=torch.float64, engine=OracleEngine(table, "cpu"))
     with np.errstate(all="ignore"):
-        got = OPD(t, field, w, num_rays=5, strategy=strategy, remove_tilt=detrend)
+        got = OPD(t, field, w, num_rays=5, strategy=strategy, remove_tilt=detrend, afocal=afocal)
     d1 = got.data
     # (the least-squares sphere is an ill-conditioned fit: SVD here and there agree to ~1e-8)
-    np.testing.assert_allclose(d1.radius, float(d0.radius),
-                               rtol=1e-6 if strategy.startswith("best_fit") else 1e-9)
+    if afocal:
+        assert d1.radius == float(d0.radius) == float("inf")
+    else:
+        np.testing.assert_allclose(d1.radius, float(d0.radius),
+                                   rtol=1e-6 if strategy.startswith("best_fit") else 1e-9)
     pupil1 = torch.stack([d1.pupil_x, d1.pupil_y, d1.pupil_z]).numpy()
     pupil0 = np.stack([np.asarray(v, dtype=np.float64) for v in (d0.pupil_x, d0.pupil_y, d0.pupil_z)])
     np.testing.assert_allclose(pupil1, pupil0, rtol=0,
                                atol=(1e-6 if strategy.startswith("best_fit") else 1e-8)
-                               * max(1.0, abs(float(d0.radius))))
+                               * max(1.0, abs(float(d0.radius)) if not afocal else
+                                     float(np.abs(pupil0).max())))
     # OPD in waves: absolute error scaled by the optical path (mm / lambda) it is the small
     # difference of
     waves = max(1.0, float(np.abs(w_opd).max()))

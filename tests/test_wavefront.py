@@ -92,13 +92,22 @@ def test_fitted_reference_spheres_on_device(tag, strategy):
     real = tr.HipRayTracer(table, "cuda:0", dtype=torch.float64)
     fake = tr.HipRayTracer(table, "cpu", dtype=torch.float64, engine=OracleEngine(table, "cpu"))
     try:
-        for detrend in (False, True):
-            a = OPD(real, field, wl, num_rays=8, strategy=strategy, remove_tilt=detrend)
-            b = OPD(fake, field, wl, num_rays=8, strategy=strategy, remove_tilt=detrend)
-            np.testing.assert_allclose(a.data.radius, b.data.radius, rtol=1e-6)
+        for detrend, afocal in ((False, False), (True, False), (False, True)):
+            a = OPD(real, field, wl, num_rays=8, strategy=strategy, remove_tilt=detrend,
+                    afocal=afocal)
+            b = OPD(fake, field, wl, num_rays=8, strategy=strategy, remove_tilt=detrend,
+                    afocal=afocal)
+            if afocal:   # planar reference (reference_geometry.py:87-128)
+                assert a.data.radius == b.data.radius == float("inf")
+            else:
+                np.testing.assert_allclose(a.data.radius, b.data.radius, rtol=1e-6)
             np.testing.assert_allclose(a.data.opd.cpu().numpy(), b.data.opd.numpy(), rtol=0,
                                        atol=1e-6 * max(1.0, float(b.data.opd.abs().max())))
             np.testing.assert_allclose(a.rms(), b.rms(), rtol=1e-5, atol=1e-7)
+        c = OPD(real, field, wl, num_rays=8, afocal=True)     # chief-ray plane
+        d = OPD(fake, field, wl, num_rays=8, afocal=True)
+        np.testing.assert_allclose(c.data.opd.cpu().numpy(), d.data.opd.numpy(), rtol=0,
+                                   atol=1e-6 * max(1.0, float(d.data.opd.abs().max())))
         psf = FFTPSF(real, field, wl, num_rays=32, strategy=strategy)
         assert 0.0 < psf.strehl_ratio() <= 1.0 + 1e-9
     finally:
