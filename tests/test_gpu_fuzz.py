@@ -651,6 +651,10 @@ def test_random_wavefront_opd(seed):
               "ux": float(rng.uniform(-0.05, 0.05)) if seed % 2 else 0.0,
               "uy": float(rng.uniform(-0.05, 0.05)) if seed % 2 else 0.0,
               "half_epd": float(rng.uniform(3, 12)), "wavelength_um": float(rng.uniform(0.4, 1.6))}
+    if seed % 4 == 3:   # ABI 4: planar reference through (xc, yc, zc) with this normal
+        nv = np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), 1.0])
+        nv /= np.linalg.norm(nv)
+        params.update(zc=zc - abs(R), nx=float(nv[0]), ny=float(nv[1]), nz=float(nv[2]))
     L, M = rng.uniform(-0.15, 0.15, n), rng.uniform(-0.15, 0.15, n)
     rays7 = [rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n), np.full(n, zc),
              L, M, np.sqrt(1 - L * L - M * M), rng.uniform(95, 105, n)]
