@@ -677,3 +677,76 @@ def test_drop_in_on_random_lenses(hip_on_cpu, seed):
         close(a, b, "record " + k)
     for k, b in want_t.items():
         close(_np(be, getattr(t1, k)), b, "trace " + k)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_bridging_on_random_lenses(sg_seam, seed):
+    """Random reference-built lenses with a thin lens (paraxial surface) or a grating
+    inserted at a random position: `Optic.trace` under enable() -- reference ray generation,
+    fused runs around the unsupported surface, that surface (and, after a thin lens, the
+    renormalising next one) on the reference -- equals the reference's NumPy-backend trace,
+    final rays and every surface's record."""
+    import importlib.util
+    import optiland.backend as be
+    spec = importlib.util.spec_from_file_location(
+        "_ref_fuzz", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_reference_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+
+    def build():
+        lens, rng = fz.build_random_lens(seed, be)
+        n_s = len(lens.surfaces.surfaces)
+        k = int(rng.integers(2, n_s - 1)) if n_s > 3 else n_s - 1
+        if seed % 2:
+            lens.surfaces.add(index=k, surface_type="paraxial", f=float(rng.uniform(60, 200)),
+                              thickness=float(rng.uniform(1, 3)))
+        else:
+            lens.surfaces.add(index=k, radius=be.inf, thickness=float(rng.uniform(1, 3)),
+                              surface_type="grating", grating_order=int(rng.choice([-1, 0, 1])),
+                              grating_period=float(rng.uniform(20.0, 60.0)),
+                              groove_orientation_angle=float(rng.uniform(0, 1.5)))
+        return lens, rng
+
+    be.set_backend("numpy")
+    try:
+        lens_np, rng = build()
+    except Exception as e:  # the reference cannot insert there (e.g. inside a mirror fold)
+        be.set_backend("torch")
+        pytest.skip(f"reference cannot build this variant: {type(e).__name__}")
+    if lens_np.polarization != "ignore":
+        be.set_backend("torch")
+        pytest.skip("polarised reference traces differ between its own backends (DESIGN 7)")
+    w = float(lens_np.primary_wavelength)
+    hx, hy = float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-1, 1))
+    try:
+        with np.errstate(all="ignore"):
+            r0 = lens_np.trace(hx, hy, w, 5, "hexapolar")
+            want = {k: np.asarray(getattr(r0, k), dtype=np.float64) for k in ("x", "y", "z", "L", "M", "N", "i", "opd")}
+            rec0 = {k: np.asarray(getattr(lens_np.surfaces, k), dtype=np.float64)
+                    for k in ("x", "y", "z", "L", "M", "N", "intensity", "opd")}
+    except ValueError:
+        be.set_backend("torch")
+        pytest.skip("reference raises a coordinate-range error for this lens")
+    be.set_backend("torch")
+    lens, _ = build()
+    sg_seam._SG.update(count=0, fallbacks=0, foreign=0)
+    with np.errstate(all="ignore"):
+        r1 = lens.trace(hx, hy, w, 5, "hexapolar")
+    assert sg_seam._SG["count"] == 1 and sg_seam._SG["foreign"] >= 1, dict(sg_seam._SG)
+    z = rec0["z"][1:]
+    scale = max(1.0, float(np.abs(z[np.isfinite(z)]).max()) if np.isfinite(z).any() else 1.0)
+
+    def close(a, b, k):
+        assert a.shape == b.shape, k
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f"{k}: NaN masks differ"
+        tol = 1e-7 * (scale if k[-1] in "xyzd" else 1.0)
+        np.testing.assert_allclose(np.nan_to_num(a, posinf=0, neginf=0),
+                                   np.nan_to_num(b, posinf=0, neginf=0), rtol=0, atol=tol,
+                                   err_msg=f"seed {seed} {k}")
+    for k, b in want.items():
+        close(_np(be, getattr(r1, k)), b, "final " + k)
+    for k, b in rec0.items():
+        a = _np(be, getattr(lens.surfaces, k))
+        if k in "xyz" and not np.isfinite(b[0]).all():
+            a, b = a[1:], b[1:]
+        close(a, b, "record " + k)
