@@ -362,7 +362,11 @@ def _sg_run(group, eng, rays, planes, first, last, polarized):
     prt = None
     if polarized:
         p = rays.p.reshape(n, 9)
-        prt = torch.cat([p.real.t(), p.imag.t()]).to(dtype).contiguous()  # (18, n)
+        if p.is_complex():
+            prt = torch.cat([p.real.t(), p.imag.t()]).to(dtype).contiguous()  # (18, n)
+        else:  # a fresh torch-backend PolarizedRays holds a REAL identity (polarized_rays.py:50)
+            prt = torch.cat([p.t().to(dtype), torch.zeros((9, n), dtype=dtype,
+                                                          device=p.device)]).contiguous()
     res = eng.trace(planes, 0, record=True, prt=prt, first=first, last=last)
     for s in range(first, last + 1):
         surf = group.surfaces[s]

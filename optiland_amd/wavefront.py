@@ -67,19 +67,23 @@ class Wavefront:
 
     @staticmethod
     def fit_and_remove_tilt(data, remove_piston: bool = False, ridge: float = 1e-12):
-        """wavefront.py:103-148: intensity-weighted least-squares plane a + b x + c y over
-        the pupil coordinates, subtracted from the OPD (the piston term a only when
-        `remove_piston`).  Six moments and a 3x3 solve -- plain tensor ops on the device."""
-        x, y, wgt, opd = data.pupil_x, data.pupil_y, data.intensity, data.opd
-        X = torch.stack([torch.ones_like(x), x, y], dim=1)
-        sw = torch.sqrt(wgt)
-        Xw, yw = X * sw[:, None], opd * sw
-        A = Xw.T @ Xw + ridge * torch.eye(3, dtype=X.dtype, device=X.device)
-        coeffs = torch.linalg.solve(A, Xw.T @ yw)
+        """Weighted plane fit of the OPD over the pupil, subtracted (wavefront.py:103-148;
+        the piston only with `remove_piston`).  Formulated as what it is on a device: ONE
+        pass that reduces the nine weighted moments
+            S = sum w [1, x, y, xx, xy, yy],   T = sum w opd [1, x, y]
+        (a (9, n) x (n,) product, a single reduction kernel), the symmetric 3x3 normal
+        system (+ ridge on the diagonal, as the reference regularises) solved on the host
+        in closed form, and one fused elementwise pass for the residual."""
+        x, y, w, opd = data.pupil_x, data.pupil_y, data.intensity, data.opd
+        basis = torch.stack([torch.ones_like(x), x, y, x * x, x * y, y * y,
+                             opd, opd * x, opd * y])
+        m = (basis @ w.to(basis.dtype)).double().cpu().numpy()   # nine moments, one read-back
+        A = np.array([[m[0], m[1], m[2]], [m[1], m[3], m[4]], [m[2], m[4], m[5]]]) \
+            + ridge * np.eye(3)
+        a0, bx, cy = np.linalg.solve(A, m[6:9])
         if not remove_piston:
-            coeffs = coeffs.clone()
-            coeffs[0] = 0.0
-        return opd - X @ coeffs
+            a0 = 0.0
+        return opd - (float(a0) + float(bx) * x + float(cy) * y)
 
     # strategy.py:83-139: tilt of the launch plane for angle fields at infinity
     def _tilt_cosines(self):
@@ -253,10 +257,13 @@ class FFTPSF:
         """psf/fft.py:101-137: A exp(-i 2 pi OPD) on the num_rays^2 grid, 0 off-disc."""
         d = self.wavefront.data
         n = self.num_rays
-        g = torch.linspace(-1, 1, n, dtype=torch.float64, device=d.opd.device)
-        # numpy meshgrid(x, x) default 'xy' indexing, then ravel
-        y, x = torch.meshgrid(g, g, indexing="ij")
-        inside = (x.reshape(-1) ** 2 + y.reshape(-1) ** 2) <= 1
+        # the disc mask comes from the SAME arithmetic that placed the traced samples
+        # (distribution._uniform: np.linspace + np.meshgrid, row-major ravel) -- a
+        # torch.linspace grid differs by an ulp on boundary points such as (0.6, 0.8)
+        # and would select a different number of cells for many odd n
+        g = np.linspace(-1.0, 1.0, n)
+        xg, yg = np.meshgrid(g, g)
+        inside = torch.from_numpy((xg**2 + yg**2 <= 1).reshape(-1)).to(d.opd.device)
         P = torch.zeros(n * n, dtype=torch.complex128, device=d.opd.device)
         amp = torch.sqrt(d.intensity)
         P[inside] = amp * torch.exp(-2j * math.pi * d.opd)

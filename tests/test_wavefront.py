@@ -60,6 +60,20 @@ def test_grid_size_rule():
         FFTPSF(None, (0, 0), 0.55, num_rays=16)
 
 
+@pytest.mark.parametrize("n", [11, 21, 31, 75])
+def test_fftpsf_odd_num_rays_with_explicit_grid(n, monkeypatch):
+    """the pupil mask must select exactly the cells the 'uniform' sampler
+    traced -- with a torch.linspace grid 41 odd sizes in 3..299 disagreed by boundary
+    points (n=11: 81 cells vs 77 samples) and the scatter raised a shape mismatch."""
+    from tests._fake_engine import OracleEngine
+    monkeypatch.setattr(tr, "_make_engine", lambda table, device: OracleEngine(table, device))
+    t = tr.HipRayTracer(load_system("cooke_generic"), dtype=torch.float64)
+    psf = FFTPSF(t, (0.0, 0.0), 0.55, num_rays=n, grid_size=2 * n)
+    assert psf.pupil.shape == (n, n) and psf.psf.shape == (2 * n, 2 * n)
+    assert int((psf.pupil.abs() > 0).sum()) <= psf.wavefront.data.opd.numel()
+    assert 0.0 < psf.strehl_ratio() <= 1.0 + 1e-9
+
+
 def test_fp32_tracer_is_refused(monkeypatch):
     from tests._fake_engine import OracleEngine
     monkeypatch.setattr(tr, "_make_engine", lambda table, device: OracleEngine(table, device))
