@@ -10,13 +10,21 @@ through the double Gauss (BASELINE.json configs[1]) in record-all mode, i.e. wha
 surfaces).  For N > 1 every rank traces its own `--rays` rays (weak scaling) and
 the step ends with the image-plane exchange: per-rank spot moments reduced with
 one RCCL all-reduce (default) or the raw all-gather of image-plane hits
-(`--exchange gather`).
+(`--exchange gather`).  `--config c3` is BASELINE.json configs[2]: fp64, 1e8 rays in
+total, strong-scaled over the ranks (1.25e7 per GPU at N = 8).
+
+`python bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks
+itself (re-exec under `python -m torch.distributed.run`, rendezvous on 127.0.0.1) and
+exits non-zero when fewer than N devices are visible; under the driver's torchrun
+launch it just joins the group.
 
 Rank 0 prints ONE JSON line (metric = ray-surface intersections/s, whole job).
-`roofline` refers to the trace kernel in the mode that was run; `cpu_baseline`
-times the CPU oracle (oracle/, a C port of the reference's algorithm) on a
-bounded sample of the same workload -- the reference itself is pure Python and
-does not exist on the GPU box.
+`roofline` refers to the trace kernel in the mode that was run: `frac` is on the bytes
+the launch really moves (== the PMC traffic), `frac_algorithmic` on SURVEY 8d's figure,
+`frac_of_achievable` against a device copy measured in the same run.  `cpu_baseline` is
+the reference's own NumPy backend (`kind: "reference"`, staged under oracle/_ref) on a
+bounded sample, with the C port of the algorithm (oracle/) beside it; `gpu_baseline` is
+the reference's stock torch backend on the same GPU.
 """
 
 from __future__ import annotations
@@ -67,15 +75,63 @@ def parse_args():
                          "block (zero-copy object row) or keep separate ray planes")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the image-plane exchange even with one rank (RCCL path check)")
+    ap.add_argument("--config", choices=("c2", "c3"), default="c2",
+                    help="c2 = BASELINE.json configs[1] (double Gauss, 1e7 rays/GPU fp32, weak "
+                         "scaling; the default).  c3 = configs[2]: double Gauss, fp64, "
+                         "--total-rays (1e8) rays in total, STRONG-scaled over the ranks")
+    ap.add_argument("--total-rays", type=float, default=1e8, help="--config c3: whole-job rays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-baselines", action="store_true",
+                    help="skip the legs that time the staged reference package (NumPy backend "
+                         "on the host, stock torch backend on the GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--ref-seconds", type=float, default=8.0)
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves.
+
+    Re-executes this script under `python -m torch.distributed.run` (one process per
+    GPU, rendezvous on 127.0.0.1) and exits with ITS return code; exits 2 with a clear
+    message when fewer than N HIP devices are visible.  Under the driver's own torchrun
+    launch (RANK / WORLD_SIZE set) this is a no-op."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: error: --gpus {args.gpus} requested but only {have} HIP device(s) "
+              f"are visible on this node; refusing to report a smaller job as n_gpus={args.gpus}",
+              file=sys.stderr)
+        sys.exit(2)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL needs it here)
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def init_dist(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if n_gpus != world:
+        if rank == 0:
+            print(f"bench.py: error: --gpus {n_gpus} but the launcher started WORLD_SIZE={world} "
+                  f"rank(s); start {n_gpus} ranks (or run `python bench.py --gpus {n_gpus}` "
+                  f"without a launcher: it starts them itself)", file=sys.stderr)
+        sys.exit(2)
+    if local >= torch.cuda.device_count():
+        print(f"bench.py: error: rank {rank} (LOCAL_RANK {local}) has no HIP device "
+              f"({torch.cuda.device_count()} visible)", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
@@ -83,10 +139,7 @@ def init_dist(n_gpus):
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))
-    if n_gpus != world:
-        if rank == 0:
-            print(f"warning: --gpus {n_gpus} but WORLD_SIZE={world}; using {world}",
-                  file=sys.stderr)
+        world = dist.get_world_size()  # the ranks RCCL really brought up
     return rank, local, world
 
 
@@ -194,20 +247,126 @@ def load_traffic(workload, dtype, mode):
         return None
 
 
+def device_bandwidth(device, gib=1, reps=10):
+    """Device-to-device copy and fill bandwidth measured in THIS run (what a pure
+    streaming kernel sustains on this box): HIP events around `reps` 1 GiB copies."""
+    nel = gib * (1 << 30) // 4
+    src = torch.empty(nel, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    for _ in range(2):
+        dst.copy_(src)
+        dst.zero_()
+    torch.cuda.synchronize(device)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    for _ in range(reps):
+        dst.zero_()
+    e2.record()
+    torch.cuda.synchronize(device)
+    size = nel * 4
+    return {"copy_GBps": 2 * size * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9,
+            "fill_GBps": size * reps / (e1.elapsed_time(e2) * 1e-3) / 1e9}
+
+
+def reference_baselines(workload, dtype, wavelength, hy, S, budget_s, device, n=1_000_000):
+    """The reference ITSELF on this node, same lens, same ray shape, bounded sample:
+    `numpy` = Optiland's NumPy backend (`backend/numpy_backend.py`, fp64 always, see
+    SURVEY Appendix D) through `Optic.trace_generic` on the host; `torch` = its stock torch
+    backend (`backend/torch_backend.py:64-102`) on the same GPU, WITHOUT the drop-in.
+    Needs the staged package (oracle/stage_reference.py -> oracle/_ref/); None otherwise."""
+    try:
+        from tests import _live
+        if _live.reference_root() is None:
+            return None
+        be = _live.import_reference()
+    except Exception as exc:  # noqa: BLE001
+        print(f"reference baselines skipped: {exc!r}", file=sys.stderr)
+        return None
+    name = {"double_gauss": "DoubleGauss", "cooke": "CookeTriplet", "rc_asphere": "RCAsphere",
+            "zernike_fresnel": "ZernikeFresnelUnpolarized"}[workload]
+    rng = np.random.default_rng(0)
+    r, th = np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
+    px, py = r * np.cos(th), r * np.sin(th)
+    out = {}
+    try:
+        be.set_backend("numpy")
+        lens, w = _live.build_system(name)
+        hx_, hy_ = np.zeros(n), np.full(n, hy)
+        lens.trace_generic(hx_[:1000], hy_[:1000], px[:1000], py[:1000], w)  # warm caches
+        reps, t0 = 0, time.perf_counter()
+        while reps < 1 or (time.perf_counter() - t0 < budget_s and reps < 8):
+            lens.trace_generic(hx_, hy_, px, py, w)
+            reps += 1
+        dt = time.perf_counter() - t0
+        out["numpy"] = {
+            "value": n * S * reps / dt, "unit": "ray-surfaces/s", "cores": 1,
+            "kind": "reference",
+            "sample": f"{reps} x Optic.trace_generic({n} rays) of the reference's {name}, NumPy "
+                      f"backend fp64, {dt:.1f} s; elementwise NumPy kernels run on one core "
+                      f"({os.cpu_count()} logical host cores available)",
+        }
+    except Exception as exc:  # noqa: BLE001
+        out["numpy"] = None
+        print(f"NumPy-backend baseline failed: {exc!r}", file=sys.stderr)
+    try:
+        be.set_backend("torch")
+        be.set_device("cuda")
+        be.set_precision("float32" if dtype == "f32" else "float64")
+        tdt = torch.float32 if dtype == "f32" else torch.float64
+        lens, w = _live.build_system(name)
+        dev = [torch.as_tensor(a, dtype=tdt, device=device)
+               for a in (np.zeros(n), np.full(n, hy), px, py)]
+        with torch.no_grad():
+            lens.trace_generic(*dev, w)  # warm (allocator, material caches)
+            torch.cuda.synchronize(device)
+            reps, t0 = 0, time.perf_counter()
+            while reps < 1 or (time.perf_counter() - t0 < budget_s and reps < 8):
+                lens.trace_generic(*dev, w)
+                torch.cuda.synchronize(device)
+                reps += 1
+            dt = time.perf_counter() - t0
+        out["torch"] = {
+            "value": n * S * reps / dt, "unit": "ray-surfaces/s", "kind": "reference",
+            "sample": f"{reps} x Optic.trace_generic({n} rays, device tensors) of the "
+                      f"reference's {name} on its stock torch backend, device cuda, {dtype}, "
+                      f"no drop-in, {dt:.1f} s",
+        }
+    except Exception as exc:  # noqa: BLE001
+        out["torch"] = None
+        print(f"torch-backend baseline failed: {exc!r}", file=sys.stderr)
+    finally:
+        be.set_precision("float64")
+        be.set_device("cpu")
+        be.set_backend("numpy")
+    return out
+
+
 def main():
     args = parse_args()
+    self_launch(args)  # N > 1 without a launcher: re-exec under torchrun and exit
     rank, local, world = init_dist(args.gpus)
     device = torch.device("cuda", local)
     from optiland_amd import load_system
+    from optiland_amd.distributed import shard_bounds
     from optiland_amd.engine import HipSystem
 
+    strong = args.config == "c3"
+    if strong:  # BASELINE.json configs[2]: double Gauss, fp64, 1e8 rays over the ranks
+        args.workload, args.dtype = "double_gauss", "f64"
     sys_name, hy, desc, wavelength = WORKLOADS[args.workload]
     table = load_system(sys_name)
     wl = table.wavelength_index(wavelength)
     hip = HipSystem(table, device)
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     b = 4 if args.dtype == "f32" else 8
-    n = int(args.rays)
+    if strong:
+        lo, hi = shard_bounds(int(args.total_rays), world, rank)
+        n, job_rays = hi - lo, int(args.total_rays)
+    else:
+        n, job_rays = int(args.rays), int(args.rays) * world
     S = table.num_traced
     pol = table.uses_polarization
 
@@ -231,6 +390,7 @@ def main():
     import torch.distributed as dist
     have_pg = dist.is_available() and dist.is_initialized()
     exchange = args.exchange if (world > 1 or (args.force_exchange and have_pg)) else "none"
+    configured_exchange = exchange
     pending = [None, None]  # in-flight all-gathers (double-buffered)
     if exchange == "gather":
         # two buffer pairs: the all-gather of step k runs on RCCL's stream while step
@@ -316,39 +476,64 @@ def main():
                                                          hits[k].view(-1), async_op=True)
         return res
 
+    def timed(steps, evs=None):
+        """EXACTLY `steps` steps between barrier + synchronize brackets; max over ranks."""
+        torch.cuda.synchronize(device)
+        if have_pg:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(*(evs[k] if evs else ()))
+        for k in range(2):
+            w = pending[k]
+            for ww in (w if isinstance(w, tuple) else (w,)):
+                if ww is not None:
+                    ww.wait()
+            pending[k] = None
+        torch.cuda.synchronize(device)
+        if have_pg:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        if have_pg:
+            tt = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
     for _ in range(args.warmup):
         step()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
            for _ in range(args.steps)]
-    torch.cuda.synchronize(device)
-    if have_pg:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(*evs[k])
-    for w in pending:
-        for ww in (w if isinstance(w, tuple) else (w,)):
-            if ww is not None:
-                ww.wait()
-    torch.cuda.synchronize(device)
-    if have_pg:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(args.steps, evs)
     if exchange == "reduce" and not spot and args.steps:
         # fold the gathered slots of the last step: whole-job spot statistics
         tot = hip.reduce_spot_slots(all_slots[(step_no[0] - 1) & 1].view(-1, 8)).cpu().numpy()
         assert tot[0] > 0, "no ray reached the image plane"
-    if have_pg:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    exchange_info = None
+    if configured_exchange != "none" and args.steps:
+        # the same steps WITHOUT the image-plane exchange (outside the reported region):
+        # the difference is what the exchange costs per step, overlap included
+        exchange = "none"
+        bare = timed(args.steps)
+        exchange = configured_exchange
+        wire = (8 * 64 * 8 if configured_exchange == "reduce" else 3 * b * n) if not spot else 56
+        exchange_info = {
+            "kind": {"reduce": "async all-gather of the 4 KB spot-moment slot block (RCCL)",
+                     "gather": "literal RCCL all-gather of image-plane hits (x, y, i)"}[
+                         configured_exchange] if not spot else "all-reduce of 7 doubles",
+            "ms_per_step_with": elapsed / args.steps * 1e3,
+            "ms_per_step_without": bare / args.steps * 1e3,
+            "exchange_ms_per_step": (elapsed - bare) / args.steps * 1e3,
+            "bytes_per_rank_per_step": wire,
+        }
 
     kern_ms = float(np.mean([a.elapsed_time(bb) for a, bb in evs])) if args.steps else float("nan")
+    bw = device_bandwidth(device) if (rank == 0 and args.steps) else None
 
     if rank == 0:
-        total_rs = float(n) * S * world * args.steps
+        total_rs = float(job_rays) * S * args.steps
         value = total_rs / elapsed
         # algorithmic bytes per launch (SURVEY.md 8d): record-all reads 8 planes and
         # writes 8 planes for each of the S+1 surfaces; record-last reads 8, writes 8.
@@ -361,11 +546,16 @@ def main():
         if pol:
             alg_bytes += 2 * 9 * b * n  # PRT read-modify-write (SURVEY figure)
         # bytes this launch really has to move: with the zero-copy object row, row 0
-        # of the record block IS the input, so only S rows are written
+        # of the record block IS the input, so only S rows are written; the PRT of a fresh
+        # trace is write-only (starts from I in-kernel)
         moved_bytes = alg_bytes - (8 * b * n if alias else 0) - (9 * b * n if pol else 0)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        alg_GBps = alg_bytes / (kern_ms * 1e-3) / 1e9
+        moved_GBps = moved_bytes / (kern_ms * 1e-3) / 1e9
         traffic = load_traffic(args.workload, args.dtype,
                                args.mode + (":alias" if alias else ""))
+        traffic_rays = 10_000_000  # every committed PMC pass ran 1e7 rays per launch
+        if traffic is not None and n != traffic_rays:
+            traffic = traffic * n / traffic_rays
         out = {
             "metric": "ray-surface intersections/s",
             "value": value,
@@ -376,49 +566,78 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": f"{desc} ({S} traced surfaces incl. image plane), "
-                            f"{n:.3g} rays/GPU {args.dtype}, lambda={wavelength} um, "
+                            + (f"{job_rays:.3g} rays in total over {world} GPU(s) "
+                               f"({n:.4g} on rank 0) " if strong else f"{n:.3g} rays/GPU ")
+                            + f"{args.dtype}, lambda={wavelength} um, "
                             f"uniform-disc pupil, Hy={hy}, "
                             f"mode={MODE_NAMES[args.mode]}",
+                "baseline_config": "configs[2]" if strong else
+                                   ("configs[1]" if (args.workload, args.dtype, args.mode, n) ==
+                                    ("double_gauss", "f32", "record", 10_000_000) else None),
                 "rays_per_gpu": n,
+                "rays_total": job_rays,
                 "surfaces": S,
                 "mode": args.mode,
                 "object_row": ("zero-copy (rays generated into record row 0)" if alias
                                else "copied") if args.mode == "record" else None,
-                "exchange": exchange,
+                "exchange": configured_exchange,
                 "parallelism": f"ray-shard x{world}",
             },
+            "exchange": exchange_info,
             "roofline": {
                 "bound": "hbm",
                 "kernel": "spot_trace_kernel" if spot else "trace_kernel",
-                "achieved": achieved,
+                # the contract's `achieved` / `frac`: bytes this launch really moves (equal
+                # to the PMC traffic within 0.1 %) over the HIP-event kernel time
+                "achieved": moved_GBps,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": moved_GBps / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / "
+                                  "WRITE_SIZE passes of this command, committed (not re-measured "
+                                  "in this run" + (f"; scaled from {traffic_rays} to {n} rays)"
+                                                   if n != traffic_rays else ")"),
                 "kernel_ms": kern_ms,
-                "algorithmic_bytes": alg_bytes,
-                "bytes_per_ray_surface": alg_bytes / (float(n) * S),
                 "moved_bytes": moved_bytes,
-                "moved_GBps": moved_bytes / (kern_ms * 1e-3) / 1e9,
+                "algorithmic_bytes": alg_bytes,
+                "achieved_algorithmic": alg_GBps,
+                "frac_algorithmic": alg_GBps / HBM_PEAK_GBS,
+                "bytes_per_ray_surface": alg_bytes / (float(n) * S),
+                "device_copy_GBps": bw and bw["copy_GBps"],
+                "device_fill_GBps": bw and bw["fill_GBps"],
+                "frac_of_achievable": bw and moved_GBps / bw["copy_GBps"],
                 "note": ("fused spot kernel: only the two pupil planes touch HBM, the kernel is "
                          "vector-ALU bound by construction -- the HBM fraction is reported for "
                          "the contract, not as its limiter" if spot else
-                         "achieved = SURVEY 8d algorithmic bytes / kernel time; moved_bytes is "
-                         "what this launch has to transfer (zero-copy object row writes S rows "
-                         "instead of S+1) and is what the PMC traffic should equal"),
+                         "frac = moved_bytes / kernel time / 8 TB/s spec peak; "
+                         "frac_algorithmic credits SURVEY 8d's figure (the object row the ray "
+                         "generator wrote into the record block outside the timed region and, "
+                         "for polarised runs, the PRT read a fresh trace never does); "
+                         "frac_of_achievable = moved GB/s over a 1 GiB device-to-device copy "
+                         "(read + write) timed in this run"),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(table, hy, "last" if spot else args.mode,
-                                               args.cpu_seconds, wl)
+            port = cpu_baseline(table, hy, "last" if spot else args.mode, args.cpu_seconds, wl)
+            ref = None if args.no_ref_baselines else reference_baselines(
+                args.workload, args.dtype, wavelength, hy, S, args.ref_seconds, device)
+            if ref is not None and ref.get("numpy"):
+                # the north-star comparator: Optiland's own NumPy path on this node's host
+                out["cpu_baseline"] = dict(ref["numpy"], port=port)
+                out["gpu_baseline"] = {"torch": ref.get("torch")}
+            else:
+                out["cpu_baseline"] = port
+                out["gpu_baseline"] = None
         else:
             out["cpu_baseline"] = None
+            out["gpu_baseline"] = None
         print(json.dumps(out))
     hip.close()
     if have_pg:

@@ -84,14 +84,32 @@ def allreduce_max(value: torch.Tensor, group=None) -> torch.Tensor:
 def spot_statistics(engine, x, y, intensity, group=None) -> dict:
     """Centroid, RMS and geometric spot radius over ALL ranks' hits with i > 0.
 
-    Two tiny collectives (6 doubles, then 1 double) instead of gathering hits.
+    Two tiny collectives (6 doubles, then 1 double) instead of gathering hits.  A rank
+    whose shard is empty (`x is None` or zero length) contributes zero moments without
+    launching anything but still takes part in both collectives; when no ray at all
+    reaches the image plane the statistics are NaN (as `spot7_statistics` reports them).
     """
-    mom = allreduce_spot_moments(engine.spot_moments(x, y, intensity), group)
+    empty = x is None or x.numel() == 0
+    if empty:
+        mom = torch.zeros(6, dtype=torch.float64, device=engine.device)
+    else:
+        mom = engine.spot_moments(x, y, intensity)
+    mom = allreduce_spot_moments(mom, group)
     cnt = float(mom[0])
-    cx, cy = float(mom[1]) / cnt, float(mom[2]) / cnt
+    if cnt == 0:
+        cx = cy = float("nan")
+    else:
+        cx, cy = float(mom[1]) / cnt, float(mom[2]) / cnt
+    if empty or cnt == 0:  # max r^2 >= 0: zero is the neutral element
+        mx = torch.zeros(1, dtype=torch.float64, device=engine.device)
+    else:
+        mx = engine.spot_max_r2(x, y, intensity, cx, cy)
+    mx = allreduce_max(mx, group)
+    if cnt == 0:
+        return {"count": 0.0, "centroid": (cx, cy), "rms_radius": float("nan"),
+                "geometric_radius": float("nan")}
     # mean of (x-cx)^2 + (y-cy)^2 = E[x^2] + E[y^2] - cx^2 - cy^2
     rms2 = float(mom[3]) / cnt + float(mom[4]) / cnt - cx * cx - cy * cy
-    mx = allreduce_max(engine.spot_max_r2(x, y, intensity, cx, cy), group)
     return {"count": cnt, "centroid": (cx, cy), "rms_radius": max(rms2, 0.0) ** 0.5,
             "geometric_radius": float(mx[0]) ** 0.5}
 
@@ -148,11 +166,17 @@ class ShardedTracer:
         arrs = [t._dev(a) for a in (Hx, Hy, Px, Py)]
         n = max(a.numel() for a in arrs)
         lo, hi = shard_bounds(n, self.world, self.rank)
-        loc = [a if a.numel() == 1 else a[lo:hi] for a in arrs]
-        rays = t.trace_generic(*loc, wavelength)
-        out = {"rays": rays, "lo": lo, "hi": hi, "n_total": n}
+        out = {"rays": None, "lo": lo, "hi": hi, "n_total": n}
+        if hi > lo:
+            # one-element coordinates are broadcast over the GLOBAL list (n is the same on
+            # every rank because it is taken before slicing)
+            loc = [a.expand(hi - lo) if a.numel() == 1 else a[lo:hi] for a in arrs]
+            rays = out["rays"] = t.trace_generic(*loc, wavelength)
+            x, y, i = rays.x, rays.y, rays.i
+        else:  # more ranks than rays: nothing to launch, zero contribution below
+            x = y = i = torch.empty(0, dtype=t.dtype, device=t.device)
         if exchange == "gather":
-            out["hits"] = allgather_hits(rays.x, rays.y, rays.i, n, self.group)
+            out["hits"] = allgather_hits(x, y, i, n, self.group)
         elif exchange == "reduce":
-            out["spot"] = spot_statistics(t.engine, rays.x, rays.y, rays.i, self.group)
+            out["spot"] = spot_statistics(t.engine, x, y, i, self.group)
         return out

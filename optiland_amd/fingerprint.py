@@ -1,0 +1,163 @@
+"""A cheap change-detector for live reference objects, so that the drop-in does not
+re-pack an unchanged `Optic` on every trace.
+
+`packer.pack_optic` reads ~700 backend scalars per call; on the `cuda` device each one is
+a blocking device-to-host copy (2.8 ms per DoubleGauss pack on the MI355X box, three
+times the whole 1e7-ray trace).  The reference lets callers mutate anything at any time
+(`optic.set_radius`, optimisation variables, `surface.geometry.k = ...`), so the packed
+table can only be reused if NOTHING the packer reads has changed.  `optic_token()` walks
+exactly those objects and collects, without touching the device:
+
+  * python / numpy scalars and strings  -> their value
+  * torch tensors                       -> (id, `_version`): a new tensor object or any
+                                           in-place write changes the token
+  * small numpy arrays                  -> their bytes
+  * lists / tuples                      -> element tokens
+  * other objects                       -> (class name, id)  [identity]
+  * dicts                               -> ignored (the reference keeps caches in them)
+
+Tokens are compared with `==`; the objects whose ids appear in a token are kept alive
+next to it (`keep`) so that an id cannot be recycled while the token is cached.  What this
+cannot see is a write through `tensor.data` / `set_` (no `_version` bump) -- nothing in the
+reference does that; `OPTILAND_HIP_PACK_CACHE=0` turns the memo off.
+"""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+ENABLED = os.environ.get("OPTILAND_HIP_PACK_CACHE", "1") != "0"
+_SCALARS = (float, int, bool, str, type(None), complex)
+_BIG_ARRAY = 1 << 14
+
+# recorded per-trace arrays and back-pointers: never part of the optical prescription
+_SURFACE_SKIP = frozenset(("x", "y", "z", "u", "L", "M", "N", "intensity", "aoi", "opd",
+                           "_listeners", "parent_surface"))
+
+
+_Tensor = torch.Tensor
+_NoneType = type(None)
+
+
+def _tok(v, keep):
+    t = type(v)
+    if t is float or t is _Tensor or t is int or t is str or t is bool or t is _NoneType:
+        if t is _Tensor:
+            keep.append(v)
+            return ("T", id(v), v._version)
+        return v
+    if t is complex:
+        return v
+    if isinstance(v, _Tensor):  # Parameter and other subclasses
+        keep.append(v)
+        return ("T", id(v), v._version)
+    if isinstance(v, np.ndarray):
+        if v.size <= _BIG_ARRAY:
+            return ("A", v.shape, v.tobytes())
+        keep.append(v)
+        return ("A", id(v), v.shape)
+    if isinstance(v, np.generic):
+        return v.item()
+    if t is list or t is tuple:
+        return tuple([_tok(e, keep) for e in v])
+    if t is dict:
+        return None
+    keep.append(v)
+    return ("O", t.__name__, id(v))
+
+
+def _obj(o, keep, memo, skip=None):
+    """One level of `o.__dict__`: values tokenised in dict order, sub-objects by identity
+    (an added / removed attribute changes the length of the list)."""
+    if o is None:
+        return None
+    key = id(o)
+    hit = memo.get(key)
+    if hit is not None:
+        return hit
+    keep.append(o)
+    d = getattr(o, "__dict__", None)
+    if d is None:
+        out = _tok(o, keep)
+    elif skip is None:
+        out = (type(o).__name__, key, [_tok(v, keep) for v in d.values()])
+    else:
+        out = (type(o).__name__, key,
+               [(k, _tok(v, keep)) for k, v in d.items() if k not in skip])
+    memo[key] = out
+    return out
+
+
+def _cs(cs, keep, memo):
+    out = []
+    while cs is not None:
+        out.append(_obj(cs, keep, memo))
+        cs = getattr(cs, "reference_cs", None)
+    return tuple(out)
+
+
+def _aperture(ap, keep, memo):
+    if ap is None:
+        return None
+    a, b = getattr(ap, "a", None), getattr(ap, "b", None)
+    sub = tuple(_aperture(c, keep, memo) for c in (a, b)
+                if c is not None and hasattr(c, "__dict__"))
+    return (_obj(ap, keep, memo), sub)
+
+
+def _coating(c, keep, memo):
+    if c is None:
+        return None
+    return (_obj(c, keep, memo),
+            _obj(getattr(c, "jones", None) or getattr(c, "_jones", None), keep, memo))
+
+
+def _material(m, keep, memo):
+    if m is None:
+        return None
+    return (_obj(m, keep, memo), type(getattr(m, "propagation_model", None)).__name__)
+
+
+def surface_token(s, keep, memo):
+    geom = s.geometry
+    im = getattr(s, "interaction_model", None)
+    return (
+        type(s).__name__, id(s),
+        _obj(geom, keep, memo), _cs(getattr(geom, "cs", None), keep, memo),
+        _obj(getattr(geom, "zernike", None), keep, memo),
+        _material(getattr(s, "material_pre", None), keep, memo),
+        _material(getattr(s, "material_post", None), keep, memo),
+        _aperture(getattr(s, "aperture", None), keep, memo),
+        _obj(im, keep, memo, _SURFACE_SKIP),
+        _coating(getattr(im, "coating", None), keep, memo),
+        _tok(getattr(s, "thickness", None), keep), bool(getattr(s, "is_stop", False)),
+    )
+
+
+def surfaces_token(surfaces, wavelength):
+    """Token of a SurfaceGroup's surface list (what `packer.pack_surfaces` reads)."""
+    keep, memo = [], {}
+    return (float(wavelength), tuple(surface_token(s, keep, memo) for s in surfaces)), keep
+
+
+def optic_token(optic, wavelength):
+    """Token of everything `packer.pack_optic(optic, [wavelength])` reads."""
+    keep, memo = [], {}
+    fields = optic.fields
+    pol = getattr(optic, "polarization", "ignore")  # "ignore" | PolarizationState
+    tok = (
+        float(wavelength),
+        tuple(surface_token(s, keep, memo) for s in optic.surfaces.surfaces),
+        _obj(optic.aperture, keep, memo),
+        tuple(_obj(f, keep, memo) for f in fields.fields),
+        type(getattr(fields, "field_definition", None)).__name__,
+        tuple(_obj(w, keep, memo) for w in optic.wavelengths.wavelengths),
+        _obj(getattr(optic, "apodization", None), keep, memo),
+        pol if isinstance(pol, str) else _obj(pol, keep, memo),
+        bool(getattr(optic, "obj_space_telecentric", False)),
+        getattr(optic.ray_tracer, "ray_aiming_config", {}).get("mode", "paraxial"),
+    )
+    return tok, keep

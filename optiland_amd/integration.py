@@ -35,12 +35,32 @@ import collections
 import numpy as np
 import torch
 
+from . import fingerprint as _fp
 from . import tracer as _tracer
-from . import _capi
 from .packer import UnsupportedSystem, pack_optic, pack_surfaces
 from .rays import _state_dict, prt_to_complex
 
 BACKEND_NAME = "hip"
+
+
+def _host_or_device(v):
+    """Coordinates as the device front end takes them: torch tensors untouched (device
+    tensors stay on the device), python / numpy scalars as floats, anything else as a
+    float64 numpy array."""
+    if isinstance(v, torch.Tensor):
+        return v.detach()
+    if isinstance(v, (int, float)):
+        return float(v)
+    a = np.asarray(v, dtype=np.float64)
+    return float(a) if a.ndim == 0 else a
+
+
+class _PupilPoints:
+    """A caller's distribution object (reference `BaseDistribution`: backend arrays in
+    `.x` / `.y`) as `HipRayTracer.trace` reads it."""
+
+    def __init__(self, dist):
+        self.x, self.y = _host_or_device(dist.x), _host_or_device(dist.y)
 
 
 def register_backend(name: str = BACKEND_NAME):
@@ -70,12 +90,34 @@ def register_backend(name: str = BACKEND_NAME):
 def _table_key(table):
     return (table.surfaces.tobytes(), table.coeffs.tobytes(), table.optics.tobytes(),
             table.wavelengths.tobytes(), repr(sorted(table.raygen.items())),
-            repr(table.fields), repr(table.polarization))
+            repr(table.fields), repr(table.polarization), float(table.last_thickness))
 
 
 _TRACER_CLASS = None
 _ORIGINALS = {}
 _MAX_ENGINES = 8  # device tables kept per tracer (a few kB each)
+_MAX_MEMO = 32    # (wavelength -> change-detector token) entries kept per tracer
+_EMPTY = {}       # (dtype, device) -> shared empty tensor for Surface.u / Surface.aoi
+
+
+def _empty(dtype, device):
+    key = (dtype, str(device))
+    t = _EMPTY.get(key)
+    if t is None:
+        t = _EMPTY[key] = torch.empty(0, dtype=dtype, device=device)
+    return t
+
+
+def _bind_surfaces(surfaces, res):
+    """Every reference `Surface` gets its recorded vectors (standard_surface.py:260-274) as
+    zero-copy views of the record block: three tensor ops per surface instead of the
+    reference's `reset()` (eleven fresh device tensors) + eight assignments."""
+    n = res.n
+    rows = res.record[: res.last - res.first + 1, :, :n].unbind(0)
+    empty = _empty(res.record.dtype, res.record.device)
+    for surf, row in zip(surfaces[res.first: res.last + 1], rows):
+        surf.x, surf.y, surf.z, surf.L, surf.M, surf.N, surf.intensity, surf.opd = row.unbind(0)
+        surf.u = surf.aoi = empty  # Surface.reset(): only paraxial traces fill these
 
 
 def _make_tracer_class():
@@ -83,25 +125,50 @@ def _make_tracer_class():
     if _TRACER_CLASS is not None:
         return _TRACER_CLASS
     import optiland.backend as be
-    from optiland.distribution import create_distribution
     from optiland.raytrace.real_ray_tracer import RealRayTracer
     from optiland.rays import PolarizedRays as RefPolarizedRays
     from optiland.rays import RealRays as RefRealRays
 
     class OptilandHipRayTracer(RealRayTracer):
-        """`RealRayTracer` whose surface loop runs in one HIP kernel."""
+        """`RealRayTracer` whose ray generation + surface loop run in HIP kernels.
+
+        Device-resident: coordinates that arrive as device tensors are used as they are
+        and range-checked inside the ray-generation kernel (`OL_RAYGEN_CHECK_*`), the rays
+        are generated straight into row 0 of the record block, the returned rays and
+        every `Surface`'s recorded arrays are views of that block.  The host does a
+        change check of the optic (`fingerprint.optic_token`, no device access), two
+        launches and ONE status read-back per call."""
 
         def __init__(self, optic, device=None, force=False):
             super().__init__(optic)
             self._hip_device = device
             self._hip_force = force  # tests: intercept regardless of backend/device
-            # packed-table fingerprint -> (engine, table): analyses alternate between the
-            # optic's wavelengths call by call, so the last few device tables stay alive
-            # instead of being re-created for every (field, wavelength) trace
+            # packed-table fingerprint -> (engine, table, {dtype: HipRayTracer}): analyses
+            # alternate between the optic's wavelengths call by call, so the last few
+            # device tables stay alive instead of being re-created for every trace
             self._hip_engines = collections.OrderedDict()
+            # wavelength -> (token, kept objects, table key | UnsupportedSystem)
+            self._hip_memo = collections.OrderedDict()
             self._hip_engine = None  # most recently used (introspection)
             self._hip_table = None
+            self.pack_count = 0      # packs really performed (introspection for tests)
             self.last_path = None  # "hip" | "reference" (introspection for tests)
+
+        def __deepcopy__(self, memo):
+            # the reference deep-copies optics (tolerancing, optimisation): the copy starts
+            # with empty device caches instead of clones of handles, tokens and the last
+            # record block (gigabytes at 1e7 rays)
+            import copy
+            new = type(self).__new__(type(self))
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                if k in ("_hip_engines", "_hip_memo"):
+                    new.__dict__[k] = collections.OrderedDict()
+                elif k in ("_hip_engine", "_hip_table"):
+                    new.__dict__[k] = None
+                else:
+                    new.__dict__[k] = copy.deepcopy(v, memo)
+            return new
 
         # ---------------------------------------------------------- eligibility
         def _eligible(self) -> bool:
@@ -119,176 +186,140 @@ def _make_tracer_class():
                 return be._backends[be.get_backend()]._config.get_precision()
             return torch.float64
 
-        def _engine_for(self, wavelength):
+        def invalidate(self):
+            """Forget the change-detector memo (the next trace re-packs the optic)."""
+            self._hip_memo.clear()
+
+        def _entry_for(self, wavelength):
+            """(engine, table, fronts) for the optic AS IT IS NOW at `wavelength`."""
             w = float(wavelength.item()) if hasattr(wavelength, "item") else float(wavelength)
-            table = pack_optic(self.optic, wavelengths=[w])
+            tok = None
+            if _fp.ENABLED:
+                tok, _keep = _fp.optic_token(self.optic, w)
+                memo = self._hip_memo.get(w)
+                if memo is not None and memo[0] == tok:
+                    key = memo[2]
+                    if isinstance(key, UnsupportedSystem):
+                        raise key
+                    hit = self._hip_engines.get(key)
+                    if hit is not None:
+                        self._hip_engines.move_to_end(key)
+                        self._hip_engine, self._hip_table = hit[0], hit[1]
+                        return hit
+            self.pack_count += 1
+            try:
+                table = pack_optic(self.optic, wavelengths=[w])
+            except UnsupportedSystem as exc:
+                self._remember(w, exc)
+                raise
             key = _table_key(table)
             hit = self._hip_engines.get(key)
             if hit is None:
-                hit = (_tracer._make_engine(table, self._hip_device), table)
+                hit = (_tracer._make_engine(table, self._hip_device), table, {})
                 self._hip_engines[key] = hit
                 while len(self._hip_engines) > _MAX_ENGINES:  # evict least recently used
-                    _, (old, _t) = self._hip_engines.popitem(last=False)
+                    _, (old, _t, _f) = self._hip_engines.popitem(last=False)
                     if hasattr(old, "close"):
                         old.close()
             else:
                 self._hip_engines.move_to_end(key)
-            self._hip_engine, self._hip_table = hit
+            self._remember(w, key)
+            self._hip_engine, self._hip_table = hit[0], hit[1]
             return hit
 
+        def _remember(self, w, key):
+            if not _fp.ENABLED:
+                return
+            # token taken AFTER the pack: whatever the pack itself touched (lazy caches of
+            # the reference objects) is then part of the steady state
+            tok, keep = _fp.optic_token(self.optic, w)
+            self._hip_memo[w] = (tok, keep, key)
+            self._hip_memo.move_to_end(w)
+            while len(self._hip_memo) > _MAX_MEMO:
+                self._hip_memo.popitem(last=False)
+
+        def _front_for(self, wavelength):
+            """The stand-alone device tracer (`tracer.HipRayTracer`) on the current table in
+            the backend's precision: it owns the whole device-side call sequence."""
+            eng, table, fronts = self._entry_for(wavelength)
+            dtype = self._dtype()
+            front = fronts.get(dtype)
+            if front is None:
+                front = fronts[dtype] = _tracer.HipRayTracer(table, dtype=dtype, engine=eng)
+            front.ray_aiming_config = self.ray_aiming_config
+            return front, table
+
+        def _engine_for(self, wavelength):  # kept for callers / tests of round 1
+            hit = self._entry_for(wavelength)
+            return hit[0], hit[1]
+
         # ---------------------------------------------------------------- trace
-        @staticmethod
-        def _scalar(v):
-            """float(v) for scalar-like field coordinates (python / numpy / 0-d or
-            one-element backend values), else None."""
-            try:
-                a = np.asarray(be.to_numpy(v), dtype=np.float64)
-            except Exception:
-                return None
-            return float(a.reshape(-1)[0]) if a.size == 1 else None
-
-        def _hip_trace(self, Hx, Hy, Px, Py, wavelength, update_intensity, prescale=False):
-            """Hx, Hy: two floats (ONE field point: launch-uniform scalars, no field or
-            vignetting planes are built) or per-ray arrays; Px, Py: per-ray arrays.
-            prescale: trace_generic's (1 - v) pre-scaling of the pupil, done in-kernel."""
-            eng, table = self._engine_for(wavelength)
-            dtype, dev = self._dtype(), eng.device
-            as_dev = lambda a: torch.as_tensor(  # noqa: E731
-                np.array(be.to_numpy(a), dtype=np.float64) if not isinstance(a, torch.Tensor) else a,
-                dtype=dtype, device=dev).reshape(-1).contiguous()
-            uniform = isinstance(Hx, float) and isinstance(Hy, float)
-            # the rays are generated (or copied) straight into row 0 of the record
-            # block: the object surface only records its input (zero-copy object row)
-            if table.raygen:
-                px, py = as_dev(Px), as_dev(Py)
-                n = int(px.numel())
-                record = eng.alloc_record(n, dtype)
-                rays = eng.row0_planes(record, n)
-                vxf, vyf = self.optic.fields.get_vig_factor(Hx, Hy)
-                flags = _capi.RAYGEN_PRESCALE_PUPIL if prescale else 0
-                if uniform:
-                    vx = 1.0 - float(np.asarray(be.to_numpy(vxf), dtype=np.float64).reshape(-1)[0])
-                    vy = 1.0 - float(np.asarray(be.to_numpy(vyf), dtype=np.float64).reshape(-1)[0])
-                    eng.generate_rays(Hx, Hy, px, py, vx, vy, out=rays, flags=flags)
-                else:
-                    hx, hy = as_dev(Hx), as_dev(Hy)
-                    vx = as_dev(1 - np.asarray(be.to_numpy(vxf), dtype=np.float64) * np.ones(n))
-                    vy = as_dev(1 - np.asarray(be.to_numpy(vyf), dtype=np.float64) * np.ones(n))
-                    eng.generate_rays(hx, hy, px, py, vx, vy, out=rays, flags=flags)
-            else:  # aiming/field type the device generator does not cover
-                if uniform:
-                    Hx = np.full(np.size(be.to_numpy(Px)), Hx)
-                    Hy = np.full(np.size(be.to_numpy(Px)), Hy)
-                if prescale:  # real_ray_tracer.py:134-137
-                    vxf, vyf = self.optic.fields.get_vig_factor(Hx, Hy)
-                    Px = np.asarray(be.to_numpy(Px), dtype=np.float64) * \
-                        (1 - np.asarray(be.to_numpy(vxf), dtype=np.float64))
-                    Py = np.asarray(be.to_numpy(Py), dtype=np.float64) * \
-                        (1 - np.asarray(be.to_numpy(vyf), dtype=np.float64))
-                r = self.ray_generator.generate_rays(Hx, Hy, Px, Py, wavelength)
-                src = [as_dev(getattr(r, k)) for k in ("x", "y", "z", "L", "M", "N", "i")]
-                n = int(src[0].numel())
-                record = eng.alloc_record(n, dtype)
-                rays = eng.row0_planes(record, n)
-                for dst, s_ in zip(rays, src):
-                    dst.copy_(s_)
-                rays[7].zero_()
-            polarized = self.optic.polarization != "ignore"
-            if not polarized and self.optic.surfaces.uses_polarization:
-                raise ValueError("Polarization must be set when surfaces have "
-                                 "polarization-dependent coatings.")
-            prt = k_init = i0 = None
-            if polarized:
-                prt = torch.empty((18 if table.needs_complex_prt else 9, n), dtype=dtype,
-                                  device=dev)  # written by the kernel (starts from I)
-                k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
-                i0 = rays[6].clone()
-            res = eng.trace(rays, 0, record=record, prt=prt, prt_identity=prt is not None)
-
-            # every Surface gets its recorded vectors (views, no copies)
-            for s, surf in enumerate(self.optic.surfaces):
-                surf.reset()
-                surf.x, surf.y, surf.z = res.row(s, 0), res.row(s, 1), res.row(s, 2)
-                surf.L, surf.M, surf.N = res.row(s, 3), res.row(s, 4), res.row(s, 5)
-                surf.intensity, surf.opd = res.row(s, 6), res.row(s, 7)
-
-            last = res.last
-            w = torch.full((n,), float(wavelength), dtype=dtype, device=dev)
-            fin = [res.row(last, k) for k in range(8)]
+        def _finish(self, front, table, mine, wavelength, update_intensity):
+            """Hand the device results over in the reference's own classes: the returned
+            `RealRays` / `PolarizedRays` and every `Surface`'s recorded arrays."""
+            res = front.surfaces._res
+            _bind_surfaces(self.optic.surfaces.surfaces, res)
+            n, dtype, dev = res.n, res.record.dtype, res.record.device
+            polarized = table.polarization is not None
             cls = RefPolarizedRays if polarized else RefRealRays
             out = cls.__new__(cls)  # fill attributes directly: no be.* round trip
-            out.x, out.y, out.z, out.L, out.M, out.N = fin[:6]
-            out.i, out.opd, out.w = fin[6], fin[7], w
+            out.x, out.y, out.z, out.L, out.M, out.N, out.i, out.opd = mine.planes()
+            out.w = torch.full((n,), float(wavelength), dtype=dtype, device=dev)
             out.is_normalized = True
-            if last > 0:
-                out.L0, out.M0, out.N0 = res.row(last - 1, 3), res.row(last - 1, 4), \
-                    res.row(last - 1, 5)
-            else:
-                out.L0 = out.M0 = out.N0 = None
+            out.L0, out.M0, out.N0 = mine.L0, mine.M0, mine.N0
             if polarized:
-                out.p = prt_to_complex(prt)
-                out._i0, out._L0, out._M0, out._N0 = i0, *k_init
-                if update_intensity:  # real_ray_tracer.py:112-113
-                    out.i = eng.polarized_intensity(prt, k_init, i0,
-                                                    _state_dict(self.optic.polarization_state))
-            # final propagation by the image thickness (0 in every sample):
-            # real_ray_tracer.py:106-110 -- identity for t == 0
+                out.p = prt_to_complex(mine._prt)
+                out._i0, out._L0, out._M0, out._N0 = mine._i0, mine._L0, mine._M0, mine._N0
+            # final propagation by the image thickness (0 in every sample; identity then):
+            # real_ray_tracer.py:104-110, BEFORE the polarised epilogue (:112-113)
             thick = float(table.last_thickness)
             if thick != 0.0:
                 last_surface = self.optic.surfaces[-1]
                 last_surface.material_post.propagation_model.propagate(out, thick)
+            if polarized and update_intensity:
+                out.i = front.engine.polarized_intensity(
+                    mine._prt, (mine._L0, mine._M0, mine._N0), mine._i0,
+                    _state_dict(self.optic.polarization_state))
             return out
 
         def trace(self, Hx, Hy, wavelength, num_rays=100, distribution="hexapolar"):
             if not self._eligible():
                 self.last_path = "reference"
                 return _ORIGINALS["trace"](self, Hx, Hy, wavelength, num_rays, distribution)
-            self._validate_normalized_coordinates(Hx, Hy, "field")
             try:
-                if isinstance(distribution, str):
-                    distribution = create_distribution(distribution)
-                    distribution.generate_points(num_rays)
-                Px, Py = be.to_numpy(distribution.x), be.to_numpy(distribution.y)
-                sx, sy = self._scalar(Hx), self._scalar(Hy)
-                if sx is not None and sy is not None:  # one field point
-                    out = self._hip_trace(sx, sy, Px, Py, wavelength, update_intensity=True)
-                else:
-                    Hxa = np.atleast_1d(np.asarray(be.to_numpy(Hx), dtype=np.float64))
-                    Hya = np.atleast_1d(np.asarray(be.to_numpy(Hy), dtype=np.float64))
-                    nf, npup = Hxa.size, Px.size
-                    out = self._hip_trace(np.repeat(Hxa, npup), np.repeat(Hya, npup),
-                                          np.tile(Px, nf), np.tile(Py, nf), wavelength,
-                                          update_intensity=True)
+                front, table = self._front_for(wavelength)
             except UnsupportedSystem:
                 self.last_path = "reference"
                 return _ORIGINALS["trace"](self, Hx, Hy, wavelength, num_rays, distribution)
+            if not table.raygen:
+                # aiming mode / field type outside the device generator: the reference
+                # builds the rays, its surface loop enters the HIP path through the
+                # SurfaceGroup.trace seam (when enable() / install() patched it)
+                self.last_path = "reference-rays"
+                return _ORIGINALS["trace"](self, Hx, Hy, wavelength, num_rays, distribution)
+            if not isinstance(distribution, str):
+                distribution = _PupilPoints(distribution)
+            mine = front.trace(_host_or_device(Hx), _host_or_device(Hy), wavelength, num_rays,
+                               distribution, update_intensity=False)
             self.last_path = "hip"
-            return out
+            return self._finish(front, table, mine, wavelength, update_intensity=True)
 
         def trace_generic(self, Hx, Hy, Px, Py, wavelength):
             if not self._eligible():
                 self.last_path = "reference"
                 return _ORIGINALS["trace_generic"](self, Hx, Hy, Px, Py, wavelength)
-            self._validate_normalized_coordinates(Hx, Hy, "field")
-            self._validate_normalized_coordinates(Px, Py, "pupil")
             try:
-                sx, sy = self._scalar(Hx), self._scalar(Hy)
-                arrs = [np.atleast_1d(np.asarray(be.to_numpy(a), dtype=np.float64))
-                        for a in (Hx, Hy, Px, Py)]
-                n = max(a.size for a in arrs)
-                Hxa, Hya, Pxa, Pya = (np.broadcast_to(a, (n,)) if a.size == 1 else a
-                                      for a in arrs)
-                if sx is not None and sy is not None:
-                    out = self._hip_trace(sx, sy, Pxa, Pya, wavelength, update_intensity=False,
-                                          prescale=True)
-                else:
-                    out = self._hip_trace(Hxa, Hya, Pxa, Pya, wavelength,
-                                          update_intensity=False, prescale=True)
+                front, table = self._front_for(wavelength)
             except UnsupportedSystem:
                 self.last_path = "reference"
                 return _ORIGINALS["trace_generic"](self, Hx, Hy, Px, Py, wavelength)
+            if not table.raygen:
+                self.last_path = "reference-rays"
+                return _ORIGINALS["trace_generic"](self, Hx, Hy, Px, Py, wavelength)
+            mine = front.trace_generic(*(_host_or_device(v) for v in (Hx, Hy, Px, Py)),
+                                       wavelength)
             self.last_path = "hip"
-            return out
+            return self._finish(front, table, mine, wavelength, update_intensity=False)
 
     # the reference's own implementations, captured before enable() can patch them
     _ORIGINALS["trace"] = RealRayTracer.trace
@@ -337,6 +368,27 @@ def _sg_engine(group, table, dev):
     else:
         cache.move_to_end(key)
     return hit
+
+
+def _sg_table(group, wavelength):
+    """`pack_surfaces(group.surfaces, tolerate=True)`, memoised on the group against the
+    change-detector token of its surfaces (fingerprint.py): a caller that pushes bundle
+    after bundle through an unchanged SurfaceGroup packs it once.  None = the fused path
+    refuses the whole group."""
+    tok = None
+    if _fp.ENABLED:
+        tok, _keep = _fp.surfaces_token(group.surfaces, wavelength)
+        memo = group.__dict__.get("_hip_sg_memo")
+        if memo is not None and memo[0] == tok:
+            return memo[2]
+    try:
+        table = pack_surfaces(group.surfaces, [wavelength], name="SurfaceGroup", tolerate=True)
+    except UnsupportedSystem:
+        table = None
+    if tok is not None:
+        tok, keep = _fp.surfaces_token(group.surfaces, wavelength)  # after the pack
+        group.__dict__["_hip_sg_memo"] = (tok, keep, table)
+    return table
 
 
 def _sg_planes(rays, force: bool):
@@ -414,9 +466,8 @@ def _hip_surface_group_trace(group, rays, skip):
     if not (lo == hi and lo > 0.0):
         return None  # per-ray wavelengths: per-ray n(w), not a launch constant
     polarized = type(rays) is RefPolarizedRays
-    try:
-        table = pack_surfaces(group.surfaces, [lo], name="SurfaceGroup", tolerate=True)
-    except UnsupportedSystem:
+    table = _sg_table(group, lo)
+    if table is None:
         return None
     foreign = set(table.unsupported)
     if len(foreign) >= n_s - skip - (1 if skip == 0 else 0):
@@ -540,5 +591,5 @@ def uninstall(optic):
     cfg = dict(optic.ray_tracer.ray_aiming_config)
     optic.ray_tracer = RealRayTracer(optic)
     optic.ray_tracer.ray_aiming_config = cfg
-    for k in ("trace", "_hip_force", "_hip_device"):
+    for k in ("trace", "_hip_force", "_hip_device", "_hip_sg_memo"):
         optic.surfaces.__dict__.pop(k, None)

@@ -170,22 +170,44 @@ class HipRayTracer:
         return self._dev(distribution.x), self._dev(distribution.y)
 
     # -------------------------------------------------------------------- trace
+    def _alloc_state(self, n):
+        """(record, ray planes): in record-all mode the rays live in row 0 of the record
+        block -- the object surface only records its input, so the trace need not copy
+        that row (zero-copy object row)."""
+        eng = self.engine
+        if self.record_all:
+            record = eng.alloc_record(n, self.dtype)
+            return record, eng.row0_planes(record, n)
+        buf = torch.empty((8, max(n, 1)), dtype=self.dtype, device=self.device)
+        return False, [buf[k, :n] for k in range(8)]
+
     def _run(self, hx, hy, px, py, vig, wavelength, update_intensity, flags):
         """hx, hy: floats (launch-uniform field) or device planes; px, py: device planes;
         vig: (1 - vx, 1 - vy) as floats or planes; flags: OL_RAYGEN_*."""
+        n = int(px.numel())
+        record, rays = self._alloc_state(n)
+        self.engine.generate_rays(hx, hy, px, py, vig[0], vig[1], out=rays, flags=flags)
+        # the generator zeroes the status word only when it also writes range bits into it
+        checked = bool(flags & (_capi.RAYGEN_CHECK_FIELD | _capi.RAYGEN_CHECK_PUPIL))
+        return self._launch(rays, record, wavelength, update_intensity, zero_status=not checked)
+
+    def trace_rays(self, planes, wavelength, update_intensity=False):
+        """Trace rays the CALLER generated (x, y, z, L, M, N, i [, opd] arrays of one
+        length; the reference's own RayGenerator for aiming modes / field types the
+        device generator does not cover)."""
+        src = [self._dev(p) for p in planes]
+        n = int(src[0].numel())
+        record, rays = self._alloc_state(n)
+        for dst, s_ in zip(rays, src):
+            dst.copy_(s_)
+        if len(src) < 8:
+            rays[7].zero_()
+        return self._launch(rays, record, wavelength, update_intensity, zero_status=True)
+
+    def _launch(self, rays, record, wavelength, update_intensity, zero_status):
         wl, w = self._wavelength_index(wavelength)
         eng = self.engine
-        n = int(px.numel())
-        if self.record_all:
-            # rays are generated straight into row 0 of the record block: the object
-            # surface only records its input, so the trace need not copy that row
-            record = eng.alloc_record(n, self.dtype)
-            rays = eng.row0_planes(record, n)
-        else:
-            record = False
-            buf = torch.empty((8, max(n, 1)), dtype=self.dtype, device=self.device)
-            rays = [buf[k, :n] for k in range(8)]
-        eng.generate_rays(hx, hy, px, py, vig[0], vig[1], out=rays, flags=flags)
+        n = int(rays[0].numel())
         polarized = self.table.polarization is not None
         if not polarized and self.table.uses_polarization:
             # rays/ray_generator.py:89-94
@@ -199,7 +221,7 @@ class HipRayTracer:
             k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
             i0 = rays[6].clone()
         deferred = hasattr(eng, "_status")
-        kw = {"defer_status": True, "zero_status": False} if deferred else {}
+        kw = {"defer_status": True, "zero_status": zero_status} if deferred else {}
         res = eng.trace(rays, wl, record=record, prt=prt, prt_identity=prt is not None, **kw)
         self._finish_checks(eng)
         self.surfaces._bind(res)
@@ -226,21 +248,23 @@ class HipRayTracer:
             out.L0, out.M0, out.N0 = L0, M0, N0
         return out
 
-    def trace(self, Hx, Hy, wavelength, num_rays=100, distribution="hexapolar"):
-        """real_ray_tracer.py:58-118: every field point x every pupil point."""
+    def trace(self, Hx, Hy, wavelength, num_rays=100, distribution="hexapolar",
+              update_intensity: bool = True):
+        """real_ray_tracer.py:58-118: every field point x every pupil point.
+        (`update_intensity=False`: the caller applies the polarised epilogue itself.)"""
         self._validate_normalized_coordinates(Hx, Hy, "field")
         Px, Py = self._pupil_planes(distribution, num_rays)
         sx, sy = self._as_scalar(Hx), self._as_scalar(Hy)
         if sx is not None and sy is not None:  # one field point: launch-uniform scalars
             return self._run(sx, sy, Px, Py, self._vig_scalar(sx, sy), wavelength,
-                             update_intensity=True, flags=0)
+                             update_intensity=update_intensity, flags=0)
         Hx, Hy = self._dev(Hx), self._dev(Hy)
         nf, npup = Hx.numel(), Px.numel()
         hx, hy = Hx.repeat_interleave(npup), Hy.repeat_interleave(npup)
         px, py = Px.repeat(nf), Py.repeat(nf)
         vxf, vyf = self._vig_factor(hx, hy)
         vig = (None, None) if vxf is None else (1 - vxf, 1 - vyf)
-        return self._run(hx, hy, px, py, vig, wavelength, update_intensity=True,
+        return self._run(hx, hy, px, py, vig, wavelength, update_intensity=update_intensity,
                          flags=_capi.RAYGEN_CHECK_FIELD)
 
     def reset_status(self):

@@ -112,3 +112,56 @@ def test_two_rank_shards_equal_single_process():
         np.testing.assert_allclose(spot["centroid"], (cx, cy), rtol=1e-12, atol=1e-13)
         np.testing.assert_allclose(spot["rms_radius"], rms, rtol=1e-6)
         np.testing.assert_allclose(spot["geometric_radius"], geo, rtol=1e-10)
+
+
+def _edge_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import optiland_amd.tracer as tr
+        from optiland_amd.distributed import ShardedTracer, spot_statistics
+        from tests._fake_engine import OracleEngine
+        from tests._util import load_case
+        tr._make_engine = lambda table, device: OracleEngine(table, device)
+        table, data = load_case("double_gauss_multifield")
+        t = tr.HipRayTracer(table, dtype=torch.float64)
+        st = ShardedTracer(t)
+        # ONE ray over two ranks: rank 1's shard is empty (used to launch a
+        # zero-length trace and disagree on n)
+        one = [data[k][:1] for k in ("Hx", "Hy", "Px", "Py")]
+        r = st.trace_generic(*one, 0.4861, exchange="reduce")
+        g = st.trace_generic(*one, 0.4861, exchange="gather")
+        # scalar field broadcast over a 3-ray pupil list
+        b = st.trace_generic(0.0, 0.7, data["Px"][:3], data["Py"][:3], 0.4861, exchange="gather")
+        # nothing reaches the image plane anywhere: NaN statistics, no ZeroDivisionError
+        z = torch.zeros(4, dtype=torch.float64)
+        dead = spot_statistics(t.engine, z, z, z)
+        q.put((rank, r["lo"], r["hi"], r["rays"] is None, r["spot"], g["hits"][0].numpy(),
+               b["hits"][0].numpy(), b["n_total"], dead))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_empty_shards_and_dead_bundles():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_edge_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert (results[0][1], results[0][2], results[0][3]) == (0, 1, False)
+    assert (results[1][1], results[1][2], results[1][3]) == (1, 1, True)
+    for res in results:
+        assert res[4]["count"] == 1.0 and np.isfinite(res[4]["rms_radius"])
+        assert res[5].shape == (1,) and res[6].shape == (3,) and res[7] == 3
+        assert res[8]["count"] == 0.0 and np.isnan(res[8]["rms_radius"])
+        assert np.isnan(res[8]["geometric_radius"])
+    assert np.array_equal(results[0][5], results[1][5])
+    assert np.array_equal(results[0][6], results[1][6])

@@ -1,0 +1,198 @@
+"""The change detector that spares the drop-in a re-pack per trace
+(optiland_amd/fingerprint.py): it must (a) be STABLE -- an untouched optic is packed
+once, however often it is traced -- and (b) see EVERY mutation the reference's public
+API (and plain attribute writes, in-place tensor writes included) can make to anything
+the packer reads.  (b) is checked differentially: after each mutation the memoised
+drop-in must return exactly what a drop-in with the memo switched off returns.
+
+CPU, live reference (build container or staged oracle/_ref), oracle-backed engine.
+"""
+
+import importlib
+import inspect
+
+import numpy as np
+import pytest
+
+from tests import _live
+
+pytestmark = pytest.mark.skipif(_live.reference_root() is None,
+                                reason="reference package not present")
+
+
+@pytest.fixture()
+def be(monkeypatch):
+    import optiland_amd.tracer as tr
+    from tests._fake_engine import OracleEngine
+    monkeypatch.setattr(tr, "_make_engine", lambda table, device: OracleEngine(table, device))
+    be = _live.import_reference()
+    be.set_backend("torch")
+    be.set_device("cpu")
+    be.set_precision("float64")
+    yield be
+    be.set_backend("numpy")
+
+
+def _snapshot(be, lens, w):
+    r = lens.trace(0.0, 0.6, w, 4, "hexapolar")
+    out = [np.asarray(be.to_numpy(getattr(r, k)), dtype=np.float64)
+           for k in ("x", "y", "z", "L", "M", "N", "i", "opd")]
+    g = lens.trace_generic(0.0, 1.0, 0.3, -0.2, w)
+    out += [np.asarray(be.to_numpy(getattr(g, k)), dtype=np.float64) for k in ("x", "y", "i")]
+    out.append(np.asarray(be.to_numpy(lens.surfaces.y), dtype=np.float64))
+    if hasattr(r, "p"):
+        out.append(np.asarray(be.to_numpy(r.p)).real)
+    return out
+
+
+def _sample_classes():
+    from optiland import optic as optic_mod
+    for m in ("eyepieces", "infrared", "lithography", "microscopes", "miscellaneous",
+              "objectives", "simple", "telescopes"):
+        mod = importlib.import_module("optiland.samples." + m)
+        for cname, cls in inspect.getmembers(mod, inspect.isclass):
+            if cls.__module__ == mod.__name__ and issubclass(cls, optic_mod.Optic):
+                yield cname, cls
+
+
+def test_untouched_optics_are_packed_once(be):
+    """Every lens of optiland.samples: three rounds of trace / trace_generic at two
+    wavelengths -> exactly one pack per wavelength (tokens are stable across traces)."""
+    from optiland_amd import integration
+    checked = 0
+    for cname, cls in _sample_classes():
+        lens = cls()
+        t = integration.install(lens, force=True)
+        ws = [float(be.to_numpy(w.value).reshape(-1)[0]) if hasattr(w.value, "shape")
+              else float(w.value) for w in lens.wavelengths.wavelengths][:2]
+        for _ in range(3):
+            for w in ws:
+                lens.trace(0.0, 0.5, w, 2, "hexapolar")
+                lens.trace_generic(0.0, 0.0, 0.1, 0.1, w)
+        if t.last_path != "hip":
+            continue  # a sample the fused path leaves to the reference
+        assert t.pack_count == len(ws), (cname, t.pack_count)
+        checked += 1
+    assert checked >= 20
+
+
+def _mutations(be):
+    from optiland import physical_apertures
+    from optiland.coatings import SimpleCoating
+    from optiland.materials import IdealMaterial
+    from optiland.rays import PolarizationState
+    state = PolarizationState(is_polarized=True, Ex=1.0, Ey=0.3, phase_x=0.0, phase_y=0.4)
+
+    def inplace(lens):
+        r = lens.surfaces[2].geometry.radius
+        if hasattr(r, "mul_"):
+            r.mul_(1.01)  # in-place tensor write: same object, `_version` bumps
+        else:
+            lens.surfaces[2].geometry.radius = r * 1.01
+
+    def ap_inplace(lens):
+        lens.surfaces[2].aperture.r_max = 3.1
+
+    def coeff_inplace(lens):
+        c = lens.surfaces[1].geometry.coefficients
+        c[0] = c[0] * 0 + 2e-5
+
+    return [
+        ("set_radius", lambda L: L.set_radius(25.0, 1)),
+        ("set_conic", lambda L: L.set_conic(-0.3, 1)),
+        ("set_thickness", lambda L: L.set_thickness(4.1, 2)),
+        ("geometry.radius attribute", lambda L: setattr(L.surfaces[3].geometry, "radius",
+                                                        be.array(-21.0))),
+        ("in-place tensor write", inplace),
+        ("set_index", lambda L: L.set_index(1.61, 1)),
+        ("set_material", lambda L: L.set_material(IdealMaterial(n=1.55, k=1e-7), 3)),
+        ("new aperture object", lambda L: setattr(L.surfaces[2], "aperture",
+                                                  physical_apertures.RadialAperture(r_max=3.5))),
+        ("aperture attribute in place", ap_inplace),
+        ("decentre", lambda L: setattr(L.surfaces[3].geometry.cs, "x", be.array(0.05))),
+        ("tilt", lambda L: setattr(L.surfaces[4].geometry.cs, "rx", be.array(0.01))),
+        ("field value", lambda L: setattr(L.fields.fields[1], "y", 12.0)),
+        ("vignetting factor", lambda L: setattr(L.fields.fields[2], "vy", 0.2)),
+        ("system aperture", lambda L: L.set_aperture("EPD", 8.0)),
+        ("coating", lambda L: setattr(L.surfaces[1].interaction_model, "coating",
+                                      SimpleCoating(transmittance=0.9, reflectance=0.05))),
+        ("fresnel coatings + polarization", lambda L: (L.surfaces.set_fresnel_coatings(),
+                                                       L.updater.set_polarization(state))),
+        ("polarization state in place", lambda L: setattr(L.polarization, "Ey", 0.8)),
+        ("apodization", lambda L: L.set_apodization("GaussianApodization", sigma=0.7)),
+        ("image thickness", lambda L: setattr(L.surfaces[-1], "thickness", 0.25)),
+    ]
+
+
+def test_every_mutation_is_seen(be):
+    from optiland.samples.objectives import CookeTriplet
+    from optiland_amd import fingerprint, integration
+    memo_lens, plain_lens = CookeTriplet(), CookeTriplet()
+    t_memo = integration.install(memo_lens, force=True)
+    t_plain = integration.install(plain_lens, force=True)
+    w = 0.55
+
+    def plain_snapshot():
+        fingerprint.ENABLED = False
+        try:
+            return _snapshot(be, plain_lens, w)
+        finally:
+            fingerprint.ENABLED = True
+
+    a, b = _snapshot(be, memo_lens, w), plain_snapshot()
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    for name, mutate in _mutations(be):
+        before = t_memo.pack_count
+        mutate(memo_lens)
+        mutate(plain_lens)
+        a, b = _snapshot(be, memo_lens, w), plain_snapshot()
+        assert t_memo.last_path == t_plain.last_path, name
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y, err_msg=f"stale table after: {name}")
+        assert t_memo.pack_count > before, f"mutation not detected: {name}"
+        again = t_memo.pack_count
+        _snapshot(be, memo_lens, w)
+        assert t_memo.pack_count == again, f"token unstable after: {name}"
+
+
+def test_asphere_coefficient_written_in_place(be):
+    from optiland.samples.simple import AsphericSinglet
+    from optiland_amd import fingerprint, integration
+    memo_lens, plain_lens = AsphericSinglet(), AsphericSinglet()
+    t = integration.install(memo_lens, force=True)
+    integration.install(plain_lens, force=True)
+    w = 0.587
+    _snapshot(be, memo_lens, w)
+    for lens in (memo_lens, plain_lens):
+        c = lens.surfaces[1].geometry.coefficients
+        c[0] = c[0] * 1.5  # element write into the list / tensor the geometry holds
+    n0 = t.pack_count
+    a = _snapshot(be, memo_lens, w)
+    fingerprint.ENABLED = False
+    try:
+        b = _snapshot(be, plain_lens, w)
+    finally:
+        fingerprint.ENABLED = True
+    assert t.pack_count > n0
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_unsupported_verdict_is_memoised_and_revisited(be):
+    """A system the fused path refuses is not re-packed on every call either -- and is
+    looked at again as soon as it changes."""
+    from optiland.samples.objectives import CookeTriplet
+    from optiland_amd import integration
+    lens = CookeTriplet()
+    geom = lens.surfaces[3].geometry
+    orig_cls = geom.__class__
+    geom.__class__ = type("ForbesQbfsGeometry", (orig_cls,), {})
+    t = integration.install(lens, force=True)
+    for _ in range(3):
+        lens.trace(0.0, 0.0, 0.55, 3, "hexapolar")
+        assert t.last_path == "reference"
+    assert t.pack_count == 1
+    geom.__class__ = orig_cls
+    lens.trace(0.0, 0.0, 0.55, 3, "hexapolar")
+    assert t.last_path == "hip" and t.pack_count == 2

@@ -301,3 +301,118 @@ def test_incoherent_irradiance_analysis_on_device():
     np.testing.assert_allclose(irr.power_map.cpu().numpy(), want, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(irr.peak_irradiance()[0][0], want.max() / irr.pixel_area, rtol=1e-10)
     t.engine.close()
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE.json configs[2..4] at their FULL sizes (VERDICT r1 "missing" #4)
+# --------------------------------------------------------------------------------------
+def _generated_record(hip, n, dtype, hy, seed):
+    """Rays generated straight into row 0 of a record block (the drop-in's layout)."""
+    rec = hip.alloc_record(n, dtype)
+    rays = hip.row0_planes(rec, n)
+    px, py = _pupil(n, seed, dtype)
+    hip.generate_rays(0.0, hy, px, py, 1.0, 1.0, out=rays)
+    return rec, rays
+
+
+def _oracle_subsample(table, rays, idx, wl, polarized=False):
+    from oracle import oracle
+    sub = {k: rays[j][idx].double().cpu().numpy() for j, k in enumerate(PLANES[:7])}
+    return sub, oracle.trace(table, sub, wl, record=True, polarized=polarized)
+
+
+def test_config4_rc_asphere_full_size():
+    """C4: Ritchey-Chretien + even-asphere corrector (Newton-Raphson sag kernel), 1e7
+    rays fp32, record-all: every 997th ray against the oracle on every surface, the
+    record-last variant bit-identical to the last recorded row, invariants on all rays."""
+    from optiland_amd import load_system
+    from optiland_amd.engine import HipSystem
+    table = load_system("rc_asphere")
+    wl = table.wavelength_index(0.55)
+    hip = HipSystem(table, DEV)
+    try:
+        n, dtype, S = 10_000_000, torch.float32, table.num_traced
+        rec, rays = _generated_record(hip, n, dtype, 1.0, seed=31)
+        res = hip.trace(rays, wl, record=rec)
+        idx = torch.arange(0, n, 997, device=DEV)
+        _, want = _oracle_subsample(table, rays, idx, wl)
+        got = rec[:, :, :n][:, :, idx].double().cpu().numpy()
+        assert_close_planes(got, want["record"], 1e-4, 1e-4, "C4 subsample fp32")
+        # the central obscuration clips the same rays (mask exact), and most rays survive
+        alive = res.row(S, 6) > 0
+        frac = float(alive.double().mean())
+        assert 0.5 < frac < 1.0, frac
+        r2 = [t.clone() for t in rays]
+        hip.trace(r2, wl, record=False)
+        for k in range(8):
+            assert torch.equal(r2[k], res.row(S, k)), PLANES[k]
+        L, M, N = (res.stack(k) for k in (3, 4, 5))
+        assert float((L * L + M * M + N * N - 1).abs().max()) < 1e-5
+        opd = res.stack(7)
+        assert bool((opd[1:] >= opd[:-1]).all())
+    finally:
+        hip.close()
+
+
+def test_config5_zernike_fresnel_polarised_full_size():
+    """C5: Zernike freeform + Fresnel coatings with the Jones / PRT path on, 1e7 rays
+    fp32, record-all, write-only PRT, then `update_intensity`: every 997th ray against
+    the oracle (records, PRT matrices, updated intensities)."""
+    from optiland_amd import load_system
+    from optiland_amd.engine import HipSystem
+    from optiland_amd.rays import prt_to_complex
+    from oracle import oracle
+    table = load_system("zernike_fresnel_fringe")
+    assert table.uses_polarization and table.polarization is not None
+    wl = table.wavelength_index(0.55)
+    hip = HipSystem(table, DEV)
+    try:
+        n, dtype = 10_000_000, torch.float32
+        rec, rays = _generated_record(hip, n, dtype, 1.0, seed=37)
+        prt = torch.empty((18 if table.needs_complex_prt else 9, n), dtype=dtype, device=DEV)
+        k_init = [rays[k].clone() for k in (3, 4, 5)]
+        i0 = rays[6].clone()
+        hip.trace(rays, wl, record=rec, prt=prt, prt_identity=True)
+        inten = hip.polarized_intensity(prt, k_init, i0, table.polarization)
+        idx = torch.arange(0, n, 997, device=DEV)
+        sub, want = _oracle_subsample(table, rays, idx, wl, polarized=True)
+        got = rec[:, :, :n][:, :, idx].double().cpu().numpy()
+        assert_close_planes(got, want["record"], 1e-4, 1e-4, "C5 subsample fp32")
+        p_got = prt_to_complex(prt[:, idx].contiguous()).cpu().numpy().astype(np.complex128)
+        p_want = want["prt"]
+        assert np.array_equal(np.isnan(p_got.real), np.isnan(p_want.real))
+        assert np.nanmax(np.abs(p_got - p_want)) < 1e-4
+        i_want, status = oracle.polarized_intensity(want["prt"], sub["L"], sub["M"], sub["N"],
+                                                    sub["i"], table.polarization)
+        assert status == 0
+        i_got = inten[idx].double().cpu().numpy()
+        assert np.array_equal(np.isnan(i_got), np.isnan(i_want))
+        np.testing.assert_allclose(i_got, i_want, rtol=1e-4, atol=1e-5)
+        # Fresnel losses: every surviving ray lost energy, none gained
+        fin = torch.isfinite(inten)
+        assert bool((inten[fin] <= i0[fin] * (1 + 1e-5)).all()) and float(inten[fin].min()) > 0.5
+    finally:
+        hip.close()
+
+
+def test_config3_per_gpu_shard_full_size_fp64(dg):
+    """C3: the 1.25e7-ray fp64 shard one of 8 GPUs traces (record-all, 10.4 GB): every
+    997th ray against the oracle to 1e-9, and shard invariance -- the second half of the
+    shard traced alone reproduces the same rows bit for bit."""
+    hip, table = dg
+    n, dtype, S = 12_500_000, torch.float64, table.num_traced
+    rec, rays = _generated_record(hip, n, dtype, 0.7, seed=41)
+    res = hip.trace(rays, 0, record=rec)
+    idx = torch.arange(0, n, 997, device=DEV)
+    _, want = _oracle_subsample(table, rays, idx, 0)
+    got = rec[:, :, :n][:, :, idx].double().cpu().numpy()
+    assert_close_planes(got, want["record"], 1e-9, 1e-9, "C3 shard subsample fp64")
+    h = n // 2 + 1
+    part = [t[h:].clone() for t in rays]
+    pr = hip.trace(part, 0, record=True)
+    for s in (1, S // 2, S):
+        for k in range(8):
+            assert torch.equal(pr.row(s, k), res.row(s, k)[h:]), (s, k)
+    assert not bool(torch.isnan(rec[:, :, :n]).any())
+    del rec, res, pr
+    torch.cuda.empty_cache()

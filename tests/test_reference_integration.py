@@ -352,13 +352,15 @@ def test_dropin_keeps_device_tables_per_wavelength(hip_on_cpu):
         for w in (0.48, 0.55, 0.65):
             lens.trace(0.0, 0.7, w, num_rays=3, distribution="hexapolar")
     assert len(t._hip_engines) == 3
-    engines = {id(e) for e, _ in t._hip_engines.values()}
+    assert t.pack_count == 3   # the change detector spared the other six packs
+    engines = {id(hit[0]) for hit in t._hip_engines.values()}
     for w in (0.48, 0.55, 0.65):
         lens.trace(0.0, 0.0, w, num_rays=3, distribution="hexapolar")
-    assert {id(e) for e, _ in t._hip_engines.values()} == engines
+    assert {id(hit[0]) for hit in t._hip_engines.values()} == engines
+    assert t.pack_count == 3
     lens.surfaces[2].geometry.radius = float(lens.surfaces[2].geometry.radius) * 1.02
     lens.trace(0.0, 0.0, 0.55, num_rays=3, distribution="hexapolar")
-    assert len(t._hip_engines) == 4
+    assert len(t._hip_engines) == 4 and t.pack_count == 4
 
 
 # ------------------------------------------------------------------------------------
