@@ -73,3 +73,39 @@ def assert_close_planes(got, want, rtol, atol_scale, label=""):
         )
         # +-inf entries must match exactly
         assert np.array_equal(np.isinf(g), np.isinf(w)), f"{label}: inf masks differ"
+
+
+def image_plane_error_over_spot(got, want, data):
+    """Worst transverse error at the LAST recorded surface relative to the RMS spot radius
+    of the golden bundle it belongs to (one bundle per distinct (Hx, Hy) of the case).
+
+    The group-scale tolerance model above compares a focused spot with the path lengths
+    that produced it; this is the complementary, image-quality view: an fp32 trace whose
+    hits wander by a sizeable fraction of the spot has lost its purpose even if it is
+    1e-7 of the system length.  Bundles that focus to (numerically) a point -- a parabola
+    on axis -- are measured against 1e-6 of the position scale instead.  Returns the max
+    over bundles of max_ray |d(x, y)| / max(rms_spot, 1e-6 * scale)."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    gx, gy, wx, wy = got[-1, 0], got[-1, 1], want[-1, 0], want[-1, 1]
+    alive = np.isfinite(wx) & np.isfinite(wy) & (want[-1, 6] > 0)
+    if not alive.any():
+        return 0.0
+    pos = want[:, :3]
+    scale = np.max(np.abs(pos[np.isfinite(pos)]))
+    hx = np.broadcast_to(np.asarray(data.get("Hx", 0.0), dtype=np.float64).reshape(-1), wx.shape) \
+        if np.size(data.get("Hx", 0.0)) in (1, wx.size) else np.zeros(wx.shape)
+    hy = np.broadcast_to(np.asarray(data.get("Hy", 0.0), dtype=np.float64).reshape(-1), wx.shape) \
+        if np.size(data.get("Hy", 0.0)) in (1, wx.size) else np.zeros(wx.shape)
+    worst = 0.0
+    for key in {(a, b) for a, b in zip(np.round(hx[alive], 9), np.round(hy[alive], 9))}:
+        sel = alive & (np.round(hx, 9) == key[0]) & (np.round(hy, 9) == key[1])
+        if sel.sum() < 3:
+            continue
+        cx, cy = wx[sel].mean(), wy[sel].mean()
+        rms = np.sqrt(np.mean((wx[sel] - cx) ** 2 + (wy[sel] - cy) ** 2))
+        err = np.hypot(gx[sel] - wx[sel], gy[sel] - wy[sel])
+        err = err[np.isfinite(err)]
+        if err.size:
+            worst = max(worst, float(err.max() / max(rms, 1e-6 * scale)))
+    return worst

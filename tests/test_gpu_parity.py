@@ -292,6 +292,61 @@ def test_every_kernel_variant_is_bit_identical(hip, case, dtype):
         assert torch.equal(one[k].nan_to_num(), last[k].nan_to_num()), (case, PLANES[k])
 
 
+def _newton_cases():
+    out = []
+    for c in golden_cases():
+        table, data = load_case(c)
+        if (table.surfaces["geom_kind"] >= 2).any() and "prt" not in data:
+            out.append(c)
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("case", _newton_cases())
+def test_shfl_compaction_variant_matches_default_and_goldens(hip, case, dtype):
+    """BASELINE.json north_star names "wavefront-level __shfl-based active-ray compaction"
+    for the Newton iteration.  It is built (`newton_compacted`: ballot + mbcnt +
+    ds_bpermute, `trace_kernel<..., NR=2>`), measured slower on MI355X (DESIGN 4.1 item 9,
+    profiles/r02_ab_compaction.txt) and therefore opt-in: `ol_set_tuning(OL_TUNE_COMPACT, 1)`.
+    Shipped-but-off code is still held to the contract: on every golden system with a
+    Newton-Raphson surface the compacted kernel must reproduce the default kernel (same
+    per-ray arithmetic, only the lane a straggler runs on differs) and the goldens."""
+    from optiland_amd import _capi
+    sysm, table, data = hip(case)
+    lib = _capi.load()
+    n = data["rays_in"].shape[1]
+    reps = max(1, -(-512 // n))  # at least a few full waves so that stragglers can be packed
+    pad = (-(n * reps)) % 4
+
+    def rays_padded():
+        r = [t.repeat(reps) for t in _device_rays(data, dtype)]
+        if pad:
+            r = [torch.cat([t, t[:pad]]).contiguous() for t in r]
+        return r
+    ref = sysm.trace(rays_padded(), 0, record=True)
+    try:
+        assert lib.ol_set_tuning(_capi.TUNE_COMPACT, 1) == 0
+        assert lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, 2) == 0
+        got = sysm.trace(rays_padded(), 0, record=True)
+        last = rays_padded()
+        sysm.trace(last, 0, record=False)
+    finally:
+        lib.ol_set_tuning(_capi.TUNE_COMPACT, 0)
+        lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, 0)
+    m = n * reps + pad
+    a, b = got.record[:, :, :m], ref.record[:, :, :m]
+    assert torch.equal(torch.isnan(a), torch.isnan(b)), case
+    # vs the goldens, at the contract tolerance
+    assert_close_planes(a[:, :, :n].double().cpu().numpy(), data["record"], TOL[dtype], TOL[dtype],
+                        f"{case} compacted {dtype}")
+    # vs the default kernel: identical per-ray arithmetic
+    diff = (a.nan_to_num() - b.nan_to_num()).abs().max().item()
+    scale = b.nan_to_num().abs().max().item()
+    assert diff <= (1e-12 if dtype == torch.float64 else 1e-5) * scale, (case, diff, scale)
+    for k in range(8):
+        assert torch.equal(torch.isnan(last[k]), torch.isnan(a[-1, k])), (case, PLANES[k])
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("case", [c for c in golden_cases() if c.startswith("sample_")])
 def test_every_sample_lens_end_to_end_against_the_oracle(case, dtype):

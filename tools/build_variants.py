@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Build A/B variants of the HIP library with other compile-time knobs (build container;
+hipcc cross-compiles).  Output: optiland_amd/lib/variant_<name>.so -- git-ignored like the
+product library, travels to the GPU box, selected there through OPTILAND_HIP_LIBRARY
+(tools/gpu_ab_variants.sh).  The PRODUCT library is never touched.
+
+    python tools/build_variants.py [name ...]      # default: all
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from optiland_amd import build as B  # noqa: E402
+
+VARIANTS = {
+    # BASELINE.json north_star: "surface coefficients staged in LDS" 
+    "lds_table": ["-DOL_TABLE_IN_LDS=1"],
+    # store flavour: plain stores for the one-ray-per-lane layout,
+    # non-temporal for the 16-byte vector layout
+    "plain_stores": ["-DOL_NT_SCALAR=0"],
+    "nt_vector": ["-DOL_NT_VECTOR=1"],
+    # workgroup size
+    "block128": ["-DOL_TRACE_BLOCK=128"],
+    "block512": ["-DOL_TRACE_BLOCK=512"],
+}
+
+
+def build(name):
+    flags = ["--offload-arch=" + B.ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
+             "-fno-math-errno"] + VARIANTS[name]
+    out = os.path.join(B.LIBDIR, f"variant_{name}.so")
+    objdir = os.path.join(B.LIBDIR, f"variant_{name}_obj")
+    os.makedirs(objdir, exist_ok=True)
+    objs, jobs = [], []
+    for src in B.SOURCES:
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        jobs.append([B._hipcc(), *flags, "-c", os.path.join(B.CSRC, src), "-o", o])
+        objs.append(o)
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        list(pool.map(subprocess.check_call, jobs))
+    subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", *objs,
+                           "-o", out])
+    for o in objs:
+        os.remove(o)
+    os.rmdir(objdir)
+    return out
+
+
+if __name__ == "__main__":
+    for nm in (sys.argv[1:] or list(VARIANTS)):
+        print(build(nm))
