@@ -13,6 +13,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/optiland_hip.h"
@@ -86,14 +87,16 @@ double factorial(int n) {
   return f;
 }
 
-// Regroup Zernike terms (c_j, n_j, m_j, N_j) into per-(|m|, cos|sin) radial
-// polynomials in u = rho^2 with the factor rho^|m| removed:
+// Regroup Zernike terms (c_j, n_j, m_j, N_j) into one LEVEL per azimuthal order |m| with
+// the (cos, sin) radial polynomials in u = rho^2, the factor rho^|m| removed:
 //   R_n^m(rho) = sum_k (-1)^k (n-k)! / (k! ((n+m)/2-k)! ((n-m)/2-k)!) rho^(n-2k)
 // (zernike/base.py:216-239), rho^(n-2k) = rho^m u^((n-m)/2-k).
-// Layout per group: [m, kind, K, a_0..a_{K-1}, b_0..b_{K-1}] (device_table.h).
+// Layout per level (device_table.h): [m, K] as integers (their slots are recorded in
+// `int_slots` and uploaded as bit patterns), then K x {a_c, a_s, b_c, b_s, d_c, d_s}.
 int build_zernike_block(const double* terms, int n_terms, std::vector<double>& out,
-                        int* n_groups) {
-  std::map<std::pair<int, int>, std::pair<std::vector<double>, std::vector<double>>> groups;
+                        std::vector<size_t>& int_slots, int* n_levels) {
+  struct Level { std::vector<double> a[2], b[2]; };
+  std::map<int, Level> levels;
   for (int j = 0; j < n_terms; ++j) {
     const double c = terms[4 * j];
     const int n = (int)terms[4 * j + 1];
@@ -103,26 +106,37 @@ int build_zernike_block(const double* terms, int n_terms, std::vector<double>& o
     const int ma = std::abs(m);
     if (n < ma || ((n - ma) & 1) || n > 60) return -1;
     const int K = (n - ma) / 2 + 1;
-    auto& g = groups[{ma, m < 0 ? 1 : 0}];
-    if ((int)g.first.size() < K) {
-      g.first.resize(K, 0.0);
-      g.second.resize(K, 0.0);
-    }
+    Level& lv = levels[ma];
+    const int kind = m < 0 ? 1 : 0;
+    for (int q = 0; q < 2; ++q)
+      if ((int)lv.a[q].size() < K) {
+        lv.a[q].resize(K, 0.0);
+        lv.b[q].resize(K, 0.0);
+      }
     for (int k = 0; k < K; ++k) {
       double coef = ((k & 1) ? -1.0 : 1.0) * factorial(n - k) /
                     (factorial(k) * factorial((n + ma) / 2 - k) * factorial((n - ma) / 2 - k));
       const int p = (n - ma) / 2 - k;
-      g.first[p] += c * N * coef;
-      g.second[p] += c * coef;
+      lv.a[kind][p] += c * N * coef;
+      lv.b[kind][p] += c * coef;
     }
   }
-  *n_groups = (int)groups.size();
-  for (auto& kv : groups) {  // std::map iterates in ascending (m, kind)
-    out.push_back((double)kv.first.first);
-    out.push_back((double)kv.first.second);
-    out.push_back((double)kv.second.first.size());
-    out.insert(out.end(), kv.second.first.begin(), kv.second.first.end());
-    out.insert(out.end(), kv.second.second.begin(), kv.second.second.end());
+  *n_levels = (int)levels.size();
+  for (auto& kv : levels) {  // std::map iterates in ascending m
+    const Level& lv = kv.second;
+    const int K = (int)lv.a[0].size();
+    int_slots.push_back(out.size());
+    out.push_back((double)kv.first);
+    int_slots.push_back(out.size());
+    out.push_back((double)K);
+    for (int k = 0; k < K; ++k) {
+      out.push_back(lv.a[0][k]);
+      out.push_back(lv.a[1][k]);
+      out.push_back(lv.b[0][k]);
+      out.push_back(lv.b[1][k]);
+      out.push_back(k + 1 < K ? (k + 1) * lv.b[0][k + 1] : 0.0);
+      out.push_back(k + 1 < K ? (k + 1) * lv.b[1][k + 1] : 0.0);
+    }
   }
   return 0;
 }
@@ -163,7 +177,7 @@ namespace {
 template <typename T>
 int upload(const std::vector<HostSurf>& surf64,
            const std::vector<ol::DevOptics<double>>& opt64, const std::vector<double>& coef64,
-           DeviceTable<T>& dst) {
+           const std::vector<size_t>& int_slots, DeviceTable<T>& dst) {
   std::vector<ol::DevSurfHot<T>> surf(surf64.size());
   std::vector<ol::DevSurfCold<T>> cold(surf64.size());
   for (size_t i = 0; i < surf64.size(); ++i) {
@@ -193,6 +207,11 @@ int upload(const std::vector<HostSurf>& surf64,
   }
   std::vector<T> coef(coef64.size() ? coef64.size() : 1, T(0));
   for (size_t i = 0; i < coef64.size(); ++i) coef[i] = (T)coef64[i];
+  for (size_t i : int_slots) {  // loop headers: integer bit patterns (scalar-unit operands)
+    using I = typename std::conditional<sizeof(T) == 4, int32_t, int64_t>::type;
+    const I v = (I)coef64[i];
+    std::memcpy(&coef[i], &v, sizeof(T));
+  }
 
   OL_HIP_CHECK(hipMalloc((void**)&dst.surf, surf.size() * sizeof(ol::DevSurfHot<T>)));
   OL_HIP_CHECK(hipMalloc((void**)&dst.cold, cold.size() * sizeof(ol::DevSurfCold<T>)));
@@ -395,6 +414,7 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
 
   std::vector<HostSurf> dev(n_surf);
   std::vector<double> dcoef;
+  std::vector<size_t> int_slots;  // dcoef entries uploaded as integer bit patterns
   int32_t prev_traced = -1;
   for (int32_t i = 0; i < n_surf; ++i) {
     const ol_surface_desc& s = surf[i];
@@ -519,7 +539,7 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
     const double* src = coeffs ? coeffs + s.coeff_offset : nullptr;
     if (s.geom_kind == OL_GEOM_ZERNIKE) {
       int ng = 0;
-      if (build_zernike_block(src, s.n_coeff, dcoef, &ng) != 0)
+      if (build_zernike_block(src, s.n_coeff, dcoef, int_slots, &ng) != 0)
         return fail(OL_EINVAL, "surface %d: invalid Zernike (n, m) index", i);
       d.n_coeff = ng;
     } else if (s.geom_kind == OL_GEOM_EVEN_ASPHERE || s.geom_kind == OL_GEOM_ODD_ASPHERE ||
@@ -594,8 +614,8 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
     delete sys;
     return fail(OL_EHIP, "ol_system_create: no HIP device (hipGetDevice failed)");
   }
-  int rc = upload<float>(dev, dopt, dcoef, sys->f32);
-  if (rc == OL_OK) rc = upload<double>(dev, dopt, dcoef, sys->f64);
+  int rc = upload<float>(dev, dopt, dcoef, int_slots, sys->f32);
+  if (rc == OL_OK) rc = upload<double>(dev, dopt, dcoef, int_slots, sys->f64);
   if (rc != OL_OK) {
     release(sys->f32);
     release(sys->f64);

@@ -94,11 +94,18 @@ struct DevOptics {
   T pad[3];
 };
 
-// Zernike group header inside the coefficient block (all stored as T):
-//   [0] m  (>= 0)   [1] trig kind: 0 = cos / m == 0, 1 = sin   [2] K = #coeffs
-//   then K sag coefficients  a_k  (sum_j c_j N_j R_n^m, ascending powers of rho^2,
-//        the common factor rho^m taken out),
-//   then K normal coefficients b_k (same without N_j).
-constexpr int kZernGroupHeader = 3;
+// Zernike block inside the coefficient array: one LEVEL per azimuthal order m that has a
+// non-zero term, ascending in m (surface.n_coeff = number of levels):
+//   [0] m >= 0   [1] K = number of powers of u = rho^2       -- INTEGER bit patterns
+//                                                              (int32 in a float slot,
+//                                                               int64 in a double slot)
+//   then, for k = 0 .. K-1, six values (cos part, sin part interleaved so that a pair is
+//   one 2-vector / one s_load_dwordx2):
+//     a_c[k] a_s[k]   sag coefficient of u^k   (sum_j c_j N_j R_n^m, rho^m taken out)
+//     b_c[k] b_s[k]   the same without N_j     (the reference's normal, zernike.py:234)
+//     d_c[k] d_s[k]   (k + 1) b[k + 1]         (coefficients of dQ_b/du; 0 for k = K-1)
+//   (m = 0 has no sin part: zeros.)
+constexpr int kZernLevelHeader = 2;
+constexpr int kZernLevelStride = 6;
 
 }  // namespace ol

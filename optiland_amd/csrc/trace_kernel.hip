@@ -355,14 +355,39 @@ __device__ __forceinline__ void polynomial_eval(const DevSurf<T>& s, const T* __
 }
 
 // zernike.py:153-252 + zernike/base.py:42-137.  Terms regrouped on the host per
-// (|m|, cos/sin) into radial polynomials rho^m * Q(rho^2); cos(m phi) / sin(m phi)
-// come from the Chebyshev recurrence on (x_n/rho, y_n/rho) -- (1, 0) at rho == 0,
-// matching atan2(0, 0) = 0 -- instead of atan2 + cos/sin per term.  The chain-rule
-// regularisers eps = 1e-14 of zernike.py:206-231 are kept.
+// azimuthal order m into radial polynomials in u = rho^2 with the factor rho^m taken out
+// (capi.hip:build_zernike_block, layout in device_table.h).  Evaluated in CARTESIAN form:
+// with the harmonic polynomials
+//     A_m + i B_m = (x_n + i y_n)^m   (= rho^m (cos m phi + i sin m phi)),
+// advanced by one complex multiply per order, the cos and sin terms of one order are
+// Qc(u) A_m + Qs(u) B_m and their gradient follows from
+//     d(A_m, B_m)/dx_n = m (A_{m-1}, B_{m-1}),   d(A_m, B_m)/dy_n = m (-B_{m-1}, A_{m-1}),
+// so there is no atan2 / cos / sin, no sqrt, no reciprocal and no polar chain rule in
+// the loop.  The (cos, sin) pair of every quantity lives in one 2-vector: in fp32 the
+// three Horner chains (sag polynomial, normal polynomial, its u-derivative from host-made
+// derivative coefficients) and the harmonic recurrence are packed v_pk_fma_f32 /
+// v_pk_mul_f32 -- one issue slot for both kinds -- and the order / length headers are
+// integer bit patterns, so the loop control stays on the scalar unit.  (The polar form
+// the reference writes down costs 4 transcendentals per evaluation and ~20 vector
+// operations per (m, kind) group; this kernel is VALU-issue bound: profiles/r02_zf_*.)
+// Away from the vertex the two forms are the same polynomial.  AT the vertex the
+// reference's chain rule is regularised with eps = 1e-14 (zernike.py:206-231:
+// drho/dx = x_n / (rho + eps) / norm, dphi/dx = -y_n / (rho^2 + eps) / norm), which damps
+// the radial part of the gradient by rho / (rho + eps), the azimuthal part by
+// rho^2 / (rho^2 + eps) and makes it exactly zero at rho == 0 (the tilt terms' true
+// gradient is not): reproduced below for the rays that need it (rho^2 < 1e-8) by
+// splitting the Cartesian gradient into those two parts.
+template <typename T>
+using vec2 = T __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int slot_int(const float* p) { return __float_as_int(*p); }
+__device__ __forceinline__ int slot_int(const double* p) { return (int)__double_as_longlong(*p); }
+
 template <typename T>
 __device__ __forceinline__ void zernike_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
                                              T y, T& sag, T& fx, T& fy, uint32_t& status) {
   using m = Math<T>;
+  using V2 = vec2<T>;
   T r2 = m::fma(x, x, y * y);
   T g = m::sqrt(m::fma(-s.kp1 * s.cv * s.cv, r2, T(1)));
   sag = m::div(s.cv * r2, T(1) + g);
@@ -373,59 +398,60 @@ __device__ __forceinline__ void zernike_eval(const DevSurf<T>& s, const T* __res
   const T xn = x * inv, yn = y * inv;
   if (m::abs(xn) > T(1) || m::abs(yn) > T(1)) status |= 0x1u;  // OL_STATUS_ZERNIKE_RANGE
   const T u = m::fma(xn, xn, yn * yn);
-  const T rho = m::sqrt(u);
-  const T eps = m::guard();
-  const T irho = rho > T(0) ? m::rcp(rho) : T(0);
-  const T c1 = rho > T(0) ? xn * irho : T(1);
-  const T s1 = rho > T(0) ? yn * irho : T(0);
-  // drho/dx = (x/norm^2)/(rho+eps), dphi/dx = -(y_n)/(rho^2+eps)/norm
-  const T ir_e = m::rcp(rho + eps);
-  const T iu_e = m::rcp(u + eps);
-  const T drho_dx = xn * inv * ir_e, drho_dy = yn * inv * ir_e;
-  const T dphi_dx = -yn * iu_e * inv, dphi_dy = xn * iu_e * inv;
+  const V2 uu = {u, u};
 
-  T zsum = T(0), gx = T(0), gy = T(0);
-  // running cos(m phi), sin(m phi), rho^m across groups (sorted by ascending m)
-  T cm = T(1), sm = T(0), rm = T(1), rm1 = T(0);  // rm1 = rho^(m-1) (0 for m = 0)
+  T zsum = T(0), gx = T(0), gy = T(0);  // gradient w.r.t. (x_n, y_n)
+  // H = (A_m, B_m) of the current order, Hp of the one below (weighted by m = 0 at order 0)
+  V2 H = {T(1), T(0)}, Hp = {T(0), T(0)};
   int mcur = 0;
-  int off = 0;
-  for (int gi = 0; gi < s.n_coeff; ++gi) {
-    const int mg = (int)c[off];
-    const int kind = (int)c[off + 1];
-    const int K = (int)c[off + 2];
-    const T* a = c + off + kZernGroupHeader;
-    const T* b = a + K;
-    off += kZernGroupHeader + 2 * K;
-    while (mcur < mg) {  // advance the recurrences (uniform trip count)
-      T cn = cm * c1 - sm * s1;
-      T sn = sm * c1 + cm * s1;
-      cm = cn;
-      sm = sn;
-      rm1 = rm;
-      rm = rm * rho;
-      ++mcur;
+  const T* p = c;
+  for (int lv = 0; lv < s.n_coeff; ++lv) {
+    const int mg = slot_int(p), K = slot_int(p + 1);
+    p += kZernLevelHeader;
+    for (; mcur < mg; ++mcur) {  // levels come sorted by ascending m (uniform trip count)
+      Hp = H;
+      // (A, B) <- (x A - y B, y A + x B)
+      const V2 sw = {-Hp.y, Hp.x};
+      H = xn * Hp + yn * sw;
     }
-    T qs = T(0), qn = T(0), dqn = T(0);
-    for (int k = K - 1; k >= 0; --k) {
-      qs = m::fma(qs, u, a[k]);
-      dqn = m::fma(dqn, u, qn);
-      qn = m::fma(qn, u, b[k]);
+    // per power of u, (cos, sin) pairs of: a = sag coefficients (normalisation constant
+    // included), b = coefficients of the NORMAL (the reference forms it without the
+    // constant, zernike.py:234-240), d = (k + 1) b_{k+1} (dQn/du)
+    // (K >= 1: the chains start from the highest coefficients instead of from zero)
+    const T* e = p + kZernLevelStride * (K - 1);
+    V2 qs = {e[0], e[1]}, qn = {e[2], e[3]}, dq = {e[4], e[5]};
+    for (int k = K - 2; k >= 0; --k) {
+      e -= kZernLevelStride;
+      const V2 ak = {e[0], e[1]}, bk = {e[2], e[3]}, dk = {e[4], e[5]};
+      qs = qs * uu + ak;
+      qn = qn * uu + bk;
+      dq = dq * uu + dk;
     }
-    const T trig = kind ? sm : cm;
-    // d/dphi: cos -> -m sin, sin -> +m cos
-    const T dtrig = kind ? T(mg) * cm : -T(mg) * sm;
-    zsum = m::fma(rm * qs, trig, zsum);
-    // d/drho [rho^m Qn(rho^2)] = m rho^(m-1) Qn + 2 rho^(m+1) Qn'
-    const T dR = m::fma(T(mg) * rm1, qn, T(2) * rm * rho * dqn);
-    const T Rn = rm * qn;
-    const T dZdrho = dR * trig;
-    const T dZdphi = Rn * dtrig;
-    gx = m::fma(dZdrho, drho_dx, m::fma(dZdphi, dphi_dx, gx));
-    gy = m::fma(dZdrho, drho_dy, m::fma(dZdphi, dphi_dy, gy));
+    p += kZernLevelStride * K;
+    const V2 zs = qs * H;
+    zsum += zs.x + zs.y;
+    const V2 t1 = dq * H;                     // dQn/dx_n = 2 x_n Qn'
+    const T t1s = (t1.x + t1.y) * T(2);
+    const V2 w = qn * T(mg);
+    const V2 hx = w * Hp;                     // cos: m Qc A_{m-1}   sin: m Qs B_{m-1}
+    const V2 swp = {-Hp.y, Hp.x};
+    const V2 hy = w * swp;                    // cos: -m Qc B_{m-1}  sin: m Qs A_{m-1}
+    gx = m::fma(t1s, xn, gx + (hx.x + hx.y));
+    gy = m::fma(t1s, yn, gy + (hy.x + hy.y));
+  }
+  if (u < T(1e-8)) {  // the reference's eps-regularised chain rule near / at the vertex
+    const T eps = m::guard();
+    const T Rr = m::fma(xn, gx, yn * gy);     // rho dZ/drho
+    const T Az = m::fma(xn, gy, -(yn * gx));  // dZ/dphi
+    const T rho = m::sqrt(u);
+    const T d1 = u > T(0) ? m::rcp(m::fma(eps, rho, u)) : T(0);  // 1 / (rho (rho + eps))
+    const T d2 = m::rcp(u + eps);
+    gx = m::fma(Rr * d1, xn, -(Az * d2 * yn));
+    gy = m::fma(Rr * d1, yn, Az * d2 * xn);
   }
   sag += zsum;
-  fx += gx;
-  fy += gy;
+  fx = m::fma(gx, inv, fx);
+  fy = m::fma(gy, inv, fy);
 }
 
 // chebyshev.py:126-225.  T_n by the three-term recurrence instead of
@@ -901,6 +927,63 @@ __device__ __forceinline__ void prt_apply(Prt<T, POLK>& P, const PolBasis<T>& b,
     }
 }
 
+// The same update for a REAL DIAGONAL Jones matrix diag(j0, j1, j2) -- uncoated and
+// Fresnel-coated surfaces (jones.py:71-117), i.e. every surface of a system without
+// polarizers / retarders.  {s, p0, k0} is an orthonormal triad (s is Gram-Schmidt-ed
+// against k0 in pol_basis), so s s^T = I - p0 p0^T - k0 k0^T and
+//     O_out J O_in = j0 s s^T + j1 p1 p0^T + j2 k1 k0^T
+//                  = j0 I + (j1 p1 - j0 p0) p0^T + (j2 k1 - j0 k0) k0^T :
+// P' = j0 P + a (p0^T P) + b (k0^T P), two row-vector products and a rank-2 update
+// (54 multiply-adds) instead of three products and a full recombination (75); s itself
+// is only needed to build p0 and p1.  Equal to the general form up to the rounding of
+// |k0|^2 - 1 (the reference never renormalises k either).
+template <typename T, int POLK>
+__device__ __forceinline__ void prt_apply_diag(Prt<T, POLK>& P, const PolBasis<T>& b, T k0x,
+                                               T k0y, T k0z, T k1x, T k1y, T k1z, T j0, T j1,
+                                               T j2) {
+  using m = Math<T>;
+  constexpr int NP = POLK == 2 ? 2 : 1;
+  const T ax = m::fma(j1, b.p1x, -(j0 * b.p0x)), ay = m::fma(j1, b.p1y, -(j0 * b.p0y)),
+          az = m::fma(j1, b.p1z, -(j0 * b.p0z));
+  const T bx = m::fma(j2, k1x, -(j0 * k0x)), by = m::fma(j2, k1y, -(j0 * k0y)),
+          bz = m::fma(j2, k1z, -(j0 * k0z));
+#pragma unroll
+  for (int c = 0; c < NP; ++c) {
+    T* Q = P.m + 9 * c;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const T r1 = m::fma(b.p0x, Q[e], m::fma(b.p0y, Q[3 + e], b.p0z * Q[6 + e]));
+      const T r2 = m::fma(k0x, Q[e], m::fma(k0y, Q[3 + e], k0z * Q[6 + e]));
+      Q[e] = m::fma(ax, r1, m::fma(bx, r2, j0 * Q[e]));
+      Q[3 + e] = m::fma(ay, r1, m::fma(by, r2, j0 * Q[3 + e]));
+      Q[6 + e] = m::fma(az, r1, m::fma(bz, r2, j0 * Q[6 + e]));
+    }
+  }
+}
+
+// First update of a FRESH matrix (P = I, OL_TRACE_PRT_IDENTITY): P' = O_out J O_in itself,
+// 21 multiply-adds instead of 54.
+template <typename T, int POLK>
+__device__ __forceinline__ void prt_first_diag(Prt<T, POLK>& P, const PolBasis<T>& b, T k0x,
+                                               T k0y, T k0z, T k1x, T k1y, T k1z, T j0, T j1,
+                                               T j2) {
+  using m = Math<T>;
+  const T a[3] = {m::fma(j1, b.p1x, -(j0 * b.p0x)), m::fma(j1, b.p1y, -(j0 * b.p0y)),
+                  m::fma(j1, b.p1z, -(j0 * b.p0z))};
+  const T bb[3] = {m::fma(j2, k1x, -(j0 * k0x)), m::fma(j2, k1y, -(j0 * k0y)),
+                   m::fma(j2, k1z, -(j0 * k0z))};
+  const T p0[3] = {b.p0x, b.p0y, b.p0z}, k0[3] = {k0x, k0y, k0z};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+      P.m[3 * i + e] = m::fma(a[i], p0[e], m::fma(bb[i], k0[e], i == e ? j0 : T(0)));
+  if constexpr (POLK == 2) {
+#pragma unroll
+    for (int e = 9; e < 18; ++e) P.m[e] = P.m[e] * T(0) + (P.m[0] * T(0));  // 0, NaN kept
+  }
+}
+
 // --------------------------------------------------------------------------
 // one surface for the RPT rays of a thread: standard_surface.py:200-248 (minus
 // record).  Phases run across the thread's rays so that independent chains
@@ -983,7 +1066,10 @@ __device__ __forceinline__ void interact(const DevSurf<typename Math<V>::scalar>
                                          const typename Math<V>::scalar* __restrict__ coeffs,
                                          const V (&t)[RPT], const V (&nx)[RPT], const V (&ny)[RPT],
                                          const V (&nz)[RPT], Ray<V> (&r)[RPT],
-                                         Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1]) {
+                                         Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
+                                         bool& prt_fresh) {
+  // prt_fresh (wave-uniform): the matrices still hold the identity a fresh trace starts
+  // from -- the first real update then writes O_out J O_in instead of multiplying by it
   using m = Math<V>;
   using T = typename m::scalar;
   static_assert(POLK == 0 || m::lanes == 1, "the polarised path is scalar");
@@ -1078,33 +1164,50 @@ __device__ __forceinline__ void interact(const DevSurf<typename Math<V>::scalar>
       }
       return;
     }
+    if (ck == kCoatFresnel || ck == kCoatNone) {
+      // real diagonal Jones matrix: rank-2 form of the update (prt_apply_diag)
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const PolBasis<T> b = pol_basis(L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, nx[k],
+                                        ny[k], nz[k]);
+        T j0 = T(1), j1 = T(1), j2 = T(1);
+        if (ck == kCoatFresnel) {
+          // coatings.py:72-92 + jones.py:71-117 with cos(aoi) = min(|n.k0|, 1):
+          // root = sqrt(nn^2 - sin^2) is real unless TIR, where k1 is NaN already.
+          T ci = adot[k] < T(1) ? adot[k] : (adot[k] >= T(1) ? T(1) : adot[k]);
+          T root = m::sqrt(m::fma(nn, nn, m::fma(ci, ci, T(-1))));
+          if (reflect) {
+            j0 = m::div(ci - root, ci + root);
+            j1 = -m::div(m::fma(nn * nn, ci, -root), m::fma(nn * nn, ci, root));
+            j2 = T(-1);
+          } else {
+            j0 = m::div(T(2) * ci, ci + root);
+            j1 = m::div(T(2) * nn * ci, m::fma(nn * nn, ci, root));
+          }
+        }
+        if (prt_fresh)
+          prt_first_diag<T, POLK>(P[k], b, L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, j0, j1,
+                                  j2);
+        else
+          prt_apply_diag<T, POLK>(P[k], b, L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, j0, j1,
+                                  j2);
+      }
+      prt_fresh = false;
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       const PolBasis<T> b = pol_basis(L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, nx[k], ny[k],
                                       nz[k]);
       Jones<T> J;
-      J.a00 = J.a11 = J.j22 = T(1);
-      J.a01 = J.a10 = J.b00 = J.b01 = J.b10 = J.b11 = T(0);
-      if (ck == kCoatFresnel) {
-        // coatings.py:72-92 + jones.py:71-117 with cos(aoi) = min(|n.k0|, 1):
-        // root = sqrt(nn^2 - sin^2) is real unless TIR, where k1 is NaN already.
-        T ci = adot[k] < T(1) ? adot[k] : (adot[k] >= T(1) ? T(1) : adot[k]);
-        T root = m::sqrt(m::fma(nn, nn, m::fma(ci, ci, T(-1))));
-        if (reflect) {
-          J.a00 = m::div(ci - root, ci + root);
-          J.a11 = -m::div(m::fma(nn * nn, ci, -root), m::fma(nn * nn, ci, root));
-          J.j22 = T(-1);
-        } else {
-          J.a00 = m::div(T(2) * ci, ci + root);
-          J.a11 = m::div(T(2) * nn * ci, m::fma(nn * nn, ci, root));
-        }
-      } else if (ck == kCoatPolarizer) {
+      if (ck == kCoatPolarizer) {
         J = axis_jones(b, s.cold->axis, false, T(0), T(0));
-      } else if (ck == kCoatRetarder) {
+      } else {  // kCoatRetarder
         J = axis_jones(b, s.cold->axis, true, s.cold->ret_cos, s.cold->ret_sin);
       }
       prt_apply<T, POLK>(P[k], b, L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, J);
     }
+    prt_fresh = false;
   }
 }
 
@@ -1117,7 +1220,7 @@ __device__ __forceinline__ void surface_step(const DevSurf<typename Math<V>::sca
                                              const typename Math<V>::scalar* __restrict__ coeffs,
                                              bool from_global, Ray<V> (&r)[RPT],
                                              Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
-                                             uint32_t& status) {
+                                             uint32_t& status, bool& prt_fresh) {
   using m = Math<V>;
   using T = typename m::scalar;
   static_assert(NR == 0 || m::lanes == 1, "the Newton-Raphson path is scalar");
@@ -1235,7 +1338,7 @@ __device__ __forceinline__ void surface_step(const DevSurf<typename Math<V>::sca
 #pragma unroll
     for (int k = 0; k < RPT; ++k) t[k] = nx[k] = ny[k] = nz[k] = m::splat(0);
   }
-  interact<V, RPT, POLK, NR != 0>(s, o, coeffs, t, nx, ny, nz, r, P);
+  interact<V, RPT, POLK, NR != 0>(s, o, coeffs, t, nx, ny, nz, r, P, prt_fresh);
 }
 
 // local -> global for the recorded state (coordinate_system.py:91-107)
@@ -1462,8 +1565,23 @@ struct SpotAcc {
 // v_readfirstlane, and -- vmcnt being in-order on gfx9-family parts -- every
 // surface's table read then waited for ALL outstanding record stores to retire,
 // serialising compute behind HBM writes (measured: 1.00 ms -> see DESIGN.md).
+// Minimum waves per SIMD asked of the register allocator.  Only the fp32 polarised
+// Newton kernel (the Zernike + Fresnel configuration, VALU-issue bound with long SMEM /
+// transcendental dependency chains) asks for more than the allocator gives by itself;
+// OL_POLNR_WAVES is the A/B knob (tools/build_variants.py), 0 = no request.
+#ifndef OL_POLNR_WAVES
+#define OL_POLNR_WAVES 0
+#endif
+template <typename T, int RPT, int POLK, int NR>
+struct WavesPerEu {
+  static constexpr int value =
+      (OL_POLNR_WAVES > 0 && sizeof(T) == 4 && RPT == 1 && POLK == 1 && NR == 1) ? OL_POLNR_WAVES
+                                                                                  : 1;
+};
+
 template <typename T, int RPT, bool RECORD, int POLK, int NR, bool SPOT>
-__global__ __launch_bounds__(kTraceBlock) void trace_kernel(
+__global__ __launch_bounds__(kTraceBlock)
+__attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
     const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
     TraceArgs<T> a) {
@@ -1572,6 +1690,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
 
   uint32_t status = 0;
   bool is_global = true;  // frame of the state held in r[]
+  bool prt_fresh = POLK != 0 && (a.flags & kTracePrtIdentity) != 0;
   DevSurf<T> last_traced;
   last_traced.cold = cold_tab;
   // hot block of the current surface by value (one s_load_dwordx16 for fp32); the
@@ -1596,7 +1715,7 @@ __global__ __launch_bounds__(kTraceBlock) void trace_kernel(
 #else
       const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
 #endif
-      surface_step<V, NV, POLK, NR>(S, O, coeff_tab, is_global, r, P, status);
+      surface_step<V, NV, POLK, NR>(S, O, coeff_tab, is_global, r, P, status, prt_fresh);
       is_global = false;
       last_traced = S;
     }
@@ -1821,6 +1940,7 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
 
   SpotAcc acc;
   uint32_t status = 0;
+  bool prt_fresh = false;  // unpolarised kernel: unused
   constexpr int64_t kTileRays = (int64_t)kTraceBlock * RPT;
   const int64_t ntiles = (a.n + kTileRays - 1) / kTileRays;
 
@@ -1906,7 +2026,7 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
       if (s < a.last) cur = surf_tab[s + 1];
       if (S.interaction != kRecordOnly) {
         const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
-        surface_step<V, NV, 0, NR>(S, O, coeff_tab, is_global, r, P, status);
+        surface_step<V, NV, 0, NR>(S, O, coeff_tab, is_global, r, P, status, prt_fresh);
         is_global = false;
         last_traced = S;
       }

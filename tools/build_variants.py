@@ -25,6 +25,9 @@ VARIANTS = {
     # workgroup size
     "block128": ["-DOL_TRACE_BLOCK=128"],
     "block512": ["-DOL_TRACE_BLOCK=512"],
+    # register-allocator occupancy request for the fp32 polarised Newton kernel (C5)
+    "polnr_waves7": ["-DOL_POLNR_WAVES=7"],
+    "polnr_waves8": ["-DOL_POLNR_WAVES=8"],
 }
 
 
