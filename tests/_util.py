@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import glob
+import json
 import os
 
 import numpy as np
@@ -38,7 +39,41 @@ def rays_in_dict(data):
     return {k: r[j].copy() for j, k in enumerate(PLANES[:7])}
 
 
-def assert_close_planes(got, want, rtol, atol_scale, label=""):
+GROUP_OF_PLANE = {0: "pos", 1: "pos", 2: "pos", 3: "dir", 4: "dir", 5: "dir", 6: "i", 7: "opd"}
+FP32_MARGINS = os.path.join(GOLDEN, "fp32_margins.json")
+_MARGINS = None
+
+
+def fp32_group_tolerances(case, factor=4.0, floor=2e-6, cap=1e-4):
+    """Per-group fp32 tolerances of one golden case: `factor` x the margin the HIP kernel
+    was MEASURED to have on it on an MI355X (tests/golden/fp32_margins.json, written by
+    tools/gpu_accuracy.py), floored at `floor` (a compiler upgrade may move the last bits)
+    and capped at the contract's 1e-4.  The contract itself (BASELINE.json: "fp32 results
+    within 1e-4") is 25-100 x looser than what the kernel achieves: on a double Gauss
+    1e-4 of the position scale is the size of the spot, so a regression that wrecked fp32
+    spot fidelity would still pass it.  Returns None for a case without measurements."""
+    global _MARGINS
+    if _MARGINS is None:
+        try:
+            with open(FP32_MARGINS) as f:
+                _MARGINS = json.load(f)
+        except OSError:
+            _MARGINS = {}
+    m = _MARGINS.get(case)
+    if m is None:
+        return None
+    return {g: min(cap, max(factor * float(m[g]), floor)) for g in ("pos", "dir", "i", "opd")}
+
+
+def fp32_image_tolerance(case, factor=4.0, floor=0.02):
+    """Allowed image-plane error in units of the RMS spot radius (see
+    `image_plane_error_over_spot`): `factor` x measured, at least `floor`."""
+    fp32_group_tolerances(case)
+    m = (_MARGINS or {}).get(case)
+    return None if m is None else max(factor * float(m["img_over_spot"]), floor)
+
+
+def assert_close_planes(got, want, rtol, atol_scale, label="", group_tol=None):
     """Compare (..., 8, N) plane stacks.
 
     Tolerance model (stated here once, used by every parity test): for each plane
@@ -48,6 +83,8 @@ def assert_close_planes(got, want, rtol, atol_scale, label=""):
     relative to the path lengths that produced it, not to itself), direction
     cosines (L, M, N) share one, intensity and opd have their own.  NaN masks must match
     exactly, and so must the `i == 0` (clipped) mask of the intensity plane.
+    `group_tol` ({"pos": t, "dir": t, "i": t, "opd": t}, e.g. `fp32_group_tolerances`)
+    replaces BOTH rtol and atol_scale for the planes of that group.
     """
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
@@ -65,7 +102,10 @@ def assert_close_planes(got, want, rtol, atol_scale, label=""):
         grp = want[..., list(groups.get(k, (k,))), :]
         scale = np.max(np.abs(grp[np.isfinite(grp)]))
         err = np.abs(g[fin] - w[fin])
-        tol = rtol * np.abs(w[fin]) + atol_scale * scale
+        rt, at = rtol, atol_scale
+        if group_tol is not None and GROUP_OF_PLANE.get(k) in group_tol:
+            rt = at = group_tol[GROUP_OF_PLANE[k]]
+        tol = rt * np.abs(w[fin]) + at * scale
         bad = err > tol
         assert not bad.any(), (
             f"{label}: plane {PLANES[k] if k < 8 else k}: max err {err.max():.3e} "
