@@ -37,7 +37,12 @@ extern "C" {
 #define OL_ENOMEM (-4)
 
 /* ---- arithmetic type of the ray buffers -------------------------------- */
-typedef enum ol_dtype { OL_F32 = 0, OL_F64 = 1 } ol_dtype;
+/* A plain 32-bit integer, not an enum type: a foreign caller (ctypes, cgo, JNI ...) can pass
+ * any value, and in the C++ implementation merely LOADING an out-of-range value of an enum
+ * type is undefined behaviour (found by the UBSAN pass, tests/test_capi_sanitized.py); as an
+ * integer it is validated and answered with OL_EINVAL.  Same size and calling convention. */
+typedef int32_t ol_dtype;
+enum { OL_F32 = 0, OL_F64 = 1 };
 
 /* ---- geometry kinds (reference class -> enum) ---------------------------
  * PLANE         optiland/geometries/plane.py:72-109

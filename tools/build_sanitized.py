@@ -39,7 +39,8 @@ def asan_runtime() -> str:
 
 def build(force=False) -> str:
     srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES]
-    hdrs = [os.path.join(B.CSRC, h) for h in B.HEADERS]
+    hdrs = [os.path.join(B.CSRC, h) for h in B.HEADERS] + \
+        [os.path.join(ROOT, "include", "optiland_hip.h")]
     if not force and os.path.exists(OUT) and \
             os.path.getmtime(OUT) >= max(os.path.getmtime(p) for p in srcs + hdrs):
         return OUT
