@@ -335,6 +335,7 @@ def _make_tracer_class():
 # SurfaceGroup.trace(rays, skip) -- the seam for callers that bring their own rays
 # --------------------------------------------------------------------------------------
 _SG = {"device": None, "force": False, "count": 0, "fallbacks": 0, "foreign": 0}
+_ENABLE = {"device": None, "force": False}  # settings of the class-wide patch (enable())
 _PLANE_ATTRS = ("x", "y", "z", "L", "M", "N", "i", "opd")
 
 
@@ -425,6 +426,13 @@ def _sg_run(group, eng, rays, planes, first, last, polarized):
         surf.x, surf.y, surf.z, surf.L, surf.M, surf.N, surf.intensity, surf.opd = res.rows(s)
     pre = res.rows(last - 1)[3:6] if last > first else planes[3:6]
     if not (first == 0 and last == 0):  # an object surface alone interacts with nothing
+        # the reference stores L0.. inside refract() / reflect(), i.e. AFTER localize():
+        # the pre-interaction cosines in the LAST surface's frame (real_rays.py:170-172)
+        srow = eng.table.surfaces[last]
+        if srow["flags"] & 1:  # SURF_ROTATED
+            R = torch.as_tensor(np.asarray(srow["rot"]).reshape(3, 3), dtype=dtype,
+                                device=planes[0].device)
+            pre = tuple(R @ torch.stack(list(pre)))
         rays.L0, rays.M0, rays.N0 = pre
     rays.x, rays.y, rays.z, rays.L, rays.M, rays.N, rays.i, rays.opd = res.rows(last)
     if polarized:
@@ -519,14 +527,20 @@ def enable(device=None, force=False):
     from optiland.raytrace.real_ray_tracer import RealRayTracer
 
     if getattr(RealRayTracer, "_hip_enabled", False):
+        # already patched: a second call only updates the settings (device / force) that
+        # future companions and the SurfaceGroup seam read
+        _ENABLE.update(device=device, force=force)
+        _SG.update(device=device, force=force)
         return
+    _ENABLE.update(device=device, force=force)
 
     def _companion(self):
         comp = self.__dict__.get("_hip_companion")
         if comp is None:
-            comp = cls(self.optic, device=device, force=force)
+            comp = cls(self.optic, device=_ENABLE["device"], force=_ENABLE["force"])
             comp.ray_generator = self.ray_generator
             self.__dict__["_hip_companion"] = comp
+        comp._hip_device, comp._hip_force = _ENABLE["device"], _ENABLE["force"]
         comp.ray_aiming_config = self.ray_aiming_config
         return comp
 

@@ -122,8 +122,16 @@ class Wavefront:
         neg, _ = t.engine.wavefront_opd(params, c7, zero, zero, want_pupil=False)
         params["opd_ref"] = -float(neg[0]) * self.wavelength * 1e-3
         # 2. the full pupil (strategy.py:190-205)
-        rays = t.trace(hx, hy, self.wavelength, None, self.distribution)
-        intensity = t.surfaces.intensity[-1].clone()
+        # the intensity the reference reads is the RECORDED image-plane row
+        # (wavefront/strategy.py:198: surfaces.intensity[-1], i.e. before a polarised
+        # update_intensity): record-all is forced for this trace whatever the caller set
+        keep_record = t.record_all
+        t.record_all = True
+        try:
+            rays = t.trace(hx, hy, self.wavelength, None, self.distribution)
+            intensity = t.surfaces.intensity[-1].clone()
+        finally:
+            t.record_all = keep_record
         px = t._dev(self.distribution.x)
         py = t._dev(self.distribution.y)
         r7 = [v.contiguous() for v in (rays.x, rays.y, rays.z, rays.L, rays.M, rays.N, rays.opd)]

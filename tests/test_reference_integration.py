@@ -415,6 +415,64 @@ def test_surface_group_seam_matches_reference_loop(sg_seam, skip):
     assert _np(be, lens.surfaces.x).shape == (len(lens.surfaces.surfaces) - skip, 41) or skip == 0
 
 
+def test_l0_is_in_the_frame_of_a_tilted_last_surface(sg_seam):
+    """the reference stores L0 / M0 / N0 inside refract() / reflect(), after
+    localize(): for a TILTED last surface they are the pre-interaction cosines in that
+    surface's own frame, not the previous surface's recorded (global) direction.  Both
+    seams -- SurfaceGroup.trace with caller-built rays and Optic.trace_generic -- must
+    reproduce that."""
+    import optiland.backend as be
+    from optiland import optic as optic_mod
+
+    def build():
+        lens = optic_mod.Optic(name="TiltedImage")
+        lens.surfaces.add(index=0, radius=be.inf, thickness=be.inf)
+        lens.surfaces.add(index=1, radius=40.0, thickness=6.0, material="N-BK7", is_stop=True)
+        lens.surfaces.add(index=2, radius=-60.0, thickness=30.0)
+        lens.surfaces.add(index=3, radius=be.inf, rx=0.6, ry=-0.2)   # tilted image plane
+        lens.set_aperture(aperture_type="EPD", value=10)
+        lens.fields.set_type(field_type="angle")
+        lens.fields.add(y=0)
+        lens.fields.add(y=2.0)
+        lens.wavelengths.add(value=0.55, is_primary=True)
+        return lens
+    lens = build()
+    px, py = be.array(np.linspace(-0.8, 0.8, 23)), be.array(np.linspace(0.6, -0.7, 23))
+    gen = lens.ray_tracer.ray_generator
+    start = gen.generate_rays(be.zeros_like(px), be.ones_like(px) * 0.7, px, py, 0.55)
+    a, b = _clone_rays(be, start), _clone_rays(be, start)
+    want = sg_seam._ORIGINALS["sg_trace"](lens.surfaces, a, 0)
+    got = lens.surfaces.trace(b, skip=0)
+    assert sg_seam._SG["count"] == 1
+    for k in ("L0", "M0", "N0", "x", "L"):
+        np.testing.assert_allclose(_np(be, getattr(got, k)), _np(be, getattr(want, k)),
+                                   rtol=1e-10, atol=1e-12, err_msg=k)
+    # the cosines really are rotated (the test would be vacuous on an untilted surface)
+    assert np.abs(_np(be, got.M0) - _np(be, lens.surfaces.surfaces[2].M)).max() > 0.1
+    g = lens.trace_generic(0.0, 0.7, px, py, 0.55)
+    assert lens.ray_tracer._hip_companion.last_path == "hip"
+    for k in ("L0", "M0", "N0"):
+        np.testing.assert_allclose(_np(be, getattr(g, k)), _np(be, getattr(want, k)),
+                                   rtol=1e-10, atol=1e-12, err_msg=k)
+
+
+def test_enable_twice_updates_the_settings(hip_on_cpu):
+    """a second enable() with another device / force is not ignored."""
+    from optiland.samples.objectives import CookeTriplet
+    from optiland_amd import integration
+    integration.enable(force=False)
+    try:
+        lens = CookeTriplet()
+        lens.trace(0.0, 0.0, 0.55, 3, "hexapolar")
+        assert lens.ray_tracer._hip_companion.last_path == "reference"   # cpu, not forced
+        integration.enable(force=True)
+        lens.trace(0.0, 0.0, 0.55, 3, "hexapolar")
+        assert lens.ray_tracer._hip_companion.last_path == "hip"
+        assert integration._SG["force"] is True
+    finally:
+        integration.disable()
+
+
 def test_surface_group_seam_advances_an_existing_prt(sg_seam):
     """PolarizedRays whose `p` is no longer the identity (traced half way by the
     reference) continue through surfaces[skip:] on the seam: p, i, and the record match

@@ -51,6 +51,20 @@ def test_wavefront_and_psf_host_logic(tag, monkeypatch):
         np.testing.assert_allclose(opd.rms(), 0.9709788038168692, rtol=1e-5)
 
 
+def test_wavefront_with_record_all_switched_off(monkeypatch):
+    """Wavefront reads the recorded image-plane intensity; with the tracer in
+    record-last mode (IncoherentIrradiance toggles it, users may) that used to raise an
+    opaque IndexError -- the trace now forces record-all and restores the flag."""
+    from tests._fake_engine import OracleEngine
+    monkeypatch.setattr(tr, "_make_engine", lambda table, device: OracleEngine(table, device))
+    t = tr.HipRayTracer(load_system("cooke_generic"), dtype=torch.float64)
+    want = OPD(t, (0.0, 1.0), 0.55).rms()
+    t.record_all = False
+    got = OPD(t, (0.0, 1.0), 0.55).rms()
+    assert t.record_all is False
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+
+
 def test_grid_size_rule():
     # psf/fft.py:20-39 (values from the reference's tests/test_fft_psf.py:60-72 table)
     assert calculate_grid_size(32) == (32, 64)
