@@ -1872,8 +1872,8 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
   if (!vector_ok || (a.prt && (a.flags & kTracePrtComplex)))
     return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
   // Defaults from interleaved A/B runs on MI355X (tools/ab_bench.py):
-  //  * record-all (HBM-write bound), fp32 and fp64: ONE ray per lane -- 36 / 81 VGPRs,
-  //    8 / 5 waves per SIMD keep more stores in flight (fp32 +2 %, fp64 +6 % over the
+  //  * record-all (HBM-write bound), fp32 and fp64: ONE ray per lane -- 46 / 103 VGPRs,
+  //    8 / 4 waves per SIMD keep more stores in flight (fp32 +2 %, fp64 +6 % over the
   //    16-byte vector layout);
   //  * record-last on conic-only ranges (ALU bound): one 16-byte vector of rays per
   //    lane, whose independent chains interleave (fp32 0.205 vs 0.259 ms);
