@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OL_ABI_VERSION 4
+#define OL_ABI_VERSION 5
 
 /* ---- error codes ------------------------------------------------------- */
 #define OL_OK 0
@@ -438,6 +438,43 @@ typedef struct ol_wavefront_params {
 int ol_wavefront_opd(const ol_wavefront_params* p, ol_dtype dt, int64_t n_rays,
                      const void* const rays[7], const void* px, const void* py,
                      void* opd_waves, void* const pupil[3], void* stream);
+
+/* ABI 5.  Fused generate -> trace -> OPD (the wavefront analogue of
+ * ol_trace_spot): ONE launch takes the normalised pupil coordinates of one field point to
+ * the OPD map.  Replaces, for unpolarised systems and the chief-ray strategy, the chain
+ * RayGenerator.generate_rays -> SurfaceGroup.trace -> ChiefRayStrategy.compute_wavefront_data
+ * (wavefront/strategy.py:163-215; reference_geometry.py:41-128) and the reductions the
+ * consumers apply to the map (wavefront/wavefront.py:103-148 fit_and_remove_tilt,
+ * wavefront/opd.py:145-159 rms; psf/fft.py:101-137 reads opd + intensity).
+ *   in         px, py planes; launch-uniform field (hx0, hy0) and vignetting (vx0, vy0);
+ *              per-ray field / vignetting planes are refused (one field per wavefront)
+ *   w          reference sphere / plane incl. opd_ref (see ol_wavefront_params)
+ *   opd_waves, intensity   n_rays outputs (what ol_wavefront_opd and
+ *              surface_group.intensity[-1] hold)
+ *   pupil      NULL, or 3 planes: the reference-surface intersection points
+ *   moments12  device doubles, ACCUMULATED (zero them first), w = intensity, o = OPD,
+ *              (X, Y) = pupil point:
+ *              {sum w, sum wX, sum wY, sum wXX, sum wXY, sum wYY, sum wo, sum woX, sum woY,
+ *               #{i > 0}, sum o [i > 0], sum o^2 [i > 0]}
+ * fp64 only (OL_F32 -> OL_EUNSUPPORTED): an OPD in waves needs 1e-9 of the path length.
+ * Systems with polarization-dependent coatings are refused like ol_trace_spot.          */
+int ol_trace_opd(const ol_system* sys, ol_dtype dt, int64_t n_rays,
+                 const ol_raygen_params* p, const ol_raygen_inputs* in,
+                 const ol_wavefront_params* w, int32_t wavelength_index,
+                 void* opd_waves, void* intensity, void* const pupil[3],
+                 double* moments12, uint32_t* status, void* stream);
+
+/* The pupil function of the scalar FFT PSF (psf/fft.py:101-137 _generate_pupil + the
+ * zero padding of :139-160): sample j of the compacted pupil list -- cell `cell[j]`
+ * (row-major) of the n_side x n_side sample grid -- becomes
+ *   sqrt(intensity[j]) * exp(-i 2 pi (opd_waves[j] - (plane[0] + plane[1] X + plane[2] Y)))
+ * at row + pad, column + pad of the grid_size x grid_size complex array `grid`
+ * (interleaved re, im doubles; pad = (grid_size - n_side) / 2; ZEROED BY THE CALLER).
+ * pupil_x / pupil_y / plane are NULL when no tilt is removed.                          */
+int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void* intensity,
+                  const void* pupil_x, const void* pupil_y, const double plane[3],
+                  const int32_t* cell, int32_t n_side, int32_t grid_size, double* grid,
+                  void* stream);
 
 /* Profiling knobs (process-wide, not part of the trace semantics).
  *   OL_TUNE_RAYS_PER_THREAD  0 = auto (16-byte vector of rays per lane for conic-only

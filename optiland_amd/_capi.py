@@ -111,11 +111,14 @@ EXPORTS = (
     "ol_trace_ex",
     "ol_radial_energy",
     "ol_irradiance",
+    "ol_trace_opd",
+    "ol_pupil_fill",
 )
 
 F32, F64 = 0, 1
 TUNE_RAYS_PER_THREAD, TUNE_COMPACT = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
+OPD_MOMENTS = 12  # kOpdMoments / ol_trace_opd
 
 
 def library_path() -> str:
@@ -176,6 +179,10 @@ def load():
                                      vp, vp]
     lib.ol_set_tuning.restype = C.c_int
     lib.ol_set_tuning.argtypes = [i32, i32]
+    lib.ol_trace_opd.restype = C.c_int
+    lib.ol_trace_opd.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, C.POINTER(vp), vp, vp, vp]
+    lib.ol_pupil_fill.restype = C.c_int
+    lib.ol_pupil_fill.argtypes = [i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     if lib.ol_abi_version() != ABI_VERSION:
         raise HipExtensionError(
             f"{path}: ABI version {lib.ol_abi_version()} != expected {ABI_VERSION}; rebuild"

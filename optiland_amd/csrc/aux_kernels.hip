@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "raygen_device.h"
+#include "wavefront_device.h"
 #include "trace_launch.h"
 
 namespace ol {
@@ -145,42 +146,56 @@ __global__ __launch_bounds__(kBlock) void wavefront_kernel(
     const T* __restrict__ z, const T* __restrict__ Ld, const T* __restrict__ Md,
     const T* __restrict__ Nd, const T* __restrict__ opd_in, const T* __restrict__ px,
     const T* __restrict__ py, T* opd_waves, T* pux, T* puy, T* puz) {
-  const T xc = (T)p.xc, yc = (T)p.yc, zc = (T)p.zc, R = (T)p.R, ni = (T)p.n_image;
-  const T inv_w = (T)(1.0 / (p.wavelength_um * 1e-3));
-  const bool planar = p.nx != 0.0 || p.ny != 0.0 || p.nz != 0.0;  // launch-uniform
-  const T nx = (T)p.nx, ny = (T)p.ny, nz = (T)p.nz;
+  const WavefrontConsts<T> w(p);
   for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
        j += (int64_t)gridDim.x * kBlock) {
-    const T xr = x[j], yr = y[j], zr = z[j];
-    const T L = -Ld[j], M = -Md[j], N = -Nd[j];  // trace backwards from the image
-    T t;
-    if (planar) {  // reference_geometry.py:104-124
-      const T num = (xr - xc) * nx + (yr - yc) * ny + (zr - zc) * nz;
-      T den = L * nx + M * ny + N * nz;
-      den = fabs(den) < T(1e-12) ? T(1e-12) : den;
-      t = -num / den;
-    } else {
-      const T a = L * L + M * M + N * N;
-      const T b = T(2) * (L * (xr - xc) + M * (yr - yc) + N * (zr - zc));
-      const T c = xr * xr + yr * yr + zr * zr - T(2) * (xr * xc + yr * yc + zr * zc) +
-                  xc * xc + yc * yc + zc * zc - R * R;
-      T d = b * b - T(4) * a * c;
-      d = d < T(0) ? T(0) : d;
-      const T sq = sqrt(d);
-      const T t1 = (-b - sq) / (T(2) * a), t2 = (-b + sq) / (T(2) * a);
-      t = t1 < T(0) ? t2 : t1;
-    }
-    const T opd_img = ni * t;
-    const T tilt = (T)p.ux * (px[j] * (T)p.half_epd) + (T)p.uy * (py[j] * (T)p.half_epd);
-    const T opd = opd_in[j] - opd_img + tilt;
-    opd_waves[j] = ((T)p.opd_ref - opd) * inv_w;
+    T pu[3];
+    opd_waves[j] = wavefront_one<T>(w, x[j], y[j], z[j], Ld[j], Md[j], Nd[j], opd_in[j], px[j],
+                                    py[j], pu);
     if (pux) {
-      const T tt = opd_img / ni;
-      pux[j] = xr - tt * Ld[j];
-      puy[j] = yr - tt * Md[j];
-      puz[j] = zr - tt * Nd[j];
+      pux[j] = pu[0];
+      puy[j] = pu[1];
+      puz[j] = pu[2];
     }
   }
+}
+
+// psf/fft.py:101-137: the pupil function A exp(-i 2 pi OPD) scattered into the zero-padded
+// FFT grid.  Sample j of the compacted 'uniform' pupil list lives in cell `cell[j]` of the
+// n x n sample grid (row-major, the host sampler's own mask); the grid is grid x grid
+// complex (re, im interleaved), zeroed by the caller, with the n x n block at offset
+// `pad`.  An intensity-weighted plane a + b X + c Y (wavefront.py:103-148, tilt removal)
+// is subtracted from the OPD when `pupil_x` is given.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pupil_fill_kernel(
+    int64_t n, const T* __restrict__ opd, const T* __restrict__ inten,
+    const T* __restrict__ pupil_x, const T* __restrict__ pupil_y, double c0, double c1,
+    double c2, const int32_t* __restrict__ cell, int32_t n_side, int32_t grid, int32_t pad,
+    double* __restrict__ out) {
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * kBlock) {
+    double o = (double)opd[j];
+    if (pupil_x) o -= c0 + c1 * (double)pupil_x[j] + c2 * (double)pupil_y[j];
+    const double amp = sqrt((double)inten[j]);
+    double sn, cs;
+    sincos(-6.283185307179586476925286766559 * o, &sn, &cs);
+    const int32_t cidx = cell[j];
+    const int64_t r = cidx / n_side, cc = cidx - r * n_side;
+    const int64_t at = ((r + pad) * (int64_t)grid + (cc + pad)) * 2;
+    out[at] = amp * cs;
+    out[at + 1] = amp * sn;
+  }
+}
+
+template <typename T>
+hipError_t launch_pupil_fill(int64_t n, const T* opd, const T* inten, const T* pupil_x,
+                             const T* pupil_y, const double coef[3], const int32_t* cell,
+                             int32_t n_side, int32_t grid, int32_t pad, double* out,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL((pupil_fill_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, stream, n, opd,
+                     inten, pupil_x, pupil_y, coef[0], coef[1], coef[2], cell, n_side, grid, pad,
+                     out);
+  return hipGetLastError();
 }
 
 template <typename T>
@@ -402,6 +417,9 @@ hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten,
                                               hipStream_t);                                    \
   template hipError_t launch_wavefront<T>(const WavefrontDev&, int64_t, const T* const[7],     \
                                           const T*, const T*, T*, T* const[3], hipStream_t);   \
+  template hipError_t launch_pupil_fill<T>(int64_t, const T*, const T*, const T*, const T*,    \
+                                           const double[3], const int32_t*, int32_t, int32_t,  \
+                                           int32_t, double*, hipStream_t);                     \
   template hipError_t launch_spot_moments<T>(int64_t, const T*, const T*, const T*, double*,   \
                                              hipStream_t);                                     \
   template hipError_t launch_irradiance<T>(int64_t, const T*, const T*, const T*,              \

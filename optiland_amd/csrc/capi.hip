@@ -379,6 +379,44 @@ int do_trace_spot(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
   return OL_OK;
 }
 
+template <typename T>
+int do_trace_opd(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
+                 const ol_raygen_params* p, const ol_raygen_inputs* in,
+                 const ol_wavefront_params* w, int32_t wl, void* opd, void* inten,
+                 void* const pupil[3], double* mom, uint32_t* status, hipStream_t stream) {
+  ol::OpdArgs<T> a;
+  bool vec = true;
+  if (int rc = convert_inputs<T>("ol_trace_opd", in, status, a.in, vec)) return rc;
+  if (a.in.hx != nullptr || a.in.vx != nullptr)
+    return fail(OL_EINVAL, "ol_trace_opd: one field point per launch (launch-uniform field and "
+                           "vignetting, no hx / hy / vx / vy planes)");
+  if (n == 0) return OL_OK;
+  a.surf = tab.surf;
+  a.cold = tab.cold;
+  a.optics = tab.optics;
+  a.coeffs = tab.coeffs;
+  a.rg = raygen_dev(p);
+  a.wf = ol::WavefrontDev{w->xc, w->yc, w->zc, w->R, w->n_image, w->opd_ref, w->ux, w->uy,
+                          w->half_epd, w->wavelength_um, w->nx, w->ny, w->nz};
+  a.opd = static_cast<T*>(opd);
+  a.inten = static_cast<T*>(inten);
+  for (int k = 0; k < 3; ++k) a.pupil[k] = pupil ? static_cast<T*>(pupil[k]) : nullptr;
+  a.mom = mom;
+  a.status = status;
+  a.n = n;
+  a.first = 0;
+  a.last = sys->n_surf - 1;
+  a.n_wl = sys->n_wl;
+  a.wl = wl;
+  bool has_newton = false;
+  for (int32_t s = 0; s < sys->n_surf; ++s)
+    has_newton = has_newton || sys->polygon[s] ||
+                 (sys->geom[s] != OL_GEOM_PLANE && sys->geom[s] != OL_GEOM_STANDARD);
+  hipError_t e = ol::launch_opd_trace<T>(a, has_newton, stream);
+  if (e != hipSuccess) return fail(OL_EHIP, "opd launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -847,6 +885,71 @@ int ol_wavefront_opd(const ol_wavefront_params* p, ol_dtype dt, int64_t n_rays,
   } else {
     return fail(OL_EINVAL, "ol_wavefront_opd: bad dtype %d", (int)dt);
   }
+  if (e != hipSuccess) return fail(OL_EHIP, "launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
+int ol_trace_opd(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_raygen_params* p,
+                 const ol_raygen_inputs* in, const ol_wavefront_params* w,
+                 int32_t wavelength_index, void* opd_waves, void* intensity,
+                 void* const pupil[3], double* moments12, uint32_t* status, void* stream) {
+  if (!sys) return fail(OL_EINVAL, "ol_trace_opd: system is NULL");
+  if (dt != OL_F64)
+    return fail(dt == OL_F32 ? OL_EUNSUPPORTED : OL_EINVAL,
+                "ol_trace_opd: wavefront work is fp64 only (dtype %d)", (int)dt);
+  if (!p || !in || !w || !opd_waves || !intensity || !moments12)
+    return fail(OL_EINVAL, "ol_trace_opd: NULL argument");
+  if (pupil && (!pupil[0] || !pupil[1] || !pupil[2]))
+    return fail(OL_EINVAL, "ol_trace_opd: pupil planes must all be given or pupil = NULL");
+  if (n_rays < 0) return fail(OL_EINVAL, "ol_trace_opd: negative ray count");
+  if (wavelength_index < 0 || wavelength_index >= sys->n_wl)
+    return fail(OL_EINVAL, "ol_trace_opd: wavelength index %d outside [0, %d)", wavelength_index,
+                sys->n_wl);
+  for (int32_t s = 0; s < sys->n_surf; ++s)
+    if (sys->coating[s] >= OL_COAT_FRESNEL)
+      return fail(OL_EINVAL,
+                  "Polarization must be set when surfaces have polarization-dependent "
+                  "coatings.");
+  if (n_rays > 0) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != sys->device)
+      return fail(OL_EINVAL, "ol_trace_opd: current HIP device %d is not the system's device %d",
+                  cur, sys->device);
+  }
+  return do_trace_opd<double>(sys, sys->f64, n_rays, p, in, w, wavelength_index, opd_waves,
+                              intensity, pupil, moments12, status,
+                              static_cast<hipStream_t>(stream));
+}
+
+int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void* intensity,
+                  const void* pupil_x, const void* pupil_y, const double plane[3],
+                  const int32_t* cell, int32_t n_side, int32_t grid_size, double* grid,
+                  void* stream) {
+  if (!opd_waves || !intensity || !cell || !grid)
+    return fail(OL_EINVAL, "ol_pupil_fill: NULL argument");
+  if ((pupil_x == nullptr) != (pupil_y == nullptr) || (pupil_x && !plane))
+    return fail(OL_EINVAL, "ol_pupil_fill: pupil_x, pupil_y and plane go together");
+  if (n_rays < 0 || n_side < 1 || grid_size < n_side || grid_size > (1 << 15))
+    return fail(OL_EINVAL, "ol_pupil_fill: n_rays %lld, %d samples per side, grid %d",
+                (long long)n_rays, n_side, grid_size);
+  if (n_rays > (int64_t)n_side * n_side)
+    return fail(OL_EINVAL, "ol_pupil_fill: more samples than cells");
+  if (n_rays == 0) return OL_OK;
+  const double zero[3] = {0.0, 0.0, 0.0};
+  const double* co = plane ? plane : zero;
+  const int32_t pad = (grid_size - n_side) / 2;  // psf/fft.py:139-160
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (dt == OL_F32)
+    e = ol::launch_pupil_fill<float>(n_rays, (const float*)opd_waves, (const float*)intensity,
+                                     (const float*)pupil_x, (const float*)pupil_y, co, cell,
+                                     n_side, grid_size, pad, grid, st);
+  else if (dt == OL_F64)
+    e = ol::launch_pupil_fill<double>(n_rays, (const double*)opd_waves, (const double*)intensity,
+                                      (const double*)pupil_x, (const double*)pupil_y, co, cell,
+                                      n_side, grid_size, pad, grid, st);
+  else
+    return fail(OL_EINVAL, "ol_pupil_fill: bad dtype %d", (int)dt);
   if (e != hipSuccess) return fail(OL_EHIP, "launch failed: %s", hipGetErrorString(e));
   return OL_OK;
 }

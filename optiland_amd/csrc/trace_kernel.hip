@@ -31,6 +31,7 @@
 
 #include "device_table.h"
 #include "raygen_device.h"
+#include "wavefront_device.h"
 #include "trace_launch.h"
 
 #ifndef OL_TABLE_IN_LDS
@@ -2102,6 +2103,137 @@ template hipError_t launch_spot_trace<float>(const SpotArgs<float>&, bool, bool,
 #endif
 #if OL_TRACE_TU != 1
 template hipError_t launch_spot_trace<double>(const SpotArgs<double>&, bool, bool, hipStream_t);
+#endif
+
+// --------------------------------------------------------------------------
+// fused generate -> trace -> OPD: the wavefront analogue of the spot
+// kernel.  One launch takes the normalised pupil coordinates of ONE field point to the
+// per-ray OPD in waves against the reference sphere / plane (wavefront_device.h), the
+// image-plane intensity and -- as device-side sums -- everything the consumers reduce
+// the map to: the nine weighted moments of the tilt fit (wavefront/wavefront.py:103-148),
+// count / sum / sum of squares of the OPD over rays with i > 0 (piston, RMS:
+// wavefront/opd.py:145-159).  The rays never exist in HBM: 2 planes in, 2 (+3) out,
+// where the un-fused chain (ol_generate_rays + record-all ol_trace + ol_wavefront_opd +
+// torch reductions) moves 8 (S + 2) + 13 planes.  One ray per lane: wavefront work is
+// fp64 (an OPD good to lambda/1000 over a 200 mm path) and the interesting systems carry
+// aspheres.  out[] of the moments:
+//   0 sum w   1 sum w X   2 sum w Y   3 sum w XX   4 sum w XY   5 sum w YY
+//   6 sum w o 7 sum w o X 8 sum w o Y      (w = intensity, o = OPD, X/Y = pupil point)
+//   9 #{i > 0}   10 sum o [i > 0]   11 sum o^2 [i > 0]
+// --------------------------------------------------------------------------
+template <typename T, int NR, bool APOD>
+__global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
+    const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
+    const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
+    OpdArgs<T> a) {
+  const RaygenConsts<T> c(a.rg);
+  const WavefrontConsts<T> w(a.wf);
+  const RaygenIn<T>& in_ = a.in;
+  uint32_t status = 0;
+  bool prt_fresh = false;
+  double s[kOpdMoments];
+#pragma unroll
+  for (int k = 0; k < kOpdMoments; ++k) s[k] = 0.0;
+
+  for (int64_t j = (int64_t)blockIdx.x * kTraceBlock + threadIdx.x; j < a.n;
+       j += (int64_t)gridDim.x * kTraceBlock) {
+    T px = in_.px[j], py = in_.py[j];
+    T vx = in_.vx0, vy = in_.vy0, o[6];
+    raygen_pupil<T>(in_.flags, vx, vy, px, py, status);
+    raygen_one<T>(c, in_.tx0, in_.ty0, px, py, vx, vy, o);
+    Ray<T> r[1];
+    r[0].x = o[0]; r[0].y = o[1]; r[0].z = o[2];
+    r[0].L = o[3]; r[0].M = o[4]; r[0].N = o[5];
+    if constexpr (APOD) r[0].i = raygen_apodize<T>(c, px, py); else r[0].i = T(1);
+    r[0].opd = T(0);
+
+    bool is_global = true;
+    DevSurf<T> last_traced;
+    last_traced.cold = cold_tab;
+    Prt<T, 0> P[1];
+    DevSurfHot<T> cur = surf_tab[a.first];
+    for (int sidx = a.first; sidx <= a.last; ++sidx) {
+      DevSurf<T> S;
+      static_cast<DevSurfHot<T>&>(S) = cur;
+      S.cold = cold_tab + sidx;
+      if (sidx < a.last) cur = surf_tab[sidx + 1];
+      if (S.interaction != kRecordOnly) {
+        const DevOptics<T> O = optics_tab[sidx * a.n_wl + a.wl];
+        surface_step<T, 1, 0, NR>(S, O, coeff_tab, is_global, r, P, status, prt_fresh);
+        is_global = false;
+        last_traced = S;
+      }
+    }
+    const Ray<T> g = is_global ? r[0] : to_global<T>(last_traced, r[0]);
+    T pu[3];
+    // the pupil coordinates of the tilt term are the ones the CALLER passed (the
+    // reference corrects with the distribution's points, strategy.py:88-139)
+    const T ov = wavefront_one<T>(w, g.x, g.y, g.z, g.L, g.M, g.N, g.opd, in_.px[j], in_.py[j], pu);
+    a.opd[j] = ov;
+    a.inten[j] = g.i;
+    if (a.pupil[0]) {
+      a.pupil[0][j] = pu[0];
+      a.pupil[1][j] = pu[1];
+      a.pupil[2][j] = pu[2];
+    }
+    const double wi = (double)g.i, od = (double)ov, X = (double)pu[0], Y = (double)pu[1];
+    s[0] += wi; s[1] += wi * X; s[2] += wi * Y;
+    s[3] += wi * X * X; s[4] += wi * X * Y; s[5] += wi * Y * Y;
+    s[6] += wi * od; s[7] += wi * od * X; s[8] += wi * od * Y;
+    if (g.i > T(0)) {
+      s[9] += 1.0;
+      s[10] += od;
+      s[11] += od * od;
+    }
+  }
+
+  // workgroup reduction -> kOpdMoments atomics (every thread reaches this point)
+  __shared__ double part[kTraceBlock / 64][kOpdMoments];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double t[kOpdMoments];
+#pragma unroll
+    for (int k = 0; k < kOpdMoments; ++k) t[k] = __shfl_down(s[k], off, 64);
+#pragma unroll
+    for (int k = 0; k < kOpdMoments; ++k) s[k] += t[k];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < kOpdMoments; ++k) part[wave][k] = s[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < kOpdMoments) {
+    double v = 0;
+    for (int q = 0; q < kTraceBlock / 64; ++q) v += part[q][threadIdx.x];
+    // (a NaN partial sum must reach the output too: v != 0.0 is true for NaN)
+    if (v != 0.0) unsafeAtomicAdd(&a.mom[threadIdx.x], v);
+  }
+  if (status && a.status) atomicOr(a.status, status);
+}
+
+template <typename T>
+hipError_t launch_opd_trace(const OpdArgs<T>& a_in, bool has_newton, hipStream_t stream) {
+  OpdArgs<T> a = a_in;
+  uniform_field_tangents<T>(a.rg, a.in);
+  int64_t blocks = (a.n + kTraceBlock - 1) / kTraceBlock;
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 8192) blocks = 8192;  // grid-stride beyond: keeps the atomics few
+  const bool apod = a.rg.apod_kind != 0;
+#define OL_OPD_LAUNCH(N, A)                                                                  \
+  hipLaunchKernelGGL((opd_trace_kernel<T, N, A>), dim3((unsigned)blocks), dim3(kTraceBlock), \
+                     0, stream, a.surf, a.cold, a.optics, a.coeffs, a)
+  if (has_newton) {
+    if (apod) OL_OPD_LAUNCH(1, true); else OL_OPD_LAUNCH(1, false);
+  } else {
+    if (apod) OL_OPD_LAUNCH(0, true); else OL_OPD_LAUNCH(0, false);
+  }
+#undef OL_OPD_LAUNCH
+  return hipGetLastError();
+}
+
+#if OL_TRACE_TU != 1
+template hipError_t launch_opd_trace<double>(const OpdArgs<double>&, bool, hipStream_t);
 #endif
 
 }  // namespace ol

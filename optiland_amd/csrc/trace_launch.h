@@ -138,6 +138,35 @@ template <typename T>
 hipError_t launch_wavefront(const WavefrontDev& p, int64_t n, const T* const rays[7], const T* px,
                             const T* py, T* opd_waves, T* const pupil[3], hipStream_t stream);
 
+// fused generate -> trace -> OPD kernel (trace_kernel.hip)
+constexpr int kOpdMoments = 12;
+template <typename T>
+struct OpdArgs {
+  const DevSurfHot<T>* surf;
+  const DevSurfCold<T>* cold;
+  const DevOptics<T>* optics;
+  const T* coeffs;
+  RaygenIn<T> in;    // pupil planes; launch-uniform field and vignetting
+  RaygenDev rg;
+  WavefrontDev wf;
+  T* opd;            // OPD in waves per ray
+  T* inten;          // image-plane intensity per ray
+  T* pupil[3];       // optional: reference-surface intersection point (all or none)
+  double* mom;       // kOpdMoments doubles, accumulated (see ol_trace_opd)
+  uint32_t* status;
+  int64_t n;
+  int32_t first, last;
+  int32_t n_wl, wl;
+};
+template <typename T>
+hipError_t launch_opd_trace(const OpdArgs<T>& a, bool has_newton, hipStream_t stream);
+
+template <typename T>
+hipError_t launch_pupil_fill(int64_t n, const T* opd, const T* inten, const T* pupil_x,
+                             const T* pupil_y, const double coef[3], const int32_t* cell,
+                             int32_t n_side, int32_t grid, int32_t pad, double* out,
+                             hipStream_t stream);
+
 template <typename T>
 hipError_t launch_spot_moments(int64_t n, const T* x, const T* y, const T* inten, double* out6,
                                hipStream_t stream);

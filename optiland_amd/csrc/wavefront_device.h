@@ -1,0 +1,59 @@
+// wavefront_device.h -- OPD of ONE image-plane ray against the reference sphere / plane.
+// ONE definition shared by the stand-alone ol_wavefront_opd kernel (aux_kernels.hip) and
+// the fused generate -> trace -> OPD kernel (trace_kernel.hip), so both produce the same
+// numbers.  Reference: wavefront/strategy.py:163-215 (ChiefRayStrategy),
+// wavefront/reference_geometry.py:41-79 (sphere) / 87-128 (plane), strategy.py:83-139
+// (_correct_tilt).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "trace_launch.h"
+
+namespace ol {
+
+template <typename T>
+struct WavefrontConsts {
+  T xc, yc, zc, R, ni, inv_w, ux, uy, half_epd, opd_ref, nx, ny, nz;
+  bool planar;
+  __device__ __forceinline__ explicit WavefrontConsts(const WavefrontDev& p)
+      : xc((T)p.xc), yc((T)p.yc), zc((T)p.zc), R((T)p.R), ni((T)p.n_image),
+        inv_w((T)(1.0 / (p.wavelength_um * 1e-3))), ux((T)p.ux), uy((T)p.uy),
+        half_epd((T)p.half_epd), opd_ref((T)p.opd_ref), nx((T)p.nx), ny((T)p.ny), nz((T)p.nz),
+        planar(p.nx != 0.0 || p.ny != 0.0 || p.nz != 0.0) {}
+};
+
+// (xr, yr, zr), (Ld, Md, Nd), opd_in: the ray at the image surface (global frame);
+// (px, py): its normalised pupil coordinates.  Returns the OPD in waves; pu = the point
+// where the back-propagated ray meets the reference surface.
+template <typename T>
+__device__ __forceinline__ T wavefront_one(const WavefrontConsts<T>& w, T xr, T yr, T zr, T Ld,
+                                           T Md, T Nd, T opd_in, T px, T py, T (&pu)[3]) {
+  const T L = -Ld, M = -Md, N = -Nd;  // trace backwards from the image
+  T t;
+  if (w.planar) {  // reference_geometry.py:104-124
+    const T num = (xr - w.xc) * w.nx + (yr - w.yc) * w.ny + (zr - w.zc) * w.nz;
+    T den = L * w.nx + M * w.ny + N * w.nz;
+    den = fabs(den) < T(1e-12) ? T(1e-12) : den;
+    t = -num / den;
+  } else {
+    const T a = L * L + M * M + N * N;
+    const T b = T(2) * (L * (xr - w.xc) + M * (yr - w.yc) + N * (zr - w.zc));
+    const T c = xr * xr + yr * yr + zr * zr - T(2) * (xr * w.xc + yr * w.yc + zr * w.zc) +
+                w.xc * w.xc + w.yc * w.yc + w.zc * w.zc - w.R * w.R;
+    T d = b * b - T(4) * a * c;
+    d = d < T(0) ? T(0) : d;
+    const T sq = sqrt(d);
+    const T t1 = (-b - sq) / (T(2) * a), t2 = (-b + sq) / (T(2) * a);
+    t = t1 < T(0) ? t2 : t1;
+  }
+  const T opd_img = w.ni * t;
+  const T tilt = w.ux * (px * w.half_epd) + w.uy * (py * w.half_epd);
+  const T opd = opd_in - opd_img + tilt;
+  const T tt = opd_img / w.ni;
+  pu[0] = xr - tt * Ld;
+  pu[1] = yr - tt * Md;
+  pu[2] = zr - tt * Nd;
+  return (w.opd_ref - opd) * w.inv_w;
+}
+
+}  // namespace ol

@@ -363,6 +363,67 @@ class HipSystem:
         _capi.check(rc, "ol_wavefront_opd")
         return opd, pupil
 
+    def trace_opd(self, params: dict, px, py, wl_index: int, *, field, vig=(1.0, 1.0),
+                  want_pupil: bool = True, moments: torch.Tensor | None = None,
+                  check_status: bool = True):
+        """Fused generate -> trace -> OPD (`ol_trace_opd`, fp64): the pupil points
+        (px, py) of ONE field point straight to the OPD map against the reference sphere /
+        plane `params` -- no ray planes.  Returns (opd_waves, intensity, pupil (3, n) or
+        None, moments): `moments` = the 12 device sums of `ol_trace_opd` (tilt-fit moments,
+        count / sum / sum of squares of the OPD over rays with i > 0), accumulated into
+        the tensor passed in (zero it to start) or a fresh one."""
+        p = self._raygen_params()
+        n = int(px.numel())
+        dtype = px.dtype
+        if dtype != torch.float64:
+            raise ValueError("trace_opd: wavefront work is fp64 only")
+        if moments is None:
+            moments = torch.zeros(_capi.OPD_MOMENTS, dtype=torch.float64, device=self.device)
+        opd = torch.empty(n, dtype=dtype, device=self.device)
+        inten = torch.empty(n, dtype=dtype, device=self.device)
+        pupil = torch.empty((3, n), dtype=dtype, device=self.device) if want_pupil else None
+        if n == 0:
+            return opd, inten, pupil, moments
+        inp, keep = self._raygen_inputs(float(field[0]), float(field[1]), px, py,
+                                        float(vig[0]), float(vig[1]), 0)
+        w = _capi.WavefrontParams(**{k: float(params.get(k, 0.0)) for k, _ in
+                                     _capi.WavefrontParams._fields_})
+        pp = (C.c_void_p * 3)(*[pupil[k].data_ptr() for k in range(3)]) if want_pupil else None
+        if check_status:
+            self._status.zero_()
+        with torch.cuda.device(self.device):
+            rc = self.lib.ol_trace_opd(self._handle, _DT[dtype], n, C.byref(p), C.byref(inp),
+                                       C.byref(w), int(wl_index), opd.data_ptr(),
+                                       inten.data_ptr(), pp, moments.data_ptr(),
+                                       self._status.data_ptr(), _stream_ptr(self.device))
+        _capi.check(rc, "ol_trace_opd")
+        if check_status:
+            self.raise_for_status(int(self._status.item()))
+        return opd, inten, pupil, moments
+
+    def pupil_fill(self, opd, intensity, cell: torch.Tensor, n_side: int, grid_size: int,
+                   pupil_xy=None, plane=None) -> torch.Tensor:
+        """`ol_pupil_fill`: A exp(-i 2 pi OPD) of the compacted samples scattered into the
+        zero-padded (grid_size, grid_size) complex128 FFT grid (psf/fft.py:101-160);
+        `cell` = int32 row-major cell index of every sample in the n_side x n_side sample
+        grid; `pupil_xy` + `plane` = (a, b, c): subtract a + b X + c Y (tilt removal)."""
+        n = int(opd.numel())
+        if cell.dtype != torch.int32 or cell.numel() != n or cell.device != self.device:
+            raise ValueError("pupil_fill: cell must be an int32 device tensor, one entry per sample")
+        grid = torch.zeros((grid_size, grid_size), dtype=torch.complex128, device=self.device)
+        co = None
+        px_ptr = py_ptr = None
+        if pupil_xy is not None:
+            co = (C.c_double * 3)(*[float(v) for v in plane])
+            px_ptr, py_ptr = pupil_xy[0].data_ptr(), pupil_xy[1].data_ptr()
+        with torch.cuda.device(self.device):
+            rc = self.lib.ol_pupil_fill(_DT[opd.dtype], n, opd.data_ptr(), intensity.data_ptr(),
+                                        px_ptr, py_ptr, co, cell.contiguous().data_ptr(),
+                                        int(n_side), int(grid_size), grid.data_ptr(),
+                                        _stream_ptr(self.device))
+        _capi.check(rc, "ol_pupil_fill")
+        return grid
+
     def trace_spot(self, px, py, wl_index: int, *, field=None, hx=None, hy=None, vig=(1.0, 1.0),
                    vx=None, vy=None, center=(0.0, 0.0), hits=None, out=None,
                    check_status: bool = True, flags: int = 0):

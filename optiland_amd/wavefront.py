@@ -25,11 +25,14 @@ from .distribution import create_distribution
 
 
 class WavefrontData:
-    """wavefront/wavefront_data.py:10-38."""
+    """wavefront/wavefront_data.py:10-38 (+ the device-side sums of the fused kernel)."""
 
-    def __init__(self, pupil_x, pupil_y, pupil_z, opd, intensity, radius):
+    def __init__(self, pupil_x, pupil_y, pupil_z, opd, intensity, radius, moments=None):
         self.pupil_x, self.pupil_y, self.pupil_z = pupil_x, pupil_y, pupil_z
         self.opd, self.intensity, self.radius = opd, intensity, radius
+        # `ol_trace_opd`'s 12 sums (tilt-fit moments; count / sum / sum of squares of the OPD
+        # over rays with i > 0) of the OPD as first computed -- None on the un-fused path
+        self.moments = moments
 
 
 class Wavefront:
@@ -37,7 +40,8 @@ class Wavefront:
 
     def __init__(self, tracer, field, wavelength, num_rays: int = 12,
                  distribution="hexapolar", strategy: str = "chief_ray",
-                 remove_tilt: bool = False, robust_trim_std: float = 3.0, afocal: bool = False):
+                 remove_tilt: bool = False, robust_trim_std: float = 3.0, afocal: bool = False,
+                 fused: bool | None = None):
         # wavefront/strategy.py:606-616 (incl. the backward-compatible aliases)
         strategy = {"centroid_sphere": "centroid", "best_fit_sphere": "best_fit"}.get(strategy,
                                                                                        strategy)
@@ -54,6 +58,14 @@ class Wavefront:
         if "pupil_z" not in rg or "n_image" not in rg:
             raise ValueError("this SystemTable carries no exit-pupil data")
         self.tracer = tracer
+        # fused generate -> trace -> OPD kernel (`ol_trace_opd`): chief-ray strategy on an
+        # unpolarised system; None = use it whenever it applies
+        can_fuse = (strategy == "chief_ray" and tracer.table.polarization is None
+                    and not tracer.table.uses_polarization
+                    and hasattr(tracer.engine, "trace_opd"))
+        if fused and not can_fuse:
+            raise ValueError("fused OPD needs the chief-ray strategy on an unpolarised system")
+        self.fused = can_fuse if fused is None else bool(fused)
         self.field = (float(field[0]), float(field[1]))
         self.wavelength = float(wavelength)
         self.num_rays = num_rays
@@ -68,16 +80,20 @@ class Wavefront:
     @staticmethod
     def fit_and_remove_tilt(data, remove_piston: bool = False, ridge: float = 1e-12):
         """Weighted plane fit of the OPD over the pupil, subtracted (wavefront.py:103-148;
-        the piston only with `remove_piston`).  Formulated as what it is on a device: ONE
-        pass that reduces the nine weighted moments
+        the piston only with `remove_piston`).  Formulated as what it is on a device: the
+        nine weighted moments
             S = sum w [1, x, y, xx, xy, yy],   T = sum w opd [1, x, y]
-        (a (9, n) x (n,) product, a single reduction kernel), the symmetric 3x3 normal
-        system (+ ridge on the diagonal, as the reference regularises) solved on the host
-        in closed form, and one fused elementwise pass for the residual."""
+        -- straight out of the fused kernel's epilogue (`data.moments`), or one (9, n) x (n,)
+        reduction on the un-fused path -- the symmetric 3x3 normal system (+ ridge on the
+        diagonal, as the reference regularises) solved on the host in closed form, and one
+        elementwise pass for the residual."""
         x, y, w, opd = data.pupil_x, data.pupil_y, data.intensity, data.opd
-        basis = torch.stack([torch.ones_like(x), x, y, x * x, x * y, y * y,
-                             opd, opd * x, opd * y])
-        m = (basis @ w.to(basis.dtype)).double().cpu().numpy()   # nine moments, one read-back
+        if getattr(data, "moments", None) is not None:
+            m = data.moments[:9].double().cpu().numpy()
+        else:
+            basis = torch.stack([torch.ones_like(x), x, y, x * x, x * y, y * y,
+                                 opd, opd * x, opd * y])
+            m = (basis @ w.to(basis.dtype)).double().cpu().numpy()   # one read-back
         A = np.array([[m[0], m[1], m[2]], [m[1], m[3], m[4]], [m[2], m[4], m[5]]]) \
             + ridge * np.eye(3)
         a0, bx, cy = np.linalg.solve(A, m[6:9])
@@ -122,6 +138,12 @@ class Wavefront:
         neg, _ = t.engine.wavefront_opd(params, c7, zero, zero, want_pupil=False)
         params["opd_ref"] = -float(neg[0]) * self.wavelength * 1e-3
         # 2. the full pupil (strategy.py:190-205)
+        if self.fused:  # one launch: pupil points -> OPD map + its reductions, no ray planes
+            px, py = t._dev(self.distribution.x), t._dev(self.distribution.y)
+            wl, _ = t._wavelength_index(self.wavelength)
+            opd, intensity, pupil, mom = t.engine.trace_opd(
+                params, px, py, wl, field=(hx, hy), vig=t._vig_scalar(hx, hy), want_pupil=True)
+            return WavefrontData(pupil[0], pupil[1], pupil[2], opd, intensity, R, moments=mom)
         # the intensity the reference reads is the RECORDED image-plane row
         # (wavefront/strategy.py:198: surfaces.intensity[-1], i.e. before a polarised
         # update_intensity): record-all is forced for this trace whatever the caller set
@@ -230,6 +252,11 @@ class OPD(Wavefront):
     def rms(self) -> float:
         """opd.py:145-159."""
         d = self.data
+        if d.moments is not None and not self.remove_tilt:
+            cnt, _s1, s2 = (float(v) for v in d.moments[9:12])  # epilogue of the fused kernel
+            if cnt == 0:
+                raise ValueError("No valid rays with non-zero intensity for RMS calculation.")
+            return math.sqrt(s2 / cnt)
         mask = d.intensity > 0
         if not bool(mask.any()):
             raise ValueError("No valid rays with non-zero intensity for RMS calculation.")
@@ -262,28 +289,34 @@ class FFTPSF:
         self.psf = self._compute_psf()
 
     def _generate_pupil(self) -> torch.Tensor:
-        """psf/fft.py:101-137: A exp(-i 2 pi OPD) on the num_rays^2 grid, 0 off-disc."""
+        """psf/fft.py:101-137: A exp(-i 2 pi OPD) on the num_rays^2 grid, 0 off-disc --
+        written straight into the zero-padded FFT grid by `ol_pupil_fill` (self._padded);
+        the n x n block is returned as a view."""
         d = self.wavefront.data
-        n = self.num_rays
+        n, gsz = self.num_rays, self.grid_size
         # the disc mask comes from the SAME arithmetic that placed the traced samples
         # (distribution._uniform: np.linspace + np.meshgrid, row-major ravel) -- a
         # torch.linspace grid differs by an ulp on boundary points such as (0.6, 0.8)
         # and would select a different number of cells for many odd n
         g = np.linspace(-1.0, 1.0, n)
         xg, yg = np.meshgrid(g, g)
-        inside = torch.from_numpy((xg**2 + yg**2 <= 1).reshape(-1)).to(d.opd.device)
-        P = torch.zeros(n * n, dtype=torch.complex128, device=d.opd.device)
-        amp = torch.sqrt(d.intensity)
-        P[inside] = amp * torch.exp(-2j * math.pi * d.opd)
-        return P.reshape(n, n)
+        cells = np.flatnonzero((xg**2 + yg**2 <= 1).reshape(-1)).astype(np.int32)
+        before = (gsz - n) // 2
+        eng = self.wavefront.tracer.engine
+        if hasattr(eng, "pupil_fill"):
+            cell = torch.from_numpy(cells).to(d.opd.device)
+            self._padded = eng.pupil_fill(d.opd, d.intensity, cell, n, gsz)
+        else:  # engines without the kernel (older stand-ins): plain tensor ops
+            P = torch.zeros(n * n, dtype=torch.complex128, device=d.opd.device)
+            P[torch.from_numpy(cells.astype(np.int64)).to(d.opd.device)] = \
+                torch.sqrt(d.intensity) * torch.exp(-2j * math.pi * d.opd)
+            after = before + (gsz - n) % 2
+            self._padded = torch.nn.functional.pad(P.reshape(n, n), (before, after, before, after))
+        return self._padded[before:before + n, before:before + n]
 
     def _compute_psf(self) -> torch.Tensor:
-        """psf/fft.py:139-200: pad, FFT (rocFFT), |.|^2, Strehl normalisation."""
-        n, gsz = self.num_rays, self.grid_size
-        before = (gsz - n) // 2
-        after = before + (gsz - n) % 2
-        padded = torch.nn.functional.pad(self.pupil, (before, after, before, after))
-        amp = torch.fft.fftshift(torch.fft.fft2(padded))
+        """psf/fft.py:139-200: (padded pupil) FFT (rocFFT), |.|^2, Strehl normalisation."""
+        amp = torch.fft.fftshift(torch.fft.fft2(self._padded))
         norm = float((self.pupil.abs() > 0).sum()) ** 2
         return (amp * amp.conj()).real / norm * 100
 

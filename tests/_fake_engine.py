@@ -133,6 +133,39 @@ class OracleEngine:
         return (torch.as_tensor(out, dtype=px.dtype),
                 torch.as_tensor(pupil, dtype=px.dtype) if want_pupil else None)
 
+    def trace_opd(self, params, px, py, wl_index, *, field, vig=(1.0, 1.0), want_pupil=True,
+                  moments=None, check_status=True):
+        """ol_trace_opd as the composition of the oracle's generate -> trace -> OPD."""
+        n = int(px.numel())
+        rays = self.generate_rays(float(field[0]), float(field[1]), px, py, float(vig[0]),
+                                  float(vig[1])) + [torch.zeros(n, dtype=px.dtype)]
+        self.trace(rays, wl_index, record=False)
+        r7 = [rays[k] for k in (0, 1, 2, 3, 4, 5, 7)]
+        opd, pupil = self.wavefront_opd(params, r7, px, py, want_pupil=True)
+        inten = rays[6].clone()
+        w, o, X, Y = inten.double(), opd.double(), pupil[0].double(), pupil[1].double()
+        alive = w > 0
+        got = torch.stack([w.sum(), (w * X).sum(), (w * Y).sum(), (w * X * X).sum(),
+                           (w * X * Y).sum(), (w * Y * Y).sum(), (w * o).sum(),
+                           (w * o * X).sum(), (w * o * Y).sum(), alive.double().sum(),
+                           o[alive].sum(), (o[alive] ** 2).sum()])
+        if moments is None:
+            moments = torch.zeros(12, dtype=torch.float64)
+        moments += got
+        return opd, inten, (pupil if want_pupil else None), moments
+
+    def pupil_fill(self, opd, intensity, cell, n_side, grid_size, pupil_xy=None, plane=None):
+        o = opd.double()
+        if pupil_xy is not None:
+            o = o - (plane[0] + plane[1] * pupil_xy[0].double() + plane[2] * pupil_xy[1].double())
+        val = torch.sqrt(intensity.double()) * torch.exp(-2j * np.pi * o)
+        grid = torch.zeros((grid_size, grid_size), dtype=torch.complex128)
+        pad = (grid_size - n_side) // 2
+        r = torch.div(cell.long(), n_side, rounding_mode="floor")
+        c = cell.long() - r * n_side
+        grid[r + pad, c + pad] = val
+        return grid
+
     def trace_spot(self, px, py, wl_index, *, field=None, hx=None, hy=None, vig=(1.0, 1.0),
                    vx=None, vy=None, center=(0.0, 0.0), hits=None, out=None, check_status=True,
                    flags=0):
