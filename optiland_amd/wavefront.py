@@ -303,10 +303,10 @@ class FFTPSF:
         cells = np.flatnonzero((xg**2 + yg**2 <= 1).reshape(-1)).astype(np.int32)
         before = (gsz - n) // 2
         eng = self.wavefront.tracer.engine
-        if hasattr(eng, "pupil_fill"):
+        if self.wavefront.fused and hasattr(eng, "pupil_fill"):
             cell = torch.from_numpy(cells).to(d.opd.device)
             self._padded = eng.pupil_fill(d.opd, d.intensity, cell, n, gsz)
-        else:  # engines without the kernel (older stand-ins): plain tensor ops
+        else:  # un-fused path (polarised systems, other strategies, A/B): plain tensor ops
             P = torch.zeros(n * n, dtype=torch.complex128, device=d.opd.device)
             P[torch.from_numpy(cells.astype(np.int64)).to(d.opd.device)] = \
                 torch.sqrt(d.intensity) * torch.exp(-2j * math.pi * d.opd)
