@@ -1427,14 +1427,41 @@ __device__ __forceinline__ T vec_get(const typename VecOf<T, RPT>::type& v, int 
   return v[k];  // ext_vector_type(1) is still a vector
 }
 
-template <typename T, int RPT>
-__device__ __forceinline__ void store_plane(T* __restrict__ p, int64_t base, int cnt,
+// Index of a lane's first ray, split into the workgroup-uniform tile start and the 32-bit
+// offset of the lane inside the tile.  With SADDR, `at(p)` = (p + tile) + lane lets the
+// compiler address every plane access as SGPR base + 32-bit VGPR offset
+// (global_store_dword v_off, v, s[b:b+1]) -- ONE lane offset shared by all planes --
+// instead of forming a 64-bit per-lane address with a v_lshl_add_u64 per load / store.
+// Same-box A/B (profiles/r02_ab_addr.txt): the VALU-bound polarised kernels gain 1.5 %
+// (33 fewer vector instructions per ray), the HBM-bound record-all kernels LOSE 0-1.7 %
+// (fp64 most: the scalar address chain sits in front of every store) -- so the form is
+// chosen per instantiation: SADDR for POLK != 0 only.
+#ifndef OL_SADDR
+#define OL_SADDR 1
+#endif
+template <bool SADDR>
+struct RayIndexT {
+  int64_t tile;   // wave-uniform
+  uint32_t lane;  // < kTraceBlock * RPT (or the re-traced last ray of the SPOT variant)
+  __device__ __forceinline__ int64_t full() const { return tile + (int64_t)lane; }
+  template <typename P>
+  __device__ __forceinline__ P* at(P* p) const {
+    if constexpr (SADDR)
+      return (p + tile) + lane;
+    else
+      return p + (tile + (int64_t)lane);
+  }
+};
+
+template <typename T, int RPT, typename RayIndex>
+__device__ __forceinline__ void store_plane(T* __restrict__ p, RayIndex base, int cnt,
                                             const T (&in)[RPT]) {
+  T* q = base.at(p);
   if constexpr (RPT == 1) {
 #if OL_NT_SCALAR
-    __builtin_nontemporal_store(in[0], p + base);
+    __builtin_nontemporal_store(in[0], q);
 #else
-    p[base] = in[0];
+    *q = in[0];
 #endif
   } else {
     using V = typename VecOf<T, RPT>::type;
@@ -1445,19 +1472,19 @@ __device__ __forceinline__ void store_plane(T* __restrict__ p, int64_t base, int
       // 8-byte lane vectors behave like the scalar fp64 stores (non-temporal wins);
       // 16-byte ones prefer plain stores
       if constexpr (OL_NT_VECTOR || sizeof(V) <= 8)
-        __builtin_nontemporal_store(v, reinterpret_cast<V*>(p + base));
+        __builtin_nontemporal_store(v, reinterpret_cast<V*>(q));
       else
-        *reinterpret_cast<V*>(p + base) = v;
+        *reinterpret_cast<V*>(q) = v;
     } else {
 #pragma unroll
       for (int k = 0; k < RPT; ++k)
-        if (k < cnt) p[base + k] = in[k];
+        if (k < cnt) q[k] = in[k];
     }
   }
 }
 
-template <typename T, int RPT>
-__device__ __forceinline__ void store_rays(T* __restrict__ row, int64_t stride, int64_t base,
+template <typename T, int RPT, typename RayIndex>
+__device__ __forceinline__ void store_rays(T* __restrict__ row, int64_t stride, RayIndex base,
                                            int cnt, const Ray<T> (&g)[RPT]) {
   T tmp[RPT];
 #define OL_STORE_FIELD(idx, fld)                         \
@@ -1613,14 +1640,15 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
   // ray (identical values to identical addresses, no predicate anywhere in the hot
   // loop -- a per-lane "live" guard around the stores cost 20 %), vector lanes take
   // the ragged-tail path with zero rays; either way they are masked out of the sums.
-  int64_t base = ((int64_t)blockIdx.x * kTraceBlock + threadIdx.x) * RPT;
-  const bool live = base < a.n;
+  using RayIndex = RayIndexT<(OL_SADDR != 0) && POLK != 0>;
+  RayIndex base{(int64_t)blockIdx.x * (kTraceBlock * RPT), (uint32_t)threadIdx.x * RPT};
+  const bool live = base.full() < a.n;
   if constexpr (!SPOT) {
     if (!live) return;
   } else if (RPT == 1 && !live) {
-    base = a.n - 1;
+    base.lane = (uint32_t)(a.n - 1 - base.tile);
   }
-  const int64_t left = a.n - base;
+  const int64_t left = a.n - base.full();
   // (one ray per lane: always exactly one ray -- said outright, so that the SPOT
   // variant's loads and stores stay as unpredicated as the plain kernel's)
   const int cnt = RPT == 1 ? 1 : (left >= RPT ? RPT : (left > 0 ? (int)left : 0));
@@ -1641,13 +1669,13 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
       using V = typename VecOf<T, RPT>::type;
       V v[8];
 #pragma unroll
-      for (int f = 0; f < 8; ++f) v[f] = *reinterpret_cast<const V*>(a.rays[f] + base);
+      for (int f = 0; f < 8; ++f) v[f] = *reinterpret_cast<const V*>(base.at(a.rays[f]));
       if constexpr (POLK != 0) {
         if (!(a.flags & kTracePrtIdentity)) {
           V pv[NPRT];
 #pragma unroll
           for (int e = 0; e < NPRT; ++e)
-            pv[e] = *reinterpret_cast<const V*>(a.prt + (int64_t)e * a.n + base);
+            pv[e] = *reinterpret_cast<const V*>(base.at(a.prt + (int64_t)e * a.n));
 #pragma unroll
           for (int e = 0; e < NPRT; ++e)
 #pragma unroll
@@ -1662,14 +1690,14 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
 #pragma unroll
       for (int f = 0; f < 8; ++f)
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) in[f][k] = k < cnt ? a.rays[f][base + k] : T(0);
+        for (int k = 0; k < RPT; ++k) in[f][k] = k < cnt ? base.at(a.rays[f])[k] : T(0);
       if constexpr (POLK != 0) {
         if (!(a.flags & kTracePrtIdentity)) {
 #pragma unroll
           for (int e = 0; e < NPRT; ++e)
 #pragma unroll
             for (int k = 0; k < RPT; ++k)
-              pin[e][k] = k < cnt ? a.prt[(int64_t)e * a.n + base + k] : T(0);
+              pin[e][k] = k < cnt ? base.at(a.prt + (int64_t)e * a.n)[k] : T(0);
         }
       }
     }
@@ -2044,9 +2072,10 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
       if (k < cnt) acc.add(g.x, g.y, g.i, a.cx, a.cy);
     }
     if (a.hits[0] != nullptr && cnt > 0) {
-      store_plane<T, RPT>(a.hits[0], base, cnt, hx_);
-      store_plane<T, RPT>(a.hits[1], base, cnt, hy_);
-      store_plane<T, RPT>(a.hits[2], base, cnt, hi_);
+      const RayIndexT<false> at{tile * (kTraceBlock * RPT), (uint32_t)threadIdx.x * RPT};
+      store_plane<T, RPT>(a.hits[0], at, cnt, hx_);
+      store_plane<T, RPT>(a.hits[1], at, cnt, hy_);
+      store_plane<T, RPT>(a.hits[2], at, cnt, hi_);
     }
   }
 

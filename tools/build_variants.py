@@ -28,6 +28,9 @@ VARIANTS = {
     # register-allocator occupancy request for the fp32 polarised Newton kernel (C5)
     "polnr_waves7": ["-DOL_POLNR_WAVES=7"],
     "polnr_waves8": ["-DOL_POLNR_WAVES=8"],
+    # plane accesses addressed per lane with 64-bit VGPR addresses (round-1 form) instead of
+    # SGPR base + one shared 32-bit lane offset
+    "vaddr": ["-DOL_SADDR=0"],
 }
 
 
