@@ -12,7 +12,8 @@ listed in .gitignore (never part of the history, never read by anything under
 exactly like the built `.so` files do.  `__graft_entry__.build()` runs this whenever
 /root/reference is present.
 
-Nothing is modified: a plain file copy of `optiland/` minus byte-code caches.  The
+Nothing is modified: a plain file copy of `optiland/` (and of the reference's `tests/`, so
+that its own consumer tests can run on the GPU through the drop-in) minus byte-code caches.  The
 import stubs for the three packages the image lacks (numba / vtk / seaborn) are this
 repo's own files under tests/refshim/.
 """
@@ -46,12 +47,21 @@ def stage(src: str = "/root/reference", force: bool = False, verbose: bool = Tru
     out = os.path.join(DEST, "optiland")
     stamp = os.path.join(DEST, ".staged_from")
     if not force and os.path.isdir(out) and os.path.exists(stamp) \
+            and os.path.isdir(os.path.join(DEST, "tests")) == os.path.isdir(os.path.join(src, "tests")) \
             and os.path.getmtime(stamp) >= _newest(pkg):
         return DEST
     if os.path.isdir(out):
         shutil.rmtree(out)
     os.makedirs(DEST, exist_ok=True)
     shutil.copytree(pkg, out, ignore=shutil.ignore_patterns("__pycache__", "*.pyc"))
+    # the reference's own test-suite (1.9 MB): run on the GPU box through the drop-in
+    # (tests/test_gpu_live_reference.py::test_reference_consumer_suite_on_device)
+    tests_src, tests_out = os.path.join(src, "tests"), os.path.join(DEST, "tests")
+    if os.path.isdir(tests_src):
+        if os.path.isdir(tests_out):
+            shutil.rmtree(tests_out)
+        shutil.copytree(tests_src, tests_out,
+                        ignore=shutil.ignore_patterns("__pycache__", "*.pyc", "gui"))
     with open(stamp, "w") as f:
         f.write(os.path.abspath(src) + "\n")
     if verbose:
@@ -60,4 +70,5 @@ def stage(src: str = "/root/reference", force: bool = False, verbose: bool = Tru
 
 
 if __name__ == "__main__":
-    stage(*(sys.argv[1:2] or ["/root/reference"]), force="--force" in sys.argv)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    stage(*(args[:1] or ["/root/reference"]), force="--force" in sys.argv)

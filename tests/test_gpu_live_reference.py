@@ -258,3 +258,34 @@ def test_reference_spot_diagram_consumer_on_device(be, precision):
         be.set_precision("float64")
         be.set_device("cpu")
         be.set_backend("numpy")
+
+
+def test_reference_consumer_suite_on_device(be):
+    """The reference's OWN tests of the consumers of the path -- tests/test_optic.py,
+    test_analysis.py (spot diagrams, encircled energy, ray fans, distortion ...),
+    test_wavefront.py, test_fft_psf.py: 182 torch-backend tests -- executed on the GPU box
+    with `be.set_device("cuda")` and `integration.enable()`: every real-ray trace inside
+    them runs through the HIP kernels and their hard-coded expectations still hold.
+    Measured with tools/gpu_ref_consumers.py (profiles/r02_reference_consumers_on_device.txt):
+    stock torch backend on cuda 2 failed / 180 passed in 106 s; with the drop-in the SAME 2
+    (a KeyError of the reference itself -- device tensors as dict keys, test_wavefront.py:51)
+    / 180 passed in 31 s, 300 device tables created.  Here only the drop-in run is repeated;
+    failures outside that known pair fail the test."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir(os.path.join(root, "oracle", "_ref", "tests")):
+        pytest.skip("reference tests not staged (oracle/stage_reference.py)")
+    spec = importlib.util.spec_from_file_location(
+        "_ol_ref_consumers", os.path.join(root, "tools", "gpu_ref_consumers.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    failed, tail, out = mod.run(True)
+    summary = [l for l in tail if " passed" in l]
+    assert summary, out.stdout[-3000:]
+    n_pass = int(summary[-1].split(" passed")[0].split()[-1])
+    assert n_pass >= 175, summary
+    made = [l for l in tail if "device tables created" in l]
+    assert made and int(made[-1].split("created:")[1].split()[0]) > 100, tail
+    unknown = [f for f in failed if "test_wavefront.py" not in f]
+    assert not unknown and len(failed) <= 2, (sorted(failed), out.stdout[-3000:])

@@ -287,3 +287,61 @@ def test_fused_opd_refusals():
         OPD(t, (0.0, 0.0), 0.55, fused=True)
     hip.close()
     t.engine.close()
+
+
+def _opd_capable_goldens():
+    from tests._util import golden_cases, load_case_table
+    out = []
+    for c in golden_cases():
+        if not (c.startswith("sample_") or c.startswith("fuzz_")):
+            continue
+        t = load_case_table(c)
+        if t.raygen and "pupil_z" in t.raygen and t.polarization is None \
+                and not t.uses_polarization:
+            out.append(c)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _opd_capable_goldens())
+def test_fused_opd_on_every_sample_and_fuzz_lens(case):
+    """Breadth: the fused kernel on every unpolarised lens of optiland.samples and of the
+    frozen fuzz set that carries exit-pupil data (real prescriptions, stops in odd places,
+    aspheres, tilts, vignetting, object-height fields ...), two fields each, against the
+    converged oracle composition."""
+    import copy
+    from tests._fake_engine import OracleEngine
+    from tests._util import load_case_table
+    table = load_case_table(case)
+    conv = copy.deepcopy(table)
+    newton = bool(np.any(conv.surfaces["max_iter"] > 0))
+    conv.surfaces["tol"] = np.where(conv.surfaces["max_iter"] > 0, 1e-13, conv.surfaces["tol"])
+    real = tr.HipRayTracer(table, "cuda:0", dtype=torch.float64)
+    fake = tr.HipRayTracer(conv, "cpu", dtype=torch.float64, engine=OracleEngine(conv, "cpu"))
+    w = float(table.wavelengths[0])
+    try:
+        for field in ((0.0, 0.0), (0.0, 0.6)):
+            try:
+                b = OPD(fake, field, w, num_rays=6, fused=True)
+            except ValueError as exc:   # e.g. Zernike range error: must be raised on both sides
+                with pytest.raises(ValueError, match=str(exc)[:30]):
+                    OPD(real, field, w, num_rays=6, fused=True)
+                continue
+            a = OPD(real, field, w, num_rays=6, fused=True)
+            ob, oa = b.data.opd.numpy(), a.data.opd.cpu().numpy()
+            assert np.array_equal(np.isnan(oa), np.isnan(ob)), case
+            fin = np.isfinite(ob)
+            scale = max(1.0, float(np.abs(ob[fin]).max())) if fin.any() else 1.0
+            # an OPD is a difference of two path lengths: rounding at 1e-12 of the PATH
+            # (57 m in the Hubble sample = 1e8 waves) is its floor, whatever its own size
+            z = table.surfaces["origin"][:, 2]
+            z = z[np.isfinite(z)]
+            path_waves = float(np.abs(np.diff(z)).sum()) / (w * 1e-3)
+            np.testing.assert_allclose(oa[fin], ob[fin], rtol=0,
+                                       atol=(5e-5 if newton else 5e-7) * scale + 3e-12 * path_waves,
+                                       err_msg=case)
+            ia, ib = a.data.intensity.cpu().numpy(), b.data.intensity.numpy()
+            assert np.array_equal(ia == 0, ib == 0), case
+            np.testing.assert_allclose(ia, ib, rtol=1e-8, atol=1e-12, equal_nan=True)
+    finally:
+        real.engine.close()
