@@ -152,6 +152,8 @@ def _make_tracer_class():
             self._hip_engine = None  # most recently used (introspection)
             self._hip_table = None
             self.pack_count = 0      # packs really performed (introspection for tests)
+            self.speculative_hits = 0    # launches queued before the change check, kept
+            self.speculative_misses = 0  # ... dropped because the optic had changed
             self.last_path = None  # "hip" | "reference" (introspection for tests)
 
         def __deepcopy__(self, memo):
@@ -282,44 +284,94 @@ def _make_tracer_class():
                     _state_dict(self.optic.polarization_state))
             return out
 
-        def trace(self, Hx, Hy, wavelength, num_rays=100, distribution="hexapolar"):
-            if not self._eligible():
-                self.last_path = "reference"
-                return _ORIGINALS["trace"](self, Hx, Hy, wavelength, num_rays, distribution)
+        def _speculate(self, wavelength):
+            """(front, table, token, w) of the table memoised for this wavelength, NOT yet
+            validated against the live optic -- or None when there is nothing to gamble on."""
+            if not _fp.ENABLED:
+                return None
+            w = float(wavelength.item()) if hasattr(wavelength, "item") else float(wavelength)
+            memo = self._hip_memo.get(w)
+            if memo is None or isinstance(memo[2], UnsupportedSystem):
+                return None
+            hit = self._hip_engines.get(memo[2])
+            if hit is None or not hit[1].raygen:
+                return None
+            eng, table, fronts = hit
+            dtype = self._dtype()
+            front = fronts.get(dtype)
+            if front is None:
+                front = fronts[dtype] = _tracer.HipRayTracer(table, dtype=dtype, engine=eng)
+            front.ray_aiming_config = self.ray_aiming_config
+            return front, table, memo[0], w
+
+        def _run(self, wavelength, call, update_intensity, original):
+            """One intercepted trace.  `call(front)` performs the device call sequence on a
+            `HipRayTracer`; `original()` is the reference's own method.
+
+            The launch is SPECULATIVE when a table is memoised for this wavelength: the
+            kernels are queued on it at once and the change check of the live optic
+            (fingerprint.optic_token, ~0.1 ms of pure host work) runs while the GPU traces;
+            only then comes the one status read-back.  If the optic did change, the results
+            of that launch are dropped (they live in a fresh block nobody has seen) and the
+            call is repeated on a re-packed table."""
+            spec = self._speculate(wavelength)
+            if spec is not None:
+                front, table, tok0, w = spec
+                mine = err = None
+                front.defer_checks = True
+                try:
+                    mine = call(front)
+                except Exception as exc:  # noqa: BLE001 - judged after the change check
+                    err = exc
+                finally:
+                    front.defer_checks = False
+                tok, _keep = _fp.optic_token(self.optic, w)
+                if tok == tok0:
+                    self.speculative_hits += 1
+                    self._hip_engine, self._hip_table = front.engine, table
+                    if err is not None:
+                        raise err
+                    front.check_status()
+                    self.last_path = "hip"
+                    return self._finish(front, table, mine, wavelength, update_intensity)
+                self.speculative_misses += 1
             try:
                 front, table = self._front_for(wavelength)
             except UnsupportedSystem:
                 self.last_path = "reference"
-                return _ORIGINALS["trace"](self, Hx, Hy, wavelength, num_rays, distribution)
+                return original()
             if not table.raygen:
                 # aiming mode / field type outside the device generator: the reference
                 # builds the rays, its surface loop enters the HIP path through the
                 # SurfaceGroup.trace seam (when enable() / install() patched it)
                 self.last_path = "reference-rays"
-                return _ORIGINALS["trace"](self, Hx, Hy, wavelength, num_rays, distribution)
-            if not isinstance(distribution, str):
-                distribution = _PupilPoints(distribution)
-            mine = front.trace(_host_or_device(Hx), _host_or_device(Hy), wavelength, num_rays,
-                               distribution, update_intensity=False)
+                return original()
+            mine = call(front)
             self.last_path = "hip"
-            return self._finish(front, table, mine, wavelength, update_intensity=True)
+            return self._finish(front, table, mine, wavelength, update_intensity)
 
-        def trace_generic(self, Hx, Hy, Px, Py, wavelength):
+        def trace(self, Hx, Hy, wavelength, num_rays=100, distribution="hexapolar"):
+            def original():
+                return _ORIGINALS["trace"](self, Hx, Hy, wavelength, num_rays, distribution)
             if not self._eligible():
                 self.last_path = "reference"
+                return original()
+            dist = distribution if isinstance(distribution, str) else _PupilPoints(distribution)
+            hx, hy = _host_or_device(Hx), _host_or_device(Hy)
+            return self._run(wavelength,
+                             lambda front: front.trace(hx, hy, wavelength, num_rays, dist,
+                                                       update_intensity=False),
+                             True, original)
+
+        def trace_generic(self, Hx, Hy, Px, Py, wavelength):
+            def original():
                 return _ORIGINALS["trace_generic"](self, Hx, Hy, Px, Py, wavelength)
-            try:
-                front, table = self._front_for(wavelength)
-            except UnsupportedSystem:
+            if not self._eligible():
                 self.last_path = "reference"
-                return _ORIGINALS["trace_generic"](self, Hx, Hy, Px, Py, wavelength)
-            if not table.raygen:
-                self.last_path = "reference-rays"
-                return _ORIGINALS["trace_generic"](self, Hx, Hy, Px, Py, wavelength)
-            mine = front.trace_generic(*(_host_or_device(v) for v in (Hx, Hy, Px, Py)),
-                                       wavelength)
-            self.last_path = "hip"
-            return self._finish(front, table, mine, wavelength, update_intensity=False)
+                return original()
+            args = [_host_or_device(v) for v in (Hx, Hy, Px, Py)]
+            return self._run(wavelength, lambda front: front.trace_generic(*args, wavelength),
+                             False, original)
 
     # the reference's own implementations, captured before enable() can patch them
     _ORIGINALS["trace"] = RealRayTracer.trace

@@ -71,6 +71,10 @@ class HipRayTracer:
         self.surfaces = RecordedSurfaces()
         self.ray_aiming_config = {"mode": "paraxial", "max_iter": 10, "tol": 1e-6}
         self.record_all = True  # drop-in semantics; False = image plane only
+        # True: launches return without the status read-back (the one sync of a call);
+        # the caller does `check_status()` itself -- integration.py overlaps its change
+        # check of the live optic with the kernels this way
+        self.defer_checks = False
         self._pupil_cache = {}  # (distribution name, num_rays) -> device planes
         f = np.asarray(table.fields, dtype=np.float64).reshape(-1, 4)
         self._fields = f
@@ -223,7 +227,8 @@ class HipRayTracer:
         deferred = hasattr(eng, "_status")
         kw = {"defer_status": True, "zero_status": zero_status} if deferred else {}
         res = eng.trace(rays, wl, record=record, prt=prt, prt_identity=prt is not None, **kw)
-        self._finish_checks(eng)
+        if not self.defer_checks:
+            self._finish_checks(eng)
         self.surfaces._bind(res)
         if res.record is not None:
             fin = res.rows(res.last)

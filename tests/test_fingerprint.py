@@ -72,6 +72,9 @@ def test_untouched_optics_are_packed_once(be):
         if t.last_path != "hip":
             continue  # a sample the fused path leaves to the reference
         assert t.pack_count == len(ws), (cname, t.pack_count)
+        # every call after the first of a wavelength was launched speculatively and kept
+        assert t.speculative_hits == 6 * len(ws) - len(ws) and t.speculative_misses == 0, \
+            (cname, t.speculative_hits, t.speculative_misses)
         checked += 1
     assert checked >= 20
 
@@ -143,7 +146,7 @@ def test_every_mutation_is_seen(be):
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
     for name, mutate in _mutations(be):
-        before = t_memo.pack_count
+        before, missed = t_memo.pack_count, t_memo.speculative_misses
         mutate(memo_lens)
         mutate(plain_lens)
         a, b = _snapshot(be, memo_lens, w), plain_snapshot()
@@ -151,6 +154,8 @@ def test_every_mutation_is_seen(be):
         for x, y in zip(a, b):
             np.testing.assert_array_equal(x, y, err_msg=f"stale table after: {name}")
         assert t_memo.pack_count > before, f"mutation not detected: {name}"
+        # the launch queued on the stale table before the check was dropped, not returned
+        assert t_memo.speculative_misses == missed + 1, name
         again = t_memo.pack_count
         _snapshot(be, memo_lens, w)
         assert t_memo.pack_count == again, f"token unstable after: {name}"
