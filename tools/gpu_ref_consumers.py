@@ -16,11 +16,12 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
-FILES = sys.argv[1:] or ["tests/test_optic.py", "tests/test_analysis.py",
-                         "tests/test_wavefront.py", "tests/test_fft_psf.py"]
+FILES = ["tests/test_optic.py", "tests/test_analysis.py", "tests/test_wavefront.py",
+         "tests/test_fft_psf.py"]
 
 
-def run(dropin: bool):
+def run(dropin: bool, files=None):
+    files = list(files or FILES)
     tmp = tempfile.mkdtemp(prefix="ol_ref_gpu_")
     dst = os.path.join(tmp, "tests")
     shutil.copytree(os.path.join(REF, "tests"), dst)
@@ -41,7 +42,7 @@ def run(dropin: bool):
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1",
                PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests", "refshim"), REF]))
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider",
-                          "-k", "torch and not autodiff", "-rf", *FILES],
+                          "-k", "torch and not autodiff", "-rf", *files],
                          cwd=tmp, env=env, capture_output=True, text=True, timeout=3000)
     shutil.rmtree(tmp, ignore_errors=True)
     failed = set(re.findall(r"^FAILED (\S+)", out.stdout, flags=re.M))
@@ -53,8 +54,8 @@ def run(dropin: bool):
 
 
 if __name__ == "__main__":
-    base_f, base_tail, _ = run(False)
-    hip_f, hip_tail, out = run(True)
+    base_f, base_tail, _ = run(False, sys.argv[1:])
+    hip_f, hip_tail, out = run(True, sys.argv[1:])
     print("stock reference on cuda :", base_tail[-3:])
     print("with the drop-in        :", hip_tail[-4:])
     new = sorted(hip_f - base_f)
