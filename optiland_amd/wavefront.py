@@ -119,30 +119,52 @@ class Wavefront:
             return self._compute_fitted()
         t, rg = self.tracer, self.tracer.table.raygen
         hx, hy = self.field
-        # 1. chief ray alone -> reference sphere (strategy.py:176-184, 228-243)
-        chief = t.trace_generic(hx, hy, 0.0, 0.0, self.wavelength)
-        xc, yc, zc = (float(v[0]) for v in (chief.x, chief.y, chief.z))
+        # 1. chief ray alone -> reference sphere (strategy.py:176-184, 228-243).  The seven
+        # numbers of the traced chief ray come back in ONE device-to-host copy (its status
+        # word is read with the fused launch's, below) and the reference geometry is worked
+        # out on the host in double -- the same expressions as wavefront_device.h -- instead
+        # of a one-ray kernel launch and four more read-backs
+        fused_status = self.fused and hasattr(t, "defer_checks")
+        if fused_status:
+            t.defer_checks = True
+        try:
+            chief = t.trace_generic(hx, hy, 0.0, 0.0, self.wavelength)
+        finally:
+            if fused_status:
+                t.defer_checks = False
+        c = torch.stack([chief.x, chief.y, chief.z, chief.L, chief.M, chief.N, chief.opd]) \
+            .reshape(7, -1)[:, 0].double().cpu().tolist()
+        xc, yc, zc, Lc, Mc, Nc, opd_c = c
         ux, uy = self._tilt_cosines()
         params = dict(xc=xc, yc=yc, zc=zc, n_image=rg["n_image"], opd_ref=0.0, ux=ux,
                       uy=uy, half_epd=rg["EPD"] / 2.0, wavelength_um=self.wavelength)
         if self.afocal:  # strategy.py:260-284: plane through the chief-ray hit, normal to it
             R = math.inf
-            params.update(R=0.0, nx=float(chief.L[0]), ny=float(chief.M[0]), nz=float(chief.N[0]))
+            params.update(R=0.0, nx=Lc, ny=Mc, nz=Nc)
+            t_back = 0.0  # the chief ray starts ON its own plane
         else:
             R = math.sqrt(xc * xc + yc * yc + (zc - rg["pupil_z"]) ** 2)
             params.update(R=R)
-        zero = torch.zeros(1, dtype=t.dtype, device=t.device)
-        # with opd_ref = 0 the kernel returns -opd/lambda for the chief ray
-        c7 = [v.contiguous() for v in (chief.x, chief.y, chief.z, chief.L, chief.M, chief.N,
-                                       chief.opd)]
-        neg, _ = t.engine.wavefront_opd(params, c7, zero, zero, want_pupil=False)
-        params["opd_ref"] = -float(neg[0]) * self.wavelength * 1e-3
+            # back-propagation distance of the chief ray from the sphere's centre (its own
+            # image point) to the sphere: the quadratic of reference_geometry.py:41-79
+            # with r = centre -> c = -R^2, b = 0
+            a_ = Lc * Lc + Mc * Mc + Nc * Nc
+            sq = math.sqrt(max(4.0 * a_ * R * R, 0.0))
+            t1, t2 = -sq / (2.0 * a_), sq / (2.0 * a_)
+            t_back = t2 if t1 < 0.0 else t1
+        # chief-ray OPD to the reference (pupil point (0, 0): no tilt term)
+        params["opd_ref"] = opd_c - rg["n_image"] * t_back
         # 2. the full pupil (strategy.py:190-205)
         if self.fused:  # one launch: pupil points -> OPD map + its reductions, no ray planes
             px, py = t._dev(self.distribution.x), t._dev(self.distribution.y)
             wl, _ = t._wavelength_index(self.wavelength)
+            # (check_status=False keeps the chief-ray launches' status bits: one read-back
+            # for the three launches)
             opd, intensity, pupil, mom = t.engine.trace_opd(
-                params, px, py, wl, field=(hx, hy), vig=t._vig_scalar(hx, hy), want_pupil=True)
+                params, px, py, wl, field=(hx, hy), vig=t._vig_scalar(hx, hy), want_pupil=True,
+                check_status=not fused_status)
+            if fused_status:
+                t.check_status()
             return WavefrontData(pupil[0], pupil[1], pupil[2], opd, intensity, R, moments=mom)
         # the intensity the reference reads is the RECORDED image-plane row
         # (wavefront/strategy.py:198: surfaces.intensity[-1], i.e. before a polarised
@@ -253,7 +275,7 @@ class OPD(Wavefront):
         """opd.py:145-159."""
         d = self.data
         if d.moments is not None and not self.remove_tilt:
-            cnt, _s1, s2 = (float(v) for v in d.moments[9:12])  # epilogue of the fused kernel
+            cnt, _s1, s2 = d.moments[9:12].tolist()  # epilogue of the fused kernel, one read-back
             if cnt == 0:
                 raise ValueError("No valid rays with non-zero intensity for RMS calculation.")
             return math.sqrt(s2 / cnt)
