@@ -268,7 +268,8 @@ def test_reference_consumer_suite_on_device(be):
     them runs through the HIP kernels and their hard-coded expectations still hold.
     Measured with tools/gpu_ref_consumers.py (profiles/r02_reference_consumers_on_device.txt):
     stock torch backend on cuda 2 failed / 180 passed in 106 s; with the drop-in the SAME 2
-    (a KeyError of the reference itself -- device tensors as dict keys, test_wavefront.py:51)
+    (KeyErrors of the reference itself -- device tensors as dict keys: test_analysis.py
+    TestCookeTripletRayFan::test_ray_fan, test_wavefront.py TestWavefront::test_generate_data)
     / 180 passed in 31 s, 300 device tables created.  Here only the drop-in run is repeated;
     failures outside that known pair fail the test."""
     import importlib.util
@@ -287,5 +288,8 @@ def test_reference_consumer_suite_on_device(be):
     assert n_pass >= 175, summary
     made = [l for l in tail if "device tables created" in l]
     assert made and int(made[-1].split("created:")[1].split()[0]) > 100, tail
-    unknown = [f for f in failed if "test_wavefront.py" not in f]
+    # the stock torch backend's own two on cuda: KeyErrors of the reference (field
+    # coordinates that are device tensors used as dict keys), with or without the drop-in
+    known = ("TestCookeTripletRayFan::test_ray_fan", "TestWavefront::test_generate_data")
+    unknown = [f for f in failed if not any(k in f for k in known)]
     assert not unknown and len(failed) <= 2, (sorted(failed), out.stdout[-3000:])
