@@ -24,7 +24,9 @@ the launch really moves (== the PMC traffic), `frac_algorithmic` on SURVEY 8d's 
 `frac_of_achievable` against a device copy measured in the same run.  `cpu_baseline` is
 the reference's own NumPy backend (`kind: "reference"`, staged under oracle/_ref) on a
 bounded sample, with the C port of the algorithm (oracle/) beside it; `gpu_baseline` is
-the reference's stock torch backend on the same GPU.
+the reference's stock torch backend on the same GPU; `dropin` is the deliverable itself --
+the same reference call (`Optic.trace_generic`, device tensors in / out) under
+`integration.enable()` at the full batch size, wall clock, with its ratio to the kernel.
 """
 
 from __future__ import annotations
@@ -271,7 +273,8 @@ def device_bandwidth(device, gib=1, reps=10):
             "fill_GBps": size * reps / (e1.elapsed_time(e2) * 1e-3) / 1e9}
 
 
-def reference_baselines(workload, dtype, wavelength, hy, S, budget_s, device, n=1_000_000):
+def reference_baselines(workload, dtype, wavelength, hy, S, budget_s, device, n=1_000_000,
+                        full_rays=10_000_000):
     """The reference ITSELF on this node, same lens, same ray shape, bounded sample:
     `numpy` = Optiland's NumPy backend (`backend/numpy_backend.py`, fp64 always, see
     SURVEY Appendix D) through `Optic.trace_generic` on the host; `torch` = its stock torch
@@ -337,6 +340,48 @@ def reference_baselines(workload, dtype, wavelength, hy, S, budget_s, device, n=
     except Exception as exc:  # noqa: BLE001
         out["torch"] = None
         print(f"torch-backend baseline failed: {exc!r}", file=sys.stderr)
+    try:
+        # the deliverable itself: the SAME reference call with the drop-in enabled
+        # (optiland_amd.integration.enable(): RealRayTracer.trace_generic -> C ABI -> HIP
+        # kernels), device tensors in / out, at the full batch size of this bench line
+        from optiland_amd import integration
+        be.set_backend("torch")
+        be.set_device("cuda")
+        be.set_precision("float32" if dtype == "f32" else "float64")
+        tdt = torch.float32 if dtype == "f32" else torch.float64
+        integration.enable()
+        try:
+            lens, w = _live.build_system(name)
+            m = int(full_rays)
+            g = torch.Generator(device=device).manual_seed(5)
+            rr = torch.rand(m, generator=g, device=device, dtype=torch.float32).sqrt()
+            tt = 2 * np.pi * torch.rand(m, generator=g, device=device, dtype=torch.float32)
+            dpx, dpy = (rr * tt.cos()).to(tdt), (rr * tt.sin()).to(tdt)
+            for _ in range(3):
+                lens.trace_generic(0.0, hy, dpx, dpy, w)
+            comp = lens.ray_tracer.__dict__.get("_hip_companion")
+            assert comp is not None and comp.last_path == "hip", "drop-in did not intercept"
+            times = []
+            for _ in range(10):
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                lens.trace_generic(0.0, hy, dpx, dpy, w)
+                torch.cuda.synchronize(device)
+                times.append(time.perf_counter() - t0)
+            ms = float(np.median(times)) * 1e3
+            out["dropin"] = {
+                "value": m * S / (ms * 1e-3), "unit": "ray-surfaces/s", "ms_per_call": ms,
+                "rays": m,
+                "sample": f"median of 10 x Optic.trace_generic({m} rays, scalar field, device "
+                          f"tensors in / out) of the reference's {name} under "
+                          f"integration.enable(), {dtype}: ray generation + record-all trace + "
+                          "result objects + status read-back, wall clock",
+            }
+        finally:
+            integration.disable()
+    except Exception as exc:  # noqa: BLE001
+        out["dropin"] = None
+        print(f"drop-in end-to-end leg failed: {exc!r}", file=sys.stderr)
     finally:
         be.set_precision("float64")
         be.set_device("cpu")
@@ -627,11 +672,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_baseline(table, hy, "last" if spot else args.mode, args.cpu_seconds, wl)
             ref = None if args.no_ref_baselines else reference_baselines(
-                args.workload, args.dtype, wavelength, hy, S, args.ref_seconds, device)
+                args.workload, args.dtype, wavelength, hy, S, args.ref_seconds, device,
+                full_rays=n)
             if ref is not None and ref.get("numpy"):
                 # the north-star comparator: Optiland's own NumPy path on this node's host
                 out["cpu_baseline"] = dict(ref["numpy"], port=port)
                 out["gpu_baseline"] = {"torch": ref.get("torch")}
+                drop = ref.get("dropin")
+                if drop:
+                    drop["over_kernel_ms"] = drop["ms_per_call"] / kern_ms
+                out["dropin"] = drop
             else:
                 out["cpu_baseline"] = port
                 out["gpu_baseline"] = None

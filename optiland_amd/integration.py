@@ -251,10 +251,6 @@ def _make_tracer_class():
             front.ray_aiming_config = self.ray_aiming_config
             return front, table
 
-        def _engine_for(self, wavelength):  # kept for callers / tests of round 1
-            hit = self._entry_for(wavelength)
-            return hit[0], hit[1]
-
         # ---------------------------------------------------------------- trace
         def _finish(self, front, table, mine, wavelength, update_intensity):
             """Hand the device results over in the reference's own classes: the returned
