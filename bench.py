@@ -680,7 +680,9 @@ def main():
                 out["gpu_baseline"] = {"torch": ref.get("torch")}
                 drop = ref.get("dropin")
                 if drop:
-                    drop["over_kernel_ms"] = drop["ms_per_call"] / kern_ms
+                    # whole reference call (ray generation + trace + objects + read-back)
+                    # over the trace kernel alone of this bench line
+                    drop["over_trace_kernel"] = drop["ms_per_call"] / kern_ms
                 out["dropin"] = drop
             else:
                 out["cpu_baseline"] = port
