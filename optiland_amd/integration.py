@@ -278,6 +278,10 @@ def _make_tracer_class():
                 out.i = front.engine.polarized_intensity(
                     mine._prt, (mine._L0, mine._M0, mine._N0), mine._i0,
                     _state_dict(self.optic.polarization_state))
+            # the record block now lives exactly as long as the reference objects that view
+            # it (the Surfaces, the returned rays): the cached front must not pin it too --
+            # up to _MAX_ENGINES x dtypes fronts would each hold their last 4 GB at 1e7 rays
+            front.surfaces._bind(None)
             return out
 
         def _speculate(self, wavelength):
@@ -331,6 +335,7 @@ def _make_tracer_class():
                     self.last_path = "hip"
                     return self._finish(front, table, mine, wavelength, update_intensity)
                 self.speculative_misses += 1
+                front.surfaces._bind(None)  # drop the stale launch's block
             try:
                 front, table = self._front_for(wavelength)
             except UnsupportedSystem:

@@ -353,6 +353,10 @@ def test_dropin_keeps_device_tables_per_wavelength(hip_on_cpu):
             lens.trace(0.0, 0.7, w, num_rays=3, distribution="hexapolar")
     assert len(t._hip_engines) == 3
     assert t.pack_count == 3   # the change detector spared the other six packs
+    # no cached front pins its last record block (4 GB each at 1e7 rays): the block lives
+    # only through the reference objects that view it
+    assert all(f.surfaces._res is None for hit in t._hip_engines.values()
+               for f in hit[2].values())
     engines = {id(hit[0]) for hit in t._hip_engines.values()}
     for w in (0.48, 0.55, 0.65):
         lens.trace(0.0, 0.0, w, num_rays=3, distribution="hexapolar")
