@@ -70,5 +70,26 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return so
 
 
+def fptoken_path() -> str:
+    return os.path.join(LIBDIR, "_fptoken.so")
+
+
+def build_fptoken(force: bool = False, verbose: bool = False) -> str:
+    """gcc-build the CPython extension behind optiland_amd/fingerprint.py (the native inner
+    loop of the drop-in's change detector; host runtime, no GPU code).  The package works
+    without it (pure-Python walk, ~5x slower)."""
+    import sysconfig
+    os.makedirs(LIBDIR, exist_ok=True)
+    src, out = os.path.join(CSRC, "fptoken.c"), fptoken_path()
+    if force or _stale(out, [src]):
+        cmd = ["gcc", "-O2", "-shared", "-fPIC", "-Wall", "-I", sysconfig.get_paths()["include"],
+               src, "-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build_library(force=False, verbose=True))
+    print(build_fptoken(force=False, verbose=True))

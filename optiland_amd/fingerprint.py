@@ -42,7 +42,7 @@ _Tensor = torch.Tensor
 _NoneType = type(None)
 
 
-def _tok(v, keep):
+def _tok_py(v, keep):
     t = type(v)
     if t is float or t is _Tensor or t is int or t is str or t is bool or t is _NoneType:
         if t is _Tensor:
@@ -62,14 +62,61 @@ def _tok(v, keep):
     if isinstance(v, np.generic):
         return v.item()
     if t is list or t is tuple:
-        return tuple([_tok(e, keep) for e in v])
+        return tuple([_tok_py(e, keep) for e in v])
     if t is dict:
         return None
     keep.append(v)
     return ("O", t.__name__, id(v))
 
 
-def _obj(o, keep, memo, skip=None):
+def _dict_tokens_py(d, skip, keep):
+    if skip is None:
+        return [_tok_py(v, keep) for v in d.values()]
+    return [(k, _tok_py(v, keep)) for k, v in d.items() if k not in skip]
+
+
+def _load_native():
+    """The same two functions from csrc/fptoken.c (`build.build_fptoken()`); None when the
+    extension has not been built -- the walk is host bookkeeping, not the compute path, so a
+    missing accelerator only costs time (OPTILAND_HIP_NATIVE_TOKEN=0 forces the Python one)."""
+    if os.environ.get("OPTILAND_HIP_NATIVE_TOKEN", "1") == "0":
+        return None
+    import importlib.machinery
+    import importlib.util
+    from . import build as _build
+    path = _build.fptoken_path()
+    if not os.path.exists(path):
+        return None
+    try:
+        loader = importlib.machinery.ExtensionFileLoader("_fptoken", path)
+        spec = importlib.util.spec_from_loader("_fptoken", loader)
+        mod = importlib.util.module_from_spec(spec)
+        loader.exec_module(mod)
+        mod.configure(torch.Tensor, np.ndarray, np.generic, _BIG_ARRAY)
+        return mod
+    except Exception:  # noqa: BLE001 - stale / foreign binary: fall back to the Python walk
+        return None
+
+
+_NATIVE = _load_native()
+_tok = _NATIVE.tok if _NATIVE is not None else _tok_py
+_dict_tokens = _NATIVE.dict_tokens if _NATIVE is not None else _dict_tokens_py
+
+
+def use_native(flag: bool) -> bool:
+    """Switch between the native and the Python walk (tests); returns whether the native
+    one is active afterwards."""
+    global _tok, _dict_tokens, _obj, surface_token
+    if flag and _NATIVE is not None:
+        _tok, _dict_tokens, _obj = _NATIVE.tok, _NATIVE.dict_tokens, _NATIVE.obj
+        surface_token = _surface_token_native
+        return True
+    _tok, _dict_tokens, _obj = _tok_py, _dict_tokens_py, _obj_py
+    surface_token = _surface_token_py
+    return False
+
+
+def _obj_py(o, keep, memo, skip=None):
     """One level of `o.__dict__`: values tokenised in dict order, sub-objects by identity
     (an added / removed attribute changes the length of the list)."""
     if o is None:
@@ -82,13 +129,13 @@ def _obj(o, keep, memo, skip=None):
     d = getattr(o, "__dict__", None)
     if d is None:
         out = _tok(o, keep)
-    elif skip is None:
-        out = (type(o).__name__, key, [_tok(v, keep) for v in d.values()])
     else:
-        out = (type(o).__name__, key,
-               [(k, _tok(v, keep)) for k, v in d.items() if k not in skip])
+        out = (type(o).__name__, key, _dict_tokens(d, skip, keep))
     memo[key] = out
     return out
+
+
+_obj = _NATIVE.obj if _NATIVE is not None else _obj_py
 
 
 def _cs(cs, keep, memo):
@@ -121,7 +168,7 @@ def _material(m, keep, memo):
     return (_obj(m, keep, memo), type(getattr(m, "propagation_model", None)).__name__)
 
 
-def surface_token(s, keep, memo):
+def _surface_token_py(s, keep, memo):
     geom = s.geometry
     im = getattr(s, "interaction_model", None)
     return (
@@ -135,6 +182,13 @@ def surface_token(s, keep, memo):
         _coating(getattr(im, "coating", None), keep, memo),
         _tok(getattr(s, "thickness", None), keep), bool(getattr(s, "is_stop", False)),
     )
+
+
+def _surface_token_native(s, keep, memo):
+    return _NATIVE.surface_token(s, keep, memo, _SURFACE_SKIP)
+
+
+surface_token = _surface_token_native if _NATIVE is not None else _surface_token_py
 
 
 def surfaces_token(surfaces, wavelength):

@@ -20,8 +20,19 @@ pytestmark = pytest.mark.skipif(_live.reference_root() is None,
                                 reason="reference package not present")
 
 
-@pytest.fixture()
-def be(monkeypatch):
+@pytest.fixture(params=["native", "python"])
+def be(monkeypatch, request):
+    """Every test runs on both walks: csrc/fptoken.c (built by build.build_fptoken) and the
+    pure-Python definitions in fingerprint.py."""
+    from optiland_amd import build, fingerprint
+    if request.param == "native":
+        build.build_fptoken()
+        if fingerprint._NATIVE is None:
+            fingerprint._NATIVE = fingerprint._load_native()
+        if not fingerprint.use_native(True):
+            pytest.skip("native token extension not available")
+    else:
+        fingerprint.use_native(False)
     import optiland_amd.tracer as tr
     from tests._fake_engine import OracleEngine
     monkeypatch.setattr(tr, "_make_engine", lambda table, device: OracleEngine(table, device))
@@ -31,6 +42,47 @@ def be(monkeypatch):
     be.set_precision("float64")
     yield be
     be.set_backend("numpy")
+    fingerprint.use_native(True)
+
+
+def test_native_and_python_walks_build_identical_tokens():
+    """The C walk (csrc/fptoken.c) and the Python one must produce the SAME token tree --
+    element for element -- on every lens of optiland.samples (plain and with coatings,
+    polarisation, apertures), so that either can validate a memo the other wrote."""
+    from optiland_amd import build, fingerprint
+    build.build_fptoken()
+    if fingerprint._NATIVE is None:
+        fingerprint._NATIVE = fingerprint._load_native()
+    if fingerprint._NATIVE is None:
+        pytest.skip("native token extension not available")
+    be_ = _live.import_reference()
+    from optiland import physical_apertures as pa
+    from optiland.rays import PolarizationState
+    checked = 0
+    try:
+        for backend in ("numpy", "torch"):
+            be_.set_backend(backend)
+            for cname, cls in _sample_classes():
+                lens = cls()
+                if checked % 3 == 0:
+                    lens.surfaces.set_fresnel_coatings()
+                    lens.updater.set_polarization(PolarizationState(is_polarized=False))
+                if checked % 4 == 0 and len(lens.surfaces.surfaces) > 3:
+                    lens.surfaces[2].aperture = pa.UnionAperture(
+                        pa.RadialAperture(r_max=5.0), pa.RectangularAperture(-1, 1, -2, 2))
+                w = 0.55
+                fingerprint.use_native(True)
+                a, _ = fingerprint.optic_token(lens, w)
+                sa, _ = fingerprint.surfaces_token(lens.surfaces.surfaces, w)
+                fingerprint.use_native(False)
+                b, _ = fingerprint.optic_token(lens, w)
+                sb, _ = fingerprint.surfaces_token(lens.surfaces.surfaces, w)
+                assert a == b and sa == sb, (backend, cname)
+                checked += 1
+    finally:
+        fingerprint.use_native(True)
+        be_.set_backend("numpy")
+    assert checked >= 50
 
 
 def _snapshot(be, lens, w):
