@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--torch-rays", type=float, default=1e6)
     ap.add_argument("--numpy-rays", type=float, default=1e6)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "live_e2e.json"))
+    ap.add_argument("--quick", action="store_true",
+                    help="skip the slow comparators (stock torch at full size, NumPy); add the "
+                         "small-trace latency table")
     args = ap.parse_args()
     n = int(args.rays)
     be = _live.import_reference()
@@ -127,6 +130,25 @@ def main():
     pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(25)
     doc["host_profile_5_calls"] = s.getvalue().splitlines()[:60]
 
+    # small traces (optimisation-loop sizes): per-call wall time through the drop-in
+    from optiland_amd import fingerprint as _fp
+    lat = {}
+    for m in (100, 10_000, 1_000_000):
+        pxs, pys = pupil(m, "cuda", dtype)
+        for _ in range(5):
+            lens.trace_generic(0.0, 0.7, pxs, pys, w)
+        lat[str(m)] = wall(lambda: lens.trace_generic(0.0, 0.7, pxs, pys, w), 200 if m < 1e6 else 30)[0]
+    doc["dropin_small_trace_ms"] = lat
+    doc["token_walk"] = "native (csrc/fptoken.c)" if _fp._NATIVE is not None else "python"
+    if _fp._NATIVE is not None:
+        _fp.use_native(False)
+        pxs, pys = pupil(100, "cuda", dtype)
+        for _ in range(5):
+            lens.trace_generic(0.0, 0.7, pxs, pys, w)
+        doc["dropin_100_rays_python_walk_ms"] = wall(
+            lambda: lens.trace_generic(0.0, 0.7, pxs, pys, w), 200)[0]
+        _fp.use_native(True)
+
     # Optic.trace, hexapolar rings (host distribution, cached pupil planes?)
     rings = 1000  # 1 + 3*1000*1001 = 3.0e6 rays
     for _ in range(2):
@@ -135,6 +157,28 @@ def main():
     integration.disable()
 
     # ------------------------------------------------- stock torch backend, same GPU
+    if args.quick:
+        lens_q, _ = _live.build_system(args.system)
+        pxs, pys = pupil(100, "cuda", dtype)
+        with torch.no_grad():
+            for _ in range(2):
+                lens_q.trace_generic(0.0, 0.7, pxs, pys, w)
+            doc["stock_torch_100_rays_ms"] = wall(lambda: lens_q.trace_generic(0.0, 0.7, pxs, pys, w), 10)[0]
+        be.set_precision("float64")
+        be.set_device("cpu")
+        be.set_backend("numpy")
+        lens_n, _ = _live.build_system(args.system)
+        pn = (np.linspace(-0.5, 0.5, 100), np.linspace(0.5, -0.5, 100))
+        lens_n.trace_generic(0.0, 0.7, pn[0], pn[1], w)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            lens_n.trace_generic(0.0, 0.7, pn[0], pn[1], w)
+        doc["numpy_100_rays_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        with open(args.out, "w") as f:
+            json.dump(doc, f, indent=1)
+        print(json.dumps({k_: v for k_, v in doc.items() if k_ != "host_profile_5_calls"}, indent=1))
+        return
     m = int(args.torch_rays)
     lens_t, _ = _live.build_system(args.system)
     pxt, pyt = pupil(m, "cuda", dtype)
