@@ -340,6 +340,32 @@ def test_packer_memoises_paraxial_scalars_and_invalidates(ref, monkeypatch):
     assert d.raygen["EPL"] == pytest.approx(float(np.asarray(lens.paraxial.EPL()).reshape(-1)[0]))
 
 
+@pytest.mark.parametrize("kind", ["uniform", "random", "cross", "ring", "line_y", "sobol"])
+def test_trace_with_a_distribution_object(hip_on_cpu, kind):
+    """`Optic.trace(..., distribution=<BaseDistribution>)`: the caller's own sampler object
+    (reference optiland/distribution.py), points taken as they are, field x pupil order of
+    real_ray_tracer.py:95-98; and every named sampler through the string form."""
+    be = hip_on_cpu
+    from optiland.distribution import create_distribution
+    from optiland.samples.objectives import CookeTriplet
+    from optiland_amd.integration import install
+    lens_ref, lens_hip = CookeTriplet(), CookeTriplet()
+    tracer = install(lens_hip, force=True)
+    d = create_distribution(kind)
+    d.generate_points(7)
+    hx, hy = be.array([0.0, 0.0]), be.array([0.0, 1.0])
+    r0 = lens_ref.trace(hx, hy, 0.55, None, d)
+    r1 = lens_hip.trace(hx, hy, 0.55, None, d)
+    assert tracer.last_path == "hip"
+    for k in ("x", "y", "z", "L", "M", "N", "i", "opd"):
+        np.testing.assert_allclose(_np(be, getattr(r1, k)), _np(be, getattr(r0, k)),
+                                   rtol=1e-9, atol=1e-10, err_msg=k)
+    if kind not in ("random", "sobol"):   # deterministic samplers: the string form too
+        r2 = lens_hip.trace(0.0, 1.0, 0.55, 7, kind)
+        r3 = lens_ref.trace(0.0, 1.0, 0.55, 7, kind)
+        np.testing.assert_allclose(_np(be, r2.y), _np(be, r3.y), rtol=1e-9, atol=1e-10)
+
+
 def test_dropin_keeps_device_tables_per_wavelength(hip_on_cpu):
     """Alternating wavelengths (what SpotDiagram does per field) reuses the device tables
     instead of re-creating one per call; a change of the prescription makes a new one."""
