@@ -366,6 +366,64 @@ def test_trace_with_a_distribution_object(hip_on_cpu, kind):
         np.testing.assert_allclose(_np(be, r2.y), _np(be, r3.y), rtol=1e-9, atol=1e-10)
 
 
+def test_trace_generic_input_matrix_matches_the_reference(hip_on_cpu):
+    """Every input form the reference's torch backend accepts for `trace_generic` -- python
+    scalars, ints, 0-d / one-element / n-element tensors in fp64 and fp32, scalar field with
+    tensor pupil and the reverse, rays on the pupil rim -- gives the reference's result, and
+    every range violation (field before pupil, NaN included) the reference's ValueError.
+    Where the reference only fails by accident (size mismatch: a RuntimeError out of a
+    tensor op; empty input: `stack expects a non-empty TensorList`; numpy arrays / lists:
+    TypeError) the drop-in is a superset: a ValueError naming the problem, an empty result,
+    and the arrays accepted."""
+    import torch
+    be = hip_on_cpu
+    from optiland.samples.objectives import CookeTriplet
+    from optiland_amd.integration import install
+    ref_lens, hip_lens = CookeTriplet(), CookeTriplet()
+    tracer = install(hip_lens, force=True)
+    T = lambda v: torch.tensor(v, dtype=torch.float64)  # noqa: E731
+
+    def run(lens, args):
+        try:
+            r = lens.trace_generic(*args, 0.55)
+            return "ok", _np(be, r.y), _np(be, r.i)
+        except Exception as e:  # noqa: BLE001
+            return "err", type(e).__name__, str(e)
+    same = [
+        (0.0, 0.5, T([0.1, -0.2, 0.3]), T([0.3, 0.2, -0.1])),
+        (0, 1, T([0.1, -0.2, 0.3]), T([0.3, 0.2, -0.1])),
+        (T([0.0, 0.0, 0.1]), T([0.0, 0.5, 1.0]), T([0.1, -0.2, 0.3]), T([0.3, 0.2, -0.1])),
+        (T(0.0), T(0.5), T(0.2), T(-0.3)),
+        (T([0.0]), T([0.5]), T([0.2]), T([-0.3])),
+        (0.0, 0.5, 0.2, -0.3),
+        (T([0.0, 0.0]), T([0.0, 1.0]), 0.2, 0.1),
+        (0.0, 0.5, torch.tensor([0.1, 0.2]), torch.tensor([0.3, -0.2])),
+        (0.0, 1.0, T([1.0, -1.0, 0.0]), T([0.0, 0.0, 1.0])),
+        (0.0, 0.5, T([0.1, 1.2]), T([0.1, 0.2])),                      # pupil range
+        (0.0, 1.5, T([0.1, 0.2]), T([0.1, 0.2])),                      # field range
+        (T([0.0, 0.0]), T([0.5, -1.5]), T([0.1, 0.2]), T([0.1, 0.2])),
+        (0.0, 1.5, T([0.1, 1.2]), T([0.1, 0.2])),                      # both: field reported
+        (0.0, 0.5, T([0.1, float("nan")]), T([0.1, 0.2])),
+    ]
+    for args in same:
+        a, b = run(ref_lens, args), run(hip_lens, args)
+        assert a[0] == b[0], (args, a, b)
+        if a[0] == "ok":
+            assert tracer.last_path == "hip"
+            np.testing.assert_allclose(b[1], a[1], rtol=1e-6, atol=1e-9)
+            np.testing.assert_allclose(b[2], a[2], rtol=1e-6, atol=1e-9)
+        else:
+            assert a[1:] == b[1:], (args, a, b)
+    # superset behaviour
+    bad_size = run(hip_lens, (0.0, 0.5, T([0.1, 0.2]), T([0.1, 0.2, 0.3])))
+    assert bad_size[:2] == ("err", "ValueError") and "one common size" in bad_size[2]
+    empty = run(hip_lens, (0.0, 0.5, T([]), T([])))
+    assert empty[0] == "ok" and empty[1].size == 0
+    arr = run(hip_lens, (0.0, 0.5, np.array([0.1, -0.2]), [0.3, 0.2]))
+    want = run(ref_lens, (0.0, 0.5, T([0.1, -0.2]), T([0.3, 0.2])))
+    np.testing.assert_allclose(arr[1], want[1], rtol=1e-9)
+
+
 def test_dropin_keeps_device_tables_per_wavelength(hip_on_cpu):
     """Alternating wavelengths (what SpotDiagram does per field) reuses the device tables
     instead of re-creating one per call; a change of the prescription makes a new one."""
