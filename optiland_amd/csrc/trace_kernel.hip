@@ -1595,10 +1595,13 @@ struct SpotAcc {
 // serialising compute behind HBM writes (measured: 1.00 ms -> see DESIGN.md).
 // Minimum waves per SIMD asked of the register allocator.  Only the fp32 polarised
 // Newton kernel (the Zernike + Fresnel configuration, VALU-issue bound with long SMEM /
-// transcendental dependency chains) asks for more than the allocator gives by itself;
-// OL_POLNR_WAVES is the A/B knob (tools/build_variants.py), 0 = no request.
+// transcendental dependency chains) asks for more than the allocator gives by itself:
+// it allocates 73 VGPRs unasked (6 waves); asked for 7 waves it fits 71 WITHOUT a spill
+// and runs 1.5-2 % faster (profiles/r02_ab_zf_occupancy.txt, last block); 8 waves (64 VGPRs)
+// spills 10 dwords and loses 30 %.  OL_POLNR_WAVES is the A/B knob
+// (tools/build_variants.py), 0 = no request.
 #ifndef OL_POLNR_WAVES
-#define OL_POLNR_WAVES 0
+#define OL_POLNR_WAVES 7
 #endif
 template <typename T, int RPT, int POLK, int NR>
 struct WavesPerEu {

@@ -26,6 +26,7 @@ VARIANTS = {
     "block128": ["-DOL_TRACE_BLOCK=128"],
     "block512": ["-DOL_TRACE_BLOCK=512"],
     # register-allocator occupancy request for the fp32 polarised Newton kernel (C5)
+    "polnr_waves0": ["-DOL_POLNR_WAVES=0"],
     "polnr_waves7": ["-DOL_POLNR_WAVES=7"],
     "polnr_waves8": ["-DOL_POLNR_WAVES=8"],
     # plane accesses addressed per lane with 64-bit VGPR addresses (round-1 form) instead of
