@@ -1432,10 +1432,10 @@ __device__ __forceinline__ T vec_get(const typename VecOf<T, RPT>::type& v, int 
 // compiler address every plane access as SGPR base + 32-bit VGPR offset
 // (global_store_dword v_off, v, s[b:b+1]) -- ONE lane offset shared by all planes --
 // instead of forming a 64-bit per-lane address with a v_lshl_add_u64 per load / store.
-// Same-box A/B (profiles/r02_ab_addr.txt): the VALU-bound polarised kernels gain 1.5 %
-// (33 fewer vector instructions per ray), the HBM-bound record-all kernels LOSE 0-1.7 %
-// (fp64 most: the scalar address chain sits in front of every store) -- so the form is
-// chosen per instantiation: SADDR for POLK != 0 only.
+// 33 fewer vector instructions per ray in the polarised Newton kernel (76 -> 73 VGPRs: it
+// then reaches 7 waves without a spill), 46 -> 30 VGPRs in the lean record-all kernel.
+// With the index split like this the compiler picks the SGPR-base form for both values
+// of SADDR (checked in the ISA); the flag is kept as the A/B handle.
 #ifndef OL_SADDR
 #define OL_SADDR 1
 #endif
