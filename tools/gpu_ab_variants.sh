@@ -16,15 +16,18 @@ run() { # label, lib ('' = product), bench args...
   fi
 }
 echo "# $(date -u) interleaved A/B, 1e7 rays, kernel_ms = mean HIP-event time of 30 launches" >> $OUT
-for rep in 1 2 3; do
+# arm order alternates from round to round: a fixed order favours the arm that runs second
+# by 1-2 % on these boxes (methodological note)
+order() { if [ $(($1 % 2)) -eq 1 ]; then echo "${@:2}"; else echo "${@:2}" | tr ' ' '\n' | tac | tr '\n' ' '; fi; }
+for rep in 1 2 3 4; do
   echo "## round $rep: double Gauss fp32 record-all" >> $OUT
-  for v in "" lds_table plain_stores block128 block512; do run "dg_f32_record ${v:-product}" "$v"; done
+  for v in $(order $rep product lds_table plain_stores block128 block512); do run "dg_f32_record $v" "${v/product/}"; done
   echo "## round $rep: double Gauss fp32 record-last" >> $OUT
-  for v in "" lds_table nt_vector; do run "dg_f32_last ${v:-product}" "$v" --mode last; done
+  for v in $(order $rep product lds_table nt_vector); do run "dg_f32_last $v" "${v/product/}" --mode last; done
   echo "## round $rep: Zernike + Fresnel fp32 record-all" >> $OUT
-  for v in "" lds_table; do run "zf_f32_record ${v:-product}" "$v" --workload zernike_fresnel; done
+  for v in $(order $rep product lds_table); do run "zf_f32_record $v" "${v/product/}" --workload zernike_fresnel; done
   echo "## round $rep: RC + asphere fp32 record-all" >> $OUT
-  for v in "" lds_table; do run "rc_f32_record ${v:-product}" "$v" --workload rc_asphere; done
+  for v in $(order $rep product lds_table); do run "rc_f32_record $v" "${v/product/}" --workload rc_asphere; done
 done
 echo "# run-time knobs, in-process interleaved (tools/ab_bench.py): vector+compaction / vector / one ray per lane" >> $OUT
 for w in rc_asphere zernike_fresnel; do
