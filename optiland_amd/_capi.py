@@ -141,6 +141,18 @@ def load():
         lib = C.CDLL(path)
     except OSError as exc:  # e.g. libamdhip64 missing
         raise HipExtensionError(f"cannot load {path}: {exc}") from exc
+    if hasattr(lib, "ol_hostmath_harness"):
+        # tests/hostmath builds the kernel arithmetic for the host as a checker; it is not
+        # an implementation of this package and must never be picked up as one
+        raise HipExtensionError(f"{path} is the host-math TEST harness, not the HIP extension")
+    bind(lib, path)
+    _LIB = lib
+    return lib
+
+
+def bind(lib, path: str = "?"):
+    """Declare the prototypes of include/optiland_hip.h on a loaded library and check its
+    ABI version."""
     vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
     lib.ol_abi_version.restype = i32
     lib.ol_abi_version.argtypes = []
@@ -187,7 +199,6 @@ def load():
         raise HipExtensionError(
             f"{path}: ABI version {lib.ol_abi_version()} != expected {ABI_VERSION}; rebuild"
         )
-    _LIB = lib
     return lib
 
 

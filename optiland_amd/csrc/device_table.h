@@ -13,6 +13,15 @@
 #pragma once
 #include <stdint.h>
 
+// Qualifier of the per-ray arithmetic (surface_math.h, raygen_device.h).  Product build:
+// device code only.  OL_HOST_MATH is defined by tests/hostmath/harness.hip alone, which
+// executes the same functions on the host as a check that needs no GPU.
+#ifdef OL_HOST_MATH
+#define OL_DEV __host__ __device__ inline
+#else
+#define OL_DEV __device__ __forceinline__
+#endif
+
 namespace ol {
 
 enum : int {

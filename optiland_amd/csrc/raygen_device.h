@@ -11,15 +11,15 @@
 namespace ol {
 
 template <typename T>
-__device__ __forceinline__ T tan_deg(T deg);
+OL_DEV T tan_deg(T deg);
 template <>
-__device__ __forceinline__ float tan_deg<float>(float deg) {
+OL_DEV float tan_deg<float>(float deg) {
   // formed in double: the field angle is a per-field constant in practice and
   // fp32 tanf of a degree->radian product would cost 1e-7 of a 20 mm offset.
   return (float)tan((double)deg * 0.017453292519943295);
 }
 template <>
-__device__ __forceinline__ double tan_deg<double>(double deg) {
+OL_DEV double tan_deg<double>(double deg) {
   return tan(deg * 0.017453292519943295);
 }
 
@@ -29,7 +29,7 @@ struct RaygenConsts {
   T EPL, EPD, maxf, off_epl, z_inf, z_fin, epl_z, tele_dz, apod_a, apod_b;
   int apod_kind;
   bool infinite, height, linear, telecentric;
-  __device__ __forceinline__ explicit RaygenConsts(const RaygenDev& p)
+  OL_DEV explicit RaygenConsts(const RaygenDev& p)
       : EPL((T)p.EPL), EPD((T)p.EPD), maxf((T)p.max_field), off_epl((T)(p.offset + p.EPL)),
         z_inf((T)(p.z_first - p.offset)), z_fin((T)p.z_first), epl_z((T)(p.EPL - p.z_first)),
         tele_dz((T)p.tele_dz), apod_a((T)p.apod_a), apod_b((T)p.apod_b),
@@ -43,7 +43,7 @@ struct RaygenConsts {
 // initial intensity from the pupil apodization (ray_generator.py:81-85,
 // optiland/apodization/*.py); launch-uniform switch
 template <typename T>
-__device__ __forceinline__ T raygen_apodize(const RaygenConsts<T>& c, T px, T py) {
+OL_DEV T raygen_apodize(const RaygenConsts<T>& c, T px, T py) {
   if (c.apod_kind == 0) return T(1);
   const T pi = T(3.14159265358979323846);
   const T r2 = px * px + py * py;
@@ -74,7 +74,7 @@ __device__ __forceinline__ T raygen_apodize(const RaygenConsts<T>& c, T px, T py
 // (object_height.py:38-41), or the paraxially scaled slope / height of an image-height
 // field (paraxial_image_height.py:36-60); hoistable when the field is launch-uniform
 template <typename T>
-__device__ __forceinline__ void raygen_field(const RaygenConsts<T>& c, T hx, T hy, T& tx, T& ty) {
+OL_DEV void raygen_field(const RaygenConsts<T>& c, T hx, T hy, T& tx, T& ty) {
   if (c.linear) {  // object height, or paraxial image height (slope or height scale)
     tx = c.maxf * hx;
     ty = c.maxf * hy;
@@ -87,10 +87,10 @@ __device__ __forceinline__ void raygen_field(const RaygenConsts<T>& c, T hx, T h
 // range checks (real_ray_tracer.py:156-173: all((v >= -1) & (v <= 1)); NaN fails) and
 // the trace_generic pre-scaling of the pupil (real_ray_tracer.py:134-137)
 template <typename T>
-__device__ __forceinline__ bool outside_unit(T v) { return !(v >= T(-1) && v <= T(1)); }
+OL_DEV bool outside_unit(T v) { return !(v >= T(-1) && v <= T(1)); }
 
 template <typename T>
-__device__ __forceinline__ void raygen_pupil(uint32_t flags, T vx, T vy, T& px, T& py,
+OL_DEV void raygen_pupil(uint32_t flags, T vx, T vy, T& px, T& py,
                                              uint32_t& status) {
   if ((flags & kRaygenCheckPupil) && (outside_unit(px) || outside_unit(py)))
     status |= kStatusPupilRange;
@@ -102,7 +102,7 @@ __device__ __forceinline__ void raygen_pupil(uint32_t flags, T vx, T vy, T& px, 
 
 // o[0..5] = x, y, z, L, M, N  (intensity is 1, ray_generator.py:81-85)
 template <typename T>
-__device__ __forceinline__ void raygen_one(const RaygenConsts<T>& c, T tx, T ty, T px, T py, T vx,
+OL_DEV void raygen_one(const RaygenConsts<T>& c, T tx, T ty, T px, T py, T vx,
                                            T vy, T (&o)[6]) {
   T x0, y0, z0;
   if (c.height) {  // object_height.py:36-47 (planar object surface)

@@ -1,0 +1,170 @@
+"""Python side of tests/hostmath: the kernel arithmetic run on the host through the C ABI,
+on NumPy arrays.  TEST INFRASTRUCTURE (see tests/hostmath/harness.hip); mirrors the subset
+of `optiland_amd.engine.HipSystem` the parity tests use.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+
+from optiland_amd import _capi
+from optiland_amd import system as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_DT = {np.dtype(np.float32): _capi.F32, np.dtype(np.float64): _capi.F64}
+
+
+def _builder():
+    spec = importlib.util.spec_from_file_location(
+        "_hostmath_build", os.path.join(_HERE, "hostmath", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def available() -> bool:
+    return _builder().available()
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        path = _builder().build()
+        lib = C.CDLL(path)
+        assert lib.ol_hostmath_harness() == 1
+        _capi.bind(lib, path)
+        _LIB = lib
+    return _LIB
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): "
+                           f"{lib.ol_last_error().decode('utf-8', 'replace')}")
+
+
+class HostMathSystem:
+    """`ol_system` of the host-math harness: the table lives in host memory."""
+
+    def __init__(self, table):
+        self.lib = load()
+        self.table = table
+        surf = np.ascontiguousarray(table.surfaces)
+        assert surf.dtype.itemsize == C.sizeof(_capi.SurfaceDesc)
+        optics = np.ascontiguousarray(table.optics)
+        coeffs = np.ascontiguousarray(table.coeffs, dtype=np.float64)
+        handle = C.c_void_p()
+        rc = self.lib.ol_system_create(
+            surf.ctypes.data, surf.shape[0], coeffs.ctypes.data if coeffs.size else None,
+            coeffs.size, optics.ctypes.data, optics.shape[1], C.byref(handle))
+        _check(self.lib, rc, "ol_system_create")
+        self._handle = handle
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self.lib.ol_system_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    @property
+    def num_surfaces(self) -> int:
+        return self.table.num_surfaces
+
+    def trace(self, rays, wavelength_index=0, record=True, prt=None, first=0, last=None,
+              write_rays=None, prt_identity=False):
+        """rays: 8 contiguous 1-D arrays (x,y,z,L,M,N,i,opd) of one dtype.  Returns
+        (record or None, status word); with write_rays the final state lands in `rays`."""
+        rays = list(rays)
+        n = rays[0].size
+        dt = rays[0].dtype
+        assert len(rays) == 8 and all(r.dtype == dt and r.size == n and r.flags.c_contiguous
+                                      for r in rays)
+        last = self.num_surfaces - 1 if last is None else last
+        rows = last - first + 1
+        rec = None
+        if record is True:
+            rec = np.full((rows, 8, n), np.nan, dtype=dt)
+        elif isinstance(record, np.ndarray):
+            rec = record
+        if write_rays is None:
+            write_rays = rec is None
+        flags = S.TRACE_WRITE_RAYS if write_rays else 0
+        if prt is not None:
+            assert prt.dtype == dt and prt.shape in ((9, n), (18, n)) and prt.flags.c_contiguous
+            if prt.shape[0] == 18:
+                flags |= S.TRACE_PRT_COMPLEX
+            if prt_identity:
+                flags |= S.TRACE_PRT_IDENTITY
+        ptrs = (C.c_void_p * 8)(*[r.ctypes.data for r in rays])
+        status = np.zeros(1, dtype=np.uint32)
+        rc = self.lib.ol_trace_ex(
+            self._handle, _DT[dt], n, ptrs, int(wavelength_index),
+            rec.ctypes.data if rec is not None else None,
+            int(rec.shape[2]) if rec is not None else 0,
+            prt.ctypes.data if prt is not None else None, int(first), int(last), flags,
+            status.ctypes.data, None, None)
+        _check(self.lib, rc, "ol_trace_ex")
+        return rec, int(status[0])
+
+    def generate_rays(self, hx, hy, px, py, vx=1.0, vy=1.0, flags=0):
+        """ol_generate_rays with the table's ray-generation block; returns (8 planes, status)."""
+        rg = self.table.raygen
+        if not rg:
+            raise ValueError("this table has no ray-generation block")
+        px = np.ascontiguousarray(px)
+        dt = px.dtype
+        n = px.size
+        py = np.ascontiguousarray(py, dtype=dt)
+        keep = [px, py]
+
+        def plane(v):
+            if np.ndim(v) == 0:
+                return None, float(v)
+            a = np.ascontiguousarray(v, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data, 0.0
+
+        phx, hx0 = plane(hx)
+        phy, hy0 = plane(hy)
+        pvx, vx0 = plane(vx)
+        pvy, vy0 = plane(vy)
+        inputs = _capi.RaygenInputs(phx, phy, px.ctypes.data, py.ctypes.data, pvx, pvy,
+                                    hx0, hy0, vx0, vy0, flags, 0)
+        # (same mapping as HipSystem._raygen_params)
+        params = _capi.RaygenParams(int(rg["object_infinite"]), int(rg.get("field_kind", 0)),
+                                    rg["EPL"], rg["EPD"],
+                                    float(rg.get("field_scale", rg["max_field"])), rg["offset"],
+                                    rg["z_first"], float(rg.get("tele_dz", 0.0)),
+                                    float(rg.get("apod_a", 0.0)), float(rg.get("apod_b", 0.0)),
+                                    int(rg.get("apod_kind", 0)), 0)
+        out = [np.empty(n, dtype=dt) for _ in range(8)]
+        ptrs = (C.c_void_p * 8)(*[o.ctypes.data for o in out])
+        status = np.zeros(1, dtype=np.uint32)
+        rc = self.lib.ol_generate_rays(C.byref(params), _DT[dt], n, C.byref(inputs), ptrs,
+                                       status.ctypes.data, None)
+        _check(self.lib, rc, "ol_generate_rays")
+        return out, int(status[0])
+
+
+def new_prt(n, dtype, complex_prt=False):
+    p = np.zeros((18 if complex_prt else 9, n), dtype=dtype)
+    p[0] = p[4] = p[8] = 1
+    return p
+
+
+def prt_to_complex(prt):
+    n = prt.shape[1]
+    re = prt[:9].T.reshape(n, 3, 3).astype(np.float64)
+    if prt.shape[0] == 18:
+        return re + 1j * prt[9:].T.reshape(n, 3, 3).astype(np.float64)
+    return re.astype(np.complex128)

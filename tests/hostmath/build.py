@@ -1,0 +1,69 @@
+"""Build tests/hostmath/_build/libol_hostmath.so: the kernel's per-surface arithmetic
+(optiland_amd/csrc/surface_math.h) compiled for the HOST behind the C ABI -- a checker for
+boxes without a GPU.  See harness.hip for what it is and is not.
+
+    python tests/hostmath/build.py
+
+hipcc is used as the C++ compiler only (`--offload-host-only`: no device code is
+generated); the link is a plain g++ link without the HIP runtime.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "optiland_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libol_hostmath.so")
+DEPS = ("surface_math.h", "raygen_device.h", "device_table.h", "trace_launch.h", "capi.hip")
+
+
+def _cpu_has_fma() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return " fma " in line + " "
+    except OSError:
+        pass
+    return False
+
+
+def available() -> bool:
+    return bool(shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(OUT, exist_ok=True)
+    deps = [os.path.join(CSRC, d) for d in DEPS] + [
+        os.path.join(HERE, "harness.hip"), os.path.join(ROOT, "include", "optiland_hip.h"),
+        os.path.abspath(__file__)]
+    if not force and os.path.exists(LIB) and \
+            all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    # fma() is written out everywhere it matters; -mfma additionally lets the host
+    # contract a*b+c the way the device compiler does (-ffp-contract=on on both sides)
+    flags = ["--offload-host-only", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=on",
+             "-fno-math-errno", "-Wall"] + (["-mfma"] if _cpu_has_fma() else [])
+    objs = []
+    for src in (os.path.join(CSRC, "capi.hip"), os.path.join(HERE, "harness.hip")):
+        o = os.path.join(OUT, os.path.basename(src).replace(".hip", ".o"))
+        cmd = [hipcc, *flags, "-c", src, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, stderr=None if verbose else subprocess.DEVNULL)
+        objs.append(o)
+    cmd = ["g++", "-shared", "-Wl,-Bsymbolic", *objs, "-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

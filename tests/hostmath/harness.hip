@@ -1,0 +1,234 @@
+// harness.hip -- TEST INFRASTRUCTURE: the kernel's per-surface arithmetic, executed ray by
+// ray on the host, behind the same C ABI.
+//
+// What this is.  optiland_amd/csrc/surface_math.h holds every arithmetic function of the
+// fused trace kernel (intersection, Newton-Raphson on the sag functors, apertures,
+// refraction / reflection, coatings, Fresnel + PRT update, frame changes).  In the product
+// library those are `__device__` functions: device code only.  This translation unit
+// defines OL_HOST_MATH, which turns them into `__host__ __device__`, and drives them with a
+// plain loop over rays that mirrors trace_kernel<T, 1, RECORD, POLK, NR, false> line by
+// line.  Linked with an unmodified, host-only compile of csrc/capi.hip and a five-function
+// stand-in for the HIP runtime (hipMalloc = malloc: the surface table stays in host
+// memory), it gives `libol_hostmath.so`: `ol_system_create` / `ol_trace_ex` with HOST
+// pointers.  tests/test_hostmath.py holds it against the golden vectors and the oracle --
+// the same checks tests/test_gpu_parity.py makes on the MI355X -- so that a change to the
+// kernel arithmetic can be verified on a box without a GPU.
+//
+// What this is not.  It is not a CPU fallback: nothing under optiland_amd/ builds, loads
+// or knows about this library, `optiland_amd._capi` only ever opens liboptiland_hip.so
+// and raises when that is missing, and the entry points other than ol_system_* / ol_trace*
+// / ol_generate_rays return "not supported" here.  It exists under tests/ and is built by
+// tests/hostmath/build.py only.
+//
+// Differences from the device: v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 / v_exp_f32 (1 ulp) are
+// the correctly rounded host operations; the order of operations, the FMA contractions
+// written out as fma() and every branch are the kernel's own.
+#define OL_HOST_MATH 1
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "../../optiland_amd/csrc/surface_math.h"
+#include "../../optiland_amd/csrc/raygen_device.h"
+#include "../../optiland_amd/csrc/trace_launch.h"
+
+// ---------------------------------------------------------------------------
+// stand-in for the five HIP runtime calls capi.hip makes for its surface tables
+// ---------------------------------------------------------------------------
+extern "C" {
+hipError_t hipMalloc(void** p, size_t n) {
+  *p = std::malloc(n ? n : 1);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipFree(void* p) {
+  std::free(p);
+  return hipSuccess;
+}
+hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) {
+  std::memcpy(dst, src, n);
+  return hipSuccess;
+}
+hipError_t hipGetDevice(int* d) {
+  *d = 0;
+  return hipSuccess;
+}
+const char* hipGetErrorString(hipError_t e) {
+  return e == hipErrorNotSupported ? "entry point not available in the host-math harness"
+                                   : "host-math harness: stand-in HIP runtime error";
+}
+// marker symbol: lets a test assert which library it has loaded
+int ol_hostmath_harness(void) { return 1; }
+}
+
+namespace ol {
+
+Tuning& tuning() {
+  static Tuning t;
+  return t;
+}
+
+namespace {
+
+// trace_kernel<T, 1, RECORD, POLK, NR, false> for ray i (trace_kernel.hip), statement by
+// statement; the loads / stores are plain indexed accesses.
+template <typename T, int POLK, int NR>
+void trace_one(const TraceArgs<T>& a, int64_t i, uint32_t& status) {
+  constexpr int NPRT = POLK == 2 ? 18 : 9;
+  Ray<T> r[1];
+  r[0].x = a.rays[0][i]; r[0].y = a.rays[1][i]; r[0].z = a.rays[2][i];
+  r[0].L = a.rays[3][i]; r[0].M = a.rays[4][i]; r[0].N = a.rays[5][i];
+  r[0].i = a.rays[6][i]; r[0].opd = a.rays[7][i];
+  Prt<T, POLK> P[1];
+  if constexpr (POLK != 0) {
+    const bool ident = (a.flags & kTracePrtIdentity) != 0;
+    for (int e = 0; e < NPRT; ++e)
+      P[0].m[e] = ident ? ((e == 0 || e == 4 || e == 8) ? T(1) : T(0)) : a.prt[(int64_t)e * a.n + i];
+  }
+  bool is_global = true;
+  bool prt_fresh = POLK != 0 && (a.flags & kTracePrtIdentity) != 0;
+  DevSurf<T> last_traced;
+  std::memset(static_cast<void*>(&last_traced), 0, sizeof(last_traced));
+  last_traced.cold = a.cold;
+  for (int s = a.first; s <= a.last; ++s) {
+    DevSurf<T> S;
+    static_cast<DevSurfHot<T>&>(S) = a.surf[s];
+    S.cold = a.cold + s;
+    if (S.interaction != kRecordOnly) {
+      const DevOptics<T> O = a.optics[s * a.n_wl + a.wl];
+      surface_step<T, 1, POLK, NR>(S, O, a.coeffs, is_global, r, P, status, prt_fresh);
+      is_global = false;
+      last_traced = S;
+    }
+    if (a.record) {
+      T* row = a.record + (int64_t)(s - a.first) * 8 * a.record_stride;
+      if (!(s == a.first && (a.flags & kTraceRow0IsInput))) {
+        const Ray<T> g = is_global ? r[0] : to_global<T>(last_traced, r[0]);
+        row[0 * a.record_stride + i] = g.x; row[1 * a.record_stride + i] = g.y;
+        row[2 * a.record_stride + i] = g.z; row[3 * a.record_stride + i] = g.L;
+        row[4 * a.record_stride + i] = g.M; row[5 * a.record_stride + i] = g.N;
+        row[6 * a.record_stride + i] = g.i; row[7 * a.record_stride + i] = g.opd;
+      }
+    }
+  }
+  if (a.flags & kTraceWriteRays) {
+    const Ray<T> g = is_global ? r[0] : to_global<T>(last_traced, r[0]);
+    a.rays[0][i] = g.x; a.rays[1][i] = g.y; a.rays[2][i] = g.z;
+    a.rays[3][i] = g.L; a.rays[4][i] = g.M; a.rays[5][i] = g.N;
+    a.rays[6][i] = g.i; a.rays[7][i] = g.opd;
+  }
+  if constexpr (POLK != 0) {
+    for (int e = 0; e < NPRT; ++e) a.prt[(int64_t)e * a.n + i] = P[0].m[e];
+  }
+}
+
+template <typename T, int POLK, int NR>
+void trace_all(const TraceArgs<T>& a) {
+  uint32_t status = 0;
+  for (int64_t i = 0; i < a.n; ++i) trace_one<T, POLK, NR>(a, i, status);
+  if (status && a.status) *a.status |= status;
+}
+
+template <typename T, int NR>
+hipError_t trace_nr(const TraceArgs<T>& a) {
+  if (a.spot != nullptr) return hipErrorNotSupported;  // the spot epilogue is a wave reduction
+  const int polk = a.prt == nullptr ? 0 : ((a.flags & kTracePrtComplex) ? 2 : 1);
+  if (polk == 2) trace_all<T, 2, NR>(a);
+  else if (polk == 1) trace_all<T, 1, NR>(a);
+  else trace_all<T, 0, NR>(a);
+  return hipSuccess;
+}
+
+}  // namespace
+
+template <typename T>
+hipError_t launch_trace(const TraceArgs<T>& a, bool, bool has_newton, hipStream_t) {
+  return has_newton ? trace_nr<T, 1>(a) : trace_nr<T, 0>(a);
+}
+template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, bool, hipStream_t);
+template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, bool, hipStream_t);
+
+// raygen_kernel + launch_raygen (aux_kernels.hip), ray by ray
+template <typename T>
+hipError_t launch_raygen(const RaygenDev& p, const RaygenIn<T>& in_, int64_t n, T* const out[8],
+                         uint32_t* status, hipStream_t) {
+  RaygenIn<T> in = in_;
+  if (in.hx == nullptr) uniform_field_tangents<T>(p, in);
+  const RaygenConsts<T> c(p);
+  const bool field_planes = in.hx != nullptr, vig_planes = in.vx != nullptr;
+  uint32_t st = 0;
+  for (int64_t j = 0; j < n; ++j) {
+    T tx = in.tx0, ty = in.ty0, o[6];
+    if (field_planes) {
+      const T hx = in.hx[j], hy = in.hy[j];
+      if ((in.flags & kRaygenCheckField) && (outside_unit(hx) || outside_unit(hy)))
+        st |= kStatusFieldRange;
+      raygen_field<T>(c, hx, hy, tx, ty);
+    }
+    T px = in.px[j], py = in.py[j];
+    const T vx = vig_planes ? in.vx[j] : in.vx0, vy = vig_planes ? in.vy[j] : in.vy0;
+    raygen_pupil<T>(in.flags, vx, vy, px, py, st);
+    raygen_one<T>(c, tx, ty, px, py, vx, vy, o);
+    for (int k = 0; k < 6; ++k) out[k][j] = o[k];
+    out[6][j] = raygen_apodize<T>(c, px, py);
+    if (out[7]) out[7][j] = T(0);
+  }
+  if (st && status) *status |= st;
+  return hipSuccess;
+}
+template hipError_t launch_raygen<float>(const RaygenDev&, const RaygenIn<float>&, int64_t,
+                                         float* const[8], uint32_t*, hipStream_t);
+template hipError_t launch_raygen<double>(const RaygenDev&, const RaygenIn<double>&, int64_t,
+                                          double* const[8], uint32_t*, hipStream_t);
+
+// everything else is a kernel with a workgroup reduction or an epilogue of its own: not
+// part of the per-surface arithmetic this harness exists for
+#define OL_UNSUPPORTED(T)                                                                       \
+  template <>                                                                                    \
+  hipError_t launch_spot_trace<T>(const SpotArgs<T>&, bool, bool, hipStream_t) {                 \
+    return hipErrorNotSupported;                                                                 \
+  }                                                                                              \
+  template <>                                                                                    \
+  hipError_t launch_pol_intensity<T>(int64_t, const T*, bool, const T* const[3], const T*,       \
+                                     const PolStateDev&, T*, uint32_t*, hipStream_t) {           \
+    return hipErrorNotSupported;                                                                 \
+  }                                                                                              \
+  template <>                                                                                    \
+  hipError_t launch_wavefront<T>(const WavefrontDev&, int64_t, const T* const[7], const T*,      \
+                                 const T*, T*, T* const[3], hipStream_t) {                       \
+    return hipErrorNotSupported;                                                                 \
+  }                                                                                              \
+  template <>                                                                                    \
+  hipError_t launch_pupil_fill<T>(int64_t, const T*, const T*, const T*, const T*,               \
+                                  const double[3], const int32_t*, int32_t, int32_t, int32_t,    \
+                                  double*, hipStream_t) {                                        \
+    return hipErrorNotSupported;                                                                 \
+  }                                                                                              \
+  template <>                                                                                    \
+  hipError_t launch_spot_moments<T>(int64_t, const T*, const T*, const T*, double*,              \
+                                    hipStream_t) {                                               \
+    return hipErrorNotSupported;                                                                 \
+  }                                                                                              \
+  template <>                                                                                    \
+  hipError_t launch_radial_energy<T>(int64_t, const T*, const T*, const T*, double, double,      \
+                                     const double*, int, double*, hipStream_t) {                 \
+    return hipErrorNotSupported;                                                                 \
+  }                                                                                              \
+  template <>                                                                                    \
+  hipError_t launch_irradiance<T>(int64_t, const T*, const T*, const T*, const double*, int,     \
+                                  const double*, int, double*, hipStream_t) {                    \
+    return hipErrorNotSupported;                                                                 \
+  }                                                                                              \
+  template <>                                                                                    \
+  hipError_t launch_spot_max_r2<T>(int64_t, const T*, const T*, const T*, double, double,        \
+                                   double*, hipStream_t) {                                       \
+    return hipErrorNotSupported;                                                                 \
+  }
+OL_UNSUPPORTED(float)
+OL_UNSUPPORTED(double)
+template <>
+hipError_t launch_opd_trace<double>(const OpdArgs<double>&, bool, hipStream_t) {
+  return hipErrorNotSupported;
+}
+
+}  // namespace ol

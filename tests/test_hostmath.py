@@ -1,0 +1,202 @@
+"""The kernel's per-surface arithmetic, executed on the HOST, against the golden vectors and
+the oracle -- the checks tests/test_gpu_parity.py makes on the MI355X, made here without a
+GPU.
+
+`optiland_amd/csrc/surface_math.h` is compiled a second time for the host by
+tests/hostmath (see harness.hip: test infrastructure, not a fallback -- the product
+library contains this arithmetic as device code only and the package never loads the
+harness).  What is checked here is the SOURCE of the kernel arithmetic: formulas, branch
+structure, table layout and the C ABI's table conversion.  What is not: the launch glue
+(plane addressing, vector / packed variants, wave-level code), the 1-ulp hardware
+rcp / sqrt / rsq / exp, and anything about speed -- those stay with the `-m gpu` tests.
+
+Tolerances are the GPU suite's own (tests/test_gpu_parity.py).
+"""
+
+import copy
+
+import numpy as np
+import pytest
+
+from tests import _hostmath as hm
+from tests._util import (PLANES, assert_close_planes, fp32_group_tolerances, fp32_image_tolerance,
+                         golden_cases, image_plane_error_over_spot, load_case)
+
+pytestmark = pytest.mark.skipif(not hm.available(), reason="hipcc (used as host C++ compiler) missing")
+
+TOL = {np.float64: 1e-6, np.float32: 1e-4}
+TIGHT64 = 1e-9
+DTYPES = [np.float64, np.float32]
+IDS = ["f64", "f32"]
+
+
+@pytest.fixture(scope="module")
+def host():
+    cache = {}
+
+    def get(case):
+        if case not in cache:
+            table, data = load_case(case)
+            cache[case] = (hm.HostMathSystem(table), table, data)
+        return cache[case]
+
+    yield get
+    for sysm, _, _ in cache.values():
+        sysm.close()
+
+
+def _rays(data, dtype, n=None):
+    r = data["rays_in"] if n is None else data["rays_in"][:, :n]
+    planes = [np.array(r[k], dtype=dtype, order="C", copy=True) for k in range(7)]  # (write-back!)
+    planes.append(np.zeros(planes[0].size, dtype=dtype))
+    return planes
+
+
+def test_harness_is_not_the_product_library():
+    """The package refuses to take the harness for the HIP extension."""
+    import subprocess
+    import sys
+    lib = hm._builder().build()
+    code = ("import os, sys; os.environ['OPTILAND_HIP_LIBRARY'] = sys.argv[1]\n"
+            "from optiland_amd import _capi\n"
+            "try:\n    _capi.load()\nexcept _capi.HipExtensionError as e:\n"
+            "    print('refused:', e); sys.exit(0)\nsys.exit(1)\n")
+    out = subprocess.run([sys.executable, "-c", code, lib], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "TEST harness" in out.stdout
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", golden_cases())
+def test_record_matches_reference(host, case, dtype):
+    sysm, table, data = host(case)
+    polarized = "prt" in data
+    rays = _rays(data, dtype)
+    n = rays[0].size
+    prt = hm.new_prt(n, dtype, table.needs_complex_prt) if polarized else None
+    rec, status = sysm.trace(rays, 0, record=True, prt=prt)
+    assert status == 0
+    got = rec.astype(np.float64)
+    tol = TOL[dtype]
+    assert_close_planes(got, data["record"], tol, tol, f"{case}:{dtype.__name__}")
+    if dtype == np.float32:
+        gt = fp32_group_tolerances(case)
+        assert gt is not None
+        assert_close_planes(got, data["record"], tol, tol, f"{case}:fp32 tight", group_tol=gt)
+        img = image_plane_error_over_spot(got, data["record"], data)
+        assert img <= fp32_image_tolerance(case), (case, img, fp32_image_tolerance(case))
+    else:
+        from oracle import oracle
+        tt = copy.deepcopy(table)
+        tt.surfaces["tol"] = np.where(tt.surfaces["max_iter"] > 0, 1e-13, tt.surfaces["tol"])
+        rin = {k: data["rays_in"][j] for j, k in enumerate(PLANES[:7])}
+        conv = oracle.trace(tt, rin, 0, record=True, polarized=polarized)["record"]
+        has_nr = bool(np.any(tt.surfaces["max_iter"] > 0))
+        tight = 1e-7 if has_nr else TIGHT64
+        assert_close_planes(got, conv, tight, tight, f"{case}:tight-vs-converged-oracle")
+        assert np.array_equal(got[:, 6, :] == 0, data["record"][:, 6, :] == 0)
+    if polarized:
+        p = hm.prt_to_complex(prt)
+        want = data["prt"]
+        ok = ~np.isnan(want.real)
+        np.testing.assert_allclose(p.real[ok], want.real[ok], rtol=tol, atol=tol)
+        np.testing.assert_allclose(np.where(np.isnan(p.imag), 0, p.imag)[ok],
+                                   np.where(np.isnan(want.imag), 0, want.imag)[ok], rtol=tol, atol=tol)
+        assert np.array_equal(np.isnan(p.real), np.isnan(want.real))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", ["double_gauss", "rc_asphere", "tilted_fold", "zernike_nopol"])
+def test_writeback_and_partial_ranges(host, case, dtype):
+    sysm, table, data = host(case)
+    full, _ = sysm.trace(_rays(data, dtype), 0, record=True)
+    rays = _rays(data, dtype)
+    sysm.trace(rays, 0, record=False)
+    for k in range(8):
+        assert np.array_equal(np.nan_to_num(rays[k], nan=-7.0), np.nan_to_num(full[-1, k], nan=-7.0))
+    S = table.num_surfaces - 1
+    k = S // 2
+    rays = _rays(data, dtype)
+    sysm.trace(rays, 0, record=False, first=0, last=k)
+    sysm.trace(rays, 0, record=False, first=k + 1, last=S)
+    tol = TOL[dtype] * 1e-2
+    assert_close_planes(np.stack(rays).astype(np.float64)[None], full[-1].astype(np.float64)[None],
+                        tol, tol, f"{case}:split")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_fresh_prt_equals_identity_prt(host, dtype):
+    """OL_TRACE_PRT_IDENTITY (write-only PRT, first update specialised) == reading an
+    identity matrix and multiplying."""
+    for case in ("zernike_fresnel_fringe", "coated_mirror_polarised", "polarizer_only"):
+        sysm, table, data = host(case)
+        n = data["rays_in"].shape[1]
+        a = hm.new_prt(n, dtype, table.needs_complex_prt)
+        b = np.full_like(a, 123.0)  # garbage: never read
+        ra, _ = sysm.trace(_rays(data, dtype), 0, record=True, prt=a)
+        rb, _ = sysm.trace(_rays(data, dtype), 0, record=True, prt=b, prt_identity=True)
+        assert np.array_equal(np.nan_to_num(ra), np.nan_to_num(rb))
+        eps = np.finfo(dtype).eps
+        np.testing.assert_allclose(np.nan_to_num(b), np.nan_to_num(a), rtol=0, atol=8 * eps)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", golden_cases())
+def test_ray_generation(host, case, dtype):
+    sysm, table, data = host(case)
+    if not table.raygen:
+        pytest.skip("no ray-generation scalars")
+    generic = not bool(data["via_trace"])
+    vx, vy = 1.0 - data["vx"], 1.0 - data["vy"]
+    px = data["Px"] * (vx if generic else 1.0)
+    py = data["Py"] * (vy if generic else 1.0)
+    a = lambda v: np.ascontiguousarray(v, dtype=dtype)
+    out, status = sysm.generate_rays(a(data["Hx"]), a(data["Hy"]), a(px), a(py), a(vx), a(vy))
+    assert status == 0
+    tol = 1e-12 if dtype == np.float64 else 2e-6
+    for j in range(7):
+        want = data["rays_in"][j]
+        scale = max(1.0, np.abs(data["rays_in"][:3]).max()) if j < 3 else 1.0
+        np.testing.assert_allclose(out[j].astype(np.float64), want, rtol=tol, atol=tol * scale,
+                                   err_msg=f"{case}:{PLANES[j]}")
+
+
+def test_status_bits(host):
+    sysm, table, data = host("zernike_nopol")
+    rays = _rays(data, np.float64)
+    rays[0] += 40.0  # far outside norm_radius
+    _, status = sysm.trace(rays, 0, record=False)
+    assert status & 0x1  # OL_STATUS_ZERNIKE_RANGE
+    sysm, table, data = host("double_gauss")
+    _, st = sysm.generate_rays(0.0, 0.5, np.array([0.0, 1.5]), np.array([0.0, 0.0]), flags=0x2)
+    assert st & 0x10  # OL_STATUS_PUPIL_RANGE
+
+
+def test_c_abi_errors_are_the_product_ones(host):
+    """Same capi.hip: the validation errors of the boundary come out of the harness too."""
+    sysm, table, data = host("zernike_fresnel_fringe")
+    with pytest.raises(RuntimeError, match="Polarization must be set"):
+        sysm.trace(_rays(data, np.float64), 0, record=False)
+    sysm, table, data = host("polarizer_retarder")
+    n = data["rays_in"].shape[1]
+    with pytest.raises(RuntimeError, match="retarder"):
+        sysm.trace(_rays(data, np.float64), 0, record=False, prt=hm.new_prt(n, np.float64, False))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_oracle_side_by_side_large(host, dtype):
+    """Seeded 1e5-ray bundle on the double Gauss: host-executed kernel arithmetic vs the
+    oracle directly."""
+    from oracle import oracle
+    sysm, table, data = host("double_gauss")
+    rng = np.random.default_rng(11)
+    n = 100_000
+    r, th = np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
+    rays = oracle.generate_rays(table.raygen, np.zeros(n), rng.uniform(-1, 1, n),
+                                r * np.cos(th), r * np.sin(th))
+    want = oracle.trace(table, rays, 0, record=True)["record"]
+    planes = [np.ascontiguousarray(rays[k], dtype=dtype) for k in PLANES[:7]]
+    planes.append(np.zeros(n, dtype=dtype))
+    rec, _ = sysm.trace(planes, 0, record=True)
+    tol = TOL[dtype]
+    assert_close_planes(rec.astype(np.float64), want, tol, tol, "oracle-1e5")
