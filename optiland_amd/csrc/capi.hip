@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -139,6 +140,76 @@ int build_zernike_block(const double* terms, int n_terms, std::vector<double>& o
     }
   }
   return 0;
+}
+
+// Low-order Zernike surfaces as ONE bivariate polynomial in the normalised Cartesian
+// coordinates (device_table.h: kGeomZernikeMono).  Every term is expanded,
+//   rho^m cos(m phi) = Re (x + i y)^m,   rho^m sin(m phi) = Im (x + i y)^m,
+//   R_n^m(rho) rho^-m = sum_k r_k (x^2 + y^2)^((n-m)/2-k)          (zernike/base.py:216-239)
+// into the monomials x^i y^j, i + j <= n: S (with the normalisation constants N_j, the
+// sag, zernike.py:153-180) and Q (without them: what the reference differentiates for the
+// normal, zernike.py:234-240); the block holds S and the two derivative triangles of Q in
+// Horner order.  The expansion is exact up to rounding in double.  Conditioning: on the unit
+// circle sum |s_ij| |x|^i |y|^j of one term is sum_k |r_k| (|x| + |y|)^m -- the radial
+// polynomial's own growth, which the per-|m| level form has too, times at most 2^(m/2)
+// from the binomial expansion of the harmonic (the level form builds the harmonics by a
+// stable recurrence instead).  The degree cap keeps that extra factor at <= 16; higher
+// orders stay on the level form.  Returns false when the surface has to stay there.
+constexpr int kZernMonoMaxDegree = 8;
+
+// OPTILAND_HIP_ZERNIKE_MONO=0 keeps every Zernike surface on the level form (A/B runs,
+// parity tests of the level evaluator on low-order systems)
+bool zernike_mono_enabled() {
+  const char* e = getenv("OPTILAND_HIP_ZERNIKE_MONO");
+  return !(e && e[0] == '0');
+}
+
+double binomial(int n, int k) { return factorial(n) / (factorial(k) * factorial(n - k)); }
+
+bool build_zernike_mono_block(const double* terms, int n_terms, std::vector<double>& out,
+                              int* degree) {
+  int nmax = -1;
+  for (int j = 0; j < n_terms; ++j) {
+    if (terms[4 * j] == 0.0) continue;
+    const int n = (int)terms[4 * j + 1], ma = std::abs((int)terms[4 * j + 2]);
+    if (n < ma || ((n - ma) & 1) || n > kZernMonoMaxDegree) return false;
+    nmax = std::max(nmax, n);
+  }
+  if (nmax < 0) return false;  // no term at all: the level form handles "nothing" already
+  const int W = nmax + 1;
+  std::vector<double> S(W * W, 0.0), Q(W * W, 0.0);  // [i * W + j] = coefficient of x^i y^j
+  for (int t = 0; t < n_terms; ++t) {
+    const double c = terms[4 * t];
+    if (c == 0.0) continue;
+    const int n = (int)terms[4 * t + 1], m = (int)terms[4 * t + 2], ma = std::abs(m);
+    const double N = terms[4 * t + 3];
+    for (int k = 0; k <= (n - ma) / 2; ++k) {
+      const double rk = ((k & 1) ? -1.0 : 1.0) * factorial(n - k) /
+                        (factorial(k) * factorial((n + ma) / 2 - k) * factorial((n - ma) / 2 - k));
+      const int pw = (n - ma) / 2 - k;  // power of u = x^2 + y^2
+      for (int q = 0; q <= pw; ++q) {   // u^pw = sum_q C(pw, q) x^(2 (pw - q)) y^(2 q)
+        const double uq = binomial(pw, q);
+        // harmonic part: cos -> even powers of y, sin -> odd powers of y
+        for (int h = (m < 0 ? 1 : 0); h <= ma; h += 2) {
+          const double sign = ((h / 2) & 1) ? -1.0 : 1.0;  // i^h: +1, (+i), -1, (-i), ...
+          const double hc = binomial(ma, h) * sign;
+          const int i = 2 * (pw - q) + (ma - h), jj = 2 * q + h;
+          S[i * W + jj] += c * N * rk * uq * hc;
+          Q[i * W + jj] += c * rk * uq * hc;
+        }
+      }
+    }
+  }
+  // Horner order: outer in x from the highest power, inner in y from the highest power
+  for (int i = nmax; i >= 0; --i)
+    for (int j = nmax - i; j >= 0; --j) out.push_back(S[i * W + j]);
+  for (int i = nmax - 1; i >= 0; --i)
+    for (int j = nmax - 1 - i; j >= 0; --j) {
+      out.push_back((i + 1) * Q[(i + 1) * W + j]);  // dQ/dx
+      out.push_back((j + 1) * Q[i * W + j + 1]);    // dQ/dy
+    }
+  *degree = nmax;
+  return true;
 }
 
 // host-side staging record: every field of both device blocks, in double
@@ -577,9 +648,14 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
     const double* src = coeffs ? coeffs + s.coeff_offset : nullptr;
     if (s.geom_kind == OL_GEOM_ZERNIKE) {
       int ng = 0;
-      if (build_zernike_block(src, s.n_coeff, dcoef, int_slots, &ng) != 0)
-        return fail(OL_EINVAL, "surface %d: invalid Zernike (n, m) index", i);
-      d.n_coeff = ng;
+      if (zernike_mono_enabled() && build_zernike_mono_block(src, s.n_coeff, dcoef, &ng)) {
+        d.geom = ol::kGeomZernikeMono;  // low order, well conditioned: one polynomial
+        d.n_coeff = ng;
+      } else {
+        if (build_zernike_block(src, s.n_coeff, dcoef, int_slots, &ng) != 0)
+          return fail(OL_EINVAL, "surface %d: invalid Zernike (n, m) index", i);
+        d.n_coeff = ng;
+      }
     } else if (s.geom_kind == OL_GEOM_EVEN_ASPHERE || s.geom_kind == OL_GEOM_ODD_ASPHERE ||
                s.geom_kind == OL_GEOM_POLYNOMIAL) {
       if (s.geom_kind == OL_GEOM_POLYNOMIAL &&

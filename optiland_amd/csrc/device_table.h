@@ -33,7 +33,10 @@ enum : int {
   kGeomPolynomial = 5,
   kGeomChebyshev = 6,  // block: {1/norm_x, 1/norm_y, c[i][j]...}
   kGeomBiconic = 7,    // block: {cy, 1 + ky}; cv/kp1 hold cx, 1 + kx
-  kGeomToroidal = 8    // block: {R_rot (or inf), 1/R_rot, 1 + k_yz, c_yz, a_1, a_2, ...}
+  kGeomToroidal = 8,   // block: {R_rot (or inf), 1/R_rot, 1 + k_yz, c_yz, a_1, a_2, ...}
+  // internal (never in ol_surface_desc): a Zernike surface of low order re-expressed by
+  // ol_system_create as one bivariate polynomial of degree n_coeff in (x, y) / norm_radius
+  kGeomZernikeMono = 9
 };
 enum : int { kRecordOnly = 0, kRefract = 1, kReflect = 2 };
 enum : int {
@@ -114,6 +117,11 @@ struct DevOptics {
 //     b_c[k] b_s[k]   the same without N_j     (the reference's normal, zernike.py:234)
 //     d_c[k] d_s[k]   (k + 1) b[k + 1]         (coefficients of dQ_b/du; 0 for k = K-1)
 //   (m = 0 has no sin part: zeros.)
+//
+// kGeomZernikeMono block (surface.n_coeff = degree n), coefficients in Horner order -- rows
+// by descending power of x, within a row by descending power of y:
+//   S:  (n + 1)(n + 2) / 2 values   s_ij of x^i y^j, i + j <= n          (the sag, with N_j)
+//   G:  n (n + 1) / 2 PAIRS         (dQ/dx, dQ/dy)_ij, i + j <= n - 1    (Q: without N_j)
 constexpr int kZernLevelHeader = 2;
 constexpr int kZernLevelStride = 6;
 

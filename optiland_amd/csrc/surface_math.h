@@ -391,11 +391,11 @@ using vec2 = T __attribute__((ext_vector_type(2)));
 OL_DEV int slot_int(const float* p) { return hw::float_bits(*p); }
 OL_DEV int slot_int(const double* p) { return (int)hw::double_bits(*p); }
 
+// conic base, normalised coordinates and the range check shared by both series forms
 template <typename T>
-OL_DEV void zernike_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
-                                             T y, T& sag, T& fx, T& fy, uint32_t& status) {
+OL_DEV void zernike_begin(const DevSurf<T>& s, T x, T y, T& sag, T& fx, T& fy, T& xn, T& yn,
+                          T& u, uint32_t& status) {
   using m = Math<T>;
-  using V2 = vec2<T>;
   T r2 = m::fma(x, x, y * y);
   T g = m::sqrt(m::fma(-s.kp1 * s.cv * s.cv, r2, T(1)));
   sag = m::div(s.cv * r2, T(1) + g);
@@ -403,9 +403,40 @@ OL_DEV void zernike_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
   fx = x * f;
   fy = y * f;
   const T inv = s.cold->inv_norm;
-  const T xn = x * inv, yn = y * inv;
+  xn = x * inv;
+  yn = y * inv;
   if (m::abs(xn) > T(1) || m::abs(yn) > T(1)) status |= 0x1u;  // OL_STATUS_ZERNIKE_RANGE
-  const T u = m::fma(xn, xn, yn * yn);
+  u = m::fma(xn, xn, yn * yn);
+}
+
+// (zsum, gx, gy): the series and its gradient w.r.t. (x_n, y_n) -> sag and sag gradient
+template <typename T>
+OL_DEV void zernike_finish(const DevSurf<T>& s, T xn, T yn, T u, T zsum, T gx, T gy, T& sag,
+                           T& fx, T& fy) {
+  using m = Math<T>;
+  if (u < T(1e-8)) {  // the reference's eps-regularised chain rule near / at the vertex
+    const T eps = m::guard();
+    const T Rr = m::fma(xn, gx, yn * gy);     // rho dZ/drho
+    const T Az = m::fma(xn, gy, -(yn * gx));  // dZ/dphi
+    const T rho = m::sqrt(u);
+    const T d1 = u > T(0) ? m::rcp(m::fma(eps, rho, u)) : T(0);  // 1 / (rho (rho + eps))
+    const T d2 = m::rcp(u + eps);
+    gx = m::fma(Rr * d1, xn, -(Az * d2 * yn));
+    gy = m::fma(Rr * d1, yn, Az * d2 * xn);
+  }
+  const T inv = s.cold->inv_norm;
+  sag += zsum;
+  fx = m::fma(gx, inv, fx);
+  fy = m::fma(gy, inv, fy);
+}
+
+template <typename T>
+OL_DEV void zernike_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
+                                             T y, T& sag, T& fx, T& fy, uint32_t& status) {
+  using m = Math<T>;
+  using V2 = vec2<T>;
+  T xn, yn, u;
+  zernike_begin(s, x, y, sag, fx, fy, xn, yn, u, status);
   const V2 uu = {u, u};
 
   T zsum = T(0), gx = T(0), gy = T(0);  // gradient w.r.t. (x_n, y_n)
@@ -447,19 +478,87 @@ OL_DEV void zernike_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
     gx = m::fma(t1s, xn, gx + (hx.x + hx.y));
     gy = m::fma(t1s, yn, gy + (hy.x + hy.y));
   }
-  if (u < T(1e-8)) {  // the reference's eps-regularised chain rule near / at the vertex
-    const T eps = m::guard();
-    const T Rr = m::fma(xn, gx, yn * gy);     // rho dZ/drho
-    const T Az = m::fma(xn, gy, -(yn * gx));  // dZ/dphi
-    const T rho = m::sqrt(u);
-    const T d1 = u > T(0) ? m::rcp(m::fma(eps, rho, u)) : T(0);  // 1 / (rho (rho + eps))
-    const T d2 = m::rcp(u + eps);
-    gx = m::fma(Rr * d1, xn, -(Az * d2 * yn));
-    gy = m::fma(Rr * d1, yn, Az * d2 * xn);
+  zernike_finish(s, xn, yn, u, zsum, gx, gy, sag, fx, fy);
+}
+
+// Low-order Zernike surface as one bivariate polynomial (kGeomZernikeMono, block layout in
+// device_table.h, expansion in capi.hip:build_zernike_mono_block): the sag polynomial S and
+// the gradient (dQ/dx_n, dQ/dy_n) of the normal's polynomial by nested Horner -- outer in
+// x_n, inner in y_n -- straight from the coefficient stream.  One FMA per coefficient for S
+// and one PACKED FMA per coefficient pair for the gradient (v_pk_fma_f32: both partial
+// derivatives in one issue slot); no harmonic recurrence, no per-order epilogue.  For the
+// 12 fringe terms of configuration C5 (degree 4): 15 + 10 FMAs against ~130 vector
+// instructions of the level form.  Degrees 2..6 are compiled with the degree known (fully
+// unrolled: the scalar loads of the whole block issue up front), the rest run the loops.
+// OL_ZERN_MONO_SPLIT (default on): keeps the compiler from hoisting ALL of the gradient
+// block's scalar loads above the sag chain -- with 35 coefficient SGPRs live at once at
+// degree 4 the allocator spilled ~17 SGPRs to VGPR lanes (v_writelane / v_readlane, vector
+// instructions) around every evaluation; split, the degree-4 block is 36 vector
+// instructions and no spill.  A/B knob, tools/build_variants.py.
+#ifndef OL_ZERN_MONO_SPLIT
+#define OL_ZERN_MONO_SPLIT 1
+#endif
+#if OL_ZERN_MONO_SPLIT && defined(__HIP_DEVICE_COMPILE__)
+#define OL_ZERN_MONO_PHASE_FENCE asm volatile("" ::: "memory");
+#else
+#define OL_ZERN_MONO_PHASE_FENCE
+#endif
+// OL_ZERN_MONO_FIXED = 0: no unrolled instances, every degree runs the loops (A/B knob)
+#ifndef OL_ZERN_MONO_FIXED
+#define OL_ZERN_MONO_FIXED 1
+#endif
+#define OL_ZERN_MONO_BODY(UNROLL)                                              \
+  using m = Math<T>;                                                           \
+  using V2 = vec2<T>;                                                          \
+  const T* p = c;                                                              \
+  T P = T(0);                                                                  \
+  UNROLL for (int i = N; i >= 0; --i) {                                        \
+    T q = *p++;                                                                \
+    UNROLL for (int j = N - i - 1; j >= 0; --j) q = m::fma(q, yn, *p++);       \
+    P = i == N ? q : m::fma(P, xn, q);                                         \
+  }                                                                            \
+  OL_ZERN_MONO_PHASE_FENCE                                                     \
+  const V2 xx = {xn, xn}, yy = {yn, yn};                                       \
+  V2 G = {T(0), T(0)};                                                         \
+  UNROLL for (int i = N - 1; i >= 0; --i) {                                    \
+    V2 q = {p[0], p[1]};                                                       \
+    p += 2;                                                                    \
+    UNROLL for (int j = N - 2 - i; j >= 0; --j) {                              \
+      const V2 cj = {p[0], p[1]};                                              \
+      p += 2;                                                                  \
+      q = q * yy + cj;                                                         \
+    }                                                                          \
+    G = i == N - 1 ? q : G * xx + q;                                           \
+  }                                                                            \
+  zsum = P;                                                                    \
+  gx = G.x;                                                                    \
+  gy = G.y;
+
+template <typename T, int N>
+OL_DEV void zernike_mono_fixed(const T* __restrict__ c, T xn, T yn, T& zsum, T& gx, T& gy) {
+  OL_ZERN_MONO_BODY(_Pragma("unroll"))
+}
+template <typename T>
+OL_DEV void zernike_mono_loop(const T* __restrict__ c, int N, T xn, T yn, T& zsum, T& gx, T& gy) {
+  OL_ZERN_MONO_BODY()
+}
+#undef OL_ZERN_MONO_BODY
+#undef OL_ZERN_MONO_PHASE_FENCE
+
+template <typename T>
+OL_DEV void zernike_mono_eval(const DevSurf<T>& s, const T* __restrict__ c, T x, T y, T& sag,
+                              T& fx, T& fy, uint32_t& status) {
+  T xn, yn, u, zsum, gx, gy;
+  zernike_begin(s, x, y, sag, fx, fy, xn, yn, u, status);
+  switch (OL_ZERN_MONO_FIXED ? s.n_coeff : 0) {  // wave-uniform
+    case 2: zernike_mono_fixed<T, 2>(c, xn, yn, zsum, gx, gy); break;
+    case 3: zernike_mono_fixed<T, 3>(c, xn, yn, zsum, gx, gy); break;
+    case 4: zernike_mono_fixed<T, 4>(c, xn, yn, zsum, gx, gy); break;
+    case 5: zernike_mono_fixed<T, 5>(c, xn, yn, zsum, gx, gy); break;
+    case 6: zernike_mono_fixed<T, 6>(c, xn, yn, zsum, gx, gy); break;
+    default: zernike_mono_loop<T>(c, s.n_coeff, xn, yn, zsum, gx, gy); break;
   }
-  sag += zsum;
-  fx = m::fma(gx, inv, fx);
-  fy = m::fma(gy, inv, fy);
+  zernike_finish(s, xn, yn, u, zsum, gx, gy, sag, fx, fy);
 }
 
 // chebyshev.py:126-225.  T_n by the three-term recurrence instead of
@@ -593,6 +692,7 @@ OL_DEV void nr_eval(const DevSurf<T>& s, const T* __restrict__ c, T x, T y,
     case kGeomChebyshev: chebyshev_eval(s, c, x, y, sag, fx, fy, status); break;
     case kGeomBiconic: biconic_eval(s, c, x, y, sag, fx, fy); break;
     case kGeomToroidal: toroidal_eval(s, c, x, y, sag, fx, fy); break;
+    case kGeomZernikeMono: zernike_mono_eval(s, c, x, y, sag, fx, fy, status); break;
     default: zernike_eval(s, c, x, y, sag, fx, fy, status); break;
   }
 }

@@ -200,3 +200,93 @@ def test_oracle_side_by_side_large(host, dtype):
     rec, _ = sysm.trace(planes, 0, record=True)
     tol = TOL[dtype]
     assert_close_planes(rec.astype(np.float64), want, tol, tol, "oracle-1e5")
+
+
+def _zernike_singlet(seed, degree, scheme_norm):
+    """A singlet whose first surface is a Zernike freeform with EVERY term of radial order
+    <= degree (random coefficients), second surface spherical, then the image plane."""
+    from optiland_amd import system as S
+    from optiland_amd.system import SystemTable
+    rng = np.random.default_rng(77_000 + 31 * seed + degree)
+    surf = np.zeros(4, dtype=S.SURFACE_DESC_DTYPE)
+    optics = np.zeros((4, 1), dtype=S.SURFACE_OPTICS_DTYPE)
+    surf["rot"] = np.eye(3).reshape(-1)
+    surf["norm_radius"] = 1.0
+    surf[0]["geom_kind"], surf[0]["interaction"] = S.GEOM_PLANE, S.INTERACT_RECORD_ONLY
+    surf[0]["origin"] = (0.0, 0.0, -10.0)
+    optics[0, 0] = (1.0, 1.0, 0.0)
+    terms = []
+    for n in range(degree + 1):
+        for m in range(-n, n + 1, 2):
+            if n == 0:
+                continue
+            c = rng.uniform(-1, 1) * 4e-3 / (1 + n * n)
+            if n < degree and rng.random() < 0.25:
+                c = 0.0  # holes, like a hand-written coefficient list
+            N = np.sqrt((2.0 if m else 1.0) * (n + 1)) if scheme_norm else 1.0
+            terms.extend([c, float(n), float(m), N])
+    surf[1]["geom_kind"], surf[1]["radius"], surf[1]["conic"] = S.GEOM_ZERNIKE, 60.0, -0.3
+    surf[1]["norm_radius"] = 9.0
+    surf[1]["max_iter"], surf[1]["tol"] = 100, 1e-12
+    surf[1]["coeff_offset"], surf[1]["n_coeff"] = 0, len(terms) // 4
+    surf[1]["interaction"] = S.INTERACT_REFRACT
+    surf[1]["origin"] = (0.0, 0.0, 0.0)
+    optics[1, 0] = (1.0, 1.5168, 0.0)
+    surf[2]["geom_kind"], surf[2]["radius"] = S.GEOM_STANDARD, -150.0
+    surf[2]["interaction"] = S.INTERACT_REFRACT
+    surf[2]["origin"] = (0.0, 0.0, 5.0)
+    optics[2, 0] = (1.5168, 1.0, 0.0)
+    surf[3]["geom_kind"], surf[3]["interaction"] = S.GEOM_PLANE, S.INTERACT_REFRACT
+    surf[3]["origin"] = (0.0, 0.0, 90.0)
+    optics[3, 0] = (1.0, 1.0, 0.0)
+    table = SystemTable(surfaces=surf, coeffs=np.array(terms, dtype=np.float64), optics=optics,
+                        wavelengths=np.array([0.55]), name=f"zern_deg{degree}_{seed}")
+    n = 1500
+    r, th = 7.5 * np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
+    rays = {"x": r * np.cos(th), "y": r * np.sin(th), "z": np.full(n, -10.0)}
+    L, M = rng.uniform(-0.05, 0.05, n), rng.uniform(-0.05, 0.05, n)
+    rays.update(L=L, M=M, N=np.sqrt(1 - L * L - M * M), i=np.ones(n))
+    # ray 0: down the axis through the vertex (the eps-regularised gradient, zernike.py:206-231);
+    # rays 1, 2: within 1e-6 / 1e-3 of it
+    for k, d in enumerate((0.0, 1e-6 * 9.0, 1e-3 * 9.0)):
+        rays["x"][k], rays["y"][k], rays["L"][k], rays["M"][k], rays["N"][k] = d, -d / 2, 0, 0, 1
+    return table, rays
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("scheme_norm", [False, True], ids=["fringe-like", "normalised"])
+@pytest.mark.parametrize("degree", range(1, 11))
+def test_zernike_every_degree(degree, scheme_norm, dtype):
+    """Degrees 2..6 run the unrolled one-polynomial evaluator, 1, 7, 8 its loop form, 9 and 10
+    the per-|m| level form (capi.hip: kZernMonoMaxDegree): each against the oracle (the
+    reference's polar formulas), including the vertex ray; and the two forms against each
+    other on the degrees where both exist."""
+    from oracle import oracle
+    from tests.test_hostmath_fuzz import _planes, _through_fp32
+    table, rays = _zernike_singlet(0, degree, scheme_norm)
+    if dtype == np.float32:
+        rays = _through_fp32(rays)
+    want = oracle.trace(table, rays, 0, record=True)
+    assert want["status"] == 0
+    sysm = hm.HostMathSystem(table)
+    got, status = sysm.trace(_planes(rays, dtype), 0, record=True)
+    sysm.close()
+    assert status == 0
+    tol = 1e-7 if dtype == np.float64 else 1e-4
+    assert_close_planes(got.astype(np.float64), want["record"], tol, tol, f"zern{degree}")
+    if dtype == np.float64:  # fp64: far inside the tolerance -- 1e-11 of the system size
+        assert_close_planes(got, want["record"], 1e-11, 1e-11, f"zern{degree}:tight")
+    # the level form of the same surface (OPTILAND_HIP_ZERNIKE_MONO=0 at ol_system_create)
+    import os
+    os.environ["OPTILAND_HIP_ZERNIKE_MONO"] = "0"
+    try:
+        lev = hm.HostMathSystem(table)
+    finally:
+        del os.environ["OPTILAND_HIP_ZERNIKE_MONO"]
+    got_lev, _ = lev.trace(_planes(rays, dtype), 0, record=True)
+    lev.close()
+    assert_close_planes(got_lev.astype(np.float64), want["record"], tol, tol, f"zern{degree}:levels")
+    same = np.array_equal(np.nan_to_num(got), np.nan_to_num(got_lev))
+    # degree <= 8 -> the two builds really are different evaluators (they differ in the last
+    # bits); above the cap both are the level form
+    assert same == (degree > 8), (degree, same)

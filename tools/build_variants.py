@@ -32,6 +32,11 @@ VARIANTS = {
     # plane accesses addressed per lane with 64-bit VGPR addresses (round-1 form) instead of
     # SGPR base + one shared 32-bit lane offset
     "vaddr": ["-DOL_SADDR=0"],
+    # low-order Zernike as one polynomial: no load fence between the sag
+    # and the gradient chains / no unrolled instances (every degree runs the loops).  The
+    # level form itself needs no build: OPTILAND_HIP_ZERNIKE_MONO=0 at ol_system_create.
+    "zmono_nosplit": ["-DOL_ZERN_MONO_SPLIT=0"],
+    "zmono_loops": ["-DOL_ZERN_MONO_FIXED=0"],
 }
 
 
