@@ -310,6 +310,32 @@ void release(DeviceTable<T>& t) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Which Newton kernel a traced range needs (trace_launch.h: launch_trace): 0 = none,
+// 3 / 4 = all of its Newton-Raphson surfaces are Zernike surfaces / even aspheres, else 1.
+// (A polygon aperture on a conic-only range also selects the generic kernel: polygons live
+// in the full kernels only.)
+int newton_family(const ol_system* sys, int32_t first, int32_t last) {
+  bool any = false, polygon = false, all_zernike = true, all_even = true;
+  for (int32_t s = first; s <= last; ++s) {
+    polygon = polygon || sys->polygon[s];
+    const int g = sys->geom[s];
+    if (g == OL_GEOM_PLANE || g == OL_GEOM_STANDARD) continue;
+    any = true;
+    all_zernike = all_zernike && g == OL_GEOM_ZERNIKE;
+    all_even = all_even && g == OL_GEOM_EVEN_ASPHERE;
+  }
+  if (!any) return polygon ? 1 : 0;
+  // OPTILAND_HIP_NR_FAMILY=0: always the generic Newton kernel (A/B runs; parity tests of the
+  // generic instantiation on single-family systems)
+  static const bool families = [] {
+    const char* e = getenv("OPTILAND_HIP_NR_FAMILY");
+    return !(e && e[0] == '0');
+  }();
+  if (families && all_zernike) return 3;
+  if (families && all_even) return 4;
+  return 1;
+}
+
 template <typename T>
 int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* const rays[8],
              int32_t wl, void* record, int64_t record_stride, void* prt, int32_t first,
@@ -352,11 +378,7 @@ int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* c
       alias = alias && (static_cast<T*>(rays[k]) == static_cast<T*>(record) + k * record_stride);
     if (alias) a.flags |= ol::kTraceRow0IsInput;
   }
-  bool has_newton = false;  // any Newton-Raphson geometry in the traced range?
-  for (int32_t s = first; s <= last; ++s)
-    has_newton = has_newton || sys->polygon[s] ||  // polygons live in the full kernels only
-                 (sys->geom[s] != OL_GEOM_PLANE && sys->geom[s] != OL_GEOM_STANDARD);
-  hipError_t e = ol::launch_trace<T>(a, vec, has_newton, stream);
+  hipError_t e = ol::launch_trace<T>(a, vec, newton_family(sys, first, last), stream);
   if (e != hipSuccess) return fail(OL_EHIP, "trace launch failed: %s", hipGetErrorString(e));
   return OL_OK;
 }

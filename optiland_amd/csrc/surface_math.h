@@ -682,9 +682,31 @@ OL_DEV void toroidal_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
   fy = valid ? sgR * d * dzy * isq : T(0);
 }
 
-template <typename T>
+// Which sag functors a kernel instantiation carries (template parameter NR of surface_step
+// and of the kernels).  The generic Newton kernel compiles all nine in: it is the kernel
+// that is shortest of scalar registers -- on MI355X ~250 of its vector instructions per
+// ray were SGPR spills to VGPR lanes (v_writelane / v_readlane) and the branch flags of
+// the nine-way dispatch, BEFORE any Newton arithmetic (profiles/r02_nr_kernel_overhead.txt).
+// A traced range whose Newton surfaces all belong to one family runs an instantiation with
+// that family's functors only (capi.hip:newton_family picks it per launch).
+constexpr int kNrNone = 0;       // conic-only range: no Newton code at all (lean kernel)
+constexpr int kNrGeneric = 1;    // every functor
+constexpr int kNrCompact = 2;    // every functor + wavefront straggler compaction (RPT > 1)
+constexpr int kNrZernike = 3;    // Zernike surfaces only (level form and one-polynomial form)
+constexpr int kNrEvenAsphere = 4;  // even aspheres only
+
+template <int NR = kNrGeneric, typename T>
 OL_DEV void nr_eval(const DevSurf<T>& s, const T* __restrict__ c, T x, T y,
                                         T& sag, T& fx, T& fy, uint32_t& status) {
+  if constexpr (NR == kNrZernike) {
+    if (s.geom == kGeomZernikeMono) zernike_mono_eval(s, c, x, y, sag, fx, fy, status);
+    else zernike_eval(s, c, x, y, sag, fx, fy, status);
+    return;
+  }
+  if constexpr (NR == kNrEvenAsphere) {
+    even_asphere_eval(s, c, x, y, sag, fx, fy);
+    return;
+  }
   switch (s.geom) {
     case kGeomEvenAsphere: even_asphere_eval(s, c, x, y, sag, fx, fy); break;
     case kGeomOddAsphere: odd_asphere_eval(s, c, x, y, sag, fx, fy); break;
@@ -721,14 +743,14 @@ struct NewtonRay {
   bool active;
 };
 
-template <typename T>
+template <int NR = kNrGeneric, typename T>
 OL_DEV void newton_iterate(const DevSurf<T>& s, const T* __restrict__ c,
                                                NewtonRay<T>& q, T L, T M, T N, int it,
                                                uint32_t& status) {
   using m = Math<T>;
   T xi = m::fma(q.dt, L, q.xb), yi = m::fma(q.dt, M, q.yb), zi = m::fma(q.dt, N, q.zb);
   T sag, fx, fy;
-  nr_eval(s, c, xi, yi, sag, fx, fy, status);
+  nr_eval<NR>(s, c, xi, yi, sag, fx, fy, status);
   T f = sag - zi;
   T af = m::abs(f);
   bool done = !(af >= s.cold->tol);                       // converged, or NaN
@@ -1371,7 +1393,7 @@ OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
       }
     }
   } else if constexpr (NR != 0) {
-    constexpr bool COMPACT = NR == 2;
+    constexpr bool COMPACT = NR == kNrCompact;
     NewtonRay<T> q[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -1391,7 +1413,7 @@ OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
       bool any = false;
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
-        if (q[k].active) newton_iterate(s, c, q[k], r[k].L, r[k].M, r[k].N, it, status);
+        if (q[k].active) newton_iterate<NR>(s, c, q[k], r[k].L, r[k].M, r[k].N, it, status);
         any = any || q[k].active;
       }
       if constexpr (COMPACT && RPT > 1) {
@@ -1431,7 +1453,7 @@ OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
       for (int k = 0; k < RPT; ++k) {
         T sag;
         uint32_t st = 0;
-        nr_eval(s, c, r[k].x, r[k].y, sag, q[k].gx, q[k].gy, st);
+        nr_eval<NR>(s, c, r[k].x, r[k].y, sag, q[k].gx, q[k].gy, st);
       }
     }
     // n = (fx, fy, -1) / |.| from the sag gradient (newton_raphson.py:80-98)

@@ -37,6 +37,9 @@
 #ifndef OL_TABLE_IN_LDS
 #define OL_TABLE_IN_LDS 0  // 1: stage the surface table in LDS (measured slower)
 #endif
+#ifndef OL_NR_PREFETCH
+#define OL_NR_PREFETCH 0  // 1: prefetch the next surface's hot block in the Newton kernels too
+#endif
 
 #include "surface_math.h"
 
@@ -283,10 +286,25 @@ struct SpotAcc {
 #ifndef OL_POLNR_WAVES
 #define OL_POLNR_WAVES 7
 #endif
+
+// trace_kernel's arguments are four table pointers (32 bytes) and then the TraceArgs block
+// (8-byte aligned): its offset in the kernarg segment.
+constexpr int kTraceArgsKernargOffset = 32;
+
+// A kernel argument block read from the kernarg segment at the point of use (scalar loads
+// from the constant address space) instead of being kept live from the prologue.  The
+// empty asm hides the pointer's provenance, so the loads cannot be hoisted back.
+template <typename A>
+__device__ __forceinline__ const __attribute__((address_space(4))) A* kernarg_again(int offset) {
+  using CP = const __attribute__((address_space(4))) char*;
+  CP p = (CP)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return reinterpret_cast<const __attribute__((address_space(4))) A*>(p + offset);
+}
 template <typename T, int RPT, int POLK, int NR>
 struct WavesPerEu {
   static constexpr int value =
-      (OL_POLNR_WAVES > 0 && sizeof(T) == 4 && RPT == 1 && POLK == 1 && NR == 1) ? OL_POLNR_WAVES
+      (OL_POLNR_WAVES > 0 && sizeof(T) == 4 && RPT == 1 && POLK == 1 && NR != 0) ? OL_POLNR_WAVES
                                                                                   : 1;
 };
 
@@ -410,17 +428,25 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
 #if OL_TABLE_IN_LDS
   DevSurfHot<T> cur = lds_hot[0];
 #else
+  // (the Newton kernels are short of SGPRs, not of latency hiding: no prefetch there --
+  // 16 fewer live scalars across the whole surface body)
+  constexpr bool kPrefetch = OL_NR_PREFETCH || NR == 0;
   DevSurfHot<T> cur = surf_tab[a.first];
 #endif
   for (int s = a.first; s <= a.last; ++s) {
     DevSurf<T> S;
-    static_cast<DevSurfHot<T>&>(S) = cur;
-    S.cold = cold_tab + s;
 #if OL_TABLE_IN_LDS
+    static_cast<DevSurfHot<T>&>(S) = cur;
     if (s < a.last) cur = lds_hot[s + 1 - a.first];
 #else
-    if (s < a.last) cur = surf_tab[s + 1];
+    if constexpr (kPrefetch) {
+      static_cast<DevSurfHot<T>&>(S) = cur;
+      if (s < a.last) cur = surf_tab[s + 1];
+    } else {
+      static_cast<DevSurfHot<T>&>(S) = surf_tab[s];
+    }
 #endif
+    S.cold = cold_tab + s;
     if (S.interaction != kRecordOnly) {
 #if OL_TABLE_IN_LDS
       const DevOptics<T> O = lds_opt[s - a.first];
@@ -466,7 +492,35 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
   }
   // (SPOT: a lane that re-traced the last ray must not write it back -- its owner may
   // already have, and then this lane started from the final state)
-  if ((a.flags & kTraceWriteRays) && (!SPOT || live)) {
+  // What the epilogue needs of the argument block -- the eight plane pointers, the PRT
+  // pointer, n, the status pointer -- is read AGAIN from the kernarg segment here, through
+  // a pointer the compiler cannot see through.  Held live from the prologue they were
+  // SGPR-spilled into VGPR lanes and reloaded (v_writelane / v_readlane are VECTOR
+  // instructions): ~45 per ray in the Newton kernels, which are short of SGPRs.
+  struct {
+    T* rays[8];
+    T* prt;
+    uint32_t* status;
+    int64_t n;
+    uint32_t flags;
+  } late;
+  if constexpr (NR != 0) {
+    const auto* q = kernarg_again<TraceArgs<T>>(kTraceArgsKernargOffset);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) late.rays[f] = q->rays[f];
+    late.prt = q->prt;
+    late.status = q->status;
+    late.n = q->n;
+    late.flags = q->flags;
+  } else {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) late.rays[f] = a.rays[f];
+    late.prt = a.prt;
+    late.status = a.status;
+    late.n = a.n;
+    late.flags = a.flags;
+  }
+  if ((late.flags & kTraceWriteRays) && (!SPOT || live)) {
     Ray<V> gv[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(last_traced, r[j]);
@@ -476,7 +530,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
     T tmp[RPT];
 #define OL_WB_FIELD(idx, fld)                                        \
   _Pragma("unroll") for (int k = 0; k < RPT; ++k) tmp[k] = g[k].fld; \
-  store_plane<T, RPT>(a.rays[idx], base, cnt, tmp);
+  store_plane<T, RPT>(late.rays[idx], base, cnt, tmp);
     OL_WB_FIELD(0, x)
     OL_WB_FIELD(1, y)
     OL_WB_FIELD(2, z)
@@ -493,10 +547,10 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
     for (int e = 0; e < NPRT; ++e) {
 #pragma unroll
       for (int k = 0; k < RPT; ++k) tmp[k] = P[k].m[e];
-      store_plane<T, RPT>(a.prt + (int64_t)e * a.n, base, cnt, tmp);
+      store_plane<T, RPT>(late.prt + (int64_t)e * late.n, base, cnt, tmp);
     }
   }
-  if (status && a.status) atomicOr(a.status, status);
+  if (status && late.status) atomicOr(late.status, status);
 }
 
 // --------------------------------------------------------------------------
@@ -543,6 +597,12 @@ static hipError_t launch_rpt(const TraceArgs<T>& a, int nr, hipStream_t stream) 
   if (nr == 0) return launch_nr<T, RPT, 0>(a, stream);
   if constexpr (RPT > 1) {
     if (nr == 2) return launch_nr<T, RPT, 2>(a, stream);
+  } else {
+    // single-family instantiations exist for one ray per lane, without the spot epilogue
+    if (a.spot == nullptr) {
+      if (nr == kNrZernike) return launch_nr<T, 1, kNrZernike>(a, stream);
+      if (nr == kNrEvenAsphere) return launch_nr<T, 1, kNrEvenAsphere>(a, stream);
+    }
   }
   return launch_nr<T, RPT, 1>(a, stream);
 }
@@ -577,10 +637,13 @@ Tuning& tuning() {
 #endif
 
 template <typename T>
-hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
+hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, int nr_family,
                         hipStream_t stream) {
   constexpr int kVec = 16 / sizeof(T);  // rays per 16-byte lane vector
-  const int nr = !has_newton ? 0 : ((a.flags & kTraceCompact) && tuning().compact ? 2 : 1);
+  // nr_family: kNrNone, kNrGeneric or a single-family kind (capi.hip:newton_family)
+  const int nr = nr_family == kNrNone
+                     ? kNrNone
+                     : ((a.flags & kTraceCompact) && tuning().compact ? kNrCompact : nr_family);
   if (!vector_ok || (a.prt && (a.flags & kTracePrtComplex)))
     return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
   // Defaults from interleaved A/B runs on MI355X (tools/ab_bench.py):
@@ -598,7 +661,7 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
     if (want == 3 && nr == 0 && a.prt == nullptr && a.spot == nullptr)
       return launch_pair<T>(a, stream);
   }
-  const bool prefer_one = nr == 1 || a.record != nullptr;
+  const bool prefer_one = (nr != kNrNone && nr != kNrCompact) || a.record != nullptr;
   if (want == 1 || (want == 0 && prefer_one && nr != 2))
     return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
   return launch_rpt<T, kVec>(a, nr, stream);
@@ -611,10 +674,10 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
 #define OL_TRACE_TU 0
 #endif
 #if OL_TRACE_TU != 2
-template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, bool, hipStream_t);
+template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, int, hipStream_t);
 #endif
 #if OL_TRACE_TU != 1
-template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, bool, hipStream_t);
+template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, int, hipStream_t);
 #endif
 
 // --------------------------------------------------------------------------

@@ -38,8 +38,11 @@ struct TraceArgs {
   uint32_t flags;
 };
 
+// nr_family: 0 = no Newton-Raphson geometry in the traced range (lean kernel), 1 = generic
+// Newton kernel, 3 / 4 = every Newton surface of the range is a Zernike surface / an even
+// asphere (single-family instantiations, surface_math.h kNr*)
 template <typename T>
-hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, bool has_newton,
+hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, int nr_family,
                         hipStream_t stream);
 
 // process-wide tuning knobs (ol_set_tuning)

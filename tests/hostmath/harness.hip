@@ -141,12 +141,18 @@ hipError_t trace_nr(const TraceArgs<T>& a) {
 
 }  // namespace
 
+// same choice of instantiation as trace_kernel.hip:launch_trace / launch_rpt (RPT = 1)
 template <typename T>
-hipError_t launch_trace(const TraceArgs<T>& a, bool, bool has_newton, hipStream_t) {
-  return has_newton ? trace_nr<T, 1>(a) : trace_nr<T, 0>(a);
+hipError_t launch_trace(const TraceArgs<T>& a, bool, int nr_family, hipStream_t) {
+  switch (nr_family) {
+    case kNrNone: return trace_nr<T, kNrNone>(a);
+    case kNrZernike: return trace_nr<T, kNrZernike>(a);
+    case kNrEvenAsphere: return trace_nr<T, kNrEvenAsphere>(a);
+    default: return trace_nr<T, kNrGeneric>(a);
+  }
 }
-template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, bool, hipStream_t);
-template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, bool, hipStream_t);
+template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, int, hipStream_t);
+template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, int, hipStream_t);
 
 // raygen_kernel + launch_raygen (aux_kernels.hip), ray by ray
 template <typename T>
