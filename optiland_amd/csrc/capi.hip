@@ -463,11 +463,7 @@ int do_trace_spot(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
   a.n_wl = sys->n_wl;
   a.wl = wl;
   a.tiles_per_block = 1;
-  bool has_newton = false;
-  for (int32_t s = 0; s < sys->n_surf; ++s)
-    has_newton = has_newton || sys->polygon[s] ||
-                 (sys->geom[s] != OL_GEOM_PLANE && sys->geom[s] != OL_GEOM_STANDARD);
-  hipError_t e = ol::launch_spot_trace<T>(a, vec, has_newton, stream);
+  hipError_t e = ol::launch_spot_trace<T>(a, vec, newton_family(sys, 0, sys->n_surf - 1), stream);
   if (e != hipSuccess) return fail(OL_EHIP, "spot launch failed: %s", hipGetErrorString(e));
   return OL_OK;
 }
@@ -501,11 +497,7 @@ int do_trace_opd(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
   a.last = sys->n_surf - 1;
   a.n_wl = sys->n_wl;
   a.wl = wl;
-  bool has_newton = false;
-  for (int32_t s = 0; s < sys->n_surf; ++s)
-    has_newton = has_newton || sys->polygon[s] ||
-                 (sys->geom[s] != OL_GEOM_PLANE && sys->geom[s] != OL_GEOM_STANDARD);
-  hipError_t e = ol::launch_opd_trace<T>(a, has_newton, stream);
+  hipError_t e = ol::launch_opd_trace<T>(a, newton_family(sys, 0, sys->n_surf - 1), stream);
   if (e != hipSuccess) return fail(OL_EHIP, "opd launch failed: %s", hipGetErrorString(e));
   return OL_OK;
 }

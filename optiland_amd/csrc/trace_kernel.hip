@@ -860,24 +860,28 @@ static hipError_t launch_spot_nr(const SpotArgs<T>& a_in, hipStream_t stream) {
 }
 
 template <typename T>
-hipError_t launch_spot_trace(const SpotArgs<T>& a, bool vector_ok, bool has_newton,
+hipError_t launch_spot_trace(const SpotArgs<T>& a, bool vector_ok, int nr_family,
                              hipStream_t stream) {
   constexpr int kVec = 16 / sizeof(T);
   // same defaults as record-last traces (launch_trace): conic-only ranges are ALU
-  // bound and want the 16-byte vector of rays per lane; Newton ranges one ray
+  // bound and want the 16-byte vector of rays per lane; Newton ranges one ray (and, like
+  // launch_trace, the single-family instantiation when the range allows it)
   const int want = tuning().rays_per_thread;
-  if (has_newton)
-    return (vector_ok && want == 2) ? launch_spot_nr<T, kVec, 1>(a, stream)
-                                    : launch_spot_nr<T, 1, 1>(a, stream);
+  if (nr_family != kNrNone) {
+    if (vector_ok && want == 2) return launch_spot_nr<T, kVec, 1>(a, stream);
+    if (nr_family == kNrZernike) return launch_spot_nr<T, 1, kNrZernike>(a, stream);
+    if (nr_family == kNrEvenAsphere) return launch_spot_nr<T, 1, kNrEvenAsphere>(a, stream);
+    return launch_spot_nr<T, 1, 1>(a, stream);
+  }
   if (!vector_ok || want == 1) return launch_spot_nr<T, 1, 0>(a, stream);
   return launch_spot_nr<T, kVec, 0>(a, stream);
 }
 
 #if OL_TRACE_TU != 2
-template hipError_t launch_spot_trace<float>(const SpotArgs<float>&, bool, bool, hipStream_t);
+template hipError_t launch_spot_trace<float>(const SpotArgs<float>&, bool, int, hipStream_t);
 #endif
 #if OL_TRACE_TU != 1
-template hipError_t launch_spot_trace<double>(const SpotArgs<double>&, bool, bool, hipStream_t);
+template hipError_t launch_spot_trace<double>(const SpotArgs<double>&, bool, int, hipStream_t);
 #endif
 
 // --------------------------------------------------------------------------
@@ -988,7 +992,7 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
 }
 
 template <typename T>
-hipError_t launch_opd_trace(const OpdArgs<T>& a_in, bool has_newton, hipStream_t stream) {
+hipError_t launch_opd_trace(const OpdArgs<T>& a_in, int nr_family, hipStream_t stream) {
   OpdArgs<T> a = a_in;
   uniform_field_tangents<T>(a.rg, a.in);
   int64_t blocks = (a.n + kTraceBlock - 1) / kTraceBlock;
@@ -998,7 +1002,11 @@ hipError_t launch_opd_trace(const OpdArgs<T>& a_in, bool has_newton, hipStream_t
 #define OL_OPD_LAUNCH(N, A)                                                                  \
   hipLaunchKernelGGL((opd_trace_kernel<T, N, A>), dim3((unsigned)blocks), dim3(kTraceBlock), \
                      0, stream, a.surf, a.cold, a.optics, a.coeffs, a)
-  if (has_newton) {
+  if (nr_family == kNrZernike) {
+    if (apod) OL_OPD_LAUNCH(kNrZernike, true); else OL_OPD_LAUNCH(kNrZernike, false);
+  } else if (nr_family == kNrEvenAsphere) {
+    if (apod) OL_OPD_LAUNCH(kNrEvenAsphere, true); else OL_OPD_LAUNCH(kNrEvenAsphere, false);
+  } else if (nr_family != kNrNone) {
     if (apod) OL_OPD_LAUNCH(1, true); else OL_OPD_LAUNCH(1, false);
   } else {
     if (apod) OL_OPD_LAUNCH(0, true); else OL_OPD_LAUNCH(0, false);
@@ -1008,7 +1016,7 @@ hipError_t launch_opd_trace(const OpdArgs<T>& a_in, bool has_newton, hipStream_t
 }
 
 #if OL_TRACE_TU != 1
-template hipError_t launch_opd_trace<double>(const OpdArgs<double>&, bool, hipStream_t);
+template hipError_t launch_opd_trace<double>(const OpdArgs<double>&, int, hipStream_t);
 #endif
 
 }  // namespace ol

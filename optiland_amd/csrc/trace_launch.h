@@ -118,7 +118,7 @@ struct SpotArgs {
 };
 
 template <typename T>
-hipError_t launch_spot_trace(const SpotArgs<T>& a, bool vector_ok, bool has_newton,
+hipError_t launch_spot_trace(const SpotArgs<T>& a, bool vector_ok, int nr_family,
                              hipStream_t stream);
 
 struct PolStateDev {
@@ -162,7 +162,7 @@ struct OpdArgs {
   int32_t n_wl, wl;
 };
 template <typename T>
-hipError_t launch_opd_trace(const OpdArgs<T>& a, bool has_newton, hipStream_t stream);
+hipError_t launch_opd_trace(const OpdArgs<T>& a, int nr_family, hipStream_t stream);
 
 template <typename T>
 hipError_t launch_pupil_fill(int64_t n, const T* opd, const T* inten, const T* pupil_x,

@@ -191,7 +191,7 @@ template hipError_t launch_raygen<double>(const RaygenDev&, const RaygenIn<doubl
 // part of the per-surface arithmetic this harness exists for
 #define OL_UNSUPPORTED(T)                                                                       \
   template <>                                                                                    \
-  hipError_t launch_spot_trace<T>(const SpotArgs<T>&, bool, bool, hipStream_t) {                 \
+  hipError_t launch_spot_trace<T>(const SpotArgs<T>&, bool, int, hipStream_t) {                 \
     return hipErrorNotSupported;                                                                 \
   }                                                                                              \
   template <>                                                                                    \
@@ -233,7 +233,7 @@ template hipError_t launch_raygen<double>(const RaygenDev&, const RaygenIn<doubl
 OL_UNSUPPORTED(float)
 OL_UNSUPPORTED(double)
 template <>
-hipError_t launch_opd_trace<double>(const OpdArgs<double>&, bool, hipStream_t) {
+hipError_t launch_opd_trace<double>(const OpdArgs<double>&, int, hipStream_t) {
   return hipErrorNotSupported;
 }
 
