@@ -484,7 +484,17 @@ int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void
  *                            (8-byte loads / stores; measured slower, kept for A/B)
  *   OL_TUNE_COMPACT          1 = wavefront straggler compaction in the Newton loop
  *                            (needs the vector layout; default 0, measured slower)
- * The environment variable OL_TRACE_RPT seeds OL_TUNE_RAYS_PER_THREAD.           */
+ * The environment variable OL_TRACE_RPT seeds OL_TUNE_RAYS_PER_THREAD.
+ *
+ * Environment variables read by the library (A/B runs and parity tests; results are the
+ * same to rounding either way):
+ *   OPTILAND_HIP_ZERNIKE_MONO=0  ol_system_create keeps every Zernike surface on the
+ *                                per-|m| level evaluator (default: radial order <= 8 is
+ *                                re-expressed as one bivariate polynomial)
+ *   OPTILAND_HIP_NR_FAMILY=0     every range with a Newton-Raphson surface runs the generic
+ *                                Newton kernel (default: a range whose Newton surfaces are
+ *                                all Zernike surfaces / all even aspheres runs a kernel
+ *                                instantiation carrying only that family's code)        */
 #define OL_TUNE_RAYS_PER_THREAD 0
 #define OL_TUNE_COMPACT 1
 int ol_set_tuning(int32_t knob, int32_t value);
