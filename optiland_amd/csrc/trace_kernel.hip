@@ -11,8 +11,10 @@
 // LDS: this is a streaming vector-ALU path bounded by HBM write bandwidth in
 // record-all mode.
 //
-// Per-surface arithmetic follows SURVEY.md Appendix A; each device function
-// cites the reference lines it implements.  Differences that are deliberate:
+// The per-surface arithmetic lives in surface_math.h (one definition for every kernel
+// here, compiled a second time for the host by tests/hostmath as a checker); it follows
+// SURVEY.md Appendix A and each function cites the reference lines it implements.
+// Differences that are deliberate:
 //   * conic intersection uses the cancellation-free root  t = C / q  (the
 //     reference's (-b +- sqrt(d)) / 2a loses digits for near-flat surfaces;
 //     same root selection rule, see conic_distance());
