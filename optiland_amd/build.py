@@ -19,7 +19,7 @@ LIBNAME = "liboptiland_hip.so"
 # translation units -- so that the two halves (the bulk of the build) run in parallel
 SOURCES = ("trace_kernel_f32.hip", "trace_kernel_f64.hip", "aux_kernels.hip", "capi.hip")
 HEADERS = ("device_table.h", "trace_launch.h", "raygen_device.h", "wavefront_device.h",
-           "surface_math.h", "trace_kernel.hip")
+           "epilogue_device.h", "surface_math.h", "trace_kernel.hip")
 ARCH = "gfx950"
 
 

@@ -7,6 +7,7 @@
 
 #include "raygen_device.h"
 #include "wavefront_device.h"
+#include "epilogue_device.h"
 #include "trace_launch.h"
 
 namespace ol {
@@ -66,8 +67,7 @@ hipError_t launch_raygen(const RaygenDev& p, const RaygenIn<T>& in_, int64_t n, 
   return hipGetLastError();
 }
 
-// rays/polarized_rays.py:68-133, 204-233.  Real PRT: |P E0|^2 = |P Re E0|^2 +
-// |P Im E0|^2; complex PRT (CPLX, 18 planes): full complex product.
+// rays/polarized_rays.py:68-133, 204-233: per-ray arithmetic in epilogue_device.h
 template <typename T, bool CPLX>
 __global__ __launch_bounds__(kBlock) void pol_intensity_kernel(int64_t n, const T* __restrict__ prt,
                                                                const T* __restrict__ k0x,
@@ -76,51 +76,17 @@ __global__ __launch_bounds__(kBlock) void pol_intensity_kernel(int64_t n, const 
                                                                const T* __restrict__ i0,
                                                                PolStateDev st, T* intensity,
                                                                uint32_t* status) {
-  // field amplitudes: E0 = Ex e^{i phx} s_hat + Ey e^{i phy} p_hat
-  T ar[2], ai[2], br[2], bi[2];
-  int nf;
-  if (st.is_polarized) {
-    nf = 1;
-    ar[0] = (T)(st.Ex * cos(st.phase_x));
-    ai[0] = (T)(st.Ex * sin(st.phase_x));
-    br[0] = (T)(st.Ey * cos(st.phase_y));
-    bi[0] = (T)(st.Ey * sin(st.phase_y));
-  } else {
-    nf = 2;
-    ar[0] = T(1); ai[0] = T(0); br[0] = T(0); bi[0] = T(0);
-    ar[1] = T(0); ai[1] = T(0); br[1] = T(1); bi[1] = T(0);
-  }
+  const PolFields<T> fld(st);
   uint32_t flag = 0;
   for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
        j += (int64_t)gridDim.x * kBlock) {
-    const T kx = k0x[j], ky = k0y[j], kz = k0z[j];
-    // p = k x x_hat = (0, kz, -ky), normalised; s = p x k
-    T nrm = sqrt(kz * kz + ky * ky);
-    if (nrm == T(0)) flag |= 0x2u;  // OL_STATUS_K_PARALLEL_X
-    const T px = T(0), py = kz / nrm, pz = -ky / nrm;
-    const T sx = py * kz - pz * ky, sy = pz * kx - px * kz, sz = px * ky - py * kx;
     T P[9], Q[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) {
       P[e] = prt[(int64_t)e * n + j];
       Q[e] = CPLX ? prt[(int64_t)(9 + e) * n + j] : T(0);
     }
-    T acc = T(0);
-    for (int f = 0; f < nf; ++f) {
-      const T er[3] = {ar[f] * sx + br[f] * px, ar[f] * sy + br[f] * py, ar[f] * sz + br[f] * pz};
-      const T ei[3] = {ai[f] * sx + bi[f] * px, ai[f] * sy + bi[f] * py, ai[f] * sz + bi[f] * pz};
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        T vr = P[3 * a] * er[0] + P[3 * a + 1] * er[1] + P[3 * a + 2] * er[2];
-        T vi = P[3 * a] * ei[0] + P[3 * a + 1] * ei[1] + P[3 * a + 2] * ei[2];
-        if (CPLX) {
-          vr -= Q[3 * a] * ei[0] + Q[3 * a + 1] * ei[1] + Q[3 * a + 2] * ei[2];
-          vi += Q[3 * a] * er[0] + Q[3 * a + 1] * er[1] + Q[3 * a + 2] * er[2];
-        }
-        acc += vr * vr + vi * vi;
-      }
-    }
-    intensity[j] = acc * i0[j] / T(nf);
+    intensity[j] = pol_intensity_one<T, CPLX>(fld, k0x[j], k0y[j], k0z[j], P, Q, i0[j], flag);
   }
   if (flag && status) atomicOr(status, flag);
 }
@@ -176,14 +142,11 @@ __global__ __launch_bounds__(kBlock) void pupil_fill_kernel(
        j += (int64_t)gridDim.x * kBlock) {
     double o = (double)opd[j];
     if (pupil_x) o -= c0 + c1 * (double)pupil_x[j] + c2 * (double)pupil_y[j];
-    const double amp = sqrt((double)inten[j]);
-    double sn, cs;
-    sincos(-6.283185307179586476925286766559 * o, &sn, &cs);
-    const int32_t cidx = cell[j];
-    const int64_t r = cidx / n_side, cc = cidx - r * n_side;
-    const int64_t at = ((r + pad) * (int64_t)grid + (cc + pad)) * 2;
-    out[at] = amp * cs;
-    out[at + 1] = amp * sn;
+    double re, im;
+    pupil_sample(o, (double)inten[j], re, im);
+    const int64_t at = pupil_cell_offset(cell[j], n_side, grid, pad);
+    out[at] = re;
+    out[at + 1] = im;
   }
 }
 

@@ -1,0 +1,83 @@
+// epilogue_device.h -- per-ray arithmetic of the epilogue kernels in aux_kernels.hip:
+// `update_intensity` of a polarised trace and one sample of the FFT-PSF pupil function.
+// OL_DEV like surface_math.h: device code in the product; tests/hostmath compiles it for
+// the host as a checker.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "trace_launch.h"
+
+namespace ol {
+
+// field amplitudes of the incident state: E0 = Ex e^{i phx} s_hat + Ey e^{i phy} p_hat
+// (rays/polarization_state.py:29-56); an unpolarised state is the mean of the x and the y
+// state (polarized_rays.py:122-133)
+template <typename T>
+struct PolFields {
+  T ar[2], ai[2], br[2], bi[2];
+  int nf;
+  OL_DEV explicit PolFields(const PolStateDev& st) {
+    if (st.is_polarized) {
+      nf = 1;
+      ar[0] = (T)(st.Ex * cos(st.phase_x));
+      ai[0] = (T)(st.Ex * sin(st.phase_x));
+      br[0] = (T)(st.Ey * cos(st.phase_y));
+      bi[0] = (T)(st.Ey * sin(st.phase_y));
+      ar[1] = ai[1] = br[1] = bi[1] = T(0);
+    } else {
+      nf = 2;
+      ar[0] = T(1); ai[0] = T(0); br[0] = T(0); bi[0] = T(0);
+      ar[1] = T(0); ai[1] = T(0); br[1] = T(1); bi[1] = T(0);
+    }
+  }
+};
+
+// rays/polarized_rays.py:68-133, 204-233.  Real PRT (P): |P E0|^2 = |P Re E0|^2 +
+// |P Im E0|^2; complex PRT (CPLX: P + i Q): full complex product.  (kx, ky, kz): the
+// direction the ray was launched with; flag gets OL_STATUS_K_PARALLEL_X (:221-222).
+template <typename T, bool CPLX>
+OL_DEV T pol_intensity_one(const PolFields<T>& f, T kx, T ky, T kz, const T (&P)[9],
+                           const T (&Q)[9], T i0, uint32_t& flag) {
+  // p = k x x_hat = (0, kz, -ky), normalised; s = p x k
+  T nrm = sqrt(kz * kz + ky * ky);
+  if (nrm == T(0)) flag |= 0x2u;  // OL_STATUS_K_PARALLEL_X
+  const T px = T(0), py = kz / nrm, pz = -ky / nrm;
+  const T sx = py * kz - pz * ky, sy = pz * kx - px * kz, sz = px * ky - py * kx;
+  T acc = T(0);
+  for (int k = 0; k < f.nf; ++k) {
+    const T er[3] = {f.ar[k] * sx + f.br[k] * px, f.ar[k] * sy + f.br[k] * py,
+                     f.ar[k] * sz + f.br[k] * pz};
+    const T ei[3] = {f.ai[k] * sx + f.bi[k] * px, f.ai[k] * sy + f.bi[k] * py,
+                     f.ai[k] * sz + f.bi[k] * pz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      T vr = P[3 * a] * er[0] + P[3 * a + 1] * er[1] + P[3 * a + 2] * er[2];
+      T vi = P[3 * a] * ei[0] + P[3 * a + 1] * ei[1] + P[3 * a + 2] * ei[2];
+      if (CPLX) {
+        vr -= Q[3 * a] * ei[0] + Q[3 * a + 1] * ei[1] + Q[3 * a + 2] * ei[2];
+        vi += Q[3 * a] * er[0] + Q[3 * a + 1] * er[1] + Q[3 * a + 2] * er[2];
+      }
+      acc += vr * vr + vi * vi;
+    }
+  }
+  return acc * i0 / T(f.nf);
+}
+
+// psf/fft.py:101-137: one sample A exp(-i 2 pi OPD) of the pupil function, and where it
+// goes in the zero-padded grid (re, im interleaved doubles)
+OL_DEV void pupil_sample(double opd_waves, double intensity, double& re, double& im) {
+  const double amp = sqrt(intensity);
+  double sn, cs;
+  sincos(-6.283185307179586476925286766559 * opd_waves, &sn, &cs);
+  re = amp * cs;
+  im = amp * sn;
+}
+
+OL_DEV int64_t pupil_cell_offset(int32_t cell, int32_t n_side, int32_t grid, int32_t pad) {
+  const int64_t r = cell / n_side, cc = cell - r * n_side;
+  return ((r + pad) * (int64_t)grid + (cc + pad)) * 2;
+}
+
+}  // namespace ol

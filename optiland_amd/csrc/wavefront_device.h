@@ -15,7 +15,7 @@ template <typename T>
 struct WavefrontConsts {
   T xc, yc, zc, R, ni, inv_w, ux, uy, half_epd, opd_ref, nx, ny, nz;
   bool planar;
-  __device__ __forceinline__ explicit WavefrontConsts(const WavefrontDev& p)
+  OL_DEV explicit WavefrontConsts(const WavefrontDev& p)
       : xc((T)p.xc), yc((T)p.yc), zc((T)p.zc), R((T)p.R), ni((T)p.n_image),
         inv_w((T)(1.0 / (p.wavelength_um * 1e-3))), ux((T)p.ux), uy((T)p.uy),
         half_epd((T)p.half_epd), opd_ref((T)p.opd_ref), nx((T)p.nx), ny((T)p.ny), nz((T)p.nz),
@@ -26,7 +26,7 @@ struct WavefrontConsts {
 // (px, py): its normalised pupil coordinates.  Returns the OPD in waves; pu = the point
 // where the back-propagated ray meets the reference surface.
 template <typename T>
-__device__ __forceinline__ T wavefront_one(const WavefrontConsts<T>& w, T xr, T yr, T zr, T Ld,
+OL_DEV T wavefront_one(const WavefrontConsts<T>& w, T xr, T yr, T zr, T Ld,
                                            T Md, T Nd, T opd_in, T px, T py, T (&pu)[3]) {
   const T L = -Ld, M = -Md, N = -Nd;  // trace backwards from the image
   T t;

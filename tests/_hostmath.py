@@ -155,6 +155,56 @@ class HostMathSystem:
         _check(self.lib, rc, "ol_generate_rays")
         return out, int(status[0])
 
+    # ---- epilogue kernels (csrc/epilogue_device.h, wavefront_device.h), host-run --------
+    def polarized_intensity(self, prt, k0, i0, polarization):
+        """ol_polarized_intensity; returns (intensity, status word)."""
+        n, dt = i0.size, i0.dtype
+        if polarization and polarization.get("is_polarized"):
+            st = _capi.PolarizationStateC(1, 0, polarization["Ex"], polarization["Ey"],
+                                          polarization["phase_x"], polarization["phase_y"])
+        else:
+            st = _capi.PolarizationStateC(0, 0, 0.0, 0.0, 0.0, 0.0)
+        k0 = [np.ascontiguousarray(k, dtype=dt) for k in k0]
+        out = np.empty(n, dtype=dt)
+        kp = (C.c_void_p * 3)(*[k.ctypes.data for k in k0])
+        status = np.zeros(1, dtype=np.uint32)
+        rc = self.lib.ol_polarized_intensity(_DT[dt], n, prt.ctypes.data,
+                                             1 if prt.shape[0] == 18 else 0, kp, i0.ctypes.data,
+                                             C.byref(st), out.ctypes.data, status.ctypes.data, None)
+        _check(self.lib, rc, "ol_polarized_intensity")
+        return out, int(status[0])
+
+    def wavefront_opd(self, params, rays7, px, py, want_pupil=True):
+        """ol_wavefront_opd; returns (opd in waves, (3, n) pupil points or None)."""
+        dt = px.dtype
+        n = px.size
+        p = _capi.WavefrontParams(**{k: float(params.get(k, 0.0)) for k, _ in
+                                     _capi.WavefrontParams._fields_})
+        rays7 = [np.ascontiguousarray(r, dtype=dt) for r in rays7]
+        opd = np.empty(n, dtype=dt)
+        pupil = np.empty((3, n), dtype=dt) if want_pupil else None
+        rp = (C.c_void_p * 7)(*[r.ctypes.data for r in rays7])
+        pp = (C.c_void_p * 3)(*[pupil[k].ctypes.data for k in range(3)]) if want_pupil else None
+        rc = self.lib.ol_wavefront_opd(C.byref(p), _DT[dt], n, rp, px.ctypes.data, py.ctypes.data,
+                                       opd.ctypes.data, pp, None)
+        _check(self.lib, rc, "ol_wavefront_opd")
+        return opd, pupil
+
+    def pupil_fill(self, opd, intensity, cell, n_side, grid_size, pupil_xy=None, plane=None):
+        """ol_pupil_fill; returns the (grid_size, grid_size) complex128 grid."""
+        n = opd.size
+        cell = np.ascontiguousarray(cell, dtype=np.int32)
+        grid = np.zeros((grid_size, grid_size), dtype=np.complex128)
+        co = px_ptr = py_ptr = None
+        if pupil_xy is not None:
+            co = (C.c_double * 3)(*[float(v) for v in plane])
+            px_ptr, py_ptr = pupil_xy[0].ctypes.data, pupil_xy[1].ctypes.data
+        rc = self.lib.ol_pupil_fill(_DT[opd.dtype], n, opd.ctypes.data, intensity.ctypes.data,
+                                    px_ptr, py_ptr, co, cell.ctypes.data, int(n_side),
+                                    int(grid_size), grid.ctypes.data, None)
+        _check(self.lib, rc, "ol_pupil_fill")
+        return grid
+
 
 def new_prt(n, dtype, complex_prt=False):
     p = np.zeros((18 if complex_prt else 9, n), dtype=dtype)

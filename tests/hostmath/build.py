@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "optiland_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libol_hostmath.so")
-DEPS = ("surface_math.h", "raygen_device.h", "device_table.h", "trace_launch.h", "capi.hip")
+DEPS = ("surface_math.h", "raygen_device.h", "wavefront_device.h", "epilogue_device.h",
+        "device_table.h", "trace_launch.h", "capi.hip")
 
 
 def _cpu_has_fma() -> bool:

@@ -31,6 +31,8 @@
 
 #include "../../optiland_amd/csrc/surface_math.h"
 #include "../../optiland_amd/csrc/raygen_device.h"
+#include "../../optiland_amd/csrc/wavefront_device.h"
+#include "../../optiland_amd/csrc/epilogue_device.h"
 #include "../../optiland_amd/csrc/trace_launch.h"
 
 // ---------------------------------------------------------------------------
@@ -187,27 +189,87 @@ template hipError_t launch_raygen<float>(const RaygenDev&, const RaygenIn<float>
 template hipError_t launch_raygen<double>(const RaygenDev&, const RaygenIn<double>&, int64_t,
                                           double* const[8], uint32_t*, hipStream_t);
 
-// everything else is a kernel with a workgroup reduction or an epilogue of its own: not
-// part of the per-surface arithmetic this harness exists for
+// pol_intensity_kernel (aux_kernels.hip), ray by ray
+template <typename T>
+hipError_t launch_pol_intensity(int64_t n, const T* prt, bool prt_complex, const T* const k0[3],
+                                const T* i0, const PolStateDev& st, T* intensity,
+                                uint32_t* status, hipStream_t) {
+  const PolFields<T> fld(st);
+  uint32_t flag = 0;
+  for (int64_t j = 0; j < n; ++j) {
+    T P[9], Q[9];
+    for (int e = 0; e < 9; ++e) {
+      P[e] = prt[(int64_t)e * n + j];
+      Q[e] = prt_complex ? prt[(int64_t)(9 + e) * n + j] : T(0);
+    }
+    intensity[j] = prt_complex
+                       ? pol_intensity_one<T, true>(fld, k0[0][j], k0[1][j], k0[2][j], P, Q, i0[j], flag)
+                       : pol_intensity_one<T, false>(fld, k0[0][j], k0[1][j], k0[2][j], P, Q, i0[j], flag);
+  }
+  if (flag && status) *status |= flag;
+  return hipSuccess;
+}
+template hipError_t launch_pol_intensity<float>(int64_t, const float*, bool, const float* const[3],
+                                                const float*, const PolStateDev&, float*,
+                                                uint32_t*, hipStream_t);
+template hipError_t launch_pol_intensity<double>(int64_t, const double*, bool,
+                                                 const double* const[3], const double*,
+                                                 const PolStateDev&, double*, uint32_t*,
+                                                 hipStream_t);
+
+// wavefront_kernel (aux_kernels.hip), ray by ray
+template <typename T>
+hipError_t launch_wavefront(const WavefrontDev& p, int64_t n, const T* const rays[7], const T* px,
+                            const T* py, T* opd_waves, T* const pupil[3], hipStream_t) {
+  const WavefrontConsts<T> w(p);
+  for (int64_t j = 0; j < n; ++j) {
+    T pu[3];
+    opd_waves[j] = wavefront_one<T>(w, rays[0][j], rays[1][j], rays[2][j], rays[3][j], rays[4][j],
+                                    rays[5][j], rays[6][j], px[j], py[j], pu);
+    if (pupil[0]) {
+      pupil[0][j] = pu[0];
+      pupil[1][j] = pu[1];
+      pupil[2][j] = pu[2];
+    }
+  }
+  return hipSuccess;
+}
+template hipError_t launch_wavefront<float>(const WavefrontDev&, int64_t, const float* const[7],
+                                            const float*, const float*, float*, float* const[3],
+                                            hipStream_t);
+template hipError_t launch_wavefront<double>(const WavefrontDev&, int64_t, const double* const[7],
+                                             const double*, const double*, double*,
+                                             double* const[3], hipStream_t);
+
+// pupil_fill_kernel (aux_kernels.hip), sample by sample
+template <typename T>
+hipError_t launch_pupil_fill(int64_t n, const T* opd, const T* inten, const T* pupil_x,
+                             const T* pupil_y, const double coef[3], const int32_t* cell,
+                             int32_t n_side, int32_t grid, int32_t pad, double* out, hipStream_t) {
+  for (int64_t j = 0; j < n; ++j) {
+    double o = (double)opd[j];
+    if (pupil_x) o -= coef[0] + coef[1] * (double)pupil_x[j] + coef[2] * (double)pupil_y[j];
+    double re, im;
+    pupil_sample(o, (double)inten[j], re, im);
+    const int64_t at = pupil_cell_offset(cell[j], n_side, grid, pad);
+    out[at] = re;
+    out[at + 1] = im;
+  }
+  return hipSuccess;
+}
+template hipError_t launch_pupil_fill<float>(int64_t, const float*, const float*, const float*,
+                                             const float*, const double[3], const int32_t*,
+                                             int32_t, int32_t, int32_t, double*, hipStream_t);
+template hipError_t launch_pupil_fill<double>(int64_t, const double*, const double*,
+                                              const double*, const double*, const double[3],
+                                              const int32_t*, int32_t, int32_t, int32_t, double*,
+                                              hipStream_t);
+
+// everything else is a kernel with a workgroup reduction of its own: not per-ray
+// arithmetic, not what this harness exists for
 #define OL_UNSUPPORTED(T)                                                                       \
   template <>                                                                                    \
   hipError_t launch_spot_trace<T>(const SpotArgs<T>&, bool, int, hipStream_t) {                 \
-    return hipErrorNotSupported;                                                                 \
-  }                                                                                              \
-  template <>                                                                                    \
-  hipError_t launch_pol_intensity<T>(int64_t, const T*, bool, const T* const[3], const T*,       \
-                                     const PolStateDev&, T*, uint32_t*, hipStream_t) {           \
-    return hipErrorNotSupported;                                                                 \
-  }                                                                                              \
-  template <>                                                                                    \
-  hipError_t launch_wavefront<T>(const WavefrontDev&, int64_t, const T* const[7], const T*,      \
-                                 const T*, T*, T* const[3], hipStream_t) {                       \
-    return hipErrorNotSupported;                                                                 \
-  }                                                                                              \
-  template <>                                                                                    \
-  hipError_t launch_pupil_fill<T>(int64_t, const T*, const T*, const T*, const T*,               \
-                                  const double[3], const int32_t*, int32_t, int32_t, int32_t,    \
-                                  double*, hipStream_t) {                                        \
     return hipErrorNotSupported;                                                                 \
   }                                                                                              \
   template <>                                                                                    \

@@ -195,3 +195,110 @@ def test_random_ray_generation(seed, dtype):
             continue
         np.testing.assert_allclose(gv, want[k], rtol=0, atol=tol * s_ * 10, err_msg=k)
     sysm.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("seed", range(25))
+def test_random_polarised_system_update_intensity(seed, dtype):
+    """trace + the `update_intensity` epilogue (csrc/epilogue_device.h) of random coated
+    systems, host-run, against the oracle's -- real and complex PRT planes."""
+    from oracle import oracle
+    table, rays = random_polarised_system(seed)
+    if dtype == np.float32:
+        rays = _through_fp32(rays)
+    n = rays["x"].size
+    out = oracle.trace(table, rays, 0, record=True, polarized=True)
+    sysm = hm.HostMathSystem(table)
+    planes = _planes(rays, dtype)
+    k0 = [planes[3].copy(), planes[4].copy(), planes[5].copy()]
+    i0 = planes[6].copy()
+    prt = np.empty((18 if table.needs_complex_prt else 9, n), dtype=dtype)
+    sysm.trace(planes, 0, record=True, prt=prt, prt_identity=True)
+    iu, status = sysm.polarized_intensity(prt, k0, i0, table.polarization)
+    sysm.close()
+    assert status == 0
+    want_i, wstatus = oracle.polarized_intensity(out["prt"], rays["L"], rays["M"], rays["N"],
+                                                 rays["i"], table.polarization)
+    assert wstatus == 0
+    tol = 1e-9 if dtype == np.float64 else 1e-4
+    np.testing.assert_allclose(np.nan_to_num(iu.astype(np.float64)), np.nan_to_num(want_i), rtol=0,
+                               atol=tol * 10)
+
+
+def test_update_intensity_k_parallel_to_x_sets_the_status_bit():
+    table, rays = random_polarised_system(0)
+    sysm = hm.HostMathSystem(table)
+    n = 4
+    prt = hm.new_prt(n, np.float64, table.needs_complex_prt)
+    k0 = [np.ones(n), np.zeros(n), np.zeros(n)]
+    _, status = sysm.polarized_intensity(prt, k0, np.ones(n), table.polarization)
+    sysm.close()
+    assert status & S.STATUS_K_PARALLEL_X
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_wavefront_opd(seed, dtype=np.float64):
+    """`ol_wavefront_opd` (csrc/wavefront_device.h), host-run, against the oracle: random
+    image-plane bundles, spherical and planar references, with and without tilt terms.
+    fp64 like the GPU test (wavefront work is fp64 throughout the package; the generator
+    starts its rays ON the reference sphere, where the reference's root choice `t1 < 0`
+    is decided by the last bits -- fine in fp64, a coin toss in fp32)."""
+    from oracle import oracle
+    from optiland_amd import load_system
+    rng = np.random.default_rng(60_000 + seed)
+    n = 5003
+    R = float(rng.uniform(30, 400)) * (1 if rng.random() < 0.8 else -1)
+    zc = float(rng.uniform(50, 150))
+    params = {"xc": float(rng.uniform(-2, 2)), "yc": float(rng.uniform(-2, 2)), "zc": zc - R,
+              "R": R, "n_image": float(rng.choice([1.0, 1.33])), "opd_ref": float(rng.uniform(90, 110)),
+              "ux": float(rng.uniform(-0.05, 0.05)) if seed % 2 else 0.0,
+              "uy": float(rng.uniform(-0.05, 0.05)) if seed % 2 else 0.0,
+              "half_epd": float(rng.uniform(3, 12)), "wavelength_um": float(rng.uniform(0.4, 1.6))}
+    if seed % 4 == 3:
+        nv = np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), 1.0])
+        nv /= np.linalg.norm(nv)
+        params.update(zc=zc - abs(R), nx=float(nv[0]), ny=float(nv[1]), nz=float(nv[2]))
+    L, M = rng.uniform(-0.15, 0.15, n), rng.uniform(-0.15, 0.15, n)
+    rays7 = [rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n), np.full(n, zc),
+             L, M, np.sqrt(1 - L * L - M * M), rng.uniform(95, 105, n)]
+    r, th = np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
+    px, py = r * np.cos(th), r * np.sin(th)
+    want, want_pupil = oracle.wavefront_opd(params, rays7, px, py)
+    sysm = hm.HostMathSystem(load_system("cooke_generic"))
+    got, pupil = sysm.wavefront_opd(params, [np.ascontiguousarray(a, dtype=dtype) for a in rays7],
+                                    np.ascontiguousarray(px, dtype=dtype),
+                                    np.ascontiguousarray(py, dtype=dtype))
+    sysm.close()
+    assert np.isfinite(want).all()
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(want).max()))
+    np.testing.assert_allclose(pupil, want_pupil, rtol=0, atol=1e-10 * abs(R))
+
+
+def test_pupil_fill_is_the_definition():
+    """`ol_pupil_fill` (psf/fft.py:101-137), host-run: A exp(-i 2 pi (OPD - plane)) of the
+    compacted samples at their cells of the zero-padded grid, everything else untouched."""
+    from optiland_amd import load_system
+    rng = np.random.default_rng(5)
+    n_side, grid = 37, 128
+    yy, xx = np.mgrid[0:n_side, 0:n_side]
+    X = (xx - (n_side - 1) / 2) / ((n_side - 1) / 2)
+    Y = (yy - (n_side - 1) / 2) / ((n_side - 1) / 2)
+    inside = (X * X + Y * Y) <= 1.0
+    cell = np.flatnonzero(inside.ravel()).astype(np.int32)
+    n = cell.size
+    opd = rng.normal(0, 0.3, n)
+    inten = rng.uniform(0.2, 1.0, n)
+    pxy = (X.ravel()[cell].copy(), Y.ravel()[cell].copy())
+    plane = (0.05, -0.2, 0.11)
+    sysm = hm.HostMathSystem(load_system("cooke_generic"))
+    for use_plane in (False, True):
+        g = sysm.pupil_fill(opd, inten, cell, n_side, grid, pupil_xy=pxy if use_plane else None,
+                            plane=plane if use_plane else None)
+        o = opd - (plane[0] + plane[1] * pxy[0] + plane[2] * pxy[1]) if use_plane else opd
+        want = np.zeros((grid, grid), dtype=np.complex128)
+        pad = (grid - n_side) // 2
+        sub = np.zeros(n_side * n_side, dtype=np.complex128)
+        sub[cell] = np.sqrt(inten) * np.exp(-2j * np.pi * o)
+        want[pad:pad + n_side, pad:pad + n_side] = sub.reshape(n_side, n_side)
+        np.testing.assert_allclose(g, want, rtol=0, atol=1e-14)
+    sysm.close()
