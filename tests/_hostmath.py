@@ -34,7 +34,8 @@ def available() -> bool:
 def load():
     global _LIB
     if _LIB is None:
-        path = _builder().build()
+        # OL_HOSTMATH_LIBRARY: the sanitized build (tests/test_hostmath_sanitized.py)
+        path = os.environ.get("OL_HOSTMATH_LIBRARY") or _builder().build()
         lib = C.CDLL(path)
         assert lib.ol_hostmath_harness() == 1
         _capi.bind(lib, path)
