@@ -94,3 +94,53 @@ def test_random_reference_lens_equals_the_kernel_source(ref, seed):  # noqa: F81
             np.testing.assert_allclose(np.nan_to_num(iu), np.nan_to_num(np.asarray(ref_rays.i)),
                                        rtol=0, atol=1e-7)
     sysm.close()
+
+
+def test_reference_prt_noise_at_equal_index_planes_beyond_45_degrees(ref):  # noqa: F811
+    """A reference finding, pinned.  At a surface that does not deviate
+    the ray (the image plane, dummy planes: n1 == n2) `RealRays.refract` computes
+    root = sqrt(1 - (1 - dot^2)); for |dot|^2 >= 1/2 that is `dot` exactly and k1 == k0, the
+    reference's `s = k0 x k1` is exactly zero and it falls back to fixed axes -- the PRT
+    matrix stays what it was.  Beyond 45 degrees of incidence the subtraction rounds, k1
+    differs from k0 in the last bit, `k0 x k1` is normalised rounding noise that is not
+    orthogonal to k0, and `O_out O_in` is no longer the identity: a growing fraction of the
+    rays leaves the image plane with a PRT off by up to ~0.3.  The kernel recognises the
+    non-deviating surface and leaves the matrix alone -- the value the reference itself
+    returns below 45 degrees."""
+    from optiland.rays.polarized_rays import PolarizedRays
+    from optiland_amd import system as S
+    from optiland_amd.system import SystemTable
+    rng = np.random.default_rng(0)
+    n = 2000
+    th, ph = np.radians(rng.uniform(0, 80, n)), rng.uniform(0, 2 * np.pi, n)
+    L, M, N = np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)
+    r = PolarizedRays(np.zeros(n), np.zeros(n), np.zeros(n), L, M, N, np.ones(n),
+                      np.full(n, 0.55))
+    r.refract(np.zeros(n), np.zeros(n), np.ones(n), 1.5, 1.5)
+    r.update(None)
+    err = np.abs(np.asarray(r.p) - np.eye(3)).max((1, 2))
+    deg = np.degrees(th)
+    assert err[deg < 44].max() < 1e-14          # exact below 45 degrees
+    assert err[deg > 46].max() > 1e-2           # noise above
+    assert (err[deg > 60] > 1e-6).mean() > 0.2
+    # the kernel source on the same rays: an uncoated plane between equal indices
+    surf = np.zeros(2, dtype=S.SURFACE_DESC_DTYPE)
+    optics = np.zeros((2, 1), dtype=S.SURFACE_OPTICS_DTYPE)
+    surf["rot"] = np.eye(3).reshape(-1)
+    surf["norm_radius"] = 1.0
+    surf[0]["interaction"] = S.INTERACT_RECORD_ONLY
+    surf[0]["origin"] = (0.0, 0.0, -1.0)
+    surf[1]["geom_kind"], surf[1]["interaction"] = S.GEOM_PLANE, S.INTERACT_REFRACT
+    surf[1]["radius"] = np.inf
+    optics[0, 0] = (1.5, 1.5, 0.0)
+    optics[1, 0] = (1.5, 1.5, 0.0)
+    table = SystemTable(surfaces=surf, coeffs=np.zeros(0), optics=optics,
+                        wavelengths=np.array([0.55]), name="equal_index_plane")
+    table.polarization = {"is_polarized": False}
+    sysm = hm.HostMathSystem(table)
+    rays = [np.zeros(n), np.zeros(n), np.full(n, -1.0), L.copy(), M.copy(), N.copy(), np.ones(n),
+            np.zeros(n)]
+    prt = np.empty((9, n))
+    sysm.trace(rays, 0, record=False, prt=prt, prt_identity=True)
+    sysm.close()
+    assert np.abs(hm.prt_to_complex(prt).real - np.eye(3)).max() == 0.0
