@@ -2,8 +2,8 @@
 """CPU: many more seeds of tests/test_gpu_fuzz.py's generators through the HOST build of the
 kernel source (tests/hostmath) against the oracle, fp64.  Not a test: with thousands of wide
 random bundles some rays land where no two implementations can agree, and every discrepancy
-wants triage.  Round 2, seeds 1000-1599 x 3 generators: 17 systems with a discrepancy, all
-of three kinds: chaotic Newton iterations on folded-over aspheres far
+wants triage.  Round 2, seeds 1000-4999 x 3 generators (12000 systems): 106 with a
+discrepancy, all of three kinds: chaotic Newton iterations on folded-over aspheres far
 outside their aperture (and what follows downstream of them), the reference's cancelling
 root formula on a paraboloid hit almost along the axis (the kernel's root is the exact one to
 1e-12, checked in 40-digit arithmetic), and the reference's noise PRT at equal-index planes
