@@ -39,8 +39,22 @@
 #ifndef OL_TABLE_IN_LDS
 #define OL_TABLE_IN_LDS 0  // 1: stage the surface table in LDS (measured slower)
 #endif
+// Hot-block prefetch policy (A/B knobs, tools/build_variants.py).  The next surface's
+// DevSurfHot (16 elements: 16 SGPRs in fp32, 32 in fp64) is requested before the current
+// surface is worked on.  Measured good for the fp32 lean trace kernel (round 1) and bad for
+// the fp32 Newton trace kernels (SGPR spills).  Not yet measured
+// separately: the fp64 kernels (where it holds 32 more SGPRs and the static spill counts
+// are high: opd_trace_kernel<double,0,false> 223 lane operations of 1072 vector
+// instructions) and the fused spot / OPD Newton kernels -- OL_PREFETCH_F64 = 0 and
+// OL_FUSED_NR_PREFETCH = 0 switch those off.
 #ifndef OL_NR_PREFETCH
 #define OL_NR_PREFETCH 0  // 1: prefetch the next surface's hot block in the Newton kernels too
+#endif
+#ifndef OL_PREFETCH_F64
+#define OL_PREFETCH_F64 1
+#endif
+#ifndef OL_FUSED_NR_PREFETCH
+#define OL_FUSED_NR_PREFETCH 1
 #endif
 
 #include "surface_math.h"
@@ -432,7 +446,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
 #else
   // (the Newton kernels are short of SGPRs, not of latency hiding: no prefetch there --
   // 16 fewer live scalars across the whole surface body)
-  constexpr bool kPrefetch = OL_NR_PREFETCH || NR == 0;
+  constexpr bool kPrefetch = (OL_NR_PREFETCH || NR == 0) && (OL_PREFETCH_F64 || sizeof(T) == 4);
   DevSurfHot<T> cur = surf_tab[a.first];
 #endif
   for (int s = a.first; s <= a.last; ++s) {
@@ -795,12 +809,18 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
     DevSurf<T> last_traced;
     last_traced.cold = cold_tab;
     Prt<T, 0> P[1];
+    constexpr bool kPrefetch =
+        (OL_FUSED_NR_PREFETCH || NR == 0) && (OL_PREFETCH_F64 || sizeof(T) == 4);
     DevSurfHot<T> cur = surf_tab[a.first];
     for (int s = a.first; s <= a.last; ++s) {
       DevSurf<T> S;
-      static_cast<DevSurfHot<T>&>(S) = cur;
+      if constexpr (kPrefetch) {
+        static_cast<DevSurfHot<T>&>(S) = cur;
+        if (s < a.last) cur = surf_tab[s + 1];
+      } else {
+        static_cast<DevSurfHot<T>&>(S) = surf_tab[s];
+      }
       S.cold = cold_tab + s;
-      if (s < a.last) cur = surf_tab[s + 1];
       if (S.interaction != kRecordOnly) {
         const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
         surface_step<V, NV, 0, NR>(S, O, coeff_tab, is_global, r, P, status, prt_fresh);
@@ -932,12 +952,18 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
     DevSurf<T> last_traced;
     last_traced.cold = cold_tab;
     Prt<T, 0> P[1];
+    constexpr bool kPrefetch =
+        (OL_FUSED_NR_PREFETCH || NR == 0) && (OL_PREFETCH_F64 || sizeof(T) == 4);
     DevSurfHot<T> cur = surf_tab[a.first];
     for (int sidx = a.first; sidx <= a.last; ++sidx) {
       DevSurf<T> S;
-      static_cast<DevSurfHot<T>&>(S) = cur;
+      if constexpr (kPrefetch) {
+        static_cast<DevSurfHot<T>&>(S) = cur;
+        if (sidx < a.last) cur = surf_tab[sidx + 1];
+      } else {
+        static_cast<DevSurfHot<T>&>(S) = surf_tab[sidx];
+      }
       S.cold = cold_tab + sidx;
-      if (sidx < a.last) cur = surf_tab[sidx + 1];
       if (S.interaction != kRecordOnly) {
         const DevOptics<T> O = optics_tab[sidx * a.n_wl + a.wl];
         surface_step<T, 1, 0, NR>(S, O, coeff_tab, is_global, r, P, status, prt_fresh);

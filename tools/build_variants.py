@@ -37,6 +37,12 @@ VARIANTS = {
     # level form itself needs no build: OPTILAND_HIP_ZERNIKE_MONO=0 at ol_system_create.
     "zmono_nosplit": ["-DOL_ZERN_MONO_SPLIT=0"],
     "zmono_loops": ["-DOL_ZERN_MONO_FIXED=0"],
+    # hot-block prefetch policy (trace_kernel.hip): not yet measured for the fp64 kernels
+    # (32 more live SGPRs; static SGPR-spill counts drop without it) and for the fused
+    # spot / OPD Newton kernels -- tools/gpu_ab_prefetch.sh
+    "noprefetch_f64": ["-DOL_PREFETCH_F64=0"],
+    "noprefetch_fused_nr": ["-DOL_FUSED_NR_PREFETCH=0"],
+    "nr_prefetch": ["-DOL_NR_PREFETCH=1"],
 }
 
 
