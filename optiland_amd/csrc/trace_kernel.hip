@@ -42,11 +42,12 @@
 // Hot-block prefetch policy (A/B knobs, tools/build_variants.py).  The next surface's
 // DevSurfHot (16 elements: 16 SGPRs in fp32, 32 in fp64) is requested before the current
 // surface is worked on.  Measured good for the fp32 lean trace kernel (round 1) and bad for
-// the fp32 Newton trace kernels (SGPR spills).  Not yet measured
-// separately: the fp64 kernels (where it holds 32 more SGPRs and the static spill counts
-// are high: opd_trace_kernel<double,0,false> 223 lane operations of 1072 vector
-// instructions) and the fused spot / OPD Newton kernels -- OL_PREFETCH_F64 = 0 and
-// OL_FUSED_NR_PREFETCH = 0 switch those off.
+// the fp32 Newton trace kernels (SGPR spills); neutral (within 1 %) on
+// the fp64 lean record-all and fused-spot kernels although it holds 32 more SGPRs there and
+// the static spill counts drop without it (profiles/r02_ab_prefetch_f64.txt).  Not yet
+// measured: the fused spot / OPD Newton kernels and opd_trace_kernel<double,0> (223 lane
+// operations of 1072 vector instructions) -- OL_PREFETCH_F64 = 0 and
+// OL_FUSED_NR_PREFETCH = 0 switch those off (tools/gpu_ab_prefetch.sh).
 #ifndef OL_NR_PREFETCH
 #define OL_NR_PREFETCH 0  // 1: prefetch the next surface's hot block in the Newton kernels too
 #endif
