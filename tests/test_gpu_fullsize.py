@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._util import PLANES, assert_close_planes, load_case
+from tests._util import PLANES, assert_close_planes
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"

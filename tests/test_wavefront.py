@@ -268,7 +268,6 @@ def test_pupil_fill_kernel_equals_definition():
 
 @pytest.mark.gpu
 def test_fused_opd_refusals():
-    from optiland_amd import _capi
     from optiland_amd.engine import HipSystem
     hip = HipSystem(load_system("zernike_fresnel_fringe"), "cuda:0")   # polarised coatings
     px = torch.zeros(8, dtype=torch.float64, device="cuda:0")

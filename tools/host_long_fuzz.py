@@ -20,7 +20,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle
 from tests import _hostmath as hm
-from tests._util import PLANES, assert_close_planes
+from tests._util import assert_close_planes
 from tests.test_gpu_fuzz import random_system, random_nr_system, random_polarised_system
 from tests.test_hostmath_fuzz import _planes
 bad=[]

@@ -6,7 +6,7 @@ import sys
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests", "refshim"), "/root/reference"]
-import numpy as np, warnings
+import warnings
 warnings.filterwarnings("ignore")
 import optiland.backend as be
 be.set_backend("numpy")
