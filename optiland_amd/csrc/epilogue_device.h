@@ -65,6 +65,40 @@ OL_DEV T pol_intensity_one(const PolFields<T>& f, T kx, T ky, T kz, const T (&P)
   return acc * i0 / T(f.nf);
 }
 
+// analysis/spot_diagram/core.py:329-372, 440-481: what one image-plane hit adds to the
+// masked (i > 0) spot moments about (cx, cy) -- count, sum dx, sum dy, sum dx^2, sum dy^2,
+// sum i -- and to the largest squared radius (NaN hits compare false and are skipped)
+template <typename T>
+OL_DEV void spot_accumulate(double (&s)[6], double& rmax, T x, T y, T i, double cx, double cy) {
+  if (i > T(0)) {
+    const double dx = (double)x - cx, dy = (double)y - cy;
+    const double dx2 = dx * dx, dy2 = dy * dy;
+    s[0] += 1.0;
+    s[1] += dx;
+    s[2] += dy;
+    s[3] += dx2;
+    s[4] += dy2;
+    s[5] += (double)i;
+    const double r2 = dx2 + dy2;
+    rmax = r2 > rmax ? r2 : rmax;
+  }
+}
+
+// what one ray adds to the twelve moments of ol_trace_opd (trace_launch.h: kOpdMoments):
+// the nine intensity-weighted moments of the tilt fit (wavefront/wavefront.py:103-148) and
+// count / sum / sum of squares of the OPD over rays with i > 0 (wavefront/opd.py:145-159)
+OL_DEV void opd_accumulate(double (&s)[kOpdMoments], double wi, double od, double X, double Y,
+                           bool alive) {
+  s[0] += wi; s[1] += wi * X; s[2] += wi * Y;
+  s[3] += wi * X * X; s[4] += wi * X * Y; s[5] += wi * Y * Y;
+  s[6] += wi * od; s[7] += wi * od * X; s[8] += wi * od * Y;
+  if (alive) {
+    s[9] += 1.0;
+    s[10] += od;
+    s[11] += od * od;
+  }
+}
+
 // psf/fft.py:101-137: one sample A exp(-i 2 pi OPD) of the pupil function, and where it
 // goes in the zero-padded grid (re, im interleaved doubles)
 OL_DEV void pupil_sample(double opd_waves, double intensity, double& re, double& im) {

@@ -34,6 +34,7 @@
 #include "device_table.h"
 #include "raygen_device.h"
 #include "wavefront_device.h"
+#include "epilogue_device.h"
 #include "trace_launch.h"
 
 #ifndef OL_TABLE_IN_LDS
@@ -224,18 +225,7 @@ struct SpotAcc {
   double rmax = 0.0;
   template <typename T>
   __device__ __forceinline__ void add(T x, T y, T i, double cx, double cy) {
-    if (i > T(0)) {
-      const double dx = (double)x - cx, dy = (double)y - cy;
-      const double dx2 = dx * dx, dy2 = dy * dy;
-      s[0] += 1.0;
-      s[1] += dx;
-      s[2] += dy;
-      s[3] += dx2;
-      s[4] += dy2;
-      s[5] += (double)i;
-      const double r2 = dx2 + dy2;
-      rmax = r2 > rmax ? r2 : rmax;  // NaN hits compare false and are skipped
-    }
+    spot_accumulate<T>(s, rmax, x, y, i, cx, cy);  // epilogue_device.h
   }
   // workgroup reduction -> 7 atomics into out[0..6]; EVERY thread of the workgroup
   // must call it (barrier inside)
@@ -984,15 +974,7 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
       a.pupil[1][j] = pu[1];
       a.pupil[2][j] = pu[2];
     }
-    const double wi = (double)g.i, od = (double)ov, X = (double)pu[0], Y = (double)pu[1];
-    s[0] += wi; s[1] += wi * X; s[2] += wi * Y;
-    s[3] += wi * X * X; s[4] += wi * X * Y; s[5] += wi * Y * Y;
-    s[6] += wi * od; s[7] += wi * od * X; s[8] += wi * od * Y;
-    if (g.i > T(0)) {
-      s[9] += 1.0;
-      s[10] += od;
-      s[11] += od * od;
-    }
+    opd_accumulate(s, (double)g.i, (double)ov, (double)pu[0], (double)pu[1], g.i > T(0));
   }
 
   // workgroup reduction -> kOpdMoments atomics (every thread reaches this point)

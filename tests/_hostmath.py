@@ -117,8 +117,8 @@ class HostMathSystem:
         _check(self.lib, rc, "ol_trace_ex")
         return rec, int(status[0])
 
-    def generate_rays(self, hx, hy, px, py, vx=1.0, vy=1.0, flags=0):
-        """ol_generate_rays with the table's ray-generation block; returns (8 planes, status)."""
+    def _raygen(self, hx, hy, px, py, vx, vy, flags):
+        """(ol_raygen_params, ol_raygen_inputs, keep-alive list, n, dtype)"""
         rg = self.table.raygen
         if not rg:
             raise ValueError("this table has no ray-generation block")
@@ -148,6 +148,45 @@ class HostMathSystem:
                                     rg["z_first"], float(rg.get("tele_dz", 0.0)),
                                     float(rg.get("apod_a", 0.0)), float(rg.get("apod_b", 0.0)),
                                     int(rg.get("apod_kind", 0)), 0)
+        return params, inputs, keep, n, dt
+
+    def trace_spot(self, px, py, wl_index=0, *, hx=0.0, hy=0.0, vx=1.0, vy=1.0,
+                   center=(0.0, 0.0), want_hits=False, out=None, flags=0):
+        """ol_trace_spot (fused generate -> trace -> reduce), host-run; returns
+        (7 moments, hits (3, n) or None, status word)."""
+        params, inputs, keep, n, dt = self._raygen(hx, hy, px, py, vx, vy, flags)
+        out = np.zeros(7) if out is None else out
+        hits = np.empty((3, n), dtype=dt) if want_hits else None
+        hp = (C.c_void_p * 3)(*[hits[k].ctypes.data for k in range(3)]) if want_hits else None
+        status = np.zeros(1, dtype=np.uint32)
+        rc = self.lib.ol_trace_spot(self._handle, _DT[dt], n, C.byref(params), C.byref(inputs),
+                                    float(center[0]), float(center[1]), int(wl_index), hp,
+                                    out.ctypes.data, status.ctypes.data, None)
+        _check(self.lib, rc, "ol_trace_spot")
+        return out, hits, int(status[0])
+
+    def trace_opd(self, wparams, px, py, wl_index=0, *, field=(0.0, 0.0), vig=(1.0, 1.0),
+                  want_pupil=True, moments=None):
+        """ol_trace_opd (fused generate -> trace -> OPD, fp64), host-run; returns
+        (opd waves, intensity, pupil (3, n) or None, 12 moments, status word)."""
+        params, inputs, keep, n, dt = self._raygen(float(field[0]), float(field[1]), px, py,
+                                                   float(vig[0]), float(vig[1]), 0)
+        w = _capi.WavefrontParams(**{k: float(wparams.get(k, 0.0)) for k, _ in
+                                     _capi.WavefrontParams._fields_})
+        moments = np.zeros(_capi.OPD_MOMENTS) if moments is None else moments
+        opd, inten = np.empty(n, dtype=dt), np.empty(n, dtype=dt)
+        pupil = np.empty((3, n), dtype=dt) if want_pupil else None
+        pp = (C.c_void_p * 3)(*[pupil[k].ctypes.data for k in range(3)]) if want_pupil else None
+        status = np.zeros(1, dtype=np.uint32)
+        rc = self.lib.ol_trace_opd(self._handle, _DT[dt], n, C.byref(params), C.byref(inputs),
+                                   C.byref(w), int(wl_index), opd.ctypes.data, inten.ctypes.data,
+                                   pp, moments.ctypes.data, status.ctypes.data, None)
+        _check(self.lib, rc, "ol_trace_opd")
+        return opd, inten, pupil, moments, int(status[0])
+
+    def generate_rays(self, hx, hy, px, py, vx=1.0, vy=1.0, flags=0):
+        """ol_generate_rays with the table's ray-generation block; returns (8 planes, status)."""
+        params, inputs, keep, n, dt = self._raygen(hx, hy, px, py, vx, vy, flags)
         out = [np.empty(n, dtype=dt) for _ in range(8)]
         ptrs = (C.c_void_p * 8)(*[o.ctypes.data for o in out])
         status = np.zeros(1, dtype=np.uint32)

@@ -265,13 +265,131 @@ template hipError_t launch_pupil_fill<double>(int64_t, const double*, const doub
                                               const int32_t*, int32_t, int32_t, int32_t, double*,
                                               hipStream_t);
 
-// everything else is a kernel with a workgroup reduction of its own: not per-ray
-// arithmetic, not what this harness exists for
+// The surface loop of the fused kernels for one ray (spot_trace_kernel / opd_trace_kernel:
+// generate -> trace -> final global state), RPT = 1
+template <typename T, int NR>
+Ray<T> fused_trace_one(const DevSurfHot<T>* surf, const DevSurfCold<T>* cold,
+                       const DevOptics<T>* optics, const T* coeffs, int first, int last,
+                       int n_wl, int wl, Ray<T> q, uint32_t& status) {
+  Ray<T> r[1] = {q};
+  Prt<T, 0> P[1];
+  bool is_global = true, prt_fresh = false;
+  DevSurf<T> last_traced;
+  std::memset(static_cast<void*>(&last_traced), 0, sizeof(last_traced));
+  last_traced.cold = cold;
+  for (int s = first; s <= last; ++s) {
+    DevSurf<T> S;
+    static_cast<DevSurfHot<T>&>(S) = surf[s];
+    S.cold = cold + s;
+    if (S.interaction != kRecordOnly) {
+      const DevOptics<T> O = optics[s * n_wl + wl];
+      surface_step<T, 1, 0, NR>(S, O, coeffs, is_global, r, P, status, prt_fresh);
+      is_global = false;
+      last_traced = S;
+    }
+  }
+  return is_global ? r[0] : to_global<T>(last_traced, r[0]);
+}
+
+template <typename T>
+Ray<T> fused_trace_family(int family, const DevSurfHot<T>* surf, const DevSurfCold<T>* cold,
+                          const DevOptics<T>* optics, const T* coeffs, int first, int last,
+                          int n_wl, int wl, const Ray<T>& q, uint32_t& status) {
+  switch (family) {
+    case kNrNone: return fused_trace_one<T, kNrNone>(surf, cold, optics, coeffs, first, last, n_wl, wl, q, status);
+    case kNrZernike: return fused_trace_one<T, kNrZernike>(surf, cold, optics, coeffs, first, last, n_wl, wl, q, status);
+    case kNrEvenAsphere: return fused_trace_one<T, kNrEvenAsphere>(surf, cold, optics, coeffs, first, last, n_wl, wl, q, status);
+    default: return fused_trace_one<T, kNrGeneric>(surf, cold, optics, coeffs, first, last, n_wl, wl, q, status);
+  }
+}
+
+// spot_trace_kernel + launch_spot_trace (trace_kernel.hip), ray by ray; the sums are
+// formed in ray order (the device adds wave / workgroup partials: equal to rounding)
+template <typename T>
+hipError_t launch_spot_trace(const SpotArgs<T>& a_in, bool, int nr_family, hipStream_t) {
+  SpotArgs<T> a = a_in;
+  if (a.in.hx == nullptr) uniform_field_tangents<T>(a.rg, a.in);
+  const RaygenConsts<T> c(a.rg);
+  const RaygenIn<T>& in_ = a.in;
+  const bool field_planes = in_.hx != nullptr, vig_planes = in_.vx != nullptr;
+  double s[6] = {0, 0, 0, 0, 0, 0}, rmax = 0.0;
+  uint32_t status = 0;
+  for (int64_t j = 0; j < a.n; ++j) {
+    T px = in_.px[j], py = in_.py[j];
+    const T vx = vig_planes ? in_.vx[j] : in_.vx0, vy = vig_planes ? in_.vy[j] : in_.vy0;
+    T tx = in_.tx0, ty = in_.ty0, o[6];
+    if (field_planes) {
+      if ((in_.flags & kRaygenCheckField) && (outside_unit(in_.hx[j]) || outside_unit(in_.hy[j])))
+        status |= kStatusFieldRange;
+      raygen_field<T>(c, in_.hx[j], in_.hy[j], tx, ty);
+    }
+    raygen_pupil<T>(in_.flags, vx, vy, px, py, status);
+    raygen_one<T>(c, tx, ty, px, py, vx, vy, o);
+    Ray<T> q;
+    q.x = o[0]; q.y = o[1]; q.z = o[2];
+    q.L = o[3]; q.M = o[4]; q.N = o[5];
+    q.i = a.rg.apod_kind != 0 ? raygen_apodize<T>(c, px, py) : T(1);
+    q.opd = T(0);
+    const Ray<T> g = fused_trace_family<T>(nr_family, a.surf, a.cold, a.optics, a.coeffs, a.first,
+                                           a.last, a.n_wl, a.wl, q, status);
+    spot_accumulate<T>(s, rmax, g.x, g.y, g.i, a.cx, a.cy);
+    if (a.hits[0] != nullptr) {
+      a.hits[0][j] = g.x;
+      a.hits[1][j] = g.y;
+      a.hits[2][j] = g.i;
+    }
+  }
+  for (int k = 0; k < 6; ++k) a.out[k] += s[k];
+  if (rmax > a.out[6]) a.out[6] = rmax;
+  if (status && a.status) *a.status |= status;
+  return hipSuccess;
+}
+template hipError_t launch_spot_trace<float>(const SpotArgs<float>&, bool, int, hipStream_t);
+template hipError_t launch_spot_trace<double>(const SpotArgs<double>&, bool, int, hipStream_t);
+
+// opd_trace_kernel + launch_opd_trace (trace_kernel.hip), ray by ray
+template <typename T>
+hipError_t launch_opd_trace(const OpdArgs<T>& a_in, int nr_family, hipStream_t) {
+  OpdArgs<T> a = a_in;
+  uniform_field_tangents<T>(a.rg, a.in);
+  const RaygenConsts<T> c(a.rg);
+  const WavefrontConsts<T> w(a.wf);
+  const RaygenIn<T>& in_ = a.in;
+  uint32_t status = 0;
+  double s[kOpdMoments];
+  for (int k = 0; k < kOpdMoments; ++k) s[k] = 0.0;
+  for (int64_t j = 0; j < a.n; ++j) {
+    T px = in_.px[j], py = in_.py[j];
+    T vx = in_.vx0, vy = in_.vy0, o[6];
+    raygen_pupil<T>(in_.flags, vx, vy, px, py, status);
+    raygen_one<T>(c, in_.tx0, in_.ty0, px, py, vx, vy, o);
+    Ray<T> q;
+    q.x = o[0]; q.y = o[1]; q.z = o[2];
+    q.L = o[3]; q.M = o[4]; q.N = o[5];
+    q.i = a.rg.apod_kind != 0 ? raygen_apodize<T>(c, px, py) : T(1);
+    q.opd = T(0);
+    const Ray<T> g = fused_trace_family<T>(nr_family, a.surf, a.cold, a.optics, a.coeffs, a.first,
+                                           a.last, a.n_wl, a.wl, q, status);
+    T pu[3];
+    const T ov = wavefront_one<T>(w, g.x, g.y, g.z, g.L, g.M, g.N, g.opd, in_.px[j], in_.py[j], pu);
+    a.opd[j] = ov;
+    a.inten[j] = g.i;
+    if (a.pupil[0]) {
+      a.pupil[0][j] = pu[0];
+      a.pupil[1][j] = pu[1];
+      a.pupil[2][j] = pu[2];
+    }
+    opd_accumulate(s, (double)g.i, (double)ov, (double)pu[0], (double)pu[1], g.i > T(0));
+  }
+  for (int k = 0; k < kOpdMoments; ++k) a.mom[k] += s[k];
+  if (status && a.status) *a.status |= status;
+  return hipSuccess;
+}
+template hipError_t launch_opd_trace<double>(const OpdArgs<double>&, int, hipStream_t);
+
+// everything else is a pure reduction kernel: not per-ray arithmetic, not what this
+// harness exists for
 #define OL_UNSUPPORTED(T)                                                                       \
-  template <>                                                                                    \
-  hipError_t launch_spot_trace<T>(const SpotArgs<T>&, bool, int, hipStream_t) {                 \
-    return hipErrorNotSupported;                                                                 \
-  }                                                                                              \
   template <>                                                                                    \
   hipError_t launch_spot_moments<T>(int64_t, const T*, const T*, const T*, double*,              \
                                     hipStream_t) {                                               \
@@ -294,9 +412,5 @@ template hipError_t launch_pupil_fill<double>(int64_t, const double*, const doub
   }
 OL_UNSUPPORTED(float)
 OL_UNSUPPORTED(double)
-template <>
-hipError_t launch_opd_trace<double>(const OpdArgs<double>&, int, hipStream_t) {
-  return hipErrorNotSupported;
-}
 
 }  // namespace ol

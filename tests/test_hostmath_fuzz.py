@@ -302,3 +302,112 @@ def test_pupil_fill_is_the_definition():
         want[pad:pad + n_side, pad:pad + n_side] = sub.reshape(n_side, n_side)
         np.testing.assert_allclose(g, want, rtol=0, atol=1e-14)
     sysm.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("seed", range(28))
+def test_random_fused_spot(seed, dtype):
+    """`ol_trace_spot` (generate -> trace -> reduce), host-run, on the random Newton-Raphson
+    lenses of tests/test_gpu_fuzz.py::test_random_fused_spot with the same generator scalars,
+    against the oracle's generate + trace + numpy moments: per-ray hits and the seven
+    moments; per-ray field / vignetting planes or one launch-uniform field."""
+    from oracle import oracle
+    from tests.test_gpu_fuzz import _random_raygen
+    from tests.test_gpu_spot import _check_moments, _scale
+    table, _ = random_nr_system(seed)
+    rng = np.random.default_rng(50_000 + seed)
+    table.raygen = _random_raygen(rng, table)
+    n = 20_011
+    r, th = np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
+    c = lambda a: np.ascontiguousarray(a, dtype=dtype)  # noqa: E731
+    px, py = c(r * np.cos(th)), c(r * np.sin(th))
+    planes = bool(seed % 2)
+    if planes:
+        hx, hy = c(rng.uniform(-1, 1, n)), c(rng.uniform(-1, 1, n))
+        vx, vy = c(rng.uniform(0.8, 1.0, n)), c(rng.uniform(0.8, 1.0, n))
+    else:
+        f, v = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))), (0.95, 0.9)
+        hx, hy, vx, vy = c(np.full(n, f[0])), c(np.full(n, f[1])), c(np.full(n, v[0])), c(np.full(n, v[1]))
+    center = (float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2)))
+    d = lambda a: a.astype(np.float64)  # noqa: E731
+    g = oracle.generate_rays(table.raygen, d(hx), d(hy), d(px), d(py), d(vx), d(vy))
+    g["opd"] = np.zeros(n)
+    o = oracle.trace(table, g, 0, record=False)
+    wx, wy, wi = o["x"], o["y"], o["i"]
+    m = wi > 0
+    dx, dy = wx[m] - center[0], wy[m] - center[1]
+    r2 = (dx * dx + dy * dy)
+    r2 = r2[~np.isnan(r2)]
+    want = np.array([m.sum(), dx.sum(), dy.sum(), (dx * dx).sum(), (dy * dy).sum(), wi[m].sum(),
+                     r2.max() if r2.size else 0.0])
+    sysm = hm.HostMathSystem(table)
+    if planes:
+        got, hits, status = sysm.trace_spot(px, py, 0, hx=hx, hy=hy, vx=vx, vy=vy, center=center,
+                                            want_hits=True)
+    else:
+        got, hits, status = sysm.trace_spot(px, py, 0, hx=f[0], hy=f[1], vx=v[0], vy=v[1],
+                                            center=center, want_hits=True)
+    sysm.close()
+    assert status == 0
+    gx, gy, gi = (h.astype(np.float64) for h in hits)
+    scale = _scale(table, wx, wy)
+    assert want[0] > 0.05 * n, "bundle lost: the fuzz case tests nothing"
+    if dtype == np.float64:
+        assert np.array_equal(gi > 0, wi > 0)
+        _check_moments(got, want, scale, 1e-7)
+        tol = 1e-7
+    else:
+        assert ((gi > 0) == (wi > 0)).mean() > 0.998
+        tol = 1e-4
+    both = (gi > 0) & (wi > 0)
+    np.testing.assert_allclose(gx[both], wx[both], rtol=0, atol=tol * scale)
+    np.testing.assert_allclose(gy[both], wy[both], rtol=0, atol=tol * scale)
+    np.testing.assert_allclose(gi[both], wi[both], rtol=0, atol=max(tol, 1e-9) * 10)
+
+
+@pytest.mark.parametrize("case", ["double_gauss", "cooke_generic", "rc_asphere", "zernike_nopol",
+                                  "aspheric_singlet"])
+def test_fused_opd_equals_the_unfused_chain(case):
+    """`ol_trace_opd` (generate -> trace -> OPD + its twelve moments in one kernel), host-run,
+    against the chain it fuses -- `ol_generate_rays`, record-last `ol_trace`,
+    `ol_wavefront_opd` -- run through the same harness: the maps must agree to rounding (same
+    per-ray code, the fused kernel only skips the planes), the moments with numpy sums."""
+    from optiland_amd import load_system
+    from tests._util import load_case
+    try:
+        table = load_system(case)
+    except KeyError:
+        table, _ = load_case(case)
+    if not table.raygen:
+        pytest.skip("no ray-generation scalars")
+    rng = np.random.default_rng(3)
+    n = 4001
+    r, th = np.sqrt(rng.random(n)) * 0.95, 2 * np.pi * rng.random(n)
+    px, py = r * np.cos(th), r * np.sin(th)
+    field = (0.0, 0.6)
+    sysm = hm.HostMathSystem(table)
+    # a plausible reference sphere: centred on the chief ray's image point, radius to z = 0
+    chief, _ = sysm.generate_rays(field[0], field[1], np.zeros(1), np.zeros(1))
+    sysm.trace(chief, 0, record=False)
+    zc = float(chief[2][0])
+    params = {"xc": float(chief[0][0]), "yc": float(chief[1][0]), "zc": zc, "R": abs(zc) * 0.8 + 5.0,
+              "n_image": 1.0, "opd_ref": float(chief[7][0]), "ux": 0.01, "uy": -0.02,
+              "half_epd": float(table.raygen["EPD"]) / 2, "wavelength_um": 0.55}
+    opd, inten, pupil, mom, status = sysm.trace_opd(params, px, py, 0, field=field)
+    assert status == 0
+    rays, _ = sysm.generate_rays(field[0], field[1], px, py)
+    sysm.trace(rays, 0, record=False)
+    want_opd, want_pupil = sysm.wavefront_opd(params, rays[:6] + [rays[7]], px, py)
+    sysm.close()
+    np.testing.assert_array_equal(np.isnan(opd), np.isnan(want_opd))
+    np.testing.assert_allclose(np.nan_to_num(opd), np.nan_to_num(want_opd), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.nan_to_num(inten), np.nan_to_num(rays[6]), rtol=0, atol=0)
+    np.testing.assert_allclose(np.nan_to_num(pupil), np.nan_to_num(want_pupil), rtol=0, atol=1e-11)
+    w, o, X, Y = inten, opd, pupil[0], pupil[1]
+    ok = ~np.isnan(o) & ~np.isnan(w)
+    alive = ok & (w > 0)
+    want_m = [w[ok].sum(), (w * X)[ok].sum(), (w * Y)[ok].sum(), (w * X * X)[ok].sum(),
+              (w * X * Y)[ok].sum(), (w * Y * Y)[ok].sum(), (w * o)[ok].sum(), (w * o * X)[ok].sum(),
+              (w * o * Y)[ok].sum(), alive.sum(), o[alive].sum(), (o * o)[alive].sum()]
+    if ok.all():
+        np.testing.assert_allclose(mom, want_m, rtol=1e-10, atol=1e-9)
