@@ -202,9 +202,9 @@ def bind(lib, path: str = "?"):
     return lib
 
 
-def check(rc: int, what: str) -> None:
+def check(rc: int, what: str, lib=None) -> None:
     if rc != 0:
-        msg = load().ol_last_error().decode("utf-8", "replace")
+        msg = (lib or load()).ol_last_error().decode("utf-8", "replace")
         if "Polarization must be set" in msg or msg.startswith("Normalized "):
             # same exception type/text as rays/ray_generator.py:89-94 and
             # raytrace/real_ray_tracer.py:170-173

@@ -74,14 +74,27 @@ class HipSystem:
         optics = np.ascontiguousarray(table.optics)
         coeffs = np.ascontiguousarray(table.coeffs, dtype=np.float64)
         handle = C.c_void_p()
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             rc = self.lib.ol_system_create(
                 surf.ctypes.data, surf.shape[0],
                 coeffs.ctypes.data if coeffs.size else None, coeffs.size,
                 optics.ctypes.data, optics.shape[1], C.byref(handle))
-        _capi.check(rc, "ol_system_create")
+        self._check(rc, "ol_system_create")
         self._handle = handle
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    # The three places that know the library is the HIP one and the tensors are device
+    # tensors.  (tests/_hostmath.HostMathEngine overrides them -- and the constructor -- to
+    # run this class's argument checking and marshalling on CPU tensors against the
+    # host build of the kernel source; the product class only ever accepts a HIP device.)
+    def _device_ctx(self):
+        return torch.cuda.device(self.device)
+
+    def _stream(self) -> int:
+        return _stream_ptr(self.device)
+
+    def _check(self, rc: int, what: str) -> None:
+        _capi.check(rc, what, self.lib)
 
     def close(self):
         if getattr(self, "_handle", None):
@@ -196,7 +209,7 @@ class HipSystem:
             extras = C.byref(_capi.TraceExtras(slots.data_ptr(), float(cx), float(cy)))
         if check_status and zero_status:  # zero_status=False: keep bits set by ray generation
             self._status.zero_()
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             rc = self.lib.ol_trace_ex(
                 self._handle, _DT[dtype], n, ptrs, int(wavelength_index),
                 rec.data_ptr() if rec is not None else None,
@@ -204,8 +217,8 @@ class HipSystem:
                 prt.data_ptr() if prt is not None else None,
                 int(first), int(last), flags,
                 self._status.data_ptr() if check_status else None,
-                extras, _stream_ptr(self.device))
-        _capi.check(rc, "ol_trace")
+                extras, self._stream())
+        self._check(rc, "ol_trace")
         # defer_status: the kernel still ORs its bits into self._status, but the caller
         # reads them back later (together with other device-side checks)
         status = int(self._status.item()) if (check_status and not defer_status) else 0
@@ -318,10 +331,10 @@ class HipSystem:
         ptrs = (C.c_void_p * 8)(*([p_.data_ptr() for p_ in planes] + [None] * (8 - len(planes))))
         if zero_status and flags & (_capi.RAYGEN_CHECK_FIELD | _capi.RAYGEN_CHECK_PUPIL):
             self._status.zero_()
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             rc = self.lib.ol_generate_rays(C.byref(p), _DT[dtype], n, C.byref(inp), ptrs,
-                                           self._status.data_ptr(), _stream_ptr(self.device))
-        _capi.check(rc, "ol_generate_rays")
+                                           self._status.data_ptr(), self._stream())
+        self._check(rc, "ol_generate_rays")
         return planes[:7]
 
     def polarized_intensity(self, prt, k0, i0, polarization: dict | None):
@@ -335,12 +348,12 @@ class HipSystem:
         out = torch.empty(n, dtype=dtype, device=self.device)
         kp = (C.c_void_p * 3)(*[t.data_ptr() for t in k0])
         self._status.zero_()
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             rc = self.lib.ol_polarized_intensity(
                 _DT[dtype], n, prt.data_ptr(), 1 if prt.shape[0] == 18 else 0, kp,
                 i0.data_ptr(), C.byref(st), out.data_ptr(),
-                self._status.data_ptr(), _stream_ptr(self.device))
-        _capi.check(rc, "ol_polarized_intensity")
+                self._status.data_ptr(), self._stream())
+        self._check(rc, "ol_polarized_intensity")
         if int(self._status.item()) & S.STATUS_K_PARALLEL_X:
             # rays/polarized_rays.py:221-222
             raise ValueError("k-vector parallel to x-axis is not currently supported.")
@@ -356,11 +369,11 @@ class HipSystem:
         pupil = torch.empty((3, n), dtype=dtype, device=self.device) if want_pupil else None
         rp = (C.c_void_p * 7)(*[t.data_ptr() for t in rays7])
         pp = (C.c_void_p * 3)(*[pupil[k].data_ptr() for k in range(3)]) if want_pupil else None
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             rc = self.lib.ol_wavefront_opd(C.byref(p), _DT[dtype], n, rp, px.data_ptr(),
                                            py.data_ptr(), opd.data_ptr(), pp,
-                                           _stream_ptr(self.device))
-        _capi.check(rc, "ol_wavefront_opd")
+                                           self._stream())
+        self._check(rc, "ol_wavefront_opd")
         return opd, pupil
 
     def trace_opd(self, params: dict, px, py, wl_index: int, *, field, vig=(1.0, 1.0),
@@ -391,12 +404,12 @@ class HipSystem:
         pp = (C.c_void_p * 3)(*[pupil[k].data_ptr() for k in range(3)]) if want_pupil else None
         if check_status:
             self._status.zero_()
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             rc = self.lib.ol_trace_opd(self._handle, _DT[dtype], n, C.byref(p), C.byref(inp),
                                        C.byref(w), int(wl_index), opd.data_ptr(),
                                        inten.data_ptr(), pp, moments.data_ptr(),
-                                       self._status.data_ptr(), _stream_ptr(self.device))
-        _capi.check(rc, "ol_trace_opd")
+                                       self._status.data_ptr(), self._stream())
+        self._check(rc, "ol_trace_opd")
         if check_status:
             self.raise_for_status(int(self._status.item()))
         return opd, inten, pupil, moments
@@ -416,12 +429,12 @@ class HipSystem:
         if pupil_xy is not None:
             co = (C.c_double * 3)(*[float(v) for v in plane])
             px_ptr, py_ptr = pupil_xy[0].data_ptr(), pupil_xy[1].data_ptr()
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             rc = self.lib.ol_pupil_fill(_DT[opd.dtype], n, opd.data_ptr(), intensity.data_ptr(),
                                         px_ptr, py_ptr, co, cell.contiguous().data_ptr(),
                                         int(n_side), int(grid_size), grid.data_ptr(),
-                                        _stream_ptr(self.device))
-        _capi.check(rc, "ol_pupil_fill")
+                                        self._stream())
+        self._check(rc, "ol_pupil_fill")
         return grid
 
     def trace_spot(self, px, py, wl_index: int, *, field=None, hx=None, hy=None, vig=(1.0, 1.0),
@@ -455,12 +468,12 @@ class HipSystem:
             hp = (C.c_void_p * 3)(*[h.data_ptr() for h in hits])
         if check_status:
             self._status.zero_()
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             rc = self.lib.ol_trace_spot(self._handle, _DT[dtype], n, C.byref(p), C.byref(inp),
                                         float(center[0]), float(center[1]), int(wl_index), hp,
                                         out.data_ptr(), self._status.data_ptr(),
-                                        _stream_ptr(self.device))
-        _capi.check(rc, "ol_trace_spot")
+                                        self._stream())
+        self._check(rc, "ol_trace_spot")
         if check_status:
             self.raise_for_status(int(self._status.item()))
         return out
@@ -472,11 +485,11 @@ class HipSystem:
             out = torch.zeros(6, dtype=torch.float64, device=self.device)
         else:
             out.zero_()
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             rc = self.lib.ol_spot_moments(_DT[x.dtype], int(x.numel()), x.data_ptr(),
                                           y.data_ptr(), intensity.data_ptr(), out.data_ptr(),
-                                          _stream_ptr(self.device))
-        _capi.check(rc, "ol_spot_moments")
+                                          self._stream())
+        self._check(rc, "ol_spot_moments")
         return out
 
     def irradiance(self, x, y, power, x_edges: torch.Tensor, y_edges: torch.Tensor,
@@ -491,11 +504,11 @@ class HipSystem:
         nx, ny = xe.numel() - 1, ye.numel() - 1
         if out is None:
             out = torch.zeros((nx, ny), dtype=torch.float64, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             rc = self.lib.ol_irradiance(_DT[x.dtype], int(x.numel()), x.data_ptr(), y.data_ptr(),
                                         power.data_ptr(), xe.data_ptr(), nx, ye.data_ptr(), ny,
-                                        out.data_ptr(), _stream_ptr(self.device))
-        _capi.check(rc, "ol_irradiance")
+                                        out.data_ptr(), self._stream())
+        self._check(rc, "ol_irradiance")
         return out
 
     def radial_energy(self, x, y, intensity, cx: float, cy: float, r_step: torch.Tensor,
@@ -509,19 +522,19 @@ class HipSystem:
         r_step = r_step.contiguous()
         if out is None:
             out = torch.zeros_like(r_step)
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             rc = self.lib.ol_radial_energy(_DT[x.dtype], int(x.numel()), x.data_ptr(),
                                            y.data_ptr(), intensity.data_ptr(), float(cx),
                                            float(cy), r_step.data_ptr(), int(r_step.numel()),
-                                           out.data_ptr(), _stream_ptr(self.device))
-        _capi.check(rc, "ol_radial_energy")
+                                           out.data_ptr(), self._stream())
+        self._check(rc, "ol_radial_energy")
         return out
 
     def spot_max_r2(self, x, y, intensity, cx: float, cy: float):
         out = torch.zeros(1, dtype=torch.float64, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._device_ctx():
             rc = self.lib.ol_spot_max_r2(_DT[x.dtype], int(x.numel()), x.data_ptr(),
                                          y.data_ptr(), intensity.data_ptr(), float(cx),
-                                         float(cy), out.data_ptr(), _stream_ptr(self.device))
-        _capi.check(rc, "ol_spot_max_r2")
+                                         float(cy), out.data_ptr(), self._stream())
+        self._check(rc, "ol_spot_max_r2")
         return out

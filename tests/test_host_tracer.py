@@ -1,4 +1,5 @@
-"""Host-side logic of the tracer mirror, on CPU with the oracle-backed engine.
+"""Host-side logic of the tracer mirror, on CPU: with the oracle-backed engine, and with
+the product's engine class on the host build of the kernel source.
 
 Checks that `HipRayTracer.trace / trace_generic` reproduce what the reference's
 `Optic.trace / trace_generic` produced for the same arguments (goldens), i.e. the
@@ -15,9 +16,20 @@ from tests._fake_engine import OracleEngine
 from tests._util import assert_close_planes, load_case
 
 
-@pytest.fixture(autouse=True)
-def oracle_engine(monkeypatch):
-    monkeypatch.setattr(tr, "_make_engine", lambda table, device: OracleEngine(table, device))
+@pytest.fixture(autouse=True, params=["oracle", "kernel-source"])
+def engine_kind(monkeypatch, request):
+    """Every test runs twice: on the oracle-backed stand-in, and on the product's own
+    `HipSystem` class driving the host build of the kernel source through the real C ABI
+    (tests/_hostmath.make_engine_class)."""
+    if request.param == "oracle":
+        monkeypatch.setattr(tr, "_make_engine", lambda table, device: OracleEngine(table, device))
+    else:
+        from tests import _hostmath as hm
+        if not hm.available():
+            pytest.skip("hipcc (used as host C++ compiler) missing")
+        cls = hm.make_engine_class()
+        monkeypatch.setattr(tr, "_make_engine", lambda table, device: cls(table, device))
+    return request.param
 
 
 def _stack(surfaces):

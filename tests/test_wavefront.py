@@ -20,6 +20,37 @@ CASES = {"cooke": ("cooke_generic", (0.0, 1.0), 0.55),
          "dgauss": ("double_gauss", (0.0, 0.7), 0.5876)}
 
 
+# Where the "real" engine of a test runs: on the MI355X, or -- the product's engine class on
+# the host build of the kernel source through the real C ABI (tests/_hostmath.py) -- on the
+# CPU of a box without a GPU.  `-m gpu` selects the first, `-m "not gpu"` the second.
+WHERE = [pytest.param("cuda", marks=pytest.mark.gpu), "host"]
+
+
+def _real_tracer(table, where):
+    if where == "cuda":
+        return tr.HipRayTracer(table, "cuda:0", dtype=torch.float64)
+    from tests import _hostmath as hm
+    if not hm.available():
+        pytest.skip("hipcc (used as host C++ compiler) missing")
+    return tr.HipRayTracer(table, "cpu", dtype=torch.float64, engine=hm.make_engine_class()(table))
+
+
+@pytest.fixture(params=["oracle", "kernel-source"])
+def cpu_engine(monkeypatch, request):
+    """Host-logic tests run twice: oracle-backed stand-in, and the product's engine class on
+    the host build of the kernel source."""
+    if request.param == "oracle":
+        from tests._fake_engine import OracleEngine
+        monkeypatch.setattr(tr, "_make_engine", lambda table, device: OracleEngine(table, device))
+    else:
+        from tests import _hostmath as hm
+        if not hm.available():
+            pytest.skip("hipcc (used as host C++ compiler) missing")
+        cls = hm.make_engine_class()
+        monkeypatch.setattr(tr, "_make_engine", lambda table, device: cls(table, device))
+    return request.param
+
+
 def _check(tracer, tag, field, wl, rtol_opd, rtol_psf):
     opd = OPD(tracer, field, wl)
     d = opd.data
@@ -41,9 +72,7 @@ def _check(tracer, tag, field, wl, rtol_opd, rtol_psf):
 
 
 @pytest.mark.parametrize("tag", list(CASES))
-def test_wavefront_and_psf_host_logic(tag, monkeypatch):
-    from tests._fake_engine import OracleEngine
-    monkeypatch.setattr(tr, "_make_engine", lambda table, device: OracleEngine(table, device))
+def test_wavefront_and_psf_host_logic(tag, cpu_engine):
     name, field, wl = CASES[tag]
     t = tr.HipRayTracer(load_system(name), dtype=torch.float64)
     opd = _check(t, tag, field, wl, 1e-7, 1e-6)
@@ -51,12 +80,10 @@ def test_wavefront_and_psf_host_logic(tag, monkeypatch):
         np.testing.assert_allclose(opd.rms(), 0.9709788038168692, rtol=1e-5)
 
 
-def test_wavefront_with_record_all_switched_off(monkeypatch):
+def test_wavefront_with_record_all_switched_off(cpu_engine):
     """Wavefront reads the recorded image-plane intensity; with the tracer in
     record-last mode (IncoherentIrradiance toggles it, users may) that used to raise an
     opaque IndexError -- the trace now forces record-all and restores the flag."""
-    from tests._fake_engine import OracleEngine
-    monkeypatch.setattr(tr, "_make_engine", lambda table, device: OracleEngine(table, device))
     t = tr.HipRayTracer(load_system("cooke_generic"), dtype=torch.float64)
     want = OPD(t, (0.0, 1.0), 0.55).rms()
     t.record_all = False
@@ -96,28 +123,28 @@ def test_fp32_tracer_is_refused(monkeypatch):
         OPD(t, (0.0, 1.0), 0.55)
 
 
-@pytest.mark.gpu
+@pytest.mark.parametrize("where", WHERE)
 @pytest.mark.parametrize("tag", list(CASES))
-def test_wavefront_and_psf_on_device(tag):
+def test_wavefront_and_psf_on_device(tag, where):
     name, field, wl = CASES[tag]
-    t = tr.HipRayTracer(load_system(name), "cuda:0", dtype=torch.float64)
+    t = _real_tracer(load_system(name), where)
     opd = _check(t, tag, field, wl, 1e-6, 1e-5)
     if tag == "cooke":
         np.testing.assert_allclose(opd.rms(), 0.9709788038168692, rtol=1e-5)
     t.engine.close()
 
 
-@pytest.mark.gpu
+@pytest.mark.parametrize("where", WHERE)
 @pytest.mark.parametrize("strategy", ["centroid_sphere", "best_fit_sphere"])
 @pytest.mark.parametrize("tag", list(CASES))
-def test_fitted_reference_spheres_on_device(tag, strategy):
+def test_fitted_reference_spheres_on_device(tag, strategy, where):
     """Centroid / best-fit reference spheres (wavefront/strategy.py:287-582) and the
     weighted tilt removal on the real engine against the same host code on the
     oracle-backed engine (itself held to the live reference by tests/test_reference_fuzz.py)."""
     from tests._fake_engine import OracleEngine
     name, field, wl = CASES[tag]
     table = load_system(name)
-    real = tr.HipRayTracer(table, "cuda:0", dtype=torch.float64)
+    real = _real_tracer(table, where)
     fake = tr.HipRayTracer(table, "cpu", dtype=torch.float64, engine=OracleEngine(table, "cpu"))
     try:
         for detrend, afocal in ((False, False), (True, False), (False, True)):
@@ -158,9 +185,9 @@ def _golden_or_data(name):
         return load_case_table(name)
 
 
-@pytest.mark.gpu
+@pytest.mark.parametrize("where", WHERE)
 @pytest.mark.parametrize("name", FUSED_SYSTEMS)
-def test_fused_opd_kernel_vs_oracle_composition(name):
+def test_fused_opd_kernel_vs_oracle_composition(name, where):
     """ol_trace_opd == oracle generate -> oracle trace -> oracle OPD on the same pupil
     points (conic, Newton, apodized, vignetted systems; hexapolar + a ragged random set),
     and its 12 device sums == the numpy reductions of that map."""
@@ -169,7 +196,7 @@ def test_fused_opd_kernel_vs_oracle_composition(name):
     if not table.raygen or "pupil_z" not in table.raygen:
         pytest.skip("no ray-generation / exit-pupil scalars in this table")
     import copy
-    real = tr.HipRayTracer(table, "cuda:0", dtype=torch.float64)
+    real = _real_tracer(table, where)
     # the oracle with its Newton loops fully converged: the reference (and the oracle as its
     # restatement) stops the whole batch at max|f| < tol = 1e-6 mm, which is 2e-3 WAVES of
     # path; the kernel's per-ray rule converges each ray further, so the
@@ -207,14 +234,14 @@ def test_fused_opd_kernel_vs_oracle_composition(name):
         real.engine.close()
 
 
-@pytest.mark.gpu
+@pytest.mark.parametrize("where", WHERE)
 @pytest.mark.parametrize("tag", list(CASES))
-def test_fused_equals_unfused_on_device(tag):
+def test_fused_equals_unfused_on_device(tag, where):
     """Same device, same kernels' arithmetic: the fused launch reproduces the chain
     ol_generate_rays -> ol_trace (record-all) -> ol_wavefront_opd -> torch reductions,
     with and without tilt removal, and so does the PSF built by ol_pupil_fill."""
     name, field, wl = CASES[tag]
-    t = tr.HipRayTracer(load_system(name), "cuda:0", dtype=torch.float64)
+    t = _real_tracer(load_system(name), where)
     try:
         for detrend in (False, True):
             a = OPD(t, field, wl, num_rays=12, remove_tilt=detrend, fused=True)
@@ -301,9 +328,9 @@ def _opd_capable_goldens():
     return out
 
 
-@pytest.mark.gpu
+@pytest.mark.parametrize("where", WHERE)
 @pytest.mark.parametrize("case", _opd_capable_goldens())
-def test_fused_opd_on_every_sample_and_fuzz_lens(case):
+def test_fused_opd_on_every_sample_and_fuzz_lens(case, where):
     """Breadth: the fused kernel on every unpolarised lens of optiland.samples and of the
     frozen fuzz set that carries exit-pupil data (real prescriptions, stops in odd places,
     aspheres, tilts, vignetting, object-height fields ...), two fields each, against the
@@ -315,7 +342,7 @@ def test_fused_opd_on_every_sample_and_fuzz_lens(case):
     conv = copy.deepcopy(table)
     newton = bool(np.any(conv.surfaces["max_iter"] > 0))
     conv.surfaces["tol"] = np.where(conv.surfaces["max_iter"] > 0, 1e-13, conv.surfaces["tol"])
-    real = tr.HipRayTracer(table, "cuda:0", dtype=torch.float64)
+    real = _real_tracer(table, where)
     fake = tr.HipRayTracer(conv, "cpu", dtype=torch.float64, engine=OracleEngine(conv, "cpu"))
     w = float(table.wavelengths[0])
     try:
