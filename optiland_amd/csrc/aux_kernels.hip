@@ -275,13 +275,8 @@ __global__ __launch_bounds__(kBlock) void radial_energy_kernel(
     const double e = (double)inten[j];
     const double dx = (double)x[j] - cx, dy = (double)y[j] - cy;
     const double r = sqrt(dx * dx + dy * dy);
-    if (!(e == e) || !(r <= steps[n_steps - 1])) continue;  // NaN energy / NaN or far radius
-    int lo = 0, hi = n_steps - 1;  // first index with r <= steps[idx]
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (r <= steps[mid]) hi = mid; else lo = mid + 1;
-    }
-    if (e != 0.0) unsafeAtomicAdd(&hist[lo], e);
+    const int lo = radial_step_index(steps, n_steps, r, e);  // epilogue_device.h
+    if (lo >= 0 && e != 0.0) unsafeAtomicAdd(&hist[lo], e);
   }
   __syncthreads();
   for (int k = threadIdx.x; k < n_steps; k += kBlock)
@@ -301,16 +296,7 @@ hipError_t launch_radial_energy(int64_t n, const T* x, const T* y, const T* inte
 // analysis/irradiance.py:341-353: numpy.histogram2d(x, y, bins=[x_edges, y_edges],
 // weights=power) for rays with power > 0.  Bin search = numpy's
 // searchsorted(edges, v, "right") - 1 with the right-most edge folded into the last bin.
-__device__ __forceinline__ int edge_bin(const double* __restrict__ e, int nb, double v) {
-  if (!(v >= e[0]) || !(v <= e[nb])) return -1;  // outside, or NaN
-  if (v == e[nb]) return nb - 1;
-  int lo = 0, hi = nb;  // invariant: e[lo] <= v < e[hi]
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (e[mid] <= v) lo = mid; else hi = mid;
-  }
-  return lo;
-}
+// (edge_bin: epilogue_device.h)
 
 constexpr int kMaxLdsBins = 4096;  // 32 KB of LDS doubles: small detectors are privatised
 

@@ -99,6 +99,32 @@ OL_DEV void opd_accumulate(double (&s)[kOpdMoments], double wi, double od, doubl
   }
 }
 
+// analysis/encircled_energy.py:147-160: the radius step a hit's energy goes to -- the first
+// index with r <= steps[idx] (the reference's own `radii <= r` comparisons), -1 for a NaN
+// energy, a NaN radius or one beyond the last step
+OL_DEV int radial_step_index(const double* steps, int n_steps, double r, double e) {
+  if (!(e == e) || !(r <= steps[n_steps - 1])) return -1;
+  int lo = 0, hi = n_steps - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (r <= steps[mid]) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+// analysis/irradiance.py:341-353: numpy.histogram2d's bin of v = searchsorted(edges, v,
+// "right") - 1 with the right-most edge folded into the last bin; -1 outside or NaN
+OL_DEV int edge_bin(const double* __restrict__ e, int nb, double v) {
+  if (!(v >= e[0]) || !(v <= e[nb])) return -1;
+  if (v == e[nb]) return nb - 1;
+  int lo = 0, hi = nb;  // invariant: e[lo] <= v < e[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (e[mid] <= v) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 // psf/fft.py:101-137: one sample A exp(-i 2 pi OPD) of the pupil function, and where it
 // goes in the zero-padded grid (re, im interleaved doubles)
 OL_DEV void pupil_sample(double opd_waves, double intensity, double& re, double& im) {

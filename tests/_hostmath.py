@@ -269,9 +269,7 @@ def make_engine_class():
     three hooks that tie it to a HIP device replaced: the library is the host-math harness,
     the tensors are CPU tensors (the harness reads and writes host memory), there is no
     stream.  Used by the CPU suite where it used to have only the oracle-backed stand-in
-    (tests/_fake_engine.py): host logic -> real engine -> real C ABI -> kernel source.  The
-    four pure reductions (no per-ray arithmetic, "not supported" in the harness) are torch
-    one-liners here."""
+    (tests/_fake_engine.py): host logic -> real engine -> real C ABI -> kernel source."""
     import contextlib
 
     import torch
@@ -308,44 +306,5 @@ def make_engine_class():
             self.calls += 1
             return super().trace(*a, **k)
 
-        # pure reductions
-        def spot_moments(self, x, y, intensity, out=None):
-            m = intensity > 0
-            xd, yd = x[m].double(), y[m].double()
-            c = float(m.sum())
-            v = torch.tensor([c, xd.sum(), yd.sum(), (xd * xd).sum(), (yd * yd).sum(), c],
-                             dtype=torch.float64)
-            if out is not None:
-                out.copy_(v)
-                return out
-            return v
-
-        def spot_max_r2(self, x, y, intensity, cx, cy):
-            m = intensity > 0
-            r2 = (x[m].double() - cx) ** 2 + (y[m].double() - cy) ** 2
-            r2 = r2[~torch.isnan(r2)]
-            return r2.max().reshape(1) if r2.numel() else torch.zeros(1, dtype=torch.float64)
-
-        def irradiance(self, x, y, power, x_edges, y_edges, out=None):
-            xn, yn, pn = (v.double().numpy() for v in (x, y, power))
-            valid = pn > 0.0
-            with np.errstate(invalid="ignore"):
-                h, _, _ = np.histogram2d(xn[valid], yn[valid],
-                                         bins=[x_edges.numpy(), y_edges.numpy()], weights=pn[valid])
-            h = torch.as_tensor(h)
-            if out is None:
-                return h
-            out += h
-            return out
-
-        def radial_energy(self, x, y, intensity, cx, cy, r_step, out=None):
-            r = torch.sqrt((x.double() - cx) ** 2 + (y.double() - cy) ** 2).numpy()
-            e = intensity.double().numpy()
-            cum = np.array([np.nansum(e[r <= v]) for v in r_step.numpy()])
-            bins = torch.as_tensor(np.diff(cum, prepend=0.0))
-            if out is None:
-                return bins
-            out += bins
-            return out
 
     return HostMathEngine

@@ -387,30 +387,80 @@ hipError_t launch_opd_trace(const OpdArgs<T>& a_in, int nr_family, hipStream_t) 
 }
 template hipError_t launch_opd_trace<double>(const OpdArgs<double>&, int, hipStream_t);
 
-// everything else is a pure reduction kernel: not per-ray arithmetic, not what this
-// harness exists for
-#define OL_UNSUPPORTED(T)                                                                       \
-  template <>                                                                                    \
-  hipError_t launch_spot_moments<T>(int64_t, const T*, const T*, const T*, double*,              \
-                                    hipStream_t) {                                               \
-    return hipErrorNotSupported;                                                                 \
-  }                                                                                              \
-  template <>                                                                                    \
-  hipError_t launch_radial_energy<T>(int64_t, const T*, const T*, const T*, double, double,      \
-                                     const double*, int, double*, hipStream_t) {                 \
-    return hipErrorNotSupported;                                                                 \
-  }                                                                                              \
-  template <>                                                                                    \
-  hipError_t launch_irradiance<T>(int64_t, const T*, const T*, const T*, const double*, int,     \
-                                  const double*, int, double*, hipStream_t) {                    \
-    return hipErrorNotSupported;                                                                 \
-  }                                                                                              \
-  template <>                                                                                    \
-  hipError_t launch_spot_max_r2<T>(int64_t, const T*, const T*, const T*, double, double,        \
-                                   double*, hipStream_t) {                                       \
-    return hipErrorNotSupported;                                                                 \
+// the four reduction kernels of aux_kernels.hip, element by element (sums in element order)
+template <typename T>
+hipError_t launch_spot_moments(int64_t n, const T* x, const T* y, const T* inten, double* out6,
+                               hipStream_t) {
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int64_t j = 0; j < n; ++j) {
+    const double xv = (double)x[j], yv = (double)y[j];
+    if (inten[j] > T(0)) {
+      s[0] += 1.0; s[1] += xv; s[2] += yv; s[3] += xv * xv; s[4] += yv * yv; s[5] += 1.0;
+    }
   }
-OL_UNSUPPORTED(float)
-OL_UNSUPPORTED(double)
+  for (int k = 0; k < 6; ++k) out6[k] += s[k];
+  return hipSuccess;
+}
+
+template <typename T>
+hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten, double cx,
+                              double cy, double* out1, hipStream_t) {
+  double best = 0.0;
+  for (int64_t j = 0; j < n; ++j) {
+    if (inten[j] > T(0)) {
+      const double dx = (double)x[j] - cx, dy = (double)y[j] - cy;
+      const double r2 = dx * dx + dy * dy;
+      best = r2 > best ? r2 : best;
+    }
+  }
+  if (best > *out1) *out1 = best;
+  return hipSuccess;
+}
+
+template <typename T>
+hipError_t launch_radial_energy(int64_t n, const T* x, const T* y, const T* inten, double cx,
+                                double cy, const double* r_step, int n_steps, double* bins,
+                                hipStream_t) {
+  if (n_steps < 1 || n_steps > 1024) return hipErrorInvalidValue;  // kMaxEeSteps
+  for (int64_t j = 0; j < n; ++j) {
+    const double e = (double)inten[j];
+    const double dx = (double)x[j] - cx, dy = (double)y[j] - cy;
+    const int lo = radial_step_index(r_step, n_steps, sqrt(dx * dx + dy * dy), e);
+    if (lo >= 0 && e != 0.0) bins[lo] += e;
+  }
+  return hipSuccess;
+}
+
+template <typename T>
+hipError_t launch_irradiance(int64_t n, const T* x, const T* y, const T* power,
+                             const double* xe, int nx, const double* ye, int ny, double* hist,
+                             hipStream_t) {
+  if (nx < 1 || ny < 1) return hipErrorInvalidValue;
+  for (int64_t j = 0; j < n; ++j) {
+    const double p = (double)power[j];
+    if (!(p > 0.0)) continue;
+    const int ix = edge_bin(xe, nx, (double)x[j]);
+    if (ix < 0) continue;
+    const int iy = edge_bin(ye, ny, (double)y[j]);
+    if (iy < 0) continue;
+    hist[(int64_t)ix * ny + iy] += p;
+  }
+  return hipSuccess;
+}
+
+#define OL_INST(T)                                                                             \
+  template hipError_t launch_spot_moments<T>(int64_t, const T*, const T*, const T*, double*,   \
+                                             hipStream_t);                                     \
+  template hipError_t launch_irradiance<T>(int64_t, const T*, const T*, const T*,              \
+                                           const double*, int, const double*, int, double*,    \
+                                           hipStream_t);                                       \
+  template hipError_t launch_radial_energy<T>(int64_t, const T*, const T*, const T*, double,   \
+                                              double, const double*, int, double*,             \
+                                              hipStream_t);                                    \
+  template hipError_t launch_spot_max_r2<T>(int64_t, const T*, const T*, const T*, double,     \
+                                            double, double*, hipStream_t);
+OL_INST(float)
+OL_INST(double)
+#undef OL_INST
 
 }  // namespace ol

@@ -411,3 +411,54 @@ def test_fused_opd_equals_the_unfused_chain(case):
               (w * o * Y)[ok].sum(), alive.sum(), o[alive].sum(), (o * o)[alive].sum()]
     if ok.all():
         np.testing.assert_allclose(mom, want_m, rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_reduction_entry_points_equal_their_definitions(dtype):
+    """`ol_spot_moments`, `ol_spot_max_r2`, `ol_radial_energy`, `ol_irradiance` through the
+    product's engine class on the host build: the bin searches (`edge_bin`,
+    `radial_step_index` in epilogue_device.h) against numpy on data with hits exactly on
+    edges, outside the detector, NaN coordinates, NaN and zero and negative weights."""
+    import torch
+    from optiland_amd import load_system
+    eng = hm.make_engine_class()(load_system("cooke_generic"))
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    rng = np.random.default_rng(9)
+    n = 20_000
+    x, y = rng.normal(0, 1.0, n), rng.normal(0.2, 0.7, n)
+    w = rng.uniform(0, 1, n)
+    xe, ye = np.linspace(-2, 2, 33), np.linspace(-1.5, 1.5, 17)
+    # exact edges (first, interior, last), outside, NaN
+    x[:6] = [xe[0], xe[5], xe[-1], 2.5, np.nan, 0.1]
+    y[:6] = [ye[0], ye[-1], ye[3], 0.0, 0.0, np.nan]
+    w[6:12] = [0.0, -1.0, np.nan, 1.0, 0.5, 0.0]
+    tx, ty, tw = (torch.tensor(np.asarray(v, dtype=dtype)) for v in (x, y, w))
+    xs, ys, ws = tx.double().numpy(), ty.double().numpy(), tw.double().numpy()
+    # irradiance == numpy.histogram2d over power > 0
+    got = eng.irradiance(tx, ty, tw, torch.tensor(xe), torch.tensor(ye)).numpy()
+    ok = ws > 0
+    with np.errstate(invalid="ignore"):
+        want, _, _ = np.histogram2d(xs[ok], ys[ok], bins=[xe, ye], weights=ws[ok])
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    # radial energy: per-step energy, cumulative sum == sum of energies with r <= step
+    cx, cy = 0.05, 0.15
+    r_step = np.linspace(0.0, 2.5, 41)
+    r_step[7] = float(np.hypot(xs[20] - cx, ys[20] - cy))   # a hit exactly on a step
+    r_step.sort()
+    bins = eng.radial_energy(tx, ty, tw, cx, cy, torch.tensor(r_step)).numpy()
+    r = np.hypot(xs - cx, ys - cy)
+    with np.errstate(invalid="ignore"):
+        want_cum = np.array([np.nansum(np.where(np.isnan(r) | (r > v), 0.0, ws)) for v in r_step])
+    np.testing.assert_allclose(np.cumsum(bins), want_cum, rtol=1e-12, atol=1e-12)
+    # spot moments / max radius over i > 0
+    m = ws > 0
+    got_m = eng.spot_moments(tx, ty, tw).numpy()
+    with np.errstate(invalid="ignore"):
+        want_m = [m.sum(), xs[m].sum(), ys[m].sum(), (xs[m] ** 2).sum(), (ys[m] ** 2).sum(), m.sum()]
+    fin = np.isfinite(want_m)
+    np.testing.assert_allclose(got_m[fin], np.asarray(want_m)[fin], rtol=1e-12)
+    assert np.array_equal(np.isnan(got_m), ~fin)
+    got_r = float(eng.spot_max_r2(tx, ty, tw, cx, cy)[0])
+    r2 = ((xs - cx) ** 2 + (ys - cy) ** 2)[m]
+    np.testing.assert_allclose(got_r, np.nanmax(r2), rtol=1e-14)  # (fused multiply-add)
+    eng.close()
