@@ -261,13 +261,20 @@ def test_reference_suite_sweeps_the_hip_backend(tmp_path):
     assert n > 300, tail
 
 
-def test_reference_consumers_run_on_the_replaced_tracer(tmp_path):
+@pytest.mark.parametrize("engine", ["oracle", "kernel-source"])
+def test_reference_consumers_run_on_the_replaced_tracer(tmp_path, engine):
     """The reference's OWN tests of the consumers of the path -- Optic.trace /
     trace_generic, spot diagrams, encircled energy, irradiance, ray fans, wavefront / OPD /
     Zernike fits -- executed with `integration.enable(force=True)`: every real-ray trace
-    inside them goes through the drop-in tracer (packer -> C-ABI-shaped engine, here the
-    oracle-backed stand-in) and their hard-coded expectations still hold.  Autograd tests
-    are deselected: the drop-in must not intercept differentiable traces."""
+    inside them goes through the drop-in tracer and their hard-coded expectations still hold.
+    Behind the tracer: the oracle-backed stand-in, or the product's engine class on the host
+    build of the kernel source through the real C ABI (tests/_hostmath.make_engine_class).
+    Autograd tests are deselected: the drop-in must not intercept differentiable traces."""
+    if engine == "kernel-source":
+        from tests import _hostmath as hm
+        if not hm.available():
+            pytest.skip("hipcc (used as host C++ compiler) missing")
+        hm.load()  # build once, here, not inside the reference's test session
     import shutil
     import subprocess
     import sys
@@ -282,19 +289,23 @@ def test_reference_consumers_run_on_the_replaced_tracer(tmp_path):
         "import optiland.backend as be\n"
         "import atexit, importlib.util, sys\n"
         "sys.path.insert(0, %r)\n"
-        "_spec = importlib.util.spec_from_file_location('_ol_fake_engine', %r)\n"
-        "_fake = importlib.util.module_from_spec(_spec)\n"
-        "_spec.loader.exec_module(_fake)\n"
+        "_spec = importlib.util.spec_from_file_location('_ol_engine_mod', %r)\n"
+        "_mod = importlib.util.module_from_spec(_spec)\n"
+        "_spec.loader.exec_module(_mod)\n"
+        "_cls = %s\n"
         "import optiland_amd.tracer as _tr\n"
         "_made = [0]\n"
         "def _mk(table, device):\n"
         "    _made[0] += 1\n"
-        "    return _fake.OracleEngine(table, device)\n"
+        "    return _cls(table, device)\n"
         "_tr._make_engine = _mk\n"
         "atexit.register(lambda: open(%r, 'w').write(str(_made[0])))\n"
         "from optiland_amd import integration as _integ\n"
         "_integ.enable(force=True)\n"
-        % (root, os.path.join(root, "tests", "_fake_engine.py"), str(counter)), 1)
+        % (root,
+           os.path.join(root, "tests", "_fake_engine.py" if engine == "oracle" else "_hostmath.py"),
+           "_mod.OracleEngine" if engine == "oracle" else "_mod.make_engine_class()",
+           str(counter)), 1)
     conf = conf.replace("be.grad_mode.enable()", "be.grad_mode.disable()")
     (dst / "conftest.py").write_text(conf)
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1",
