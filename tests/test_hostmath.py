@@ -290,3 +290,98 @@ def test_zernike_every_degree(degree, scheme_norm, dtype):
     # degree <= 8 -> the two builds really are different evaluators (they differ in the last
     # bits); above the cap both are the level form
     assert same == (degree > 8), (degree, same)
+
+
+def _plane_system(aperture_kind=0, aperture=(0, 0, 0, 0), geom=None, n2=1.0, polarization=None):
+    """object plane -> one plane surface (optional aperture) -> image plane"""
+    from optiland_amd import system as S
+    from optiland_amd.system import SystemTable
+    surf = np.zeros(3, dtype=S.SURFACE_DESC_DTYPE)
+    optics = np.zeros((3, 1), dtype=S.SURFACE_OPTICS_DTYPE)
+    surf["rot"] = np.eye(3).reshape(-1)
+    surf["norm_radius"] = 1.0
+    surf[0]["interaction"] = S.INTERACT_RECORD_ONLY
+    surf[0]["origin"] = (0.0, 0.0, -10.0)
+    surf[1]["geom_kind"] = S.GEOM_PLANE if geom is None else geom
+    surf[1]["radius"] = np.inf
+    surf[1]["interaction"] = S.INTERACT_REFRACT
+    surf[1]["aperture_kind"], surf[1]["aperture"] = aperture_kind, aperture
+    surf[2]["geom_kind"], surf[2]["interaction"] = S.GEOM_PLANE, S.INTERACT_REFRACT
+    surf[2]["radius"] = np.inf
+    surf[2]["origin"] = (0.0, 0.0, 20.0)
+    optics[0, 0] = (1.0, 1.0, 0.0)
+    optics[1, 0] = (1.0, n2, 0.0)
+    optics[2, 0] = (n2, n2, 0.0)
+    t = SystemTable(surfaces=surf, coeffs=np.zeros(0), optics=optics, wavelengths=np.array([0.55]),
+                    name="plane_system")
+    t.polarization = polarization
+    return t
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_aperture_rims_are_inside(dtype):
+    """Rays EXACTLY on an aperture's edge (physical_apertures/radial.py:56-70 and friends use
+    <= / >=): the rim belongs to the aperture, one ulp beyond does not.  (The mutation test
+    of the kernel source -- tools/host_mutation_test.py -- found the `<` / `<=` mutants of
+    these comparisons alive: no golden has a ray exactly on a rim.)"""
+    from optiland_amd import system as S
+    from oracle import oracle
+    up = lambda v: np.nextafter(dtype(v), dtype(np.inf))    # noqa: E731
+    dn = lambda v: np.nextafter(dtype(v), dtype(-np.inf))   # noqa: E731
+    cases = [
+        # (kind, aperture, [(x, y, inside?) ...])
+        (S.AP_RADIAL, (2.0, 5.0, 0, 0), [(3, 4, True), (up(3), 4, False), (0, 2, True), (0, dn(2), False),
+                                         (5, 0, True), (0, -5, True)]),
+        (S.AP_OFFSET_RADIAL, (0.0, 5.0, 1.0, -2.0), [(4, 2, True), (up(4), 2, False), (1, 3, True)]),
+        (S.AP_RECTANGULAR, (-2.0, 3.0, -1.0, 4.0), [(3, 4, True), (up(3), 0, False), (0, up(4), False),
+                                                    (-2, -1, True), (dn(-2), 0, False), (0, dn(-1), False)]),
+        (S.AP_ELLIPTICAL, (4.0, 2.0, 0.0, 0.0), [(4, 0, True), (0, 2, True), (up(4), 0, False),
+                                                 (0, up(2), False)]),
+    ]
+    for kind, ap, pts in cases:
+        table = _plane_system(kind, ap)
+        n = len(pts)
+        rays = {"x": np.array([p[0] for p in pts], dtype=np.float64),
+                "y": np.array([p[1] for p in pts], dtype=np.float64), "z": np.full(n, -10.0),
+                "L": np.zeros(n), "M": np.zeros(n), "N": np.ones(n), "i": np.ones(n)}
+        want = oracle.trace(table, rays, 0, record=True)["record"]
+        sysm = hm.HostMathSystem(table)
+        planes = [np.ascontiguousarray(rays[k], dtype=dtype) for k in PLANES[:7]] + [np.zeros(n, dtype=dtype)]
+        got, _ = sysm.trace(planes, 0, record=True)
+        sysm.close()
+        inside = np.array([p[2] for p in pts])
+        assert np.array_equal(got[-1, 6] > 0, inside), (kind, got[-1, 6])
+        assert np.array_equal(want[-1, 6] > 0, inside), (kind, "oracle", want[-1, 6])
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_sign_of_zero_dot_zeroes_the_normal(dtype):
+    """real_rays.py:535-571: the normal is multiplied by `sign(dot)`, and sign(0) = 0 -- a ray
+    travelling exactly IN the surface (N = 0 at a flat one) keeps u * k0 as its new direction
+    (SURVEY.md Appendix D).  Mutant found alive by tools/host_mutation_test.py."""
+    from optiland_amd import system as S
+    from oracle import oracle
+    table = _plane_system(geom=S.GEOM_STANDARD, n2=1.5)
+    rays = {"x": np.zeros(2), "y": np.zeros(2), "z": np.array([-10.0, -10.0]),
+            "L": np.array([1.0, 0.6]), "M": np.zeros(2), "N": np.array([0.0, 0.8]), "i": np.ones(2)}
+    want = oracle.trace(table, rays, 0, record=True)["record"]
+    sysm = hm.HostMathSystem(table)
+    planes = [np.ascontiguousarray(rays[k], dtype=dtype) for k in PLANES[:7]] + [np.zeros(2, dtype=dtype)]
+    got, _ = sysm.trace(planes, 0, record=True)
+    sysm.close()
+    # direction after the surface: u * k0 for the in-plane ray (no normal component added)
+    np.testing.assert_allclose(got[1, 3:6, 0], [1.0 / 1.5, 0.0, 0.0], atol=1e-7)
+    np.testing.assert_allclose(got[1, 3:6, 0], want[1, 3:6, 0], atol=1e-7)
+    np.testing.assert_allclose(got[1, 3:6, 1], want[1, 3:6, 1], atol=1e-6)
+
+
+def test_zernike_range_bit_just_outside_the_unit_square(host):
+    """zernike.py:254-266 raises when |x / norm| > 1 or |y / norm| > 1: a ray at 1.2 norm radii
+    must set the bit, one at 0.99 must not."""
+    sysm, table, data = host("zernike_nopol")
+    norm = float(table.surfaces["norm_radius"][table.surfaces["geom_kind"] == 3][0])
+    for frac, flagged in ((0.99, False), (1.2, True)):
+        rays = [np.array([frac * norm]), np.zeros(1), np.array([-10.0]), np.zeros(1), np.zeros(1),
+                np.ones(1), np.ones(1), np.zeros(1)]
+        _, status = sysm.trace(rays, 0, record=False)
+        assert bool(status & 0x1) == flagged, (frac, status)

@@ -136,15 +136,23 @@ def test_random_newton_raphson_system_polarised(seed, dtype):
     n = rays["x"].size
     out = oracle.trace(table, rays, 0, record=True, polarized=True)
     assert out["status"] == 0
-    sysm = hm.HostMathSystem(table)
+    sysm2 = hm.HostMathSystem(table)
     prt = np.empty((9, n), dtype=dtype)
-    got, _ = sysm.trace(_planes(rays, dtype), 0, record=True, prt=prt, prt_identity=True)
-    sysm.close()
+    got, _ = sysm2.trace(_planes(rays, dtype), 0, record=True, prt=prt, prt_identity=True)
+    planes0 = _planes(rays, dtype)
+    iu, ist = sysm2.polarized_intensity(prt, planes0[3:6], planes0[6], table.polarization)
+    sysm2.close()
     p = hm.prt_to_complex(prt)
     tol = 1e-7 if dtype == np.float64 else 1e-4
     assert_close_planes(got.astype(np.float64), out["record"], tol, tol, f"nrpol{seed}")
     assert np.array_equal(np.isnan(p.real), np.isnan(out["prt"].real))
     np.testing.assert_allclose(np.nan_to_num(p.real), np.nan_to_num(out["prt"].real), rtol=0,
+                               atol=tol * 10)
+    # update_intensity: polarised (odd seeds) and UNPOLARISED states (mean of two, even seeds)
+    want_i, wst = oracle.polarized_intensity(out["prt"], rays["L"], rays["M"], rays["N"], rays["i"],
+                                             table.polarization)
+    assert ist == 0 and wst == 0
+    np.testing.assert_allclose(np.nan_to_num(iu.astype(np.float64)), np.nan_to_num(want_i), rtol=0,
                                atol=tol * 10)
 
 

@@ -1,0 +1,144 @@
+#!/usr/bin/env python
+"""Mutation test of the KERNEL SOURCE on the CPU: how many injected faults do the tests see?
+
+Each mutant is one small textual change to a copy of optiland_amd/csrc (a flipped sign, an
+off-by-one comparison, a dropped term, a swapped argument ...).  The host harness
+(tests/hostmath) is built from the mutated copy and the host-math tests are run against it;
+a mutant is KILLED when any of them fails.  A surviving mutant is a hole in the tests (or an
+equivalent mutant: a change with no observable effect, listed as such).
+
+    python tools/host_mutation_test.py [--only N ...]   ->  profiles/r02_mutation_test.txt
+
+CPU only; ~25 s per mutant (rebuild + tests/test_hostmath.py + the fuzz file).
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H = "surface_math.h"
+
+# (file under csrc, exact old text, new text, what it breaks)
+MUTANTS = [
+    (H, "  return -m::div(z, Ns);\n}", "  return m::div(z, Ns);\n}", "flat_distance: sign of the plane distance"),
+    (H, "V q = -(E + m::copysign(sq, E));", "V q = -(E - m::copysign(sq, E));", "curved_distance: the cancelling root"),
+    (H, "V disc = m::fma(E, E, -A * C);", "V disc = m::fma(E, E, A * C);", "curved_distance: discriminant sign"),
+    (H, "V t = m::select(m::le(z1, z2), t1, t2);", "V t = m::select(m::le(z1, z2), t2, t1);", "curved_distance: root selection rule"),
+    (H, "t = m::select(m::eq(A, zero), ta, t);", "t = m::select(m::eq(A, zero), tb, t);", "curved_distance: a == 0 branch"),
+    (H, "      return (r2 <= ap[1]) && (r2 >= ap[0]);\n    }\n    case kApOffsetRadial", "      return (r2 < ap[1]) && (r2 >= ap[0]);\n    }\n    case kApOffsetRadial", "radial aperture: rim is inside (<=)"),
+    (H, "T dx = x - ap[2], dy = y - ap[3];\n      T r2 = m::fma(dx, dx, dy * dy);", "T dx = x + ap[2], dy = y - ap[3];\n      T r2 = m::fma(dx, dx, dy * dy);", "offset radial aperture: offset sign"),
+    (H, "return (ap[0] <= x) && (x <= ap[1]) && (ap[2] <= y) && (y <= ap[3]);", "return (ap[0] <= x) && (x <= ap[1]) && (ap[2] <= y) && (y < ap[3]);", "rectangular aperture: upper edge inclusive"),
+    (H, "return m::fma(dx * dx, ap[0], dy * dy * ap[1]) <= T(1);", "return m::fma(dx * dx, ap[1], dy * dy * ap[0]) <= T(1);", "elliptical aperture: axes swapped"),
+    (H, "V root = m::sqrt(m::fma(m::splat(-u * u), m::fma(-adot[k], adot[k], one), one));", "V root = m::sqrt(m::fma(m::splat(-u), m::fma(-adot[k], adot[k], one), one));", "refract: u instead of u^2 under the root"),
+    (H, "V k2 = m::splat(-2) * adot[k];", "V k2 = m::splat(2) * adot[k];", "reflect: sign of the reflected component"),
+    (H, "const V sgn = m::select(m::ne(dot, zero), m::copysign(one, dot), zero);", "const V sgn = m::copysign(one, dot);", "align normal: sign(0) = 0 kept"),
+    (H, "r[k].opd = r[k].opd + m::abs(t[k] * o.n1);", "r[k].opd = r[k].opd + m::abs(t[k] * o.n2);", "opd: index of the medium the ray came through"),
+    (H, "r[k].opd = r[k].opd + m::abs(t[k] * o.n1);", "r[k].opd = r[k].opd + (t[k] * o.n1);", "opd: |t n| (negative distances)"),
+    (H, "const V arg = -o.absorb * t[k];", "const V arg = o.absorb * t[k];", "absorption: sign of the exponent"),
+    (H, "    const T f = s.interaction == kReflect ? s.cold->coat[1] : s.cold->coat[0];", "    const T f = s.interaction == kReflect ? s.cold->coat[0] : s.cold->coat[1];", "simple coating: R and T swapped"),
+    (H, "    if (ck == kCoatSimple) return;", "    if (false) return;", "simple coating leaves the PRT untouched"),
+    (H, "            j0 = m::div(T(2) * ci, ci + root);", "            j0 = m::div(T(2) * ci, ci - root);", "Fresnel ts"),
+    (H, "            j1 = m::div(T(2) * nn * ci, m::fma(nn * nn, ci, root));", "            j1 = m::div(T(2) * ci, m::fma(nn * nn, ci, root));", "Fresnel tp: factor n"),
+    (H, "            j2 = T(-1);", "            j2 = T(1);", "Fresnel reflection: k k^T sign"),
+    (H, "  const T bx = m::fma(j2, k1x, -(j0 * k0x)), by = m::fma(j2, k1y, -(j0 * k0y)),\n          bz = m::fma(j2, k1z, -(j0 * k0z));\n#pragma unroll\n  for (int c = 0; c < NP; ++c) {", "  const T bx = m::fma(j2, k1x, (j0 * k0x)), by = m::fma(j2, k1y, -(j0 * k0y)),\n          bz = m::fma(j2, k1z, -(j0 * k0z));\n#pragma unroll\n  for (int c = 0; c < NP; ++c) {", "prt_apply_diag: one component of the rank-2 update"),
+    (H, "      P.m[3 * i + e] = m::fma(a[i], p0[e], m::fma(bb[i], k0[e], i == e ? j0 : T(0)));", "      P.m[3 * i + e] = m::fma(a[i], p0[e], m::fma(bb[i], k0[e], i == e ? j1 : T(0)));", "prt_first_diag: diagonal term"),
+    (H, "  T sx = k0y * nz - k0z * ny, sy = k0z * nx - k0x * nz, sz = k0x * ny - k0y * nx;", "  T sx = k0y * nz - k0z * ny, sy = k0z * nx + k0x * nz, sz = k0x * ny - k0y * nx;", "pol_basis: s = k0 x n"),
+    (H, "  bool done = !(af >= s.cold->tol);                       // converged, or NaN", "  bool done = !(af >= s.cold->tol * T(1e6));                       // converged, or NaN", "Newton: convergence tolerance 1e6 x looser"),
+    (H, "  T df = m::fma(fx, L, m::fma(fy, M, -N));", "  T df = m::fma(fx, L, m::fma(fy, M, N));", "Newton: f' = fx L + fy M - N"),
+    (H, "      const T im = m::rsqrt(m::fma(q[k].gx, q[k].gx, m::fma(q[k].gy, q[k].gy, T(1))));\n      nx[k] = q[k].gx * im;", "      const T im = m::rsqrt(m::fma(q[k].gx, q[k].gx, m::fma(q[k].gy, q[k].gy, T(1))));\n      nx[k] = -q[k].gx * im;", "Newton surfaces: normal from the sag gradient"),
+    (H, "    P = i == N ? q : m::fma(P, xn, q);", "    P = i == N ? q : m::fma(P, yn, q);", "Zernike one-polynomial form: outer Horner variable"),
+    (H, "      q = q * yy + cj;", "      q = q * xx + cj;", "Zernike one-polynomial form: gradient inner variable"),
+    (H, "    const T t1s = (t1.x + t1.y) * T(2);", "    const T t1s = (t1.x + t1.y);", "Zernike level form: dQ/dx = 2 x Q'"),
+    (H, "    const V2 w = qn * T(mg);", "    const V2 w = qn * T(mg + 1);", "Zernike level form: harmonic derivative factor m"),
+    (H, "  if (u < T(1e-8)) {  // the reference's eps-regularised chain rule near / at the vertex", "  if (false) {  // the reference's eps-regularised chain rule near / at the vertex", "Zernike: vertex regularisation"),
+    (H, "  if (m::abs(xn) > T(1) || m::abs(yn) > T(1)) status |= 0x1u;  // OL_STATUS_ZERNIKE_RANGE", "  if (m::abs(xn) > T(2) || m::abs(yn) > T(2)) status |= 0x1u;  // OL_STATUS_ZERNIKE_RANGE", "Zernike: range check threshold"),
+    (H, "    g.x = R[0] * r.x + R[3] * r.y + R[6] * r.z;\n    g.y = R[1] * r.x + R[4] * r.y + R[7] * r.z;", "    g.x = R[0] * r.x + R[1] * r.y + R[2] * r.z;\n    g.y = R[1] * r.x + R[4] * r.y + R[7] * r.z;", "to_global: inverse rotation = transpose"),
+    (H, "        r[k].z -= oz;\n      }\n    }\n  } else if", "        r[k].z += oz;\n      }\n    }\n  } else if", "into_local_frame: translation sign (from global)"),
+    ("raygen_device.h", "    x0 = px * c.EPD / T(2) * vx + (-tx * c.off_epl);", "    x0 = px * c.EPD / T(2) * vx + (tx * c.off_epl);", "ray generation: field offset sign at infinity"),
+    ("raygen_device.h", "  const bool is_zero = mag < T(1e-9);  // paraxial.py:96-104", "  const bool is_zero = mag < T(1e9);  // paraxial.py:96-104", "ray generation: zero-length direction guard"),
+    ("wavefront_device.h", "    t = t1 < T(0) ? t2 : t1;", "    t = t1 < T(0) ? t1 : t2;", "wavefront: root choice on the reference sphere"),
+    ("epilogue_device.h", "  return acc * i0 / T(f.nf);", "  return acc * i0;", "update_intensity: mean over the two unpolarised states"),
+    ("epilogue_device.h", "  if (v == e[nb]) return nb - 1;", "  if (v == e[nb]) return -1;", "histogram: right-most edge folded into the last bin"),
+    ("epilogue_device.h", "    if (r <= steps[mid]) hi = mid; else lo = mid + 1;", "    if (r < steps[mid]) hi = mid; else lo = mid + 1;", "encircled energy: radii <= r"),
+    ("capi.hip", "      out.push_back((i + 1) * Q[(i + 1) * W + j]);  // dQ/dx", "      out.push_back((i + 2) * Q[(i + 1) * W + j]);  // dQ/dx", "host: monomial derivative coefficients"),
+    ("capi.hip", "          const double sign = ((h / 2) & 1) ? -1.0 : 1.0;  // i^h: +1, (+i), -1, (-i), ...", "          const double sign = 1.0;  // i^h: +1, (+i), -1, (-i), ...", "host: harmonic expansion signs"),
+]
+
+TESTS = ["tests/test_hostmath.py", "tests/test_hostmath_fuzz.py"]
+
+
+def run(cmd, **kw):
+    return subprocess.run(cmd, capture_output=True, text=True, **kw)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", type=int, nargs="*")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_mutation_test.txt"))
+    args = ap.parse_args()
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hb", os.path.join(ROOT, "tests", "hostmath", "build.py"))
+    hb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hb)
+    flags = ["--offload-host-only", "-O1", "-std=c++17", "-fPIC", "-ffp-contract=on",
+             "-fno-math-errno"] + (["-mfma"] if hb._cpu_has_fma() else [])
+    rows = []
+    todo = range(len(MUTANTS)) if not args.only else args.only
+    for idx in todo:
+        fname, old, new, what = MUTANTS[idx]
+        t0 = time.time()
+        with tempfile.TemporaryDirectory() as tmp:
+            # the harness includes "../../optiland_amd/csrc/..." and "../../include/...": same tree
+            shutil.copytree(os.path.join(ROOT, "optiland_amd", "csrc"), os.path.join(tmp, "optiland_amd", "csrc"))
+            shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
+            os.makedirs(os.path.join(tmp, "tests", "hostmath"))
+            shutil.copy(os.path.join(ROOT, "tests", "hostmath", "harness.hip"), os.path.join(tmp, "tests", "hostmath"))
+            path = os.path.join(tmp, "optiland_amd", "csrc", fname)
+            src = open(path).read()
+            if src.count(old) < 1:
+                rows.append((idx, what, "STALE (pattern not found)", 0.0))
+                continue
+            open(path, "w").write(src.replace(old, new, 1))
+            objs = []
+            ok = True
+            for s in (os.path.join(tmp, "optiland_amd", "csrc", "capi.hip"),
+                      os.path.join(tmp, "tests", "hostmath", "harness.hip")):
+                o = s + ".o"
+                r = run(["/opt/rocm/bin/hipcc", *flags, "-c", s, "-o", o])
+                if r.returncode != 0:
+                    ok = False
+                    break
+                objs.append(o)
+            if not ok:
+                rows.append((idx, what, "DOES NOT COMPILE", time.time() - t0))
+                continue
+            lib = os.path.join(tmp, "libmut.so")
+            subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", *objs, "-o", lib])
+            env = dict(os.environ, OL_HOSTMATH_LIBRARY=lib, PYTHONPATH=ROOT)
+            r = run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", *TESTS],
+                    cwd=ROOT, env=env, timeout=900)
+            if r.returncode == 0:
+                verdict = "SURVIVED"
+            else:
+                first = [ln for ln in r.stdout.splitlines() if ln.startswith("FAILED")]
+                verdict = "killed by " + (first[0].split("::", 1)[1][:70] if first else "a crash")
+            rows.append((idx, what, verdict, time.time() - t0))
+            print(f"[{idx:2d}] {what:60s} {verdict}  ({time.time() - t0:.0f} s)", flush=True)
+    killed = sum(1 for r in rows if r[2].startswith("killed"))
+    with open(args.out, "w") as f:
+        f.write("# r02: mutation test of the kernel source on the CPU (tools/host_mutation_test.py): one small fault per\n"
+                "# mutant in a copy of optiland_amd/csrc, host harness rebuilt from it, tests/test_hostmath.py +\n"
+                "# tests/test_hostmath_fuzz.py run against it (-x: the first failing test is named).\n"
+                f"# {killed} of {len(rows)} mutants killed.\n")
+        for idx, what, verdict, dt in rows:
+            f.write(f"{idx:3d}  {what:62s} {verdict}\n")
+    print(open(args.out).read())
+
+
+if __name__ == "__main__":
+    main()
