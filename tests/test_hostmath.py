@@ -385,3 +385,36 @@ def test_zernike_range_bit_just_outside_the_unit_square(host):
                 np.ones(1), np.ones(1), np.zeros(1)]
         _, status = sysm.trace(rays, 0, record=False)
         assert bool(status & 0x1) == flagged, (frac, status)
+
+
+def test_polygon_aperture_points_on_edges_and_vertices():
+    """physical_apertures/polygon.py delegates to matplotlib's `Path.contains_points`, whose
+    crossings test decides points exactly on an edge or a vertex by its tie rule (`>=`); the
+    oracle's restatement is pinned to matplotlib on such points (tests/test_oracle_polygon.py),
+    and the kernel source is held to the oracle here -- convex and concave polygons, points on
+    vertices, on horizontal / vertical / slanted edges, just inside and just outside.  (The
+    `>` for `>=` mutant of the crossing test survived tools/host_mutation_test.py before.)"""
+    from optiland_amd import system as S
+    from oracle import oracle
+    polys = [
+        [(-2, -2), (2, -2), (2, 2), (-2, 2)],
+        [(0, 0), (4, 0), (4, 4), (2, 1.5), (0, 4)],            # concave
+        [(-3, 0), (0, -3), (3, 0), (0, 3)],                    # diamond: slanted edges
+    ]
+    pts = [(2, 0), (0, 2), (-2, 0), (0, -2), (2, 2), (-2, -2), (2, -2), (-2, 2), (0, 0), (4, 2), (2, 1.5),
+           (3, 0), (0, 3), (1.5, 1.5), (-1.5, 1.5), (1.5, -1.5), (-1.5, -1.5), (1, 0.75), (3, 2.75),
+           (0, 4), (4, 4), (4, 0), (2, 0.5), (1.9999999, 0), (2.0000001, 0), (5, 5)]
+    n = len(pts)
+    for verts in polys:
+        table = _plane_system(S.AP_POLYGON, (0.0, float(len(verts)), 0.0, 0.0))
+        table.coeffs = np.array([c for v in verts for c in v], dtype=np.float64)
+        rays = {"x": np.array([p[0] for p in pts], dtype=np.float64),
+                "y": np.array([p[1] for p in pts], dtype=np.float64), "z": np.full(n, -10.0),
+                "L": np.zeros(n), "M": np.zeros(n), "N": np.ones(n), "i": np.ones(n)}
+        want = oracle.trace(table, rays, 0, record=True)["record"][-1, 6] > 0
+        sysm = hm.HostMathSystem(table)
+        planes = [np.ascontiguousarray(rays[k]) for k in PLANES[:7]] + [np.zeros(n)]
+        got, _ = sysm.trace(planes, 0, record=True)
+        sysm.close()
+        assert np.array_equal(got[-1, 6] > 0, want), (verts, list(zip(pts, got[-1, 6] > 0, want)))
+        assert want.any() and not want.all()

@@ -66,6 +66,26 @@ MUTANTS = [
     ("epilogue_device.h", "    if (r <= steps[mid]) hi = mid; else lo = mid + 1;", "    if (r < steps[mid]) hi = mid; else lo = mid + 1;", "encircled energy: radii <= r"),
     ("capi.hip", "      out.push_back((i + 1) * Q[(i + 1) * W + j]);  // dQ/dx", "      out.push_back((i + 2) * Q[(i + 1) * W + j]);  // dQ/dx", "host: monomial derivative coefficients"),
     ("capi.hip", "          const double sign = ((h / 2) & 1) ? -1.0 : 1.0;  // i^h: +1, (+i), -1, (-i), ...", "          const double sign = 1.0;  // i^h: +1, (+i), -1, (-i), ...", "host: harmonic expansion signs"),
+    # second batch: the other sag functors, polygon / boolean apertures, polarizer / retarder,
+    # the ray generator's other branches, the host's table conversion
+    (H, "    dp = m::fma(dp, r2, T(i + 1) * ci);\n    p = m::fma(p, r2, ci);\n  }\n  sag = m::fma(p, r2, sag);\n  f = m::fma(T(2), dp, f);", "    dp = m::fma(dp, r2, T(i + 1) * ci);\n    p = m::fma(p, r2, ci);\n  }\n  sag = m::fma(p, r2, sag);\n  f = m::fma(T(1), dp, f);", "even asphere: d(r^2)/dx = 2 x"),
+    (H, "    if (i >= 1) q = m::fma(q, r, T(i + 1) * ci);", "    if (i >= 1) q = m::fma(q, r, T(i) * ci);", "odd asphere: derivative factor (i + 1)"),
+    (H, "  T t0 = r > T(0) ? m::div(c0, r) : T(0);  // i = 0 term: x C_0 / r, 0 at r == 0", "  T t0 = T(0);  // i = 0 term: x C_0 / r, 0 at r == 0", "odd asphere: the linear term's gradient"),
+    (H, "      dqi = m::fma(dqi, y, qi);\n      qi = m::fma(qi, y, cij);", "      dqi = m::fma(dqi, y, cij);\n      qi = m::fma(qi, y, cij);", "XY polynomial: d/dy by Horner"),
+    (H, "      dq = m::fma(cij * T(j), Uj1, dq);", "      dq = m::fma(cij, Uj1, dq);", "Chebyshev: T_j' = j U_(j-1)"),
+    (H, "    zy = m::div(cy * y * y, T(1) + m::sqrt(st0));", "    zy = m::div(cy * y * y, T(1) - m::sqrt(st0));", "biconic: y profile"),
+    (H, "  const T d = R - zy;", "  const T d = R + zy;", "toroidal: rotation about the axis at R"),
+    (H, "    if (yflag0 != yflag1 && (((y1 - ty) * (x0 - x1) >= (x1 - tx) * (y0 - y1)) == yflag1))", "    if (yflag0 != yflag1 && (((y1 - ty) * (x0 - x1) > (x1 - tx) * (y0 - y1)) == yflag1))", "polygon: edge crossing with >="),
+    (H, "const uint32_t v = op == kApOpUnion ? (a | b) : (op == kApOpIntersection ? (a & b) : (a & ~b & 1u));", "const uint32_t v = op == kApOpUnion ? (a | b) : (op == kApOpIntersection ? (a & b) : (b & ~a & 1u));", "boolean apertures: difference a \\ b operand order"),
+    (H, "    J.a00 = uso * usi; J.a01 = uso * upi; J.a10 = upo * usi; J.a11 = upo * upi;", "    J.a00 = uso * usi; J.a01 = upo * usi; J.a10 = uso * upi; J.a11 = upo * upi;", "polarizer Jones: u_out u_in^T transposed"),
+    (H, "    J.b01 = J.b10 = T(-2) * rs * q01;", "    J.b01 = J.b10 = T(2) * rs * q01;", "retarder Jones: off-diagonal sign"),
+    (H, "    T px = T(0), py = k0z, pz = -k0y;\n    if (py == T(0) && pz == T(0)) {", "    T px = T(0), py = -k0z, pz = k0y;\n    if (py == T(0) && pz == T(0)) {", "pol_basis: normal-incidence fallback axis  [EQUIVALENT: s and p flip together; s s^T, p1 p0^T, and the axis projections of polarizer / retarder are even in that sign]"),
+    (H, "      r[k].i = m::select(aperture_mask<V, FULL>(s, coeffs, r[k].x, r[k].y), r[k].i, zero);", "      r[k].i = m::select(aperture_mask<V, FULL>(s, coeffs, r[k].x, r[k].y), r[k].i, r[k].i);", "clip: outside rays lose their intensity"),
+    ("raygen_device.h", "    x1 = px * vx + x0;\n    y1 = py * vy + y0;\n    z1 = c.tele_dz + z0;", "    x1 = px * vx - x0;\n    y1 = py * vy + y0;\n    z1 = c.tele_dz + z0;", "ray generation: telecentric target point"),
+    ("raygen_device.h", "    case 1: return exp(-r2 / (T(2) * a * a));                                  // gaussian.py", "    case 1: return exp(-r2 / (a * a));                                  // gaussian.py", "apodization: Gaussian width"),
+    ("raygen_device.h", "    x0 = -tx * c.epl_z;", "    x0 = tx * c.epl_z;", "ray generation: finite-object angle field origin"),
+    ("capi.hip", "      out[0] = a[0] * a[0];\n      out[1] = a[1] * a[1];", "      out[0] = a[0];\n      out[1] = a[1] * a[1];", "host: radial aperture r_min squared"),
+    ("capi.hip", "      out[0] = 1.0 / (a[0] * a[0]);", "      out[0] = 1.0 / (a[0]);", "host: elliptical aperture semi-axis squared"),
 ]
 
 TESTS = ["tests/test_hostmath.py", "tests/test_hostmath_fuzz.py"]
@@ -130,13 +150,14 @@ def main():
             rows.append((idx, what, verdict, time.time() - t0))
             print(f"[{idx:2d}] {what:60s} {verdict}  ({time.time() - t0:.0f} s)", flush=True)
     killed = sum(1 for r in rows if r[2].startswith("killed"))
+    equivalent = sum(1 for r in rows if "[EQUIVALENT" in r[1])
     with open(args.out, "w") as f:
         f.write("# r02: mutation test of the kernel source on the CPU (tools/host_mutation_test.py): one small fault per\n"
                 "# mutant in a copy of optiland_amd/csrc, host harness rebuilt from it, tests/test_hostmath.py +\n"
                 "# tests/test_hostmath_fuzz.py run against it (-x: the first failing test is named).\n"
-                f"# {killed} of {len(rows)} mutants killed.\n")
+                f"# {killed} of {len(rows)} mutants killed ({equivalent} marked equivalent: no observable effect).\n")
         for idx, what, verdict, dt in rows:
-            f.write(f"{idx:3d}  {what:62s} {verdict}\n")
+            f.write(f"{idx:3d}  {what[:110]:62s} {verdict}\n")
     print(open(args.out).read())
 
 
