@@ -7,10 +7,24 @@
 # identically WITHOUT the drop-in in this container (seaborn stub).
 # With the SurfaceGroup.trace seam and the bridging of unsupported surfaces enabled the
 # result is unchanged; the seam itself served 52 caller-built bundles and declined 17.
+#
+#   tools/ref_sweep.sh [workdir] [oracle|kernel-source]
+# kernel-source (round 2): behind the tracer sits the product's own engine class on the host
+# build of the kernel source (tests/_hostmath.make_engine_class) instead of the oracle.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 W=${1:-/tmp/ol_ref_sweep}
+ENGINE=${2:-oracle}
 rm -rf "$W" && mkdir -p "$W" && cp -r /root/reference/tests "$W/tests"
+if [ "$ENGINE" = kernel-source ]; then
+cat > "$W/tests_fake.py" <<PY
+import importlib.util, sys
+sys.path.insert(0, "$R")
+spec = importlib.util.spec_from_file_location("_ol_hostmath", "$R/tests/_hostmath.py")
+mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+OracleEngine = mod.make_engine_class()
+PY
+else
 cat > "$W/tests_fake.py" <<PY
 import importlib.util, sys
 sys.path.insert(0, "$R")
@@ -18,6 +32,7 @@ spec = importlib.util.spec_from_file_location("_ol_fake_engine", "$R/tests/_fake
 mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
 OracleEngine = mod.OracleEngine
 PY
+fi
 python - "$W" "$R" <<'PY'
 import sys
 w, r = sys.argv[1:3]
