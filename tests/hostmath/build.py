@@ -61,7 +61,7 @@ def build(force: bool = False, verbose: bool = False, sanitize: bool = False) ->
     deps = [os.path.join(CSRC, d) for d in DEPS] + [
         os.path.join(HERE, "harness.hip"), os.path.join(ROOT, "include", "optiland_hip.h"),
         os.path.abspath(__file__)]
-    if not force and os.path.exists(lib) and \
+    if not force and not os.environ.get("OL_HOSTMATH_CXXFLAGS") and os.path.exists(lib) and \
             all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
         return lib
     # fma() is written out everywhere it matters; -mfma additionally lets the host
@@ -70,9 +70,16 @@ def build(force: bool = False, verbose: bool = False, sanitize: bool = False) ->
              "-fno-math-errno", "-Wall"] + (["-mfma"] if _cpu_has_fma() else [])
     flags += ["-O1", "-g1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
               "-fno-sanitize-recover=undefined"] if sanitize else ["-O2"]
+    # extra compile-time knobs of the kernel source (A/B variants checked for accuracy here
+    # before they cost GPU time); a variant build goes to its own file
+    extra = os.environ.get("OL_HOSTMATH_CXXFLAGS", "").split()
+    if extra:
+        flags += extra
+        lib = lib.replace(".so", "_variant.so")
     objs = []
     for src in (os.path.join(CSRC, "capi.hip"), os.path.join(HERE, "harness.hip")):
-        o = os.path.join(OUT, os.path.basename(src).replace(".hip", "_asan.o" if sanitize else ".o"))
+        o = os.path.join(OUT, os.path.basename(src).replace(
+            ".hip", "_asan.o" if sanitize else ("_variant.o" if extra else ".o")))
         cmd = [hipcc, *flags, "-c", src, "-o", o]
         if verbose:
             print(" ".join(cmd))
