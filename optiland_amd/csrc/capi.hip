@@ -341,7 +341,7 @@ int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* c
              int32_t wl, void* record, int64_t record_stride, void* prt, int32_t first,
              int32_t last, uint32_t flags, uint32_t* status, const ol_trace_extras* extras,
              hipStream_t stream) {
-  ol::TraceArgs<T> a;
+  ol::TraceArgs<T> a{};
   a.spot = extras ? extras->spot_slots : nullptr;
   a.cx = extras ? extras->cx : 0.0;
   a.cy = extras ? extras->cy : 0.0;
@@ -440,7 +440,7 @@ int do_trace_spot(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
                   const ol_raygen_params* p, const ol_raygen_inputs* in, double cx, double cy,
                   int32_t wl, void* const hits[3], double* out7, uint32_t* status,
                   hipStream_t stream) {
-  ol::SpotArgs<T> a;
+  ol::SpotArgs<T> a{};
   bool vec = true;
   if (int rc = convert_inputs<T>("ol_trace_spot", in, status, a.in, vec)) return rc;
   if (n == 0) return OL_OK;
@@ -473,7 +473,7 @@ int do_trace_opd(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
                  const ol_raygen_params* p, const ol_raygen_inputs* in,
                  const ol_wavefront_params* w, int32_t wl, void* opd, void* inten,
                  void* const pupil[3], double* mom, uint32_t* status, hipStream_t stream) {
-  ol::OpdArgs<T> a;
+  ol::OpdArgs<T> a{};
   bool vec = true;
   if (int rc = convert_inputs<T>("ol_trace_opd", in, status, a.in, vec)) return rc;
   if (a.in.hx != nullptr || a.in.vx != nullptr)
