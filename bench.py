@@ -45,7 +45,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MODE_NAMES = {"record": "record-all", "last": "record-last",
-              "spot": "fused generate+trace+spot-reduce (no ray planes)"}
+              "spot": "fused generate+trace+spot-reduce (no ray planes)",
+              "opd": "fused generate+trace+OPD (ol_trace_opd: 2 pupil planes in, OPD + "
+                     "intensity + pupil point out, 12 device moments)"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 WORKLOADS = {
@@ -55,7 +57,22 @@ WORKLOADS = {
     "rc_asphere": ("rc_asphere", 1.0, "RC + even-asphere corrector (Newton-Raphson)", 0.55),
     "zernike_fresnel": ("zernike_fresnel_fringe", 1.0, "Zernike freeform + Fresnel/polarized",
                         0.55),
+    # the same singlet with the coatings stripped and polarisation ignored: the Zernike
+    # Newton kernels on the unpolarised paths (fused spot / OPD kernels refuse polarised
+    # systems)
+    "zernike": ("zernike_fresnel_fringe", 1.0, "Zernike freeform, uncoated, unpolarised", 0.55),
 }
+
+
+def load_workload(name):
+    from optiland_amd import load_system
+    sys_name, hy, desc, wavelength = WORKLOADS[name]
+    table = load_system(sys_name)
+    if name == "zernike":
+        table.surfaces["coating_kind"] = 0
+        table.polarization = None
+        table.name = "zernike_uncoated"
+    return table, hy, desc, wavelength
 
 
 def parse_args():
@@ -66,10 +83,11 @@ def parse_args():
     ap.add_argument("--rays", type=float, default=1e7, help="rays per GPU per step")
     ap.add_argument("--dtype", choices=("f32", "f64"), default="f32")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="double_gauss")
-    ap.add_argument("--mode", choices=("record", "last", "spot"), default="record",
+    ap.add_argument("--mode", choices=("record", "last", "spot", "opd"), default="record",
                     help="record: all surfaces (drop-in semantics); last: image plane only; "
                          "spot: fused generate -> trace -> reduce kernel (ol_trace_spot), "
-                         "no ray planes at all")
+                         "no ray planes at all; opd: fused generate -> trace -> OPD kernel "
+                         "(ol_trace_opd, fp64)")
     ap.add_argument("--exchange", choices=("reduce", "gather", "none"), default="reduce",
                     help="image-plane exchange when --gpus > 1")
     ap.add_argument("--object-row", choices=("alias", "copy"), default="alias",
@@ -289,7 +307,9 @@ def reference_baselines(workload, dtype, wavelength, hy, S, budget_s, device, n=
         print(f"reference baselines skipped: {exc!r}", file=sys.stderr)
         return None
     name = {"double_gauss": "DoubleGauss", "cooke": "CookeTriplet", "rc_asphere": "RCAsphere",
-            "zernike_fresnel": "ZernikeFresnelUnpolarized"}[workload]
+            "zernike_fresnel": "ZernikeFresnelUnpolarized"}.get(workload)
+    if name is None:
+        return None
     rng = np.random.default_rng(0)
     r, th = np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
     px, py = r * np.cos(th), r * np.sin(th)
@@ -394,15 +414,15 @@ def main():
     self_launch(args)  # N > 1 without a launcher: re-exec under torchrun and exit
     rank, local, world = init_dist(args.gpus)
     device = torch.device("cuda", local)
-    from optiland_amd import load_system
     from optiland_amd.distributed import shard_bounds
     from optiland_amd.engine import HipSystem
 
     strong = args.config == "c3"
     if strong:  # BASELINE.json configs[2]: double Gauss, fp64, 1e8 rays over the ranks
         args.workload, args.dtype = "double_gauss", "f64"
-    sys_name, hy, desc, wavelength = WORKLOADS[args.workload]
-    table = load_system(sys_name)
+    if args.mode == "opd":
+        args.dtype = "f64"  # ol_trace_opd is fp64 only (an OPD in waves)
+    table, hy, desc, wavelength = load_workload(args.workload)
     wl = table.wavelength_index(wavelength)
     hip = HipSystem(table, device)
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
@@ -417,13 +437,23 @@ def main():
 
     record = hip.alloc_record(n, dtype) if args.mode == "record" else None
     alias = record is not None and args.object_row == "alias"
-    spot = args.mode == "spot"
+    opd_mode = args.mode == "opd"
+    spot = args.mode == "spot" or opd_mode  # the fused, ray-plane-free pipelines
     if spot:
         if pol:
-            raise SystemExit("--mode spot needs an unpolarised workload")
+            raise SystemExit(f"--mode {args.mode} needs an unpolarised workload")
         px, py = make_pupil(n, dtype, 1234 + rank, device)
         rays = []
-        mom = [torch.zeros(7, dtype=torch.float64, device=device) for _ in range(2)]
+        mom = [torch.zeros(12 if opd_mode else 7, dtype=torch.float64, device=device)
+               for _ in range(2)]
+        if opd_mode:
+            # reference sphere of the chief ray of this field (wavefront/strategy.py:176-184),
+            # worked out once outside the timed region like a consumer's first step
+            from optiland_amd.tracer import HipRayTracer
+            from optiland_amd.wavefront import Wavefront
+            wf = Wavefront(HipRayTracer(table, device, dtype=torch.float64, engine=hip),
+                           (0.0, hy), wavelength, num_rays=3)
+            opd_params = wf.chief_reference()[0]
     else:
         rays = make_rays(hip, n, dtype, hy, seed=1234 + rank, device=device,
                          out=hip.row0_planes(record, n) if alias else None)
@@ -465,12 +495,19 @@ def main():
         mom[k].zero_()
         if ev0 is not None:
             ev0.record()
-        hip.trace_spot(px, py, wl, field=(0.0, hy), out=mom[k], check_status=False)
+        if opd_mode:
+            hip.trace_opd(opd_params, px, py, wl, field=(0.0, hy), want_pupil=True,
+                          moments=mom[k], check_status=False)
+        else:
+            hip.trace_spot(px, py, wl, field=(0.0, hy), out=mom[k], check_status=False)
         if ev1 is not None:
             ev1.record()
         if exchange != "none":
-            pending[k] = (dist.all_reduce(mom[k][:6], async_op=True),
-                          dist.all_reduce(mom[k][6:], op=dist.ReduceOp.MAX, async_op=True))
+            if opd_mode:  # the twelve sums add up across ray shards
+                pending[k] = (dist.all_reduce(mom[k], async_op=True),)
+            else:
+                pending[k] = (dist.all_reduce(mom[k][:6], async_op=True),
+                              dist.all_reduce(mom[k][6:], op=dist.ReduceOp.MAX, async_op=True))
         return mom[k]
 
     def step(ev0=None, ev1=None):
@@ -564,7 +601,8 @@ def main():
         step()  # untimed: the launch without the spot epilogue is a different kernel variant
         bare = timed(args.steps)
         exchange = configured_exchange
-        wire = (8 * 64 * 8 if configured_exchange == "reduce" else 3 * b * n) if not spot else 56
+        wire = (8 * 64 * 8 if configured_exchange == "reduce" else 3 * b * n) if not spot \
+            else (96 if opd_mode else 56)
         exchange_info = {
             "kind": {"reduce": "async all-gather of the 4 KB spot-moment slot block (RCCL)",
                      "gather": "literal RCCL all-gather of image-plane hits (x, y, i)"}[
@@ -585,6 +623,8 @@ def main():
         # writes 8 planes for each of the S+1 surfaces; record-last reads 8, writes 8.
         if args.mode == "record":
             alg_bytes = 8 * b * (S + 2) * n
+        elif opd_mode:
+            alg_bytes = (2 + 5) * b * n  # pupil planes in; OPD, intensity, pupil point out
         elif spot:
             alg_bytes = 2 * b * n  # the two pupil planes; everything else stays in registers
         else:
@@ -638,7 +678,8 @@ def main():
             "exchange": exchange_info,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "spot_trace_kernel" if spot else "trace_kernel",
+                "kernel": "opd_trace_kernel" if opd_mode else
+                          ("spot_trace_kernel" if spot else "trace_kernel"),
                 # the contract's `achieved` / `frac`: bytes this launch really moves (equal
                 # to the PMC traffic within 0.1 %) over the HIP-event kernel time
                 "achieved": moved_GBps,

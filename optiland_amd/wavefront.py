@@ -31,8 +31,11 @@ class WavefrontData:
         self.pupil_x, self.pupil_y, self.pupil_z = pupil_x, pupil_y, pupil_z
         self.opd, self.intensity, self.radius = opd, intensity, radius
         # `ol_trace_opd`'s 12 sums (tilt-fit moments; count / sum / sum of squares of the OPD
-        # over rays with i > 0) of the OPD as first computed -- None on the un-fused path
+        # over rays with i > 0) of the OPD as first computed -- None on the un-fused path.
+        # They describe `_moments_of` (that exact tensor) only: consumers check identity, so a
+        # caller who replaces or detrends `opd` gets sums recomputed from the data it passes
         self.moments = moments
+        self._moments_of = opd if moments is not None else None
 
 
 class Wavefront:
@@ -76,6 +79,10 @@ class Wavefront:
         self.data = self._compute()
         if self.remove_tilt:  # wavefront.py:173-174
             self.data.opd = self.fit_and_remove_tilt(self.data)
+            # the device sums describe the OPD as the kernel produced it, not the detrended
+            # map now stored: a later fit (or rms) must take its sums from the data it is
+            # given, as the reference's always does
+            self.data.moments = None
 
     @staticmethod
     def fit_and_remove_tilt(data, remove_piston: bool = False, ridge: float = 1e-12):
@@ -88,8 +95,10 @@ class Wavefront:
         diagonal, as the reference regularises) solved on the host in closed form, and one
         elementwise pass for the residual."""
         x, y, w, opd = data.pupil_x, data.pupil_y, data.intensity, data.opd
-        if getattr(data, "moments", None) is not None:
-            m = data.moments[:9].double().cpu().numpy()
+        mom = getattr(data, "moments", None)
+        if mom is not None and getattr(data, "_moments_of", None) is opd:
+            # the kernel's own sums -- valid only for the very OPD tensor they were taken of
+            m = mom[:9].double().cpu().numpy()
         else:
             basis = torch.stack([torch.ones_like(x), x, y, x * x, x * y, y * y,
                                  opd, opd * x, opd * y])
@@ -114,14 +123,14 @@ class Wavefront:
         uz = 1.0 / math.sqrt(1.0 + tx * tx + ty * ty)
         return tx * uz, ty * uz
 
-    def _compute(self) -> WavefrontData:
-        if self.strategy != "chief_ray":
-            return self._compute_fitted()
+    def chief_reference(self):
+        """(params, R, fused_status): the `ol_wavefront_params` of the chief-ray reference
+        sphere / plane for this field and wavelength (strategy.py:176-184, 228-243), from one
+        traced chief ray."""
         t, rg = self.tracer, self.tracer.table.raygen
         hx, hy = self.field
-        # 1. chief ray alone -> reference sphere (strategy.py:176-184, 228-243).  The seven
-        # numbers of the traced chief ray come back in ONE device-to-host copy (its status
-        # word is read with the fused launch's, below) and the reference geometry is worked
+        # The seven numbers of the traced chief ray come back in ONE device-to-host copy (its
+        # status word is read with the fused launch's) and the reference geometry is worked
         # out on the host in double -- the same expressions as wavefront_device.h -- instead
         # of a one-ray kernel launch and four more read-backs
         fused_status = self.fused and hasattr(t, "defer_checks")
@@ -154,6 +163,15 @@ class Wavefront:
             t_back = t2 if t1 < 0.0 else t1
         # chief-ray OPD to the reference (pupil point (0, 0): no tilt term)
         params["opd_ref"] = opd_c - rg["n_image"] * t_back
+        return params, R, fused_status
+
+    def _compute(self) -> WavefrontData:
+        if self.strategy != "chief_ray":
+            return self._compute_fitted()
+        t = self.tracer
+        hx, hy = self.field
+        # 1. chief ray alone -> reference sphere
+        params, R, fused_status = self.chief_reference()
         # 2. the full pupil (strategy.py:190-205)
         if self.fused:  # one launch: pupil points -> OPD map + its reductions, no ray planes
             px, py = t._dev(self.distribution.x), t._dev(self.distribution.y)
@@ -274,7 +292,7 @@ class OPD(Wavefront):
     def rms(self) -> float:
         """opd.py:145-159."""
         d = self.data
-        if d.moments is not None and not self.remove_tilt:
+        if d.moments is not None and d._moments_of is d.opd:
             cnt, _s1, s2 = d.moments[9:12].tolist()  # epilogue of the fused kernel, one read-back
             if cnt == 0:
                 raise ValueError("No valid rays with non-zero intensity for RMS calculation.")
