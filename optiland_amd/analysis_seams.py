@@ -1,0 +1,325 @@
+"""The fused kernels behind the reference's OWN analysis classes.
+
+`integration.enable()` / `install()` make `Optic.trace` a launch of the fused trace; the
+reference's analyses on top of it would still pay for a record-all trace (8 planes for each
+of the S + 1 surfaces) and reduce it with a chain of backend array operations, although
+all they read is the image plane.  This module patches the methods that sit between "an
+optic" and "the arrays the analysis keeps" so that they call the kernels that were built
+for exactly that:
+
+* `SpotDiagram._generate_field_data` (analysis/spot_diagram/core.py:440-481) and
+  `EncircledEnergy._generate_field_data` (analysis/encircled_energy.py:170-197)
+  -> `ol_trace_spot` with hit planes: generate -> trace -> image-plane x, y, intensity
+  (+ the seven masked moments) in ONE kernel, three planes written instead of 8 (S + 1);
+* `ChiefRayStrategy.compute_wavefront_data` (wavefront/strategy.py:163-215)
+  -> `ol_trace_opd`: pupil points -> OPD in waves, intensity, pupil intersection points;
+* `ScalarFFTPSF._generate_pupils` / `_pad_pupils` (psf/fft.py:123-161, 203-230)
+  -> `ol_pupil_fill`: the pupil function scattered straight into the zero-padded FFT grid.
+
+Every patched method first asks whether the call is one the fused path covers -- drop-in
+active for this optic, torch backend on the HIP device without autograd, a system the
+packer accepts with device-side ray generation, unpolarised, (for the wavefront) fp64 --
+and otherwise runs the reference's own method untouched, which then still traces through
+the drop-in's `Optic.trace`.  Results are the reference's own dataclasses.
+
+Observable difference to the un-patched classes: the analysis' last trace is not recorded
+on the `Surface` objects (nothing in the reference reads that after an analysis).
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from .packer import UnsupportedSystem
+
+_ORIG: dict = {}
+STATS = {"spot": 0, "spot_fallback": 0, "ee": 0, "ee_fallback": 0, "opd": 0, "opd_fallback": 0,
+         "pupil": 0, "pupil_fallback": 0}
+
+
+def _front(optic, wavelength, need_fp64=False):
+    """(front, table) -- the stand-alone device tracer on the CURRENT packed table of
+    `optic` -- when the fused analysis kernels apply to it, else None."""
+    from . import integration as ig
+
+    comp = ig.hip_tracer_of(optic)
+    if comp is None or not comp._eligible():
+        return None
+    try:
+        front, table = comp._front_for(wavelength)
+    except UnsupportedSystem:
+        return None
+    if not table.raygen or table.polarization is not None or table.uses_polarization:
+        return None  # reference-side ray generation / polarised epilogue: not fused
+    if need_fp64 and front.dtype != torch.float64:
+        return None
+    if not hasattr(front.engine, "trace_spot"):
+        return None
+    return front, table
+
+
+def _scalar(v):
+    if isinstance(v, torch.Tensor):
+        return float(v.detach().cpu().reshape(-1)[0]) if v.numel() == 1 else None
+    try:
+        a = np.asarray(v, dtype=np.float64)
+    except (TypeError, ValueError):
+        return None
+    return float(a.reshape(-1)[0]) if a.size == 1 else None
+
+
+def _dist_arg(distribution):
+    from . import integration as ig
+
+    return distribution if isinstance(distribution, str) else ig._PupilPoints(distribution)
+
+
+def _image_hits(optic, field, wavelength, num_rays, distribution):
+    """(front, table, moments7 (host), (x, y, i)) of one fused spot launch, or None."""
+    hx, hy = _scalar(field[0]), _scalar(field[1])
+    if hx is None or hy is None:
+        return None
+    got = _front(optic, wavelength)
+    if got is None:
+        return None
+    front, table = got
+    mom, hits = front.trace_spot(hx, hy, wavelength, num_rays, _dist_arg(distribution),
+                                 hits=True)
+    return front, table, mom.cpu().numpy(), hits
+
+
+# ------------------------------------------------------------------------------- spot
+def _spot_generate_field_data(self, field, wavelength, num_rays, distribution, coordinates):
+    out = None
+    rot = False
+    got = None
+    try:
+        got = _image_hits(self.optic, field, wavelength, num_rays, distribution)
+    except UnsupportedSystem:
+        got = None
+    if got is not None:
+        front, table, mom, (x, y, inten) = got
+        s = table.surfaces[-1]
+        rot = bool(s["flags"] & 1)
+        if not (rot and coordinates == "local"):
+            if int(mom[0]) != x.numel():  # core.py:470-473: ignore rays with zero intensity
+                mask = inten > 0
+                x, y, inten = x[mask], y[mask], inten[mask]
+            if coordinates == "local":
+                # visualization/system/utils.py:17-47 with an untilted image surface:
+                # localize = translate by the (folded) origin
+                ox, oy = float(s["origin"][0]), float(s["origin"][1])
+                if ox != 0.0:
+                    x = x - ox
+                if oy != 0.0:
+                    y = y - oy
+            from optiland.analysis.spot_diagram.core import SpotData
+
+            out = SpotData(x=x, y=y, intensity=inten)
+    if out is None:
+        STATS["spot_fallback"] += 1
+        return _ORIG["spot"](self, field, wavelength, num_rays, distribution, coordinates)
+    STATS["spot"] += 1
+    return out
+
+
+def _ee_generate_field_data(self, field, wavelength, num_rays=100, distribution="hexapolar",
+                            coordinates="local"):
+    try:
+        got = _image_hits(self.optic, field, wavelength, num_rays, distribution)
+    except UnsupportedSystem:
+        got = None
+    if got is None:
+        STATS["ee_fallback"] += 1
+        return _ORIG["ee"](self, field, wavelength, num_rays, distribution, coordinates)
+    from optiland.analysis.spot_diagram.core import SpotData
+
+    _front_, _table, _mom, (x, y, inten) = got
+    STATS["ee"] += 1
+    return SpotData(x=x, y=y, intensity=inten)  # encircled_energy.py:193-197: unmasked, global
+
+
+# -------------------------------------------------------------------------- wavefront
+def _f(v) -> float:
+    if isinstance(v, torch.Tensor):
+        return float(v.detach().cpu().reshape(-1)[0])
+    return float(np.asarray(v, dtype=np.float64).reshape(-1)[0])
+
+
+def _chief_compute_wavefront_data(self, field, wavelength):
+    out = None
+    try:
+        out = _fused_wavefront(self, field, wavelength)
+    except UnsupportedSystem:
+        out = None
+    if out is None:
+        STATS["opd_fallback"] += 1
+        return _ORIG["opd"](self, field, wavelength)
+    STATS["opd"] += 1
+    return out
+
+
+def _fused_wavefront(self, field, wavelength):
+    hx, hy = _scalar(field[0]), _scalar(field[1])
+    w = _scalar(wavelength)
+    if hx is None or hy is None or w is None:
+        return None
+    if self.reference_type not in ("sphere", "plane"):
+        return None
+    got = _front(self.optic, w, need_fp64=True)
+    if got is None:
+        return None
+    front, table = got
+    rg = table.raygen
+    if not hasattr(front.engine, "trace_opd"):
+        return None
+    dist = self.distribution
+    dx, dy = getattr(dist, "x", None), getattr(dist, "y", None)
+    if dx is None or dy is None:
+        return None
+    # 1. chief ray alone (strategy.py:176-179) -- through Optic.trace_generic, i.e. the
+    # drop-in's own one-ray launch; kept on the strategy like the reference does
+    self._chief_ray = chief = self.optic.trace_generic(hx, hy, Px=0.0, Py=0.0, wavelength=w)
+    c = torch.stack([t.reshape(-1)[0] for t in (chief.x, chief.y, chief.z, chief.L, chief.M,
+                                                 chief.N, chief.opd)]).double().cpu().tolist()
+    xc, yc, zc, Lc, Mc, Nc, opd_c = c
+    n_image = _f(self.n_image)
+    # strategy.py:83-139 _correct_tilt: AngleField with the object at infinity only
+    ux = uy = 0.0
+    if rg.get("object_infinite") and int(rg.get("field_kind", 0)) == 0:
+        tx = math.tan(math.radians(hx * rg["max_field"]))
+        ty = math.tan(math.radians(hy * rg["max_field"]))
+        uz = 1.0 / math.sqrt(1.0 + tx * tx + ty * ty)
+        ux, uy = tx * uz, ty * uz
+    params = dict(xc=xc, yc=yc, zc=zc, n_image=n_image, opd_ref=0.0, ux=ux, uy=uy,
+                  half_epd=rg["EPD"] / 2.0, wavelength_um=w)
+    if self.reference_type == "plane":  # strategy.py:260-284
+        R = math.inf
+        params.update(R=0.0, nx=Lc, ny=Mc, nz=Nc)
+        t_back = 0.0
+    else:                               # strategy.py:228-243
+        R = math.sqrt(xc * xc + yc * yc + (zc - _f(self.pupil_z)) ** 2)
+        params.update(R=R)
+        a_ = Lc * Lc + Mc * Mc + Nc * Nc
+        sq = math.sqrt(max(4.0 * a_ * R * R, 0.0))
+        t1, t2 = -sq / (2.0 * a_), sq / (2.0 * a_)
+        t_back = t2 if t1 < 0.0 else t1
+    params["opd_ref"] = opd_c - n_image * t_back  # pupil point (0, 0): no tilt term
+    # 2. the full pupil: one launch, no ray planes (strategy.py:190-205)
+    px, py = front._dev(_as_input(dx)), front._dev(_as_input(dy))
+    wl, _ = front._wavelength_index(w)
+    opd, inten, pupil, mom = front.engine.trace_opd(
+        params, px, py, wl, field=(hx, hy), vig=front._vig_scalar(hx, hy), want_pupil=True)
+    from optiland.wavefront.wavefront_data import WavefrontData
+
+    data = WavefrontData(pupil_x=pupil[0], pupil_y=pupil[1], pupil_z=pupil[2], opd=opd,
+                         intensity=inten, radius=R)
+    data._hip_fused = True  # lets the FFT-PSF seam recognise device data it can scatter
+    return data
+
+
+def _as_input(v):
+    if isinstance(v, torch.Tensor):
+        return v.detach()
+    return np.asarray(v, dtype=np.float64)
+
+
+# ---------------------------------------------------------------------------- FFT PSF
+def _fft_generate_pupils(self):
+    """psf/fft.py:123-161 with `ol_pupil_fill`: the samples go straight into the zero-padded
+    grid; the list the reference keeps (`self.pupils`, n x n each) are views of it."""
+    import optiland.backend as be
+
+    out = None
+    try:
+        out = _fused_pupils(self, be)
+    except UnsupportedSystem:
+        out = None
+    if out is None:
+        STATS["pupil_fallback"] += 1
+        self.__dict__.pop("_hip_padded", None)
+        return _ORIG["pupils"](self)
+    STATS["pupil"] += 1
+    return out
+
+
+def _fused_pupils(self, be):
+    n, gsz = int(self.num_rays), int(self.grid_size)
+    field = self.fields[0]
+    datas = [self.get_data(field, wl) for wl in self.wavelengths]
+    if not datas or any(not getattr(d, "_hip_fused", False) for d in datas):
+        return None
+    got = _front(self.optic, _f(getattr(self.wavelengths[0], "value", self.wavelengths[0])),
+                 need_fp64=True)
+    if got is None:
+        return None
+    front, _table = got
+    if not hasattr(front.engine, "pupil_fill"):
+        return None
+    # the disc mask in the reference's own arithmetic (fft.py:140-144)
+    x = be.linspace(-1, 1, n)
+    x, y = be.meshgrid(x, x)
+    cells = torch.nonzero((x.ravel() ** 2 + y.ravel() ** 2) <= 1).reshape(-1)
+    dev = datas[0].opd.device
+    cell = cells.to(device=dev, dtype=torch.int32)
+    before = (gsz - n) // 2
+    padded, views = [], []
+    for d in datas:
+        if d.opd.numel() != cell.numel() or d.opd.dtype != torch.float64:
+            return None
+        grid = front.engine.pupil_fill(d.opd.contiguous(), d.intensity.contiguous(), cell, n, gsz)
+        padded.append(grid)
+        views.append(grid[before:before + n, before:before + n])
+    self._hip_padded = (padded, views)
+    return views
+
+
+def _fft_pad_pupils(self):
+    """psf/fft.py:203-230: the grids `ol_pupil_fill` wrote ARE the padded pupils -- as long
+    as `self.pupils` still holds the views handed out by `_generate_pupils`."""
+    kept = self.__dict__.get("_hip_padded")
+    if kept is not None and len(kept[1]) == len(self.pupils) \
+            and all(a is b for a, b in zip(kept[1], self.pupils)):
+        return list(kept[0])
+    return _ORIG["pad"](self)
+
+
+# --------------------------------------------------------------------------- (de)activate
+def enable():
+    """Patch the reference classes (idempotent).  Safe class-wide: each call falls back to
+    the original method unless the optic it concerns is served by the drop-in."""
+    if _ORIG:
+        return
+    from optiland.analysis.encircled_energy import EncircledEnergy
+    from optiland.analysis.spot_diagram.core import SpotDiagram
+    from optiland.psf.fft import ScalarFFTPSF
+    from optiland.wavefront.strategy import ChiefRayStrategy
+
+    _ORIG.update(spot=SpotDiagram._generate_field_data,
+                 ee=EncircledEnergy._generate_field_data,
+                 opd=ChiefRayStrategy.compute_wavefront_data,
+                 pupils=ScalarFFTPSF._generate_pupils, pad=ScalarFFTPSF._pad_pupils)
+    SpotDiagram._generate_field_data = _spot_generate_field_data
+    EncircledEnergy._generate_field_data = _ee_generate_field_data
+    ChiefRayStrategy.compute_wavefront_data = _chief_compute_wavefront_data
+    ScalarFFTPSF._generate_pupils = _fft_generate_pupils
+    ScalarFFTPSF._pad_pupils = _fft_pad_pupils
+
+
+def disable():
+    if not _ORIG:
+        return
+    from optiland.analysis.encircled_energy import EncircledEnergy
+    from optiland.analysis.spot_diagram.core import SpotDiagram
+    from optiland.psf.fft import ScalarFFTPSF
+    from optiland.wavefront.strategy import ChiefRayStrategy
+
+    SpotDiagram._generate_field_data = _ORIG["spot"]
+    EncircledEnergy._generate_field_data = _ORIG["ee"]
+    ChiefRayStrategy.compute_wavefront_data = _ORIG["opd"]
+    ScalarFFTPSF._generate_pupils = _ORIG["pupils"]
+    ScalarFFTPSF._pad_pupils = _ORIG["pad"]
+    _ORIG.clear()

@@ -22,6 +22,61 @@
 #define OL_DEV __device__ __forceinline__
 #endif
 
+// Table memory as the kernels address it.  In device code every pointer into the surface
+// table (hot / cold / optics rows, coefficient blocks) is a CONSTANT-address-space pointer
+// (amdgcn address space 4): loads through it are scalar loads (s_load_dword*, the K$ path)
+// by construction -- not by an alias analysis that has to prove the record stores cannot
+// clobber the table -- and, unlike loads through a `__restrict__` kernel argument, they stay
+// scalar loads when the pointer value has been passed through `refresh()` below.  On the
+// host (the argument marshalling of the launchers; tests/hostmath) it is a plain pointer.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OL_CONST_AS __attribute__((address_space(4)))
+#else
+#define OL_CONST_AS
+#endif
+
+namespace ol {
+template <typename X>
+using cptr = const OL_CONST_AS X*;
+
+// global -> constant address space (the same addresses on amdgcn)
+template <typename X>
+OL_DEV cptr<X> as_const(const X* p) {
+  return (cptr<X>)p;
+}
+
+// `refresh(p)`: the same pointer, but opaque to the optimiser from here on.  Loads through
+// the returned value cannot be merged with, or hoisted above, anything before this point,
+// so a table field is fetched WHERE it is used (a scalar load that hits the K$) instead of
+// once in the prologue and then kept live across the whole surface body -- in the
+// Newton-Raphson and fp64 kernels those long-lived scalars overflowed the ~100 SGPRs a
+// wave has and were spilled to VGPR lanes (v_writelane / v_readlane: VECTOR instructions,
+// in kernels that are bound by vector issue).  Costs nothing at run time: the asm is empty.
+template <typename P>
+OL_DEV P refresh(P p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+s"(p));
+#else
+  asm volatile("" : "+r"(p));
+#endif
+  return p;
+}
+
+// refresh(p) that is additionally ORDERED AFTER the computation of `acc` (the asm takes it
+// as an in/out operand): loads through the result cannot be issued before `acc` exists.
+// Used to meter a long coefficient stream -- chunk k + 2 is requested when chunk k has been
+// consumed -- so that only a bounded window of it occupies SGPRs (CoeffStream below).
+template <typename P, typename A>
+OL_DEV P refresh_after(P p, A& acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+s"(p), "+v"(acc));
+#else
+  asm volatile("" : "+r"(p), "+x"(acc));
+#endif
+  return p;
+}
+}  // namespace ol
+
 namespace ol {
 
 enum : int {
@@ -93,7 +148,7 @@ struct DevSurfCold {
 // the cold block.
 template <typename T>
 struct DevSurf : DevSurfHot<T> {
-  const DevSurfCold<T>* cold;
+  cptr<DevSurfCold<T>> cold;
 };
 
 template <typename T>
@@ -104,6 +159,77 @@ struct DevOptics {
   T nn;      // n2 / n1 (Fresnel: jones.py:95)
   T absorb;  // 4 pi k1 / lambda * 1e3, 0 => skip
   T pad[3];
+};
+
+// Field-wise copies out of the constant address space (a struct assignment would have to
+// bind a generic reference to constant-address-space memory).
+template <typename T>
+OL_DEV DevSurfHot<T> load_hot(cptr<DevSurfHot<T>> p) {
+  DevSurfHot<T> h;
+  h.geom = p->geom;
+  h.interaction = p->interaction;
+  h.aperture_kind = p->aperture_kind;
+  h.coating_kind = p->coating_kind;
+  h.flags = p->flags;
+  h.coeff_off = p->coeff_off;
+  h.n_coeff = p->n_coeff;
+  h.max_iter = p->max_iter;
+  h.cv = p->cv;
+  h.kp1 = p->kp1;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    h.rel_off[k] = p->rel_off[k];
+    h.origin[k] = p->origin[k];
+  }
+  return h;
+}
+
+template <typename T>
+OL_DEV DevOptics<T> load_optics(cptr<DevOptics<T>> p) {
+  DevOptics<T> o;
+  o.n1 = p->n1;
+  o.n2 = p->n2;
+  o.u = p->u;
+  o.nn = p->nn;
+  o.absorb = p->absorb;
+  return o;
+}
+
+// How a kernel hands one surface's table rows to surface_step() (surface_math.h).
+//  * SurfLoaded: the hot block and the optics row were loaded ONCE, by value, and stay in
+//    SGPRs for the whole surface body -- the lean (conic-only) kernels, where that is a
+//    single s_load_dwordx16 prefetched one surface ahead and nothing spills;
+//  * SurfFetched: three table pointers; every phase of the surface body (frame change,
+//    intersection, each Newton iteration, interaction, record) re-reads the few fields it
+//    needs through refresh() -- the Newton-Raphson kernels, which are short of SGPRs.
+template <typename T>
+struct SurfLoaded {
+  const DevSurf<T>& s;
+  const DevOptics<T>& o;
+  OL_DEV const DevSurf<T>& surf() const { return s; }
+  OL_DEV const DevOptics<T>& optics() const { return o; }
+};
+
+template <typename T>
+struct SurfFetched {
+  cptr<DevSurfHot<T>> hot;
+  cptr<DevSurfCold<T>> cold;
+  cptr<DevOptics<T>> opt;
+  OL_DEV DevSurf<T> surf() const {
+    DevSurf<T> S;
+#ifdef OL_EXP_NOREFRESH
+    static_cast<DevSurfHot<T>&>(S) = load_hot<T>(hot);
+    S.cold = cold;
+    return S;
+  }
+  OL_DEV DevOptics<T> optics() const { return load_optics<T>(opt); }
+#else
+    static_cast<DevSurfHot<T>&>(S) = load_hot<T>(refresh(hot));
+    S.cold = refresh(cold);
+    return S;
+  }
+  OL_DEV DevOptics<T> optics() const { return load_optics<T>(refresh(opt)); }
+#endif
 };
 
 // Zernike block inside the coefficient array: one LEVEL per azimuthal order m that has a

@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "device_table.h"
 #include "trace_launch.h"
 
 namespace ol {
@@ -23,22 +24,17 @@ OL_DEV double tan_deg<double>(double deg) {
   return tan(deg * 0.017453292519943295);
 }
 
-// launch-invariant scalars, converted to the working precision once
+// RaygenConsts (trace_launch.h) read out of the kernarg segment, field by field (scalar loads)
 template <typename T>
-struct RaygenConsts {
-  T EPL, EPD, maxf, off_epl, z_inf, z_fin, epl_z, tele_dz, apod_a, apod_b;
-  int apod_kind;
-  bool infinite, height, linear, telecentric;
-  OL_DEV explicit RaygenConsts(const RaygenDev& p)
-      : EPL((T)p.EPL), EPD((T)p.EPD), maxf((T)p.max_field), off_epl((T)(p.offset + p.EPL)),
-        z_inf((T)(p.z_first - p.offset)), z_fin((T)p.z_first), epl_z((T)(p.EPL - p.z_first)),
-        tele_dz((T)p.tele_dz), apod_a((T)p.apod_a), apod_b((T)p.apod_b),
-        apod_kind(p.apod_kind), infinite(p.object_infinite != 0),
-        // the field quantity is a POSITION on the object for object-height fields and
-        // for paraxial-image-height fields with a finite object; otherwise a slope
-        height(p.field_kind == 1 || (p.field_kind == 2 && p.object_infinite == 0)),
-        linear(p.field_kind != 0), telecentric(p.tele_dz > 0.0) {}
-};
+OL_DEV RaygenConsts<T> load_consts(cptr<RaygenConsts<T>> p) {
+  RaygenConsts<T> c;
+  c.EPL = p->EPL; c.EPD = p->EPD; c.maxf = p->maxf; c.off_epl = p->off_epl;
+  c.z_inf = p->z_inf; c.z_fin = p->z_fin; c.epl_z = p->epl_z; c.tele_dz = p->tele_dz;
+  c.apod_a = p->apod_a; c.apod_b = p->apod_b; c.apod_kind = p->apod_kind;
+  c.infinite = p->infinite; c.height = p->height; c.linear = p->linear;
+  c.telecentric = p->telecentric;
+  return c;
+}
 
 // initial intensity from the pupil apodization (ray_generator.py:81-85,
 // optiland/apodization/*.py); launch-uniform switch

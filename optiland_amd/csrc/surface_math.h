@@ -285,7 +285,7 @@ OL_DEV void conic_normal(typename Math<V>::scalar cv,
 // --------------------------------------------------------------------------
 // even_asphere.py:93-140 (Horner in r^2 instead of r2**(i+1))
 template <typename T>
-OL_DEV void even_asphere_eval(const DevSurf<T>& s, const T* __restrict__ c,
+OL_DEV void even_asphere_eval(const DevSurf<T>& s, cptr<T> c,
                                                   T x, T y, T& sag, T& fx, T& fy) {
   using m = Math<T>;
   T r2 = m::fma(x, x, y * y);
@@ -308,7 +308,7 @@ OL_DEV void even_asphere_eval(const DevSurf<T>& s, const T* __restrict__ c,
 // odd_asphere.py:86-143: sum C_i r^(i+1); gradient terms (i+1) x C_i r^(i-1),
 // non-finite terms (i == 0 at r == 0) zeroed.
 template <typename T>
-OL_DEV void odd_asphere_eval(const DevSurf<T>& s, const T* __restrict__ c,
+OL_DEV void odd_asphere_eval(const DevSurf<T>& s, cptr<T> c,
                                                  T x, T y, T& sag, T& fx, T& fy) {
   using m = Math<T>;
   T r2 = m::fma(x, x, y * y);
@@ -333,7 +333,7 @@ OL_DEV void odd_asphere_eval(const DevSurf<T>& s, const T* __restrict__ c,
 
 // polynomial.py:105-155: sum c[i][j] x^i y^j (row i = x power), nested Horner.
 template <typename T>
-OL_DEV void polynomial_eval(const DevSurf<T>& s, const T* __restrict__ c,
+OL_DEV void polynomial_eval(const DevSurf<T>& s, cptr<T> c,
                                                 T x, T y, T& sag, T& fx, T& fy) {
   using m = Math<T>;
   T r2 = m::fma(x, x, y * y);
@@ -388,8 +388,8 @@ OL_DEV void polynomial_eval(const DevSurf<T>& s, const T* __restrict__ c,
 template <typename T>
 using vec2 = T __attribute__((ext_vector_type(2)));
 
-OL_DEV int slot_int(const float* p) { return hw::float_bits(*p); }
-OL_DEV int slot_int(const double* p) { return (int)hw::double_bits(*p); }
+OL_DEV int slot_int(cptr<float> p) { return hw::float_bits(*p); }
+OL_DEV int slot_int(cptr<double> p) { return (int)hw::double_bits(*p); }
 
 // conic base, normalised coordinates and the range check shared by both series forms
 template <typename T>
@@ -431,7 +431,7 @@ OL_DEV void zernike_finish(const DevSurf<T>& s, T xn, T yn, T u, T zsum, T gx, T
 }
 
 template <typename T>
-OL_DEV void zernike_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
+OL_DEV void zernike_eval(const DevSurf<T>& s, cptr<T> c, T x,
                                              T y, T& sag, T& fx, T& fy, uint32_t& status) {
   using m = Math<T>;
   using V2 = vec2<T>;
@@ -443,7 +443,7 @@ OL_DEV void zernike_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
   // H = (A_m, B_m) of the current order, Hp of the one below (weighted by m = 0 at order 0)
   V2 H = {T(1), T(0)}, Hp = {T(0), T(0)};
   int mcur = 0;
-  const T* p = c;
+  cptr<T> p = c;
   for (int lv = 0; lv < s.n_coeff; ++lv) {
     const int mg = slot_int(p), K = slot_int(p + 1);
     p += kZernLevelHeader;
@@ -457,7 +457,7 @@ OL_DEV void zernike_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
     // included), b = coefficients of the NORMAL (the reference forms it without the
     // constant, zernike.py:234-240), d = (k + 1) b_{k+1} (dQn/du)
     // (K >= 1: the chains start from the highest coefficients instead of from zero)
-    const T* e = p + kZernLevelStride * (K - 1);
+    cptr<T> e = p + kZernLevelStride * (K - 1);
     V2 qs = {e[0], e[1]}, qn = {e[2], e[3]}, dq = {e[4], e[5]};
     for (int k = K - 2; k >= 0; --k) {
       e -= kZernLevelStride;
@@ -495,58 +495,170 @@ OL_DEV void zernike_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
 // degree 4 the allocator spilled ~17 SGPRs to VGPR lanes (v_writelane / v_readlane, vector
 // instructions) around every evaluation; split, the degree-4 block is 36 vector
 // instructions and no spill.  A/B knob, tools/build_variants.py.
+// OL_ZERN_MONO_SPLIT (default on): the coefficient stream of an unrolled instance is read
+// through a WINDOW (CoeffWindow): chunks of 16 dwords, chunk k + OL_ZERN_MONO_AHEAD requested
+// when the Horner chain starts to consume chunk k (the request is ordered after the chain's
+// accumulator, device_table.h: refresh_after).  Without it the scheduler hoists every scalar
+// load of the block to the top of the evaluation -- 35 (degree 4) to 70 (degree 6)
+// coefficient values, twice as many SGPRs in fp64, on top of what the kernel holds anyway --
+// and the allocator spills scalars to VGPR lanes (v_writelane / v_readlane: vector
+// instructions) around every evaluation.  A/B knob, tools/build_variants.py.
 #ifndef OL_ZERN_MONO_SPLIT
 #define OL_ZERN_MONO_SPLIT 1
 #endif
-#if OL_ZERN_MONO_SPLIT && defined(__HIP_DEVICE_COMPILE__)
-#define OL_ZERN_MONO_PHASE_FENCE asm volatile("" ::: "memory");
-#else
-#define OL_ZERN_MONO_PHASE_FENCE
+#ifndef OL_ZERN_MONO_AHEAD
+#define OL_ZERN_MONO_AHEAD 1
+#endif
+#ifndef OL_ZERN_MONO_CHUNK
+#define OL_ZERN_MONO_CHUNK 8  // dwords (SGPRs) per chunk
 #endif
 // OL_ZERN_MONO_FIXED = 0: no unrolled instances, every degree runs the loops (A/B knob)
 #ifndef OL_ZERN_MONO_FIXED
 #define OL_ZERN_MONO_FIXED 1
 #endif
-#define OL_ZERN_MONO_BODY(UNROLL)                                              \
+
+// Sequential reader of TOTAL coefficients for FULLY UNROLLED code: the element index `e`
+// of every call is a constant after unrolling, so the chunk table is scalar-replaced and the
+// request branches fold away.
+template <typename T, int TOTAL, bool WINDOWED>
+struct CoeffWindow {
+  static constexpr int CH = 4 * OL_ZERN_MONO_CHUNK / sizeof(T);  // elements per chunk
+  static constexpr int NCH = (TOTAL + CH - 1) / CH;
+  cptr<T> base;
+  cptr<T> chunk[NCH];
+  OL_DEV explicit CoeffWindow(cptr<T> c) : base(c) {
+    if constexpr (WINDOWED) {
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) chunk[j] = c + j * CH;
+#pragma unroll
+      for (int j = 0; j < NCH && j < OL_ZERN_MONO_AHEAD; ++j) chunk[j] = refresh(c + j * CH);
+    }
+  }
+  // element e; `acc` = the value the consuming chain has reached (orders the next request)
+  template <typename A>
+  OL_DEV T get(int e, A& acc) {
+    if constexpr (WINDOWED) {
+      const int j = e / CH, k = e % CH;
+      if (k == 0 && j + OL_ZERN_MONO_AHEAD < NCH)
+        chunk[j + OL_ZERN_MONO_AHEAD] =
+            refresh_after(base + (j + OL_ZERN_MONO_AHEAD) * CH, acc);
+      return chunk[j][k];
+    } else {
+      return base[e];
+    }
+  }
+};
+
+#define OL_ZERN_MONO_BODY(UNROLL, STREAM)                                      \
   using m = Math<T>;                                                           \
   using V2 = vec2<T>;                                                          \
-  const T* p = c;                                                              \
+  int e = 0;                                                                   \
   T P = T(0);                                                                  \
   UNROLL for (int i = N; i >= 0; --i) {                                        \
-    T q = *p++;                                                                \
-    UNROLL for (int j = N - i - 1; j >= 0; --j) q = m::fma(q, yn, *p++);       \
+    T q = STREAM.get(e, P);                                                    \
+    ++e;                                                                       \
+    UNROLL for (int j = N - i - 1; j >= 0; --j) {                              \
+      const T cj = STREAM.get(e, q);                                           \
+      ++e;                                                                     \
+      q = m::fma(q, yn, cj);                                                   \
+    }                                                                          \
     P = i == N ? q : m::fma(P, xn, q);                                         \
   }                                                                            \
-  OL_ZERN_MONO_PHASE_FENCE                                                     \
   const V2 xx = {xn, xn}, yy = {yn, yn};                                       \
   V2 G = {T(0), T(0)};                                                         \
+  T tie = P;                                                                   \
   UNROLL for (int i = N - 1; i >= 0; --i) {                                    \
-    V2 q = {p[0], p[1]};                                                       \
-    p += 2;                                                                    \
+    V2 q;                                                                      \
+    q.x = STREAM.get(e, tie);                                                  \
+    q.y = STREAM.get(e + 1, tie);                                              \
+    e += 2;                                                                    \
     UNROLL for (int j = N - 2 - i; j >= 0; --j) {                              \
-      const V2 cj = {p[0], p[1]};                                              \
-      p += 2;                                                                  \
+      tie = q.x;                                                               \
+      V2 cj;                                                                   \
+      cj.x = STREAM.get(e, tie);                                               \
+      cj.y = STREAM.get(e + 1, tie);                                           \
+      e += 2;                                                                  \
+      q.x = tie;                                                               \
       q = q * yy + cj;                                                         \
     }                                                                          \
     G = i == N - 1 ? q : G * xx + q;                                           \
+    tie = G.x;                                                                 \
   }                                                                            \
+  P = tie == tie ? P : P; /* (tie is only an ordering handle) */               \
   zsum = P;                                                                    \
   gx = G.x;                                                                    \
   gy = G.y;
 
 template <typename T, int N>
-OL_DEV void zernike_mono_fixed(const T* __restrict__ c, T xn, T yn, T& zsum, T& gx, T& gy) {
-  OL_ZERN_MONO_BODY(_Pragma("unroll"))
-}
-template <typename T>
-OL_DEV void zernike_mono_loop(const T* __restrict__ c, int N, T xn, T yn, T& zsum, T& gx, T& gy) {
-  OL_ZERN_MONO_BODY()
+OL_DEV void zernike_mono_fixed(cptr<T> c, T xn, T yn, T& zsum, T& gx, T& gy) {
+  constexpr int TOTAL = (N + 1) * (N + 2) / 2 + N * (N + 1);
+  CoeffWindow<T, TOTAL, OL_ZERN_MONO_SPLIT != 0> stream(c);
+  OL_ZERN_MONO_BODY(_Pragma("unroll"), stream)
 }
 #undef OL_ZERN_MONO_BODY
-#undef OL_ZERN_MONO_PHASE_FENCE
+
+// Degrees without an unrolled instance: the same nested Horner, one ROW per loop trip.  A
+// row's coefficients (at most OL_ZERN_MONO_MAX_DEG + 1 values, or that many pairs) are
+// consecutive in the stream and are requested together -- the row length is wave-uniform, so
+// each length has its own unrolled chain -- and at most one row occupies SGPRs.
+constexpr int kZernMonoMaxRow = 9;  // radial order <= 8 (capi.hip: kZernMonoMaxOrder)
+
+template <typename T, int LEN>
+OL_DEV T mono_row(cptr<T> p, T yn) {
+  using m = Math<T>;
+  T q = p[0];
+#pragma unroll
+  for (int j = 1; j < LEN; ++j) q = m::fma(q, yn, p[j]);
+  return q;
+}
+template <typename T, int LEN>
+OL_DEV vec2<T> mono_row2(cptr<T> p, vec2<T> yy) {
+  vec2<T> q = {p[0], p[1]};
+#pragma unroll
+  for (int j = 1; j < LEN; ++j) {
+    const vec2<T> cj = {p[2 * j], p[2 * j + 1]};
+    q = q * yy + cj;
+  }
+  return q;
+}
 
 template <typename T>
-OL_DEV void zernike_mono_eval(const DevSurf<T>& s, const T* __restrict__ c, T x, T y, T& sag,
+OL_DEV void zernike_mono_loop(cptr<T> c, int N, T xn, T yn, T& zsum, T& gx, T& gy) {
+  using m = Math<T>;
+  using V2 = vec2<T>;
+  cptr<T> p = c;
+  T P = T(0);
+  for (int len = 1; len <= N + 1; ++len) {  // rows by descending power of x
+    T q;
+    switch (len) {
+#define OL_ROW(L) case L: q = mono_row<T, L>(p, yn); break;
+      OL_ROW(1) OL_ROW(2) OL_ROW(3) OL_ROW(4) OL_ROW(5) OL_ROW(6) OL_ROW(7) OL_ROW(8)
+#undef OL_ROW
+      default: q = mono_row<T, kZernMonoMaxRow>(p, yn); break;
+    }
+    p = refresh(p + len);
+    P = len == 1 ? q : m::fma(P, xn, q);
+  }
+  const V2 xx = {xn, xn}, yy = {yn, yn};
+  V2 G = {T(0), T(0)};
+  for (int len = 1; len <= N; ++len) {
+    V2 q;
+    switch (len) {
+#define OL_ROW(L) case L: q = mono_row2<T, L>(p, yy); break;
+      OL_ROW(1) OL_ROW(2) OL_ROW(3) OL_ROW(4) OL_ROW(5) OL_ROW(6) OL_ROW(7)
+#undef OL_ROW
+      default: q = mono_row2<T, kZernMonoMaxRow - 1>(p, yy); break;
+    }
+    p = refresh(p + 2 * len);
+    G = len == 1 ? q : G * xx + q;
+  }
+  zsum = P;
+  gx = G.x;
+  gy = G.y;
+}
+
+template <typename T>
+OL_DEV void zernike_mono_eval(const DevSurf<T>& s, cptr<T> c, T x, T y, T& sag,
                               T& fx, T& fy, uint32_t& status) {
   T xn, yn, u, zsum, gx, gy;
   zernike_begin(s, x, y, sag, fx, fy, xn, yn, u, status);
@@ -554,8 +666,6 @@ OL_DEV void zernike_mono_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
     case 2: zernike_mono_fixed<T, 2>(c, xn, yn, zsum, gx, gy); break;
     case 3: zernike_mono_fixed<T, 3>(c, xn, yn, zsum, gx, gy); break;
     case 4: zernike_mono_fixed<T, 4>(c, xn, yn, zsum, gx, gy); break;
-    case 5: zernike_mono_fixed<T, 5>(c, xn, yn, zsum, gx, gy); break;
-    case 6: zernike_mono_fixed<T, 6>(c, xn, yn, zsum, gx, gy); break;
     default: zernike_mono_loop<T>(c, s.n_coeff, xn, yn, zsum, gx, gy); break;
   }
   zernike_finish(s, xn, yn, u, zsum, gx, gy, sag, fx, fy);
@@ -567,7 +677,7 @@ OL_DEV void zernike_mono_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
 // reference the derivative is taken w.r.t. the NORMALISED coordinate and is not
 // divided by norm_x / norm_y (chebyshev.py:176-186).
 template <typename T>
-OL_DEV void chebyshev_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
+OL_DEV void chebyshev_eval(const DevSurf<T>& s, cptr<T> c, T x,
                                                T y, T& sag, T& fx, T& fy, uint32_t& status) {
   using m = Math<T>;
   T r2 = m::fma(x, x, y * y);
@@ -580,7 +690,7 @@ OL_DEV void chebyshev_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
   if (m::abs(xn) > T(1) || m::abs(yn) > T(1)) status |= 0x4u;  // OL_STATUS_CHEBYSHEV_RANGE
   const int cols = s.cold->poly_cols;
   const int rows = cols > 0 ? s.n_coeff / cols : 0;
-  const T* grid = c + 2;
+  cptr<T> grid = c + 2;
   // Ti, Ui1 = T_i(xn), U_{i-1}(xn)
   T Ti = T(1), Tim = T(0), Ui1 = T(0), Ui2 = T(0);
   T S = T(0), Sx = T(0), Sy = T(0);
@@ -611,7 +721,7 @@ OL_DEV void chebyshev_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
 
 // biconic.py:69-158: z = zx(x) + zy(y), each a conic profile; clamps kept.
 template <typename T>
-OL_DEV void biconic_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
+OL_DEV void biconic_eval(const DevSurf<T>& s, cptr<T> c, T x,
                                              T y, T& sag, T& fx, T& fy) {
   using m = Math<T>;
   const T cx = s.cv, kx1 = s.kp1, cy = c[0], ky1 = c[1];
@@ -640,11 +750,11 @@ OL_DEV void biconic_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
 // axis parallel to Y at distance R_rot.  Invalid domain ((R - z_y)^2 < x^2): sag is
 // NaN and the reference's normal is (0, 0, -1), i.e. zero gradient.
 template <typename T>
-OL_DEV void toroidal_eval(const DevSurf<T>& s, const T* __restrict__ c, T x,
+OL_DEV void toroidal_eval(const DevSurf<T>& s, cptr<T> c, T x,
                                               T y, T& sag, T& fx, T& fy) {
   using m = Math<T>;
   const T R = c[0], invR = c[1], k1 = c[2], cyz = c[3];
-  const T* a = c + 4;
+  cptr<T> a = c + 4;
   const T y2 = y * y;
   const T lim = m::guard();
   T zy = T(0), dzy = T(0);
@@ -696,7 +806,7 @@ constexpr int kNrZernike = 3;    // Zernike surfaces only (level form and one-po
 constexpr int kNrEvenAsphere = 4;  // even aspheres only
 
 template <int NR = kNrGeneric, typename T>
-OL_DEV void nr_eval(const DevSurf<T>& s, const T* __restrict__ c, T x, T y,
+OL_DEV void nr_eval(const DevSurf<T>& s, cptr<T> c, T x, T y,
                                         T& sag, T& fx, T& fy, uint32_t& status) {
   if constexpr (NR == kNrZernike) {
     if (s.geom == kGeomZernikeMono) zernike_mono_eval(s, c, x, y, sag, fx, fy, status);
@@ -744,7 +854,7 @@ struct NewtonRay {
 };
 
 template <int NR = kNrGeneric, typename T>
-OL_DEV void newton_iterate(const DevSurf<T>& s, const T* __restrict__ c,
+OL_DEV void newton_iterate(const DevSurf<T>& s, cptr<T> c,
                                                NewtonRay<T>& q, T L, T M, T N, int it,
                                                uint32_t& status) {
   using m = Math<T>;
@@ -788,7 +898,7 @@ __device__ __forceinline__ int nth_set_bit(uint64_t mask, int rank) {
 }
 
 template <typename T, int RPT>
-__device__ __forceinline__ void newton_compacted(const DevSurf<T>& s, const T* __restrict__ c,
+__device__ __forceinline__ void newton_compacted(const DevSurf<T>& s, cptr<T> c,
                                                  NewtonRay<T> (&q)[RPT], const Ray<T> (&r)[RPT],
                                                  const uint64_t (&ballots)[RPT], int total,
                                                  int it_start, uint32_t& status) {
@@ -857,7 +967,7 @@ __device__ __forceinline__ void newton_compacted(const DevSurf<T>& s, const T* _
 // closed polygon (see oracle/trace_oracle.c:polygon_contains, checked against
 // matplotlib itself); vertices x0, y0, x1, y1, ... in the coefficient buffer.
 template <typename T>
-OL_DEV bool polygon_contains(const T* __restrict__ v, int nv, T tx, T ty) {
+OL_DEV bool polygon_contains(cptr<T> v, int nv, T tx, T ty) {
   if (!(tx - tx == T(0) && ty - ty == T(0))) return false;  // non-finite points are outside
   bool inside = false;
   T x0 = v[0], y0 = v[1];
@@ -880,8 +990,8 @@ OL_DEV bool polygon_contains(const T* __restrict__ v, int nv, T tx, T ty) {
 // the host routes systems with polygon apertures there; in the lean conic-only kernels
 // it cost 12 VGPRs (46 -> 58) for a case that almost never occurs
 template <typename T, bool FULL>
-OL_DEV bool leaf_contains(int kind, const T* __restrict__ ap,
-                                              const T* __restrict__ coeffs, T x, T y) {
+OL_DEV bool leaf_contains(int kind, cptr<T> ap,
+                                              cptr<T> coeffs, T x, T y) {
   using m = Math<T>;
   if constexpr (FULL) {
     if (kind == kApPolygon) return polygon_contains<T>(coeffs + (int)ap[0], (int)ap[1], x, y);
@@ -912,10 +1022,10 @@ OL_DEV bool leaf_contains(int kind, const T* __restrict__ ap,
 // (depth <= 16 checked on the host).  Token stream and op codes are wave-uniform.
 template <typename T, bool FULL>
 OL_DEV bool aperture_contains(const DevSurf<T>& s,
-                                                  const T* __restrict__ coeffs, T x, T y) {
+                                                  cptr<T> coeffs, T x, T y) {
   if (s.aperture_kind != kApComposite)
     return leaf_contains<T, FULL>(s.aperture_kind, s.cold->ap, coeffs, x, y);
-  const T* tok = coeffs + s.cold->ap_off;
+  cptr<T> tok = coeffs + s.cold->ap_off;
   uint32_t stack = 0;  // bit 0 = top of stack
   for (int i = 0; i < s.cold->ap_len; ++i, tok += kApTokenLen) {
     const int op = (int)tok[0];
@@ -987,7 +1097,7 @@ OL_DEV PolBasis<T> pol_basis(T k0x, T k0y, T k0z, T k1x, T k1y, T k1z, T nx,
 // jones.py:120-181 (polarizer: J = u_out u_in^T) and jones.py:331-393 (retarder:
 // J = cos(d/2) I - i sin(d/2) (2 u u^T - I)), u = the axis projected on (s, p).
 template <typename T>
-OL_DEV Jones<T> axis_jones(const PolBasis<T>& b, const T* __restrict__ axis,
+OL_DEV Jones<T> axis_jones(const PolBasis<T>& b, cptr<T> axis,
                                                bool retarder, T rc, T rs) {
   using m = Math<T>;
   const T ax = axis[0], ay = axis[1], az = axis[2];
@@ -1131,7 +1241,7 @@ OL_DEV void into_local_frame(const DevSurf<typename Math<V>::scalar>& s,
   if (from_global) {
     const T ox = s.origin[0], oy = s.origin[1], oz = s.origin[2];
     if (s.flags & kSurfRotated) {
-      const T* R = s.cold->rot;
+      cptr<T> R = s.cold->rot;
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         V x = r[k].x - ox, y = r[k].y - oy, z = r[k].z - oz;
@@ -1152,7 +1262,7 @@ OL_DEV void into_local_frame(const DevSurf<typename Math<V>::scalar>& s,
       }
     }
   } else if (s.flags & kSurfRelRotated) {
-    const T* R = s.cold->rel_rot;
+    cptr<T> R = s.cold->rel_rot;
     const T ox = s.rel_off[0], oy = s.rel_off[1], oz = s.rel_off[2];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -1180,7 +1290,7 @@ OL_DEV void into_local_frame(const DevSurf<typename Math<V>::scalar>& s,
 // lane-wise aperture test: the scalar predicate per ray of the pack
 template <typename V, bool FULL>
 OL_DEV typename Math<V>::mask aperture_mask(
-    const DevSurf<typename Math<V>::scalar>& s, const typename Math<V>::scalar* __restrict__ coeffs,
+    const DevSurf<typename Math<V>::scalar>& s, cptr<typename Math<V>::scalar> coeffs,
     V x, V y) {
   if constexpr (Math<V>::lanes == 1) {
     return aperture_contains<typename Math<V>::scalar, FULL>(s, coeffs, x, y);
@@ -1193,7 +1303,7 @@ OL_DEV typename Math<V>::mask aperture_mask(
 template <typename V, int RPT, int POLK, bool FULL>
 OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
                                          const DevOptics<typename Math<V>::scalar>& o,
-                                         const typename Math<V>::scalar* __restrict__ coeffs,
+                                         cptr<typename Math<V>::scalar> coeffs,
                                          const V (&t)[RPT], const V (&nx)[RPT], const V (&ny)[RPT],
                                          const V (&nz)[RPT], Ray<V> (&r)[RPT],
                                          Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
@@ -1344,21 +1454,25 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
 // NR: 0 = the surface range holds no Newton-Raphson geometry (lean kernel: none of
 // that code, or its registers, is compiled in), 1 = Newton loop, 2 = Newton loop
 // with wavefront straggler compaction.
-template <typename V, int RPT, int POLK, int NR>
-OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
-                                             const DevOptics<typename Math<V>::scalar>& o,
-                                             const typename Math<V>::scalar* __restrict__ coeffs,
-                                             bool from_global, Ray<V> (&r)[RPT],
-                                             Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
-                                             uint32_t& status, bool& prt_fresh) {
+// H: SurfLoaded<T> or SurfFetched<T> (device_table.h) -- `h.surf()` / `h.optics()` are asked
+// for again at every phase; with SurfFetched each call re-reads the table, so no table
+// field is live from one phase into the next.
+template <typename V, int RPT, int POLK, int NR, typename H>
+OL_DEV void surface_step(const H& h, cptr<typename Math<V>::scalar> coeffs, bool from_global,
+                         Ray<V> (&r)[RPT],
+                         Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
+                         uint32_t& status, bool& prt_fresh) {
   using m = Math<V>;
   using T = typename m::scalar;
   static_assert(NR == 0 || m::lanes == 1, "the Newton-Raphson path is scalar");
-  into_local_frame<V, RPT>(s, from_global, r);
+  {
+    const DevSurf<T> s = h.surf();
+    into_local_frame<V, RPT>(s, from_global, r);
+  }
 
-  const T* c = coeffs + s.coeff_off;
   V t[RPT], nx[RPT], ny[RPT], nz[RPT];  // distance, unit normal at the hit
-  if (s.geom == kGeomPlane) {
+  const int geom = h.surf().geom;
+  if (geom == kGeomPlane) {
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       t[k] = -m::div(r[k].z, r[k].N);  // plane.py:72-88
@@ -1368,7 +1482,8 @@ OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
       r[k].y = m::fma(t[k], r[k].M, r[k].y);
       r[k].z = m::fma(t[k], r[k].N, r[k].z);
     }
-  } else if (s.geom == kGeomStandard) {
+  } else if (geom == kGeomStandard) {
+    const DevSurf<T> s = h.surf();
     if (s.flags & kSurfRadiusInf) {
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
@@ -1395,22 +1510,33 @@ OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
   } else if constexpr (NR != 0) {
     constexpr bool COMPACT = NR == kNrCompact;
     NewtonRay<T> q[RPT];
+    int max_iter;
+    {
+      const DevSurf<T> s = h.surf();
+      max_iter = s.max_iter;
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      t[k] = conic_distance(s, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M, r[k].N);
-      q[k].xb = m::fma(t[k], r[k].L, r[k].x);
-      q[k].yb = m::fma(t[k], r[k].M, r[k].y);
-      q[k].zb = m::fma(t[k], r[k].N, r[k].z);
-      q[k].dt = T(0);
-      q[k].fprev = T(0);
-      q[k].gx = q[k].gy = T(0);
-      q[k].active = true;
+      for (int k = 0; k < RPT; ++k) {
+        t[k] = conic_distance(s, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M, r[k].N);
+        q[k].xb = m::fma(t[k], r[k].L, r[k].x);
+        q[k].yb = m::fma(t[k], r[k].M, r[k].y);
+        q[k].zb = m::fma(t[k], r[k].N, r[k].z);
+        q[k].dt = T(0);
+        q[k].fprev = T(0);
+        q[k].gx = q[k].gy = T(0);
+        q[k].active = true;
+      }
     }
     int it = 0;
     bool can_compact = false;  // (only when every lane of the wave is alive)
     if constexpr (COMPACT && RPT > 1) can_compact = __popcll(__ballot(true)) == 64;
-    for (; it < s.max_iter; ++it) {
+    for (; it < max_iter; ++it) {
       bool any = false;
+      // one copy of the table fields per ITERATION: with SurfFetched the few scalars an
+      // evaluation needs (curvature, tolerance, block offset) are re-read here and the
+      // coefficient loads below them start from a fresh pointer -- nothing of the surface
+      // is carried around the loop in SGPRs
+      const DevSurf<T> s = h.surf();
+      cptr<T> c = coeffs + s.coeff_off;
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         if (q[k].active) newton_iterate<NR>(s, c, q[k], r[k].L, r[k].M, r[k].N, it, status);
@@ -1449,6 +1575,8 @@ OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
       t[k] = t[k] + q[k].dt;
     }
     if (it == 0) {  // max_iter == 0: no evaluation happened, take the gradient here
+      const DevSurf<T> s = h.surf();
+      cptr<T> c = coeffs + s.coeff_off;
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         T sag;
@@ -1469,7 +1597,23 @@ OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
 #pragma unroll
     for (int k = 0; k < RPT; ++k) t[k] = nx[k] = ny[k] = nz[k] = m::splat(0);
   }
-  interact<V, RPT, POLK, NR != 0>(s, o, coeffs, t, nx, ny, nz, r, P, prt_fresh);
+  {
+    const DevSurf<T> s = h.surf();
+    const DevOptics<T> o = h.optics();
+    interact<V, RPT, POLK, NR != 0>(s, o, coeffs, t, nx, ny, nz, r, P, prt_fresh);
+  }
+}
+
+// the rows loaded by the caller (lean kernels; tests)
+template <typename V, int RPT, int POLK, int NR>
+OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
+                         const DevOptics<typename Math<V>::scalar>& o,
+                         cptr<typename Math<V>::scalar> coeffs, bool from_global,
+                         Ray<V> (&r)[RPT],
+                         Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
+                         uint32_t& status, bool& prt_fresh) {
+  const SurfLoaded<typename Math<V>::scalar> h{s, o};
+  surface_step<V, RPT, POLK, NR>(h, coeffs, from_global, r, P, status, prt_fresh);
 }
 
 // local -> global for the recorded state (coordinate_system.py:91-107)
@@ -1479,7 +1623,7 @@ OL_DEV Ray<V> to_global(const DevSurf<typename Math<V>::scalar>& s,
   using T = typename Math<V>::scalar;
   Ray<V> g = r;
   if (s.flags & kSurfRotated) {
-    const T* R = s.cold->rot;  // inverse = transpose
+    cptr<T> R = s.cold->rot;  // inverse = transpose
     g.x = R[0] * r.x + R[3] * r.y + R[6] * r.z;
     g.y = R[1] * r.x + R[4] * r.y + R[7] * r.z;
     g.z = R[2] * r.x + R[5] * r.y + R[8] * r.z;

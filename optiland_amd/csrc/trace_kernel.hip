@@ -58,6 +58,31 @@
 #ifndef OL_FUSED_NR_PREFETCH
 #define OL_FUSED_NR_PREFETCH 1
 #endif
+// 1 (default): the Newton-Raphson kernels re-read table rows and kernel arguments where they
+// are used (SurfFetched / kernargs()) instead of holding them in SGPRs; 0 = round-2 form
+// (hot block by value), kept as the A/B handle (tools/build_variants.py)
+#ifndef OL_NR_FETCH
+#define OL_NR_FETCH 1
+#endif
+// fp64 instances of the fused spot / OPD kernels without a Newton surface: fetch as well
+// (a wave has the same ~100 SGPRs for values twice as wide)
+#ifndef OL_FETCH_F64
+#define OL_FETCH_F64 1
+#endif
+// the fp32 conic-only spot kernels: fetch too (0 SGPR spills instead of 17-43, 40 instead of
+// 52 VGPRs at one ray per lane) -- A/B handle
+#ifndef OL_FETCH_LEAN_SPOT
+#define OL_FETCH_LEAN_SPOT 1
+#endif
+#ifndef OL_EXP_A
+#define OL_EXP_A 0
+#endif
+#ifndef OL_EXP_B
+#define OL_EXP_B 0
+#endif
+#ifndef OL_EXP_C
+#define OL_EXP_C 0
+#endif
 
 #include "surface_math.h"
 
@@ -302,17 +327,67 @@ constexpr int kTraceArgsKernargOffset = 32;
 // from the constant address space) instead of being kept live from the prologue.  The
 // empty asm hides the pointer's provenance, so the loads cannot be hoisted back.
 template <typename A>
-__device__ __forceinline__ const __attribute__((address_space(4))) A* kernarg_again(int offset) {
+__device__ __forceinline__ cptr<A> kernarg_again(int offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
   using CP = const __attribute__((address_space(4))) char*;
   CP p = (CP)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(p));
-  return reinterpret_cast<const __attribute__((address_space(4))) A*>(p + offset);
+  return reinterpret_cast<cptr<A>>(p + offset);
+#else
+  return nullptr;  // (host pass of the single-source compile: never executed)
+#endif
 }
+
+// The kernarg segment of the three trace kernels as a struct: four table pointers, then the
+// argument block (8-byte aligned, so at offset 32).  `kernargs<T, A>()` is a fresh view of it
+// (kernarg_again): a kernel that is short of SGPRs reads a pointer or a stride from it where
+// it needs one instead of carrying it from the prologue.
+template <typename T, typename A>
+struct KernArgs {
+  const DevSurfHot<T>* surf;
+  const DevSurfCold<T>* cold;
+  const DevOptics<T>* optics;
+  const T* coeffs;
+  A a;
+};
+template <typename T, typename A>
+__device__ __forceinline__ cptr<KernArgs<T, A>> kernargs() {
+  using KA = KernArgs<T, A>;
+  static_assert(__builtin_offsetof(KA, a) == kTraceArgsKernargOffset, "kernarg layout");
+  return kernarg_again<KernArgs<T, A>>(0);
+}
+// The argument block as a kernel phase reads it: FETCH = a fresh view of the kernarg segment
+// (constant address space; fields are scalar-loaded where they are used and die with the
+// phase), otherwise the by-value parameter (loaded once in the prologue).
+template <bool FETCH, typename T, typename A>
+__device__ __forceinline__ auto arg_view(const A& a) {
+  if constexpr (FETCH) return &kernargs<T, A>()->a;
+  else return &a;
+}
+template <typename C>
+__device__ __forceinline__ C consts_of(const C* p) { return *p; }
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename C>
+__device__ __forceinline__ C consts_of(cptr<C> p) { return load_consts(p); }
+#endif
+// the rows of surface `s` for wavelength slot (n_wl, wl), addressed from the kernarg segment
+template <typename T, typename A>
+__device__ __forceinline__ SurfFetched<T> fetched_surface(int s) {
+  const auto ka = kernargs<T, A>();
+  return SurfFetched<T>{as_const(ka->surf) + s, as_const(ka->cold) + s,
+                        as_const(ka->optics) + (s * ka->a.n_wl + ka->a.wl)};
+}
+#ifndef OL_POLNR_WAVES_F64
+#define OL_POLNR_WAVES_F64 0
+#endif
 template <typename T, int RPT, int POLK, int NR>
 struct WavesPerEu {
   static constexpr int value =
-      (OL_POLNR_WAVES > 0 && sizeof(T) == 4 && RPT == 1 && POLK == 1 && NR != 0) ? OL_POLNR_WAVES
-                                                                                  : 1;
+      (OL_POLNR_WAVES > 0 && sizeof(T) == 4 && RPT == 1 && POLK == 1 && NR != 0)
+          ? OL_POLNR_WAVES
+          : ((OL_POLNR_WAVES_F64 > 0 && sizeof(T) == 8 && RPT == 1 && POLK == 1 && NR != 0)
+                 ? OL_POLNR_WAVES_F64
+                 : 1);
 };
 
 template <typename T, int RPT, bool RECORD, int POLK, int NR, bool SPOT>
@@ -428,8 +503,23 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
   uint32_t status = 0;
   bool is_global = true;  // frame of the state held in r[]
   bool prt_fresh = POLK != 0 && (a.flags & kTracePrtIdentity) != 0;
+  // Newton-Raphson ranges: table rows re-read phase by phase (SurfFetched), kernel arguments
+  // re-read from the kernarg segment where they are used -- these kernels are short of SGPRs
+  constexpr bool kFetch = NR != 0 && !OL_TABLE_IN_LDS && OL_NR_FETCH;
+  const cptr<T> coeffs_c = as_const(coeff_tab);
   DevSurf<T> last_traced;
-  last_traced.cold = cold_tab;
+  last_traced.cold = as_const(cold_tab);
+  int last_idx = a.first;  // kFetch: the surface whose frame r[] is held in
+  auto to_global_now = [&](Ray<V> (&gv)[NV]) {
+    if constexpr (kFetch && !OL_EXP_B) {
+      const DevSurf<T> lt = fetched_surface<T, TraceArgs<T>>(last_idx).surf();
+#pragma unroll
+      for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(lt, r[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(last_traced, r[j]);
+    }
+  };
   // hot block of the current surface by value (one s_load_dwordx16 for fp32); the
   // next surface's block is requested before the current one is worked on.
 #if OL_TABLE_IN_LDS
@@ -438,45 +528,74 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
   // (the Newton kernels are short of SGPRs, not of latency hiding: no prefetch there --
   // 16 fewer live scalars across the whole surface body)
   constexpr bool kPrefetch = (OL_NR_PREFETCH || NR == 0) && (OL_PREFETCH_F64 || sizeof(T) == 4);
-  DevSurfHot<T> cur = surf_tab[a.first];
+  DevSurfHot<T> cur;
+  if constexpr (!kFetch) cur = surf_tab[a.first];
 #endif
-  for (int s = a.first; s <= a.last; ++s) {
-    DevSurf<T> S;
-#if OL_TABLE_IN_LDS
-    static_cast<DevSurfHot<T>&>(S) = cur;
-    if (s < a.last) cur = lds_hot[s + 1 - a.first];
+  const int first = a.first, last = a.last;
+  for (int s = first; s <= last; ++s) {
+    if constexpr (kFetch) {
+#if OL_EXP_C
+      const SurfFetched<T> h{as_const(surf_tab) + s, as_const(cold_tab) + s,
+                             as_const(optics_tab) + (s * a.n_wl + a.wl)};
 #else
-    if constexpr (kPrefetch) {
-      static_cast<DevSurfHot<T>&>(S) = cur;
-      if (s < a.last) cur = surf_tab[s + 1];
+      const SurfFetched<T> h = fetched_surface<T, TraceArgs<T>>(s);
+#endif
+      if (refresh(h.hot)->interaction != kRecordOnly) {
+        surface_step<V, NV, POLK, NR>(h, refresh(coeffs_c), is_global, r, P, status, prt_fresh);
+        is_global = false;
+        last_idx = s;
+        if constexpr (OL_EXP_B != 0) last_traced = h.surf();
+      }
     } else {
-      static_cast<DevSurfHot<T>&>(S) = surf_tab[s];
-    }
-#endif
-    S.cold = cold_tab + s;
-    if (S.interaction != kRecordOnly) {
+      DevSurf<T> S;
 #if OL_TABLE_IN_LDS
-      const DevOptics<T> O = lds_opt[s - a.first];
+      static_cast<DevSurfHot<T>&>(S) = cur;
+      if (s < a.last) cur = lds_hot[s + 1 - a.first];
 #else
-      const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
+      if constexpr (kPrefetch) {
+        static_cast<DevSurfHot<T>&>(S) = cur;
+        if (s < a.last) cur = surf_tab[s + 1];
+      } else {
+        static_cast<DevSurfHot<T>&>(S) = surf_tab[s];
+      }
 #endif
-      surface_step<V, NV, POLK, NR>(S, O, coeff_tab, is_global, r, P, status, prt_fresh);
-      is_global = false;
-      last_traced = S;
+      S.cold = as_const(cold_tab) + s;
+      if (S.interaction != kRecordOnly) {
+#if OL_TABLE_IN_LDS
+        const DevOptics<T> O = lds_opt[s - a.first];
+#else
+        const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
+#endif
+        surface_step<V, NV, POLK, NR>(S, O, coeffs_c, is_global, r, P, status, prt_fresh);
+        is_global = false;
+        last_traced = S;
+      }
     }
     if constexpr (RECORD) {
-      T* row = a.record + (int64_t)(s - a.first) * 8 * a.record_stride;
-      if (s == a.first && (a.flags & kTraceRow0IsInput)) {
+      T* record;
+      int64_t stride;
+      uint32_t flags;
+      if constexpr (kFetch && !OL_EXP_A) {
+        const auto ka = kernargs<T, TraceArgs<T>>();
+        record = ka->a.record;
+        stride = ka->a.record_stride;
+        flags = ka->a.flags;
+      } else {
+        record = a.record;
+        stride = a.record_stride;
+        flags = a.flags;
+      }
+      T* row = record + (int64_t)(s - first) * 8 * stride;
+      if (s == first && (flags & kTraceRow0IsInput)) {
         // the caller generated the rays straight into row 0 of the record block
         // (the object surface only records its input): nothing to write
       } else {
         Ray<V> gv[NV];
-#pragma unroll
-        for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(last_traced, r[j]);
+        to_global_now(gv);
         Ray<T> g[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; ++k) g[k] = LP::ray(gv, k);
-        store_rays<T, RPT>(row, a.record_stride, base, cnt, g);
+        store_rays<T, RPT>(row, stride, base, cnt, g);
       }
     }
   }
@@ -487,8 +606,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
     // the ~4e4 workgroups of a 1e7-ray launch off one address (7 x 39 k same-address
     // atomics were measured at 0.95 ms); the consumer adds the slots up
     Ray<V> gv[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(last_traced, r[j]);
+    to_global_now(gv);
     SpotAcc acc;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -529,8 +647,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
   }
   if ((late.flags & kTraceWriteRays) && (!SPOT || live)) {
     Ray<V> gv[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(last_traced, r[j]);
+    to_global_now(gv);
     Ray<T> g[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) g[k] = LP::ray(gv, k);
@@ -632,7 +749,7 @@ static hipError_t launch_pair(const TraceArgs<T>& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-#if OL_TRACE_TU != 2
+#if OL_TRACE_TU == 0 || OL_TRACE_TU == 1
 Tuning& tuning() {
   static Tuning t = [] {
     Tuning v;
@@ -676,14 +793,15 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, int nr_family,
 
 // OL_TRACE_TU: 0 = everything in this translation unit; 1 / 2 = the fp32 / fp64
 // instantiations only (trace_kernel_f32.hip / trace_kernel_f64.hip include this file so
-// that the two halves compile in parallel)
+// that the two halves compile in parallel); 3 = no launcher at all: the including file
+// instantiates the kernels it wants to look at (tools/kernel_probe.py)
 #ifndef OL_TRACE_TU
 #define OL_TRACE_TU 0
 #endif
-#if OL_TRACE_TU != 2
+#if OL_TRACE_TU == 0 || OL_TRACE_TU == 1
 template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, int, hipStream_t);
 #endif
-#if OL_TRACE_TU != 1
+#if OL_TRACE_TU == 0 || OL_TRACE_TU == 2
 template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, int, hipStream_t);
 #endif
 
@@ -710,28 +828,35 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
     const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
     SpotArgs<T> a) {
-  const RaygenConsts<T> c(a.rg);
+  // Newton ranges (and every fp64 instance): nothing of the argument block is held across the
+  // surface loop -- each phase of a tile reads what it needs from the kernarg segment
+  constexpr bool kFetch =
+      OL_NR_FETCH && (NR != 0 || (OL_FETCH_F64 && sizeof(T) == 8) || OL_FETCH_LEAN_SPOT);
   // FIELDP: per-ray field planes.  A template parameter because the per-ray
   // double-precision tangent (tan_deg) would otherwise set the register budget of
   // the common launch-uniform-field case as well.
   constexpr bool field_planes = FIELDP;
-  const RaygenIn<T>& in_ = a.in;
-  const bool vig_planes = in_.vx != nullptr;
-  // launch-uniform field: the two tangents come from the host (uniform_field_tangents)
-  const T tx0 = in_.tx0, ty0 = in_.ty0;
 
   SpotAcc acc;
   uint32_t status = 0;
   bool prt_fresh = false;  // unpolarised kernel: unused
   constexpr int64_t kTileRays = (int64_t)kTraceBlock * RPT;
-  const int64_t ntiles = (a.n + kTileRays - 1) / kTileRays;
+  const int tiles_per_block = a.tiles_per_block;
 
-  for (int tt = 0; tt < a.tiles_per_block; ++tt) {
-    const int64_t tile = (int64_t)blockIdx.x * a.tiles_per_block + tt;
+  for (int tt = 0; tt < tiles_per_block; ++tt) {
+    const auto A0 = arg_view<kFetch, T>(a);
+    const int64_t n_rays = A0->n;
+    const int64_t ntiles = (n_rays + kTileRays - 1) / kTileRays;
+    const int64_t tile = (int64_t)blockIdx.x * tiles_per_block + tt;
     if (tile >= ntiles) break;  // workgroup-uniform
     const int64_t base = (tile * kTraceBlock + threadIdx.x) * RPT;
-    const int64_t left = a.n - base;
+    const int64_t left = n_rays - base;
     const int cnt = left >= RPT ? RPT : (left > 0 ? (int)left : 0);
+    const auto& in_ = A0->in;
+    const bool vig_planes = in_.vx != nullptr;
+    // launch-uniform field: the two tangents come from the host (uniform_field_tangents)
+    const T tx0 = in_.tx0, ty0 = in_.ty0;
+    const uint32_t rg_flags = in_.flags;
 
     // pupil (and optional per-ray field / vignetting) planes; lanes past the end
     // trace the on-axis pupil point and are masked out of the sums
@@ -775,71 +900,98 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
     using V = typename LP::V;
     constexpr int NV = LP::NV;
     Ray<V> r[NV];
+    {
+      const RaygenConsts<T> c = consts_of(&A0->rgc);
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      T tx = tx0, ty = ty0, o[6];
-      if constexpr (FIELDP) {
-        if ((in_.flags & kRaygenCheckField) && (outside_unit(in[2][k]) || outside_unit(in[3][k])))
-          status |= kStatusFieldRange;
-        raygen_field<T>(c, in[2][k], in[3][k], tx, ty);
+      for (int k = 0; k < RPT; ++k) {
+        T tx = tx0, ty = ty0, o[6];
+        if constexpr (FIELDP) {
+          if ((rg_flags & kRaygenCheckField) && (outside_unit(in[2][k]) || outside_unit(in[3][k])))
+            status |= kStatusFieldRange;
+          raygen_field<T>(c, in[2][k], in[3][k], tx, ty);
+        }
+        raygen_pupil<T>(rg_flags, in[4][k], in[5][k], in[0][k], in[1][k], status);
+        raygen_one<T>(c, tx, ty, in[0][k], in[1][k], in[4][k], in[5][k], o);
+        Ray<T> q;
+        q.x = o[0]; q.y = o[1]; q.z = o[2];
+        q.L = o[3]; q.M = o[4]; q.N = o[5];
+        // APOD: a template parameter -- the exp / cos / pow code of the apodization
+        // switch would otherwise set the register budget of every spot launch
+        // (fp32 packed 74 -> 129 VGPRs, fp64 113 -> 186: 0.23 -> 0.26 / 0.57 -> 0.70 ms)
+        if constexpr (APOD) q.i = raygen_apodize<T>(c, in[0][k], in[1][k]); else q.i = T(1);
+        q.opd = T(0);
+        LP::put(r, k, q);
       }
-      raygen_pupil<T>(in_.flags, in[4][k], in[5][k], in[0][k], in[1][k], status);
-      raygen_one<T>(c, tx, ty, in[0][k], in[1][k], in[4][k], in[5][k], o);
-      Ray<T> q;
-      q.x = o[0]; q.y = o[1]; q.z = o[2];
-      q.L = o[3]; q.M = o[4]; q.N = o[5];
-      // APOD: a template parameter -- the exp / cos / pow code of the apodization
-      // switch would otherwise set the register budget of every spot launch
-      // (fp32 packed 74 -> 129 VGPRs, fp64 113 -> 186: 0.23 -> 0.26 / 0.57 -> 0.70 ms)
-      if constexpr (APOD) q.i = raygen_apodize<T>(c, in[0][k], in[1][k]); else q.i = T(1);
-      q.opd = T(0);
-      LP::put(r, k, q);
     }
 
     bool is_global = true;
     DevSurf<T> last_traced;
-    last_traced.cold = cold_tab;
+    last_traced.cold = as_const(cold_tab);
     Prt<T, 0> P[1];
-    constexpr bool kPrefetch =
-        (OL_FUSED_NR_PREFETCH || NR == 0) && (OL_PREFETCH_F64 || sizeof(T) == 4);
-    DevSurfHot<T> cur = surf_tab[a.first];
-    for (int s = a.first; s <= a.last; ++s) {
-      DevSurf<T> S;
-      if constexpr (kPrefetch) {
-        static_cast<DevSurfHot<T>&>(S) = cur;
-        if (s < a.last) cur = surf_tab[s + 1];
-      } else {
-        static_cast<DevSurfHot<T>&>(S) = surf_tab[s];
+    Ray<V> gv[NV];
+    if constexpr (kFetch) {
+      // table rows and loop bounds re-read where they are used (see trace_kernel); nothing
+      // of the argument block is carried through the surface loop
+      int last_idx = 0;
+      const int first = kernargs<T, SpotArgs<T>>()->a.first;
+      for (int s = first; s <= kernargs<T, SpotArgs<T>>()->a.last; ++s) {
+        const SurfFetched<T> h = fetched_surface<T, SpotArgs<T>>(s);
+        if (refresh(h.hot)->interaction != kRecordOnly) {
+          surface_step<V, NV, 0, NR>(h, as_const(kernargs<T, SpotArgs<T>>()->coeffs), is_global, r,
+                                     P, status, prt_fresh);
+          is_global = false;
+          last_idx = s;
+        }
       }
-      S.cold = cold_tab + s;
-      if (S.interaction != kRecordOnly) {
-        const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
-        surface_step<V, NV, 0, NR>(S, O, coeff_tab, is_global, r, P, status, prt_fresh);
-        is_global = false;
-        last_traced = S;
+      const DevSurf<T> lt = fetched_surface<T, SpotArgs<T>>(last_idx).surf();
+#pragma unroll
+      for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(lt, r[j]);
+    } else {
+      constexpr bool kPrefetch =
+          (OL_FUSED_NR_PREFETCH || NR == 0) && (OL_PREFETCH_F64 || sizeof(T) == 4);
+      DevSurfHot<T> cur = surf_tab[a.first];
+      for (int s = a.first; s <= a.last; ++s) {
+        DevSurf<T> S;
+        if constexpr (kPrefetch) {
+          static_cast<DevSurfHot<T>&>(S) = cur;
+          if (s < a.last) cur = surf_tab[s + 1];
+        } else {
+          static_cast<DevSurfHot<T>&>(S) = surf_tab[s];
+        }
+        S.cold = as_const(cold_tab) + s;
+        if (S.interaction != kRecordOnly) {
+          const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
+          surface_step<V, NV, 0, NR>(S, O, as_const(coeff_tab), is_global, r, P, status,
+                                     prt_fresh);
+          is_global = false;
+          last_traced = S;
+        }
       }
+#pragma unroll
+      for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(last_traced, r[j]);
     }
 
-    Ray<V> gv[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(last_traced, r[j]);
     T hx_[RPT], hy_[RPT], hi_[RPT];
+    const auto A1 = arg_view<kFetch, T>(a);
+    const double cx = A1->cx, cy = A1->cy;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       const Ray<T> g = LP::ray(gv, k);
       hx_[k] = g.x; hy_[k] = g.y; hi_[k] = g.i;
-      if (k < cnt) acc.add(g.x, g.y, g.i, a.cx, a.cy);
+      if (k < cnt) acc.add(g.x, g.y, g.i, cx, cy);
     }
-    if (a.hits[0] != nullptr && cnt > 0) {
+    if (A1->hits[0] != nullptr && cnt > 0) {
       const RayIndexT<false> at{tile * (kTraceBlock * RPT), (uint32_t)threadIdx.x * RPT};
-      store_plane<T, RPT>(a.hits[0], at, cnt, hx_);
-      store_plane<T, RPT>(a.hits[1], at, cnt, hy_);
-      store_plane<T, RPT>(a.hits[2], at, cnt, hi_);
+      store_plane<T, RPT>(A1->hits[0], at, cnt, hx_);
+      store_plane<T, RPT>(A1->hits[1], at, cnt, hy_);
+      store_plane<T, RPT>(A1->hits[2], at, cnt, hi_);
     }
   }
 
-  acc.flush(a.out);
-  if (status && a.status) atomicOr(a.status, status);
+  const auto A2 = arg_view<kFetch, T>(a);
+  acc.flush(A2->out);
+  uint32_t* status_out = A2->status;
+  if (status && status_out) atomicOr(status_out, status);
 }
 
 template <typename T, int RPT, int NR>
@@ -856,6 +1008,7 @@ static hipError_t launch_spot_nr(const SpotArgs<T>& a_in, hipStream_t stream) {
   if (tpb < 1) tpb = 1;
   if (tpb > 1024) tpb = 1024;
   a.tiles_per_block = (int32_t)tpb;
+  a.rgc = RaygenConsts<T>(a.rg);
   if (a.in.hx == nullptr) uniform_field_tangents<T>(a.rg, a.in);
   const int64_t blocks = (ntiles + tpb - 1) / tpb;
   if (blocks == 0) return hipSuccess;
@@ -890,10 +1043,10 @@ hipError_t launch_spot_trace(const SpotArgs<T>& a, bool vector_ok, int nr_family
   return launch_spot_nr<T, kVec, 0>(a, stream);
 }
 
-#if OL_TRACE_TU != 2
+#if OL_TRACE_TU == 0 || OL_TRACE_TU == 1
 template hipError_t launch_spot_trace<float>(const SpotArgs<float>&, bool, int, hipStream_t);
 #endif
-#if OL_TRACE_TU != 1
+#if OL_TRACE_TU == 0 || OL_TRACE_TU == 2
 template hipError_t launch_spot_trace<double>(const SpotArgs<double>&, bool, int, hipStream_t);
 #endif
 
@@ -918,61 +1071,90 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
     const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
     OpdArgs<T> a) {
-  const RaygenConsts<T> c(a.rg);
-  const WavefrontConsts<T> w(a.wf);
-  const RaygenIn<T>& in_ = a.in;
+  // every instance is fp64: nothing of the argument block is held across the surface loop,
+  // each phase of a ray reads what it needs from the kernarg segment (see spot_trace_kernel)
+  constexpr bool kFetch = OL_NR_FETCH && (NR != 0 || (OL_FETCH_F64 && sizeof(T) == 8));
   uint32_t status = 0;
   bool prt_fresh = false;
   double s[kOpdMoments];
 #pragma unroll
   for (int k = 0; k < kOpdMoments; ++k) s[k] = 0.0;
 
-  for (int64_t j = (int64_t)blockIdx.x * kTraceBlock + threadIdx.x; j < a.n;
-       j += (int64_t)gridDim.x * kTraceBlock) {
-    T px = in_.px[j], py = in_.py[j];
-    T vx = in_.vx0, vy = in_.vy0, o[6];
-    raygen_pupil<T>(in_.flags, vx, vy, px, py, status);
-    raygen_one<T>(c, in_.tx0, in_.ty0, px, py, vx, vy, o);
+  for (int64_t j = (int64_t)blockIdx.x * kTraceBlock + threadIdx.x;
+       j < arg_view<kFetch, T>(a)->n; j += (int64_t)gridDim.x * kTraceBlock) {
     Ray<T> r[1];
-    r[0].x = o[0]; r[0].y = o[1]; r[0].z = o[2];
-    r[0].L = o[3]; r[0].M = o[4]; r[0].N = o[5];
-    if constexpr (APOD) r[0].i = raygen_apodize<T>(c, px, py); else r[0].i = T(1);
-    r[0].opd = T(0);
+    {
+      const auto A0 = arg_view<kFetch, T>(a);
+      const auto& in_ = A0->in;
+      T px = in_.px[j], py = in_.py[j];
+      T vx = in_.vx0, vy = in_.vy0, o[6];
+      raygen_pupil<T>(in_.flags, vx, vy, px, py, status);
+      const RaygenConsts<T> c = consts_of(&A0->rgc);
+      raygen_one<T>(c, in_.tx0, in_.ty0, px, py, vx, vy, o);
+      r[0].x = o[0]; r[0].y = o[1]; r[0].z = o[2];
+      r[0].L = o[3]; r[0].M = o[4]; r[0].N = o[5];
+      if constexpr (APOD) r[0].i = raygen_apodize<T>(c, px, py); else r[0].i = T(1);
+      r[0].opd = T(0);
+    }
 
     bool is_global = true;
     DevSurf<T> last_traced;
-    last_traced.cold = cold_tab;
+    last_traced.cold = as_const(cold_tab);
     Prt<T, 0> P[1];
-    constexpr bool kPrefetch =
-        (OL_FUSED_NR_PREFETCH || NR == 0) && (OL_PREFETCH_F64 || sizeof(T) == 4);
-    DevSurfHot<T> cur = surf_tab[a.first];
-    for (int sidx = a.first; sidx <= a.last; ++sidx) {
-      DevSurf<T> S;
-      if constexpr (kPrefetch) {
-        static_cast<DevSurfHot<T>&>(S) = cur;
-        if (sidx < a.last) cur = surf_tab[sidx + 1];
-      } else {
-        static_cast<DevSurfHot<T>&>(S) = surf_tab[sidx];
+    Ray<T> g;
+    if constexpr (kFetch) {
+      int last_idx = 0;
+      const int first = kernargs<T, OpdArgs<T>>()->a.first;
+      for (int sidx = first; sidx <= kernargs<T, OpdArgs<T>>()->a.last; ++sidx) {
+        const SurfFetched<T> h = fetched_surface<T, OpdArgs<T>>(sidx);
+        if (refresh(h.hot)->interaction != kRecordOnly) {
+          surface_step<T, 1, 0, NR>(h, as_const(kernargs<T, OpdArgs<T>>()->coeffs), is_global, r,
+                                    P, status, prt_fresh);
+          is_global = false;
+          last_idx = sidx;
+        }
       }
-      S.cold = cold_tab + sidx;
-      if (S.interaction != kRecordOnly) {
-        const DevOptics<T> O = optics_tab[sidx * a.n_wl + a.wl];
-        surface_step<T, 1, 0, NR>(S, O, coeff_tab, is_global, r, P, status, prt_fresh);
-        is_global = false;
-        last_traced = S;
+      const DevSurf<T> lt = fetched_surface<T, OpdArgs<T>>(last_idx).surf();
+      g = is_global ? r[0] : to_global<T>(lt, r[0]);
+    } else {
+      constexpr bool kPrefetch =
+          (OL_FUSED_NR_PREFETCH || NR == 0) && (OL_PREFETCH_F64 || sizeof(T) == 4);
+      DevSurfHot<T> cur = surf_tab[a.first];
+      for (int sidx = a.first; sidx <= a.last; ++sidx) {
+        DevSurf<T> S;
+        if constexpr (kPrefetch) {
+          static_cast<DevSurfHot<T>&>(S) = cur;
+          if (sidx < a.last) cur = surf_tab[sidx + 1];
+        } else {
+          static_cast<DevSurfHot<T>&>(S) = surf_tab[sidx];
+        }
+        S.cold = as_const(cold_tab) + sidx;
+        if (S.interaction != kRecordOnly) {
+          const DevOptics<T> O = optics_tab[sidx * a.n_wl + a.wl];
+          surface_step<T, 1, 0, NR>(S, O, as_const(coeff_tab), is_global, r, P, status, prt_fresh);
+          is_global = false;
+          last_traced = S;
+        }
       }
+      g = is_global ? r[0] : to_global<T>(last_traced, r[0]);
     }
-    const Ray<T> g = is_global ? r[0] : to_global<T>(last_traced, r[0]);
     T pu[3];
+    const auto A1 = arg_view<kFetch, T>(a);
     // the pupil coordinates of the tilt term are the ones the CALLER passed (the
     // reference corrects with the distribution's points, strategy.py:88-139)
-    const T ov = wavefront_one<T>(w, g.x, g.y, g.z, g.L, g.M, g.N, g.opd, in_.px[j], in_.py[j], pu);
-    a.opd[j] = ov;
-    a.inten[j] = g.i;
-    if (a.pupil[0]) {
-      a.pupil[0][j] = pu[0];
-      a.pupil[1][j] = pu[1];
-      a.pupil[2][j] = pu[2];
+    T ov;
+    {
+      const WavefrontConsts<T> w = consts_of(&A1->wfc);
+      ov = wavefront_one<T>(w, g.x, g.y, g.z, g.L, g.M, g.N, g.opd, A1->in.px[j], A1->in.py[j],
+                            pu);
+    }
+    A1->opd[j] = ov;
+    A1->inten[j] = g.i;
+    T* const pup0 = A1->pupil[0];
+    if (pup0) {
+      pup0[j] = pu[0];
+      A1->pupil[1][j] = pu[1];
+      A1->pupil[2][j] = pu[2];
     }
     opd_accumulate(s, (double)g.i, (double)ov, (double)pu[0], (double)pu[1], g.i > T(0));
   }
@@ -997,15 +1179,18 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
     double v = 0;
     for (int q = 0; q < kTraceBlock / 64; ++q) v += part[q][threadIdx.x];
     // (a NaN partial sum must reach the output too: v != 0.0 is true for NaN)
-    if (v != 0.0) unsafeAtomicAdd(&a.mom[threadIdx.x], v);
+    if (v != 0.0) unsafeAtomicAdd(&arg_view<kFetch, T>(a)->mom[threadIdx.x], v);
   }
-  if (status && a.status) atomicOr(a.status, status);
+  uint32_t* status_out = arg_view<kFetch, T>(a)->status;
+  if (status && status_out) atomicOr(status_out, status);
 }
 
 template <typename T>
 hipError_t launch_opd_trace(const OpdArgs<T>& a_in, int nr_family, hipStream_t stream) {
   OpdArgs<T> a = a_in;
   uniform_field_tangents<T>(a.rg, a.in);
+  a.rgc = RaygenConsts<T>(a.rg);
+  a.wfc = WavefrontConsts<T>(a.wf);
   int64_t blocks = (a.n + kTraceBlock - 1) / kTraceBlock;
   if (blocks == 0) return hipSuccess;
   if (blocks > 8192) blocks = 8192;  // grid-stride beyond: keeps the atomics few
@@ -1026,7 +1211,7 @@ hipError_t launch_opd_trace(const OpdArgs<T>& a_in, int nr_family, hipStream_t s
   return hipGetLastError();
 }
 
-#if OL_TRACE_TU != 1
+#if OL_TRACE_TU == 0 || OL_TRACE_TU == 2
 template hipError_t launch_opd_trace<double>(const OpdArgs<double>&, int, hipStream_t);
 #endif
 

@@ -61,6 +61,32 @@ struct RaygenDev {
   int32_t apod_kind;
 };
 
+// launch-invariant scalars of the ray generator in the working precision.  Formed on the
+// HOST by the launchers of the fused kernels (SpotArgs / OpdArgs carry them), so that a
+// kernel can read a value from the kernarg segment where it uses it instead of converting
+// the whole block in its prologue and holding it in SGPRs through the surface loop.
+#if defined(__HIPCC__)
+#define OL_HD __host__ __device__
+#else
+#define OL_HD
+#endif
+template <typename T>
+struct RaygenConsts {
+  T EPL, EPD, maxf, off_epl, z_inf, z_fin, epl_z, tele_dz, apod_a, apod_b;
+  int32_t apod_kind;
+  int32_t infinite, height, linear, telecentric;  // flags (0 / 1)
+  RaygenConsts() = default;
+  OL_HD explicit RaygenConsts(const RaygenDev& p)
+      : EPL((T)p.EPL), EPD((T)p.EPD), maxf((T)p.max_field), off_epl((T)(p.offset + p.EPL)),
+        z_inf((T)(p.z_first - p.offset)), z_fin((T)p.z_first), epl_z((T)(p.EPL - p.z_first)),
+        tele_dz((T)p.tele_dz), apod_a((T)p.apod_a), apod_b((T)p.apod_b),
+        apod_kind(p.apod_kind), infinite(p.object_infinite != 0),
+        // the field quantity is a POSITION on the object for object-height fields and
+        // for paraxial-image-height fields with a finite object; otherwise a slope
+        height(p.field_kind == 1 || (p.field_kind == 2 && p.object_infinite == 0)),
+        linear(p.field_kind != 0), telecentric(p.tele_dz > 0.0) {}
+};
+
 constexpr uint32_t kRaygenCheckField = 0x1u;    // OL_RAYGEN_CHECK_FIELD
 constexpr uint32_t kRaygenCheckPupil = 0x2u;    // OL_RAYGEN_CHECK_PUPIL
 constexpr uint32_t kRaygenPrescalePupil = 0x4u; // OL_RAYGEN_PRESCALE_PUPIL
@@ -107,6 +133,7 @@ struct SpotArgs {
   const T* coeffs;
   RaygenIn<T> in;
   RaygenDev rg;
+  RaygenConsts<T> rgc;  // = RaygenConsts<T>(rg), set by the launcher
   double cx, cy;     // centre the moments are taken about (global image coordinates)
   T* hits[3];        // optional image-plane x, y, intensity planes (all or none)
   double* out;       // 7 doubles, accumulated
@@ -137,6 +164,20 @@ struct WavefrontDev {
   double nx, ny, nz;  // all zero: spherical reference; else planar reference normal
 };
 
+// reference sphere / plane of the wavefront kernels in the working precision (host-formed,
+// like RaygenConsts)
+template <typename T>
+struct WavefrontConsts {
+  T xc, yc, zc, R, ni, inv_w, ux, uy, half_epd, opd_ref, nx, ny, nz;
+  int32_t planar;
+  WavefrontConsts() = default;
+  OL_HD explicit WavefrontConsts(const WavefrontDev& p)
+      : xc((T)p.xc), yc((T)p.yc), zc((T)p.zc), R((T)p.R), ni((T)p.n_image),
+        inv_w((T)(1.0 / (p.wavelength_um * 1e-3))), ux((T)p.ux), uy((T)p.uy),
+        half_epd((T)p.half_epd), opd_ref((T)p.opd_ref), nx((T)p.nx), ny((T)p.ny), nz((T)p.nz),
+        planar(p.nx != 0.0 || p.ny != 0.0 || p.nz != 0.0) {}
+};
+
 template <typename T>
 hipError_t launch_wavefront(const WavefrontDev& p, int64_t n, const T* const rays[7], const T* px,
                             const T* py, T* opd_waves, T* const pupil[3], hipStream_t stream);
@@ -152,6 +193,8 @@ struct OpdArgs {
   RaygenIn<T> in;    // pupil planes; launch-uniform field and vignetting
   RaygenDev rg;
   WavefrontDev wf;
+  RaygenConsts<T> rgc;     // = RaygenConsts<T>(rg), set by the launcher
+  WavefrontConsts<T> wfc;  // = WavefrontConsts<T>(wf), set by the launcher
   T* opd;            // OPD in waves per ray
   T* inten;          // image-plane intensity per ray
   T* pupil[3];       // optional: reference-surface intersection point (all or none)

@@ -7,20 +7,19 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "device_table.h"
 #include "trace_launch.h"
 
 namespace ol {
 
 template <typename T>
-struct WavefrontConsts {
-  T xc, yc, zc, R, ni, inv_w, ux, uy, half_epd, opd_ref, nx, ny, nz;
-  bool planar;
-  OL_DEV explicit WavefrontConsts(const WavefrontDev& p)
-      : xc((T)p.xc), yc((T)p.yc), zc((T)p.zc), R((T)p.R), ni((T)p.n_image),
-        inv_w((T)(1.0 / (p.wavelength_um * 1e-3))), ux((T)p.ux), uy((T)p.uy),
-        half_epd((T)p.half_epd), opd_ref((T)p.opd_ref), nx((T)p.nx), ny((T)p.ny), nz((T)p.nz),
-        planar(p.nx != 0.0 || p.ny != 0.0 || p.nz != 0.0) {}
-};
+OL_DEV WavefrontConsts<T> load_consts(cptr<WavefrontConsts<T>> p) {
+  WavefrontConsts<T> w;
+  w.xc = p->xc; w.yc = p->yc; w.zc = p->zc; w.R = p->R; w.ni = p->ni; w.inv_w = p->inv_w;
+  w.ux = p->ux; w.uy = p->uy; w.half_epd = p->half_epd; w.opd_ref = p->opd_ref;
+  w.nx = p->nx; w.ny = p->ny; w.nz = p->nz; w.planar = p->planar;
+  return w;
+}
 
 // (xr, yr, zr), (Ld, Md, Nd), opd_in: the ray at the image surface (global frame);
 // (px, py): its normalised pupil coordinates.  Returns the OPD in waves; pu = the point

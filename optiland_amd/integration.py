@@ -565,7 +565,39 @@ def _sg_trace(self, rays, skip=0):
     return out
 
 
-def enable(device=None, force=False):
+def _companion(rt):
+    """The `OptilandHipRayTracer` behind a reference tracer object: the object itself when
+    `install()` put one there, else (under `enable()`) its lazily created companion."""
+    cls = _make_tracer_class()
+    if isinstance(rt, cls):
+        return rt
+    comp = rt.__dict__.get("_hip_companion")
+    if comp is None:
+        comp = cls(rt.optic, device=_ENABLE["device"], force=_ENABLE["force"])
+        comp.ray_generator = rt.ray_generator
+        rt.__dict__["_hip_companion"] = comp
+    comp._hip_device, comp._hip_force = _ENABLE["device"], _ENABLE["force"]
+    comp.ray_aiming_config = rt.ray_aiming_config
+    return comp
+
+
+def hip_tracer_of(optic):
+    """The drop-in tracer serving `optic`, or None when neither `install(optic)` nor
+    `enable()` is in effect for it."""
+    from optiland.raytrace.real_ray_tracer import RealRayTracer
+
+    rt = getattr(optic, "ray_tracer", None)
+    if rt is None:
+        return None
+    cls = _make_tracer_class()
+    if isinstance(rt, cls):
+        return rt
+    if getattr(RealRayTracer, "_hip_enabled", False) and isinstance(rt, RealRayTracer):
+        return _companion(rt)
+    return None
+
+
+def enable(device=None, force=False, analyses=True):
     """Route EVERY `Optic` (existing and future) through the HIP path.
 
     Patches `RealRayTracer.trace / trace_generic` (raytrace/real_ray_tracer.py:58-154)
@@ -575,27 +607,29 @@ def enable(device=None, force=False):
     stock `"torch"` backend: about thirty sites of the reference branch on
     `be.get_backend() == "torch"` (Forbes, NURBS, optimisers ...), which a backend
     registered under another name does not satisfy.
+
+    `analyses` (default on): also put the FUSED kernels behind the reference's own analysis
+    classes (`analysis_seams.enable()`): `SpotDiagram` / `EncircledEnergy` get their
+    image-plane hits from `ol_trace_spot`, the chief-ray wavefront strategy its OPD map from
+    `ol_trace_opd`, `ScalarFFTPSF` its pupil function from `ol_pupil_fill` -- no record
+    block, no ray planes.  The one observable difference: after such an analysis the
+    `Surface` objects do not hold the recorded arrays of its last trace.
     """
     cls = _make_tracer_class()
     from optiland.raytrace.real_ray_tracer import RealRayTracer
+
+    from . import analysis_seams
 
     if getattr(RealRayTracer, "_hip_enabled", False):
         # already patched: a second call only updates the settings (device / force) that
         # future companions and the SurfaceGroup seam read
         _ENABLE.update(device=device, force=force)
         _SG.update(device=device, force=force)
+        (analysis_seams.enable if analyses else analysis_seams.disable)()
         return
     _ENABLE.update(device=device, force=force)
-
-    def _companion(self):
-        comp = self.__dict__.get("_hip_companion")
-        if comp is None:
-            comp = cls(self.optic, device=_ENABLE["device"], force=_ENABLE["force"])
-            comp.ray_generator = self.ray_generator
-            self.__dict__["_hip_companion"] = comp
-        comp._hip_device, comp._hip_force = _ENABLE["device"], _ENABLE["force"]
-        comp.ray_aiming_config = self.ray_aiming_config
-        return comp
+    if analyses:
+        analysis_seams.enable()
 
     def trace(self, Hx, Hy, wavelength, num_rays=100, distribution="hexapolar"):
         if isinstance(self, cls):
@@ -630,6 +664,9 @@ def disable():
 
         SurfaceGroup.trace = _ORIGINALS["sg_trace"]
         _SG.update(device=None, force=False)
+        from . import analysis_seams
+
+        analysis_seams.disable()
 
 
 def install(optic, device=None, force=False):

@@ -97,8 +97,15 @@ void trace_one(const TraceArgs<T>& a, int64_t i, uint32_t& status) {
     static_cast<DevSurfHot<T>&>(S) = a.surf[s];
     S.cold = a.cold + s;
     if (S.interaction != kRecordOnly) {
-      const DevOptics<T> O = a.optics[s * a.n_wl + a.wl];
-      surface_step<T, 1, POLK, NR>(S, O, a.coeffs, is_global, r, P, status, prt_fresh);
+      if constexpr (NR != 0) {
+        // the Newton kernels hand surface_step table POINTERS and every phase re-reads its
+        // fields (SurfFetched, device_table.h) -- same handle here
+        const SurfFetched<T> h{a.surf + s, a.cold + s, a.optics + (s * a.n_wl + a.wl)};
+        surface_step<T, 1, POLK, NR>(h, a.coeffs, is_global, r, P, status, prt_fresh);
+      } else {
+        const DevOptics<T> O = a.optics[s * a.n_wl + a.wl];
+        surface_step<T, 1, POLK, NR>(S, O, a.coeffs, is_global, r, P, status, prt_fresh);
+      }
       is_global = false;
       last_traced = S;
     }

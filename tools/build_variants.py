@@ -43,6 +43,16 @@ VARIANTS = {
     "noprefetch_f64": ["-DOL_PREFETCH_F64=0"],
     "noprefetch_fused_nr": ["-DOL_FUSED_NR_PREFETCH=0"],
     "nr_prefetch": ["-DOL_NR_PREFETCH=1"],
+    # round 3: table rows / kernel arguments re-read where they are used (SurfFetched,
+    # kernargs()) instead of held in SGPRs; windowed coefficient stream of the unrolled
+    # Zernike polynomial.  (The round-2 library itself is built from its commit as
+    # variant_r02.so by tools/build_r02_variant.sh.)
+    "nr_byvalue": ["-DOL_NR_FETCH=0"],
+    "f64_byvalue": ["-DOL_FETCH_F64=0"],
+    "leanspot_byvalue": ["-DOL_FETCH_LEAN_SPOT=0"],
+    "zmono_ahead2": ["-DOL_ZERN_MONO_AHEAD=2"],
+    "zmono_chunk16": ["-DOL_ZERN_MONO_CHUNK=16"],
+    "polnr_waves6": ["-DOL_POLNR_WAVES=6"],
 }
 
 
