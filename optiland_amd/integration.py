@@ -669,9 +669,14 @@ def disable():
         analysis_seams.disable()
 
 
-def install(optic, device=None, force=False):
-    """Replace `optic.ray_tracer` with the HIP tracer (keeps the aiming config)."""
+def install(optic, device=None, force=False, analyses=True):
+    """Replace `optic.ray_tracer` with the HIP tracer (keeps the aiming config).  `analyses`:
+    see `enable()` -- the class-wide analysis seams only act on optics the drop-in serves."""
     cls = _make_tracer_class()
+    if analyses:
+        from . import analysis_seams
+
+        analysis_seams.enable()
     old = optic.ray_tracer
     new = cls(optic, device=device, force=force)
     new.ray_aiming_config = dict(getattr(old, "ray_aiming_config", new.ray_aiming_config))

@@ -1,0 +1,255 @@
+"""The fused kernels behind the reference's OWN analysis classes (build container only).
+
+`integration.enable()` / `install()` patch `SpotDiagram` / `EncircledEnergy`
+(`_generate_field_data`), the chief-ray wavefront strategy (`compute_wavefront_data`) and
+`ScalarFFTPSF` (`_generate_pupils`, `_pad_pupils`) so that they call `ol_trace_spot`,
+`ol_trace_opd` and `ol_pupil_fill` (optiland_amd/analysis_seams.py).  Here the reference's
+classes are run three ways on the same lens -- NumPy backend (the yardstick), torch backend
+with the drop-in but WITHOUT the analysis seams (record-all trace + the reference's own
+reductions), and with the seams -- on the CPU stand-ins for the device engine (the
+oracle-backed engine and the product engine class on the host build of the kernel source).
+
+Skipped where /root/reference does not exist (the GPU box runs the same checks against the
+real library in tests/test_gpu_live_reference.py).
+"""
+
+import numpy as np
+import pytest
+
+from tests.test_reference_integration import REF, hip_on_cpu, ref  # noqa: F401 (fixtures)
+
+import os
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "optiland")),
+                                reason="reference package not present")
+
+
+def _np(be, a):
+    return np.asarray(be.to_numpy(a), dtype=np.float64)
+
+
+@pytest.fixture
+def seams(hip_on_cpu):
+    from optiland_amd import analysis_seams, integration
+    be = hip_on_cpu
+    integration.enable(force=True, analyses=True)
+    for k in analysis_seams.STATS:
+        analysis_seams.STATS[k] = 0
+    yield be, analysis_seams.STATS
+    integration.disable()
+
+
+def _numpy_reference(be, build, run):
+    """`run(lens)` under the NumPy backend, results as numpy."""
+    from optiland_amd import analysis_seams
+    was = be.get_backend()
+    be.set_backend("numpy")
+    keep = dict(analysis_seams.STATS)  # NumPy-backend calls decline the seams: not counted
+    try:
+        return run(build())
+    finally:
+        analysis_seams.STATS.update(keep)
+        be.set_backend(was)
+        if was == "torch":
+            be.set_device("cpu")
+            be.set_precision("float64")
+
+
+def _cooke():
+    from optiland.samples.objectives import CookeTriplet
+    return CookeTriplet()
+
+
+def _singlet_asphere():
+    from optiland.samples.simple import AsphericSinglet
+    return AsphericSinglet()
+
+
+@pytest.mark.parametrize("build", [_cooke, _singlet_asphere])
+@pytest.mark.parametrize("reference", ["chief_ray", "centroid"])
+def test_spot_diagram_through_the_fused_seam(seams, build, reference):
+    be, stats = seams
+    from optiland import analysis
+
+    def run(lens, coords="local"):
+        s = analysis.SpotDiagram(lens, num_rings=5, reference=reference, coordinates=coords)
+        return ([[(_np(be, d.x), _np(be, d.y), _np(be, d.intensity)) for d in f] for f in s.data],
+                [[float(_np(be, v)) for v in f] for f in s.rms_spot_radius()],
+                [[float(_np(be, v)) for v in f] for f in s.geometric_spot_radius()],
+                [(float(_np(be, a)), float(_np(be, b))) for a, b in s.centroid()])
+
+    want = _numpy_reference(be, build, run)
+    got = run(build())
+    assert stats["spot"] > 0 and stats["spot_fallback"] == 0
+    for fg, fw in zip(got[0], want[0]):
+        for (x, y, i), (xw, yw, iw) in zip(fg, fw):
+            assert x.shape == xw.shape
+            np.testing.assert_allclose(x, xw, rtol=0, atol=1e-8)
+            np.testing.assert_allclose(y, yw, rtol=0, atol=1e-8)
+            np.testing.assert_allclose(i, iw, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-7)
+    np.testing.assert_allclose(got[2], want[2], rtol=1e-7)
+    np.testing.assert_allclose(got[3], want[3], rtol=0, atol=1e-8)
+    # global coordinates too
+    want_g = _numpy_reference(be, build, lambda lens: run(lens, "global"))
+    got_g = run(build(), "global")
+    np.testing.assert_allclose(got_g[1], want_g[1], rtol=1e-7)
+    np.testing.assert_allclose(got_g[3], want_g[3], rtol=0, atol=1e-8)
+
+
+def test_spot_seam_masks_clipped_rays_like_the_reference(seams):
+    """core.py:470-476: rays with zero intensity are dropped -- a system that vignettes."""
+    be, stats = seams
+    from optiland import analysis
+    from tests import _live
+
+    def run(lens):
+        s = analysis.SpotDiagram(lens, num_rings=8)
+        return [[_np(be, d.x) for d in f] for f in s.data]
+
+    want = _numpy_reference(be, _live.rc_asphere, run)
+    got = run(_live.rc_asphere())
+    assert stats["spot"] > 0
+    n_all = 1 + 3 * 8 * 9
+    assert any(x.size < n_all for f in want for x in f), "no ray was clipped: weak test"
+    for fg, fw in zip(got, want):
+        for x, xw in zip(fg, fw):
+            assert x.shape == xw.shape
+            np.testing.assert_allclose(x, xw, rtol=0, atol=1e-6)
+
+
+def test_encircled_energy_through_the_fused_seam(seams):
+    be, stats = seams
+    from optiland import analysis
+
+    def run(lens):
+        e = analysis.EncircledEnergy(lens, num_rays=7, distribution="hexapolar", num_points=32)
+        return ([[(_np(be, d.x), _np(be, d.y), _np(be, d.intensity)) for d in f] for f in e.data],
+                [(float(_np(be, a)), float(_np(be, b))) for a, b in e.centroid()])
+
+    want = _numpy_reference(be, _cooke, run)
+    got = run(_cooke())
+    assert stats["ee"] > 0 and stats["ee_fallback"] == 0
+    for fg, fw in zip(got[0], want[0]):
+        for a, b in zip(fg, fw):
+            for u, v in zip(a, b):
+                np.testing.assert_allclose(u, v, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(got[1], want[1], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("build", [_cooke, _singlet_asphere])
+@pytest.mark.parametrize("remove_tilt", [False, True])
+def test_wavefront_opd_through_the_fused_seam(seams, build, remove_tilt):
+    be, stats = seams
+    from optiland.wavefront import OPD, Wavefront
+
+    def run(lens):
+        w = Wavefront(lens, fields=[(0.0, 0.7)], wavelengths="primary", num_rays=9,
+                      distribution="hexapolar", remove_tilt=remove_tilt)
+        d = w.get_data((0.0, 0.7), lens.primary_wavelength)
+        o = OPD(lens, (0.0, 1.0), lens.primary_wavelength, num_rings=7, remove_tilt=remove_tilt)
+        return ([_np(be, getattr(d, k)) for k in ("opd", "intensity", "pupil_x", "pupil_y",
+                                                   "pupil_z")], float(_np(be, d.radius)),
+                float(_np(be, o.rms())))
+
+    want = _numpy_reference(be, build, run)
+    got = run(build())
+    assert stats["opd"] >= 2 and stats["opd_fallback"] == 0
+    newton = build is _singlet_asphere  # the reference stops Newton at 1e-6 mm = 2e-3 waves
+    np.testing.assert_allclose(got[0][0], want[0][0], rtol=0, atol=5e-3 if newton else 1e-6)
+    for a, b in zip(got[0][1:], want[0][1:]):
+        np.testing.assert_allclose(a, b, rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-10)
+    np.testing.assert_allclose(got[2], want[2], rtol=0, atol=5e-3 if newton else 1e-6)
+
+
+def test_fft_psf_through_the_fused_seams(seams):
+    be, stats = seams
+    from optiland.psf import FFTPSF
+
+    def run(lens):
+        p = FFTPSF(lens, (0.0, 0.7), lens.primary_wavelength, num_rays=64, grid_size=128)
+        return _np(be, p.psf), float(_np(be, p.strehl_ratio())), \
+            np.asarray(be.to_numpy(p.pupils[0]))
+
+    want = _numpy_reference(be, _cooke, run)
+    got = run(_cooke())
+    assert stats["opd"] >= 1 and stats["pupil"] >= 1 and stats["pupil_fallback"] == 0
+    np.testing.assert_allclose(got[2], want[2], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got[0], want[0], rtol=0, atol=1e-4 * want[0].max())
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-5)
+    # default grid (num_rays -> OpticStudio-like sampling, odd pupil size)
+    want2 = _numpy_reference(be, _cooke,
+                             lambda lens: _np(be, FFTPSF(lens, (0.0, 0.0), 0.55, num_rays=40).psf))
+    got2 = _np(be, FFTPSF(_cooke(), (0.0, 0.0), 0.55, num_rays=40).psf)
+    np.testing.assert_allclose(got2, want2, rtol=0, atol=1e-4 * want2.max())
+
+
+def test_seams_fall_back_where_the_fused_path_does_not_apply(seams):
+    """Polarised system, tilted image surface in local coordinates, fitted reference
+    strategies, autograd: the reference's own method runs (and still traces through the
+    drop-in's Optic.trace); results equal the NumPy backend's."""
+    be, stats = seams
+    from optiland import analysis
+    from optiland.wavefront import Wavefront
+    from tests import _live
+
+    def spot_rms(lens):
+        return [[float(_np(be, v)) for v in f]
+                for f in analysis.SpotDiagram(lens, num_rings=4).rms_spot_radius()]
+
+    # polarised: ol_trace_spot refuses -> original method
+    build = lambda: _live.zernike_fresnel("unpolarized")  # noqa: E731
+    want = _numpy_reference(be, build, spot_rms)
+    got = spot_rms(build())
+    assert stats["spot"] == 0 and stats["spot_fallback"] > 0
+    np.testing.assert_allclose(got, want, rtol=1e-6)
+
+    # centroid wavefront strategy is not patched at all; chief-ray on fp32 falls back
+    def opd_centroid(lens):
+        w = Wavefront(lens, fields=[(0.0, 0.0)], wavelengths="primary", num_rays=6,
+                      strategy="centroid_sphere")
+        return _np(be, w.get_data((0.0, 0.0), lens.primary_wavelength).opd)
+
+    want = _numpy_reference(be, _cooke, opd_centroid)
+    before = stats["opd"]
+    got = opd_centroid(_cooke())
+    assert stats["opd"] == before
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+
+    # tilted image surface, local coordinates -> original method
+    def tilted():
+        lens = _cooke()
+        lens.surfaces[-1].geometry.cs.rx = 0.05
+        return lens
+
+    f0 = stats["spot_fallback"]
+    want = _numpy_reference(be, tilted, spot_rms)
+    got = spot_rms(tilted())
+    assert stats["spot_fallback"] > f0
+    np.testing.assert_allclose(got, want, rtol=1e-6)
+
+
+def test_seams_are_inert_without_the_drop_in(hip_on_cpu):
+    """The patches are class-wide; an optic the drop-in does not serve runs the original
+    methods (and `disable()` restores the classes)."""
+    be = hip_on_cpu
+    from optiland import analysis
+    from optiland.analysis.spot_diagram.core import SpotDiagram
+    from optiland_amd import analysis_seams, integration
+    orig = SpotDiagram._generate_field_data
+    lens = _cooke()
+    integration.install(lens, force=True)       # patches the classes, serves THIS optic only
+    assert SpotDiagram._generate_field_data is not orig
+    for k in analysis_seams.STATS:
+        analysis_seams.STATS[k] = 0
+    other = _cooke()                              # not installed, enable() not active
+    a = analysis.SpotDiagram(other, num_rings=3).rms_spot_radius()
+    assert analysis_seams.STATS["spot"] == 0 and analysis_seams.STATS["spot_fallback"] > 0
+    b = analysis.SpotDiagram(lens, num_rings=3).rms_spot_radius()
+    assert analysis_seams.STATS["spot"] > 0
+    np.testing.assert_allclose([[float(_np(be, v)) for v in f] for f in a],
+                               [[float(_np(be, v)) for v in f] for f in b], rtol=1e-7)
+    integration.uninstall(lens)
+    analysis_seams.disable()
+    assert SpotDiagram._generate_field_data is orig
