@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OL_ABI_VERSION 5
+#define OL_ABI_VERSION 6
 
 /* ---- error codes ------------------------------------------------------- */
 #define OL_OK 0
@@ -260,6 +260,14 @@ int ol_trace(const ol_system* sys, ol_dtype dt, int64_t n_rays,
 typedef struct ol_trace_extras {
   double* spot_slots;
   double cx, cy;
+  /* ABI 6.  First RECORDED surface: row 0 of `record` then holds surface
+   * `record_first_surface` and only last_surface - record_first_surface + 1 rows are
+   * written -- e.g. last_surface - 1 for a consumer that reads the image plane and the
+   * pre-interaction direction cosines only (RealRays.L0/M0/N0, real_rays.py:170-172), which
+   * is what the drop-in's lazy-record mode launches.  Values <= first_surface (0 in a
+   * zero-initialised struct) record every traced surface, as before.                    */
+  int32_t record_first_surface;
+  int32_t reserved_;
 } ol_trace_extras;
 
 int ol_trace_ex(const ol_system* sys, ol_dtype dt, int64_t n_rays,
@@ -343,6 +351,29 @@ typedef struct ol_raygen_inputs {
 int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n,
                      const ol_raygen_inputs* in, void* const out[8],
                      uint32_t* status, void* stream);
+
+/* ABI 6.  ol_generate_rays + ol_trace in ONE launch ("fuse generation into
+ * the trace kernel"): each lane builds its ray from the normalised pupil point and the
+ * launch-uniform field exactly like ol_generate_rays (same device code), records it as the
+ * object row and walks surfaces [0, num_surfaces).  Replaces the chain
+ * RayGenerator.generate_rays -> SurfaceGroup.trace of Optic.trace / trace_generic
+ * (raytrace/real_ray_tracer.py:58-154, rays/ray_generator.py:47-99) for one field point:
+ * no generator launch, and the object row is written once instead of written by one kernel
+ * and read back by the next.
+ *   in        px, py planes; launch-uniform field (hx0, hy0) and vignetting (vx0, vy0);
+ *             per-ray field / vignetting planes and apodized pupils are refused with
+ *             OL_EUNSUPPORTED (callers take ol_generate_rays + ol_trace for those)
+ *   record    required; rows as in ol_trace (row 0 = the generated rays unless
+ *             extras->record_first_surface says otherwise)
+ *   rays_out  NULL, or 8 planes receiving the final state (what OL_TRACE_WRITE_RAYS writes)
+ *   prt       NULL, or the 9- / 18-plane PRT buffer, WRITE-ONLY (starts from the identity)
+ *   flags     OL_TRACE_PRT_COMPLEX only; extras: record_first_surface only (no spot slots) */
+int ol_trace_generate(const ol_system* sys, ol_dtype dt, int64_t n_rays,
+                      const ol_raygen_params* p, const ol_raygen_inputs* in,
+                      int32_t wavelength_index, void* record, int64_t record_stride,
+                      void* const rays_out[8], void* prt, uint32_t flags, uint32_t* status,
+                      const ol_trace_extras* extras, void* stream);
+
 
 /* update_intensity epilogue for polarised traces (trace() only):
  * i = sum_fields |P E0|^2 * i0 / n_fields.  k0[3]: initial direction planes.  */

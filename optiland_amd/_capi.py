@@ -72,7 +72,8 @@ RAYGEN_CHECK_FIELD, RAYGEN_CHECK_PUPIL, RAYGEN_PRESCALE_PUPIL = 0x1, 0x2, 0x4
 
 
 class TraceExtras(C.Structure):
-    _fields_ = [("spot_slots", C.c_void_p), ("cx", C.c_double), ("cy", C.c_double)]
+    _fields_ = [("spot_slots", C.c_void_p), ("cx", C.c_double), ("cy", C.c_double),
+                ("record_first_surface", C.c_int32), ("reserved_", C.c_int32)]
 
 
 SPOT_SLOTS = 64
@@ -113,11 +114,12 @@ EXPORTS = (
     "ol_irradiance",
     "ol_trace_opd",
     "ol_pupil_fill",
+    "ol_trace_generate",
 )
 
 F32, F64 = 0, 1
 TUNE_RAYS_PER_THREAD, TUNE_COMPACT = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 OPD_MOMENTS = 12  # kOpdMoments / ol_trace_opd
 
 
@@ -195,10 +197,19 @@ def bind(lib, path: str = "?"):
     lib.ol_trace_opd.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, C.POINTER(vp), vp, vp, vp]
     lib.ol_pupil_fill.restype = C.c_int
     lib.ol_pupil_fill.argtypes = [i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
-    if lib.ol_abi_version() != ABI_VERSION:
+    have = lib.ol_abi_version()
+    if have == ABI_VERSION - 1 and os.environ.get("OPTILAND_HIP_ALLOW_ABI5") == "1":
+        # A/B runs against the round-2 library (tools/gpu_ab_r03.sh): ABI 5 lacks
+        # ol_trace_generate and the record_first_surface extra; the engine takes the
+        # two-launch path when the symbol is missing
+        return lib
+    if have != ABI_VERSION:
         raise HipExtensionError(
-            f"{path}: ABI version {lib.ol_abi_version()} != expected {ABI_VERSION}; rebuild"
+            f"{path}: ABI version {have} != expected {ABI_VERSION}; rebuild"
         )
+    lib.ol_trace_generate.restype = C.c_int
+    lib.ol_trace_generate.argtypes = [vp, C.c_int, i64, vp, vp, i32, vp, i64, C.POINTER(vp), vp,
+                                      u32, vp, vp, vp]
     return lib
 
 

@@ -22,8 +22,9 @@ packer accepts with device-side ray generation, unpolarised, (for the wavefront)
 and otherwise runs the reference's own method untouched, which then still traces through
 the drop-in's `Optic.trace`.  Results are the reference's own dataclasses.
 
-Observable difference to the un-patched classes: the analysis' last trace is not recorded
-on the `Surface` objects (nothing in the reference reads that after an analysis).
+What `Optic.trace()` would have left on the `Surface` objects -- the recorded arrays of the
+analysis' last trace -- is registered as a PENDING record (integration.py: lazy records) and
+produced by a record-all re-run of that trace if anybody reads it.
 """
 
 from __future__ import annotations
@@ -58,7 +59,14 @@ def _front(optic, wavelength, need_fp64=False):
         return None
     if not hasattr(front.engine, "trace_spot"):
         return None
+    comp.last_path = "hip"  # (introspection, as after an intercepted Optic.trace)
     return front, table
+
+
+def _register(optic, front, table, launch):
+    from . import integration as ig
+
+    ig.register_pending_record(optic, table, front.engine, front.dtype, launch)
 
 
 def _scalar(v):
@@ -86,8 +94,11 @@ def _image_hits(optic, field, wavelength, num_rays, distribution):
     if got is None:
         return None
     front, table = got
-    mom, hits = front.trace_spot(hx, hy, wavelength, num_rays, _dist_arg(distribution),
-                                 hits=True)
+    dist = _dist_arg(distribution)
+    mom, hits = front.trace_spot(hx, hy, wavelength, num_rays, dist, hits=True)
+    # what Optic.trace() would have left on the Surface objects, produced on first read
+    px, py = front.last_spot_pupil
+    _register(optic, front, table, (hx, hy, px, py, front._vig_scalar(hx, hy), wavelength, 0))
     return front, table, mom.cpu().numpy(), hits
 
 
@@ -213,6 +224,7 @@ def _fused_wavefront(self, field, wavelength):
     wl, _ = front._wavelength_index(w)
     opd, inten, pupil, mom = front.engine.trace_opd(
         params, px, py, wl, field=(hx, hy), vig=front._vig_scalar(hx, hy), want_pupil=True)
+    _register(self.optic, front, table, (hx, hy, px, py, front._vig_scalar(hx, hy), w, 0))
     from optiland.wavefront.wavefront_data import WavefrontData
 
     data = WavefrontData(pupil_x=pupil[0], pupil_y=pupil[1], pupil_z=pupil[2], opd=opd,

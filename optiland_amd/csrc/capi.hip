@@ -368,11 +368,13 @@ int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* c
   a.n_wl = sys->n_wl;
   a.wl = wl;
   a.flags = flags & 0xffu;  // public flags only
+  a.record_from = (extras && extras->record_first_surface > first) ? extras->record_first_surface
+                                                                     : first;
   if (!prt) a.flags &= ~ol::kTracePrtIdentity;
   // Zero-copy object row: when the caller's ray planes ARE row 0 of the record
   // block and the first surface only records (ObjectSurface.trace,
   // surfaces/object_surface.py:56-69), the kernel skips that row's stores.
-  if (record && sys->interaction[first] == OL_INTERACT_RECORD_ONLY) {
+  if (record && a.record_from == first && sys->interaction[first] == OL_INTERACT_RECORD_ONLY) {
     bool alias = true;
     for (int k = 0; k < 8; ++k)
       alias = alias && (static_cast<T*>(rays[k]) == static_cast<T*>(record) + k * record_stride);
@@ -432,6 +434,41 @@ int do_generate_rays(const ol_raygen_params* p, int64_t n, const ol_raygen_input
   for (int k = 0; k < 8; ++k) o[k] = static_cast<T*>(out[k]);
   hipError_t e = ol::launch_raygen<T>(raygen_dev(p), ri, n, o, status, stream);
   if (e != hipSuccess) return fail(OL_EHIP, "raygen launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
+template <typename T>
+int do_trace_generate(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
+                      const ol_raygen_params* p, const ol_raygen_inputs* in, int32_t wl,
+                      void* record, int64_t record_stride, void* const rays_out[8], void* prt,
+                      uint32_t flags, uint32_t* status, const ol_trace_extras* extras,
+                      hipStream_t stream) {
+  ol::TraceArgs<T> a{};
+  bool al = true;
+  if (int rc = convert_inputs<T>("ol_trace_generate", in, status, a.in, al)) return rc;
+  if (n == 0) return OL_OK;
+  a.surf = tab.surf;
+  a.cold = tab.cold;
+  a.optics = tab.optics;
+  a.coeffs = tab.coeffs;
+  const ol::RaygenDev rg = raygen_dev(p);
+  a.rgc = ol::RaygenConsts<T>(rg);
+  ol::uniform_field_tangents<T>(rg, a.in);
+  for (int k = 0; k < 8; ++k) a.rays[k] = rays_out ? static_cast<T*>(rays_out[k]) : nullptr;
+  a.record = static_cast<T*>(record);
+  a.prt = static_cast<T*>(prt);
+  a.status = status;
+  a.n = n;
+  a.record_stride = record_stride;
+  a.first = 0;
+  a.last = sys->n_surf - 1;
+  a.record_from = (extras && extras->record_first_surface > 0) ? extras->record_first_surface : 0;
+  a.n_wl = sys->n_wl;
+  a.wl = wl;
+  a.flags = (flags & ol::kTracePrtComplex) | (prt ? ol::kTracePrtIdentity : 0u) |
+            (rays_out ? ol::kTraceWriteRays : 0u);
+  hipError_t e = ol::launch_trace_generate<T>(a, newton_family(sys, 0, sys->n_surf - 1), stream);
+  if (e != hipSuccess) return fail(OL_EHIP, "trace launch failed: %s", hipGetErrorString(e));
   return OL_OK;
 }
 
@@ -799,6 +836,9 @@ int ol_trace_ex(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const r
                 (long long)n_rays);
   if (!record && !(flags & OL_TRACE_WRITE_RAYS) && !prt && !(extras && extras->spot_slots))
     return fail(OL_EINVAL, "ol_trace: nothing to write (no record, no OL_TRACE_WRITE_RAYS)");
+  if (extras && extras->record_first_surface > last_surface)
+    return fail(OL_EINVAL, "ol_trace_ex: record_first_surface %d beyond last_surface %d",
+                extras->record_first_surface, last_surface);
   if (prt && extras && extras->spot_slots)
     return fail(OL_EINVAL, "ol_trace_ex: the spot epilogue is for unpolarised traces (the "
                            "polarised intensity needs ol_polarized_intensity first)");
@@ -822,6 +862,64 @@ int ol_trace_ex(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const r
                            prt, first_surface, last_surface, flags, status, extras, st);
   return do_trace<double>(sys, sys->f64, n_rays, rays, wavelength_index, record, record_stride,
                           prt, first_surface, last_surface, flags, status, extras, st);
+}
+
+int ol_trace_generate(const ol_system* sys, ol_dtype dt, int64_t n_rays,
+                      const ol_raygen_params* p, const ol_raygen_inputs* in,
+                      int32_t wavelength_index, void* record, int64_t record_stride,
+                      void* const rays_out[8], void* prt, uint32_t flags, uint32_t* status,
+                      const ol_trace_extras* extras, void* stream) {
+  if (!sys) return fail(OL_EINVAL, "ol_trace_generate: system is NULL");
+  if (dt != OL_F32 && dt != OL_F64)
+    return fail(OL_EINVAL, "ol_trace_generate: bad dtype %d", (int)dt);
+  if (!p || !in) return fail(OL_EINVAL, "ol_trace_generate: NULL argument");
+  if (n_rays < 0) return fail(OL_EINVAL, "ol_trace_generate: negative ray count");
+  if (wavelength_index < 0 || wavelength_index >= sys->n_wl)
+    return fail(OL_EINVAL, "ol_trace_generate: wavelength index %d outside [0, %d)",
+                wavelength_index, sys->n_wl);
+  if (in->hx || in->hy || in->vx || in->vy)
+    return fail(OL_EUNSUPPORTED, "ol_trace_generate: one field point per launch (per-ray field "
+                                 "/ vignetting planes take ol_generate_rays + ol_trace)");
+  if (p->apod_kind != OL_APOD_NONE)
+    return fail(OL_EUNSUPPORTED, "ol_trace_generate: apodized pupils take ol_generate_rays + "
+                                 "ol_trace");
+  if (extras && extras->spot_slots)
+    return fail(OL_EINVAL, "ol_trace_generate: no spot epilogue (use ol_trace_spot)");
+  if (!record) return fail(OL_EINVAL, "ol_trace_generate: record is NULL");
+  if (record_stride < n_rays)
+    return fail(OL_EINVAL, "ol_trace_generate: record_stride %lld < n_rays %lld",
+                (long long)record_stride, (long long)n_rays);
+  if (extras && extras->record_first_surface >= sys->n_surf)
+    return fail(OL_EINVAL, "ol_trace_generate: record_first_surface %d outside [0, %d)",
+                extras->record_first_surface, sys->n_surf);
+  if (rays_out)
+    for (int k = 0; k < 8; ++k)
+      if (!rays_out[k]) return fail(OL_EINVAL, "ol_trace_generate: rays_out[%d] is NULL", k);
+  if (!prt) {
+    for (int32_t s = 0; s < sys->n_surf; ++s)
+      if (sys->coating[s] >= OL_COAT_FRESNEL)
+        return fail(OL_EINVAL,
+                    "Polarization must be set when surfaces have polarization-dependent "
+                    "coatings.");
+  }
+  if (prt && !(flags & OL_TRACE_PRT_COMPLEX)) {
+    for (int32_t s = 0; s < sys->n_surf; ++s)
+      if (sys->coating[s] == OL_COAT_RETARDER)
+        return fail(OL_EINVAL, "ol_trace_generate: surface %d is a retarder (complex Jones "
+                               "matrix): pass an 18-plane prt with OL_TRACE_PRT_COMPLEX", s);
+  }
+  if (n_rays > 0) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != sys->device)
+      return fail(OL_EINVAL, "ol_trace_generate: current HIP device %d is not the system's "
+                             "device %d", cur, sys->device);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dt == OL_F32)
+    return do_trace_generate<float>(sys, sys->f32, n_rays, p, in, wavelength_index, record,
+                                    record_stride, rays_out, prt, flags, status, extras, st);
+  return do_trace_generate<double>(sys, sys->f64, n_rays, p, in, wavelength_index, record,
+                                   record_stride, rays_out, prt, flags, status, extras, st);
 }
 
 int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n,

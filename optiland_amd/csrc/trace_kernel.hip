@@ -58,36 +58,44 @@
 #ifndef OL_FUSED_NR_PREFETCH
 #define OL_FUSED_NR_PREFETCH 1
 #endif
-// 1 (default): the Newton-Raphson kernels re-read table rows and kernel arguments where they
-// are used (SurfFetched / kernargs()) instead of holding them in SGPRs; 0 = round-2 form
-// (hot block by value), kept as the A/B handle (tools/build_variants.py)
-#ifndef OL_NR_FETCH
-#define OL_NR_FETCH 1
+// How much a kernel re-reads at the point of use instead of holding it in SGPRs from its
+// prologue ("fetch level"):
+//   0  nothing: argument block and the current surface's table rows by value (round-2 form);
+//   1  the ARGUMENT BLOCK (plane pointers, strides, counts, generator constants) is read from
+//      the kernarg segment by the phase that needs it (kernargs(), arg_view<true>);
+//   2  ... and the TABLE ROWS too: every phase of the surface body re-reads the few fields it
+//      uses (SurfFetched), nothing of a surface is live across the Newton loop.
+// Every level has 0-6 static SGPR spills where level 0 had 50-320 in the fp64 Newton / fused
+// kernels, but the extra scalar-load round trips cost where the kernel was not short of
+// SGPRs to begin with: the levels below are the ones that won the interleaved A/Bs
+// (profiles/r03_ab_fetch_levels.txt).  Per kernel class, overridable for A/B builds.
+#ifndef OL_FETCH_NR_F32
+#define OL_FETCH_NR_F32 2
 #endif
-// fp64 instances of the fused spot / OPD kernels without a Newton surface: fetch as well
-// (a wave has the same ~100 SGPRs for values twice as wide)
-#ifndef OL_FETCH_F64
-#define OL_FETCH_F64 1
+#ifndef OL_FETCH_NR_F64
+#define OL_FETCH_NR_F64 2
 #endif
-// the fp32 conic-only spot kernels: fetch too (0 SGPR spills instead of 17-43, 40 instead of
-// 52 VGPRs at one ray per lane) -- A/B handle
-#ifndef OL_FETCH_LEAN_SPOT
-#define OL_FETCH_LEAN_SPOT 1
+#ifndef OL_FETCH_LEAN_F64   // fused spot / OPD kernels without a Newton surface, fp64
+#define OL_FETCH_LEAN_F64 1
 #endif
-#ifndef OL_EXP_A
-#define OL_EXP_A 0
-#endif
-#ifndef OL_EXP_B
-#define OL_EXP_B 0
-#endif
-#ifndef OL_EXP_C
-#define OL_EXP_C 0
+#ifndef OL_FETCH_LEAN_F32   // fused spot kernels without a Newton surface, fp32
+#define OL_FETCH_LEAN_F32 0
 #endif
 
 #include "surface_math.h"
 
 namespace ol {
 
+// fetch level of a kernel instance (see the OL_FETCH_* knobs above); `fused` = the spot / OPD
+// kernels (the plain trace kernel without a Newton surface is always level 0: its hot block
+// is one prefetched s_load_dwordx16 and it spills nothing)
+template <typename T, int NR, bool FUSED>
+constexpr int fetch_level() {
+  if (OL_TABLE_IN_LDS) return 0;
+  if (NR != 0) return sizeof(T) == 4 ? OL_FETCH_NR_F32 : OL_FETCH_NR_F64;
+  if (!FUSED) return 0;
+  return sizeof(T) == 4 ? OL_FETCH_LEAN_F32 : OL_FETCH_LEAN_F64;
+}
 
 // The lean fp32 configuration -- four rays per lane, conic-only range, no
 // polarisation -- runs on packed pairs: two f32x2 rays instead of four scalar ones.
@@ -390,7 +398,12 @@ struct WavesPerEu {
                  : 1);
 };
 
-template <typename T, int RPT, bool RECORD, int POLK, int NR, bool SPOT>
+// GEN: the rays are GENERATED in the prologue from normalised pupil planes and a
+// launch-uniform field (raygen_device.h, the arithmetic of ol_generate_rays) instead of being
+// read from eight planes -- ol_trace_generate, the record-all path of Optic.trace() in one
+// launch: no separate generator launch, and the object row is written once instead of
+// written by one kernel and read back by the next.
+template <typename T, int RPT, bool RECORD, int POLK, int NR, bool SPOT, bool GEN = false>
 __global__ __launch_bounds__(kTraceBlock)
 __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
@@ -442,6 +455,27 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
   Ray<V> r[NV];
   constexpr int NPRT = POLK == 2 ? 18 : 9;  // PRT planes (real, then imaginary)
   Prt<T, POLK> P[POLK ? RPT : 1];
+  uint32_t status = 0;
+  if constexpr (GEN) {
+    static_assert(RPT == 1 && !SPOT, "the generating prologue is one ray per lane");
+    const auto A0 = arg_view<(fetch_level<T, NR, false>() >= 1), T>(a);
+    const auto& in_ = A0->in;
+    T px = base.at(in_.px)[0], py = base.at(in_.py)[0];
+    T vx = in_.vx0, vy = in_.vy0, o[6];
+    raygen_pupil<T>(in_.flags, vx, vy, px, py, status);
+    const RaygenConsts<T> c = consts_of(&A0->rgc);
+    raygen_one<T>(c, in_.tx0, in_.ty0, px, py, vx, vy, o);
+    Ray<T> q;
+    q.x = o[0]; q.y = o[1]; q.z = o[2];
+    q.L = o[3]; q.M = o[4]; q.N = o[5];
+    q.i = T(1);  // (apodized pupils take the two-launch path: ol_generate_rays + ol_trace)
+    q.opd = T(0);
+    LP::put(r, 0, q);
+    if constexpr (POLK != 0) {
+#pragma unroll
+      for (int e = 0; e < NPRT; ++e) P[0].m[e] = (e == 0 || e == 4 || e == 8) ? T(1) : T(0);
+    }
+  } else
   {
     // All plane loads are issued back to back under ONE branch (full vector vs
     // ragged tail): with the branch inside each plane's load the compiler placed
@@ -500,18 +534,18 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
     }
   }
 
-  uint32_t status = 0;
   bool is_global = true;  // frame of the state held in r[]
-  bool prt_fresh = POLK != 0 && (a.flags & kTracePrtIdentity) != 0;
+  bool prt_fresh = POLK != 0 && (GEN || (a.flags & kTracePrtIdentity) != 0);
   // Newton-Raphson ranges: table rows re-read phase by phase (SurfFetched), kernel arguments
   // re-read from the kernarg segment where they are used -- these kernels are short of SGPRs
-  constexpr bool kFetch = NR != 0 && !OL_TABLE_IN_LDS && OL_NR_FETCH;
+  constexpr bool kFetch = fetch_level<T, NR, false>() >= 2;      // table rows
+  constexpr bool kFetchArgs = fetch_level<T, NR, false>() >= 1;  // argument block
   const cptr<T> coeffs_c = as_const(coeff_tab);
   DevSurf<T> last_traced;
   last_traced.cold = as_const(cold_tab);
   int last_idx = a.first;  // kFetch: the surface whose frame r[] is held in
   auto to_global_now = [&](Ray<V> (&gv)[NV]) {
-    if constexpr (kFetch && !OL_EXP_B) {
+    if constexpr (kFetch) {
       const DevSurf<T> lt = fetched_surface<T, TraceArgs<T>>(last_idx).surf();
 #pragma unroll
       for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(lt, r[j]);
@@ -532,19 +566,14 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
   if constexpr (!kFetch) cur = surf_tab[a.first];
 #endif
   const int first = a.first, last = a.last;
+  const int rec_from = a.record_from > first ? a.record_from : first;
   for (int s = first; s <= last; ++s) {
     if constexpr (kFetch) {
-#if OL_EXP_C
-      const SurfFetched<T> h{as_const(surf_tab) + s, as_const(cold_tab) + s,
-                             as_const(optics_tab) + (s * a.n_wl + a.wl)};
-#else
       const SurfFetched<T> h = fetched_surface<T, TraceArgs<T>>(s);
-#endif
       if (refresh(h.hot)->interaction != kRecordOnly) {
         surface_step<V, NV, POLK, NR>(h, refresh(coeffs_c), is_global, r, P, status, prt_fresh);
         is_global = false;
         last_idx = s;
-        if constexpr (OL_EXP_B != 0) last_traced = h.surf();
       }
     } else {
       DevSurf<T> S;
@@ -571,11 +600,11 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
         last_traced = S;
       }
     }
-    if constexpr (RECORD) {
+    if (RECORD && s >= rec_from) {
       T* record;
       int64_t stride;
       uint32_t flags;
-      if constexpr (kFetch && !OL_EXP_A) {
+      if constexpr (kFetchArgs) {
         const auto ka = kernargs<T, TraceArgs<T>>();
         record = ka->a.record;
         stride = ka->a.record_stride;
@@ -585,7 +614,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
         stride = a.record_stride;
         flags = a.flags;
       }
-      T* row = record + (int64_t)(s - first) * 8 * stride;
+      T* row = record + (int64_t)(s - rec_from) * 8 * stride;
       if (s == first && (flags & kTraceRow0IsInput)) {
         // the caller generated the rays straight into row 0 of the record block
         // (the object surface only records its input): nothing to write
@@ -749,6 +778,33 @@ static hipError_t launch_pair(const TraceArgs<T>& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// ol_trace_generate: one ray per lane, recording, no spot epilogue
+template <typename T, int NR>
+static hipError_t launch_gen_nr(const TraceArgs<T>& a, hipStream_t stream) {
+  const int64_t blocks = (a.n + kTraceBlock - 1) / kTraceBlock;
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  dim3 grid((unsigned)blocks), block(kTraceBlock);
+  const int polk = a.prt == nullptr ? 0 : ((a.flags & kTracePrtComplex) ? 2 : 1);
+#define OL_LAUNCH_G(P)                                                                       \
+  hipLaunchKernelGGL((trace_kernel<T, 1, true, P, NR, false, true>), grid, block, 0, stream, \
+                     a.surf, a.cold, a.optics, a.coeffs, a)
+  if (polk == 2) OL_LAUNCH_G(2);
+  else if (polk == 1) OL_LAUNCH_G(1);
+  else OL_LAUNCH_G(0);
+#undef OL_LAUNCH_G
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_trace_generate(const TraceArgs<T>& a_in, int nr_family, hipStream_t stream) {
+  TraceArgs<T> a = a_in;
+  if (nr_family == kNrNone) return launch_gen_nr<T, 0>(a, stream);
+  if (nr_family == kNrZernike) return launch_gen_nr<T, kNrZernike>(a, stream);
+  if (nr_family == kNrEvenAsphere) return launch_gen_nr<T, kNrEvenAsphere>(a, stream);
+  return launch_gen_nr<T, 1>(a, stream);
+}
+
 #if OL_TRACE_TU == 0 || OL_TRACE_TU == 1
 Tuning& tuning() {
   static Tuning t = [] {
@@ -800,9 +856,11 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, int nr_family,
 #endif
 #if OL_TRACE_TU == 0 || OL_TRACE_TU == 1
 template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, int, hipStream_t);
+template hipError_t launch_trace_generate<float>(const TraceArgs<float>&, int, hipStream_t);
 #endif
 #if OL_TRACE_TU == 0 || OL_TRACE_TU == 2
 template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, int, hipStream_t);
+template hipError_t launch_trace_generate<double>(const TraceArgs<double>&, int, hipStream_t);
 #endif
 
 // --------------------------------------------------------------------------
@@ -830,8 +888,8 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
     SpotArgs<T> a) {
   // Newton ranges (and every fp64 instance): nothing of the argument block is held across the
   // surface loop -- each phase of a tile reads what it needs from the kernarg segment
-  constexpr bool kFetch =
-      OL_NR_FETCH && (NR != 0 || (OL_FETCH_F64 && sizeof(T) == 8) || OL_FETCH_LEAN_SPOT);
+  constexpr bool kFetch = fetch_level<T, NR, true>() >= 1;      // argument block
+  constexpr bool kFetchRows = fetch_level<T, NR, true>() >= 2;  // table rows
   // FIELDP: per-ray field planes.  A template parameter because the per-ray
   // double-precision tangent (tan_deg) would otherwise set the register budget of
   // the common launch-uniform-field case as well.
@@ -929,7 +987,7 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
     last_traced.cold = as_const(cold_tab);
     Prt<T, 0> P[1];
     Ray<V> gv[NV];
-    if constexpr (kFetch) {
+    if constexpr (kFetchRows) {
       // table rows and loop bounds re-read where they are used (see trace_kernel); nothing
       // of the argument block is carried through the surface loop
       int last_idx = 0;
@@ -1073,7 +1131,8 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
     OpdArgs<T> a) {
   // every instance is fp64: nothing of the argument block is held across the surface loop,
   // each phase of a ray reads what it needs from the kernarg segment (see spot_trace_kernel)
-  constexpr bool kFetch = OL_NR_FETCH && (NR != 0 || (OL_FETCH_F64 && sizeof(T) == 8));
+  constexpr bool kFetch = fetch_level<T, NR, true>() >= 1;      // argument block
+  constexpr bool kFetchRows = fetch_level<T, NR, true>() >= 2;  // table rows
   uint32_t status = 0;
   bool prt_fresh = false;
   double s[kOpdMoments];
@@ -1102,7 +1161,7 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
     last_traced.cold = as_const(cold_tab);
     Prt<T, 0> P[1];
     Ray<T> g;
-    if constexpr (kFetch) {
+    if constexpr (kFetchRows) {
       int last_idx = 0;
       const int first = kernargs<T, OpdArgs<T>>()->a.first;
       for (int sidx = first; sidx <= kernargs<T, OpdArgs<T>>()->a.last; ++sidx) {

@@ -18,33 +18,6 @@ constexpr uint32_t kTracePrtComplex = 0x4u;  // OL_TRACE_PRT_COMPLEX
 constexpr uint32_t kTracePrtIdentity = 0x8u;  // OL_TRACE_PRT_IDENTITY
 constexpr uint32_t kTraceRow0IsInput = 0x100u;  // internal: rays[] ARE record row 0
 
-template <typename T>
-struct TraceArgs {
-  const DevSurfHot<T>* surf;   // [n_surf] hot blocks
-  const DevSurfCold<T>* cold;  // [n_surf] cold blocks
-  const DevOptics<T>* optics;  // [n_surf][n_wl]
-  const T* coeffs;             // coefficient blocks
-  T* rays[8];                  // x,y,z,L,M,N,i,opd planes
-  T* record;                   // rows x 8 x record_stride or nullptr
-  T* prt;                      // 9 x n (18 x n with kTracePrtComplex) or nullptr
-  uint32_t* status;            // device word or nullptr
-  double* spot;                // [spot_slots][8] doubles (epilogue moments) or nullptr
-  double cx, cy;               // centre of the epilogue moments
-  int32_t spot_slots;
-  int64_t n;
-  int64_t record_stride;
-  int32_t first, last;
-  int32_t n_wl, wl;
-  uint32_t flags;
-};
-
-// nr_family: 0 = no Newton-Raphson geometry in the traced range (lean kernel), 1 = generic
-// Newton kernel, 3 / 4 = every Newton surface of the range is a Zernike surface / an even
-// asphere (single-family instantiations, surface_math.h kNr*)
-template <typename T>
-hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, int nr_family,
-                        hipStream_t stream);
-
 // process-wide tuning knobs (ol_set_tuning)
 struct Tuning {
   int rays_per_thread = 0;  // 0 = default, 1 = one ray per lane, 2 = force vector
@@ -119,6 +92,42 @@ inline void uniform_field_tangents(const RaygenDev& rg, RaygenIn<T>& in) {
     in.ty0 = (T)tan((double)(maxf * in.hy0) * 0.017453292519943295);
   }
 }
+
+template <typename T>
+struct TraceArgs {
+  const DevSurfHot<T>* surf;   // [n_surf] hot blocks
+  const DevSurfCold<T>* cold;  // [n_surf] cold blocks
+  const DevOptics<T>* optics;  // [n_surf][n_wl]
+  const T* coeffs;             // coefficient blocks
+  T* rays[8];                  // x,y,z,L,M,N,i,opd planes
+  T* record;                   // rows x 8 x record_stride or nullptr
+  T* prt;                      // 9 x n (18 x n with kTracePrtComplex) or nullptr
+  uint32_t* status;            // device word or nullptr
+  double* spot;                // [spot_slots][8] doubles (epilogue moments) or nullptr
+  double cx, cy;               // centre of the epilogue moments
+  int32_t spot_slots;
+  int64_t n;
+  int64_t record_stride;
+  int32_t first, last;
+  int32_t n_wl, wl;
+  uint32_t flags;
+  int32_t record_from;   // first RECORDED surface (row 0 of `record`); <= first: all of them
+  // generating launches (ol_trace_generate; trace_kernel<..., GEN = true>): the normalised
+  // coordinates and the generator constants instead of rays[]
+  RaygenIn<T> in;
+  RaygenConsts<T> rgc;
+};
+
+// nr_family: 0 = no Newton-Raphson geometry in the traced range (lean kernel), 1 = generic
+// Newton kernel, 3 / 4 = every Newton surface of the range is a Zernike surface / an even
+// asphere (single-family instantiations, surface_math.h kNr*)
+template <typename T>
+hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, int nr_family,
+                        hipStream_t stream);
+// the generating variant: a.in / a.rgc instead of a.rays (one ray per lane, record-all form)
+template <typename T>
+hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, hipStream_t stream);
+
 
 template <typename T>
 hipError_t launch_raygen(const RaygenDev& p, const RaygenIn<T>& in, int64_t n, T* const out[8],

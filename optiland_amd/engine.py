@@ -151,7 +151,7 @@ class HipSystem:
               first: int = 0, last: int | None = None, write_rays: bool | None = None,
               check_status: bool = True, prt_identity: bool = False,
               defer_status: bool = False, zero_status: bool = True,
-              spot=None) -> TraceResult:
+              spot=None, record_first: int | None = None) -> TraceResult:
         """Launch the fused trace.
 
         rays: sequence of 8 contiguous 1-D device tensors (x,y,z,L,M,N,i,opd) of one
@@ -178,7 +178,11 @@ class HipSystem:
             if t.device != self.device or t.dtype != dtype or t.numel() != n or not t.is_contiguous():
                 raise ValueError("ray planes must be contiguous, same dtype/size, on the system's device")
         last = self.num_surfaces - 1 if last is None else last
-        rows = last - first + 1
+        # record_first (ABI 6): rows start at that surface instead of `first`
+        rec_first = first if record_first is None else max(int(record_first), first)
+        if rec_first > last:
+            raise ValueError("record_first beyond the last traced surface")
+        rows = last - rec_first + 1
         rec = None
         if record is True:
             rec = self.alloc_record(n, dtype, rows)
@@ -201,12 +205,16 @@ class HipSystem:
                 flags |= S.TRACE_PRT_IDENTITY
         ptrs = (C.c_void_p * 8)(*[t.data_ptr() for t in rays])
         extras = None
+        if rec_first != first:
+            extras = C.byref(_capi.TraceExtras(None, 0.0, 0.0, rec_first, 0))
         if spot is not None:
+            if rec_first != first:
+                raise ValueError("spot epilogue and record_first cannot be combined")
             slots, cx, cy = spot
             if slots.dtype != torch.float64 or slots.numel() != 8 * _capi.SPOT_SLOTS \
                     or slots.device != self.device or not slots.is_contiguous():
                 raise ValueError("spot slots must come from alloc_spot_slots()")
-            extras = C.byref(_capi.TraceExtras(slots.data_ptr(), float(cx), float(cy)))
+            extras = C.byref(_capi.TraceExtras(slots.data_ptr(), float(cx), float(cy), 0, 0))
         if check_status and zero_status:  # zero_status=False: keep bits set by ray generation
             self._status.zero_()
         with self._device_ctx():
@@ -224,6 +232,75 @@ class HipSystem:
         status = int(self._status.item()) if (check_status and not defer_status) else 0
         self.raise_for_status(status)
         return TraceResult(n, rays, rec, prt, status, first, last)
+
+    def can_trace_generate(self) -> bool:
+        """`ol_trace_generate` present (ABI 6) and the table carries generator scalars without
+        a pupil apodization (those take the two-launch path)."""
+        rg = self.table.raygen
+        return bool(rg) and int(rg.get("apod_kind", 0)) == 0 and hasattr(self.lib,
+                                                                         "ol_trace_generate")
+
+    def trace_generate(self, px, py, wavelength_index: int = 0, *, field, vig=(1.0, 1.0),
+                       record=True, record_first: int = 0, prt: torch.Tensor | None = None,
+                       rays_out=None, flags: int = 0, zero_status: bool = True,
+                       defer_status: bool = False) -> TraceResult:
+        """`ol_trace_generate`: rays of ONE field point generated from the normalised pupil
+        planes and traced through the whole system in one launch.  record: True (allocate)
+        or a preallocated (rows, 8, stride) block; rows start at surface `record_first`
+        (0 = the generated rays themselves as the object row).  prt: write-only (9 | 18, n)
+        buffer of a polarised trace.  rays_out: optional 8 planes for the final state.
+        flags: `_capi.RAYGEN_*` (pupil range check, trace_generic pre-scaling).
+        The result's `rays` are the planes of record row 0 when that row is recorded."""
+        p = self._raygen_params()
+        n = int(px.numel())
+        dtype = px.dtype
+        if dtype not in _DT:
+            raise TypeError(f"unsupported ray dtype {dtype}")
+        last = self.num_surfaces - 1
+        record_first = int(record_first)
+        if not 0 <= record_first <= last:
+            raise ValueError("record_first outside the surface range")
+        rows = last - record_first + 1
+        if record is True:
+            rec = self.alloc_record(n, dtype, rows)
+        else:
+            rec = record
+            if not isinstance(rec, torch.Tensor) or rec.dtype != dtype or rec.dim() != 3 \
+                    or rec.shape[0] < rows or rec.shape[1] != 8 or rec.shape[2] < n \
+                    or not rec.is_contiguous():
+                raise ValueError("record must be a contiguous (rows, 8, stride>=n) tensor")
+        tflags = 0
+        if prt is not None:
+            if prt.dtype != dtype or prt.dim() != 2 or prt.shape[0] not in (9, 18) \
+                    or prt.shape[1] != n or not prt.is_contiguous():
+                raise ValueError("prt must be a contiguous (9, n) [real] or (18, n) "
+                                 "[real + imaginary] tensor of the ray dtype")
+            if prt.shape[0] == 18:
+                tflags |= S.TRACE_PRT_COMPLEX
+        rays0 = list(rec[0, :, :n].unbind(0)) if record_first == 0 else None
+        res = TraceResult(n, rays0, rec, prt, 0, record_first, last)
+        if n == 0:
+            return res
+        inp, keep = self._raygen_inputs(float(field[0]), float(field[1]), px, py,
+                                        float(vig[0]), float(vig[1]), flags)
+        outp = None
+        if rays_out is not None:
+            self._check_out_planes(list(rays_out), n, dtype, "trace_generate")
+            outp = (C.c_void_p * 8)(*[t.data_ptr() for t in rays_out])
+        extras = C.byref(_capi.TraceExtras(None, 0.0, 0.0, record_first, 0))
+        if zero_status:
+            self._status.zero_()
+        with self._device_ctx():
+            rc = self.lib.ol_trace_generate(
+                self._handle, _DT[dtype], n, C.byref(p), C.byref(inp), int(wavelength_index),
+                rec.data_ptr(), int(rec.shape[2]), outp,
+                prt.data_ptr() if prt is not None else None, tflags,
+                self._status.data_ptr(), extras, self._stream())
+        self._check(rc, "ol_trace_generate")
+        if not defer_status:
+            res.status = int(self._status.item())
+            self.raise_for_status(res.status)
+        return res
 
     def alloc_spot_slots(self) -> torch.Tensor:
         """Zeroed [OL_SPOT_SLOTS, 8] float64 buffer for the spot epilogue of `trace`."""

@@ -120,6 +120,133 @@ def _bind_surfaces(surfaces, res):
         surf.u = surf.aoi = empty  # Surface.reset(): only paraxial traces fill these
 
 
+# --------------------------------------------------------------------------------------
+# lazy per-surface records (SURVEY.md 7 step 4, 8b output contract)
+# --------------------------------------------------------------------------------------
+# A trace that nobody has asked the interior surfaces of runs record-LAST (the image plane and
+# the row before it: what the returned rays need); what it was launched with is remembered,
+# and the first read of ANY `Surface.x / .y / ... / .opd` afterwards re-runs it record-all and
+# binds every surface -- so `SurfaceGroup.x` (surface_group.py:108-153) and friends still see
+# exactly what `Surface._record_real` (standard_surface.py:260-274) would have stored.  The
+# fused analysis kernels (analysis_seams.py) register their traces the same way.
+# Implementation: data descriptors for the eight recorded attributes on the reference's
+# `Surface` class (values stay in the instance `__dict__`), and a weak side table
+# surface -> pending trace.  A write to any of the eight (Surface.reset(), a reference-side
+# trace) drops that surface's pending entry.
+_PENDING: "weakref.WeakKeyDictionary" = None  # created with the descriptors
+_RECORDED = ("x", "y", "z", "L", "M", "N", "intensity", "opd")
+
+
+class _RecordedPlane:
+    """Data descriptor of one recorded attribute of the reference's `Surface`."""
+
+    __slots__ = ("name",)
+
+    def __init__(self, name):
+        self.name = name
+
+    def __get__(self, obj, cls=None):
+        if obj is None:
+            return self
+        if _PENDING:
+            pend = _PENDING.get(obj)
+            if pend is not None:
+                pend.materialize()
+        try:
+            return obj.__dict__[self.name]
+        except KeyError:
+            raise AttributeError(self.name) from None
+
+    def __set__(self, obj, value):
+        if _PENDING:
+            _PENDING.pop(obj, None)
+        obj.__dict__[self.name] = value
+
+    def __delete__(self, obj):
+        if _PENDING:
+            _PENDING.pop(obj, None)
+        try:
+            del obj.__dict__[self.name]
+        except KeyError:
+            raise AttributeError(self.name) from None
+
+
+def _install_lazy_descriptors():
+    global _PENDING
+    import weakref
+
+    from optiland.surfaces.standard_surface import Surface
+
+    if _PENDING is None:
+        _PENDING = weakref.WeakKeyDictionary()
+    if not isinstance(Surface.__dict__.get("x"), _RecordedPlane):
+        for name in _RECORDED:
+            setattr(Surface, name, _RecordedPlane(name))
+
+
+def _remove_lazy_descriptors():
+    from optiland.surfaces.standard_surface import Surface
+
+    if _PENDING:
+        for pend in {id(p): p for p in list(_PENDING.values())}.values():
+            pend.materialize()  # nothing may stay unbound once the descriptors are gone
+    for name in _RECORDED:
+        if isinstance(Surface.__dict__.get(name), _RecordedPlane):
+            delattr(Surface, name)
+
+
+class _PendingRecord:
+    """One record-all trace that has not been run: the table it was launched on, the inputs
+    of the fused launch, the optic whose surfaces it belongs to."""
+
+    def __init__(self, optic, table, engine, dtype, launch):
+        import weakref
+
+        self.optic = weakref.ref(optic)
+        self.table, self.engine, self.dtype, self.launch = table, engine, dtype, launch
+        self.done = False
+
+    def materialize(self):
+        if self.done:
+            return
+        self.done = True
+        optic = self.optic()
+        if optic is None:
+            return
+        surfaces = optic.surfaces.surfaces
+        for s in surfaces:
+            _PENDING.pop(s, None)
+        if len(surfaces) != self.table.num_surfaces:
+            return  # the optic was rebuilt in between: nothing sensible to bind
+        eng = self.engine
+        if getattr(eng, "_handle", True) is None:  # evicted and closed meanwhile
+            eng = _tracer._make_engine(self.table, getattr(eng, "device", None))
+        front = _tracer.HipRayTracer(self.table, dtype=self.dtype, engine=eng)
+        hx, hy, px, py, vig, wavelength, flags = self.launch
+        front._run(hx, hy, px, py, vig, wavelength, False, flags)  # record-all, eager
+        _bind_surfaces(surfaces, front.surfaces._res)
+        front.surfaces._bind(None)
+        self.launch = None
+
+
+def register_pending_record(optic, table, engine, dtype, launch):
+    """Mark every surface of `optic` as "recorded state = this trace, not yet run".  The
+    instance attributes are emptied first (as `Surface.reset()` leaves them), so a copy of
+    the optic taken before anybody reads them sees a reset surface, never stale arrays."""
+    _install_lazy_descriptors()
+    pend = _PendingRecord(optic, table, engine, dtype, launch)
+    empty = None
+    for surf in optic.surfaces.surfaces:
+        if empty is None:
+            old = surf.__dict__.get("x")
+            empty = _empty(dtype, old.device if isinstance(old, torch.Tensor) else "cpu")
+        for name in _RECORDED:
+            surf.__dict__[name] = empty
+        surf.__dict__["u"] = surf.__dict__["aoi"] = empty
+        _PENDING[surf] = pend
+    return pend
+
+
 def _make_tracer_class():
     global _TRACER_CLASS
     if _TRACER_CLASS is not None:
@@ -143,6 +270,9 @@ def _make_tracer_class():
             super().__init__(optic)
             self._hip_device = device
             self._hip_force = force  # tests: intercept regardless of backend/device
+            # True: traces of ONE field point run record-last and the per-surface arrays are
+            # materialised on first access (see the lazy-record block above)
+            self._hip_lazy = False
             # packed-table fingerprint -> (engine, table, {dtype: HipRayTracer}): analyses
             # alternate between the optic's wavelengths call by call, so the last few
             # device tables stay alive instead of being re-created for every trace
@@ -249,14 +379,20 @@ def _make_tracer_class():
             if front is None:
                 front = fronts[dtype] = _tracer.HipRayTracer(table, dtype=dtype, engine=eng)
             front.ray_aiming_config = self.ray_aiming_config
+            front.lazy_records = self._hip_lazy
             return front, table
 
         # ---------------------------------------------------------------- trace
         def _finish(self, front, table, mine, wavelength, update_intensity):
             """Hand the device results over in the reference's own classes: the returned
             `RealRays` / `PolarizedRays` and every `Surface`'s recorded arrays."""
-            res = front.surfaces._res
-            _bind_surfaces(self.optic.surfaces.surfaces, res)
+            lazy = front.last_was_lazy
+            res = front._last_res if lazy else front.surfaces._res
+            if lazy:
+                register_pending_record(self.optic, table, front.engine, front.dtype,
+                                        front.last_fused_launch)
+            else:
+                _bind_surfaces(self.optic.surfaces.surfaces, res)
             n, dtype, dev = res.n, res.record.dtype, res.record.device
             polarized = table.polarization is not None
             cls = RefPolarizedRays if polarized else RefRealRays
@@ -302,6 +438,7 @@ def _make_tracer_class():
             if front is None:
                 front = fronts[dtype] = _tracer.HipRayTracer(table, dtype=dtype, engine=eng)
             front.ray_aiming_config = self.ray_aiming_config
+            front.lazy_records = self._hip_lazy
             return front, table, memo[0], w
 
         def _run(self, wavelength, call, update_intensity, original):
@@ -388,7 +525,8 @@ def _make_tracer_class():
 # SurfaceGroup.trace(rays, skip) -- the seam for callers that bring their own rays
 # --------------------------------------------------------------------------------------
 _SG = {"device": None, "force": False, "count": 0, "fallbacks": 0, "foreign": 0}
-_ENABLE = {"device": None, "force": False}  # settings of the class-wide patch (enable())
+# settings of the class-wide patch (enable())
+_ENABLE = {"device": None, "force": False, "lazy": False}
 _PLANE_ATTRS = ("x", "y", "z", "L", "M", "N", "i", "opd")
 
 
@@ -577,6 +715,7 @@ def _companion(rt):
         comp.ray_generator = rt.ray_generator
         rt.__dict__["_hip_companion"] = comp
     comp._hip_device, comp._hip_force = _ENABLE["device"], _ENABLE["force"]
+    comp._hip_lazy = _ENABLE["lazy"]
     comp.ray_aiming_config = rt.ray_aiming_config
     return comp
 
@@ -597,7 +736,7 @@ def hip_tracer_of(optic):
     return None
 
 
-def enable(device=None, force=False, analyses=True):
+def enable(device=None, force=False, analyses=True, lazy_records=False):
     """Route EVERY `Optic` (existing and future) through the HIP path.
 
     Patches `RealRayTracer.trace / trace_generic` (raytrace/real_ray_tracer.py:58-154)
@@ -613,7 +752,14 @@ def enable(device=None, force=False, analyses=True):
     image-plane hits from `ol_trace_spot`, the chief-ray wavefront strategy its OPD map from
     `ol_trace_opd`, `ScalarFFTPSF` its pupil function from `ol_pupil_fill` -- no record
     block, no ray planes.  The one observable difference: after such an analysis the
-    `Surface` objects do not hold the recorded arrays of its last trace.
+    `Surface` objects hold that trace lazily (below).
+
+    `lazy_records` (default off): `Optic.trace` / `trace_generic` calls for ONE field point run
+    record-last -- the returned rays and nothing else touch HBM -- and the per-surface arrays
+    (`Surface.x ... .opd`, `SurfaceGroup.x ...`) are produced by re-running the trace
+    record-all on their first read.  A consumer that only uses the returned rays pays for
+    24 planes instead of 8 (S + 2); one that does read the surfaces pays one extra
+    record-last launch.  Results are identical either way.
     """
     cls = _make_tracer_class()
     from optiland.raytrace.real_ray_tracer import RealRayTracer
@@ -623,11 +769,11 @@ def enable(device=None, force=False, analyses=True):
     if getattr(RealRayTracer, "_hip_enabled", False):
         # already patched: a second call only updates the settings (device / force) that
         # future companions and the SurfaceGroup seam read
-        _ENABLE.update(device=device, force=force)
+        _ENABLE.update(device=device, force=force, lazy=bool(lazy_records))
         _SG.update(device=device, force=force)
         (analysis_seams.enable if analyses else analysis_seams.disable)()
         return
-    _ENABLE.update(device=device, force=force)
+    _ENABLE.update(device=device, force=force, lazy=bool(lazy_records))
     if analyses:
         analysis_seams.enable()
 
@@ -667,11 +813,14 @@ def disable():
         from . import analysis_seams
 
         analysis_seams.disable()
+        _ENABLE.update(lazy=False)
+        _remove_lazy_descriptors()
 
 
-def install(optic, device=None, force=False, analyses=True):
-    """Replace `optic.ray_tracer` with the HIP tracer (keeps the aiming config).  `analyses`:
-    see `enable()` -- the class-wide analysis seams only act on optics the drop-in serves."""
+def install(optic, device=None, force=False, analyses=True, lazy_records=False):
+    """Replace `optic.ray_tracer` with the HIP tracer (keeps the aiming config).  `analyses`,
+    `lazy_records`: see `enable()` -- the class-wide analysis seams only act on optics the
+    drop-in serves."""
     cls = _make_tracer_class()
     if analyses:
         from . import analysis_seams
@@ -679,6 +828,7 @@ def install(optic, device=None, force=False, analyses=True):
         analysis_seams.enable()
     old = optic.ray_tracer
     new = cls(optic, device=device, force=force)
+    new._hip_lazy = bool(lazy_records)
     new.ray_aiming_config = dict(getattr(old, "ray_aiming_config", new.ray_aiming_config))
     optic.ray_tracer = new
     # this optic's SurfaceGroup too: caller-built rays, and the surface loop of traces whose

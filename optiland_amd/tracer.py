@@ -71,6 +71,16 @@ class HipRayTracer:
         self.surfaces = RecordedSurfaces()
         self.ray_aiming_config = {"mode": "paraxial", "max_iter": 10, "tol": 1e-6}
         self.record_all = True  # drop-in semantics; False = image plane only
+        # one field point per call: ray generation fused into the trace launch
+        # (`ol_trace_generate`) when the engine offers it; False = always two launches
+        self.fuse_generate = True
+        # lazy records: a fused single-field launch records its last two surfaces only and
+        # remembers its inputs (`last_fused_launch`) so that the caller can re-run it
+        # record-all when somebody asks for the interior surfaces (integration.py)
+        self.lazy_records = False
+        self.last_fused_launch = None
+        self.last_was_lazy = False
+        self._last_res = None
         # True: launches return without the status read-back (the one sync of a call);
         # the caller does `check_status()` itself -- integration.py overlaps its change
         # check of the live optic with the kernels this way
@@ -194,11 +204,59 @@ class HipRayTracer:
         """hx, hy: floats (launch-uniform field) or device planes; px, py: device planes;
         vig: (1 - vx, 1 - vy) as floats or planes; flags: OL_RAYGEN_*."""
         n = int(px.numel())
+        eng = self.engine
+        self.last_fused_launch = None
+        self.last_was_lazy = False
+        uniform = isinstance(hx, float) and isinstance(hy, float) \
+            and isinstance(vig[0], float) and isinstance(vig[1], float)
+        can = getattr(eng, "can_trace_generate", None)
+        if self.fuse_generate and uniform and n > 0 and can is not None and can():
+            return self._run_fused(hx, hy, px, py, vig, wavelength, update_intensity, flags)
         record, rays = self._alloc_state(n)
-        self.engine.generate_rays(hx, hy, px, py, vig[0], vig[1], out=rays, flags=flags)
+        eng.generate_rays(hx, hy, px, py, vig[0], vig[1], out=rays, flags=flags)
         # the generator zeroes the status word only when it also writes range bits into it
         checked = bool(flags & (_capi.RAYGEN_CHECK_FIELD | _capi.RAYGEN_CHECK_PUPIL))
         return self._launch(rays, record, wavelength, update_intensity, zero_status=not checked)
+
+    def _run_fused(self, hx, hy, px, py, vig, wavelength, update_intensity, flags):
+        """One field point: generate + trace + record in ONE launch (`ol_trace_generate`).
+        `record_all`: every surface, row 0 = the generated rays (which are also the initial
+        direction cosines / intensity a polarised bundle keeps -- no copies).  Otherwise the
+        last TWO surfaces only: the image plane (the returned rays) and the row before it
+        (the pre-interaction cosines L0, M0, N0)."""
+        wl, w = self._wavelength_index(wavelength)
+        eng = self.engine
+        n = int(px.numel())
+        self.last_fused_launch = (hx, hy, px, py, vig, wavelength, flags)
+        polarized = self.table.polarization is not None
+        # (a polarised bundle records from row 0 anyway -- its initial cosines and intensity
+        # live there -- so there is nothing to be lazy about)
+        lazy = self.record_all and self.lazy_records and not polarized
+        full = self.record_all and not lazy
+        self.last_was_lazy = lazy
+        if not polarized and self._uses_polarization:
+            # rays/ray_generator.py:89-94
+            raise ValueError("Polarization must be set when surfaces have "
+                             "polarization-dependent coatings.")
+        last = eng.num_surfaces - 1
+        # a polarised bundle keeps its initial cosines and intensity (polarized_rays.py:50-54):
+        # they are row 0, so row 0 is recorded whenever the trace is polarised
+        first_row = 0 if (full or polarized) else max(last - 1, 0)
+        prt = None
+        if polarized:
+            prt = torch.empty((18 if self._complex_prt else 9, n), dtype=self.dtype,
+                              device=self.device)  # written by the kernel (starts from I)
+        res = eng.trace_generate(px, py, wl, field=(hx, hy), vig=vig, record=True,
+                                 record_first=first_row, prt=prt, flags=flags,
+                                 defer_status=True)
+        if not self.defer_checks:
+            self._finish_checks(eng)
+        k_init = i0 = None
+        if polarized:
+            r0 = res.rows(0)
+            k_init, i0 = (r0[3], r0[4], r0[5]), r0[6]
+        return self._wrap(res, res.rows(res.last), w, prt, k_init, i0, update_intensity,
+                          bind=full)
 
     def trace_rays(self, planes, wavelength, update_intensity=False):
         """Trace rays the CALLER generated (x, y, z, L, M, N, i [, opd] arrays of one
@@ -227,19 +285,31 @@ class HipRayTracer:
         if polarized:
             prt = torch.empty((18 if self._complex_prt else 9, n), dtype=self.dtype,
                               device=self.device)  # written by the kernel (starts from I)
-            k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
-            i0 = rays[6].clone()
+            if isinstance(record, torch.Tensor):
+                # record-all: the rays ARE row 0 of the record block, which the trace never
+                # rewrites -- the initial cosines / intensity need no copies
+                k_init, i0 = (rays[3], rays[4], rays[5]), rays[6]
+            else:  # the trace writes the final state back into these planes
+                k_init = (rays[3].clone(), rays[4].clone(), rays[5].clone())
+                i0 = rays[6].clone()
         deferred = hasattr(eng, "_status")
         kw = {"defer_status": True, "zero_status": zero_status} if deferred else {}
         res = eng.trace(rays, wl, record=record, prt=prt, prt_identity=prt is not None, **kw)
         if not self.defer_checks:
             self._finish_checks(eng)
-        self.surfaces._bind(res)
-        if res.record is not None:
-            fin = res.rows(res.last)
-        else:
-            fin = rays
-        if polarized:
+        fin = res.rows(res.last) if res.record is not None else rays
+        return self._wrap(res, fin, w, prt, k_init, i0, update_intensity)
+
+    def _wrap(self, res, fin, w, prt, k_init, i0, update_intensity, bind=None):
+        """The result objects of one launch: bound recorded surfaces + the returned rays."""
+        eng = self.engine
+        # record-last / lazy launches bind no surfaces; the rows they did record serve
+        # L0 / M0 / N0 below
+        if bind is None:
+            bind = self.record_all
+        self.surfaces._bind(res if bind else None)
+        self._last_res = res
+        if prt is not None:
             out = PolarizedRays(*fin[:7], w, fin[7], engine=eng, prt=prt, i0=i0, k_init=k_init)
             if update_intensity:  # real_ray_tracer.py:112-113 -- trace() only
                 out.update_intensity(_state_dict(self.table.polarization))
@@ -305,6 +375,7 @@ class HipRayTracer:
         if self.table.polarization is not None or self.table.uses_polarization:
             raise ValueError("trace_spot: fused spot reduction needs an unpolarised system")
         px, py = self._pupil_planes(distribution, num_rays)
+        self.last_spot_pupil = (px, py)
         wl, _ = self._wavelength_index(wavelength)
         out3 = None
         if hits:

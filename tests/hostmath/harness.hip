@@ -74,24 +74,36 @@ namespace {
 
 // trace_kernel<T, 1, RECORD, POLK, NR, false> for ray i (trace_kernel.hip), statement by
 // statement; the loads / stores are plain indexed accesses.
-template <typename T, int POLK, int NR>
+template <typename T, int POLK, int NR, bool GEN = false>
 void trace_one(const TraceArgs<T>& a, int64_t i, uint32_t& status) {
   constexpr int NPRT = POLK == 2 ? 18 : 9;
   Ray<T> r[1];
-  r[0].x = a.rays[0][i]; r[0].y = a.rays[1][i]; r[0].z = a.rays[2][i];
-  r[0].L = a.rays[3][i]; r[0].M = a.rays[4][i]; r[0].N = a.rays[5][i];
-  r[0].i = a.rays[6][i]; r[0].opd = a.rays[7][i];
+  if constexpr (GEN) {  // trace_kernel<..., GEN = true>: the generating prologue
+    const RaygenIn<T>& in_ = a.in;
+    T px = in_.px[i], py = in_.py[i];
+    T vx = in_.vx0, vy = in_.vy0, o[6];
+    raygen_pupil<T>(in_.flags, vx, vy, px, py, status);
+    raygen_one<T>(a.rgc, in_.tx0, in_.ty0, px, py, vx, vy, o);
+    r[0].x = o[0]; r[0].y = o[1]; r[0].z = o[2];
+    r[0].L = o[3]; r[0].M = o[4]; r[0].N = o[5];
+    r[0].i = T(1); r[0].opd = T(0);
+  } else {
+    r[0].x = a.rays[0][i]; r[0].y = a.rays[1][i]; r[0].z = a.rays[2][i];
+    r[0].L = a.rays[3][i]; r[0].M = a.rays[4][i]; r[0].N = a.rays[5][i];
+    r[0].i = a.rays[6][i]; r[0].opd = a.rays[7][i];
+  }
   Prt<T, POLK> P[1];
   if constexpr (POLK != 0) {
-    const bool ident = (a.flags & kTracePrtIdentity) != 0;
+    const bool ident = GEN || (a.flags & kTracePrtIdentity) != 0;
     for (int e = 0; e < NPRT; ++e)
       P[0].m[e] = ident ? ((e == 0 || e == 4 || e == 8) ? T(1) : T(0)) : a.prt[(int64_t)e * a.n + i];
   }
   bool is_global = true;
-  bool prt_fresh = POLK != 0 && (a.flags & kTracePrtIdentity) != 0;
+  bool prt_fresh = POLK != 0 && (GEN || (a.flags & kTracePrtIdentity) != 0);
   DevSurf<T> last_traced;
   std::memset(static_cast<void*>(&last_traced), 0, sizeof(last_traced));
   last_traced.cold = a.cold;
+  const int rec_from = a.record_from > a.first ? a.record_from : a.first;
   for (int s = a.first; s <= a.last; ++s) {
     DevSurf<T> S;
     static_cast<DevSurfHot<T>&>(S) = a.surf[s];
@@ -109,8 +121,8 @@ void trace_one(const TraceArgs<T>& a, int64_t i, uint32_t& status) {
       is_global = false;
       last_traced = S;
     }
-    if (a.record) {
-      T* row = a.record + (int64_t)(s - a.first) * 8 * a.record_stride;
+    if (a.record && s >= rec_from) {
+      T* row = a.record + (int64_t)(s - rec_from) * 8 * a.record_stride;
       if (!(s == a.first && (a.flags & kTraceRow0IsInput))) {
         const Ray<T> g = is_global ? r[0] : to_global<T>(last_traced, r[0]);
         row[0 * a.record_stride + i] = g.x; row[1 * a.record_stride + i] = g.y;
@@ -131,10 +143,10 @@ void trace_one(const TraceArgs<T>& a, int64_t i, uint32_t& status) {
   }
 }
 
-template <typename T, int POLK, int NR>
+template <typename T, int POLK, int NR, bool GEN = false>
 void trace_all(const TraceArgs<T>& a) {
   uint32_t status = 0;
-  for (int64_t i = 0; i < a.n; ++i) trace_one<T, POLK, NR>(a, i, status);
+  for (int64_t i = 0; i < a.n; ++i) trace_one<T, POLK, NR, GEN>(a, i, status);
   if (status && a.status) *a.status |= status;
 }
 
@@ -162,6 +174,27 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool, int nr_family, hipStream_t)
 }
 template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, int, hipStream_t);
 template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, int, hipStream_t);
+
+// launch_trace_generate (trace_kernel.hip): the generating variant, same instance choice
+template <typename T, int NR>
+static hipError_t gen_nr(const TraceArgs<T>& a) {
+  const int polk = a.prt == nullptr ? 0 : ((a.flags & kTracePrtComplex) ? 2 : 1);
+  if (polk == 2) trace_all<T, 2, NR, true>(a);
+  else if (polk == 1) trace_all<T, 1, NR, true>(a);
+  else trace_all<T, 0, NR, true>(a);
+  return hipSuccess;
+}
+template <typename T>
+hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, hipStream_t) {
+  switch (nr_family) {
+    case kNrNone: return gen_nr<T, kNrNone>(a);
+    case kNrZernike: return gen_nr<T, kNrZernike>(a);
+    case kNrEvenAsphere: return gen_nr<T, kNrEvenAsphere>(a);
+    default: return gen_nr<T, kNrGeneric>(a);
+  }
+}
+template hipError_t launch_trace_generate<float>(const TraceArgs<float>&, int, hipStream_t);
+template hipError_t launch_trace_generate<double>(const TraceArgs<double>&, int, hipStream_t);
 
 // raygen_kernel + launch_raygen (aux_kernels.hip), ray by ray
 template <typename T>

@@ -1,0 +1,142 @@
+"""Lazy per-surface records behind the live reference (build container only).
+
+`integration.enable(lazy_records=True)` / `install(..., lazy_records=True)`: a trace of one
+field point runs record-LAST (`ol_trace_generate` with `record_first_surface = S - 1`); the
+per-surface arrays the reference leaves on its `Surface` objects
+(surfaces/standard_surface.py:260-274, read through `SurfaceGroup.x ...`,
+surfaces/surface_group.py:108-153) are produced by a record-all re-run on their first read.
+Checked here against the eager drop-in and the NumPy backend on the host build of the kernel
+source (the engine that has `ol_trace_generate`; the oracle-backed stand-in takes the
+two-launch path, where lazy mode does not apply).
+"""
+
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_reference_integration import REF, hip_on_cpu, ref  # noqa: F401 (fixtures)
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "optiland")),
+                                reason="reference package not present")
+PLANES = ("x", "y", "z", "L", "M", "N", "intensity", "opd")
+
+
+def _np(be, a):
+    return np.asarray(be.to_numpy(a), dtype=np.float64)
+
+
+def _lens(name):
+    from tests import _live
+    return _live.build_system(name)
+
+
+@pytest.fixture
+def kernel_source(hip_on_cpu, request):
+    if "kernel-source" not in request.node.name:
+        pytest.skip("lazy records need an engine with ol_trace_generate")
+    return hip_on_cpu
+
+
+@pytest.mark.parametrize("name", ["CookeTriplet", "RCAsphere", "ZernikeFresnelUnpolarized"])
+def test_lazy_records_equal_eager_records(kernel_source, name):
+    be = kernel_source
+    from optiland_amd import integration
+    eager, w = _lens(name)
+    lazy, _ = _lens(name)
+    te = integration.install(eager, force=True)
+    tl = integration.install(lazy, force=True, lazy_records=True)
+    try:
+        for call in (lambda o: o.trace(0.0, 0.7, w, 5, "hexapolar"),
+                     lambda o: o.trace_generic(0.0, 1.0, be.array([0.1, -0.4, 0.7]),
+                                               be.array([0.3, 0.2, -0.5]), w)):
+            r0, r1 = call(eager), call(lazy)
+            assert te.last_path == "hip" and tl.last_path == "hip"
+            for k in ("x", "y", "z", "L", "M", "N", "i", "opd", "L0", "M0", "N0"):
+                np.testing.assert_array_equal(_np(be, getattr(r1, k)), _np(be, getattr(r0, k)), k)
+            if hasattr(r0, "p"):
+                np.testing.assert_array_equal(be.to_numpy(r1.p), be.to_numpy(r0.p))
+            polarised = hasattr(r0, "p")
+            # nothing was bound yet unless the trace is polarised (those record from row 0)
+            from optiland_amd import integration as ig
+            pending = ig._PENDING is not None and lazy.surfaces.surfaces[1] in ig._PENDING
+            assert pending == (not polarised)
+            # first read of ANY surface attribute materialises all of them
+            for k in PLANES:
+                a, b = _np(be, getattr(lazy.surfaces, k)), _np(be, getattr(eager.surfaces, k))
+                assert a.shape == b.shape
+                np.testing.assert_array_equal(a, b, k)
+            assert lazy.surfaces.surfaces[1] not in ig._PENDING
+    finally:
+        integration.uninstall(eager)
+        integration.uninstall(lazy)
+
+
+def test_lazy_trace_launches_no_record_all_until_asked(kernel_source):
+    be = kernel_source
+    from optiland_amd import integration
+    lens, w = _lens("DoubleGauss")
+    t = integration.install(lens, force=True, lazy_records=True)
+    try:
+        rays = lens.trace(0.0, 0.7, w, 6, "hexapolar")
+        eng = t._hip_engine
+        front = next(iter(next(iter(t._hip_engines.values()))[2].values()))
+        res = front._last_res
+        assert res.first == eng.num_surfaces - 2 and res.record.shape[0] == 2  # two rows only
+        n = _np(be, rays.x).size
+        # a second lazy trace supersedes the first pending record without running it
+        lens.trace(0.0, 0.0, w, 6, "hexapolar")
+        x_img = _np(be, lens.image_surface.x)        # -> record-all of the SECOND trace
+        assert x_img.shape == (n,)
+        be.set_backend("numpy")
+        try:
+            ref_lens, _ = _lens("DoubleGauss")
+            ref_lens.trace(0.0, 0.0, w, 6, "hexapolar")
+            want = np.asarray(ref_lens.surfaces.y)
+        finally:
+            be.set_backend("torch")
+            be.set_device("cpu")
+            be.set_precision("float64")
+        np.testing.assert_allclose(_np(be, lens.surfaces.y), want, rtol=0, atol=1e-9)
+    finally:
+        integration.uninstall(lens)
+
+
+def test_pending_record_is_dropped_by_reset_and_survives_deepcopy(kernel_source):
+    be = kernel_source
+    from optiland_amd import integration as ig
+    lens, w = _lens("CookeTriplet")
+    ig.install(lens, force=True, lazy_records=True)
+    try:
+        lens.trace(0.0, 1.0, w, 4, "hexapolar")
+        assert lens.surfaces.surfaces[2] in ig._PENDING
+        dup = copy.deepcopy(lens)            # a copy taken before anybody read the record:
+        assert be.size(dup.surfaces.surfaces[2].x) == 0   # a reset surface, never stale arrays
+        lens.surfaces.reset()                # surface_group.py:373-380
+        assert lens.surfaces.surfaces[2] not in ig._PENDING
+        assert be.size(lens.surfaces.surfaces[2].x) == 0
+        # a reference-side trace (NumPy backend) after a lazy one writes its own arrays
+        lens.trace(0.0, 1.0, w, 4, "hexapolar")
+        assert lens.surfaces.surfaces[2] in ig._PENDING
+        with be.grad_mode.temporary_enable():   # autograd: the reference's own loop runs
+            lens.trace(0.0, 0.0, w, 3, "hexapolar")
+        assert lens.surfaces.surfaces[2] not in ig._PENDING
+        assert _np(be, lens.surfaces.x).shape[1] == 1 + 3 * 3 * 4  # 3 hexapolar rings
+    finally:
+        ig.uninstall(lens)
+
+
+def test_disable_materialises_what_is_still_pending(kernel_source):
+    be = kernel_source
+    from optiland.surfaces.standard_surface import Surface
+    from optiland_amd import integration as ig
+    ig.enable(force=True, lazy_records=True)
+    try:
+        lens, w = _lens("CookeTriplet")
+        lens.trace(0.0, 0.7, w, 4, "hexapolar")
+        assert isinstance(Surface.__dict__["x"], ig._RecordedPlane)
+    finally:
+        ig.disable()
+    assert "x" not in Surface.__dict__ or not isinstance(Surface.__dict__["x"], ig._RecordedPlane)
+    assert _np(be, lens.surfaces.x).shape == (len(lens.surfaces.surfaces), 1 + 3 * 4 * 5)

@@ -47,9 +47,18 @@ VARIANTS = {
     # kernargs()) instead of held in SGPRs; windowed coefficient stream of the unrolled
     # Zernike polynomial.  (The round-2 library itself is built from its commit as
     # variant_r02.so by tools/build_r02_variant.sh.)
-    "nr_byvalue": ["-DOL_NR_FETCH=0"],
-    "f64_byvalue": ["-DOL_FETCH_F64=0"],
-    "leanspot_byvalue": ["-DOL_FETCH_LEAN_SPOT=0"],
+    # fetch levels per kernel class (trace_kernel.hip: OL_FETCH_*)
+    "nr32_0": ["-DOL_FETCH_NR_F32=0"],
+    "nr32_1": ["-DOL_FETCH_NR_F32=1"],
+    "nr32_2": ["-DOL_FETCH_NR_F32=2"],
+    "nr64_0": ["-DOL_FETCH_NR_F64=0"],
+    "nr64_1": ["-DOL_FETCH_NR_F64=1"],
+    "lean64_0": ["-DOL_FETCH_LEAN_F64=0"],
+    "lean64_2": ["-DOL_FETCH_LEAN_F64=2"],
+    "lean32_1": ["-DOL_FETCH_LEAN_F32=1"],
+    "lean32_2": ["-DOL_FETCH_LEAN_F32=2"],
+    "nr32_2_waves0": ["-DOL_FETCH_NR_F32=2", "-DOL_POLNR_WAVES=0"],
+    "nr32_0_waves0": ["-DOL_FETCH_NR_F32=0", "-DOL_POLNR_WAVES=0"],
     "zmono_ahead2": ["-DOL_ZERN_MONO_AHEAD=2"],
     "zmono_chunk16": ["-DOL_ZERN_MONO_CHUNK=16"],
     "polnr_waves6": ["-DOL_POLNR_WAVES=6"],

@@ -12,7 +12,7 @@ run() { # label, lib ('' = product), bench args...
   local label=$1 lib=$2; shift 2
   echo -n "$label" >> $OUT
   if [ -n "$lib" ]; then
-    OPTILAND_HIP_LIBRARY=$R/optiland_amd/lib/variant_$lib.so python bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | show >> $OUT
+    OPTILAND_HIP_ALLOW_ABI5=1 OPTILAND_HIP_LIBRARY=$R/optiland_amd/lib/variant_$lib.so python bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | show >> $OUT
   else
     python bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | show >> $OUT
   fi
