@@ -23,6 +23,11 @@
 #include <Python.h>
 
 static PyObject *g_tensor = NULL, *g_ndarray = NULL, *g_generic = NULL;
+/* Python callables for the two rare cases (fingerprint.py): a tensor that requires grad
+ * (writes through `.data` leave `_version` alone: never trusted), a numpy array too big to
+ * carry by value (content digest) */
+static PyObject *g_grad_tok = NULL, *g_big_tok = NULL;
+static PyObject* s_requires_grad = NULL;
 static Py_ssize_t g_big = 1 << 14;
 static PyObject *s_T, *s_A, *s_O, *s_version, *s_shape, *s_size, *s_tobytes, *s_item, *s_dict,
     *s_reference_cs, *s_propagation_model, *s_a, *s_b, *s_jones, *s__jones, *s_geometry,
@@ -35,6 +40,14 @@ static PyObject* tok(PyObject* v, PyObject* keep);
 
 static PyObject* tensor_tok(PyObject* v, PyObject* keep) {
   if (PyList_Append(keep, v) < 0) return NULL;
+  if (g_grad_tok) {
+    PyObject* rg = PyObject_GetAttr(v, s_requires_grad);
+    if (!rg) return NULL;
+    const int yes = PyObject_IsTrue(rg);
+    Py_DECREF(rg);
+    if (yes < 0) return NULL;
+    if (yes) return PyObject_CallOneArg(g_grad_tok, v);
+  }
   PyObject* ver = PyObject_GetAttr(v, s_version);
   if (!ver) return NULL;
   PyObject* idv = id_of(v);
@@ -61,10 +74,14 @@ static PyObject* ndarray_tok(PyObject* v, PyObject* keep) {
       Py_DECREF(bytes);
     }
   } else if (PyList_Append(keep, v) == 0) {
-    PyObject* idv = id_of(v);
-    if (idv) {
-      out = PyTuple_Pack(3, s_A, idv, shape);
-      Py_DECREF(idv);
+    if (g_big_tok) {
+      out = PyObject_CallOneArg(g_big_tok, v);
+    } else {
+      PyObject* idv = id_of(v);
+      if (idv) {
+        out = PyTuple_Pack(3, s_A, idv, shape);
+        Py_DECREF(idv);
+      }
     }
   }
   Py_DECREF(shape);
@@ -403,12 +420,16 @@ static PyObject* py_dict_tokens(PyObject* self, PyObject* args) {
 }
 
 static PyObject* py_configure(PyObject* self, PyObject* args) {
-  PyObject *tensor, *ndarray, *generic;
+  PyObject *tensor, *ndarray, *generic, *grad_tok = NULL, *big_tok = NULL;
   Py_ssize_t big;
-  if (!PyArg_ParseTuple(args, "OOOn", &tensor, &ndarray, &generic, &big)) return NULL;
+  if (!PyArg_ParseTuple(args, "OOOn|OO", &tensor, &ndarray, &generic, &big, &grad_tok, &big_tok))
+    return NULL;
   Py_XDECREF(g_tensor); Py_XDECREF(g_ndarray); Py_XDECREF(g_generic);
+  Py_XDECREF(g_grad_tok); Py_XDECREF(g_big_tok);
   Py_INCREF(tensor); Py_INCREF(ndarray); Py_INCREF(generic);
   g_tensor = tensor; g_ndarray = ndarray; g_generic = generic;
+  g_grad_tok = (grad_tok && grad_tok != Py_None) ? (Py_INCREF(grad_tok), grad_tok) : NULL;
+  g_big_tok = (big_tok && big_tok != Py_None) ? (Py_INCREF(big_tok), big_tok) : NULL;
   g_big = big;
   Py_RETURN_NONE;
 }
@@ -430,6 +451,7 @@ PyMODINIT_FUNC PyInit__fptoken(void) {
   s_A = PyUnicode_InternFromString("A");
   s_O = PyUnicode_InternFromString("O");
   s_version = PyUnicode_InternFromString("_version");
+  s_requires_grad = PyUnicode_InternFromString("requires_grad");
   s_shape = PyUnicode_InternFromString("shape");
   s_size = PyUnicode_InternFromString("size");
   s_tobytes = PyUnicode_InternFromString("tobytes");

@@ -231,7 +231,8 @@ class HipSystem:
         # reads them back later (together with other device-side checks)
         status = int(self._status.item()) if (check_status and not defer_status) else 0
         self.raise_for_status(status)
-        return TraceResult(n, rays, rec, prt, status, first, last)
+        return TraceResult(n, rays, rec, prt, status, rec_first if rec is not None else first,
+                           last)
 
     def can_trace_generate(self) -> bool:
         """`ol_trace_generate` present (ABI 6) and the table carries generator scalars without

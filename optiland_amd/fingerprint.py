@@ -11,15 +11,28 @@ exactly those objects and collects, without touching the device:
   * python / numpy scalars and strings  -> their value
   * torch tensors                       -> (id, `_version`): a new tensor object or any
                                            in-place write changes the token
-  * small numpy arrays                  -> their bytes
+  * tensors that REQUIRE GRAD           -> never equal to anything (a fresh serial number):
+                                           the reference's optimisers write their variables
+                                           through `param.data` (optimization/optimizer/torch/
+                                           base.py:90-94, variable/torch.py:59, torch_backend.py
+                                           :214), which leaves `_version` alone -- such a
+                                           tensor anywhere in the prescription means "pack
+                                           again", every time
+  * numpy arrays up to 16 384 elements  -> their bytes
+  * larger numpy arrays                 -> shape + a 64-bit digest of their CONTENTS (xxh3
+                                           when the module is there, else zlib.adler32 over
+                                           the buffer): an in-place edit of a 20 000-vertex
+                                           polygon aperture is seen
   * lists / tuples                      -> element tokens
   * other objects                       -> (class name, id)  [identity]
   * dicts                               -> ignored (the reference keeps caches in them)
 
 Tokens are compared with `==`; the objects whose ids appear in a token are kept alive
 next to it (`keep`) so that an id cannot be recycled while the token is cached.  What this
-cannot see is a write through `tensor.data` / `set_` (no `_version` bump) -- nothing in the
-reference does that; `OPTILAND_HIP_PACK_CACHE=0` turns the memo off.
+still cannot see is a write through `.data` / `set_` of a tensor that does NOT require grad
+(no `_version` bump; nothing in the reference does that to a prescription value);
+`OPTILAND_HIP_PACK_CACHE=0` turns the memo off.  tests/test_fingerprint.py derives the set
+of attributes the packer really reads from a traced `pack_optic` run and mutates each one.
 """
 
 from __future__ import annotations
@@ -40,25 +53,54 @@ _SURFACE_SKIP = frozenset(("x", "y", "z", "u", "L", "M", "N", "intensity", "aoi"
 
 _Tensor = torch.Tensor
 _NoneType = type(None)
+_SERIAL = [0]
+
+try:  # content digest of big arrays
+    import xxhash as _xx
+
+    def _digest(buf) -> int:
+        return _xx.xxh3_64_intdigest(buf)
+except Exception:  # noqa: BLE001 - optional accelerator
+    import zlib as _zlib
+
+    def _digest(buf) -> int:
+        return _zlib.adler32(buf)
+
+
+def _grad_tensor_token(v):
+    """A tensor that requires grad: `.data` writes do not bump `_version`, so it is never
+    trusted -- every token of it is unique."""
+    _SERIAL[0] += 1
+    return ("G", id(v), _SERIAL[0])
+
+
+def _big_array_token(v):
+    a = v if v.flags.c_contiguous else np.ascontiguousarray(v)
+    return ("A", v.shape, str(v.dtype), _digest(memoryview(a).cast("B")))
+
+
+def _tensor_token(v, keep):
+    keep.append(v)
+    if v.requires_grad:
+        return _grad_tensor_token(v)
+    return ("T", id(v), v._version)
 
 
 def _tok_py(v, keep):
     t = type(v)
     if t is float or t is _Tensor or t is int or t is str or t is bool or t is _NoneType:
         if t is _Tensor:
-            keep.append(v)
-            return ("T", id(v), v._version)
+            return _tensor_token(v, keep)
         return v
     if t is complex:
         return v
     if isinstance(v, _Tensor):  # Parameter and other subclasses
-        keep.append(v)
-        return ("T", id(v), v._version)
+        return _tensor_token(v, keep)
     if isinstance(v, np.ndarray):
         if v.size <= _BIG_ARRAY:
             return ("A", v.shape, v.tobytes())
         keep.append(v)
-        return ("A", id(v), v.shape)
+        return _big_array_token(v)
     if isinstance(v, np.generic):
         return v.item()
     if t is list or t is tuple:
@@ -92,7 +134,8 @@ def _load_native():
         spec = importlib.util.spec_from_loader("_fptoken", loader)
         mod = importlib.util.module_from_spec(spec)
         loader.exec_module(mod)
-        mod.configure(torch.Tensor, np.ndarray, np.generic, _BIG_ARRAY)
+        mod.configure(torch.Tensor, np.ndarray, np.generic, _BIG_ARRAY, _grad_tensor_token,
+                      _big_array_token)
         return mod
     except Exception:  # noqa: BLE001 - stale / foreign binary: fall back to the Python walk
         return None

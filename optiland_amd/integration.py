@@ -432,6 +432,7 @@ def _make_tracer_class():
             hit = self._hip_engines.get(memo[2])
             if hit is None or not hit[1].raygen:
                 return None
+            self._hip_engines.move_to_end(memo[2])  # speculative use is use: keep LRU honest
             eng, table, fronts = hit
             dtype = self._dtype()
             front = fronts.get(dtype)
@@ -466,9 +467,15 @@ def _make_tracer_class():
                 if tok == tok0:
                     self.speculative_hits += 1
                     self._hip_engine, self._hip_table = front.engine, table
-                    if err is not None:
-                        raise err
-                    front.check_status()
+                    try:
+                        if err is not None:
+                            raise err
+                        front.check_status()
+                    except BaseException:
+                        # the cached front must not pin the record block of a failed call
+                        front.surfaces._bind(None)
+                        front._last_res = None
+                        raise
                     self.last_path = "hip"
                     return self._finish(front, table, mine, wavelength, update_intensity)
                 self.speculative_misses += 1
@@ -606,11 +613,21 @@ def _sg_run(group, eng, rays, planes, first, last, polarized):
     prt = None
     if polarized:
         p = rays.p.reshape(n, 9)
-        if p.is_complex():
-            prt = torch.cat([p.real.t(), p.imag.t()]).to(dtype).contiguous()  # (18, n)
-        else:  # a fresh torch-backend PolarizedRays holds a REAL identity (polarized_rays.py:50)
-            prt = torch.cat([p.t().to(dtype), torch.zeros((9, n), dtype=dtype,
-                                                          device=p.device)]).contiguous()
+        # 18 planes (real + imaginary) only when they can be non-zero: behind a retarder in
+        # THIS table, or in a bundle that arrives with an imaginary part already (traced
+        # through one elsewhere); otherwise the 9-plane real form and the kernels that go
+        # with it (92-99 VGPRs for the complex-PRT instances against 60-70)
+        need18 = bool(eng.table.needs_complex_prt)
+        if p.is_complex() and not need18:
+            need18 = bool(torch.count_nonzero(p.imag))
+        if need18:
+            if p.is_complex():
+                prt = torch.cat([p.real.t(), p.imag.t()]).to(dtype).contiguous()  # (18, n)
+            else:  # a fresh torch-backend PolarizedRays holds a REAL identity
+                prt = torch.cat([p.t().to(dtype), torch.zeros((9, n), dtype=dtype,
+                                                              device=p.device)]).contiguous()
+        else:
+            prt = (p.real if p.is_complex() else p).t().to(dtype).contiguous()  # (9, n)
     res = eng.trace(planes, 0, record=True, prt=prt, first=first, last=last)
     for s in range(first, last + 1):
         surf = group.surfaces[s]

@@ -1,0 +1,176 @@
+"""`ol_trace_generate` (ABI 6): ray generation fused into the recording trace kernel, and
+`record_first_surface`.
+
+The fused launch must reproduce the two-launch chain `ol_generate_rays` -> `ol_trace` BIT FOR
+BIT (same device functions, same order of operations): every recorded row, the PRT planes of
+polarised systems, the status bits -- on every golden system that carries generator scalars,
+in fp32 and fp64, for `trace()`-style launches and for `trace_generic`-style ones (pupil
+range check, vignetting pre-scaling).  `-m gpu`: the HIP library on the MI355X;
+`-m "not gpu"`: the product's engine class on the host build of the kernel source.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from optiland_amd import _capi, load_system, tracer as tr
+from tests._util import golden_cases, load_case
+
+WHERE = [pytest.param("cuda", marks=pytest.mark.gpu), "host"]
+CASES = [c for c in golden_cases() if not c.startswith("fuzz_")] + ["fuzz_00", "fuzz_03"]
+
+
+def _engine(table, where):
+    if where == "cuda":
+        from optiland_amd.engine import HipSystem
+        return HipSystem(table, "cuda:0"), "cuda:0"
+    from tests import _hostmath as hm
+    if not hm.available():
+        pytest.skip("hipcc (used as host C++ compiler) missing")
+    return hm.make_engine_class()(table), "cpu"
+
+
+def _pupil(n, dtype, dev, seed):
+    g = np.random.default_rng(seed)
+    r, th = np.sqrt(g.random(n)) * 0.98, 2 * np.pi * g.random(n)
+    return (torch.tensor(r * np.cos(th), dtype=dtype, device=dev),
+            torch.tensor(r * np.sin(th), dtype=dtype, device=dev))
+
+
+@pytest.mark.parametrize("where", WHERE)
+@pytest.mark.parametrize("case", CASES)
+def test_fused_generate_equals_generate_then_trace(case, where):
+    table, _ = load_case(case)
+    if not table.raygen:
+        pytest.skip("no ray-generation scalars in this table")
+    eng, dev = _engine(table, where)
+    try:
+        if not eng.can_trace_generate():
+            pytest.skip("apodized pupil: the two-launch path is the only one")
+        pol = table.polarization is not None
+        if table.uses_polarization and not pol:
+            pytest.skip("coatings need a polarisation state")
+        for dtype in (torch.float64, torch.float32):
+            for n in (1, 257, 1000):
+                px, py = _pupil(n, dtype, dev, n)
+                for field, vig, flags in (((0.0, 0.7), (1.0, 1.0), 0),
+                                          ((0.3, -0.5), (0.9, 0.8),
+                                           _capi.RAYGEN_CHECK_PUPIL | _capi.RAYGEN_PRESCALE_PUPIL)):
+                    # two launches
+                    rec_a = eng.alloc_record(n, dtype)
+                    rays = eng.row0_planes(rec_a, n)
+                    eng.generate_rays(field[0], field[1], px, py, vig[0], vig[1], out=rays,
+                                      flags=flags)
+                    prt_a = torch.empty((18 if table.needs_complex_prt else 9, n), dtype=dtype,
+                                        device=dev) if pol else None
+                    a = eng.trace(rays, 0, record=rec_a, prt=prt_a, prt_identity=pol,
+                                  zero_status=False)
+                    # one launch
+                    prt_b = torch.empty_like(prt_a) if pol else None
+                    b = eng.trace_generate(px, py, 0, field=field, vig=vig, flags=flags,
+                                           prt=prt_b)
+                    ra, rb = a.record[:, :, :n].cpu().numpy(), b.record[:, :, :n].cpu().numpy()
+                    assert ra.shape == rb.shape
+                    np.testing.assert_array_equal(ra, rb, err_msg=f"{case} {dtype} n={n}")
+                    if pol:
+                        np.testing.assert_array_equal(prt_a.cpu().numpy(), prt_b.cpu().numpy())
+                    # the last two rows alone (lazy-record launches) and a final-state copy
+                    S = eng.num_surfaces
+                    out = [torch.empty(n, dtype=dtype, device=dev) for _ in range(8)]
+                    c = eng.trace_generate(px, py, 0, field=field, vig=vig, flags=flags,
+                                           prt=torch.empty_like(prt_a) if pol else None,
+                                           record_first=max(S - 2, 0), rays_out=out)
+                    rc = c.record[: min(2, S), :, :n].cpu().numpy()
+                    np.testing.assert_array_equal(rc, ra[max(S - 2, 0):])
+                    np.testing.assert_array_equal(torch.stack(out).cpu().numpy(), ra[-1])
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("where", WHERE)
+def test_record_first_surface_on_plain_traces(where):
+    table, data = load_case("double_gauss")
+    eng, dev = _engine(table, where)
+    try:
+        S = eng.num_surfaces
+        for dtype in (torch.float64, torch.float32):
+            src = [torch.tensor(data["rays_in"][k], dtype=dtype, device=dev) for k in range(7)]
+            src.append(torch.zeros_like(src[0]))
+            n = src[0].numel()
+            full = eng.trace([t.clone() for t in src], 0, record=True)
+            for first in (3, S - 2, S - 1):
+                part = eng.trace([t.clone() for t in src], 0, record=True, record_first=first)
+                assert part.record.shape[0] == S - first and part.first == first
+                np.testing.assert_array_equal(part.record[:, :, :n].cpu().numpy(),
+                                              full.record[first:, :, :n].cpu().numpy())
+                np.testing.assert_array_equal(part.row(S - 1, "x").cpu().numpy(),
+                                              full.row(S - 1, "x").cpu().numpy())
+        with pytest.raises(ValueError):
+            eng.trace([t.clone() for t in src], 0, record=True, record_first=S)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("where", WHERE)
+def test_fused_generate_status_bits_and_refusals(where):
+    table = load_system("double_gauss")
+    eng, dev = _engine(table, where)
+    try:
+        px = torch.tensor([0.0, 0.5, 1.5], dtype=torch.float64, device=dev)
+        py = torch.zeros_like(px)
+        with pytest.raises(ValueError, match="pupil coordinates must be within"):
+            eng.trace_generate(px, py, 0, field=(0.0, 0.0), flags=_capi.RAYGEN_CHECK_PUPIL)
+        with pytest.raises(ValueError, match="field coordinates must be within"):
+            eng.trace_generate(px * 0.1, py, 0, field=(0.0, 1.5), flags=_capi.RAYGEN_CHECK_FIELD)
+        ok = eng.trace_generate(px * 0.1, py, 0, field=(0.0, 1.0), flags=_capi.RAYGEN_CHECK_PUPIL)
+        assert bool(torch.isfinite(ok.record[-1, 0, :3]).all())
+    finally:
+        eng.close()
+    apod, _ = load_case("apodized_gaussian_trace")
+    eng, dev = _engine(apod, where)
+    try:
+        assert not eng.can_trace_generate()
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("where", WHERE)
+@pytest.mark.parametrize("name", ["double_gauss", "rc_asphere", "zernike_fresnel_fringe"])
+def test_tracer_fused_and_two_launch_paths_agree(name, where):
+    """`HipRayTracer.trace / trace_generic` through `ol_trace_generate` (default) and through
+    the two launches (`fuse_generate = False`): identical rays, records, L0 / M0 / N0, PRT and
+    polarised intensities; record-last mode returns the same final state."""
+    table = load_system(name)
+    eng, dev = _engine(table, where)
+    try:
+        for dtype in (torch.float64, torch.float32):
+            a = tr.HipRayTracer(table, dev, dtype=dtype, engine=eng)
+            b = tr.HipRayTracer(table, dev, dtype=dtype, engine=eng)
+            b.fuse_generate = False
+            w = float(table.wavelengths[0])
+            px, py = _pupil(500, dtype, dev, 7)
+            for call in (lambda t: t.trace(0.0, 0.7, w, 5, "hexapolar"),
+                         lambda t: t.trace_generic(0.0, 1.0, px, py, w)):
+                ra, rb = call(a), call(b)
+                assert a.last_fused_launch is not None and b.last_fused_launch is None
+                for k in ("x", "y", "z", "L", "M", "N", "i", "opd", "L0", "M0", "N0"):
+                    np.testing.assert_array_equal(getattr(ra, k).cpu().numpy(),
+                                                  getattr(rb, k).cpu().numpy(), k)
+                for k in ("x", "L", "intensity", "opd"):
+                    np.testing.assert_array_equal(getattr(a.surfaces, k).cpu().numpy(),
+                                                  getattr(b.surfaces, k).cpu().numpy())
+                if table.polarization is not None:
+                    np.testing.assert_array_equal(ra._prt.cpu().numpy(), rb._prt.cpu().numpy())
+                    np.testing.assert_array_equal(ra._i0.cpu().numpy(), rb._i0.cpu().numpy())
+                # record-last
+                a.record_all = b.record_all = False
+                la, lb = call(a), call(b)
+                a.record_all = b.record_all = True
+                for k in ("x", "y", "z", "L", "M", "N", "i", "opd"):
+                    np.testing.assert_array_equal(getattr(la, k).cpu().numpy(),
+                                                  getattr(ra, k).cpu().numpy(), k)
+                    np.testing.assert_array_equal(getattr(lb, k).cpu().numpy(),
+                                                  getattr(ra, k).cpu().numpy(), k)
+                assert a.surfaces.x.numel() == 0
+    finally:
+        eng.close()

@@ -367,3 +367,131 @@ def test_random_reference_lenses_on_device(be, seed):
             bad |= fin & ~np.isfinite(g)
         ray_bad = bad.any(axis=(0, 1))
         assert ray_bad.mean() <= 0.01, (seed, float(ray_bad.mean()))
+
+
+# ------------------------------------------------------------------------------------------
+# round 3: the fused kernels behind the reference's own analysis classes; lazy records
+# ------------------------------------------------------------------------------------------
+def _on_device(be, precision="float64", **kw):
+    from optiland_amd import analysis_seams, integration
+    be.set_backend("torch")
+    be.set_device("cuda")
+    be.set_precision(precision)
+    integration.enable(**kw)
+    for k in analysis_seams.STATS:
+        analysis_seams.STATS[k] = 0
+    return analysis_seams.STATS
+
+
+def _off(be):
+    from optiland_amd import integration
+    integration.disable()
+    be.set_precision("float64")
+    be.set_device("cpu")
+    be.set_backend("numpy")
+
+
+@pytest.mark.parametrize("name", ["CookeTriplet", "RCAsphere"])
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_spot_diagram_and_encircled_energy_through_the_fused_seam_on_device(be, name, precision):
+    """analysis/spot_diagram/core.py:440-481 and analysis/encircled_energy.py:170-197 served
+    by `ol_trace_spot` on the MI355X: the data the classes keep equals the NumPy backend's."""
+    from optiland import analysis
+
+    def run(lens):
+        s = analysis.SpotDiagram(lens, num_rings=6)
+        e = analysis.EncircledEnergy(lens, num_rays=8, distribution="hexapolar", num_points=16)
+        return ([[(_np(be, d.x), _np(be, d.y), _np(be, d.intensity)) for d in f] for f in s.data],
+                [[float(_np(be, v)) for v in f] for f in s.rms_spot_radius()],
+                [[float(_np(be, v)) for v in f] for f in s.geometric_spot_radius()],
+                [[(_np(be, d.x), _np(be, d.y), _np(be, d.intensity)) for d in f] for f in e.data])
+
+    be.set_backend("numpy")
+    want = run(_live.build_system(name)[0])
+    stats = _on_device(be, precision)
+    try:
+        lens = _live.build_system(name)[0]
+        got = run(lens)
+        assert stats["spot"] > 0 and stats["spot_fallback"] == 0 and stats["ee"] > 0
+        scale = max(np.abs(x).max() for f in want[3] for (x, _, _) in f)
+        tol = TOL[precision]
+        for gf, wf in zip(got[0] + got[3], want[0] + want[3]):
+            for (x, y, i), (xw, yw, iw) in zip(gf, wf):
+                assert x.shape == xw.shape
+                np.testing.assert_allclose(x, xw, rtol=0, atol=tol * max(scale, 1.0))
+                np.testing.assert_allclose(y, yw, rtol=0, atol=tol * max(scale, 1.0))
+                np.testing.assert_allclose(i, iw, rtol=tol, atol=tol)
+        if precision == "float64":
+            np.testing.assert_allclose(got[1], want[1], rtol=1e-5)
+            np.testing.assert_allclose(got[2], want[2], rtol=1e-5)
+        # what Optic.trace() would have left on the surfaces is there when somebody looks
+        assert _np(be, lens.surfaces.x).shape == (len(lens.surfaces.surfaces), 1 + 3 * 8 * 9)
+    finally:
+        _off(be)
+
+
+@pytest.mark.parametrize("name", ["CookeTriplet", "DoubleGauss"])
+def test_wavefront_and_fft_psf_through_the_fused_seams_on_device(be, name):
+    """wavefront/strategy.py:163-215 served by `ol_trace_opd`, psf/fft.py:123-161 by
+    `ol_pupil_fill`, the FFT by rocFFT (torch.fft): OPD map, RMS, PSF and Strehl ratio equal
+    the NumPy backend's."""
+    from optiland.psf import FFTPSF
+    from optiland.wavefront import OPD
+
+    def run(lens):
+        w = lens.primary_wavelength
+        o = OPD(lens, (0.0, 0.7), w, num_rings=9)
+        d = o.get_data((0.0, 0.7), w)
+        p = FFTPSF(lens, (0.0, 0.7), w, num_rays=64, grid_size=128)
+        return (_np(be, d.opd), _np(be, d.intensity), float(_np(be, o.rms())), _np(be, p.psf),
+                float(_np(be, p.strehl_ratio())))
+
+    be.set_backend("numpy")
+    want = run(_live.build_system(name)[0])
+    stats = _on_device(be, "float64")
+    try:
+        got = run(_live.build_system(name)[0])
+        assert stats["opd"] >= 2 and stats["opd_fallback"] == 0 and stats["pupil"] >= 1
+        np.testing.assert_allclose(got[0], want[0], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(got[2], want[2], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(got[3], want[3], rtol=0, atol=1e-5 * want[3].max())
+        np.testing.assert_allclose(got[4], want[4], rtol=1e-5)
+    finally:
+        _off(be)
+
+
+@pytest.mark.parametrize("name", ["DoubleGauss", "RCAsphere", "ZernikeFresnelUnpolarized"])
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_lazy_records_on_device(be, name, precision):
+    """enable(lazy_records=True): Optic.trace launches record-last (two rows), the surfaces
+    are bound when read -- bit-identical to the eager drop-in."""
+    import torch
+    from optiland_amd import integration
+
+    def run(lens, w):
+        r = lens.trace(0.0, 0.7, w, 9, "hexapolar")
+        return r, {k: getattr(r, k).clone() for k in PLANES + ("L0", "M0", "N0")}
+
+    _on_device(be, precision)
+    try:
+        lens, w = _live.build_system(name)
+        _, eager = run(lens, w)
+        eager_surf = {k: getattr(lens.surfaces, k).clone() for k in SURF}
+    finally:
+        _off(be)
+    _on_device(be, precision, lazy_records=True)
+    try:
+        lens, w = _live.build_system(name)
+        rays, lazy = run(lens, w)
+        comp = lens.ray_tracer.__dict__["_hip_companion"]
+        assert comp.last_path == "hip"
+        for k in eager:
+            assert torch.equal(lazy[k], eager[k]), k
+        polarised = hasattr(rays, "p")
+        assert (lens.surfaces.surfaces[1] in integration._PENDING) == (not polarised)
+        for k in SURF:
+            assert torch.equal(getattr(lens.surfaces, k), eager_surf[k]), k
+        assert lens.surfaces.surfaces[1] not in integration._PENDING
+    finally:
+        _off(be)
