@@ -309,7 +309,7 @@ def _traced_reads(optic, fn):
     return out
 
 
-def _mutations(obj, name):
+def _value_changes(obj, name):
     """(apply, undo) pairs that change the VALUE of obj.name the way user code can: rebinding
     for python numbers / bools, in-place writes for tensors, arrays and lists."""
     import torch
@@ -392,7 +392,7 @@ def test_every_attribute_the_packer_reads_is_seen_by_the_change_detector(backend
             for obj, name in reads:
                 if name in fp._SURFACE_SKIP or type(obj.__dict__[name]) is dict:
                     continue  # recorded arrays; caches
-                for apply, undo in _mutations(obj, name):
+                for apply, undo in _value_changes(obj, name):
                     t0, _k0 = fp.optic_token(lens, w)
                     apply()
                     try:
