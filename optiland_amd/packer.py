@@ -22,12 +22,34 @@ class UnsupportedSystem(Exception):
     """The optic contains something the fused HIP path does not implement."""
 
 
+# Values of device tensors already read back: id(tensor) -> (weakref, _version, float).  On the
+# `cuda` device every scalar of the prescription is a tensor and reading one is a BLOCKING
+# device-to-host copy (~4 us each, ~700 per pack: the whole cost of a re-pack); a re-pack
+# after `set_radius` finds all but the changed tensor here.  Keyed like the change detector
+# (fingerprint.py): object identity + in-place version; tensors that require grad are never
+# cached (their `.data` can be rewritten without a version bump).
+_TENSOR_VALUES: dict = {}
+
+
 def _f(v) -> float:
     """Backend scalar / 0-d array / python number -> float."""
     if type(v) is float or type(v) is int:  # the common case, ~160 calls per pack
         return float(v)
     if hasattr(v, "detach"):
-        v = v.detach().cpu().numpy()
+        cacheable = not v.requires_grad and v.numel() == 1
+        if cacheable:
+            hit = _TENSOR_VALUES.get(id(v))
+            if hit is not None and hit[1] == v._version and hit[0]() is v:
+                return hit[2]
+        val = float(v.detach().reshape(-1)[0].item()) if v.numel() else float("nan")
+        if cacheable:
+            if len(_TENSOR_VALUES) > 20000:
+                _TENSOR_VALUES.clear()
+            try:
+                _TENSOR_VALUES[id(v)] = (weakref.ref(v), v._version, val)
+            except TypeError:
+                pass
+        return val
     return float(np.asarray(v).reshape(-1)[0]) if np.ndim(v) else float(v)
 
 
@@ -496,18 +518,31 @@ def _compute_raygen(optic, table: SystemTable) -> None:
         if not 0.0 < sin < 1.0:
             return
         tele_dz = math.sqrt(1.0 - sin * sin) / sin
-    EPL = _f(optic.paraxial.EPL())
-    EPD = _f(optic.paraxial.EPD())
     # SurfaceGroup.positions (surface_group.py:155-161) = z of every vertex in the
     # global frame = the origins already folded by cs_to_affine
     pos = np.asarray(table.surfaces["origin"][:, 2], dtype=np.float64).reshape(-1)
+    fo = _host_first_order(optic, table, pos, infinite) if kind != S.FIELD_PARAXIAL_IMAGE_HEIGHT \
+        else None
+    if fo is not None:
+        # the reference's own recurrences on the packed table (paraxial_host.py): no backend
+        # array operation, no read-back
+        EPL, EPD = fo["EPL"], fo["EPD"]
+    else:
+        EPL = _f(optic.paraxial.EPL())
+        EPD = _f(optic.paraxial.EPD())
     if infinite:
-        offset = _f(fd._get_starting_z_offset(optic))
+        # angle.py:102-118 (the same expression in paraxial_image_height.py:124-140)
+        offset = (EPD - float(np.min(pos[1:-1]))) if fo is not None \
+            else _f(fd._get_starting_z_offset(optic))
         z_first = float(pos[1])
     else:
         offset = 0.0
         z_first = float(pos[0])
-    max_field = _f(optic.fields.max_field)
+    if fo is not None:   # fields/field_group.py:63-67
+        fxy = [(_f(f.x), _f(f.y)) for f in optic.fields.fields]
+        max_field = max((math.hypot(a, b) for a, b in fxy), default=0.0)
+    else:
+        max_field = _f(optic.fields.max_field)
     field_scale = max_field
     if kind == S.FIELD_PARAXIAL_IMAGE_HEIGHT:
         # paraxial_image_height.py:36-60: two unit paraxial chief-ray traces from the stop
@@ -535,7 +570,49 @@ def _compute_raygen(optic, table: SystemTable) -> None:
     # wavefront analysis (wavefront/strategy.py:157-160, 63): exit pupil z and the
     # image-space index at the PRIMARY wavelength
     try:
-        table.raygen["pupil_z"] = _f(optic.paraxial.XPL()) + float(pos[-1])
-        table.raygen["n_image"] = _f(optic.surfaces.n(optic.primary_wavelength)[-1])
+        if fo is not None:
+            table.raygen["pupil_z"] = fo["XPL"] + float(pos[-1])
+            table.raygen["n_image"] = fo["n_image"]
+        else:
+            table.raygen["pupil_z"] = _f(optic.paraxial.XPL()) + float(pos[-1])
+            table.raygen["n_image"] = _f(optic.surfaces.n(optic.primary_wavelength)[-1])
     except Exception:  # systems without a well-defined exit pupil: no wavefront data
         pass
+
+
+_HOST_PARAXIAL_GEOMS = (S.GEOM_PLANE, S.GEOM_STANDARD, S.GEOM_EVEN_ASPHERE, S.GEOM_ODD_ASPHERE,
+                        S.GEOM_POLYNOMIAL, S.GEOM_CHEBYSHEV, S.GEOM_ZERNIKE)
+
+
+def _host_first_order(optic, table: SystemTable, pos, infinite):
+    """EPL / EPD / XPL / n_image from the packed table (paraxial_host.first_order), or None
+    when the system has something that restatement does not cover."""
+    import os
+
+    if os.environ.get("OPTILAND_HIP_HOST_PARAXIAL", "1") == "0":
+        return None
+    from . import paraxial_host
+
+    surf = table.surfaces
+    if any(int(g) not in _HOST_PARAXIAL_GEOMS for g in surf["geom_kind"]):
+        return None
+    surfaces = list(optic.surfaces)
+    if any(getattr(s, "surface_type", None) == "paraxial" for s in surfaces):
+        return None
+    obj = surfaces[0]
+    if getattr(obj.geometry.cs, "reference_cs", None) is not None:
+        return None
+    stop = [i for i, s in enumerate(surfaces) if getattr(s, "is_stop", False)]
+    ap = optic.aperture
+    if not stop or ap is None:
+        return None
+    prim = _f(optic.primary_wavelength)
+    n = [_scalar_index(s.material_post, prim, "n") for s in surfaces]
+    reflect = [bool(k == S.INTERACT_REFLECT) for k in surf["interaction"]]
+    radii = [float(r) for r in surf["radius"]]
+    fo = paraxial_host.first_order(radii, n, [float(p) for p in pos], reflect, stop[0],
+                                   type(ap).__name__, _f(ap.value), infinite,
+                                   _f(obj.geometry.cs.z))
+    if fo is not None:
+        fo["n_image"] = n[-1]
+    return fo
