@@ -15,6 +15,8 @@ from a live reference `Optic` through `optiland_amd.integration`.
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -73,7 +75,7 @@ class HipRayTracer:
         self.record_all = True  # drop-in semantics; False = image plane only
         # one field point per call: ray generation fused into the trace launch
         # (`ol_trace_generate`) when the engine offers it; False = always two launches
-        self.fuse_generate = True
+        self.fuse_generate = os.environ.get("OPTILAND_HIP_FUSE_GENERATE", "1") != "0"
         # lazy records: a fused single-field launch records its last two surfaces only and
         # remembers its inputs (`last_fused_launch`) so that the caller can re-run it
         # record-all when somebody asks for the interior surfaces (integration.py)
