@@ -44,7 +44,10 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-MODE_NAMES = {"record": "record-all", "last": "record-last",
+MODE_NAMES = {"gen": "record-all, rays generated inside the launch (ol_trace_generate: what "
+                     "Optic.trace / trace_generic run for one field point)",
+              "record": "record-all from eight resident ray planes (ol_trace)",
+              "last": "record-last",
               "spot": "fused generate+trace+spot-reduce (no ray planes)",
               "opd": "fused generate+trace+OPD (ol_trace_opd: 2 pupil planes in, OPD + "
                      "intensity + pupil point out, 12 device moments)"}
@@ -83,8 +86,11 @@ def parse_args():
     ap.add_argument("--rays", type=float, default=1e7, help="rays per GPU per step")
     ap.add_argument("--dtype", choices=("f32", "f64"), default="f32")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="double_gauss")
-    ap.add_argument("--mode", choices=("record", "last", "spot", "opd"), default="record",
-                    help="record: all surfaces (drop-in semantics); last: image plane only; "
+    ap.add_argument("--mode", choices=("gen", "record", "last", "spot", "opd"), default="gen",
+                    help="gen (default): all surfaces recorded, the rays generated inside the "
+                         "same launch from resident pupil planes (ol_trace_generate, the "
+                         "drop-in's Optic.trace path); record: all surfaces, from eight resident "
+                         "ray planes (ol_trace); last: image plane only; "
                          "spot: fused generate -> trace -> reduce kernel (ol_trace_spot), "
                          "no ray planes at all; opd: fused generate -> trace -> OPD kernel "
                          "(ol_trace_opd, fp64)")
@@ -100,6 +106,12 @@ def parse_args():
                          "scaling; the default).  c3 = configs[2]: double Gauss, fp64, "
                          "--total-rays (1e8) rays in total, STRONG-scaled over the ranks")
     ap.add_argument("--total-rays", type=float, default=1e8, help="--config c3: whole-job rays")
+    ap.add_argument("--plumbing-check", action="store_true",
+                    help="TEST ONLY, not a measurement: run the launch / sharding / exchange / "
+                         "JSON plumbing on CPU tensors with gloo and the host build of the "
+                         "kernel source (tests/hostmath) standing in for the device library -- "
+                         "tests/test_bench_cli.py uses it for the N > 1 path; the line says "
+                         "`\"data\": \"plumbing-check\"` and carries no roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-baselines", action="store_true",
                     help="skip the legs that time the staged reference package (NumPy backend "
@@ -107,6 +119,31 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--ref-seconds", type=float, default=8.0)
     return ap.parse_args()
+
+
+class _HostEvent:
+    """torch.cuda.Event stand-in of --plumbing-check (wall clock)."""
+
+    def __init__(self, enable_timing=True):
+        self.t = 0.0
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+PLUMBING = {"on": False}
+
+
+def sync(device=None):
+    if not PLUMBING["on"]:
+        torch.cuda.synchronize(device)
+
+
+def make_event():
+    return _HostEvent() if PLUMBING["on"] else torch.cuda.Event(enable_timing=True)
 
 
 def self_launch(args):
@@ -120,7 +157,7 @@ def self_launch(args):
         return
     import socket
     import subprocess
-    have = torch.cuda.device_count()
+    have = args.gpus if args.plumbing_check else torch.cuda.device_count()
     if have < args.gpus:
         print(f"bench.py: error: --gpus {args.gpus} requested but only {have} HIP device(s) "
               f"are visible on this node; refusing to report a smaller job as n_gpus={args.gpus}",
@@ -138,7 +175,18 @@ def self_launch(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def init_dist(n_gpus):
+def init_dist(n_gpus, plumbing=False):
+    if plumbing:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        if n_gpus != world:
+            sys.exit(2)
+        if world > 1 or "RANK" in os.environ:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        return rank, 0, world
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -248,12 +296,25 @@ def cpu_baseline(table, hy, mode, budget_s, wl=0, threads=None):
         "value": value,
         "unit": "ray-surfaces/s",
         "cores": threads,
+        "cpu_model": cpu_model(),
         "kind": "port",
         "single_thread_value": single,
         "sample": f"{reps} x {n} rays x {S} surfaces on {threads} threads ({total:.1f} s) after "
                   f"{r1} x {n} rays on 1 thread ({t1:.1f} s); fp64, oracle/trace_oracle.c "
                   f"(gcc -O2), mode={mode}; {os.cpu_count()} logical host cores available",
     }
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def load_traffic(workload, dtype, mode):
@@ -326,6 +387,7 @@ def reference_baselines(workload, dtype, wavelength, hy, S, budget_s, device, n=
         dt = time.perf_counter() - t0
         out["numpy"] = {
             "value": n * S * reps / dt, "unit": "ray-surfaces/s", "cores": 1,
+            "cpu_model": cpu_model(), "host_logical_cores": os.cpu_count(),
             "kind": "reference",
             "sample": f"{reps} x Optic.trace_generic({n} rays) of the reference's {name}, NumPy "
                       f"backend fp64, {dt:.1f} s; elementwise NumPy kernels run on one core "
@@ -412,10 +474,19 @@ def reference_baselines(workload, dtype, wavelength, hy, S, budget_s, device, n=
 def main():
     args = parse_args()
     self_launch(args)  # N > 1 without a launcher: re-exec under torchrun and exit
-    rank, local, world = init_dist(args.gpus)
-    device = torch.device("cuda", local)
+    PLUMBING["on"] = bool(args.plumbing_check)
+    rank, local, world = init_dist(args.gpus, args.plumbing_check)
     from optiland_amd.distributed import shard_bounds
-    from optiland_amd.engine import HipSystem
+    if args.plumbing_check:
+        # TEST ONLY: CPU tensors + the host build of the kernel source behind the same engine
+        # class (tests/_hostmath.py); nothing here is a measurement
+        from tests import _hostmath
+        device = torch.device("cpu")
+        HipSystem = _hostmath.make_engine_class()
+        args.no_cpu_baseline = True
+    else:
+        from optiland_amd.engine import HipSystem
+        device = torch.device("cuda", local)
 
     strong = args.config == "c3"
     if strong:  # BASELINE.json configs[2]: double Gauss, fp64, 1e8 rays over the ranks
@@ -435,11 +506,17 @@ def main():
     S = table.num_traced
     pol = table.uses_polarization
 
-    record = hip.alloc_record(n, dtype) if args.mode == "record" else None
-    alias = record is not None and args.object_row == "alias"
+    gen = args.mode == "gen"
+    if gen and not hip.can_trace_generate():
+        raise SystemExit("--mode gen needs generator scalars without a pupil apodization")
+    record = hip.alloc_record(n, dtype) if args.mode in ("record", "gen") else None
+    alias = record is not None and args.object_row == "alias" and not gen
     opd_mode = args.mode == "opd"
     spot = args.mode == "spot" or opd_mode  # the fused, ray-plane-free pipelines
-    if spot:
+    if gen:
+        px, py = make_pupil(n, dtype, 1234 + rank, device)
+        rays = []
+    elif spot:
         if pol:
             raise SystemExit(f"--mode {args.mode} needs an unpolarised workload")
         px, py = make_pupil(n, dtype, 1234 + rank, device)
@@ -467,12 +544,18 @@ def main():
     exchange = args.exchange if (world > 1 or (args.force_exchange and have_pg)) else "none"
     configured_exchange = exchange
     pending = [None, None]  # in-flight all-gathers (double-buffered)
-    if exchange == "gather":
+    # buffers of BOTH exchange kinds whenever one is configured: the kind that is not timed
+    # runs afterwards as an extra, untimed-for-`value` leg, so that one run at N > 1 shows
+    # the reduce-first exchange and the literal all-gather of hits side by side
+    if exchange != "none" and not (args.mode in ("spot", "opd")):
         # two buffer pairs: the all-gather of step k runs on RCCL's stream while step
         # k+1 traces; a buffer is only reused after its collective has completed
-        gather_buf = [torch.empty((world, 3, n), dtype=dtype, device=device) for _ in range(2)]
-        hits = [torch.empty((3, n), dtype=dtype, device=device) for _ in range(2)]
-    if exchange == "reduce":
+        # (strong scaling of a total that does not divide: every rank contributes the
+        # largest shard's size, the tail of a smaller shard is padding)
+        n_g = -(-job_rays // world) if strong else n
+        gather_buf = [torch.empty((world, 3, n_g), dtype=dtype, device=device) for _ in range(2)]
+        hits = [torch.zeros((3, n_g), dtype=dtype, device=device) for _ in range(2)]
+    if exchange != "none":
         # spot moments come out of the trace launch itself (epilogue of the same kernel,
         # ol_trace_ex): slotted partial sums -> 7 doubles -> one small all-reduce
         # Per step: zero 4 KB, trace (+ epilogue), ONE async all-gather of the 4 KB slot
@@ -513,7 +596,7 @@ def main():
     def step(ev0=None, ev1=None):
         if spot:
             return spot_step(ev0, ev1)
-        if args.mode == "record":
+        if args.mode in ("record", "gen"):
             src = rays
         else:  # last-surface mode mutates the rays in place: refresh from the source
             for d, s_ in zip(scratch, rays):
@@ -532,8 +615,15 @@ def main():
                 spot_arg = (slots[k], 0.0, 0.0)
         if ev0 is not None:
             ev0.record()
-        res = hip.trace(src, wl, record=record if record is not None else False, prt=prt,
-                        check_status=False, prt_identity=pol, spot=spot_arg)
+        if gen:
+            res = hip.trace_generate(px, py, wl, field=(0.0, hy), record=record, prt=prt,
+                                     zero_status=False, defer_status=True)
+            if spot_arg is not None:  # (the generating kernel has no spot epilogue)
+                hip.spot_moments(res.row(res.last, 0), res.row(res.last, 1),
+                                 res.row(res.last, 6), out=slots[k].view(-1)[:6])
+        else:
+            res = hip.trace(src, wl, record=record if record is not None else False, prt=prt,
+                            check_status=False, prt_identity=pol, spot=spot_arg)
         if ev1 is not None:
             ev1.record()
         if exchange != "none":
@@ -542,28 +632,28 @@ def main():
                     # the epilogue is for unpolarised traces: reduce the image-plane planes
                     # with the stand-alone kernel into slot 0 of the same block
                     xi, yi, ii = ((res.row(res.last, q) for q in (0, 1, 6))
-                                  if args.mode == "record" else (src[0], src[1], src[6]))
+                                  if record is not None else (src[0], src[1], src[6]))
                     hip.spot_moments(xi, yi, ii, out=slots[k].view(-1)[:6])
                 pending[k] = dist.all_gather_into_tensor(all_slots[k].view(-1),
                                                          slots[k].view(-1), async_op=True)
             else:
-                if args.mode == "record":
+                if record is not None:
                     x, y, inten = res.row(res.last, 0), res.row(res.last, 1), res.row(res.last, 6)
                 else:
                     x, y, inten = src[0], src[1], src[6]
-                hits[k][0].copy_(x)
-                hits[k][1].copy_(y)
-                hits[k][2].copy_(inten)
+                hits[k][0, :n].copy_(x)
+                hits[k][1, :n].copy_(y)
+                hits[k][2, :n].copy_(inten)
                 pending[k] = dist.all_gather_into_tensor(gather_buf[k].view(-1),
                                                          hits[k].view(-1), async_op=True)
         return res
 
     def timed(steps, evs=None):
         """EXACTLY `steps` steps between barrier + synchronize brackets; max over ranks."""
-        torch.cuda.synchronize(device)
+        sync(device)
         if have_pg:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        sync(device)
         t0 = time.perf_counter()
         for k in range(steps):
             step(*(evs[k] if evs else ()))
@@ -573,10 +663,10 @@ def main():
                 if ww is not None:
                     ww.wait()
             pending[k] = None
-        torch.cuda.synchronize(device)
+        sync(device)
         if have_pg:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        sync(device)
         dt = time.perf_counter() - t0
         if have_pg:
             tt = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -586,8 +676,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(args.steps)]
+    evs = [(make_event(), make_event()) for _ in range(args.steps)]
     elapsed = timed(args.steps, evs)
     if exchange == "reduce" and not spot and args.steps:
         # fold the gathered slots of the last step: whole-job spot statistics
@@ -603,25 +692,39 @@ def main():
         exchange = configured_exchange
         wire = (8 * 64 * 8 if configured_exchange == "reduce" else 3 * b * n) if not spot \
             else (96 if opd_mode else 56)
+        kinds = {"reduce": "async all-gather of the 4 KB spot-moment slot block (RCCL)",
+                 "gather": "literal RCCL all-gather of image-plane hits (x, y, i)"}
         exchange_info = {
-            "kind": {"reduce": "async all-gather of the 4 KB spot-moment slot block (RCCL)",
-                     "gather": "literal RCCL all-gather of image-plane hits (x, y, i)"}[
-                         configured_exchange] if not spot else "all-reduce of 7 doubles",
+            "kind": kinds[configured_exchange] if not spot else "all-reduce of 7 doubles",
             "ms_per_step_with": elapsed / args.steps * 1e3,
             "ms_per_step_without": bare / args.steps * 1e3,
             "exchange_ms_per_step": (elapsed - bare) / args.steps * 1e3,
             "bytes_per_rank_per_step": wire,
         }
+        if not spot:
+            # the OTHER exchange kind, same steps, outside the reported region
+            other = "gather" if configured_exchange == "reduce" else "reduce"
+            exchange = other
+            step()
+            alt = timed(args.steps)
+            exchange = configured_exchange
+            exchange_info["other"] = {
+                "kind": kinds[other],
+                "ms_per_step_with": alt / args.steps * 1e3,
+                "exchange_ms_per_step": (alt - bare) / args.steps * 1e3,
+                "bytes_per_rank_per_step": 8 * 64 * 8 if other == "reduce" else 3 * b * n,
+            }
 
     kern_ms = float(np.mean([a.elapsed_time(bb) for a, bb in evs])) if args.steps else float("nan")
-    bw = device_bandwidth(device) if (rank == 0 and args.steps) else None
+    bw = device_bandwidth(device) if (rank == 0 and args.steps and not args.plumbing_check) \
+        else None
 
     if rank == 0:
         total_rs = float(job_rays) * S * args.steps
         value = total_rs / elapsed
         # algorithmic bytes per launch: record-all reads 8 planes and
         # writes 8 planes for each of the S+1 surfaces; record-last reads 8, writes 8.
-        if args.mode == "record":
+        if args.mode in ("record", "gen"):
             alg_bytes = 8 * b * (S + 2) * n
         elif opd_mode:
             alg_bytes = (2 + 5) * b * n  # pupil planes in; OPD, intensity, pupil point out
@@ -635,6 +738,8 @@ def main():
         # of the record block IS the input, so only S rows are written; the PRT of a fresh
         # trace is write-only (starts from I in-kernel)
         moved_bytes = alg_bytes - (8 * b * n if alias else 0) - (9 * b * n if pol else 0)
+        if gen:  # two pupil planes are read instead of eight ray planes; row 0 IS written
+            moved_bytes -= 6 * b * n
         alg_GBps = alg_bytes / (kern_ms * 1e-3) / 1e9
         moved_GBps = moved_bytes / (kern_ms * 1e-3) / 1e9
         traffic = load_traffic(args.workload, args.dtype,
@@ -655,7 +760,8 @@ def main():
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic",
+            "data": "plumbing-check (CPU, not a measurement)" if args.plumbing_check
+                    else "synthetic",
             "config": {
                 "workload": f"{desc} ({S} traced surfaces incl. image plane), "
                             + (f"{job_rays:.3g} rays in total over {world} GPU(s) "
@@ -664,14 +770,16 @@ def main():
                             f"uniform-disc pupil, Hy={hy}, "
                             f"mode={MODE_NAMES[args.mode]}",
                 "baseline_config": "configs[2]" if strong else
-                                   ("configs[1]" if (args.workload, args.dtype, args.mode, n) ==
-                                    ("double_gauss", "f32", "record", 10_000_000) else None),
+                                   ("configs[1]" if (args.workload, args.dtype, n) ==
+                                    ("double_gauss", "f32", 10_000_000)
+                                    and args.mode in ("gen", "record") else None),
                 "rays_per_gpu": n,
                 "rays_total": job_rays,
                 "surfaces": S,
                 "mode": args.mode,
-                "object_row": ("zero-copy (rays generated into record row 0)" if alias
-                               else "copied") if args.mode == "record" else None,
+                "object_row": ("written by the tracing launch itself (generated there)" if gen else
+                               ("zero-copy (rays generated into record row 0)" if alias
+                                else "copied")) if args.mode in ("record", "gen") else None,
                 "exchange": configured_exchange,
                 "parallelism": f"ray-shard x{world}",
             },
@@ -679,7 +787,8 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": "opd_trace_kernel" if opd_mode else
-                          ("spot_trace_kernel" if spot else "trace_kernel"),
+                          ("spot_trace_kernel" if spot else
+                           ("trace_kernel<..., GEN = true>" if gen else "trace_kernel")),
                 # the contract's `achieved` / `frac`: bytes this launch really moves (equal
                 # to the PMC traffic within 0.1 %) over the HIP-event kernel time
                 "achieved": moved_GBps,
@@ -712,7 +821,8 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            port = cpu_baseline(table, hy, "last" if spot else args.mode, args.cpu_seconds, wl)
+            port = cpu_baseline(table, hy, "last" if spot else ("record" if gen else args.mode),
+                                args.cpu_seconds, wl)
             ref = None if args.no_ref_baselines else reference_baselines(
                 args.workload, args.dtype, wavelength, hy, S, args.ref_seconds, device,
                 full_rays=n)

@@ -222,6 +222,18 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf,
                      const double* coeffs, int32_t n_coeffs,
                      const ol_surface_optics* optics, int32_t n_wavelengths,
                      ol_system** out);
+/* ABI 6.  Rewrite the device tables of an EXISTING system from a new description -- same
+ * arguments as ol_system_create -- in place: no allocation, four small host-to-device copies
+ * per precision queued on `stream` (so ordered after every launch already queued there that
+ * reads the old tables).  For the callers that edit a prescription between traces
+ * (optimisers, tolerancing loops: `Optic.updater.set_radius(...)` then `Optic.trace(...)`),
+ * where create + destroy per edit would dominate a small trace.
+ * Returns OL_EUNSUPPORTED -- the system is untouched, create a new one -- when the new
+ * description does not fit the existing allocations (other surface / wavelength counts, a
+ * device coefficient block beyond the allocated capacity).                               */
+int ol_system_update(ol_system* sys, const ol_surface_desc* surf, int32_t n_surf,
+                     const double* coeffs, int32_t n_coeffs,
+                     const ol_surface_optics* optics, int32_t n_wavelengths, void* stream);
 void ol_system_destroy(ol_system* sys);
 int32_t ol_system_num_surfaces(const ol_system* sys);
 

@@ -115,6 +115,7 @@ EXPORTS = (
     "ol_trace_opd",
     "ol_pupil_fill",
     "ol_trace_generate",
+    "ol_system_update",
 )
 
 F32, F64 = 0, 1
@@ -207,6 +208,8 @@ def bind(lib, path: str = "?"):
         raise HipExtensionError(
             f"{path}: ABI version {have} != expected {ABI_VERSION}; rebuild"
         )
+    lib.ol_system_update.restype = C.c_int
+    lib.ol_system_update.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]
     lib.ol_trace_generate.restype = C.c_int
     lib.ol_trace_generate.argtypes = [vp, C.c_int, i64, vp, vp, i32, vp, i64, C.POINTER(vp), vp,
                                       u32, vp, vp, vp]

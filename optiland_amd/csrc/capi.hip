@@ -227,6 +227,17 @@ struct DeviceTable {
   ol::DevSurfCold<T>* cold = nullptr;
   ol::DevOptics<T>* optics = nullptr;
   T* coeffs = nullptr;
+  size_t n_surf = 0, n_opt = 0, coef_capacity = 0;  // allocation sizes (ol_system_update)
+};
+
+// everything ol_system_create derives from its arguments, in double, before any device call
+struct Staged {
+  std::vector<struct HostSurf> surf;
+  std::vector<ol::DevOptics<double>> optics;
+  std::vector<double> coeffs;
+  std::vector<size_t> int_slots;  // coeffs entries uploaded as integer bit patterns
+  std::vector<int32_t> interaction, coating, geom;
+  std::vector<uint8_t> polygon;
 };
 
 }  // namespace
@@ -245,10 +256,14 @@ struct ol_system {
 
 namespace {
 
+// in_place: the allocations of `dst` are reused (they must fit: checked by the caller) and
+// the copies are queued on `stream`, i.e. ordered after every launch already queued there
+// that still reads the old table; otherwise fresh allocations and blocking copies.
 template <typename T>
 int upload(const std::vector<HostSurf>& surf64,
            const std::vector<ol::DevOptics<double>>& opt64, const std::vector<double>& coef64,
-           const std::vector<size_t>& int_slots, DeviceTable<T>& dst) {
+           const std::vector<size_t>& int_slots, DeviceTable<T>& dst, bool in_place = false,
+           hipStream_t stream = nullptr) {
   std::vector<ol::DevSurfHot<T>> surf(surf64.size());
   std::vector<ol::DevSurfCold<T>> cold(surf64.size());
   for (size_t i = 0; i < surf64.size(); ++i) {
@@ -284,12 +299,29 @@ int upload(const std::vector<HostSurf>& surf64,
     std::memcpy(&coef[i], &v, sizeof(T));
   }
 
+  if (in_place) {
+    // (pageable sources: the runtime stages them before it returns, the vectors may go)
+    OL_HIP_CHECK(hipMemcpyAsync(dst.cold, cold.data(), cold.size() * sizeof(ol::DevSurfCold<T>),
+                                hipMemcpyHostToDevice, stream));
+    OL_HIP_CHECK(hipMemcpyAsync(dst.surf, surf.data(), surf.size() * sizeof(ol::DevSurfHot<T>),
+                                hipMemcpyHostToDevice, stream));
+    OL_HIP_CHECK(hipMemcpyAsync(dst.optics, opt.data(), opt.size() * sizeof(ol::DevOptics<T>),
+                                hipMemcpyHostToDevice, stream));
+    OL_HIP_CHECK(hipMemcpyAsync(dst.coeffs, coef.data(), coef.size() * sizeof(T),
+                                hipMemcpyHostToDevice, stream));
+    return OL_OK;
+  }
+  dst.n_surf = surf.size();
+  dst.n_opt = opt.size();
+  // head room: a surface whose coefficient block grows a little (an asphere gaining a term)
+  // still updates in place
+  dst.coef_capacity = coef.size() + 64;
   OL_HIP_CHECK(hipMalloc((void**)&dst.surf, surf.size() * sizeof(ol::DevSurfHot<T>)));
   OL_HIP_CHECK(hipMalloc((void**)&dst.cold, cold.size() * sizeof(ol::DevSurfCold<T>)));
   OL_HIP_CHECK(hipMemcpy(dst.cold, cold.data(), cold.size() * sizeof(ol::DevSurfCold<T>),
                          hipMemcpyHostToDevice));
   OL_HIP_CHECK(hipMalloc((void**)&dst.optics, opt.size() * sizeof(ol::DevOptics<T>)));
-  OL_HIP_CHECK(hipMalloc((void**)&dst.coeffs, coef.size() * sizeof(T)));
+  OL_HIP_CHECK(hipMalloc((void**)&dst.coeffs, dst.coef_capacity * sizeof(T)));
   OL_HIP_CHECK(hipMemcpy(dst.surf, surf.data(), surf.size() * sizeof(ol::DevSurfHot<T>),
                          hipMemcpyHostToDevice));
   OL_HIP_CHECK(hipMemcpy(dst.optics, opt.data(), opt.size() * sizeof(ol::DevOptics<T>),
@@ -562,19 +594,20 @@ int ol_set_tuning(int32_t knob, int32_t value) {
   }
 }
 
-int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* coeffs,
-                     int32_t n_coeffs, const ol_surface_optics* optics, int32_t n_wavelengths,
-                     ol_system** out) {
-  if (!out) return fail(OL_EINVAL, "ol_system_create: out is NULL");
-  *out = nullptr;
+namespace {
+// argument validation + every host-side conversion of ol_system_create / ol_system_update
+int stage_system(const ol_surface_desc* surf, int32_t n_surf, const double* coeffs,
+                 int32_t n_coeffs, const ol_surface_optics* optics, int32_t n_wavelengths,
+                 Staged& st) {
   if (!surf || n_surf <= 0) return fail(OL_EINVAL, "ol_system_create: no surfaces");
   if (!optics || n_wavelengths <= 0) return fail(OL_EINVAL, "ol_system_create: no optics table");
   if (n_coeffs < 0 || (n_coeffs > 0 && !coeffs))
     return fail(OL_EINVAL, "ol_system_create: bad coefficient buffer");
 
-  std::vector<HostSurf> dev(n_surf);
-  std::vector<double> dcoef;
-  std::vector<size_t> int_slots;  // dcoef entries uploaded as integer bit patterns
+  st.surf.assign(n_surf, HostSurf());
+  std::vector<HostSurf>& dev = st.surf;
+  std::vector<double>& dcoef = st.coeffs;
+  std::vector<size_t>& int_slots = st.int_slots;
   int32_t prev_traced = -1;
   for (int32_t i = 0; i < n_surf; ++i) {
     const ol_surface_desc& s = surf[i];
@@ -746,7 +779,8 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
     d.coeff_len = (int32_t)dcoef.size() - d.coeff_off;
   }
 
-  std::vector<ol::DevOptics<double>> dopt((size_t)n_surf * n_wavelengths);
+  std::vector<ol::DevOptics<double>>& dopt = st.optics;
+  dopt.assign((size_t)n_surf * n_wavelengths, ol::DevOptics<double>());
   for (size_t i = 0; i < dopt.size(); ++i) {
     const ol_surface_optics& o = optics[i];
     std::memset(&dopt[i], 0, sizeof(dopt[i]));
@@ -757,14 +791,10 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
     dopt[i].absorb = o.absorb > 0.0 ? o.absorb : 0.0;
   }
 
-  ol_system* sys = new (std::nothrow) ol_system();
-  if (!sys) return fail(OL_ENOMEM, "ol_system_create: out of host memory");
-  sys->n_surf = n_surf;
-  sys->n_wl = n_wavelengths;
   for (int32_t i = 0; i < n_surf; ++i) {
-    sys->interaction.push_back(surf[i].interaction);
-    sys->coating.push_back(surf[i].coating_kind);
-    sys->geom.push_back(surf[i].geom_kind);
+    st.interaction.push_back(surf[i].interaction);
+    st.coating.push_back(surf[i].coating_kind);
+    st.geom.push_back(surf[i].geom_kind);
     {
       bool poly = surf[i].aperture_kind == OL_AP_POLYGON;
       if (surf[i].aperture_kind == OL_AP_COMPOSITE) {
@@ -772,15 +802,38 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
         for (int64_t t = 0; t < cnt; ++t)
           poly = poly || (int)coeffs[off + t * OL_AP_TOKEN_DOUBLES] == OL_AP_POLYGON;
       }
-      sys->polygon.push_back(poly ? 1 : 0);
+      st.polygon.push_back(poly ? 1 : 0);
     }
   }
+  return OL_OK;
+}
+
+void adopt_host_copies(ol_system* sys, Staged& st) {
+  sys->interaction.swap(st.interaction);
+  sys->coating.swap(st.coating);
+  sys->geom.swap(st.geom);
+  sys->polygon.swap(st.polygon);
+}
+}  // namespace
+
+int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* coeffs,
+                     int32_t n_coeffs, const ol_surface_optics* optics, int32_t n_wavelengths,
+                     ol_system** out) {
+  if (!out) return fail(OL_EINVAL, "ol_system_create: out is NULL");
+  *out = nullptr;
+  Staged st;
+  if (int rc = stage_system(surf, n_surf, coeffs, n_coeffs, optics, n_wavelengths, st)) return rc;
+  ol_system* sys = new (std::nothrow) ol_system();
+  if (!sys) return fail(OL_ENOMEM, "ol_system_create: out of host memory");
+  sys->n_surf = n_surf;
+  sys->n_wl = n_wavelengths;
+  adopt_host_copies(sys, st);
   if (hipGetDevice(&sys->device) != hipSuccess) {
     delete sys;
     return fail(OL_EHIP, "ol_system_create: no HIP device (hipGetDevice failed)");
   }
-  int rc = upload<float>(dev, dopt, dcoef, int_slots, sys->f32);
-  if (rc == OL_OK) rc = upload<double>(dev, dopt, dcoef, int_slots, sys->f64);
+  int rc = upload<float>(st.surf, st.optics, st.coeffs, st.int_slots, sys->f32);
+  if (rc == OL_OK) rc = upload<double>(st.surf, st.optics, st.coeffs, st.int_slots, sys->f64);
   if (rc != OL_OK) {
     release(sys->f32);
     release(sys->f64);
@@ -788,6 +841,35 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
     return rc;
   }
   *out = sys;
+  return OL_OK;
+}
+
+int ol_system_update(ol_system* sys, const ol_surface_desc* surf, int32_t n_surf,
+                     const double* coeffs, int32_t n_coeffs, const ol_surface_optics* optics,
+                     int32_t n_wavelengths, void* stream) {
+  if (!sys) return fail(OL_EINVAL, "ol_system_update: system is NULL");
+  if (n_surf != sys->n_surf || n_wavelengths != sys->n_wl)
+    return fail(OL_EUNSUPPORTED, "ol_system_update: %d surfaces x %d wavelengths do not fit the "
+                                 "system's %d x %d tables", n_surf, n_wavelengths, sys->n_surf,
+                sys->n_wl);
+  Staged st;
+  if (int rc = stage_system(surf, n_surf, coeffs, n_coeffs, optics, n_wavelengths, st)) return rc;
+  const size_t need = st.coeffs.size() ? st.coeffs.size() : 1;
+  if (need > sys->f32.coef_capacity || need > sys->f64.coef_capacity)
+    return fail(OL_EUNSUPPORTED, "ol_system_update: coefficient block of %zu values exceeds the "
+                                 "allocated %zu", need, sys->f32.coef_capacity);
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != sys->device)
+      return fail(OL_EINVAL, "ol_system_update: current HIP device %d is not the system's "
+                             "device %d", cur, sys->device);
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = upload<float>(st.surf, st.optics, st.coeffs, st.int_slots, sys->f32, true, s);
+  if (rc == OL_OK)
+    rc = upload<double>(st.surf, st.optics, st.coeffs, st.int_slots, sys->f64, true, s);
+  if (rc != OL_OK) return rc;
+  adopt_host_copies(sys, st);
   return OL_OK;
 }
 

@@ -65,21 +65,38 @@
 //      the kernarg segment by the phase that needs it (kernargs(), arg_view<true>);
 //   2  ... and the TABLE ROWS too: every phase of the surface body re-reads the few fields it
 //      uses (SurfFetched), nothing of a surface is live across the Newton loop.
-// Every level has 0-6 static SGPR spills where level 0 had 50-320 in the fp64 Newton / fused
-// kernels, but the extra scalar-load round trips cost where the kernel was not short of
-// SGPRs to begin with: the levels below are the ones that won the interleaved A/Bs
-// (profiles/r03_ab_fetch_levels.txt).  Per kernel class, overridable for A/B builds.
-#ifndef OL_FETCH_NR_F32
-#define OL_FETCH_NR_F32 2
+// Level 2 has 0-6 static SGPR spills where level 0 has 40-320 in the Newton / fp64 kernels,
+// but every re-read is a scalar-load round trip the by-value form does not make, and that
+// costs where the kernel was not short of SGPRs to begin with.  Interleaved A/Bs against the
+// round-2 library on one MI355X, 1e7 rays (profiles/r03_ab_fetch_levels.txt; ratio of kernel
+// times, < 1 = faster than round 2):
+//   fp32 Newton kernels   level 0  1.00   level 1  1.00-1.26   level 2  1.02-1.18
+//                         (C5 fp32 record-all: 0.322 / 0.404 / 0.380 ms -- 38 spills cost
+//                          less than the extra round trips; fp32 has 8 waves to hide neither)
+//   fp64 Zernike kernels  level 1  0.80-0.94   level 2  0.77-0.94   (fused OPD 0.637 -> 0.488,
+//                         fused spot 0.449 -> 0.358, record-all 0.530 -> 0.497 ms)
+//   fp64 even-asphere     level 1  0.90-0.98   level 2  0.96-1.00
+//   fp64 conic fused      level 0  0.99-1.00   level 1  0.99   level 2  1.02-1.06
+//   fp32 conic fused spot level 0  1.00        level 1  0.97   level 2  1.07
+// Hence: the level per kernel class below.  Overridable for A/B builds
+// (tools/build_variants.py).
+#ifndef OL_FETCH_NR_F32           // polarised fp32 Newton trace kernels, fused fp32 Newton
+#define OL_FETCH_NR_F32 0         // kernels (spot)
 #endif
-#ifndef OL_FETCH_NR_F64
+#ifndef OL_FETCH_NR_F32_PLAIN     // unpolarised fp32 Newton trace kernels: level 1 is as fast
+#define OL_FETCH_NR_F32_PLAIN 1   // as level 0 (1.00) and spills 0-1 scalars instead of 23
+#endif
+#ifndef OL_FETCH_NR_F64           // Zernike-family and generic Newton kernels, fp64
 #define OL_FETCH_NR_F64 2
+#endif
+#ifndef OL_FETCH_NR_F64_ASPHERE   // even-asphere family, fp64
+#define OL_FETCH_NR_F64_ASPHERE 1
 #endif
 #ifndef OL_FETCH_LEAN_F64   // fused spot / OPD kernels without a Newton surface, fp64
 #define OL_FETCH_LEAN_F64 1
 #endif
 #ifndef OL_FETCH_LEAN_F32   // fused spot kernels without a Newton surface, fp32
-#define OL_FETCH_LEAN_F32 0
+#define OL_FETCH_LEAN_F32 1
 #endif
 
 #include "surface_math.h"
@@ -89,10 +106,13 @@ namespace ol {
 // fetch level of a kernel instance (see the OL_FETCH_* knobs above); `fused` = the spot / OPD
 // kernels (the plain trace kernel without a Newton surface is always level 0: its hot block
 // is one prefetched s_load_dwordx16 and it spills nothing)
-template <typename T, int NR, bool FUSED>
+template <typename T, int NR, bool FUSED, int POLK = 0>
 constexpr int fetch_level() {
   if (OL_TABLE_IN_LDS) return 0;
-  if (NR != 0) return sizeof(T) == 4 ? OL_FETCH_NR_F32 : OL_FETCH_NR_F64;
+  if (NR != 0) {
+    if (sizeof(T) == 4) return (!FUSED && POLK == 0) ? OL_FETCH_NR_F32_PLAIN : OL_FETCH_NR_F32;
+    return NR == kNrEvenAsphere ? OL_FETCH_NR_F64_ASPHERE : OL_FETCH_NR_F64;
+  }
   if (!FUSED) return 0;
   return sizeof(T) == 4 ? OL_FETCH_LEAN_F32 : OL_FETCH_LEAN_F64;
 }
@@ -458,7 +478,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
   uint32_t status = 0;
   if constexpr (GEN) {
     static_assert(RPT == 1 && !SPOT, "the generating prologue is one ray per lane");
-    const auto A0 = arg_view<(fetch_level<T, NR, false>() >= 1), T>(a);
+    const auto A0 = arg_view<(fetch_level<T, NR, false, POLK>() >= 1), T>(a);
     const auto& in_ = A0->in;
     T px = base.at(in_.px)[0], py = base.at(in_.py)[0];
     T vx = in_.vx0, vy = in_.vy0, o[6];
@@ -538,8 +558,8 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void t
   bool prt_fresh = POLK != 0 && (GEN || (a.flags & kTracePrtIdentity) != 0);
   // Newton-Raphson ranges: table rows re-read phase by phase (SurfFetched), kernel arguments
   // re-read from the kernarg segment where they are used -- these kernels are short of SGPRs
-  constexpr bool kFetch = fetch_level<T, NR, false>() >= 2;      // table rows
-  constexpr bool kFetchArgs = fetch_level<T, NR, false>() >= 1;  // argument block
+  constexpr bool kFetch = fetch_level<T, NR, false, POLK>() >= 2;      // table rows
+  constexpr bool kFetchArgs = fetch_level<T, NR, false, POLK>() >= 1;  // argument block
   const cptr<T> coeffs_c = as_const(coeff_tab);
   DevSurf<T> last_traced;
   last_traced.cold = as_const(cold_tab);

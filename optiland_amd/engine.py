@@ -96,6 +96,30 @@ class HipSystem:
     def _check(self, rc: int, what: str) -> None:
         _capi.check(rc, what, self.lib)
 
+    def update(self, table: SystemTable) -> bool:
+        """`ol_system_update`: rewrite this system's device tables IN PLACE from `table`
+        (no allocation; the copies are queued on the current stream, after everything that
+        still reads the old tables).  False -- nothing changed -- when the new table does not
+        fit the existing allocations or the library predates ABI 6; the caller then builds a
+        new `HipSystem`."""
+        if not getattr(self, "_handle", None) or not hasattr(self.lib, "ol_system_update"):
+            return False
+        surf = np.ascontiguousarray(table.surfaces)
+        optics = np.ascontiguousarray(table.optics)
+        coeffs = np.ascontiguousarray(table.coeffs, dtype=np.float64)
+        if surf.shape[0] != self.table.num_surfaces or optics.shape[1] != self.table.optics.shape[1]:
+            return False
+        with self._device_ctx():
+            rc = self.lib.ol_system_update(
+                self._handle, surf.ctypes.data, surf.shape[0],
+                coeffs.ctypes.data if coeffs.size else None, coeffs.size,
+                optics.ctypes.data, optics.shape[1], self._stream())
+        if rc == -2:  # OL_EUNSUPPORTED: does not fit
+            return False
+        self._check(rc, "ol_system_update")
+        self.table = table
+        return True
+
     def close(self):
         if getattr(self, "_handle", None):
             self.lib.ol_system_destroy(self._handle)

@@ -219,7 +219,8 @@ class _PendingRecord:
         if len(surfaces) != self.table.num_surfaces:
             return  # the optic was rebuilt in between: nothing sensible to bind
         eng = self.engine
-        if getattr(eng, "_handle", True) is None:  # evicted and closed meanwhile
+        if getattr(eng, "_handle", True) is None or getattr(eng, "table", self.table) \
+                is not self.table:  # evicted and closed, or patched to another prescription
             eng = _tracer._make_engine(self.table, getattr(eng, "device", None))
         front = _tracer.HipRayTracer(self.table, dtype=self.dtype, engine=eng)
         hx, hy, px, py, vig, wavelength, flags = self.launch
@@ -279,11 +280,14 @@ def _make_tracer_class():
             self._hip_engines = collections.OrderedDict()
             # wavelength -> (token, kept objects, table key | UnsupportedSystem)
             self._hip_memo = collections.OrderedDict()
+            self._hip_surface_cache = {}  # id(surface) -> (token, packed row): incremental pack
             self._hip_engine = None  # most recently used (introspection)
             self._hip_table = None
             self.pack_count = 0      # packs really performed (introspection for tests)
+            self.engine_updates = 0  # ... of which patched the device table in place
             self.speculative_hits = 0    # launches queued before the change check, kept
             self.speculative_misses = 0  # ... dropped because the optic had changed
+            self._hip_spec_ok = True     # False right after a miss: validate before launching
             self.last_path = None  # "hip" | "reference" (introspection for tests)
 
         def __deepcopy__(self, memo):
@@ -296,6 +300,8 @@ def _make_tracer_class():
             for k, v in self.__dict__.items():
                 if k in ("_hip_engines", "_hip_memo"):
                     new.__dict__[k] = collections.OrderedDict()
+                elif k == "_hip_surface_cache":
+                    new.__dict__[k] = {}
                 elif k in ("_hip_engine", "_hip_table"):
                     new.__dict__[k] = None
                 else:
@@ -322,12 +328,13 @@ def _make_tracer_class():
             """Forget the change-detector memo (the next trace re-packs the optic)."""
             self._hip_memo.clear()
 
-        def _entry_for(self, wavelength):
-            """(engine, table, fronts) for the optic AS IT IS NOW at `wavelength`."""
+        def _entry_for(self, wavelength, tok=None):
+            """(engine, table, fronts) for the optic AS IT IS NOW at `wavelength`.  `tok`: its
+            change-detector token if the caller has just taken it."""
             w = float(wavelength.item()) if hasattr(wavelength, "item") else float(wavelength)
-            tok = None
             if _fp.ENABLED:
-                tok, _keep = _fp.optic_token(self.optic, w)
+                if tok is None:
+                    tok, _keep = _fp.optic_token(self.optic, w)
                 memo = self._hip_memo.get(w)
                 if memo is not None and memo[0] == tok:
                     key = memo[2]
@@ -340,14 +347,30 @@ def _make_tracer_class():
                         return hit
             self.pack_count += 1
             try:
-                table = pack_optic(self.optic, wavelengths=[w])
+                # incremental: surfaces whose change-detector token is the one they were
+                # last packed under are taken from the per-surface cache, not read again
+                table = pack_optic(self.optic, wavelengths=[w],
+                                   tokens=None if tok is None else tok[1],
+                                   cache=self._hip_surface_cache)
             except UnsupportedSystem as exc:
                 self._remember(w, exc)
                 raise
             key = _table_key(table)
             hit = self._hip_engines.get(key)
             if hit is None:
-                hit = (_tracer._make_engine(table, self._hip_device), table, {})
+                # an optic edited between traces: the engine this wavelength was traced on
+                # last time is patched in place (ol_system_update: four small async copies)
+                # instead of being replaced by a new one (allocations, blocking copies)
+                old_memo = self._hip_memo.get(w)
+                old_key = old_memo[2] if old_memo is not None else None
+                old = self._hip_engines.get(old_key) if isinstance(old_key, tuple) else None
+                upd = getattr(old[0], "update", None) if old is not None else None
+                if upd is not None and upd(table):
+                    del self._hip_engines[old_key]
+                    hit = (old[0], table, {})
+                    self.engine_updates += 1
+                else:
+                    hit = (_tracer._make_engine(table, self._hip_device), table, {})
                 self._hip_engines[key] = hit
                 while len(self._hip_engines) > _MAX_ENGINES:  # evict least recently used
                     _, (old, _t, _f) = self._hip_engines.popitem(last=False)
@@ -370,10 +393,10 @@ def _make_tracer_class():
             while len(self._hip_memo) > _MAX_MEMO:
                 self._hip_memo.popitem(last=False)
 
-        def _front_for(self, wavelength):
+        def _front_for(self, wavelength, tok=None):
             """The stand-alone device tracer (`tracer.HipRayTracer`) on the current table in
             the backend's precision: it owns the whole device-side call sequence."""
-            eng, table, fronts = self._entry_for(wavelength)
+            eng, table, fronts = self._entry_for(wavelength, tok)
             dtype = self._dtype()
             front = fronts.get(dtype)
             if front is None:
@@ -452,7 +475,12 @@ def _make_tracer_class():
             only then comes the one status read-back.  If the optic did change, the results
             of that launch are dropped (they live in a fresh block nobody has seen) and the
             call is repeated on a re-packed table."""
-            spec = self._speculate(wavelength)
+            # (an optic that is being edited between traces -- an optimiser, a tolerancing
+            # loop -- misses every time: after a miss the next call validates first instead
+            # of queueing a launch that is thrown away)
+            spec = self._speculate(wavelength) if self._hip_spec_ok else None
+            self._hip_spec_ok = True
+            tok = None
             if spec is not None:
                 front, table, tok0, w = spec
                 mine = err = None
@@ -479,9 +507,11 @@ def _make_tracer_class():
                     self.last_path = "hip"
                     return self._finish(front, table, mine, wavelength, update_intensity)
                 self.speculative_misses += 1
+                self._hip_spec_ok = False
                 front.surfaces._bind(None)  # drop the stale launch's block
+                front._last_res = None
             try:
-                front, table = self._front_for(wavelength)
+                front, table = self._front_for(wavelength, tok)
             except UnsupportedSystem:
                 self.last_path = "reference"
                 return original()

@@ -297,8 +297,88 @@ def _scalar_index(material, w: float, which: str) -> float:
     return hit
 
 
+def _pack_surface_local(is_object: bool, surf, wl):
+    """One surface, packed by itself: (desc row, its coefficient block as a list with every
+    offset RELATIVE to the block, optics rows per wavelength).  Raises `UnsupportedSystem`."""
+    row = np.zeros((), dtype=S.SURFACE_DESC_DTYPE)
+    opt = np.zeros(wl.size, dtype=S.SURFACE_OPTICS_DTYPE)
+    coeffs: list = []
+    geom = surf.geometry
+    R, t = cs_to_affine(geom.cs)
+    row["origin"] = t
+    row["rot"] = R.reshape(-1)
+    row["flags"] = 0 if (R is _EYE3 or np.array_equal(R, _EYE3)) else S.SURF_ROTATED
+    im = surf.interaction_model
+    if type(im).__name__ != "RefractiveReflectiveModel":
+        raise UnsupportedSystem(
+            f"interaction model {type(im).__name__} is not on the fused path"
+        )
+    if getattr(im, "bsdf", None) is not None:
+        raise UnsupportedSystem("BSDF scatter is not on the fused path")
+    _pack_geometry(geom, row, coeffs)
+    _pack_aperture(surf.aperture, row, coeffs)
+    _pack_coating(surf.coating, row, coeffs)
+    if is_object:
+        # ObjectSurface.trace only records (surfaces/object_surface.py:56-93)
+        row["interaction"] = S.INTERACT_RECORD_ONLY
+        opt[:] = (1.0, 1.0, 0.0)
+        opt["n2"] = [_scalar_index(surf.material_post, float(w), "n") for w in wl]
+        return row, coeffs, opt
+    row["interaction"] = S.INTERACT_REFLECT if im.is_reflective else S.INTERACT_REFRACT
+    pre, post = surf.material_pre, surf.material_post
+    for m in (pre, post):
+        pm = type(m.propagation_model).__name__
+        if pm != "HomogeneousPropagation":
+            raise UnsupportedSystem(f"propagation model {pm} is not on the fused path")
+    for j, w in enumerate(wl):
+        w = float(w)
+        n1 = _scalar_index(pre, w, "n")
+        n2 = _scalar_index(post, w, "n")
+        k1 = _scalar_index(pre, w, "k")
+        # propagation/homogeneous.py:44-53: alpha = 4 pi k / lambda, applied
+        # as exp(-alpha * t * 1e3) only when k > 0.
+        absorb = (4.0 * math.pi * k1 / w) * 1e3 if k1 > 0 else 0.0
+        opt[j] = (n1, n2, absorb)
+    return row, coeffs, opt
+
+
+def _relocate(row, local: list, base: int):
+    """The row and the coefficient block of `_pack_surface_local` moved to offset `base` of
+    the table's coefficient buffer: every stored offset shifted (the geometry block, a
+    polygon's vertex block, a boolean aperture's token list and the polygon leaves inside
+    it, a polarizer / retarder axis block)."""
+    if base == 0:
+        return row, local
+    row = row.copy()
+    row["coeff_offset"] = int(row["coeff_offset"]) + base
+    ak = int(row["aperture_kind"])
+    if ak == S.AP_POLYGON:
+        ap = np.array(row["aperture"])
+        ap[0] += base
+        row["aperture"] = ap
+    elif ak == S.AP_COMPOSITE:
+        ap = np.array(row["aperture"])
+        off, cnt = int(ap[0]), int(ap[1])
+        ap[0] += base
+        row["aperture"] = ap
+        fixed = None
+        for k in range(cnt):
+            j = off + 5 * k
+            if int(local[j]) == S.AP_POLYGON:
+                if fixed is None:
+                    fixed = list(local)
+                fixed[j + 1] = local[j + 1] + base
+        if fixed is not None:
+            local = fixed
+    if int(row["coating_kind"]) in (S.COAT_POLARIZER, S.COAT_RETARDER):
+        c = np.array(row["coat"])
+        c[0] += base
+        row["coat"] = c
+    return row, local
+
+
 def pack_surfaces(surfaces, wavelengths, name: str = "surfaces",
-                  tolerate: bool = False) -> SystemTable:
+                  tolerate: bool = False, tokens=None, cache: dict | None = None) -> SystemTable:
     """Flatten a sequence of reference `Surface` objects (a `SurfaceGroup`'s list) for
     the given wavelengths (microns): everything `SurfaceGroup.trace`
     (surfaces/surface_group.py:245-257) needs -- no ray-generator scalars, no
@@ -309,72 +389,52 @@ def pack_surfaces(surfaces, wavelengths, name: str = "surfaces",
     object surface) and lists their indices in `table.unsupported`: the caller then
     launches the fused trace on the `[first, last]` runs between them and leaves those
     surfaces to the reference (integration._hip_surface_group_trace).
+
+    `tokens` + `cache` (both or neither): per-surface change-detector tokens
+    (fingerprint.surface_token, i.e. element [1] of `optic_token`) and a dict the caller
+    keeps -- a surface whose token is the one it was last packed under is NOT read again,
+    its row and coefficient block are taken from the cache and only relocated.  A re-pack
+    after `set_radius` then touches one surface instead of all of them.
     """
     _INDEX_MEMO.clear()
     surfaces = list(surfaces)
     unsupported: list = []
     wl = np.array([float(w) for w in np.atleast_1d(wavelengths)], dtype=np.float64)
+    wl_key = wl.tobytes()
     n_s = len(surfaces)
     desc = np.zeros(n_s, dtype=S.SURFACE_DESC_DTYPE)
     optics = np.zeros((n_s, wl.size), dtype=S.SURFACE_OPTICS_DTYPE)
     coeffs: list = []
-
-    def pack_one(i, surf):
-        row = desc[i]
-        geom = surf.geometry
-        R, t = cs_to_affine(geom.cs)
-        row["origin"] = t
-        row["rot"] = R.reshape(-1)
-        row["flags"] = 0 if (R is _EYE3 or np.array_equal(R, _EYE3)) else S.SURF_ROTATED
-        im = surf.interaction_model
-        if type(im).__name__ != "RefractiveReflectiveModel":
-            raise UnsupportedSystem(
-                f"interaction model {type(im).__name__} is not on the fused path"
-            )
-        if getattr(im, "bsdf", None) is not None:
-            raise UnsupportedSystem("BSDF scatter is not on the fused path")
-        _pack_geometry(geom, row, coeffs)
-        _pack_aperture(surf.aperture, row, coeffs)
-        _pack_coating(surf.coating, row, coeffs)
-        if i == 0:
-            # ObjectSurface.trace only records (surfaces/object_surface.py:56-93)
-            row["interaction"] = S.INTERACT_RECORD_ONLY
-            optics[i, :] = (1.0, 1.0, 0.0)
-            optics[i, :]["n2"] = [
-                _scalar_index(surf.material_post, float(w), "n") for w in wl
-            ]
-            return
-        row["interaction"] = (
-            S.INTERACT_REFLECT if im.is_reflective else S.INTERACT_REFRACT
-        )
-        pre, post = surf.material_pre, surf.material_post
-        for m in (pre, post):
-            pm = type(m.propagation_model).__name__
-            if pm != "HomogeneousPropagation":
-                raise UnsupportedSystem(f"propagation model {pm} is not on the fused path")
-        for j, w in enumerate(wl):
-            w = float(w)
-            n1 = _scalar_index(pre, w, "n")
-            n2 = _scalar_index(post, w, "n")
-            k1 = _scalar_index(pre, w, "k")
-            # propagation/homogeneous.py:44-53: alpha = 4 pi k / lambda, applied
-            # as exp(-alpha * t * 1e3) only when k > 0.
-            absorb = (4.0 * math.pi * k1 / w) * 1e3 if k1 > 0 else 0.0
-            optics[i, j] = (n1, n2, absorb)
+    use_cache = cache is not None and tokens is not None and len(tokens) == n_s
+    if use_cache and len(cache) > 4 * n_s + 64:
+        cache.clear()  # surfaces that left the optic
 
     for i, surf in enumerate(surfaces):
-        mark = len(coeffs)
-        try:
-            pack_one(i, surf)
-        except UnsupportedSystem:
-            if not tolerate or i == 0:
-                raise
-            del coeffs[mark:]
-            desc[i] = np.zeros((), dtype=S.SURFACE_DESC_DTYPE)  # placeholder, never traced
-            desc[i]["rot"] = _EYE3.reshape(-1)
+        packed = None
+        if use_cache:
+            hit = cache.get(id(surf))
+            if hit is not None and hit[0] == (tokens[i], i == 0, wl_key):
+                packed = hit[1]
+        if packed is None:
+            try:
+                packed = _pack_surface_local(i == 0, surf, wl)
+            except UnsupportedSystem:
+                if not tolerate or i == 0:
+                    raise
+                packed = None
+            if use_cache and packed is not None:
+                cache[id(surf)] = ((tokens[i], i == 0, wl_key), packed)
+        if packed is None:
+            desc[i]["rot"] = _EYE3.reshape(-1)  # placeholder row, never traced
             desc[i]["interaction"] = S.INTERACT_RECORD_ONLY
             optics[i, :] = (1.0, 1.0, 0.0)
             unsupported.append(i)
+            continue
+        row, local, opt = packed
+        row, local = _relocate(row, local, len(coeffs))
+        desc[i] = row
+        optics[i, :] = opt
+        coeffs.extend(local)
 
     table = SystemTable(
         surfaces=desc,
@@ -388,16 +448,19 @@ def pack_surfaces(surfaces, wavelengths, name: str = "surfaces",
     return table
 
 
-def pack_optic(optic, wavelengths=None, name: str | None = None) -> SystemTable:
+def pack_optic(optic, wavelengths=None, name: str | None = None, tokens=None,
+               cache: dict | None = None) -> SystemTable:
     """Flatten `optic` (a reference `Optic`) for the given wavelengths (microns):
     `pack_surfaces` + the ray-generator scalars + the polarisation state.
+    `tokens`, `cache`: see `pack_surfaces` (incremental re-pack).
 
     Raises `UnsupportedSystem` for anything outside the fused path.
     """
     if wavelengths is None:
         wavelengths = [_f(w.value) for w in optic.wavelengths.wavelengths]
     table = pack_surfaces(optic.surfaces, wavelengths,
-                          name or (optic.name or type(optic).__name__))
+                          name or (optic.name or type(optic).__name__), tokens=tokens,
+                          cache=cache)
     _pack_raygen(optic, table)
     table.primary_wavelength = _f(optic.primary_wavelength)
     pol = optic.polarization
@@ -441,6 +504,10 @@ def _raygen_fingerprint(optic, table: SystemTable):
 
 
 def _pack_raygen(optic, table: SystemTable) -> None:
+    # host first-order model (paraxial_host.py): as cheap as the memo's own fingerprint --
+    # computed outright, no memo
+    if _compute_raygen(optic, table, host_only=True):
+        return
     try:
         key = _raygen_fingerprint(optic, table)
         hit = _RAYGEN_CACHE.get(optic)
@@ -480,8 +547,10 @@ def _pack_apodization(ap):
     return None
 
 
-def _compute_raygen(optic, table: SystemTable) -> None:
-    """Scalars for on-device ray generation.
+def _compute_raygen(optic, table: SystemTable, host_only: bool = False) -> bool:
+    """Scalars for on-device ray generation.  `host_only`: give up
+    (return False, table untouched) as soon as the reference's paraxial tracer would have to
+    be asked; otherwise True.
 
     Packed: paraxial aiming, any apodization of optiland/apodization/, for AngleField
     (object at infinity or finite, fields/field_types/angle.py:17-58), ObjectHeightField
@@ -495,28 +564,28 @@ def _compute_raygen(optic, table: SystemTable) -> None:
     kind = {"AngleField": S.FIELD_ANGLE, "ObjectHeightField": S.FIELD_OBJECT_HEIGHT,
             "ParaxialImageHeightField": S.FIELD_PARAXIAL_IMAGE_HEIGHT}.get(type(fd).__name__)
     if kind is None:
-        return
+        return True
     apod = _pack_apodization(optic.apodization)
     if apod is None:
-        return
+        return True
     mode = getattr(optic.ray_tracer, "ray_aiming_config", {}).get("mode", "paraxial")
     if mode != "paraxial":
-        return
+        return True
     obj = optic.object_surface
     infinite = bool(obj.is_infinite)
     if kind == S.FIELD_OBJECT_HEIGHT or (kind == S.FIELD_PARAXIAL_IMAGE_HEIGHT and not infinite):
         # object_height.py:36-47: z0 = obj.geometry.sag(x0, y0) + obj z -- planar objects only
         if infinite or table.surfaces[0]["geom_kind"] != S.GEOM_PLANE:
-            return
+            return True
     tele_dz = 0.0
     if optic.obj_space_telecentric:
         # ray_aiming/paraxial.py:82-87, 108-123: object-height fields with an
         # object-NA aperture only; z1 - z0 = sqrt(1 - sin^2) / sin
         if kind == S.FIELD_ANGLE or type(optic.aperture).__name__ != "ObjectNAAperture":
-            return
+            return True
         sin = _f(optic.aperture.value)
         if not 0.0 < sin < 1.0:
-            return
+            return True
         tele_dz = math.sqrt(1.0 - sin * sin) / sin
     # SurfaceGroup.positions (surface_group.py:155-161) = z of every vertex in the
     # global frame = the origins already folded by cs_to_affine
@@ -527,6 +596,8 @@ def _compute_raygen(optic, table: SystemTable) -> None:
         # the reference's own recurrences on the packed table (paraxial_host.py): no backend
         # array operation, no read-back
         EPL, EPD = fo["EPL"], fo["EPD"]
+    elif host_only:
+        return False
     else:
         EPL = _f(optic.paraxial.EPL())
         EPD = _f(optic.paraxial.EPD())
@@ -578,6 +649,7 @@ def _compute_raygen(optic, table: SystemTable) -> None:
             table.raygen["n_image"] = _f(optic.surfaces.n(optic.primary_wavelength)[-1])
     except Exception:  # systems without a well-defined exit pupil: no wavefront data
         pass
+    return True
 
 
 _HOST_PARAXIAL_GEOMS = (S.GEOM_PLANE, S.GEOM_STANDARD, S.GEOM_EVEN_ASPHERE, S.GEOM_ODD_ASPHERE,

@@ -324,9 +324,13 @@ def test_reference_consumers_run_on_the_replaced_tracer(tmp_path, engine):
 def test_packer_memoises_paraxial_scalars_and_invalidates(ref, monkeypatch):
     """The reference's paraxial traces (EPL / EPD / XPL) are memoised per optic against
     a fingerprint of the first-order layout: repeated packs (one per field / wavelength
-    of an analysis) call them once; any change that moves them recomputes."""
+    of an analysis) call them once; any change that moves them recomputes.  (The path that
+    asks the reference at all: since round 3 the packer computes these scalars itself from
+    the packed table -- paraxial_host.py, tests/test_paraxial_host.py -- and only falls back
+    here for systems that restatement does not cover.)"""
     be = ref
     be.set_backend("numpy")
+    monkeypatch.setenv("OPTILAND_HIP_HOST_PARAXIAL", "0")
     from optiland.paraxial import Paraxial
     from optiland.samples.objectives import CookeTriplet
     from optiland_amd.packer import pack_optic
@@ -470,7 +474,11 @@ def test_dropin_keeps_device_tables_per_wavelength(hip_on_cpu):
     assert t.pack_count == 3
     lens.surfaces[2].geometry.radius = float(lens.surfaces[2].geometry.radius) * 1.02
     lens.trace(0.0, 0.0, 0.55, num_rays=3, distribution="hexapolar")
-    assert len(t._hip_engines) == 4 and t.pack_count == 4
+    assert t.pack_count == 4
+    if t.engine_updates:   # an engine with ol_system_update: that wavelength's table is
+        assert len(t._hip_engines) == 3 and t.engine_updates == 1   # patched in place
+    else:
+        assert len(t._hip_engines) == 4
 
 
 # ------------------------------------------------------------------------------------
