@@ -76,7 +76,10 @@ __global__ __launch_bounds__(256) void k_rowsync(const float* in, float* out, lo
       if (threadIdx.x == 0) {
         const unsigned slot = (unsigned)(q * ROWS + r);
         __hip_atomic_fetch_add(&ctr[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(&ctr[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x)
+        // (bounded: a grid that is not fully resident must not hang the box)
+        for (int spin = 0; spin < (1 << 20) &&
+             __hip_atomic_load(&ctr[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x;
+             ++spin)
           __builtin_amdgcn_s_sleep(1);
       }
       __syncthreads();
@@ -177,7 +180,8 @@ int main() {
     rep("lds_burst   one plane's 1 KB per wave via LDS", gb, [&] { hipLaunchKernelGGL(k_lds_burst, dim3(b256), dim3(256), 0, 0, in, out, n, stride); });
     rep("tiled       (rows, tiles, 8, 256): 8 KB burst per row", gb, [&] { hipLaunchKernelGGL(k_tiled, dim3(b256), dim3(256), 0, 0, in, out, n, stride); });
     rep("fill        3.84 GB written, 16-byte stores", 4.0 * n * 8 * ROWS / 1e9, [&] { hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, out, (long)n * 8 * ROWS); });
-    rep("copy        2.08 GB read + 2.08 GB written", gb, [&] { hipLaunchKernelGGL(k_copy, dim3(8192), dim3(256), 0, 0, in + 0, out, (long)(gb * 1e9 / 8)); });
+    const long half = (long)(gb * 1e9 / 8);  // floats: 2.08 GB read from the upper half of out
+    rep("copy        2.08 GB read + 2.08 GB written", gb, [&] { hipLaunchKernelGGL(k_copy, dim3(8192), dim3(256), 0, 0, out + half, out, half); });
   }
   return 0;
 }
