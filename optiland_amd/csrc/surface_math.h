@@ -40,6 +40,57 @@ OL_DEV bool wave_any(bool v) { return v; }  // a "wave" of one ray
 OL_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 OL_DEV float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 OL_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+// fp64 division and square root from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-27
+// relative) refined by two Newton / Goldschmidt steps in FMA arithmetic: within ~1 ulp of the
+// correctly rounded result (not always THE correctly rounded one), zeros, infinities and
+// NaNs as IEEE has them.  The compiler's own sequences are correctly rounded and carry the
+// scaling that makes them so for operands near the ends of the exponent range
+// (v_div_scale / v_div_fmas / v_div_fixup: 10 vector instructions for a quotient; 20 for a
+// square root) -- lengths, cosines and optical paths are nowhere near those ends, and the
+// fused fp64 kernels (spot, OPD: the wavefront path) are bound by vector issue, with two
+// square roots and two quotients per conic surface.
+OL_DEV double rcp_f64(double x) {
+  const double y0 = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y0, 1.0);
+  double y = __builtin_fma(y0, e, y0);
+  e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  // x = 0 / inf: the seed IS the answer (inf / 0), the refinement would make it NaN
+  return __builtin_amdgcn_class(x, 0x260) ? y0 : y;   // +-0 | +-inf
+}
+OL_DEV double div_f64(double a, double b) {
+  const double y0 = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y0, 1.0);
+  double y = __builtin_fma(y0, e, y0);
+  e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  const double q = a * y;
+  const double r = __builtin_fma(-b, q, a);
+  const double refined = __builtin_fma(r, y, q);
+  return __builtin_amdgcn_class(b, 0x260) ? a * y0 : refined;
+}
+OL_DEV double sqrt_f64(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  // sqrt(+-0) = +-0, sqrt(+inf) = +inf (0 * inf above); negative / NaN arguments are NaN
+  // through the seed already
+  return __builtin_amdgcn_class(x, 0x260) ? x : g;
+}
+OL_DEV double rsq_f64(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  // y <- y (1.5 - 0.5 x y^2), twice
+  double hx = 0.5 * x;
+  double e = __builtin_fma(-hx * y0, y0, 0.5);
+  double y = __builtin_fma(y0, e, y0);
+  e = __builtin_fma(-hx * y, y, 0.5);
+  y = __builtin_fma(y, e, y);
+  return __builtin_amdgcn_class(x, 0x260) ? y0 : y;
+}
 OL_DEV float exp(float x) { return __expf(x); }
 OL_DEV int float_bits(float x) { return __float_as_int(x); }
 OL_DEV long long double_bits(double x) { return __double_as_longlong(x); }
@@ -95,12 +146,31 @@ struct Math<float> {
   OL_SCALAR_LANE_OPS(float)
 };
 
+// OL_FAST_F64 (default on, device code only): fp64 quotients and square roots from the
+// hardware seeds + two refinement steps (hw::div_f64 ...) instead of the compiler's correctly
+// rounded sequences.  A/B knob, tools/build_variants.py.
+#ifndef OL_FAST_F64
+#define OL_FAST_F64 1
+#endif
+#if OL_FAST_F64 && !(defined(OL_HOST_MATH) && !defined(__HIP_DEVICE_COMPILE__))
+#define OL_F64_FAST_PATH 1
+#else
+#define OL_F64_FAST_PATH 0
+#endif
+
 template <>
 struct Math<double> {
+#if OL_F64_FAST_PATH
+  static OL_DEV double rcp(double x) { return hw::rcp_f64(x); }
+  static OL_DEV double sqrt(double x) { return hw::sqrt_f64(x); }
+  static OL_DEV double rsqrt(double x) { return hw::rsq_f64(x); }
+  static OL_DEV double div(double a, double b) { return hw::div_f64(a, b); }
+#else
   static OL_DEV double rcp(double x) { return 1.0 / x; }
   static OL_DEV double sqrt(double x) { return __builtin_sqrt(x); }
   static OL_DEV double rsqrt(double x) { return 1.0 / __builtin_sqrt(x); }
   static OL_DEV double div(double a, double b) { return a / b; }
+#endif
   static OL_DEV double exp(double x) { return ::exp(x); }
   static OL_DEV double abs(double x) { return __builtin_fabs(x); }
   static OL_DEV double copysign(double a, double b) {

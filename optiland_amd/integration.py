@@ -332,6 +332,7 @@ def _make_tracer_class():
             """(engine, table, fronts) for the optic AS IT IS NOW at `wavelength`.  `tok`: its
             change-detector token if the caller has just taken it."""
             w = float(wavelength.item()) if hasattr(wavelength, "item") else float(wavelength)
+            _keep = None
             if _fp.ENABLED:
                 if tok is None:
                     tok, _keep = _fp.optic_token(self.optic, w)
@@ -378,16 +379,23 @@ def _make_tracer_class():
                         old.close()
             else:
                 self._hip_engines.move_to_end(key)
-            self._remember(w, key)
+            self._remember(w, key, None if (tok is None or _keep is None) else (tok, _keep))
             self._hip_engine, self._hip_table = hit[0], hit[1]
             return hit
 
-        def _remember(self, w, key):
+        def _remember(self, w, key, before=None):
             if not _fp.ENABLED:
                 return
             # token taken AFTER the pack: whatever the pack itself touched (lazy caches of
-            # the reference objects) is then part of the steady state
-            tok, keep = _fp.optic_token(self.optic, w)
+            # the reference objects) is then part of the steady state.  A RE-pack of a
+            # wavelength that has been packed before reads (almost) nothing new -- the lazy
+            # caches exist, unchanged surfaces come from the per-surface cache -- so the token
+            # taken before it (`before`) stands; should the pack have touched something after
+            # all, the next trace sees a mismatch and re-packs once more, incrementally.
+            if before is not None and w in self._hip_memo:
+                tok, keep = before
+            else:
+                tok, keep = _fp.optic_token(self.optic, w)
             self._hip_memo[w] = (tok, keep, key)
             self._hip_memo.move_to_end(w)
             while len(self._hip_memo) > _MAX_MEMO:
@@ -510,6 +518,7 @@ def _make_tracer_class():
                 self._hip_spec_ok = False
                 front.surfaces._bind(None)  # drop the stale launch's block
                 front._last_res = None
+            packs = self.pack_count
             try:
                 front, table = self._front_for(wavelength, tok)
             except UnsupportedSystem:
@@ -521,6 +530,9 @@ def _make_tracer_class():
                 # SurfaceGroup.trace seam (when enable() / install() patched it)
                 self.last_path = "reference-rays"
                 return original()
+            # an optic that had to be re-packed for this call is being edited between traces:
+            # the next call validates first as well; speculation resumes after a quiet call
+            self._hip_spec_ok = self.pack_count == packs
             mine = call(front)
             self.last_path = "hip"
             return self._finish(front, table, mine, wavelength, update_intensity)

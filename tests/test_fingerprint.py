@@ -124,8 +124,10 @@ def test_untouched_optics_are_packed_once(be):
         if t.last_path != "hip":
             continue  # a sample the fused path leaves to the reference
         assert t.pack_count == len(ws), (cname, t.pack_count)
-        # every call after the first of a wavelength was launched speculatively and kept
-        assert t.speculative_hits == 6 * len(ws) - len(ws) and t.speculative_misses == 0, \
+        # per wavelength: the first call packs, the one after a pack validates before it
+        # launches (an optic that has just been packed may be one that is being edited);
+        # every later call was launched speculatively and kept
+        assert t.speculative_hits == 6 * len(ws) - 2 * len(ws) and t.speculative_misses == 0, \
             (cname, t.speculative_hits, t.speculative_misses)
         checked += 1
     assert checked >= 20

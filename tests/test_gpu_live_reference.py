@@ -400,6 +400,9 @@ def test_spot_diagram_and_encircled_energy_through_the_fused_seam_on_device(be, 
 
     def run(lens):
         s = analysis.SpotDiagram(lens, num_rings=6)
+        if be.get_backend() != "numpy":
+            # what Optic.trace() would have left on the surfaces is there when somebody looks
+            assert _np(be, lens.surfaces.x).shape == (len(lens.surfaces.surfaces), 1 + 3 * 6 * 7)
         e = analysis.EncircledEnergy(lens, num_rays=8, distribution="hexapolar", num_points=16)
         return ([[(_np(be, d.x), _np(be, d.y), _np(be, d.intensity)) for d in f] for f in s.data],
                 [[float(_np(be, v)) for v in f] for f in s.rms_spot_radius()],
@@ -415,17 +418,19 @@ def test_spot_diagram_and_encircled_energy_through_the_fused_seam_on_device(be, 
         assert stats["spot"] > 0 and stats["spot_fallback"] == 0 and stats["ee"] > 0
         scale = max(np.abs(x).max() for f in want[3] for (x, _, _) in f)
         tol = TOL[precision]
-        for gf, wf in zip(got[0] + got[3], want[0] + want[3]):
-            for (x, y, i), (xw, yw, iw) in zip(gf, wf):
-                assert x.shape == xw.shape
-                np.testing.assert_allclose(x, xw, rtol=0, atol=tol * max(scale, 1.0))
-                np.testing.assert_allclose(y, yw, rtol=0, atol=tol * max(scale, 1.0))
-                np.testing.assert_allclose(i, iw, rtol=tol, atol=tol)
+        bad = []
+        for kind, G, W in (("spot", got[0], want[0]), ("ee", got[3], want[3])):
+            for fi, (gf, wf) in enumerate(zip(G, W)):
+                for wi, ((x, y, i), (xw, yw, iw)) in enumerate(zip(gf, wf)):
+                    assert x.shape == xw.shape, (kind, fi, wi, x.shape, xw.shape)
+                    err = max(np.abs(x - xw).max(), np.abs(y - yw).max())
+                    if not (err <= tol * max(scale, 1.0)
+                            and np.allclose(i, iw, rtol=tol, atol=tol)):
+                        bad.append((kind, fi, wi, float(err)))
+        assert not bad, (bad, dict(stats))
         if precision == "float64":
             np.testing.assert_allclose(got[1], want[1], rtol=1e-5)
             np.testing.assert_allclose(got[2], want[2], rtol=1e-5)
-        # what Optic.trace() would have left on the surfaces is there when somebody looks
-        assert _np(be, lens.surfaces.x).shape == (len(lens.surfaces.surfaces), 1 + 3 * 8 * 9)
     finally:
         _off(be)
 
@@ -489,9 +494,10 @@ def test_lazy_records_on_device(be, name, precision):
         for k in eager:
             assert torch.equal(lazy[k], eager[k]), k
         polarised = hasattr(rays, "p")
-        assert (lens.surfaces.surfaces[1] in integration._PENDING) == (not polarised)
+        pend = integration._PENDING is not None and lens.surfaces.surfaces[1] in integration._PENDING
+        assert pend == (not polarised)
         for k in SURF:
             assert torch.equal(getattr(lens.surfaces, k), eager_surf[k]), k
-        assert lens.surfaces.surfaces[1] not in integration._PENDING
+        assert integration._PENDING is None or lens.surfaces.surfaces[1] not in integration._PENDING
     finally:
         _off(be)
