@@ -368,7 +368,9 @@ def _make_tracer_class():
                 upd = getattr(old[0], "update", None) if old is not None else None
                 if upd is not None and upd(table):
                     del self._hip_engines[old_key]
-                    hit = (old[0], table, {})
+                    for front in old[2].values():  # same engine, new prescription
+                        front.rebind(table)
+                    hit = (old[0], table, old[2])
                     self.engine_updates += 1
                 else:
                     hit = (_tracer._make_engine(table, self._hip_device), table, {})

@@ -402,12 +402,18 @@ def pack_surfaces(surfaces, wavelengths, name: str = "surfaces",
     wl = np.array([float(w) for w in np.atleast_1d(wavelengths)], dtype=np.float64)
     wl_key = wl.tobytes()
     n_s = len(surfaces)
+    use_cache = cache is not None and tokens is not None and len(tokens) == n_s
+    if use_cache and len(cache) > 6 * n_s + 64:
+        cache.clear()  # surfaces that left the optic
+
+    if use_cache:
+        table = _patched_table(surfaces, wl, wl_key, name, tokens, cache)
+        if table is not None:
+            return table
     desc = np.zeros(n_s, dtype=S.SURFACE_DESC_DTYPE)
     optics = np.zeros((n_s, wl.size), dtype=S.SURFACE_OPTICS_DTYPE)
     coeffs: list = []
-    use_cache = cache is not None and tokens is not None and len(tokens) == n_s
-    if use_cache and len(cache) > 4 * n_s + 64:
-        cache.clear()  # surfaces that left the optic
+    bases = []
 
     for i, surf in enumerate(surfaces):
         packed = None
@@ -431,6 +437,7 @@ def pack_surfaces(surfaces, wavelengths, name: str = "surfaces",
             unsupported.append(i)
             continue
         row, local, opt = packed
+        bases.append((len(coeffs), len(local)))
         row, local = _relocate(row, local, len(coeffs))
         desc[i] = row
         optics[i, :] = opt
@@ -445,6 +452,47 @@ def pack_surfaces(surfaces, wavelengths, name: str = "surfaces",
     )
     table.last_thickness = _f(surfaces[-1].thickness) if n_s else 0.0
     table.unsupported = tuple(unsupported)
+    if use_cache and not unsupported:
+        cache["assembled"] = (tuple(id(s_) for s_ in surfaces), wl_key, list(tokens), bases,
+                              table)
+    return table
+
+
+def _patched_table(surfaces, wl, wl_key, name, tokens, cache):
+    """The table of the previous `pack_surfaces` call with the rows of the CHANGED surfaces
+    replaced, or None when that does not apply (other surfaces, other wavelengths, a
+    coefficient block that changed its length, an unsupported surface).  An optimiser's
+    `set_radius` re-pack then costs one surface, not one surface plus the re-assembly of all."""
+    prev = cache.get("assembled")
+    if prev is None:
+        return None
+    ids, p_wl, p_tokens, bases, p_table = prev
+    n_s = len(surfaces)
+    if p_wl != wl_key or len(ids) != n_s or any(id(s_) != k for s_, k in zip(surfaces, ids)):
+        return None
+    changed = [i for i in range(n_s) if tokens[i] != p_tokens[i]]
+    desc = p_table.surfaces.copy()
+    optics = p_table.optics.copy()
+    coeffs = p_table.coeffs.copy()
+    for i in changed:
+        try:
+            packed = _pack_surface_local(i == 0, surfaces[i], wl)
+        except UnsupportedSystem:
+            return None  # the full path decides (tolerate / raise)
+        row, local, opt = packed
+        base, length = bases[i]
+        if len(local) != length:
+            return None
+        cache[id(surfaces[i])] = ((tokens[i], i == 0, wl_key), packed)
+        row, local = _relocate(row, local, base)
+        desc[i] = row
+        optics[i, :] = opt
+        if length:
+            coeffs[base:base + length] = local
+    table = SystemTable(surfaces=desc, coeffs=coeffs, optics=optics, wavelengths=wl, name=name)
+    table.last_thickness = _f(surfaces[-1].thickness) if n_s else 0.0
+    table.unsupported = ()
+    cache["assembled"] = (ids, wl_key, list(tokens), bases, table)
     return table
 
 
@@ -461,7 +509,7 @@ def pack_optic(optic, wavelengths=None, name: str | None = None, tokens=None,
     table = pack_surfaces(optic.surfaces, wavelengths,
                           name or (optic.name or type(optic).__name__), tokens=tokens,
                           cache=cache)
-    _pack_raygen(optic, table)
+    _pack_raygen(optic, table, tokens, cache)
     table.primary_wavelength = _f(optic.primary_wavelength)
     pol = optic.polarization
     if pol != "ignore":
@@ -503,10 +551,10 @@ def _raygen_fingerprint(optic, table: SystemTable):
     ))
 
 
-def _pack_raygen(optic, table: SystemTable) -> None:
+def _pack_raygen(optic, table: SystemTable, tokens=None, cache=None) -> None:
     # host first-order model (paraxial_host.py): as cheap as the memo's own fingerprint --
     # computed outright, no memo
-    if _compute_raygen(optic, table, host_only=True):
+    if _compute_raygen(optic, table, host_only=True, tokens=tokens, cache=cache):
         return
     try:
         key = _raygen_fingerprint(optic, table)
@@ -547,7 +595,8 @@ def _pack_apodization(ap):
     return None
 
 
-def _compute_raygen(optic, table: SystemTable, host_only: bool = False) -> bool:
+def _compute_raygen(optic, table: SystemTable, host_only: bool = False, tokens=None,
+                    cache=None) -> bool:
     """Scalars for on-device ray generation.  `host_only`: give up
     (return False, table untouched) as soon as the reference's paraxial tracer would have to
     be asked; otherwise True.
@@ -572,7 +621,9 @@ def _compute_raygen(optic, table: SystemTable, host_only: bool = False) -> bool:
     if mode != "paraxial":
         return True
     obj = optic.object_surface
-    infinite = bool(obj.is_infinite)
+    # surfaces/object_surface.py:48-50 `is_infinite` = isinf(cs.z), read through the packer's
+    # read-back cache instead of a backend reduction
+    infinite = math.isinf(_f(obj.geometry.cs.z))
     if kind == S.FIELD_OBJECT_HEIGHT or (kind == S.FIELD_PARAXIAL_IMAGE_HEIGHT and not infinite):
         # object_height.py:36-47: z0 = obj.geometry.sag(x0, y0) + obj z -- planar objects only
         if infinite or table.surfaces[0]["geom_kind"] != S.GEOM_PLANE:
@@ -590,8 +641,8 @@ def _compute_raygen(optic, table: SystemTable, host_only: bool = False) -> bool:
     # SurfaceGroup.positions (surface_group.py:155-161) = z of every vertex in the
     # global frame = the origins already folded by cs_to_affine
     pos = np.asarray(table.surfaces["origin"][:, 2], dtype=np.float64).reshape(-1)
-    fo = _host_first_order(optic, table, pos, infinite) if kind != S.FIELD_PARAXIAL_IMAGE_HEIGHT \
-        else None
+    fo = _host_first_order(optic, table, pos, infinite, tokens, cache) \
+        if kind != S.FIELD_PARAXIAL_IMAGE_HEIGHT else None
     if fo is not None:
         # the reference's own recurrences on the packed table (paraxial_host.py): no backend
         # array operation, no read-back
@@ -652,11 +703,32 @@ def _compute_raygen(optic, table: SystemTable, host_only: bool = False) -> bool:
     return True
 
 
-_HOST_PARAXIAL_GEOMS = (S.GEOM_PLANE, S.GEOM_STANDARD, S.GEOM_EVEN_ASPHERE, S.GEOM_ODD_ASPHERE,
-                        S.GEOM_POLYNOMIAL, S.GEOM_CHEBYSHEV, S.GEOM_ZERNIKE)
+_HOST_PARAXIAL_GEOMS = frozenset((S.GEOM_PLANE, S.GEOM_STANDARD, S.GEOM_EVEN_ASPHERE,
+                                  S.GEOM_ODD_ASPHERE, S.GEOM_POLYNOMIAL, S.GEOM_CHEBYSHEV,
+                                  S.GEOM_ZERNIKE))
 
 
-def _host_first_order(optic, table: SystemTable, pos, infinite):
+def _primary_indices(surfaces, prim: float, tokens, cache):
+    """n(primary wavelength) behind every surface.  With the change-detector tokens of an
+    incremental re-pack (`pack_surfaces`), a surface whose token stands keeps the value it
+    had: the token covers both material objects, so the ~13 `material.n()` calls of a
+    re-pack (a cache-key build each, materials/base.py:73-100) shrink to the edited one."""
+    if cache is None or tokens is None or len(tokens) != len(surfaces):
+        return [_scalar_index(s.material_post, prim, "n") for s in surfaces]
+    out = []
+    for s, tok in zip(surfaces, tokens):
+        key = ("n_primary", id(s))
+        hit = cache.get(key)
+        if hit is not None and hit[0] == prim and hit[1] == tok:
+            out.append(hit[2])
+            continue
+        v = _scalar_index(s.material_post, prim, "n")
+        cache[key] = (prim, tok, v)
+        out.append(v)
+    return out
+
+
+def _host_first_order(optic, table: SystemTable, pos, infinite, tokens=None, cache=None):
     """EPL / EPD / XPL / n_image from the packed table (paraxial_host.first_order), or None
     when the system has something that restatement does not cover."""
     import os
@@ -666,23 +738,25 @@ def _host_first_order(optic, table: SystemTable, pos, infinite):
     from . import paraxial_host
 
     surf = table.surfaces
-    if any(int(g) not in _HOST_PARAXIAL_GEOMS for g in surf["geom_kind"]):
+    if not _HOST_PARAXIAL_GEOMS.issuperset(surf["geom_kind"].tolist()):
         return None
     surfaces = list(optic.surfaces)
-    if any(getattr(s, "surface_type", None) == "paraxial" for s in surfaces):
-        return None
+    stop = None
+    for i, s in enumerate(surfaces):
+        if getattr(s, "surface_type", None) == "paraxial":
+            return None
+        if stop is None and getattr(s, "is_stop", False):
+            stop = i
     obj = surfaces[0]
     if getattr(obj.geometry.cs, "reference_cs", None) is not None:
         return None
-    stop = [i for i, s in enumerate(surfaces) if getattr(s, "is_stop", False)]
     ap = optic.aperture
-    if not stop or ap is None:
+    if stop is None or ap is None:
         return None
     prim = _f(optic.primary_wavelength)
-    n = [_scalar_index(s.material_post, prim, "n") for s in surfaces]
-    reflect = [bool(k == S.INTERACT_REFLECT) for k in surf["interaction"]]
-    radii = [float(r) for r in surf["radius"]]
-    fo = paraxial_host.first_order(radii, n, [float(p) for p in pos], reflect, stop[0],
+    n = _primary_indices(surfaces, prim, tokens, cache)
+    reflect = (surf["interaction"] == S.INTERACT_REFLECT).tolist()
+    fo = paraxial_host.first_order(surf["radius"].tolist(), n, pos.tolist(), reflect, stop,
                                    type(ap).__name__, _f(ap.value), infinite,
                                    _f(obj.geometry.cs.z))
     if fo is not None:

@@ -66,7 +66,6 @@ class HipRayTracer:
     """Drop-in for `RealRayTracer` on a packed system."""
 
     def __init__(self, table: SystemTable, device=None, dtype=torch.float32, engine=None):
-        self.table = table
         self.dtype = dtype
         self.engine = engine if engine is not None else _make_engine(table, device)
         self.device = self.engine.device
@@ -88,13 +87,23 @@ class HipRayTracer:
         # check of the live optic with the kernels this way
         self.defer_checks = False
         self._pupil_cache = {}  # (distribution name, num_rays) -> device planes
+        self.rebind(table)
+
+    def rebind(self, table: SystemTable):
+        """Point this tracer at another packed table of the same engine (the engine's device
+        tables were just patched in place, `HipSystem.update`): everything that does not depend
+        on the prescription -- cached pupil planes, configuration -- stays."""
+        self.table = table
+        self._uses_polarization = bool(table.uses_polarization)
+        self._complex_prt = bool(table.needs_complex_prt)
+        if getattr(self, "_fields_of", None) == table.fields:
+            return  # (an optimiser's re-pack: the field list is what it was)
+        self._fields_of = list(table.fields)
         f = np.asarray(table.fields, dtype=np.float64).reshape(-1, 4)
         self._fields = f
         # facts of the (immutable, packed) table that every launch asks for: taken once --
         # as numpy reductions per call they were ~35 us of a ~230 us small trace
         self._has_vignetting = bool(f.shape[0] != 0 and np.any(f[:, 2:]))
-        self._uses_polarization = bool(table.uses_polarization)
-        self._complex_prt = bool(table.needs_complex_prt)
 
     # ------------------------------------------------------------ configuration
     def set_aiming(self, mode: str, max_iter: int = 10, tol: float = 1e-6, **kwargs):

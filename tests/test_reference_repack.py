@@ -146,12 +146,17 @@ def test_incremental_pack_equals_full_pack_on_random_lenses(ref, seed):
     lens, rng = build_random_lens(seed, be)
     w = float(lens.primary_wavelength)
     cache = {}
+    handed_out = []   # (table, its bytes when it was returned): later packs patch COPIES
     try:
-        for step in range(4):
+        for step in range(5):
             if step:
                 i = int(rng.integers(1, len(lens.surfaces.surfaces) - 1))
                 g = lens.surfaces[i].geometry
-                if hasattr(g, "radius") and np.isfinite(float(g.radius)):
+                coef = getattr(g, "coefficients", None)
+                if step == 4 and coef is not None and np.ndim(coef) == 1 and len(coef):
+                    # a coefficient block that changes its LENGTH: every later block moves
+                    g.coefficients = list(np.asarray(coef, dtype=float)) + [0.0, 0.0]
+                elif hasattr(g, "radius") and np.isfinite(float(g.radius)):
                     g.radius = float(g.radius) * (1.0 + 1e-3 * step)
                 else:
                     lens.surfaces[i].geometry.cs.x = float(lens.surfaces[i].geometry.cs.x) + 1e-3
@@ -162,5 +167,10 @@ def test_incremental_pack_equals_full_pack_on_random_lenses(ref, seed):
             assert a.coeffs.tobytes() == b.coeffs.tobytes()
             assert a.optics.tobytes() == b.optics.tobytes()
             assert a.raygen == b.raygen
+            for t_old, bytes_old in handed_out:
+                assert (t_old.surfaces.tobytes(), t_old.coeffs.tobytes(),
+                        t_old.optics.tobytes()) == bytes_old
+            handed_out.append((a, (a.surfaces.tobytes(), a.coeffs.tobytes(),
+                                   a.optics.tobytes())))
     except UnsupportedSystem:
         pytest.skip("outside the fused path")

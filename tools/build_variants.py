@@ -62,6 +62,9 @@ VARIANTS = {
     "zmono_ahead2": ["-DOL_ZERN_MONO_AHEAD=2"],
     "zmono_chunk16": ["-DOL_ZERN_MONO_CHUNK=16"],
     "polnr_waves6": ["-DOL_POLNR_WAVES=6"],
+    # fp64 division / square root: IEEE library sequences instead of the hardware-seed +
+    # two refinement steps form (surface_math.h: OL_FAST_F64)
+    "fast64_0": ["-DOL_FAST_F64=0"],
 }
 
 

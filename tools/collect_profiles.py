@@ -28,6 +28,14 @@ TAGS = {  # tag -> traffic key
     "dg_f32_copy": "double_gauss:f32:record",
     "dg_f32_spot": "double_gauss:f32:spot",
     "dg_f64_spot": "double_gauss:f64:spot",
+    # round 3 (tools/gpu_round3.sh): generation fused into the record-all launch is the
+    # default bench mode; the fp64 / Newton kernels whose table access changed
+    "r03_dg_f32_gen": "double_gauss:f32:gen",
+    "r03_zf_f32_gen": "zernike_fresnel:f32:gen",
+    "r03_rc_f32_gen": "rc_asphere:f32:gen",
+    "r03_zf_f64": "zernike_fresnel:f64:record:alias",
+    "r03_rc_f64": "rc_asphere:f64:record:alias",
+    "r03_z_opd": "zernike:f64:opd",
 }
 
 
@@ -79,7 +87,8 @@ def main():
             lines.append(f"# PMC (separate passes): FETCH_SIZE={f_kib:.1f} KiB (x2 gfx950 correction "
                          f"-> {2*f_kib*1024/1e6:.1f} MB), WRITE_SIZE={w_kib:.1f} KiB "
                          f"({w_kib*1024/1e6:.1f} MB) per trace_kernel launch; HBM bytes = {hbm/1e6:.1f} MB")
-        open(os.path.join(PROF, f"{ROUND}_{tag}_rocprof.txt"), "w").write("\n".join(lines) + "\n")
+        name = tag[len(ROUND) + 1:] if tag.startswith(ROUND + "_") else tag
+        open(os.path.join(PROF, f"{ROUND}_{name}_rocprof.txt"), "w").write("\n".join(lines) + "\n")
         print("\n".join(lines[:4]))
     json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
     bd = os.path.join(OUT, "bench_default.json")
