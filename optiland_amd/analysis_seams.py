@@ -13,6 +13,8 @@ for exactly that:
   (+ the seven masked moments) in ONE kernel, three planes written instead of 8 (S + 1);
 * `ChiefRayStrategy.compute_wavefront_data` (wavefront/strategy.py:163-215)
   -> `ol_trace_opd`: pupil points -> OPD in waves, intensity, pupil intersection points;
+  its constructor (strategy.py:156-160) takes the exit-pupil position from the packed table
+  instead of `optic.paraxial.XPL()` + `surfaces.positions` (6 of the 8 ms of an `OPD(...)`);
 * `ScalarFFTPSF._generate_pupils` / `_pad_pupils` (psf/fft.py:123-161, 203-230)
   -> `ol_pupil_fill`: the pupil function scattered straight into the zero-padded FFT grid.
 
@@ -38,7 +40,7 @@ from .packer import UnsupportedSystem
 
 _ORIG: dict = {}
 STATS = {"spot": 0, "spot_fallback": 0, "ee": 0, "ee_fallback": 0, "opd": 0, "opd_fallback": 0,
-         "pupil": 0, "pupil_fallback": 0}
+         "pupil": 0, "pupil_fallback": 0, "opd_init": 0, "opd_init_fallback": 0}
 
 
 def _front(optic, wavelength, need_fp64=False):
@@ -171,6 +173,31 @@ def _chief_compute_wavefront_data(self, field, wavelength):
         return _ORIG["opd"](self, field, wavelength)
     STATS["opd"] += 1
     return out
+
+
+def _chief_init(self, optic, distribution, **kwargs):
+    """wavefront/strategy.py:156-160.  `optic.paraxial.XPL() + optic.surfaces.positions[-1]`
+    is three walks over the surfaces in backend array operations (6.2 of the 8.3 ms an
+    `OPD(lens, ...)` takes on the MI355X box, profiles/r03_analyses_profile.txt); the packed
+    table of the drop-in already holds that number (packer._compute_raygen "pupil_z": the
+    host first-order model, else the reference's own value)."""
+    import optiland.backend as be
+    from optiland.wavefront.strategy import ReferenceStrategy
+
+    pupil_z = None
+    try:
+        got = _front(optic, _f(optic.primary_wavelength))
+        if got is not None:
+            pupil_z = got[1].raygen.get("pupil_z")
+    except Exception:  # noqa: BLE001 - anything unexpected: the reference's own constructor
+        pupil_z = None
+    if pupil_z is None or not math.isfinite(pupil_z):
+        STATS["opd_init_fallback"] += 1
+        return _ORIG["chief_init"](self, optic, distribution, **kwargs)
+    ReferenceStrategy.__init__(self, optic, distribution, **kwargs)  # optic, n_image, ...
+    self.pupil_z = be.array([pupil_z])
+    self._chief_ray = None
+    STATS["opd_init"] += 1
 
 
 def _fused_wavefront(self, field, wavelength):
@@ -313,10 +340,12 @@ def enable():
     _ORIG.update(spot=SpotDiagram._generate_field_data,
                  ee=EncircledEnergy._generate_field_data,
                  opd=ChiefRayStrategy.compute_wavefront_data,
+                 chief_init=ChiefRayStrategy.__init__,
                  pupils=ScalarFFTPSF._generate_pupils, pad=ScalarFFTPSF._pad_pupils)
     SpotDiagram._generate_field_data = _spot_generate_field_data
     EncircledEnergy._generate_field_data = _ee_generate_field_data
     ChiefRayStrategy.compute_wavefront_data = _chief_compute_wavefront_data
+    ChiefRayStrategy.__init__ = _chief_init
     ScalarFFTPSF._generate_pupils = _fft_generate_pupils
     ScalarFFTPSF._pad_pupils = _fft_pad_pupils
 
@@ -332,6 +361,7 @@ def disable():
     SpotDiagram._generate_field_data = _ORIG["spot"]
     EncircledEnergy._generate_field_data = _ORIG["ee"]
     ChiefRayStrategy.compute_wavefront_data = _ORIG["opd"]
+    ChiefRayStrategy.__init__ = _ORIG["chief_init"]
     ScalarFFTPSF._generate_pupils = _ORIG["pupils"]
     ScalarFFTPSF._pad_pupils = _ORIG["pad"]
     _ORIG.clear()

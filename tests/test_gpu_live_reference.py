@@ -288,6 +288,13 @@ def test_reference_consumer_suite_on_device(be):
     assert n_pass >= 175, summary
     made = [l for l in tail if "device tables created" in l]
     assert made and int(made[-1].split("created:")[1].split()[0]) > 100, tail
+    # round 3: enable() also puts the fused spot / OPD / pupil kernels behind the reference's
+    # own SpotDiagram / EncircledEnergy / Wavefront / FFTPSF classes -- those tests ran
+    # THROUGH the seams (analysis_seams.STATS), not around them
+    seams = [l for l in tail if l.startswith("[seams]")]
+    assert seams, tail
+    stats = dict(kv.split("=") for kv in seams[-1].split()[1:])
+    assert int(stats["spot"]) > 50 and int(stats["opd"]) > 20 and int(stats["pupil"]) > 5, stats
     # the stock torch backend's own two on cuda: KeyErrors of the reference (field
     # coordinates that are device tensors used as dict keys), with or without the drop-in
     known = ("TestCookeTripletRayFan::test_ray_fan", "TestWavefront::test_generate_data")

@@ -163,6 +163,43 @@ def test_wavefront_opd_through_the_fused_seam(seams, build, remove_tilt):
     np.testing.assert_allclose(got[2], want[2], rtol=0, atol=5e-3 if newton else 1e-6)
 
 
+@pytest.mark.parametrize("build", [_cooke, _singlet_asphere])
+def test_chief_ray_strategy_constructor_takes_the_exit_pupil_from_the_packed_table(seams, build):
+    """wavefront/strategy.py:156-160: `pupil_z` (= XPL + last vertex z) comes from the packed
+    table instead of three backend walks over the surfaces -- same value, shape and dtype as
+    the reference's constructor; optics the drop-in does not serve keep that constructor."""
+    be, stats = seams
+    from optiland.distribution import create_distribution
+    from optiland.wavefront.strategy import ChiefRayStrategy
+    from optiland_amd import analysis_seams
+
+    dist = create_distribution("hexapolar")
+    dist.generate_points(3)
+    lens = build()
+    s = ChiefRayStrategy(lens, dist, reference_type="plane")
+    assert stats["opd_init"] == 1 and stats["opd_init_fallback"] == 0
+    ref_s = analysis_seams._ORIG["chief_init"]
+    t = ChiefRayStrategy.__new__(ChiefRayStrategy)
+    ref_s(t, build(), dist, reference_type="plane")
+    assert type(s.pupil_z) is type(t.pupil_z) and s.pupil_z.shape == t.pupil_z.shape
+    assert s.pupil_z.dtype == t.pupil_z.dtype
+    np.testing.assert_allclose(_np(be, s.pupil_z), _np(be, t.pupil_z), rtol=1e-12)
+    assert float(_np(be, s.n_image)) == float(_np(be, t.n_image))
+    assert s.reference_type == t.reference_type == "plane" and s._chief_ray is None
+    assert s.optic is lens and s.distribution is dist
+    # NumPy backend: the drop-in declines, the reference's constructor runs
+    was = dict(stats)
+    be.set_backend("numpy")
+    try:
+        ChiefRayStrategy(build(), dist)
+    finally:
+        be.set_backend("torch")
+        be.set_device("cpu")
+        be.set_precision("float64")
+    assert stats["opd_init"] == was["opd_init"]
+    assert stats["opd_init_fallback"] == was["opd_init_fallback"] + 1
+
+
 def test_fft_psf_through_the_fused_seams(seams):
     be, stats = seams
     from optiland.psf import FFTPSF

@@ -123,6 +123,28 @@ def main():
             lambda: FFTPSF(lens, (0.0, 1.0), w, num_rays=512, grid_size=1024).strehl_ratio(), 5)
         row["seam_calls"] = dict(analysis_seams.STATS)
         ana[label] = row
+        if flag:  # where the remaining host time of the seamed analyses goes
+            import cProfile
+            import io
+            import pstats
+            buf = io.StringIO()
+            for nm, fn in (("SpotDiagram(400 rings).rms_spot_radius()",
+                            lambda: analysis.SpotDiagram(lens, num_rings=400).rms_spot_radius()),
+                           ("OPD(256 rings).rms()",
+                            lambda: OPD(lens, (0.0, 1.0), w, num_rings=256).rms()),
+                           ("FFTPSF(512, 1024).strehl_ratio()",
+                            lambda: FFTPSF(lens, (0.0, 1.0), w, num_rays=512,
+                                           grid_size=1024).strehl_ratio())):
+                pr = cProfile.Profile()
+                pr.enable()
+                for _ in range(5):
+                    fn()
+                torch.cuda.synchronize()
+                pr.disable()
+                buf.write(f"\n===== {nm} x5\n")
+                pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(28)
+            with open(os.path.join(ROOT, "gpurun_out", "r03_analyses_profile.txt"), "w") as fh:
+                fh.write(buf.getvalue())
         integration.disable()
     doc["reference_analyses_cooke_fp64"] = ana
 

@@ -37,7 +37,10 @@ def run(dropin: bool, files=None):
             "def _mk(table, device):\n    _made[0] += 1\n    return _orig(table, device)\n"
             "_tr._make_engine = _mk\n"
             "atexit.register(lambda: print('\\n[drop-in] device tables created:', _made[0], "
-            "'SurfaceGroup seam launches:', _integ._SG['count']))\n" % ROOT, 1)
+            "'SurfaceGroup seam launches:', _integ._SG['count']))\n"
+            "import optiland_amd.analysis_seams as _seams\n"
+            "atexit.register(lambda: print('\\n[seams] ' + ' '.join('%%s=%%d' %% kv for kv in "
+            "_seams.STATS.items())))\n" % ROOT, 1)
     open(os.path.join(dst, "conftest.py"), "w").write(conf)
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1",
                PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests", "refshim"), REF]))
@@ -48,7 +51,8 @@ def run(dropin: bool, files=None):
     failed = set(re.findall(r"^FAILED (\S+)", out.stdout, flags=re.M))
     errors = set(re.findall(r"^ERROR (\S+)", out.stdout, flags=re.M))
     tail = [l for l in out.stdout.strip().splitlines()
-            if " passed" in l or " failed" in l or "drop-in" in l or "error" in l.lower()[:40]]
+            if " passed" in l or " failed" in l or "drop-in" in l or "[seams]" in l
+            or "error" in l.lower()[:40]]
     tail.append(f"(pytest rc {out.returncode})")
     return failed | errors, tail, out
 
@@ -57,7 +61,7 @@ if __name__ == "__main__":
     base_f, base_tail, _ = run(False, sys.argv[1:])
     hip_f, hip_tail, out = run(True, sys.argv[1:])
     print("stock reference on cuda :", base_tail[-3:])
-    print("with the drop-in        :", hip_tail[-4:])
+    print("with the drop-in        :", hip_tail[-5:])
     new = sorted(hip_f - base_f)
     print("failing on the stock torch backend (cuda):", sorted(base_f))
     print("failing with the drop-in                 :", sorted(hip_f))
