@@ -223,12 +223,19 @@ struct HostSurf {
 
 template <typename T>
 struct DeviceTable {
+  // ONE allocation: [hot rows | cold rows | optics rows | coefficients], each block on a
+  // 256-byte boundary -- created by one copy and re-written in place by one copy
+  // (ol_system_update: an optimiser edits the prescription between every two traces)
+  char* blob = nullptr;
   ol::DevSurfHot<T>* surf = nullptr;
   ol::DevSurfCold<T>* cold = nullptr;
   ol::DevOptics<T>* optics = nullptr;
   T* coeffs = nullptr;
   size_t n_surf = 0, n_opt = 0, coef_capacity = 0;  // allocation sizes (ol_system_update)
+  size_t off_cold = 0, off_opt = 0, off_coef = 0;
 };
+
+inline size_t round256(size_t v) { return (v + 255u) & ~size_t(255u); }
 
 // everything ol_system_create derives from its arguments, in double, before any device call
 struct Staged {
@@ -256,22 +263,29 @@ struct ol_system {
 
 namespace {
 
-// in_place: the allocations of `dst` are reused (they must fit: checked by the caller) and
-// the copies are queued on `stream`, i.e. ordered after every launch already queued there
-// that still reads the old table; otherwise fresh allocations and blocking copies.
+// in_place: the allocation of `dst` is reused (it must fit: checked by the caller) and the
+// copy is queued on `stream`, i.e. ordered after every launch already queued there that
+// still reads the old table; otherwise a fresh allocation and a blocking copy.
 template <typename T>
 int upload(const std::vector<HostSurf>& surf64,
            const std::vector<ol::DevOptics<double>>& opt64, const std::vector<double>& coef64,
            const std::vector<size_t>& int_slots, DeviceTable<T>& dst, bool in_place = false,
            hipStream_t stream = nullptr) {
-  std::vector<ol::DevSurfHot<T>> surf(surf64.size());
-  std::vector<ol::DevSurfCold<T>> cold(surf64.size());
-  for (size_t i = 0; i < surf64.size(); ++i) {
+  const size_t n_surf = surf64.size(), n_opt = opt64.size();
+  const size_t n_coef = coef64.size() ? coef64.size() : 1;
+  const size_t off_cold = round256(n_surf * sizeof(ol::DevSurfHot<T>));
+  const size_t off_opt = off_cold + round256(n_surf * sizeof(ol::DevSurfCold<T>));
+  const size_t off_coef = off_opt + round256(n_opt * sizeof(ol::DevOptics<T>));
+  const size_t used = off_coef + n_coef * sizeof(T);
+  std::vector<char> host(used, 0);
+  auto* surf = reinterpret_cast<ol::DevSurfHot<T>*>(host.data());
+  auto* cold = reinterpret_cast<ol::DevSurfCold<T>*>(host.data() + off_cold);
+  auto* opt = reinterpret_cast<ol::DevOptics<T>*>(host.data() + off_opt);
+  T* coef = reinterpret_cast<T*>(host.data() + off_coef);
+  for (size_t i = 0; i < n_surf; ++i) {
     const auto& a = surf64[i];
     auto& b = surf[i];
     auto& c = cold[i];
-    std::memset(&b, 0, sizeof(b));
-    std::memset(&c, 0, sizeof(c));
     b.geom = a.geom; b.interaction = a.interaction; b.aperture_kind = a.aperture_kind;
     b.coating_kind = a.coating_kind; b.coeff_off = a.coeff_off; b.n_coeff = a.n_coeff;
     b.max_iter = a.max_iter; b.flags = a.flags;
@@ -285,13 +299,10 @@ int upload(const std::vector<HostSurf>& surf64,
     for (int k = 0; k < 3; ++k) c.axis[k] = (T)a.axis[k];
     c.ret_cos = (T)a.ret_cos; c.ret_sin = (T)a.ret_sin;
   }
-  std::vector<ol::DevOptics<T>> opt(opt64.size());
-  for (size_t i = 0; i < opt64.size(); ++i) {
-    std::memset(&opt[i], 0, sizeof(opt[i]));
+  for (size_t i = 0; i < n_opt; ++i) {
     opt[i].n1 = (T)opt64[i].n1; opt[i].n2 = (T)opt64[i].n2; opt[i].u = (T)opt64[i].u;
     opt[i].nn = (T)opt64[i].nn; opt[i].absorb = (T)opt64[i].absorb;
   }
-  std::vector<T> coef(coef64.size() ? coef64.size() : 1, T(0));
   for (size_t i = 0; i < coef64.size(); ++i) coef[i] = (T)coef64[i];
   for (size_t i : int_slots) {  // loop headers: integer bit patterns (scalar-unit operands)
     using I = typename std::conditional<sizeof(T) == 4, int32_t, int64_t>::type;
@@ -300,43 +311,30 @@ int upload(const std::vector<HostSurf>& surf64,
   }
 
   if (in_place) {
-    // (pageable sources: the runtime stages them before it returns, the vectors may go)
-    OL_HIP_CHECK(hipMemcpyAsync(dst.cold, cold.data(), cold.size() * sizeof(ol::DevSurfCold<T>),
-                                hipMemcpyHostToDevice, stream));
-    OL_HIP_CHECK(hipMemcpyAsync(dst.surf, surf.data(), surf.size() * sizeof(ol::DevSurfHot<T>),
-                                hipMemcpyHostToDevice, stream));
-    OL_HIP_CHECK(hipMemcpyAsync(dst.optics, opt.data(), opt.size() * sizeof(ol::DevOptics<T>),
-                                hipMemcpyHostToDevice, stream));
-    OL_HIP_CHECK(hipMemcpyAsync(dst.coeffs, coef.data(), coef.size() * sizeof(T),
-                                hipMemcpyHostToDevice, stream));
+    // same surface / wavelength counts (checked by the caller): the block offsets are the
+    // ones of the allocation.  (Pageable source: the runtime stages it before it returns,
+    // the vector may go.)
+    OL_HIP_CHECK(hipMemcpyAsync(dst.blob, host.data(), used, hipMemcpyHostToDevice, stream));
     return OL_OK;
   }
-  dst.n_surf = surf.size();
-  dst.n_opt = opt.size();
+  dst.n_surf = n_surf;
+  dst.n_opt = n_opt;
   // head room: a surface whose coefficient block grows a little (an asphere gaining a term)
   // still updates in place
-  dst.coef_capacity = coef.size() + 64;
-  OL_HIP_CHECK(hipMalloc((void**)&dst.surf, surf.size() * sizeof(ol::DevSurfHot<T>)));
-  OL_HIP_CHECK(hipMalloc((void**)&dst.cold, cold.size() * sizeof(ol::DevSurfCold<T>)));
-  OL_HIP_CHECK(hipMemcpy(dst.cold, cold.data(), cold.size() * sizeof(ol::DevSurfCold<T>),
-                         hipMemcpyHostToDevice));
-  OL_HIP_CHECK(hipMalloc((void**)&dst.optics, opt.size() * sizeof(ol::DevOptics<T>)));
-  OL_HIP_CHECK(hipMalloc((void**)&dst.coeffs, dst.coef_capacity * sizeof(T)));
-  OL_HIP_CHECK(hipMemcpy(dst.surf, surf.data(), surf.size() * sizeof(ol::DevSurfHot<T>),
-                         hipMemcpyHostToDevice));
-  OL_HIP_CHECK(hipMemcpy(dst.optics, opt.data(), opt.size() * sizeof(ol::DevOptics<T>),
-                         hipMemcpyHostToDevice));
-  OL_HIP_CHECK(hipMemcpy(dst.coeffs, coef.data(), coef.size() * sizeof(T),
-                         hipMemcpyHostToDevice));
+  dst.coef_capacity = n_coef + 64;
+  dst.off_cold = off_cold; dst.off_opt = off_opt; dst.off_coef = off_coef;
+  OL_HIP_CHECK(hipMalloc((void**)&dst.blob, off_coef + dst.coef_capacity * sizeof(T)));
+  dst.surf = reinterpret_cast<ol::DevSurfHot<T>*>(dst.blob);
+  dst.cold = reinterpret_cast<ol::DevSurfCold<T>*>(dst.blob + off_cold);
+  dst.optics = reinterpret_cast<ol::DevOptics<T>*>(dst.blob + off_opt);
+  dst.coeffs = reinterpret_cast<T*>(dst.blob + off_coef);
+  OL_HIP_CHECK(hipMemcpy(dst.blob, host.data(), used, hipMemcpyHostToDevice));
   return OL_OK;
 }
 
 template <typename T>
 void release(DeviceTable<T>& t) {
-  if (t.surf) (void)hipFree(t.surf);
-  if (t.cold) (void)hipFree(t.cold);
-  if (t.optics) (void)hipFree(t.optics);
-  if (t.coeffs) (void)hipFree(t.coeffs);
+  if (t.blob) (void)hipFree(t.blob);
   t = DeviceTable<T>();
 }
 
