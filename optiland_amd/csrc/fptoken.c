@@ -210,11 +210,16 @@ static PyObject* obj(PyObject* o, PyObject* keep, PyObject* memo, PyObject* skip
   if (PyList_Append(keep, o) < 0) { Py_DECREF(key); return NULL; }
   PyObject* out = NULL;
   PyObject* d = NULL;
+#if PY_VERSION_HEX < 0x030C0000
+  /* fast path while the interpreter still keeps instance dicts behind a plain pointer
+     (CPython < 3.12); everything newer takes the public attribute lookup below */
   PyObject** dictptr = _PyObject_GetDictPtr(o);
   if (dictptr && *dictptr && PyDict_Check(*dictptr)) {
     d = *dictptr;
     Py_INCREF(d);
-  } else {
+  }
+#endif
+  if (!d) {
     d = PyObject_GetAttr(o, s_dict);
     if (!d) PyErr_Clear();
   }
