@@ -108,15 +108,24 @@ def _empty(dtype, device):
     return t
 
 
-def _bind_surfaces(surfaces, res):
+def _surface_views(res):
+    """The per-surface plane views of a record block (one tuple of eight per recorded
+    surface): tensor bookkeeping only, nothing of the reference is touched -- so it can run
+    while the kernels that fill the block are still in flight."""
+    n = res.n
+    rows = res.record[: res.last - res.first + 1, :, :n].unbind(0)
+    return [row.unbind(0) for row in rows]
+
+
+def _bind_surfaces(surfaces, res, views=None):
     """Every reference `Surface` gets its recorded vectors (standard_surface.py:260-274) as
     zero-copy views of the record block: three tensor ops per surface instead of the
     reference's `reset()` (eleven fresh device tensors) + eight assignments."""
-    n = res.n
-    rows = res.record[: res.last - res.first + 1, :, :n].unbind(0)
+    if views is None:
+        views = _surface_views(res)
     empty = _empty(res.record.dtype, res.record.device)
-    for surf, row in zip(surfaces[res.first: res.last + 1], rows):
-        surf.x, surf.y, surf.z, surf.L, surf.M, surf.N, surf.intensity, surf.opd = row.unbind(0)
+    for surf, row in zip(surfaces[res.first: res.last + 1], views):
+        surf.x, surf.y, surf.z, surf.L, surf.M, surf.N, surf.intensity, surf.opd = row
         surf.u = surf.aoi = empty  # Surface.reset(): only paraxial traces fill these
 
 
@@ -416,16 +425,20 @@ def _make_tracer_class():
             return front, table
 
         # ---------------------------------------------------------------- trace
-        def _finish(self, front, table, mine, wavelength, update_intensity):
+        def _finish(self, front, table, mine, wavelength, update_intensity,
+                    before_commit=None):
             """Hand the device results over in the reference's own classes: the returned
-            `RealRays` / `PolarizedRays` and every `Surface`'s recorded arrays."""
+            `RealRays` / `PolarizedRays` and every `Surface`'s recorded arrays.
+
+            Everything that only BUILDS objects (plane views, the rays object, the epilogue
+            launches) comes first; `before_commit()` -- the status read-back of a launch whose
+            checks were deferred, the one synchronisation of the call, which may raise -- runs
+            after it and before the first reference object is modified: the host work
+            overlaps the kernels instead of following them, and a range error still leaves
+            the optic's surfaces as they were."""
             lazy = front.last_was_lazy
             res = front._last_res if lazy else front.surfaces._res
-            if lazy:
-                register_pending_record(self.optic, table, front.engine, front.dtype,
-                                        front.last_fused_launch)
-            else:
-                _bind_surfaces(self.optic.surfaces.surfaces, res)
+            views = None if lazy else _surface_views(res)
             n, dtype, dev = res.n, res.record.dtype, res.record.device
             polarized = table.polarization is not None
             cls = RefPolarizedRays if polarized else RefRealRays
@@ -447,6 +460,13 @@ def _make_tracer_class():
                 out.i = front.engine.polarized_intensity(
                     mine._prt, (mine._L0, mine._M0, mine._N0), mine._i0,
                     _state_dict(self.optic.polarization_state))
+            if before_commit is not None:
+                before_commit()
+            if lazy:
+                register_pending_record(self.optic, table, front.engine, front.dtype,
+                                        front.last_fused_launch)
+            else:
+                _bind_surfaces(self.optic.surfaces.surfaces, res, views)
             # the record block now lives exactly as long as the reference objects that view
             # it (the Surfaces, the returned rays): the cached front must not pin it too --
             # up to _MAX_ENGINES x dtypes fronts would each hold their last 4 GB at 1e7 rays
@@ -508,14 +528,15 @@ def _make_tracer_class():
                     try:
                         if err is not None:
                             raise err
-                        front.check_status()
+                        out = self._finish(front, table, mine, wavelength, update_intensity,
+                                           before_commit=front.check_status)
                     except BaseException:
                         # the cached front must not pin the record block of a failed call
                         front.surfaces._bind(None)
                         front._last_res = None
                         raise
                     self.last_path = "hip"
-                    return self._finish(front, table, mine, wavelength, update_intensity)
+                    return out
                 self.speculative_misses += 1
                 self._hip_spec_ok = False
                 front.surfaces._bind(None)  # drop the stale launch's block

@@ -440,6 +440,13 @@ def test_trace_generic_input_matrix_matches_the_reference(hip_on_cpu):
             np.testing.assert_allclose(b[2], a[2], rtol=1e-6, atol=1e-9)
         else:
             assert a[1:] == b[1:], (args, a, b)
+    # a call that fails its range check leaves the optic's surfaces as the last good trace
+    # left them (the reference validates before it touches anything; here the status word is
+    # read back after the result objects were BUILT but before any Surface is written)
+    run(hip_lens, same[0])
+    held = [s_.x for s_ in hip_lens.surfaces.surfaces]
+    assert run(hip_lens, (0.0, 0.5, T([0.1, 1.2, 0.0]), T([0.1, 0.2, 0.0])))[0] == "err"
+    assert all(a_ is b_ for a_, b_ in zip(held, [s_.x for s_ in hip_lens.surfaces.surfaces]))
     # superset behaviour
     bad_size = run(hip_lens, (0.0, 0.5, T([0.1, 0.2]), T([0.1, 0.2, 0.3])))
     assert bad_size[:2] == ("err", "ValueError") and "one common size" in bad_size[2]
