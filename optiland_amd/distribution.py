@@ -17,14 +17,19 @@ def _line(n, positive):
 
 
 def _hexapolar(rings):
-    # distribution.py:201-220: centre + 6(i+1) points on ring i, radius linspace
-    xs, ys = [np.zeros(1)], [np.zeros(1)]
+    # distribution.py:201-220: centre + 6(i+1) points on ring i, radius linspace.  One
+    # vectorised pass; the values are those of the reference's per-ring
+    # `linspace(0, 2 pi, 6 k + 1)[:-1]` bit for bit (j * (2 pi / 6 k), tests/test_host_tracer.py)
     radii = np.linspace(0.0, 1.0, rings + 1)
-    for i in range(rings):
-        theta = np.linspace(0.0, 2.0 * np.pi, 6 * (i + 1) + 1)[:-1]
-        xs.append(radii[i + 1] * np.cos(theta))
-        ys.append(radii[i + 1] * np.sin(theta))
-    return np.concatenate(xs), np.concatenate(ys)
+    k = np.arange(1, rings + 1)
+    cnt = 6 * k
+    ks = np.repeat(k, cnt)
+    j = np.arange(ks.size) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    theta = j * np.repeat((2.0 * np.pi) / cnt.astype(np.float64), cnt)
+    r = radii[ks]
+    x, y = np.zeros(ks.size + 1), np.zeros(ks.size + 1)
+    x[1:], y[1:] = r * np.cos(theta), r * np.sin(theta)
+    return x, y
 
 
 def _uniform(n):

@@ -15,7 +15,9 @@ from a live reference `Optic` through `optiland_amd.integration`.
 
 from __future__ import annotations
 
+import math
 import os
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -60,6 +62,36 @@ class RecordedSurfaces:
     @property
     def num_surfaces(self):
         return 0 if self._res is None else self._res.last - self._res.first + 1
+
+
+# Device planes of the deterministic pupil samplers, shared by every tracer of the process:
+# a spot diagram over three wavelengths runs on three tracers (one device table each), and
+# 400 hexapolar rings are 26 ms of host sampling + 8 MB of upload per tracer otherwise.  The
+# planes are kernel INPUTS only (never written).  Least recently used out beyond 256 MB.
+_PUPIL_PLANES: "OrderedDict" = OrderedDict()
+_PUPIL_PLANES_CAP = 256 << 20
+
+
+def _shared_pupil_planes(key, dtype, device, to_device):
+    name = key[0]
+    if name in ("random", "sobol"):
+        d = create_distribution(name)
+        d.generate_points(key[1])
+        return to_device(d.x), to_device(d.y)
+    full = (key, dtype, str(device))
+    hit = _PUPIL_PLANES.get(full)
+    if hit is None:
+        d = create_distribution(name)
+        d.generate_points(key[1])
+        hit = (to_device(d.x), to_device(d.y))
+        _PUPIL_PLANES[full] = hit
+        total = sum(2 * h[0].numel() * h[0].element_size() for h in _PUPIL_PLANES.values())
+        while total > _PUPIL_PLANES_CAP and len(_PUPIL_PLANES) > 1:
+            _, old = _PUPIL_PLANES.popitem(last=False)
+            total -= 2 * old[0].numel() * old[0].element_size()
+    else:
+        _PUPIL_PLANES.move_to_end(full)
+    return hit
 
 
 class HipRayTracer:
@@ -188,13 +220,18 @@ class HipRayTracer:
         """Device planes of a pupil distribution; named distributions are cached per
         (name, num_rays) so that repeated traces do not re-sample / re-upload them."""
         if isinstance(distribution, str):
+            if distribution == "random" and self.device.type == "cuda":
+                # distribution.py:132-158 with the draws made on the device, as the reference's
+                # torch backend makes them (a fresh sample per call; 1e6 points took 31 ms
+                # as host arrays + upload, the trace they feed 0.1 ms)
+                u = torch.rand((2, int(num_rays)), dtype=self.dtype, device=self.device)
+                r, th = u[0].sqrt_(), u[1].mul_(2.0 * math.pi)
+                return r * th.cos(), r * th.sin()
             key = (distribution, int(num_rays) if num_rays is not None else None)
             hit = self._pupil_cache.get(key)
             if hit is None:
-                d = create_distribution(distribution)
-                d.generate_points(num_rays)
-                hit = (self._dev(d.x), self._dev(d.y))
-                if distribution != "random":  # a fresh sample per call, like the reference
+                hit = _shared_pupil_planes(key, self.dtype, self.device, self._dev)
+                if distribution not in ("random", "sobol"):  # those: a fresh sample per call
                     self._pupil_cache[key] = hit
             return hit
         return self._dev(distribution.x), self._dev(distribution.y)

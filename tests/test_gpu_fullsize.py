@@ -79,6 +79,43 @@ def test_fullsize_properties(dg, dtype, n):
     assert_close_planes(got, want, t, t, f"subsample {dtype}")
 
 
+@pytest.mark.parametrize("dtype,n", [(torch.float32, 10_000_000), (torch.float64, 5_000_000)],
+                         ids=["f32-1e7", "f64-5e6"])
+def test_fullsize_generation_inside_the_record_kernel(dg, dtype, n):
+    """`ol_trace_generate` at BASELINE size (the default bench step): every recorded plane of
+    every surface, row 0 included, equals `ol_generate_rays` + `ol_trace` bit for bit; a
+    launch that records from surface S - 1 on (lazy records) equals the last two rows; two
+    ragged halves equal the whole."""
+    hip, table = dg
+    if not hip.can_trace_generate():
+        pytest.skip("library without ol_trace_generate")
+    S = table.num_traced
+    px, py = _pupil(n, 11, dtype)
+    hx = torch.zeros(n, dtype=dtype, device=DEV)
+    hy = torch.full((n,), 0.7, dtype=dtype, device=DEV)
+    record = hip.alloc_record(n, dtype)
+    rays = hip.row0_planes(record, n)
+    hip.generate_rays(hx, hy, px, py, out=rays)
+    two = hip.trace(rays, 0, record=record)
+    one = hip.trace_generate(px, py, 0, field=(0.0, 0.7))
+    for s in range(S + 1):
+        for k in range(8):
+            assert torch.equal(one.row(s, k), two.row(s, k)), (s, PLANES[k])
+    del two, record, rays
+    tail = hip.trace_generate(px, py, 0, field=(0.0, 0.7), record_first=S - 1)
+    assert tail.record.shape[0] >= 2 and tail.first == S - 1
+    for s in (S - 1, S):
+        for k in range(8):
+            assert torch.equal(tail.row(s, k), one.row(s, k)), (s, PLANES[k])
+    h = n // 2 + 5
+    for lo, hi in ((0, h), (h, n)):
+        part = hip.trace_generate(px[lo:hi].contiguous(), py[lo:hi].contiguous(), 0,
+                                  field=(0.0, 0.7))
+        for s in (0, S // 2, S):
+            for k in (0, 2, 4, 6, 7):
+                assert torch.equal(part.row(s, k), one.row(s, k)[lo:hi]), (s, k)
+
+
 def test_mirror_symmetry_is_exact(dg):
     """On-axis field of a rotationally symmetric lens: (Px, Py) -> (-Px, Py) mirrors
     x and L exactly (IEEE arithmetic is sign-symmetric; no op order depends on sign)."""

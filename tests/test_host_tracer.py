@@ -131,6 +131,46 @@ def test_distributions_match_reference_counts_and_order():
     assert create_distribution("ring").generate_points(7).x.size == 7
     r = create_distribution("random").generate_points(1000)
     assert np.all(r.x**2 + r.y**2 <= 1)
+    # the one-pass hexapolar sampler IS the per-ring definition (distribution.py:201-220:
+    # centre, then `r_k (cos, sin)(linspace(0, 2 pi, 6 k + 1)[:-1])` ring by ring), bit for bit
+    for rings in list(range(1, 24)) + [64, 257]:
+        xs, ys = [np.zeros(1)], [np.zeros(1)]
+        radii = np.linspace(0.0, 1.0, rings + 1)
+        for i in range(rings):
+            theta = np.linspace(0.0, 2.0 * np.pi, 6 * (i + 1) + 1)[:-1]
+            xs.append(radii[i + 1] * np.cos(theta))
+            ys.append(radii[i + 1] * np.sin(theta))
+        d = create_distribution("hexapolar").generate_points(rings)
+        assert np.array_equal(d.x, np.concatenate(xs)), rings
+        assert np.array_equal(d.y, np.concatenate(ys)), rings
+
+
+def test_pupil_planes_are_shared_between_tracers_of_a_process():
+    """A spot diagram over three wavelengths runs on three tracers: the deterministic pupil
+    planes are sampled and uploaded once (`tracer._shared_pupil_planes`); stochastic samplers
+    draw afresh on every call."""
+    from optiland_amd import tracer as tr
+    made = []
+    to_dev = lambda a: (made.append(1), torch.as_tensor(a, dtype=torch.float64))[1]  # noqa: E731
+    tr._PUPIL_PLANES.clear()
+    a = tr._shared_pupil_planes(("hexapolar", 5), torch.float64, "cpu", to_dev)
+    b = tr._shared_pupil_planes(("hexapolar", 5), torch.float64, "cpu", to_dev)
+    assert a[0] is b[0] and len(made) == 2
+    c = tr._shared_pupil_planes(("hexapolar", 5), torch.float32, "cpu", to_dev)
+    assert c[0] is not a[0] and len(made) == 4          # other precision: other planes
+    r1 = tr._shared_pupil_planes(("random", 50), torch.float64, "cpu", to_dev)
+    r2 = tr._shared_pupil_planes(("random", 50), torch.float64, "cpu", to_dev)
+    assert not torch.equal(r1[0], r2[0])
+    cap = tr._PUPIL_PLANES_CAP
+    tr._PUPIL_PLANES_CAP = 3 * 2 * 91 * 8                 # room for ~3 five-ring samplers
+    try:
+        for n in range(6, 12):
+            tr._shared_pupil_planes(("hexapolar", n), torch.float64, "cpu", to_dev)
+        assert 1 <= len(tr._PUPIL_PLANES) <= 3             # least recently used went
+        assert (("hexapolar", 11), torch.float64, "cpu") in tr._PUPIL_PLANES
+    finally:
+        tr._PUPIL_PLANES_CAP = cap
+        tr._PUPIL_PLANES.clear()
 
 
 # reference goldens: tests/test_analysis.py:76-102 (CookeTriplet, fields 0/14/20 deg,

@@ -132,6 +132,8 @@ def main():
                             lambda: analysis.SpotDiagram(lens, num_rings=400).rms_spot_radius()),
                            ("OPD(256 rings).rms()",
                             lambda: OPD(lens, (0.0, 1.0), w, num_rings=256).rms()),
+                           ("EncircledEnergy(1e6 rays).centroid()",
+                            lambda: analysis.EncircledEnergy(lens, num_rays=1_000_000).centroid()),
                            ("FFTPSF(512, 1024).strehl_ratio()",
                             lambda: FFTPSF(lens, (0.0, 1.0), w, num_rays=512,
                                            grid_size=1024).strehl_ratio())):
