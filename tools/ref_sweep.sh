@@ -8,13 +8,15 @@
 # With the SurfaceGroup.trace seam and the bridging of unsupported surfaces enabled the
 # result is unchanged; the seam itself served 52 caller-built bundles and declined 17.
 #
-#   tools/ref_sweep.sh [workdir] [oracle|kernel-source]
+#   tools/ref_sweep.sh [workdir] [oracle|kernel-source] [lazy]
 # kernel-source (round 2): behind the tracer sits the product's own engine class on the host
 # build of the kernel source (tests/_hostmath.make_engine_class) instead of the oracle.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 W=${1:-/tmp/ol_ref_sweep}
 ENGINE=${2:-oracle}
+# third argument "lazy": integration.enable(force=True, lazy_records=True)
+export OL_SWEEP_LAZY=$([ "${3:-}" = lazy ] && echo True || echo False)
 rm -rf "$W" && mkdir -p "$W" && cp -r /root/reference/tests "$W/tests"
 if [ "$ENGINE" = kernel-source ]; then
 cat > "$W/tests_fake.py" <<PY
@@ -42,7 +44,8 @@ s = s.replace("import optiland.backend as be\n",
               "import optiland.backend as be\nimport sys\nsys.path.insert(0, %r)\n"
               "import optiland_amd.tracer as _tr\nfrom tests_fake import OracleEngine\n"
               "_tr._make_engine = lambda table, device: OracleEngine(table, device)\n"
-              "from optiland_amd import integration as _integ\n_integ.enable(force=True)\n" % r, 1)
+              "from optiland_amd import integration as _integ\nimport os\n"
+              "_integ.enable(force=True, lazy_records=os.environ.get('OL_SWEEP_LAZY') == 'True')\n" % r, 1)
 s = s.replace("be.grad_mode.enable()", "be.grad_mode.disable()")
 s += """
 
