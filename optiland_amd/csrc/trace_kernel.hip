@@ -408,10 +408,13 @@ __device__ __forceinline__ SurfFetched<T> fetched_surface(int s) {
 #ifndef OL_POLNR_WAVES_F64
 #define OL_POLNR_WAVES_F64 0
 #endif
-template <typename T, int RPT, int POLK, int NR>
+// (The generic-family kernel WITH the generator prologue does not fit 7 waves without two
+// dwords of scratch: it keeps the allocator's own choice.)
+template <typename T, int RPT, int POLK, int NR, bool GEN = false>
 struct WavesPerEu {
   static constexpr int value =
-      (OL_POLNR_WAVES > 0 && sizeof(T) == 4 && RPT == 1 && POLK == 1 && NR != 0)
+      (OL_POLNR_WAVES > 0 && sizeof(T) == 4 && RPT == 1 && POLK == 1 && NR != 0 &&
+       !(GEN && NR == 1))
           ? OL_POLNR_WAVES
           : ((OL_POLNR_WAVES_F64 > 0 && sizeof(T) == 8 && RPT == 1 && POLK == 1 && NR != 0)
                  ? OL_POLNR_WAVES_F64
@@ -425,7 +428,7 @@ struct WavesPerEu {
 // written by one kernel and read back by the next.
 template <typename T, int RPT, bool RECORD, int POLK, int NR, bool SPOT, bool GEN = false>
 __global__ __launch_bounds__(kTraceBlock)
-__attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR>::value))) void trace_kernel(
+__attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN>::value))) void trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
     const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
     TraceArgs<T> a) {
