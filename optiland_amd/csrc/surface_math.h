@@ -659,11 +659,60 @@ struct CoeffWindow {
   gx = G.x;                                                                    \
   gy = G.y;
 
+// OL_ZERN_MONO_F32_TWO_BLOCKS (default on): the fp32 unrolled instances read the stream as
+// TWO blocks -- the sag polynomial's coefficients, then, requested when the sag chain has
+// finished, the gradient's -- instead of through the 8-dword window.  In fp32 one block is at
+// most 15 + 20 SGPRs at degree 4 and the window's ordering handles cost vector moves in a
+// kernel (C5) that is bound by vector issue: 732 -> 672 vector instructions per ray.  The fp64
+// kernels, where a block is twice as wide, keep the window.
+#ifndef OL_ZERN_MONO_F32_TWO_BLOCKS
+#define OL_ZERN_MONO_F32_TWO_BLOCKS 1
+#endif
+template <typename T, int N>
+OL_DEV void zernike_mono_two_blocks(cptr<T> c, T xn, T yn, T& zsum, T& gx, T& gy) {
+  using m = Math<T>;
+  using V2 = vec2<T>;
+  constexpr int NS = (N + 1) * (N + 2) / 2;
+  cptr<T> p = refresh(c);
+  int e = 0;
+  T P = T(0);
+#pragma unroll
+  for (int i = N; i >= 0; --i) {
+    T q = p[e++];
+#pragma unroll
+    for (int j = N - i - 1; j >= 0; --j) q = m::fma(q, yn, p[e++]);
+    P = i == N ? q : m::fma(P, xn, q);
+  }
+  cptr<T> g = refresh_after(c + NS, P);  // the gradient block: not before the sag chain ends
+  e = 0;
+  const V2 xx = {xn, xn}, yy = {yn, yn};
+  V2 G = {T(0), T(0)};
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    V2 q = {g[e], g[e + 1]};
+    e += 2;
+#pragma unroll
+    for (int j = N - 2 - i; j >= 0; --j) {
+      const V2 cj = {g[e], g[e + 1]};
+      e += 2;
+      q = q * yy + cj;
+    }
+    G = i == N - 1 ? q : G * xx + q;
+  }
+  zsum = P;
+  gx = G.x;
+  gy = G.y;
+}
+
 template <typename T, int N>
 OL_DEV void zernike_mono_fixed(cptr<T> c, T xn, T yn, T& zsum, T& gx, T& gy) {
-  constexpr int TOTAL = (N + 1) * (N + 2) / 2 + N * (N + 1);
-  CoeffWindow<T, TOTAL, OL_ZERN_MONO_SPLIT != 0> stream(c);
-  OL_ZERN_MONO_BODY(_Pragma("unroll"), stream)
+  if constexpr (OL_ZERN_MONO_F32_TWO_BLOCKS && OL_ZERN_MONO_SPLIT && sizeof(T) == 4) {
+    zernike_mono_two_blocks<T, N>(c, xn, yn, zsum, gx, gy);
+  } else {
+    constexpr int TOTAL = (N + 1) * (N + 2) / 2 + N * (N + 1);
+    CoeffWindow<T, TOTAL, OL_ZERN_MONO_SPLIT != 0> stream(c);
+    OL_ZERN_MONO_BODY(_Pragma("unroll"), stream)
+  }
 }
 #undef OL_ZERN_MONO_BODY
 

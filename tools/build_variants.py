@@ -65,6 +65,9 @@ VARIANTS = {
     # fp64 division / square root: IEEE library sequences instead of the hardware-seed +
     # two refinement steps form (surface_math.h: OL_FAST_F64)
     "fast64_0": ["-DOL_FAST_F64=0"],
+    # fp32 unrolled Zernike polynomial through the 8-dword window (as fp64) instead of as two
+    # blocks (sag, then gradient)
+    "zmono_window32": ["-DOL_ZERN_MONO_F32_TWO_BLOCKS=0"],
 }
 
 
