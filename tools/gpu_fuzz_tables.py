@@ -18,7 +18,7 @@ from optiland_amd.system import SystemTable  # noqa: E402
 
 DEV = "cuda:0"
 worst = {torch.float64: 0.0, torch.float32: 0.0}
-over, checked, flagged = [], 0, 0
+over, checked, flagged, fused = [], 0, 0, 0
 for path in sorted(glob.glob(os.path.join(ROOT, "fuzz_tables", "*.json"))):
     table = SystemTable.load(path)
     seed = int(os.path.basename(path)[5:9])
@@ -48,6 +48,27 @@ for path in sorted(glob.glob(os.path.join(ROOT, "fuzz_tables", "*.json"))):
                 continue
             assert want["status"] == 0, (path, "oracle flags a range error, kernel does not")
             got = res.record[:, :, :n].double().cpu().numpy()
+            # round 3: the same rays generated INSIDE the recording launch (ol_trace_generate)
+            # -- every plane of every row, the generated row 0 and the PRT included, must be
+            # the two-launch result bit for bit
+            if hip.can_trace_generate():
+                # (against generate-then-trace with the field as launch-uniform SCALARS: per-ray
+                # field planes take tan() on the device, scalars on the host -- 1 ulp apart)
+                fld = (float(hx[0]), float(hy[0]))
+                rec2 = hip.alloc_record(n, dtype)
+                rays2 = hip.row0_planes(rec2, n)
+                hip.generate_rays(fld[0], fld[1], f(px), f(py), 1.0, 1.0, out=rays2)
+                prt1 = torch.empty_like(prt) if pol else None
+                res2 = hip.trace(rays2, 0, record=rec2, prt=prt1, prt_identity=pol)
+                prt2 = torch.empty_like(prt) if pol else None
+                gen = hip.trace_generate(f(px), f(py), 0, field=fld, prt=prt2)
+                a_, b_ = gen.record[:, :, :n], res2.record[:, :, :n]
+                same = (a_ == b_) | (torch.isnan(a_) & torch.isnan(b_))
+                assert bool(same.all()), (path, str(dtype), "fused generation differs")
+                if pol:
+                    same = (prt2 == prt1) | (torch.isnan(prt2) & torch.isnan(prt1))
+                    assert bool(same.all()), (path, str(dtype), "fused generation: PRT differs")
+                fused += 1
         finally:
             hip.close()
         rec = want["record"]
@@ -73,7 +94,8 @@ for path in sorted(glob.glob(os.path.join(ROOT, "fuzz_tables", "*.json"))):
         if err > tol:
             over.append((os.path.basename(path), str(dtype), err, float(ok.mean())))
         checked += 1
-print(f"checked {checked} (table, dtype) pairs, {flagged} range-flagged on both sides")
+print(f"checked {checked} (table, dtype) pairs, {flagged} range-flagged on both sides; "
+      f"{fused} of them also through ol_trace_generate (bit-identical records)")
 print("worst fp64 margin %.3e   worst fp32 margin %.3e" % (worst[torch.float64], worst[torch.float32]))
 print("over the contract:", len(over))
 for o in over[:20]:
