@@ -38,7 +38,10 @@ def both(fn, table):
     return out
 
 
+ONLY = {int(a) for a in sys.argv[1:]}   # optional: seeds to look at (triage of flagged lenses)
 for path in sorted(glob.glob(os.path.join(ROOT, "fuzz_tables", "*.json"))):
+    if ONLY and int(os.path.basename(path)[5:9]) not in ONLY:
+        continue
     table = SystemTable.load(path)
     name = os.path.basename(path)
 
