@@ -204,6 +204,42 @@ def _remove_lazy_descriptors():
             delattr(Surface, name)
 
 
+class _LazyPrt:
+    """Data descriptor for `PolarizedRays.p` (rays/polarized_rays.py:50-54: the (N, 3, 3)
+    complex polarisation ray-tracing matrices).  The kernels keep the matrices as nine (or,
+    with a retarder, eighteen) real planes; the reference's layout is a transposing copy of
+    360 MB into 720 MB at 1e7 rays plus a NaN scan that synchronises -- 0.5 of the 0.9 ms a
+    polarised `Optic.trace_generic` took.  A traced bundle carries the planes
+    (`__dict__["_hip_prt"]`, so that copies of the object carry them too) and gets its `p`
+    when somebody reads it; a write behaves like a plain attribute.  Installed on the
+    reference's class the first time the drop-in is used and left there (without planes it IS
+    a plain attribute)."""
+
+    def __get__(self, obj, cls=None):
+        if obj is None:
+            return self
+        d = obj.__dict__
+        try:
+            return d["p"]
+        except KeyError:
+            planes = d.pop("_hip_prt", None)
+            if planes is None:
+                raise AttributeError("p") from None
+            out = d["p"] = prt_to_complex(planes)
+            return out
+
+    def __set__(self, obj, value):
+        d = obj.__dict__
+        d.pop("_hip_prt", None)
+        d["p"] = value
+
+    def __delete__(self, obj):
+        d = obj.__dict__
+        had = d.pop("_hip_prt", None) is not None
+        if d.pop("p", None) is None and not had:
+            raise AttributeError("p")
+
+
 class _PendingRecord:
     """One record-all trace that has not been run: the table it was launched on, the inputs
     of the fused launch, the optic whose surfaces it belongs to."""
@@ -265,6 +301,9 @@ def _make_tracer_class():
     from optiland.raytrace.real_ray_tracer import RealRayTracer
     from optiland.rays import PolarizedRays as RefPolarizedRays
     from optiland.rays import RealRays as RefRealRays
+
+    if not isinstance(RefPolarizedRays.__dict__.get("p"), _LazyPrt):
+        RefPolarizedRays.p = _LazyPrt()
 
     class OptilandHipRayTracer(RealRayTracer):
         """`RealRayTracer` whose ray generation + surface loop run in HIP kernels.
@@ -448,7 +487,8 @@ def _make_tracer_class():
             out.is_normalized = True
             out.L0, out.M0, out.N0 = mine.L0, mine.M0, mine.N0
             if polarized:
-                out.p = prt_to_complex(mine._prt)
+                # `p` in the reference's (N, 3, 3) complex layout: produced on first read
+                out.__dict__["_hip_prt"] = mine._prt
                 out._i0, out._L0, out._M0, out._N0 = mine._i0, mine._L0, mine._M0, mine._N0
             # final propagation by the image thickness (0 in every sample; identity then):
             # real_ray_tracer.py:104-110, BEFORE the polarised epilogue (:112-113)
@@ -709,7 +749,12 @@ def _sg_run(group, eng, rays, planes, first, last, polarized):
         rays.L0, rays.M0, rays.N0 = pre
     rays.x, rays.y, rays.z, rays.L, rays.M, rays.N, rays.i, rays.opd = res.rows(last)
     if polarized:
-        rays.p = prt_to_complex(prt)
+        if isinstance(type(rays).__dict__.get("p"), _LazyPrt) or any(
+                isinstance(c.__dict__.get("p"), _LazyPrt) for c in type(rays).__mro__):
+            rays.__dict__.pop("p", None)        # produced from the planes on first read
+            rays.__dict__["_hip_prt"] = prt
+        else:
+            rays.p = prt_to_complex(prt)
 
 
 def _hip_surface_group_trace(group, rays, skip):

@@ -154,7 +154,21 @@ def test_polarized_system_through_the_drop_in(hip_on_cpu):
     assert tracer.last_path == "hip"
     assert type(r1).__name__ == "PolarizedRays"
     np.testing.assert_allclose(_np(be, r1.i), i0, rtol=1e-8)
+    # `p` in the reference's (N, 3, 3) complex layout is produced from the kernel's planes on
+    # first read (integration._LazyPrt); copies taken before that read carry the planes
+    import copy
+    assert "p" not in vars(r1) and "_hip_prt" in vars(r1)
+    twin, deep = copy.copy(r1), copy.deepcopy(r1)
+    assert hasattr(r1, "p") and "p" in vars(r1) and "_hip_prt" not in vars(r1)
+    assert r1.p.shape == (p0.shape[0], 3, 3) and r1.p.is_complex()
     np.testing.assert_allclose(be.to_numpy(r1.p).real, p0.real, rtol=1e-7, atol=1e-10)
+    for other in (twin, deep):
+        assert "p" not in vars(other)
+        np.testing.assert_array_equal(be.to_numpy(other.p), be.to_numpy(r1.p))
+    twin.p = twin.p * 2                                   # a write is a plain attribute write
+    np.testing.assert_array_equal(be.to_numpy(twin.p), 2 * be.to_numpy(r1.p))
+    del deep.p
+    assert not hasattr(deep, "p")
     # the tutorial recipe: repeated update_intensity on the returned object (this
     # runs the REFERENCE's PolarizedRays.update_intensity on our p / _i0 / _L0..)
     r1.update_intensity(PolarizationState(is_polarized=True, Ex=1, Ey=0, phase_x=0, phase_y=0))
