@@ -38,7 +38,7 @@ import torch
 from . import fingerprint as _fp
 from . import tracer as _tracer
 from .packer import UnsupportedSystem, pack_optic, pack_surfaces
-from .rays import _state_dict, prt_to_complex
+from .rays import prt_to_complex
 
 BACKEND_NAME = "hip"
 
@@ -497,9 +497,10 @@ def _make_tracer_class():
                 last_surface = self.optic.surfaces[-1]
                 last_surface.material_post.propagation_model.propagate(out, thick)
             if polarized and update_intensity:
+                # (the state as packed: the change detector covers the live object, and reading
+                # it again would be four blocking read-backs in front of the epilogue launch)
                 out.i = front.engine.polarized_intensity(
-                    mine._prt, (mine._L0, mine._M0, mine._N0), mine._i0,
-                    _state_dict(self.optic.polarization_state))
+                    mine._prt, (mine._L0, mine._M0, mine._N0), mine._i0, table.polarization)
             if before_commit is not None:
                 before_commit()
             if lazy:
