@@ -31,6 +31,7 @@ installed (e.g. the GPU test box).
 from __future__ import annotations
 
 import collections
+import os
 
 import numpy as np
 import torch
@@ -117,14 +118,20 @@ def _surface_views(res):
     return [row.unbind(0) for row in rows]
 
 
-def _bind_surfaces(surfaces, res, views=None):
+def _bind_surfaces(surfaces, res, views=None, owner=None):
     """Every reference `Surface` gets its recorded vectors (standard_surface.py:260-274) as
     zero-copy views of the record block: three tensor ops per surface instead of the
-    reference's `reset()` (eleven fresh device tensors) + eight assignments."""
+    reference's `reset()` (eleven fresh device tensors) + eight assignments.  `owner`: bind
+    only the surfaces whose pending entry is still this object (a surface written since --
+    `Surface.reset()`, a reference-side trace -- keeps what was written)."""
     if views is None:
         views = _surface_views(res)
     empty = _empty(res.record.dtype, res.record.device)
     for surf, row in zip(surfaces[res.first: res.last + 1], views):
+        if owner is not None:
+            if _PENDING.get(surf) is not owner:
+                continue
+            del _PENDING[surf]
         surf.x, surf.y, surf.z, surf.L, surf.M, surf.N, surf.intensity, surf.opd = row
         surf.u = surf.aoi = empty  # Surface.reset(): only paraxial traces fill these
 
@@ -143,6 +150,9 @@ def _bind_surfaces(surfaces, res, views=None):
 # surface -> pending trace.  A write to any of the eight (Surface.reset(), a reference-side
 # trace) drops that surface's pending entry.
 _PENDING: "weakref.WeakKeyDictionary" = None  # created with the descriptors
+# eager traces too make their per-surface views on first read (`_PendingViews`);
+# OPTILAND_HIP_DEFER_VIEWS=0: bind every surface inside the call, as rounds 1-2 did
+_DEFER_VIEWS = os.environ.get("OPTILAND_HIP_DEFER_VIEWS", "1") != "0"
 _RECORDED = ("x", "y", "z", "L", "M", "N", "intensity", "opd")
 
 
@@ -168,16 +178,31 @@ class _RecordedPlane:
 
     def __set__(self, obj, value):
         if _PENDING:
-            _PENDING.pop(obj, None)
+            _written(obj)
         obj.__dict__[self.name] = value
 
     def __delete__(self, obj):
         if _PENDING:
-            _PENDING.pop(obj, None)
+            _written(obj)
         try:
             del obj.__dict__[self.name]
         except KeyError:
             raise AttributeError(self.name) from None
+
+
+def _written(surf):
+    """A recorded attribute of `surf` is about to be written.  Views that only wait to be made
+    (`_PendingViews`: an eager trace) are made first -- the other attributes of this and of
+    every other surface then hold exactly what an eager bind would have left; a trace that has
+    not been RUN (`_PendingRecord`, opt-in lazy records) is not run for a write: the surface
+    leaves it and keeps its reset state."""
+    pend = _PENDING.get(surf)
+    if pend is None:
+        return
+    if isinstance(pend, _PendingViews):
+        pend.materialize()
+    else:
+        del _PENDING[surf]
 
 
 def _install_lazy_descriptors():
@@ -259,9 +284,10 @@ class _PendingRecord:
         if optic is None:
             return
         surfaces = optic.surfaces.surfaces
-        for s in surfaces:
-            _PENDING.pop(s, None)
         if len(surfaces) != self.table.num_surfaces:
+            for s in surfaces:
+                if _PENDING.get(s) is self:
+                    del _PENDING[s]
             return  # the optic was rebuilt in between: nothing sensible to bind
         eng = self.engine
         if getattr(eng, "_handle", True) is None or getattr(eng, "table", self.table) \
@@ -270,9 +296,58 @@ class _PendingRecord:
         front = _tracer.HipRayTracer(self.table, dtype=self.dtype, engine=eng)
         hx, hy, px, py, vig, wavelength, flags = self.launch
         front._run(hx, hy, px, py, vig, wavelength, False, flags)  # record-all, eager
-        _bind_surfaces(surfaces, front.surfaces._res)
+        _bind_surfaces(surfaces, front.surfaces._res, owner=self)
         front.surfaces._bind(None)
         self.launch = None
+
+
+class _PendingViews:
+    """An EAGER trace whose record block exists, but whose per-surface plane views have not
+    been made: 13 surfaces x (an unbind + ten attribute writes) are a quarter of the host time
+    of a small trace, and most callers read the returned rays only.  The views are made when
+    somebody reads a recorded attribute of any surface of the optic."""
+
+    def __init__(self, optic, res):
+        import weakref
+
+        self.optic = weakref.ref(optic)
+        self.res = res
+        self.done = False
+
+    def materialize(self):
+        if self.done:
+            return
+        self.done = True
+        optic, res = self.optic(), self.res
+        self.res = None
+        if optic is None:
+            return
+        surfaces = optic.surfaces.surfaces
+        if len(surfaces) <= res.last:
+            for s in surfaces:
+                if _PENDING.get(s) is self:
+                    del _PENDING[s]
+            return
+        _bind_surfaces(surfaces, res, owner=self)
+
+
+def _mark_pending(optic, pend, dtype):
+    empty = None
+    for surf in optic.surfaces.surfaces:
+        d = surf.__dict__
+        if empty is None:
+            old = d.get("x")
+            empty = _empty(dtype, old.device if isinstance(old, torch.Tensor) else "cpu")
+        d["x"] = d["y"] = d["z"] = d["L"] = d["M"] = d["N"] = d["intensity"] = d["opd"] = empty
+        d["u"] = d["aoi"] = empty
+        _PENDING[surf] = pend
+    return pend
+
+
+def register_pending_views(optic, res):
+    """Eager trace, views deferred (`_PendingViews`); same bookkeeping as a pending record."""
+    _install_lazy_descriptors()
+    return _mark_pending(optic, _PendingViews(optic, res), res.record.dtype)
 
 
 def register_pending_record(optic, table, engine, dtype, launch):
@@ -280,17 +355,7 @@ def register_pending_record(optic, table, engine, dtype, launch):
     instance attributes are emptied first (as `Surface.reset()` leaves them), so a copy of
     the optic taken before anybody reads them sees a reset surface, never stale arrays."""
     _install_lazy_descriptors()
-    pend = _PendingRecord(optic, table, engine, dtype, launch)
-    empty = None
-    for surf in optic.surfaces.surfaces:
-        if empty is None:
-            old = surf.__dict__.get("x")
-            empty = _empty(dtype, old.device if isinstance(old, torch.Tensor) else "cpu")
-        for name in _RECORDED:
-            surf.__dict__[name] = empty
-        surf.__dict__["u"] = surf.__dict__["aoi"] = empty
-        _PENDING[surf] = pend
-    return pend
+    return _mark_pending(optic, _PendingRecord(optic, table, engine, dtype, launch), dtype)
 
 
 def _make_tracer_class():
@@ -477,7 +542,7 @@ def _make_tracer_class():
             the optic's surfaces as they were."""
             lazy = front.last_was_lazy
             res = front._last_res if lazy else front.surfaces._res
-            views = None if lazy else _surface_views(res)
+            views = None if (lazy or _DEFER_VIEWS) else _surface_views(res)
             n, dtype, dev = res.n, res.record.dtype, res.record.device
             polarized = table.polarization is not None
             cls = RefPolarizedRays if polarized else RefRealRays
@@ -506,6 +571,8 @@ def _make_tracer_class():
             if lazy:
                 register_pending_record(self.optic, table, front.engine, front.dtype,
                                         front.last_fused_launch)
+            elif _DEFER_VIEWS:
+                register_pending_views(self.optic, res)
             else:
                 _bind_surfaces(self.optic.surfaces.surfaces, res, views)
             # the record block now lives exactly as long as the reference objects that view

@@ -58,10 +58,13 @@ def test_lazy_records_equal_eager_records(kernel_source, name):
             if hasattr(r0, "p"):
                 np.testing.assert_array_equal(be.to_numpy(r1.p), be.to_numpy(r0.p))
             polarised = hasattr(r0, "p")
-            # nothing was bound yet unless the trace is polarised (those record from row 0)
+            # nothing was bound yet: an un-run record-all trace -- or, for a polarised bundle
+            # (those record from row 0 anyway) and for the eager optic, a record block whose
+            # per-surface views are not made yet
             from optiland_amd import integration as ig
-            pending = ig._PENDING is not None and lazy.surfaces.surfaces[1] in ig._PENDING
-            assert pending == (not polarised)
+            pend = ig._PENDING.get(lazy.surfaces.surfaces[1])
+            assert isinstance(pend, ig._PendingViews if polarised else ig._PendingRecord)
+            assert isinstance(ig._PENDING.get(eager.surfaces.surfaces[1]), ig._PendingViews)
             # first read of ANY surface attribute materialises all of them
             for k in PLANES:
                 a, b = _np(be, getattr(lazy.surfaces, k)), _np(be, getattr(eager.surfaces, k))
@@ -140,3 +143,40 @@ def test_disable_materialises_what_is_still_pending(kernel_source):
         ig.disable()
     assert "x" not in Surface.__dict__ or not isinstance(Surface.__dict__["x"], ig._RecordedPlane)
     assert _np(be, lens.surfaces.x).shape == (len(lens.surfaces.surfaces), 1 + 3 * 4 * 5)
+
+
+@pytest.mark.parametrize("lazy", [False, True], ids=["deferred-views", "lazy-records"])
+def test_a_surface_written_since_the_trace_keeps_what_was_written(kernel_source, lazy):
+    """The recorded attributes of a traced optic are made on first read -- the plane views of
+    an eager trace (`_PendingViews`) as well as the re-run of a lazy one (`_PendingRecord`).
+    A surface somebody has WRITTEN in between (`Surface.reset()`, a reference-side
+    `_record_real`) is no longer part of that: the read that materialises the others must not
+    put the old trace back on it."""
+    be = kernel_source
+    from optiland_amd import integration as ig
+    lens, w = _lens("CookeTriplet")
+    ref_lens, _ = _lens("CookeTriplet")
+    ig.install(lens, force=True, lazy_records=lazy)
+    ig.install(ref_lens, force=True)
+    try:
+        for o in (lens, ref_lens):
+            o.trace(0.0, 0.7, w, 4, "hexapolar")
+        kind = ig._PendingRecord if lazy else ig._PendingViews
+        assert all(isinstance(ig._PENDING.get(s), kind) for s in lens.surfaces.surfaces)
+        marker = be.array([1.0, 2.0, 3.0])
+        lens.surfaces.surfaces[2].reset()                 # the reference's own reset
+        lens.surfaces.surfaces[3].x = marker              # a plain write
+        assert lens.surfaces.surfaces[2] not in ig._PENDING
+        got = _np(be, lens.surfaces.surfaces[4].y)        # first read: the others appear
+        np.testing.assert_array_equal(got, _np(be, ref_lens.surfaces.surfaces[4].y))
+        assert _np(be, lens.surfaces.surfaces[2].x).size == 0          # still reset
+        assert lens.surfaces.surfaces[3].x is marker                   # still the written value
+        if lazy:   # opt-in lazy records: a written surface has left the un-run trace
+            assert _np(be, lens.surfaces.surfaces[3].y).size == 0
+        else:      # default: exactly what an eager bind + the two writes would have left
+            np.testing.assert_array_equal(_np(be, lens.surfaces.surfaces[3].y),
+                                          _np(be, ref_lens.surfaces.surfaces[3].y))
+        assert not any(s in ig._PENDING for s in lens.surfaces.surfaces)
+    finally:
+        ig.uninstall(lens)
+        ig.uninstall(ref_lens)
