@@ -216,6 +216,19 @@ def _install_lazy_descriptors():
     if not isinstance(Surface.__dict__.get("x"), _RecordedPlane):
         for name in _RECORDED:
             setattr(Surface, name, _RecordedPlane(name))
+        # copies / pickles of a surface take its `__dict__` (standard_surface.py:90-94): views
+        # that only wait to be made are made first, so that the copy carries what an eager
+        # bind would have left on the original
+        orig = Surface.__getstate__
+        _ORIGINALS["surface_getstate"] = orig
+
+        def __getstate__(self):
+            pend = _PENDING.get(self) if _PENDING else None
+            if isinstance(pend, _PendingViews):
+                pend.materialize()
+            return orig(self)
+
+        Surface.__getstate__ = __getstate__
 
 
 def _remove_lazy_descriptors():
@@ -227,6 +240,9 @@ def _remove_lazy_descriptors():
     for name in _RECORDED:
         if isinstance(Surface.__dict__.get(name), _RecordedPlane):
             delattr(Surface, name)
+    orig = _ORIGINALS.pop("surface_getstate", None)
+    if orig is not None:
+        Surface.__getstate__ = orig
 
 
 class _LazyPrt:

@@ -180,3 +180,24 @@ def test_a_surface_written_since_the_trace_keeps_what_was_written(kernel_source,
     finally:
         ig.uninstall(lens)
         ig.uninstall(ref_lens)
+
+
+def test_copies_of_an_eagerly_traced_optic_carry_the_records(kernel_source):
+    """Default mode (views deferred): `copy.deepcopy(optic)` after a trace carries the recorded
+    arrays, as it did when the surfaces were bound inside the call (the reference's
+    `Surface.__getstate__`, standard_surface.py:90-94, is what copies go through)."""
+    be = kernel_source
+    from optiland_amd import integration as ig
+    lens, w = _lens("CookeTriplet")
+    ig.install(lens, force=True)
+    try:
+        lens.trace(0.0, 0.7, w, 4, "hexapolar")
+        assert isinstance(ig._PENDING.get(lens.surfaces.surfaces[2]), ig._PendingViews)
+        dup = copy.deepcopy(lens)
+        for k in PLANES:
+            a, b = _np(be, getattr(dup.surfaces, k)), _np(be, getattr(lens.surfaces, k))
+            assert a.shape == b.shape and a.shape[1] == 61
+            np.testing.assert_array_equal(a, b, k)
+        assert dup.surfaces.surfaces[2].x is not lens.surfaces.surfaces[2].x
+    finally:
+        ig.uninstall(lens)
