@@ -196,6 +196,8 @@ def _chief_init(self, optic, distribution, **kwargs):
         return _ORIG["chief_init"](self, optic, distribution, **kwargs)
     ReferenceStrategy.__init__(self, optic, distribution, **kwargs)  # optic, n_image, ...
     self.pupil_z = be.array([pupil_z])
+    self._hip_pupil_z = float(pupil_z)  # (host copy: spares `_fused_wavefront` a read-back)
+    self._hip_pupil_z_of = self.pupil_z
     self._chief_ray = None
     STATS["opd_init"] += 1
 
@@ -224,7 +226,9 @@ def _fused_wavefront(self, field, wavelength):
     c = torch.stack([t.reshape(-1)[0] for t in (chief.x, chief.y, chief.z, chief.L, chief.M,
                                                  chief.N, chief.opd)]).double().cpu().tolist()
     xc, yc, zc, Lc, Mc, Nc, opd_c = c
-    n_image = _f(self.n_image)
+    n_image = rg.get("n_image")  # packed at the primary wavelength, like strategy.py:57
+    if n_image is None:
+        n_image = _f(self.n_image)
     # strategy.py:83-139 _correct_tilt: AngleField with the object at infinity only
     ux = uy = 0.0
     if rg.get("object_infinite") and int(rg.get("field_kind", 0)) == 0:
@@ -239,7 +243,10 @@ def _fused_wavefront(self, field, wavelength):
         params.update(R=0.0, nx=Lc, ny=Mc, nz=Nc)
         t_back = 0.0
     else:                               # strategy.py:228-243
-        R = math.sqrt(xc * xc + yc * yc + (zc - _f(self.pupil_z)) ** 2)
+        pz = self.__dict__.get("_hip_pupil_z")
+        if pz is None or self.pupil_z is not self.__dict__.get("_hip_pupil_z_of"):
+            pz = _f(self.pupil_z)  # somebody replaced the attribute: read it
+        R = math.sqrt(xc * xc + yc * yc + (zc - pz) ** 2)
         params.update(R=R)
         a_ = Lc * Lc + Mc * Mc + Nc * Nc
         sq = math.sqrt(max(4.0 * a_ * R * R, 0.0))
