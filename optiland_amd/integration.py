@@ -323,10 +323,10 @@ class _PendingViews:
     of a small trace, and most callers read the returned rays only.  The views are made when
     somebody reads a recorded attribute of any surface of the optic."""
 
-    def __init__(self, optic, res):
+    def __init__(self, group, res):
         import weakref
 
-        self.optic = weakref.ref(optic)
+        self.group = weakref.ref(group)  # the SurfaceGroup whose surfaces[first..last] it binds
         self.res = res
         self.done = False
 
@@ -334,11 +334,11 @@ class _PendingViews:
         if self.done:
             return
         self.done = True
-        optic, res = self.optic(), self.res
+        group, res = self.group(), self.res
         self.res = None
-        if optic is None:
+        if group is None:
             return
-        surfaces = optic.surfaces.surfaces
+        surfaces = group.surfaces
         if len(surfaces) <= res.last:
             for s in surfaces:
                 if _PENDING.get(s) is self:
@@ -347,9 +347,9 @@ class _PendingViews:
         _bind_surfaces(surfaces, res, owner=self)
 
 
-def _mark_pending(optic, pend, dtype):
+def _mark_pending(surfaces, pend, dtype):
     empty = None
-    for surf in optic.surfaces.surfaces:
+    for surf in surfaces:
         d = surf.__dict__
         if empty is None:
             old = d.get("x")
@@ -360,10 +360,12 @@ def _mark_pending(optic, pend, dtype):
     return pend
 
 
-def register_pending_views(optic, res):
-    """Eager trace, views deferred (`_PendingViews`); same bookkeeping as a pending record."""
+def register_pending_views(group, res):
+    """Eager trace of `group.surfaces[res.first .. res.last]`, views deferred
+    (`_PendingViews`); same bookkeeping as a pending record."""
     _install_lazy_descriptors()
-    return _mark_pending(optic, _PendingViews(optic, res), res.record.dtype)
+    return _mark_pending(group.surfaces[res.first: res.last + 1], _PendingViews(group, res),
+                         res.record.dtype)
 
 
 def register_pending_record(optic, table, engine, dtype, launch):
@@ -371,7 +373,8 @@ def register_pending_record(optic, table, engine, dtype, launch):
     instance attributes are emptied first (as `Surface.reset()` leaves them), so a copy of
     the optic taken before anybody reads them sees a reset surface, never stale arrays."""
     _install_lazy_descriptors()
-    return _mark_pending(optic, _PendingRecord(optic, table, engine, dtype, launch), dtype)
+    return _mark_pending(optic.surfaces.surfaces,
+                         _PendingRecord(optic, table, engine, dtype, launch), dtype)
 
 
 def _make_tracer_class():
@@ -588,7 +591,7 @@ def _make_tracer_class():
                 register_pending_record(self.optic, table, front.engine, front.dtype,
                                         front.last_fused_launch)
             elif _DEFER_VIEWS:
-                register_pending_views(self.optic, res)
+                register_pending_views(self.optic.surfaces, res)
             else:
                 _bind_surfaces(self.optic.surfaces.surfaces, res, views)
             # the record block now lives exactly as long as the reference objects that view
@@ -818,9 +821,13 @@ def _sg_run(group, eng, rays, planes, first, last, polarized):
         else:
             prt = (p.real if p.is_complex() else p).t().to(dtype).contiguous()  # (9, n)
     res = eng.trace(planes, 0, record=True, prt=prt, first=first, last=last)
-    for s in range(first, last + 1):
-        surf = group.surfaces[s]
-        surf.x, surf.y, surf.z, surf.L, surf.M, surf.N, surf.intensity, surf.opd = res.rows(s)
+    if _DEFER_VIEWS:
+        register_pending_views(group, res)   # the traced surfaces' views: on first read
+    else:
+        for s in range(first, last + 1):
+            surf = group.surfaces[s]
+            surf.x, surf.y, surf.z, surf.L, surf.M, surf.N, surf.intensity, surf.opd = \
+                res.rows(s)
     pre = res.rows(last - 1)[3:6] if last > first else planes[3:6]
     if not (first == 0 and last == 0):  # an object surface alone interacts with nothing
         # the reference stores L0.. inside refract() / reflect(), i.e. AFTER localize():
@@ -886,6 +893,9 @@ def _hip_surface_group_trace(group, rays, skip):
         return None  # RealRays.update() ignores Jones matrices; keep that on the reference
     eng, table = _sg_engine(group, table, rays.x.device)
 
+    if _PENDING:   # what an earlier trace left pending is about to be overwritten by reset()
+        for surf in group.surfaces:
+            _PENDING.pop(surf, None)
     group.reset()
     s = skip
     while s < n_s:
