@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OL_ABI_VERSION 6
+#define OL_ABI_VERSION 7
 
 /* ---- error codes ------------------------------------------------------- */
 #define OL_OK 0
@@ -280,6 +280,16 @@ typedef struct ol_trace_extras {
    * zero-initialised struct) record every traced surface, as before.                    */
   int32_t record_first_surface;
   int32_t reserved_;
+  /* ABI 7, ol_trace_generate with a `prt` only.  PolarizedRays.update_intensity
+   * (rays/polarized_rays.py:68-133, what RealRayTracer.trace applies to a polarised bundle,
+   * raytrace/real_ray_tracer.py:112-113) as an EPILOGUE of the same launch: the intensity
+   * i0 |P E0|^2 of every ray from the polarisation ray-tracing matrix the kernel still holds
+   * in registers and the direction it generated the ray with -- instead of a second launch
+   * (ol_polarized_intensity) that reads the nine PRT planes, three direction planes and the
+   * intensity plane back.  `updated_intensity`: n values of the ray dtype (device), written;
+   * NULL (or a NULL state): no epilogue.  The PRT planes are written either way.        */
+  const ol_polarization_state* update_intensity_state;
+  void* updated_intensity;
 } ol_trace_extras;
 
 int ol_trace_ex(const ol_system* sys, ol_dtype dt, int64_t n_rays,
@@ -379,7 +389,8 @@ int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n,
  *             extras->record_first_surface says otherwise)
  *   rays_out  NULL, or 8 planes receiving the final state (what OL_TRACE_WRITE_RAYS writes)
  *   prt       NULL, or the 9- / 18-plane PRT buffer, WRITE-ONLY (starts from the identity)
- *   flags     OL_TRACE_PRT_COMPLEX only; extras: record_first_surface only (no spot slots) */
+ *   flags     OL_TRACE_PRT_COMPLEX only; extras: record_first_surface and (ABI 7) the
+ *             update_intensity epilogue of a polarised launch (no spot slots)          */
 int ol_trace_generate(const ol_system* sys, ol_dtype dt, int64_t n_rays,
                       const ol_raygen_params* p, const ol_raygen_inputs* in,
                       int32_t wavelength_index, void* record, int64_t record_stride,

@@ -73,7 +73,9 @@ RAYGEN_CHECK_FIELD, RAYGEN_CHECK_PUPIL, RAYGEN_PRESCALE_PUPIL = 0x1, 0x2, 0x4
 
 class TraceExtras(C.Structure):
     _fields_ = [("spot_slots", C.c_void_p), ("cx", C.c_double), ("cy", C.c_double),
-                ("record_first_surface", C.c_int32), ("reserved_", C.c_int32)]
+                ("record_first_surface", C.c_int32), ("reserved_", C.c_int32),
+                # ABI 7: update_intensity as an epilogue of ol_trace_generate
+                ("update_intensity_state", C.c_void_p), ("updated_intensity", C.c_void_p)]
 
 
 SPOT_SLOTS = 64
@@ -120,7 +122,7 @@ EXPORTS = (
 
 F32, F64 = 0, 1
 TUNE_RAYS_PER_THREAD, TUNE_COMPACT = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 OPD_MOMENTS = 12  # kOpdMoments / ol_trace_opd
 
 
@@ -199,7 +201,7 @@ def bind(lib, path: str = "?"):
     lib.ol_pupil_fill.restype = C.c_int
     lib.ol_pupil_fill.argtypes = [i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     have = lib.ol_abi_version()
-    if have == ABI_VERSION - 1 and os.environ.get("OPTILAND_HIP_ALLOW_ABI5") == "1":
+    if have == 5 and os.environ.get("OPTILAND_HIP_ALLOW_ABI5") == "1":
         # A/B runs against the round-2 library (tools/gpu_ab_r03.sh): ABI 5 lacks
         # ol_trace_generate and the record_first_surface extra; the engine takes the
         # two-launch path when the symbol is missing

@@ -74,9 +74,10 @@ __global__ __launch_bounds__(kBlock) void pol_intensity_kernel(int64_t n, const 
                                                                const T* __restrict__ k0y,
                                                                const T* __restrict__ k0z,
                                                                const T* __restrict__ i0,
-                                                               PolStateDev st, T* intensity,
+                                                               PolFields<T> fld, T* intensity,
                                                                uint32_t* status) {
-  const PolFields<T> fld(st);
+  // (the incident state's amplitudes are formed by the launcher: fp64 sin / cos on the device
+  // brought a private array -- LDS or scratch -- into this streaming kernel)
   uint32_t flag = 0;
   for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
        j += (int64_t)gridDim.x * kBlock) {
@@ -95,12 +96,13 @@ template <typename T>
 hipError_t launch_pol_intensity(int64_t n, const T* prt, bool prt_complex, const T* const k0[3],
                                 const T* i0, const PolStateDev& st, T* intensity,
                                 uint32_t* status, hipStream_t stream) {
+  const PolFields<T> fld(st);
   if (prt_complex)
     hipLaunchKernelGGL((pol_intensity_kernel<T, true>), dim3(grid_for(n)), dim3(kBlock), 0,
-                       stream, n, prt, k0[0], k0[1], k0[2], i0, st, intensity, status);
+                       stream, n, prt, k0[0], k0[1], k0[2], i0, fld, intensity, status);
   else
     hipLaunchKernelGGL((pol_intensity_kernel<T, false>), dim3(grid_for(n)), dim3(kBlock), 0,
-                       stream, n, prt, k0[0], k0[1], k0[2], i0, st, intensity, status);
+                       stream, n, prt, k0[0], k0[1], k0[2], i0, fld, intensity, status);
   return hipGetLastError();
 }
 

@@ -497,6 +497,15 @@ int do_trace_generate(const ol_system* sys, const DeviceTable<T>& tab, int64_t n
   a.wl = wl;
   a.flags = (flags & ol::kTracePrtComplex) | (prt ? ol::kTracePrtIdentity : 0u) |
             (rays_out ? ol::kTraceWriteRays : 0u);
+  if (extras && extras->updated_intensity && extras->update_intensity_state) {
+    if (!prt)
+      return fail(OL_EINVAL, "ol_trace_generate: the update_intensity epilogue needs a "
+                             "polarised launch (prt)");
+    const ol_polarization_state* ps = extras->update_intensity_state;
+    ol::PolStateDev st{ps->is_polarized, ps->Ex, ps->Ey, ps->phase_x, ps->phase_y};
+    a.pf = ol::PolFields<T>(st);
+    a.i_updated = static_cast<T*>(extras->updated_intensity);
+  }
   hipError_t e = ol::launch_trace_generate<T>(a, newton_family(sys, 0, sys->n_surf - 1), stream);
   if (e != hipSuccess) return fail(OL_EHIP, "trace launch failed: %s", hipGetErrorString(e));
   return OL_OK;

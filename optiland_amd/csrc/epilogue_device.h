@@ -11,57 +11,43 @@
 
 namespace ol {
 
-// field amplitudes of the incident state: E0 = Ex e^{i phx} s_hat + Ey e^{i phy} p_hat
-// (rays/polarization_state.py:29-56); an unpolarised state is the mean of the x and the y
-// state (polarized_rays.py:122-133)
-template <typename T>
-struct PolFields {
-  T ar[2], ai[2], br[2], bi[2];
-  int nf;
-  OL_DEV explicit PolFields(const PolStateDev& st) {
-    if (st.is_polarized) {
-      nf = 1;
-      ar[0] = (T)(st.Ex * cos(st.phase_x));
-      ai[0] = (T)(st.Ex * sin(st.phase_x));
-      br[0] = (T)(st.Ey * cos(st.phase_y));
-      bi[0] = (T)(st.Ey * sin(st.phase_y));
-      ar[1] = ai[1] = br[1] = bi[1] = T(0);
-    } else {
-      nf = 2;
-      ar[0] = T(1); ai[0] = T(0); br[0] = T(0); bi[0] = T(0);
-      ar[1] = T(0); ai[1] = T(0); br[1] = T(1); bi[1] = T(0);
-    }
-  }
-};
+// (PolFields<T>: trace_launch.h)
 
 // rays/polarized_rays.py:68-133, 204-233.  Real PRT (P): |P E0|^2 = |P Re E0|^2 +
 // |P Im E0|^2; complex PRT (CPLX: P + i Q): full complex product.  (kx, ky, kz): the
 // direction the ray was launched with; flag gets OL_STATUS_K_PARALLEL_X (:221-222).
+// One incident state E0 = (ar + i ai) s_hat + (br + i bi) p_hat:
+template <typename T, bool CPLX>
+OL_DEV T pol_state_term(T ar, T ai, T br, T bi, const T (&s)[3], const T (&p)[3],
+                        const T (&P)[9], const T (&Q)[9]) {
+  const T er[3] = {ar * s[0] + br * p[0], ar * s[1] + br * p[1], ar * s[2] + br * p[2]};
+  const T ei[3] = {ai * s[0] + bi * p[0], ai * s[1] + bi * p[1], ai * s[2] + bi * p[2]};
+  T acc = T(0);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    T vr = P[3 * a] * er[0] + P[3 * a + 1] * er[1] + P[3 * a + 2] * er[2];
+    T vi = P[3 * a] * ei[0] + P[3 * a + 1] * ei[1] + P[3 * a + 2] * ei[2];
+    if (CPLX) {
+      vr -= Q[3 * a] * ei[0] + Q[3 * a + 1] * ei[1] + Q[3 * a + 2] * ei[2];
+      vi += Q[3 * a] * er[0] + Q[3 * a + 1] * er[1] + Q[3 * a + 2] * er[2];
+    }
+    acc += vr * vr + vi * vi;
+  }
+  return acc;
+}
+
 template <typename T, bool CPLX>
 OL_DEV T pol_intensity_one(const PolFields<T>& f, T kx, T ky, T kz, const T (&P)[9],
                            const T (&Q)[9], T i0, uint32_t& flag) {
   // p = k x x_hat = (0, kz, -ky), normalised; s = p x k
   T nrm = sqrt(kz * kz + ky * ky);
   if (nrm == T(0)) flag |= 0x2u;  // OL_STATUS_K_PARALLEL_X
-  const T px = T(0), py = kz / nrm, pz = -ky / nrm;
-  const T sx = py * kz - pz * ky, sy = pz * kx - px * kz, sz = px * ky - py * kx;
-  T acc = T(0);
-  for (int k = 0; k < f.nf; ++k) {
-    const T er[3] = {f.ar[k] * sx + f.br[k] * px, f.ar[k] * sy + f.br[k] * py,
-                     f.ar[k] * sz + f.br[k] * pz};
-    const T ei[3] = {f.ai[k] * sx + f.bi[k] * px, f.ai[k] * sy + f.bi[k] * py,
-                     f.ai[k] * sz + f.bi[k] * pz};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      T vr = P[3 * a] * er[0] + P[3 * a + 1] * er[1] + P[3 * a + 2] * er[2];
-      T vi = P[3 * a] * ei[0] + P[3 * a + 1] * ei[1] + P[3 * a + 2] * ei[2];
-      if (CPLX) {
-        vr -= Q[3 * a] * ei[0] + Q[3 * a + 1] * ei[1] + Q[3 * a + 2] * ei[2];
-        vi += Q[3 * a] * er[0] + Q[3 * a + 1] * er[1] + Q[3 * a + 2] * er[2];
-      }
-      acc += vr * vr + vi * vi;
-    }
-  }
+  const T p[3] = {T(0), kz / nrm, -ky / nrm};
+  const T s[3] = {p[1] * kz - p[2] * ky, p[2] * kx - p[0] * kz, p[0] * ky - p[1] * kx};
+  // (the one or two incident states by CONSTANT index: a run-time index into the amplitude
+  // arrays sends them to LDS / scratch)
+  T acc = pol_state_term<T, CPLX>(f.ar[0], f.ai[0], f.br[0], f.bi[0], s, p, P, Q);
+  if (f.nf > 1) acc += pol_state_term<T, CPLX>(f.ar[1], f.ai[1], f.br[1], f.bi[1], s, p, P, Q);
   return acc * i0 / T(f.nf);
 }
 

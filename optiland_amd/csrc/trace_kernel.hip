@@ -426,9 +426,12 @@ struct WavesPerEu {
 // read from eight planes -- ol_trace_generate, the record-all path of Optic.trace() in one
 // launch: no separate generator launch, and the object row is written once instead of
 // written by one kernel and read back by the next.
-template <typename T, int RPT, bool RECORD, int POLK, int NR, bool SPOT, bool GEN = false>
+// EPI (GEN && POLK != 0 only): PolarizedRays.update_intensity as an epilogue of the launch --
+// an instantiation of its own, so that launches without it keep their register budget
+template <typename T, int RPT, bool RECORD, int POLK, int NR, bool SPOT, bool GEN = false,
+          bool EPI = false>
 __global__ __launch_bounds__(kTraceBlock)
-__attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN>::value))) void trace_kernel(
+__attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN || EPI>::value))) void trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
     const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
     TraceArgs<T> a) {
@@ -726,6 +729,40 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN>::value))) v
       store_plane<T, RPT>(late.prt + (int64_t)e * late.n, base, cnt, tmp);
     }
   }
+  if constexpr (EPI) {
+    static_assert(GEN && POLK != 0, "the update_intensity epilogue: generating polarised launches");
+    // PolarizedRays.update_intensity (rays/polarized_rays.py:68-133) of the traced bundle, from
+    // the matrix still in registers (ol_trace_extras.updated_intensity, ABI 7) -- instead of a
+    // second launch that reads nine PRT planes, three direction planes and the intensity
+    // plane back.  The launch direction is GENERATED again from the two pupil values (the
+    // same arithmetic on the same inputs: the same bits as row 0) rather than kept live
+    // through the surface loop; the initial intensity of a generated ray is 1.
+    const auto ka = kernargs<T, TraceArgs<T>>();
+    T* upd = ka->a.i_updated;
+    {
+      const auto& in_ = ka->a.in;
+      T px = base.at(in_.px)[0], py = base.at(in_.py)[0];
+      T vx = in_.vx0, vy = in_.vy0, o[6];
+      uint32_t again = 0;  // (range bits were raised by the prologue already)
+      raygen_pupil<T>(in_.flags, vx, vy, px, py, again);
+      const RaygenConsts<T> c = consts_of(&ka->a.rgc);
+      raygen_one<T>(c, in_.tx0, in_.ty0, px, py, vx, vy, o);
+      PolFields<T> f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        f.ar[k] = ka->a.pf.ar[k]; f.ai[k] = ka->a.pf.ai[k];
+        f.br[k] = ka->a.pf.br[k]; f.bi[k] = ka->a.pf.bi[k];
+      }
+      f.nf = ka->a.pf.nf;
+      T Pm[9], Qm[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        Pm[e] = P[0].m[e];
+        Qm[e] = POLK == 2 ? P[0].m[POLK == 2 ? 9 + e : e] : T(0);
+      }
+      base.at(upd)[0] = pol_intensity_one<T, POLK == 2>(f, o[3], o[4], o[5], Pm, Qm, T(1), status);
+    }
+  }
   if (status && late.status) atomicOr(late.status, status);
 }
 
@@ -809,12 +846,13 @@ static hipError_t launch_gen_nr(const TraceArgs<T>& a, hipStream_t stream) {
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)blocks), block(kTraceBlock);
   const int polk = a.prt == nullptr ? 0 : ((a.flags & kTracePrtComplex) ? 2 : 1);
-#define OL_LAUNCH_G(P)                                                                       \
-  hipLaunchKernelGGL((trace_kernel<T, 1, true, P, NR, false, true>), grid, block, 0, stream, \
-                     a.surf, a.cold, a.optics, a.coeffs, a)
-  if (polk == 2) OL_LAUNCH_G(2);
-  else if (polk == 1) OL_LAUNCH_G(1);
-  else OL_LAUNCH_G(0);
+#define OL_LAUNCH_G(P, E)                                                                    \
+  hipLaunchKernelGGL((trace_kernel<T, 1, true, P, NR, false, true, E>), grid, block, 0,      \
+                     stream, a.surf, a.cold, a.optics, a.coeffs, a)
+  const bool epi = polk != 0 && a.i_updated != nullptr;  // update_intensity epilogue (ABI 7)
+  if (polk == 2) { if (epi) OL_LAUNCH_G(2, true); else OL_LAUNCH_G(2, false); }
+  else if (polk == 1) { if (epi) OL_LAUNCH_G(1, true); else OL_LAUNCH_G(1, false); }
+  else OL_LAUNCH_G(0, false);
 #undef OL_LAUNCH_G
   return hipGetLastError();
 }

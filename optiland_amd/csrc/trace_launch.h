@@ -93,6 +93,35 @@ inline void uniform_field_tangents(const RaygenDev& rg, RaygenIn<T>& in) {
   }
 }
 
+struct PolStateDev {
+  int32_t is_polarized;
+  double Ex, Ey, phase_x, phase_y;
+};
+
+// field amplitudes of the incident state: E0 = Ex e^{i phx} s_hat + Ey e^{i phy} p_hat
+// (rays/polarization_state.py:29-56); an unpolarised state is the mean of the x and the y
+// state (polarized_rays.py:122-133).  Plain data: formed once per launch (host or device).
+template <typename T>
+struct PolFields {
+  T ar[2], ai[2], br[2], bi[2];
+  int32_t nf;
+  PolFields() = default;
+  OL_HD explicit PolFields(const PolStateDev& st) {
+    if (st.is_polarized) {
+      nf = 1;
+      ar[0] = (T)(st.Ex * cos(st.phase_x));
+      ai[0] = (T)(st.Ex * sin(st.phase_x));
+      br[0] = (T)(st.Ey * cos(st.phase_y));
+      bi[0] = (T)(st.Ey * sin(st.phase_y));
+      ar[1] = ai[1] = br[1] = bi[1] = T(0);
+    } else {
+      nf = 2;
+      ar[0] = T(1); ai[0] = T(0); br[0] = T(0); bi[0] = T(0);
+      ar[1] = T(0); ai[1] = T(0); br[1] = T(1); bi[1] = T(0);
+    }
+  }
+};
+
 template <typename T>
 struct TraceArgs {
   const DevSurfHot<T>* surf;   // [n_surf] hot blocks
@@ -116,6 +145,10 @@ struct TraceArgs {
   // coordinates and the generator constants instead of rays[]
   RaygenIn<T> in;
   RaygenConsts<T> rgc;
+  // generating polarised launches: PolarizedRays.update_intensity as an epilogue of the same
+  // kernel (ol_trace_extras.updated_intensity, ABI 7); nullptr = none
+  T* i_updated;
+  PolFields<T> pf;
 };
 
 // nr_family: 0 = no Newton-Raphson geometry in the traced range (lean kernel), 1 = generic
@@ -156,11 +189,6 @@ struct SpotArgs {
 template <typename T>
 hipError_t launch_spot_trace(const SpotArgs<T>& a, bool vector_ok, int nr_family,
                              hipStream_t stream);
-
-struct PolStateDev {
-  int32_t is_polarized;
-  double Ex, Ey, phase_x, phase_y;
-};
 
 template <typename T>
 hipError_t launch_pol_intensity(int64_t n, const T* prt, bool prt_complex, const T* const k0[3],

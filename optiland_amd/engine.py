@@ -42,11 +42,12 @@ def _stream_ptr(device) -> int:
 class TraceResult:
     """Outputs of one launch.  `record` is (rows, 8, stride) with [:, :, :n] valid."""
 
-    __slots__ = ("n", "rays", "record", "prt", "status", "first", "last")
+    __slots__ = ("n", "rays", "record", "prt", "status", "first", "last", "updated_intensity")
 
     def __init__(self, n, rays, record, prt, status, first, last):
         self.n, self.rays, self.record, self.prt = n, rays, record, prt
         self.status, self.first, self.last = status, first, last
+        self.updated_intensity = None  # ol_trace_generate's update_intensity epilogue (ABI 7)
 
     def row(self, s: int, plane: str | int) -> torch.Tensor:
         k = PLANES.index(plane) if isinstance(plane, str) else plane
@@ -268,13 +269,16 @@ class HipSystem:
     def trace_generate(self, px, py, wavelength_index: int = 0, *, field, vig=(1.0, 1.0),
                        record=True, record_first: int = 0, prt: torch.Tensor | None = None,
                        rays_out=None, flags: int = 0, zero_status: bool = True,
-                       defer_status: bool = False) -> TraceResult:
+                       defer_status: bool = False, update_intensity=None) -> TraceResult:
         """`ol_trace_generate`: rays of ONE field point generated from the normalised pupil
         planes and traced through the whole system in one launch.  record: True (allocate)
         or a preallocated (rows, 8, stride) block; rows start at surface `record_first`
         (0 = the generated rays themselves as the object row).  prt: write-only (9 | 18, n)
         buffer of a polarised trace.  rays_out: optional 8 planes for the final state.
         flags: `_capi.RAYGEN_*` (pupil range check, trace_generic pre-scaling).
+        update_intensity: polarisation state dict (`is_polarized`, `Ex`, `Ey`, `phase_x`,
+        `phase_y`) -- with a `prt`, `PolarizedRays.update_intensity` runs as an epilogue of the
+        same launch and the result carries `updated_intensity` (n values).
         The result's `rays` are the planes of record row 0 when that row is recorded."""
         p = self._raygen_params()
         n = int(px.numel())
@@ -312,7 +316,19 @@ class HipSystem:
         if rays_out is not None:
             self._check_out_planes(list(rays_out), n, dtype, "trace_generate")
             outp = (C.c_void_p * 8)(*[t.data_ptr() for t in rays_out])
-        extras = C.byref(_capi.TraceExtras(None, 0.0, 0.0, record_first, 0))
+        ex = _capi.TraceExtras(None, 0.0, 0.0, record_first, 0, None, None)
+        if update_intensity is not None and prt is not None and self.can_fuse_update_intensity():
+            pol = update_intensity
+            if pol.get("is_polarized"):
+                st = _capi.PolarizationStateC(1, 0, pol["Ex"], pol["Ey"], pol["phase_x"],
+                                              pol["phase_y"])
+            else:
+                st = _capi.PolarizationStateC(0, 0, 0.0, 0.0, 0.0, 0.0)
+            res.updated_intensity = torch.empty(n, dtype=dtype, device=self.device)
+            keep.append(st)
+            ex.update_intensity_state = C.addressof(st)
+            ex.updated_intensity = res.updated_intensity.data_ptr()
+        extras = C.byref(ex)
         if zero_status:
             self._status.zero_()
         with self._device_ctx():
@@ -339,6 +355,15 @@ class HipSystem:
         torch.sum(slots[:, :6], dim=0, out=out[:6])
         torch.amax(slots[:, 6], dim=0, out=out[6])
         return out
+
+    def can_fuse_update_intensity(self) -> bool:
+        """The library runs `update_intensity` inside `ol_trace_generate` (ABI >= 7)."""
+        ok = getattr(self, "_abi7", None)
+        if ok is None:
+            ok = self._abi7 = bool(hasattr(self.lib, "ol_trace_generate")
+                                   and self.lib.ol_abi_version() >= 7
+                                   and os.environ.get("OPTILAND_HIP_FUSE_INTENSITY", "1") != "0")
+        return ok
 
     def row0_planes(self, record: torch.Tensor, n: int):
         """The 8 planes of record row 0 as ray planes (zero-copy object row)."""

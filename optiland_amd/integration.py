@@ -583,7 +583,8 @@ def _make_tracer_class():
             if polarized and update_intensity:
                 # (the state as packed: the change detector covers the live object, and reading
                 # it again would be four blocking read-backs in front of the epilogue launch)
-                out.i = front.engine.polarized_intensity(
+                fused = getattr(mine, "_i_updated", None)  # epilogue of the trace launch
+                out.i = fused if fused is not None else front.engine.polarized_intensity(
                     mine._prt, (mine._L0, mine._M0, mine._N0), mine._i0, table.polarization)
             if before_commit is not None:
                 before_commit()
@@ -697,7 +698,7 @@ def _make_tracer_class():
             hx, hy = _host_or_device(Hx), _host_or_device(Hy)
             return self._run(wavelength,
                              lambda front: front.trace(hx, hy, wavelength, num_rays, dist,
-                                                       update_intensity=False),
+                                                       update_intensity="defer"),
                              True, original)
 
         def trace_generic(self, Hx, Hy, Px, Py, wavelength):

@@ -294,9 +294,15 @@ class HipRayTracer:
         if polarized:
             prt = torch.empty((18 if self._complex_prt else 9, n), dtype=self.dtype,
                               device=self.device)  # written by the kernel (starts from I)
+        # polarised Optic.trace: update_intensity as an epilogue of the same launch
+        fuse = None
+        if polarized and update_intensity and getattr(eng, "can_fuse_update_intensity",
+                                                      lambda: False)():
+            fuse = _state_dict(self.table.polarization)
+        kw = {} if fuse is None else {"update_intensity": fuse}
         res = eng.trace_generate(px, py, wl, field=(hx, hy), vig=vig, record=True,
                                  record_first=first_row, prt=prt, flags=flags,
-                                 defer_status=True)
+                                 defer_status=True, **kw)
         if not self.defer_checks:
             self._finish_checks(eng)
         k_init = i0 = None
@@ -359,8 +365,16 @@ class HipRayTracer:
         self._last_res = res
         if prt is not None:
             out = PolarizedRays(*fin[:7], w, fin[7], engine=eng, prt=prt, i0=i0, k_init=k_init)
-            if update_intensity:  # real_ray_tracer.py:112-113 -- trace() only
-                out.update_intensity(_state_dict(self.table.polarization))
+            # real_ray_tracer.py:112-113 -- trace() only.  `update_intensity == "defer"`: the
+            # caller places the epilogue itself (integration._finish, after the final
+            # propagation) and takes `_i_updated` when the launch already produced it
+            fused = getattr(res, "updated_intensity", None)
+            out._i_updated = fused
+            if update_intensity is True:
+                if fused is not None:
+                    out.i = fused
+                else:
+                    out.update_intensity(_state_dict(self.table.polarization))
         else:
             out = RealRays(*fin[:7], w, fin[7])
         # pre-interaction cosines at the last surface = directions recorded on the

@@ -186,6 +186,26 @@ static hipError_t gen_nr(const TraceArgs<T>& a) {
   if (polk == 2) trace_all<T, 2, NR, true>(a);
   else if (polk == 1) trace_all<T, 1, NR, true>(a);
   else trace_all<T, 0, NR, true>(a);
+  if (polk != 0 && a.i_updated != nullptr) {
+    // the update_intensity epilogue of the generating launch (trace_kernel.hip, ABI 7): the
+    // device takes the matrix from its registers and regenerates the launch direction; here
+    // both are read back from what the launch wrote (PRT planes, row 0 of the record)
+    uint32_t flag = 0;
+    for (int64_t j = 0; j < a.n; ++j) {
+      T P[9], Q[9];
+      for (int e = 0; e < 9; ++e) {
+        P[e] = a.prt[(int64_t)e * a.n + j];
+        Q[e] = polk == 2 ? a.prt[(int64_t)(9 + e) * a.n + j] : T(0);
+      }
+      const T* row0 = a.record;
+      const T kx = row0[3 * a.record_stride + j], ky = row0[4 * a.record_stride + j],
+              kz = row0[5 * a.record_stride + j];
+      a.i_updated[j] = polk == 2
+                           ? pol_intensity_one<T, true>(a.pf, kx, ky, kz, P, Q, T(1), flag)
+                           : pol_intensity_one<T, false>(a.pf, kx, ky, kz, P, Q, T(1), flag);
+    }
+    if (flag && a.status) *a.status |= flag;
+  }
   return hipSuccess;
 }
 template <typename T>

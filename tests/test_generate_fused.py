@@ -174,3 +174,54 @@ def test_tracer_fused_and_two_launch_paths_agree(name, where):
                 assert a.surfaces.x.numel() == 0
     finally:
         eng.close()
+
+
+STATES = [
+    {"is_polarized": False},
+    {"is_polarized": True, "Ex": 1.0, "Ey": 0.0, "phase_x": 0.0, "phase_y": 0.0},
+    {"is_polarized": True, "Ex": 0.6, "Ey": 0.8, "phase_x": 0.3, "phase_y": -1.1},
+]
+
+
+@pytest.mark.parametrize("where", WHERE)
+@pytest.mark.parametrize("case", ["zernike_fresnel_fringe", "zernike_fresnel_polarized",
+                                  "polarizer_retarder", "polarizer_only",
+                                  "coated_mirror_polarised", "fuzz_03", "fuzz_05"])
+def test_update_intensity_epilogue_of_the_generating_launch(case, where):
+    """ABI 7: `ol_trace_extras.updated_intensity` -- `PolarizedRays.update_intensity`
+    (rays/polarized_rays.py:68-133) inside `ol_trace_generate`, from the matrix in registers
+    and the regenerated launch direction -- equals `ol_polarized_intensity` on what the same
+    launch wrote (PRT planes, row 0 of the record): same device function, same inputs.  Real
+    and complex (retarder) matrices, unpolarised / linear / elliptical states, both dtypes;
+    the PRT planes and the record are those of a launch without the epilogue."""
+    table, _ = load_case(case)
+    if not table.raygen or table.polarization is None:
+        pytest.skip("not a polarised case with generator scalars")
+    eng, dev = _engine(table, where)
+    try:
+        if not eng.can_trace_generate() or not eng.can_fuse_update_intensity():
+            pytest.skip("library without the fused epilogue")
+        for dtype in (torch.float64, torch.float32):
+            n = 777
+            px, py = _pupil(n, dtype, dev, 21)
+            cplx = 18 if table.needs_complex_prt else 9
+            for st in STATES:
+                prt0 = torch.empty((cplx, n), dtype=dtype, device=dev)
+                plain = eng.trace_generate(px, py, 0, field=(0.0, 0.6), prt=prt0)
+                assert plain.updated_intensity is None
+                prt1 = torch.empty((cplx, n), dtype=dtype, device=dev)
+                fused = eng.trace_generate(px, py, 0, field=(0.0, 0.6), prt=prt1,
+                                           update_intensity=st)
+                assert fused.updated_intensity is not None
+                np.testing.assert_array_equal(prt1.cpu().numpy(), prt0.cpu().numpy())
+                np.testing.assert_array_equal(fused.record[:, :, :n].cpu().numpy(),
+                                              plain.record[:, :, :n].cpu().numpy())
+                r0 = plain.rows(0)
+                want = eng.polarized_intensity(prt0, (r0[3], r0[4], r0[5]), r0[6], st)
+                got = fused.updated_intensity
+                a, b = got.cpu().numpy(), want.cpu().numpy()
+                assert np.array_equal(np.isnan(a), np.isnan(b))
+                tol = 1e-13 if dtype == torch.float64 else 2e-6
+                np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
+    finally:
+        eng.close()
