@@ -33,6 +33,7 @@ TAGS = {  # tag -> traffic key
     "r03_dg_f32_gen": "double_gauss:f32:gen",
     "r03_zf_f32_gen": "zernike_fresnel:f32:gen",
     "r03_rc_f32_gen": "rc_asphere:f32:gen",
+    "r03_dg_f64_gen": "double_gauss:f64:gen",
     "r03_zf_f64": "zernike_fresnel:f64:record:alias",
     "r03_rc_f64": "rc_asphere:f64:record:alias",
     "r03_z_opd": "zernike:f64:opd",
@@ -91,7 +92,7 @@ def main():
         open(os.path.join(PROF, f"{ROUND}_{name}_rocprof.txt"), "w").write("\n".join(lines) + "\n")
         print("\n".join(lines[:4]))
     json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
-    bd = os.path.join(OUT, "bench_default.json")
+    bd = os.path.join(OUT, f"{ROUND}_bench_default.json")
     if os.path.exists(bd):
         open(os.path.join(PROF, f"{ROUND}_bench_default.json"), "w").write(open(bd).read())
 
