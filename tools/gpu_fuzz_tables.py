@@ -18,7 +18,7 @@ from optiland_amd.system import SystemTable  # noqa: E402
 
 DEV = "cuda:0"
 worst = {torch.float64: 0.0, torch.float32: 0.0}
-over, checked, flagged, fused = [], 0, 0, 0
+over, checked, flagged, fused, epilogues = [], 0, 0, 0, 0
 for path in sorted(glob.glob(os.path.join(ROOT, "fuzz_tables", "*.json"))):
     table = SystemTable.load(path)
     seed = int(os.path.basename(path)[5:9])
@@ -69,6 +69,22 @@ for path in sorted(glob.glob(os.path.join(ROOT, "fuzz_tables", "*.json"))):
                     same = (prt2 == prt1) | (torch.isnan(prt2) & torch.isnan(prt1))
                     assert bool(same.all()), (path, str(dtype), "fused generation: PRT differs")
                 fused += 1
+                if pol and hip.can_fuse_update_intensity():
+                    # ABI 7: update_intensity as an epilogue of the generating launch against
+                    # ol_polarized_intensity on what the same launch wrote
+                    st = dict(table.polarization)
+                    prt3 = torch.empty_like(prt)
+                    ep = hip.trace_generate(f(px), f(py), 0, field=fld, prt=prt3,
+                                            update_intensity=st)
+                    r0 = gen.rows(0)
+                    want_i = hip.polarized_intensity(prt2, (r0[3], r0[4], r0[5]), r0[6], st)
+                    a_, b_ = ep.updated_intensity, want_i
+                    assert bool((torch.isnan(a_) == torch.isnan(b_)).all()), (path, "epilogue NaNs")
+                    t_ = 1e-13 if dtype == torch.float64 else 2e-6
+                    d_ = torch.nan_to_num(a_ - b_).abs().max().item()
+                    m_ = max(1.0, torch.nan_to_num(b_).abs().max().item())
+                    assert d_ <= t_ * m_, (path, str(dtype), "fused update_intensity", d_)
+                    epilogues += 1
         finally:
             hip.close()
         rec = want["record"]
@@ -95,7 +111,8 @@ for path in sorted(glob.glob(os.path.join(ROOT, "fuzz_tables", "*.json"))):
             over.append((os.path.basename(path), str(dtype), err, float(ok.mean())))
         checked += 1
 print(f"checked {checked} (table, dtype) pairs, {flagged} range-flagged on both sides; "
-      f"{fused} of them also through ol_trace_generate (bit-identical records)")
+      f"{fused} of them also through ol_trace_generate (bit-identical records), {epilogues} "
+      f"with the update_intensity epilogue against ol_polarized_intensity")
 print("worst fp64 margin %.3e   worst fp32 margin %.3e" % (worst[torch.float64], worst[torch.float32]))
 print("over the contract:", len(over))
 for o in over[:20]:
