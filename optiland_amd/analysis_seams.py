@@ -104,6 +104,15 @@ def _image_hits(optic, field, wavelength, num_rays, distribution):
     return front, table, mom.cpu().numpy(), hits
 
 
+def _spot_generate_data(self):
+    """analysis/spot_diagram/core.py:420-438: the fields x wavelengths loop -- nothing inside it
+    edits the optic, so its tables are validated once per wavelength (`integration.unchanged`)."""
+    from . import integration as ig
+
+    with ig.unchanged(self.optic):
+        return _ORIG["spot_data"](self)
+
+
 # ------------------------------------------------------------------------------- spot
 def _spot_generate_field_data(self, field, wavelength, num_rays, distribution, coordinates):
     out = None
@@ -344,12 +353,13 @@ def enable():
     from optiland.psf.fft import ScalarFFTPSF
     from optiland.wavefront.strategy import ChiefRayStrategy
 
-    _ORIG.update(spot=SpotDiagram._generate_field_data,
+    _ORIG.update(spot=SpotDiagram._generate_field_data, spot_data=SpotDiagram._generate_data,
                  ee=EncircledEnergy._generate_field_data,
                  opd=ChiefRayStrategy.compute_wavefront_data,
                  chief_init=ChiefRayStrategy.__init__,
                  pupils=ScalarFFTPSF._generate_pupils, pad=ScalarFFTPSF._pad_pupils)
     SpotDiagram._generate_field_data = _spot_generate_field_data
+    SpotDiagram._generate_data = _spot_generate_data
     EncircledEnergy._generate_field_data = _ee_generate_field_data
     ChiefRayStrategy.compute_wavefront_data = _chief_compute_wavefront_data
     ChiefRayStrategy.__init__ = _chief_init
@@ -366,6 +376,7 @@ def disable():
     from optiland.wavefront.strategy import ChiefRayStrategy
 
     SpotDiagram._generate_field_data = _ORIG["spot"]
+    SpotDiagram._generate_data = _ORIG["spot_data"]
     EncircledEnergy._generate_field_data = _ORIG["ee"]
     ChiefRayStrategy.compute_wavefront_data = _ORIG["opd"]
     ChiefRayStrategy.__init__ = _ORIG["chief_init"]

@@ -31,6 +31,7 @@ installed (e.g. the GPU test box).
 from __future__ import annotations
 
 import collections
+import contextlib
 import os
 
 import numpy as np
@@ -420,6 +421,10 @@ def _make_tracer_class():
             self.speculative_hits = 0    # launches queued before the change check, kept
             self.speculative_misses = 0  # ... dropped because the optic had changed
             self._hip_spec_ok = True     # False right after a miss: validate before launching
+            # inside `unchanged(optic)`: wavelengths whose table was validated in the scope --
+            # their change check is not repeated until the scope ends (None: no scope)
+            self._hip_trusted = None
+            self._hip_trust_depth = 0
             self.last_path = None  # "hip" | "reference" (introspection for tests)
 
         def __deepcopy__(self, memo):
@@ -465,6 +470,16 @@ def _make_tracer_class():
             change-detector token if the caller has just taken it."""
             w = float(wavelength.item()) if hasattr(wavelength, "item") else float(wavelength)
             _keep = None
+            trusted = self._hip_trusted
+            if trusted is not None and tok is None and w in trusted:
+                memo = self._hip_memo.get(w)  # validated earlier in this `unchanged` scope
+                hit = self._hip_engines.get(memo[2]) if memo is not None \
+                    and not isinstance(memo[2], UnsupportedSystem) else None
+                if hit is not None:
+                    self._hip_engine, self._hip_table = hit[0], hit[1]
+                    return hit
+            if trusted is not None:
+                trusted.add(w)
             if _fp.ENABLED:
                 if tok is None:
                     tok, _keep = _fp.optic_token(self.optic, w)
@@ -947,6 +962,28 @@ def _companion(rt):
     comp._hip_lazy = _ENABLE["lazy"]
     comp.ray_aiming_config = rt.ray_aiming_config
     return comp
+
+
+@contextlib.contextmanager
+def unchanged(optic):
+    """Scope in which `optic` is known not to be edited -- a loop of the reference that only
+    traces (`SpotDiagram._generate_data`: fields x wavelengths).  The change detector validates
+    each wavelength's table once inside the scope and its verdict stands until the scope ends
+    (9 token walks of a 3 x 3 spot diagram become 3).  No effect on optics the drop-in does not
+    serve."""
+    comp = hip_tracer_of(optic)
+    if comp is None:
+        yield
+        return
+    if comp._hip_trust_depth == 0:
+        comp._hip_trusted = set()
+    comp._hip_trust_depth += 1
+    try:
+        yield
+    finally:
+        comp._hip_trust_depth -= 1
+        if comp._hip_trust_depth == 0:
+            comp._hip_trusted = None
 
 
 def hip_tracer_of(optic):

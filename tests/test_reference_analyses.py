@@ -290,3 +290,38 @@ def test_seams_are_inert_without_the_drop_in(hip_on_cpu):
     integration.uninstall(lens)
     analysis_seams.disable()
     assert SpotDiagram._generate_field_data is orig
+
+
+def test_spot_diagram_validates_each_wavelength_once(seams, monkeypatch):
+    """`SpotDiagram._generate_data` (core.py:420-438) traces fields x wavelengths and edits
+    nothing: inside `integration.unchanged(optic)` the change detector runs once per
+    wavelength, not once per (field, wavelength) -- and again on the next analysis."""
+    be, stats = seams
+    from optiland import analysis
+    from optiland_amd import fingerprint as fp
+    from optiland_amd import integration as ig
+    lens = _cooke()                                  # 3 fields x 3 wavelengths
+    walks = {"n": 0}
+    orig = fp.optic_token
+
+    def counting(*a, **k):
+        walks["n"] += 1
+        return orig(*a, **k)
+
+    monkeypatch.setattr(fp, "optic_token", counting)
+    analysis.SpotDiagram(lens, num_rings=3)
+    first = walks["n"]
+    n_w = len(lens.wavelengths.wavelengths)
+    assert stats["spot"] == 3 * n_w
+    walks["n"] = 0
+    analysis.SpotDiagram(lens, num_rings=3)
+    assert walks["n"] == n_w, (first, walks["n"])     # validated again, once per wavelength
+    comp = ig.hip_tracer_of(lens)
+    assert comp._hip_trusted is None and comp._hip_trust_depth == 0
+    # an edit between two analyses is seen
+    before = [[float(_np(be, v)) for v in f]
+              for f in analysis.SpotDiagram(lens, num_rings=3).rms_spot_radius()]
+    lens.updater.set_radius(float(lens.surfaces[1].geometry.radius) * 1.05, 1)
+    after = [[float(_np(be, v)) for v in f]
+             for f in analysis.SpotDiagram(lens, num_rings=3).rms_spot_radius()]
+    assert abs(after[0][0] - before[0][0]) > 1e-6 * abs(before[0][0])
