@@ -113,6 +113,14 @@ def _spot_generate_data(self):
         return _ORIG["spot_data"](self)
 
 
+def _wavefront_generate_data(self):
+    """wavefront/wavefront.py:161-176: the same kind of loop (chief-ray traces + OPD launches)."""
+    from . import integration as ig
+
+    with ig.unchanged(self.optic):
+        return _ORIG["wavefront_data"](self)
+
+
 # ------------------------------------------------------------------------------- spot
 def _spot_generate_field_data(self, field, wavelength, num_rays, distribution, coordinates):
     out = None
@@ -352,7 +360,10 @@ def enable():
     from optiland.analysis.spot_diagram.core import SpotDiagram
     from optiland.psf.fft import ScalarFFTPSF
     from optiland.wavefront.strategy import ChiefRayStrategy
+    from optiland.wavefront.wavefront import Wavefront
 
+    _ORIG.update(wavefront_data=Wavefront._generate_data)
+    Wavefront._generate_data = _wavefront_generate_data
     _ORIG.update(spot=SpotDiagram._generate_field_data, spot_data=SpotDiagram._generate_data,
                  ee=EncircledEnergy._generate_field_data,
                  opd=ChiefRayStrategy.compute_wavefront_data,
@@ -377,6 +388,9 @@ def disable():
 
     SpotDiagram._generate_field_data = _ORIG["spot"]
     SpotDiagram._generate_data = _ORIG["spot_data"]
+    from optiland.wavefront.wavefront import Wavefront
+
+    Wavefront._generate_data = _ORIG["wavefront_data"]
     EncircledEnergy._generate_field_data = _ORIG["ee"]
     ChiefRayStrategy.compute_wavefront_data = _ORIG["opd"]
     ChiefRayStrategy.__init__ = _ORIG["chief_init"]

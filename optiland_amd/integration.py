@@ -664,7 +664,13 @@ def _make_tracer_class():
                     err = exc
                 finally:
                     front.defer_checks = False
-                tok, _keep = _fp.optic_token(self.optic, w)
+                trusted = self._hip_trusted
+                if trusted is not None and w in trusted:
+                    tok = tok0          # validated earlier in this `unchanged` scope
+                else:
+                    tok, _keep = _fp.optic_token(self.optic, w)
+                    if trusted is not None and tok == tok0:
+                        trusted.add(w)
                 if tok == tok0:
                     self.speculative_hits += 1
                     self._hip_engine, self._hip_table = front.engine, table
