@@ -145,6 +145,18 @@ def test_distributions_match_reference_counts_and_order():
         assert np.array_equal(d.y, np.concatenate(ys)), rings
 
 
+def test_uniform_sampler_is_the_masked_meshgrid():
+    """distribution.py:161-186 (`UniformDistribution`): the row-by-row sampler gives the
+    masked n x n meshgrid, value for value and in its order."""
+    from optiland_amd.distribution import create_distribution
+    for n in (1, 2, 3, 4, 5, 8, 24, 25, 64, 101, 300):
+        g = np.linspace(-1.0, 1.0, n)
+        x, y = np.meshgrid(g, g)
+        keep = x**2 + y**2 <= 1
+        d = create_distribution("uniform").generate_points(n)
+        assert np.array_equal(d.x, x[keep]) and np.array_equal(d.y, y[keep]), n
+
+
 def test_pupil_planes_are_shared_between_tracers_of_a_process():
     """A spot diagram over three wavelengths runs on three tracers: the deterministic pupil
     planes are sampled and uploaded once (`tracer._shared_pupil_planes`); stochastic samplers
