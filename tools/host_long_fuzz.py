@@ -70,6 +70,16 @@ for seed in range(lo,hi):
                 why = "reference PRT noise at an equal-index surface"
             else:
                 why = "UNKNOWN"
+                # the first surface whose record deviates: a near-parabolic conic there is the
+                # cancelling-root kind even when rays further down clip differently
+                with np.errstate(invalid="ignore"):
+                    dev = np.nan_to_num(np.abs(got - want["record"])
+                                        / np.maximum(1.0, np.abs(want["record"])))
+                rows = np.nonzero(dev.reshape(dev.shape[0], -1).max(axis=1) > 1e-10)[0]
+                if rows.size and sk["geom_kind"][rows[0]] == 1 \
+                        and abs(float(sk["conic"][rows[0]]) + 1.0) < 0.6 \
+                        and float(dev.max()) < 1e-4:
+                    why = "cancelling reference root (|1 + k N^2| small)"
             bad.append((seed, kind, why, msg[:120].replace("\n", " ")))
 print("seeds",lo,hi,"bad",len(bad),"time",time.time()-t0)
 import collections
