@@ -225,3 +225,29 @@ def test_update_intensity_epilogue_of_the_generating_launch(case, where):
                 np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
     finally:
         eng.close()
+
+
+def test_update_intensity_epilogue_is_refused_without_a_prt():
+    """C ABI, host build: `ol_trace_extras.updated_intensity` on an unpolarised launch is an
+    argument error (OL_EINVAL with a message), not something silently ignored."""
+    import ctypes as C
+    from tests import _hostmath as hm
+    if not hm.available():
+        pytest.skip("hipcc (used as host C++ compiler) missing")
+    eng = hm.make_engine_class()(load_system("double_gauss"))
+    try:
+        n = 16
+        px, py = _pupil(n, torch.float64, "cpu", 3)
+        rec = eng.alloc_record(n, torch.float64)
+        out = torch.empty(n, dtype=torch.float64)
+        st = _capi.PolarizationStateC(0, 0, 0.0, 0.0, 0.0, 0.0)
+        ex = _capi.TraceExtras(None, 0.0, 0.0, 0, 0, C.addressof(st), out.data_ptr())
+        p = eng._raygen_params()
+        inp, keep = eng._raygen_inputs(0.0, 0.5, px, py, 1.0, 1.0, 0)
+        rc = eng.lib.ol_trace_generate(eng._handle, 1, n, C.byref(p), C.byref(inp), 0,
+                                       rec.data_ptr(), int(rec.shape[2]), None, None, 0,
+                                       eng._status.data_ptr(), C.byref(ex), None)
+        assert rc == -1  # OL_EINVAL
+        assert b"polarised launch" in eng.lib.ol_last_error()
+    finally:
+        eng.close()
