@@ -42,12 +42,24 @@ def _stream_ptr(device) -> int:
 class TraceResult:
     """Outputs of one launch.  `record` is (rows, 8, stride) with [:, :, :n] valid."""
 
-    __slots__ = ("n", "rays", "record", "prt", "status", "first", "last", "updated_intensity")
+    __slots__ = ("n", "_rays", "record", "prt", "status", "first", "last", "updated_intensity")
 
     def __init__(self, n, rays, record, prt, status, first, last):
-        self.n, self.rays, self.record, self.prt = n, rays, record, prt
+        self.n, self._rays, self.record, self.prt = n, rays, record, prt
         self.status, self.first, self.last = status, first, last
         self.updated_intensity = None  # ol_trace_generate's update_intensity epilogue (ABI 7)
+
+    @property
+    def rays(self):
+        """The eight ray planes of the launch; for a generating launch that recorded row 0,
+        the planes of that row (made when asked for)."""
+        if self._rays is None and self.record is not None and self.first == 0:
+            self._rays = list(self.record[0, :, : self.n].unbind(0))
+        return self._rays
+
+    @rays.setter
+    def rays(self, value):
+        self._rays = value
 
     def row(self, s: int, plane: str | int) -> torch.Tensor:
         k = PLANES.index(plane) if isinstance(plane, str) else plane
@@ -306,8 +318,7 @@ class HipSystem:
                                  "[real + imaginary] tensor of the ray dtype")
             if prt.shape[0] == 18:
                 tflags |= S.TRACE_PRT_COMPLEX
-        rays0 = list(rec[0, :, :n].unbind(0)) if record_first == 0 else None
-        res = TraceResult(n, rays0, rec, prt, 0, record_first, last)
+        res = TraceResult(n, None, rec, prt, 0, record_first, last)  # .rays: row 0, on demand
         if n == 0:
             return res
         inp, keep = self._raygen_inputs(float(field[0]), float(field[1]), px, py,
