@@ -225,9 +225,20 @@ def _install_lazy_descriptors():
 
         def __getstate__(self):
             pend = _PENDING.get(self) if _PENDING else None
-            if isinstance(pend, _PendingViews):
+            if pend is not None:
+                # views that only wait to be made are made; a lazy record that has not been
+                # run is run: the copy carries what `Surface._record_real` would have left
                 pend.materialize()
-            return orig(self)
+            state = orig(self)
+            # the recorded vectors are VIEWS of one record block: torch pickles / deep-copies
+            # the whole storage behind every view (8 x (S+1) copies of the block).  The copy
+            # gets what the reference's own `_record_real` would have left: one array each
+            for name in _RECORDED + ("u", "aoi"):
+                t = state.get(name)
+                if isinstance(t, torch.Tensor) and t.numel() * t.element_size() \
+                        < t.untyped_storage().nbytes():
+                    state[name] = t.clone()
+            return state
 
         Surface.__getstate__ = __getstate__
 
@@ -254,8 +265,9 @@ class _LazyPrt:
     polarised `Optic.trace_generic` took.  A traced bundle carries the planes
     (`__dict__["_hip_prt"]`, so that copies of the object carry them too) and gets its `p`
     when somebody reads it; a write behaves like a plain attribute.  Installed on the
-    reference's class the first time the drop-in is used and left there (without planes it IS
-    a plain attribute)."""
+    reference's class while the drop-in is in use (`_install_lazy_prt`); `disable()` gives
+    every live bundle that still waits its `p` and takes the descriptor off the class again
+    (`_remove_lazy_prt`)."""
 
     def __get__(self, obj, cls=None):
         if obj is None:
@@ -280,6 +292,45 @@ class _LazyPrt:
         had = d.pop("_hip_prt", None) is not None
         if d.pop("p", None) is None and not had:
             raise AttributeError("p")
+
+
+_PRT_WAITING = None  # weak set of ray bundles that carry `_hip_prt` planes instead of `p`
+
+
+def _install_lazy_prt():
+    global _PRT_WAITING
+    import weakref
+
+    from optiland.rays import PolarizedRays as RefPolarizedRays
+
+    if _PRT_WAITING is None:
+        _PRT_WAITING = weakref.WeakSet()
+    if not isinstance(RefPolarizedRays.__dict__.get("p"), _LazyPrt):
+        RefPolarizedRays.p = _LazyPrt()
+
+
+def _carry_prt_planes(rays, planes):
+    """`rays.p` = the matrices these planes hold, produced on first read."""
+    d = rays.__dict__
+    d.pop("p", None)
+    d["_hip_prt"] = planes
+    _PRT_WAITING.add(rays)
+
+
+def _remove_lazy_prt():
+    """`disable()`: the reference's `PolarizedRays` is a plain class again.  Bundles the
+    drop-in handed out and nobody has read the `p` of get it now (a deep copy of such a
+    bundle, taken before the read, is not known here: read `p` before `disable()`)."""
+    from optiland.rays import PolarizedRays as RefPolarizedRays
+
+    if _PRT_WAITING is not None:
+        for rays in list(_PRT_WAITING):
+            planes = rays.__dict__.pop("_hip_prt", None)
+            if planes is not None and "p" not in rays.__dict__:
+                rays.__dict__["p"] = prt_to_complex(planes)
+        _PRT_WAITING.clear()
+    if isinstance(RefPolarizedRays.__dict__.get("p"), _LazyPrt):
+        del RefPolarizedRays.p
 
 
 class _PendingRecord:
@@ -371,11 +422,93 @@ def register_pending_views(group, res):
 
 def register_pending_record(optic, table, engine, dtype, launch):
     """Mark every surface of `optic` as "recorded state = this trace, not yet run".  The
-    instance attributes are emptied first (as `Surface.reset()` leaves them), so a copy of
-    the optic taken before anybody reads them sees a reset surface, never stale arrays."""
+    instance attributes are emptied first (as `Surface.reset()` leaves them): nothing can
+    see stale arrays.  A copy / pickle of a surface (`Surface.__getstate__`) runs the trace."""
     _install_lazy_descriptors()
     return _mark_pending(optic.surfaces.surfaces,
                          _PendingRecord(optic, table, engine, dtype, launch), dtype)
+
+
+class _Volatile:
+    """Holder of drop-in state that hangs on a REFERENCE object (`SurfaceGroup.__dict__`) and
+    must not travel with it: change-detector tokens embed `id()`s, engines own device handles.
+    `copy.copy` / `copy.deepcopy` / `pickle` of the reference object carry an EMPTY holder --
+    the copy re-packs on its first trace, exactly like a freshly built optic."""
+
+    __slots__ = ("value",)
+
+    def __init__(self, value=None):
+        self.value = value
+
+    def __reduce__(self):
+        return (_Volatile, ())
+
+    def __copy__(self):
+        return _Volatile()
+
+    def __deepcopy__(self, memo):
+        return _Volatile()
+
+
+class _VolatileCache(collections.OrderedDict):
+    """LRU of (engine, table) entries on a reference `SurfaceGroup`; copies and pickles of the
+    group start with an empty one (see `_Volatile`)."""
+
+    def __reduce__(self):
+        return (_VolatileCache, ())
+
+    def __copy__(self):
+        return _VolatileCache()
+
+    def __deepcopy__(self, memo):
+        return _VolatileCache()
+
+
+class _BoundSgTrace:
+    """`install(optic)`'s per-instance replacement of `SurfaceGroup.trace`: what
+    `types.MethodType(_sg_trace, group)` would be, but one that survives `pickle` (a bound
+    method of a module-level function pickles as `getattr(group, "_sg_trace")`, which does
+    not exist) and `copy.deepcopy` (re-bound to the COPY of the group)."""
+
+    __slots__ = ("group",)
+
+    def __init__(self, group):
+        self.group = group
+
+    def __call__(self, rays, skip=0):
+        return _sg_trace(self.group, rays, skip)
+
+    @property
+    def __self__(self):
+        return self.group
+
+    def __reduce__(self):
+        return (_BoundSgTrace, (self.group,))
+
+    def __deepcopy__(self, memo):
+        import copy
+        return _BoundSgTrace(copy.deepcopy(self.group, memo))
+
+
+# attributes of an `OptilandHipRayTracer` that are caches of THIS process / device (handles,
+# id()-based tokens, the last table): a copy or a pickle of the tracer starts without them
+_TRACER_VOLATILE = {
+    "_hip_engines": collections.OrderedDict, "_hip_memo": collections.OrderedDict,
+    "_hip_surface_cache": dict, "_hip_engine": lambda: None, "_hip_table": lambda: None,
+    "_hip_trusted": lambda: None, "_hip_trust_depth": lambda: 0,
+}
+
+
+def _restore_tracer(state):
+    """Unpickle an `OptilandHipRayTracer` (its `__reduce__`): the class is created on first
+    use of the drop-in (it subclasses the reference's `RealRayTracer`, imported lazily), so a
+    pickle cannot name it -- it names this function instead."""
+    cls = _make_tracer_class()
+    new = cls.__new__(cls)
+    new.__dict__.update(state)
+    for k, make in _TRACER_VOLATILE.items():
+        new.__dict__[k] = make()
+    return new
 
 
 def _make_tracer_class():
@@ -386,9 +519,6 @@ def _make_tracer_class():
     from optiland.raytrace.real_ray_tracer import RealRayTracer
     from optiland.rays import PolarizedRays as RefPolarizedRays
     from optiland.rays import RealRays as RefRealRays
-
-    if not isinstance(RefPolarizedRays.__dict__.get("p"), _LazyPrt):
-        RefPolarizedRays.p = _LazyPrt()
 
     class OptilandHipRayTracer(RealRayTracer):
         """`RealRayTracer` whose ray generation + surface loop run in HIP kernels.
@@ -427,23 +557,32 @@ def _make_tracer_class():
             self._hip_trust_depth = 0
             self.last_path = None  # "hip" | "reference" (introspection for tests)
 
+        def _portable_state(self):
+            """`__dict__` minus this process's device caches (handles, id()-based tokens, the
+            last record block -- gigabytes at 1e7 rays)."""
+            return {k: v for k, v in self.__dict__.items() if k not in _TRACER_VOLATILE}
+
         def __deepcopy__(self, memo):
             # the reference deep-copies optics (tolerancing, optimisation): the copy starts
-            # with empty device caches instead of clones of handles, tokens and the last
-            # record block (gigabytes at 1e7 rays)
+            # with empty device caches instead of clones of handles and tokens
             import copy
             new = type(self).__new__(type(self))
             memo[id(self)] = new
-            for k, v in self.__dict__.items():
-                if k in ("_hip_engines", "_hip_memo"):
-                    new.__dict__[k] = collections.OrderedDict()
-                elif k == "_hip_surface_cache":
-                    new.__dict__[k] = {}
-                elif k in ("_hip_engine", "_hip_table"):
-                    new.__dict__[k] = None
-                else:
-                    new.__dict__[k] = copy.deepcopy(v, memo)
+            for k, v in self._portable_state().items():
+                new.__dict__[k] = copy.deepcopy(v, memo)
+            for k, make in _TRACER_VOLATILE.items():
+                new.__dict__[k] = make()
             return new
+
+        def __reduce__(self):
+            # pickle (multiprocessing / joblib over optics, optic/optic.py:121: the tracer is
+            # an attribute of the Optic): same contract as a deep copy.  The two-argument
+            # form lets pickle restore the state AFTER the object exists, so the cycle
+            # tracer -> optic -> tracer is handled by its memo.
+            return (_restore_tracer, ({},), self._portable_state())
+
+        def __setstate__(self, state):
+            self.__dict__.update(state)
 
         # ---------------------------------------------------------- eligibility
         def _eligible(self) -> bool:
@@ -462,14 +601,23 @@ def _make_tracer_class():
             return torch.float64
 
         def invalidate(self):
-            """Forget the change-detector memo (the next trace re-packs the optic)."""
-            self._hip_memo.clear()
+            """Forget everything the change detector relies on: the token memo, the
+            per-surface packed rows and the device scalars read back so far.  The next trace
+            re-reads the WHOLE prescription from the live objects (the manual override for
+            edits the detector cannot see, e.g. a `tensor.data` write)."""
+            from . import packer as _packer
 
-        def _entry_for(self, wavelength, tok=None):
-            """(engine, table, fronts) for the optic AS IT IS NOW at `wavelength`.  `tok`: its
-            change-detector token if the caller has just taken it."""
+            self._hip_memo.clear()
+            self._hip_surface_cache.clear()
+            self._hip_spec_ok = False  # validate before launching, not after
+            _packer.clear_tensor_values()
+
+        def _entry_for(self, wavelength, tok=None, keep=None):
+            """(engine, table, fronts) for the optic AS IT IS NOW at `wavelength`.  `tok`,
+            `keep`: its change-detector token (and the objects the token's ids belong to) if
+            the caller has just taken it."""
             w = float(wavelength.item()) if hasattr(wavelength, "item") else float(wavelength)
-            _keep = None
+            _keep = keep if tok is not None else None
             trusted = self._hip_trusted
             if trusted is not None and tok is None and w in trusted:
                 memo = self._hip_memo.get(w)  # validated earlier in this `unchanged` scope
@@ -499,7 +647,7 @@ def _make_tracer_class():
                 # last packed under are taken from the per-surface cache, not read again
                 table = pack_optic(self.optic, wavelengths=[w],
                                    tokens=None if tok is None else tok[1],
-                                   cache=self._hip_surface_cache)
+                                   cache=self._hip_surface_cache, keep=_keep)
             except UnsupportedSystem as exc:
                 self._remember(w, exc)
                 raise
@@ -550,10 +698,10 @@ def _make_tracer_class():
             while len(self._hip_memo) > _MAX_MEMO:
                 self._hip_memo.popitem(last=False)
 
-        def _front_for(self, wavelength, tok=None):
+        def _front_for(self, wavelength, tok=None, keep=None):
             """The stand-alone device tracer (`tracer.HipRayTracer`) on the current table in
             the backend's precision: it owns the whole device-side call sequence."""
-            eng, table, fronts = self._entry_for(wavelength, tok)
+            eng, table, fronts = self._entry_for(wavelength, tok, keep)
             dtype = self._dtype()
             front = fronts.get(dtype)
             if front is None:
@@ -587,7 +735,8 @@ def _make_tracer_class():
             out.L0, out.M0, out.N0 = mine.L0, mine.M0, mine.N0
             if polarized:
                 # `p` in the reference's (N, 3, 3) complex layout: produced on first read
-                out.__dict__["_hip_prt"] = mine._prt
+                _install_lazy_prt()
+                _carry_prt_planes(out, mine._prt)
                 out._i0, out._L0, out._M0, out._N0 = mine._i0, mine._L0, mine._M0, mine._N0
             # final propagation by the image thickness (0 in every sample; identity then):
             # real_ray_tracer.py:104-110, BEFORE the polarised epilogue (:112-113)
@@ -653,7 +802,7 @@ def _make_tracer_class():
             # of queueing a launch that is thrown away)
             spec = self._speculate(wavelength) if self._hip_spec_ok else None
             self._hip_spec_ok = True
-            tok = None
+            tok = _keep = None
             if spec is not None:
                 front, table, tok0, w = spec
                 mine = err = None
@@ -692,7 +841,7 @@ def _make_tracer_class():
                 front._last_res = None
             packs = self.pack_count
             try:
-                front, table = self._front_for(wavelength, tok)
+                front, table = self._front_for(wavelength, tok, _keep)
             except UnsupportedSystem:
                 self.last_path = "reference"
                 return original()
@@ -768,7 +917,7 @@ def _sg_engine(group, table, dev):
     """(engine, table) for this SurfaceGroup's packed table on the rays' device,
     LRU-cached on the group against the packed bytes (a changed surface re-packs and
     misses)."""
-    cache = group.__dict__.setdefault("_hip_engines", collections.OrderedDict())
+    cache = group.__dict__.setdefault("_hip_engines", _VolatileCache())
     dev = dev if dev.type == "cuda" else (group.__dict__.get("_hip_device") or _SG["device"])
     key = (_table_key(table), str(dev))
     hit = cache.get(key)
@@ -792,6 +941,7 @@ def _sg_table(group, wavelength):
     if _fp.ENABLED:
         tok, _keep = _fp.surfaces_token(group.surfaces, wavelength)
         memo = group.__dict__.get("_hip_sg_memo")
+        memo = memo.value if memo is not None else None
         if memo is not None and memo[0] == tok:
             return memo[2]
     try:
@@ -800,7 +950,7 @@ def _sg_table(group, wavelength):
         table = None
     if tok is not None:
         tok, keep = _fp.surfaces_token(group.surfaces, wavelength)  # after the pack
-        group.__dict__["_hip_sg_memo"] = (tok, keep, table)
+        group.__dict__["_hip_sg_memo"] = _Volatile((tok, keep, table))
     return table
 
 
@@ -862,12 +1012,8 @@ def _sg_run(group, eng, rays, planes, first, last, polarized):
         rays.L0, rays.M0, rays.N0 = pre
     rays.x, rays.y, rays.z, rays.L, rays.M, rays.N, rays.i, rays.opd = res.rows(last)
     if polarized:
-        if isinstance(type(rays).__dict__.get("p"), _LazyPrt) or any(
-                isinstance(c.__dict__.get("p"), _LazyPrt) for c in type(rays).__mro__):
-            rays.__dict__.pop("p", None)        # produced from the planes on first read
-            rays.__dict__["_hip_prt"] = prt
-        else:
-            rays.p = prt_to_complex(prt)
+        _install_lazy_prt()
+        _carry_prt_planes(rays, prt)        # `p` is produced from the planes on first read
 
 
 def _hip_surface_group_trace(group, rays, skip):
@@ -920,9 +1066,16 @@ def _hip_surface_group_trace(group, rays, skip):
     # device allocations for a double Gauss: 0.4 of the 0.5 ms this seam took on a small
     # bundle); one shared empty tensor says the same.
     empty = _empty(rays.x.dtype, rays.x.device)
+    base_reset = _ORIGINALS.get("surface_reset")
+    if base_reset is None:
+        from optiland.surfaces.standard_surface import Surface
+        base_reset = _ORIGINALS["surface_reset"] = Surface.reset
     for surf in group.surfaces:
         if _PENDING:   # what an earlier trace left pending is overwritten
             _PENDING.pop(surf, None)
+        if type(surf).reset is not base_reset:
+            surf.reset()   # a subclass with its own reset(): it is the one that knows
+            continue
         d = surf.__dict__
         d["x"] = d["y"] = d["z"] = d["L"] = d["M"] = d["N"] = d["intensity"] = d["opd"] = empty
         d["u"] = d["aoi"] = empty
@@ -1087,6 +1240,7 @@ def disable():
         analysis_seams.disable()
         _ENABLE.update(lazy=False)
         _remove_lazy_descriptors()
+        _remove_lazy_prt()
 
 
 def install(optic, device=None, force=False, analyses=True, lazy_records=False):
@@ -1105,14 +1259,12 @@ def install(optic, device=None, force=False, analyses=True, lazy_records=False):
     optic.ray_tracer = new
     # this optic's SurfaceGroup too: caller-built rays, and the surface loop of traces whose
     # ray generation stays on the reference (aiming modes, unsupported surfaces bridged)
-    import types
-
     from optiland.surfaces.surface_group import SurfaceGroup
 
     _ORIGINALS.setdefault("sg_trace", SurfaceGroup.trace)
     group = optic.surfaces
     group.__dict__["_hip_force"], group.__dict__["_hip_device"] = bool(force), device
-    group.__dict__["trace"] = types.MethodType(_sg_trace, group)
+    group.__dict__["trace"] = _BoundSgTrace(group)
     return new
 
 
@@ -1122,5 +1274,5 @@ def uninstall(optic):
     cfg = dict(optic.ray_tracer.ray_aiming_config)
     optic.ray_tracer = RealRayTracer(optic)
     optic.ray_tracer.ray_aiming_config = cfg
-    for k in ("trace", "_hip_force", "_hip_device", "_hip_sg_memo"):
+    for k in ("trace", "_hip_force", "_hip_device", "_hip_sg_memo", "_hip_engines"):
         optic.surfaces.__dict__.pop(k, None)

@@ -29,6 +29,16 @@ class UnsupportedSystem(Exception):
 # (fingerprint.py): object identity + in-place version; tensors that require grad are never
 # cached (their `.data` can be rewritten without a version bump).
 _TENSOR_VALUES: dict = {}
+# The cache is only consulted during an INCREMENTAL pack (`pack_surfaces(tokens=..., cache=...)`
+# under the change detector): a forced full pack -- no tokens, OPTILAND_HIP_PACK_CACHE=0, or
+# after `tracer.invalidate()` -- reads every tensor live, so the documented escape hatches for
+# the detector's blind spot (a `.data` write bumps no version) really re-read the prescription.
+_TENSOR_CACHE_ACTIVE = False
+
+
+def clear_tensor_values() -> None:
+    """Forget every device scalar read back so far (`tracer.invalidate()`)."""
+    _TENSOR_VALUES.clear()
 
 
 def _f(v) -> float:
@@ -36,7 +46,7 @@ def _f(v) -> float:
     if type(v) is float or type(v) is int:  # the common case, ~160 calls per pack
         return float(v)
     if hasattr(v, "detach"):
-        cacheable = not v.requires_grad and v.numel() == 1
+        cacheable = _TENSOR_CACHE_ACTIVE and not v.requires_grad and v.numel() == 1
         if cacheable:
             hit = _TENSOR_VALUES.get(id(v))
             if hit is not None and hit[1] == v._version and hit[0]() is v:
@@ -378,7 +388,8 @@ def _relocate(row, local: list, base: int):
 
 
 def pack_surfaces(surfaces, wavelengths, name: str = "surfaces",
-                  tolerate: bool = False, tokens=None, cache: dict | None = None) -> SystemTable:
+                  tolerate: bool = False, tokens=None, cache: dict | None = None,
+                  keep=None) -> SystemTable:
     """Flatten a sequence of reference `Surface` objects (a `SurfaceGroup`'s list) for
     the given wavelengths (microns): everything `SurfaceGroup.trace`
     (surfaces/surface_group.py:245-257) needs -- no ray-generator scalars, no
@@ -395,6 +406,11 @@ def pack_surfaces(surfaces, wavelengths, name: str = "surfaces",
     keeps -- a surface whose token is the one it was last packed under is NOT read again,
     its row and coefficient block are taken from the cache and only relocated.  A re-pack
     after `set_radius` then touches one surface instead of all of them.
+    `keep`: the objects the tokens' `id()`s belong to (second element of `optic_token`): the
+    cache pins them -- and the surfaces -- for as long as it holds rows stored under those
+    tokens, so that no freed object can be recycled at the same address with the same version
+    and make a stale row look current (the contract of fingerprint.py: ids are only valid
+    while `keep` is held).
     """
     _INDEX_MEMO.clear()
     surfaces = list(surfaces)
@@ -403,8 +419,19 @@ def pack_surfaces(surfaces, wavelengths, name: str = "surfaces",
     wl_key = wl.tobytes()
     n_s = len(surfaces)
     use_cache = cache is not None and tokens is not None and len(tokens) == n_s
-    if use_cache and len(cache) > 6 * n_s + 64:
-        cache.clear()  # surfaces that left the optic
+    if use_cache:
+        # rows of surfaces that left the optic go (their ids are free to be recycled); what
+        # stays is pinned: the surfaces themselves and everything the current tokens name
+        live = {id(s_) for s_ in surfaces}
+        for k in [k for k in cache if (k if isinstance(k, int) else
+                                       k[1] if isinstance(k, tuple) else None) not in live
+                  and not isinstance(k, str)]:
+            del cache[k]
+        if keep is None:  # a caller without the keep list: rows without pins are not kept
+            for k in [k for k in cache if not isinstance(k, str)]:
+                del cache[k]
+            cache.pop("assembled", None)
+        cache["pinned"] = (surfaces, keep)
 
     if use_cache:
         table = _patched_table(surfaces, wl, wl_key, name, tokens, cache)
@@ -497,18 +524,30 @@ def _patched_table(surfaces, wl, wl_key, name, tokens, cache):
 
 
 def pack_optic(optic, wavelengths=None, name: str | None = None, tokens=None,
-               cache: dict | None = None) -> SystemTable:
+               cache: dict | None = None, keep=None) -> SystemTable:
     """Flatten `optic` (a reference `Optic`) for the given wavelengths (microns):
     `pack_surfaces` + the ray-generator scalars + the polarisation state.
     `tokens`, `cache`: see `pack_surfaces` (incremental re-pack).
 
     Raises `UnsupportedSystem` for anything outside the fused path.
     """
+    global _TENSOR_CACHE_ACTIVE
+    from . import fingerprint as _fp
+
+    before = _TENSOR_CACHE_ACTIVE
+    _TENSOR_CACHE_ACTIVE = bool(_fp.ENABLED and tokens is not None and cache is not None)
+    try:
+        return _pack_optic(optic, wavelengths, name, tokens, cache, keep)
+    finally:
+        _TENSOR_CACHE_ACTIVE = before
+
+
+def _pack_optic(optic, wavelengths, name, tokens, cache, keep) -> SystemTable:
     if wavelengths is None:
         wavelengths = [_f(w.value) for w in optic.wavelengths.wavelengths]
     table = pack_surfaces(optic.surfaces, wavelengths,
                           name or (optic.name or type(optic).__name__), tokens=tokens,
-                          cache=cache)
+                          cache=cache, keep=keep)
     _pack_raygen(optic, table, tokens, cache)
     table.primary_wavelength = _f(optic.primary_wavelength)
     pol = optic.polarization
