@@ -634,11 +634,10 @@ def main():
         if ev0 is not None:
             ev0.record()
         if gen:
+            # ONE launch per step also at N > 1: the masked image-plane moments are an
+            # epilogue of the generating kernel (ABI 8, trace_kernel<..., SPOT, GEN>)
             res = hip.trace_generate(px, py, wl, field=(0.0, hy), record=record, prt=prt,
-                                     zero_status=False, defer_status=True)
-            if spot_arg is not None:  # (the generating kernel has no spot epilogue)
-                hip.spot_moments(res.row(res.last, 0), res.row(res.last, 1),
-                                 res.row(res.last, 6), out=slots[k].view(-1)[:6])
+                                     zero_status=False, defer_status=True, spot=spot_arg)
         else:
             res = hip.trace(src, wl, record=record if record is not None else False, prt=prt,
                             check_status=False, prt_identity=pol, spot=spot_arg)

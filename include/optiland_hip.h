@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OL_ABI_VERSION 7
+#define OL_ABI_VERSION 8
 
 /* ---- error codes ------------------------------------------------------- */
 #define OL_OK 0
@@ -382,15 +382,25 @@ int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n,
  * (raytrace/real_ray_tracer.py:58-154, rays/ray_generator.py:47-99) for one field point:
  * no generator launch, and the object row is written once instead of written by one kernel
  * and read back by the next.
- *   in        px, py planes; launch-uniform field (hx0, hy0) and vignetting (vx0, vy0);
- *             per-ray field / vignetting planes and apodized pupils are refused with
- *             OL_EUNSUPPORTED (callers take ol_generate_rays + ol_trace for those)
+ *   in        px, py planes; launch-uniform field (hx0, hy0) and vignetting (vx0, vy0).
+ *             ABI 8, unpolarised launches (prt == NULL): per-ray field planes hx, hy (and,
+ *             with them, per-ray vignetting planes vx, vy) -- trace_generic(Hx[], Hy[], Px[],
+ *             Py[]) and the fields x pupil expansion of a multi-field trace
+ *             (real_ray_tracer.py:88-98, 120-154) -- and apodized pupils (p->apod_kind: the
+ *             initial intensity is the apodization, ray_generator.py:81-85) are ONE launch
+ *             too.  Polarised launches with either are refused with OL_EUNSUPPORTED
+ *             (callers take ol_generate_rays + ol_trace for those), as are vx, vy planes
+ *             without hx, hy
  *   record    required; rows as in ol_trace (row 0 = the generated rays unless
  *             extras->record_first_surface says otherwise)
  *   rays_out  NULL, or 8 planes receiving the final state (what OL_TRACE_WRITE_RAYS writes)
  *   prt       NULL, or the 9- / 18-plane PRT buffer, WRITE-ONLY (starts from the identity)
- *   flags     OL_TRACE_PRT_COMPLEX only; extras: record_first_surface and (ABI 7) the
- *             update_intensity epilogue of a polarised launch (no spot slots)          */
+ *   flags     OL_TRACE_PRT_COMPLEX only; extras: record_first_surface, (ABI 7) the
+ *             update_intensity epilogue of a polarised launch, and (ABI 8) spot_slots /
+ *             cx / cy -- the masked image-plane moments of ol_trace_ex as an epilogue of
+ *             the GENERATING launch (unpolarised, one field point, no apodization): the
+ *             per-step form of a sharded trace whose exchange is the moments
+ *             (distributed.py) -- generate, trace, record and reduce in one launch        */
 int ol_trace_generate(const ol_system* sys, ol_dtype dt, int64_t n_rays,
                       const ol_raygen_params* p, const ol_raygen_inputs* in,
                       int32_t wavelength_index, void* record, int64_t record_stride,

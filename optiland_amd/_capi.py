@@ -122,7 +122,7 @@ EXPORTS = (
 
 F32, F64 = 0, 1
 TUNE_RAYS_PER_THREAD, TUNE_COMPACT = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 OPD_MOMENTS = 12  # kOpdMoments / ol_trace_opd
 
 

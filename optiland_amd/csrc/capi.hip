@@ -477,13 +477,17 @@ int do_trace_generate(const ol_system* sys, const DeviceTable<T>& tab, int64_t n
   bool al = true;
   if (int rc = convert_inputs<T>("ol_trace_generate", in, status, a.in, al)) return rc;
   if (n == 0) return OL_OK;
+  a.spot = extras ? extras->spot_slots : nullptr;
+  a.cx = extras ? extras->cx : 0.0;
+  a.cy = extras ? extras->cy : 0.0;
+  a.spot_slots = OL_SPOT_SLOTS;
   a.surf = tab.surf;
   a.cold = tab.cold;
   a.optics = tab.optics;
   a.coeffs = tab.coeffs;
   const ol::RaygenDev rg = raygen_dev(p);
   a.rgc = ol::RaygenConsts<T>(rg);
-  ol::uniform_field_tangents<T>(rg, a.in);
+  if (a.in.hx == nullptr) ol::uniform_field_tangents<T>(rg, a.in);
   for (int k = 0; k < 8; ++k) a.rays[k] = rays_out ? static_cast<T*>(rays_out[k]) : nullptr;
   a.record = static_cast<T*>(record);
   a.prt = static_cast<T*>(prt);
@@ -966,14 +970,26 @@ int ol_trace_generate(const ol_system* sys, ol_dtype dt, int64_t n_rays,
   if (wavelength_index < 0 || wavelength_index >= sys->n_wl)
     return fail(OL_EINVAL, "ol_trace_generate: wavelength index %d outside [0, %d)",
                 wavelength_index, sys->n_wl);
-  if (in->hx || in->hy || in->vx || in->vy)
-    return fail(OL_EUNSUPPORTED, "ol_trace_generate: one field point per launch (per-ray field "
-                                 "/ vignetting planes take ol_generate_rays + ol_trace)");
-  if (p->apod_kind != OL_APOD_NONE)
-    return fail(OL_EUNSUPPORTED, "ol_trace_generate: apodized pupils take ol_generate_rays + "
-                                 "ol_trace");
-  if (extras && extras->spot_slots)
-    return fail(OL_EINVAL, "ol_trace_generate: no spot epilogue (use ol_trace_spot)");
+  if ((in->vx || in->vy) && !(in->hx && in->hy))
+    return fail(OL_EUNSUPPORTED, "ol_trace_generate: per-ray vignetting planes come with "
+                                 "per-ray field planes (else ol_generate_rays + ol_trace)");
+  if (prt && (in->hx || in->hy))
+    return fail(OL_EUNSUPPORTED, "ol_trace_generate: a polarised launch is one field point "
+                                 "(per-ray field planes take ol_generate_rays + ol_trace)");
+  if (prt && p->apod_kind != OL_APOD_NONE)
+    return fail(OL_EUNSUPPORTED, "ol_trace_generate: a polarised launch with an apodized pupil "
+                                 "takes ol_generate_rays + ol_trace");
+  if (extras && extras->spot_slots) {
+    if (prt)
+      return fail(OL_EINVAL, "ol_trace_generate: the spot epilogue is for unpolarised traces "
+                             "(the polarised intensity needs update_intensity first)");
+    if (in->hx || in->hy || p->apod_kind != OL_APOD_NONE)
+      return fail(OL_EUNSUPPORTED, "ol_trace_generate: the spot epilogue is one field point "
+                                   "without apodization (else ol_trace_spot)");
+    if (extras->record_first_surface > 0)
+      return fail(OL_EINVAL, "ol_trace_generate: spot epilogue and record_first_surface "
+                             "cannot be combined");
+  }
   if (!record) return fail(OL_EINVAL, "ol_trace_generate: record is NULL");
   if (record_stride < n_rays)
     return fail(OL_EINVAL, "ol_trace_generate: record_stride %lld < n_rays %lld",

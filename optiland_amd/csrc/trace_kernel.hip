@@ -410,7 +410,7 @@ __device__ __forceinline__ SurfFetched<T> fetched_surface(int s) {
 #endif
 // (The generic-family kernel WITH the generator prologue does not fit 7 waves without two
 // dwords of scratch: it keeps the allocator's own choice.)
-template <typename T, int RPT, int POLK, int NR, bool GEN = false>
+template <typename T, int RPT, int POLK, int NR, bool GEN = false>  // GEN: any generating form
 struct WavesPerEu {
   static constexpr int value =
       (OL_POLNR_WAVES > 0 && sizeof(T) == 4 && RPT == 1 && POLK == 1 && NR != 0 &&
@@ -421,17 +421,27 @@ struct WavesPerEu {
                  : 1);
 };
 
-// GEN: the rays are GENERATED in the prologue from normalised pupil planes and a
+// GEN != 0: the rays are GENERATED in the prologue from normalised pupil planes and a
 // launch-uniform field (raygen_device.h, the arithmetic of ol_generate_rays) instead of being
 // read from eight planes -- ol_trace_generate, the record-all path of Optic.trace() in one
 // launch: no separate generator launch, and the object row is written once instead of
-// written by one kernel and read back by the next.
-// EPI (GEN && POLK != 0 only): PolarizedRays.update_intensity as an epilogue of the launch --
-// an instantiation of its own, so that launches without it keep their register budget
-template <typename T, int RPT, bool RECORD, int POLK, int NR, bool SPOT, bool GEN = false,
+// written by one kernel and read back by the next.  GEN is a bit set (trace_launch.h):
+// kGenUniform alone is that form; | kGenFieldPlanes reads per-ray field planes hx, hy (and
+// vx, vy when the caller has them) -- trace_generic(Hx[], Hy[], Px[], Py[]), the expanded
+// fields x pupil of a multi-field trace (real_ray_tracer.py:88-98, 120-154); | kGenApod
+// takes the initial intensity from the pupil apodization (ray_generator.py:81-85).  Template
+// parameters because the per-ray fp64 tangent and the exp / cos / pow of the apodization
+// switch would otherwise set the register budget of the plain form (the same split as
+// spot_trace_kernel's FIELDP / APOD).
+// SPOT with GEN: the masked image-plane moments as an epilogue of the GENERATING launch --
+// the per-step form of the sharded trace (distributed.py): one launch per step at N > 1.
+// EPI (GEN == kGenUniform && POLK != 0 only): PolarizedRays.update_intensity as an epilogue
+// of the launch -- an instantiation of its own, so that launches without it keep their
+// register budget
+template <typename T, int RPT, bool RECORD, int POLK, int NR, bool SPOT, int GEN = 0,
           bool EPI = false>
 __global__ __launch_bounds__(kTraceBlock)
-__attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN || EPI>::value))) void trace_kernel(
+__attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>::value))) void trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
     const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
     TraceArgs<T> a) {
@@ -482,19 +492,33 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN || EPI>::val
   constexpr int NPRT = POLK == 2 ? 18 : 9;  // PRT planes (real, then imaginary)
   Prt<T, POLK> P[POLK ? RPT : 1];
   uint32_t status = 0;
-  if constexpr (GEN) {
-    static_assert(RPT == 1 && !SPOT, "the generating prologue is one ray per lane");
+  if constexpr (GEN != 0) {
+    static_assert(RPT == 1, "the generating prologue is one ray per lane");
+    static_assert(GEN == kGenUniform || POLK == 0,
+                  "per-ray field planes / apodized pupils: unpolarised launches");
     const auto A0 = arg_view<(fetch_level<T, NR, false, POLK>() >= 1), T>(a);
     const auto& in_ = A0->in;
-    T px = base.at(in_.px)[0], py = base.at(in_.py)[0];
-    T vx = in_.vx0, vy = in_.vy0, o[6];
-    raygen_pupil<T>(in_.flags, vx, vy, px, py, status);
+    // (same order of operations as raygen_kernel, aux_kernels.hip: the two-launch path and
+    // this prologue produce the same bits)
+    T tx = in_.tx0, ty = in_.ty0, vx = in_.vx0, vy = in_.vy0, o[6];
     const RaygenConsts<T> c = consts_of(&A0->rgc);
-    raygen_one<T>(c, in_.tx0, in_.ty0, px, py, vx, vy, o);
+    if constexpr ((GEN & kGenFieldPlanes) != 0) {
+      const T hx = base.at(in_.hx)[0], hy = base.at(in_.hy)[0];
+      if (in_.vx != nullptr) {  // launch-uniform
+        vx = base.at(in_.vx)[0];
+        vy = base.at(in_.vy)[0];
+      }
+      if ((in_.flags & kRaygenCheckField) && (outside_unit(hx) || outside_unit(hy)))
+        status |= kStatusFieldRange;
+      raygen_field<T>(c, hx, hy, tx, ty);
+    }
+    T px = base.at(in_.px)[0], py = base.at(in_.py)[0];
+    raygen_pupil<T>(in_.flags, vx, vy, px, py, status);
+    raygen_one<T>(c, tx, ty, px, py, vx, vy, o);
     Ray<T> q;
     q.x = o[0]; q.y = o[1]; q.z = o[2];
     q.L = o[3]; q.M = o[4]; q.N = o[5];
-    q.i = T(1);  // (apodized pupils take the two-launch path: ol_generate_rays + ol_trace)
+    if constexpr ((GEN & kGenApod) != 0) q.i = raygen_apodize<T>(c, px, py); else q.i = T(1);
     q.opd = T(0);
     LP::put(r, 0, q);
     if constexpr (POLK != 0) {
@@ -561,7 +585,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN || EPI>::val
   }
 
   bool is_global = true;  // frame of the state held in r[]
-  bool prt_fresh = POLK != 0 && (GEN || (a.flags & kTracePrtIdentity) != 0);
+  bool prt_fresh = POLK != 0 && (GEN != 0 || (a.flags & kTracePrtIdentity) != 0);
   // Newton-Raphson ranges: table rows re-read phase by phase (SurfFetched), kernel arguments
   // re-read from the kernarg segment where they are used -- these kernels are short of SGPRs
   constexpr bool kFetch = fetch_level<T, NR, false, POLK>() >= 2;      // table rows
@@ -730,7 +754,8 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN || EPI>::val
     }
   }
   if constexpr (EPI) {
-    static_assert(GEN && POLK != 0, "the update_intensity epilogue: generating polarised launches");
+    static_assert(GEN == kGenUniform && POLK != 0,
+                  "the update_intensity epilogue: generating polarised launches");
     // PolarizedRays.update_intensity (rays/polarized_rays.py:68-133) of the traced bundle, from
     // the matrix still in registers (ol_trace_extras.updated_intensity, ABI 7) -- instead of a
     // second launch that reads nine PRT planes, three direction planes and the intensity
@@ -838,7 +863,7 @@ static hipError_t launch_pair(const TraceArgs<T>& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// ol_trace_generate: one ray per lane, recording, no spot epilogue
+// ol_trace_generate: one ray per lane, recording
 template <typename T, int NR>
 static hipError_t launch_gen_nr(const TraceArgs<T>& a, hipStream_t stream) {
   const int64_t blocks = (a.n + kTraceBlock - 1) / kTraceBlock;
@@ -846,13 +871,27 @@ static hipError_t launch_gen_nr(const TraceArgs<T>& a, hipStream_t stream) {
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)blocks), block(kTraceBlock);
   const int polk = a.prt == nullptr ? 0 : ((a.flags & kTracePrtComplex) ? 2 : 1);
-#define OL_LAUNCH_G(P, E)                                                                    \
-  hipLaunchKernelGGL((trace_kernel<T, 1, true, P, NR, false, true, E>), grid, block, 0,      \
+#define OL_LAUNCH_G(P, S, G, E)                                                              \
+  hipLaunchKernelGGL((trace_kernel<T, 1, true, P, NR, S, G, E>), grid, block, 0,             \
                      stream, a.surf, a.cold, a.optics, a.coeffs, a)
   const bool epi = polk != 0 && a.i_updated != nullptr;  // update_intensity epilogue (ABI 7)
-  if (polk == 2) { if (epi) OL_LAUNCH_G(2, true); else OL_LAUNCH_G(2, false); }
-  else if (polk == 1) { if (epi) OL_LAUNCH_G(1, true); else OL_LAUNCH_G(1, false); }
-  else OL_LAUNCH_G(0, false);
+  const bool fieldp = a.in.hx != nullptr, apod = a.rgc.apod_kind != 0;
+  if (polk != 0) {
+    // polarised launches: the launch-uniform form only (capi.hip refuses the others)
+    if (fieldp || apod || a.spot != nullptr) return hipErrorInvalidValue;
+    if (polk == 2) { if (epi) OL_LAUNCH_G(2, false, 1, true); else OL_LAUNCH_G(2, false, 1, false); }
+    else { if (epi) OL_LAUNCH_G(1, false, 1, true); else OL_LAUNCH_G(1, false, 1, false); }
+  } else if (a.spot != nullptr) {
+    // spot epilogue of the generating launch (ABI 8): the per-step form of the sharded trace
+    // (one field point per step; capi.hip refuses it with field planes / apodization)
+    if (fieldp || apod) return hipErrorInvalidValue;
+    OL_LAUNCH_G(0, true, 1, false);
+  } else {
+    if (fieldp && apod) OL_LAUNCH_G(0, false, 7, false);
+    else if (fieldp) OL_LAUNCH_G(0, false, 3, false);
+    else if (apod) OL_LAUNCH_G(0, false, 5, false);
+    else OL_LAUNCH_G(0, false, 1, false);
+  }
 #undef OL_LAUNCH_G
   return hipGetLastError();
 }

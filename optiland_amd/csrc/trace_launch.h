@@ -18,6 +18,12 @@ constexpr uint32_t kTracePrtComplex = 0x4u;  // OL_TRACE_PRT_COMPLEX
 constexpr uint32_t kTracePrtIdentity = 0x8u;  // OL_TRACE_PRT_IDENTITY
 constexpr uint32_t kTraceRow0IsInput = 0x100u;  // internal: rays[] ARE record row 0
 
+// GEN template parameter of trace_kernel: 0 = the rays come from eight planes; otherwise the
+// generating prologue, a bit set
+constexpr int kGenUniform = 1;      // launch-uniform field point, unit initial intensity
+constexpr int kGenFieldPlanes = 2;  // + per-ray field planes hx, hy (and, if given, vx, vy)
+constexpr int kGenApod = 4;         // + pupil apodization as the initial intensity
+
 // process-wide tuning knobs (ol_set_tuning)
 struct Tuning {
   int rays_per_thread = 0;  // 0 = default, 1 = one ray per lane, 2 = force vector

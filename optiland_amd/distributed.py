@@ -180,3 +180,28 @@ class ShardedTracer:
         elif exchange == "reduce":
             out["spot"] = spot_statistics(t.engine, x, y, i, self.group)
         return out
+
+    def trace_field(self, Hx: float, Hy: float, Px, Py, wavelength, center=(0.0, 0.0)):
+        """ONE field point over a GLOBAL pupil list, record-all, reduce-first exchange -- the
+        per-step form of BASELINE config C3 (`bench.py --gpus N`): this rank generates,
+        traces, records AND reduces its shard in ONE launch (`ol_trace_generate` with the
+        spot epilogue, ABI 8); the 4 KB slot block is the only thing that crosses xGMI.
+        Returns the record of the local shard and the whole-job statistics (RMS / geometric
+        radius about `center`, e.g. the chief-ray hit; the centroid is absolute)."""
+        t = self.tracer
+        if t.table.polarization is not None or t.table.uses_polarization:
+            raise ValueError("trace_field: the spot epilogue needs an unpolarised system")
+        px, py = t._dev(Px), t._dev(Py)
+        lo, hi = shard_bounds(px.numel(), self.world, self.rank)
+        wl, _ = t._wavelength_index(wavelength)
+        hx, hy = float(Hx), float(Hy)
+        eng = t.engine
+        slots = eng.alloc_spot_slots()
+        res = None
+        if hi > lo:
+            res = eng.trace_generate(px[lo:hi].contiguous(), py[lo:hi].contiguous(), wl,
+                                     field=(hx, hy), vig=t._vig_scalar(hx, hy),
+                                     spot=(slots, float(center[0]), float(center[1])))
+        mom = allreduce_spot7(eng.reduce_spot_slots(slots), self.group)
+        return {"result": res, "lo": lo, "hi": hi, "n_total": int(px.numel()),
+                "spot": spot7_statistics(mom.cpu(), center)}

@@ -271,19 +271,28 @@ class HipSystem:
         return TraceResult(n, rays, rec, prt, status, rec_first if rec is not None else first,
                            last)
 
-    def can_trace_generate(self) -> bool:
-        """`ol_trace_generate` present (ABI 6) and the table carries generator scalars without
-        a pupil apodization (those take the two-launch path)."""
+    def can_trace_generate(self, field_planes: bool = False) -> bool:
+        """`ol_trace_generate` serves this launch: the table carries generator scalars, and --
+        for per-ray field planes (`field_planes`) or an apodized pupil -- the trace is
+        unpolarised (ABI 8; polarised launches with either take the two-launch path)."""
         rg = self.table.raygen
-        return bool(rg) and int(rg.get("apod_kind", 0)) == 0 and hasattr(self.lib,
-                                                                         "ol_trace_generate")
+        if not rg or not hasattr(self.lib, "ol_trace_generate"):
+            return False
+        if field_planes or int(rg.get("apod_kind", 0)) != 0:
+            return self.table.polarization is None and not self.table.uses_polarization
+        return True
 
     def trace_generate(self, px, py, wavelength_index: int = 0, *, field, vig=(1.0, 1.0),
                        record=True, record_first: int = 0, prt: torch.Tensor | None = None,
                        rays_out=None, flags: int = 0, zero_status: bool = True,
-                       defer_status: bool = False, update_intensity=None) -> TraceResult:
-        """`ol_trace_generate`: rays of ONE field point generated from the normalised pupil
-        planes and traced through the whole system in one launch.  record: True (allocate)
+                       defer_status: bool = False, update_intensity=None,
+                       spot=None) -> TraceResult:
+        """`ol_trace_generate`: rays generated from the normalised pupil planes and traced
+        through the whole system in one launch.  field: (hx, hy) floats -- ONE field point --
+        or two device planes (per-ray fields, unpolarised traces; `vig` then floats or two
+        planes, None = unvignetted).  spot: optional (slots, cx, cy) as in `trace` -- the masked
+        image-plane moments as an epilogue of the same launch (one field point, unpolarised,
+        no apodization).  record: True (allocate)
         or a preallocated (rows, 8, stride) block; rows start at surface `record_first`
         (0 = the generated rays themselves as the object row).  prt: write-only (9 | 18, n)
         buffer of a polarised trace.  rays_out: optional 8 planes for the final state.
@@ -321,13 +330,26 @@ class HipSystem:
         res = TraceResult(n, None, rec, prt, 0, record_first, last)  # .rays: row 0, on demand
         if n == 0:
             return res
-        inp, keep = self._raygen_inputs(float(field[0]), float(field[1]), px, py,
-                                        float(vig[0]), float(vig[1]), flags)
+        planes = isinstance(field[0], torch.Tensor)
+        if planes:
+            vx, vy = vig if vig is not None else (None, None)
+            if not isinstance(vx, torch.Tensor) and vx is not None:
+                vx, vy = float(vx), float(vy)
+            inp, keep = self._raygen_inputs(field[0], field[1], px, py, vx, vy, flags)
+        else:
+            inp, keep = self._raygen_inputs(float(field[0]), float(field[1]), px, py,
+                                            float(vig[0]), float(vig[1]), flags)
         outp = None
         if rays_out is not None:
             self._check_out_planes(list(rays_out), n, dtype, "trace_generate")
             outp = (C.c_void_p * 8)(*[t.data_ptr() for t in rays_out])
         ex = _capi.TraceExtras(None, 0.0, 0.0, record_first, 0, None, None)
+        if spot is not None:
+            slots, cx, cy = spot
+            if slots.dtype != torch.float64 or slots.numel() != 8 * _capi.SPOT_SLOTS \
+                    or slots.device != self.device or not slots.is_contiguous():
+                raise ValueError("spot slots must come from alloc_spot_slots()")
+            ex.spot_slots, ex.cx, ex.cy = slots.data_ptr(), float(cx), float(cy)
         if update_intensity is not None and prt is not None and self.can_fuse_update_intensity():
             pol = update_intensity
             if pol.get("is_polarized"):

@@ -94,6 +94,13 @@ def _shared_pupil_planes(key, dtype, device, to_device):
     return hit
 
 
+def _can_field_planes(can) -> bool:
+    try:
+        return bool(can(field_planes=True))
+    except TypeError:  # an engine stand-in with the ABI-6 signature
+        return False
+
+
 class HipRayTracer:
     """Drop-in for `RealRayTracer` on a packed system."""
 
@@ -257,8 +264,13 @@ class HipRayTracer:
         self.last_was_lazy = False
         uniform = isinstance(hx, float) and isinstance(hy, float) \
             and isinstance(vig[0], float) and isinstance(vig[1], float)
+        # per-ray field planes (trace_generic with arrays, the fields x pupil expansion of a
+        # multi-field trace): one launch as well when the engine serves them (ABI 8)
+        per_ray = isinstance(hx, torch.Tensor) and isinstance(hy, torch.Tensor) \
+            and (vig[0] is None or isinstance(vig[0], torch.Tensor))
         can = getattr(eng, "can_trace_generate", None)
-        if self.fuse_generate and uniform and n > 0 and can is not None and can():
+        if self.fuse_generate and n > 0 and can is not None \
+                and ((uniform and can()) or (per_ray and _can_field_planes(can))):
             return self._run_fused(hx, hy, px, py, vig, wavelength, update_intensity, flags)
         record, rays = self._alloc_state(n)
         eng.generate_rays(hx, hy, px, py, vig[0], vig[1], out=rays, flags=flags)

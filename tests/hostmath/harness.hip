@@ -83,14 +83,24 @@ void trace_one(const TraceArgs<T>& a, int64_t i, uint32_t& status) {
   constexpr int NPRT = POLK == 2 ? 18 : 9;
   Ray<T> r[1];
   if constexpr (GEN) {  // trace_kernel<..., GEN = true>: the generating prologue
+    // (GEN's kGenFieldPlanes / kGenApod forms are template variants on the device; one
+    // run-time switch here)
     const RaygenIn<T>& in_ = a.in;
+    T tx = in_.tx0, ty = in_.ty0, vx = in_.vx0, vy = in_.vy0, o[6];
+    if (in_.hx != nullptr) {
+      const T hx = in_.hx[i], hy = in_.hy[i];
+      if (in_.vx != nullptr) { vx = in_.vx[i]; vy = in_.vy[i]; }
+      if ((in_.flags & kRaygenCheckField) && (outside_unit(hx) || outside_unit(hy)))
+        status |= kStatusFieldRange;
+      raygen_field<T>(a.rgc, hx, hy, tx, ty);
+    }
     T px = in_.px[i], py = in_.py[i];
-    T vx = in_.vx0, vy = in_.vy0, o[6];
     raygen_pupil<T>(in_.flags, vx, vy, px, py, status);
-    raygen_one<T>(a.rgc, in_.tx0, in_.ty0, px, py, vx, vy, o);
+    raygen_one<T>(a.rgc, tx, ty, px, py, vx, vy, o);
     r[0].x = o[0]; r[0].y = o[1]; r[0].z = o[2];
     r[0].L = o[3]; r[0].M = o[4]; r[0].N = o[5];
-    r[0].i = T(1); r[0].opd = T(0);
+    r[0].i = a.rgc.apod_kind != 0 ? raygen_apodize<T>(a.rgc, px, py) : T(1);
+    r[0].opd = T(0);
   } else {
     r[0].x = a.rays[0][i]; r[0].y = a.rays[1][i]; r[0].z = a.rays[2][i];
     r[0].L = a.rays[3][i]; r[0].M = a.rays[4][i]; r[0].N = a.rays[5][i];
@@ -183,9 +193,26 @@ template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, int, hi
 template <typename T, int NR>
 static hipError_t gen_nr(const TraceArgs<T>& a) {
   const int polk = a.prt == nullptr ? 0 : ((a.flags & kTracePrtComplex) ? 2 : 1);
+  if (polk != 0 && (a.in.hx != nullptr || a.rgc.apod_kind != 0 || a.spot != nullptr))
+    return hipErrorInvalidValue;  // as launch_gen_nr
+  if (a.spot != nullptr && (a.in.hx != nullptr || a.rgc.apod_kind != 0))
+    return hipErrorInvalidValue;
   if (polk == 2) trace_all<T, 2, NR, true>(a);
   else if (polk == 1) trace_all<T, 1, NR, true>(a);
   else trace_all<T, 0, NR, true>(a);
+  if (a.spot != nullptr) {
+    // the spot epilogue of the generating launch (ABI 8): on the device a workgroup
+    // reduction of the final state in registers; here the same per-ray accumulation
+    // (epilogue_device.h) over the last recorded row, ray by ray into slot 0
+    const int rec_from = a.record_from > a.first ? a.record_from : a.first;
+    const T* row = a.record + (int64_t)(a.last - rec_from) * 8 * a.record_stride;
+    double m[6] = {0, 0, 0, 0, 0, 0}, rmax = 0.0;
+    for (int64_t j = 0; j < a.n; ++j)
+      spot_accumulate<T>(m, rmax, row[j], row[a.record_stride + j], row[6 * a.record_stride + j],
+                         a.cx, a.cy);
+    for (int k = 0; k < 6; ++k) a.spot[k] += m[k];
+    a.spot[6] = rmax > a.spot[6] ? rmax : a.spot[6];
+  }
   if (polk != 0 && a.i_updated != nullptr) {
     // the update_intensity epilogue of the generating launch (trace_kernel.hip, ABI 7): the
     // device takes the matrix from its registers and regenerates the launch direction; here

@@ -165,3 +165,80 @@ def test_empty_shards_and_dead_bundles():
         assert np.isnan(res[8]["geometric_radius"])
     assert np.array_equal(results[0][5], results[1][5])
     assert np.array_equal(results[0][6], results[1][6])
+
+
+def _field_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import optiland_amd.tracer as tr
+        from optiland_amd import load_system
+        from optiland_amd.distributed import ShardedTracer
+        from tests import _hostmath as hm
+        cls = hm.make_engine_class()
+        tr._make_engine = lambda table, device: cls(table, device)
+        table = load_system("double_gauss")
+        g = np.random.default_rng(5)
+        n = 1001  # ragged on purpose
+        r, th = np.sqrt(g.random(n)), 2 * np.pi * g.random(n)
+        px, py = r * np.cos(th), r * np.sin(th)
+        t = tr.HipRayTracer(table, dtype=torch.float64)
+        out = ShardedTracer(t).trace_field(0.0, 0.7, px, py, 0.5876, center=(0.0, 15.0))
+        res = out["result"]
+        q.put((rank, out["lo"], out["hi"], res.record[:, :, : res.n].numpy(), out["spot"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_one_launch_field_step_equals_single_process():
+    """`ShardedTracer.trace_field`: generate + trace + record + reduce in ONE launch per rank
+    (`ol_trace_generate` with the spot epilogue, ABI 8 -- the per-step form of config C3),
+    the 4 KB slot block the only exchange.  The product's engine class on the host build of
+    the kernel source, world size 2 over gloo: the shards' records concatenate to the
+    single-process record bit for bit and every rank holds the whole-job statistics."""
+    from tests import _hostmath as hm
+    if not hm.available():
+        pytest.skip("hipcc (used as host C++ compiler) missing")
+    hm.make_engine_class()  # build before the workers race for it
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_field_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+
+    import optiland_amd.tracer as tr
+    from optiland_amd import load_system
+    table = load_system("double_gauss")
+    g = np.random.default_rng(5)
+    n = 1001
+    r, th = np.sqrt(g.random(n)), 2 * np.pi * g.random(n)
+    px, py = torch.tensor(r * np.cos(th)), torch.tensor(r * np.sin(th))
+    eng = hm.make_engine_class()(table)
+    try:
+        full = eng.trace_generate(px, py, table.wavelength_index(0.5876), field=(0.0, 0.7))
+        rec = full.record[:, :, :n].numpy()
+    finally:
+        eng.close()
+    assert results[0][1] == 0 and results[0][2] == results[1][1] and results[1][2] == n
+    cat = np.concatenate([results[0][3], results[1][3]], axis=2)
+    assert np.array_equal(cat, rec, equal_nan=True)
+    x, y, i = rec[-1, 0], rec[-1, 1], rec[-1, 6]
+    m = i > 0
+    for res in results:
+        s = res[4]
+        assert s["count"] == m.sum()
+        np.testing.assert_allclose(s["centroid"], (x[m].mean(), y[m].mean()), rtol=1e-12,
+                                   atol=1e-13)
+        np.testing.assert_allclose(s["rms_radius"],
+                                   np.sqrt(np.mean(x[m] ** 2 + (y[m] - 15.0) ** 2)), rtol=1e-12)
+        np.testing.assert_allclose(s["geometric_radius"],
+                                   np.sqrt(np.max(x[m] ** 2 + (y[m] - 15.0) ** 2)), rtol=1e-12)
+    assert results[0][4] == results[1][4]

@@ -126,10 +126,24 @@ def test_fused_generate_status_bits_and_refusals(where):
         assert bool(torch.isfinite(ok.record[-1, 0, :3]).all())
     finally:
         eng.close()
+    # ABI 8: an apodized pupil is served by the generating launch too -- unless the trace is
+    # polarised (those keep the two launches)
     apod, _ = load_case("apodized_gaussian_trace")
     eng, dev = _engine(apod, where)
     try:
-        assert not eng.can_trace_generate()
+        assert eng.can_trace_generate() and eng.can_trace_generate(field_planes=True)
+    finally:
+        eng.close()
+    pol, _ = load_case("zernike_fresnel_fringe")
+    eng, dev = _engine(pol, where)
+    try:
+        assert eng.can_trace_generate() and not eng.can_trace_generate(field_planes=True)
+        n = 8
+        px, py = _pupil(n, torch.float64, dev, 5)
+        hx = torch.zeros(n, dtype=torch.float64, device=dev)
+        prt = torch.empty((9, n), dtype=torch.float64, device=dev)
+        with pytest.raises(RuntimeError, match="one field point"):
+            eng.trace_generate(px, py, 0, field=(hx, hx), vig=None, prt=prt)
     finally:
         eng.close()
 
@@ -249,5 +263,191 @@ def test_update_intensity_epilogue_is_refused_without_a_prt():
                                        eng._status.data_ptr(), C.byref(ex), None)
         assert rc == -1  # OL_EINVAL
         assert b"polarised launch" in eng.lib.ol_last_error()
+    finally:
+        eng.close()
+
+
+# ------------------------------------------------------------------------------------------
+# ABI 8: per-ray field planes, apodized pupils and the spot epilogue in the generating launch
+# ------------------------------------------------------------------------------------------
+APODIZATIONS = [  # (apod_kind, a, b): optiland/apodization/*.py as packed by packer._pack_apodization
+    (1, 0.7, 0.0),    # gaussian
+    (2, 0.9, 0.0),    # cosine squared
+    (3, 1.6, 0.0),    # hann
+    (4, 1.0, 2.0),    # polynomial
+    (5, 0.8, 4.0),    # super-gaussian
+    (6, 0.95, 0.4),   # tukey
+]
+
+
+def _table(name):
+    try:
+        return load_system(name)
+    except Exception:  # not a shipped table: a golden case
+        return load_case(name)[0]
+
+
+def _fields(n, dtype, dev, seed, discrete):
+    g = np.random.default_rng(seed)
+    if discrete:   # C1: three field points x the pupil, expanded (real_ray_tracer.py:95-98)
+        pts = np.array([[0.0, 0.0], [0.0, 0.7], [0.0, 1.0]])
+        idx = np.arange(n) * 3 // max(n, 1)
+        hx, hy = pts[idx, 0], pts[idx, 1]
+    else:
+        hx, hy = g.uniform(-1, 1, n), g.uniform(-1, 1, n)
+    return (torch.tensor(hx, dtype=dtype, device=dev), torch.tensor(hy, dtype=dtype, device=dev))
+
+
+def _two_launch_then_fused(eng, dev, n, dtype, px, py, field, vig, flags):
+    rec_a = eng.alloc_record(n, dtype)
+    rays = eng.row0_planes(rec_a, n)
+    vx, vy = vig if vig is not None else (None, None)
+    eng.generate_rays(field[0], field[1], px, py, vx, vy, out=rays, flags=flags)
+    a = eng.trace(rays, 0, record=rec_a, zero_status=False)
+    b = eng.trace_generate(px, py, 0, field=field, vig=vig, flags=flags)
+    return a.record[:, :, :n].cpu().numpy(), b.record[:, :, :n].cpu().numpy()
+
+
+@pytest.mark.parametrize("where", WHERE)
+@pytest.mark.parametrize("case", CASES)
+def test_generating_launch_with_field_planes_equals_two_launches(case, where):
+    """`trace_generic(Hx[], Hy[], Px[], Py[])` and the fields x pupil expansion of a
+    multi-field trace as ONE launch (`trace_kernel<..., GEN | kGenFieldPlanes>`): every
+    recorded row bit for bit what `ol_generate_rays` + `ol_trace` give, with and without
+    per-ray vignetting planes, fp32 and fp64, ragged sizes."""
+    table, _ = load_case(case)
+    if not table.raygen:
+        pytest.skip("no ray-generation scalars in this table")
+    eng, dev = _engine(table, where)
+    try:
+        if not eng.can_trace_generate(field_planes=True):
+            pytest.skip("polarised system: per-ray fields keep the two launches")
+        for dtype in (torch.float64, torch.float32):
+            for n, discrete in ((1, False), (259, True), (1000, False)):
+                px, py = _pupil(n, dtype, dev, n + 1)
+                hx, hy = _fields(n, dtype, dev, n + 2, discrete)
+                g = np.random.default_rng(n)
+                vplanes = (torch.tensor(g.uniform(0.8, 1.0, n), dtype=dtype, device=dev),
+                           torch.tensor(g.uniform(0.8, 1.0, n), dtype=dtype, device=dev))
+                for vig, flags in ((None, _capi.RAYGEN_CHECK_FIELD),
+                                   (vplanes, _capi.RAYGEN_CHECK_FIELD | _capi.RAYGEN_CHECK_PUPIL
+                                    | _capi.RAYGEN_PRESCALE_PUPIL),
+                                   ((0.9, 0.85), _capi.RAYGEN_PRESCALE_PUPIL)):
+                    ra, rb = _two_launch_then_fused(eng, dev, n, dtype, px, py, (hx, hy), vig,
+                                                    flags)
+                    np.testing.assert_array_equal(ra, rb, err_msg=f"{case} {dtype} n={n}")
+        # range check of the field planes inside the generating launch
+        bad = torch.tensor([0.0, 1.5], dtype=torch.float64, device=dev)
+        ok = torch.tensor([0.0, 0.1], dtype=torch.float64, device=dev)
+        with pytest.raises(ValueError, match="field coordinates must be within"):
+            eng.trace_generate(ok, ok, 0, field=(ok, bad), vig=None,
+                               flags=_capi.RAYGEN_CHECK_FIELD)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("where", WHERE)
+@pytest.mark.parametrize("kind,a,b", APODIZATIONS)
+@pytest.mark.parametrize("name", ["double_gauss", "rc_asphere", "zernike_nopol"])
+def test_generating_launch_with_apodized_pupil_equals_two_launches(name, kind, a, b, where):
+    """Apodized pupils (ray_generator.py:81-85: the initial intensity) in the generating
+    launch, alone and together with per-ray field planes: every apodization the packer
+    knows, on a conic-only, an even-asphere and a Zernike system (the three Newton families
+    of the generating kernels), bit for bit the two-launch result."""
+    import copy
+    table = copy.deepcopy(_table(name))
+    if table.polarization is not None or table.uses_polarization:
+        pytest.skip("polarised table")
+    table.raygen = dict(table.raygen, apod_kind=kind, apod_a=a, apod_b=b)
+    eng, dev = _engine(table, where)
+    try:
+        assert eng.can_trace_generate()
+        for dtype in (torch.float64, torch.float32):
+            n = 517
+            px, py = _pupil(n, dtype, dev, 40 + kind)
+            hx, hy = _fields(n, dtype, dev, 50 + kind, False)
+            for field, vig, flags in (((0.0, 0.7), (1.0, 1.0), 0),
+                                      ((hx, hy), None, _capi.RAYGEN_CHECK_FIELD)):
+                ra, rb = _two_launch_then_fused(eng, dev, n, dtype, px, py, field, vig, flags)
+                np.testing.assert_array_equal(ra, rb, err_msg=f"{name} apod {kind} {dtype}")
+                assert not np.all(ra[0, 6] == 1.0)  # the apodization really is in row 0
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("where", WHERE)
+@pytest.mark.parametrize("name", ["double_gauss", "rc_asphere", "zernike_nopol"])
+def test_spot_epilogue_of_the_generating_launch(name, where):
+    """ABI 8: `ol_trace_extras.spot_slots` on `ol_trace_generate` -- generate, trace, record
+    and reduce in one launch (the per-step form of the sharded trace).  The record is the one
+    a launch without the epilogue writes; the moments are the masked sums of its last row."""
+    table = _table(name)
+    eng, dev = _engine(table, where)
+    try:
+        for dtype in (torch.float64, torch.float32):
+            for n in (1, 255, 30_011 if where == "cuda" else 2_003):
+                px, py = _pupil(n, dtype, dev, n + 3)
+                slots = eng.alloc_spot_slots()
+                cx, cy = 0.01, 0.25
+                plain = eng.trace_generate(px, py, 0, field=(0.0, 0.6))
+                fused = eng.trace_generate(px, py, 0, field=(0.0, 0.6), spot=(slots, cx, cy))
+                assert torch.equal(fused.record[:, :, :n].nan_to_num(),
+                                   plain.record[:, :, :n].nan_to_num())
+                got = eng.reduce_spot_slots(slots).cpu().numpy()
+                x, y, i = (plain.row(plain.last, k) for k in (0, 1, 6))
+                m = i > 0
+                dx, dy = x[m].double() - cx, y[m].double() - cy
+                ok = ~(torch.isnan(dx) | torch.isnan(dy))
+                want = np.array([float(m.sum()), float(dx.sum()), float(dy.sum()),
+                                 float((dx * dx).sum()), float((dy * dy).sum()),
+                                 float(i[m].double().sum()),
+                                 float((dx * dx + dy * dy)[ok].max()) if bool(ok.any()) else 0.0])
+                assert got[0] == want[0]
+                np.testing.assert_allclose(got[1:6], want[1:6], rtol=1e-10, atol=1e-9)
+                assert got[6] == want[6]
+                if where == "cuda":
+                    # ... and bit-equal to the library's own plane reduction of that row
+                    # (`ol_spot_moments`: the count and the max; the sums agree to rounding
+                    # -- different summation trees)
+                    mom = eng.spot_moments(x, y, i) if hasattr(eng, "spot_moments") else None
+                    if mom is not None:
+                        assert float(mom[0]) == got[0] or float(mom[5]) == got[0]
+        # refused combinations: per-ray fields or an apodized pupil with the epilogue
+        n = 16
+        px, py = _pupil(n, torch.float64, dev, 1)
+        hx = torch.zeros(n, dtype=torch.float64, device=dev)
+        with pytest.raises(RuntimeError, match="one field point"):
+            eng.trace_generate(px, py, 0, field=(hx, hx), vig=None,
+                               spot=(eng.alloc_spot_slots(), 0.0, 0.0))
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("where", WHERE)
+def test_tracer_takes_the_generating_launch_for_field_arrays(where):
+    """`HipRayTracer.trace_generic(Hx[], Hy[], Px[], Py[])` and `trace()` over several field
+    points: ONE launch (`last_fused_launch` set), results identical to the two launches."""
+    table = load_system("cooke_generic")
+    eng, dev = _engine(table, where)
+    try:
+        for dtype in (torch.float64, torch.float32):
+            a = tr.HipRayTracer(table, dev, dtype=dtype, engine=eng)
+            b = tr.HipRayTracer(table, dev, dtype=dtype, engine=eng)
+            b.fuse_generate = False
+            w = float(table.wavelengths[0])
+            n = 300
+            px, py = _pupil(n, dtype, dev, 9)
+            hx, hy = _fields(n, dtype, dev, 10, True)
+            for call in (lambda t: t.trace_generic(hx, hy, px, py, w),
+                         lambda t: t.trace(torch.tensor([0.0, 0.0, 0.0]),
+                                           torch.tensor([0.0, 0.7, 1.0]), w, 6, "hexapolar")):
+                ra, rb = call(a), call(b)
+                assert a.last_fused_launch is not None and b.last_fused_launch is None
+                for k in ("x", "y", "z", "L", "M", "N", "i", "opd", "L0", "M0", "N0"):
+                    np.testing.assert_array_equal(getattr(ra, k).cpu().numpy(),
+                                                  getattr(rb, k).cpu().numpy(), k)
+                for k in ("x", "L", "intensity", "opd"):
+                    np.testing.assert_array_equal(getattr(a.surfaces, k).cpu().numpy(),
+                                                  getattr(b.surfaces, k).cpu().numpy())
     finally:
         eng.close()
