@@ -416,6 +416,14 @@ int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt,
                            const ol_polarization_state* state, void* intensity,
                            uint32_t* status, void* stream);
 
+/* ABI 8, diagnostics.  Write-only streaming yardstick: fills `bytes` of device memory with
+ * `pattern` using the non-temporal stores of the record-all trace kernels, `store_bytes`
+ * (4, 8 or 16) per lane per store.  bench.py times it on a buffer the size of what the
+ * trace launch writes: the ceiling a kernel that only writes reaches on this part for that
+ * footprint, next to the 8 TB/s of the data sheet.                                        */
+int ol_stream_fill(void* dst, int64_t bytes, int32_t store_bytes, uint32_t pattern,
+                   void* stream);
+
 /* Image-plane reductions for one ray block (analysis/spot_diagram/core.py:
  * 329-372): out[0..5] += {sum w, sum w x, sum w y, sum w x^2, sum w y^2,
  * count} with w = (i>0 ? 1 : 0) -- the masked centroid / RMS building blocks;

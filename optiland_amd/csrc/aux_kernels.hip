@@ -360,6 +360,41 @@ hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten,
   return hipGetLastError();
 }
 
+// Write-only streaming yardstick (ol_stream_fill): every lane stores WIDTH bytes per trip
+// with the same non-temporal stores the record-all kernels use (trace_kernel.hip:
+// store_plane), grid-stride over the buffer.  What a kernel that ONLY writes sustains on this
+// part for a given footprint -- the ceiling the record-all kernels are held against.
+template <typename V>
+__global__ __launch_bounds__(kBlock) void stream_fill_kernel(V* __restrict__ dst, int64_t n,
+                                                             V value) {
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * kBlock)
+    __builtin_nontemporal_store(value, dst + j);
+}
+
+hipError_t launch_stream_fill(void* dst, int64_t bytes, int width, uint32_t pattern,
+                              hipStream_t stream) {
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  if (bytes <= 0) return hipSuccess;
+  const int64_t n = bytes / width;
+  // one element per lane per trip, as many workgroups as the trace kernels launch for
+  // the same number of elements (capped: grid-stride beyond)
+  int64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > (1 << 22)) blocks = 1 << 22;
+  if (width == 4)
+    hipLaunchKernelGGL((stream_fill_kernel<uint32_t>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                       stream, static_cast<uint32_t*>(dst), n, pattern);
+  else if (width == 8)
+    hipLaunchKernelGGL((stream_fill_kernel<u32x2>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                       stream, static_cast<u32x2*>(dst), n, u32x2{pattern, pattern});
+  else
+    hipLaunchKernelGGL((stream_fill_kernel<u32x4>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                       stream, static_cast<u32x4*>(dst), n,
+                       u32x4{pattern, pattern, pattern, pattern});
+  return hipGetLastError();
+}
+
 #define OL_INST(T)                                                                             \
   template hipError_t launch_raygen<T>(const RaygenDev&, const RaygenIn<T>&, int64_t,            \
                                        T* const[8], uint32_t*, hipStream_t);                    \

@@ -1247,6 +1247,19 @@ int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void
   return OL_OK;
 }
 
+int ol_stream_fill(void* dst, int64_t bytes, int32_t store_bytes, uint32_t pattern,
+                   void* stream) {
+  if (bytes < 0 || (bytes > 0 && !dst)) return fail(OL_EINVAL, "ol_stream_fill: bad buffer");
+  if (store_bytes != 4 && store_bytes != 8 && store_bytes != 16)
+    return fail(OL_EINVAL, "ol_stream_fill: store_bytes must be 4, 8 or 16");
+  if (bytes % store_bytes != 0 || (reinterpret_cast<uintptr_t>(dst) % store_bytes) != 0)
+    return fail(OL_EINVAL, "ol_stream_fill: buffer not a multiple of / aligned to store_bytes");
+  hipError_t e = ol::launch_stream_fill(dst, bytes, store_bytes, pattern,
+                                        static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(OL_EHIP, "fill launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
 int ol_spot_moments(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
                     const void* intensity, double* out6, void* stream) {
   if (!x || !y || !intensity || !out6) return fail(OL_EINVAL, "ol_spot_moments: NULL argument");

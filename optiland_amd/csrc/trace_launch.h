@@ -267,6 +267,10 @@ template <typename T>
 hipError_t launch_irradiance(int64_t n, const T* x, const T* y, const T* power,
                              const double* x_edges, int nx, const double* y_edges, int ny,
                              double* hist, hipStream_t stream);
+// write-only streaming yardstick (aux_kernels.hip; ol_stream_fill)
+hipError_t launch_stream_fill(void* dst, int64_t bytes, int width, uint32_t pattern,
+                              hipStream_t stream);
+
 template <typename T>
 hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten, double cx,
                               double cy, double* out1, hipStream_t stream);

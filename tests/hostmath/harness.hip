@@ -247,6 +247,14 @@ hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, hipStream
 template hipError_t launch_trace_generate<float>(const TraceArgs<float>&, int, hipStream_t);
 template hipError_t launch_trace_generate<double>(const TraceArgs<double>&, int, hipStream_t);
 
+// launch_stream_fill (aux_kernels.hip): the device kernel is a bandwidth yardstick; the
+// host stand-in just writes the pattern
+hipError_t launch_stream_fill(void* dst, int64_t bytes, int, uint32_t pattern, hipStream_t) {
+  uint32_t* p = static_cast<uint32_t*>(dst);
+  for (int64_t j = 0; j < bytes / 4; ++j) p[j] = pattern;
+  return hipSuccess;
+}
+
 // raygen_kernel + launch_raygen (aux_kernels.hip), ray by ray
 template <typename T>
 hipError_t launch_raygen(const RaygenDev& p, const RaygenIn<T>& in_, int64_t n, T* const out[8],

@@ -432,6 +432,99 @@ def test_config5_zernike_fresnel_polarised_full_size():
         hip.close()
 
 
+def _generated_subsample(table, res, n, idx, wl, polarized):
+    """Oracle trace of every `idx`-th ray of a GENERATING launch: its inputs are row 0 of
+    the launch's own record (the generated rays)."""
+    from oracle import oracle
+    row0 = res.record[0, :, :n]
+    sub = {k: row0[j][idx].double().cpu().numpy() for j, k in enumerate(PLANES[:7])}
+    return sub, oracle.trace(table, sub, wl, record=True, polarized=polarized)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.float64, 1e-9)],
+                         ids=["f32", "f64"])
+def test_config4_rc_asphere_full_size_generating_kernel(dtype, tol):
+    """C4 through the kernel `bench.py --workload rc_asphere` times:
+    `trace_kernel<T, 1, true, 0, kNrEvenAsphere, false, GEN>` (`ol_trace_generate`), 1e7 rays,
+    fp32 and fp64: every 997th ray on every surface against the oracle; the generated row 0
+    bit-equal to `ol_generate_rays`; the spot epilogue on the same launch (ABI 8) leaves the
+    record untouched and counts the surviving rays."""
+    from optiland_amd import load_system
+    from optiland_amd.engine import HipSystem
+    table = load_system("rc_asphere")
+    wl = table.wavelength_index(0.55)
+    hip = HipSystem(table, DEV)
+    try:
+        n, S = 10_000_000, table.num_traced
+        px, py = _pupil(n, 31, dtype)
+        res = hip.trace_generate(px, py, wl, field=(0.0, 1.0))
+        idx = torch.arange(0, n, 997, device=DEV)
+        _, want = _generated_subsample(table, res, n, idx, wl, False)
+        got = res.record[:, :, :n][:, :, idx].double().cpu().numpy()
+        assert_close_planes(got, want["record"], tol, tol, f"C4 generating {dtype}")
+        gen = hip.generate_rays(0.0, 1.0, px, py, 1.0, 1.0)
+        for k in range(7):
+            assert torch.equal(gen[k], res.record[0, k, :n]), PLANES[k]
+        del gen
+        slots = hip.alloc_spot_slots()
+        again = hip.trace_generate(px, py, wl, field=(0.0, 1.0), spot=(slots, 0.0, 0.0))
+        assert torch.equal(again.record[:, :, :n].nan_to_num(), res.record[:, :, :n].nan_to_num())
+        mom = hip.reduce_spot_slots(slots).cpu().numpy()
+        alive = res.row(S, 6) > 0
+        assert mom[0] == float(alive.sum()) and 0.5 * n < mom[0] < n
+    finally:
+        hip.close()
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype,tol,itol", [(torch.float32, 1e-4, 1e-4),
+                                            (torch.float64, 1e-9, 1e-9)], ids=["f32", "f64"])
+def test_config5_zernike_fresnel_full_size_generating_kernel_with_epilogue(dtype, tol, itol):
+    """C5 through the kernel `bench.py --workload zernike_fresnel` and the polarised
+    `Optic.trace` run: `trace_kernel<T, 1, true, 1, kNrZernike, false, GEN, EPI>`
+    (`ol_trace_generate` + the `update_intensity` epilogue), 1e7 rays, fp32 and fp64: every
+    997th ray against the oracle -- records, PRT matrices, and `i_updated` against
+    `oracle.polarized_intensity`."""
+    from optiland_amd import load_system
+    from optiland_amd.engine import HipSystem
+    from optiland_amd.rays import _state_dict, prt_to_complex
+    from oracle import oracle
+    table = load_system("zernike_fresnel_fringe")
+    wl = table.wavelength_index(0.55)
+    hip = HipSystem(table, DEV)
+    try:
+        n = 10_000_000
+        px, py = _pupil(n, 37, dtype)
+        prt = torch.empty((18 if table.needs_complex_prt else 9, n), dtype=dtype, device=DEV)
+        res = hip.trace_generate(px, py, wl, field=(0.0, 1.0), prt=prt,
+                                 update_intensity=_state_dict(table.polarization))
+        assert res.updated_intensity is not None
+        idx = torch.arange(0, n, 997, device=DEV)
+        sub, want = _generated_subsample(table, res, n, idx, wl, True)
+        got = res.record[:, :, :n][:, :, idx].double().cpu().numpy()
+        assert_close_planes(got, want["record"], tol, tol, f"C5 generating {dtype}")
+        p_got = prt_to_complex(prt[:, idx].contiguous()).cpu().numpy().astype(np.complex128)
+        p_want = want["prt"]
+        assert np.array_equal(np.isnan(p_got.real), np.isnan(p_want.real))
+        assert np.nanmax(np.abs(p_got - p_want)) < tol
+        i_want, status = oracle.polarized_intensity(want["prt"], sub["L"], sub["M"], sub["N"],
+                                                    sub["i"], table.polarization)
+        assert status == 0
+        i_got = res.updated_intensity[idx].double().cpu().numpy()
+        assert np.array_equal(np.isnan(i_got), np.isnan(i_want))
+        np.testing.assert_allclose(i_got, i_want, rtol=itol, atol=itol * 0.1)
+        # the epilogue equals the stand-alone launch on what this launch wrote
+        r0 = res.rows(0)
+        two = hip.polarized_intensity(prt, (r0[3], r0[4], r0[5]), r0[6], table.polarization)
+        fin = torch.isfinite(two)
+        assert bool(torch.equal(torch.isfinite(res.updated_intensity), fin))
+        err = (res.updated_intensity[fin] - two[fin]).abs().max()
+        assert float(err) < (2e-6 if dtype == torch.float32 else 1e-13)
+    finally:
+        hip.close()
+        torch.cuda.empty_cache()
+
+
 def test_config3_per_gpu_shard_full_size_fp64(dg):
     """C3: the 1.25e7-ray fp64 shard one of 8 GPUs traces (record-all, 10.4 GB): every
     997th ray against the oracle to 1e-9, and shard invariance -- the second half of the
