@@ -8,6 +8,17 @@
 
 #include "device_table.h"
 #include "trace_launch.h"
+#include "surface_math.h"  // Math<T>: the hardware reciprocal square root
+
+// OL_RAYGEN_RSQ (default on): the launch direction is normalised with ONE reciprocal square
+// root (v_rsq_f32; in fp64 the hardware seed + two refinement steps, Math<double>::rsqrt)
+// instead of an IEEE square root and three IEEE quotients -- 37 instead of 72 vector
+// instructions per generated ray in fp32, ~40 instead of ~150 in fp64, in every generating
+// kernel (trace, spot, OPD, the update_intensity epilogue regenerates the ray once more).
+// Within 2 ulp of the correctly rounded direction cosines.  A/B knob, tools/build_variants.py.
+#ifndef OL_RAYGEN_RSQ
+#define OL_RAYGEN_RSQ 1
+#endif
 
 namespace ol {
 
@@ -125,15 +136,26 @@ OL_DEV void raygen_one(const RaygenConsts<T>& c, T tx, T ty, T px, T py, T vx,
     z1 = c.EPL;
   }
   const T dx = x1 - x0, dy = y1 - y0, dz = z1 - z0;
-  T mag = sqrt(dx * dx + dy * dy + dz * dz);
-  const bool is_zero = mag < T(1e-9);  // paraxial.py:96-104
-  mag = is_zero ? T(1) : mag;
   o[0] = x0;
   o[1] = y0;
   o[2] = z0;
+#if OL_RAYGEN_RSQ
+  using m = Math<T>;
+  const T m2 = m::fma(dx, dx, m::fma(dy, dy, dz * dz));
+  // paraxial.py:96-104: mag < 1e-9  <=>  mag^2 < 1e-18 (NaN compares false either way)
+  const bool is_zero = m2 < T(1e-18);
+  const T inv = m::rsqrt(m2);
+  o[3] = is_zero ? T(0) : dx * inv;
+  o[4] = is_zero ? T(0) : dy * inv;
+  o[5] = is_zero ? T(1) : dz * inv;
+#else
+  T mag = sqrt(dx * dx + dy * dy + dz * dz);
+  const bool is_zero = mag < T(1e-9);  // paraxial.py:96-104
+  mag = is_zero ? T(1) : mag;
   o[3] = is_zero ? T(0) : dx / mag;
   o[4] = is_zero ? T(0) : dy / mag;
   o[5] = is_zero ? T(1) : dz / mag;
+#endif
 }
 
 }  // namespace ol

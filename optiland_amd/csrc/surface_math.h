@@ -1518,8 +1518,11 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         const T poison = (r[k].L + r[k].M + r[k].N) * T(0);  // 0, or NaN for a lost ray
+        // (a branch: the nine additions only run in waves that hold a lost ray)
+        if (poison != poison) {
 #pragma unroll
-        for (int e = 0; e < (POLK == 2 ? 18 : 9); ++e) P[k].m[e] += poison;
+          for (int e = 0; e < (POLK == 2 ? 18 : 9); ++e) P[k].m[e] += poison;
+        }
       }
       return;
     }
@@ -1534,6 +1537,9 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
           // coatings.py:72-92 + jones.py:71-117 with cos(aoi) = min(|n.k0|, 1):
           // root = sqrt(nn^2 - sin^2) is real unless TIR, where k1 is NaN already.
           T ci = adot[k] < T(1) ? adot[k] : (adot[k] >= T(1) ? T(1) : adot[k]);
+          // (root = nn cos(theta_t) could be taken from Snell's square root above, but keeping
+          // that value live to here costs the fp32 polarised Newton kernel its 7th wave: two
+          // VGPR spills to scratch, tools/kernel_probe.py)
           T root = m::sqrt(m::fma(nn, nn, m::fma(ci, ci, T(-1))));
           if (reflect) {
             j0 = m::div(ci - root, ci + root);

@@ -9,6 +9,16 @@
 
 #include "device_table.h"
 #include "trace_launch.h"
+#include "surface_math.h"  // Math<T>
+
+// OL_WAVEFRONT_FAST (default on): the reference-sphere intersection takes its square root
+// and its quotients from Math<T> (fp64: hardware seeds + two refinement steps, ~1 ulp; ONE
+// reciprocal of 2a serves both roots) instead of the IEEE library sequences -- in fp64 an
+// IEEE quotient is ~30 vector instructions and a square root ~30, and the fused OPD kernel
+// (every instance fp64) is bound by vector issue.  A/B knob, tools/build_variants.py.
+#ifndef OL_WAVEFRONT_FAST
+#define OL_WAVEFRONT_FAST 1
+#endif
 
 namespace ol {
 
@@ -29,6 +39,30 @@ OL_DEV T wavefront_one(const WavefrontConsts<T>& w, T xr, T yr, T zr, T Ld,
                                            T Md, T Nd, T opd_in, T px, T py, T (&pu)[3]) {
   const T L = -Ld, M = -Md, N = -Nd;  // trace backwards from the image
   T t;
+#if OL_WAVEFRONT_FAST
+  using m = Math<T>;
+  if (w.planar) {  // reference_geometry.py:104-124
+    const T num = (xr - w.xc) * w.nx + (yr - w.yc) * w.ny + (zr - w.zc) * w.nz;
+    T den = L * w.nx + M * w.ny + N * w.nz;
+    den = m::abs(den) < T(1e-12) ? T(1e-12) : den;
+    t = -m::div(num, den);
+  } else {
+    const T a = L * L + M * M + N * N;
+    const T b = T(2) * (L * (xr - w.xc) + M * (yr - w.yc) + N * (zr - w.zc));
+    const T c = xr * xr + yr * yr + zr * zr - T(2) * (xr * w.xc + yr * w.yc + zr * w.zc) +
+                w.xc * w.xc + w.yc * w.yc + w.zc * w.zc - w.R * w.R;
+    T d = b * b - T(4) * a * c;
+    d = d < T(0) ? T(0) : d;
+    const T sq = m::sqrt(d);
+    const T i2a = m::rcp(T(2) * a);
+    const T t1 = (-b - sq) * i2a, t2 = (-b + sq) * i2a;
+    t = t1 < T(0) ? t2 : t1;
+  }
+  const T opd_img = w.ni * t;
+  const T tilt = w.ux * (px * w.half_epd) + w.uy * (py * w.half_epd);
+  const T opd = opd_in - opd_img + tilt;
+  const T tt = m::div(opd_img, w.ni);
+#else
   if (w.planar) {  // reference_geometry.py:104-124
     const T num = (xr - w.xc) * w.nx + (yr - w.yc) * w.ny + (zr - w.zc) * w.nz;
     T den = L * w.nx + M * w.ny + N * w.nz;
@@ -49,6 +83,7 @@ OL_DEV T wavefront_one(const WavefrontConsts<T>& w, T xr, T yr, T zr, T Ld,
   const T tilt = w.ux * (px * w.half_epd) + w.uy * (py * w.half_epd);
   const T opd = opd_in - opd_img + tilt;
   const T tt = opd_img / w.ni;
+#endif
   pu[0] = xr - tt * Ld;
   pu[1] = yr - tt * Md;
   pu[2] = zr - tt * Nd;
