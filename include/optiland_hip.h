@@ -416,6 +416,14 @@ int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt,
                            const ol_polarization_state* state, void* intensity,
                            uint32_t* status, void* stream);
 
+/* ABI 8, diagnostics.  The kernels' arithmetic primitives applied element-wise on the
+ * device: op 0 = 1 / a, 1 = a / b, 2 = sqrt(a), 3 = 1 / sqrt(a), exactly as the trace kernels
+ * form them (fp32: v_rcp_f32 / v_sqrt_f32 / v_rsq_f32, 1 ulp; fp64: the hardware seeds
+ * refined by two Newton steps, ~1 ulp, IEEE special values except an infinite numerator /
+ * a denormal divisor).  For tests that pin those error bounds; b may be NULL unless op == 1. */
+int ol_math_probe(int32_t op, ol_dtype dt, int64_t n, const void* a, const void* b, void* out,
+                  void* stream);
+
 /* ABI 8, diagnostics.  Write-only streaming yardstick: fills `bytes` of device memory with
  * `pattern` using the non-temporal stores of the record-all trace kernels, `store_bytes`
  * (4, 8 or 16) per lane per store.  bench.py times it on a buffer the size of what the

@@ -9,6 +9,7 @@
 #include "wavefront_device.h"
 #include "epilogue_device.h"
 #include "trace_launch.h"
+#include "surface_math.h"
 
 namespace ol {
 
@@ -359,6 +360,43 @@ hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten,
                      inten, cx, cy, out1);
   return hipGetLastError();
 }
+
+// ol_math_probe: the kernels' own arithmetic primitives (Math<T>, surface_math.h) applied
+// element-wise -- lets the GPU tests hold the hardware-seed fp64 quotient / square root
+// (OL_FAST_F64) and the fp32 1-ulp instructions to their stated error bounds and to IEEE's
+// special values, on the device, outside any trace.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void math_probe_kernel(int op, int64_t n,
+                                                            const T* __restrict__ a,
+                                                            const T* __restrict__ b,
+                                                            T* __restrict__ out) {
+  using m = Math<T>;
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * kBlock) {
+    const T x = a[j], y = b ? b[j] : T(0);
+    T r;
+    switch (op) {
+      case 0: r = m::rcp(x); break;
+      case 1: r = m::div(x, y); break;
+      case 2: r = m::sqrt(x); break;
+      default: r = m::rsqrt(x); break;
+    }
+    out[j] = r;
+  }
+}
+
+template <typename T>
+hipError_t launch_math_probe(int op, int64_t n, const T* a, const T* b, T* out,
+                             hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL((math_probe_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, stream, op, n,
+                     a, b, out);
+  return hipGetLastError();
+}
+template hipError_t launch_math_probe<float>(int, int64_t, const float*, const float*, float*,
+                                             hipStream_t);
+template hipError_t launch_math_probe<double>(int, int64_t, const double*, const double*, double*,
+                                              hipStream_t);
 
 // Write-only streaming yardstick (ol_stream_fill): every lane stores WIDTH bytes per trip
 // with the same non-temporal stores the record-all kernels use (trace_kernel.hip:

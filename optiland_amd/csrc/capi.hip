@@ -259,7 +259,16 @@ struct ol_system {
   std::vector<int32_t> coating;
   std::vector<int32_t> geom;
   std::vector<uint8_t> polygon;  // surface uses a polygon aperture (top level or in a tree)
+  // false between the two in-place uploads of ol_system_update and for good if the second
+  // one fails: the fp32 and fp64 tables (and the host copies) then describe different
+  // prescriptions -- every entry point refuses such a system instead of tracing through it
+  bool consistent = true;
 };
+
+#define OL_CHECK_CONSISTENT(sys, who)                                                          \
+  if (!(sys)->consistent)                                                                      \
+    return fail(OL_EINVAL, who ": the system's tables are inconsistent after a failed "         \
+                               "ol_system_update (destroy it and create a new one)")
 
 namespace {
 
@@ -607,13 +616,13 @@ int ol_set_tuning(int32_t knob, int32_t value) {
 
 namespace {
 // argument validation + every host-side conversion of ol_system_create / ol_system_update
-int stage_system(const ol_surface_desc* surf, int32_t n_surf, const double* coeffs,
-                 int32_t n_coeffs, const ol_surface_optics* optics, int32_t n_wavelengths,
-                 Staged& st) {
-  if (!surf || n_surf <= 0) return fail(OL_EINVAL, "ol_system_create: no surfaces");
-  if (!optics || n_wavelengths <= 0) return fail(OL_EINVAL, "ol_system_create: no optics table");
+int stage_system(const char* who, const ol_surface_desc* surf, int32_t n_surf,
+                 const double* coeffs, int32_t n_coeffs, const ol_surface_optics* optics,
+                 int32_t n_wavelengths, Staged& st) {
+  if (!surf || n_surf <= 0) return fail(OL_EINVAL, "%s: no surfaces", who);
+  if (!optics || n_wavelengths <= 0) return fail(OL_EINVAL, "%s: no optics table", who);
   if (n_coeffs < 0 || (n_coeffs > 0 && !coeffs))
-    return fail(OL_EINVAL, "ol_system_create: bad coefficient buffer");
+    return fail(OL_EINVAL, "%s: bad coefficient buffer", who);
 
   st.surf.assign(n_surf, HostSurf());
   std::vector<HostSurf>& dev = st.surf;
@@ -833,7 +842,9 @@ int ol_system_create(const ol_surface_desc* surf, int32_t n_surf, const double* 
   if (!out) return fail(OL_EINVAL, "ol_system_create: out is NULL");
   *out = nullptr;
   Staged st;
-  if (int rc = stage_system(surf, n_surf, coeffs, n_coeffs, optics, n_wavelengths, st)) return rc;
+  if (int rc = stage_system("ol_system_create", surf, n_surf, coeffs, n_coeffs, optics,
+                            n_wavelengths, st))
+    return rc;
   ol_system* sys = new (std::nothrow) ol_system();
   if (!sys) return fail(OL_ENOMEM, "ol_system_create: out of host memory");
   sys->n_surf = n_surf;
@@ -864,7 +875,10 @@ int ol_system_update(ol_system* sys, const ol_surface_desc* surf, int32_t n_surf
                                  "system's %d x %d tables", n_surf, n_wavelengths, sys->n_surf,
                 sys->n_wl);
   Staged st;
-  if (int rc = stage_system(surf, n_surf, coeffs, n_coeffs, optics, n_wavelengths, st)) return rc;
+  if (int rc = stage_system("ol_system_update", surf, n_surf, coeffs, n_coeffs, optics,
+                            n_wavelengths, st))
+    return rc;
+  OL_CHECK_CONSISTENT(sys, "ol_system_update");
   const size_t need = st.coeffs.size() ? st.coeffs.size() : 1;
   if (need > sys->f32.coef_capacity || need > sys->f64.coef_capacity)
     return fail(OL_EUNSUPPORTED, "ol_system_update: coefficient block of %zu values exceeds the "
@@ -876,11 +890,15 @@ int ol_system_update(ol_system* sys, const ol_surface_desc* surf, int32_t n_surf
                              "device %d", cur, sys->device);
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int rc = upload<float>(st.surf, st.optics, st.coeffs, st.int_slots, sys->f32, true, s);
-  if (rc == OL_OK)
-    rc = upload<double>(st.surf, st.optics, st.coeffs, st.int_slots, sys->f64, true, s);
+  // the fp64 table first: if its copy fails nothing has changed yet and the system stays
+  // usable; only a failure of the SECOND copy leaves the two precisions apart
+  int rc = upload<double>(st.surf, st.optics, st.coeffs, st.int_slots, sys->f64, true, s);
+  if (rc != OL_OK) return rc;
+  sys->consistent = false;
+  rc = upload<float>(st.surf, st.optics, st.coeffs, st.int_slots, sys->f32, true, s);
   if (rc != OL_OK) return rc;
   adopt_host_copies(sys, st);
+  sys->consistent = true;
   return OL_OK;
 }
 
@@ -906,6 +924,7 @@ int ol_trace_ex(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const r
                 int32_t first_surface, int32_t last_surface, uint32_t flags, uint32_t* status,
                 const ol_trace_extras* extras, void* stream) {
   if (!sys) return fail(OL_EINVAL, "ol_trace: system is NULL");
+  OL_CHECK_CONSISTENT(sys, "ol_trace");
   if (dt != OL_F32 && dt != OL_F64) return fail(OL_EINVAL, "ol_trace: bad dtype %d", (int)dt);
   if (n_rays < 0) return fail(OL_EINVAL, "ol_trace: negative ray count");
   if (first_surface < 0 || last_surface >= sys->n_surf || first_surface > last_surface)
@@ -963,6 +982,7 @@ int ol_trace_generate(const ol_system* sys, ol_dtype dt, int64_t n_rays,
                       void* const rays_out[8], void* prt, uint32_t flags, uint32_t* status,
                       const ol_trace_extras* extras, void* stream) {
   if (!sys) return fail(OL_EINVAL, "ol_trace_generate: system is NULL");
+  OL_CHECK_CONSISTENT(sys, "ol_trace_generate");
   if (dt != OL_F32 && dt != OL_F64)
     return fail(OL_EINVAL, "ol_trace_generate: bad dtype %d", (int)dt);
   if (!p || !in) return fail(OL_EINVAL, "ol_trace_generate: NULL argument");
@@ -1044,6 +1064,7 @@ int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_ra
                   const ol_raygen_inputs* in, double cx, double cy, int32_t wavelength_index,
                   void* const hits[3], double* out7, uint32_t* status, void* stream) {
   if (!sys) return fail(OL_EINVAL, "ol_trace_spot: system is NULL");
+  OL_CHECK_CONSISTENT(sys, "ol_trace_spot");
   if (dt != OL_F32 && dt != OL_F64) return fail(OL_EINVAL, "ol_trace_spot: bad dtype %d", (int)dt);
   if (!p || !in || !out7) return fail(OL_EINVAL, "ol_trace_spot: NULL argument");
   if (hits && (!hits[0] || !hits[1] || !hits[2]))
@@ -1187,6 +1208,7 @@ int ol_trace_opd(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_ray
                  int32_t wavelength_index, void* opd_waves, void* intensity,
                  void* const pupil[3], double* moments12, uint32_t* status, void* stream) {
   if (!sys) return fail(OL_EINVAL, "ol_trace_opd: system is NULL");
+  OL_CHECK_CONSISTENT(sys, "ol_trace_opd");
   if (dt != OL_F64)
     return fail(dt == OL_F32 ? OL_EUNSUPPORTED : OL_EINVAL,
                 "ol_trace_opd: wavefront work is fp64 only (dtype %d)", (int)dt);
@@ -1244,6 +1266,26 @@ int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void
   else
     return fail(OL_EINVAL, "ol_pupil_fill: bad dtype %d", (int)dt);
   if (e != hipSuccess) return fail(OL_EHIP, "launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
+int ol_math_probe(int32_t op, ol_dtype dt, int64_t n, const void* a, const void* b, void* out,
+                  void* stream) {
+  if (op < 0 || op > 3) return fail(OL_EINVAL, "ol_math_probe: op must be 0..3");
+  if (n < 0 || (n > 0 && (!a || !out || (op == 1 && !b))))
+    return fail(OL_EINVAL, "ol_math_probe: NULL argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (dt == OL_F32)
+    e = ol::launch_math_probe<float>(op, n, static_cast<const float*>(a),
+                                     static_cast<const float*>(b), static_cast<float*>(out), st);
+  else if (dt == OL_F64)
+    e = ol::launch_math_probe<double>(op, n, static_cast<const double*>(a),
+                                      static_cast<const double*>(b), static_cast<double*>(out),
+                                      st);
+  else
+    return fail(OL_EINVAL, "ol_math_probe: bad dtype %d", (int)dt);
+  if (e != hipSuccess) return fail(OL_EHIP, "probe launch failed: %s", hipGetErrorString(e));
   return OL_OK;
 }
 

@@ -49,15 +49,22 @@ OL_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 // square root) -- lengths, cosines and optical paths are nowhere near those ends, and the
 // fused fp64 kernels (spot, OPD: the wavefront path) are bound by vector issue, with two
 // square roots and two quotients per conic surface.
+// v_cmp_class masks: bit 2 -inf, 5 -0, 6 +0, 9 +inf
+constexpr int kClassZeroOrInf = 0x264;  // +-0 | +-inf
 OL_DEV double rcp_f64(double x) {
   const double y0 = __builtin_amdgcn_rcp(x);
   double e = __builtin_fma(-x, y0, 1.0);
   double y = __builtin_fma(y0, e, y0);
   e = __builtin_fma(-x, y, 1.0);
   y = __builtin_fma(y, e, y);
-  // x = 0 / inf: the seed IS the answer (inf / 0), the refinement would make it NaN
-  return __builtin_amdgcn_class(x, 0x260) ? y0 : y;   // +-0 | +-inf
+  // x = +-0 / +-inf: the seed IS the answer (+-inf / +-0), the refinement would make it NaN
+  return __builtin_amdgcn_class(x, kClassZeroOrInf) ? y0 : y;
 }
+// Not IEEE in two corners, both outside anything a trace forms (lengths, cosines, optical
+// paths): an INFINITE numerator with a finite divisor gives NaN (the residual is inf - inf),
+// and a DENORMAL divisor whose seed overflows gives NaN instead of inf.  Catching them costs
+// two more v_cmp_class per quotient in kernels that are bound by vector issue; the
+// hostmath / GPU edge-case tests pin the behaviour (tests/test_gpu_hostmath.py).
 OL_DEV double div_f64(double a, double b) {
   const double y0 = __builtin_amdgcn_rcp(b);
   double e = __builtin_fma(-b, y0, 1.0);
@@ -67,7 +74,7 @@ OL_DEV double div_f64(double a, double b) {
   const double q = a * y;
   const double r = __builtin_fma(-b, q, a);
   const double refined = __builtin_fma(r, y, q);
-  return __builtin_amdgcn_class(b, 0x260) ? a * y0 : refined;
+  return __builtin_amdgcn_class(b, kClassZeroOrInf) ? a * y0 : refined;
 }
 OL_DEV double sqrt_f64(double x) {
   const double y = __builtin_amdgcn_rsq(x);
@@ -79,7 +86,7 @@ OL_DEV double sqrt_f64(double x) {
   g = __builtin_fma(d, h, g);
   // sqrt(+-0) = +-0, sqrt(+inf) = +inf (0 * inf above); negative / NaN arguments are NaN
   // through the seed already
-  return __builtin_amdgcn_class(x, 0x260) ? x : g;
+  return __builtin_amdgcn_class(x, 0x260) ? x : g;   // +-0 | +inf (-inf: NaN via the seed)
 }
 OL_DEV double rsq_f64(double x) {
   const double y0 = __builtin_amdgcn_rsq(x);
@@ -89,6 +96,7 @@ OL_DEV double rsq_f64(double x) {
   double y = __builtin_fma(y0, e, y0);
   e = __builtin_fma(-hx * y, y, 0.5);
   y = __builtin_fma(y, e, y);
+  // +-0 (seed +-inf) and +inf (seed 0): the seed is the answer; -inf: NaN through the seed
   return __builtin_amdgcn_class(x, 0x260) ? y0 : y;
 }
 OL_DEV float exp(float x) { return __expf(x); }

@@ -661,7 +661,16 @@ def _make_tracer_class():
                 old_key = old_memo[2] if old_memo is not None else None
                 old = self._hip_engines.get(old_key) if isinstance(old_key, tuple) else None
                 upd = getattr(old[0], "update", None) if old is not None else None
-                if upd is not None and upd(table):
+                try:
+                    patched = upd is not None and upd(table)
+                except Exception:
+                    # a failed in-place update (ol_system_update) may have left the engine's
+                    # tables behind the prescription: it must not stay cached under its key
+                    self._hip_engines.pop(old_key, None)
+                    if hasattr(old[0], "close"):
+                        old[0].close()
+                    patched = False
+                if patched:
                     del self._hip_engines[old_key]
                     for front in old[2].values():  # same engine, new prescription
                         front.rebind(table)

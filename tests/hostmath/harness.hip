@@ -247,6 +247,21 @@ hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, hipStream
 template hipError_t launch_trace_generate<float>(const TraceArgs<float>&, int, hipStream_t);
 template hipError_t launch_trace_generate<double>(const TraceArgs<double>&, int, hipStream_t);
 
+// launch_math_probe (aux_kernels.hip): the host run of Math<T> (IEEE operations)
+template <typename T>
+hipError_t launch_math_probe(int op, int64_t n, const T* a, const T* b, T* out, hipStream_t) {
+  using m = Math<T>;
+  for (int64_t j = 0; j < n; ++j) {
+    const T x = a[j], y = b ? b[j] : T(0);
+    out[j] = op == 0 ? m::rcp(x) : (op == 1 ? m::div(x, y) : (op == 2 ? m::sqrt(x) : m::rsqrt(x)));
+  }
+  return hipSuccess;
+}
+template hipError_t launch_math_probe<float>(int, int64_t, const float*, const float*, float*,
+                                             hipStream_t);
+template hipError_t launch_math_probe<double>(int, int64_t, const double*, const double*, double*,
+                                              hipStream_t);
+
 // launch_stream_fill (aux_kernels.hip): the device kernel is a bandwidth yardstick; the
 // host stand-in just writes the pattern
 hipError_t launch_stream_fill(void* dst, int64_t bytes, int, uint32_t pattern, hipStream_t) {
