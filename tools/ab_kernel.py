@@ -25,6 +25,11 @@ ap.add_argument("--mode", default="record", choices=("record", "last", "spot", "
 ap.add_argument("--rays", type=float, default=1e7)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--sustained", action="store_true",
+                help="queue every launch back to back (no host sync in between) and report the "
+                     "steady state: the part's power management needs ~100 ms of sustained "
+                     "load to settle (profiles/r04_clock_transient.txt); use with "
+                     "--warmup 150 --steps 60")
 a = ap.parse_args()
 if a.mode == "opd":
     a.dtype = "f64"
@@ -86,12 +91,24 @@ else:
         e1.record()
 
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for _ in range(a.warmup):
-    step()
-ts = []
-for _ in range(a.steps):
-    step()
+if a.sustained:
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+             for _ in range(a.warmup + a.steps)]
+    for e0, e1 in pairs:
+        step()
     torch.cuda.synchronize(dev)
-    ts.append(e0.elapsed_time(e1))
-print(f"kernel_ms={np.mean(ts):.4f} min={np.min(ts):.4f}")
+    ts = [p0.elapsed_time(p1) for p0, p1 in pairs[a.warmup:]]
+    head = [p0.elapsed_time(p1) for p0, p1 in pairs[:a.warmup]]
+    print(f"kernel_ms={np.mean(ts):.4f} min={np.min(ts):.4f} median={np.median(ts):.4f} "
+          f"max={np.max(ts):.4f} first5={np.mean(head[1:6]) if len(head) > 6 else float('nan'):.4f} "
+          f"trough={np.max(head) if head else float('nan'):.4f}")
+else:
+    for _ in range(a.warmup):
+        step()
+    ts = []
+    for _ in range(a.steps):
+        step()
+        torch.cuda.synchronize(dev)
+        ts.append(e0.elapsed_time(e1))
+    print(f"kernel_ms={np.mean(ts):.4f} min={np.min(ts):.4f}")
 hip.close()

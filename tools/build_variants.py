@@ -68,6 +68,9 @@ VARIANTS = {
     # fp32 unrolled Zernike polynomial through the 8-dword window (as fp64) instead of as two
     # blocks (sag, then gradient)
     "zmono_window32": ["-DOL_ZERN_MONO_F32_TWO_BLOCKS=0"],
+    # round 4: IEEE square root + quotients in the ray generator and the reference-sphere
+    # intersection (the round-3 form) instead of the hardware reciprocal square root / seeds
+    "raygen_ieee": ["-DOL_RAYGEN_RSQ=0", "-DOL_WAVEFRONT_FAST=0"],
 }
 
 
