@@ -340,14 +340,16 @@ def traffic_meta() -> dict:
         return {}
 
 
-def stream_fill_bandwidth(hip, device, nbytes, store_bytes, reps=6):
-    """GB/s of `ol_stream_fill` over a buffer of `nbytes` (the write footprint of the trace
-    launch): a kernel that ONLY writes, with the trace kernels' own non-temporal stores of
-    `store_bytes` per lane -- timed in THIS run, on this box.  A footprint far beyond the
-    256 MB Infinity Cache is what makes it a yardstick for the record-all kernels (a 1 GiB
-    fill still drains its tail into the cache and reads ~25 % high)."""
+def stream_fill_bandwidth(hip, device, nbytes, store_bytes, planes, reps=6):
+    """GB/s of `ol_stream_fill` over a buffer of `nbytes` in `planes` planes (the write
+    footprint and store pattern of the trace launch): a kernel that ONLY writes, every lane
+    one element of `store_bytes` into each plane with the trace kernels' own non-temporal
+    stores -- timed in THIS run, on this box.  A footprint far beyond the 256 MB Infinity
+    Cache is what makes it a yardstick for the record-all kernels (a 1 GiB fill still drains
+    its tail into the cache and reads ~25 % high)."""
     import ctypes as C
-    nbytes = int(nbytes) // 16 * 16
+    unit = int(store_bytes) * int(planes)
+    nbytes = int(nbytes) // unit * unit
     if nbytes <= 0 or not hasattr(hip.lib, "ol_stream_fill"):
         return None
     buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -357,7 +359,7 @@ def stream_fill_bandwidth(hip, device, nbytes, store_bytes, reps=6):
         if k == 2:
             e0.record()
         rc = hip.lib.ol_stream_fill(C.c_void_p(buf.data_ptr()), nbytes, int(store_bytes),
-                                    0x3f800000, stream)
+                                    int(planes), 0x3f800000, stream)
         if rc != 0:
             return None
     e1.record()
@@ -833,7 +835,8 @@ def main():
         written = moved_bytes - (2 * b * n if (gen or spot) else 8 * b * n)
         fill_big = None
         if bw is not None and args.mode in ("record", "gen") and written >= (1 << 28):
-            fill_big = stream_fill_bandwidth(hip, device, min(written, 16 << 30), b)
+            fill_big = stream_fill_bandwidth(hip, device, min(written, 16 << 30), b,
+                                             max(int(round(written / (b * n))), 1))
         if steady is not None:
             steady["achieved"] = moved_bytes / (steady["kernel_ms"] * 1e-3) / 1e9
             steady["frac"] = steady["achieved"] / HBM_PEAK_GBS
@@ -914,12 +917,10 @@ def main():
                          "frac_algorithmic credits SURVEY 8d's figure (the object row the ray "
                          "generator wrote into the record block outside the timed region and, "
                          "for polarised runs, the PRT read a fresh trace never does); "
-                         "frac_of_write_ceiling = moved GB/s over `ol_stream_fill` -- a kernel "
-                         "that only writes, same non-temporal store width, over a buffer the "
-                         "size of this launch's own write footprint, timed in this run; it can "
-                         "exceed 1 by a few per cent because the trace launch's last "
-                         "~256 MB drain into the Infinity Cache while the next launch "
-                         "starts, which back-to-back fills of the same buffer cannot do; "
+                         "frac_of_write_ceiling = moved GB/s over `ol_stream_fill` -- this "
+                         "launch's own store pattern (as many planes, one non-temporal store "
+                         "of the same width per lane and plane, the same footprint) with the "
+                         "arithmetic taken out, timed in this run; "
                          "steady_state = the same launch after the clock transient of the "
                          "first ~100 ms (outside the reported region)"),
             },

@@ -416,6 +416,23 @@ int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt,
                            const ol_polarization_state* state, void* intensity,
                            uint32_t* status, void* stream);
 
+/* ABI 8.  The reference's deterministic pupil samplers (optiland/distribution.py:161-220) on
+ * the device, one point per lane from its index: no host sampling pass and no upload in front
+ * of the first trace of a `num_rays` / distribution pair (1e7 hexapolar points: ~0.1 s of
+ * NumPy + an 80 MB copy before).  Same values in the same ORDER as the reference's samplers
+ * (fp64 arithmetic as NumPy's, then rounded to the ray dtype; cos / sin are the device libm's:
+ * <= 1 ulp from NumPy's in fp64).
+ *   OL_PUPIL_HEXAPOLAR  param = number of rings R; n_points must be 1 + 3 R (R + 1)
+ *   OL_PUPIL_UNIFORM    param = grid side n (>= 2); the disc mask comes from the caller as
+ *                       two DEVICE tables: row_first[n] = first kept column of row j,
+ *                       row_offset[n + 1] = index of row j's first point (row_offset[n] =
+ *                       n_points); both NULL for the hexapolar sampler                     */
+#define OL_PUPIL_HEXAPOLAR 0
+#define OL_PUPIL_UNIFORM 1
+int ol_pupil_points(int32_t kind, int32_t param, ol_dtype dt, int64_t n_points,
+                    const int32_t* row_first, const int64_t* row_offset, void* x, void* y,
+                    void* stream);
+
 /* ABI 8, diagnostics.  The kernels' arithmetic primitives applied element-wise on the
  * device: op 0 = 1 / a, 1 = a / b, 2 = sqrt(a), 3 = 1 / sqrt(a), exactly as the trace kernels
  * form them (fp32: v_rcp_f32 / v_sqrt_f32 / v_rsq_f32, 1 ulp; fp64: the hardware seeds
@@ -424,13 +441,14 @@ int ol_polarized_intensity(ol_dtype dt, int64_t n_rays, const void* prt,
 int ol_math_probe(int32_t op, ol_dtype dt, int64_t n, const void* a, const void* b, void* out,
                   void* stream);
 
-/* ABI 8, diagnostics.  Write-only streaming yardstick: fills `bytes` of device memory with
- * `pattern` using the non-temporal stores of the record-all trace kernels, `store_bytes`
- * (4, 8 or 16) per lane per store.  bench.py times it on a buffer the size of what the
- * trace launch writes: the ceiling a kernel that only writes reaches on this part for that
- * footprint, next to the 8 TB/s of the data sheet.                                        */
-int ol_stream_fill(void* dst, int64_t bytes, int32_t store_bytes, uint32_t pattern,
-                   void* stream);
+/* ABI 8, diagnostics.  Write-only streaming yardstick: the store pattern of a record-all
+ * trace launch with the arithmetic taken out.  `dst` is viewed as `planes` planes of
+ * bytes / planes each; every lane stores ONE element of `store_bytes` (4, 8 or 16) into each
+ * plane with the non-temporal stores of the trace kernels.  bench.py times it on a buffer the
+ * size and shape of what the trace launch writes: the ceiling a kernel that only writes
+ * reaches on this part for that footprint, next to the 8 TB/s of the data sheet.        */
+int ol_stream_fill(void* dst, int64_t bytes, int32_t store_bytes, int32_t planes,
+                   uint32_t pattern, void* stream);
 
 /* Image-plane reductions for one ray block (analysis/spot_diagram/core.py:
  * 329-372): out[0..5] += {sum w, sum w x, sum w y, sum w x^2, sum w y^2,

@@ -120,6 +120,7 @@ EXPORTS = (
     "ol_system_update",
     "ol_stream_fill",
     "ol_math_probe",
+    "ol_pupil_points",
 )
 
 F32, F64 = 0, 1
@@ -217,10 +218,12 @@ def bind(lib, path: str = "?"):
     lib.ol_trace_generate.restype = C.c_int
     lib.ol_trace_generate.argtypes = [vp, C.c_int, i64, vp, vp, i32, vp, i64, C.POINTER(vp), vp,
                                       u32, vp, vp, vp]
+    lib.ol_pupil_points.restype = C.c_int
+    lib.ol_pupil_points.argtypes = [i32, i32, C.c_int, i64, vp, vp, vp, vp, vp]
     lib.ol_math_probe.restype = C.c_int
     lib.ol_math_probe.argtypes = [i32, C.c_int, i64, vp, vp, vp, vp]
     lib.ol_stream_fill.restype = C.c_int
-    lib.ol_stream_fill.argtypes = [vp, i64, i32, u32, vp]
+    lib.ol_stream_fill.argtypes = [vp, i64, i32, i32, u32, vp]
     return lib
 
 

@@ -351,49 +351,95 @@ def _fft_pad_pupils(self):
 
 
 # --------------------------------------------------------------------------- (de)activate
+# The seams replace PRIVATE methods of the reference.  Each entry: key in _ORIG -> (module,
+# class, method, the parameter names the replacement was written against, replacement).  A
+# seam is only installed when the reference's method still has exactly that signature: a
+# release that renames a parameter, adds one or drops the method leaves that seam OFF (the
+# analysis then runs the reference's own code on top of the drop-in's `Optic.trace`) instead
+# of silently losing half of a fast path.  Seams that only work as a pair are installed
+# together or not at all (`_GROUPS`).  What was skipped is listed in `SKIPPED`.
+_SEAMS = {
+    "wavefront_data": ("optiland.wavefront.wavefront", "Wavefront", "_generate_data",
+                       ("self",), "_wavefront_generate_data"),
+    "spot": ("optiland.analysis.spot_diagram.core", "SpotDiagram", "_generate_field_data",
+             ("self", "field", "wavelength", "num_rays", "distribution", "coordinates"),
+             "_spot_generate_field_data"),
+    "spot_data": ("optiland.analysis.spot_diagram.core", "SpotDiagram", "_generate_data",
+                  ("self",), "_spot_generate_data"),
+    "ee": ("optiland.analysis.encircled_energy", "EncircledEnergy", "_generate_field_data",
+           ("self", "field", "wavelength", "num_rays", "distribution", "coordinates"),
+           "_ee_generate_field_data"),
+    "opd": ("optiland.wavefront.strategy", "ChiefRayStrategy", "compute_wavefront_data",
+            ("self", "field", "wavelength"), "_chief_compute_wavefront_data"),
+    "chief_init": ("optiland.wavefront.strategy", "ChiefRayStrategy", "__init__",
+                   ("self", "optic", "distribution", "kwargs"), "_chief_init"),
+    "pupils": ("optiland.psf.fft", "ScalarFFTPSF", "_generate_pupils", ("self",),
+               "_fft_generate_pupils"),
+    "pad": ("optiland.psf.fft", "ScalarFFTPSF", "_pad_pupils", ("self",), "_fft_pad_pupils"),
+}
+# (dependent seams ..., the seam they need): the FFT-PSF pair scatters the OPD seam's device data
+_GROUPS = (("pupils", "pad", "opd"),)
+SKIPPED: dict = {}                      # key -> why the seam was not installed
+
+
+def _resolve(key):
+    """(class, current method) of a seam, or a reason (str) why it cannot be installed."""
+    import importlib
+    import inspect
+
+    mod, cls_name, meth, params, _ = _SEAMS[key]
+    try:
+        cls = getattr(importlib.import_module(mod), cls_name)
+    except (ImportError, AttributeError) as exc:
+        return f"{mod}.{cls_name} not found ({exc})"
+    fn = cls.__dict__.get(meth)
+    if fn is None:
+        return f"{cls_name}.{meth} is not defined on the class"
+    try:
+        have = tuple(inspect.signature(fn).parameters)
+    except (TypeError, ValueError) as exc:
+        return f"{cls_name}.{meth}: no signature ({exc})"
+    if have != params:
+        return f"{cls_name}.{meth}{have} is not the {params} this seam was written against"
+    return cls, fn
+
+
 def enable():
     """Patch the reference classes (idempotent).  Safe class-wide: each call falls back to
-    the original method unless the optic it concerns is served by the drop-in."""
+    the original method unless the optic it concerns is served by the drop-in.  Seams whose
+    target no longer has the signature they were written against are left off (`SKIPPED`)."""
     if _ORIG:
         return
-    from optiland.analysis.encircled_energy import EncircledEnergy
-    from optiland.analysis.spot_diagram.core import SpotDiagram
-    from optiland.psf.fft import ScalarFFTPSF
-    from optiland.wavefront.strategy import ChiefRayStrategy
-    from optiland.wavefront.wavefront import Wavefront
-
-    _ORIG.update(wavefront_data=Wavefront._generate_data)
-    Wavefront._generate_data = _wavefront_generate_data
-    _ORIG.update(spot=SpotDiagram._generate_field_data, spot_data=SpotDiagram._generate_data,
-                 ee=EncircledEnergy._generate_field_data,
-                 opd=ChiefRayStrategy.compute_wavefront_data,
-                 chief_init=ChiefRayStrategy.__init__,
-                 pupils=ScalarFFTPSF._generate_pupils, pad=ScalarFFTPSF._pad_pupils)
-    SpotDiagram._generate_field_data = _spot_generate_field_data
-    SpotDiagram._generate_data = _spot_generate_data
-    EncircledEnergy._generate_field_data = _ee_generate_field_data
-    ChiefRayStrategy.compute_wavefront_data = _chief_compute_wavefront_data
-    ChiefRayStrategy.__init__ = _chief_init
-    ScalarFFTPSF._generate_pupils = _fft_generate_pupils
-    ScalarFFTPSF._pad_pupils = _fft_pad_pupils
+    SKIPPED.clear()
+    found = {}
+    for key in _SEAMS:
+        got = _resolve(key)
+        if isinstance(got, str):
+            SKIPPED[key] = got
+        else:
+            found[key] = got
+    for *dependents, needs in _GROUPS:
+        missing = [k for k in (*dependents, needs) if k not in found]
+        if missing:   # the dependent seams go together; the one they depend on may stay
+            for k in dependents:
+                if found.pop(k, None) is not None:
+                    SKIPPED[k] = (f"needs {missing[0]}: "
+                                  f"{SKIPPED.get(missing[0], 'not installed')}")
+    for key, (cls, fn) in found.items():
+        _ORIG[key] = fn
+        setattr(cls, _SEAMS[key][2], globals()[_SEAMS[key][4]])
+    if not _ORIG:
+        _ORIG["_none"] = None   # (enable() stays idempotent even if nothing could be patched)
 
 
 def disable():
     if not _ORIG:
         return
-    from optiland.analysis.encircled_energy import EncircledEnergy
-    from optiland.analysis.spot_diagram.core import SpotDiagram
-    from optiland.psf.fft import ScalarFFTPSF
-    from optiland.wavefront.strategy import ChiefRayStrategy
+    import importlib
 
-    SpotDiagram._generate_field_data = _ORIG["spot"]
-    SpotDiagram._generate_data = _ORIG["spot_data"]
-    from optiland.wavefront.wavefront import Wavefront
-
-    Wavefront._generate_data = _ORIG["wavefront_data"]
-    EncircledEnergy._generate_field_data = _ORIG["ee"]
-    ChiefRayStrategy.compute_wavefront_data = _ORIG["opd"]
-    ChiefRayStrategy.__init__ = _ORIG["chief_init"]
-    ScalarFFTPSF._generate_pupils = _ORIG["pupils"]
-    ScalarFFTPSF._pad_pupils = _ORIG["pad"]
+    for key, fn in _ORIG.items():
+        if key == "_none":
+            continue
+        mod, cls_name, meth, _params, _ = _SEAMS[key]
+        setattr(getattr(importlib.import_module(mod), cls_name), meth, fn)
     _ORIG.clear()

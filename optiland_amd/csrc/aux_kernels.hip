@@ -361,6 +361,93 @@ hipError_t launch_spot_max_r2(int64_t n, const T* x, const T* y, const T* inten,
   return hipGetLastError();
 }
 
+// ol_pupil_points: the deterministic pupil samplers on the device (distribution.py:161-220
+// of the reference: "hexapolar", "uniform"), one point per lane from its INDEX -- no host
+// sampling pass, no upload.  Values are formed in fp64 exactly as the reference's NumPy code
+// forms them (the same products and sums, no contraction) and then rounded to T; the one
+// thing that is not NumPy's is the libm behind cos / sin (<= 1 ulp apart in fp64; after
+// rounding to fp32 the planes agree bit for bit but for ~1 value in 1e8).
+//   hexapolar(R): point 0 = the centre; ring i = 1..R holds 6 i points at radius
+//     linspace(0, 1, R + 1)[i] = i * (1 / R) (the last one exactly 1) and azimuth
+//     j * (2 pi / (6 i)).  Ring of point p (q = p - 1): the largest i with 3 i (i - 1) <= q,
+//     from an fp64 square root corrected by integer arithmetic.
+//   uniform(n): the n x n grid linspace(-1, 1, n)^2 masked to the unit disc, row-major.  The
+//     mask is evaluated by the caller (the reference's own x^2 + y^2 <= 1 on the same
+//     squares): row j keeps the columns [first[j], first[j] + offset[j + 1] - offset[j]);
+//     the lane finds its row by bisection of `offset` (n + 1 entries, L2-resident).
+namespace {
+__device__ __forceinline__ double linspace_at(int64_t i, int64_t last, double start, double stop,
+                                              double step) {
+  // numpy.linspace: y = arange(num) * step + start (two roundings), y[-1] = stop
+#pragma clang fp contract(off)
+  const double v = (double)i * step;
+  return i == last ? stop : v + start;
+}
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pupil_hexapolar_kernel(int32_t rings, int64_t n,
+                                                                 T* __restrict__ x,
+                                                                 T* __restrict__ y) {
+#pragma clang fp contract(off)
+  const double step = 1.0 / (double)rings;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n;
+       p += (int64_t)gridDim.x * kBlock) {
+    if (p == 0) {
+      x[0] = T(0);
+      y[0] = T(0);
+      continue;
+    }
+    const int64_t q = p - 1;
+    int64_t i = (int64_t)((3.0 + sqrt(9.0 + 12.0 * (double)q)) / 6.0);
+    while (3 * i * (i - 1) > q) --i;
+    while (3 * (i + 1) * i <= q) ++i;
+    const int64_t j = q - 3 * i * (i - 1);
+    const double theta = (double)j * (6.283185307179586 / (double)(6 * i));
+    const double r = linspace_at(i, rings, 0.0, 1.0, step);
+    x[p] = (T)(r * cos(theta));
+    y[p] = (T)(r * sin(theta));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void pupil_uniform_kernel(int32_t side, int64_t n,
+                                                               const int32_t* __restrict__ first,
+                                                               const int64_t* __restrict__ offset,
+                                                               T* __restrict__ x,
+                                                               T* __restrict__ y) {
+#pragma clang fp contract(off)
+  const double step = 2.0 / (double)(side - 1);
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n;
+       p += (int64_t)gridDim.x * kBlock) {
+    int lo = 0, hi = side;  // invariant: offset[lo] <= p < offset[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (offset[mid] <= p) lo = mid; else hi = mid;
+    }
+    const int64_t col = (int64_t)first[lo] + (p - offset[lo]);
+    x[p] = (T)linspace_at(col, side - 1, -1.0, 1.0, step);
+    y[p] = (T)linspace_at(lo, side - 1, -1.0, 1.0, step);
+  }
+}
+
+template <typename T>
+hipError_t launch_pupil_points(int kind, int32_t param, int64_t n, const int32_t* first,
+                               const int64_t* offset, T* x, T* y, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  if (kind == 0)
+    hipLaunchKernelGGL((pupil_hexapolar_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, stream,
+                       param, n, x, y);
+  else
+    hipLaunchKernelGGL((pupil_uniform_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, stream,
+                       param, n, first, offset, x, y);
+  return hipGetLastError();
+}
+template hipError_t launch_pupil_points<float>(int, int32_t, int64_t, const int32_t*,
+                                               const int64_t*, float*, float*, hipStream_t);
+template hipError_t launch_pupil_points<double>(int, int32_t, int64_t, const int32_t*,
+                                                const int64_t*, double*, double*, hipStream_t);
+
 // ol_math_probe: the kernels' own arithmetic primitives (Math<T>, surface_math.h) applied
 // element-wise -- lets the GPU tests hold the hardware-seed fp64 quotient / square root
 // (OL_FAST_F64) and the fp32 1-ulp instructions to their stated error bounds and to IEEE's
@@ -398,37 +485,42 @@ template hipError_t launch_math_probe<float>(int, int64_t, const float*, const f
 template hipError_t launch_math_probe<double>(int, int64_t, const double*, const double*, double*,
                                               hipStream_t);
 
-// Write-only streaming yardstick (ol_stream_fill): every lane stores WIDTH bytes per trip
-// with the same non-temporal stores the record-all kernels use (trace_kernel.hip:
-// store_plane), grid-stride over the buffer.  What a kernel that ONLY writes sustains on this
-// part for a given footprint -- the ceiling the record-all kernels are held against.
+// Write-only streaming yardstick (ol_stream_fill): the STORE PATTERN of a record-all trace
+// launch with the arithmetic taken out -- the buffer is `planes` planes of n elements, every
+// lane stores ONE element of WIDTH bytes into each plane (the same non-temporal stores,
+// trace_kernel.hip: store_plane; one workgroup per 256 consecutive elements, like the trace
+// kernels).  What a kernel that ONLY writes sustains on this part for that footprint and
+// that pattern: the ceiling the record-all kernels are held against.  (A linear one-store-
+// per-lane fill of the same bytes is bound by wave launch rate instead: 4.6-4.8 TB/s.)
 template <typename V>
 __global__ __launch_bounds__(kBlock) void stream_fill_kernel(V* __restrict__ dst, int64_t n,
+                                                             int64_t stride, int planes,
                                                              V value) {
-  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
-       j += (int64_t)gridDim.x * kBlock)
-    __builtin_nontemporal_store(value, dst + j);
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n) return;
+  V* p = dst + j;
+  for (int k = 0; k < planes; ++k, p += stride) __builtin_nontemporal_store(value, p);
 }
 
-hipError_t launch_stream_fill(void* dst, int64_t bytes, int width, uint32_t pattern,
+hipError_t launch_stream_fill(void* dst, int64_t bytes, int width, int planes, uint32_t pattern,
                               hipStream_t stream) {
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   if (bytes <= 0) return hipSuccess;
-  const int64_t n = bytes / width;
-  // one element per lane per trip, as many workgroups as the trace kernels launch for
-  // the same number of elements (capped: grid-stride beyond)
-  int64_t blocks = (n + kBlock - 1) / kBlock;
-  if (blocks > (1 << 22)) blocks = 1 << 22;
+  if (planes < 1) planes = 1;
+  const int64_t n = bytes / width / planes;  // elements per plane
+  if (n <= 0) return hipSuccess;
+  const int64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   if (width == 4)
     hipLaunchKernelGGL((stream_fill_kernel<uint32_t>), dim3((unsigned)blocks), dim3(kBlock), 0,
-                       stream, static_cast<uint32_t*>(dst), n, pattern);
+                       stream, static_cast<uint32_t*>(dst), n, n, planes, pattern);
   else if (width == 8)
     hipLaunchKernelGGL((stream_fill_kernel<u32x2>), dim3((unsigned)blocks), dim3(kBlock), 0,
-                       stream, static_cast<u32x2*>(dst), n, u32x2{pattern, pattern});
+                       stream, static_cast<u32x2*>(dst), n, n, planes, u32x2{pattern, pattern});
   else
     hipLaunchKernelGGL((stream_fill_kernel<u32x4>), dim3((unsigned)blocks), dim3(kBlock), 0,
-                       stream, static_cast<u32x4*>(dst), n,
+                       stream, static_cast<u32x4*>(dst), n, n, planes,
                        u32x4{pattern, pattern, pattern, pattern});
   return hipGetLastError();
 }

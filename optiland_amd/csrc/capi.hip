@@ -1269,6 +1269,37 @@ int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void
   return OL_OK;
 }
 
+int ol_pupil_points(int32_t kind, int32_t param, ol_dtype dt, int64_t n_points,
+                    const int32_t* row_first, const int64_t* row_offset, void* x, void* y,
+                    void* stream) {
+  if (kind != OL_PUPIL_HEXAPOLAR && kind != OL_PUPIL_UNIFORM)
+    return fail(OL_EINVAL, "ol_pupil_points: unknown sampler %d", kind);
+  if (n_points < 0 || (n_points > 0 && (!x || !y)))
+    return fail(OL_EINVAL, "ol_pupil_points: bad output planes");
+  if (kind == OL_PUPIL_HEXAPOLAR) {
+    if (param < 0 || n_points != 1 + 3 * (int64_t)param * ((int64_t)param + 1))
+      return fail(OL_EINVAL, "ol_pupil_points: %d rings are %lld points, not %lld", param,
+                  (long long)(1 + 3 * (int64_t)param * ((int64_t)param + 1)),
+                  (long long)n_points);
+  } else {
+    if (param < 2) return fail(OL_EINVAL, "ol_pupil_points: uniform grid side %d < 2", param);
+    if (n_points > 0 && (!row_first || !row_offset))
+      return fail(OL_EINVAL, "ol_pupil_points: the uniform sampler needs its row tables");
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (dt == OL_F32)
+    e = ol::launch_pupil_points<float>(kind, param, n_points, row_first, row_offset,
+                                       static_cast<float*>(x), static_cast<float*>(y), st);
+  else if (dt == OL_F64)
+    e = ol::launch_pupil_points<double>(kind, param, n_points, row_first, row_offset,
+                                        static_cast<double*>(x), static_cast<double*>(y), st);
+  else
+    return fail(OL_EINVAL, "ol_pupil_points: bad dtype %d", (int)dt);
+  if (e != hipSuccess) return fail(OL_EHIP, "pupil launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
 int ol_math_probe(int32_t op, ol_dtype dt, int64_t n, const void* a, const void* b, void* out,
                   void* stream) {
   if (op < 0 || op > 3) return fail(OL_EINVAL, "ol_math_probe: op must be 0..3");
@@ -1289,14 +1320,17 @@ int ol_math_probe(int32_t op, ol_dtype dt, int64_t n, const void* a, const void*
   return OL_OK;
 }
 
-int ol_stream_fill(void* dst, int64_t bytes, int32_t store_bytes, uint32_t pattern,
-                   void* stream) {
+int ol_stream_fill(void* dst, int64_t bytes, int32_t store_bytes, int32_t planes,
+                   uint32_t pattern, void* stream) {
   if (bytes < 0 || (bytes > 0 && !dst)) return fail(OL_EINVAL, "ol_stream_fill: bad buffer");
+  if (planes < 1) return fail(OL_EINVAL, "ol_stream_fill: planes must be >= 1");
   if (store_bytes != 4 && store_bytes != 8 && store_bytes != 16)
     return fail(OL_EINVAL, "ol_stream_fill: store_bytes must be 4, 8 or 16");
-  if (bytes % store_bytes != 0 || (reinterpret_cast<uintptr_t>(dst) % store_bytes) != 0)
-    return fail(OL_EINVAL, "ol_stream_fill: buffer not a multiple of / aligned to store_bytes");
-  hipError_t e = ol::launch_stream_fill(dst, bytes, store_bytes, pattern,
+  if (bytes % ((int64_t)store_bytes * planes) != 0 ||
+      (reinterpret_cast<uintptr_t>(dst) % store_bytes) != 0)
+    return fail(OL_EINVAL, "ol_stream_fill: buffer not a multiple of planes x store_bytes, or "
+                           "not aligned to store_bytes");
+  hipError_t e = ol::launch_stream_fill(dst, bytes, store_bytes, planes, pattern,
                                         static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(OL_EHIP, "fill launch failed: %s", hipGetErrorString(e));
   return OL_OK;

@@ -267,13 +267,18 @@ template <typename T>
 hipError_t launch_irradiance(int64_t n, const T* x, const T* y, const T* power,
                              const double* x_edges, int nx, const double* y_edges, int ny,
                              double* hist, hipStream_t stream);
+// deterministic pupil samplers on the device (aux_kernels.hip; ol_pupil_points)
+template <typename T>
+hipError_t launch_pupil_points(int kind, int32_t param, int64_t n, const int32_t* first,
+                               const int64_t* offset, T* x, T* y, hipStream_t stream);
+
 // Math<T> primitives element-wise (aux_kernels.hip; ol_math_probe)
 template <typename T>
 hipError_t launch_math_probe(int op, int64_t n, const T* a, const T* b, T* out,
                              hipStream_t stream);
 
 // write-only streaming yardstick (aux_kernels.hip; ol_stream_fill)
-hipError_t launch_stream_fill(void* dst, int64_t bytes, int width, uint32_t pattern,
+hipError_t launch_stream_fill(void* dst, int64_t bytes, int width, int planes, uint32_t pattern,
                               hipStream_t stream);
 
 template <typename T>

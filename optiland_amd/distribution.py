@@ -50,6 +50,46 @@ def _uniform(n):
     return np.concatenate(xs), np.concatenate(ys)
 
 
+def uniform_rows(n):
+    """The disc mask of `_uniform(n)` as two row tables: `first[j]` = first kept column of
+    grid row j, `offset[j]` = index of that row's first point in the output (`offset[n]` =
+    number of points).  The kept columns of a row are contiguous (g^2 falls to the centre and
+    rises after it, floating-point addition is monotone), so both ends come from a bisection
+    guess corrected with the reference's OWN predicate `x**2 + y**2 <= 1` on the same squares
+    -- the two ends separately: linspace(-1, 1, n) is not mirror-symmetric to the last bit.
+    O(n log n) instead of the n^2 comparisons of the mask itself."""
+    g = np.linspace(-1.0, 1.0, n)
+    g2 = g ** 2
+    c = int(np.argmin(g2))                      # g2 non-increasing on [0, c], non-decreasing after
+    rows = np.arange(n)
+
+    def keep(col):                              # the reference's predicate, vectorised over rows
+        col = np.clip(col, 0, n - 1)
+        return g2[col] + g2 <= 1.0
+
+    bound = 1.0 - g2
+    # left end: first column in [0, c] that is kept (g2 descending there)
+    first = np.searchsorted(-g2[: c + 1], -bound, side="left")
+    # right end: last column in [c, n - 1] that is kept (g2 ascending there)
+    last = c + np.searchsorted(g2[c:], bound, side="right") - 1
+    for _ in range(3):  # the bound is a rounded difference: settle the ends with the predicate
+        first = np.where((first > 0) & keep(first - 1), first - 1,
+                         np.where((first <= c) & ~keep(first), first + 1, first))
+        last = np.where((last < n - 1) & keep(last + 1), last + 1,
+                        np.where((last >= c) & ~keep(last), last - 1, last))
+    any_kept = keep(np.full(n, c))              # the centre column is the last one to go
+    count = np.where(any_kept, last - first + 1, 0)
+    first = np.where(any_kept, first, 0)
+    offset = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(count, out=offset[1:])
+    del rows
+    return first.astype(np.int32), offset
+
+
+def hexapolar_count(rings: int) -> int:
+    return 1 + 3 * int(rings) * (int(rings) + 1)
+
+
 def _cross(n):
     # distribution.py:235-262: vertical arm first, horizontal arm without its
     # duplicate origin when n is odd

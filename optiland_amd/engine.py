@@ -497,6 +497,37 @@ class HipSystem:
         self._check(rc, "ol_generate_rays")
         return planes[:7]
 
+    def can_pupil_points(self) -> bool:
+        return hasattr(self.lib, "ol_pupil_points") \
+            and os.environ.get("OPTILAND_HIP_DEVICE_PUPIL", "1") != "0"
+
+    def pupil_points(self, name: str, num: int, dtype):
+        """`ol_pupil_points`: the "hexapolar" (num = rings) or "uniform" (num = grid side)
+        sampler of the reference evaluated on the device -- (x, y) planes of `dtype`, same
+        values and order as `distribution.create_distribution(name).generate_points(num)`."""
+        from . import distribution as D
+
+        num = int(num)
+        if name == "hexapolar":
+            n, kind, first, offset = D.hexapolar_count(num), 0, None, None
+        elif name == "uniform":
+            f, o = D.uniform_rows(num)
+            n, kind = int(o[-1]), 1
+            first = torch.as_tensor(f, device=self.device)
+            offset = torch.as_tensor(o, device=self.device)
+        else:
+            raise ValueError(f"no device sampler for {name!r}")
+        x = torch.empty(n, dtype=dtype, device=self.device)
+        y = torch.empty(n, dtype=dtype, device=self.device)
+        with self._device_ctx():
+            rc = self.lib.ol_pupil_points(
+                kind, num, _DT[dtype], n,
+                first.data_ptr() if first is not None else None,
+                offset.data_ptr() if offset is not None else None,
+                x.data_ptr(), y.data_ptr(), self._stream())
+        self._check(rc, "ol_pupil_points")
+        return x, y
+
     def polarized_intensity(self, prt, k0, i0, polarization: dict | None):
         n = int(i0.numel())
         dtype = i0.dtype

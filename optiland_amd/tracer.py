@@ -72,7 +72,7 @@ _PUPIL_PLANES: "OrderedDict" = OrderedDict()
 _PUPIL_PLANES_CAP = 256 << 20
 
 
-def _shared_pupil_planes(key, dtype, device, to_device):
+def _shared_pupil_planes(key, dtype, device, to_device, engine=None):
     name = key[0]
     if name in ("random", "sobol"):
         d = create_distribution(name)
@@ -81,9 +81,16 @@ def _shared_pupil_planes(key, dtype, device, to_device):
     full = (key, dtype, str(device))
     hit = _PUPIL_PLANES.get(full)
     if hit is None:
-        d = create_distribution(name)
-        d.generate_points(key[1])
-        hit = (to_device(d.x), to_device(d.y))
+        can = getattr(engine, "can_pupil_points", None)
+        if name in ("hexapolar", "uniform") and can is not None and can() \
+                and (name == "hexapolar" or int(key[1]) >= 2):
+            # sampled ON the device from the point index (`ol_pupil_points`): no host pass
+            # over the points, no upload
+            hit = engine.pupil_points(name, key[1], dtype)
+        else:
+            d = create_distribution(name)
+            d.generate_points(key[1])
+            hit = (to_device(d.x), to_device(d.y))
         _PUPIL_PLANES[full] = hit
         total = sum(2 * h[0].numel() * h[0].element_size() for h in _PUPIL_PLANES.values())
         while total > _PUPIL_PLANES_CAP and len(_PUPIL_PLANES) > 1:
@@ -237,7 +244,7 @@ class HipRayTracer:
             key = (distribution, int(num_rays) if num_rays is not None else None)
             hit = self._pupil_cache.get(key)
             if hit is None:
-                hit = _shared_pupil_planes(key, self.dtype, self.device, self._dev)
+                hit = _shared_pupil_planes(key, self.dtype, self.device, self._dev, self.engine)
                 if distribution not in ("random", "sobol"):  # those: a fresh sample per call
                     self._pupil_cache[key] = hit
             return hit

@@ -247,6 +247,49 @@ hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, hipStream
 template hipError_t launch_trace_generate<float>(const TraceArgs<float>&, int, hipStream_t);
 template hipError_t launch_trace_generate<double>(const TraceArgs<double>&, int, hipStream_t);
 
+// launch_pupil_points (aux_kernels.hip), point by point, the same fp64 expressions
+template <typename T>
+hipError_t launch_pupil_points(int kind, int32_t param, int64_t n, const int32_t* first,
+                               const int64_t* offset, T* x, T* y, hipStream_t) {
+#pragma clang fp contract(off)
+  auto lin = [](int64_t i, int64_t last, double start, double stop, double step) {
+    const double v = (double)i * step;
+    return i == last ? stop : v + start;
+  };
+  if (kind == 0) {
+    const double step = 1.0 / (double)param;
+    for (int64_t p = 0; p < n; ++p) {
+      if (p == 0) { x[0] = T(0); y[0] = T(0); continue; }
+      const int64_t q = p - 1;
+      int64_t i = (int64_t)((3.0 + std::sqrt(9.0 + 12.0 * (double)q)) / 6.0);
+      while (3 * i * (i - 1) > q) --i;
+      while (3 * (i + 1) * i <= q) ++i;
+      const int64_t j = q - 3 * i * (i - 1);
+      const double theta = (double)j * (6.283185307179586 / (double)(6 * i));
+      const double r = lin(i, param, 0.0, 1.0, step);
+      x[p] = (T)(r * std::cos(theta));
+      y[p] = (T)(r * std::sin(theta));
+    }
+  } else {
+    const double step = 2.0 / (double)(param - 1);
+    for (int64_t p = 0; p < n; ++p) {
+      int lo = 0, hi = param;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offset[mid] <= p) lo = mid; else hi = mid;
+      }
+      const int64_t col = (int64_t)first[lo] + (p - offset[lo]);
+      x[p] = (T)lin(col, param - 1, -1.0, 1.0, step);
+      y[p] = (T)lin(lo, param - 1, -1.0, 1.0, step);
+    }
+  }
+  return hipSuccess;
+}
+template hipError_t launch_pupil_points<float>(int, int32_t, int64_t, const int32_t*,
+                                               const int64_t*, float*, float*, hipStream_t);
+template hipError_t launch_pupil_points<double>(int, int32_t, int64_t, const int32_t*,
+                                                const int64_t*, double*, double*, hipStream_t);
+
 // launch_math_probe (aux_kernels.hip): the host run of Math<T> (IEEE operations)
 template <typename T>
 hipError_t launch_math_probe(int op, int64_t n, const T* a, const T* b, T* out, hipStream_t) {
@@ -264,7 +307,7 @@ template hipError_t launch_math_probe<double>(int, int64_t, const double*, const
 
 // launch_stream_fill (aux_kernels.hip): the device kernel is a bandwidth yardstick; the
 // host stand-in just writes the pattern
-hipError_t launch_stream_fill(void* dst, int64_t bytes, int, uint32_t pattern, hipStream_t) {
+hipError_t launch_stream_fill(void* dst, int64_t bytes, int, int, uint32_t pattern, hipStream_t) {
   uint32_t* p = static_cast<uint32_t*>(dst);
   for (int64_t j = 0; j < bytes / 4; ++j) p[j] = pattern;
   return hipSuccess;

@@ -325,3 +325,46 @@ def test_spot_diagram_validates_each_wavelength_once(seams, monkeypatch):
     after = [[float(_np(be, v)) for v in f]
              for f in analysis.SpotDiagram(lens, num_rings=3).rms_spot_radius()]
     assert abs(after[0][0] - before[0][0]) > 1e-6 * abs(before[0][0])
+
+
+def test_seams_are_left_off_when_the_reference_signature_changed(ref, monkeypatch):
+    """Version guard: the seams replace private methods of the reference;
+    one whose target no longer has the signature it was written against is NOT installed (and
+    the seams that depend on it go with it), the others are, and `disable()` restores
+    exactly what was patched."""
+    from optiland.analysis.spot_diagram.core import SpotDiagram
+    from optiland.psf.fft import ScalarFFTPSF
+    from optiland.wavefront.strategy import ChiefRayStrategy
+    from optiland_amd import analysis_seams as seams
+    seams.disable()
+    stock = {"spot": SpotDiagram._generate_field_data, "pupils": ScalarFFTPSF._generate_pupils,
+             "pad": ScalarFFTPSF._pad_pupils, "opd": ChiefRayStrategy.compute_wavefront_data}
+
+    def renamed(self, field, wavelength, num_rays, distribution, coords):  # one name differs
+        return stock["spot"](self, field, wavelength, num_rays, distribution, coords)
+
+    def extra(self, field, wavelength, mode="x"):                          # one parameter more
+        return stock["opd"](self, field, wavelength)
+
+    monkeypatch.setattr(SpotDiagram, "_generate_field_data", renamed)
+    monkeypatch.setattr(ChiefRayStrategy, "compute_wavefront_data", extra)
+    try:
+        seams.enable()
+        assert set(seams.SKIPPED) == {"spot", "opd", "pupils", "pad"}, seams.SKIPPED
+        assert "coords" in seams.SKIPPED["spot"] and "needs opd" in seams.SKIPPED["pupils"]
+        assert SpotDiagram._generate_field_data is renamed          # untouched
+        assert ChiefRayStrategy.compute_wavefront_data is extra
+        assert ScalarFFTPSF._generate_pupils is stock["pupils"]
+        assert SpotDiagram._generate_data is seams._spot_generate_data   # the others are on
+        assert ChiefRayStrategy.__init__ is seams._chief_init
+    finally:
+        seams.disable()
+    assert ScalarFFTPSF._pad_pupils is stock["pad"]
+    assert SpotDiagram._generate_data is not seams._spot_generate_data
+    monkeypatch.undo()
+    seams.enable()
+    try:
+        assert seams.SKIPPED == {}
+        assert SpotDiagram._generate_field_data is seams._spot_generate_field_data
+    finally:
+        seams.disable()
