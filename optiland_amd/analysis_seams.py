@@ -16,7 +16,10 @@ for exactly that:
   its constructor (strategy.py:156-160) takes the exit-pupil position from the packed table
   instead of `optic.paraxial.XPL()` + `surfaces.positions` (6 of the 8 ms of an `OPD(...)`);
 * `ScalarFFTPSF._generate_pupils` / `_pad_pupils` (psf/fft.py:123-161, 203-230)
-  -> `ol_pupil_fill`: the pupil function scattered straight into the zero-padded FFT grid.
+  -> `ol_pupil_fill`: the pupil function scattered straight into the zero-padded FFT grid;
+* `HexagonalDistribution.generate_points` / `UniformDistribution.generate_points`
+  (distribution.py:175-220) -> `ol_pupil_points`: the pupil grid of an analysis in one launch
+  instead of a Python loop over the rings (round 4: 10 of the 11 ms of an OPD at 256 rings).
 
 Every patched method first asks whether the call is one the fused path covers -- drop-in
 active for this optic, torch backend on the HIP device without autograd, a system the
@@ -40,7 +43,8 @@ from .packer import UnsupportedSystem
 
 _ORIG: dict = {}
 STATS = {"spot": 0, "spot_fallback": 0, "ee": 0, "ee_fallback": 0, "opd": 0, "opd_fallback": 0,
-         "pupil": 0, "pupil_fallback": 0, "opd_init": 0, "opd_init_fallback": 0}
+         "pupil": 0, "pupil_fallback": 0, "opd_init": 0, "opd_init_fallback": 0,
+         "dist": 0, "dist_fallback": 0}
 
 
 def _front(optic, wavelength, need_fp64=False):
@@ -350,6 +354,89 @@ def _fft_pad_pupils(self):
     return _ORIG["pad"](self)
 
 
+# ------------------------------------------------------------------- pupil distributions
+POINTS_HOOK = None  # tests: callable(kind, num, dtype) -> (x, y) standing in for the device
+
+
+def _device_points(kind, num):
+    """(x, y) of a deterministic sampler from `ol_pupil_points` in the backend's precision on
+    the HIP device, or None when the call is not one the device sampler serves (another
+    backend / device, autograd on, library without the entry point)."""
+    import ctypes as C
+
+    import optiland.backend as be
+
+    from . import _capi
+    from . import distribution as D
+    from . import integration as ig
+
+    if be.get_backend() not in (ig.BACKEND_NAME, "torch"):
+        return None
+    cfg = be._backends[be.get_backend()]._config
+    if cfg.grad_mode.requires_grad:
+        return None
+    try:
+        num = int(num)
+    except (TypeError, ValueError):
+        return None
+    if POINTS_HOOK is not None:  # tests: the host build of the same source
+        return POINTS_HOOK(kind, num, cfg.get_precision())
+    if cfg.get_device() != "cuda" or not torch.cuda.is_available():
+        return None
+    try:
+        lib = _capi.load()
+    except Exception:  # noqa: BLE001 - no library: the reference's own sampler
+        return None
+    if not hasattr(lib, "ol_pupil_points"):
+        return None
+    dtype = cfg.get_precision()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    first = offset = None
+    if kind == "hexapolar":
+        if num < 0:
+            return None
+        n, code = D.hexapolar_count(num), 0
+    else:
+        if num < 2:
+            return None
+        f, o = D.uniform_rows(num)
+        n, code = int(o[-1]), 1
+        first, offset = torch.as_tensor(f, device=dev), torch.as_tensor(o, device=dev)
+    x = torch.empty(n, dtype=dtype, device=dev)
+    y = torch.empty(n, dtype=dtype, device=dev)
+    rc = lib.ol_pupil_points(code, num, _capi.F32 if dtype == torch.float32 else _capi.F64, n,
+                             C.c_void_p(first.data_ptr()) if first is not None else None,
+                             C.c_void_p(offset.data_ptr()) if offset is not None else None,
+                             C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                             C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        return None
+    return x, y
+
+
+def _hexapolar_generate_points(self, num_rings=6):
+    """distribution.py:201-220 is a Python loop over the rings with four backend array
+    operations and two concatenations each: 10.2 of the 11 ms an `OPD(lens, ..., num_rays=256)`
+    takes on the device (profiles/r04_opd_profile.txt).  Same points, same order, from ONE
+    launch of `ol_pupil_points`."""
+    got = _device_points("hexapolar", num_rings)
+    if got is None:
+        STATS["dist_fallback"] += 1
+        return _ORIG["dist_hex"](self, num_rings)
+    STATS["dist"] += 1
+    self.x, self.y = got
+
+
+def _uniform_generate_points(self, num_points):
+    """distribution.py:175-186 (an n x n meshgrid masked to the disc) from `ol_pupil_points`."""
+    got = _device_points("uniform", num_points)
+    if got is None:
+        STATS["dist_fallback"] += 1
+        return _ORIG["dist_uniform"](self, num_points)
+    STATS["dist"] += 1
+    self.x, self.y = got
+
+
 # --------------------------------------------------------------------------- (de)activate
 # The seams replace PRIVATE methods of the reference.  Each entry: key in _ORIG -> (module,
 # class, method, the parameter names the replacement was written against, replacement).  A
@@ -376,6 +463,10 @@ _SEAMS = {
     "pupils": ("optiland.psf.fft", "ScalarFFTPSF", "_generate_pupils", ("self",),
                "_fft_generate_pupils"),
     "pad": ("optiland.psf.fft", "ScalarFFTPSF", "_pad_pupils", ("self",), "_fft_pad_pupils"),
+    "dist_hex": ("optiland.distribution", "HexagonalDistribution", "generate_points",
+                 ("self", "num_rings"), "_hexapolar_generate_points"),
+    "dist_uniform": ("optiland.distribution", "UniformDistribution", "generate_points",
+                     ("self", "num_points"), "_uniform_generate_points"),
 }
 # (dependent seams ..., the seam they need): the FFT-PSF pair scatters the OPD seam's device data
 _GROUPS = (("pupils", "pad", "opd"),)

@@ -368,3 +368,61 @@ def test_seams_are_left_off_when_the_reference_signature_changed(ref, monkeypatc
         assert SpotDiagram._generate_field_data is seams._spot_generate_field_data
     finally:
         seams.disable()
+
+
+def test_distribution_seams_sample_the_reference_grids(ref, monkeypatch):
+    """`HexagonalDistribution.generate_points` / `UniformDistribution.generate_points` through
+    `ol_pupil_points` (here: the host build of the same source): the reference's own points in
+    the reference's own order -- hexapolar within a few ulps of the radius (another libm),
+    uniform bit for bit -- and an `OPD` built on top of them equals the stock one."""
+    import torch
+    from tests import _hostmath as hm
+    if not hm.available():
+        pytest.skip("hipcc (used as host C++ compiler) missing")
+    be = ref
+    from optiland.distribution import create_distribution
+    from optiland_amd import analysis_seams as seams, load_system
+    eng = hm.make_engine_class()(load_system("double_gauss"))
+    try:
+        # the truth: the reference's NumPy backend (its torch backend's own `linspace` walks
+        # the second half of an interval backwards from the end point and lands a few ulps
+        # away from it)
+        be.set_backend("numpy")
+        stock = {}
+        for name, num in (("hexapolar", 7), ("hexapolar", 0), ("uniform", 12), ("uniform", 33)):
+            d = create_distribution(name)
+            d.generate_points(num)
+            stock[(name, num)] = (_np(be, d.x), _np(be, d.y))
+        be.set_backend("torch")
+        be.set_device("cpu")
+        be.set_precision("float64")
+        monkeypatch.setattr(seams, "POINTS_HOOK",
+                            lambda kind, num, dtype: eng.pupil_points(kind, num, dtype))
+        seams.enable()
+        n0 = seams.STATS["dist"]
+        for (name, num), (wx, wy) in stock.items():
+            d = create_distribution(name)
+            d.generate_points(num)
+            gx, gy = _np(be, d.x), _np(be, d.y)
+            assert gx.shape == wx.shape
+            if name == "uniform":
+                np.testing.assert_array_equal(gx, wx)
+                np.testing.assert_array_equal(gy, wy)
+            else:
+                np.testing.assert_allclose(gx, wx, rtol=0, atol=7e-16)
+                np.testing.assert_allclose(gy, wy, rtol=0, atol=7e-16)
+        assert seams.STATS["dist"] == n0 + 4
+        # autograd on: the reference's own sampler
+        with be.grad_mode.temporary_enable():
+            d = create_distribution("hexapolar")
+            d.generate_points(3)
+        assert seams.STATS["dist"] == n0 + 4 and seams.STATS["dist_fallback"] >= 1
+        # NumPy backend: untouched
+        be.set_backend("numpy")
+        d = create_distribution("hexapolar")
+        d.generate_points(3)
+        assert isinstance(d.x, np.ndarray)
+    finally:
+        seams.disable()
+        be.set_backend("numpy")
+        eng.close()
