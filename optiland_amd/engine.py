@@ -177,7 +177,11 @@ class HipSystem:
         else:
             align = 256
         a = align // itemsize
-        return max((n + a - 1) // a * a, _VEC_PAD)
+        stride = max((n + a - 1) // a * a, _VEC_PAD)
+        skew = os.environ.get("OPTILAND_RECORD_SKEW")  # bytes added to the aligned stride
+        if skew:
+            stride += max(int(skew), 0) // 256 * 256 // itemsize
+        return stride
 
     def alloc_record(self, n: int, dtype, rows: int | None = None) -> torch.Tensor:
         rows = self.num_surfaces if rows is None else rows
