@@ -65,12 +65,23 @@ OL_DEV double rcp_f64(double x) {
 // and a DENORMAL divisor whose seed overflows gives NaN instead of inf.  Catching them costs
 // two more v_cmp_class per quotient in kernels that are bound by vector issue; the
 // hostmath / GPU edge-case tests pin the behaviour (tests/test_gpu_hostmath.py).
+// OL_DIV_F64_STEPS (1 | 2): Newton steps on the reciprocal before the quotient is formed.  ONE
+// is enough: the residual correction q + (a - b q) y squares the error once more, so the
+// quotient is within 2^-52 x 2^-52 of exact before its final rounding whether y carries 2^-52
+// or 2^-100 -- measured on 8e6 operands per range (tests/test_gpu_math_probe.py): 0.5 ulp
+// maximum, i.e. correctly rounded, with either; two fewer FMAs per quotient, two quotients per
+// conic surface.
+#ifndef OL_DIV_F64_STEPS
+#define OL_DIV_F64_STEPS 1
+#endif
 OL_DEV double div_f64(double a, double b) {
   const double y0 = __builtin_amdgcn_rcp(b);
   double e = __builtin_fma(-b, y0, 1.0);
   double y = __builtin_fma(y0, e, y0);
+#if OL_DIV_F64_STEPS > 1
   e = __builtin_fma(-b, y, 1.0);
   y = __builtin_fma(y, e, y);
+#endif
   const double q = a * y;
   const double r = __builtin_fma(-b, q, a);
   const double refined = __builtin_fma(r, y, q);

@@ -71,6 +71,8 @@ VARIANTS = {
     # round 4: IEEE square root + quotients in the ray generator and the reference-sphere
     # intersection (the round-3 form) instead of the hardware reciprocal square root / seeds
     "raygen_ieee": ["-DOL_RAYGEN_RSQ=0", "-DOL_WAVEFRONT_FAST=0"],
+    # fp64 quotient with two Newton steps on the reciprocal (rounds 3 - 4a) instead of one
+    "div64_2steps": ["-DOL_DIV_F64_STEPS=2"],
 }
 
 
