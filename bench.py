@@ -112,6 +112,9 @@ def parse_args():
                          "kernel source (tests/hostmath) standing in for the device library -- "
                          "tests/test_bench_cli.py uses it for the N > 1 path; the line says "
                          "`\"data\": \"plumbing-check\"` and carries no roofline")
+    ap.add_argument("--placement", choices=("probe", "plain"), default="probe",
+                    help="record block placed in the fastest window of an arena (default) or a "
+                         "plain allocation")
     ap.add_argument("--settle", type=int, default=120,
                     help="extra launches AFTER the timed region whose last third is reported as "
                          "roofline.steady_state (0 = skip)")
@@ -568,7 +571,18 @@ def main():
     gen = args.mode == "gen"
     if gen and not hip.can_trace_generate():
         raise SystemExit("--mode gen needs generator scalars without a pupil apodization")
-    record = hip.alloc_record(n, dtype) if args.mode in ("record", "gen") else None
+    # The record block is reused by every step: it is PLACED (engine.alloc_record_placed: the
+    # window of an arena in which this launch's own store pattern writes fastest, found with
+    # `ol_stream_fill` outside the timed region).  `--placement plain` = one ordinary
+    # allocation, as the drop-in makes for every trace it hands to a user.
+    placement = None
+    record = None
+    if args.mode in ("record", "gen"):
+        if args.placement == "probe" and not args.plumbing_check \
+                and hasattr(hip, "alloc_record_placed"):
+            record, placement = hip.alloc_record_placed(n, dtype)
+        else:
+            record = hip.alloc_record(n, dtype)
     alias = record is not None and args.object_row == "alias" and not gen
     opd_mode = args.mode == "opd"
     spot = args.mode == "spot" or opd_mode  # the fused, ray-plane-free pipelines
@@ -801,6 +815,20 @@ def main():
         steady = {"launches_before": args.warmup + args.steps + len(each) - len(tail),
                   "launches_averaged": len(tail), "kernel_ms": float(np.mean(tail)),
                   "kernel_us_minmax": [min(tail) * 1e3, max(tail) * 1e3]}
+        if placement is not None and placement.get("placed") and gen:
+            # the same launch into an ORDINARY allocation (what a drop-in trace gets), for
+            # comparison -- outside the reported region
+            plain = hip.alloc_record(n, dtype)
+            pev = [(make_event(), make_event()) for _ in range(40)]
+            for e0_, e1_ in pev:
+                e0_.record()
+                hip.trace_generate(px, py, wl, field=(0.0, hy), record=plain, prt=prt,
+                                   zero_status=False, defer_status=True)
+                e1_.record()
+            sync(device)
+            pt = [a.elapsed_time(bb) for a, bb in pev][10:]
+            placement["kernel_ms_plain_block"] = float(np.mean(pt))
+            del plain
 
     if rank == 0:
         total_rs = float(job_rays) * S * args.steps
@@ -900,6 +928,7 @@ def main():
                 "kernel_us_minmax": [min(kern_each) * 1e3, max(kern_each) * 1e3]
                                     if kern_each else None,
                 "steady_state": steady,
+                "record_placement": placement,
                 "moved_bytes": moved_bytes,
                 "algorithmic_bytes": alg_bytes,
                 "achieved_algorithmic": alg_GBps,

@@ -188,6 +188,80 @@ class HipSystem:
         stride = self.record_stride(n, torch.empty((), dtype=dtype).element_size())
         return torch.empty((rows, 8, stride), dtype=dtype, device=self.device)
 
+    def alloc_record_placed(self, n: int, dtype, rows: int | None = None,
+                            arena_bytes: int | None = None, min_gain: float = 0.04):
+        """A record block PLACED where this part writes it fastest -- for callers that reuse
+        one block over many traces (`bench.py`, a sharded step loop, `GraphedTrace`).
+
+        Measured on MI355X (profiles/r04_window_scan_*.txt, r04_block_placement_*.txt): the
+        record-all store pattern -- 104 planes of 40 MB written concurrently -- sustains
+        5.7-5.8 TB/s inside most 4 GiB windows of device memory and **7.0 TB/s** in windows
+        that straddle certain boundaries of the physical backing (every 32 GiB of a 128 GiB
+        allocation on the boxes measured; the same windows for the arithmetic-free pattern of
+        `ol_stream_fill`, correlation 0.96-0.998; stable while the allocation lives).  Where
+        such a boundary falls is the driver's business, so it is FOUND: an arena is allocated,
+        `ol_stream_fill` times this block's own store pattern over candidate offsets (coarse
+        pass, then a fine one around the best; ~0.1 s), and the block is a view of the fastest
+        window -- or a plain allocation when no window is at least `min_gain` faster than the
+        median one.  Returns (record, info).  The view pins the arena: not for results that
+        are handed to a user (the drop-in keeps `alloc_record`)."""
+        rows = self.num_surfaces if rows is None else rows
+        b = torch.empty((), dtype=dtype).element_size()
+        stride = self.record_stride(n, b)
+        need = rows * 8 * stride * b
+        info = {"placed": False, "block_bytes": need}
+        if not hasattr(self.lib, "ol_stream_fill") or self.device.type != "cuda" \
+                or need < (256 << 20):
+            return self.alloc_record(n, dtype, rows), info
+        free, _total = torch.cuda.mem_get_info(self.device)
+        if arena_bytes is None:
+            env = os.environ.get("OPTILAND_HIP_RECORD_ARENA_GIB")
+            arena_bytes = int(float(env) * (1 << 30)) if env else max(3 * need, 40 << 30)
+        arena_bytes = min(arena_bytes, int(free * 0.45)) // (2 << 20) * (2 << 20)
+        if arena_bytes < 2 * need:
+            return self.alloc_record(n, dtype, rows), info
+        arena = torch.empty(arena_bytes, dtype=torch.uint8, device=self.device)
+        stream = self._stream()
+        base = arena.data_ptr()
+
+        def fill_ms(off, reps=2):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            for k in range(1 + reps):
+                if k == 1:
+                    e0.record()
+                self._check(self.lib.ol_stream_fill(C.c_void_p(base + off), need, b, rows * 8, 0,
+                                                    stream), "ol_stream_fill")
+            e1.record()
+            torch.cuda.synchronize(self.device)
+            return e0.elapsed_time(e1) / reps
+
+        with self._device_ctx():
+            for _ in range(30):  # past the clock transient of the first launches
+                self.lib.ol_stream_fill(C.c_void_p(base), need, b, rows * 8, 0, stream)
+            last = arena_bytes - need
+            coarse = max(need // 4 // (2 << 20) * (2 << 20), 2 << 20)
+            offs = list(range(0, last + 1, coarse))
+            times = {o: fill_ms(o) for o in offs}
+            best = min(times, key=times.get)
+            fine = max(coarse // 4 // (2 << 20) * (2 << 20), 2 << 20)
+            for o in range(max(best - coarse + fine, 0), min(best + coarse, last + 1), fine):
+                if o not in times:
+                    times[o] = fill_ms(o)
+            best = min(times, key=times.get)
+        med = float(np.median([times[o] for o in offs]))
+        info.update(arena_bytes=arena_bytes, probes=len(times), probe_best_ms=times[best],
+                    probe_median_ms=med, window_offset_bytes=best,
+                    probe_best_GBps=need / (times[best] * 1e-3) / 1e9,
+                    probe_median_GBps=need / (med * 1e-3) / 1e9)
+        if times[best] > med * (1.0 - min_gain):
+            del arena
+            torch.cuda.empty_cache()
+            return self.alloc_record(n, dtype, rows), info
+        info["placed"] = True
+        rec = arena[best: best + need].view(dtype).view(rows, 8, stride)
+        return rec, info
+
     def trace(self, rays, wavelength_index: int = 0, record=True, prt: torch.Tensor | None = None,
               first: int = 0, last: int | None = None, write_rays: bool | None = None,
               check_status: bool = True, prt_identity: bool = False,

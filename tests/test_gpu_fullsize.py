@@ -546,3 +546,26 @@ def test_config3_per_gpu_shard_full_size_fp64(dg):
     assert not bool(torch.isnan(rec[:, :, :n]).any())
     del rec, res, pr
     torch.cuda.empty_cache()
+
+
+def test_placed_record_block_is_a_plain_record_block(dg):
+    """`HipSystem.alloc_record_placed` (round 4): the record block as a view of the fastest
+    window of an arena, found with `ol_stream_fill`.  Whatever window is chosen -- or none --
+    the block has the engine's shape and stride and a trace into it is bit-identical to a
+    trace into an ordinary allocation."""
+    hip, table = dg
+    n, dtype = 2_000_000, torch.float32
+    px, py = _pupil(n, 53, dtype)
+    rec, info = hip.alloc_record_placed(n, dtype, arena_bytes=3 << 30, min_gain=0.0)
+    plain = hip.alloc_record(n, dtype)
+    assert rec.shape == plain.shape and rec.stride() == plain.stride() and rec.dtype == dtype
+    assert info["block_bytes"] == plain.numel() * 4 and info["probes"] >= 4
+    assert rec.data_ptr() % (2 << 20) == 0
+    a = hip.trace_generate(px, py, 0, field=(0.0, 0.7), record=rec)
+    b = hip.trace_generate(px, py, 0, field=(0.0, 0.7), record=plain)
+    assert torch.equal(a.record[:, :, :n].nan_to_num(), b.record[:, :, :n].nan_to_num())
+    # a tiny block is never placed (nothing to gain below the cache sizes)
+    small, sinfo = hip.alloc_record_placed(1000, dtype)
+    assert not sinfo["placed"] and small.shape[0] == plain.shape[0]
+    del rec, plain, a, b
+    torch.cuda.empty_cache()
