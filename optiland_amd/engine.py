@@ -222,7 +222,11 @@ class HipSystem:
             return self.alloc_record(n, dtype, rows), info
         arena = torch.empty(arena_bytes, dtype=torch.uint8, device=self.device)
         stream = self._stream()
-        base = arena.data_ptr()
+        # (a block the caching allocator carved out of an older segment is only 512 B
+        # aligned: windows start on 2 MiB boundaries of the ADDRESS, like plain blocks)
+        pad = (-arena.data_ptr()) % (2 << 20)
+        base = arena.data_ptr() + pad
+        arena_bytes -= pad + (2 << 20)
 
         def fill_ms(off, reps=2):
             e0 = torch.cuda.Event(enable_timing=True)
@@ -259,7 +263,7 @@ class HipSystem:
             torch.cuda.empty_cache()
             return self.alloc_record(n, dtype, rows), info
         info["placed"] = True
-        rec = arena[best: best + need].view(dtype).view(rows, 8, stride)
+        rec = arena[pad + best: pad + best + need].view(dtype).view(rows, 8, stride)
         return rec, info
 
     def trace(self, rays, wavelength_index: int = 0, record=True, prt: torch.Tensor | None = None,
