@@ -37,6 +37,11 @@ TAGS = {  # tag -> traffic key
     "r03_zf_f64": "zernike_fresnel:f64:record:alias",
     "r03_rc_f64": "rc_asphere:f64:record:alias",
     "r03_z_opd": "zernike:f64:opd",
+    # round 4 (tools/gpu_r04_final.sh): the default line with the placed record block
+    "r04_dg_f32_gen": "double_gauss:f32:gen",
+    "r04_dg_f64_gen": "double_gauss:f64:gen",
+    "r04_rc_f32_gen": "rc_asphere:f32:gen",
+    "r04_zf_f32_gen": "zernike_fresnel:f32:gen",
 }
 
 
@@ -91,6 +96,11 @@ def main():
         name = tag[len(ROUND) + 1:] if tag.startswith(ROUND + "_") else tag
         open(os.path.join(PROF, f"{ROUND}_{name}_rocprof.txt"), "w").write("\n".join(lines) + "\n")
         print("\n".join(lines[:4]))
+    box = os.path.join(OUT, f"{ROUND}_box.txt")
+    if os.path.exists(box):
+        traffic["_meta"] = {"round": ROUND,
+                            "box": " ".join(open(box).read().split())[:200],
+                            "note": "rows of earlier rounds were taken on those rounds' boxes"}
     json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
     bd = os.path.join(OUT, f"{ROUND}_bench_default.json")
     if os.path.exists(bd):
