@@ -935,6 +935,7 @@ def main():
                 "kernel_ms": kern_ms,
                 "kernel_us_minmax": [min(kern_each) * 1e3, max(kern_each) * 1e3]
                                     if kern_each else None,
+                "kernel_us_each": [round(t * 1e3, 1) for t in kern_each[:64]],
                 "steady_state": steady,
                 "record_placement": placement,
                 "moved_bytes": moved_bytes,

@@ -17,9 +17,9 @@ for exactly that:
   instead of `optic.paraxial.XPL()` + `surfaces.positions` (6 of the 8 ms of an `OPD(...)`);
 * `ScalarFFTPSF._generate_pupils` / `_pad_pupils` (psf/fft.py:123-161, 203-230)
   -> `ol_pupil_fill`: the pupil function scattered straight into the zero-padded FFT grid;
-* `HexagonalDistribution.generate_points` / `UniformDistribution.generate_points`
-  (distribution.py:175-220) -> `ol_pupil_points`: the pupil grid of an analysis in one launch
-  instead of a Python loop over the rings (round 4: 10 of the 11 ms of an OPD at 256 rings).
+* `HexagonalDistribution.generate_points` (distribution.py:201-220) -> `ol_pupil_points`: the
+  pupil grid of an analysis in one launch instead of a Python loop over the rings (round 4:
+  10 of the 11 ms of an OPD at 256 rings).
 
 Every patched method first asks whether the call is one the fused path covers -- drop-in
 active for this optic, torch backend on the HIP device without autograd, a system the
@@ -396,7 +396,7 @@ def _device_points(kind, num):
         if num < 0:
             return None
         n, code = D.hexapolar_count(num), 0
-    else:
+    else:  # (no seam uses it; kept for callers of `_device_points("uniform", n)`)
         if num < 2:
             return None
         f, o = D.uniform_rows(num)
@@ -427,14 +427,12 @@ def _hexapolar_generate_points(self, num_rings=6):
     self.x, self.y = got
 
 
-def _uniform_generate_points(self, num_points):
-    """distribution.py:175-186 (an n x n meshgrid masked to the disc) from `ol_pupil_points`."""
-    got = _device_points("uniform", num_points)
-    if got is None:
-        STATS["dist_fallback"] += 1
-        return _ORIG["dist_uniform"](self, num_points)
-    STATS["dist"] += 1
-    self.x, self.y = got
+# (No seam on `UniformDistribution.generate_points`: it is five array operations on the device
+# already, and its consumers build the SAME grid once more with the backend's own `linspace`
+# and rely on the two masks agreeing point for point (psf/fft.py:140-155) -- the torch
+# backend's `linspace` walks the upper half of the interval back from the end point and its
+# disc mask differs from NumPy's in a few rim points (25445 vs 25441 at 181 x 181).  The
+# stand-alone tracer's "uniform" keeps NumPy's arithmetic, as before.)
 
 
 # --------------------------------------------------------------------------- (de)activate
@@ -465,8 +463,6 @@ _SEAMS = {
     "pad": ("optiland.psf.fft", "ScalarFFTPSF", "_pad_pupils", ("self",), "_fft_pad_pupils"),
     "dist_hex": ("optiland.distribution", "HexagonalDistribution", "generate_points",
                  ("self", "num_rings"), "_hexapolar_generate_points"),
-    "dist_uniform": ("optiland.distribution", "UniformDistribution", "generate_points",
-                     ("self", "num_points"), "_uniform_generate_points"),
 }
 # (dependent seams ..., the seam they need): the FFT-PSF pair scatters the OPD seam's device data
 _GROUPS = (("pupils", "pad", "opd"),)

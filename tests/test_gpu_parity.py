@@ -316,7 +316,7 @@ def test_shfl_compaction_variant_matches_default_and_goldens(hip, case, dtype):
     """BASELINE.json north_star names "wavefront-level __shfl-based active-ray compaction"
     for the Newton iteration.  It is built (`newton_compacted`: ballot + mbcnt +
     ds_bpermute, `trace_kernel<..., NR=2>`), measured slower on MI355X (DESIGN 4.1 item 9,
-    profiles/r02_ab_compaction.txt) and therefore opt-in: `ol_set_tuning(OL_TUNE_COMPACT, 1)`.
+    profiles/r02_ab_variants.txt:50-93) and therefore opt-in: `ol_set_tuning(OL_TUNE_COMPACT, 1)`.
     Shipped-but-off code is still held to the contract: on every golden system with a
     Newton-Raphson surface the compacted kernel must reproduce the default kernel (same
     per-ray arithmetic, only the lane a straggler runs on differs) and the goldens."""

@@ -69,7 +69,7 @@ def main():
         if not os.path.isdir(d):
             continue
         lines = [f"# {ROUND} {key}: rocprofv3 --kernel-trace --stats --output-format csv -- "
-                 f"python bench.py --steps 20 --warmup 3 --no-cpu-baseline (+ workload flags)"]
+                 f"python bench.py --steps 20 --warmup 5 --settle 0 --no-cpu-baseline (+ workload flags)"]
         bench = [l for l in open(os.path.join(d, "stats.log")) if l.startswith("{")]
         if bench:
             b = json.loads(bench[-1])

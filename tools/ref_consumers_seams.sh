@@ -25,7 +25,14 @@ s = s.replace("import optiland.backend as be\n",
               "import optiland_amd.tracer as _tr\nfrom tests_fake import OracleEngine\n"
               "_tr._make_engine = lambda table, device: OracleEngine(table, device)\n"
               "from optiland_amd import integration as _integ\n"
-              "_integ.enable(force=True, analyses=True)\n" % r, 1)
+              "_integ.enable(force=True, analyses=True)\n"
+              # the distribution seams too: `ol_pupil_points` of the host build stands in
+              # for the device
+              "import optiland_amd.analysis_seams as _seams\n"
+              "from optiland_amd import load_system as _ls\n"
+              "_peng = OracleEngine(_ls('double_gauss'), 'cpu')\n"
+              "_seams.POINTS_HOOK = lambda kind, num, dtype: _peng.pupil_points(kind, num, dtype)\n"
+              % r, 1)
 s = s.replace("be.grad_mode.enable()", "be.grad_mode.disable()")
 s += """
 
