@@ -220,7 +220,11 @@ class HipSystem:
         arena_bytes = min(arena_bytes, int(free * 0.45)) // (2 << 20) * (2 << 20)
         if arena_bytes < 2 * need:
             return self.alloc_record(n, dtype, rows), info
-        arena = torch.empty(arena_bytes, dtype=torch.uint8, device=self.device)
+        try:
+            arena = torch.empty(arena_bytes, dtype=torch.uint8, device=self.device)
+        except RuntimeError:  # out of memory after all: the plain block
+            torch.cuda.empty_cache()
+            return self.alloc_record(n, dtype, rows), info
         stream = self._stream()
         # (a block the caching allocator carved out of an older segment is only 512 B
         # aligned: windows start on 2 MiB boundaries of the ADDRESS, like plain blocks)
