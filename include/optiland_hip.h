@@ -562,6 +562,28 @@ int ol_trace_opd(const ol_system* sys, ol_dtype dt, int64_t n_rays,
                  void* opd_waves, void* intensity, void* const pupil[3],
                  double* moments12, uint32_t* status, void* stream);
 
+/* ABI 8.  The reference sphere / plane of a wavefront, DEVICE-RESIDENT.
+ * ol_wavefront_reference traces the chief ray of one field point (pupil point (0, 0)) with one
+ * lane and leaves in `reference_dev` (OL_WAVEFRONT_REFERENCE_DOUBLES doubles of device memory,
+ * opaque but for [0..2] = centre, [3] = radius) what ChiefRayStrategy derives from it on the
+ * host (wavefront/strategy.py:176-184, 228-284): the sphere centred on the chief ray's image
+ * point with radius to (0, 0, pupil_z), or (planar != 0) the plane through that point normal
+ * to the chief ray, and the chief ray's own optical path to it.  `w` supplies n_image,
+ * wavelength_um, ux, uy, half_epd (the tilt term); its centre / radius / normal are ignored.
+ * chief8 (nullable): 8 doubles receiving x, y, z, L, M, N, i, opd of the chief ray.
+ * ol_trace_opd_dev is ol_trace_opd reading the reference from such a structure: an OPD map
+ * is two launches and no read-back in between.  fp64 only.                                */
+#define OL_WAVEFRONT_REFERENCE_DOUBLES 14
+int ol_wavefront_reference(const ol_system* sys, ol_dtype dt, const ol_raygen_params* p,
+                           const ol_raygen_inputs* in, const ol_wavefront_params* w,
+                           double pupil_z, int32_t planar, int32_t wavelength_index,
+                           void* reference_dev, void* chief8, uint32_t* status, void* stream);
+int ol_trace_opd_dev(const ol_system* sys, ol_dtype dt, int64_t n_rays,
+                     const ol_raygen_params* p, const ol_raygen_inputs* in,
+                     const void* reference_dev, int32_t wavelength_index, void* opd_waves,
+                     void* intensity, void* const pupil[3], double* moments12, uint32_t* status,
+                     void* stream);
+
 /* The pupil function of the scalar FFT PSF (psf/fft.py:101-137 _generate_pupil + the
  * zero padding of :139-160): sample j of the compacted pupil list -- cell `cell[j]`
  * (row-major) of the n_side x n_side sample grid -- becomes

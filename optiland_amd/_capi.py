@@ -121,12 +121,15 @@ EXPORTS = (
     "ol_stream_fill",
     "ol_math_probe",
     "ol_pupil_points",
+    "ol_wavefront_reference",
+    "ol_trace_opd_dev",
 )
 
 F32, F64 = 0, 1
 TUNE_RAYS_PER_THREAD, TUNE_COMPACT = 0, 1
 ABI_VERSION = 8
 OPD_MOMENTS = 12  # kOpdMoments / ol_trace_opd
+WAVEFRONT_REFERENCE_DOUBLES = 14  # OL_WAVEFRONT_REFERENCE_DOUBLES
 
 
 def library_path() -> str:
@@ -201,6 +204,12 @@ def bind(lib, path: str = "?"):
     lib.ol_set_tuning.argtypes = [i32, i32]
     lib.ol_trace_opd.restype = C.c_int
     lib.ol_trace_opd.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, C.POINTER(vp), vp, vp, vp]
+    lib.ol_wavefront_reference.restype = C.c_int
+    lib.ol_wavefront_reference.argtypes = [vp, i32, vp, vp, vp, C.c_double, i32, i32, vp, vp, vp,
+                                           vp]
+    lib.ol_trace_opd_dev.restype = C.c_int
+    lib.ol_trace_opd_dev.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, C.POINTER(vp), vp,
+                                     vp, vp]
     lib.ol_pupil_fill.restype = C.c_int
     lib.ol_pupil_fill.argtypes = [i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     have = lib.ol_abi_version()

@@ -558,11 +558,47 @@ int do_trace_spot(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
 }
 
 template <typename T>
+int do_wavefront_reference(const ol_system* sys, const DeviceTable<T>& tab,
+                           const ol_raygen_params* p, const ol_raygen_inputs* in,
+                           const ol_wavefront_params* w, double pupil_z, int32_t planar,
+                           int32_t wl, void* reference_dev, void* chief8, uint32_t* status,
+                           hipStream_t stream) {
+  ol::ChiefArgs<T> a{};
+  // launch-uniform field / vignetting only; the pupil point is (0, 0)
+  a.in.hx = a.in.hy = a.in.px = a.in.py = a.in.vx = a.in.vy = nullptr;
+  a.in.hx0 = (T)in->hx0; a.in.hy0 = (T)in->hy0; a.in.vx0 = (T)in->vx0; a.in.vy0 = (T)in->vy0;
+  a.in.tx0 = a.in.ty0 = T(0);
+  a.in.flags = in->flags & OL_RAYGEN_PRESCALE_PUPIL;
+  a.surf = tab.surf;
+  a.cold = tab.cold;
+  a.optics = tab.optics;
+  a.coeffs = tab.coeffs;
+  a.rg = raygen_dev(p);
+  ol::WavefrontDev wd{0, 0, 0, 0, w->n_image, 0, w->ux, w->uy, w->half_epd, w->wavelength_um,
+                      0, 0, planar ? 1.0 : 0.0};
+  a.wfc = ol::WavefrontConsts<T>(wd);   // planar flag from nz != 0; centre / R filled on device
+  a.pupil_z = (T)pupil_z;
+  a.out = static_cast<ol::WavefrontConsts<T>*>(reference_dev);
+  a.chief = static_cast<T*>(chief8);
+  a.status = status;
+  a.first = 0;
+  a.last = sys->n_surf - 1;
+  a.n_wl = sys->n_wl;
+  a.wl = wl;
+  hipError_t e = ol::launch_chief_reference<T>(a, newton_family(sys, 0, sys->n_surf - 1), stream);
+  if (e != hipSuccess)
+    return fail(OL_EHIP, "chief-ray launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
+template <typename T>
 int do_trace_opd(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
                  const ol_raygen_params* p, const ol_raygen_inputs* in,
                  const ol_wavefront_params* w, int32_t wl, void* opd, void* inten,
-                 void* const pupil[3], double* mom, uint32_t* status, hipStream_t stream) {
+                 void* const pupil[3], double* mom, uint32_t* status, hipStream_t stream,
+                 const void* reference_dev = nullptr) {
   ol::OpdArgs<T> a{};
+  a.wf_dev = static_cast<const ol::WavefrontConsts<T>*>(reference_dev);
   bool vec = true;
   if (int rc = convert_inputs<T>("ol_trace_opd", in, status, a.in, vec)) return rc;
   if (a.in.hx != nullptr || a.in.vx != nullptr)
@@ -574,8 +610,11 @@ int do_trace_opd(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
   a.optics = tab.optics;
   a.coeffs = tab.coeffs;
   a.rg = raygen_dev(p);
-  a.wf = ol::WavefrontDev{w->xc, w->yc, w->zc, w->R, w->n_image, w->opd_ref, w->ux, w->uy,
-                          w->half_epd, w->wavelength_um, w->nx, w->ny, w->nz};
+  if (w)
+    a.wf = ol::WavefrontDev{w->xc, w->yc, w->zc, w->R, w->n_image, w->opd_ref, w->ux, w->uy,
+                            w->half_epd, w->wavelength_um, w->nx, w->ny, w->nz};
+  else
+    a.wf = ol::WavefrontDev{0, 0, 0, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0};  // (unused: reference_dev)
   a.opd = static_cast<T*>(opd);
   a.inten = static_cast<T*>(inten);
   for (int k = 0; k < 3; ++k) a.pupil[k] = pupil ? static_cast<T*>(pupil[k]) : nullptr;
@@ -1234,6 +1273,62 @@ int ol_trace_opd(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_ray
   return do_trace_opd<double>(sys, sys->f64, n_rays, p, in, w, wavelength_index, opd_waves,
                               intensity, pupil, moments12, status,
                               static_cast<hipStream_t>(stream));
+}
+
+static int opd_common_checks(const char* who, const ol_system* sys, ol_dtype dt,
+                             int32_t wavelength_index) {
+  if (!sys) return fail(OL_EINVAL, "%s: system is NULL", who);
+  if (!sys->consistent)
+    return fail(OL_EINVAL, "%s: the system's tables are inconsistent after a failed "
+                           "ol_system_update (destroy it and create a new one)", who);
+  if (dt == OL_F32)
+    return fail(OL_EUNSUPPORTED, "%s: wavefront work is fp64 only (an OPD in waves needs 1e-9 "
+                                 "of the path length)", who);
+  if (dt != OL_F64) return fail(OL_EINVAL, "%s: bad dtype %d", who, (int)dt);
+  if (wavelength_index < 0 || wavelength_index >= sys->n_wl)
+    return fail(OL_EINVAL, "%s: wavelength index %d outside [0, %d)", who, wavelength_index,
+                sys->n_wl);
+  for (int32_t s = 0; s < sys->n_surf; ++s)
+    if (sys->coating[s] >= OL_COAT_FRESNEL)
+      return fail(OL_EINVAL,
+                  "Polarization must be set when surfaces have polarization-dependent "
+                  "coatings.");
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != sys->device)
+    return fail(OL_EINVAL, "%s: current HIP device %d is not the system's device %d", who, cur,
+                sys->device);
+  return OL_OK;
+}
+
+int ol_wavefront_reference(const ol_system* sys, ol_dtype dt, const ol_raygen_params* p,
+                           const ol_raygen_inputs* in, const ol_wavefront_params* w,
+                           double pupil_z, int32_t planar, int32_t wavelength_index,
+                           void* reference_dev, void* chief8, uint32_t* status, void* stream) {
+  if (int rc = opd_common_checks("ol_wavefront_reference", sys, dt, wavelength_index)) return rc;
+  if (!p || !in || !w || !reference_dev)
+    return fail(OL_EINVAL, "ol_wavefront_reference: NULL argument");
+  if (in->hx || in->hy || in->vx || in->vy)
+    return fail(OL_EINVAL, "ol_wavefront_reference: one field point (launch-uniform field and "
+                           "vignetting)");
+  return do_wavefront_reference<double>(sys, sys->f64, p, in, w, pupil_z, planar,
+                                        wavelength_index, reference_dev, chief8, status,
+                                        static_cast<hipStream_t>(stream));
+}
+
+int ol_trace_opd_dev(const ol_system* sys, ol_dtype dt, int64_t n_rays,
+                     const ol_raygen_params* p, const ol_raygen_inputs* in,
+                     const void* reference_dev, int32_t wavelength_index, void* opd_waves,
+                     void* intensity, void* const pupil[3], double* moments12, uint32_t* status,
+                     void* stream) {
+  if (int rc = opd_common_checks("ol_trace_opd_dev", sys, dt, wavelength_index)) return rc;
+  if (!p || !in || !reference_dev || !opd_waves || !intensity || !moments12)
+    return fail(OL_EINVAL, "ol_trace_opd_dev: NULL argument");
+  if (pupil && (!pupil[0] || !pupil[1] || !pupil[2]))
+    return fail(OL_EINVAL, "ol_trace_opd_dev: pupil needs three planes");
+  if (n_rays < 0) return fail(OL_EINVAL, "ol_trace_opd_dev: negative ray count");
+  return do_trace_opd<double>(sys, sys->f64, n_rays, p, in, nullptr, wavelength_index, opd_waves,
+                              intensity, pupil, moments12, status,
+                              static_cast<hipStream_t>(stream), reference_dev);
 }
 
 int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void* intensity,

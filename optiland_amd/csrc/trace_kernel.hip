@@ -1303,7 +1303,13 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
     // reference corrects with the distribution's points, strategy.py:88-139)
     T ov;
     {
-      const WavefrontConsts<T> w = consts_of(&A1->wfc);
+      // the reference sphere / plane: from the argument block, or (ol_trace_opd_dev) from the
+      // device structure ol_wavefront_reference left -- a launch-uniform choice, scalar loads
+      // from the constant address space either way
+      WavefrontConsts<T> w;
+      const WavefrontConsts<T>* wdev = A1->wf_dev;
+      if (wdev != nullptr) w = load_consts(as_const(wdev));
+      else w = consts_of(&A1->wfc);
       ov = wavefront_one<T>(w, g.x, g.y, g.z, g.L, g.M, g.N, g.opd, A1->in.px[j], A1->in.py[j],
                             pu);
     }
@@ -1372,6 +1378,96 @@ hipError_t launch_opd_trace(const OpdArgs<T>& a_in, int nr_family, hipStream_t s
 
 #if OL_TRACE_TU == 0 || OL_TRACE_TU == 2
 template hipError_t launch_opd_trace<double>(const OpdArgs<double>&, int, hipStream_t);
+#endif
+
+// --------------------------------------------------------------------------
+// chief ray -> reference sphere / plane, device-resident (ol_wavefront_reference)
+// --------------------------------------------------------------------------
+// One lane generates the chief ray of the field point (pupil point (0, 0)), walks the surface
+// table like opd_trace_kernel and writes the WavefrontConsts the OPD launch reads:
+// centre = the chief ray's image point, R = its distance to the exit pupil on the axis
+// (strategy.py:228-243), or the plane through it normal to the chief ray (:260-284);
+// opd_ref = the chief ray's own path length to that surface (:181-184: its pupil point is
+// (0, 0), so the tilt term vanishes).  A cold kernel (one wave, once per wavefront).
+template <typename T, int NR>
+__global__ __launch_bounds__(64) void chief_ref_kernel(
+    const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
+    const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
+    ChiefArgs<T> a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  using m = Math<T>;
+  uint32_t status = 0;
+  bool prt_fresh = false;
+  Ray<T> r[1];
+  {
+    T px = T(0), py = T(0), vx = a.in.vx0, vy = a.in.vy0, o[6];
+    raygen_pupil<T>(a.in.flags, vx, vy, px, py, status);
+    raygen_one<T>(a.rgc, a.in.tx0, a.in.ty0, px, py, vx, vy, o);
+    r[0].x = o[0]; r[0].y = o[1]; r[0].z = o[2];
+    r[0].L = o[3]; r[0].M = o[4]; r[0].N = o[5];
+    r[0].i = T(1);
+    r[0].opd = T(0);
+  }
+  bool is_global = true;
+  int last_idx = a.first;
+  Prt<T, 0> P[1];
+  for (int s = a.first; s <= a.last; ++s) {
+    const SurfFetched<T> h{as_const(surf_tab) + s, as_const(cold_tab) + s,
+                           as_const(optics_tab) + (s * a.n_wl + a.wl)};
+    if (refresh(h.hot)->interaction != kRecordOnly) {
+      surface_step<T, 1, 0, NR>(h, as_const(coeff_tab), is_global, r, P, status, prt_fresh);
+      is_global = false;
+      last_idx = s;
+    }
+  }
+  Ray<T> g = r[0];
+  if (!is_global) {
+    const SurfFetched<T> h{as_const(surf_tab) + last_idx, as_const(cold_tab) + last_idx,
+                           as_const(optics_tab) + (last_idx * a.n_wl + a.wl)};
+    g = to_global<T>(h.surf(), r[0]);
+  }
+  WavefrontConsts<T> w = a.wfc;
+  w.xc = g.x; w.yc = g.y; w.zc = g.z;
+  T t_back;
+  if (w.planar) {
+    w.R = T(0);
+    w.nx = g.L; w.ny = g.M; w.nz = g.N;
+    t_back = T(0);  // the chief ray's image point lies ON the plane
+  } else {
+    const T dz = g.z - a.pupil_z;
+    w.R = m::sqrt(g.x * g.x + g.y * g.y + dz * dz);
+    w.nx = w.ny = w.nz = T(0);
+    // path_length of the chief ray itself: the sphere is centred on its image point
+    const T aa = g.L * g.L + g.M * g.M + g.N * g.N;
+    const T d = T(4) * aa * w.R * w.R;
+    const T sq = m::sqrt(d < T(0) ? T(0) : d);
+    const T t1 = m::div(-sq, T(2) * aa), t2 = m::div(sq, T(2) * aa);
+    t_back = t1 < T(0) ? t2 : t1;
+  }
+  w.opd_ref = g.opd - w.ni * t_back;
+  *a.out = w;
+  if (a.chief != nullptr) {
+    a.chief[0] = g.x; a.chief[1] = g.y; a.chief[2] = g.z; a.chief[3] = g.L;
+    a.chief[4] = g.M; a.chief[5] = g.N; a.chief[6] = g.i; a.chief[7] = g.opd;
+  }
+  if (status && a.status) atomicOr(a.status, status);
+}
+
+template <typename T>
+hipError_t launch_chief_reference(const ChiefArgs<T>& a_in, int nr_family, hipStream_t stream) {
+  ChiefArgs<T> a = a_in;
+  uniform_field_tangents<T>(a.rg, a.in);
+  a.rgc = RaygenConsts<T>(a.rg);
+#define OL_CHIEF_LAUNCH(N)                                                                   \
+  hipLaunchKernelGGL((chief_ref_kernel<T, N>), dim3(1), dim3(64), 0, stream, a.surf, a.cold, \
+                     a.optics, a.coeffs, a)
+  if (nr_family == kNrNone) OL_CHIEF_LAUNCH(0);
+  else OL_CHIEF_LAUNCH(1);   // (cold: the generic Newton instantiation serves every family)
+#undef OL_CHIEF_LAUNCH
+  return hipGetLastError();
+}
+#if OL_TRACE_TU == 0 || OL_TRACE_TU == 2
+template hipError_t launch_chief_reference<double>(const ChiefArgs<double>&, int, hipStream_t);
 #endif
 
 }  // namespace ol

@@ -246,9 +246,36 @@ struct OpdArgs {
   int64_t n;
   int32_t first, last;
   int32_t n_wl, wl;
+  // ABI 8 (ol_trace_opd_dev): the reference sphere / plane from DEVICE memory -- written there
+  // by ol_wavefront_reference (chief_ref_kernel) -- instead of the kernel argument `wfc`
+  const WavefrontConsts<T>* wf_dev;
 };
 template <typename T>
 hipError_t launch_opd_trace(const OpdArgs<T>& a, int nr_family, hipStream_t stream);
+
+// ol_wavefront_reference: the chief ray of one field point traced by ONE lane and turned into
+// the reference sphere / plane of the wavefront kernels, left in device memory
+// (wavefront/strategy.py:176-184, 228-284 -- what the host did with a one-ray trace, a
+// read-back and a handful of scalar operations)
+template <typename T>
+struct ChiefArgs {
+  const DevSurfHot<T>* surf;
+  const DevSurfCold<T>* cold;
+  const DevOptics<T>* optics;
+  const T* coeffs;
+  RaygenIn<T> in;          // launch-uniform field and vignetting; the pupil point is (0, 0)
+  RaygenDev rg;
+  RaygenConsts<T> rgc;     // set by the launcher
+  WavefrontConsts<T> wfc;  // ni, inv_w, ux, uy, half_epd, planar (the rest is filled in)
+  T pupil_z;               // exit-pupil position (spherical reference)
+  WavefrontConsts<T>* out; // device
+  T* chief;                // optional: 8 values x, y, z, L, M, N, i, opd of the chief ray
+  uint32_t* status;
+  int32_t first, last;
+  int32_t n_wl, wl;
+};
+template <typename T>
+hipError_t launch_chief_reference(const ChiefArgs<T>& a, int nr_family, hipStream_t stream);
 
 template <typename T>
 hipError_t launch_pupil_fill(int64_t n, const T* opd, const T* inten, const T* pupil_x,

@@ -653,9 +653,10 @@ class HipSystem:
         self._check(rc, "ol_wavefront_opd")
         return opd, pupil
 
-    def trace_opd(self, params: dict, px, py, wl_index: int, *, field, vig=(1.0, 1.0),
+    def trace_opd(self, params: dict | None, px, py, wl_index: int, *, field, vig=(1.0, 1.0),
                   want_pupil: bool = True, moments: torch.Tensor | None = None,
-                  check_status: bool = True):
+                  check_status: bool = True, reference: torch.Tensor | None = None,
+                  zero_status: bool = True):
         """Fused generate -> trace -> OPD (`ol_trace_opd`, fp64): the pupil points
         (px, py) of ONE field point straight to the OPD map against the reference sphere /
         plane `params` -- no ray planes.  Returns (opd_waves, intensity, pupil (3, n) or
@@ -676,20 +677,60 @@ class HipSystem:
             return opd, inten, pupil, moments
         inp, keep = self._raygen_inputs(float(field[0]), float(field[1]), px, py,
                                         float(vig[0]), float(vig[1]), 0)
-        w = _capi.WavefrontParams(**{k: float(params.get(k, 0.0)) for k, _ in
-                                     _capi.WavefrontParams._fields_})
         pp = (C.c_void_p * 3)(*[pupil[k].data_ptr() for k in range(3)]) if want_pupil else None
-        if check_status:
+        if check_status and zero_status:
             self._status.zero_()
         with self._device_ctx():
-            rc = self.lib.ol_trace_opd(self._handle, _DT[dtype], n, C.byref(p), C.byref(inp),
-                                       C.byref(w), int(wl_index), opd.data_ptr(),
-                                       inten.data_ptr(), pp, moments.data_ptr(),
-                                       self._status.data_ptr(), self._stream())
+            if reference is not None:
+                # `reference`: what `wavefront_reference` left on the device (ol_trace_opd_dev)
+                rc = self.lib.ol_trace_opd_dev(
+                    self._handle, _DT[dtype], n, C.byref(p), C.byref(inp), reference.data_ptr(),
+                    int(wl_index), opd.data_ptr(), inten.data_ptr(), pp, moments.data_ptr(),
+                    self._status.data_ptr(), self._stream())
+            else:
+                w = _capi.WavefrontParams(**{k: float(params.get(k, 0.0)) for k, _ in
+                                             _capi.WavefrontParams._fields_})
+                rc = self.lib.ol_trace_opd(self._handle, _DT[dtype], n, C.byref(p), C.byref(inp),
+                                           C.byref(w), int(wl_index), opd.data_ptr(),
+                                           inten.data_ptr(), pp, moments.data_ptr(),
+                                           self._status.data_ptr(), self._stream())
         self._check(rc, "ol_trace_opd")
         if check_status:
             self.raise_for_status(int(self._status.item()))
         return opd, inten, pupil, moments
+
+    def can_wavefront_reference(self) -> bool:
+        return hasattr(self.lib, "ol_wavefront_reference") \
+            and os.environ.get("OPTILAND_HIP_DEVICE_REFERENCE", "1") != "0"
+
+    def wavefront_reference(self, params: dict, wl_index: int, *, field, vig=(1.0, 1.0),
+                            pupil_z: float = 0.0, planar: bool = False, want_chief: bool = False,
+                            zero_status: bool = True):
+        """`ol_wavefront_reference`: the chief ray of one field point traced on the device and
+        turned into the reference sphere (centre = its image point, radius to (0, 0, pupil_z))
+        or plane (`planar`) of the wavefront kernels -- LEFT ON THE DEVICE.  `params`: n_image,
+        wavelength_um, ux, uy, half_epd.  Returns (reference, chief): `reference` = a float64
+        device tensor (`[0:3]` centre, `[3]` radius) for `trace_opd(reference=...)`, `chief` = the
+        chief ray's x, y, z, L, M, N, i, opd (8 values) or None.  No read-back."""
+        p = self._raygen_params()
+        ref = torch.empty(_capi.WAVEFRONT_REFERENCE_DOUBLES, dtype=torch.float64,
+                          device=self.device)
+        chief = torch.empty(8, dtype=torch.float64, device=self.device) if want_chief else None
+        zero = torch.zeros(1, dtype=torch.float64, device=self.device)
+        inp, keep = self._raygen_inputs(float(field[0]), float(field[1]), zero, zero,
+                                        float(vig[0]), float(vig[1]), 0)
+        w = _capi.WavefrontParams(**{k: float(params.get(k, 0.0)) for k, _ in
+                                     _capi.WavefrontParams._fields_})
+        if zero_status:
+            self._status.zero_()
+        with self._device_ctx():
+            rc = self.lib.ol_wavefront_reference(
+                self._handle, _DT[torch.float64], C.byref(p), C.byref(inp), C.byref(w),
+                float(pupil_z), 1 if planar else 0, int(wl_index), ref.data_ptr(),
+                chief.data_ptr() if chief is not None else None, self._status.data_ptr(),
+                self._stream())
+        self._check(rc, "ol_wavefront_reference")
+        return ref, chief
 
     def pupil_fill(self, opd, intensity, cell: torch.Tensor, n_side: int, grid_size: int,
                    pupil_xy=None, plane=None) -> torch.Tensor:

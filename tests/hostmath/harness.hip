@@ -510,7 +510,8 @@ hipError_t launch_opd_trace(const OpdArgs<T>& a_in, int nr_family, hipStream_t) 
   OpdArgs<T> a = a_in;
   uniform_field_tangents<T>(a.rg, a.in);
   const RaygenConsts<T> c(a.rg);
-  const WavefrontConsts<T> w(a.wf);
+  // (ol_trace_opd_dev: the reference left in "device" memory by launch_chief_reference)
+  const WavefrontConsts<T> w = a.wf_dev ? *a.wf_dev : WavefrontConsts<T>(a.wf);
   const RaygenIn<T>& in_ = a.in;
   uint32_t status = 0;
   double s[kOpdMoments];
@@ -543,6 +544,53 @@ hipError_t launch_opd_trace(const OpdArgs<T>& a_in, int nr_family, hipStream_t) 
   return hipSuccess;
 }
 template hipError_t launch_opd_trace<double>(const OpdArgs<double>&, int, hipStream_t);
+
+// chief_ref_kernel + launch_chief_reference (trace_kernel.hip), statement by statement
+template <typename T>
+hipError_t launch_chief_reference(const ChiefArgs<T>& a_in, int nr_family, hipStream_t) {
+  using m = Math<T>;
+  ChiefArgs<T> a = a_in;
+  uniform_field_tangents<T>(a.rg, a.in);
+  const RaygenConsts<T> c(a.rg);
+  uint32_t status = 0;
+  T px = T(0), py = T(0), vx = a.in.vx0, vy = a.in.vy0, o[6];
+  raygen_pupil<T>(a.in.flags, vx, vy, px, py, status);
+  raygen_one<T>(c, a.in.tx0, a.in.ty0, px, py, vx, vy, o);
+  Ray<T> q;
+  q.x = o[0]; q.y = o[1]; q.z = o[2];
+  q.L = o[3]; q.M = o[4]; q.N = o[5];
+  q.i = T(1);
+  q.opd = T(0);
+  const Ray<T> g = fused_trace_family<T>(nr_family == kNrNone ? kNrNone : kNrGeneric, a.surf,
+                                         a.cold, a.optics, a.coeffs, a.first, a.last, a.n_wl, a.wl,
+                                         q, status);
+  WavefrontConsts<T> w = a.wfc;
+  w.xc = g.x; w.yc = g.y; w.zc = g.z;
+  T t_back;
+  if (w.planar) {
+    w.R = T(0);
+    w.nx = g.L; w.ny = g.M; w.nz = g.N;
+    t_back = T(0);
+  } else {
+    const T dz = g.z - a.pupil_z;
+    w.R = m::sqrt(g.x * g.x + g.y * g.y + dz * dz);
+    w.nx = w.ny = w.nz = T(0);
+    const T aa = g.L * g.L + g.M * g.M + g.N * g.N;
+    const T d = T(4) * aa * w.R * w.R;
+    const T sq = m::sqrt(d < T(0) ? T(0) : d);
+    const T t1 = m::div(-sq, T(2) * aa), t2 = m::div(sq, T(2) * aa);
+    t_back = t1 < T(0) ? t2 : t1;
+  }
+  w.opd_ref = g.opd - w.ni * t_back;
+  *a.out = w;
+  if (a.chief != nullptr) {
+    a.chief[0] = g.x; a.chief[1] = g.y; a.chief[2] = g.z; a.chief[3] = g.L;
+    a.chief[4] = g.M; a.chief[5] = g.N; a.chief[6] = g.i; a.chief[7] = g.opd;
+  }
+  if (status && a.status) *a.status |= status;
+  return hipSuccess;
+}
+template hipError_t launch_chief_reference<double>(const ChiefArgs<double>&, int, hipStream_t);
 
 // the four reduction kernels of aux_kernels.hip, element by element (sums in element order)
 template <typename T>
