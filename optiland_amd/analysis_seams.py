@@ -61,6 +61,12 @@ def _front(optic, wavelength, need_fp64=False):
         return None
     if not table.raygen or table.polarization is not None or table.uses_polarization:
         return None  # reference-side ray generation / polarised epilogue: not fused
+    if float(table.last_thickness) != 0.0:
+        # `Optic.trace` propagates the rays on by the LAST surface's thickness
+        # (real_ray_tracer.py:104-110; 0 in every sample: the last surface is the image
+        # plane).  The fused kernels end at the last surface: such an optic keeps the
+        # reference's own analysis code on top of the drop-in's trace, which does propagate.
+        return None
     if need_fp64 and front.dtype != torch.float64:
         return None
     if not hasattr(front.engine, "trace_spot"):
@@ -241,6 +247,9 @@ def _fused_wavefront(self, field, wavelength):
     dx, dy = getattr(dist, "x", None), getattr(dist, "y", None)
     if dx is None or dy is None:
         return None
+    can_dev = getattr(front.engine, "can_wavefront_reference", None)
+    if can_dev is not None and can_dev():
+        return _fused_wavefront_device(self, front, table, hx, hy, w, dx, dy)
     # 1. chief ray alone (strategy.py:176-179) -- through Optic.trace_generic, i.e. the
     # drop-in's own one-ray launch; kept on the strategy like the reference does
     self._chief_ray = chief = self.optic.trace_generic(hx, hy, Px=0.0, Py=0.0, wavelength=w)
@@ -285,6 +294,72 @@ def _fused_wavefront(self, field, wavelength):
     data = WavefrontData(pupil_x=pupil[0], pupil_y=pupil[1], pupil_z=pupil[2], opd=opd,
                          intensity=inten, radius=R)
     data._hip_fused = True  # lets the FFT-PSF seam recognise device data it can scatter
+    return data
+
+
+class _LazyChiefRay:
+    """`ChiefRayStrategy._chief_ray` (strategy.py:160, 176): the one-ray `RealRays` of the
+    chief ray.  The device-resident path has its eight numbers in device memory and nobody in
+    the reference reads the attribute outside `compute_wavefront_data`; it is built (one
+    `RealRays` from eight device scalars) only if somebody does."""
+
+    def __init__(self, chief8, wavelength):
+        self._chief8, self._w, self._rays = chief8, wavelength, None
+
+    def _make(self):
+        if self._rays is None:
+            from optiland.rays import RealRays
+
+            c = self._chief8
+            self._rays = RealRays(c[0:1], c[1:2], c[2:3], c[3:4], c[4:5], c[5:6], c[6:7], self._w)
+            self._rays.opd = c[7:8]
+        return self._rays
+
+    def __getattr__(self, name):
+        return getattr(self._make(), name)
+
+
+def _fused_wavefront_device(self, front, table, hx, hy, w, dx, dy):
+    """strategy.py:163-215 as TWO launches and no read-back: `ol_wavefront_reference` traces
+    the chief ray on the device and leaves the reference sphere / plane there,
+    `ol_trace_opd_dev` reads it.  (Round 3: a one-ray `Optic.trace_generic` through the
+    drop-in, a read-back of seven scalars and the sphere arithmetic on the host -- 0.4 of the
+    0.8 ms of an OPD at 256 rings.)"""
+    rg = table.raygen
+    n_image = rg.get("n_image")
+    if n_image is None:
+        n_image = _f(self.n_image)
+    ux = uy = 0.0
+    if rg.get("object_infinite") and int(rg.get("field_kind", 0)) == 0:
+        tx = math.tan(math.radians(hx * rg["max_field"]))
+        ty = math.tan(math.radians(hy * rg["max_field"]))
+        uz = 1.0 / math.sqrt(1.0 + tx * tx + ty * ty)
+        ux, uy = tx * uz, ty * uz
+    planar = self.reference_type == "plane"
+    pz = 0.0
+    if not planar:
+        pz = self.__dict__.get("_hip_pupil_z")
+        if pz is None or self.pupil_z is not self.__dict__.get("_hip_pupil_z_of"):
+            pz = _f(self.pupil_z)  # somebody replaced the attribute: read it
+    params = dict(n_image=n_image, ux=ux, uy=uy, half_epd=rg["EPD"] / 2.0, wavelength_um=w)
+    vig = front._vig_scalar(hx, hy)
+    wl, _ = front._wavelength_index(w)
+    eng = front.engine
+    ref, chief = eng.wavefront_reference(params, wl, field=(hx, hy), vig=vig, pupil_z=pz,
+                                         planar=planar, want_chief=True)
+    self._chief_ray = _LazyChiefRay(chief, w)
+    px, py = front._dev(_as_input(dx)), front._dev(_as_input(dy))
+    opd, inten, pupil, mom = eng.trace_opd(None, px, py, wl, field=(hx, hy), vig=vig,
+                                           want_pupil=True, reference=ref, zero_status=False)
+    _register(self.optic, front, table, (hx, hy, px, py, vig, w, 0))
+    from optiland.wavefront.wavefront_data import WavefrontData
+
+    # (`radius`: the reference says float; a 0-d device tensor here -- its one consumer, the
+    # Huygens PSF (psf/huygens_fresnel.py:283-300), uses it in backend arithmetic)
+    radius = math.inf if planar else ref[3]
+    data = WavefrontData(pupil_x=pupil[0], pupil_y=pupil[1], pupil_z=pupil[2], opd=opd,
+                         intensity=inten, radius=radius)
+    data._hip_fused = True
     return data
 
 

@@ -1307,7 +1307,10 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
       // device structure ol_wavefront_reference left -- a launch-uniform choice, scalar loads
       // from the constant address space either way
       WavefrontConsts<T> w;
-      const WavefrontConsts<T>* wdev = A1->wf_dev;
+#ifndef OL_OPD_DEVICE_REFERENCE
+#define OL_OPD_DEVICE_REFERENCE 1  // 0: argument block only (A/B knob, tools/build_variants.py)
+#endif
+      const WavefrontConsts<T>* wdev = OL_OPD_DEVICE_REFERENCE ? A1->wf_dev : nullptr;
       if (wdev != nullptr) w = load_consts(as_const(wdev));
       else w = consts_of(&A1->wfc);
       ov = wavefront_one<T>(w, g.x, g.y, g.z, g.L, g.M, g.N, g.opd, A1->in.px[j], A1->in.py[j],

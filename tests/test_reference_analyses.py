@@ -426,3 +426,75 @@ def test_distribution_seams_sample_the_reference_grids(ref, monkeypatch):
         seams.disable()
         be.set_backend("numpy")
         eng.close()
+
+
+@pytest.mark.parametrize("reference_type", ["sphere", "plane"])
+def test_device_resident_reference_equals_the_host_built_one(seams, reference_type, monkeypatch,
+                                                             request):
+    """`ol_wavefront_reference` + `ol_trace_opd_dev` (round 4: the chief ray traced on the
+    device, the reference sphere / plane left there, no read-back between the two launches)
+    against round 3's form of the same seam (one-ray `Optic.trace_generic`, seven scalars read
+    back, the sphere built on the host, `ol_trace_opd`): same OPD map, pupil points, radius; the
+    strategy's `_chief_ray` is the chief ray, built on first use."""
+    be, stats = seams
+    if "oracle" in request.node.name:
+        pytest.skip("the oracle-backed stand-in has no ol_wavefront_reference")
+    from optiland.wavefront import Wavefront
+
+    def run(lens):
+        w = Wavefront(lens, fields=[(0.0, 0.7)], wavelengths="primary", num_rays=8,
+                      distribution="hexapolar", afocal=(reference_type == "plane"))
+        d = w.get_data((0.0, 0.7), lens.primary_wavelength)
+        chief = w.strategy._chief_ray
+        return ([_np(be, getattr(d, k)) for k in ("opd", "intensity", "pupil_x", "pupil_y",
+                                                   "pupil_z")],
+                float(_np(be, d.radius)) if reference_type == "sphere" else float(d.radius),
+                [float(_np(be, getattr(chief, k)).reshape(-1)[0]) for k in
+                 ("x", "y", "z", "L", "M", "N", "opd")], type(chief).__name__)
+
+    got = run(_cooke())
+    assert got[3] == "_LazyChiefRay" and stats["opd"] >= 1 and stats["opd_fallback"] == 0
+    monkeypatch.setenv("OPTILAND_HIP_DEVICE_REFERENCE", "0")
+    want = run(_cooke())
+    assert want[3] == "RealRays"
+    for a, b in zip(got[0], want[0]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-9)   # OPD in waves; mm elsewhere
+    if reference_type == "sphere":
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-14)
+    else:
+        assert got[1] == want[1] == float("inf")
+    np.testing.assert_allclose(got[2], want[2], rtol=1e-13, atol=1e-13)
+
+
+def test_seams_decline_an_optic_whose_last_surface_has_a_thickness(seams):
+    """`Optic.trace` ends with a propagation by the last surface's thickness
+    (real_ray_tracer.py:104-110); the fused spot / OPD kernels end AT the last surface.  An
+    optic without an image plane (the reference's own `test_finite_conjugate_angle_field_opd`
+    builds one: object, two lens surfaces, 95 mm to nowhere) must therefore take the reference's
+    analysis code on top of the drop-in trace -- found in round 4: the OPD seam had been off by
+    exactly those 95 mm (172 727 waves of piston), invisibly to that test, which compares two
+    such optics with each other."""
+    be, stats = seams
+    from optiland.optic import Optic
+    from optiland.wavefront import OPD
+
+    def build():
+        optic = Optic()
+        optic.surfaces.add(index=0, thickness=100.0)
+        optic.surfaces.add(index=1, radius=50.0, thickness=5.0, material="BK7", is_stop=True)
+        optic.surfaces.add(index=2, radius=-50.0, thickness=95.0)
+        optic.set_aperture("EPD", 10.0)
+        optic.wavelengths.add(0.55, is_primary=True)
+        optic.fields.set_type("angle")
+        optic.fields.add(y=5.0)
+        return optic
+
+    def run(lens):
+        o = OPD(lens, field=(0, 1), wavelength="primary", num_rays=10, distribution="line_y")
+        return _np(be, o.get_data((0, 1), lens.primary_wavelength).opd)
+
+    want = _numpy_reference(be, build, run)
+    before = stats["opd"]
+    got = run(build())
+    assert stats["opd"] == before            # declined ...
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)   # ... and right
