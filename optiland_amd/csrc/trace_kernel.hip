@@ -1224,7 +1224,10 @@ template hipError_t launch_spot_trace<double>(const SpotArgs<double>&, bool, int
 //   6 sum w o 7 sum w o X 8 sum w o Y      (w = intensity, o = OPD, X/Y = pupil point)
 //   9 #{i > 0}   10 sum o [i > 0]   11 sum o^2 [i > 0]
 // --------------------------------------------------------------------------
-template <typename T, int NR, bool APOD>
+// DEVREF: the reference sphere / plane is read from device memory (ol_trace_opd_dev) -- an
+// instantiation of its own: as a launch-uniform branch in the one kernel it cost the 1e7-ray
+// launches 0.9-1.8 % (profiles/r04_ab_opd_devref.txt)
+template <typename T, int NR, bool APOD, bool DEVREF = false>
 __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
     const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
@@ -1307,11 +1310,7 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
       // device structure ol_wavefront_reference left -- a launch-uniform choice, scalar loads
       // from the constant address space either way
       WavefrontConsts<T> w;
-#ifndef OL_OPD_DEVICE_REFERENCE
-#define OL_OPD_DEVICE_REFERENCE 1  // 0: argument block only (A/B knob, tools/build_variants.py)
-#endif
-      const WavefrontConsts<T>* wdev = OL_OPD_DEVICE_REFERENCE ? A1->wf_dev : nullptr;
-      if (wdev != nullptr) w = load_consts(as_const(wdev));
+      if constexpr (DEVREF) w = load_consts(as_const(A1->wf_dev));
       else w = consts_of(&A1->wfc);
       ov = wavefront_one<T>(w, g.x, g.y, g.z, g.L, g.M, g.N, g.opd, A1->in.px[j], A1->in.py[j],
                             pu);
@@ -1364,8 +1363,14 @@ hipError_t launch_opd_trace(const OpdArgs<T>& a_in, int nr_family, hipStream_t s
   if (blocks > 8192) blocks = 8192;  // grid-stride beyond: keeps the atomics few
   const bool apod = a.rg.apod_kind != 0;
 #define OL_OPD_LAUNCH(N, A)                                                                  \
-  hipLaunchKernelGGL((opd_trace_kernel<T, N, A>), dim3((unsigned)blocks), dim3(kTraceBlock), \
-                     0, stream, a.surf, a.cold, a.optics, a.coeffs, a)
+  do {                                                                                       \
+    if (a.wf_dev != nullptr)                                                                 \
+      hipLaunchKernelGGL((opd_trace_kernel<T, N, A, true>), dim3((unsigned)blocks),          \
+                         dim3(kTraceBlock), 0, stream, a.surf, a.cold, a.optics, a.coeffs, a); \
+    else                                                                                     \
+      hipLaunchKernelGGL((opd_trace_kernel<T, N, A, false>), dim3((unsigned)blocks),         \
+                         dim3(kTraceBlock), 0, stream, a.surf, a.cold, a.optics, a.coeffs, a); \
+  } while (0)
   if (nr_family == kNrZernike) {
     if (apod) OL_OPD_LAUNCH(kNrZernike, true); else OL_OPD_LAUNCH(kNrZernike, false);
   } else if (nr_family == kNrEvenAsphere) {

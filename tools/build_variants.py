@@ -73,8 +73,6 @@ VARIANTS = {
     "raygen_ieee": ["-DOL_RAYGEN_RSQ=0", "-DOL_WAVEFRONT_FAST=0"],
     # fp64 quotient with two Newton steps on the reciprocal (rounds 3 - 4a) instead of one
     "div64_2steps": ["-DOL_DIV_F64_STEPS=2"],
-    # OPD kernels without the launch-uniform choice "reference from device memory"
-    "opd_nodevref": ["-DOL_OPD_DEVICE_REFERENCE=0"],
 }
 
 
