@@ -352,15 +352,48 @@ def _fused_wavefront_device(self, front, table, hx, hy, w, dx, dy):
     opd, inten, pupil, mom = eng.trace_opd(None, px, py, wl, field=(hx, hy), vig=vig,
                                            want_pupil=True, reference=ref, zero_status=False)
     _register(self.optic, front, table, (hx, hy, px, py, vig, w, 0))
-    from optiland.wavefront.wavefront_data import WavefrontData
-
-    # (`radius`: the reference says float; a 0-d device tensor here -- its one consumer, the
-    # Huygens PSF (psf/huygens_fresnel.py:283-300), uses it in backend arithmetic)
-    radius = math.inf if planar else ref[3]
-    data = WavefrontData(pupil_x=pupil[0], pupil_y=pupil[1], pupil_z=pupil[2], opd=opd,
-                         intensity=inten, radius=radius)
+    # `radius`: the reference says float (strategy.py:248 `.item()`); here a 0-d device tensor
+    # that becomes that float when somebody reads the attribute (the Huygens PSFs do,
+    # psf/huygens_fresnel.py:283-300; OPD maps, Zernike fits and the FFT PSF never do)
+    data = _device_wavefront_data()(pupil_x=pupil[0], pupil_y=pupil[1], pupil_z=pupil[2],
+                                    opd=opd, intensity=inten,
+                                    radius=math.inf if planar else ref[3])
     data._hip_fused = True
     return data
+
+
+_DEVICE_WAVEFRONT_DATA = None
+
+
+def _device_wavefront_data():
+    """`WavefrontData` whose `radius` may be handed over as a 0-d device tensor: read back
+    (once) when the attribute is read, so that the two launches of
+    `_fused_wavefront_device` need no synchronisation and the attribute still IS the float
+    the reference's dataclass declares (wavefront_data.py:36).  Pickles as the stock class."""
+    global _DEVICE_WAVEFRONT_DATA
+    if _DEVICE_WAVEFRONT_DATA is None:
+        from optiland.wavefront.wavefront_data import WavefrontData
+
+        class DeviceWavefrontData(WavefrontData):
+            @property
+            def radius(self):
+                r = self.__dict__["_radius"]
+                if isinstance(r, torch.Tensor):
+                    r = self.__dict__["_radius"] = float(r)
+                return r
+
+            @radius.setter
+            def radius(self, value):
+                self.__dict__["_radius"] = value
+
+            def __reduce__(self):
+                return (WavefrontData, (self.pupil_x, self.pupil_y, self.pupil_z, self.opd,
+                                        self.intensity, self.radius, self.prt_matrix,
+                                        self.E_exits))
+
+        DeviceWavefrontData.__name__ = DeviceWavefrontData.__qualname__ = "WavefrontData"
+        _DEVICE_WAVEFRONT_DATA = DeviceWavefrontData
+    return _DEVICE_WAVEFRONT_DATA
 
 
 def _as_input(v):

@@ -13,6 +13,8 @@ Skipped where /root/reference does not exist (the GPU box runs the same checks a
 real library in tests/test_gpu_live_reference.py).
 """
 
+import pickle
+
 import numpy as np
 import pytest
 
@@ -446,9 +448,13 @@ def test_device_resident_reference_equals_the_host_built_one(seams, reference_ty
                       distribution="hexapolar", afocal=(reference_type == "plane"))
         d = w.get_data((0.0, 0.7), lens.primary_wavelength)
         chief = w.strategy._chief_ray
+        # wavefront_data.py:36 and the reference's own test_wavefront_strategy.py:191: a float
+        assert isinstance(d.radius, float)
+        from optiland.wavefront.wavefront_data import WavefrontData
+        back = pickle.loads(pickle.dumps(d))
+        assert type(back) is WavefrontData and back.radius == d.radius
         return ([_np(be, getattr(d, k)) for k in ("opd", "intensity", "pupil_x", "pupil_y",
-                                                   "pupil_z")],
-                float(_np(be, d.radius)) if reference_type == "sphere" else float(d.radius),
+                                                   "pupil_z")], d.radius,
                 [float(_np(be, getattr(chief, k)).reshape(-1)[0]) for k in
                  ("x", "y", "z", "L", "M", "N", "opd")], type(chief).__name__)
 
