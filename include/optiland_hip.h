@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OL_ABI_VERSION 8
+#define OL_ABI_VERSION 9
 
 /* ---- error codes ------------------------------------------------------- */
 #define OL_OK 0
@@ -583,6 +583,48 @@ int ol_trace_opd_dev(const ol_system* sys, ol_dtype dt, int64_t n_rays,
                      const void* reference_dev, int32_t wavelength_index, void* opd_waves,
                      void* intensity, void* const pupil[3], double* moments12, uint32_t* status,
                      void* stream);
+
+/* ABI 9.  The FITTED reference of a wavefront, device-resident: what CentroidStrategy and
+ * BestFitStrategy (wavefront/strategy.py:287-620) derive from the traced bundle -- the sphere
+ * centred on the intensity-weighted (optionally k-sigma trimmed) centroid of the image points
+ * with the weighted mean wavefront distance as radius, or the least-squares sphere through the
+ * wavefront points; planar != 0: the plane through that centroid normal to the weighted mean
+ * direction, or the least-squares plane -- and the piston (:331-340: the mean optical path of
+ * the rays with intensity > 0).  A chain of reduction passes on `stream`, no read-back; the
+ * result is left in `reference_dev` (OL_WAVEFRONT_REFERENCE_DOUBLES doubles, the structure
+ * ol_wavefront_reference writes: [0..2] centre / plane point, [3] radius).
+ *   rays[8]    x, y, z, L, M, N, opd, intensity at the image surface (fp64 planes)
+ *   px, py     normalised pupil coordinates (the launch-plane tilt of strategy.py:88-139)
+ *   w          n_image, wavelength_um, ux, uy, half_epd; the rest is ignored
+ *   trim_std   CentroidStrategy.robust_trim_std (<= 0: no trimming)
+ *   flags      where the reference's two backends differ: OL_FIT_STD_DDOF1 = the trimming's
+ *              standard deviation divides by n - 1 (torch.std; numpy.std: n);
+ *              OL_FIT_PISTON_SKIPS_NAN = the piston is a mean over the non-NaN values (the
+ *              torch backend's be.mean, backend/torch_backend.py:969-989; numpy: NaN spreads)
+ *   workspace  OL_WAVEFRONT_FIT_WORKSPACE_DOUBLES doubles of device memory (contents undefined)
+ *   fit_status device word, WRITTEN: OL_FIT_NO_VALID / _TOO_FEW / _NO_ALIVE -- the three
+ *              ValueErrors of strategy.py:387, 536, 334 -- or OL_FIT_SINGULAR
+ * The sums are formed in a fixed order (bit-reproducible for a given n_rays).  The least-squares
+ * fits solve their normal equations in centred, per-axis scaled coordinates.
+ * ol_wavefront_opd_fitted is ol_wavefront_opd against such a reference, with the tilt added
+ * before the image-to-reference path is subtracted, as those two strategies do (:318-325). */
+#define OL_WAVEFRONT_FIT_WORKSPACE_DOUBLES 8256
+#define OL_FIT_CENTROID 0
+#define OL_FIT_BEST_FIT 1
+#define OL_FIT_NO_VALID 1u
+#define OL_FIT_TOO_FEW 2u
+#define OL_FIT_NO_ALIVE 4u
+#define OL_FIT_SINGULAR 8u
+#define OL_FIT_STD_DDOF1 1u
+#define OL_FIT_PISTON_SKIPS_NAN 2u
+int ol_wavefront_fit(int32_t kind, const ol_wavefront_params* w, double trim_std,
+                     uint32_t flags, int32_t planar, int64_t n_rays,
+                     const double* const rays[8], const double* px, const double* py,
+                     double* workspace, void* reference_dev, uint32_t* fit_status,
+                     void* stream);
+int ol_wavefront_opd_fitted(int64_t n_rays, const double* const rays[7], const double* px,
+                            const double* py, const void* reference_dev, double* opd_waves,
+                            double* const pupil[3], void* stream);
 
 /* The pupil function of the scalar FFT PSF (psf/fft.py:101-137 _generate_pupil + the
  * zero padding of :139-160): sample j of the compacted pupil list -- cell `cell[j]`

@@ -123,13 +123,19 @@ EXPORTS = (
     "ol_pupil_points",
     "ol_wavefront_reference",
     "ol_trace_opd_dev",
+    "ol_wavefront_fit",
+    "ol_wavefront_opd_fitted",
 )
 
 F32, F64 = 0, 1
 TUNE_RAYS_PER_THREAD, TUNE_COMPACT = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 OPD_MOMENTS = 12  # kOpdMoments / ol_trace_opd
 WAVEFRONT_REFERENCE_DOUBLES = 14  # OL_WAVEFRONT_REFERENCE_DOUBLES
+WAVEFRONT_FIT_WORKSPACE_DOUBLES = 8256  # OL_WAVEFRONT_FIT_WORKSPACE_DOUBLES
+FIT_CENTROID, FIT_BEST_FIT = 0, 1
+FIT_NO_VALID, FIT_TOO_FEW, FIT_NO_ALIVE, FIT_SINGULAR = 1, 2, 4, 8
+FIT_STD_DDOF1, FIT_PISTON_SKIPS_NAN = 1, 2  # the torch backend's flavour: both
 
 
 def library_path() -> str:
@@ -210,6 +216,11 @@ def bind(lib, path: str = "?"):
     lib.ol_trace_opd_dev.restype = C.c_int
     lib.ol_trace_opd_dev.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, C.POINTER(vp), vp,
                                      vp, vp]
+    lib.ol_wavefront_fit.restype = C.c_int
+    lib.ol_wavefront_fit.argtypes = [i32, vp, C.c_double, C.c_uint32, i32, i64, C.POINTER(vp), vp, vp,
+                                     vp, vp, vp, vp]
+    lib.ol_wavefront_opd_fitted.restype = C.c_int
+    lib.ol_wavefront_opd_fitted.argtypes = [i64, C.POINTER(vp), vp, vp, vp, vp, C.POINTER(vp), vp]
     lib.ol_pupil_fill.restype = C.c_int
     lib.ol_pupil_fill.argtypes = [i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     have = lib.ol_abi_version()

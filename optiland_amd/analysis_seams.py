@@ -17,6 +17,10 @@ for exactly that:
   instead of `optic.paraxial.XPL()` + `surfaces.positions` (6 of the 8 ms of an `OPD(...)`);
 * `ScalarFFTPSF._generate_pupils` / `_pad_pupils` (psf/fft.py:123-161, 203-230)
   -> `ol_pupil_fill`: the pupil function scattered straight into the zero-padded FFT grid;
+* `CentroidStrategy.compute_wavefront_data` (strategy.py:307-364; `BestFitStrategy` inherits
+  it) -> one generating launch recording the image surface + `ol_wavefront_fit` +
+  `ol_wavefront_opd_fitted`: the reference's ~100 array operations and half a dozen host
+  decisions between them as a chain of device passes with one read-back at the end;
 * `HexagonalDistribution.generate_points` (distribution.py:201-220) -> `ol_pupil_points`: the
   pupil grid of an analysis in one launch instead of a Python loop over the rings (round 4:
   10 of the 11 ms of an OPD at 256 rings).
@@ -44,7 +48,7 @@ from .packer import UnsupportedSystem
 _ORIG: dict = {}
 STATS = {"spot": 0, "spot_fallback": 0, "ee": 0, "ee_fallback": 0, "opd": 0, "opd_fallback": 0,
          "pupil": 0, "pupil_fallback": 0, "opd_init": 0, "opd_init_fallback": 0,
-         "dist": 0, "dist_fallback": 0}
+         "dist": 0, "dist_fallback": 0, "opd_fit": 0, "opd_fit_fallback": 0}
 
 
 def _front(optic, wavelength, need_fp64=False):
@@ -229,6 +233,17 @@ def _chief_init(self, optic, distribution, **kwargs):
     STATS["opd_init"] += 1
 
 
+def _launch_plane_tilt(rg, hx, hy):
+    """strategy.py:83-139 _correct_tilt: the direction cosines (ux, uy) of the launch plane's
+    tilt -- AngleField with the object at infinity only, else (0, 0)."""
+    if rg.get("object_infinite") and int(rg.get("field_kind", 0)) == 0:
+        tx = math.tan(math.radians(hx * rg["max_field"]))
+        ty = math.tan(math.radians(hy * rg["max_field"]))
+        uz = 1.0 / math.sqrt(1.0 + tx * tx + ty * ty)
+        return tx * uz, ty * uz
+    return 0.0, 0.0
+
+
 def _fused_wavefront(self, field, wavelength):
     hx, hy = _scalar(field[0]), _scalar(field[1])
     w = _scalar(wavelength)
@@ -259,13 +274,7 @@ def _fused_wavefront(self, field, wavelength):
     n_image = rg.get("n_image")  # packed at the primary wavelength, like strategy.py:57
     if n_image is None:
         n_image = _f(self.n_image)
-    # strategy.py:83-139 _correct_tilt: AngleField with the object at infinity only
-    ux = uy = 0.0
-    if rg.get("object_infinite") and int(rg.get("field_kind", 0)) == 0:
-        tx = math.tan(math.radians(hx * rg["max_field"]))
-        ty = math.tan(math.radians(hy * rg["max_field"]))
-        uz = 1.0 / math.sqrt(1.0 + tx * tx + ty * ty)
-        ux, uy = tx * uz, ty * uz
+    ux, uy = _launch_plane_tilt(rg, hx, hy)
     params = dict(xc=xc, yc=yc, zc=zc, n_image=n_image, opd_ref=0.0, ux=ux, uy=uy,
                   half_epd=rg["EPD"] / 2.0, wavelength_um=w)
     if self.reference_type == "plane":  # strategy.py:260-284
@@ -329,12 +338,7 @@ def _fused_wavefront_device(self, front, table, hx, hy, w, dx, dy):
     n_image = rg.get("n_image")
     if n_image is None:
         n_image = _f(self.n_image)
-    ux = uy = 0.0
-    if rg.get("object_infinite") and int(rg.get("field_kind", 0)) == 0:
-        tx = math.tan(math.radians(hx * rg["max_field"]))
-        ty = math.tan(math.radians(hy * rg["max_field"]))
-        uz = 1.0 / math.sqrt(1.0 + tx * tx + ty * ty)
-        ux, uy = tx * uz, ty * uz
+    ux, uy = _launch_plane_tilt(rg, hx, hy)
     planar = self.reference_type == "plane"
     pz = 0.0
     if not planar:
@@ -358,6 +362,97 @@ def _fused_wavefront_device(self, front, table, hx, hy, w, dx, dy):
     data = _device_wavefront_data()(pupil_x=pupil[0], pupil_y=pupil[1], pupil_z=pupil[2],
                                     opd=opd, intensity=inten,
                                     radius=math.inf if planar else ref[3])
+    data._hip_fused = True
+    return data
+
+
+def _fitted_compute_wavefront_data(self, field, wavelength):
+    out = None
+    try:
+        out = _fused_fitted(self, field, wavelength)
+    except UnsupportedSystem:
+        out = None
+    if out is None:
+        STATS["opd_fit_fallback"] += 1
+        return _ORIG["opd_fit"](self, field, wavelength)
+    STATS["opd_fit"] += 1
+    return out
+
+
+_FITTED_METHODS = ("_create_reference_geometry", "_points_from_rays", "_calculate_weights",
+                   "_create_spherical_ref", "_create_planar_ref", "_correct_tilt")
+
+
+def _fitted_kind(cls):
+    """"centroid" / "best_fit" when `cls` computes its reference with the stock methods of
+    CentroidStrategy / BestFitStrategy (strategy.py:287-605), None for a subclass that
+    overrides any of them (which then keeps the reference's own code path)."""
+    from optiland.wavefront.strategy import BestFitStrategy, CentroidStrategy
+
+    for kind, owner in (("best_fit", BestFitStrategy), ("centroid", CentroidStrategy)):
+        if issubclass(cls, owner):
+            same = all(getattr(owner, m, None) is not None
+                       and getattr(cls, m, None) is getattr(owner, m) for m in _FITTED_METHODS)
+            return kind if same else None
+    return None
+
+
+def _fused_fitted(self, field, wavelength):
+    """strategy.py:307-364 (CentroidStrategy.compute_wavefront_data, inherited by
+    BestFitStrategy) as: ONE generating launch that records the image surface only,
+    `ol_wavefront_fit` (the reference's chain of array reductions and host decisions as a chain
+    of device passes, result left on the device), `ol_wavefront_opd_fitted` -- and one read-back
+    at the end (radius, centre, the fit's status) next to the trace's status word."""
+    hx, hy = _scalar(field[0]), _scalar(field[1])
+    w = _scalar(wavelength)
+    if hx is None or hy is None or w is None:
+        return None
+    if self.reference_type not in ("sphere", "plane"):
+        return None
+    kind = _fitted_kind(type(self))
+    if kind is None:
+        return None
+    got = _front(self.optic, w, need_fp64=True)
+    if got is None:
+        return None
+    front, table = got
+    eng = front.engine
+    if not getattr(eng, "can_wavefront_fit", lambda: False)() \
+            or not getattr(eng, "can_trace_generate", lambda: False)():
+        return None
+    dist = self.distribution
+    dx, dy = getattr(dist, "x", None), getattr(dist, "y", None)
+    if dx is None or dy is None:
+        return None
+    trim = getattr(self, "robust_trim_std", 0.0)
+    trim = float(trim) if trim else 0.0
+    rg = table.raygen
+    n_image = rg.get("n_image")
+    if n_image is None:
+        n_image = _f(self.n_image)
+    ux, uy = _launch_plane_tilt(rg, hx, hy)
+    planar = self.reference_type == "plane"
+    params = dict(n_image=n_image, ux=ux, uy=uy, half_epd=rg["EPD"] / 2.0, wavelength_um=w)
+    px = front._dev(_as_input(dx)).contiguous()
+    py = front._dev(_as_input(dy)).contiguous()
+    vig = front._vig_scalar(hx, hy)
+    wl, _ = front._wavelength_index(w)
+    res = eng.trace_generate(px, py, wl, field=(hx, hy), vig=vig, record=True,
+                             record_first=eng.num_surfaces - 1, defer_status=True)
+    x, y, z, L, M, N, inten, opd_in = res.rows(res.last)
+    r8 = [x, y, z, L, M, N, opd_in, inten]
+    ref = eng.wavefront_fit(kind, params, r8, px, py, trim_std=trim, flavour="torch",
+                            planar=planar)
+    opd, pupil = eng.wavefront_opd_fitted(ref, r8[:7], px, py, want_pupil=True)
+    host = ref.cpu()                                    # the one wait for the device
+    front._finish_checks(eng)
+    eng.raise_for_fit_status(int(host[-1:].view(torch.int32)[0]))
+    if kind == "best_fit" and not planar:
+        self.center = tuple(float(v) for v in host[0:3])  # strategy.py:581
+    _register(self.optic, front, table, (hx, hy, px, py, vig, w, 0))
+    data = _device_wavefront_data()(pupil_x=pupil[0], pupil_y=pupil[1], pupil_z=pupil[2],
+                                    opd=opd, intensity=inten,
+                                    radius=math.inf if planar else float(host[3]))
     data._hip_fused = True
     return data
 
@@ -564,6 +659,8 @@ _SEAMS = {
            "_ee_generate_field_data"),
     "opd": ("optiland.wavefront.strategy", "ChiefRayStrategy", "compute_wavefront_data",
             ("self", "field", "wavelength"), "_chief_compute_wavefront_data"),
+    "opd_fit": ("optiland.wavefront.strategy", "CentroidStrategy", "compute_wavefront_data",
+                ("self", "field", "wavelength"), "_fitted_compute_wavefront_data"),
     "chief_init": ("optiland.wavefront.strategy", "ChiefRayStrategy", "__init__",
                    ("self", "optic", "distribution", "kwargs"), "_chief_init"),
     "pupils": ("optiland.psf.fft", "ScalarFFTPSF", "_generate_pupils", ("self",),

@@ -7,6 +7,7 @@
 
 #include "raygen_device.h"
 #include "wavefront_device.h"
+#include "wavefront_fit_device.h"
 #include "epilogue_device.h"
 #include "trace_launch.h"
 #include "surface_math.h"
@@ -522,6 +523,134 @@ hipError_t launch_stream_fill(void* dst, int64_t bytes, int width, int planes, u
     hipLaunchKernelGGL((stream_fill_kernel<u32x4>), dim3((unsigned)blocks), dim3(kBlock), 0,
                        stream, static_cast<u32x4*>(dst), n, n, planes,
                        u32x4{pattern, pattern, pattern, pattern});
+  return hipGetLastError();
+}
+
+// ---- ol_wavefront_fit: the fitted reference of CentroidStrategy / BestFitStrategy -----------
+// One launch per pass (wavefront_fit_device.h).  Every block leaves its sums as one row of the
+// workspace; the block that finishes LAST (a ticket taken after a release fence) adds the rows
+// in a fixed order -- the result does not depend on which block that was -- and its thread 0
+// takes the decision the reference takes on the host at that point.  The next pass is the next
+// launch on the same stream: no read-back anywhere in the chain.
+template <int PASS>
+__global__ __launch_bounds__(kBlock) void fit_pass_kernel(FitArgs a) {
+  FitState* st = reinterpret_cast<FitState*>(a.workspace);
+  double* rows = a.workspace + kFitStateDoubles;
+  const FitState seen = *st;  // as the previous pass left it
+  WavefrontConsts<double> ref{};
+  if constexpr (PASS == kPassMean) ref = load_consts(as_const(a.out));
+  double s[kFitSums];
+#pragma unroll
+  for (int k = 0; k < kFitSums; ++k) s[k] = 0.0;
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < a.n;
+       j += (int64_t)gridDim.x * kBlock) {
+    const FitRay r{a.ray[0][j], a.ray[1][j], a.ray[2][j], a.ray[3][j], a.ray[4][j],
+                   a.ray[5][j], a.ray[6][j], a.ray[7][j], a.px[j],     a.py[j]};
+    fit_accumulate<PASS>(a.p, seen, ref, r, s);
+  }
+  __shared__ double part[kBlock / 64][kFitSums];
+  __shared__ double fin[kBlock / kFitSums][kFitSums];
+  __shared__ bool last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double o[kFitSums];
+#pragma unroll
+    for (int k = 0; k < kFitSums; ++k) o[k] = __shfl_down(s[k], off, 64);
+#pragma unroll
+    for (int k = 0; k < kFitSums; ++k) s[k] += o[k];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < kFitSums; ++k) part[wave][k] = s[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < kFitSums) {
+    double v = 0;
+    for (int w = 0; w < kBlock / 64; ++w) v += part[w][threadIdx.x];
+    rows[(int64_t)blockIdx.x * kFitSums + threadIdx.x] = v;
+    __threadfence();  // the row before the ticket
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&st->ticket[PASS], 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  {  // rows of all blocks, in block order: 16 interleaved chains per sum, then those in order
+    const int k = threadIdx.x % kFitSums, g = threadIdx.x / kFitSums;
+    double v = 0;
+    for (unsigned b = g; b < gridDim.x; b += kBlock / kFitSums)
+      v += __hip_atomic_load(&rows[(int64_t)b * kFitSums + k], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    fin[g][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot[kFitSums];
+    for (int k = 0; k < kFitSums; ++k) {
+      double v = 0;
+      for (int g = 0; g < kBlock / kFitSums; ++g) v += fin[g][k];
+      tot[k] = v;
+    }
+    uint32_t bits = 0;
+    fit_finish<PASS>(a.p, *st, tot, a.out, &bits);
+    if (bits) atomicOr(a.status, bits);
+  }
+}
+
+hipError_t launch_wavefront_fit(const FitArgs& a, hipStream_t stream) {
+  static_assert(kBlock % kFitSums == 0 && kBlock / 64 <= kBlock / kFitSums, "fit reduction shape");
+  hipError_t e = hipMemsetAsync(a.workspace, 0, kFitStateDoubles * sizeof(double), stream);
+  if (e != hipSuccess) return e;
+  int64_t b = (a.n + kBlock - 1) / kBlock;
+  const dim3 grid((unsigned)(b < 1 ? 1 : (b > kFitMaxBlocks ? kFitMaxBlocks : b)));
+#define OL_FIT_PASS(P) \
+  hipLaunchKernelGGL((fit_pass_kernel<P>), grid, dim3(kBlock), 0, stream, a)
+  if (a.p.kind == kFitBestFit) {
+    OL_FIT_PASS(kPassB1);
+    OL_FIT_PASS(kPassB2);
+  } else {
+    OL_FIT_PASS(kPassC1);
+    if (a.p.trim_std > 0.0) {  // strategy.py:417 (`robust_trim_std and robust_trim_std > 0`)
+      OL_FIT_PASS(kPassC2);
+      OL_FIT_PASS(kPassC3);
+      OL_FIT_PASS(kPassC4);
+    }
+    if (!a.p.planar) OL_FIT_PASS(kPassC5);
+  }
+  OL_FIT_PASS(kPassMean);
+#undef OL_FIT_PASS
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(kBlock) void wavefront_fitted_kernel(
+    const WavefrontConsts<double>* ref, int64_t n, const double* __restrict__ x,
+    const double* __restrict__ y, const double* __restrict__ z, const double* __restrict__ Ld,
+    const double* __restrict__ Md, const double* __restrict__ Nd,
+    const double* __restrict__ opd_in, const double* __restrict__ px,
+    const double* __restrict__ py, double* opd_waves, double* pux, double* puy, double* puz) {
+  const WavefrontConsts<double> w = load_consts(as_const(ref));
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * kBlock) {
+    double pu[3];
+    opd_waves[j] = wavefront_one<double, true>(w, x[j], y[j], z[j], Ld[j], Md[j], Nd[j],
+                                               opd_in[j], px[j], py[j], pu);
+    if (pux) {
+      pux[j] = pu[0];
+      puy[j] = pu[1];
+      puz[j] = pu[2];
+    }
+  }
+}
+
+hipError_t launch_wavefront_fitted(const WavefrontConsts<double>* ref, int64_t n,
+                                   const double* const rays[7], const double* px,
+                                   const double* py, double* opd_waves, double* const pupil[3],
+                                   hipStream_t stream) {
+  hipLaunchKernelGGL(wavefront_fitted_kernel, dim3(grid_for(n)), dim3(kBlock), 0, stream, ref, n,
+                     rays[0], rays[1], rays[2], rays[3], rays[4], rays[5], rays[6], px, py,
+                     opd_waves, pupil ? pupil[0] : nullptr, pupil ? pupil[1] : nullptr,
+                     pupil ? pupil[2] : nullptr);
   return hipGetLastError();
 }
 

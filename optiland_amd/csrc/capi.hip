@@ -1331,6 +1331,71 @@ int ol_trace_opd_dev(const ol_system* sys, ol_dtype dt, int64_t n_rays,
                               static_cast<hipStream_t>(stream), reference_dev);
 }
 
+int ol_wavefront_fit(int32_t kind, const ol_wavefront_params* w, double trim_std,
+                     uint32_t flags, int32_t planar, int64_t n_rays,
+                     const double* const rays[8], const double* px, const double* py,
+                     double* workspace, void* reference_dev, uint32_t* fit_status,
+                     void* stream) {
+  static_assert(OL_WAVEFRONT_FIT_WORKSPACE_DOUBLES == ol::kFitWorkspaceDoubles, "header");
+  static_assert(OL_FIT_NO_VALID == ol::kFitNoValid && OL_FIT_TOO_FEW == ol::kFitTooFew &&
+                OL_FIT_NO_ALIVE == ol::kFitNoAlive && OL_FIT_SINGULAR == ol::kFitSingular &&
+                OL_FIT_CENTROID == ol::kFitCentroid && OL_FIT_BEST_FIT == ol::kFitBestFit,
+                "header");
+  if (!w || !rays || !px || !py || !workspace || !reference_dev || !fit_status)
+    return fail(OL_EINVAL, "ol_wavefront_fit: NULL argument");
+  if (kind != OL_FIT_CENTROID && kind != OL_FIT_BEST_FIT)
+    return fail(OL_EINVAL, "ol_wavefront_fit: unknown kind %d", (int)kind);
+  if (n_rays < 0) return fail(OL_EINVAL, "ol_wavefront_fit: negative count");
+  if (flags & ~(uint32_t)(OL_FIT_STD_DDOF1 | OL_FIT_PISTON_SKIPS_NAN))
+    return fail(OL_EINVAL, "ol_wavefront_fit: unknown flags 0x%x", (unsigned)flags);
+  if (!(w->n_image > 0.0) || !(w->wavelength_um > 0.0))
+    return fail(OL_EINVAL, "ol_wavefront_fit: n_image %g, wavelength %g", w->n_image,
+                w->wavelength_um);
+  for (int k = 0; k < 8; ++k)
+    if (!rays[k]) return fail(OL_EINVAL, "ol_wavefront_fit: rays[%d] is NULL", k);
+  ol::FitArgs a{};
+  a.p.ni = w->n_image;
+  a.p.inv_w = 1.0 / (w->wavelength_um * 1e-3);
+  a.p.ux = w->ux;
+  a.p.uy = w->uy;
+  a.p.half_epd = w->half_epd;
+  a.p.trim_std = trim_std > 0.0 ? trim_std : 0.0;  // (NaN: no trimming either)
+  a.p.kind = kind;
+  a.p.planar = planar ? 1 : 0;
+  a.p.ddof = (flags & OL_FIT_STD_DDOF1) ? 1 : 0;
+  a.p.skip_nan = (flags & OL_FIT_PISTON_SKIPS_NAN) ? 1 : 0;
+  for (int k = 0; k < 8; ++k) a.ray[k] = rays[k];
+  a.px = px;
+  a.py = py;
+  a.n = n_rays;
+  a.workspace = workspace;
+  a.out = static_cast<ol::WavefrontConsts<double>*>(reference_dev);
+  a.status = fit_status;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(fit_status, 0, sizeof(uint32_t), st);
+  if (e == hipSuccess) e = ol::launch_wavefront_fit(a, st);
+  if (e != hipSuccess) return fail(OL_EHIP, "ol_wavefront_fit: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
+int ol_wavefront_opd_fitted(int64_t n_rays, const double* const rays[7], const double* px,
+                            const double* py, const void* reference_dev, double* opd_waves,
+                            double* const pupil[3], void* stream) {
+  if (!rays || !px || !py || !reference_dev || !opd_waves)
+    return fail(OL_EINVAL, "ol_wavefront_opd_fitted: NULL argument");
+  if (n_rays < 0) return fail(OL_EINVAL, "ol_wavefront_opd_fitted: negative count");
+  for (int k = 0; k < 7; ++k)
+    if (!rays[k]) return fail(OL_EINVAL, "ol_wavefront_opd_fitted: rays[%d] is NULL", k);
+  if (pupil && (!pupil[0] || !pupil[1] || !pupil[2]))
+    return fail(OL_EINVAL, "ol_wavefront_opd_fitted: pupil needs three planes");
+  if (n_rays == 0) return OL_OK;
+  hipError_t e = ol::launch_wavefront_fitted(
+      static_cast<const ol::WavefrontConsts<double>*>(reference_dev), n_rays, rays, px, py,
+      opd_waves, pupil, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(OL_EHIP, "ol_wavefront_opd_fitted: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
 int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void* intensity,
                   const void* pupil_x, const void* pupil_y, const double plane[3],
                   const int32_t* cell, int32_t n_side, int32_t grid_size, double* grid,

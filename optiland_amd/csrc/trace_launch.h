@@ -277,6 +277,45 @@ struct ChiefArgs {
 template <typename T>
 hipError_t launch_chief_reference(const ChiefArgs<T>& a, int nr_family, hipStream_t stream);
 
+// ol_wavefront_fit (aux_kernels.hip, wavefront_fit_device.h): the reference sphere / plane of
+// CentroidStrategy / BestFitStrategy (wavefront/strategy.py:287-620) from the traced bundle,
+// as a chain of reduction passes that leaves a WavefrontConsts<double> in device memory
+constexpr int kFitSums = 16;        // running sums per pass (at most)
+constexpr int kFitMaxBlocks = 512;  // grid of a pass; one row of partial sums per block
+constexpr int kFitStateDoubles = 64;
+constexpr int kFitWorkspaceDoubles = kFitStateDoubles + kFitMaxBlocks * kFitSums;
+
+enum : int32_t { kFitCentroid = 0, kFitBestFit = 1 };
+enum : int32_t { kPassC1 = 0, kPassC2, kPassC3, kPassC4, kPassC5, kPassB1, kPassB2, kPassMean,
+                 kFitPasses };
+// fit_status bits (ol_wavefront_fit): the reference's three ValueErrors and a singular fit
+enum : uint32_t { kFitNoValid = 1u, kFitTooFew = 2u, kFitNoAlive = 4u, kFitSingular = 8u };
+
+struct FitParams {
+  double ni, inv_w, ux, uy, half_epd, trim_std;
+  int32_t kind, planar;
+  int32_t ddof;      // of the trimming's standard deviation: torch.std 1, numpy.std 0
+  int32_t skip_nan;  // the piston is a mean that ignores NaN (the torch backend's be.mean)
+};
+
+struct FitArgs {
+  FitParams p;
+  const double* ray[8];  // x, y, z, L, M, N, opd, intensity at the image surface
+  const double* px;
+  const double* py;
+  int64_t n;
+  double* workspace;     // kFitWorkspaceDoubles: between-pass state + one row of sums per block
+  WavefrontConsts<double>* out;
+  uint32_t* status;      // kFit* bits, OR-ed in
+};
+hipError_t launch_wavefront_fit(const FitArgs& a, hipStream_t stream);
+// the OPD map against such a device-resident reference (tilt added before the subtraction,
+// strategy.py:318-340)
+hipError_t launch_wavefront_fitted(const WavefrontConsts<double>* ref, int64_t n,
+                                   const double* const rays[7], const double* px,
+                                   const double* py, double* opd_waves, double* const pupil[3],
+                                   hipStream_t stream);
+
 template <typename T>
 hipError_t launch_pupil_fill(int64_t n, const T* opd, const T* inten, const T* pupil_x,
                              const T* pupil_y, const double coef[3], const int32_t* cell,

@@ -32,11 +32,14 @@ OL_DEV WavefrontConsts<T> load_consts(cptr<WavefrontConsts<T>> p) {
 }
 
 // (xr, yr, zr), (Ld, Md, Nd), opd_in: the ray at the image surface (global frame);
-// (px, py): its normalised pupil coordinates.  Returns the OPD in waves; pu = the point
-// where the back-propagated ray meets the reference surface.
-template <typename T>
-OL_DEV T wavefront_one(const WavefrontConsts<T>& w, T xr, T yr, T zr, T Ld,
-                                           T Md, T Nd, T opd_in, T px, T py, T (&pu)[3]) {
+// (px, py): its normalised pupil coordinates.  Returns the ray's optical path to the reference
+// surface in mm; pu = the point where the back-propagated ray meets that surface.
+// TILT_FIRST: the launch-plane tilt is added to the ray's path BEFORE the image-to-reference
+// path is subtracted (CentroidStrategy / BestFitStrategy, strategy.py:318-325) instead of
+// after it (ChiefRayStrategy, :190-195) -- the same number but for the last bit.
+template <typename T, bool TILT_FIRST = false>
+OL_DEV T wavefront_opd_mm(const WavefrontConsts<T>& w, T xr, T yr, T zr, T Ld, T Md, T Nd,
+                          T opd_in, T px, T py, T (&pu)[3]) {
   const T L = -Ld, M = -Md, N = -Nd;  // trace backwards from the image
   T t;
 #if OL_WAVEFRONT_FAST
@@ -60,7 +63,7 @@ OL_DEV T wavefront_one(const WavefrontConsts<T>& w, T xr, T yr, T zr, T Ld,
   }
   const T opd_img = w.ni * t;
   const T tilt = w.ux * (px * w.half_epd) + w.uy * (py * w.half_epd);
-  const T opd = opd_in - opd_img + tilt;
+  const T opd = TILT_FIRST ? (opd_in + tilt) - opd_img : opd_in - opd_img + tilt;
   const T tt = m::div(opd_img, w.ni);
 #else
   if (w.planar) {  // reference_geometry.py:104-124
@@ -81,12 +84,20 @@ OL_DEV T wavefront_one(const WavefrontConsts<T>& w, T xr, T yr, T zr, T Ld,
   }
   const T opd_img = w.ni * t;
   const T tilt = w.ux * (px * w.half_epd) + w.uy * (py * w.half_epd);
-  const T opd = opd_in - opd_img + tilt;
+  const T opd = TILT_FIRST ? (opd_in + tilt) - opd_img : opd_in - opd_img + tilt;
   const T tt = opd_img / w.ni;
 #endif
   pu[0] = xr - tt * Ld;
   pu[1] = yr - tt * Md;
   pu[2] = zr - tt * Nd;
+  return opd;
+}
+
+// ... and the OPD in waves against the reference's own path `opd_ref`
+template <typename T, bool TILT_FIRST = false>
+OL_DEV T wavefront_one(const WavefrontConsts<T>& w, T xr, T yr, T zr, T Ld, T Md, T Nd, T opd_in,
+                       T px, T py, T (&pu)[3]) {
+  const T opd = wavefront_opd_mm<T, TILT_FIRST>(w, xr, yr, zr, Ld, Md, Nd, opd_in, px, py, pu);
   return (w.opd_ref - opd) * w.inv_w;
 }
 

@@ -732,6 +732,77 @@ class HipSystem:
         self._check(rc, "ol_wavefront_reference")
         return ref, chief
 
+    def can_wavefront_fit(self) -> bool:
+        return hasattr(self.lib, "ol_wavefront_fit")
+
+    def wavefront_fit(self, kind: str, params: dict, rays8, px, py, *, trim_std: float = 3.0,
+                      flavour: str = "torch", planar: bool = False) -> torch.Tensor:
+        """`ol_wavefront_fit`: the reference sphere / plane `CentroidStrategy` (kind "centroid")
+        or `BestFitStrategy` ("best_fit") derive from the traced bundle `rays8` = x, y, z, L, M,
+        N, opd, intensity at the image surface (fp64 device planes), and the piston, as a chain
+        of device reductions -- LEFT ON THE DEVICE.  `params`: n_image, wavelength_um, ux, uy,
+        half_epd; `flavour`: which of the reference's backends to follow where they differ
+        ("torch": std with n - 1, NaN-ignoring piston mean; "numpy": n, plain mean).
+        Returns `reference`, a float64 device tensor for `wavefront_opd_fitted`: `[0:3]` centre
+        / plane point, `[3]` radius, `[10:13]` plane normal, and in its last slot the status
+        word of the fit (`fit_result` reads both back in one copy).  No read-back here."""
+        n = int(px.numel())
+        for t in (*rays8, px, py):
+            if t.dtype != torch.float64 or t.numel() != n or not t.is_contiguous():
+                raise ValueError("wavefront_fit: contiguous float64 planes of one length")
+        nref = _capi.WAVEFRONT_REFERENCE_DOUBLES
+        ref = torch.empty(nref + 1, dtype=torch.float64, device=self.device)
+        work = torch.empty(_capi.WAVEFRONT_FIT_WORKSPACE_DOUBLES, dtype=torch.float64,
+                           device=self.device)
+        w = _capi.WavefrontParams(**{k: float(params.get(k, 0.0)) for k, _ in
+                                     _capi.WavefrontParams._fields_})
+        rp = (C.c_void_p * 8)(*[t.data_ptr() for t in rays8])
+        code = {"centroid": _capi.FIT_CENTROID, "best_fit": _capi.FIT_BEST_FIT}[kind]
+        flags = {"torch": _capi.FIT_STD_DDOF1 | _capi.FIT_PISTON_SKIPS_NAN, "numpy": 0}[flavour]
+        with self._device_ctx():
+            rc = self.lib.ol_wavefront_fit(code, C.byref(w), float(trim_std or 0.0),
+                                           flags, 1 if planar else 0, n, rp,
+                                           px.data_ptr(), py.data_ptr(), work.data_ptr(),
+                                           ref.data_ptr(), ref[nref:].data_ptr(), self._stream())
+        self._check(rc, "ol_wavefront_fit")
+        return ref
+
+    @staticmethod
+    def fit_result(reference: torch.Tensor):
+        """(radius, status bits) of a `wavefront_fit` reference: ONE device-to-host copy."""
+        host = reference.cpu()
+        return float(host[3]), int(host[-1:].view(torch.int32)[0])
+
+    @staticmethod
+    def raise_for_fit_status(bits: int) -> None:
+        """The reference's own errors (wavefront/strategy.py:387, 536, 334) for the bits
+        `ol_wavefront_fit` left."""
+        if bits & _capi.FIT_NO_VALID:
+            raise ValueError("No valid ray samples found for best-fit geometry.")
+        if bits & _capi.FIT_TOO_FEW:
+            raise ValueError("Need at least 4 valid ray samples for best-fit.")
+        if bits & _capi.FIT_SINGULAR:
+            raise RuntimeError("Least-squares sphere fit failed: singular normal equations")
+        if bits & _capi.FIT_NO_ALIVE:
+            raise ValueError("No valid rays with non-zero intensity for OPD calculation.")
+
+    def wavefront_opd_fitted(self, reference: torch.Tensor, rays7, px, py,
+                             want_pupil: bool = True):
+        """`ol_wavefront_opd_fitted`: OPD in waves (+ the reference-surface intersection
+        points) of the bundle against a device-resident fitted reference."""
+        n = int(px.numel())
+        opd = torch.empty(n, dtype=torch.float64, device=self.device)
+        pupil = torch.empty((3, n), dtype=torch.float64, device=self.device) if want_pupil \
+            else None
+        rp = (C.c_void_p * 7)(*[t.data_ptr() for t in rays7])
+        pp = (C.c_void_p * 3)(*[pupil[k].data_ptr() for k in range(3)]) if want_pupil else None
+        with self._device_ctx():
+            rc = self.lib.ol_wavefront_opd_fitted(n, rp, px.data_ptr(), py.data_ptr(),
+                                                  reference.data_ptr(), opd.data_ptr(), pp,
+                                                  self._stream())
+        self._check(rc, "ol_wavefront_opd_fitted")
+        return opd, pupil
+
     def pupil_fill(self, opd, intensity, cell: torch.Tensor, n_side: int, grid_size: int,
                    pupil_xy=None, plane=None) -> torch.Tensor:
         """`ol_pupil_fill`: A exp(-i 2 pi OPD) of the compacted samples scattered into the

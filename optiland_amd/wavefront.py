@@ -202,79 +202,33 @@ class Wavefront:
 
 
     def _compute_fitted(self) -> WavefrontData:
-        """CentroidStrategy / BestFitStrategy with a spherical reference
-        (wavefront/strategy.py:287-582): the reference sphere comes from the traced bundle
-        itself -- centred on the intensity-weighted (3-sigma trimmed) centroid of the image
-        points with the weighted mean wavefront distance as radius, or the least-squares
-        sphere through the wavefront points -- and the piston is the mean OPD of the rays
-        with intensity > 0.  A handful of device reductions around the same
-        `ol_wavefront_opd` launch."""
+        """CentroidStrategy / BestFitStrategy (wavefront/strategy.py:287-620): the reference
+        sphere / plane comes from the traced bundle itself -- centred on the intensity-weighted
+        (3-sigma trimmed) centroid of the image points with the weighted mean wavefront
+        distance as radius, or the least-squares sphere / plane through the wavefront points
+        -- and the piston is the mean OPD of the rays with intensity > 0.  Three steps on the
+        device: the trace, `ol_wavefront_fit` (a chain of reductions that leaves the reference
+        in device memory) and `ol_wavefront_opd_fitted`; ONE read-back (radius + fit status).
+        This stand-alone class follows the reference's NumPy backend where its two backends
+        differ (np.std, plain mean)."""
         t, rg = self.tracer, self.tracer.table.raygen
         hx, hy = self.field
         rays = t.trace(hx, hy, self.wavelength, None, self.distribution)
         px, py = t._dev(self.distribution.x), t._dev(self.distribution.y)
         ux, uy = self._tilt_cosines()
-        half = rg["EPD"] / 2.0
-        opd_c = rays.opd + ux * (px * half) + uy * (py * half)          # strategy.py:88-139
-        inten = rays.i
-        P = torch.stack([rays.x, rays.y, rays.z], dim=1)
-        D = torch.stack([rays.L, rays.M, rays.N], dim=1)
-        valid = (torch.isfinite(P).all(1) & torch.isfinite(D).all(1) & torch.isfinite(opd_c)
-                 & (inten != 0))                                         # :367-393
-        if not bool(valid.any()):
-            raise ValueError("No valid ray samples found for best-fit geometry.")
-        img = P[valid]
-        pts = img - (opd_c[valid] / rg["n_image"])[:, None] * D[valid]
-        normal = None
-        if self.strategy == "centroid":
-            w = inten[valid].clamp(min=0.0)                              # :395-431
-            total = w.sum()
-            if float(total) == 0.0:
-                w = torch.ones_like(w)
-                total = w.sum()
-            if self.robust_trim_std > 0:
-                c0 = (img * w[:, None]).sum(0) / total
-                dist = torch.linalg.norm(img - c0, dim=1)
-                mean_d, std_d = dist.mean(), dist.std(unbiased=False)
-                if float(std_d) > 0:
-                    keep = dist <= mean_d + self.robust_trim_std * std_d
-                    if int(keep.sum()) >= 4:
-                        w = w * keep
-            center = (img * w[:, None]).sum(0) / w.sum()                 # :433-474
-            if self.afocal:                                              # :485-517
-                normal = (D[valid] * w[:, None]).sum(0) / w.sum()
-                nrm = torch.linalg.norm(normal)
-                normal = normal / nrm if float(nrm) > 0 else normal
-                R = math.inf
-            else:
-                R = float((w * torch.linalg.norm(pts - center, dim=1)).sum() / w.sum())
-        elif self.afocal:                                                # :584-605
-            if pts.shape[0] < 4:
-                raise ValueError("Need at least 4 valid ray samples for best-fit.")
-            center = pts.mean(0)
-            normal = torch.linalg.svd((pts - center).cpu(), full_matrices=False).Vh[-1].to(pts)
-            R = math.inf
-        else:
-            if pts.shape[0] < 4:
-                raise ValueError("Need at least 4 valid ray samples for best-fit.")
-            A = torch.cat([pts, torch.ones_like(pts[:, :1])], dim=1)     # :556-582
-            b = (pts * pts).sum(1)
-            c = torch.linalg.lstsq(A.cpu(), b.cpu()[:, None], driver="gelsd").solution[:, 0].to(A)
-            center = c[:3] / 2
-            R = float(torch.sqrt(c[3] + (center * center).sum()))
-        xc, yc, zc = (float(v) for v in center)
-        params = dict(xc=xc, yc=yc, zc=zc, R=0.0 if normal is not None else R,
-                      n_image=rg["n_image"], opd_ref=0.0, ux=ux,
-                      uy=uy, half_epd=half, wavelength_um=self.wavelength)
-        if normal is not None:
-            params.update(nx=float(normal[0]), ny=float(normal[1]), nz=float(normal[2]))
-        r7 = [v.contiguous() for v in (rays.x, rays.y, rays.z, rays.L, rays.M, rays.N, rays.opd)]
-        neg, pupil = t.engine.wavefront_opd(params, r7, px, py, want_pupil=True)
-        alive = inten > 0                                                # :331-340
-        if not bool(alive.any()):
-            raise ValueError("No valid rays with non-zero intensity for OPD calculation.")
-        opd = neg - neg[alive].mean()       # (mean_opd - opd) / lambda
-        return WavefrontData(pupil[0], pupil[1], pupil[2], opd, inten.clone(), R)
+        params = dict(n_image=rg["n_image"], wavelength_um=self.wavelength, ux=ux, uy=uy,
+                      half_epd=rg["EPD"] / 2.0)
+        r8 = [v.contiguous() for v in (rays.x, rays.y, rays.z, rays.L, rays.M, rays.N, rays.opd,
+                                       rays.i)]
+        px, py = px.contiguous(), py.contiguous()
+        ref = t.engine.wavefront_fit(self.strategy, params, r8, px, py,
+                                     trim_std=self.robust_trim_std, flavour="numpy",
+                                     planar=self.afocal)
+        opd, pupil = t.engine.wavefront_opd_fitted(ref, r8[:7], px, py, want_pupil=True)
+        R, bits = t.engine.fit_result(ref)
+        t.engine.raise_for_fit_status(bits)
+        return WavefrontData(pupil[0], pupil[1], pupil[2], opd, r8[7].clone(),
+                             math.inf if self.afocal else R)
 
 
 class OPD(Wavefront):

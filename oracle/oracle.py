@@ -181,6 +181,112 @@ def distance(table, surface_index, x, y, z, L, M, N):
     return t
 
 
+def wavefront_fit(kind: str, params: dict, rays8, px, py, *, trim_std=3.0, flavour="torch",
+                  planar=False) -> dict:
+    """CentroidStrategy / BestFitStrategy of the reference restated in NumPy, operation for
+    operation (wavefront/strategy.py:287-620): from the bundle at the image surface `rays8` =
+    x, y, z, L, M, N, opd, intensity to the reference sphere / plane, the piston, the OPD map in
+    waves and the reference-surface intersection points.  `params`: n_image, wavelength_um,
+    ux, uy, half_epd (the launch-plane tilt, strategy.py:88-139).  `flavour`: which backend's
+    reductions -- "torch": std with n - 1 (torch.std) and a NaN-ignoring mean
+    (backend/torch_backend.py:969-1001), "numpy": np.std / np.mean.  Raises the reference's
+    ValueErrors.  Pinned by tests/golden/wavefront_fitted.npz (tools/make_golden_fitted.py)."""
+    x, y, z, L, M, N, opd, inten = (np.asarray(v, dtype=np.float64) for v in rays8)
+    px, py = np.asarray(px, dtype=np.float64), np.asarray(py, dtype=np.float64)
+    ni = float(params["n_image"])
+    wl = float(params["wavelength_um"])
+    ux, uy, half = (float(params.get(k, 0.0)) for k in ("ux", "uy", "half_epd"))
+    torch_like = flavour == "torch"
+
+    def mean(v):
+        if torch_like:
+            ok = ~np.isnan(v)
+            return v[ok].sum() / ok.sum() if ok.any() else np.nan
+        return np.mean(v)
+
+    with np.errstate(all="ignore"):
+        opd = opd + (ux * (px * half) + uy * (py * half))             # :318-319 _correct_tilt
+        valid = (np.isfinite(x) & np.isfinite(y) & np.isfinite(z) & np.isfinite(L)
+                 & np.isfinite(M) & np.isfinite(N) & np.isfinite(opd) & (inten != 0))  # :376-385
+        if not valid.any():
+            raise ValueError("No valid ray samples found for best-fit geometry.")
+        P = np.stack((x, y, z), axis=1)[valid]
+        D = np.stack((L, M, N), axis=1)[valid]
+        pts = P - (opd[valid] / ni)[:, None] * D                      # :389-393
+        normal = None
+        if kind == "centroid":
+            w = inten[valid]
+            w = np.where(w < 0.0, 0.0, w)                             # :406-408
+            total = w.sum()
+            if total == 0:
+                w = np.ones_like(w)
+                total = w.sum()
+            if trim_std and trim_std > 0:                             # :417-429
+                c0 = (P * w[:, None]).sum(axis=0) / total
+                dist = np.linalg.norm(P - c0, axis=1)
+                mean_d = mean(dist)
+                std_d = np.std(dist, ddof=1 if torch_like else 0)
+                if std_d > 0:
+                    keep = dist <= mean_d + trim_std * std_d
+                    if keep.sum() >= 4:
+                        w = w * keep
+            total = w.sum()
+            center = (P * w[:, None]).sum(axis=0) / total             # :447-450
+            if planar:                                                # :485-517
+                normal = (D * w[:, None]).sum(axis=0) / w.sum()
+                nrm = np.linalg.norm(normal)
+                if nrm > 0:
+                    normal = normal / nrm
+                radius = np.inf
+            else:                                                     # :457-474
+                radius = float((w * np.linalg.norm(pts - center, axis=1)).sum() / w.sum())
+        elif kind == "best_fit":
+            if pts.shape[0] < 4:
+                raise ValueError("Need at least 4 valid ray samples for best-fit.")
+            if planar:                                                # :584-605
+                center = pts.mean(axis=0)
+                normal = np.linalg.svd(pts - center, full_matrices=False)[2][-1, :]
+                radius = np.inf
+            else:                                                     # :556-582
+                A = np.stack([pts[:, 0], pts[:, 1], pts[:, 2], np.ones(len(pts))], axis=1)
+                b = (pts ** 2).sum(axis=1)
+                c = np.linalg.lstsq(A, b, rcond=None)[0]
+                center = c[:3] / 2
+                radius = float(np.sqrt(c[3] + (center ** 2).sum()))
+        else:
+            raise ValueError(kind)
+        # reference_geometry.py:55-83 / 99-124 path_length, strategy.py:321-345
+        bl, bm, bn = -L, -M, -N
+        if normal is None:
+            xc, yc, zc = center
+            a_ = bl ** 2 + bm ** 2 + bn ** 2
+            b_ = 2 * (bl * (x - xc) + bm * (y - yc) + bn * (z - zc))
+            c_ = (x ** 2 + y ** 2 + z ** 2 - 2 * (x * xc + y * yc + z * zc)
+                  + xc ** 2 + yc ** 2 + zc ** 2 - radius ** 2)
+            d_ = b_ ** 2 - 4 * a_ * c_
+            d_ = np.where(d_ < 0, 0, d_)
+            t1 = (-b_ - np.sqrt(d_)) / (2 * a_)
+            t2 = (-b_ + np.sqrt(d_)) / (2 * a_)
+            t = np.where(t1 < 0, t2, t1)
+        else:
+            num = (x - center[0]) * normal[0] + (y - center[1]) * normal[1] \
+                + (z - center[2]) * normal[2]
+            den = bl * normal[0] + bm * normal[1] + bn * normal[2]
+            den = np.where(np.abs(den) < 1e-12, 1e-12, den)
+            t = -num / den
+        opd_img = ni * t
+        o = opd - opd_img
+        alive = inten > 0
+        if not alive.any():
+            raise ValueError("No valid rays with non-zero intensity for OPD calculation.")
+        mean_opd = mean(o[alive])
+        waves = (mean_opd - o) / (wl * 1e-3)
+        tt = opd_img / ni
+        pupil = np.stack([x - tt * L, y - tt * M, z - tt * N])
+    return dict(center=np.asarray(center, dtype=np.float64), radius=radius, normal=normal,
+                opd_ref=float(mean_opd), opd=waves, pupil=pupil)
+
+
 class WavefrontParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("xc", "yc", "zc", "R", "n_image", "opd_ref", "ux",
                                           "uy", "half_epd", "wavelength_um", "nx", "ny", "nz")]

@@ -133,6 +133,51 @@ class OracleEngine:
         return (torch.as_tensor(out, dtype=px.dtype),
                 torch.as_tensor(pupil, dtype=px.dtype) if want_pupil else None)
 
+    # ol_wavefront_fit / ol_wavefront_opd_fitted through oracle.wavefront_fit (the NumPy
+    # restatement of strategy.py:287-620): same reference layout as the product's engine
+    def can_wavefront_fit(self):
+        return True
+
+    def wavefront_fit(self, kind, params, rays8, px, py, *, trim_std=3.0, flavour="torch",
+                      planar=False):
+        ref = torch.zeros(15, dtype=torch.float64)
+        bits = 0
+        try:
+            got = oracle.wavefront_fit(kind, params, [t.double().numpy() for t in rays8],
+                                       px.double().numpy(), py.double().numpy(),
+                                       trim_std=trim_std, flavour=flavour, planar=planar)
+        except ValueError as exc:
+            msg = str(exc)
+            bits = 1 if "No valid ray samples" in msg else 2 if "at least 4" in msg else 4
+            got = None
+        if got is not None:
+            ref[0:3] = torch.as_tensor(got["center"])
+            ref[3] = 0.0 if planar else got["radius"]
+            ref[9] = got["opd_ref"]
+            if got["normal"] is not None:
+                ref[10:13] = torch.as_tensor(got["normal"])
+        ref[4] = params["n_image"]
+        ref[5] = 1.0 / (params["wavelength_um"] * 1e-3)
+        ref[6], ref[7], ref[8] = params.get("ux", 0.0), params.get("uy", 0.0), params["half_epd"]
+        ref[14:].view(torch.int32)[0] = bits
+        return ref
+
+    @staticmethod
+    def fit_result(reference):
+        return float(reference[3]), int(reference[-1:].view(torch.int32)[0])
+
+    @staticmethod
+    def raise_for_fit_status(bits):
+        from optiland_amd.engine import HipSystem
+        HipSystem.raise_for_fit_status(bits)
+
+    def wavefront_opd_fitted(self, reference, rays7, px, py, want_pupil=True):
+        r = reference.tolist()
+        params = dict(xc=r[0], yc=r[1], zc=r[2], R=r[3], n_image=r[4], opd_ref=r[9], ux=r[6],
+                      uy=r[7], half_epd=r[8], wavelength_um=1.0 / r[5] * 1e3, nx=r[10], ny=r[11],
+                      nz=r[12])
+        return self.wavefront_opd(params, rays7, px, py, want_pupil)
+
     def trace_opd(self, params, px, py, wl_index, *, field, vig=(1.0, 1.0), want_pupil=True,
                   moments=None, check_status=True):
         """ol_trace_opd as the composition of the oracle's generate -> trace -> OPD."""

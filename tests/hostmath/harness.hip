@@ -32,6 +32,7 @@
 #include "../../optiland_amd/csrc/surface_math.h"
 #include "../../optiland_amd/csrc/raygen_device.h"
 #include "../../optiland_amd/csrc/wavefront_device.h"
+#include "../../optiland_amd/csrc/wavefront_fit_device.h"
 #include "../../optiland_amd/csrc/epilogue_device.h"
 #include "../../optiland_amd/csrc/trace_launch.h"
 
@@ -53,6 +54,10 @@ hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) {
 }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t) {
   std::memcpy(dst, src, n);
+  return hipSuccess;
+}
+hipError_t hipMemsetAsync(void* dst, int value, size_t n, hipStream_t) {
+  std::memset(dst, value, n);
   return hipSuccess;
 }
 hipError_t hipGetDevice(int* d) {
@@ -591,6 +596,62 @@ hipError_t launch_chief_reference(const ChiefArgs<T>& a_in, int nr_family, hipSt
   return hipSuccess;
 }
 template hipError_t launch_chief_reference<double>(const ChiefArgs<double>&, int, hipStream_t);
+
+// fit_pass_kernel + launch_wavefront_fit (aux_kernels.hip): the same passes in the same order,
+// each pass's sums formed ray by ray (the device adds per-block rows in block order)
+template <int PASS>
+void fit_pass(const FitArgs& a) {
+  FitState* st = reinterpret_cast<FitState*>(a.workspace);
+  const FitState seen = *st;
+  WavefrontConsts<double> ref{};
+  if (PASS == kPassMean) ref = *a.out;
+  double s[kFitSums] = {0};
+  for (int64_t j = 0; j < a.n; ++j) {
+    const FitRay r{a.ray[0][j], a.ray[1][j], a.ray[2][j], a.ray[3][j], a.ray[4][j],
+                   a.ray[5][j], a.ray[6][j], a.ray[7][j], a.px[j],     a.py[j]};
+    fit_accumulate<PASS>(a.p, seen, ref, r, s);
+  }
+  uint32_t bits = 0;
+  fit_finish<PASS>(a.p, *st, s, a.out, &bits);
+  *a.status |= bits;
+}
+
+hipError_t launch_wavefront_fit(const FitArgs& a, hipStream_t) {
+  std::memset(a.workspace, 0, kFitStateDoubles * sizeof(double));
+  if (a.p.kind == kFitBestFit) {
+    fit_pass<kPassB1>(a);
+    fit_pass<kPassB2>(a);
+  } else {
+    fit_pass<kPassC1>(a);
+    if (a.p.trim_std > 0.0) {
+      fit_pass<kPassC2>(a);
+      fit_pass<kPassC3>(a);
+      fit_pass<kPassC4>(a);
+    }
+    if (!a.p.planar) fit_pass<kPassC5>(a);
+  }
+  fit_pass<kPassMean>(a);
+  return hipSuccess;
+}
+
+hipError_t launch_wavefront_fitted(const WavefrontConsts<double>* ref, int64_t n,
+                                   const double* const rays[7], const double* px,
+                                   const double* py, double* opd_waves, double* const pupil[3],
+                                   hipStream_t) {
+  const WavefrontConsts<double> w = *ref;
+  for (int64_t j = 0; j < n; ++j) {
+    double pu[3];
+    opd_waves[j] = wavefront_one<double, true>(w, rays[0][j], rays[1][j], rays[2][j], rays[3][j],
+                                               rays[4][j], rays[5][j], rays[6][j], px[j], py[j],
+                                               pu);
+    if (pupil) {
+      pupil[0][j] = pu[0];
+      pupil[1][j] = pu[1];
+      pupil[2][j] = pu[2];
+    }
+  }
+  return hipSuccess;
+}
 
 // the four reduction kernels of aux_kernels.hip, element by element (sums in element order)
 template <typename T>

@@ -504,3 +504,88 @@ def test_seams_decline_an_optic_whose_last_surface_has_a_thickness(seams):
     got = run(build())
     assert stats["opd"] == before            # declined ...
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)   # ... and right
+
+
+# ----------------------------------------------------------------------------------
+# CentroidStrategy / BestFitStrategy behind the reference's own classes (round 4)
+# ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("reference_type", ["sphere", "plane"])
+@pytest.mark.parametrize("strategy", ["centroid", "best_fit"])
+@pytest.mark.parametrize("build", [_cooke, _singlet_asphere])
+def test_fitted_strategies_through_the_fit_seam(seams, build, strategy, reference_type, request):
+    """`CentroidStrategy.compute_wavefront_data` (strategy.py:307-364, inherited by
+    `BestFitStrategy`) as generating launch + `ol_wavefront_fit` + `ol_wavefront_opd_fitted`,
+    against the reference's own method run on the same strategy object (torch backend, through
+    the drop-in's `Optic.trace`: the same rays): reference centre / radius, OPD map, pupil
+    points, intensity, the `center` attribute BestFitStrategy keeps."""
+    be, stats = seams
+    if "oracle" in request.node.name:
+        pytest.skip("the fit seam needs the generating launch of the product's engine")
+    from optiland.wavefront import Wavefront
+    from optiland_amd import analysis_seams
+
+    lens = build()
+    field, wl = (0.0, 0.7), lens.primary_wavelength
+    w = Wavefront(lens, fields=[field], wavelengths="primary", num_rays=8,
+                  distribution="hexapolar", strategy=strategy,
+                  afocal=(reference_type == "plane"))
+    assert stats["opd_fit"] == 1 and stats["opd_fit_fallback"] == 0
+    got = w.get_data(field, wl)
+    assert isinstance(got.radius, float)
+    centre = getattr(w.strategy, "center", None)
+    want = analysis_seams._ORIG["opd_fit"](w.strategy, field, wl)
+    for k in ("opd", "intensity", "pupil_x", "pupil_y", "pupil_z"):
+        a, b = _np(be, getattr(got, k)), _np(be, getattr(want, k))
+        assert np.array_equal(np.isnan(a), np.isnan(b)), k
+        # OPD in waves: 1e-8 (the two backends of the reference differ by 1.5e-10 on the golden
+        # bundles, tools/make_golden_fitted.py); positions in mm
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-8 if k == "opd" else 1e-9,
+                                   equal_nan=True)
+    if reference_type == "sphere":
+        np.testing.assert_allclose(got.radius, want.radius, rtol=1e-12)
+        if strategy == "best_fit":
+            np.testing.assert_allclose(centre, w.strategy.center, rtol=0, atol=1e-9)
+    else:
+        assert got.radius == want.radius == float("inf")
+    # what Optic.trace would have left on the surfaces is there when somebody reads it
+    assert lens.surfaces.x.shape[-1] == got.opd.shape[0]
+
+
+def test_fit_seam_declines_a_subclass_with_its_own_geometry(seams, request):
+    be, stats = seams
+    if "oracle" in request.node.name:
+        pytest.skip("the fit seam needs the generating launch of the product's engine")
+    from optiland.distribution import create_distribution
+    from optiland.wavefront.strategy import CentroidStrategy
+
+    class Mine(CentroidStrategy):
+        def _calculate_weights(self, rays, image_points, valid_mask):
+            return be.ones_like(rays.i[valid_mask])
+
+    dist = create_distribution("hexapolar")
+    dist.generate_points(4)
+    lens = _cooke()
+    d = Mine(lens, dist).compute_wavefront_data((0.0, 0.0), lens.primary_wavelength)
+    assert stats["opd_fit"] == 0 and stats["opd_fit_fallback"] == 1
+    assert np.isfinite(_np(be, d.opd)).all()
+
+
+def test_fit_seam_raises_the_reference_errors(seams, request):
+    """A bundle that is vignetted entirely: strategy.py:387 `No valid ray samples found`."""
+    be, stats = seams
+    if "oracle" in request.node.name:
+        pytest.skip("the fit seam needs the generating launch of the product's engine")
+    from optiland import physical_apertures
+    from optiland.distribution import create_distribution
+    from optiland.wavefront.strategy import BestFitStrategy, CentroidStrategy
+
+    lens = _cooke()
+    lens.surfaces.surfaces[2].aperture = physical_apertures.RadialAperture(r_max=1e-9,
+                                                                                r_min=0.0)
+    dist = create_distribution("hexapolar")
+    dist.generate_points(3)
+    dist.x, dist.y = dist.x[1:], dist.y[1:]   # without the chief ray: every ray is clipped
+    for cls in (CentroidStrategy, BestFitStrategy):
+        with pytest.raises(ValueError, match="No valid ray samples"):
+            cls(lens, dist).compute_wavefront_data((0.0, 0.0), lens.primary_wavelength)
+    assert stats["opd_fit"] == 0 and stats["opd_fit_fallback"] == 0
