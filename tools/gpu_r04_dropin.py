@@ -192,7 +192,9 @@ def main():
     for nm, fn in (("OPD(256 rings, chief_ray).rms()",
                     lambda: OPD(lens, (0.0, 1.0), w, num_rays=256).rms()),
                    ("OPD(256 rings, centroid).rms()",
-                    lambda: OPD(lens, (0.0, 1.0), w, num_rays=256, strategy="centroid").rms())):
+                    lambda: OPD(lens, (0.0, 1.0), w, num_rays=256, strategy="centroid").rms()),
+                   ("OPD(256 rings, best_fit).rms()",
+                    lambda: OPD(lens, (0.0, 1.0), w, num_rays=256, strategy="best_fit").rms())):
         pr = cProfile.Profile()
         pr.enable()
         for _ in range(5):
