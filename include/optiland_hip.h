@@ -608,7 +608,7 @@ int ol_trace_opd_dev(const ol_system* sys, ol_dtype dt, int64_t n_rays,
  * fits solve their normal equations in centred, per-axis scaled coordinates.
  * ol_wavefront_opd_fitted is ol_wavefront_opd against such a reference, with the tilt added
  * before the image-to-reference path is subtracted, as those two strategies do (:318-325). */
-#define OL_WAVEFRONT_FIT_WORKSPACE_DOUBLES 8256
+#define OL_WAVEFRONT_FIT_WORKSPACE_DOUBLES 32832
 #define OL_FIT_CENTROID 0
 #define OL_FIT_BEST_FIT 1
 #define OL_FIT_NO_VALID 1u
@@ -646,6 +646,8 @@ int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void
  *                            (8-byte loads / stores; measured slower, kept for A/B)
  *   OL_TUNE_COMPACT          1 = wavefront straggler compaction in the Newton loop
  *                            (needs the vector layout; default 0, measured slower)
+ *   OL_TUNE_FIT_GRID         most blocks an ol_wavefront_fit pass is launched with (0 = the
+ *                            default, 768; at most 2048 -- the rows of its workspace)
  * The environment variable OL_TRACE_RPT seeds OL_TUNE_RAYS_PER_THREAD.
  *
  * Environment variables read by the library (A/B runs and parity tests; results are the
@@ -659,6 +661,7 @@ int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void
  *                                instantiation carrying only that family's code)        */
 #define OL_TUNE_RAYS_PER_THREAD 0
 #define OL_TUNE_COMPACT 1
+#define OL_TUNE_FIT_GRID 2
 int ol_set_tuning(int32_t knob, int32_t value);
 
 const char* ol_last_error(void);

@@ -128,11 +128,11 @@ EXPORTS = (
 )
 
 F32, F64 = 0, 1
-TUNE_RAYS_PER_THREAD, TUNE_COMPACT = 0, 1
+TUNE_RAYS_PER_THREAD, TUNE_COMPACT, TUNE_FIT_GRID = 0, 1, 2
 ABI_VERSION = 9
 OPD_MOMENTS = 12  # kOpdMoments / ol_trace_opd
 WAVEFRONT_REFERENCE_DOUBLES = 14  # OL_WAVEFRONT_REFERENCE_DOUBLES
-WAVEFRONT_FIT_WORKSPACE_DOUBLES = 8256  # OL_WAVEFRONT_FIT_WORKSPACE_DOUBLES
+WAVEFRONT_FIT_WORKSPACE_DOUBLES = 32832  # OL_WAVEFRONT_FIT_WORKSPACE_DOUBLES
 FIT_CENTROID, FIT_BEST_FIT = 0, 1
 FIT_NO_VALID, FIT_TOO_FEW, FIT_NO_ALIVE, FIT_SINGULAR = 1, 2, 4, 8
 FIT_STD_DDOF1, FIT_PISTON_SKIPS_NAN = 1, 2  # the torch backend's flavour: both

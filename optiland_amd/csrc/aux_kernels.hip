@@ -577,11 +577,22 @@ __global__ __launch_bounds__(kBlock) void fit_pass_kernel(FitArgs a) {
   if (!last) return;
   __threadfence();
   {  // rows of all blocks, in block order: 16 interleaved chains per sum, then those in order
+    // (agent-scope loads: past this XCD's L2; eight in flight per thread, added in row order)
     const int k = threadIdx.x % kFitSums, g = threadIdx.x / kFitSums;
+    constexpr unsigned kStep = kBlock / kFitSums, kFly = 8;
     double v = 0;
-    for (unsigned b = g; b < gridDim.x; b += kBlock / kFitSums)
-      v += __hip_atomic_load(&rows[(int64_t)b * kFitSums + k], __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned b = g; b < gridDim.x; b += kStep * kFly) {
+      double t[kFly];
+#pragma unroll
+      for (unsigned u = 0; u < kFly; ++u) {
+        const unsigned row = b + u * kStep;
+        t[u] = row < gridDim.x ? __hip_atomic_load(&rows[(int64_t)row * kFitSums + k],
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : 0.0;
+      }
+#pragma unroll
+      for (unsigned u = 0; u < kFly; ++u) v += t[u];
+    }
     fin[g][k] = v;
   }
   __syncthreads();
@@ -594,7 +605,9 @@ __global__ __launch_bounds__(kBlock) void fit_pass_kernel(FitArgs a) {
     }
     uint32_t bits = 0;
     fit_finish<PASS>(a.p, *st, tot, a.out, &bits);
-    if (bits) atomicOr(a.status, bits);
+    // one thread per pass, the passes in stream order: the first one WRITES the word
+    if constexpr (PASS == kPassC1 || PASS == kPassB1) *a.status = bits;
+    else if (bits) atomicOr(a.status, bits);
   }
 }
 
@@ -602,8 +615,10 @@ hipError_t launch_wavefront_fit(const FitArgs& a, hipStream_t stream) {
   static_assert(kBlock % kFitSums == 0 && kBlock / 64 <= kBlock / kFitSums, "fit reduction shape");
   hipError_t e = hipMemsetAsync(a.workspace, 0, kFitStateDoubles * sizeof(double), stream);
   if (e != hipSuccess) return e;
-  int64_t b = (a.n + kBlock - 1) / kBlock;
-  const dim3 grid((unsigned)(b < 1 ? 1 : (b > kFitMaxBlocks ? kFitMaxBlocks : b)));
+  // four rays per lane before another block is worth its row in the finishing sum
+  int64_t b = (a.n + 4 * kBlock - 1) / (4 * kBlock);
+  const int cap = tuning().fit_grid > 0 ? tuning().fit_grid : kFitDefaultBlocks;
+  const dim3 grid((unsigned)(b < 1 ? 1 : (b > cap ? cap : b)));
 #define OL_FIT_PASS(P) \
   hipLaunchKernelGGL((fit_pass_kernel<P>), grid, dim3(kBlock), 0, stream, a)
   if (a.p.kind == kFitBestFit) {

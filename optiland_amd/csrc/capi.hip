@@ -648,6 +648,11 @@ int ol_set_tuning(int32_t knob, int32_t value) {
     case OL_TUNE_COMPACT:
       ol::tuning().compact = value ? 1 : 0;
       return OL_OK;
+    case OL_TUNE_FIT_GRID:
+      if (value < 0 || value > ol::kFitMaxBlocks)
+        return fail(OL_EINVAL, "ol_set_tuning: fit grid 0 (default) ... %d", ol::kFitMaxBlocks);
+      ol::tuning().fit_grid = value;
+      return OL_OK;
     default:
       return fail(OL_EINVAL, "ol_set_tuning: unknown knob %d", knob);
   }
@@ -1372,8 +1377,7 @@ int ol_wavefront_fit(int32_t kind, const ol_wavefront_params* w, double trim_std
   a.out = static_cast<ol::WavefrontConsts<double>*>(reference_dev);
   a.status = fit_status;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(fit_status, 0, sizeof(uint32_t), st);
-  if (e == hipSuccess) e = ol::launch_wavefront_fit(a, st);
+  hipError_t e = ol::launch_wavefront_fit(a, st);  // (its first pass writes fit_status)
   if (e != hipSuccess) return fail(OL_EHIP, "ol_wavefront_fit: %s", hipGetErrorString(e));
   return OL_OK;
 }

@@ -28,6 +28,7 @@ constexpr int kGenApod = 4;         // + pupil apodization as the initial intens
 struct Tuning {
   int rays_per_thread = 0;  // 0 = default, 1 = one ray per lane, 2 = force vector
   int compact = 0;          // measured slower; opt-in (OL_TUNE_COMPACT)
+  int fit_grid = 0;         // blocks of an ol_wavefront_fit pass: 0 = default cap
 };
 Tuning& tuning();
 
@@ -281,7 +282,8 @@ hipError_t launch_chief_reference(const ChiefArgs<T>& a, int nr_family, hipStrea
 // CentroidStrategy / BestFitStrategy (wavefront/strategy.py:287-620) from the traced bundle,
 // as a chain of reduction passes that leaves a WavefrontConsts<double> in device memory
 constexpr int kFitSums = 16;        // running sums per pass (at most)
-constexpr int kFitMaxBlocks = 512;  // grid of a pass; one row of partial sums per block
+constexpr int kFitMaxBlocks = 2048;  // most blocks of a pass; one row of partial sums per block
+constexpr int kFitDefaultBlocks = 768;  // 3 per CU: measured best, profiles/r04_fit_timing.txt
 constexpr int kFitStateDoubles = 64;
 constexpr int kFitWorkspaceDoubles = kFitStateDoubles + kFitMaxBlocks * kFitSums;
 

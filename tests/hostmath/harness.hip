@@ -613,7 +613,8 @@ void fit_pass(const FitArgs& a) {
   }
   uint32_t bits = 0;
   fit_finish<PASS>(a.p, *st, s, a.out, &bits);
-  *a.status |= bits;
+  if (PASS == kPassC1 || PASS == kPassB1) *a.status = bits;
+  else *a.status |= bits;
 }
 
 hipError_t launch_wavefront_fit(const FitArgs& a, hipStream_t) {

@@ -185,6 +185,24 @@ def test_fit_kernels_against_the_oracle_on_random_bundles(engines, kind, planar,
         _same(pupil, want["pupil"], 1e-9, "pupil")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS)
+def test_fit_kernels_beyond_the_grid_cap(engines, kind):
+    """3e6 rays: more than 2048 blocks x 4 rays per lane -- the grid-stride loop, every row of
+    the workspace in the finishing sum."""
+    eng = engines("cuda")
+    rng = np.random.default_rng(17)
+    rays, px, py = _random_bundle(rng, 3_000_001)
+    rays[1, :50] += 0.5
+    want = oracle.wavefront_fit(kind, PARAMS, rays, px, py, flavour="torch")
+    ref, bits, opd, pupil = _fit(eng, kind, PARAMS, rays, px, py, flavour="torch")
+    assert bits == 0
+    _same(ref[0:3], want["center"], 1e-9 if kind == "centroid" else 1e-9 * want["radius"], "c")
+    np.testing.assert_allclose(ref[3], want["radius"], rtol=1e-9)
+    _same(opd, want["opd"], 5e-8, "opd")
+    _same(pupil, want["pupil"], 1e-9, "pupil")
+
+
 @pytest.mark.parametrize("where", WHERE)
 def test_fit_status_bits_are_the_reference_errors(engines, where):
     eng = engines(where)

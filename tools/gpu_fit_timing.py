@@ -51,6 +51,16 @@ def timed(fn, reps=50, warm=10):
 
 
 print("# ol_wavefront_fit + ol_wavefront_opd_fitted on", torch.cuda.get_device_name(0))
+from optiland_amd import _capi  # noqa: E402
+
+print("# grid cap of a pass (ol_set_tuning(OL_TUNE_FIT_GRID)), 1e7 rays, centroid with trimming")
+r8, px, py = bundle(10_000_000)
+for cap in (128, 256, 384, 512, 768, 1024, 1536, 2048):
+    assert eng.lib.ol_set_tuning(_capi.TUNE_FIT_GRID, cap) == 0
+    us = timed(lambda: eng.wavefront_fit("centroid", PARAMS, r8, px, py), reps=20, warm=5)
+    print(f"  cap {cap:5d}: {us:8.1f} us  {6 * 10_000_000 * 80 / 1e9 / (us * 1e-6):6.0f} GB/s")
+assert eng.lib.ol_set_tuning(_capi.TUNE_FIT_GRID, 0) == 0
+del r8, px, py
 for n in (197_377, 10_000_000):
     r8, px, py = bundle(n)
     for kind, trim, passes in (("centroid", 3.0, 6), ("centroid", 0.0, 3), ("best_fit", 0.0, 3)):
