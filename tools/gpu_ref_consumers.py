@@ -17,7 +17,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
 FILES = ["tests/test_optic.py", "tests/test_analysis.py", "tests/test_wavefront.py",
-         "tests/test_fft_psf.py"]
+         "tests/test_fft_psf.py", "tests/test_wavefront_strategy.py"]
 
 
 def run(dropin: bool, files=None):
