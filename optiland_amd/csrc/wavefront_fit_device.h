@@ -63,8 +63,8 @@ OL_DEV double fit_norm3(double a, double b, double c) { return ::sqrt(a * a + b 
 
 // The terms ONE ray adds to the running sums of a pass.  `s` has kFitSums entries.
 template <int PASS>
-OL_DEV void fit_accumulate(const FitParams& p, const FitState& st, const WavefrontConsts<double>& ref,
-                           const FitRay& r, double* s) {
+OL_DEV void fit_accumulate(const FitParams& p, const FitState& st,
+                           const WavefrontConsts<double>& ref, const FitRay& r, double* s) {
   if constexpr (PASS == kPassMean) {
     // strategy.py:325-340: opd = rays.opd - opd_img over the rays with intensity > 0
     if (r.i > 0.0) {
@@ -185,7 +185,8 @@ OL_DEV void fit_smallest_eigenvector(double (&C)[3][3], double (&v)[3]) {
       for (int b = a + 1; b < 3; ++b) {
         if (C[a][b] == 0.0) continue;
         const double theta = (C[b][b] - C[a][a]) / (2.0 * C[a][b]);
-        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (::fabs(theta) + ::sqrt(theta * theta + 1.0));
+        const double t =
+            (theta >= 0.0 ? 1.0 : -1.0) / (::fabs(theta) + ::sqrt(theta * theta + 1.0));
         const double c = 1.0 / ::sqrt(t * t + 1.0), s = t * c;
         for (int k = 0; k < 3; ++k) {  // columns a, b of C and V
           const double ca = C[k][a], cb = C[k][b];

@@ -777,13 +777,18 @@ class HipSystem:
             if t.dtype != torch.float64 or t.numel() != n or not t.is_contiguous():
                 raise ValueError("wavefront_fit: contiguous float64 planes of one length")
         nref = _capi.WAVEFRONT_REFERENCE_DOUBLES
+        code = {"centroid": _capi.FIT_CENTROID, "best_fit": _capi.FIT_BEST_FIT}[kind]
+        if n == 0:  # an empty bundle has no planes to point at: strategy.py:387 directly
+            ref = torch.full((nref + 1,), float("nan"), dtype=torch.float64, device=self.device)
+            ref[nref:].view(torch.int32)[:] = 0
+            ref[nref:].view(torch.int32)[0] = _capi.FIT_NO_VALID
+            return ref
         ref = torch.empty(nref + 1, dtype=torch.float64, device=self.device)
         work = torch.empty(_capi.WAVEFRONT_FIT_WORKSPACE_DOUBLES, dtype=torch.float64,
                            device=self.device)
         w = _capi.WavefrontParams(**{k: float(params.get(k, 0.0)) for k, _ in
                                      _capi.WavefrontParams._fields_})
         rp = (C.c_void_p * 8)(*[t.data_ptr() for t in rays8])
-        code = {"centroid": _capi.FIT_CENTROID, "best_fit": _capi.FIT_BEST_FIT}[kind]
         flags = {"torch": _capi.FIT_STD_DDOF1 | _capi.FIT_PISTON_SKIPS_NAN, "numpy": 0}[flavour]
         with self._device_ctx():
             rc = self.lib.ol_wavefront_fit(code, C.byref(w), float(trim_std or 0.0),
@@ -820,6 +825,8 @@ class HipSystem:
         opd = torch.empty(n, dtype=torch.float64, device=self.device)
         pupil = torch.empty((3, n), dtype=torch.float64, device=self.device) if want_pupil \
             else None
+        if n == 0:
+            return opd, pupil
         rp = (C.c_void_p * 7)(*[t.data_ptr() for t in rays7])
         pp = (C.c_void_p * 3)(*[pupil[k].data_ptr() for k in range(3)]) if want_pupil else None
         with self._device_ctx():

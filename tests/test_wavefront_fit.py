@@ -279,6 +279,17 @@ def test_fit_is_reproducible_and_leaves_the_bundle_alone(engines, where):
         assert torch.equal(t, k)
 
 
+@pytest.mark.parametrize("where", WHERE)
+def test_empty_bundle(engines, where):
+    eng = engines(where)
+    e = [torch.empty(0, dtype=torch.float64, device=eng.device) for _ in range(10)]
+    ref = eng.wavefront_fit("centroid", PARAMS, e[:8], e[8], e[9])
+    _r, bits = eng.fit_result(ref)
+    assert bits == _capi.FIT_NO_VALID
+    opd, pupil = eng.wavefront_opd_fitted(ref, e[:7], e[8], e[9])
+    assert opd.numel() == 0 and pupil.shape == (3, 0)
+
+
 def test_argument_checks():
     from tests import _hostmath as hm
     if not hm.available():
