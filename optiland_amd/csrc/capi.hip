@@ -519,7 +519,13 @@ int do_trace_generate(const ol_system* sys, const DeviceTable<T>& tab, int64_t n
     a.pf = ol::PolFields<T>(st);
     a.i_updated = static_cast<T*>(extras->updated_intensity);
   }
-  hipError_t e = ol::launch_trace_generate<T>(a, newton_family(sys, 0, sys->n_surf - 1), stream);
+  // packed pairs (fp32 lean form): 8-byte accesses to px / py, the record rows, the final state
+  bool pair_ok = al && (reinterpret_cast<uintptr_t>(record) % 8 == 0) && record_stride % 2 == 0;
+  if (rays_out)
+    for (int k = 0; k < 8; ++k)
+      pair_ok = pair_ok && reinterpret_cast<uintptr_t>(rays_out[k]) % 8 == 0;
+  hipError_t e = ol::launch_trace_generate<T>(a, newton_family(sys, 0, sys->n_surf - 1), pair_ok,
+                                              stream);
   if (e != hipSuccess) return fail(OL_EHIP, "trace launch failed: %s", hipGetErrorString(e));
   return OL_OK;
 }

@@ -493,7 +493,11 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
   Prt<T, POLK> P[POLK ? RPT : 1];
   uint32_t status = 0;
   if constexpr (GEN != 0) {
-    static_assert(RPT == 1, "the generating prologue is one ray per lane");
+    // one ray per lane -- or, for the lean fp32 launch-uniform form, the packed PAIR of the
+    // record-mode kernel (two rays generated one after the other, then traced as one f32x2)
+    static_assert(RPT == 1 || (RPT == 2 && GEN == kGenUniform && POLK == 0 && NR == 0 && !SPOT &&
+                               sizeof(T) == 4),
+                  "the generating prologue: one ray per lane, or the lean fp32 pair");
     static_assert(GEN == kGenUniform || POLK == 0,
                   "per-ray field planes / apodized pupils: unpolarised launches");
     const auto A0 = arg_view<(fetch_level<T, NR, false, POLK>() >= 1), T>(a);
@@ -512,15 +516,40 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
         status |= kStatusFieldRange;
       raygen_field<T>(c, hx, hy, tx, ty);
     }
-    T px = base.at(in_.px)[0], py = base.at(in_.py)[0];
-    raygen_pupil<T>(in_.flags, vx, vy, px, py, status);
-    raygen_one<T>(c, tx, ty, px, py, vx, vy, o);
-    Ray<T> q;
-    q.x = o[0]; q.y = o[1]; q.z = o[2];
-    q.L = o[3]; q.M = o[4]; q.N = o[5];
-    if constexpr ((GEN & kGenApod) != 0) q.i = raygen_apodize<T>(c, px, py); else q.i = T(1);
-    q.opd = T(0);
-    LP::put(r, 0, q);
+    T pxs[RPT], pys[RPT];
+    if constexpr (RPT == 1) {
+      pxs[0] = base.at(in_.px)[0];
+      pys[0] = base.at(in_.py)[0];
+    } else if (cnt == RPT) {
+      using PV = typename VecOf<T, RPT>::type;
+      const PV vx_ = *reinterpret_cast<const PV*>(base.at(in_.px));
+      const PV vy_ = *reinterpret_cast<const PV*>(base.at(in_.py));
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        pxs[k] = vec_get<T, RPT>(vx_, k);
+        pys[k] = vec_get<T, RPT>(vy_, k);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        pxs[k] = k < cnt ? base.at(in_.px)[k] : T(0);
+        pys[k] = k < cnt ? base.at(in_.py)[k] : T(0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      T px = pxs[k], py = pys[k];
+      uint32_t st_k = 0;
+      raygen_pupil<T>(in_.flags, vx, vy, px, py, st_k);
+      if (k < cnt) status |= st_k;  // (a padding ray of the ragged tail reports nothing)
+      raygen_one<T>(c, tx, ty, px, py, vx, vy, o);
+      Ray<T> q;
+      q.x = o[0]; q.y = o[1]; q.z = o[2];
+      q.L = o[3]; q.M = o[4]; q.N = o[5];
+      if constexpr ((GEN & kGenApod) != 0) q.i = raygen_apodize<T>(c, px, py); else q.i = T(1);
+      q.opd = T(0);
+      LP::put(r, k, q);
+    }
     if constexpr (POLK != 0) {
 #pragma unroll
       for (int e = 0; e < NPRT; ++e) P[0].m[e] = (e == 0 || e == 4 || e == 8) ? T(1) : T(0);
@@ -863,9 +892,36 @@ static hipError_t launch_pair(const TraceArgs<T>& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// ol_trace_generate on the lean fp32 form (conic-only range, unpolarised, launch-uniform field,
+// no apodization, no spot epilogue): one packed PAIR of rays per lane, as launch_pair.
+// 100 vector instructions per pair and surface against 2 x 76: in steady state the two forms
+// tie on a placed block (HBM-bound either way); in the first ~25 launches after an idle part
+// -- where the power management throttles a vector-ALU-heavy kernel, profiles/
+// r04_clock_transient.txt -- the pair form is 5-7 % faster (profiles/r04_pair_window.txt).
+#ifndef OL_GEN_PAIR
+#define OL_GEN_PAIR 1
+#endif
+template <typename T>
+static hipError_t launch_gen_pair(const TraceArgs<T>& a, hipStream_t stream) {
+  const int64_t threads = (a.n + 1) / 2;
+  const int64_t blocks = (threads + kTraceBlock - 1) / kTraceBlock;
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((trace_kernel<T, 2, true, 0, 0, false, kGenUniform, false>),
+                     dim3((unsigned)blocks), dim3(kTraceBlock), 0, stream, a.surf, a.cold,
+                     a.optics, a.coeffs, a);
+  return hipGetLastError();
+}
+
 // ol_trace_generate: one ray per lane, recording
 template <typename T, int NR>
-static hipError_t launch_gen_nr(const TraceArgs<T>& a, hipStream_t stream) {
+static hipError_t launch_gen_nr(const TraceArgs<T>& a, bool pair_ok, hipStream_t stream) {
+  if constexpr (sizeof(T) == 4 && NR == 0) {
+    const int want = tuning().rays_per_thread;
+    if (pair_ok && a.prt == nullptr && a.spot == nullptr && a.in.hx == nullptr &&
+        a.rgc.apod_kind == 0 && (want == 3 || (want == 0 && OL_GEN_PAIR)))
+      return launch_gen_pair<T>(a, stream);
+  }
   const int64_t blocks = (a.n + kTraceBlock - 1) / kTraceBlock;
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -896,13 +952,16 @@ static hipError_t launch_gen_nr(const TraceArgs<T>& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// pair_ok: px / py, the record block and the optional final-state planes allow 8-byte lane
+// accesses (capi.hip checks addresses and the record stride)
 template <typename T>
-hipError_t launch_trace_generate(const TraceArgs<T>& a_in, int nr_family, hipStream_t stream) {
+hipError_t launch_trace_generate(const TraceArgs<T>& a_in, int nr_family, bool pair_ok,
+                                 hipStream_t stream) {
   TraceArgs<T> a = a_in;
-  if (nr_family == kNrNone) return launch_gen_nr<T, 0>(a, stream);
-  if (nr_family == kNrZernike) return launch_gen_nr<T, kNrZernike>(a, stream);
-  if (nr_family == kNrEvenAsphere) return launch_gen_nr<T, kNrEvenAsphere>(a, stream);
-  return launch_gen_nr<T, 1>(a, stream);
+  if (nr_family == kNrNone) return launch_gen_nr<T, 0>(a, pair_ok, stream);
+  if (nr_family == kNrZernike) return launch_gen_nr<T, kNrZernike>(a, false, stream);
+  if (nr_family == kNrEvenAsphere) return launch_gen_nr<T, kNrEvenAsphere>(a, false, stream);
+  return launch_gen_nr<T, 1>(a, false, stream);
 }
 
 #if OL_TRACE_TU == 0 || OL_TRACE_TU == 1
@@ -956,11 +1015,13 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, int nr_family,
 #endif
 #if OL_TRACE_TU == 0 || OL_TRACE_TU == 1
 template hipError_t launch_trace<float>(const TraceArgs<float>&, bool, int, hipStream_t);
-template hipError_t launch_trace_generate<float>(const TraceArgs<float>&, int, hipStream_t);
+template hipError_t launch_trace_generate<float>(const TraceArgs<float>&, int, bool,
+                                                 hipStream_t);
 #endif
 #if OL_TRACE_TU == 0 || OL_TRACE_TU == 2
 template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, int, hipStream_t);
-template hipError_t launch_trace_generate<double>(const TraceArgs<double>&, int, hipStream_t);
+template hipError_t launch_trace_generate<double>(const TraceArgs<double>&, int, bool,
+                                                  hipStream_t);
 #endif
 
 // --------------------------------------------------------------------------

@@ -164,9 +164,12 @@ struct TraceArgs {
 template <typename T>
 hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, int nr_family,
                         hipStream_t stream);
-// the generating variant: a.in / a.rgc instead of a.rays (one ray per lane, record-all form)
+// the generating variant: a.in / a.rgc instead of a.rays (one ray per lane, record-all form;
+// pair_ok: every plane the launch touches may be accessed two rays = 8 bytes at a time, which
+// lets the lean fp32 form run on packed pairs)
 template <typename T>
-hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, hipStream_t stream);
+hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, bool pair_ok,
+                                 hipStream_t stream);
 
 
 template <typename T>

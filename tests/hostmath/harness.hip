@@ -241,7 +241,7 @@ static hipError_t gen_nr(const TraceArgs<T>& a) {
   return hipSuccess;
 }
 template <typename T>
-hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, hipStream_t) {
+hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, bool, hipStream_t) {
   switch (nr_family) {
     case kNrNone: return gen_nr<T, kNrNone>(a);
     case kNrZernike: return gen_nr<T, kNrZernike>(a);
@@ -249,8 +249,9 @@ hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, hipStream
     default: return gen_nr<T, kNrGeneric>(a);
   }
 }
-template hipError_t launch_trace_generate<float>(const TraceArgs<float>&, int, hipStream_t);
-template hipError_t launch_trace_generate<double>(const TraceArgs<double>&, int, hipStream_t);
+template hipError_t launch_trace_generate<float>(const TraceArgs<float>&, int, bool, hipStream_t);
+template hipError_t launch_trace_generate<double>(const TraceArgs<double>&, int, bool,
+                                                  hipStream_t);
 
 // launch_pupil_points (aux_kernels.hip), point by point, the same fp64 expressions
 template <typename T>
