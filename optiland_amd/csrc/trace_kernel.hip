@@ -495,7 +495,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
   if constexpr (GEN != 0) {
     // one ray per lane -- or, for the lean fp32 launch-uniform form, the packed PAIR of the
     // record-mode kernel (two rays generated one after the other, then traced as one f32x2)
-    static_assert(RPT == 1 || (RPT == 2 && GEN == kGenUniform && POLK == 0 && NR == 0 && !SPOT &&
+    static_assert(RPT == 1 || (RPT == 2 && GEN == kGenUniform && POLK == 0 && NR == 0 &&
                                sizeof(T) == 4),
                   "the generating prologue: one ray per lane, or the lean fp32 pair");
     static_assert(GEN == kGenUniform || POLK == 0,
@@ -893,7 +893,8 @@ static hipError_t launch_pair(const TraceArgs<T>& a, hipStream_t stream) {
 }
 
 // ol_trace_generate on the lean fp32 form (conic-only range, unpolarised, launch-uniform field,
-// no apodization, no spot epilogue): one packed PAIR of rays per lane, as launch_pair.
+// no apodization; with or without the spot epilogue): one packed PAIR of rays per lane, as
+// launch_pair.
 // 100 vector instructions per pair and surface against 2 x 76: in steady state the two forms
 // tie on a placed block (HBM-bound either way); in the first ~25 launches after an idle part
 // -- where the power management throttles a vector-ALU-heavy kernel, profiles/
@@ -907,9 +908,13 @@ static hipError_t launch_gen_pair(const TraceArgs<T>& a, hipStream_t stream) {
   const int64_t blocks = (threads + kTraceBlock - 1) / kTraceBlock;
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((trace_kernel<T, 2, true, 0, 0, false, kGenUniform, false>),
-                     dim3((unsigned)blocks), dim3(kTraceBlock), 0, stream, a.surf, a.cold,
-                     a.optics, a.coeffs, a);
+  const dim3 grid((unsigned)blocks), block(kTraceBlock);
+  if (a.spot != nullptr)  // the per-step form of the sharded trace: moments as an epilogue
+    hipLaunchKernelGGL((trace_kernel<T, 2, true, 0, 0, true, kGenUniform, false>), grid, block,
+                       0, stream, a.surf, a.cold, a.optics, a.coeffs, a);
+  else
+    hipLaunchKernelGGL((trace_kernel<T, 2, true, 0, 0, false, kGenUniform, false>), grid, block,
+                       0, stream, a.surf, a.cold, a.optics, a.coeffs, a);
   return hipGetLastError();
 }
 
@@ -918,8 +923,8 @@ template <typename T, int NR>
 static hipError_t launch_gen_nr(const TraceArgs<T>& a, bool pair_ok, hipStream_t stream) {
   if constexpr (sizeof(T) == 4 && NR == 0) {
     const int want = tuning().rays_per_thread;
-    if (pair_ok && a.prt == nullptr && a.spot == nullptr && a.in.hx == nullptr &&
-        a.rgc.apod_kind == 0 && (want == 3 || (want == 0 && OL_GEN_PAIR)))
+    if (pair_ok && a.prt == nullptr && a.in.hx == nullptr && a.rgc.apod_kind == 0 &&
+        (want == 3 || (want == 0 && OL_GEN_PAIR)))
       return launch_gen_pair<T>(a, stream);
   }
   const int64_t blocks = (a.n + kTraceBlock - 1) / kTraceBlock;
