@@ -567,5 +567,11 @@ def test_placed_record_block_is_a_plain_record_block(dg):
     # a tiny block is never placed (nothing to gain below the cache sizes)
     small, sinfo = hip.alloc_record_placed(1000, dtype)
     assert not sinfo["placed"] and small.shape[0] == plain.shape[0]
-    del rec, plain, a, b
+    # no window is ever 90 % faster than the median: every arena is tried, then a plain block
+    none, ninfo = hip.alloc_record_placed(n, dtype, arena_bytes=2 << 30, min_gain=0.9,
+                                          max_arenas=3)
+    assert not ninfo["placed"] and ninfo["arenas_tried"] == 3 and none.shape == plain.shape
+    c = hip.trace_generate(px, py, 0, field=(0.0, 0.7), record=none)
+    assert torch.equal(c.record[:, :, :n].nan_to_num(), b.record[:, :, :n].nan_to_num())
+    del rec, plain, none, a, b, c
     torch.cuda.empty_cache()
