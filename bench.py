@@ -32,6 +32,7 @@ the same reference call (`Optic.trace_generic`, device tensors in / out) under
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -732,6 +733,13 @@ def main():
         if have_pg:
             dist.barrier()
         sync(device)
+        # The interpreter's cyclic garbage collector stays out of the region: a generation-2
+        # pass over a process with torch.distributed loaded is a 35-53 ms pause of the HOST
+        # between two launches, wherever its allocation count happens to trip
+        # (profiles/r04_host_gc_stall.txt: no HIP call at all for 39 ms between the first
+        # timed step's hipEventRecord and its hipLaunchKernel).
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         for k in range(steps):
             step(*(evs[k] if evs else ()))
@@ -746,17 +754,29 @@ def main():
             dist.barrier()
         sync(device)
         dt = time.perf_counter() - t0
+        gc.enable()
         if have_pg:
             tt = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt
 
+    if have_pg:
+        # RCCL's first collective (the barrier of `timed` when the step itself has none) is made
+        # HERE, before the placement arena exists and outside every timed region
+        dist.barrier()
+        sync(device)
     if gen:
         record, placement = make_record()
     for _ in range(args.warmup):
         step()
     evs = [(make_event(), make_event()) for _ in range(args.steps)]
+    # (HIP events are created at their first record(): done here, once, so that the timed region
+    # creates nothing)
+    for e0_, e1_ in evs:
+        e0_.record()
+        e1_.record()
+    sync(device)
     elapsed = timed(args.steps, evs)
     if exchange == "reduce" and not spot and args.steps:
         # fold the gathered slots of the last step: whole-job spot statistics

@@ -205,8 +205,8 @@ class HipSystem:
         pass, then a fine one around the best; ~0.1 s), and the block is a view of the fastest
         window.  An arena need not contain such a window (one process in five on the boxes
         measured, profiles/r04_placement_attempts.txt): up to `max_arenas` are tried, each
-        allocated while the earlier ones are still held; the others return to torch's caching
-        allocator once the choice is made.  A plain allocation when no window is at least `min_gain` faster than
+        allocated while the earlier ones are still held; the others are released once the choice
+        is made.  A plain allocation when no window is at least `min_gain` faster than
         the median one.  Returns (record, info).  The view pins its arena: not for results
         that are handed to a user (the drop-in keeps `alloc_record`)."""
         rows = self.num_surfaces if rows is None else rows
@@ -275,11 +275,6 @@ class HipSystem:
                 chosen = (times[best], len(held) - 1, pad, best)
             if chosen[0] <= float(np.median(coarse_ms)) * (1.0 - min_gain):
                 break
-        # Arenas that are not kept go back to torch's caching allocator, NOT to the driver:
-        # `torch.cuda.empty_cache()` here was followed, tens of milliseconds later, by a 35-49 ms
-        # stall of the first launch after the next runtime allocation
-        # (profiles/r04_empty_cache_stall.txt).  A caller that wants the memory back for other
-        # processes calls it at a time of its choosing.
         if chosen is None:
             del held
             return self.alloc_record(n, dtype, rows), info
@@ -291,7 +286,10 @@ class HipSystem:
                     probe_median_GBps=need / (med * 1e-3) / 1e9)
         placed = t_best <= med * (1.0 - min_gain)
         arena = held[which] if placed else None
+        discarded = len(held) - (1 if placed else 0)
         del held
+        if discarded:
+            torch.cuda.empty_cache()  # arenas that were not chosen go back to the driver
         if not placed:
             return self.alloc_record(n, dtype, rows), info
         info["placed"] = True
