@@ -218,6 +218,18 @@ def init_dist(n_gpus, plumbing=False):
     return rank, local, world
 
 
+def gen_kernel_label(table, dtype, pol):
+    """Which instantiation `ol_trace_generate` picks for this workload (trace_kernel.hip:
+    launch_gen_nr): conic-only, unpolarised, fp32, no apodization -> one packed pair of rays per
+    lane (unless OL_TRACE_RPT=1 asks for one ray per lane)."""
+    conic = bool(np.all(np.asarray(table.surfaces["geom_kind"]) <= 1))
+    apod = int((table.raygen or {}).get("apod_kind", 0) or 0) != 0
+    if dtype == "f32" and conic and not pol and not apod \
+            and os.environ.get("OL_TRACE_RPT", "0") in ("0", "3"):
+        return "trace_kernel<float, RPT = 2 (packed pair), RECORD, GEN = uniform>"
+    return "trace_kernel<..., RPT = 1, GEN = true>"
+
+
 def make_pupil(n, dtype, seed, device):
     """Seeded uniform-disc pupil sampling on device."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -937,7 +949,7 @@ def main():
                 "bound": "hbm",
                 "kernel": "opd_trace_kernel" if opd_mode else
                           ("spot_trace_kernel" if spot else
-                           ("trace_kernel<..., GEN = true>" if gen else "trace_kernel")),
+                           (gen_kernel_label(table, args.dtype, pol) if gen else "trace_kernel")),
                 # the contract's `achieved` / `frac`: bytes this launch really moves (equal
                 # to the PMC traffic within 0.1 %) over the HIP-event kernel time
                 "achieved": moved_GBps,
