@@ -745,13 +745,6 @@ def main():
         if have_pg:
             dist.barrier()
         sync(device)
-        # The interpreter's cyclic garbage collector stays out of the region: a generation-2
-        # pass over a process with torch.distributed loaded is a 35-53 ms pause of the HOST
-        # between two launches, wherever its allocation count happens to trip
-        # (profiles/r04_host_gc_stall.txt: no HIP call at all for 39 ms between the first
-        # timed step's hipEventRecord and its hipLaunchKernel).
-        gc.collect()
-        gc.disable()
         t0 = time.perf_counter()
         for k in range(steps):
             step(*(evs[k] if evs else ()))
@@ -766,13 +759,20 @@ def main():
             dist.barrier()
         sync(device)
         dt = time.perf_counter() - t0
-        gc.enable()
         if have_pg:
             tt = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt
 
+    # The interpreter's cyclic garbage collector stays out of the measurements: a generation-2
+    # pass over a process with torch.distributed loaded is a 35-53 ms pause of the HOST between
+    # two launches, wherever its allocation count happens to trip (profiles/r04_host_gc_stall.txt:
+    # no HIP call at all for 39 ms between a step's hipEventRecord and its hipLaunchKernel).
+    # Collected once HERE -- in front of the warm-up steps, so that the idle gap it leaves on the
+    # device is not the start of a timed region -- and switched off until the GPU legs are done.
+    gc.collect()
+    gc.disable()
     if have_pg:
         # RCCL's first collective (the barrier of `timed` when the step itself has none) is made
         # HERE, before the placement arena exists and outside every timed region
@@ -995,6 +995,7 @@ def main():
                          "first ~100 ms (outside the reported region)"),
             },
         }
+        gc.enable()  # (the GPU legs of this line are done)
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_baseline(table, hy, "last" if spot else ("record" if gen else args.mode),
                                 args.cpu_seconds, wl)
