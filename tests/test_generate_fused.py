@@ -451,3 +451,43 @@ def test_tracer_takes_the_generating_launch_for_field_arrays(where):
                                                   getattr(b.surfaces, k).cpu().numpy())
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("where", WHERE)
+def test_packed_pair_form_of_the_generating_launch(where):
+    """Round 4: the lean fp32 form of `ol_trace_generate` runs one packed PAIR of rays per lane
+    (`trace_kernel<float, 2, true, 0, 0, SPOT, kGenUniform>`).  Same bits as one ray per lane
+    (`OL_TUNE_RAYS_PER_THREAD = 1`) for even and odd counts, with the spot epilogue, and when
+    the planes are NOT 8-byte aligned (the C ABI then keeps one ray per lane by itself)."""
+    table = load_system("double_gauss")
+    eng, dev = _engine(table, where)
+    dtype = torch.float32
+    try:
+        for n in (2, 3, 511, 512, 513, 100_001):
+            px, py = _pupil(n + 1, dtype, dev, n)
+            got = {}
+            for rpt in (0, 1):
+                assert eng.lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, rpt) == 0
+                out = [torch.empty(n, dtype=dtype, device=dev) for _ in range(8)]
+                slots = eng.alloc_spot_slots()
+                r = eng.trace_generate(px[:n], py[:n], 0, field=(0.0, 0.7), rays_out=out,
+                                       spot=(slots, 0.0, 0.0))
+                got[rpt] = (r.record[:, :, :n].cpu().numpy(), torch.stack(out).cpu().numpy(),
+                            eng.reduce_spot_slots(slots).cpu().numpy())
+            assert eng.lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, 0) == 0
+            np.testing.assert_array_equal(got[0][0], got[1][0])
+            np.testing.assert_array_equal(got[0][1], got[1][1])
+            # count and max: exact; the sums are accumulated in another order
+            assert got[0][2][0] == got[1][2][0] and got[0][2][6] == got[1][2][6]
+            np.testing.assert_allclose(got[0][2], got[1][2], rtol=1e-12)
+            # misaligned planes (a view one element into its storage): still the same rays
+            out = [torch.empty(n + 1, dtype=dtype, device=dev)[1:] for _ in range(8)]
+            m = eng.trace_generate(px[1:], py[1:], 0, field=(0.0, 0.7), rays_out=out)
+            a = eng.trace_generate(px[1:].clone(), py[1:].clone(), 0, field=(0.0, 0.7))
+            np.testing.assert_array_equal(m.record[:, :, :n].cpu().numpy(),
+                                          a.record[:, :, :n].cpu().numpy())
+            np.testing.assert_array_equal(torch.stack(out).cpu().numpy(),
+                                          a.record[-1, :, :n].cpu().numpy())
+    finally:
+        eng.lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, 0)
+        eng.close()
