@@ -184,7 +184,14 @@ def _field_worker(rank, world, port, q):
         r, th = np.sqrt(g.random(n)), 2 * np.pi * g.random(n)
         px, py = r * np.cos(th), r * np.sin(th)
         t = tr.HipRayTracer(table, dtype=torch.float64)
-        out = ShardedTracer(t).trace_field(0.0, 0.7, px, py, 0.5876, center=(0.0, 15.0))
+        st = ShardedTracer(t)
+        block = st.alloc_field_record(n)  # the step loop's form: one block, reused
+        first = st.trace_field(0.0, 0.7, px, py, 0.5876, center=(0.0, 15.0), record=block)
+        out = st.trace_field(0.0, 0.7, px, py, 0.5876, center=(0.0, 15.0), record=block)
+        assert out["result"].record.data_ptr() == block.data_ptr() == \
+            first["result"].record.data_ptr()
+        fresh = st.trace_field(0.0, 0.7, px, py, 0.5876, center=(0.0, 15.0))
+        assert torch.equal(fresh["result"].record.nan_to_num(), block.nan_to_num())
         res = out["result"]
         q.put((rank, out["lo"], out["hi"], res.record[:, :, : res.n].numpy(), out["spot"]))
     finally:
