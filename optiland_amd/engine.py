@@ -75,6 +75,118 @@ class TraceResult:
         return self.record[:, k, : self.n]
 
 
+_POOL_CONFIG = {"slots": 0, "min_bytes": 256 << 20}
+_RECORD_POOLS: dict = {}   # (device index, n, dtype, rows) -> RecordPool
+
+
+class _Lease:
+    """One window of a placement arena while it is the storage of a record block handed to a
+    user.  `torch.as_tensor(lease)` (CUDA array interface) makes a tensor on the window and
+    keeps a reference to this object for as long as that storage -- any view of it -- lives;
+    when the last one dies the window goes back to its pool.  The lease holds the arena, so
+    the memory outlives the pool if it must."""
+
+    __slots__ = ("pool", "index", "arena", "ptr", "nbytes")
+
+    def __init__(self, pool, index, arena, ptr, nbytes):
+        self.pool, self.index, self.arena, self.ptr, self.nbytes = pool, index, arena, ptr, nbytes
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False),
+                "strides": None, "version": 2}
+
+    def __del__(self):
+        try:
+            self.pool._give_back(self.index)
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+class RecordPool:
+    """A few PLACED record blocks of one shape for traces whose record is handed to a user
+    (the drop-in's `Optic.trace`): windows of device memory in which the record-all store
+    pattern writes fastest (`HipSystem.alloc_record_placed`), lent out one trace at a time and
+    returned when the user's last view of the block dies.  A loop that keeps one result alive
+    while it makes the next needs two.  Opt-in (`HipSystem.enable_record_pool`,
+    `integration.enable(placed_records=...)`): the arenas behind the windows stay allocated --
+    ~40 GiB for two 4 GiB windows on the boxes measured."""
+
+    def __init__(self, hip, n: int, dtype, rows: int, slots: int = 2, arena_bytes=None,
+                 min_gain: float = 0.04, max_arenas: int = 3):
+        import threading
+
+        self.device, self.dtype, self.rows = hip.device, dtype, rows  # (`hip`: for the probe only)
+        b = torch.empty((), dtype=dtype).element_size()
+        self.stride = hip.record_stride(n, b)
+        self.need = need = rows * 8 * self.stride * b
+        self.windows = []          # (arena, address)
+        self.free = []
+        self.lock = threading.Lock()
+        self.info = {"block_bytes": need, "slots_wanted": slots, "probes": 0, "arenas": 0}
+        if arena_bytes is None:
+            arena_bytes = max(3 * need, 40 << 30)
+        coarse_ms, candidates, held = [], [], []
+        for _ in range(max(1, int(max_arenas))):
+            free, _total = torch.cuda.mem_get_info(hip.device)
+            size = min(arena_bytes, int(free * 0.45)) // (2 << 20) * (2 << 20)
+            if size < 2 * need:
+                break
+            try:
+                arena = torch.empty(size, dtype=torch.uint8, device=hip.device)
+            except RuntimeError:
+                break
+            held.append(arena)
+            times, offs, pad = hip._probe_windows(arena, size, need, b, rows * 8)
+            self.info["probes"] += len(times)
+            coarse_ms += [times[o] for o in offs]
+            candidates += [(t, len(held) - 1, pad + o) for o, t in times.items()]
+            med = float(np.median(coarse_ms))
+            picked = self._pick(candidates, med * (1.0 - min_gain), need, slots)
+            if len(picked) >= slots:
+                break
+        self.info["arenas"] = len(held)
+        if coarse_ms:
+            med = float(np.median(coarse_ms))
+            picked = self._pick(candidates, med * (1.0 - min_gain), need, slots)
+            self.info["probe_median_GBps"] = need / (med * 1e-3) / 1e9
+            self.info["window_GBps"] = [need / (t * 1e-3) / 1e9 for t, _a, _o in picked]
+            used = set()
+            for _t, a, off in picked:
+                self.windows.append((held[a], held[a].data_ptr() + off))
+                used.add(a)
+            held = None  # arenas without a window are released with this frame
+        self.free = list(range(len(self.windows)))
+        self.info["slots"] = len(self.windows)
+
+    @staticmethod
+    def _pick(candidates, limit_ms, need, slots):
+        """The fastest non-overlapping windows at least `min_gain` under the median."""
+        out = []
+        for t, a, off in sorted(candidates):
+            if t > limit_ms or len(out) >= slots:
+                break
+            if all(a != a2 or abs(off - o2) >= need for _t2, a2, o2 in out):
+                out.append((t, a, off))
+        return out
+
+    def _give_back(self, index):
+        with self.lock:
+            self.free.append(index)
+
+    def acquire(self):
+        """A (rows, 8, stride) record block on a free window, or None when all are lent out."""
+        with self.lock:
+            if not self.free:
+                return None
+            index = self.free.pop()
+        arena, ptr = self.windows[index]
+        lease = _Lease(self, index, arena, ptr, self.need)
+        flat = torch.as_tensor(lease, device=self.device)
+        del lease  # (the tensor's storage holds the only reference now)
+        return flat.view(self.dtype).view(self.rows, 8, self.stride)
+
+
 class HipSystem:
     """A surface table resident on one GPU (wraps `ol_system`)."""
 
@@ -183,10 +295,71 @@ class HipSystem:
             stride += max(int(skew), 0) // 256 * 256 // itemsize
         return stride
 
+    @staticmethod
+    def enable_record_pool(slots: int = 2, min_bytes: int = 256 << 20) -> None:
+        """From now on `alloc_record` (of every system of this process) lends out PLACED blocks
+        (`RecordPool`) for block shapes of at least `min_bytes` -- for traces whose record goes
+        to a user; `slots` blocks per shape may be alive at a time, further ones are ordinary
+        allocations; two shapes per device are kept.  0 = off (the pools and their arenas go)."""
+        _POOL_CONFIG["slots"], _POOL_CONFIG["min_bytes"] = int(slots), int(min_bytes)
+        if not slots:
+            _RECORD_POOLS.clear()
+
     def alloc_record(self, n: int, dtype, rows: int | None = None) -> torch.Tensor:
         rows = self.num_surfaces if rows is None else rows
-        stride = self.record_stride(n, torch.empty((), dtype=dtype).element_size())
+        b = torch.empty((), dtype=dtype).element_size()
+        stride = self.record_stride(n, b)
+        slots = _POOL_CONFIG["slots"]
+        if slots and rows * 8 * stride * b >= _POOL_CONFIG["min_bytes"] \
+                and self.device.type == "cuda" and hasattr(self.lib, "ol_stream_fill"):
+            key = (self.device.index, int(n), dtype, rows)
+            pool = _RECORD_POOLS.get(key)
+            if pool is None:
+                mine = [k for k in _RECORD_POOLS if k[0] == self.device.index]
+                if len(mine) >= 2:        # a third shape: the oldest pool (and its arenas) goes
+                    _RECORD_POOLS.pop(mine[0])
+                pool = _RECORD_POOLS[key] = RecordPool(self, n, dtype, rows, slots)
+            block = pool.acquire()
+            if block is not None:
+                return block
         return torch.empty((rows, 8, stride), dtype=dtype, device=self.device)
+
+    def _probe_windows(self, arena: torch.Tensor, size: int, need: int, b: int, planes: int):
+        """(times [ms] by byte offset, the coarse offsets, pad): `ol_stream_fill` -- the record
+        block's own store pattern without arithmetic -- timed over candidate windows of `arena`
+        (coarse pass in quarter-block steps, a fine pass around the best)."""
+        stream = self._stream()
+        # (a block the caching allocator carved out of an older segment is only 512 B
+        # aligned: windows start on 2 MiB boundaries of the ADDRESS, like plain blocks)
+        pad = (-arena.data_ptr()) % (2 << 20)
+        base = arena.data_ptr() + pad
+        size -= pad + (2 << 20)
+
+        def fill_ms(off, reps=2):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            for k in range(1 + reps):
+                if k == 1:
+                    e0.record()
+                self._check(self.lib.ol_stream_fill(C.c_void_p(base + off), need, b, planes, 0,
+                                                    stream), "ol_stream_fill")
+            e1.record()
+            torch.cuda.synchronize(self.device)
+            return e0.elapsed_time(e1) / reps
+
+        with self._device_ctx():
+            for _ in range(30):  # past the clock transient of the first launches
+                self.lib.ol_stream_fill(C.c_void_p(base), need, b, planes, 0, stream)
+            last = size - need
+            coarse = max(need // 4 // (2 << 20) * (2 << 20), 2 << 20)
+            offs = list(range(0, last + 1, coarse))
+            times = {o: fill_ms(o) for o in offs}
+            best = min(times, key=times.get)
+            fine = max(coarse // 4 // (2 << 20) * (2 << 20), 2 << 20)
+            for o in range(max(best - coarse + fine, 0), min(best + coarse, last + 1), fine):
+                if o not in times:
+                    times[o] = fill_ms(o)
+        return times, offs, pad
 
     def alloc_record_placed(self, n: int, dtype, rows: int | None = None,
                             arena_bytes: int | None = None, min_gain: float = 0.04,
@@ -220,41 +393,8 @@ class HipSystem:
         if arena_bytes is None:
             env = os.environ.get("OPTILAND_HIP_RECORD_ARENA_GIB")
             arena_bytes = int(float(env) * (1 << 30)) if env else max(3 * need, 40 << 30)
-        stream = self._stream()
-
         def probe(arena, size):
-            """(times by offset, coarse offsets, pad) of one arena."""
-            # (a block the caching allocator carved out of an older segment is only 512 B
-            # aligned: windows start on 2 MiB boundaries of the ADDRESS, like plain blocks)
-            pad = (-arena.data_ptr()) % (2 << 20)
-            base = arena.data_ptr() + pad
-            size -= pad + (2 << 20)
-
-            def fill_ms(off, reps=2):
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                for k in range(1 + reps):
-                    if k == 1:
-                        e0.record()
-                    self._check(self.lib.ol_stream_fill(C.c_void_p(base + off), need, b,
-                                                        rows * 8, 0, stream), "ol_stream_fill")
-                e1.record()
-                torch.cuda.synchronize(self.device)
-                return e0.elapsed_time(e1) / reps
-
-            with self._device_ctx():
-                for _ in range(30):  # past the clock transient of the first launches
-                    self.lib.ol_stream_fill(C.c_void_p(base), need, b, rows * 8, 0, stream)
-                last = size - need
-                coarse = max(need // 4 // (2 << 20) * (2 << 20), 2 << 20)
-                offs = list(range(0, last + 1, coarse))
-                times = {o: fill_ms(o) for o in offs}
-                best = min(times, key=times.get)
-                fine = max(coarse // 4 // (2 << 20) * (2 << 20), 2 << 20)
-                for o in range(max(best - coarse + fine, 0), min(best + coarse, last + 1), fine):
-                    if o not in times:
-                        times[o] = fill_ms(o)
-            return times, offs, pad
+            return self._probe_windows(arena, size, need, b, rows * 8)
 
         held, coarse_ms, chosen, probes = [], [], None, 0
         for _attempt in range(max(1, int(max_arenas))):

@@ -575,3 +575,54 @@ def test_placed_record_block_is_a_plain_record_block(dg):
     assert torch.equal(c.record[:, :, :n].nan_to_num(), b.record[:, :, :n].nan_to_num())
     del rec, plain, none, a, b, c
     torch.cuda.empty_cache()
+
+
+def test_record_pool_lends_placed_blocks_and_takes_them_back(dg):
+    """`engine.RecordPool` (round 4, opt-in: `integration.enable(placed_records=...)`): record
+    blocks that are handed to a user come from placed windows and return to the pool when the
+    user's LAST view of the block dies; beyond the pool's size, and for small blocks, ordinary
+    allocations.  However many windows this box offers (0 ... 2), a trace into a pool block is
+    a trace into a plain block, bit for bit."""
+    import gc
+
+    from optiland_amd import engine as E
+    hip, table = dg
+    n, dtype = 2_000_000, torch.float32
+    px, py = _pupil(n, 59, dtype)
+    plain = hip.alloc_record(n, dtype)
+    want = hip.trace_generate(px, py, 0, field=(0.0, 0.7), record=plain).record[:, :, :n].clone()
+    E.HipSystem.enable_record_pool(2)
+    try:
+        a, b, c = (hip.alloc_record(n, dtype) for _ in range(3))
+        pool = next(iter(E._RECORD_POOLS.values()))
+        k = pool.info["slots"]
+        assert 0 <= k <= 2 and pool.info["probes"] >= 4
+        windows = {p for _arena, p in pool.windows}
+        lent = [t for t in (a, b, c) if t.data_ptr() in windows]
+        assert len(lent) == k and len(pool.free) == 0
+        assert c.data_ptr() not in windows            # the third one is an ordinary allocation
+        for t in (a, b, c):
+            assert t.shape == plain.shape and t.stride() == plain.stride()
+            got = hip.trace_generate(px, py, 0, field=(0.0, 0.7), record=t)
+            assert torch.equal(got.record[:, :, :n].nan_to_num(), want.nan_to_num())
+            del got
+        small = hip.alloc_record(1000, dtype)         # below min_bytes: never from a pool
+        assert small.data_ptr() not in windows and len(E._RECORD_POOLS) == 1
+        if k:
+            t = lent[0]
+            where = t.data_ptr()
+            view = t[0, 0, :10]                       # any view keeps the window lent out
+            a = b = c = lent = t = None
+            gc.collect()
+            assert len(pool.free) == k - 1
+            del view
+            gc.collect()
+            assert len(pool.free) == k
+            again = [hip.alloc_record(n, dtype) for _ in range(k)]
+            assert where in {x.data_ptr() for x in again}
+            del again
+    finally:
+        E.HipSystem.enable_record_pool(0)
+        gc.collect()
+        torch.cuda.empty_cache()
+    assert not E._RECORD_POOLS
