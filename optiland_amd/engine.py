@@ -381,7 +381,8 @@ class HipSystem:
         allocated while the earlier ones are still held; the others are released once the choice
         is made.  A plain allocation when no window is at least `min_gain` faster than
         the median one.  Returns (record, info).  The view pins its arena: not for results
-        that are handed to a user (the drop-in keeps `alloc_record`)."""
+        that are handed to a user (those come from `alloc_record`, i.e. an ordinary
+        allocation or, when `enable_record_pool` is on, a window LENT by a `RecordPool`)."""
         rows = self.num_surfaces if rows is None else rows
         b = torch.empty((), dtype=dtype).element_size()
         stride = self.record_stride(n, b)
