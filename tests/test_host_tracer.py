@@ -285,3 +285,17 @@ def test_analysis_signatures_follow_the_reference(monkeypatch):
     oz = np.asarray(t.table.surfaces[-1]["origin"], dtype=np.float64)
     for (a, b), (c, d) in zip(loc.centroid(), glo.centroid()):
         np.testing.assert_allclose([c - a, d - b], oz[:2], atol=1e-12)
+
+
+def test_record_pool_window_choice():
+    """`RecordPool._pick`: the fastest windows under the limit that do not overlap (offsets of
+    one arena closer than a block are the same boundary seen twice); windows of other arenas
+    never overlap."""
+    from optiland_amd.engine import RecordPool
+    need = 4
+    cand = [(0.60, 0, 30), (0.61, 0, 31), (0.62, 0, 14), (0.70, 0, 0), (0.59, 1, 5),
+            (0.595, 1, 8)]
+    assert RecordPool._pick(cand, 0.65, need, 2) == [(0.59, 1, 5), (0.60, 0, 30)]
+    assert RecordPool._pick(cand, 0.65, need, 4) == [(0.59, 1, 5), (0.60, 0, 30), (0.62, 0, 14)]
+    assert RecordPool._pick(cand, 0.50, need, 2) == []
+    assert RecordPool._pick([], 1.0, need, 2) == []
