@@ -37,7 +37,11 @@ class GraphedTrace:
                                               for _ in range(4))
         self.record_all = record_all
         if record_all:
-            self.record = engine.alloc_record(self.n, dtype)
+            # one block, replayed into forever: placed where the part writes it fastest when it
+            # is big enough for that to matter (engine.alloc_record_placed; small: plain)
+            placed = getattr(engine, "alloc_record_placed", None)
+            self.record = placed(self.n, dtype)[0] if placed is not None \
+                else engine.alloc_record(self.n, dtype)
             self.rays = engine.row0_planes(self.record, self.n)
         else:
             self.record = False
