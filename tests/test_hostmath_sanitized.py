@@ -6,7 +6,8 @@ HOST side of the product library).  The host build of the kernel source
 (tests/hostmath) closes most of that gap: compiled with `-fsanitize=address,undefined`, every
 read of the surface table / coefficient blocks / aperture token lists / polygon tables and
 every read and write of the ray, record and PRT planes that `surface_math.h`,
-`raygen_device.h`, `wavefront_device.h` and `epilogue_device.h` perform is checked, on all
+`raygen_device.h`, `wavefront_device.h`, `wavefront_fit_device.h` and `epilogue_device.h`
+perform is checked, on all
 golden systems and on the randomised ones -- the whole of tests/test_hostmath.py and
 tests/test_hostmath_fuzz.py re-run in a subprocess against the sanitized harness (python
 itself is not instrumented: the ASAN runtime is LD_PRELOADed).  A report aborts the run
@@ -40,7 +41,9 @@ def test_kernel_arithmetic_under_asan_and_ubsan():
     out = subprocess.run(
         [sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
          os.path.join(ROOT, "tests", "test_hostmath.py"),
-         os.path.join(ROOT, "tests", "test_hostmath_fuzz.py")],
+         os.path.join(ROOT, "tests", "test_hostmath_fuzz.py"),
+         # round 4: the reduction passes of ol_wavefront_fit (wavefront_fit_device.h)
+         os.path.join(ROOT, "tests", "test_wavefront_fit.py"), "-m", "not gpu"],
         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     tail = (out.stdout + out.stderr)[-3000:]
     assert out.returncode == 0, tail
