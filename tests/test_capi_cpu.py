@@ -111,6 +111,30 @@ def test_argument_validation_without_a_device(lib):
     assert rc == -1 and b"system is NULL" in lib.ol_last_error()
     assert lib.ol_system_num_surfaces(None) == 0
     lib.ol_system_destroy(None)  # no-op
+    # ABI 9: ol_wavefront_fit / ol_wavefront_opd_fitted refuse before they touch a device
+    from optiland_amd._capi import WavefrontParams
+    w = WavefrontParams(n_image=1.0, wavelength_um=0.55, half_epd=5.0)
+    planes = (C.c_void_p * 8)(*([16] * 8))  # never dereferenced
+    rc = lib.ol_wavefront_fit(0, None, 3.0, 0, 0, 4, planes, 16, 16, 16, 16, 16, None)
+    assert rc == -1 and b"NULL argument" in lib.ol_last_error()
+    rc = lib.ol_wavefront_fit(7, C.byref(w), 3.0, 0, 0, 4, planes, 16, 16, 16, 16, 16, None)
+    assert rc == -1 and b"unknown kind" in lib.ol_last_error()
+    rc = lib.ol_wavefront_fit(0, C.byref(w), 3.0, 0x10, 0, 4, planes, 16, 16, 16, 16, 16, None)
+    assert rc == -1 and b"unknown flags" in lib.ol_last_error()
+    rc = lib.ol_wavefront_fit(0, C.byref(w), 3.0, 0, 0, -1, planes, 16, 16, 16, 16, 16, None)
+    assert rc == -1 and b"negative count" in lib.ol_last_error()
+    bad = WavefrontParams(n_image=0.0, wavelength_um=0.55, half_epd=5.0)
+    rc = lib.ol_wavefront_fit(1, C.byref(bad), 3.0, 0, 0, 4, planes, 16, 16, 16, 16, 16, None)
+    assert rc == -1 and b"n_image" in lib.ol_last_error()
+    hole = (C.c_void_p * 8)(*([16] * 5 + [None] + [16] * 2))
+    rc = lib.ol_wavefront_fit(1, C.byref(w), 3.0, 0, 0, 4, hole, 16, 16, 16, 16, 16, None)
+    assert rc == -1 and b"rays[5] is NULL" in lib.ol_last_error()
+    rc = lib.ol_wavefront_opd_fitted(4, planes, 16, 16, None, 16, None, None)
+    assert rc == -1 and b"NULL argument" in lib.ol_last_error()
+    three = (C.c_void_p * 3)(16, None, 16)
+    rc = lib.ol_wavefront_opd_fitted(4, planes, 16, 16, 16, 16, three, None)
+    assert rc == -1 and b"pupil needs three planes" in lib.ol_last_error()
+    assert lib.ol_set_tuning(2, 4096) == -1 and lib.ol_set_tuning(2, 0) == 0
 
 
 def test_unsupported_kinds_are_refused(lib):
