@@ -151,11 +151,9 @@ class RecordPool:
             picked = self._pick(candidates, med * (1.0 - min_gain), need, slots)
             self.info["probe_median_GBps"] = need / (med * 1e-3) / 1e9
             self.info["window_GBps"] = [need / (t * 1e-3) / 1e9 for t, _a, _o in picked]
-            used = set()
             for _t, a, off in picked:
                 self.windows.append((held[a], held[a].data_ptr() + off))
-                used.add(a)
-            held = None  # arenas without a window are released with this frame
+            held = None  # (arenas without a window are released with this frame)
         self.free = list(range(len(self.windows)))
         self.info["slots"] = len(self.windows)
 

@@ -8,7 +8,6 @@ size (256 hexapolar rings = 197 377 rays) and at 1e7 rays, against the bytes the
 import os
 import sys
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
