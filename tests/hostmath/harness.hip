@@ -70,6 +70,9 @@ const char* hipGetErrorString(hipError_t e) {
 }
 // marker symbol: lets a test assert which library it has loaded
 int ol_hostmath_harness(void) { return 1; }
+// how many generating launches took the packed-pair form (tests/test_generate_fused.py)
+static long g_pair_launches = 0;
+long ol_hostmath_pair_launches(void) { return g_pair_launches; }
 }
 
 namespace ol {
@@ -162,6 +165,56 @@ void trace_one(const TraceArgs<T>& a, int64_t i, uint32_t& status) {
   }
 }
 
+// trace_kernel<float, 2, true, 0, 0, SPOT, kGenUniform> (the packed PAIR form of the lean fp32
+// generating launch): two rays generated one after the other, traced as ONE f32x2 through the
+// same surface_step<f32x2, ...> the device instantiates; a ragged tail's second ray is a
+// padding ray from pupil point (0, 0) that is neither reported nor stored.
+inline void trace_pair_gen(const TraceArgs<float>& a, int64_t i0, uint32_t& status) {
+  using V = f32x2;
+  const int cnt = (a.n - i0) >= 2 ? 2 : 1;
+  Ray<V> r[1];
+  const RaygenIn<float>& in_ = a.in;
+  for (int k = 0; k < 2; ++k) {
+    float px = k < cnt ? in_.px[i0 + k] : 0.0f, py = k < cnt ? in_.py[i0 + k] : 0.0f, o[6];
+    uint32_t st_k = 0;
+    raygen_pupil<float>(in_.flags, in_.vx0, in_.vy0, px, py, st_k);
+    if (k < cnt) status |= st_k;
+    raygen_one<float>(a.rgc, in_.tx0, in_.ty0, px, py, in_.vx0, in_.vy0, o);
+    r[0].x[k] = o[0]; r[0].y[k] = o[1]; r[0].z[k] = o[2];
+    r[0].L[k] = o[3]; r[0].M[k] = o[4]; r[0].N[k] = o[5];
+    r[0].i[k] = 1.0f; r[0].opd[k] = 0.0f;
+  }
+  Prt<float, 0> P[1];
+  bool is_global = true, prt_fresh = false;
+  DevSurf<float> last_traced;
+  std::memset(static_cast<void*>(&last_traced), 0, sizeof(last_traced));
+  last_traced.cold = a.cold;
+  const int rec_from = a.record_from > a.first ? a.record_from : a.first;
+  auto put = [&](float* const plane[8], int64_t stride_or_zero, float* row) {
+    const Ray<V> g = is_global ? r[0] : to_global<V>(last_traced, r[0]);
+    const V f[8] = {g.x, g.y, g.z, g.L, g.M, g.N, g.i, g.opd};
+    for (int q = 0; q < 8; ++q)
+      for (int k = 0; k < cnt; ++k) {
+        if (row) row[q * stride_or_zero + i0 + k] = f[q][k];
+        else plane[q][i0 + k] = f[q][k];
+      }
+  };
+  for (int s = a.first; s <= a.last; ++s) {
+    DevSurf<float> S;
+    static_cast<DevSurfHot<float>&>(S) = a.surf[s];
+    S.cold = a.cold + s;
+    if (S.interaction != kRecordOnly) {
+      const DevOptics<float> O = a.optics[s * a.n_wl + a.wl];
+      surface_step<V, 1, 0, 0>(S, O, a.coeffs, is_global, r, P, status, prt_fresh);
+      is_global = false;
+      last_traced = S;
+    }
+    if (a.record && s >= rec_from && !(s == a.first && (a.flags & kTraceRow0IsInput)))
+      put(nullptr, a.record_stride, a.record + (int64_t)(s - rec_from) * 8 * a.record_stride);
+  }
+  if (a.flags & kTraceWriteRays) put(a.rays, 0, nullptr);
+}
+
 template <typename T, int POLK, int NR, bool GEN = false>
 void trace_all(const TraceArgs<T>& a) {
   uint32_t status = 0;
@@ -196,13 +249,27 @@ template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, int, hi
 
 // launch_trace_generate (trace_kernel.hip): the generating variant, same instance choice
 template <typename T, int NR>
-static hipError_t gen_nr(const TraceArgs<T>& a) {
+static hipError_t gen_nr(const TraceArgs<T>& a, bool pair_ok) {
   const int polk = a.prt == nullptr ? 0 : ((a.flags & kTracePrtComplex) ? 2 : 1);
   if (polk != 0 && (a.in.hx != nullptr || a.rgc.apod_kind != 0 || a.spot != nullptr))
     return hipErrorInvalidValue;  // as launch_gen_nr
   if (a.spot != nullptr && (a.in.hx != nullptr || a.rgc.apod_kind != 0))
     return hipErrorInvalidValue;
-  if (polk == 2) trace_all<T, 2, NR, true>(a);
+  bool paired = false;
+  if constexpr (sizeof(T) == 4 && NR == 0) {
+    // the device's choice (trace_kernel.hip: launch_gen_nr): the lean fp32 form on packed pairs
+    const int want = tuning().rays_per_thread;
+    if (pair_ok && polk == 0 && a.in.hx == nullptr && a.rgc.apod_kind == 0 &&
+        (want == 3 || want == 0)) {
+      uint32_t status = 0;
+      ++g_pair_launches;
+      for (int64_t i = 0; i < a.n; i += 2) trace_pair_gen(a, i, status);
+      if (status && a.status) *a.status |= status;
+      paired = true;
+    }
+  }
+  if (paired) {
+  } else if (polk == 2) trace_all<T, 2, NR, true>(a);
   else if (polk == 1) trace_all<T, 1, NR, true>(a);
   else trace_all<T, 0, NR, true>(a);
   if (a.spot != nullptr) {
@@ -241,12 +308,13 @@ static hipError_t gen_nr(const TraceArgs<T>& a) {
   return hipSuccess;
 }
 template <typename T>
-hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, bool, hipStream_t) {
+hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, bool pair_ok,
+                                 hipStream_t) {
   switch (nr_family) {
-    case kNrNone: return gen_nr<T, kNrNone>(a);
-    case kNrZernike: return gen_nr<T, kNrZernike>(a);
-    case kNrEvenAsphere: return gen_nr<T, kNrEvenAsphere>(a);
-    default: return gen_nr<T, kNrGeneric>(a);
+    case kNrNone: return gen_nr<T, kNrNone>(a, pair_ok);
+    case kNrZernike: return gen_nr<T, kNrZernike>(a, false);
+    case kNrEvenAsphere: return gen_nr<T, kNrEvenAsphere>(a, false);
+    default: return gen_nr<T, kNrGeneric>(a, false);
   }
 }
 template hipError_t launch_trace_generate<float>(const TraceArgs<float>&, int, bool, hipStream_t);

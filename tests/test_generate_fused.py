@@ -468,12 +468,16 @@ def test_packed_pair_form_of_the_generating_launch(where):
             got = {}
             for rpt in (0, 1):
                 assert eng.lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, rpt) == 0
+                pairs = getattr(eng.lib, "ol_hostmath_pair_launches", None)  # host build only
+                before = pairs() if pairs is not None else None
                 out = [torch.empty(n, dtype=dtype, device=dev) for _ in range(8)]
                 slots = eng.alloc_spot_slots()
                 r = eng.trace_generate(px[:n], py[:n], 0, field=(0.0, 0.7), rays_out=out,
                                        spot=(slots, 0.0, 0.0))
                 got[rpt] = (r.record[:, :, :n].cpu().numpy(), torch.stack(out).cpu().numpy(),
                             eng.reduce_spot_slots(slots).cpu().numpy())
+                if pairs is not None:  # the host mirror took the form the device would take
+                    assert pairs() - before == (1 if rpt == 0 else 0)
             assert eng.lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, 0) == 0
             np.testing.assert_array_equal(got[0][0], got[1][0])
             np.testing.assert_array_equal(got[0][1], got[1][1])
