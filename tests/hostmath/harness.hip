@@ -20,6 +20,10 @@
 // / ol_generate_rays return "not supported" here.  It exists under tests/ and is built by
 // tests/hostmath/build.py only.
 //
+// Round 4: the packed-pair form of the lean fp32 generating launch (trace_kernel<float, 2, ...,
+// kGenUniform>) is mirrored as well -- surface_step<f32x2, ...> compiles for the host, two rays
+// in one ext_vector -- and chosen by the same rule as the device's launcher.
+//
 // Differences from the device: v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 / v_exp_f32 (1 ulp) are
 // the correctly rounded host operations; the order of operations, the FMA contractions
 // written out as fma() and every branch are the kernel's own.
