@@ -204,6 +204,53 @@ def test_fit_kernels_beyond_the_grid_cap(engines, kind):
 
 
 @pytest.mark.parametrize("where", WHERE)
+def test_trimming_follows_the_flavour_of_the_standard_deviation(engines, where):
+    """Eight rays, one far out, k = 2.55: a single outlier among n has a z-score of
+    sqrt(n - 1) = 2.65 with np.std (ddof 0) and (n - 1) / sqrt(n) = 2.47 with torch.std (ddof 1)
+    -- the NumPy flavour trims it, the torch flavour cannot.  (Found by the mutation test of round 4: no
+    other case told the two divisors apart.)"""
+    eng = engines(where)
+    rng = np.random.default_rng(8)
+    rays, px, py = _random_bundle(rng, 8, spread=1e-4, dead=0.0)
+    rays[0, 0] += 5.0
+    got = {}
+    for flavour in ("numpy", "torch"):
+        want = oracle.wavefront_fit("centroid", PARAMS, rays, px, py, trim_std=2.55,
+                                    flavour=flavour)
+        ref, bits, opd, _ = _fit(eng, "centroid", PARAMS, rays, px, py, trim_std=2.55,
+                                 flavour=flavour)
+        assert bits == 0
+        _same(ref[0:3], want["center"], 1e-10, flavour)
+        np.testing.assert_allclose(ref[3], want["radius"], rtol=1e-12)
+        _same(opd, want["opd"], 5e-8, flavour)
+        got[flavour] = ref[0:3].copy()
+    assert abs(got["numpy"][0] - got["torch"][0]) > 0.1   # trimmed vs kept: 5 mm / 8 apart
+
+
+@pytest.mark.parametrize("where", WHERE)
+@pytest.mark.parametrize("axes", [(0, 1, 2), (2, 0, 1), (1, 2, 0)])
+def test_best_fit_plane_whatever_axis_the_normal_is_along(engines, axes, where):
+    """The least-squares plane's normal is the eigenvector of the SMALLEST eigenvalue wherever
+    it ends up on the diagonal: the same bundle with its coordinate axes permuted.  (Mutation
+    test of round 4: with the beam along z the smallest eigenvalue is always the third.)"""
+    eng = engines(where)
+    rng = np.random.default_rng(21)
+    rays, px, py = _random_bundle(rng, 500, dead=0.05)
+    perm = rays.copy()
+    for k, a in enumerate(axes):
+        perm[k], perm[3 + k] = rays[a], rays[3 + a]
+    want = oracle.wavefront_fit("best_fit", PARAMS, perm, px, py, planar=True)
+    ref, bits, opd, pupil = _fit(eng, "best_fit", PARAMS, perm, px, py, planar=True)
+    assert bits == 0
+    n, w = ref[10:13], want["normal"]
+    assert min(np.abs(n - w).max(), np.abs(n + w).max()) <= 1e-10
+    assert int(np.argmax(np.abs(n))) == axes.index(2)  # the beam axis, wherever it went
+    _same(ref[0:3], want["center"], 1e-9, "plane point")
+    _same(opd, want["opd"], 5e-8, "opd")
+    _same(pupil, want["pupil"], 1e-9, "pupil")
+
+
+@pytest.mark.parametrize("where", WHERE)
 def test_fit_status_bits_are_the_reference_errors(engines, where):
     eng = engines(where)
     rng = np.random.default_rng(5)

@@ -90,6 +90,36 @@ MUTANTS = [
 
 TESTS = ["tests/test_hostmath.py", "tests/test_hostmath_fuzz.py"]
 
+# round 4: the reduction passes of ol_wavefront_fit (wavefront_fit_device.h) and the other
+# arithmetic touched this round; killed or not by tests/test_wavefront_fit.py + the fused-generate
+# tests (`--set r04` -> profiles/r04_mutation_test.txt)
+F = "wavefront_fit_device.h"
+MUTANTS_R04 = [
+    (F, "fit_finite(r.N) && fit_finite(opd_t) && r.i != 0.0;", "fit_finite(r.N) && fit_finite(opd_t);", "validity: unlit rays (i == 0) are not samples"),
+    (F, "OL_DEV bool fit_finite(double v) { return v - v == 0.0; }", "OL_DEV bool fit_finite(double v) { return v == v; }", "validity: infinities are not finite"),
+    (F, "  const double s = opd_t / p.ni;\n  pts[0] = r.x - s * r.L;", "  const double s = opd_t / p.ni;\n  pts[0] = r.x + s * r.L;", "wavefront point: back along the ray"),
+    (F, "    const double wi = r.i < 0.0 ? 0.0 : r.i;\n    s[0] += 1.0;", "    const double wi = r.i;\n    s[0] += 1.0;", "weights: negative intensities clamp to 0"),
+    (F, "    const bool unit = s[1] == 0.0;  // strategy.py:411-414", "    const bool unit = false;  // strategy.py:411-414", "weights: all ones when they sum to 0"),
+    (F, "    const double sd = ::sqrt(s[0] / (st.n_valid - (double)p.ddof));", "    const double sd = ::sqrt(s[0] / (st.n_valid));", "trimming: Bessel's correction of the torch flavour"),
+    (F, "    st.thr = st.mean_d + p.trim_std * sd;", "    st.thr = st.mean_d + sd;", "trimming: k sigma"),
+    (F, "    if (st.trim_on != 0.0 && s[0] >= 4.0) {  // strategy.py:426-429", "    if (st.trim_on != 0.0 && s[0] >= 400.0) {  // strategy.py:426-429", "trimming: used when at least 4 rays are kept"),
+    (F, "    if (fit_norm3(r.x - st.c0[0], r.y - st.c0[1], r.z - st.c0[2]) <= st.thr) {", "    if (fit_norm3(r.x - st.c0[0], r.y - st.c0[1], r.z - st.c0[2]) >= st.thr) {", "trimming: keep the NEAR rays"),
+    (F, "      s[0] += w * fit_norm3(pts[0] - st.cen[0], pts[1] - st.cen[1], pts[2] - st.cen[2]);", "      s[0] += fit_norm3(pts[0] - st.cen[0], pts[1] - st.cen[1], pts[2] - st.cen[2]);", "centroid sphere: WEIGHTED mean distance"),
+    (F, "    if (len > 0.0) { n[0] /= len; n[1] /= len; n[2] /= len; }", "    if (false) { n[0] /= len; n[1] /= len; n[2] /= len; }", "centroid plane: unit normal"),
+    (F, "    else if (s[0] < 4.0) *status |= kFitTooFew;", "    else if (s[0] < 3.0) *status |= kFitTooFew;", "best fit: at least 4 samples"),
+    (F, "      st.sc[k] = var > 0.0 ? ::sqrt(var) : 1.0;  // a scale, not a statistic: any value > 0 works", "      st.sc[k] = var > 0.0 ? 7.0 * ::sqrt(var) : 3.0;  // a scale, not a statistic: any value > 0 works", "best fit: the scale of the normal equations  [EQUIVALENT by design: the fit is invariant under it]"),
+    (F, "    const double b = u0 * u0 + u1 * u1 + u2 * u2;", "    const double b = u0 * u0 + u1 * u1 - u2 * u2;", "best-fit sphere: right-hand side |u|^2"),
+    (F, "      const double R = ::sqrt(g[3] + a0 * a0 + a1 * a1 + a2 * a2);", "      const double R = ::sqrt(g[3] + a0 * a0 + a1 * a1);", "best-fit sphere: R^2 = e + |a|^2"),
+    (F, "      const double a0 = g[0] * st.isc[0] * 0.5,", "      const double a0 = g[0] * st.isc[0],", "best-fit sphere: centre = g / (2 s)"),
+    (F, "  if (C[1][1] < C[lo][lo]) lo = 1;", "  if (C[1][1] > C[lo][lo]) lo = 1;", "best-fit plane: the SMALLEST eigenvalue"),
+    (F, "      if (!(p.skip_nan && o != o)) {  // backend/torch_backend.py:969-989: be.mean drops NaN", "      if (true) {  // backend/torch_backend.py:969-989: be.mean drops NaN", "piston: the torch flavour's mean ignores NaN"),
+    (F, "    if (r.i > 0.0) {\n      double pu[3];", "    if (r.i != 0.0) {\n      double pu[3];", "piston: over the rays with i > 0"),
+    (F, "    out->opd_ref = s[1] / s[2];", "    out->opd_ref = s[1] / (s[2] + 1.0);", "piston: the mean"),
+    ("wavefront_device.h", "  const T opd = TILT_FIRST ? (opd_in + tilt) - opd_img : opd_in - opd_img + tilt;\n  const T tt = m::div(opd_img, w.ni);", "  const T opd = TILT_FIRST ? (opd_in - tilt) - opd_img : opd_in - opd_img + tilt;\n  const T tt = m::div(opd_img, w.ni);", "fitted OPD map: launch-plane tilt sign"),
+    ("raygen_device.h", "m::rsqrt(m2)", "m::rsqrt(m2 + T(1e-3))", "ray generator: normalisation by the reciprocal square root"),
+]
+TESTS_R04 = ["tests/test_wavefront_fit.py", "tests/test_generate_fused.py", "tests/test_hostmath.py"]
+
 
 def run(cmd, **kw):
     return subprocess.run(cmd, capture_output=True, text=True, **kw)
@@ -98,8 +128,15 @@ def run(cmd, **kw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", type=int, nargs="*")
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_mutation_test.txt"))
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--set", default="r02", choices=("r02", "r04"))
     args = ap.parse_args()
+    global MUTANTS, TESTS
+    if args.set == "r04":
+        MUTANTS, TESTS = [(f, o.replace("\\n", "\n"), n.replace("\\n", "\n"), w)
+                          for f, o, n, w in MUTANTS_R04], TESTS_R04
+    if args.out is None:
+        args.out = os.path.join(ROOT, "profiles", f"{args.set}_mutation_test.txt")
     sys.path.insert(0, ROOT)
     import importlib.util
     spec = importlib.util.spec_from_file_location("hb", os.path.join(ROOT, "tests", "hostmath", "build.py"))
@@ -140,7 +177,8 @@ def main():
             lib = os.path.join(tmp, "libmut.so")
             subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", *objs, "-o", lib])
             env = dict(os.environ, OL_HOSTMATH_LIBRARY=lib, PYTHONPATH=ROOT)
-            r = run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", *TESTS],
+            r = run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                     "-m", "not gpu", *TESTS],
                     cwd=ROOT, env=env, timeout=900)
             if r.returncode == 0:
                 verdict = "SURVIVED"
@@ -152,9 +190,9 @@ def main():
     killed = sum(1 for r in rows if r[2].startswith("killed"))
     equivalent = sum(1 for r in rows if "[EQUIVALENT" in r[1])
     with open(args.out, "w") as f:
-        f.write("# r02: mutation test of the kernel source on the CPU (tools/host_mutation_test.py): one small fault per\n"
-                "# mutant in a copy of optiland_amd/csrc, host harness rebuilt from it, tests/test_hostmath.py +\n"
-                "# tests/test_hostmath_fuzz.py run against it (-x: the first failing test is named).\n"
+        f.write(f"# {args.set}: mutation test of the kernel source on the CPU (tools/host_mutation_test.py --set {args.set}): one\n"
+                "# small fault per mutant in a copy of optiland_amd/csrc, host harness rebuilt from it,\n"
+                f"# {' + '.join(TESTS)} run against it (-x: the first failing test is named).\n"
                 f"# {killed} of {len(rows)} mutants killed ({equivalent} marked equivalent: no observable effect).\n")
         for idx, what, verdict, dt in rows:
             f.write(f"{idx:3d}  {what[:110]:62s} {verdict}\n")
