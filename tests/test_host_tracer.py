@@ -299,3 +299,25 @@ def test_record_pool_window_choice():
     assert RecordPool._pick(cand, 0.65, need, 4) == [(0.59, 1, 5), (0.60, 0, 30), (0.62, 0, 14)]
     assert RecordPool._pick(cand, 0.50, need, 2) == []
     assert RecordPool._pick([], 1.0, need, 2) == []
+
+
+def test_record_pool_configuration(monkeypatch):
+    """`integration.enable(placed_records=...)` / OPTILAND_HIP_PLACED_RECORDS only set the
+    process-wide pool configuration; on a CPU engine `alloc_record` never consults it."""
+    from optiland_amd import engine as E
+    from optiland_amd import integration as ig
+    assert E._POOL_CONFIG["slots"] == 0
+    try:
+        ig._set_record_pool(True)
+        assert E._POOL_CONFIG["slots"] == 2
+        ig._set_record_pool(3)
+        assert E._POOL_CONFIG["slots"] == 3
+        ig._set_record_pool(None)                      # None: leave as is ...
+        assert E._POOL_CONFIG["slots"] == 3
+        monkeypatch.setenv("OPTILAND_HIP_PLACED_RECORDS", "1")
+        ig._set_record_pool(None)                      # ... unless the environment says
+        assert E._POOL_CONFIG["slots"] == 1
+        ig._set_record_pool(False)
+        assert E._POOL_CONFIG["slots"] == 0 and not E._RECORD_POOLS
+    finally:
+        E.HipSystem.enable_record_pool(0)
