@@ -780,6 +780,12 @@ def main():
         sync(device)
     if gen:
         record, placement = make_record()
+    if have_pg:
+        # the placement probe takes 0.1-0.5 s, rank by rank different (one to three arenas): the
+        # ranks meet HERE, so that they start the warm-up together and none of them sits idle at
+        # the timed region's barrier with a part that has dropped out of its loaded state
+        dist.barrier()
+        sync(device)
     for _ in range(args.warmup):
         step()
     evs = [(make_event(), make_event()) for _ in range(args.steps)]
