@@ -122,7 +122,7 @@ class RecordPool:
         self.need = need = rows * 8 * self.stride * b
         self.windows = []          # (arena, address)
         self.free = []
-        self.lock = threading.Lock()
+        self.lock = threading.RLock()  # (a lease's finaliser may run while this thread holds it)
         self.info = {"block_bytes": need, "slots_wanted": slots, "probes": 0, "arenas": 0}
         if arena_bytes is None:
             arena_bytes = max(3 * need, 40 << 30)
