@@ -210,17 +210,6 @@ def bind(lib, path: str = "?"):
     lib.ol_set_tuning.argtypes = [i32, i32]
     lib.ol_trace_opd.restype = C.c_int
     lib.ol_trace_opd.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, C.POINTER(vp), vp, vp, vp]
-    lib.ol_wavefront_reference.restype = C.c_int
-    lib.ol_wavefront_reference.argtypes = [vp, i32, vp, vp, vp, C.c_double, i32, i32, vp, vp, vp,
-                                           vp]
-    lib.ol_trace_opd_dev.restype = C.c_int
-    lib.ol_trace_opd_dev.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, C.POINTER(vp), vp,
-                                     vp, vp]
-    lib.ol_wavefront_fit.restype = C.c_int
-    lib.ol_wavefront_fit.argtypes = [i32, vp, C.c_double, C.c_uint32, i32, i64, C.POINTER(vp), vp, vp,
-                                     vp, vp, vp, vp]
-    lib.ol_wavefront_opd_fitted.restype = C.c_int
-    lib.ol_wavefront_opd_fitted.argtypes = [i64, C.POINTER(vp), vp, vp, vp, vp, C.POINTER(vp), vp]
     lib.ol_pupil_fill.restype = C.c_int
     lib.ol_pupil_fill.argtypes = [i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     have = lib.ol_abi_version()
@@ -233,6 +222,19 @@ def bind(lib, path: str = "?"):
         raise HipExtensionError(
             f"{path}: ABI version {have} != expected {ABI_VERSION}; rebuild"
         )
+    # (entry points newer than ABI 5 are bound BELOW the version check: a stale library then
+    # says "ABI version X != expected" instead of a ctypes "undefined symbol")
+    lib.ol_wavefront_reference.restype = C.c_int
+    lib.ol_wavefront_reference.argtypes = [vp, i32, vp, vp, vp, C.c_double, i32, i32, vp, vp, vp,
+                                           vp]
+    lib.ol_trace_opd_dev.restype = C.c_int
+    lib.ol_trace_opd_dev.argtypes = [vp, i32, i64, vp, vp, vp, i32, vp, vp, C.POINTER(vp), vp,
+                                     vp, vp]
+    lib.ol_wavefront_fit.restype = C.c_int
+    lib.ol_wavefront_fit.argtypes = [i32, vp, C.c_double, C.c_uint32, i32, i64, C.POINTER(vp), vp, vp,
+                                     vp, vp, vp, vp]
+    lib.ol_wavefront_opd_fitted.restype = C.c_int
+    lib.ol_wavefront_opd_fitted.argtypes = [i64, C.POINTER(vp), vp, vp, vp, vp, C.POINTER(vp), vp]
     lib.ol_system_update.restype = C.c_int
     lib.ol_system_update.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]
     lib.ol_trace_generate.restype = C.c_int

@@ -325,7 +325,18 @@ class _LazyChiefRay:
         return self._rays
 
     def __getattr__(self, name):
+        # own slots and dunder probes never build the rays: copy.deepcopy / pickle look up
+        # `__deepcopy__`, `__reduce_ex__`, `__setstate__` ... on an instance whose __init__ has
+        # not run, and `_make()` reading `self._rays` there would re-enter this method for ever
+        if name in ("_chief8", "_w", "_rays") or (name.startswith("__") and name.endswith("__")):
+            raise AttributeError(name)
         return getattr(self._make(), name)
+
+    def __reduce__(self):
+        """pickle / copy.deepcopy (the reference deep-copies strategies with their optic): the
+        copy owns its own eight numbers."""
+        c = self._chief8
+        return (_LazyChiefRay, (c.clone() if hasattr(c, "clone") else c, self._w))
 
 
 def _fused_wavefront_device(self, front, table, hx, hy, w, dx, dy):
@@ -593,7 +604,13 @@ def _device_points(kind, num):
     if not hasattr(lib, "ol_pupil_points"):
         return None
     dtype = cfg.get_precision()
-    dev = torch.device("cuda", torch.cuda.current_device())
+    # the backend's configured device (backend/torch/config: `get_device()`), not whatever
+    # device happens to be current in this thread
+    dev = torch.device(cfg.get_device())
+    if dev.type != "cuda":
+        return None
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     first = offset = None
     if kind == "hexapolar":
         if num < 0:
@@ -621,7 +638,9 @@ def _hexapolar_generate_points(self, num_rings=6):
     """distribution.py:201-220 is a Python loop over the rings with four backend array
     operations and two concatenations each: 10.2 of the 11 ms an `OPD(lens, ..., num_rays=256)`
     takes on the device (profiles/r04_opd_profile.txt).  Same points, same order, from ONE
-    launch of `ol_pupil_points`."""
+    launch of `ol_pupil_points`: NumPy's formula in fp64 rounded to the backend's precision --
+    in fp32 that is within 1 ulp of, not bit-identical to, what the reference's torch backend
+    computes with its own fp32 `linspace / cos / sin`."""
     got = _device_points("hexapolar", num_rings)
     if got is None:
         STATS["dist_fallback"] += 1
@@ -681,9 +700,14 @@ def _resolve(key):
 
     mod, cls_name, meth, params, _ = _SEAMS[key]
     try:
-        cls = getattr(importlib.import_module(mod), cls_name)
-    except (ImportError, AttributeError) as exc:
-        return f"{mod}.{cls_name} not found ({exc})"
+        module = importlib.import_module(mod)
+    except ImportError as exc:
+        # an optional dependency of the reference that is not installed (numba, vtk ...): the
+        # seam stays off -- and `enable()` SAYS so: the analyses then run at reference speed
+        return f"import of {mod} failed ({exc})"
+    cls = getattr(module, cls_name, None)
+    if cls is None:
+        return f"{mod}.{cls_name} not found"
     fn = cls.__dict__.get(meth)
     if fn is None:
         return f"{cls_name}.{meth} is not defined on the class"
@@ -720,6 +744,13 @@ def enable():
     for key, (cls, fn) in found.items():
         _ORIG[key] = fn
         setattr(cls, _SEAMS[key][2], globals()[_SEAMS[key][4]])
+    if SKIPPED:
+        import warnings
+
+        warnings.warn("optiland_amd: analysis seams left OFF (the reference's own code runs on "
+                      "top of the drop-in trace for them): "
+                      + "; ".join(f"{k}: {why}" for k, why in SKIPPED.items()),
+                      RuntimeWarning, stacklevel=2)
     if not _ORIG:
         _ORIG["_none"] = None   # (enable() stays idempotent even if nothing could be patched)
 

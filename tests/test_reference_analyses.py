@@ -453,6 +453,15 @@ def test_device_resident_reference_equals_the_host_built_one(seams, reference_ty
         from optiland.wavefront.wavefront_data import WavefrontData
         back = pickle.loads(pickle.dumps(d))
         assert type(back) is WavefrontData and back.radius == d.radius
+        if type(chief).__name__ == "_LazyChiefRay":
+            # (advisor, round 4: deepcopy / pickle of the lazy chief ray recursed for ever --
+            # and with it every object that holds the strategy)
+            import copy
+            for dup in (copy.deepcopy(chief), pickle.loads(pickle.dumps(chief)),
+                        copy.deepcopy(w.strategy)._chief_ray):
+                assert type(dup).__name__ == "_LazyChiefRay"
+                assert float(_np(be, dup.y).reshape(-1)[0]) == \
+                    float(_np(be, chief.y).reshape(-1)[0])
         return ([_np(be, getattr(d, k)) for k in ("opd", "intensity", "pupil_x", "pupil_y",
                                                    "pupil_z")], d.radius,
                 [float(_np(be, getattr(chief, k)).reshape(-1)[0]) for k in
