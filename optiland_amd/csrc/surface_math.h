@@ -1476,39 +1476,46 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
       r[k].i = m::select(aperture_mask<V, FULL>(s, coeffs, r[k].x, r[k].y), r[k].i, zero);
   }
 
-  // refract / reflect (real_rays.py:163-205, 535-571)
-  V L0[RPT], M0[RPT], N0[RPT], adot[RPT], ax[RPT], ay[RPT], az[RPT];
+  // refract / reflect (real_rays.py:163-205, 535-571).  The reference aligns the normal with
+  // the ray first (n <- sign(n.k) n, dot <- |n.k|; sign(0) = 0) and then forms
+  //   reflect:  k' = k - 2 |dot| n_aligned          refract:  k' = u k + n_aligned (root - u |dot|)
+  // Multiplying by sign(dot) = +-1 (or 0) is exact and round-to-nearest is symmetric, so the
+  // same bits come out of
+  //   reflect:  k' = k - 2 dot n                    refract:  k' = u k + n (sign(dot) root - u dot)
+  // with ONE product sign(dot) root instead of three products n sign(dot): 2 vector
+  // instructions fewer per ray and refracting surface, 4 per reflecting one (round 5).
+  V L0[RPT], M0[RPT], N0[RPT], adot[RPT];
+  V sdot[RPT];
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
     L0[k] = r[k].L;
     M0[k] = r[k].M;
     N0[k] = r[k].N;
-    V dot = m::fma(L0[k], nx[k], m::fma(M0[k], ny[k], N0[k] * nz[k]));
-    // be.sign(dot): +-1, and 0 at 0.  (A NaN dot still poisons the new direction
-    // through adot below, whatever sign it is given here.)
-    const V sgn = m::select(m::ne(dot, zero), m::copysign(one, dot), zero);
-    ax[k] = nx[k] * sgn;
-    ay[k] = ny[k] * sgn;
-    az[k] = nz[k] * sgn;
-    adot[k] = m::abs(dot);
+    sdot[k] = m::fma(L0[k], nx[k], m::fma(M0[k], ny[k], N0[k] * nz[k]));
+    adot[k] = m::abs(sdot[k]);  // (read by the polarised coatings below only)
   }
   if (s.interaction == kReflect) {
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-      V k2 = m::splat(-2) * adot[k];
-      r[k].L = m::fma(k2, ax[k], L0[k]);
-      r[k].M = m::fma(k2, ay[k], M0[k]);
-      r[k].N = m::fma(k2, az[k], N0[k]);
+      V k2 = m::splat(-2) * sdot[k];
+      r[k].L = m::fma(k2, nx[k], L0[k]);
+      r[k].M = m::fma(k2, ny[k], M0[k]);
+      r[k].N = m::fma(k2, nz[k], N0[k]);
     }
   } else {
     const T u = o.u;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-      V root = m::sqrt(m::fma(m::splat(-u * u), m::fma(-adot[k], adot[k], one), one));  // NaN on TIR
-      V w = m::fma(m::splat(-u), adot[k], root);
-      r[k].L = m::fma(m::splat(u), L0[k], ax[k] * w);
-      r[k].M = m::fma(m::splat(u), M0[k], ay[k] * w);
-      r[k].N = m::fma(m::splat(u), N0[k], az[k] * w);
+      V root = m::sqrt(m::fma(m::splat(-u * u), m::fma(-sdot[k], sdot[k], one), one));  // NaN on TIR
+      // be.sign(dot): +-1, and 0 at 0 -- as a FACTOR of root, so that a NaN root (total
+      // internal reflection) at exactly grazing incidence still poisons the direction as the
+      // reference's 0 * NaN does.  (A NaN dot poisons it through the product u dot below,
+      // whatever sign it is given here.)
+      const V sgn = m::select(m::ne(sdot[k], zero), m::copysign(one, sdot[k]), zero);
+      V w = m::fma(m::splat(-u), sdot[k], sgn * root);
+      r[k].L = m::fma(m::splat(u), L0[k], nx[k] * w);
+      r[k].M = m::fma(m::splat(u), M0[k], ny[k] * w);
+      r[k].N = m::fma(m::splat(u), N0[k], nz[k] * w);
     }
   }
 

@@ -12,6 +12,35 @@ for leg in "$@"; do
     pairs)     # which two half-block pieces make a fast block (tools/microbench/vmm_pairs.hip)
       timeout 420 tools/microbench/vmm_pairs ${PAIRS_GIB:-230} > $O/r05_vmm_pairs.txt 2>&1; echo "rc=$?" >> $O/r05_vmm_pairs.txt
       tail -12 $O/r05_vmm_pairs.txt ;;
+    mode)      # the store pattern over TIME next to the part's clocks / power / temperature
+      rocm-smi --showclocks --showperflevel --showpower --showtemp > $O/r05_mode_smi_before.txt 2>&1
+      (while true; do t=$(date +%s.%N); for c in /sys/class/drm/card[0-9]*/device; do
+          [ -r $c/gpu_busy_percent ] || continue
+          echo "$t $(basename $(dirname $c)) busy=$(cat $c/gpu_busy_percent 2>/dev/null) mclk=$(grep '\*' $c/pp_dpm_mclk 2>/dev/null | tr -d '\n') fclk=$(grep '\*' $c/pp_dpm_fclk 2>/dev/null | tr -d '\n') sclk=$(grep '\*' $c/pp_dpm_sclk 2>/dev/null | tr -d '\n' | cut -c1-40) socclk=$(grep '\*' $c/pp_dpm_socclk 2>/dev/null | tr -d '\n') perf=$(cat $c/power_dpm_force_performance_level 2>/dev/null) pwr=$(cat $c/hwmon/hwmon*/power1_average 2>/dev/null | tr '\n' ',') temp=$(cat $c/hwmon/hwmon*/temp*_input 2>/dev/null | tr '\n' ',')"
+        done; sleep 0.2; done) > $O/r05_mode_sampler.txt 2>&1 &
+      SAMP=$!
+      timeout 120 tools/microbench/mode_probe ${MODE_S:-40} 0 > $O/r05_mode_probe_fill.txt 2>&1
+      tail -14 $O/r05_mode_probe_fill.txt
+      echo "--- forcing the performance level" > $O/r05_mode_force.txt
+      for c in /sys/class/drm/card[0-9]*/device; do
+        (echo high > $c/power_dpm_force_performance_level) >> $O/r05_mode_force.txt 2>&1; echo "$c rc=$? now=$(cat $c/power_dpm_force_performance_level 2>&1)" >> $O/r05_mode_force.txt
+      done
+      rocm-smi --setperflevel high >> $O/r05_mode_force.txt 2>&1
+      rocm-smi --showperflevel >> $O/r05_mode_force.txt 2>&1
+      tail -5 $O/r05_mode_force.txt
+      timeout 60 tools/microbench/mode_probe 12 0 > $O/r05_mode_probe_fill_high.txt 2>&1
+      head -12 $O/r05_mode_probe_fill_high.txt
+      for c in /sys/class/drm/card[0-9]*/device; do (echo auto > $c/power_dpm_force_performance_level) 2>/dev/null; done
+      rocm-smi --setperflevel auto > /dev/null 2>&1
+      timeout 120 tools/microbench/mode_probe ${MODE_S:-40} ${MODE_WORK:-8} > $O/r05_mode_probe_alu.txt 2>&1
+      tail -14 $O/r05_mode_probe_alu.txt
+      kill $SAMP ;;
+    junctions) # the smallest arena whose junction makes a fast block (tools/microbench/vmm_junctions.hip)
+      timeout 300 tools/microbench/vmm_junctions > $O/r05_vmm_junctions.txt 2>&1; echo "rc=$?" >> $O/r05_vmm_junctions.txt
+      cat $O/r05_vmm_junctions.txt | cut -c1-400 ;;
+    split)     # a displacement between two groups of planes inside ONE allocation
+      timeout 300 tools/microbench/split_offset > $O/r05_split_offset.txt 2>&1; echo "rc=$?" >> $O/r05_split_offset.txt
+      grep -c . $O/r05_split_offset.txt ;;
     debugfs)   # can the box show where a buffer lies physically?
       (mount -t debugfs none /sys/kernel/debug 2>&1; ls /sys/kernel/debug/dri/ 2>&1 | head; ls /sys/class/kfd/kfd/topology/nodes/ 2>&1;
        cat /sys/module/amdgpu/version 2>&1; uname -r; cat /sys/class/drm/card*/device/mem_info_vram_total 2>&1 | head -3;
