@@ -119,6 +119,10 @@ def parse_args():
     ap.add_argument("--settle", type=int, default=120,
                     help="extra launches AFTER the timed region whose last third is reported as "
                          "roofline.steady_state (0 = skip)")
+    ap.add_argument("--traffic", choices=("live", "committed"), default="live",
+                    help="roofline.traffic: re-measured in THIS run (two short rocprofv3 --pmc "
+                         "passes of this command as child processes, when rocprofv3 is on PATH "
+                         "and N = 1), or read from profiles/traffic.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-baselines", action="store_true",
                     help="skip the legs that time the staged reference package (NumPy backend "
@@ -347,6 +351,51 @@ def load_traffic(workload, dtype, mode):
         return None
 
 
+def measure_traffic_live(args, kernel_substr, log=None):
+    """HBM bytes per launch of the dominant kernel, measured NOW: this command again, short
+    (3 steps, no baselines, plain block), under `rocprofv3 --kernel-trace --pmc <counter>` --
+    one pass per counter, as MI355X_MICROARCH.md prescribes (FETCH_SIZE / WRITE_SIZE in KiB;
+    gfx950 reports half of a wide coalesced read: x 2).  None when rocprofv3 is missing, this
+    process is itself such a child, or a pass fails (the committed figure is used then)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if os.environ.get("OPTILAND_BENCH_CHILD") == "1" or shutil.which("rocprofv3") is None:
+        return None
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ol_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d,
+               "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--gpus", "1",
+               "--steps", "3", "--warmup", "1", "--settle", "0", "--no-cpu-baseline",
+               "--no-ref-baselines", "--placement", "plain", "--traffic", "committed",
+               "--rays", str(args.rays), "--dtype", args.dtype, "--workload", args.workload,
+               "--mode", args.mode, "--object-row", args.object_row]
+        try:
+            subprocess.run(cmd, cwd="/tmp", timeout=180, capture_output=True,
+                           env=dict(os.environ, TMPDIR="/tmp", OPTILAND_BENCH_CHILD="1"))
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    rows += [float(r["Counter_Value"]) for r in csv.DictReader(fh)
+                             if r.get("Counter_Name") == ctr
+                             and kernel_substr in r.get("Kernel_Name", "")]
+            if not rows:
+                return None
+            # (the first launch of a process also faults its pages in: the later ones)
+            rows = rows[1:] if len(rows) > 1 else rows
+            vals[ctr] = sum(rows) / len(rows)
+        except (OSError, subprocess.SubprocessError, ValueError, KeyError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"bytes": 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024,
+            "FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"]}
+
+
 def traffic_meta() -> dict:
     """Where / when the committed PMC passes ran (profiles/traffic.json: "_meta")."""
     try:
@@ -356,7 +405,7 @@ def traffic_meta() -> dict:
         return {}
 
 
-def stream_fill_bandwidth(hip, device, nbytes, store_bytes, planes, reps=6):
+def stream_fill_bandwidth(hip, device, nbytes, store_bytes, planes, reps=6, block=None):
     """GB/s of `ol_stream_fill` over a buffer of `nbytes` in `planes` planes (the write
     footprint and store pattern of the trace launch): a kernel that ONLY writes, every lane
     one element of `store_bytes` into each plane with the trace kernels' own non-temporal
@@ -368,7 +417,10 @@ def stream_fill_bandwidth(hip, device, nbytes, store_bytes, planes, reps=6):
     nbytes = int(nbytes) // unit * unit
     if nbytes <= 0 or not hasattr(hip.lib, "ol_stream_fill"):
         return None
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    # `block`: the fill goes into THAT memory (the record block of this run's steps, planes at
+    # its own stride) -- where a block lies decides 5.8 or 7.1 TB/s, so a ceiling for a kernel
+    # is only one when it is measured where the kernel writes
+    buf = block if block is not None else torch.empty(nbytes, dtype=torch.uint8, device=device)
     stream = hip._stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for k in range(2 + reps):
@@ -633,6 +685,13 @@ def main():
 
     import torch.distributed as dist
     have_pg = dist.is_available() and dist.is_initialized()
+    rccl_world = None
+    if have_pg:
+        # the number of ranks as a REAL collective on the compute device reports it (a sum of
+        # ones over the group), not as the launcher's environment claims it
+        ones = torch.ones(1, dtype=torch.float64, device=device)
+        dist.all_reduce(ones)
+        rccl_world = int(round(float(ones.item())))
     exchange = args.exchange if (world > 1 or (args.force_exchange and have_pg)) else "none"
     configured_exchange = exchange
     pending = [None, None]  # in-flight all-gathers (double-buffered)
@@ -907,10 +966,23 @@ def main():
         # write-only yardstick of THIS run: a non-temporal fill of the launch's own write
         # footprint with its own store width
         written = moved_bytes - (2 * b * n if (gen or spot) else 8 * b * n)
-        fill_big = None
+        fill_big = fill_plain = None
         if bw is not None and args.mode in ("record", "gen") and written >= (1 << 28):
-            fill_big = stream_fill_bandwidth(hip, device, min(written, 16 << 30), b,
-                                             max(int(round(written / (b * n))), 1))
+            fill_plain = stream_fill_bandwidth(hip, device, min(written, 16 << 30), b,
+                                               max(int(round(written / (b * n))), 1))
+            if record is not None and record.is_contiguous():
+                # ... and on the record block of the timed steps ITSELF (its trace legs are
+                # done; the fill overwrites it): the ceiling of the place the kernel wrote to
+                rb = record.view(-1).view(torch.uint8)
+                fill_big = stream_fill_bandwidth(hip, device, rb.numel(), b,
+                                                 int(record.shape[0]) * 8, block=rb)
+        live = None
+        if args.traffic == "live" and world == 1 and not args.plumbing_check and args.steps:
+            live = measure_traffic_live(
+                args, "opd_trace_kernel" if opd_mode else
+                ("spot_trace_kernel" if spot else "trace_kernel"))
+            if live is not None:
+                traffic = live["bytes"]
         if steady is not None:
             steady["achieved"] = moved_bytes / (steady["kernel_ms"] * 1e-3) / 1e9
             steady["frac"] = steady["achieved"] / HBM_PEAK_GBS
@@ -950,7 +1022,9 @@ def main():
                 "exchange": configured_exchange,
                 "parallelism": f"ray-shard x{world}",
             },
-            "exchange": exchange_info,
+            "exchange": (dict(exchange_info or {}, rccl_world=rccl_world,
+                              backend=dist.get_backend() if have_pg else None)
+                         if (exchange_info or have_pg) else None),
             "roofline": {
                 "bound": "hbm",
                 "kernel": "opd_trace_kernel" if opd_mode else
@@ -963,13 +1037,21 @@ def main():
                 "unit": "GB/s",
                 "frac": moved_GBps / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / "
-                                  "WRITE_SIZE passes of this command, committed (not re-measured "
-                                  "in this run" + (f"; scaled from {traffic_rays} to {n} rays)"
-                                                   if n != traffic_rays else ")"),
-                "traffic_box": traffic_meta().get("box") or
-                               "the builder's MI355X box of the round the PMC passes ran in "
-                               "(tools/collect_profiles.py); another box than this run's",
+                "traffic_source": (
+                    "measured in THIS run on this box: two child runs of this command (3 steps, "
+                    "plain block) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc "
+                    "WRITE_SIZE`, mean over the kernel's launches after the first; "
+                    f"2 x {live['FETCH_SIZE_KiB']:.1f} KiB (gfx950 halves wide reads) + "
+                    f"{live['WRITE_SIZE_KiB']:.1f} KiB") if live is not None else (
+                    "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / "
+                    "WRITE_SIZE passes of this command, committed (not re-measured "
+                    "in this run" + (f"; scaled from {traffic_rays} to {n} rays)"
+                                     if n != traffic_rays else ")")),
+                "traffic_box": "this run's" if live is not None else (
+                    traffic_meta().get("box") or
+                    "the builder's MI355X box of the round the PMC passes ran in "
+                    "(tools/collect_profiles.py); another box than this run's"),
+                "traffic_over_moved": (traffic / moved_bytes) if traffic else None,
                 "kernel_ms": kern_ms,
                 "kernel_us_minmax": [min(kern_each) * 1e3, max(kern_each) * 1e3]
                                     if kern_each else None,
@@ -984,7 +1066,9 @@ def main():
                 "device_copy_GBps": bw and bw["copy_GBps"],
                 "device_fill_1GiB_GBps": bw and bw["fill_GBps"],
                 "stream_fill_GBps": fill_big,
-                "stream_fill_bytes": int(min(written, 16 << 30)) if fill_big else None,
+                "stream_fill_where": "the record block of the timed steps itself" if fill_big
+                                     else None,
+                "stream_fill_plain_block_GBps": fill_plain,
                 "frac_of_write_ceiling": (moved_GBps / fill_big) if fill_big else None,
                 "note": ("fused spot kernel: only the two pupil planes touch HBM, the kernel is "
                          "vector-ALU bound by construction -- the HBM fraction is reported for "
@@ -994,9 +1078,11 @@ def main():
                          "generator wrote into the record block outside the timed region and, "
                          "for polarised runs, the PRT read a fresh trace never does); "
                          "frac_of_write_ceiling = moved GB/s over `ol_stream_fill` -- this "
-                         "launch's own store pattern (as many planes, one non-temporal store "
-                         "of the same width per lane and plane, the same footprint) with the "
-                         "arithmetic taken out, timed in this run; "
+                         "launch's own store pattern (as many planes at the same stride, one "
+                         "non-temporal store per lane and plane) with the arithmetic taken out, "
+                         "timed in this run INTO THE SAME record block (the fill writes the "
+                         "stride padding too and issues 4-byte stores where the packed-pair "
+                         "kernel issues 8-byte ones: a few % either way); "
                          "steady_state = the same launch after the clock transient of the "
                          "first ~100 ms (outside the reported region)"),
             },

@@ -405,6 +405,13 @@ __device__ __forceinline__ SurfFetched<T> fetched_surface(int s) {
   return SurfFetched<T>{as_const(ka->surf) + s, as_const(ka->cold) + s,
                         as_const(ka->optics) + (s * ka->a.n_wl + ka->a.wl)};
 }
+// ... for an explicit wavelength slot (the batched spot kernel: one per cell)
+template <typename T, typename A>
+__device__ __forceinline__ SurfFetched<T> fetched_surface_wl(int s, int wl) {
+  const auto ka = kernargs<T, A>();
+  return SurfFetched<T>{as_const(ka->surf) + s, as_const(ka->cold) + s,
+                        as_const(ka->optics) + (s * ka->a.n_wl + wl)};
+}
 #ifndef OL_POLNR_WAVES_F64
 #define OL_POLNR_WAVES_F64 0
 #endif
@@ -1047,11 +1054,17 @@ template hipError_t launch_trace_generate<double>(const TraceArgs<double>&, int,
 // L2 atomic rate, many enough (>= ~8 rounds of resident workgroups) that the last
 // round's partial occupancy does not show.
 
-template <typename T, int RPT, int NR, bool FIELDP, bool APOD>
+// BATCH: blockIdx.y = cell of a (field, wavelength) grid (`batch`, see trace_launch.h); the
+// single-cell form carries a one-byte stand-in so that its kernarg segment stays what it was.
+struct NoBatch {
+  char unused;
+};
+template <typename T, int RPT, int NR, bool FIELDP, bool APOD, bool BATCH = false>
 __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
     const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
-    SpotArgs<T> a) {
+    SpotArgs<T> a, typename std::conditional<BATCH, SpotBatch<T>, NoBatch>::type batch) {
+  static_assert(!(BATCH && FIELDP), "a batched cell has ONE field point");
   // Newton ranges (and every fp64 instance): nothing of the argument block is held across the
   // surface loop -- each phase of a tile reads what it needs from the kernarg segment
   constexpr bool kFetch = fetch_level<T, NR, true>() >= 1;      // argument block
@@ -1077,9 +1090,15 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
     const int64_t left = n_rays - base;
     const int cnt = left >= RPT ? RPT : (left > 0 ? (int)left : 0);
     const auto& in_ = A0->in;
-    const bool vig_planes = in_.vx != nullptr;
+    const bool vig_planes = !BATCH && in_.vx != nullptr;
     // launch-uniform field: the two tangents come from the host (uniform_field_tangents)
-    const T tx0 = in_.tx0, ty0 = in_.ty0;
+    T tx0, ty0, vx0, vy0;
+    if constexpr (BATCH) {
+      const SpotCell<T>& cell = batch.c[blockIdx.y];
+      tx0 = cell.tx; ty0 = cell.ty; vx0 = cell.vx; vy0 = cell.vy;
+    } else {
+      tx0 = in_.tx0; ty0 = in_.ty0; vx0 = in_.vx0; vy0 = in_.vy0;
+    }
     const uint32_t rg_flags = in_.flags;
 
     // pupil (and optional per-ray field / vignetting) planes; lanes past the end
@@ -1104,8 +1123,8 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
         in[1][k] = vec_get<T, RPT>(v[1], k);
         in[2][k] = field_planes ? vec_get<T, RPT>(v[2], k) : T(0);
         in[3][k] = field_planes ? vec_get<T, RPT>(v[3], k) : T(0);
-        in[4][k] = vig_planes ? vec_get<T, RPT>(v[4], k) : in_.vx0;
-        in[5][k] = vig_planes ? vec_get<T, RPT>(v[5], k) : in_.vy0;
+        in[4][k] = vig_planes ? vec_get<T, RPT>(v[4], k) : vx0;
+        in[5][k] = vig_planes ? vec_get<T, RPT>(v[5], k) : vy0;
       }
     } else {
 #pragma unroll
@@ -1115,8 +1134,8 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
         in[1][k] = ok ? in_.py[base + k] : T(0);
         in[2][k] = (ok && field_planes) ? in_.hx[base + k] : T(0);
         in[3][k] = (ok && field_planes) ? in_.hy[base + k] : T(0);
-        in[4][k] = (ok && vig_planes) ? in_.vx[base + k] : in_.vx0;
-        in[5][k] = (ok && vig_planes) ? in_.vy[base + k] : in_.vy0;
+        in[4][k] = (ok && vig_planes) ? in_.vx[base + k] : vx0;
+        in[5][k] = (ok && vig_planes) ? in_.vy[base + k] : vy0;
       }
     }
 
@@ -1159,7 +1178,12 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
       int last_idx = 0;
       const int first = kernargs<T, SpotArgs<T>>()->a.first;
       for (int s = first; s <= kernargs<T, SpotArgs<T>>()->a.last; ++s) {
-        const SurfFetched<T> h = fetched_surface<T, SpotArgs<T>>(s);
+        const SurfFetched<T> h = [&](int s_) {
+          if constexpr (BATCH)
+            return fetched_surface_wl<T, SpotArgs<T>>(s_, batch.c[blockIdx.y].wl);
+          else
+            return fetched_surface<T, SpotArgs<T>>(s_);
+        }(s);
         if (refresh(h.hot)->interaction != kRecordOnly) {
           surface_step<V, NV, 0, NR>(h, as_const(kernargs<T, SpotArgs<T>>()->coeffs), is_global, r,
                                      P, status, prt_fresh);
@@ -1167,7 +1191,7 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
           last_idx = s;
         }
       }
-      const DevSurf<T> lt = fetched_surface<T, SpotArgs<T>>(last_idx).surf();
+      const DevSurf<T> lt = fetched_surface<T, SpotArgs<T>>(last_idx).surf();  // (no optics row)
 #pragma unroll
       for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(lt, r[j]);
     } else {
@@ -1184,7 +1208,9 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
         }
         S.cold = as_const(cold_tab) + s;
         if (S.interaction != kRecordOnly) {
-          const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
+          int wl_ = a.wl;
+          if constexpr (BATCH) wl_ = batch.c[blockIdx.y].wl;
+          const DevOptics<T> O = optics_tab[s * a.n_wl + wl_];
           surface_step<V, NV, 0, NR>(S, O, as_const(coeff_tab), is_global, r, P, status,
                                      prt_fresh);
           is_global = false;
@@ -1197,7 +1223,12 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
 
     T hx_[RPT], hy_[RPT], hi_[RPT];
     const auto A1 = arg_view<kFetch, T>(a);
-    const double cx = A1->cx, cy = A1->cy;
+    double cx, cy;
+    if constexpr (BATCH) {
+      cx = batch.c[blockIdx.y].cx; cy = batch.c[blockIdx.y].cy;
+    } else {
+      cx = A1->cx; cy = A1->cy;
+    }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       const Ray<T> g = LP::ray(gv, k);
@@ -1206,20 +1237,24 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
     }
     if (A1->hits[0] != nullptr && cnt > 0) {
       const RayIndexT<false> at{tile * (kTraceBlock * RPT), (uint32_t)threadIdx.x * RPT};
-      store_plane<T, RPT>(A1->hits[0], at, cnt, hx_);
-      store_plane<T, RPT>(A1->hits[1], at, cnt, hy_);
-      store_plane<T, RPT>(A1->hits[2], at, cnt, hi_);
+      int64_t cell_off = 0;
+      if constexpr (BATCH) cell_off = (int64_t)blockIdx.y * 3 * batch.hits_stride;
+      store_plane<T, RPT>(A1->hits[0] + cell_off, at, cnt, hx_);
+      store_plane<T, RPT>(A1->hits[1] + cell_off, at, cnt, hy_);
+      store_plane<T, RPT>(A1->hits[2] + cell_off, at, cnt, hi_);
     }
   }
 
   const auto A2 = arg_view<kFetch, T>(a);
-  acc.flush(A2->out);
+  if constexpr (BATCH) acc.flush(A2->out + 8 * blockIdx.y);
+  else acc.flush(A2->out);
   uint32_t* status_out = A2->status;
   if (status && status_out) atomicOr(status_out, status);
 }
 
-template <typename T, int RPT, int NR>
-static hipError_t launch_spot_nr(const SpotArgs<T>& a_in, hipStream_t stream) {
+template <typename T, int RPT, int NR, bool BATCH = false>
+static hipError_t launch_spot_nr(const SpotArgs<T>& a_in, hipStream_t stream,
+                                 const SpotBatch<T>* batch = nullptr) {
   SpotArgs<T> a = a_in;
   const int64_t tile_rays = (int64_t)kTraceBlock * RPT;
   const int64_t ntiles = (a.n + tile_rays - 1) / tile_rays;
@@ -1228,50 +1263,82 @@ static hipError_t launch_spot_nr(const SpotArgs<T>& a_in, hipStream_t stream) {
     return e ? atoi(e) : 0;
   }();
   constexpr int64_t kTargetBlocks = 8192;  // ~8 rounds of 256 CUs x 4 resident workgroups
-  int64_t tpb = forced > 0 ? forced : (ntiles + kTargetBlocks - 1) / kTargetBlocks;
+  const int64_t cells = BATCH ? batch->n_cells : 1;
+  // (a batch fills the part with cells x blocks workgroups: fewer blocks per cell do)
+  int64_t tpb = forced > 0 ? forced : (ntiles * cells + kTargetBlocks - 1) / kTargetBlocks;
   if (tpb < 1) tpb = 1;
   if (tpb > 1024) tpb = 1024;
   a.tiles_per_block = (int32_t)tpb;
   a.rgc = RaygenConsts<T>(a.rg);
-  if (a.in.hx == nullptr) uniform_field_tangents<T>(a.rg, a.in);
+  if (!BATCH && a.in.hx == nullptr) uniform_field_tangents<T>(a.rg, a.in);
   const int64_t blocks = (ntiles + tpb - 1) / tpb;
-  if (blocks == 0) return hipSuccess;
+  if (blocks == 0 || cells == 0) return hipSuccess;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  const bool apod = a.rg.apod_kind != 0;
+  if constexpr (BATCH) {
+#define OL_SPOT_LAUNCH_B(A)                                                                   \
+  hipLaunchKernelGGL((spot_trace_kernel<T, RPT, NR, false, A, true>),                         \
+                     dim3((unsigned)blocks, (unsigned)cells), dim3(kTraceBlock), 0, stream,   \
+                     a.surf, a.cold, a.optics, a.coeffs, a, *batch)
+    if (apod) OL_SPOT_LAUNCH_B(true);
+    else OL_SPOT_LAUNCH_B(false);
+#undef OL_SPOT_LAUNCH_B
+  } else {
 #define OL_SPOT_LAUNCH(F, A)                                                               \
   hipLaunchKernelGGL((spot_trace_kernel<T, RPT, NR, F, A>), dim3((unsigned)blocks),        \
-                     dim3(kTraceBlock), 0, stream, a.surf, a.cold, a.optics, a.coeffs, a)
-  const bool fieldp = a.in.hx != nullptr, apod = a.rg.apod_kind != 0;
-  if (fieldp && apod) OL_SPOT_LAUNCH(true, true);
-  else if (fieldp) OL_SPOT_LAUNCH(true, false);
-  else if (apod) OL_SPOT_LAUNCH(false, true);
-  else OL_SPOT_LAUNCH(false, false);
+                     dim3(kTraceBlock), 0, stream, a.surf, a.cold, a.optics, a.coeffs, a,  \
+                     NoBatch{})
+    const bool fieldp = a.in.hx != nullptr;
+    if (fieldp && apod) OL_SPOT_LAUNCH(true, true);
+    else if (fieldp) OL_SPOT_LAUNCH(true, false);
+    else if (apod) OL_SPOT_LAUNCH(false, true);
+    else OL_SPOT_LAUNCH(false, false);
 #undef OL_SPOT_LAUNCH
+  }
   return hipGetLastError();
 }
 
-template <typename T>
-hipError_t launch_spot_trace(const SpotArgs<T>& a, bool vector_ok, int nr_family,
-                             hipStream_t stream) {
+template <typename T, bool BATCH>
+static hipError_t dispatch_spot(const SpotArgs<T>& a, const SpotBatch<T>* batch, bool vector_ok,
+                                int nr_family, hipStream_t stream) {
   constexpr int kVec = 16 / sizeof(T);
   // same defaults as record-last traces (launch_trace): conic-only ranges are ALU
   // bound and want the 16-byte vector of rays per lane; Newton ranges one ray (and, like
   // launch_trace, the single-family instantiation when the range allows it)
   const int want = tuning().rays_per_thread;
   if (nr_family != kNrNone) {
-    if (vector_ok && want == 2) return launch_spot_nr<T, kVec, 1>(a, stream);
-    if (nr_family == kNrZernike) return launch_spot_nr<T, 1, kNrZernike>(a, stream);
-    if (nr_family == kNrEvenAsphere) return launch_spot_nr<T, 1, kNrEvenAsphere>(a, stream);
-    return launch_spot_nr<T, 1, 1>(a, stream);
+    if (vector_ok && want == 2) return launch_spot_nr<T, kVec, 1, BATCH>(a, stream, batch);
+    if (nr_family == kNrZernike) return launch_spot_nr<T, 1, kNrZernike, BATCH>(a, stream, batch);
+    if (nr_family == kNrEvenAsphere)
+      return launch_spot_nr<T, 1, kNrEvenAsphere, BATCH>(a, stream, batch);
+    return launch_spot_nr<T, 1, 1, BATCH>(a, stream, batch);
   }
-  if (!vector_ok || want == 1) return launch_spot_nr<T, 1, 0>(a, stream);
-  return launch_spot_nr<T, kVec, 0>(a, stream);
+  if (!vector_ok || want == 1) return launch_spot_nr<T, 1, 0, BATCH>(a, stream, batch);
+  return launch_spot_nr<T, kVec, 0, BATCH>(a, stream, batch);
+}
+
+template <typename T>
+hipError_t launch_spot_trace(const SpotArgs<T>& a, bool vector_ok, int nr_family,
+                             hipStream_t stream) {
+  return dispatch_spot<T, false>(a, nullptr, vector_ok, nr_family, stream);
+}
+
+template <typename T>
+hipError_t launch_spot_batch(const SpotArgs<T>& a, const SpotBatch<T>& batch, bool vector_ok,
+                             int nr_family, hipStream_t stream) {
+  if (batch.n_cells < 0 || batch.n_cells > kSpotBatchCells) return hipErrorInvalidValue;
+  return dispatch_spot<T, true>(a, &batch, vector_ok, nr_family, stream);
 }
 
 #if OL_TRACE_TU == 0 || OL_TRACE_TU == 1
 template hipError_t launch_spot_trace<float>(const SpotArgs<float>&, bool, int, hipStream_t);
+template hipError_t launch_spot_batch<float>(const SpotArgs<float>&, const SpotBatch<float>&, bool,
+                                             int, hipStream_t);
 #endif
 #if OL_TRACE_TU == 0 || OL_TRACE_TU == 2
 template hipError_t launch_spot_trace<double>(const SpotArgs<double>&, bool, int, hipStream_t);
+template hipError_t launch_spot_batch<double>(const SpotArgs<double>&, const SpotBatch<double>&,
+                                              bool, int, hipStream_t);
 #endif
 
 // --------------------------------------------------------------------------

@@ -200,6 +200,32 @@ template <typename T>
 hipError_t launch_spot_trace(const SpotArgs<T>& a, bool vector_ok, int nr_family,
                              hipStream_t stream);
 
+// ONE launch for a grid of (field, wavelength) cells over the same pupil planes
+// (ol_trace_spot_batch: SpotDiagram._generate_data, analysis/spot_diagram/core.py:420-438):
+// blockIdx.y is the cell, so everything a cell changes -- the field tangents, the vignetting
+// factors, the wavelength row of the optics table, the centre of the moments, where its hits
+// and its eight sums go -- is workgroup-uniform and read from this block with scalar loads.
+// It travels as a kernel parameter of its own BEHIND the SpotArgs block, whose kernarg layout
+// (kernargs<T, SpotArgs<T>>) stays what the single-cell kernels read.
+constexpr int kSpotBatchCells = 32;
+template <typename T>
+struct SpotCell {
+  T tx, ty, vx, vy;   // field tangents (uniform_field_tangents), vignetting factors
+  double cx, cy;
+  int32_t wl, pad_;
+};
+template <typename T>
+struct SpotBatch {
+  int32_t n_cells, pad_;
+  int64_t hits_stride;   // elements between the planes of the hits block (cell-major, x / y / i)
+  SpotCell<T> c[kSpotBatchCells];
+};
+// a.hits[k] = plane k of cell 0 (cell c: + c * 3 * hits_stride), a.out = the 8 doubles of cell 0
+// (cell c: + 8 c); a.in.hx / hy / vx / vy must be null (one field per cell)
+template <typename T>
+hipError_t launch_spot_batch(const SpotArgs<T>& a, const SpotBatch<T>& batch, bool vector_ok,
+                             int nr_family, hipStream_t stream);
+
 template <typename T>
 hipError_t launch_pol_intensity(int64_t n, const T* prt, bool prt_complex, const T* const k0[3],
                                 const T* i0,

@@ -6,6 +6,7 @@ arithmetic happens in the hand-written HIP kernels behind the C ABI.
 
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 
@@ -75,8 +76,26 @@ class TraceResult:
         return self.record[:, k, : self.n]
 
 
-_POOL_CONFIG = {"slots": 0, "min_bytes": 256 << 20}
-_RECORD_POOLS: dict = {}   # (device index, n, dtype, rows) -> RecordPool
+# Record blocks that are handed to a user (`alloc_record`).  "auto" (the default since round 5):
+# a shape of `min_bytes` or more that is asked for a SECOND time -- a loop, not a one-off trace --
+# gets a `RecordPool` of two placed windows, provided the device has memory to spare (see
+# `_auto_arena_bytes`); an int = that many windows per shape from the first request on; 0 = off.
+# OPTILAND_HIP_PLACED_RECORDS (auto | 0 | n) seeds it.
+def _default_slots():
+    env = os.environ.get("OPTILAND_HIP_PLACED_RECORDS", "auto").strip().lower()
+    if env in ("", "auto"):
+        return "auto"
+    try:
+        return max(int(env), 0)
+    except ValueError:
+        return "auto"
+
+
+_POOL_CONFIG = {"slots": _default_slots(), "min_bytes": 256 << 20, "max_pools": 2,
+                "cooldown": 64}
+_RECORD_POOLS: "collections.OrderedDict" = collections.OrderedDict()  # key -> RecordPool (LRU)
+_SHAPE_SEEN: dict = {}     # key -> requests so far ("auto": the second one builds the pool)
+_POOL_COOLDOWN: dict = {}  # device index -> big allocations left before another pool is built
 
 
 class _Lease:
@@ -108,9 +127,11 @@ class RecordPool:
     (the drop-in's `Optic.trace`): windows of device memory in which the record-all store
     pattern writes fastest (`HipSystem.alloc_record_placed`), lent out one trace at a time and
     returned when the user's last view of the block dies.  A loop that keeps one result alive
-    while it makes the next needs two.  Opt-in (`HipSystem.enable_record_pool`,
-    `integration.enable(placed_records=...)`): the arenas behind the windows stay allocated --
-    ~40 GiB for two 4 GiB windows on the boxes measured."""
+    while it makes the next needs two.  The arenas behind the windows stay allocated for the
+    life of the pool -- ~40 GiB for two 4 GiB windows on the boxes measured
+    (`HipSystem.enable_record_pool(0)` / `integration.enable(placed_records=0)` gives them
+    back).  WHY a window is fast is still not known (five experiments of round 5
+    say what it is NOT); it is therefore found, not built."""
 
     def __init__(self, hip, n: int, dtype, rows: int, slots: int = 2, arena_bytes=None,
                  min_gain: float = 0.04, max_arenas: int = 3):
@@ -153,7 +174,10 @@ class RecordPool:
             self.info["window_GBps"] = [need / (t * 1e-3) / 1e9 for t, _a, _o in picked]
             for _t, a, off in picked:
                 self.windows.append((held[a], held[a].data_ptr() + off))
-            held = None  # (arenas without a window are released with this frame)
+            unused = len(held) - len({a for _t, a, _o in picked})
+            held = None  # (arenas without a window are released with this frame ...
+            if unused:
+                torch.cuda.empty_cache()  # ... and go back to the DRIVER, not to torch's cache)
         self.free = list(range(len(self.windows)))
         self.info["slots"] = len(self.windows)
 
@@ -294,29 +318,78 @@ class HipSystem:
         return stride
 
     @staticmethod
-    def enable_record_pool(slots: int = 2, min_bytes: int = 256 << 20) -> None:
-        """From now on `alloc_record` (of every system of this process) lends out PLACED blocks
-        (`RecordPool`) for block shapes of at least `min_bytes` -- for traces whose record goes
-        to a user; `slots` blocks per shape may be alive at a time, further ones are ordinary
-        allocations; two shapes per device are kept.  0 = off (the pools and their arenas go)."""
-        _POOL_CONFIG["slots"], _POOL_CONFIG["min_bytes"] = int(slots), int(min_bytes)
-        if not slots:
+    def enable_record_pool(slots=2, min_bytes: int = 256 << 20) -> None:
+        """How `alloc_record` (of every system of this process) serves block shapes of at least
+        `min_bytes` -- the blocks of traces whose record goes to a user.  `slots` = n: n PLACED
+        blocks (`RecordPool`) per shape may be alive at a time from the first request on;
+        "auto" (the default): two, from the SECOND request of a shape on and only while the
+        device has memory to spare; 0 = off (the pools and their arenas go).  Further blocks
+        are ordinary allocations; the two most recently used shapes per device are kept."""
+        _POOL_CONFIG["slots"] = "auto" if slots == "auto" else max(int(slots), 0)
+        _POOL_CONFIG["min_bytes"] = int(min_bytes)
+        if not _POOL_CONFIG["slots"]:
             _RECORD_POOLS.clear()
+        _SHAPE_SEEN.clear()
+        _POOL_COOLDOWN.clear()
+
+    @staticmethod
+    def reset_record_pool() -> None:
+        """Back to the default policy (OPTILAND_HIP_PLACED_RECORDS, else "auto"); pools go."""
+        _RECORD_POOLS.clear()
+        HipSystem.enable_record_pool(_default_slots())
+
+    def _auto_arena_bytes(self, need: int):
+        """Arena size of an "auto" pool, or None when the device cannot spare one: at least
+        half of the device memory must be free, and the arena takes at most a quarter of
+        that."""
+        free, total = torch.cuda.mem_get_info(self.device)
+        if free < total // 2:
+            return None
+        size = min(max(3 * need, 40 << 30), free // 4)
+        return size if size >= 2 * need else None
+
+    def _pool_for(self, n: int, dtype, rows: int, need: int):
+        """The `RecordPool` that serves this shape, or None (policy: see `enable_record_pool`)."""
+        slots = _POOL_CONFIG["slots"]
+        if not slots or need < _POOL_CONFIG["min_bytes"] or self.device.type != "cuda" \
+                or not hasattr(self.lib, "ol_stream_fill"):
+            return None
+        dev = self.device.index
+        key = (dev, int(n), dtype, rows)
+        pool = _RECORD_POOLS.get(key)
+        if pool is not None:
+            _RECORD_POOLS.move_to_end(key)     # least recently USED goes first
+            return pool
+        auto = slots == "auto"
+        seen = _SHAPE_SEEN[key] = _SHAPE_SEEN.get(key, 0) + 1
+        if auto and seen < 2:
+            return None                        # a one-off trace does not pay for a probe
+        left = _POOL_COOLDOWN.get(dev, 0)
+        if left > 0:                           # a pool was evicted a moment ago: a workload that
+            _POOL_COOLDOWN[dev] = left - 1     # cycles through many shapes is served plain
+            return None
+        arena_bytes = None
+        if auto:
+            arena_bytes = self._auto_arena_bytes(need)
+            if arena_bytes is None:
+                return None
+        mine = [k for k in _RECORD_POOLS if k[0] == dev]
+        if len(mine) >= _POOL_CONFIG["max_pools"]:
+            _RECORD_POOLS.pop(mine[0])         # the least recently used shape (and its arenas)
+            _POOL_COOLDOWN[dev] = _POOL_CONFIG["cooldown"]
+        # (a pool whose probe found no window stays registered -- empty, without arenas -- so
+        # that the shape is not probed again)
+        pool = _RECORD_POOLS[key] = RecordPool(self, n, dtype, rows, 2 if auto else slots,
+                                               arena_bytes=arena_bytes,
+                                               max_arenas=2 if auto else 3)
+        return pool
 
     def alloc_record(self, n: int, dtype, rows: int | None = None) -> torch.Tensor:
         rows = self.num_surfaces if rows is None else rows
         b = torch.empty((), dtype=dtype).element_size()
         stride = self.record_stride(n, b)
-        slots = _POOL_CONFIG["slots"]
-        if slots and rows * 8 * stride * b >= _POOL_CONFIG["min_bytes"] \
-                and self.device.type == "cuda" and hasattr(self.lib, "ol_stream_fill"):
-            key = (self.device.index, int(n), dtype, rows)
-            pool = _RECORD_POOLS.get(key)
-            if pool is None:
-                mine = [k for k in _RECORD_POOLS if k[0] == self.device.index]
-                if len(mine) >= 2:        # a third shape: the oldest pool (and its arenas) goes
-                    _RECORD_POOLS.pop(mine[0])
-                pool = _RECORD_POOLS[key] = RecordPool(self, n, dtype, rows, slots)
+        pool = self._pool_for(n, dtype, rows, rows * 8 * stride * b)
+        if pool is not None:
             block = pool.acquire()
             if block is not None:
                 return block

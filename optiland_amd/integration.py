@@ -1171,16 +1171,19 @@ def hip_tracer_of(optic):
 
 
 def _set_record_pool(placed_records):
-    """`placed_records` of enable() / install(): None = leave as is (the environment variable
-    OPTILAND_HIP_PLACED_RECORDS seeds it), False / 0 = off, True = 2 blocks per shape, n = n."""
-    if placed_records is None:
-        env = os.environ.get("OPTILAND_HIP_PLACED_RECORDS")
-        if env is None:
-            return
-        placed_records = int(env)
-    from .engine import HipSystem
+    """`placed_records` of enable() / install(): None = leave as is (the default policy is
+    "auto", seeded by the environment variable OPTILAND_HIP_PLACED_RECORDS = auto | 0 | n);
+    "auto"; False / 0 = off; True = 2 blocks per shape from the first request on; n = n."""
+    from .engine import HipSystem, _default_slots
 
-    HipSystem.enable_record_pool(2 if placed_records is True else int(placed_records))
+    if placed_records is None:
+        if os.environ.get("OPTILAND_HIP_PLACED_RECORDS") is None:
+            return
+        placed_records = _default_slots()
+    if placed_records == "auto":
+        HipSystem.enable_record_pool("auto")
+    else:
+        HipSystem.enable_record_pool(2 if placed_records is True else int(placed_records))
 
 
 def enable(device=None, force=False, analyses=True, lazy_records=False, placed_records=None):
@@ -1208,13 +1211,14 @@ def enable(device=None, force=False, analyses=True, lazy_records=False, placed_r
     24 planes instead of 8 (S + 2); one that does read the surfaces pays one extra
     record-last launch.  Results are identical either way.
 
-    `placed_records` (default off; True = 2, or a count): record blocks of 256 MB and more come
-    from a pool of PLACED windows (`engine.RecordPool`: where this part writes the record-all
-    pattern 7.1 instead of 5.8 TB/s; a 1e7-ray double-Gauss trace 0.60 instead of 0.73 ms) and
-    go back to it when the caller's last view of the block dies -- as many blocks per shape may
-    be alive at a time, further ones are ordinary allocations.  Costs the arenas behind the
-    windows (~40 GiB per shape on the boxes measured, two shapes kept) and ~0.3 s of probing at
-    the first trace of a shape.
+    `placed_records` (default "auto"; True = 2, a count, or 0 = off): record blocks of 256 MB
+    and more come from a pool of PLACED windows (`engine.RecordPool`: where this part writes the
+    record-all pattern 7.1 instead of 5.8 TB/s; a 1e7-ray double-Gauss trace 0.60 instead of
+    0.73 ms) and go back to it when the caller's last view of the block dies -- as many blocks
+    per shape may be alive at a time, further ones are ordinary allocations.  Costs the arenas
+    behind the windows (~40 GiB per shape on the boxes measured, the two most recently used
+    shapes kept) and ~0.3 s of probing.  "auto" builds the pool at the SECOND trace of a shape
+    (a loop, not a one-off) and only while at least half of the device memory is free.
     """
     _set_record_pool(placed_records)
     cls = _make_tracer_class()
@@ -1274,7 +1278,7 @@ def disable():
         _remove_lazy_prt()
         from .engine import HipSystem
 
-        HipSystem.enable_record_pool(0)
+        HipSystem.reset_record_pool()
 
 
 def install(optic, device=None, force=False, analyses=True, lazy_records=False,

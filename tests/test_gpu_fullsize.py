@@ -578,7 +578,8 @@ def test_placed_record_block_is_a_plain_record_block(dg):
 
 
 def test_record_pool_lends_placed_blocks_and_takes_them_back(dg):
-    """`engine.RecordPool` (round 4, opt-in: `integration.enable(placed_records=...)`): record
+    """`engine.RecordPool` (round 4; since round 5 the default for the second trace of a shape,
+    `integration.enable(placed_records="auto")`; here with an explicit count): record
     blocks that are handed to a user come from placed windows and return to the pool when the
     user's LAST view of the block dies; beyond the pool's size, and for small blocks, ordinary
     allocations.  However many windows this box offers (0 ... 2), a trace into a pool block is
@@ -591,10 +592,11 @@ def test_record_pool_lends_placed_blocks_and_takes_them_back(dg):
     px, py = _pupil(n, 59, dtype)
     plain = hip.alloc_record(n, dtype)
     want = hip.trace_generate(px, py, 0, field=(0.0, 0.7), record=plain).record[:, :, :n].clone()
+    E.HipSystem.enable_record_pool(0)      # (pools the default policy built earlier in the run go)
     E.HipSystem.enable_record_pool(2)
     try:
         a, b, c = (hip.alloc_record(n, dtype) for _ in range(3))
-        pool = next(iter(E._RECORD_POOLS.values()))
+        pool = E._RECORD_POOLS[(hip.device.index, n, dtype, hip.num_surfaces)]
         k = pool.info["slots"]
         assert 0 <= k <= 2 and pool.info["probes"] >= 4
         windows = {p for _arena, p in pool.windows}
@@ -625,4 +627,61 @@ def test_record_pool_lends_placed_blocks_and_takes_them_back(dg):
         E.HipSystem.enable_record_pool(0)
         gc.collect()
         torch.cuda.empty_cache()
-    assert not E._RECORD_POOLS
+        assert not E._RECORD_POOLS
+        E.HipSystem.reset_record_pool()
+
+
+def test_auto_pool_waits_for_a_loop_and_an_evicted_pool_outlives_its_leases(dg):
+    """Round 5.  (a) The default policy ("auto"): the FIRST record block of a shape is an
+    ordinary allocation, the second request builds the pool (a loop, not a one-off trace), small
+    blocks never do.  (b) A pool that is evicted (a third shape on the device) while one of its
+    blocks is still in a user's hands: the block stays valid -- the lease holds the arena -- a
+    trace into it is a trace into a plain block, and giving it back afterwards is harmless."""
+    import gc
+
+    from optiland_amd import engine as E
+    hip, table = dg
+    dtype = torch.float32
+    E.HipSystem.reset_record_pool()
+    try:
+        if E._POOL_CONFIG["slots"] == "auto":
+            n = 700_000                                 # 13 x 8 x 2.8 MB = 291 MB >= 256 MB
+            first = hip.alloc_record(n, dtype)
+            assert not E._RECORD_POOLS                  # one-off: no probe, no arena
+            second = hip.alloc_record(n, dtype)
+            free, total = torch.cuda.mem_get_info(hip.device)
+            if free >= total // 2:
+                assert len(E._RECORD_POOLS) == 1
+                pool = next(iter(E._RECORD_POOLS.values()))
+                assert pool.info["slots"] <= 2 and pool.info["arenas"] <= 2
+            assert hip.alloc_record(1000, dtype).numel() and len(E._RECORD_POOLS) <= 1
+            del first, second
+        # (b) explicit count: pools from the first request on
+        E.HipSystem.enable_record_pool(1)
+        shapes = (700_000, 800_000, 900_000)
+        px, py = _pupil(shapes[0], 61, dtype)
+        plain = torch.empty((hip.num_surfaces, 8, hip.record_stride(shapes[0], 4)), dtype=dtype,
+                            device=hip.device)
+        want = hip.trace_generate(px, py, 0, field=(0.0, 0.7), record=plain
+                                  ).record[:, :, :shapes[0]].clone()
+        held = hip.alloc_record(shapes[0], dtype)
+        pool0 = E._RECORD_POOLS[(hip.device.index, shapes[0], dtype, hip.num_surfaces)]
+        lent = bool(pool0.windows) and held.data_ptr() == pool0.windows[0][1]
+        others = [hip.alloc_record(m, dtype) for m in shapes[1:]]   # the third shape evicts pool0
+        assert (hip.device.index, shapes[0], dtype, hip.num_surfaces) not in E._RECORD_POOLS
+        assert len(E._RECORD_POOLS) == 2
+        got = hip.trace_generate(px, py, 0, field=(0.0, 0.7), record=held)
+        assert torch.equal(got.record[:, :, :shapes[0]].nan_to_num(), want.nan_to_num())
+        del got, held                                   # the lease's finaliser: pool0 is gone
+        gc.collect()
+        if lent:
+            assert len(pool0.free) == 1                 # ... and took the window back all the same
+        # the cool-down after the eviction: shape 0 again is served plain, no new pool
+        again = hip.alloc_record(shapes[0], dtype)
+        assert (hip.device.index, shapes[0], dtype, hip.num_surfaces) not in E._RECORD_POOLS
+        del again, others, pool0
+    finally:
+        E.HipSystem.enable_record_pool(0)
+        gc.collect()
+        torch.cuda.empty_cache()
+        E.HipSystem.reset_record_pool()

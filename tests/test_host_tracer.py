@@ -303,10 +303,13 @@ def test_record_pool_window_choice():
 
 def test_record_pool_configuration(monkeypatch):
     """`integration.enable(placed_records=...)` / OPTILAND_HIP_PLACED_RECORDS only set the
-    process-wide pool configuration; on a CPU engine `alloc_record` never consults it."""
+    process-wide pool configuration ("auto" by default since round 5); on a CPU engine
+    `alloc_record` never consults it."""
     from optiland_amd import engine as E
     from optiland_amd import integration as ig
-    assert E._POOL_CONFIG["slots"] == 0
+    monkeypatch.delenv("OPTILAND_HIP_PLACED_RECORDS", raising=False)
+    E.HipSystem.reset_record_pool()
+    assert E._POOL_CONFIG["slots"] == "auto"
     try:
         ig._set_record_pool(True)
         assert E._POOL_CONFIG["slots"] == 2
@@ -317,7 +320,81 @@ def test_record_pool_configuration(monkeypatch):
         monkeypatch.setenv("OPTILAND_HIP_PLACED_RECORDS", "1")
         ig._set_record_pool(None)                      # ... unless the environment says
         assert E._POOL_CONFIG["slots"] == 1
+        monkeypatch.setenv("OPTILAND_HIP_PLACED_RECORDS", "auto")
+        ig._set_record_pool(None)
+        assert E._POOL_CONFIG["slots"] == "auto"
         ig._set_record_pool(False)
         assert E._POOL_CONFIG["slots"] == 0 and not E._RECORD_POOLS
+        ig._set_record_pool("auto")
+        assert E._POOL_CONFIG["slots"] == "auto"
     finally:
+        monkeypatch.delenv("OPTILAND_HIP_PLACED_RECORDS", raising=False)
+        E.HipSystem.reset_record_pool()
+
+
+def test_record_pool_policy_auto_lru_and_cooldown(monkeypatch):
+    """Which shapes get a pool (`HipSystem._pool_for`), on a stand-in that builds no arenas:
+    "auto" waits for the SECOND request of a shape and for spare device memory; the least
+    recently USED shape is evicted; after an eviction the device is served plain for a while
+    (a workload cycling through three shapes does not rebuild a pool per trace); a shape whose
+    probe found no window is not probed again."""
+    import torch
+
+    from optiland_amd import engine as E
+
+    built = []
+
+    class FakePool:
+        def __init__(self, hip, n, dtype, rows, slots, arena_bytes=None, max_arenas=3):
+            built.append((n, slots, arena_bytes, max_arenas))
+            self.windows = []
+
+        def acquire(self):
+            return None
+
+    class Dev:
+        type, index = "cuda", 0
+
+    class Lib:
+        ol_stream_fill = True
+
+    class Sys:
+        device, lib = Dev(), Lib()
+        _pool_for = E.HipSystem._pool_for
+        free = 200 << 30
+
+        def _auto_arena_bytes(self, need):
+            return None if self.free < (144 << 30) else min(max(3 * need, 40 << 30), self.free // 4)
+
+    monkeypatch.setattr(E, "RecordPool", FakePool)
+    monkeypatch.delenv("OPTILAND_HIP_PLACED_RECORDS", raising=False)
+    E.HipSystem.reset_record_pool()
+    hip, f32, big = Sys(), torch.float32, 1 << 30
+    try:
+        assert hip._pool_for(1000, f32, 13, 1 << 20) is None            # small: never
+        assert hip._pool_for(10, f32, 13, big) is None and not built    # first request: plain
+        assert hip._pool_for(10, f32, 13, big) is not None              # second: a pool
+        assert built == [(10, 2, 40 << 30, 2)]
+        assert hip._pool_for(10, f32, 13, big) is not None and len(built) == 1   # (kept, empty)
+        hip.free = 100 << 30                                            # memory is short
+        assert hip._pool_for(11, f32, 13, big) is None
+        assert hip._pool_for(11, f32, 13, big) is None and len(built) == 1
+        hip.free = 200 << 30
+        assert hip._pool_for(11, f32, 13, big) is not None and len(built) == 2
+        hip._pool_for(10, f32, 13, big)                                 # 10 is used again ...
+        hip._pool_for(12, f32, 13, big)
+        assert hip._pool_for(12, f32, 13, big) is not None              # ... so 11 goes
+        assert [k[1] for k in E._RECORD_POOLS] == [10, 12]
+        # cool-down: shape 11 coming back right away is served plain, not re-probed
+        n_built = len(built)
+        for _ in range(5):
+            assert hip._pool_for(11, f32, 13, big) is None
+        assert len(built) == n_built and [k[1] for k in E._RECORD_POOLS] == [10, 12]
+        # an explicit count: from the first request on, three arenas at most
+        E.HipSystem.enable_record_pool(3)
+        assert hip._pool_for(20, f32, 13, big) is not None
+        assert built[-1] == (20, 3, None, 3)
         E.HipSystem.enable_record_pool(0)
+        assert hip._pool_for(20, f32, 13, big) is None and not E._RECORD_POOLS
+    finally:
+        E.HipSystem.reset_record_pool()

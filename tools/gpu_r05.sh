@@ -63,6 +63,11 @@ for leg in "$@"; do
       tail -3 $O/r05_rccl_alone.log ;;
     window_pmc)
       bash tools/gpu_window_pmc.sh > $O/r05_window_pmc.log 2>&1; tail -30 $O/r05_window_pmc.log ;;
+    bench1rank) # the N > 1 launch form with ONE rank: RCCL init, barrier, exchange legs, placement
+      python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
+        bench.py --gpus 1 --force-exchange --steps 20 --warmup 5 --no-cpu-baseline --no-ref-baselines --traffic committed \
+        > $O/r05_bench_1rank_${TAG:-0}.json 2> $O/r05_bench_1rank_${TAG:-0}.err
+      tail -c 1200 $O/r05_bench_1rank_${TAG:-0}.json; tail -3 $O/r05_bench_1rank_${TAG:-0}.err ;;
     bench)
       python bench.py ${BENCH_ARGS:-} > $O/r05_bench_${TAG:-default}.json 2> $O/r05_bench_${TAG:-default}.err
       tail -c 1500 $O/r05_bench_${TAG:-default}.json ;;
