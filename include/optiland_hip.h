@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OL_ABI_VERSION 9
+#define OL_ABI_VERSION 10
 
 /* ---- error codes ------------------------------------------------------- */
 #define OL_OK 0
@@ -508,6 +508,40 @@ int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays,
                   const ol_raygen_params* p, const ol_raygen_inputs* in,
                   double cx, double cy, int32_t wavelength_index,
                   void* const hits[3], double* out7, uint32_t* status, void* stream);
+
+/* ABI 10.  ol_trace_spot for a whole GRID of (field, wavelength) cells in ONE launch: what
+ * SpotDiagram._generate_data / EncircledEnergy._generate_data loop over
+ * (analysis/spot_diagram/core.py:420-438, analysis/encircled_energy.py: fields x wavelengths,
+ * one Optic.trace each) -- every cell traces the SAME pupil planes; the cell is the launch
+ * grid's second dimension, so its field, vignetting factors, wavelength row, centre and
+ * outputs are workgroup-uniform.  A 3 x 3 spot diagram at 6 rings is ~10 us of kernel: nine
+ * launches, nine status read-backs and nine result objects of Python cost 1.3 ms, this 0.1.
+ *   in        px, py planes and flags only (hx / hy / vx / vy planes must be NULL; hx0 ...
+ *             vy0 are ignored: the cells carry them)
+ *   cells     n_cells (<= OL_SPOT_BATCH_MAX_CELLS) of HOST memory
+ *   hits      NULL, or ONE block of n_cells x 3 planes (x, y, intensity of cell c at
+ *             hits + (3 c + k) hits_stride elements), hits_stride >= n_rays
+ *   out8      n_cells x 8 DEVICE doubles, ACCUMULATED (zero them first): per cell the seven
+ *             of ol_trace_spot, element 7 unused
+ * Same refusals as ol_trace_spot.                                                         */
+#define OL_SPOT_BATCH_MAX_CELLS 32
+typedef struct ol_spot_cell {
+  double hx, hy;            /* normalised field of the cell                               */
+  double vx, vy;            /* 1 - vignetting factor at that field                        */
+  double cx, cy;            /* centre the moments are taken about                         */
+  int32_t wavelength_index;
+  int32_t reserved_;
+  /* NULL, or ANOTHER system of the same optic whose refractive-index rows this cell traces with
+   * (wavelength_index then counts in THAT system): a host that keeps one packed table per
+   * wavelength -- the drop-in does -- still gets the whole fields x wavelengths grid in one
+   * launch.  Geometry, apertures and coatings are `sys`'s; the two must have the same number
+   * of surfaces, live on the same device and be unpolarised alike.                        */
+  const ol_system* optics_of;
+} ol_spot_cell;
+int ol_trace_spot_batch(const ol_system* sys, ol_dtype dt, int64_t n_rays,
+                        const ol_raygen_params* p, const ol_raygen_inputs* in,
+                        int32_t n_cells, const ol_spot_cell* cells, void* hits,
+                        int64_t hits_stride, double* out8, uint32_t* status, void* stream);
 
 /* Wavefront OPD against a spherical reference centred on the chief-ray image point
  * (wavefront/strategy.py:163-215 ChiefRayStrategy.

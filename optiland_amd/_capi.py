@@ -86,6 +86,16 @@ class WavefrontParams(C.Structure):
                                           "uy", "half_epd", "wavelength_um", "nx", "ny", "nz")]
 
 
+SPOT_BATCH_MAX_CELLS = 32  # OL_SPOT_BATCH_MAX_CELLS
+
+
+class SpotCell(C.Structure):
+    """ol_spot_cell"""
+    _fields_ = [("hx", C.c_double), ("hy", C.c_double), ("vx", C.c_double), ("vy", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("wavelength_index", C.c_int32),
+                ("reserved_", C.c_int32), ("optics_of", C.c_void_p)]
+
+
 class PolarizationStateC(C.Structure):
     _fields_ = [
         ("is_polarized", C.c_int32),
@@ -125,11 +135,12 @@ EXPORTS = (
     "ol_trace_opd_dev",
     "ol_wavefront_fit",
     "ol_wavefront_opd_fitted",
+    "ol_trace_spot_batch",
 )
 
 F32, F64 = 0, 1
 TUNE_RAYS_PER_THREAD, TUNE_COMPACT, TUNE_FIT_GRID = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 OPD_MOMENTS = 12  # kOpdMoments / ol_trace_opd
 WAVEFRONT_REFERENCE_DOUBLES = 14  # OL_WAVEFRONT_REFERENCE_DOUBLES
 WAVEFRONT_FIT_WORKSPACE_DOUBLES = 32832  # OL_WAVEFRONT_FIT_WORKSPACE_DOUBLES
@@ -240,6 +251,8 @@ def bind(lib, path: str = "?"):
     lib.ol_trace_generate.restype = C.c_int
     lib.ol_trace_generate.argtypes = [vp, C.c_int, i64, vp, vp, i32, vp, i64, C.POINTER(vp), vp,
                                       u32, vp, vp, vp]
+    lib.ol_trace_spot_batch.restype = C.c_int
+    lib.ol_trace_spot_batch.argtypes = [vp, C.c_int, i64, vp, vp, i32, vp, vp, i64, vp, vp, vp]
     lib.ol_pupil_points.restype = C.c_int
     lib.ol_pupil_points.argtypes = [i32, i32, C.c_int, i64, vp, vp, vp, vp, vp]
     lib.ol_math_probe.restype = C.c_int

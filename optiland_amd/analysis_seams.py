@@ -48,7 +48,7 @@ from .packer import UnsupportedSystem
 _ORIG: dict = {}
 STATS = {"spot": 0, "spot_fallback": 0, "ee": 0, "ee_fallback": 0, "opd": 0, "opd_fallback": 0,
          "pupil": 0, "pupil_fallback": 0, "opd_init": 0, "opd_init_fallback": 0,
-         "dist": 0, "dist_fallback": 0, "opd_fit": 0, "opd_fit_fallback": 0}
+         "dist": 0, "dist_fallback": 0, "opd_fit": 0, "opd_fit_fallback": 0, "spot_grid": 0}
 
 
 def _front(optic, wavelength, need_fp64=False):
@@ -120,11 +120,108 @@ def _image_hits(optic, field, wavelength, num_rays, distribution):
 
 def _spot_generate_data(self):
     """analysis/spot_diagram/core.py:420-438: the fields x wavelengths loop -- nothing inside it
-    edits the optic, so its tables are validated once per wavelength (`integration.unchanged`)."""
+    edits the optic, so its tables are validated once per wavelength (`integration.unchanged`).
+    Round 5: the WHOLE grid is one launch (`ol_trace_spot_batch`: the cell is the launch grid's
+    second dimension) and one read-back when every cell is one the fused kernel serves; the
+    reference's own loop -- with the per-cell seam inside it -- otherwise."""
     from . import integration as ig
 
     with ig.unchanged(self.optic):
+        out = None
+        try:
+            out = _spot_grid(self)
+        except UnsupportedSystem:
+            out = None
+        if out is not None:
+            return out
         return _ORIG["spot_data"](self)
+
+
+def _spot_grid(self):
+    """[[SpotData per wavelength] per field] from ONE `ol_trace_spot_batch` launch per device
+    table (normally one), or None when the grid is not one the batch serves: a per-cell method
+    that is not one of this module's seams (a user's subclass), non-scalar fields, a sampler
+    that draws a fresh sample per call ("random": every cell of the reference's loop gets its
+    own draw), a tilted image surface in local coordinates, an optic the fused kernels decline."""
+    per_cell = getattr(type(self), "_generate_field_data", None)
+    if per_cell is _spot_generate_field_data:
+        masked, coordinates = True, self.coordinates
+    elif per_cell is _ee_generate_field_data:
+        masked, coordinates = False, "global"   # encircled_energy.py:193-197: unmasked, global
+    else:
+        return None
+    if "spot_data" not in _ORIG or isinstance(self.distribution, str) and \
+            self.distribution in ("random", "sobol"):
+        return None
+    fields = [(_scalar(fp.coord[0]), _scalar(fp.coord[1])) for fp in self.fields]
+    if not fields or any(hx is None or hy is None for hx, hy in fields):
+        return None
+    wls = [wp.value for wp in self.wavelengths]
+    if not wls:
+        return None
+    main = None      # the front whose geometry the launch reads; the others lend index rows
+    cells, last = [], None
+    for wi, w in enumerate(wls):
+        got = _front(self.optic, w)
+        if got is None:
+            return None
+        front, table = got
+        if not hasattr(front.engine, "trace_spot_batch"):
+            return None
+        s = table.surfaces[-1]
+        if bool(s["flags"] & 1) and coordinates == "local":
+            return None     # tilted image surface: the reference's own transform
+        if main is None:
+            main = (front, table)
+        elif front.dtype != main[0].dtype or table.num_surfaces != main[1].num_surfaces:
+            return None
+        wl, wv = front._wavelength_index(w)
+        for fi, (hx, hy) in enumerate(fields):
+            front._validate_normalized_coordinates(hx, hy, "field")
+            vx, vy = front._vig_scalar(hx, hy)
+            cells.append((fi, wi, (hx, hy, vx, vy, 0.0, 0.0, wl, front.engine), wv, front, table))
+    from optiland.analysis.spot_diagram.core import SpotData
+
+    data = [[None] * len(wls) for _ in fields]
+    front, table = main
+    px, py = front._pupil_planes(_dist_arg(self.distribution), self.num_rings)
+    n = int(px.numel())
+    mom, hits = front.engine.trace_spot_batch(px, py, [c[2] for c in cells], hits=True)
+    counts = mom[:, 0].cpu().numpy().astype(np.int64)   # the ONE read-back of the grid
+    xs, ys, ins = hits[:, 0, :n], hits[:, 1, :n], hits[:, 2, :n]
+    clipped = masked and bool((counts != n).any())
+    if clipped:
+        # core.py:470-473 (ignore rays with zero intensity) for ALL cells at once: one
+        # `nonzero` over the (cells, n) mask -- cell-major, so every cell's survivors are one
+        # contiguous run of `counts[k]` entries -- and three gathers
+        sel = (ins > 0).reshape(-1).nonzero().reshape(-1)
+        gx, gy, gi = (t.reshape(-1)[sel] for t in (xs, ys, ins))
+        ends = np.cumsum(counts)
+    s = table.surfaces[-1]
+    ox, oy = float(s["origin"][0]), float(s["origin"][1])
+    for k, (fi, wi, cell, wv, fr, tb) in enumerate(cells):
+        if clipped:
+            lo, hi = int(ends[k] - counts[k]), int(ends[k])
+            x, y, inten = gx[lo:hi], gy[lo:hi], gi[lo:hi]
+        else:
+            x, y, inten = xs[k], ys[k], ins[k]
+        if coordinates == "local":
+            # visualization/system/utils.py:17-47 with an untilted image surface:
+            # localize = translate by the (folded) origin
+            if ox != 0.0:
+                x = x - ox
+            if oy != 0.0:
+                y = y - oy
+        data[fi][wi] = SpotData(x=x, y=y, intensity=inten)
+        STATS["spot" if masked else "ee"] += 1
+        if fi == len(fields) - 1 and wi == len(wls) - 1:
+            last = (fr, tb, (cell[0], cell[1], px, py, (cell[2], cell[3]), wv, 0))
+    STATS["spot_grid"] += 1
+    if last is not None:
+        # what the LAST Optic.trace() of the reference's loop would have left on the Surface
+        # objects, produced on first read
+        _register(self.optic, last[0], last[1], last[2])
+    return data
 
 
 def _wavefront_generate_data(self):

@@ -564,6 +564,63 @@ int do_trace_spot(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
 }
 
 template <typename T>
+const DeviceTable<T>& table_of(const ol_system* sys);
+template <>
+const DeviceTable<float>& table_of<float>(const ol_system* sys) { return sys->f32; }
+template <>
+const DeviceTable<double>& table_of<double>(const ol_system* sys) { return sys->f64; }
+
+template <typename T>
+int do_trace_spot_batch(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
+                        const ol_raygen_params* p, const ol_raygen_inputs* in, int32_t n_cells,
+                        const ol_spot_cell* cells, void* hits, int64_t hits_stride, double* out8,
+                        uint32_t* status, hipStream_t stream) {
+  ol::SpotArgs<T> a{};
+  bool vec = true;
+  if (int rc = convert_inputs<T>("ol_trace_spot_batch", in, status, a.in, vec)) return rc;
+  if (n == 0 || n_cells == 0) return OL_OK;
+  a.surf = tab.surf;
+  a.cold = tab.cold;
+  a.optics = tab.optics;
+  a.coeffs = tab.coeffs;
+  a.rg = raygen_dev(p);
+  T* hb = static_cast<T*>(hits);
+  for (int k = 0; k < 3; ++k) a.hits[k] = hb ? hb + k * hits_stride : nullptr;
+  // every cell's planes must keep the 16-byte alignment the vector stores need
+  vec = vec && aligned16(hb) && (hits_stride * (int64_t)sizeof(T)) % 16 == 0;
+  a.out = out8;
+  a.status = status;
+  a.n = n;
+  a.first = 0;
+  a.last = sys->n_surf - 1;
+  a.n_wl = sys->n_wl;
+  a.wl = 0;
+  a.tiles_per_block = 1;
+  ol::SpotBatch<T> b{};
+  b.n_cells = n_cells;
+  b.hits_stride = hits_stride;
+  for (int c = 0; c < n_cells; ++c) {
+    ol::RaygenIn<T> f = a.in;   // the launch-uniform field of this cell -> its tangents
+    f.hx0 = (T)cells[c].hx;
+    f.hy0 = (T)cells[c].hy;
+    ol::uniform_field_tangents<T>(a.rg, f);
+    b.c[c].tx = f.tx0;
+    b.c[c].ty = f.ty0;
+    b.c[c].vx = (T)cells[c].vx;
+    b.c[c].vy = (T)cells[c].vy;
+    b.c[c].cx = cells[c].cx;
+    b.c[c].cy = cells[c].cy;
+    b.c[c].wl = cells[c].wavelength_index;
+    const ol_system* from = cells[c].optics_of ? cells[c].optics_of : sys;
+    b.c[c].optics = table_of<T>(from).optics;
+    b.c[c].n_wl = from->n_wl;
+  }
+  hipError_t e = ol::launch_spot_batch<T>(a, b, vec, newton_family(sys, 0, sys->n_surf - 1), stream);
+  if (e != hipSuccess) return fail(OL_EHIP, "spot batch launch failed: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
+template <typename T>
 int do_wavefront_reference(const ol_system* sys, const DeviceTable<T>& tab,
                            const ol_raygen_params* p, const ol_raygen_inputs* in,
                            const ol_wavefront_params* w, double pupil_z, int32_t planar,
@@ -1140,6 +1197,64 @@ int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_ra
                                 out7, status, st);
   return do_trace_spot<double>(sys, sys->f64, n_rays, p, in, cx, cy, wavelength_index, hits,
                                out7, status, st);
+}
+
+int ol_trace_spot_batch(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_raygen_params* p,
+                        const ol_raygen_inputs* in, int32_t n_cells, const ol_spot_cell* cells,
+                        void* hits, int64_t hits_stride, double* out8, uint32_t* status,
+                        void* stream) {
+  if (!sys) return fail(OL_EINVAL, "ol_trace_spot_batch: system is NULL");
+  OL_CHECK_CONSISTENT(sys, "ol_trace_spot_batch");
+  if (dt != OL_F32 && dt != OL_F64)
+    return fail(OL_EINVAL, "ol_trace_spot_batch: bad dtype %d", (int)dt);
+  if (!p || !in || !out8 || (n_cells > 0 && !cells))
+    return fail(OL_EINVAL, "ol_trace_spot_batch: NULL argument");
+  if (n_rays < 0) return fail(OL_EINVAL, "ol_trace_spot_batch: negative ray count");
+  if (n_cells < 0 || n_cells > OL_SPOT_BATCH_MAX_CELLS)
+    return fail(OL_EINVAL, "ol_trace_spot_batch: %d cells outside [0, %d]", n_cells,
+                OL_SPOT_BATCH_MAX_CELLS);
+  if (in->hx || in->hy || in->vx || in->vy)
+    return fail(OL_EINVAL, "ol_trace_spot_batch: per-ray field / vignetting planes with cells "
+                           "(each cell has ONE field point)");
+  if (hits && hits_stride < n_rays)
+    return fail(OL_EINVAL, "ol_trace_spot_batch: hits_stride %lld < %lld rays",
+                (long long)hits_stride, (long long)n_rays);
+  for (int32_t c = 0; c < n_cells; ++c) {
+    const ol_system* from = cells[c].optics_of ? cells[c].optics_of : sys;
+    if (from != sys) {
+      OL_CHECK_CONSISTENT(from, "ol_trace_spot_batch (optics_of)");
+      if (from->n_surf != sys->n_surf || from->device != sys->device)
+        return fail(OL_EINVAL, "ol_trace_spot_batch: cell %d: optics_of has %d surfaces on device "
+                               "%d, the system %d on device %d", c, from->n_surf, from->device,
+                    sys->n_surf, sys->device);
+    }
+    if (cells[c].wavelength_index < 0 || cells[c].wavelength_index >= from->n_wl)
+      return fail(OL_EINVAL, "ol_trace_spot_batch: cell %d: wavelength index %d outside [0, %d)",
+                  c, cells[c].wavelength_index, from->n_wl);
+    if (in->flags & OL_RAYGEN_CHECK_FIELD) {
+      auto bad = [](double v) { return !(v >= -1.0 && v <= 1.0); };
+      if (bad(cells[c].hx) || bad(cells[c].hy))  // real_ray_tracer.py:156-173, same text
+        return fail(OL_EINVAL, "Normalized field coordinates must be within (-1, 1)");
+    }
+  }
+  for (int32_t s = 0; s < sys->n_surf; ++s)
+    if (sys->coating[s] >= OL_COAT_FRESNEL)
+      return fail(OL_EINVAL,
+                  "Polarization must be set when surfaces have polarization-dependent "
+                  "coatings.");
+  if (n_rays > 0 && n_cells > 0) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != sys->device)
+      return fail(OL_EINVAL,
+                  "ol_trace_spot_batch: current HIP device %d is not the system's device %d", cur,
+                  sys->device);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dt == OL_F32)
+    return do_trace_spot_batch<float>(sys, sys->f32, n_rays, p, in, n_cells, cells, hits,
+                                      hits_stride, out8, status, st);
+  return do_trace_spot_batch<double>(sys, sys->f64, n_rays, p, in, n_cells, cells, hits,
+                                     hits_stride, out8, status, st);
 }
 
 int ol_irradiance(ol_dtype dt, int64_t n_rays, const void* x, const void* y, const void* power,

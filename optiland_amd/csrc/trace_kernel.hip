@@ -405,12 +405,13 @@ __device__ __forceinline__ SurfFetched<T> fetched_surface(int s) {
   return SurfFetched<T>{as_const(ka->surf) + s, as_const(ka->cold) + s,
                         as_const(ka->optics) + (s * ka->a.n_wl + ka->a.wl)};
 }
-// ... for an explicit wavelength slot (the batched spot kernel: one per cell)
+// ... for an explicit optics table and wavelength slot (the batched spot kernel: per cell)
 template <typename T, typename A>
-__device__ __forceinline__ SurfFetched<T> fetched_surface_wl(int s, int wl) {
+__device__ __forceinline__ SurfFetched<T> fetched_surface_of(int s, const DevOptics<T>* optics,
+                                                             int n_wl, int wl) {
   const auto ka = kernargs<T, A>();
   return SurfFetched<T>{as_const(ka->surf) + s, as_const(ka->cold) + s,
-                        as_const(ka->optics) + (s * ka->a.n_wl + wl)};
+                        as_const(optics) + (s * n_wl + wl)};
 }
 #ifndef OL_POLNR_WAVES_F64
 #define OL_POLNR_WAVES_F64 0
@@ -1180,7 +1181,9 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
       for (int s = first; s <= kernargs<T, SpotArgs<T>>()->a.last; ++s) {
         const SurfFetched<T> h = [&](int s_) {
           if constexpr (BATCH)
-            return fetched_surface_wl<T, SpotArgs<T>>(s_, batch.c[blockIdx.y].wl);
+            return fetched_surface_of<T, SpotArgs<T>>(s_, batch.c[blockIdx.y].optics,
+                                                      batch.c[blockIdx.y].n_wl,
+                                                      batch.c[blockIdx.y].wl);
           else
             return fetched_surface<T, SpotArgs<T>>(s_);
         }(s);
@@ -1208,9 +1211,13 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
         }
         S.cold = as_const(cold_tab) + s;
         if (S.interaction != kRecordOnly) {
-          int wl_ = a.wl;
-          if constexpr (BATCH) wl_ = batch.c[blockIdx.y].wl;
-          const DevOptics<T> O = optics_tab[s * a.n_wl + wl_];
+          DevOptics<T> O;
+          if constexpr (BATCH) {
+            const SpotCell<T>& cell = batch.c[blockIdx.y];
+            O = cell.optics[s * cell.n_wl + cell.wl];
+          } else {
+            O = optics_tab[s * a.n_wl + a.wl];
+          }
           surface_step<V, NV, 0, NR>(S, O, as_const(coeff_tab), is_global, r, P, status,
                                      prt_fresh);
           is_global = false;

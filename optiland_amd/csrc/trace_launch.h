@@ -212,7 +212,8 @@ template <typename T>
 struct SpotCell {
   T tx, ty, vx, vy;   // field tangents (uniform_field_tangents), vignetting factors
   double cx, cy;
-  int32_t wl, pad_;
+  const DevOptics<T>* optics;   // the optics table this cell reads (a.optics unless the cell
+  int32_t n_wl, wl;             // brings another system's) and its wavelength slot in it
 };
 template <typename T>
 struct SpotBatch {

@@ -1112,6 +1112,53 @@ class HipSystem:
             self.raise_for_status(int(self._status.item()))
         return out
 
+    def trace_spot_batch(self, px, py, cells, *, hits: bool = False, out=None,
+                         check_status: bool = True, flags: int = 0):
+        """A grid of fused spots in ONE launch (`ol_trace_spot_batch`, ABI 10): `cells` is a
+        sequence of (Hx, Hy, vig_x, vig_y, cx, cy, wavelength index[, engine]); every cell
+        traces the same pupil planes.  `engine`: another `HipSystem` of the SAME optic (one
+        packed table per wavelength, as the drop-in keeps them) whose index rows the cell reads.  Returns (moments, hits): moments a (cells, 8) float64 device tensor (per
+        cell the seven of `trace_spot`; `out`, if given, is accumulated into), hits None or a
+        (cells, 3, stride) block of the image-plane x, y, intensity (use `[..., :n]`).  More
+        cells than one launch takes (32) go out as several launches; the status word is read
+        back ONCE."""
+        p = self._raygen_params()
+        n, dtype = int(px.numel()), px.dtype
+        cells = list(cells)
+        k = len(cells)
+        if out is None:
+            out = torch.zeros((k, 8), dtype=torch.float64, device=self.device)
+        elif out.shape != (k, 8) or out.dtype != torch.float64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous (cells, 8) float64 tensor")
+        hb = None
+        stride = 0
+        if hits:
+            b = px.element_size()
+            stride = (n + 16 // b - 1) // (16 // b) * (16 // b)   # planes stay 16-byte aligned
+            hb = torch.empty((k, 3, max(stride, 1)), dtype=dtype, device=self.device)
+        if n == 0 or k == 0:
+            return out, hb
+        inp, keep = self._raygen_inputs(0.0, 0.0, px, py, 1.0, 1.0, flags)
+        if check_status:
+            self._status.zero_()
+        step = _capi.SPOT_BATCH_MAX_CELLS
+        with self._device_ctx():
+            for lo in range(0, k, step):
+                part = cells[lo: lo + step]
+                arr = (_capi.SpotCell * len(part))(*[
+                    _capi.SpotCell(float(c[0]), float(c[1]), float(c[2]), float(c[3]), float(c[4]),
+                                   float(c[5]), int(c[6]), 0,
+                                   c[7]._handle if len(c) > 7 and c[7] is not None
+                                   and c[7] is not self else None) for c in part])
+                rc = self.lib.ol_trace_spot_batch(
+                    self._handle, _DT[dtype], n, C.byref(p), C.byref(inp), len(part), arr,
+                    hb[lo].data_ptr() if hb is not None else None, stride, out[lo].data_ptr(),
+                    self._status.data_ptr(), self._stream())
+                self._check(rc, "ol_trace_spot_batch")
+        if check_status:
+            self.raise_for_status(int(self._status.item()))
+        return out, hb
+
     def spot_moments(self, x, y, intensity, out=None):
         """Device reduction: returns float64 tensor [count, sx, sy, sxx, syy, count]
         (`out`: optional preallocated 6-element float64 tensor, zeroed here)."""

@@ -541,9 +541,16 @@ Ray<T> fused_trace_family(int family, const DevSurfHot<T>* surf, const DevSurfCo
 // spot_trace_kernel + launch_spot_trace (trace_kernel.hip), ray by ray; the sums are
 // formed in ray order (the device adds wave / workgroup partials: equal to rounding)
 template <typename T>
+static hipError_t launch_spot_cell(const SpotArgs<T>& a, int nr_family);
+template <typename T>
 hipError_t launch_spot_trace(const SpotArgs<T>& a_in, bool, int nr_family, hipStream_t) {
   SpotArgs<T> a = a_in;
   if (a.in.hx == nullptr) uniform_field_tangents<T>(a.rg, a.in);
+  return launch_spot_cell<T>(a, nr_family);
+}
+// one (field, wavelength) cell; the launch-uniform tangents are in a.in.tx0 / ty0 already
+template <typename T>
+static hipError_t launch_spot_cell(const SpotArgs<T>& a, int nr_family) {
   const RaygenConsts<T> c(a.rg);
   const RaygenIn<T>& in_ = a.in;
   const bool field_planes = in_.hx != nullptr, vig_planes = in_.vx != nullptr;
@@ -581,6 +588,36 @@ hipError_t launch_spot_trace(const SpotArgs<T>& a_in, bool, int nr_family, hipSt
 }
 template hipError_t launch_spot_trace<float>(const SpotArgs<float>&, bool, int, hipStream_t);
 template hipError_t launch_spot_trace<double>(const SpotArgs<double>&, bool, int, hipStream_t);
+
+// launch_spot_batch (trace_kernel.hip: blockIdx.y = cell): cell by cell through the single-cell
+// launch above, with what the cell changes put where that launch reads it
+template <typename T>
+hipError_t launch_spot_batch(const SpotArgs<T>& a_in, const SpotBatch<T>& b, bool vec, int nr_family,
+                             hipStream_t st) {
+  for (int c = 0; c < b.n_cells; ++c) {
+    SpotArgs<T> a = a_in;
+    a.in.vx0 = b.c[c].vx;
+    a.in.vy0 = b.c[c].vy;
+    a.in.tx0 = b.c[c].tx;
+    a.in.ty0 = b.c[c].ty;
+    a.cx = b.c[c].cx;
+    a.cy = b.c[c].cy;
+    a.wl = b.c[c].wl;
+    a.optics = b.c[c].optics;
+    a.n_wl = b.c[c].n_wl;
+    for (int k = 0; k < 3; ++k)
+      if (a.hits[k]) a.hits[k] += (int64_t)c * 3 * b.hits_stride;
+    a.out = a_in.out + 8 * c;
+    hipError_t e = launch_spot_cell<T>(a, nr_family);
+    if (e != hipSuccess) return e;
+  }
+  (void)vec; (void)st;
+  return hipSuccess;
+}
+template hipError_t launch_spot_batch<float>(const SpotArgs<float>&, const SpotBatch<float>&, bool,
+                                             int, hipStream_t);
+template hipError_t launch_spot_batch<double>(const SpotArgs<double>&, const SpotBatch<double>&,
+                                              bool, int, hipStream_t);
 
 // opd_trace_kernel + launch_opd_trace (trace_kernel.hip), ray by ray
 template <typename T>

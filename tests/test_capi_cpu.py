@@ -41,7 +41,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.ol_abi_version() == _capi.ABI_VERSION == 9
+    assert lib.ol_abi_version() == _capi.ABI_VERSION == 10
 
 
 def test_struct_layouts_agree_with_the_c_compiler():
@@ -108,6 +108,9 @@ def test_argument_validation_without_a_device(lib):
     rc = lib.ol_spot_moments(0, 4, None, None, None, None, None)
     assert rc == -1
     rc = lib.ol_trace_spot(None, 0, 4, None, None, 0.0, 0.0, 0, None, None, None, None)
+    assert rc == -1 and b"system is NULL" in lib.ol_last_error()
+    # ABI 10: the batched spot refuses before it touches a device
+    rc = lib.ol_trace_spot_batch(None, 0, 4, None, None, 1, None, None, 0, None, None, None)
     assert rc == -1 and b"system is NULL" in lib.ol_last_error()
     assert lib.ol_system_num_surfaces(None) == 0
     lib.ol_system_destroy(None)  # no-op

@@ -429,6 +429,9 @@ def test_spot_diagram_and_encircled_energy_through_the_fused_seam_on_device(be, 
         lens = _live.build_system(name)[0]
         got = run(lens)
         assert stats["spot"] > 0 and stats["spot_fallback"] == 0 and stats["ee"] > 0
+        # round 5: each of the two grids (fields x wavelengths, one packed table per
+        # wavelength) was ONE `ol_trace_spot_batch` launch
+        assert stats["spot_grid"] == 2
         scale = max(size, max(np.abs(x).max() for f in want[3] for (x, _, _) in f))
         tol = TOL[precision]
         bad = []

@@ -298,3 +298,42 @@ def test_fused_spot_field_kinds_and_apodization(case, field, dtype):
             np.testing.assert_allclose(got[1:3] / nrm, want[1:3] / nrm, atol=2e-5 * sc)
     finally:
         hip.close()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("n", [1, 37, 1025, 200_003])
+def test_spot_batch_equals_single_launches(system, dtype, n):
+    """`ol_trace_spot_batch` (ABI 10: blockIdx.y = (field, wavelength) cell) against one
+    `ol_trace_spot` per cell: the hits bit for bit (the same per-ray arithmetic), the counts
+    exactly, the sums to the rounding of a different summation order; more cells than one
+    launch takes (32) and every wavelength row of the table."""
+    hip, table, wl0, field = system
+    px, py = _pupil(n, 7 + n, dtype)
+    rng = np.random.default_rng(5)
+    n_wl = int(table.optics.shape[1]) if table.optics.ndim > 1 else 1
+    cells = []
+    for k in range(35):
+        hx, hy = (0.0, 0.0) if k == 0 else tuple(rng.uniform(-1, 1, 2) * field[1])
+        cells.append((hx, hy, 1.0 - 0.1 * (k % 3), 1.0 - 0.05 * (k % 2), rng.normal(), rng.normal(),
+                      k % n_wl))
+    mom, hits = hip.trace_spot_batch(px, py, cells, hits=True)
+    assert mom.shape == (35, 8) and hits.shape[:2] == (35, 3)
+    mom = mom.cpu().numpy()
+    for k, (hx, hy, vx, vy, cx, cy, wl) in enumerate(cells):
+        one = [torch.empty(n, dtype=dtype, device=DEV) for _ in range(3)]
+        want = hip.trace_spot(px, py, wl, field=(hx, hy), vig=(vx, vy), center=(cx, cy),
+                              hits=one).cpu().numpy()
+        for q in range(3):
+            assert torch.equal(hits[k, q, :n].nan_to_num(), one[q].nan_to_num()), (k, q)
+        assert mom[k, 0] == want[0]
+        np.testing.assert_allclose(mom[k, 1:6], want[1:6], rtol=1e-9 if dtype == torch.float64
+                                   else 1e-6, atol=1e-9 * max(n, 1))
+        assert mom[k, 6] == want[6]                   # a maximum: no rounding
+    # accumulation into a caller's block, no hits, empty cell list
+    again, none = hip.trace_spot_batch(px, py, cells[:3], out=torch.zeros((3, 8), dtype=torch.float64,
+                                                                            device=DEV))
+    assert none is None
+    np.testing.assert_allclose(again.cpu().numpy()[:, :6], mom[:3, :6], rtol=1e-9 if
+                               dtype == torch.float64 else 1e-6, atol=1e-9 * max(n, 1))
+    empty, _ = hip.trace_spot_batch(px, py, [])
+    assert empty.shape == (0, 8)

@@ -69,7 +69,7 @@ def _singlet_asphere():
 
 @pytest.mark.parametrize("build", [_cooke, _singlet_asphere])
 @pytest.mark.parametrize("reference", ["chief_ray", "centroid"])
-def test_spot_diagram_through_the_fused_seam(seams, build, reference):
+def test_spot_diagram_through_the_fused_seam(seams, build, reference, request):
     be, stats = seams
     from optiland import analysis
 
@@ -83,6 +83,10 @@ def test_spot_diagram_through_the_fused_seam(seams, build, reference):
     want = _numpy_reference(be, build, run)
     got = run(build())
     assert stats["spot"] > 0 and stats["spot_fallback"] == 0
+    if "kernel-source" in request.node.name:
+        # round 5: the whole fields x wavelengths grid is ONE `ol_trace_spot_batch` launch (the
+        # oracle-backed stand-in has no such entry point and keeps the per-cell seam)
+        assert stats["spot_grid"] >= 1
     for fg, fw in zip(got[0], want[0]):
         for (x, y, i), (xw, yw, iw) in zip(fg, fw):
             assert x.shape == xw.shape
@@ -97,6 +101,44 @@ def test_spot_diagram_through_the_fused_seam(seams, build, reference):
     got_g = run(build(), "global")
     np.testing.assert_allclose(got_g[1], want_g[1], rtol=1e-7)
     np.testing.assert_allclose(got_g[3], want_g[3], rtol=0, atol=1e-8)
+
+
+def test_spot_grid_equals_the_per_cell_seam(seams, request, monkeypatch):
+    """`_spot_generate_data` as ONE batched launch against the same seam cell by cell (the batch
+    switched off): the same `SpotData`, bit for bit, for a spot diagram in local and global
+    coordinates and for an encircled energy (whose cells are unmasked and global); "random"
+    pupils -- a fresh draw per cell in the reference's loop -- keep the per-cell path; and what
+    `Optic.trace` would have left on the surfaces is the LAST cell's trace."""
+    if "kernel-source" not in request.node.name:
+        pytest.skip("the oracle-backed stand-in has no ol_trace_spot_batch")
+    be, stats = seams
+    from optiland import analysis
+    from optiland_amd import analysis_seams
+
+    def run(lens, cls, **kw):
+        a = cls(lens, **kw)
+        out = [[(_np(be, d.x), _np(be, d.y), _np(be, d.intensity)) for d in f] for f in a.data]
+        return out, _np(be, lens.surfaces.y)[-1]
+
+    for cls, kw in ((analysis.SpotDiagram, dict(num_rings=4, coordinates="local")),
+                    (analysis.SpotDiagram, dict(num_rings=4, coordinates="global")),
+                    (analysis.EncircledEnergy, dict(num_rays=5, distribution="hexapolar",
+                                                    num_points=16))):
+        n0 = stats["spot_grid"]
+        got, last_y = run(_cooke(), cls, **kw)
+        assert stats["spot_grid"] == n0 + 1
+        with monkeypatch.context() as m:
+            m.setattr(analysis_seams, "_spot_grid", lambda self: None)
+            want, last_y_w = run(_cooke(), cls, **kw)
+        assert stats["spot_grid"] == n0 + 1
+        for fg, fw in zip(got, want):
+            for a, b in zip(fg, fw):
+                for u, v in zip(a, b):
+                    np.testing.assert_array_equal(u, v)
+        np.testing.assert_array_equal(last_y, last_y_w)
+    n0 = stats["spot_grid"]
+    analysis.SpotDiagram(_cooke(), num_rings=50, distribution="random")
+    assert stats["spot_grid"] == n0
 
 
 def test_spot_seam_masks_clipped_rays_like_the_reference(seams):

@@ -63,6 +63,8 @@ for leg in "$@"; do
       tail -3 $O/r05_rccl_alone.log ;;
     window_pmc)
       bash tools/gpu_window_pmc.sh > $O/r05_window_pmc.log 2>&1; tail -30 $O/r05_window_pmc.log ;;
+    spotdiag)  # the reference's SpotDiagram through the seams: one launch per grid vs per cell
+      timeout 600 python tools/gpu_r05_spotdiag.py > $O/r05_spotdiag.txt 2>&1; tail -5 $O/r05_spotdiag.txt | cut -c1-600 ;;
     bench1rank) # the N > 1 launch form with ONE rank: RCCL init, barrier, exchange legs, placement
       python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
         bench.py --gpus 1 --force-exchange --steps 20 --warmup 5 --no-cpu-baseline --no-ref-baselines --traffic committed \
