@@ -388,9 +388,10 @@ int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n,
  *             Py[]) and the fields x pupil expansion of a multi-field trace
  *             (real_ray_tracer.py:88-98, 120-154) -- and apodized pupils (p->apod_kind: the
  *             initial intensity is the apodization, ray_generator.py:81-85) are ONE launch
- *             too.  Polarised launches with either are refused with OL_EUNSUPPORTED
- *             (callers take ol_generate_rays + ol_trace for those), as are vx, vy planes
- *             without hx, hy
+ *             too -- since ABI 10 also for POLARISED launches (prt != NULL, with or without the
+ *             update_intensity epilogue, whose initial intensity is then the apodization:
+ *             rays/polarized_rays.py:51).  vx, vy planes without hx, hy are refused with
+ *             OL_EUNSUPPORTED
  *   record    required; rows as in ol_trace (row 0 = the generated rays unless
  *             extras->record_first_surface says otherwise)
  *   rays_out  NULL, or 8 planes receiving the final state (what OL_TRACE_WRITE_RAYS writes)

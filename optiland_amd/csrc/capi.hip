@@ -1100,12 +1100,7 @@ int ol_trace_generate(const ol_system* sys, ol_dtype dt, int64_t n_rays,
   if ((in->vx || in->vy) && !(in->hx && in->hy))
     return fail(OL_EUNSUPPORTED, "ol_trace_generate: per-ray vignetting planes come with "
                                  "per-ray field planes (else ol_generate_rays + ol_trace)");
-  if (prt && (in->hx || in->hy))
-    return fail(OL_EUNSUPPORTED, "ol_trace_generate: a polarised launch is one field point "
-                                 "(per-ray field planes take ol_generate_rays + ol_trace)");
-  if (prt && p->apod_kind != OL_APOD_NONE)
-    return fail(OL_EUNSUPPORTED, "ol_trace_generate: a polarised launch with an apodized pupil "
-                                 "takes ol_generate_rays + ol_trace");
+  // (ABI 10: polarised launches take per-ray field planes and apodized pupils too)
   if (extras && extras->spot_slots) {
     if (prt)
       return fail(OL_EINVAL, "ol_trace_generate: the spot epilogue is for unpolarised traces "

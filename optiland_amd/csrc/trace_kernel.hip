@@ -506,23 +506,31 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
     static_assert(RPT == 1 || (RPT == 2 && GEN == kGenUniform && POLK == 0 && NR == 0 &&
                                sizeof(T) == 4),
                   "the generating prologue: one ray per lane, or the lean fp32 pair");
+    // POLARISED generating launches (round 5): ONE form, GEN == kGenUniform, that takes per-ray
+    // field planes and an apodized pupil at RUN time (launch-uniform branches) -- the
+    // prologue is nowhere near the register peak of a kernel that carries a PRT matrix through
+    // the surface loop, so the split that protects the lean kernels' budget buys nothing here
+    // and would double the polarised instantiations.
     static_assert(GEN == kGenUniform || POLK == 0,
-                  "per-ray field planes / apodized pupils: unpolarised launches");
+                  "polarised launches: the run-time general form (GEN == kGenUniform)");
+    constexpr bool kGeneral = POLK != 0;
     const auto A0 = arg_view<(fetch_level<T, NR, false, POLK>() >= 1), T>(a);
     const auto& in_ = A0->in;
     // (same order of operations as raygen_kernel, aux_kernels.hip: the two-launch path and
     // this prologue produce the same bits)
     T tx = in_.tx0, ty = in_.ty0, vx = in_.vx0, vy = in_.vy0, o[6];
     const RaygenConsts<T> c = consts_of(&A0->rgc);
-    if constexpr ((GEN & kGenFieldPlanes) != 0) {
-      const T hx = base.at(in_.hx)[0], hy = base.at(in_.hy)[0];
-      if (in_.vx != nullptr) {  // launch-uniform
-        vx = base.at(in_.vx)[0];
-        vy = base.at(in_.vy)[0];
+    if constexpr ((GEN & kGenFieldPlanes) != 0 || kGeneral) {
+      if (!kGeneral || in_.hx != nullptr) {  // (kGeneral: launch-uniform)
+        const T hx = base.at(in_.hx)[0], hy = base.at(in_.hy)[0];
+        if (in_.vx != nullptr) {  // launch-uniform
+          vx = base.at(in_.vx)[0];
+          vy = base.at(in_.vy)[0];
+        }
+        if ((in_.flags & kRaygenCheckField) && (outside_unit(hx) || outside_unit(hy)))
+          status |= kStatusFieldRange;
+        raygen_field<T>(c, hx, hy, tx, ty);
       }
-      if ((in_.flags & kRaygenCheckField) && (outside_unit(hx) || outside_unit(hy)))
-        status |= kStatusFieldRange;
-      raygen_field<T>(c, hx, hy, tx, ty);
     }
     T pxs[RPT], pys[RPT];
     if constexpr (RPT == 1) {
@@ -554,7 +562,9 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
       Ray<T> q;
       q.x = o[0]; q.y = o[1]; q.z = o[2];
       q.L = o[3]; q.M = o[4]; q.N = o[5];
-      if constexpr ((GEN & kGenApod) != 0) q.i = raygen_apodize<T>(c, px, py); else q.i = T(1);
+      // (raygen_apodize returns 1 for apod_kind == 0: a launch-uniform branch)
+      if constexpr ((GEN & kGenApod) != 0 || kGeneral) q.i = raygen_apodize<T>(c, px, py);
+      else q.i = T(1);
       q.opd = T(0);
       LP::put(r, k, q);
     }
@@ -796,19 +806,29 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
     // PolarizedRays.update_intensity (rays/polarized_rays.py:68-133) of the traced bundle, from
     // the matrix still in registers (ol_trace_extras.updated_intensity, ABI 7) -- instead of a
     // second launch that reads nine PRT planes, three direction planes and the intensity
-    // plane back.  The launch direction is GENERATED again from the two pupil values (the
-    // same arithmetic on the same inputs: the same bits as row 0) rather than kept live
-    // through the surface loop; the initial intensity of a generated ray is 1.
+    // plane back.  The launch direction is GENERATED again from the pupil (and, when the launch
+    // has them, field) values (the same arithmetic on the same inputs: the same bits as row 0)
+    // rather than kept live through the surface loop; so is the initial intensity `_i0` -- 1,
+    // or the apodization of the pupil point (polarized_rays.py:51, ray_generator.py:81-85).
     const auto ka = kernargs<T, TraceArgs<T>>();
     T* upd = ka->a.i_updated;
     {
       const auto& in_ = ka->a.in;
       T px = base.at(in_.px)[0], py = base.at(in_.py)[0];
-      T vx = in_.vx0, vy = in_.vy0, o[6];
+      T vx = in_.vx0, vy = in_.vy0, tx = in_.tx0, ty = in_.ty0, o[6];
+      const RaygenConsts<T> c = consts_of(&ka->a.rgc);
+      if (in_.hx != nullptr) {  // launch-uniform
+        const T hx = base.at(in_.hx)[0], hy = base.at(in_.hy)[0];
+        if (in_.vx != nullptr) {
+          vx = base.at(in_.vx)[0];
+          vy = base.at(in_.vy)[0];
+        }
+        raygen_field<T>(c, hx, hy, tx, ty);
+      }
       uint32_t again = 0;  // (range bits were raised by the prologue already)
       raygen_pupil<T>(in_.flags, vx, vy, px, py, again);
-      const RaygenConsts<T> c = consts_of(&ka->a.rgc);
-      raygen_one<T>(c, in_.tx0, in_.ty0, px, py, vx, vy, o);
+      raygen_one<T>(c, tx, ty, px, py, vx, vy, o);
+      const T i0 = raygen_apodize<T>(c, px, py);
       PolFields<T> f;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -822,7 +842,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
         Pm[e] = P[0].m[e];
         Qm[e] = POLK == 2 ? P[0].m[POLK == 2 ? 9 + e : e] : T(0);
       }
-      base.at(upd)[0] = pol_intensity_one<T, POLK == 2>(f, o[3], o[4], o[5], Pm, Qm, T(1), status);
+      base.at(upd)[0] = pol_intensity_one<T, POLK == 2>(f, o[3], o[4], o[5], Pm, Qm, i0, status);
     }
   }
   if (status && late.status) atomicOr(late.status, status);
@@ -946,8 +966,8 @@ static hipError_t launch_gen_nr(const TraceArgs<T>& a, bool pair_ok, hipStream_t
   const bool epi = polk != 0 && a.i_updated != nullptr;  // update_intensity epilogue (ABI 7)
   const bool fieldp = a.in.hx != nullptr, apod = a.rgc.apod_kind != 0;
   if (polk != 0) {
-    // polarised launches: the launch-uniform form only (capi.hip refuses the others)
-    if (fieldp || apod || a.spot != nullptr) return hipErrorInvalidValue;
+    // polarised launches: ONE form that takes field planes / an apodized pupil at run time
+    if (a.spot != nullptr) return hipErrorInvalidValue;
     if (polk == 2) { if (epi) OL_LAUNCH_G(2, false, 1, true); else OL_LAUNCH_G(2, false, 1, false); }
     else { if (epi) OL_LAUNCH_G(1, false, 1, true); else OL_LAUNCH_G(1, false, 1, false); }
   } else if (a.spot != nullptr) {

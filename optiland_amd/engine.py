@@ -596,14 +596,15 @@ class HipSystem:
                            last)
 
     def can_trace_generate(self, field_planes: bool = False) -> bool:
-        """`ol_trace_generate` serves this launch: the table carries generator scalars, and --
-        for per-ray field planes (`field_planes`) or an apodized pupil -- the trace is
-        unpolarised (ABI 8; polarised launches with either take the two-launch path)."""
+        """`ol_trace_generate` serves this launch: the table carries generator scalars.  Per-ray
+        field planes (`field_planes`) and apodized pupils are one launch too -- unpolarised
+        traces since ABI 8, polarised ones since ABI 10."""
         rg = self.table.raygen
         if not rg or not hasattr(self.lib, "ol_trace_generate"):
             return False
         if field_planes or int(rg.get("apod_kind", 0)) != 0:
-            return self.table.polarization is None and not self.table.uses_polarization
+            return (self.table.polarization is None and not self.table.uses_polarization) \
+                or hasattr(self.lib, "ol_trace_spot_batch")   # (an ABI-10 library)
         return True
 
     def trace_generate(self, px, py, wavelength_index: int = 0, *, field, vig=(1.0, 1.0),
@@ -613,8 +614,8 @@ class HipSystem:
                        spot=None) -> TraceResult:
         """`ol_trace_generate`: rays generated from the normalised pupil planes and traced
         through the whole system in one launch.  field: (hx, hy) floats -- ONE field point --
-        or two device planes (per-ray fields, unpolarised traces; `vig` then floats or two
-        planes, None = unvignetted).  spot: optional (slots, cx, cy) as in `trace` -- the masked
+        or two device planes (per-ray fields; `vig` then floats or two planes, None =
+        unvignetted).  spot: optional (slots, cx, cy) as in `trace` -- the masked
         image-plane moments as an epilogue of the same launch (one field point, unpolarised,
         no apodization).  record: True (allocate)
         or a preallocated (rows, 8, stride) block; rows start at surface `record_first`

@@ -255,8 +255,7 @@ template hipError_t launch_trace<double>(const TraceArgs<double>&, bool, int, hi
 template <typename T, int NR>
 static hipError_t gen_nr(const TraceArgs<T>& a, bool pair_ok) {
   const int polk = a.prt == nullptr ? 0 : ((a.flags & kTracePrtComplex) ? 2 : 1);
-  if (polk != 0 && (a.in.hx != nullptr || a.rgc.apod_kind != 0 || a.spot != nullptr))
-    return hipErrorInvalidValue;  // as launch_gen_nr
+  if (polk != 0 && a.spot != nullptr) return hipErrorInvalidValue;  // as launch_gen_nr
   if (a.spot != nullptr && (a.in.hx != nullptr || a.rgc.apod_kind != 0))
     return hipErrorInvalidValue;
   bool paired = false;
@@ -303,9 +302,11 @@ static hipError_t gen_nr(const TraceArgs<T>& a, bool pair_ok) {
       const T* row0 = a.record;
       const T kx = row0[3 * a.record_stride + j], ky = row0[4 * a.record_stride + j],
               kz = row0[5 * a.record_stride + j];
+      // `_i0`: the intensity the ray was generated with (1, or the pupil apodization)
+      const T i0 = row0[6 * a.record_stride + j];
       a.i_updated[j] = polk == 2
-                           ? pol_intensity_one<T, true>(a.pf, kx, ky, kz, P, Q, T(1), flag)
-                           : pol_intensity_one<T, false>(a.pf, kx, ky, kz, P, Q, T(1), flag);
+                           ? pol_intensity_one<T, true>(a.pf, kx, ky, kz, P, Q, i0, flag)
+                           : pol_intensity_one<T, false>(a.pf, kx, ky, kz, P, Q, i0, flag);
     }
     if (flag && a.status) *a.status |= flag;
   }

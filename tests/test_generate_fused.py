@@ -126,8 +126,8 @@ def test_fused_generate_status_bits_and_refusals(where):
         assert bool(torch.isfinite(ok.record[-1, 0, :3]).all())
     finally:
         eng.close()
-    # ABI 8: an apodized pupil is served by the generating launch too -- unless the trace is
-    # polarised (those keep the two launches)
+    # ABI 8: an apodized pupil is served by the generating launch too; ABI 10: also when the
+    # trace is polarised
     apod, _ = load_case("apodized_gaussian_trace")
     eng, dev = _engine(apod, where)
     try:
@@ -137,13 +137,7 @@ def test_fused_generate_status_bits_and_refusals(where):
     pol, _ = load_case("zernike_fresnel_fringe")
     eng, dev = _engine(pol, where)
     try:
-        assert eng.can_trace_generate() and not eng.can_trace_generate(field_planes=True)
-        n = 8
-        px, py = _pupil(n, torch.float64, dev, 5)
-        hx = torch.zeros(n, dtype=torch.float64, device=dev)
-        prt = torch.empty((9, n), dtype=torch.float64, device=dev)
-        with pytest.raises(RuntimeError, match="one field point"):
-            eng.trace_generate(px, py, 0, field=(hx, hx), vig=None, prt=prt)
+        assert eng.can_trace_generate() and eng.can_trace_generate(field_planes=True)
     finally:
         eng.close()
 
@@ -321,7 +315,9 @@ def test_generating_launch_with_field_planes_equals_two_launches(case, where):
     eng, dev = _engine(table, where)
     try:
         if not eng.can_trace_generate(field_planes=True):
-            pytest.skip("polarised system: per-ray fields keep the two launches")
+            pytest.skip("no generating launch for this table")
+        if table.polarization is not None or table.uses_polarization:
+            pytest.skip("polarised: test_polarised_generating_launch_with_fields_and_apodization")
         for dtype in (torch.float64, torch.float32):
             for n, discrete in ((1, False), (259, True), (1000, False)):
                 px, py = _pupil(n, dtype, dev, n + 1)
@@ -495,3 +491,73 @@ def test_packed_pair_form_of_the_generating_launch(where):
     finally:
         eng.lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, 0)
         eng.close()
+
+
+# ------------------------------------------------------------------------------------------
+# ABI 10: POLARISED generating launches with per-ray field planes / an apodized pupil
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("where", WHERE)
+@pytest.mark.parametrize("case", ["zernike_fresnel_fringe", "zernike_fresnel_polarized",
+                                  "polarizer_retarder", "coated_mirror_polarised", "fuzz_03"])
+def test_polarised_generating_launch_with_fields_and_apodization(case, where):
+    """`PolarizedRays` bundles take per-ray fields (`trace_generic(Hx[], Hy[], ...)`, the
+    fields x pupil expansion of a multi-field trace: real_ray_tracer.py:88-98, 120-154) and
+    apodized pupils (ray_generator.py:81-85) like any other -- since ABI 10 in ONE launch too:
+    every recorded row AND the nine / eighteen PRT planes bit for bit what `ol_generate_rays`
+    + `ol_trace` give, and the `update_intensity` epilogue (whose `_i0` is then the
+    apodization, polarized_rays.py:51) equal to `ol_polarized_intensity` on what the launch
+    wrote.  Real and complex matrices, fp32 and fp64, with and without vignetting planes."""
+    import copy
+    table, _ = load_case(case)
+    if not table.raygen or table.polarization is None:
+        pytest.skip("not a polarised case with generator scalars")
+    for apod in (None, (1, 0.7, 0.0), (4, 1.0, 2.0)):
+        tb = copy.deepcopy(table)
+        if apod is not None:
+            tb.raygen = dict(tb.raygen, apod_kind=apod[0], apod_a=apod[1], apod_b=apod[2])
+        eng, dev = _engine(tb, where)
+        try:
+            assert eng.can_trace_generate(field_planes=True)
+            cplx = 18 if tb.needs_complex_prt else 9
+            for dtype in (torch.float64, torch.float32):
+                n = 389
+                px, py = _pupil(n, dtype, dev, 31)
+                hx, hy = _fields(n, dtype, dev, 32, False)
+                g = np.random.default_rng(7)
+                vpl = (torch.tensor(g.uniform(0.8, 1.0, n), dtype=dtype, device=dev),
+                       torch.tensor(g.uniform(0.8, 1.0, n), dtype=dtype, device=dev))
+                for field, vig, flags in (((hx, hy), None, _capi.RAYGEN_CHECK_FIELD),
+                                          ((hx, hy), vpl, _capi.RAYGEN_CHECK_FIELD
+                                           | _capi.RAYGEN_PRESCALE_PUPIL),
+                                          ((0.0, 0.6), (1.0, 1.0), 0)):
+                    if apod is None and not isinstance(field[0], torch.Tensor):
+                        continue   # (the launch-uniform plain form: the ABI 7 tests)
+                    # two launches
+                    rec_a = eng.alloc_record(n, dtype)
+                    rays = eng.row0_planes(rec_a, n)
+                    vx, vy = vig if vig is not None else (None, None)
+                    eng.generate_rays(field[0], field[1], px, py, vx, vy, out=rays, flags=flags)
+                    prt_a = torch.empty((cplx, n), dtype=dtype, device=dev)
+                    a = eng.trace(rays, 0, record=rec_a, prt=prt_a, prt_identity=True,
+                                  zero_status=False)
+                    # one
+                    prt_b = torch.empty((cplx, n), dtype=dtype, device=dev)
+                    st = STATES[2]
+                    b = eng.trace_generate(px, py, 0, field=field, vig=vig, flags=flags, prt=prt_b,
+                                           update_intensity=st)
+                    np.testing.assert_array_equal(a.record[:, :, :n].cpu().numpy(),
+                                                  b.record[:, :, :n].cpu().numpy(),
+                                                  err_msg=f"{case} apod={apod} {dtype}")
+                    np.testing.assert_array_equal(prt_a.cpu().numpy(), prt_b.cpu().numpy())
+                    if apod is not None:
+                        assert not np.all(b.record[0, 6, :n].cpu().numpy() == 1.0)
+                    r0 = b.rows(0)
+                    want = eng.polarized_intensity(prt_b, (r0[3], r0[4], r0[5]), r0[6], st)
+                    got = b.updated_intensity
+                    assert got is not None
+                    x, y = got.cpu().numpy(), want.cpu().numpy()
+                    assert np.array_equal(np.isnan(x), np.isnan(y))
+                    tol = 1e-13 if dtype == torch.float64 else 2e-6
+                    np.testing.assert_allclose(x, y, rtol=tol, atol=tol)
+        finally:
+            eng.close()
