@@ -566,6 +566,18 @@ typedef struct ol_wavefront_params {
    * the plane through (xc, yc, zc) with this normal, R is ignored and
    *   t = -((r - c) . n) / (k_back . n),  |k_back . n| < 1e-12 replaced by 1e-12.       */
   double nx, ny, nz;
+  /* ABI 10, the FUSED entry points only (ol_trace_opd, ol_wavefront_reference -- through whose
+   * device structure ol_trace_opd_dev reads them): what ends Optic.trace / trace_generic when
+   * the last surface has a thickness (raytrace/real_ray_tracer.py:104-110, 145-149,
+   * propagation/homogeneous.py:30-57) -- the rays go on by `last_thickness` through that
+   * surface's post-medium before the reference sphere is intersected; the optical path is not
+   * extended.  `last_absorb` (4 pi k / lambda_um * 1e3 per mm, 0 when k = 0) attenuates the
+   * chief ray ol_wavefront_reference hands back (`chief8[6]`, what trace_generic returns) and
+   * nothing else: the intensity a wavefront reports is the RECORDED last row
+   * (wavefront/strategy.py:188), which the reference's write-back never reaches.  0 / 0 (a
+   * zero-initialised struct; every sample lens) = the trace ends at the last surface.
+   * ol_wavefront_opd, which is handed finished rays, ignores them.                      */
+  double last_thickness, last_absorb;
 } ol_wavefront_params;
 
 int ol_wavefront_opd(const ol_wavefront_params* p, ol_dtype dt, int64_t n_rays,
@@ -608,7 +620,7 @@ int ol_trace_opd(const ol_system* sys, ol_dtype dt, int64_t n_rays,
  * chief8 (nullable): 8 doubles receiving x, y, z, L, M, N, i, opd of the chief ray.
  * ol_trace_opd_dev is ol_trace_opd reading the reference from such a structure: an OPD map
  * is two launches and no read-back in between.  fp64 only.                                */
-#define OL_WAVEFRONT_REFERENCE_DOUBLES 14
+#define OL_WAVEFRONT_REFERENCE_DOUBLES 16
 int ol_wavefront_reference(const ol_system* sys, ol_dtype dt, const ol_raygen_params* p,
                            const ol_raygen_inputs* in, const ol_wavefront_params* w,
                            double pupil_z, int32_t planar, int32_t wavelength_index,

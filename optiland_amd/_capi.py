@@ -83,7 +83,8 @@ SPOT_SLOTS = 64
 
 class WavefrontParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("xc", "yc", "zc", "R", "n_image", "opd_ref", "ux",
-                                          "uy", "half_epd", "wavelength_um", "nx", "ny", "nz")]
+                                          "uy", "half_epd", "wavelength_um", "nx", "ny", "nz",
+                                          "last_thickness", "last_absorb")]
 
 
 SPOT_BATCH_MAX_CELLS = 32  # OL_SPOT_BATCH_MAX_CELLS
@@ -142,7 +143,7 @@ F32, F64 = 0, 1
 TUNE_RAYS_PER_THREAD, TUNE_COMPACT, TUNE_FIT_GRID = 0, 1, 2
 ABI_VERSION = 10
 OPD_MOMENTS = 12  # kOpdMoments / ol_trace_opd
-WAVEFRONT_REFERENCE_DOUBLES = 14  # OL_WAVEFRONT_REFERENCE_DOUBLES
+WAVEFRONT_REFERENCE_DOUBLES = 16  # OL_WAVEFRONT_REFERENCE_DOUBLES
 WAVEFRONT_FIT_WORKSPACE_DOUBLES = 32832  # OL_WAVEFRONT_FIT_WORKSPACE_DOUBLES
 FIT_CENTROID, FIT_BEST_FIT = 0, 1
 FIT_NO_VALID, FIT_TOO_FEW, FIT_NO_ALIVE, FIT_SINGULAR = 1, 2, 4, 8

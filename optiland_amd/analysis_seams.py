@@ -51,32 +51,62 @@ STATS = {"spot": 0, "spot_fallback": 0, "ee": 0, "ee_fallback": 0, "opd": 0, "op
          "dist": 0, "dist_fallback": 0, "opd_fit": 0, "opd_fit_fallback": 0, "spot_grid": 0}
 
 
-def _front(optic, wavelength, need_fp64=False):
+def _why(seam, reason):
+    """OPTILAND_HIP_SEAM_LOG=<file>: one line per declined seam call (which, why, and -- under
+    pytest -- in which test): how `tools/ref_consumers_seams.sh` attributes its fall-backs."""
+    import os
+
+    path = os.environ.get("OPTILAND_HIP_SEAM_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{seam}: {reason} [{os.environ.get('PYTEST_CURRENT_TEST', '')}]\n")
+
+
+def _front(optic, wavelength, need_fp64=False, final_propagation=False):
     """(front, table) -- the stand-alone device tracer on the CURRENT packed table of
     `optic` -- when the fused analysis kernels apply to it, else None."""
     from . import integration as ig
 
     comp = ig.hip_tracer_of(optic)
     if comp is None or not comp._eligible():
+        _why("front", "optic not served by the drop-in (backend / device / autograd)")
         return None
     try:
         front, table = comp._front_for(wavelength)
-    except UnsupportedSystem:
+    except UnsupportedSystem as exc:
+        _why("front", f"unsupported system: {exc}")
         return None
     if not table.raygen or table.polarization is not None or table.uses_polarization:
+        _why("front", "no device ray generation" if not table.raygen else "polarised")
         return None  # reference-side ray generation / polarised epilogue: not fused
-    if float(table.last_thickness) != 0.0:
+    if float(table.last_thickness) != 0.0 and not final_propagation:
+        _why("front", "last surface has a thickness")
         # `Optic.trace` propagates the rays on by the LAST surface's thickness
         # (real_ray_tracer.py:104-110; 0 in every sample: the last surface is the image
-        # plane).  The fused kernels end at the last surface: such an optic keeps the
-        # reference's own analysis code on top of the drop-in's trace, which does propagate.
+        # plane).  `final_propagation`: the caller either does not look at the returned rays
+        # (the spot / encircled-energy data are the RECORDED last row) or hands the
+        # propagation to the kernel (`_final_propagation`: the OPD seams, ABI 10).  Anybody
+        # else keeps the reference's own analysis code on top of the drop-in's trace.
         return None
     if need_fp64 and front.dtype != torch.float64:
+        _why("front", "fp32 wavefront")
         return None
     if not hasattr(front.engine, "trace_spot"):
         return None
     comp.last_path = "hip"  # (introspection, as after an intercepted Optic.trace)
     return front, table
+
+
+def _final_propagation(optic, table, wavelength) -> dict:
+    """`last_thickness` / `last_absorb` of `ol_wavefront_params`: what ends `Optic.trace`
+    (real_ray_tracer.py:104-110 with propagation/homogeneous.py:44-53) when the last surface
+    has a thickness -- {} (0 / 0) otherwise."""
+    t = float(table.last_thickness)
+    if t == 0.0:
+        return {}
+    k = _f(optic.surfaces[-1].material_post.k(wavelength))
+    return {"last_thickness": t,
+            "last_absorb": (4.0 * math.pi * k / float(wavelength)) * 1e3 if k > 0 else 0.0}
 
 
 def _register(optic, front, table, launch):
@@ -106,7 +136,7 @@ def _image_hits(optic, field, wavelength, num_rays, distribution):
     hx, hy = _scalar(field[0]), _scalar(field[1])
     if hx is None or hy is None:
         return None
-    got = _front(optic, wavelength)
+    got = _front(optic, wavelength, final_propagation=True)  # (the data are the recorded row)
     if got is None:
         return None
     front, table = got
@@ -162,7 +192,7 @@ def _spot_grid(self):
     main = None      # the front whose geometry the launch reads; the others lend index rows
     cells, last = [], None
     for wi, w in enumerate(wls):
-        got = _front(self.optic, w)
+        got = _front(self.optic, w, final_propagation=True)
         if got is None:
             return None
         front, table = got
@@ -314,7 +344,7 @@ def _chief_init(self, optic, distribution, **kwargs):
 
     pupil_z = None
     try:
-        got = _front(optic, _f(optic.primary_wavelength))
+        got = _front(optic, _f(optic.primary_wavelength), final_propagation=True)
         if got is not None:
             pupil_z = got[1].raygen.get("pupil_z")
     except Exception:  # noqa: BLE001 - anything unexpected: the reference's own constructor
@@ -348,12 +378,16 @@ def _fused_wavefront(self, field, wavelength):
         return None
     if self.reference_type not in ("sphere", "plane"):
         return None
-    got = _front(self.optic, w, need_fp64=True)
+    got = _front(self.optic, w, need_fp64=True, final_propagation=True)
     if got is None:
         return None
     front, table = got
     rg = table.raygen
     if not hasattr(front.engine, "trace_opd"):
+        return None
+    if float(table.last_thickness) != 0.0 and not hasattr(
+            getattr(front.engine, "lib", None), "ol_trace_spot_batch"):
+        _why("opd", "last surface has a thickness and the engine does not propagate (ABI < 10)")
         return None
     dist = self.distribution
     dx, dy = getattr(dist, "x", None), getattr(dist, "y", None)
@@ -373,7 +407,8 @@ def _fused_wavefront(self, field, wavelength):
         n_image = _f(self.n_image)
     ux, uy = _launch_plane_tilt(rg, hx, hy)
     params = dict(xc=xc, yc=yc, zc=zc, n_image=n_image, opd_ref=0.0, ux=ux, uy=uy,
-                  half_epd=rg["EPD"] / 2.0, wavelength_um=w)
+                  half_epd=rg["EPD"] / 2.0, wavelength_um=w,
+                  **_final_propagation(self.optic, table, w))
     if self.reference_type == "plane":  # strategy.py:260-284
         R = math.inf
         params.update(R=0.0, nx=Lc, ny=Mc, nz=Nc)
@@ -453,7 +488,8 @@ def _fused_wavefront_device(self, front, table, hx, hy, w, dx, dy):
         pz = self.__dict__.get("_hip_pupil_z")
         if pz is None or self.pupil_z is not self.__dict__.get("_hip_pupil_z_of"):
             pz = _f(self.pupil_z)  # somebody replaced the attribute: read it
-    params = dict(n_image=n_image, ux=ux, uy=uy, half_epd=rg["EPD"] / 2.0, wavelength_um=w)
+    params = dict(n_image=n_image, ux=ux, uy=uy, half_epd=rg["EPD"] / 2.0, wavelength_um=w,
+                  **_final_propagation(self.optic, table, w))
     vig = front._vig_scalar(hx, hy)
     wl, _ = front._wavelength_index(w)
     eng = front.engine

@@ -638,7 +638,7 @@ int do_wavefront_reference(const ol_system* sys, const DeviceTable<T>& tab,
   a.coeffs = tab.coeffs;
   a.rg = raygen_dev(p);
   ol::WavefrontDev wd{0, 0, 0, 0, w->n_image, 0, w->ux, w->uy, w->half_epd, w->wavelength_um,
-                      0, 0, planar ? 1.0 : 0.0};
+                      0, 0, planar ? 1.0 : 0.0, w->last_thickness, w->last_absorb};
   a.wfc = ol::WavefrontConsts<T>(wd);   // planar flag from nz != 0; centre / R filled on device
   a.pupil_z = (T)pupil_z;
   a.out = static_cast<ol::WavefrontConsts<T>*>(reference_dev);
@@ -675,7 +675,8 @@ int do_trace_opd(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
   a.rg = raygen_dev(p);
   if (w)
     a.wf = ol::WavefrontDev{w->xc, w->yc, w->zc, w->R, w->n_image, w->opd_ref, w->ux, w->uy,
-                            w->half_epd, w->wavelength_um, w->nx, w->ny, w->nz};
+                            w->half_epd, w->wavelength_um, w->nx, w->ny, w->nz,
+                            w->last_thickness, w->last_absorb};
   else
     a.wf = ol::WavefrontDev{0, 0, 0, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0};  // (unused: reference_dev)
   a.opd = static_cast<T*>(opd);
@@ -1458,6 +1459,8 @@ int ol_wavefront_fit(int32_t kind, const ol_wavefront_params* w, double trim_std
                      double* workspace, void* reference_dev, uint32_t* fit_status,
                      void* stream) {
   static_assert(OL_WAVEFRONT_FIT_WORKSPACE_DOUBLES == ol::kFitWorkspaceDoubles, "header");
+  static_assert(sizeof(ol::WavefrontConsts<double>) <= OL_WAVEFRONT_REFERENCE_DOUBLES * 8,
+                "header: the device reference structure");
   static_assert(OL_FIT_NO_VALID == ol::kFitNoValid && OL_FIT_TOO_FEW == ol::kFitTooFew &&
                 OL_FIT_NO_ALIVE == ol::kFitNoAlive && OL_FIT_SINGULAR == ol::kFitSingular &&
                 OL_FIT_CENTROID == ol::kFitCentroid && OL_FIT_BEST_FIT == ol::kFitBestFit,

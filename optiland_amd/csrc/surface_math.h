@@ -87,6 +87,33 @@ OL_DEV double div_f64(double a, double b) {
   const double refined = __builtin_fma(r, y, q);
   return __builtin_amdgcn_class(b, kClassZeroOrInf) ? a * y0 : refined;
 }
+// TWO quotients n1 / d1 and n2 / d2 from ONE reciprocal seed: y ~ 1 / (d1 d2) (seed + one
+// Newton step), 1 / d1 ~ d2 y, 1 / d2 ~ d1 y, each quotient then corrected once with its own
+// residual like div_f64 -- 12 vector instructions and one quarter-rate seed where two div_f64
+// take 20 and two.  The conic intersection forms C / q and q / A for every ray and surface
+// (standard.py:112-146): with the sign product of round 5 the fp64 surface goes 124 -> 114.
+// Lanes whose product d1 d2 is zero or infinite (a paraboloid met by an axis-parallel ray has
+// A = 0 exactly) take div_f64 -- per LANE, under a wave-uniform branch that such waves alone
+// enter: a ray's result never depends on its neighbours in the wave.
+OL_DEV void div2_f64(double n1, double d1, double n2, double d2, double& q1, double& q2) {
+  const double dd = d1 * d2;
+  const double y0 = __builtin_amdgcn_rcp(dd);
+  const double e = __builtin_fma(-dd, y0, 1.0);
+  const double y = __builtin_fma(y0, e, y0);
+  const double i1 = d2 * y, i2 = d1 * y;
+  double a = n1 * i1;
+  a = __builtin_fma(__builtin_fma(-d1, a, n1), i1, a);
+  double b = n2 * i2;
+  b = __builtin_fma(__builtin_fma(-d2, b, n2), i2, b);
+  const bool odd = __builtin_amdgcn_class(dd, kClassZeroOrInf);
+  if (__any(odd)) {
+    const double sa = div_f64(n1, d1), sb = div_f64(n2, d2);
+    a = odd ? sa : a;
+    b = odd ? sb : b;
+  }
+  q1 = a;
+  q2 = b;
+}
 OL_DEV double sqrt_f64(double x) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
@@ -152,6 +179,10 @@ struct Math<float> {
   static OL_DEV float sqrt(float x) { return hw::sqrt(x); }
   static OL_DEV float rsqrt(float x) { return hw::rsq(x); }
   static OL_DEV float div(float a, float b) { return a * rcp(b); }
+  static OL_DEV void div2(float n1, float d1, float n2, float d2, float& q1, float& q2) {
+    q1 = div(n1, d1);
+    q2 = div(n2, d2);
+  }
   static OL_DEV float exp(float x) { return hw::exp(x); }
   static OL_DEV float abs(float x) { return __builtin_fabsf(x); }
   static OL_DEV float copysign(float a, float b) {
@@ -184,11 +215,26 @@ struct Math<double> {
   static OL_DEV double sqrt(double x) { return hw::sqrt_f64(x); }
   static OL_DEV double rsqrt(double x) { return hw::rsq_f64(x); }
   static OL_DEV double div(double a, double b) { return hw::div_f64(a, b); }
+#ifndef OL_DIV2_F64
+#define OL_DIV2_F64 1
+#endif
+  static OL_DEV void div2(double n1, double d1, double n2, double d2, double& q1, double& q2) {
+    if (OL_DIV2_F64) {
+      hw::div2_f64(n1, d1, n2, d2, q1, q2);
+    } else {
+      q1 = div(n1, d1);
+      q2 = div(n2, d2);
+    }
+  }
 #else
   static OL_DEV double rcp(double x) { return 1.0 / x; }
   static OL_DEV double sqrt(double x) { return __builtin_sqrt(x); }
   static OL_DEV double rsqrt(double x) { return 1.0 / __builtin_sqrt(x); }
   static OL_DEV double div(double a, double b) { return a / b; }
+  static OL_DEV void div2(double n1, double d1, double n2, double d2, double& q1, double& q2) {
+    q1 = n1 / d1;
+    q2 = n2 / d2;
+  }
 #endif
   static OL_DEV double exp(double x) { return ::exp(x); }
   static OL_DEV double abs(double x) { return __builtin_fabs(x); }
@@ -231,6 +277,10 @@ struct Math<f32x2> {
     return V{hw::rsq(x.x), hw::rsq(x.y)};
   }
   static OL_DEV V div(V a, V b) { return a * rcp(b); }
+  static OL_DEV void div2(V n1, V d1, V n2, V d2, V& q1, V& q2) {
+    q1 = div(n1, d1);
+    q2 = div(n2, d2);
+  }
   static OL_DEV V exp(V x) { return V{hw::exp(x.x), hw::exp(x.y)}; }
   static OL_DEV V abs(V x) {
     return V{__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
@@ -315,8 +365,8 @@ OL_DEV V curved_distance(typename Math<V>::scalar cv,
   V disc = m::fma(E, E, -A * C);
   V sq = m::sqrt(disc);  // NaN when the ray misses (standard.py:132-137)
   V q = -(E + m::copysign(sq, E));
-  V ta = m::div(C, q);
-  V tb = m::div(q, A);
+  V ta, tb;
+  m::div2(C, q, q, A, ta, tb);
   // t_b is the reference's t1 iff -sgn(E) == sgn(R); the reference keeps t1 when
   // |z + t1 N| <= |z + t2 N| and t2 otherwise (also when the comparison is NaN)
   const auto b_is_t1 = m::same(m::lt(E, zero), m::all(cv > 0));
@@ -1484,6 +1534,9 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
   //   reflect:  k' = k - 2 dot n                    refract:  k' = u k + n (sign(dot) root - u dot)
   // with ONE product sign(dot) root instead of three products n sign(dot): 2 vector
   // instructions fewer per ray and refracting surface, 4 per reflecting one (round 5).
+#ifndef OL_SNELL_SIGN_ON_ROOT
+#define OL_SNELL_SIGN_ON_ROOT 1   // 0: rounds 1-4, the aligned normal formed explicitly (A/B knob)
+#endif
   V L0[RPT], M0[RPT], N0[RPT], adot[RPT];
   V sdot[RPT];
 #pragma unroll
@@ -1494,6 +1547,7 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
     sdot[k] = m::fma(L0[k], nx[k], m::fma(M0[k], ny[k], N0[k] * nz[k]));
     adot[k] = m::abs(sdot[k]);  // (read by the polarised coatings below only)
   }
+#if OL_SNELL_SIGN_ON_ROOT
   if (s.interaction == kReflect) {
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -1518,6 +1572,37 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
       r[k].N = m::fma(m::splat(u), N0[k], nz[k] * w);
     }
   }
+#else
+  {
+    V ax[RPT], ay[RPT], az[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const V sgn = m::select(m::ne(sdot[k], zero), m::copysign(one, sdot[k]), zero);
+      ax[k] = nx[k] * sgn;
+      ay[k] = ny[k] * sgn;
+      az[k] = nz[k] * sgn;
+    }
+    if (s.interaction == kReflect) {
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        V k2 = m::splat(-2) * adot[k];
+        r[k].L = m::fma(k2, ax[k], L0[k]);
+        r[k].M = m::fma(k2, ay[k], M0[k]);
+        r[k].N = m::fma(k2, az[k], N0[k]);
+      }
+    } else {
+      const T u = o.u;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        V root = m::sqrt(m::fma(m::splat(-u * u), m::fma(-adot[k], adot[k], one), one));
+        V w = m::fma(m::splat(-u), adot[k], root);
+        r[k].L = m::fma(m::splat(u), L0[k], ax[k] * w);
+        r[k].M = m::fma(m::splat(u), M0[k], ay[k] * w);
+        r[k].N = m::fma(m::splat(u), N0[k], az[k] * w);
+      }
+    }
+  }
+#endif
 
   // coating (interactions/base.py:111-128)
   if (s.coating_kind == kCoatSimple) {

@@ -1472,6 +1472,7 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
       WavefrontConsts<T> w;
       if constexpr (DEVREF) w = load_consts(as_const(A1->wf_dev));
       else w = consts_of(&A1->wfc);
+      final_propagate<T, false>(w, g);
       ov = wavefront_one<T>(w, g.x, g.y, g.z, g.L, g.M, g.N, g.opd, A1->in.px[j], A1->in.py[j],
                             pu);
     }
@@ -1595,6 +1596,7 @@ __global__ __launch_bounds__(64) void chief_ref_kernel(
     g = to_global<T>(h.surf(), r[0]);
   }
   WavefrontConsts<T> w = a.wfc;
+  final_propagate<T, true>(w, g);
   w.xc = g.x; w.yc = g.y; w.zc = g.z;
   T t_back;
   if (w.planar) {

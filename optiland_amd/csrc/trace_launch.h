@@ -236,6 +236,10 @@ hipError_t launch_pol_intensity(int64_t n, const T* prt, bool prt_complex, const
 struct WavefrontDev {
   double xc, yc, zc, R, n_image, opd_ref, ux, uy, half_epd, wavelength_um;
   double nx, ny, nz;  // all zero: spherical reference; else planar reference normal
+  // ABI 10: the propagation that ends Optic.trace / trace_generic -- on by the LAST surface's
+  // thickness through its post-medium (real_ray_tracer.py:104-110, 145-149) -- for the fused
+  // kernels, which end at the last surface: 0 (every sample lens) = none
+  double last_t = 0.0, last_absorb = 0.0;
 };
 
 // reference sphere / plane of the wavefront kernels in the working precision (host-formed,
@@ -243,12 +247,14 @@ struct WavefrontDev {
 template <typename T>
 struct WavefrontConsts {
   T xc, yc, zc, R, ni, inv_w, ux, uy, half_epd, opd_ref, nx, ny, nz;
+  T last_t = T(0), last_absorb = T(0);   // (see WavefrontDev)
   int32_t planar;
   WavefrontConsts() = default;
   OL_HD explicit WavefrontConsts(const WavefrontDev& p)
       : xc((T)p.xc), yc((T)p.yc), zc((T)p.zc), R((T)p.R), ni((T)p.n_image),
         inv_w((T)(1.0 / (p.wavelength_um * 1e-3))), ux((T)p.ux), uy((T)p.uy),
         half_epd((T)p.half_epd), opd_ref((T)p.opd_ref), nx((T)p.nx), ny((T)p.ny), nz((T)p.nz),
+        last_t((T)p.last_t), last_absorb((T)p.last_absorb),
         planar(p.nx != 0.0 || p.ny != 0.0 || p.nz != 0.0) {}
 };
 

@@ -28,7 +28,29 @@ OL_DEV WavefrontConsts<T> load_consts(cptr<WavefrontConsts<T>> p) {
   w.xc = p->xc; w.yc = p->yc; w.zc = p->zc; w.R = p->R; w.ni = p->ni; w.inv_w = p->inv_w;
   w.ux = p->ux; w.uy = p->uy; w.half_epd = p->half_epd; w.opd_ref = p->opd_ref;
   w.nx = p->nx; w.ny = p->ny; w.nz = p->nz; w.planar = p->planar;
+  w.last_t = p->last_t; w.last_absorb = p->last_absorb;
   return w;
+}
+
+// What ends Optic.trace / trace_generic (real_ray_tracer.py:104-110, 145-149;
+// propagation/homogeneous.py:30-57): the rays go on by the last surface's thickness through
+// its post-medium -- position and, in an absorbing medium, intensity; the optical path is NOT
+// extended.  0 in every sample lens (the last surface is the image plane); the reference's own
+// test_finite_conjugate_angle_field_opd ends 95 mm behind its last surface.
+// INTENSITY: the returned rays' intensity is attenuated too (what trace_generic hands back: the
+// chief ray); the intensity a wavefront REPORTS is `surfaces.intensity[-1]` (strategy.py:188),
+// the recorded last row, which the reference's write-back of `rays.i` never reaches (SURVEY.md
+// Appendix D: it assigns into a temporary stack) -- so the OPD kernels leave it alone.
+template <typename T, bool INTENSITY>
+OL_DEV void final_propagate(const WavefrontConsts<T>& w, Ray<T>& g) {
+  if (w.last_t != T(0)) {   // launch-uniform
+    g.x = g.x + w.last_t * g.L;
+    g.y = g.y + w.last_t * g.M;
+    g.z = g.z + w.last_t * g.N;
+    if constexpr (INTENSITY) {
+      if (w.last_absorb > T(0)) g.i = g.i * Math<T>::exp(-w.last_absorb * w.last_t);
+    }
+  }
 }
 
 // (xr, yr, zr), (Ld, Md, Nd), opd_in: the ray at the image surface (global frame);

@@ -131,6 +131,7 @@ OL_DEV void fit_write_reference(const FitParams& p, WavefrontConsts<double>* out
   out->ni = p.ni; out->inv_w = p.inv_w; out->ux = p.ux; out->uy = p.uy;
   out->half_epd = p.half_epd; out->opd_ref = 0.0;
   out->nx = nx; out->ny = ny; out->nz = nz; out->planar = p.planar ? 1 : 0;
+  out->last_t = 0.0; out->last_absorb = 0.0;   // (the fitted strategies read TRACED bundles)
 }
 
 // strategy.py:433-455 once the weights are final: the centroid, and for a planar reference the

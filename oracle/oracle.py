@@ -289,7 +289,7 @@ def wavefront_fit(kind: str, params: dict, rays8, px, py, *, trim_std=3.0, flavo
 
 class WavefrontParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("xc", "yc", "zc", "R", "n_image", "opd_ref", "ux",
-                                          "uy", "half_epd", "wavelength_um", "nx", "ny", "nz")]
+                                          "uy", "half_epd", "wavelength_um", "nx", "ny", "nz", "last_thickness", "last_absorb")]
 
 
 def wavefront_opd(params: dict, rays7, px, py):

@@ -645,15 +645,18 @@ hipError_t launch_opd_trace(const OpdArgs<T>& a_in, int nr_family, hipStream_t) 
     const Ray<T> g = fused_trace_family<T>(nr_family, a.surf, a.cold, a.optics, a.coeffs, a.first,
                                            a.last, a.n_wl, a.wl, q, status);
     T pu[3];
-    const T ov = wavefront_one<T>(w, g.x, g.y, g.z, g.L, g.M, g.N, g.opd, in_.px[j], in_.py[j], pu);
+    Ray<T> gp = g;
+    final_propagate<T, false>(w, gp);
+    const T ov = wavefront_one<T>(w, gp.x, gp.y, gp.z, gp.L, gp.M, gp.N, gp.opd, in_.px[j],
+                                  in_.py[j], pu);
     a.opd[j] = ov;
-    a.inten[j] = g.i;
+    a.inten[j] = gp.i;
     if (a.pupil[0]) {
       a.pupil[0][j] = pu[0];
       a.pupil[1][j] = pu[1];
       a.pupil[2][j] = pu[2];
     }
-    opd_accumulate(s, (double)g.i, (double)ov, (double)pu[0], (double)pu[1], g.i > T(0));
+    opd_accumulate(s, (double)gp.i, (double)ov, (double)pu[0], (double)pu[1], gp.i > T(0));
   }
   for (int k = 0; k < kOpdMoments; ++k) a.mom[k] += s[k];
   if (status && a.status) *a.status |= status;
@@ -677,10 +680,11 @@ hipError_t launch_chief_reference(const ChiefArgs<T>& a_in, int nr_family, hipSt
   q.L = o[3]; q.M = o[4]; q.N = o[5];
   q.i = T(1);
   q.opd = T(0);
-  const Ray<T> g = fused_trace_family<T>(nr_family == kNrNone ? kNrNone : kNrGeneric, a.surf,
-                                         a.cold, a.optics, a.coeffs, a.first, a.last, a.n_wl, a.wl,
-                                         q, status);
+  Ray<T> g = fused_trace_family<T>(nr_family == kNrNone ? kNrNone : kNrGeneric, a.surf,
+                                   a.cold, a.optics, a.coeffs, a.first, a.last, a.n_wl, a.wl,
+                                   q, status);
   WavefrontConsts<T> w = a.wfc;
+  final_propagate<T, true>(w, g);
   w.xc = g.x; w.yc = g.y; w.zc = g.z;
   T t_back;
   if (w.planar) {

@@ -523,23 +523,34 @@ def test_device_resident_reference_equals_the_host_built_one(seams, reference_ty
     np.testing.assert_allclose(got[2], want[2], rtol=1e-13, atol=1e-13)
 
 
-def test_seams_decline_an_optic_whose_last_surface_has_a_thickness(seams):
+@pytest.mark.parametrize("absorbing", [False, True])
+def test_an_optic_whose_last_surface_has_a_thickness(seams, request, absorbing, monkeypatch):
     """`Optic.trace` ends with a propagation by the last surface's thickness
-    (real_ray_tracer.py:104-110); the fused spot / OPD kernels end AT the last surface.  An
-    optic without an image plane (the reference's own `test_finite_conjugate_angle_field_opd`
-    builds one: object, two lens surfaces, 95 mm to nowhere) must therefore take the reference's
-    analysis code on top of the drop-in trace -- found in round 4: the OPD seam had been off by
-    exactly those 95 mm (172 727 waves of piston), invisibly to that test, which compares two
-    such optics with each other."""
+    (real_ray_tracer.py:104-110); the fused kernels end AT the last surface.  An optic without an
+    image plane (the reference's own `test_finite_conjugate_angle_field_opd` builds one: object,
+    two lens surfaces, 95 mm to nowhere): round 4 made the seams DECLINE it (the OPD seam had
+    been off by exactly those 95 mm -- 172 727 waves of piston -- invisibly to that test, which
+    compares two such optics with each other); round 5 (ABI 10) hands the propagation to the
+    kernels (`ol_wavefront_params.last_thickness / last_absorb`), host-built and
+    device-resident reference alike, through an absorbing last medium too; the spot data are the
+    RECORDED last row and never saw it.  The oracle-backed stand-in does not propagate and
+    still declines."""
     be, stats = seams
+    from optiland import analysis
+    from optiland.materials import IdealMaterial
     from optiland.optic import Optic
     from optiland.wavefront import OPD
+    served = "kernel-source" in request.node.name
 
     def build():
         optic = Optic()
         optic.surfaces.add(index=0, thickness=100.0)
         optic.surfaces.add(index=1, radius=50.0, thickness=5.0, material="BK7", is_stop=True)
-        optic.surfaces.add(index=2, radius=-50.0, thickness=95.0)
+        if absorbing:
+            optic.surfaces.add(index=2, radius=-50.0, thickness=95.0,
+                               material=IdealMaterial(n=1.1, k=2e-7))
+        else:
+            optic.surfaces.add(index=2, radius=-50.0, thickness=95.0)
         optic.set_aperture("EPD", 10.0)
         optic.wavelengths.add(0.55, is_primary=True)
         optic.fields.set_type("angle")
@@ -548,13 +559,27 @@ def test_seams_decline_an_optic_whose_last_surface_has_a_thickness(seams):
 
     def run(lens):
         o = OPD(lens, field=(0, 1), wavelength="primary", num_rays=10, distribution="line_y")
-        return _np(be, o.get_data((0, 1), lens.primary_wavelength).opd)
+        d = o.get_data((0, 1), lens.primary_wavelength)
+        s = analysis.SpotDiagram(lens, num_rings=4)
+        return (_np(be, d.opd), _np(be, d.intensity), _np(be, d.pupil_z), float(d.radius),
+                _np(be, s.data[0][0].x), _np(be, s.data[0][0].y), _np(be, s.data[0][0].intensity))
 
     want = _numpy_reference(be, build, run)
-    before = stats["opd"]
-    got = run(build())
-    assert stats["opd"] == before            # declined ...
-    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)   # ... and right
+    for device_reference in ("1", "0"):
+        monkeypatch.setenv("OPTILAND_HIP_DEVICE_REFERENCE", device_reference)
+        before, spots = stats["opd"], stats["spot"]
+        got = run(build())
+        assert stats["opd"] == before + (1 if served else 0)
+        assert stats["spot"] == spots + 1
+        np.testing.assert_allclose(got[0], want[0], rtol=0, atol=1e-6)     # waves
+        # (the REPORTED intensity is the recorded last row: the 95 mm of absorbing medium
+        # behind it -- exp(-0.43) -- do not show, in the reference or here)
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-12, atol=0)
+        assert want[1].min() > 0.99
+        np.testing.assert_allclose(got[2], want[2], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(got[3], want[3], rtol=1e-12)
+        for a, b in zip(got[4:], want[4:]):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-9)
 
 
 # ----------------------------------------------------------------------------------

@@ -73,6 +73,12 @@ VARIANTS = {
     "raygen_ieee": ["-DOL_RAYGEN_RSQ=0", "-DOL_WAVEFRONT_FAST=0"],
     # fp64 quotient with two Newton steps on the reciprocal (rounds 3 - 4a) instead of one
     "div64_2steps": ["-DOL_DIV_F64_STEPS=2"],
+    # round 5: the two quotients of the conic intersection from two reciprocal seeds (rounds
+    # 3-4) instead of one shared; the aligned normal formed explicitly (rounds 1-4) instead of
+    # the sign carried on Snell's root; both = the arithmetic of round 4's library
+    "div2_off": ["-DOL_DIV2_F64=0"],
+    "snell_r04": ["-DOL_SNELL_SIGN_ON_ROOT=0"],
+    "arith_r04": ["-DOL_DIV2_F64=0", "-DOL_SNELL_SIGN_ON_ROOT=0"],
 }
 
 

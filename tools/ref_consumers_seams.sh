@@ -43,9 +43,9 @@ def pytest_sessionfinish(session, exitstatus):
 open(p, "w").write(s)
 PY
 cd "$W"
-PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=$R/tests/refshim:/root/reference:$W \
+OPTILAND_HIP_SEAM_LOG=$W/seam_log.txt PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=$R/tests/refshim:/root/reference:$W \
   python -m pytest -q -p no:cacheprovider -k "torch and not autodiff" \
   tests/test_analysis.py tests/test_analysis_extended.py tests/test_wavefront.py \
   tests/test_fft_psf.py tests/test_mtf.py tests/test_optic.py tests/test_zernike.py \
   > "$W/log.txt" 2>&1 || true
-grep -E "^\[seams\]|^FAILED|^ERROR| passed| failed" "$W/log.txt" | tail -30
+sort "$W/seam_log.txt" 2>/dev/null | uniq -c | sort -rn | head -20; grep -E "^\[seams\]|^FAILED|^ERROR| passed| failed" "$W/log.txt" | tail -30
