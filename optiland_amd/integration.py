@@ -630,7 +630,13 @@ def _make_tracer_class():
                 trusted.add(w)
             if _fp.ENABLED:
                 if tok is None:
-                    tok, _keep = _fp.optic_token(self.optic, w)
+                    seen = getattr(trusted, "token", None)
+                    if seen is not None:   # (same optic, same scope: only the wavelength differs)
+                        tok, _keep = (w,) + seen[0][1:], seen[1]
+                    else:
+                        tok, _keep = _fp.optic_token(self.optic, w)
+                        if trusted is not None:
+                            trusted.token = (tok, _keep)
                 memo = self._hip_memo.get(w)
                 if memo is not None and memo[0] == tok:
                     key = memo[2]
@@ -1132,6 +1138,15 @@ def _companion(rt):
     return comp
 
 
+class _TrustedScope(set):
+    """The wavelengths validated inside an `unchanged` scope, and the token of the optic taken
+    for the first of them: tokens of ONE optic differ between wavelengths in their first
+    element only (`fingerprint.optic_token`), so the second and third wavelength of a spot
+    diagram re-use the walk over the surfaces (3 token walks become 1)."""
+
+    token = None   # (tok, keep) of the first wavelength validated in this scope
+
+
 @contextlib.contextmanager
 def unchanged(optic):
     """Scope in which `optic` is known not to be edited -- a loop of the reference that only
@@ -1144,7 +1159,7 @@ def unchanged(optic):
         yield
         return
     if comp._hip_trust_depth == 0:
-        comp._hip_trusted = set()
+        comp._hip_trusted = _TrustedScope()
     comp._hip_trust_depth += 1
     try:
         yield

@@ -338,8 +338,10 @@ def test_seams_are_inert_without_the_drop_in(hip_on_cpu):
 
 def test_spot_diagram_validates_each_wavelength_once(seams, monkeypatch):
     """`SpotDiagram._generate_data` (core.py:420-438) traces fields x wavelengths and edits
-    nothing: inside `integration.unchanged(optic)` the change detector runs once per
-    wavelength, not once per (field, wavelength) -- and again on the next analysis."""
+    nothing: inside `integration.unchanged(optic)` the change detector validates every
+    wavelength's table once, not once per (field, wavelength) -- with ONE walk over the optic
+    (round 5: the tokens of one optic differ between wavelengths in their first element only) --
+    and again on the next analysis."""
     be, stats = seams
     from optiland import analysis
     from optiland_amd import fingerprint as fp
@@ -359,7 +361,7 @@ def test_spot_diagram_validates_each_wavelength_once(seams, monkeypatch):
     assert stats["spot"] == 3 * n_w
     walks["n"] = 0
     analysis.SpotDiagram(lens, num_rings=3)
-    assert walks["n"] == n_w, (first, walks["n"])     # validated again, once per wavelength
+    assert walks["n"] == 1, (first, walks["n"], n_w)  # validated again: one walk, three tables
     comp = ig.hip_tracer_of(lens)
     assert comp._hip_trusted is None and comp._hip_trust_depth == 0
     # an edit between two analyses is seen

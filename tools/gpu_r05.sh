@@ -63,6 +63,28 @@ for leg in "$@"; do
       tail -3 $O/r05_rccl_alone.log ;;
     window_pmc)
       bash tools/gpu_window_pmc.sh > $O/r05_window_pmc.log 2>&1; tail -30 $O/r05_window_pmc.log ;;
+    ab)        # in-process A/B: ARMS=product,arith_r04 CONFIGS=dg_f64_gen,zf_f32_gen [ROUNDS=2] [AB_EXTRA=--placed]
+      timeout 600 python tools/ab_inproc.py --arms ${ARMS:-product} --configs ${CONFIGS:-dg_f32_gen} \
+        --rounds ${ROUNDS:-2} ${AB_EXTRA:-} >> $O/r05_ab_${TAG:-0}.txt 2>&1; tail -${AB_TAIL:-12} $O/r05_ab_${TAG:-0}.txt ;;
+    kernel_table) # rocprofv3 duration + SQ counters per ray of the dominant kernel, final library
+      bash tools/gpu_kernel_table.sh $O/r05_kernel_table.txt > /dev/null 2>&1 <<'CFG'
+dg_f32_gen  |
+dg_f64_gen  | --dtype f64
+rc_f32_gen  | --workload rc_asphere
+zf_f32_gen  | --workload zernike_fresnel
+zf_f64_gen  | --workload zernike_fresnel --dtype f64
+dg_f64_spot | --mode spot --dtype f64
+dg_opd      | --mode opd
+CFG
+      python - <<'PY'
+import json
+print(f"{'tag':<12} {'kernel':<58} {'us':>8} {'VALU/ray':>9} {'SALU/ray':>9} {'SMEM/ray':>8} {'issue_ms':>8} {'movedGB':>8} {'TB/s':>6} {'frac':>6}")
+for ln in open("gpurun_out/r05_kernel_table.txt"):
+    if not ln.startswith('{'): continue
+    r=json.loads(ln)
+    print(f"{r['tag']:<12} {r.get('kernel','?')[:58]:<58} {r.get('avg_us',0):8.1f} {r.get('VALU_per_ray',0):9.0f} {r.get('SALU_per_ray',0):9.0f} {r.get('SMEM_per_ray',0):8.0f} {r.get('valu_issue_ms',0):8.3f} {r.get('moved_GB',0):8.3f} {r.get('TBps_moved',0):6.2f} {r.get('frac',0):6.3f}")
+PY
+      ;;
     spotdiag)  # the reference's SpotDiagram through the seams: one launch per grid vs per cell
       timeout 600 python tools/gpu_r05_spotdiag.py > $O/r05_spotdiag.txt 2>&1; tail -5 $O/r05_spotdiag.txt | cut -c1-600 ;;
     bench1rank) # the N > 1 launch form with ONE rank: RCCL init, barrier, exchange legs, placement
