@@ -91,7 +91,8 @@ OL_DEV double div_f64(double a, double b) {
 // Newton step), 1 / d1 ~ d2 y, 1 / d2 ~ d1 y, each quotient then corrected once with its own
 // residual like div_f64 -- 12 vector instructions and one quarter-rate seed where two div_f64
 // take 20 and two.  The conic intersection forms C / q and q / A for every ray and surface
-// (standard.py:112-146): with the sign product of round 5 the fp64 surface goes 124 -> 114.
+// (standard.py:112-146): with the sign product of round 5 an fp64 surface goes 124 -> ~113
+// in the kernels that take it (curved_distance<V, SHARE>: the vector-issue-bound ones).
 // Lanes whose product d1 d2 is zero or infinite (a paraboloid met by an axis-parallel ray has
 // A = 0 exactly) take div_f64 -- per LANE, under a wave-uniform branch that such waves alone
 // enter: a ray's result never depends on its neighbours in the wave.
@@ -352,7 +353,13 @@ OL_DEV V flat_distance(V z, V N) {  // standard.py:108-111
   return -m::div(z, Ns);
 }
 
-template <typename V>
+// SHARE: the two quotients of the intersection from ONE reciprocal (Math<V>::div2; fp64 only
+// makes a difference).  On for the kernels that are bound by vector issue (fused spot / OPD /
+// chief ray, record-last: dg_f64_spot -4.0 / -5.5 %), OFF for the record-all kernels, which are
+// bound by their stores and measured 2.5-3.9 % SLOWER with it on a placed block
+// (profiles/r05_ab_arith.txt) -- stores that issue faster collide more, the same thing the
+// arithmetic-free fill shows when 8 FMAs are put in front of every store (§4.9).
+template <typename V, bool SHARE = false>
 OL_DEV V curved_distance(typename Math<V>::scalar cv,
                                              typename Math<V>::scalar kp1, V x, V y, V z, V L, V M,
                                              V N) {
@@ -366,7 +373,12 @@ OL_DEV V curved_distance(typename Math<V>::scalar cv,
   V sq = m::sqrt(disc);  // NaN when the ray misses (standard.py:132-137)
   V q = -(E + m::copysign(sq, E));
   V ta, tb;
-  m::div2(C, q, q, A, ta, tb);
+  if constexpr (SHARE) {
+    m::div2(C, q, q, A, ta, tb);
+  } else {
+    ta = m::div(C, q);
+    tb = m::div(q, A);
+  }
   // t_b is the reference's t1 iff -sgn(E) == sgn(R); the reference keeps t1 when
   // |z + t1 N| <= |z + t2 N| and t2 otherwise (also when the comparison is NaN)
   const auto b_is_t1 = m::same(m::lt(E, zero), m::all(cv > 0));
@@ -377,10 +389,10 @@ OL_DEV V curved_distance(typename Math<V>::scalar cv,
   return t;
 }
 
-template <typename T>
+template <typename T, bool SHARE = false>
 OL_DEV T conic_distance(const DevSurf<T>& s, T x, T y, T z, T L, T M, T N) {
   if (s.flags & kSurfRadiusInf) return flat_distance(z, N);
-  return curved_distance(s.cv, s.kp1, x, y, z, L, M, N);
+  return curved_distance<T, SHARE>(s.cv, s.kp1, x, y, z, L, M, N);
 }
 
 // Unit normal of the conic at the hit point (x, y, z).
@@ -1693,7 +1705,8 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
 // H: SurfLoaded<T> or SurfFetched<T> (device_table.h) -- `h.surf()` / `h.optics()` are asked
 // for again at every phase; with SurfFetched each call re-reads the table, so no table
 // field is live from one phase into the next.
-template <typename V, int RPT, int POLK, int NR, typename H>
+// SHARE: see curved_distance.
+template <typename V, int RPT, int POLK, int NR, bool SHARE = false, typename H>
 OL_DEV void surface_step(const H& h, cptr<typename Math<V>::scalar> coeffs, bool from_global,
                          Ray<V> (&r)[RPT],
                          Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
@@ -1734,7 +1747,8 @@ OL_DEV void surface_step(const H& h, cptr<typename Math<V>::scalar> coeffs, bool
       const T cv = s.cv, kp1 = s.kp1;
 #pragma unroll
       for (int k = 0; k < RPT; ++k)
-        t[k] = curved_distance<V>(cv, kp1, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M, r[k].N);
+        t[k] = curved_distance<V, SHARE>(cv, kp1, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M,
+                                         r[k].N);
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         r[k].x = m::fma(t[k], r[k].L, r[k].x);
@@ -1752,7 +1766,7 @@ OL_DEV void surface_step(const H& h, cptr<typename Math<V>::scalar> coeffs, bool
       max_iter = s.max_iter;
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
-        t[k] = conic_distance(s, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M, r[k].N);
+        t[k] = conic_distance<T, SHARE>(s, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M, r[k].N);
         q[k].xb = m::fma(t[k], r[k].L, r[k].x);
         q[k].yb = m::fma(t[k], r[k].M, r[k].y);
         q[k].zb = m::fma(t[k], r[k].N, r[k].z);
@@ -1841,7 +1855,7 @@ OL_DEV void surface_step(const H& h, cptr<typename Math<V>::scalar> coeffs, bool
 }
 
 // the rows loaded by the caller (lean kernels; tests)
-template <typename V, int RPT, int POLK, int NR>
+template <typename V, int RPT, int POLK, int NR, bool SHARE = false>
 OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
                          const DevOptics<typename Math<V>::scalar>& o,
                          cptr<typename Math<V>::scalar> coeffs, bool from_global,
@@ -1849,7 +1863,7 @@ OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
                          Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
                          uint32_t& status, bool& prt_fresh) {
   const SurfLoaded<typename Math<V>::scalar> h{s, o};
-  surface_step<V, RPT, POLK, NR>(h, coeffs, from_global, r, P, status, prt_fresh);
+  surface_step<V, RPT, POLK, NR, SHARE>(h, coeffs, from_global, r, P, status, prt_fresh);
 }
 
 // local -> global for the recorded state (coordinate_system.py:91-107)

@@ -668,7 +668,8 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
     if constexpr (kFetch) {
       const SurfFetched<T> h = fetched_surface<T, TraceArgs<T>>(s);
       if (refresh(h.hot)->interaction != kRecordOnly) {
-        surface_step<V, NV, POLK, NR>(h, refresh(coeffs_c), is_global, r, P, status, prt_fresh);
+        surface_step<V, NV, POLK, NR, !RECORD>(h, refresh(coeffs_c), is_global, r, P, status,
+                                               prt_fresh);
         is_global = false;
         last_idx = s;
       }
@@ -692,7 +693,8 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
 #else
         const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
 #endif
-        surface_step<V, NV, POLK, NR>(S, O, coeffs_c, is_global, r, P, status, prt_fresh);
+        surface_step<V, NV, POLK, NR, !RECORD>(S, O, coeffs_c, is_global, r, P, status,
+                                               prt_fresh);
         is_global = false;
         last_traced = S;
       }
@@ -1208,7 +1210,7 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
             return fetched_surface<T, SpotArgs<T>>(s_);
         }(s);
         if (refresh(h.hot)->interaction != kRecordOnly) {
-          surface_step<V, NV, 0, NR>(h, as_const(kernargs<T, SpotArgs<T>>()->coeffs), is_global, r,
+          surface_step<V, NV, 0, NR, true>(h, as_const(kernargs<T, SpotArgs<T>>()->coeffs), is_global, r,
                                      P, status, prt_fresh);
           is_global = false;
           last_idx = s;
@@ -1238,7 +1240,7 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
           } else {
             O = optics_tab[s * a.n_wl + a.wl];
           }
-          surface_step<V, NV, 0, NR>(S, O, as_const(coeff_tab), is_global, r, P, status,
+          surface_step<V, NV, 0, NR, true>(S, O, as_const(coeff_tab), is_global, r, P, status,
                                      prt_fresh);
           is_global = false;
           last_traced = S;
@@ -1430,7 +1432,7 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
       for (int sidx = first; sidx <= kernargs<T, OpdArgs<T>>()->a.last; ++sidx) {
         const SurfFetched<T> h = fetched_surface<T, OpdArgs<T>>(sidx);
         if (refresh(h.hot)->interaction != kRecordOnly) {
-          surface_step<T, 1, 0, NR>(h, as_const(kernargs<T, OpdArgs<T>>()->coeffs), is_global, r,
+          surface_step<T, 1, 0, NR, true>(h, as_const(kernargs<T, OpdArgs<T>>()->coeffs), is_global, r,
                                     P, status, prt_fresh);
           is_global = false;
           last_idx = sidx;
@@ -1453,7 +1455,8 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
         S.cold = as_const(cold_tab) + sidx;
         if (S.interaction != kRecordOnly) {
           const DevOptics<T> O = optics_tab[sidx * a.n_wl + a.wl];
-          surface_step<T, 1, 0, NR>(S, O, as_const(coeff_tab), is_global, r, P, status, prt_fresh);
+          surface_step<T, 1, 0, NR, true>(S, O, as_const(coeff_tab), is_global, r, P, status,
+                                          prt_fresh);
           is_global = false;
           last_traced = S;
         }
@@ -1584,7 +1587,7 @@ __global__ __launch_bounds__(64) void chief_ref_kernel(
     const SurfFetched<T> h{as_const(surf_tab) + s, as_const(cold_tab) + s,
                            as_const(optics_tab) + (s * a.n_wl + a.wl)};
     if (refresh(h.hot)->interaction != kRecordOnly) {
-      surface_step<T, 1, 0, NR>(h, as_const(coeff_tab), is_global, r, P, status, prt_fresh);
+      surface_step<T, 1, 0, NR, true>(h, as_const(coeff_tab), is_global, r, P, status, prt_fresh);
       is_global = false;
       last_idx = s;
     }

@@ -42,6 +42,11 @@ TAGS = {  # tag -> traffic key
     "r04_dg_f64_gen": "double_gauss:f64:gen",
     "r04_rc_f32_gen": "rc_asphere:f32:gen",
     "r04_zf_f32_gen": "zernike_fresnel:f32:gen",
+    # round 5 (tools/gpu_r05.sh prof): the final library
+    "r05_dg_f32_gen": "double_gauss:f32:gen",
+    "r05_dg_f64_gen": "double_gauss:f64:gen",
+    "r05_rc_f32_gen": "rc_asphere:f32:gen",
+    "r05_zf_f32_gen": "zernike_fresnel:f32:gen",
 }
 
 

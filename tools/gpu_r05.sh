@@ -87,6 +87,31 @@ PY
       ;;
     spotdiag)  # the reference's SpotDiagram through the seams: one launch per grid vs per cell
       timeout 600 python tools/gpu_r05_spotdiag.py > $O/r05_spotdiag.txt 2>&1; tail -5 $O/r05_spotdiag.txt | cut -c1-600 ;;
+    prof)      # rocprofv3 stats + PMC passes of the BASELINE configurations (tools/collect_profiles.py r05)
+      rocm-smi --showserial > $O/r05_box.txt 2>&1
+      bash tools/gpu_prof.sh r05_dg_f32_gen > $O/r05_prof.log 2>&1
+      bash tools/gpu_prof.sh r05_dg_f64_gen --dtype f64 >> $O/r05_prof.log 2>&1
+      bash tools/gpu_prof.sh r05_rc_f32_gen --workload rc_asphere >> $O/r05_prof.log 2>&1
+      bash tools/gpu_prof.sh r05_zf_f32_gen --workload zernike_fresnel >> $O/r05_prof.log 2>&1
+      grep -h "trace_kernel" $O/prof_r05_*/summary.txt | head -8 ;;
+    benches)   # the other BASELINE configurations, steady state included (no baselines)
+      for cfg in "dg_f64:--dtype f64" "c4_f32:--workload rc_asphere" "c4_f64:--workload rc_asphere --dtype f64" \
+                 "c5_f32:--workload zernike_fresnel" "c5_f64:--workload zernike_fresnel --dtype f64" \
+                 "dg_f64_spot:--mode spot --dtype f64" "dg_opd:--mode opd"; do
+        tag=${cfg%%:*}; args=${cfg#*:}
+        python bench.py --steps 20 --warmup 5 --no-cpu-baseline --traffic committed $args \
+          > $O/r05_bench_$tag.json 2> $O/r05_bench_$tag.err
+        python - $O/r05_bench_$tag.json $tag <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    r = d["roofline"]; st = r.get("steady_state") or {}
+    print(f"{sys.argv[2]:12s} value {d['value']:.4g} kernel_ms {r['kernel_ms']:.4f} ({r['kernel_us_minmax']}) frac {r['frac']:.3f}"
+          f" steady {st.get('kernel_ms')} frac {st.get('frac')} placed {(r.get('record_placement') or {}).get('placed')}")
+except Exception as e:
+    print(sys.argv[2], "ERR", e)
+PY
+      done ;;
     bench1rank) # the N > 1 launch form with ONE rank: RCCL init, barrier, exchange legs, placement
       python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
         bench.py --gpus 1 --force-exchange --steps 20 --warmup 5 --no-cpu-baseline --no-ref-baselines --traffic committed \
