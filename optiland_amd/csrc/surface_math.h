@@ -354,11 +354,13 @@ OL_DEV V flat_distance(V z, V N) {  // standard.py:108-111
 }
 
 // SHARE: the two quotients of the intersection from ONE reciprocal (Math<V>::div2; fp64 only
-// makes a difference).  On for the kernels that are bound by vector issue (fused spot / OPD /
-// chief ray, record-last: dg_f64_spot -4.0 / -5.5 %), OFF for the record-all kernels, which are
-// bound by their stores and measured 2.5-3.9 % SLOWER with it on a placed block
-// (profiles/r05_ab_arith.txt) -- stores that issue faster collide more, the same thing the
-// arithmetic-free fill shows when 8 FMAs are put in front of every store (§4.9).
+// makes a difference).  Measured arm against arm in one process (profiles/r05_ab_arith.txt):
+// ON where vector issue binds and a lane carries two rays whose chains interleave -- the fused
+// fp64 spot kernel -4 ... -5 %, on the asphere system -1 ... -3 %; OFF in the record-all kernels,
+// which are bound by their stores and ran 2.5-3.9 % SLOWER with it on a placed block (stores
+// that issue faster collide more: the arithmetic-free fill GAINS 5 % when 8 FMAs are put in
+// front of every store), and OFF with one ray per lane (fused OPD kernel: the one
+// long dependent chain cost 7-9 % more than the eight instructions saved).
 template <typename V, bool SHARE = false>
 OL_DEV V curved_distance(typename Math<V>::scalar cv,
                                              typename Math<V>::scalar kp1, V x, V y, V z, V L, V M,

@@ -638,6 +638,12 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
   constexpr bool kFetch = fetch_level<T, NR, false, POLK>() >= 2;      // table rows
   constexpr bool kFetchArgs = fetch_level<T, NR, false, POLK>() >= 1;  // argument block
   const cptr<T> coeffs_c = as_const(coeff_tab);
+  // one reciprocal for both quotients of the conic intersection (curved_distance<V, SHARE>):
+  // only where vector issue binds AND a lane carries more than one ray -- record-last traces
+  // on vectors of rays.  Record-all kernels are bound by their stores (-2.5 ... -3.9 % with it);
+  // with one ray per lane the longer dependent chain costs more than the 8 instructions save
+  // (fused OPD kernel: -7 ... -9 %, profiles/r05_ab_arith.txt).
+  constexpr bool kShareRcp = !RECORD && RPT > 1;
   DevSurf<T> last_traced;
   last_traced.cold = as_const(cold_tab);
   int last_idx = a.first;  // kFetch: the surface whose frame r[] is held in
@@ -668,7 +674,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
     if constexpr (kFetch) {
       const SurfFetched<T> h = fetched_surface<T, TraceArgs<T>>(s);
       if (refresh(h.hot)->interaction != kRecordOnly) {
-        surface_step<V, NV, POLK, NR, !RECORD>(h, refresh(coeffs_c), is_global, r, P, status,
+        surface_step<V, NV, POLK, NR, kShareRcp>(h, refresh(coeffs_c), is_global, r, P, status,
                                                prt_fresh);
         is_global = false;
         last_idx = s;
@@ -693,7 +699,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
 #else
         const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
 #endif
-        surface_step<V, NV, POLK, NR, !RECORD>(S, O, coeffs_c, is_global, r, P, status,
+        surface_step<V, NV, POLK, NR, kShareRcp>(S, O, coeffs_c, is_global, r, P, status,
                                                prt_fresh);
         is_global = false;
         last_traced = S;
@@ -1210,7 +1216,7 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
             return fetched_surface<T, SpotArgs<T>>(s_);
         }(s);
         if (refresh(h.hot)->interaction != kRecordOnly) {
-          surface_step<V, NV, 0, NR, true>(h, as_const(kernargs<T, SpotArgs<T>>()->coeffs), is_global, r,
+          surface_step<V, NV, 0, NR, (RPT > 1)>(h, as_const(kernargs<T, SpotArgs<T>>()->coeffs), is_global, r,
                                      P, status, prt_fresh);
           is_global = false;
           last_idx = s;
@@ -1240,7 +1246,7 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
           } else {
             O = optics_tab[s * a.n_wl + a.wl];
           }
-          surface_step<V, NV, 0, NR, true>(S, O, as_const(coeff_tab), is_global, r, P, status,
+          surface_step<V, NV, 0, NR, (RPT > 1)>(S, O, as_const(coeff_tab), is_global, r, P, status,
                                      prt_fresh);
           is_global = false;
           last_traced = S;
@@ -1432,7 +1438,7 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
       for (int sidx = first; sidx <= kernargs<T, OpdArgs<T>>()->a.last; ++sidx) {
         const SurfFetched<T> h = fetched_surface<T, OpdArgs<T>>(sidx);
         if (refresh(h.hot)->interaction != kRecordOnly) {
-          surface_step<T, 1, 0, NR, true>(h, as_const(kernargs<T, OpdArgs<T>>()->coeffs), is_global, r,
+          surface_step<T, 1, 0, NR>(h, as_const(kernargs<T, OpdArgs<T>>()->coeffs), is_global, r,
                                     P, status, prt_fresh);
           is_global = false;
           last_idx = sidx;
@@ -1455,8 +1461,7 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
         S.cold = as_const(cold_tab) + sidx;
         if (S.interaction != kRecordOnly) {
           const DevOptics<T> O = optics_tab[sidx * a.n_wl + a.wl];
-          surface_step<T, 1, 0, NR, true>(S, O, as_const(coeff_tab), is_global, r, P, status,
-                                          prt_fresh);
+          surface_step<T, 1, 0, NR>(S, O, as_const(coeff_tab), is_global, r, P, status, prt_fresh);
           is_global = false;
           last_traced = S;
         }
@@ -1587,7 +1592,7 @@ __global__ __launch_bounds__(64) void chief_ref_kernel(
     const SurfFetched<T> h{as_const(surf_tab) + s, as_const(cold_tab) + s,
                            as_const(optics_tab) + (s * a.n_wl + a.wl)};
     if (refresh(h.hot)->interaction != kRecordOnly) {
-      surface_step<T, 1, 0, NR, true>(h, as_const(coeff_tab), is_global, r, P, status, prt_fresh);
+      surface_step<T, 1, 0, NR>(h, as_const(coeff_tab), is_global, r, P, status, prt_fresh);
       is_global = false;
       last_idx = s;
     }

@@ -379,9 +379,10 @@ class HipSystem:
             _POOL_COOLDOWN[dev] = _POOL_CONFIG["cooldown"]
         # (a pool whose probe found no window stays registered -- empty, without arenas -- so
         # that the shape is not probed again)
+        # (one arena in three to seven holds no fast window, profiles/r05_vmm_junctions.txt,
+        # r04_placement_attempts.txt: up to three are tried; those without one go straight back)
         pool = _RECORD_POOLS[key] = RecordPool(self, n, dtype, rows, 2 if auto else slots,
-                                               arena_bytes=arena_bytes,
-                                               max_arenas=2 if auto else 3)
+                                               arena_bytes=arena_bytes, max_arenas=3)
         return pool
 
     def alloc_record(self, n: int, dtype, rows: int | None = None) -> torch.Tensor:

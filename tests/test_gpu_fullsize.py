@@ -653,7 +653,7 @@ def test_auto_pool_waits_for_a_loop_and_an_evicted_pool_outlives_its_leases(dg):
             if free >= total // 2:
                 assert len(E._RECORD_POOLS) == 1
                 pool = next(iter(E._RECORD_POOLS.values()))
-                assert pool.info["slots"] <= 2 and pool.info["arenas"] <= 2
+                assert pool.info["slots"] <= 2 and pool.info["arenas"] <= 3
             assert hip.alloc_record(1000, dtype).numel() and len(E._RECORD_POOLS) <= 1
             del first, second
         # (b) explicit count: pools from the first request on

@@ -374,7 +374,7 @@ def test_record_pool_policy_auto_lru_and_cooldown(monkeypatch):
         assert hip._pool_for(1000, f32, 13, 1 << 20) is None            # small: never
         assert hip._pool_for(10, f32, 13, big) is None and not built    # first request: plain
         assert hip._pool_for(10, f32, 13, big) is not None              # second: a pool
-        assert built == [(10, 2, 40 << 30, 2)]
+        assert built == [(10, 2, 40 << 30, 3)]
         assert hip._pool_for(10, f32, 13, big) is not None and len(built) == 1   # (kept, empty)
         hip.free = 100 << 30                                            # memory is short
         assert hip._pool_for(11, f32, 13, big) is None

@@ -39,6 +39,8 @@ CONFIGS = {  # name -> (workload, dtype, mode)
     "dg_f64_spot": ("double_gauss", "f64", "spot"),
     "rc_f64_spot": ("rc_asphere", "f64", "spot"),
     "z_f64_spot": ("zernike", "f64", "spot"),
+    "dg_opd": ("double_gauss", "f64", "opd"),
+    "z_opd": ("zernike", "f64", "opd"),
 }
 
 
@@ -85,10 +87,20 @@ def main():
                             dtype=dtype, device=dev)
         prt = torch.empty((18 if table.needs_complex_prt else 9, n), dtype=dtype, device=dev) \
             if pol else None
-        mom = torch.zeros(7, dtype=torch.float64, device=dev)
+        mom = torch.zeros(12 if mode == "opd" else 7, dtype=torch.float64, device=dev)
+        opd_params = None
+        if mode == "opd":
+            from optiland_amd.tracer import HipRayTracer
+            from optiland_amd.wavefront import Wavefront
+            wf = Wavefront(HipRayTracer(table, dev, dtype=torch.float64, engine=first), (0.0, hy),
+                           wavelength, num_rays=3)
+            opd_params = wf.chief_reference()[0]
 
         def launch(hip):
-            if mode == "gen":
+            if mode == "opd":
+                hip.trace_opd(opd_params, px, py, wl, field=(0.0, hy), want_pupil=True,
+                              moments=mom, check_status=False)
+            elif mode == "gen":
                 hip.trace_generate(px, py, wl, field=(0.0, hy), record=record, prt=prt,
                                    zero_status=False, defer_status=True)
             else:
