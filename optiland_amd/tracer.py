@@ -101,6 +101,13 @@ def _shared_pupil_planes(key, dtype, device, to_device, engine=None):
     return hit
 
 
+def _broadcast_message(a: int, b: int) -> str:
+    """NumPy's text for the mismatch the reference runs into when Hx, Hy, Px, Py are arrays of
+    different lengths (real_ray_tracer.py:175-194 pads scalars only; the first array operation
+    of the generator then fails to broadcast)."""
+    return f"operands could not be broadcast together with shapes ({int(a)},) ({int(b)},) "
+
+
 def _can_field_planes(can) -> bool:
     try:
         return bool(can(field_planes=True))
@@ -486,14 +493,14 @@ class HipRayTracer:
             n = max(a.numel() for a in (hx, hy, px, py))
             hx, hy = (a.expand(n).contiguous() if a.numel() == 1 else a for a in (hx, hy))
             if hx.numel() != n or hy.numel() != n:
-                raise ValueError("Hx, Hy, Px, Py must be scalars or arrays of one common size")
+                raise ValueError(_broadcast_message(n, min(hx.numel(), hy.numel())))
             vxf, vyf = self._vig_factor(hx, hy)
             vignetted = vxf is not None
             vig = (1 - vxf, 1 - vyf) if vignetted else (None, None)
             flags |= _capi.RAYGEN_CHECK_FIELD
         px, py = (a.expand(n).contiguous() if a.numel() == 1 else a for a in (px, py))
         if px.numel() != n or py.numel() != n:
-            raise ValueError("Hx, Hy, Px, Py must be scalars or arrays of one common size")
+            raise ValueError(_broadcast_message(n, min(px.numel(), py.numel())))
         if vignetted:
             flags |= _capi.RAYGEN_PRESCALE_PUPIL
         return self._run(hx, hy, px, py, vig, wavelength, update_intensity=False, flags=flags)
