@@ -41,6 +41,8 @@ for leg in "$@"; do
     split)     # a displacement between two groups of planes inside ONE allocation
       timeout 300 tools/microbench/split_offset > $O/r05_split_offset.txt 2>&1; echo "rc=$?" >> $O/r05_split_offset.txt
       grep -c . $O/r05_split_offset.txt ;;
+    pace)      # evenly paced stores against rows of 8 back to back (tools/microbench/pace_probe.hip)
+      timeout 300 tools/microbench/pace_probe > $O/r05_pace_probe.txt 2>&1; cat $O/r05_pace_probe.txt ;;
     debugfs)   # can the box show where a buffer lies physically?
       (mount -t debugfs none /sys/kernel/debug 2>&1; ls /sys/kernel/debug/dri/ 2>&1 | head; ls /sys/class/kfd/kfd/topology/nodes/ 2>&1;
        cat /sys/module/amdgpu/version 2>&1; uname -r; cat /sys/class/drm/card*/device/mem_info_vram_total 2>&1 | head -3;
