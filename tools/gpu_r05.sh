@@ -43,6 +43,8 @@ for leg in "$@"; do
       grep -c . $O/r05_split_offset.txt ;;
     pace)      # evenly paced stores against rows of 8 back to back (tools/microbench/pace_probe.hip)
       timeout 300 tools/microbench/pace_probe > $O/r05_pace_probe.txt 2>&1; cat $O/r05_pace_probe.txt ;;
+    lottery)   # how often a junction of two pieces makes a fast block, by the pieces' sizes
+      timeout 600 tools/microbench/vmm_lottery ${LOTTERY_REPS:-6} > $O/r05_vmm_lottery.txt 2>&1; cat $O/r05_vmm_lottery.txt ;;
     debugfs)   # can the box show where a buffer lies physically?
       (mount -t debugfs none /sys/kernel/debug 2>&1; ls /sys/kernel/debug/dri/ 2>&1 | head; ls /sys/class/kfd/kfd/topology/nodes/ 2>&1;
        cat /sys/module/amdgpu/version 2>&1; uname -r; cat /sys/class/drm/card*/device/mem_info_vram_total 2>&1 | head -3;
