@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import collections
 import ctypes as C
+import threading
 import os
 
 import numpy as np
@@ -94,6 +95,7 @@ def _default_slots():
 _POOL_CONFIG = {"slots": _default_slots(), "min_bytes": 256 << 20, "max_pools": 2,
                 "cooldown": 64}
 _RECORD_POOLS: "collections.OrderedDict" = collections.OrderedDict()  # key -> RecordPool (LRU)
+_POOL_LOCK = threading.RLock()  # pools are process-wide; traces may come from several threads
 _SHAPE_SEEN: dict = {}     # key -> requests so far ("auto": the second one builds the pool)
 _POOL_COOLDOWN: dict = {}  # device index -> big allocations left before another pool is built
 
@@ -325,18 +327,20 @@ class HipSystem:
         "auto" (the default): two, from the SECOND request of a shape on and only while the
         device has memory to spare; 0 = off (the pools and their arenas go).  Further blocks
         are ordinary allocations; the two most recently used shapes per device are kept."""
-        _POOL_CONFIG["slots"] = "auto" if slots == "auto" else max(int(slots), 0)
-        _POOL_CONFIG["min_bytes"] = int(min_bytes)
-        if not _POOL_CONFIG["slots"]:
-            _RECORD_POOLS.clear()
-        _SHAPE_SEEN.clear()
-        _POOL_COOLDOWN.clear()
+        with _POOL_LOCK:
+            _POOL_CONFIG["slots"] = "auto" if slots == "auto" else max(int(slots), 0)
+            _POOL_CONFIG["min_bytes"] = int(min_bytes)
+            if not _POOL_CONFIG["slots"]:
+                _RECORD_POOLS.clear()
+            _SHAPE_SEEN.clear()
+            _POOL_COOLDOWN.clear()
 
     @staticmethod
     def reset_record_pool() -> None:
         """Back to the default policy (OPTILAND_HIP_PLACED_RECORDS, else "auto"); pools go."""
-        _RECORD_POOLS.clear()
-        HipSystem.enable_record_pool(_default_slots())
+        with _POOL_LOCK:
+            _RECORD_POOLS.clear()
+            HipSystem.enable_record_pool(_default_slots())
 
     def _auto_arena_bytes(self, need: int):
         """Arena size of an "auto" pool, or None when the device cannot spare one: at least
@@ -354,6 +358,10 @@ class HipSystem:
         if not slots or need < _POOL_CONFIG["min_bytes"] or self.device.type != "cuda" \
                 or not hasattr(self.lib, "ol_stream_fill"):
             return None
+        with _POOL_LOCK:
+            return self._pool_for_locked(n, dtype, rows, need, slots)
+
+    def _pool_for_locked(self, n, dtype, rows, need, slots):
         dev = self.device.index
         key = (dev, int(n), dtype, rows)
         pool = _RECORD_POOLS.get(key)

@@ -361,6 +361,7 @@ def test_record_pool_policy_auto_lru_and_cooldown(monkeypatch):
     class Sys:
         device, lib = Dev(), Lib()
         _pool_for = E.HipSystem._pool_for
+        _pool_for_locked = E.HipSystem._pool_for_locked
         free = 200 << 30
 
         def _auto_arena_bytes(self, need):
