@@ -116,6 +116,8 @@ except Exception as e:
     print(sys.argv[2], "ERR", e)
 PY
       done ;;
+    smoke)     # what the driver runs before its bench
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" > $O/r05_smoke.log 2>&1; tail -4 $O/r05_smoke.log ;;
     bench1rank) # the N > 1 launch form with ONE rank: RCCL init, barrier, exchange legs, placement
       python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
         bench.py --gpus 1 --force-exchange --steps 20 --warmup 5 --no-cpu-baseline --no-ref-baselines --traffic committed \
