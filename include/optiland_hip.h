@@ -138,6 +138,14 @@ typedef enum ol_coating_kind {
 } ol_coating_kind;
 
 #define OL_SURF_ROTATED 0x1u /* rot[] is not the identity */
+#define OL_SURF_REFERENCE_ROOT 0x2u /* ABI 10, OL_GEOM_STANDARD with a finite radius only: the
+                                       intersection in the reference's own form, (-b +- sqrt d) /
+                                       2a with R-scaled coefficients (geometries/standard.py:
+                                       112-146), instead of the cancellation-free one -- for
+                                       callers who need the reference's NUMBERS where its formula
+                                       is ill conditioned (|1 + k| << 1: goldens generated with it
+                                       encode its systematic error, e.g. tests/test_operand.py
+                                       test_opd_diff_on_axis).  Default off: less accurate         */
 
 /* One traced surface.  All lengths in mm, angles already folded into rot[]. */
 typedef struct ol_surface_desc {

@@ -219,6 +219,7 @@ struct HostSurf {
   int32_t poly_cols, coeff_len, ap_off, ap_len;
   double cv, kp1, tol, inv_norm;
   double origin[3], rot[9], rel_off[3], rel_rot[9], ap[4], coat[2], axis[3], ret_cos, ret_sin;
+  double radius, conic;
 };
 
 template <typename T>
@@ -307,6 +308,7 @@ int upload(const std::vector<HostSurf>& surf64,
     for (int k = 0; k < 2; ++k) c.coat[k] = (T)a.coat[k];
     for (int k = 0; k < 3; ++k) c.axis[k] = (T)a.axis[k];
     c.ret_cos = (T)a.ret_cos; c.ret_sin = (T)a.ret_sin;
+    c.radius = (T)a.radius; c.conic = (T)a.conic;
   }
   for (size_t i = 0; i < n_opt; ++i) {
     opt[i].n1 = (T)opt64[i].n1; opt[i].n2 = (T)opt64[i].n2; opt[i].u = (T)opt64[i].u;
@@ -765,8 +767,12 @@ int stage_system(const char* who, const ol_surface_desc* surf, int32_t n_surf,
     d.flags = (s.flags & OL_SURF_ROTATED) ? ol::kSurfRotated : 0u;
     const bool inf_r = std::isinf(s.radius) || s.geom_kind == OL_GEOM_PLANE;
     if (inf_r) d.flags |= ol::kSurfRadiusInf;
+    if ((s.flags & OL_SURF_REFERENCE_ROOT) && s.geom_kind == OL_GEOM_STANDARD && !inf_r)
+      d.flags |= ol::kSurfReferenceRoot;
     d.cv = inf_r ? 0.0 : 1.0 / s.radius;
     d.kp1 = 1.0 + s.conic;
+    d.radius = s.radius;
+    d.conic = s.conic;
     d.tol = s.tol;
     d.inv_norm = s.norm_radius != 0.0 ? 1.0 / s.norm_radius : 0.0;
     for (int k = 0; k < 3; ++k) d.origin[k] = s.origin[k];

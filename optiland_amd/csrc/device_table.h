@@ -106,6 +106,7 @@ enum : int {
 constexpr uint32_t kSurfRotated = 0x1u;     // this surface's own frame is rotated
 constexpr uint32_t kSurfRelRotated = 0x2u;  // transform from the previous frame rotates
 constexpr uint32_t kSurfRadiusInf = 0x4u;   // |R| = inf (standard.py:108-111 branch)
+constexpr uint32_t kSurfReferenceRoot = 0x8u;  // OL_SURF_REFERENCE_ROOT on a curved standard surface
 
 // Hot part: everything a plain conic surface needs, exactly 16 elements so the
 // kernel fetches it with ONE s_load_dwordx16 (fp32) / two (fp64) per surface and
@@ -142,6 +143,7 @@ struct DevSurfCold {
   T coat[2];           // simple coating: T, R
   T axis[3];           // polarizer / retarder axis (normalised)
   T ret_cos, ret_sin;  // retarder: cos(d/2), sin(d/2)
+  T radius, conic;     // as given (kSurfReferenceRoot: the reference's own R-scaled quadratic)
 };
 
 // What the device functions see: the hot block BY VALUE (SGPRs) + a pointer to

@@ -391,6 +391,37 @@ OL_DEV V curved_distance(typename Math<V>::scalar cv,
   return t;
 }
 
+// OL_SURF_REFERENCE_ROOT (opt-in, per surface): the intersection in the reference's OWN form
+// (standard.py:112-146) -- the quadratic in R-scaled coefficients, both roots from
+// (-b +- sqrt(d)) / (2 a), nothing contracted into FMAs -- instead of the cancellation-free
+// form above.  The two agree to rounding wherever the reference's formula is well conditioned;
+// where it is not (|a| = |1 + k| << 1 with near-axial rays: a nearly parabolic mirror) the
+// reference carries a SYSTEMATIC error of eps |b| / |2a| in t, and goldens generated with it
+// encode that error: the Hubble on-axis `OPD_difference` of the reference's test_operand.py is
+// 0.00132951 waves with this form and 0.00132994 with the stable one, against a tolerance of
+// 1.1e-7.  (One-ulp changes of the inputs move it by 7e-9: the form matters, not the bits.)
+// (R and k as given: with |a| << 1 even one ulp of R = 1 / cv moves t by eps |R| / |a|.)
+template <typename V>
+OL_DEV V reference_distance(typename Math<V>::scalar R, typename Math<V>::scalar k, V x, V y,
+                            V z, V L, V M, V N) {
+#pragma clang fp contract(off)
+  using m = Math<V>;
+  using T = typename m::scalar;
+  const V NN = N * N, zz = z * z;
+  const V a = ((m::splat(k) * NN + L * L) + M * M) + NN;
+  const V b = ((((m::splat(T(2) * k) * N) * z + (m::splat(2) * L) * x) + (m::splat(2) * M) * y) -
+               (m::splat(2) * N) * m::splat(R)) + (m::splat(2) * N) * z;
+  const V c = (((m::splat(k) * zz - m::splat(T(2) * R) * z) + x * x) + y * y) + zz;
+  const V d = b * b - (m::splat(4) * a) * c;
+  const V sq = m::sqrt(d);  // NaN when the ray misses (standard.py:132-137)
+  const V two_a = m::splat(2) * a;
+  const V t1 = m::div(-b + sq, two_a), t2 = m::div(-b - sq, two_a);
+  const V z1 = m::abs(z + t1 * N), z2 = m::abs(z + t2 * N);
+  V t = m::select(m::le(z1, z2), t1, t2);
+  t = m::select(m::eq(a, m::splat(0)), m::div(-c, b), t);
+  return t;
+}
+
 template <typename T, bool SHARE = false>
 OL_DEV T conic_distance(const DevSurf<T>& s, T x, T y, T z, T L, T M, T N) {
   if (s.flags & kSurfRadiusInf) return flat_distance(z, N);
@@ -1747,10 +1778,20 @@ OL_DEV void surface_step(const H& h, cptr<typename Math<V>::scalar> coeffs, bool
       }
     } else {
       const T cv = s.cv, kp1 = s.kp1;
+#ifndef OL_REFERENCE_ROOT
+#define OL_REFERENCE_ROOT 1   // 0: the opt-in reference-formula root compiled out (A/B knob)
+#endif
+      if (OL_REFERENCE_ROOT && (s.flags & kSurfReferenceRoot)) {  // surface-uniform, opt-in
+        const T Rr = s.cold->radius, kr = s.cold->conic;
 #pragma unroll
-      for (int k = 0; k < RPT; ++k)
-        t[k] = curved_distance<V, SHARE>(cv, kp1, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M,
-                                         r[k].N);
+        for (int k = 0; k < RPT; ++k)
+          t[k] = reference_distance<V>(Rr, kr, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M, r[k].N);
+      } else {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+          t[k] = curved_distance<V, SHARE>(cv, kp1, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M,
+                                           r[k].N);
+      }
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         r[k].x = m::fma(t[k], r[k].L, r[k].x);

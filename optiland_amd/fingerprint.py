@@ -234,10 +234,16 @@ def _surface_token_native(s, keep, memo):
 surface_token = _surface_token_native if _NATIVE is not None else _surface_token_py
 
 
+def _packing_options():
+    from . import system as S
+    return bool(S.OPTIONS["reference_root"])
+
+
 def surfaces_token(surfaces, wavelength):
     """Token of a SurfaceGroup's surface list (what `packer.pack_surfaces` reads)."""
     keep, memo = [], {}
-    return (float(wavelength), tuple(surface_token(s, keep, memo) for s in surfaces)), keep
+    return (float(wavelength), tuple(surface_token(s, keep, memo) for s in surfaces),
+            _packing_options()), keep
 
 
 def optic_token(optic, wavelength):
@@ -256,5 +262,6 @@ def optic_token(optic, wavelength):
         pol if isinstance(pol, str) else _obj(pol, keep, memo),
         bool(getattr(optic, "obj_space_telecentric", False)),
         getattr(optic.ray_tracer, "ray_aiming_config", {}).get("mode", "paraxial"),
+        _packing_options(),
     )
     return tok, keep

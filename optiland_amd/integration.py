@@ -1201,7 +1201,18 @@ def _set_record_pool(placed_records):
         HipSystem.enable_record_pool(2 if placed_records is True else int(placed_records))
 
 
-def enable(device=None, force=False, analyses=True, lazy_records=False, placed_records=None):
+def _set_reference_root(reference_root):
+    """`reference_root` of enable() / install(): None = leave as is (OPTILAND_HIP_REFERENCE_ROOT=1
+    seeds it).  The option is part of every change-detector token and of the packer's cache
+    keys: tables packed before a change are re-packed at the next trace."""
+    if reference_root is not None:
+        from . import system as _S
+
+        _S.OPTIONS["reference_root"] = bool(reference_root)
+
+
+def enable(device=None, force=False, analyses=True, lazy_records=False, placed_records=None,
+           reference_root=None):
     """Route EVERY `Optic` (existing and future) through the HIP path.
 
     Patches `RealRayTracer.trace / trace_generic` (raytrace/real_ray_tracer.py:58-154)
@@ -1234,8 +1245,17 @@ def enable(device=None, force=False, analyses=True, lazy_records=False, placed_r
     behind the windows (~40 GiB per shape on the boxes measured, the two most recently used
     shapes kept) and ~0.3 s of probing.  "auto" builds the pool at the SECOND trace of a shape
     (a loop, not a one-off) and only while at least half of the device memory is free.
+
+    `reference_root` (default off): conic surfaces are intersected in the reference's OWN form,
+    `(-b +- sqrt(d)) / 2a` with R-scaled coefficients (geometries/standard.py:112-146), instead
+    of the cancellation-free form -- for users who need the reference's NUMBERS where its
+    formula is ill conditioned (a nearly parabolic mirror, `|1 + k| << 1`): there the reference
+    is off by up to `eps |b| / |2a|` in the intersection distance, systematically, and its own
+    golden `tests/test_operand.py::test_opd_diff_on_axis` (Hubble, on axis) encodes that: it
+    passes through the drop-in with this option and misses by 4e-7 waves without it.
     """
     _set_record_pool(placed_records)
+    _set_reference_root(reference_root)
     cls = _make_tracer_class()
     from optiland.raytrace.real_ray_tracer import RealRayTracer
 
@@ -1297,11 +1317,12 @@ def disable():
 
 
 def install(optic, device=None, force=False, analyses=True, lazy_records=False,
-            placed_records=None):
+            placed_records=None, reference_root=None):
     """Replace `optic.ray_tracer` with the HIP tracer (keeps the aiming config).  `analyses`,
     `lazy_records`: see `enable()` -- the class-wide analysis seams only act on optics the
     drop-in serves."""
     _set_record_pool(placed_records)
+    _set_reference_root(reference_root)
     cls = _make_tracer_class()
     if analyses:
         from . import analysis_seams

@@ -318,6 +318,8 @@ def _pack_surface_local(is_object: bool, surf, wl):
     row["origin"] = t
     row["rot"] = R.reshape(-1)
     row["flags"] = 0 if (R is _EYE3 or np.array_equal(R, _EYE3)) else S.SURF_ROTATED
+    if S.OPTIONS["reference_root"]:   # (the C side honours it on curved standard surfaces only)
+        row["flags"] |= S.SURF_REFERENCE_ROOT
     im = surf.interaction_model
     if type(im).__name__ != "RefractiveReflectiveModel":
         raise UnsupportedSystem(
@@ -416,7 +418,7 @@ def pack_surfaces(surfaces, wavelengths, name: str = "surfaces",
     surfaces = list(surfaces)
     unsupported: list = []
     wl = np.array([float(w) for w in np.atleast_1d(wavelengths)], dtype=np.float64)
-    wl_key = wl.tobytes()
+    wl_key = wl.tobytes() + (b"|reference_root" if S.OPTIONS["reference_root"] else b"")
     n_s = len(surfaces)
     use_cache = cache is not None and tokens is not None and len(tokens) == n_s
     if use_cache:

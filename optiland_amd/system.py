@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import json
 import math
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -31,6 +32,9 @@ AP_POLYGON = 6
 AP_OP_UNION, AP_OP_INTERSECTION, AP_OP_DIFFERENCE = 10, 11, 12
 COAT_NONE, COAT_SIMPLE, COAT_FRESNEL, COAT_POLARIZER, COAT_RETARDER = 0, 1, 2, 3, 4
 SURF_ROTATED = 0x1
+SURF_REFERENCE_ROOT = 0x2   # OL_SURF_REFERENCE_ROOT
+# packing options (process-wide; `integration.enable(reference_root=...)` sets them)
+OPTIONS = {"reference_root": os.environ.get("OPTILAND_HIP_REFERENCE_ROOT", "0") == "1"}
 
 STATUS_ZERNIKE_RANGE = 0x1
 STATUS_K_PARALLEL_X = 0x2

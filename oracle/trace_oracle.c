@@ -405,9 +405,11 @@ static double conic_distance(double R, double k, double x, double y, double z,
     double N_safe = fabs(N) > 1e-14 ? N : 1e-14;
     return -z / N_safe;
   }
-  double a = k * N * N + L * L + M * M + N * N;
+  /* (NumPy's association: `self.k * rays.N**2` is k (N N), not (k N) N -- where the formula
+   * is ill conditioned, |1 + k| << 1, that last bit shows at 1e-9 mm) */
+  double a = k * (N * N) + L * L + M * M + N * N;
   double b = 2 * k * N * z + 2 * L * x + 2 * M * y - 2 * N * R + 2 * N * z;
-  double c = k * z * z - 2 * R * z + x * x + y * y + z * z;
+  double c = k * (z * z) - 2 * R * z + x * x + y * y + z * z;
   double d = b * b - 4 * a * c;
   double sq = sqrt(d); /* NaN for d < 0, silently (standard.py:132-137) */
   double t1 = (-b + sq) / (2 * a);

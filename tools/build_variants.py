@@ -79,6 +79,9 @@ VARIANTS = {
     "div2_off": ["-DOL_DIV2_F64=0"],
     "snell_r04": ["-DOL_SNELL_SIGN_ON_ROOT=0"],
     "arith_r04": ["-DOL_DIV2_F64=0", "-DOL_SNELL_SIGN_ON_ROOT=0"],
+    # the opt-in reference-formula conic root compiled out (what its launch-uniform branch costs
+    # the kernels that never take it)
+    "no_refroot": ["-DOL_REFERENCE_ROOT=0"],
 }
 
 
