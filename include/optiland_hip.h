@@ -376,6 +376,20 @@ typedef struct ol_raygen_inputs {
                                       scales it again (ray_aiming/paraxial.py:60-62,
                                       90-91) -- SURVEY.md Appendix D                */
 
+/* ABI 10, ol_trace_spot / ol_trace_spot_batch only:                                        */
+#define OL_SPOT_POLARIZED_OK 0x8u  /* the optic HAS a polarization state.  What a spot diagram
+                                      reads of a polarised trace is the RECORDED last row
+                                      (analysis/spot_diagram/core.py:462-468): positions and the
+                                      geometric intensity -- clipping, absorption, SimpleCoating;
+                                      Fresnel / polarizer / retarder coatings only act on the PRT
+                                      matrix (interactions/base.py:111-128, rays/polarized_rays.py:
+                                      136-202) and update_intensity's result never reaches that row
+                                      (SURVEY.md Appendix D).  With this flag systems with
+                                      polarization-dependent coatings are traced instead of refused */
+#define OL_SPOT_HITS_LOCAL 0x10u   /* hits and moments in the LAST surface's own frame instead of
+                                      the global one: SpotDiagram(coordinates="local") on a tilted
+                                      image surface (visualization/system/utils.py:17-47)           */
+
 /* out[0..6]: x,y,z,L,M,N,i planes (i = 1); out[7]: optional opd plane, zero-filled
  * (NULL to skip).  status: nullable unless a CHECK flag is set.                 */
 int ol_generate_rays(const ol_raygen_params* p, ol_dtype dt, int64_t n,

@@ -69,6 +69,7 @@ class RaygenInputs(C.Structure):
 
 
 RAYGEN_CHECK_FIELD, RAYGEN_CHECK_PUPIL, RAYGEN_PRESCALE_PUPIL = 0x1, 0x2, 0x4
+SPOT_POLARIZED_OK, SPOT_HITS_LOCAL = 0x8, 0x10   # ol_trace_spot / ol_trace_spot_batch (ABI 10)
 
 
 class TraceExtras(C.Structure):

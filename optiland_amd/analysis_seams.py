@@ -62,7 +62,7 @@ def _why(seam, reason):
             f.write(f"{seam}: {reason} [{os.environ.get('PYTEST_CURRENT_TEST', '')}]\n")
 
 
-def _front(optic, wavelength, need_fp64=False, final_propagation=False):
+def _front(optic, wavelength, need_fp64=False, final_propagation=False, recorded_row=False):
     """(front, table) -- the stand-alone device tracer on the CURRENT packed table of
     `optic` -- when the fused analysis kernels apply to it, else None."""
     from . import integration as ig
@@ -76,7 +76,13 @@ def _front(optic, wavelength, need_fp64=False, final_propagation=False):
     except UnsupportedSystem as exc:
         _why("front", f"unsupported system: {exc}")
         return None
-    if not table.raygen or table.polarization is not None or table.uses_polarization:
+    polarised = table.polarization is not None or table.uses_polarization
+    if polarised and recorded_row and table.polarization is not None \
+            and hasattr(getattr(front.engine, "lib", None), "ol_trace_spot_batch"):
+        # the caller reads the RECORDED last row only (spot diagram, encircled energy): positions
+        # and the geometric intensity, which no PRT matrix enters -- OL_SPOT_POLARIZED_OK, ABI 10
+        polarised = False
+    if not table.raygen or polarised:
         _why("front", "no device ray generation" if not table.raygen else "polarised")
         return None  # reference-side ray generation / polarised epilogue: not fused
     if float(table.last_thickness) != 0.0 and not final_propagation:
@@ -131,17 +137,18 @@ def _dist_arg(distribution):
     return distribution if isinstance(distribution, str) else ig._PupilPoints(distribution)
 
 
-def _image_hits(optic, field, wavelength, num_rays, distribution):
+def _image_hits(optic, field, wavelength, num_rays, distribution, local=False):
     """(front, table, moments7 (host), (x, y, i)) of one fused spot launch, or None."""
     hx, hy = _scalar(field[0]), _scalar(field[1])
     if hx is None or hy is None:
         return None
-    got = _front(optic, wavelength, final_propagation=True)  # (the data are the recorded row)
-    if got is None:
+    got = _front(optic, wavelength, final_propagation=True, recorded_row=True)
+    if got is None:     # (the data are the recorded row: no final propagation, no PRT matrix)
         return None
     front, table = got
     dist = _dist_arg(distribution)
-    mom, hits = front.trace_spot(hx, hy, wavelength, num_rays, dist, hits=True)
+    mom, hits = front.trace_spot(hx, hy, wavelength, num_rays, dist, hits=True,
+                                 recorded_row=True, local=local)
     # what Optic.trace() would have left on the Surface objects, produced on first read
     px, py = front.last_spot_pupil
     _register(optic, front, table, (hx, hy, px, py, front._vig_scalar(hx, hy), wavelength, 0))
@@ -192,15 +199,17 @@ def _spot_grid(self):
     main = None      # the front whose geometry the launch reads; the others lend index rows
     cells, last = [], None
     for wi, w in enumerate(wls):
-        got = _front(self.optic, w, final_propagation=True)
+        got = _front(self.optic, w, final_propagation=True, recorded_row=True)
         if got is None:
             return None
         front, table = got
         if not hasattr(front.engine, "trace_spot_batch"):
             return None
         s = table.surfaces[-1]
-        if bool(s["flags"] & 1) and coordinates == "local":
-            return None     # tilted image surface: the reference's own transform
+        # tilted image surface in local coordinates: the kernel leaves the hits in the last
+        # surface's own frame (OL_SPOT_HITS_LOCAL) -- visualization/system/utils.py:17-47
+        tilted_local = bool(s["flags"] & 1) and coordinates == "local"
+        polarised = table.polarization is not None
         if main is None:
             main = (front, table)
         elif front.dtype != main[0].dtype or table.num_surfaces != main[1].num_surfaces:
@@ -216,7 +225,12 @@ def _spot_grid(self):
     front, table = main
     px, py = front._pupil_planes(_dist_arg(self.distribution), self.num_rings)
     n = int(px.numel())
-    mom, hits = front.engine.trace_spot_batch(px, py, [c[2] for c in cells], hits=True)
+    from . import _capi
+
+    flags = (_capi.SPOT_HITS_LOCAL if tilted_local else 0) \
+        | (_capi.SPOT_POLARIZED_OK if polarised else 0)
+    mom, hits = front.engine.trace_spot_batch(px, py, [c[2] for c in cells], hits=True,
+                                              flags=flags)
     counts = mom[:, 0].cpu().numpy().astype(np.int64)   # the ONE read-back of the grid
     xs, ys, ins = hits[:, 0, :n], hits[:, 1, :n], hits[:, 2, :n]
     clipped = masked and bool((counts != n).any())
@@ -235,7 +249,7 @@ def _spot_grid(self):
             x, y, inten = gx[lo:hi], gy[lo:hi], gi[lo:hi]
         else:
             x, y, inten = xs[k], ys[k], ins[k]
-        if coordinates == "local":
+        if coordinates == "local" and not tilted_local:
             # visualization/system/utils.py:17-47 with an untilted image surface:
             # localize = translate by the (folded) origin
             if ox != 0.0:
@@ -265,31 +279,38 @@ def _wavefront_generate_data(self):
 # ------------------------------------------------------------------------------- spot
 def _spot_generate_field_data(self, field, wavelength, num_rays, distribution, coordinates):
     out = None
-    rot = False
     got = None
     try:
+        # a tilted image surface in local coordinates: the kernel leaves the hits in the last
+        # surface's own frame (decided after the table is known: two tries at most)
         got = _image_hits(self.optic, field, wavelength, num_rays, distribution)
+        tilted_local = False
+        if got is not None and bool(got[1].surfaces[-1]["flags"] & 1) and coordinates == "local":
+            if hasattr(getattr(got[0].engine, "lib", None), "ol_trace_spot_batch"):  # ABI 10
+                got = _image_hits(self.optic, field, wavelength, num_rays, distribution,
+                                  local=True)
+                tilted_local = True
+            else:
+                got = None   # an engine without OL_SPOT_HITS_LOCAL: the reference's transform
     except UnsupportedSystem:
         got = None
     if got is not None:
         front, table, mom, (x, y, inten) = got
         s = table.surfaces[-1]
-        rot = bool(s["flags"] & 1)
-        if not (rot and coordinates == "local"):
-            if int(mom[0]) != x.numel():  # core.py:470-473: ignore rays with zero intensity
-                mask = inten > 0
-                x, y, inten = x[mask], y[mask], inten[mask]
-            if coordinates == "local":
-                # visualization/system/utils.py:17-47 with an untilted image surface:
-                # localize = translate by the (folded) origin
-                ox, oy = float(s["origin"][0]), float(s["origin"][1])
-                if ox != 0.0:
-                    x = x - ox
-                if oy != 0.0:
-                    y = y - oy
-            from optiland.analysis.spot_diagram.core import SpotData
+        if int(mom[0]) != x.numel():  # core.py:470-473: ignore rays with zero intensity
+            mask = inten > 0
+            x, y, inten = x[mask], y[mask], inten[mask]
+        if coordinates == "local" and not tilted_local:
+            # visualization/system/utils.py:17-47 with an untilted image surface:
+            # localize = translate by the (folded) origin
+            ox, oy = float(s["origin"][0]), float(s["origin"][1])
+            if ox != 0.0:
+                x = x - ox
+            if oy != 0.0:
+                y = y - oy
+        from optiland.analysis.spot_diagram.core import SpotData
 
-            out = SpotData(x=x, y=y, intensity=inten)
+        out = SpotData(x=x, y=y, intensity=inten)
     if out is None:
         STATS["spot_fallback"] += 1
         return _ORIG["spot"](self, field, wavelength, num_rays, distribution, coordinates)

@@ -1182,11 +1182,12 @@ int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_ra
   if (wavelength_index < 0 || wavelength_index >= sys->n_wl)
     return fail(OL_EINVAL, "ol_trace_spot: wavelength index %d outside [0, %d)", wavelength_index,
                 sys->n_wl);
-  for (int32_t s = 0; s < sys->n_surf; ++s)
-    if (sys->coating[s] >= OL_COAT_FRESNEL)
-      return fail(OL_EINVAL,
-                  "Polarization must be set when surfaces have polarization-dependent "
-                  "coatings.");
+  if (!(in->flags & OL_SPOT_POLARIZED_OK))
+    for (int32_t s = 0; s < sys->n_surf; ++s)
+      if (sys->coating[s] >= OL_COAT_FRESNEL)
+        return fail(OL_EINVAL,
+                    "Polarization must be set when surfaces have polarization-dependent "
+                    "coatings.");
   if (n_rays > 0) {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != sys->device)
@@ -1239,11 +1240,12 @@ int ol_trace_spot_batch(const ol_system* sys, ol_dtype dt, int64_t n_rays, const
         return fail(OL_EINVAL, "Normalized field coordinates must be within (-1, 1)");
     }
   }
-  for (int32_t s = 0; s < sys->n_surf; ++s)
-    if (sys->coating[s] >= OL_COAT_FRESNEL)
-      return fail(OL_EINVAL,
-                  "Polarization must be set when surfaces have polarization-dependent "
-                  "coatings.");
+  if (!(in->flags & OL_SPOT_POLARIZED_OK))
+    for (int32_t s = 0; s < sys->n_surf; ++s)
+      if (sys->coating[s] >= OL_COAT_FRESNEL)
+        return fail(OL_EINVAL,
+                    "Polarization must be set when surfaces have polarization-dependent "
+                    "coatings.");
   if (n_rays > 0 && n_cells > 0) {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != sys->device)

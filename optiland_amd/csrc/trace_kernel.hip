@@ -1223,8 +1223,12 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
         }
       }
       const DevSurf<T> lt = fetched_surface<T, SpotArgs<T>>(last_idx).surf();  // (no optics row)
+      // kSpotHitsLocal: the hits stay in the last surface's own frame (the flag word is read
+      // again here: nothing of the argument block is carried through the surface loop)
+      const bool keep =
+          is_global || (kernargs<T, SpotArgs<T>>()->a.in.flags & kSpotHitsLocal) != 0;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(lt, r[j]);
+      for (int j = 0; j < NV; ++j) gv[j] = keep ? r[j] : to_global<V>(lt, r[j]);
     } else {
       constexpr bool kPrefetch =
           (OL_FUSED_NR_PREFETCH || NR == 0) && (OL_PREFETCH_F64 || sizeof(T) == 4);
@@ -1252,8 +1256,9 @@ __global__ __launch_bounds__(kTraceBlock) void spot_trace_kernel(
           last_traced = S;
         }
       }
+      const bool keep = is_global || (a.in.flags & kSpotHitsLocal) != 0;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) gv[j] = is_global ? r[j] : to_global<V>(last_traced, r[j]);
+      for (int j = 0; j < NV; ++j) gv[j] = keep ? r[j] : to_global<V>(last_traced, r[j]);
     }
 
     T hx_[RPT], hy_[RPT], hi_[RPT];

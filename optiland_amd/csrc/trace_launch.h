@@ -70,6 +70,8 @@ struct RaygenConsts {
 constexpr uint32_t kRaygenCheckField = 0x1u;    // OL_RAYGEN_CHECK_FIELD
 constexpr uint32_t kRaygenCheckPupil = 0x2u;    // OL_RAYGEN_CHECK_PUPIL
 constexpr uint32_t kRaygenPrescalePupil = 0x4u; // OL_RAYGEN_PRESCALE_PUPIL
+constexpr uint32_t kSpotPolarizedOk = 0x8u;     // OL_SPOT_POLARIZED_OK (capi.hip only)
+constexpr uint32_t kSpotHitsLocal = 0x10u;      // OL_SPOT_HITS_LOCAL
 constexpr uint32_t kStatusFieldRange = 0x8u;    // OL_STATUS_FIELD_RANGE
 constexpr uint32_t kStatusPupilRange = 0x10u;   // OL_STATUS_PUPIL_RANGE
 

@@ -1148,7 +1148,7 @@ class HipSystem:
             hb = torch.empty((k, 3, max(stride, 1)), dtype=dtype, device=self.device)
         if n == 0 or k == 0:
             return out, hb
-        inp, keep = self._raygen_inputs(0.0, 0.0, px, py, 1.0, 1.0, flags)
+        inp, keep = self._raygen_inputs(0.0, 0.0, px, py, 1.0, 1.0, flags)  # (flags: _capi.RAYGEN_* | SPOT_*)
         if check_status:
             self._status.zero_()
         step = _capi.SPOT_BATCH_MAX_CELLS

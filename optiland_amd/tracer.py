@@ -449,19 +449,28 @@ class HipRayTracer:
 
     def trace_spot(self, Hx: float, Hy: float, wavelength, num_rays=100,
                    distribution="hexapolar", center=(0.0, 0.0), hits: bool = False,
-                   check_status: bool = True):
+                   check_status: bool = True, recorded_row: bool = False, local: bool = False):
         """`trace(Hx, Hy, ...)` for ONE field point fused with the image-plane
         reduction (`ol_trace_spot`): rays are generated, traced and folded into masked
         moments about `center` in one kernel and never exist in HBM.  Returns
         (moments7, hits) with moments7 = {count, sum dx, sum dy, sum dx^2, sum dy^2,
         sum i, max r^2} (float64 device tensor) and hits = (x, y, intensity) at the last
-        surface or None.  Unpolarised systems only (the polarised `update_intensity`
-        epilogue needs the PRT planes); the masks are those of
+        surface or None.  Unpolarised systems (the polarised `update_intensity` epilogue needs
+        the PRT planes) -- unless `recorded_row`: what a spot diagram reads of a POLARISED trace
+        is the recorded last row, positions and the geometric intensity, which no PRT matrix
+        enters (`OL_SPOT_POLARIZED_OK`).  `local`: hits and moments in the last surface's own
+        frame (`OL_SPOT_HITS_LOCAL`).  The masks are those of
         analysis/spot_diagram/core.py:470-476."""
         Hx, Hy = float(Hx), float(Hy)
         self._validate_normalized_coordinates(Hx, Hy, "field")
-        if self.table.polarization is not None or self.table.uses_polarization:
-            raise ValueError("trace_spot: fused spot reduction needs an unpolarised system")
+        polarised = self.table.polarization is not None or self.table.uses_polarization
+        if polarised and not (recorded_row and self.table.polarization is not None):
+            # (coatings that need a polarization state on an optic without one: the reference's
+            # own error comes from the library, rays/ray_generator.py:89-94)
+            if self.table.polarization is not None:
+                raise ValueError("trace_spot: fused spot reduction needs an unpolarised system")
+        flags = (_capi.SPOT_POLARIZED_OK if (recorded_row and polarised) else 0) \
+            | (_capi.SPOT_HITS_LOCAL if local else 0)
         px, py = self._pupil_planes(distribution, num_rays)
         self.last_spot_pupil = (px, py)
         wl, _ = self._wavelength_index(wavelength)
@@ -471,7 +480,8 @@ class HipRayTracer:
             buf = torch.empty((3, max(n, 1)), dtype=self.dtype, device=self.device)
             out3 = [buf[k, :n] for k in range(3)]
         mom = self.engine.trace_spot(px, py, wl, field=(Hx, Hy), vig=self._vig_scalar(Hx, Hy),
-                                     center=center, hits=out3, check_status=check_status)
+                                     center=center, hits=out3, check_status=check_status,
+                                     flags=flags)
         return mom, out3
 
     def trace_generic(self, Hx, Hy, Px, Py, wavelength):

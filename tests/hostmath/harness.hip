@@ -506,7 +506,7 @@ template hipError_t launch_pupil_fill<double>(int64_t, const double*, const doub
 template <typename T, int NR>
 Ray<T> fused_trace_one(const DevSurfHot<T>* surf, const DevSurfCold<T>* cold,
                        const DevOptics<T>* optics, const T* coeffs, int first, int last,
-                       int n_wl, int wl, Ray<T> q, uint32_t& status) {
+                       int n_wl, int wl, Ray<T> q, uint32_t& status, bool keep_local = false) {
   Ray<T> r[1] = {q};
   Prt<T, 0> P[1];
   bool is_global = true, prt_fresh = false;
@@ -524,18 +524,19 @@ Ray<T> fused_trace_one(const DevSurfHot<T>* surf, const DevSurfCold<T>* cold,
       last_traced = S;
     }
   }
-  return is_global ? r[0] : to_global<T>(last_traced, r[0]);
+  return (is_global || keep_local) ? r[0] : to_global<T>(last_traced, r[0]);
 }
 
 template <typename T>
 Ray<T> fused_trace_family(int family, const DevSurfHot<T>* surf, const DevSurfCold<T>* cold,
                           const DevOptics<T>* optics, const T* coeffs, int first, int last,
-                          int n_wl, int wl, const Ray<T>& q, uint32_t& status) {
+                          int n_wl, int wl, const Ray<T>& q, uint32_t& status,
+                          bool keep_local = false) {
   switch (family) {
-    case kNrNone: return fused_trace_one<T, kNrNone>(surf, cold, optics, coeffs, first, last, n_wl, wl, q, status);
-    case kNrZernike: return fused_trace_one<T, kNrZernike>(surf, cold, optics, coeffs, first, last, n_wl, wl, q, status);
-    case kNrEvenAsphere: return fused_trace_one<T, kNrEvenAsphere>(surf, cold, optics, coeffs, first, last, n_wl, wl, q, status);
-    default: return fused_trace_one<T, kNrGeneric>(surf, cold, optics, coeffs, first, last, n_wl, wl, q, status);
+    case kNrNone: return fused_trace_one<T, kNrNone>(surf, cold, optics, coeffs, first, last, n_wl, wl, q, status, keep_local);
+    case kNrZernike: return fused_trace_one<T, kNrZernike>(surf, cold, optics, coeffs, first, last, n_wl, wl, q, status, keep_local);
+    case kNrEvenAsphere: return fused_trace_one<T, kNrEvenAsphere>(surf, cold, optics, coeffs, first, last, n_wl, wl, q, status, keep_local);
+    default: return fused_trace_one<T, kNrGeneric>(surf, cold, optics, coeffs, first, last, n_wl, wl, q, status, keep_local);
   }
 }
 
@@ -574,7 +575,8 @@ static hipError_t launch_spot_cell(const SpotArgs<T>& a, int nr_family) {
     q.i = a.rg.apod_kind != 0 ? raygen_apodize<T>(c, px, py) : T(1);
     q.opd = T(0);
     const Ray<T> g = fused_trace_family<T>(nr_family, a.surf, a.cold, a.optics, a.coeffs, a.first,
-                                           a.last, a.n_wl, a.wl, q, status);
+                                           a.last, a.n_wl, a.wl, q, status,
+                                           (in_.flags & kSpotHitsLocal) != 0);
     spot_accumulate<T>(s, rmax, g.x, g.y, g.i, a.cx, a.cy);
     if (a.hits[0] != nullptr) {
       a.hits[0][j] = g.x;

@@ -521,3 +521,40 @@ def test_lazy_records_on_device(be, name, precision):
         assert integration._PENDING is None or lens.surfaces.surfaces[1] not in integration._PENDING
     finally:
         _off(be)
+
+
+@pytest.mark.parametrize("precision", ["float64", "float32"])
+def test_spot_seams_on_a_polarised_optic_and_a_tilted_image_surface_on_device(be, precision):
+    """Round 5 (ABI 10) on the MI355X: the reference's `SpotDiagram` of a POLARISED optic
+    (BASELINE C5's Zernike + Fresnel system: the recorded last row needs no PRT matrix,
+    `OL_SPOT_POLARIZED_OK`) and of a lens with a TILTED image surface in local coordinates
+    (`OL_SPOT_HITS_LOCAL`) through the batched seam, against the NumPy backend."""
+    from optiland import analysis
+    from optiland.samples.objectives import CookeTriplet
+
+    def tilted():
+        lens = CookeTriplet()
+        lens.surfaces[-1].geometry.cs.rx = be.array(0.05) if be.get_backend() == "torch" else 0.05
+        return lens
+
+    def run(build, **kw):
+        s = analysis.SpotDiagram(build(), num_rings=5, **kw)
+        return [[(_np(be, d.x), _np(be, d.y), _np(be, d.intensity)) for d in f] for f in s.data]
+
+    cases = [(lambda: _live.zernike_fresnel("elliptical"), {}), (tilted, dict(coordinates="local"))]
+    be.set_backend("numpy")
+    want = [run(b, **kw) for b, kw in cases]
+    stats = _on_device(be, precision)
+    try:
+        got = [run(b, **kw) for b, kw in cases]
+        assert stats["spot_grid"] == 2 and stats["spot_fallback"] == 0
+        tol = TOL[precision]
+        for G, W in zip(got, want):
+            for fg, fw in zip(G, W):
+                for (x, y, i), (xw, yw, iw) in zip(fg, fw):
+                    assert x.shape == xw.shape
+                    scale = max(1.0, float(np.abs(xw).max()), float(np.abs(yw).max()), 75.0)
+                    assert np.abs(x - xw).max() <= tol * scale and np.abs(y - yw).max() <= tol * scale
+                    np.testing.assert_allclose(i, iw, rtol=tol, atol=tol)
+    finally:
+        _off(be)

@@ -141,6 +141,83 @@ def test_spot_grid_equals_the_per_cell_seam(seams, request, monkeypatch):
     assert stats["spot_grid"] == n0
 
 
+@pytest.mark.parametrize("state", ["unpolarized", "elliptical"])
+def test_spot_seams_serve_polarised_optics(seams, request, state):
+    """A POLARISED optic (Fresnel coatings + a polarization state; BASELINE C5's system): what
+    `SpotDiagram` / `EncircledEnergy` read is the recorded last row -- positions and the
+    geometric intensity; the PRT matrix and `update_intensity` never reach it (SURVEY.md
+    Appendix D) -- so the fused spot kernel serves it (`OL_SPOT_POLARIZED_OK`, ABI 10; round 4
+    declined).  Against the NumPy backend, which traces `PolarizedRays`."""
+    if "kernel-source" not in request.node.name:
+        pytest.skip("the oracle-backed stand-in refuses polarised spots")
+    be, stats = seams
+    from optiland import analysis
+    from tests import _live
+
+    def build():
+        return _live.zernike_fresnel(polarization=state)
+
+    def run(lens):
+        s = analysis.SpotDiagram(lens, num_rings=5)
+        e = analysis.EncircledEnergy(lens, num_rays=6, distribution="hexapolar", num_points=16)
+        return ([[(_np(be, d.x), _np(be, d.y), _np(be, d.intensity)) for d in f] for f in s.data],
+                [[(_np(be, d.x), _np(be, d.y), _np(be, d.intensity)) for d in f] for f in e.data],
+                _np(be, lens.surfaces.y)[-1])
+
+    want = _numpy_reference(be, build, run)
+    got = run(build())
+    assert stats["spot"] > 0 and stats["spot_fallback"] == 0 and stats["spot_grid"] >= 1
+    assert stats["ee"] > 0 and stats["ee_fallback"] == 0
+    for G, W in ((got[0], want[0]), (got[1], want[1])):
+        for fg, fw in zip(G, W):
+            for (x, y, i), (xw, yw, iw) in zip(fg, fw):
+                assert x.shape == xw.shape
+                np.testing.assert_allclose(x, xw, rtol=0, atol=1e-7)   # Newton stop tolerance
+                np.testing.assert_allclose(y, yw, rtol=0, atol=1e-7)
+                np.testing.assert_allclose(i, iw, rtol=1e-12, atol=0)
+    # what Optic.trace would have left on the surfaces (a polarised record-all re-run)
+    np.testing.assert_allclose(got[2], want[2], rtol=0, atol=1e-7)
+
+
+def test_spot_seam_on_a_tilted_image_surface_in_local_coordinates(seams, request):
+    """`SpotDiagram(coordinates="local")` localises the image-plane hits into the image
+    surface's own frame (visualization/system/utils.py:17-47); with a TILTED image surface the
+    kernel leaves the hits in that frame itself (`OL_SPOT_HITS_LOCAL`, ABI 10; round 4 declined),
+    batched and cell by cell."""
+    if "kernel-source" not in request.node.name:
+        pytest.skip("the oracle-backed stand-in has no local-frame hits")
+    be, stats = seams
+    from optiland import analysis
+    from optiland_amd import analysis_seams
+
+    def build():
+        lens = _cooke()
+        lens.surfaces[-1].geometry.cs.rx = be.array(0.05) if be.get_backend() == "torch" else 0.05
+        lens.surfaces[-1].geometry.cs.ry = be.array(-0.03) if be.get_backend() == "torch" else -0.03
+        return lens
+
+    def run(lens, coords):
+        s = analysis.SpotDiagram(lens, num_rings=4, coordinates=coords)
+        return [[(_np(be, d.x), _np(be, d.y)) for d in f] for f in s.data]
+
+    for coords in ("local", "global"):
+        want = _numpy_reference(be, build, lambda lens: run(lens, coords))
+        n0, g0 = stats["spot"], stats["spot_grid"]
+        got = run(build(), coords)
+        assert stats["spot"] > n0 and stats["spot_fallback"] == 0 and stats["spot_grid"] == g0 + 1
+        with __import__("contextlib").ExitStack() as st:
+            mp = pytest.MonkeyPatch()
+            st.callback(mp.undo)
+            mp.setattr(analysis_seams, "_spot_grid", lambda self: None)
+            cell = run(build(), coords)                     # the per-cell seam
+        assert stats["spot_fallback"] == 0
+        for G in (got, cell):
+            for fg, fw in zip(G, want):
+                for (x, y), (xw, yw) in zip(fg, fw):
+                    np.testing.assert_allclose(x, xw, rtol=0, atol=1e-9)
+                    np.testing.assert_allclose(y, yw, rtol=0, atol=1e-9)
+
+
 def test_spot_seam_masks_clipped_rays_like_the_reference(seams):
     """core.py:470-476: rays with zero intensity are dropped -- a system that vignettes."""
     be, stats = seams
@@ -266,11 +343,14 @@ def test_fft_psf_through_the_fused_seams(seams):
     np.testing.assert_allclose(got2, want2, rtol=0, atol=1e-4 * want2.max())
 
 
-def test_seams_fall_back_where_the_fused_path_does_not_apply(seams):
-    """Polarised system, tilted image surface in local coordinates, fitted reference
-    strategies, autograd: the reference's own method runs (and still traces through the
-    drop-in's Optic.trace); results equal the NumPy backend's."""
+def test_seams_fall_back_where_the_fused_path_does_not_apply(seams, request):
+    """Where a seam does not apply the reference's own method runs (and still traces through
+    the drop-in's Optic.trace); results equal the NumPy backend's: a centroid strategy asked
+    for by name, and -- on an engine without the ABI-10 spot flags (the oracle-backed
+    stand-in; the product serves both since round 5, see the two tests above) -- a polarised
+    system and a tilted image surface in local coordinates."""
     be, stats = seams
+    old_engine = "oracle" in request.node.name
     from optiland import analysis
     from optiland.wavefront import Wavefront
     from tests import _live
@@ -283,7 +363,10 @@ def test_seams_fall_back_where_the_fused_path_does_not_apply(seams):
     build = lambda: _live.zernike_fresnel("unpolarized")  # noqa: E731
     want = _numpy_reference(be, build, spot_rms)
     got = spot_rms(build())
-    assert stats["spot"] == 0 and stats["spot_fallback"] > 0
+    if old_engine:
+        assert stats["spot"] == 0 and stats["spot_fallback"] > 0
+    else:
+        assert stats["spot"] > 0 and stats["spot_fallback"] == 0
     np.testing.assert_allclose(got, want, rtol=1e-6)
 
     # centroid wavefront strategy is not patched at all; chief-ray on fp32 falls back
@@ -307,7 +390,7 @@ def test_seams_fall_back_where_the_fused_path_does_not_apply(seams):
     f0 = stats["spot_fallback"]
     want = _numpy_reference(be, tilted, spot_rms)
     got = spot_rms(tilted())
-    assert stats["spot_fallback"] > f0
+    assert (stats["spot_fallback"] > f0) == old_engine
     np.testing.assert_allclose(got, want, rtol=1e-6)
 
 
