@@ -598,6 +598,11 @@ def reference_baselines(workload, dtype, wavelength, hy, S, budget_s, device, n=
     return out
 
 
+# OL_BENCH_EXCH_DEBUG = nozero | nocoll: what the pieces of the reduce-first exchange cost per step
+# (diagnostic only: the statistics of such a run are wrong)
+_DBG = os.environ.get("OL_BENCH_EXCH_DEBUG", "")
+
+
 def main():
     args = parse_args()
     self_launch(args)  # N > 1 without a launcher: re-exec under torchrun and exit
@@ -757,11 +762,16 @@ def main():
         step_no[0] += 1
         if exchange != "none" and pending[k] is not None:
             for w in (pending[k] if isinstance(pending[k], tuple) else (pending[k],)):
-                w.wait()  # stream-level wait: this buffer pair is free again
+                # this buffer pair is free again once its collective (two steps back) is done:
+                # normally it IS by now, and asking (an event query on the host) spares the
+                # compute stream a wait packet between two trace launches
+                if _DBG == "alwayswait" or not w.is_completed():
+                    w.wait()
             pending[k] = None
         spot_arg = None
         if exchange == "reduce":
-            slots[k].zero_()
+            if _DBG != "nozero":
+                slots[k].zero_()
             if not pol:  # polarised traces reduce after the launch (see below)
                 spot_arg = (slots[k], 0.0, 0.0)
         if ev0 is not None:
@@ -784,8 +794,9 @@ def main():
                     xi, yi, ii = ((res.row(res.last, q) for q in (0, 1, 6))
                                   if record is not None else (src[0], src[1], src[6]))
                     hip.spot_moments(xi, yi, ii, out=slots[k].view(-1)[:6])
-                pending[k] = dist.all_gather_into_tensor(all_slots[k].view(-1),
-                                                         slots[k].view(-1), async_op=True)
+                if _DBG not in ("nocoll", "nozero_nocoll"):
+                    pending[k] = dist.all_gather_into_tensor(all_slots[k].view(-1),
+                                                             slots[k].view(-1), async_op=True)
             else:
                 if record is not None:
                     x, y, inten = res.row(res.last, 0), res.row(res.last, 1), res.row(res.last, 6)
@@ -858,7 +869,7 @@ def main():
     if exchange == "reduce" and not spot and args.steps:
         # fold the gathered slots of the last step: whole-job spot statistics
         tot = hip.reduce_spot_slots(all_slots[(step_no[0] - 1) & 1].view(-1, 8)).cpu().numpy()
-        assert tot[0] > 0, "no ray reached the image plane"
+        assert tot[0] > 0 or _DBG, "no ray reached the image plane"
     exchange_info = None
     if configured_exchange != "none" and args.steps:
         # the same steps WITHOUT the image-plane exchange (outside the reported region):

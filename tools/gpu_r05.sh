@@ -118,6 +118,20 @@ PY
       done ;;
     smoke)     # what the driver runs before its bench
       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" > $O/r05_smoke.log 2>&1; tail -4 $O/r05_smoke.log ;;
+    exch)      # where the +0.05 ms per step of the reduce-first exchange go (one rank, RCCL)
+      for dbg in none alwayswait nocoll; do
+        OL_BENCH_EXCH_DEBUG=$dbg python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 \
+          bench.py --gpus 1 --force-exchange --steps 40 --warmup 10 --settle 0 --no-cpu-baseline --no-ref-baselines --traffic committed \
+          > $O/r05_exch_$dbg.json 2> $O/r05_exch_$dbg.err
+        python - $O/r05_exch_$dbg.json $dbg <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); e = d["exchange"]
+    print(f"{sys.argv[2]:8s} with {e['ms_per_step_with']:.4f} without {e['ms_per_step_without']:.4f} diff {e['exchange_ms_per_step']:.4f} kernel {d['roofline']['kernel_ms']:.4f}")
+except Exception as ex:
+    print(sys.argv[2], "ERR", ex)
+PY
+      done ;;
     bench1rank) # the N > 1 launch form with ONE rank: RCCL init, barrier, exchange legs, placement
       python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
         bench.py --gpus 1 --force-exchange --steps 20 --warmup 5 --no-cpu-baseline --no-ref-baselines --traffic committed \
