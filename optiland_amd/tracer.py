@@ -463,13 +463,12 @@ class HipRayTracer:
         analysis/spot_diagram/core.py:470-476."""
         Hx, Hy = float(Hx), float(Hy)
         self._validate_normalized_coordinates(Hx, Hy, "field")
-        polarised = self.table.polarization is not None or self.table.uses_polarization
-        if polarised and not (recorded_row and self.table.polarization is not None):
-            # (coatings that need a polarization state on an optic without one: the reference's
-            # own error comes from the library, rays/ray_generator.py:89-94)
-            if self.table.polarization is not None:
-                raise ValueError("trace_spot: fused spot reduction needs an unpolarised system")
-        flags = (_capi.SPOT_POLARIZED_OK if (recorded_row and polarised) else 0) \
+        has_state = self.table.polarization is not None
+        if has_state and not recorded_row:
+            raise ValueError("trace_spot: fused spot reduction needs an unpolarised system")
+        # (coatings that need a polarization state on an optic WITHOUT one: the library refuses
+        # with the reference's own error, rays/ray_generator.py:89-94)
+        flags = (_capi.SPOT_POLARIZED_OK if (recorded_row and has_state) else 0) \
             | (_capi.SPOT_HITS_LOCAL if local else 0)
         px, py = self._pupil_planes(distribution, num_rays)
         self.last_spot_pupil = (px, py)
