@@ -416,6 +416,11 @@ __device__ __forceinline__ SurfFetched<T> fetched_surface_of(int s, const DevOpt
 #ifndef OL_POLNR_WAVES_F64
 #define OL_POLNR_WAVES_F64 0
 #endif
+// occupancy request for the lean (conic-only, unpolarised) fp64 kernels: the generating
+// record-all form allocates 82 VGPRs = 5 waves, two registers over the 6-wave budget
+#ifndef OL_LEAN_F64_WAVES
+#define OL_LEAN_F64_WAVES 0
+#endif
 // (The generic-family kernel WITH the generator prologue does not fit 7 waves without two
 // dwords of scratch: it keeps the allocator's own choice.)
 template <typename T, int RPT, int POLK, int NR, bool GEN = false>  // GEN: any generating form
@@ -426,7 +431,9 @@ struct WavesPerEu {
           ? OL_POLNR_WAVES
           : ((OL_POLNR_WAVES_F64 > 0 && sizeof(T) == 8 && RPT == 1 && POLK == 1 && NR != 0)
                  ? OL_POLNR_WAVES_F64
-                 : 1);
+                 : ((OL_LEAN_F64_WAVES > 0 && sizeof(T) == 8 && RPT == 1 && POLK == 0 && NR == 0)
+                        ? OL_LEAN_F64_WAVES
+                        : 1));
 };
 
 // GEN != 0: the rays are GENERATED in the prologue from normalised pupil planes and a

@@ -82,6 +82,10 @@ VARIANTS = {
     # the opt-in reference-formula conic root compiled out (what its launch-uniform branch costs
     # the kernels that never take it)
     "no_refroot": ["-DOL_REFERENCE_ROOT=0"],
+    # occupancy request for the lean fp64 kernels (the generating record-all form: 82 VGPRs = 5
+    # waves by itself; 79 / 6 waves on request without spills; 72 / 7 waves with 12 B of scratch)
+    "lean64_w6": ["-DOL_LEAN_F64_WAVES=6"],
+    "lean64_w7": ["-DOL_LEAN_F64_WAVES=7"],
 }
 
 
