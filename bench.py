@@ -931,6 +931,24 @@ def main():
         steady = {"launches_before": args.warmup + args.steps + len(each) - len(tail),
                   "launches_averaged": len(tail), "kernel_ms": float(np.mean(tail)),
                   "kernel_us_minmax": [min(tail) * 1e3, max(tail) * 1e3]}
+        if gen and not pol and args.workload == "double_gauss" and hasattr(hip.lib, "ol_set_tuning"):
+            # the same launch with at most two workgroups resident per CU: what a LOOP of
+            # hundreds of back-to-back traces can ask for (`ol_set_tuning`): faster once the
+            # clocks have settled, slower in the first 25 launches -- hence not the default
+            # for a placed block (profiles/r05_ab_wgcap.txt)
+            lib_, knob_ = hip.lib, 3  # OL_TUNE_RECORD_WG_CAP
+            if lib_.ol_set_tuning(knob_, 2) == 0:
+                cev = [(make_event(), make_event()) for _ in range(max(args.settle // 2, 30))]
+                for e0_, e1_ in cev:
+                    e0_.record()
+                    hip.trace_generate(px, py, wl, field=(0.0, hy), record=record, prt=prt,
+                                       zero_status=False, defer_status=True)
+                    e1_.record()
+                sync(device)
+                lib_.ol_set_tuning(knob_, 0)
+                ct = [a.elapsed_time(bb) for a, bb in cev]
+                ct = ct[-max(len(ct) // 3, 1):]
+                steady["kernel_ms_two_workgroups_per_cu"] = float(np.mean(ct))
         if placement is not None and placement.get("placed") and gen:
             # the same launch into an ORDINARY allocation (what a drop-in trace gets), for
             # comparison -- outside the reported region

@@ -211,6 +211,14 @@ typedef struct ol_system ol_system; /* opaque */
                                       and the caller's fill                          */
 #define OL_TRACE_COMPACT 0x2u      /* allow wavefront straggler compaction in the
                                       Newton loop (only if OL_TUNE_COMPACT=1) */
+#define OL_TRACE_FEW_WAVES 0x10u   /* ABI 10, record-all launches of ol_trace /
+                                      ol_trace_generate: the caller's word that the record
+                                      block is NOT in a placed window (an ordinary
+                                      allocation).  The fp32 conic-only unpolarised kernels
+                                      then run with at most two workgroups resident per CU
+                                      (an untouched dynamic-LDS request): fewer stores in
+                                      flight write ~3 % faster there.  Results are
+                                      identical; ignored by every other kernel.         */
 
 /* Polarisation state for the update_intensity epilogue
  * (rays/polarized_rays.py:122-133, rays/polarization_state.py:29-56).      */
@@ -717,6 +725,10 @@ int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void
  *                            (needs the vector layout; default 0, measured slower)
  *   OL_TUNE_FIT_GRID         most blocks an ol_wavefront_fit pass is launched with (0 = the
  *                            default, 768; at most 2048 -- the rows of its workspace)
+ *   OL_TUNE_RECORD_WG_CAP    record-all launches, resident workgroups per CU: 0 = the
+ *                            default policy (conic-only unpolarised ranges: fp64 three,
+ *                            fp32 two under OL_TRACE_FEW_WAVES; nothing else is capped),
+ *                            1 = never, 2 ... 8 = every record launch (A/B)
  * The environment variable OL_TRACE_RPT seeds OL_TUNE_RAYS_PER_THREAD.
  *
  * Environment variables read by the library (A/B runs and parity tests; results are the
@@ -731,6 +743,7 @@ int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void
 #define OL_TUNE_RAYS_PER_THREAD 0
 #define OL_TUNE_COMPACT 1
 #define OL_TUNE_FIT_GRID 2
+#define OL_TUNE_RECORD_WG_CAP 3
 int ol_set_tuning(int32_t knob, int32_t value);
 
 const char* ol_last_error(void);

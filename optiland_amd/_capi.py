@@ -141,7 +141,7 @@ EXPORTS = (
 )
 
 F32, F64 = 0, 1
-TUNE_RAYS_PER_THREAD, TUNE_COMPACT, TUNE_FIT_GRID = 0, 1, 2
+TUNE_RAYS_PER_THREAD, TUNE_COMPACT, TUNE_FIT_GRID, TUNE_RECORD_WG_CAP = 0, 1, 2, 3
 ABI_VERSION = 10
 OPD_MOMENTS = 12  # kOpdMoments / ol_trace_opd
 WAVEFRONT_REFERENCE_DOUBLES = 16  # OL_WAVEFRONT_REFERENCE_DOUBLES

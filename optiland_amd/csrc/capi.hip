@@ -510,8 +510,8 @@ int do_trace_generate(const ol_system* sys, const DeviceTable<T>& tab, int64_t n
   a.record_from = (extras && extras->record_first_surface > 0) ? extras->record_first_surface : 0;
   a.n_wl = sys->n_wl;
   a.wl = wl;
-  a.flags = (flags & ol::kTracePrtComplex) | (prt ? ol::kTracePrtIdentity : 0u) |
-            (rays_out ? ol::kTraceWriteRays : 0u);
+  a.flags = (flags & (ol::kTracePrtComplex | ol::kTraceFewWaves)) |
+            (prt ? ol::kTracePrtIdentity : 0u) | (rays_out ? ol::kTraceWriteRays : 0u);
   if (extras && extras->updated_intensity && extras->update_intensity_state) {
     if (!prt)
       return fail(OL_EINVAL, "ol_trace_generate: the update_intensity epilogue needs a "
@@ -713,6 +713,12 @@ int ol_set_tuning(int32_t knob, int32_t value) {
       return OL_OK;
     case OL_TUNE_COMPACT:
       ol::tuning().compact = value ? 1 : 0;
+      return OL_OK;
+    case OL_TUNE_RECORD_WG_CAP:
+      if (value < 0 || value > 8)
+        return fail(OL_EINVAL, "ol_set_tuning: record workgroup cap 0 (default policy), "
+                               "1 (never) or 2 ... 8");
+      ol::tuning().record_wg_cap = value;
       return OL_OK;
     case OL_TUNE_FIT_GRID:
       if (value < 0 || value > ol::kFitMaxBlocks)

@@ -866,6 +866,32 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
 // --------------------------------------------------------------------------
 // host-side launcher
 // --------------------------------------------------------------------------
+// Dynamic LDS nobody touches, asked for so that at most `cap` workgroups are resident on a CU
+// (160 KB per CU): the record-all kernels of conic-only unpolarised ranges ("lean": ~76 vector
+// instructions per ray and surface against 8 stores) write FASTER with fewer stores in flight
+// (tools/microbench/pace_probe.hip; the real kernels: profiles/r05_ab_wgcap.txt):
+//   fp64  three workgroups instead of the four its registers allow: -3 ... -4 % in the first
+//         launches after an idle part, -1.6 ... -3 % sustained, placed block or not
+//   fp32  two instead of eight: -2 ... -3.6 % (-7.5 % at 1e6 rays) into a block that is NOT in
+//         a placed window (OL_TRACE_FEW_WAVES: the caller knows); in a placed window -3.8 %
+//         sustained (7.37 TB/s) but +11 ... +13 % in the first 25 launches after an idle part
+//         (throttled clocks want the latency hiding): not there by default.  The form that
+//         READS its rays from eight planes (ol_trace) wants three (-1.3 %; two: +5 % in the
+//         window); its fp64 sibling gains 7 % from three, placed or not
+// Newton / polarised kernels lose 5 ... 65 % under any cap and are never capped.
+// OL_TUNE_RECORD_WG_CAP: 0 = this policy, 1 = never, 2 ... 8 = every record launch (A/B).
+// cap >= 2 keeps the request under the 64 KB a launch may ask for without a function attribute.
+template <typename T>
+static unsigned record_lds(const TraceArgs<T>& a, bool lean, bool generating) {
+  if (a.record == nullptr) return 0;
+  int cap = tuning().record_wg_cap;
+  if (cap == 0)
+    cap = !lean ? 1 : sizeof(T) == 8 ? 3 : !(a.flags & kTraceFewWaves) ? 1 : generating ? 2 : 3;
+  if (cap < 2) return 0;
+  const unsigned want = 160u * 1024u / (unsigned)cap - 1024u;
+  return want > 64u * 1024u ? 64u * 1024u : want;
+}
+
 template <typename T, int RPT, int NR>
 static hipError_t launch_nr(const TraceArgs<T>& a, hipStream_t stream) {
   const int64_t threads = (a.n + RPT - 1) / RPT;
@@ -876,8 +902,9 @@ static hipError_t launch_nr(const TraceArgs<T>& a, hipStream_t stream) {
   const bool rec = a.record != nullptr;
   const int polk = a.prt == nullptr ? 0 : ((a.flags & kTracePrtComplex) ? 2 : 1);
 #define OL_LAUNCH_S(R, P, S)                                                                 \
-  hipLaunchKernelGGL((trace_kernel<T, RPT, R, P, NR, S>), grid, block, 0, stream, a.surf,    \
-                     a.cold, a.optics, a.coeffs, a)
+  hipLaunchKernelGGL((trace_kernel<T, RPT, R, P, NR, S>), grid, block,                        \
+                     record_lds(a, NR == 0 && P == 0, false), stream, a.surf, a.cold,         \
+                     a.optics, a.coeffs, a)
 #define OL_LAUNCH(R, P) OL_LAUNCH_S(R, P, false)
   if (a.spot != nullptr) {
     // the spot epilogue exists for unpolarised traces (the polarised intensity needs
@@ -927,8 +954,9 @@ static hipError_t launch_pair(const TraceArgs<T>& a, hipStream_t stream) {
   if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   dim3 grid((unsigned)blocks), block(kTraceBlock);
   if (a.record != nullptr)
-    hipLaunchKernelGGL((trace_kernel<T, 2, true, 0, 0, false>), grid, block, 0, stream, a.surf,
-                       a.cold, a.optics, a.coeffs, a);
+    hipLaunchKernelGGL((trace_kernel<T, 2, true, 0, 0, false>), grid, block,
+                       record_lds(a, true, false), stream, a.surf, a.cold, a.optics, a.coeffs,
+                       a);
   else
     hipLaunchKernelGGL((trace_kernel<T, 2, false, 0, 0, false>), grid, block, 0, stream, a.surf,
                        a.cold, a.optics, a.coeffs, a);
@@ -954,10 +982,10 @@ static hipError_t launch_gen_pair(const TraceArgs<T>& a, hipStream_t stream) {
   const dim3 grid((unsigned)blocks), block(kTraceBlock);
   if (a.spot != nullptr)  // the per-step form of the sharded trace: moments as an epilogue
     hipLaunchKernelGGL((trace_kernel<T, 2, true, 0, 0, true, kGenUniform, false>), grid, block,
-                       0, stream, a.surf, a.cold, a.optics, a.coeffs, a);
+                       record_lds(a, true, true), stream, a.surf, a.cold, a.optics, a.coeffs, a);
   else
     hipLaunchKernelGGL((trace_kernel<T, 2, true, 0, 0, false, kGenUniform, false>), grid, block,
-                       0, stream, a.surf, a.cold, a.optics, a.coeffs, a);
+                       record_lds(a, true, true), stream, a.surf, a.cold, a.optics, a.coeffs, a);
   return hipGetLastError();
 }
 
@@ -976,8 +1004,9 @@ static hipError_t launch_gen_nr(const TraceArgs<T>& a, bool pair_ok, hipStream_t
   dim3 grid((unsigned)blocks), block(kTraceBlock);
   const int polk = a.prt == nullptr ? 0 : ((a.flags & kTracePrtComplex) ? 2 : 1);
 #define OL_LAUNCH_G(P, S, G, E)                                                              \
-  hipLaunchKernelGGL((trace_kernel<T, 1, true, P, NR, S, G, E>), grid, block, 0,             \
-                     stream, a.surf, a.cold, a.optics, a.coeffs, a)
+  hipLaunchKernelGGL((trace_kernel<T, 1, true, P, NR, S, G, E>), grid, block,                 \
+                     record_lds(a, NR == 0 && P == 0, G == kGenUniform), stream, a.surf,     \
+                     a.cold, a.optics, a.coeffs, a)
   const bool epi = polk != 0 && a.i_updated != nullptr;  // update_intensity epilogue (ABI 7)
   const bool fieldp = a.in.hx != nullptr, apod = a.rgc.apod_kind != 0;
   if (polk != 0) {

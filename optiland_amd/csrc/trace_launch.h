@@ -16,6 +16,7 @@ constexpr uint32_t kTraceWriteRays = 0x1u; // OL_TRACE_WRITE_RAYS
 constexpr uint32_t kTraceCompact = 0x2u;   // OL_TRACE_COMPACT
 constexpr uint32_t kTracePrtComplex = 0x4u;  // OL_TRACE_PRT_COMPLEX
 constexpr uint32_t kTracePrtIdentity = 0x8u;  // OL_TRACE_PRT_IDENTITY
+constexpr uint32_t kTraceFewWaves = 0x10u;    // OL_TRACE_FEW_WAVES
 constexpr uint32_t kTraceRow0IsInput = 0x100u;  // internal: rays[] ARE record row 0
 
 // GEN template parameter of trace_kernel: 0 = the rays come from eight planes; otherwise the
@@ -29,6 +30,7 @@ struct Tuning {
   int rays_per_thread = 0;  // 0 = default, 1 = one ray per lane, 2 = force vector
   int compact = 0;          // measured slower; opt-in (OL_TUNE_COMPACT)
   int fit_grid = 0;         // blocks of an ol_wavefront_fit pass: 0 = default cap
+  int record_wg_cap = 0;    // record-all launches: resident workgroups per CU (0 = no cap)
 };
 Tuning& tuning();
 

@@ -98,6 +98,32 @@ _RECORD_POOLS: "collections.OrderedDict" = collections.OrderedDict()  # key -> R
 _POOL_LOCK = threading.RLock()  # pools are process-wide; traces may come from several threads
 _SHAPE_SEEN: dict = {}     # key -> requests so far ("auto": the second one builds the pool)
 _POOL_COOLDOWN: dict = {}  # device index -> big allocations left before another pool is built
+# Placed windows handed out so far: (device index, first byte) -> bytes.  A record launch into
+# a big block that lies in NONE of them says so (`TRACE_FEW_WAVES`: the fp32 conic-only kernels
+# write ~3 % faster into an ordinary allocation with fewer workgroups resident).  An entry whose
+# arena has since been freed only costs that hint; a few dozen entries at most.
+_PLACED_WINDOWS: "collections.OrderedDict" = collections.OrderedDict()
+_PLACED_MAX = 64
+_FEW_WAVES_MIN_BYTES = 256 << 20
+
+
+def _note_placed(device, ptr: int, nbytes: int) -> None:
+    key = (device.index or 0, int(ptr))
+    _PLACED_WINDOWS[key] = int(nbytes)
+    _PLACED_WINDOWS.move_to_end(key)
+    while len(_PLACED_WINDOWS) > _PLACED_MAX:
+        _PLACED_WINDOWS.popitem(last=False)
+
+
+def _few_waves_flag(rec) -> int:
+    """`TRACE_FEW_WAVES` for a record block of >= 256 MB outside every placed window."""
+    if rec is None or rec.numel() * rec.element_size() < _FEW_WAVES_MIN_BYTES:
+        return 0
+    dev, ptr = rec.device.index or 0, rec.data_ptr()
+    for (d, lo), nb in list(_PLACED_WINDOWS.items()):
+        if d == dev and lo <= ptr < lo + nb:
+            return 0
+    return S.TRACE_FEW_WAVES
 
 
 class _Lease:
@@ -176,6 +202,7 @@ class RecordPool:
             self.info["window_GBps"] = [need / (t * 1e-3) / 1e9 for t, _a, _o in picked]
             for _t, a, off in picked:
                 self.windows.append((held[a], held[a].data_ptr() + off))
+                _note_placed(hip.device, held[a].data_ptr() + off, need)
             unused = len(held) - len({a for _t, a, _o in picked})
             held = None  # (arenas without a window are released with this frame ...
             if unused:
@@ -515,6 +542,7 @@ class HipSystem:
             return self.alloc_record(n, dtype, rows), info
         info["placed"] = True
         rec = arena[pad + off: pad + off + need].view(dtype).view(rows, 8, stride)
+        _note_placed(self.device, rec.data_ptr(), need)
         return rec, info
 
     def trace(self, rays, wavelength_index: int = 0, record=True, prt: torch.Tensor | None = None,
@@ -563,7 +591,7 @@ class HipSystem:
                 raise ValueError("record must be a contiguous (rows, 8, stride>=n) tensor")
         if write_rays is None:
             write_rays = rec is None
-        flags = (S.TRACE_WRITE_RAYS if write_rays else 0) | S.TRACE_COMPACT
+        flags = (S.TRACE_WRITE_RAYS if write_rays else 0) | S.TRACE_COMPACT | _few_waves_flag(rec)
         if prt is not None:
             if prt.dtype != dtype or prt.dim() != 2 or prt.shape[0] not in (9, 18) \
                     or prt.shape[1] != n or not prt.is_contiguous():
@@ -653,7 +681,7 @@ class HipSystem:
                     or rec.shape[0] < rows or rec.shape[1] != 8 or rec.shape[2] < n \
                     or not rec.is_contiguous():
                 raise ValueError("record must be a contiguous (rows, 8, stride>=n) tensor")
-        tflags = 0
+        tflags = _few_waves_flag(rec)
         if prt is not None:
             if prt.dtype != dtype or prt.dim() != 2 or prt.shape[0] not in (9, 18) \
                     or prt.shape[1] != n or not prt.is_contiguous():

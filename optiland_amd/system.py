@@ -47,6 +47,7 @@ STATUS_PUPIL_RANGE = 0x10
 
 TRACE_WRITE_RAYS = 0x1
 TRACE_COMPACT = 0x2
+TRACE_FEW_WAVES = 0x10  # the record block is an ordinary allocation (not a placed window)
 TRACE_PRT_COMPLEX = 0x4
 TRACE_PRT_IDENTITY = 0x8
 

@@ -138,6 +138,10 @@ def test_argument_validation_without_a_device(lib):
     rc = lib.ol_wavefront_opd_fitted(4, planes, 16, 16, 16, 16, three, None)
     assert rc == -1 and b"pupil needs three planes" in lib.ol_last_error()
     assert lib.ol_set_tuning(2, 4096) == -1 and lib.ol_set_tuning(2, 0) == 0
+    # OL_TUNE_RECORD_WG_CAP: 0 (default policy), 1 (never), 2 ... 8
+    assert lib.ol_set_tuning(3, 9) == -1 and b"workgroup cap" in lib.ol_last_error()
+    assert lib.ol_set_tuning(3, -1) == -1
+    assert all(lib.ol_set_tuning(3, v) == 0 for v in (8, 2, 1, 0))
 
 
 def test_unsupported_kinds_are_refused(lib):

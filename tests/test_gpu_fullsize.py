@@ -685,3 +685,50 @@ def test_auto_pool_waits_for_a_loop_and_an_evicted_pool_outlives_its_leases(dg):
         gc.collect()
         torch.cuda.empty_cache()
         E.HipSystem.reset_record_pool()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,n", [(torch.float32, 3_000_000), (torch.float64, 1_500_000)],
+                         ids=["f32", "f64"])
+def test_resident_workgroup_cap_changes_nothing_but_time(dg, dtype, n):
+    """Round 5.  Record launches of the conic-only kernels ask for fewer resident workgroups per
+    CU (an untouched dynamic-LDS request: fp64 always three, fp32 two when the engine says the
+    block is an ordinary allocation, `OL_TRACE_FEW_WAVES`).  Every value of the knob -- the
+    default policy, never, forced 2 ... 8 -- writes the same bits, for the generating launch
+    and for the one that reads its rays from eight planes; a block of >= 256 MB outside every
+    placed window carries the hint, a placed one does not."""
+    from optiland_amd import _capi, engine as E
+    from optiland_amd import system as S
+    hip, table = dg
+    px, py = _pupil(n, 77, dtype)
+    rec = torch.empty((hip.num_surfaces, 8, hip.record_stride(n, px.element_size())), dtype=dtype,
+                      device=hip.device)
+    assert rec.numel() * rec.element_size() >= 256 << 20
+    assert E._few_waves_flag(rec) == S.TRACE_FEW_WAVES
+    assert E._few_waves_flag(rec[:2]) == 0                      # small: no hint
+    E._note_placed(hip.device, rec.data_ptr() - 4096, 1 << 20)  # "a window" that holds its start
+    try:
+        assert E._few_waves_flag(rec) == 0
+    finally:
+        E._PLACED_WINDOWS.pop((hip.device.index or 0, rec.data_ptr() - 4096))
+    rays = [torch.empty(n, dtype=dtype, device=hip.device) for _ in range(8)]
+    hip.generate_rays(0.0, 0.7, px, py, out=rays)
+    want = want_t = None
+    try:
+        for cap in (1, 0, 2, 3, 5, 8):
+            assert hip.lib.ol_set_tuning(_capi.TUNE_RECORD_WG_CAP, cap) == 0
+            rec.fill_(float("nan"))
+            got = hip.trace_generate(px, py, 0, field=(0.0, 0.7), record=rec).record[:, :, :n]
+            if want is None:
+                want = got.clone()
+                assert torch.isfinite(want[:, :3]).all()
+            assert torch.equal(got, want), cap
+            rec.fill_(float("nan"))
+            got = hip.trace(rays, 0, record=rec, write_rays=False).record[:, :, :n]
+            if want_t is None:
+                want_t = got.clone()
+                assert torch.isfinite(want_t[:, :3]).all()
+            assert torch.equal(got, want_t), cap
+        assert hip.lib.ol_set_tuning(_capi.TUNE_RECORD_WG_CAP, 9) != 0
+    finally:
+        hip.lib.ol_set_tuning(_capi.TUNE_RECORD_WG_CAP, 0)

@@ -399,3 +399,44 @@ def test_record_pool_policy_auto_lru_and_cooldown(monkeypatch):
         assert hip._pool_for(20, f32, 13, big) is None and not E._RECORD_POOLS
     finally:
         E.HipSystem.reset_record_pool()
+
+
+def test_few_waves_hint_follows_the_placed_windows():
+    """Round 5: `TRACE_FEW_WAVES` goes with record blocks of >= 256 MB that lie in no placed
+    window; windows are remembered per device, newest last, at most `_PLACED_MAX` of them."""
+    from optiland_amd import engine as E
+    from optiland_amd import system as S
+
+    class Block:
+        def __init__(self, ptr, nbytes, index=0):
+            self._ptr, self._n = ptr, nbytes
+            self.device = torch.device("cuda", index)
+
+        def numel(self):
+            return self._n
+
+        def element_size(self):
+            return 1
+
+        def data_ptr(self):
+            return self._ptr
+
+    saved = E._PLACED_WINDOWS.copy()
+    E._PLACED_WINDOWS.clear()
+    try:
+        big, small = 1 << 30, 1 << 20
+        assert E._few_waves_flag(None) == 0
+        assert E._few_waves_flag(Block(0x1000, small)) == 0
+        assert E._few_waves_flag(Block(0x1000, big)) == S.TRACE_FEW_WAVES
+        E._note_placed(torch.device("cuda", 0), 0x7000_0000_0000, big)
+        assert E._few_waves_flag(Block(0x7000_0000_0000, big)) == 0
+        assert E._few_waves_flag(Block(0x7000_0000_0000 + big - 1, big)) == 0
+        assert E._few_waves_flag(Block(0x7000_0000_0000 + big, big)) == S.TRACE_FEW_WAVES
+        assert E._few_waves_flag(Block(0x7000_0000_0000, big, index=1)) == S.TRACE_FEW_WAVES
+        for k in range(E._PLACED_MAX + 5):
+            E._note_placed(torch.device("cuda", 0), 0x1_0000_0000 * (k + 1), big)
+        assert len(E._PLACED_WINDOWS) == E._PLACED_MAX
+        assert E._few_waves_flag(Block(0x7000_0000_0000, big)) == S.TRACE_FEW_WAVES  # forgotten
+    finally:
+        E._PLACED_WINDOWS.clear()
+        E._PLACED_WINDOWS.update(saved)

@@ -70,6 +70,9 @@ for leg in "$@"; do
     ab)        # in-process A/B: ARMS=product,arith_r04 CONFIGS=dg_f64_gen,zf_f32_gen [ROUNDS=2] [AB_EXTRA=--placed]
       timeout 600 python tools/ab_inproc.py --arms ${ARMS:-product} --configs ${CONFIGS:-dg_f32_gen} \
         --rounds ${ROUNDS:-2} ${AB_EXTRA:-} >> $O/r05_ab_${TAG:-0}.txt 2>&1; tail -${AB_TAIL:-12} $O/r05_ab_${TAG:-0}.txt ;;
+    wgcap)     # resident-workgroup cap of the record launches: CAPS=0,2,3,4 CONFIGS=... [AB_EXTRA=--placed]
+      timeout 600 python tools/ab_wgcap.py --caps ${CAPS:-0,2,3,4} --configs ${CONFIGS:-dg_f32_gen,dg_f64_gen} \
+        --rounds ${ROUNDS:-2} ${AB_EXTRA:-} >> $O/r05_ab_wgcap_${TAG:-0}.txt 2>&1; tail -${AB_TAIL:-40} $O/r05_ab_wgcap_${TAG:-0}.txt ;;
     kernel_table) # rocprofv3 duration + SQ counters per ray of the dominant kernel, final library
       bash tools/gpu_kernel_table.sh $O/r05_kernel_table.txt > /dev/null 2>&1 <<'CFG'
 dg_f32_gen  |
