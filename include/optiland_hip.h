@@ -729,7 +729,8 @@ int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void
  *                            default policy (conic-only unpolarised ranges: fp64 three,
  *                            fp32 two under OL_TRACE_FEW_WAVES; nothing else is capped),
  *                            1 = never, 2 ... 8 = every record launch (A/B)
- * The environment variable OL_TRACE_RPT seeds OL_TUNE_RAYS_PER_THREAD.
+ * The environment variables OL_TRACE_RPT / OL_RECORD_WG_CAP seed OL_TUNE_RAYS_PER_THREAD /
+ * OL_TUNE_RECORD_WG_CAP.
  *
  * Environment variables read by the library (A/B runs and parity tests; results are the
  * same to rounding either way):

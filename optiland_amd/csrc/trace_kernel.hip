@@ -1046,6 +1046,10 @@ Tuning& tuning() {
   static Tuning t = [] {
     Tuning v;
     if (const char* e = getenv("OL_TRACE_RPT")) v.rays_per_thread = atoi(e);
+    if (const char* e = getenv("OL_RECORD_WG_CAP")) {
+      const int c = atoi(e);
+      if (c >= 0 && c <= 8) v.record_wg_cap = c;
+    }
     return v;
   }();
   return t;

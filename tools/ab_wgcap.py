@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--placed", action="store_true", help="also time a placed record block")
     ap.add_argument("--mode", default="gen", choices=("gen", "trace"))
+    ap.add_argument("--regimes", default="window,sustained")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     lib = _capi.load()
@@ -93,16 +94,32 @@ def main():
             torch.cuda.synchronize(dev)
             return float(np.mean([p.elapsed_time(q) for p, q in ev[90:]]))
 
+        def spaced(record):
+            # a loop with host work between its traces: 5 ms of idle before every launch
+            ts = []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for k in range(70):
+                time.sleep(0.005)
+                e0.record()
+                launch(record)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                if k >= 10:
+                    ts.append(e0.elapsed_time(e1))
+            return float(np.mean(ts))
+
+        regimes = [(r, {"window": window, "sustained": sustained, "spaced": spaced}[r])
+                   for r in a.regimes.split(",")]
         for where, record in blocks.items():
-            res = {(r, c): [] for r in ("window", "sustained") for c in caps}
+            res = {(r, c): [] for r, _f in regimes for c in caps}
             for rnd in range(a.rounds):
                 order = caps if rnd % 2 == 0 else caps[::-1]
-                for regime, fn in (("window", window), ("sustained", sustained)):
+                for regime, fn in regimes:
                     for c in order:
                         assert lib.ol_set_tuning(_capi.TUNE_RECORD_WG_CAP, c) == 0
                         res[(regime, c)].append(fn(record))
             lib.ol_set_tuning(_capi.TUNE_RECORD_WG_CAP, 0)
-            for regime in ("window", "sustained"):
+            for regime, _f in regimes:
                 base = np.mean(res[(regime, caps[0])])
                 for c in caps:
                     v = res[(regime, c)]
