@@ -691,7 +691,10 @@ int do_trace_opd(const ol_system* sys, const DeviceTable<T>& tab, int64_t n,
   a.last = sys->n_surf - 1;
   a.n_wl = sys->n_wl;
   a.wl = wl;
-  hipError_t e = ol::launch_opd_trace<T>(a, newton_family(sys, 0, sys->n_surf - 1), stream);
+  vec = vec && aligned16(opd) && aligned16(inten);
+  for (int k = 0; k < 3; ++k) vec = vec && aligned16(a.pupil[k]);
+  hipError_t e =
+      ol::launch_opd_trace<T>(a, vec, newton_family(sys, 0, sys->n_surf - 1), stream);
   if (e != hipSuccess) return fail(OL_EHIP, "opd launch failed: %s", hipGetErrorString(e));
   return OL_OK;
 }

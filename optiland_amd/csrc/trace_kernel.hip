@@ -1430,9 +1430,9 @@ template hipError_t launch_spot_batch<double>(const SpotArgs<double>&, const Spo
 // count / sum / sum of squares of the OPD over rays with i > 0 (piston, RMS:
 // wavefront/opd.py:145-159).  The rays never exist in HBM: 2 planes in, 2 (+3) out,
 // where the un-fused chain (ol_generate_rays + record-all ol_trace + ol_wavefront_opd +
-// torch reductions) moves 8 (S + 2) + 13 planes.  One ray per lane: wavefront work is
-// fp64 (an OPD good to lambda/1000 over a 200 mm path) and the interesting systems carry
-// aspheres.  out[] of the moments:
+// torch reductions) moves 8 (S + 2) + 13 planes.  Wavefront work is fp64 (an OPD good to
+// lambda/1000 over a 200 mm path); one ray per lane where the range has a Newton surface (the
+// register budget), two without (RPT).  out[] of the moments:
 //   0 sum w   1 sum w X   2 sum w Y   3 sum w XX   4 sum w XY   5 sum w YY
 //   6 sum w o 7 sum w o X 8 sum w o Y      (w = intensity, o = OPD, X/Y = pupil point)
 //   9 #{i > 0}   10 sum o [i > 0]   11 sum o^2 [i > 0]
@@ -1440,7 +1440,11 @@ template hipError_t launch_spot_batch<double>(const SpotArgs<double>&, const Spo
 // DEVREF: the reference sphere / plane is read from device memory (ol_trace_opd_dev) -- an
 // instantiation of its own: as a launch-uniform branch in the one kernel it cost the 1e7-ray
 // launches 0.9-1.8 % (profiles/r04_ab_opd_devref.txt)
-template <typename T, int NR, bool APOD, bool DEVREF = false>
+// RPT: rays per lane -- 2 (one 16-byte vector of pupil coordinates, two independent chains of
+// fp64 arithmetic per lane) for ranges without a Newton surface: one ray per lane is bound by
+// the latency of its dependent chain there.  The arithmetic of a ray is the
+// same either way (no shared reciprocals): the per-ray outputs are bit-identical.
+template <typename T, int NR, bool APOD, bool DEVREF = false, int RPT = 1>
 __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
     const DevSurfHot<T>* __restrict__ surf_tab, const DevSurfCold<T>* __restrict__ cold_tab,
     const DevOptics<T>* __restrict__ optics_tab, const T* __restrict__ coeff_tab,
@@ -1455,42 +1459,72 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
 #pragma unroll
   for (int k = 0; k < kOpdMoments; ++k) s[k] = 0.0;
 
-  for (int64_t j = (int64_t)blockIdx.x * kTraceBlock + threadIdx.x;
-       j < arg_view<kFetch, T>(a)->n; j += (int64_t)gridDim.x * kTraceBlock) {
-    Ray<T> r[1];
+  // lane l of tile t works on rays (t * kTraceBlock + l) * RPT ... + RPT - 1
+  for (int64_t j = ((int64_t)blockIdx.x * kTraceBlock + threadIdx.x) * RPT;
+       j < arg_view<kFetch, T>(a)->n; j += (int64_t)gridDim.x * kTraceBlock * RPT) {
+    Ray<T> r[RPT];
+    int cnt = RPT;
     {
       const auto A0 = arg_view<kFetch, T>(a);
       const auto& in_ = A0->in;
-      T px = in_.px[j], py = in_.py[j];
-      T vx = in_.vx0, vy = in_.vy0, o[6];
-      raygen_pupil<T>(in_.flags, vx, vy, px, py, status);
+      T px[RPT], py[RPT];
+      if constexpr (RPT == 1) {
+        px[0] = in_.px[j]; py[0] = in_.py[j];
+      } else {
+        const int64_t left = A0->n - j;
+        cnt = left >= RPT ? RPT : (int)left;
+        if (cnt == RPT) {
+          using PV = typename VecOf<T, RPT>::type;
+          const PV vx_ = *reinterpret_cast<const PV*>(in_.px + j);
+          const PV vy_ = *reinterpret_cast<const PV*>(in_.py + j);
+#pragma unroll
+          for (int k = 0; k < RPT; ++k) {
+            px[k] = vec_get<T, RPT>(vx_, k); py[k] = vec_get<T, RPT>(vy_, k);
+          }
+        } else {
+          // the last lane of an odd launch: the rays past the end trace the pupil's centre
+          // and are kept out of every output
+#pragma unroll
+          for (int k = 0; k < RPT; ++k) {
+            px[k] = k < cnt ? in_.px[j + k] : T(0); py[k] = k < cnt ? in_.py[j + k] : T(0);
+          }
+        }
+      }
       const RaygenConsts<T> c = consts_of(&A0->rgc);
-      raygen_one<T>(c, in_.tx0, in_.ty0, px, py, vx, vy, o);
-      r[0].x = o[0]; r[0].y = o[1]; r[0].z = o[2];
-      r[0].L = o[3]; r[0].M = o[4]; r[0].N = o[5];
-      if constexpr (APOD) r[0].i = raygen_apodize<T>(c, px, py); else r[0].i = T(1);
-      r[0].opd = T(0);
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        T vx = in_.vx0, vy = in_.vy0, o[6];
+        uint32_t st = 0;
+        raygen_pupil<T>(in_.flags, vx, vy, px[k], py[k], st);
+        if (k < cnt) status |= st;
+        raygen_one<T>(c, in_.tx0, in_.ty0, px[k], py[k], vx, vy, o);
+        r[k].x = o[0]; r[k].y = o[1]; r[k].z = o[2];
+        r[k].L = o[3]; r[k].M = o[4]; r[k].N = o[5];
+        if constexpr (APOD) r[k].i = raygen_apodize<T>(c, px[k], py[k]); else r[k].i = T(1);
+        r[k].opd = T(0);
+      }
     }
 
     bool is_global = true;
     DevSurf<T> last_traced;
     last_traced.cold = as_const(cold_tab);
     Prt<T, 0> P[1];
-    Ray<T> g;
+    Ray<T> g[RPT];
     if constexpr (kFetchRows) {
       int last_idx = 0;
       const int first = kernargs<T, OpdArgs<T>>()->a.first;
       for (int sidx = first; sidx <= kernargs<T, OpdArgs<T>>()->a.last; ++sidx) {
         const SurfFetched<T> h = fetched_surface<T, OpdArgs<T>>(sidx);
         if (refresh(h.hot)->interaction != kRecordOnly) {
-          surface_step<T, 1, 0, NR>(h, as_const(kernargs<T, OpdArgs<T>>()->coeffs), is_global, r,
-                                    P, status, prt_fresh);
+          surface_step<T, RPT, 0, NR>(h, as_const(kernargs<T, OpdArgs<T>>()->coeffs), is_global,
+                                      r, P, status, prt_fresh);
           is_global = false;
           last_idx = sidx;
         }
       }
       const DevSurf<T> lt = fetched_surface<T, OpdArgs<T>>(last_idx).surf();
-      g = is_global ? r[0] : to_global<T>(lt, r[0]);
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) g[k] = is_global ? r[k] : to_global<T>(lt, r[k]);
     } else {
       constexpr bool kPrefetch =
           (OL_FUSED_NR_PREFETCH || NR == 0) && (OL_PREFETCH_F64 || sizeof(T) == 4);
@@ -1506,18 +1540,19 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
         S.cold = as_const(cold_tab) + sidx;
         if (S.interaction != kRecordOnly) {
           const DevOptics<T> O = optics_tab[sidx * a.n_wl + a.wl];
-          surface_step<T, 1, 0, NR>(S, O, as_const(coeff_tab), is_global, r, P, status, prt_fresh);
+          surface_step<T, RPT, 0, NR>(S, O, as_const(coeff_tab), is_global, r, P, status,
+                                      prt_fresh);
           is_global = false;
           last_traced = S;
         }
       }
-      g = is_global ? r[0] : to_global<T>(last_traced, r[0]);
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) g[k] = is_global ? r[k] : to_global<T>(last_traced, r[k]);
     }
-    T pu[3];
     const auto A1 = arg_view<kFetch, T>(a);
     // the pupil coordinates of the tilt term are the ones the CALLER passed (the
     // reference corrects with the distribution's points, strategy.py:88-139)
-    T ov;
+    T ov[RPT], gi[RPT], pu[3][RPT];
     {
       // the reference sphere / plane: from the argument block, or (ol_trace_opd_dev) from the
       // device structure ol_wavefront_reference left -- a launch-uniform choice, scalar loads
@@ -1525,19 +1560,41 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
       WavefrontConsts<T> w;
       if constexpr (DEVREF) w = load_consts(as_const(A1->wf_dev));
       else w = consts_of(&A1->wfc);
-      final_propagate<T, false>(w, g);
-      ov = wavefront_one<T>(w, g.x, g.y, g.z, g.L, g.M, g.N, g.opd, A1->in.px[j], A1->in.py[j],
-                            pu);
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        final_propagate<T, false>(w, g[k]);
+        const int64_t jk = k < cnt ? j + k : j;
+        T q[3];
+        ov[k] = wavefront_one<T>(w, g[k].x, g[k].y, g[k].z, g[k].L, g[k].M, g[k].N, g[k].opd,
+                                 A1->in.px[jk], A1->in.py[jk], q);
+        gi[k] = g[k].i;
+        pu[0][k] = q[0]; pu[1][k] = q[1]; pu[2][k] = q[2];
+      }
     }
-    A1->opd[j] = ov;
-    A1->inten[j] = g.i;
     T* const pup0 = A1->pupil[0];
-    if (pup0) {
-      pup0[j] = pu[0];
-      A1->pupil[1][j] = pu[1];
-      A1->pupil[2][j] = pu[2];
+    if constexpr (RPT == 1) {
+      A1->opd[j] = ov[0];
+      A1->inten[j] = gi[0];
+      if (pup0) {
+        pup0[j] = pu[0][0];
+        A1->pupil[1][j] = pu[1][0];
+        A1->pupil[2][j] = pu[2][0];
+      }
+    } else {
+      const RayIndexT<false> at{j, 0u};
+      store_plane<T, RPT>(A1->opd, at, cnt, ov);
+      store_plane<T, RPT>(A1->inten, at, cnt, gi);
+      if (pup0) {
+        store_plane<T, RPT>(pup0, at, cnt, pu[0]);
+        store_plane<T, RPT>(A1->pupil[1], at, cnt, pu[1]);
+        store_plane<T, RPT>(A1->pupil[2], at, cnt, pu[2]);
+      }
     }
-    opd_accumulate(s, (double)g.i, (double)ov, (double)pu[0], (double)pu[1], g.i > T(0));
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+      if (k < cnt)
+        opd_accumulate(s, (double)gi[k], (double)ov[k], (double)pu[0][k], (double)pu[1][k],
+                       gi[k] > T(0));
   }
 
   // workgroup reduction -> kOpdMoments atomics (every thread reaches this point)
@@ -1566,40 +1623,54 @@ __global__ __launch_bounds__(kTraceBlock) void opd_trace_kernel(
   if (status && status_out) atomicOr(status_out, status);
 }
 
+// vector_ok: px / py and every output plane allow 16-byte lane accesses (capi.hip)
 template <typename T>
-hipError_t launch_opd_trace(const OpdArgs<T>& a_in, int nr_family, hipStream_t stream) {
+hipError_t launch_opd_trace(const OpdArgs<T>& a_in, bool vector_ok, int nr_family,
+                            hipStream_t stream) {
   OpdArgs<T> a = a_in;
   uniform_field_tangents<T>(a.rg, a.in);
   a.rgc = RaygenConsts<T>(a.rg);
   a.wfc = WavefrontConsts<T>(a.wf);
-  int64_t blocks = (a.n + kTraceBlock - 1) / kTraceBlock;
-  if (blocks == 0) return hipSuccess;
+  if (a.n == 0) return hipSuccess;
+  // two rays per lane where there is no Newton surface and the launch fills the part either
+  // way (>= 2048 workgroups; OL_TUNE_RAYS_PER_THREAD = 1: always one)
+#ifndef OL_OPD_TWO_RAYS
+#define OL_OPD_TWO_RAYS 1
+#endif
+  const bool two = OL_OPD_TWO_RAYS && vector_ok && nr_family == kNrNone &&
+                   tuning().rays_per_thread != 1 && a.n >= (int64_t)4096 * kTraceBlock;
+  const int64_t per_block = (int64_t)kTraceBlock * (two ? 2 : 1);
+  int64_t blocks = (a.n + per_block - 1) / per_block;
   if (blocks > 8192) blocks = 8192;  // grid-stride beyond: keeps the atomics few
   const bool apod = a.rg.apod_kind != 0;
-#define OL_OPD_LAUNCH(N, A)                                                                  \
+#define OL_OPD_LAUNCH_R(N, A, R)                                                             \
   do {                                                                                       \
     if (a.wf_dev != nullptr)                                                                 \
-      hipLaunchKernelGGL((opd_trace_kernel<T, N, A, true>), dim3((unsigned)blocks),          \
+      hipLaunchKernelGGL((opd_trace_kernel<T, N, A, true, R>), dim3((unsigned)blocks),       \
                          dim3(kTraceBlock), 0, stream, a.surf, a.cold, a.optics, a.coeffs, a); \
     else                                                                                     \
-      hipLaunchKernelGGL((opd_trace_kernel<T, N, A, false>), dim3((unsigned)blocks),         \
+      hipLaunchKernelGGL((opd_trace_kernel<T, N, A, false, R>), dim3((unsigned)blocks),      \
                          dim3(kTraceBlock), 0, stream, a.surf, a.cold, a.optics, a.coeffs, a); \
   } while (0)
+#define OL_OPD_LAUNCH(N, A) OL_OPD_LAUNCH_R(N, A, 1)
   if (nr_family == kNrZernike) {
     if (apod) OL_OPD_LAUNCH(kNrZernike, true); else OL_OPD_LAUNCH(kNrZernike, false);
   } else if (nr_family == kNrEvenAsphere) {
     if (apod) OL_OPD_LAUNCH(kNrEvenAsphere, true); else OL_OPD_LAUNCH(kNrEvenAsphere, false);
   } else if (nr_family != kNrNone) {
     if (apod) OL_OPD_LAUNCH(1, true); else OL_OPD_LAUNCH(1, false);
+  } else if (two) {
+    if (apod) OL_OPD_LAUNCH_R(0, true, 2); else OL_OPD_LAUNCH_R(0, false, 2);
   } else {
     if (apod) OL_OPD_LAUNCH(0, true); else OL_OPD_LAUNCH(0, false);
   }
 #undef OL_OPD_LAUNCH
+#undef OL_OPD_LAUNCH_R
   return hipGetLastError();
 }
 
 #if OL_TRACE_TU == 0 || OL_TRACE_TU == 2
-template hipError_t launch_opd_trace<double>(const OpdArgs<double>&, int, hipStream_t);
+template hipError_t launch_opd_trace<double>(const OpdArgs<double>&, bool, int, hipStream_t);
 #endif
 
 // --------------------------------------------------------------------------

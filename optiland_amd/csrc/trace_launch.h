@@ -292,7 +292,8 @@ struct OpdArgs {
   const WavefrontConsts<T>* wf_dev;
 };
 template <typename T>
-hipError_t launch_opd_trace(const OpdArgs<T>& a, int nr_family, hipStream_t stream);
+hipError_t launch_opd_trace(const OpdArgs<T>& a, bool vector_ok, int nr_family,
+                            hipStream_t stream);
 
 // ol_wavefront_reference: the chief ray of one field point traced by ONE lane and turned into
 // the reference sphere / plane of the wavefront kernels, left in device memory

@@ -624,7 +624,8 @@ template hipError_t launch_spot_batch<double>(const SpotArgs<double>&, const Spo
 
 // opd_trace_kernel + launch_opd_trace (trace_kernel.hip), ray by ray
 template <typename T>
-hipError_t launch_opd_trace(const OpdArgs<T>& a_in, int nr_family, hipStream_t) {
+hipError_t launch_opd_trace(const OpdArgs<T>& a_in, bool /*vector_ok*/, int nr_family,
+                            hipStream_t) {
   OpdArgs<T> a = a_in;
   uniform_field_tangents<T>(a.rg, a.in);
   const RaygenConsts<T> c(a.rg);
@@ -664,7 +665,7 @@ hipError_t launch_opd_trace(const OpdArgs<T>& a_in, int nr_family, hipStream_t) 
   if (status && a.status) *a.status |= status;
   return hipSuccess;
 }
-template hipError_t launch_opd_trace<double>(const OpdArgs<double>&, int, hipStream_t);
+template hipError_t launch_opd_trace<double>(const OpdArgs<double>&, bool, int, hipStream_t);
 
 // chief_ref_kernel + launch_chief_reference (trace_kernel.hip), statement by statement
 template <typename T>

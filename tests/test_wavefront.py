@@ -409,3 +409,45 @@ def test_fused_opd_on_every_sample_and_fuzz_lens(case, where):
             np.testing.assert_allclose(ia, ib, rtol=1e-8, atol=1e-12, equal_nan=True)
     finally:
         real.engine.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["double_gauss", "apodized_gaussian_trace"])
+def test_fused_opd_two_rays_per_lane_is_bit_identical(name):
+    """Round 5: without a Newton surface a launch of >= 2^20 rays runs `opd_trace_kernel` with
+    TWO rays per lane (16-byte loads / stores, two independent chains); a ray's arithmetic is
+    the same, so the map, the intensities and the pupil points equal the one-ray form's bit
+    for bit (`OL_TUNE_RAYS_PER_THREAD = 1`), the 12 sums to their rounding.  An odd count
+    (the last lane holds one ray) and an unaligned plane (one ray per lane again) included."""
+    from optiland_amd import _capi
+    from optiland_amd.engine import HipSystem
+    table = _golden_or_data(name)
+    hip = HipSystem(table, "cuda:0")
+    t = tr.HipRayTracer(table, "cuda:0", dtype=torch.float64, engine=hip)
+    wf = Wavefront(t, (0.0, 0.7), float(table.wavelengths[0]), num_rays=3)
+    params = wf.chief_reference()[0]
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    n = (1 << 20) + 4097
+    r = torch.rand(n + 1, generator=g, device="cuda:0", dtype=torch.float64).sqrt()
+    th = 2 * np.pi * torch.rand(n + 1, generator=g, device="cuda:0", dtype=torch.float64)
+    px_all, py_all = r * th.cos(), r * th.sin()
+    try:
+        for lo, count, want_pupil in ((0, n - 1, True), (0, n, False), (1, n - 1, False)):
+            px, py = px_all[lo:lo + count], py_all[lo:lo + count]   # lo = 1: 8-byte aligned only
+            out = {}
+            for rpt in (1, 0):
+                assert hip.lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, rpt) == 0
+                out[rpt] = hip.trace_opd(params, px, py, 0, field=(0.0, 0.7),
+                                         want_pupil=want_pupil)
+            a, b = out[1], out[0]
+            assert torch.isfinite(a[0]).float().mean() > 0.5
+            assert torch.equal(a[0].nan_to_num(), b[0].nan_to_num())
+            assert torch.equal(torch.isnan(a[0]), torch.isnan(b[0]))
+            assert torch.equal(a[1], b[1])
+            if want_pupil:
+                assert torch.equal(a[2].nan_to_num(), b[2].nan_to_num())
+            np.testing.assert_allclose(b[3].cpu().numpy(), a[3].cpu().numpy(), rtol=1e-11,
+                                       atol=1e-9 * float(a[3].abs().max()))
+    finally:
+        hip.lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, 0)
+        hip.close()

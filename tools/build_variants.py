@@ -86,6 +86,9 @@ VARIANTS = {
     # waves by itself; 79 / 6 waves on request without spills; 72 / 7 waves with 12 B of scratch)
     "lean64_w6": ["-DOL_LEAN_F64_WAVES=6"],
     "lean64_w7": ["-DOL_LEAN_F64_WAVES=7"],
+    # the fused OPD kernel with one ray per lane everywhere (round 5 default: two without a
+    # Newton surface, launches of >= 2^20 rays)
+    "opd_one": ["-DOL_OPD_TWO_RAYS=0"],
 }
 
 
