@@ -108,6 +108,29 @@ def _broadcast_message(a: int, b: int) -> str:
     return f"operands could not be broadcast together with shapes ({int(a)},) ({int(b)},) "
 
 
+def _size_mismatch_message(nhx, nhy, npx, npy):
+    """The text of the ValueError the reference's NumPy backend ends in when the coordinate
+    arrays of `trace_generic` differ in length, or None when they agree (sizes; None = a scalar
+    or a one-element array, which broadcasts).  Which operation fails first decides the text:
+    `FieldGroup.get_vig_factor` broadcasts Hx against Hy (fields/field_group.py:93-122);
+    `Px * (1 - vx)` / `Py * (1 - vy)` meet the field length next (real_ray_tracer.py:134-137);
+    without field arrays the scalars were padded to the LONGER pupil array
+    (real_ray_tracer.py:175-194) and the shorter one fails against it in
+    `AngleField.get_ray_origins` (fields/field_types/angle.py:40-47)."""
+    if nhx is not None and nhy is not None and nhx != nhy:
+        return ("shape mismatch: objects cannot be broadcast to a single shape.  Mismatch is "
+                f"between arg 0 with shape ({int(nhx)},) and arg 1 with shape ({int(nhy)},).")
+    f = nhx if nhx is not None else nhy
+    if f is not None:
+        for p in (npx, npy):
+            if p is not None and p != f:
+                return _broadcast_message(p, f)
+        return None
+    if npx is not None and npy is not None and npx != npy:
+        return _broadcast_message(min(npx, npy), max(npx, npy))
+    return None
+
+
 def _can_field_planes(can) -> bool:
     try:
         return bool(can(field_planes=True))
@@ -492,6 +515,12 @@ class HipRayTracer:
         sx, sy = self._as_scalar(Hx), self._as_scalar(Hy)
         px, py = self._dev(Px), self._dev(Py)
         flags = _capi.RAYGEN_CHECK_PUPIL
+        sizes = [None if s_ is not None else int(np.size(v) if not isinstance(v, torch.Tensor)
+                                                  else v.numel())
+                 for s_, v in ((sx, Hx), (sy, Hy))] + [int(px.numel()), int(py.numel())]
+        bad = _size_mismatch_message(*[None if k == 1 else k for k in sizes])
+        if bad is not None:
+            raise ValueError(bad)
         if sx is not None and sy is not None:
             n = max(px.numel(), py.numel())
             hx, hy = sx, sy

@@ -466,7 +466,9 @@ def test_trace_generic_input_matrix_matches_the_reference(hip_on_cpu):
     # (arrays of different lengths: NumPy's broadcast error text, the exception the reference's
     # NumPy backend ends in; its torch backend raises torch's RuntimeError for the same call)
     assert bad_size[:2] == ("err", "ValueError")
-    assert bad_size[2] == "operands could not be broadcast together with shapes (3,) (2,) "
+    assert bad_size[2] == "operands could not be broadcast together with shapes (2,) (3,) "
+    both = run(hip_lens, (T([0.0, 0.1]), T([0.0, 0.1, 0.2]), T([0.1, 0.2]), 0.1))
+    assert both[1] == "ValueError" and both[2].startswith("shape mismatch: objects cannot be")
     empty = run(hip_lens, (0.0, 0.5, T([]), T([])))
     assert empty[0] == "ok" and empty[1].size == 0
     arr = run(hip_lens, (0.0, 0.5, np.array([0.1, -0.2]), [0.3, 0.2]))
@@ -954,3 +956,31 @@ def test_bridging_on_random_lenses(sg_seam, seed):
         if k in "xyz" and not np.isfinite(b[0]).all():
             a, b = a[1:], b[1:]
         close(a, b, "record " + k)
+
+
+def test_size_mismatch_text_is_the_numpy_backends(ref):
+    """Round 5 ("array-length mismatch -- same type, different text").  The text
+    `HipRayTracer.trace_generic` raises for coordinate arrays of different lengths is the one
+    the LIVE reference's NumPy backend ends in, for every combination of array / scalar
+    arguments (which operation of the reference fails first decides it)."""
+    import itertools
+
+    from optiland.samples.objectives import CookeTriplet
+    from optiland_amd.tracer import _size_mismatch_message
+    be = ref
+    be.set_backend("numpy")
+    lens = CookeTriplet()
+    for lens_ in ((3, 4, 5, 6), (6, 5, 4, 3), (4, 4, 5, 6), (4, 4, 4, 6), (4, 4, 6, 4), (2, 2, 7, 5),
+                  (9, 9, 2, 9), (3, 3, 3, 3)):
+        for mask in itertools.product([0, 1], repeat=4):
+            args = [np.full(n, 0.1) if m else 0.1 for n, m in zip(lens_, mask)]
+            try:
+                lens.trace_generic(*args, 0.55)
+                want = None
+            except ValueError as e:
+                want = str(e)
+            got = _size_mismatch_message(*[n if m else None for n, m in zip(lens_, mask)])
+            assert got == want, (lens_, mask, got, want)
+    # a one-element array broadcasts like a scalar
+    assert lens.trace_generic(np.array([0.0]), 0.1, np.full(5, 0.1), np.array([0.2]), 0.55) \
+        .x.shape == (5,)
