@@ -104,15 +104,17 @@ _POOL_COOLDOWN: dict = {}  # device index -> big allocations left before another
 # arena has since been freed only costs that hint; a few dozen entries at most.
 _PLACED_WINDOWS: "collections.OrderedDict" = collections.OrderedDict()
 _PLACED_MAX = 64
+_PLACED_LOCK = threading.Lock()
 _FEW_WAVES_MIN_BYTES = 256 << 20
 
 
 def _note_placed(device, ptr: int, nbytes: int) -> None:
     key = (device.index or 0, int(ptr))
-    _PLACED_WINDOWS[key] = int(nbytes)
-    _PLACED_WINDOWS.move_to_end(key)
-    while len(_PLACED_WINDOWS) > _PLACED_MAX:
-        _PLACED_WINDOWS.popitem(last=False)
+    with _PLACED_LOCK:
+        _PLACED_WINDOWS[key] = int(nbytes)
+        _PLACED_WINDOWS.move_to_end(key)
+        while len(_PLACED_WINDOWS) > _PLACED_MAX:
+            _PLACED_WINDOWS.popitem(last=False)
 
 
 def _few_waves_flag(rec) -> int:
@@ -120,9 +122,10 @@ def _few_waves_flag(rec) -> int:
     if rec is None or rec.numel() * rec.element_size() < _FEW_WAVES_MIN_BYTES:
         return 0
     dev, ptr = rec.device.index or 0, rec.data_ptr()
-    for (d, lo), nb in list(_PLACED_WINDOWS.items()):
-        if d == dev and lo <= ptr < lo + nb:
-            return 0
+    with _PLACED_LOCK:
+        for (d, lo), nb in _PLACED_WINDOWS.items():
+            if d == dev and lo <= ptr < lo + nb:
+                return 0
     return S.TRACE_FEW_WAVES
 
 
