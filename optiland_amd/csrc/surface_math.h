@@ -1074,8 +1074,13 @@ OL_DEV void nr_eval(const DevSurf<T>& s, cptr<T> c, T x, T y,
 //    (newton_raphson.py:148); here a ray that sees |f| < tol takes ONE more
 //    update and leaves (quadratic convergence => its residual is far below the
 //    reference's own), NaN rays leave at once, and a ray whose residual no longer
-//    halves (rounding floor reached -- fp32 with tol below the noise of sag - z)
-//    leaves too instead of spinning to max_iter;
+//    halves AT THE ROUNDING FLOOR of sag - z (fp32 with tol below that noise: within
+//    OL_NR_STALL_ULPS eps of |sag| + |z|) leaves too instead of spinning to
+//    max_iter.  (Until round 5 the rule had no floor: a ray that starts badly -- the rim
+//    of an oblate biconic mirror, residuals 4.0, 2.3, 0.97, 0.13, 2e-3, 7e-7 mm -- was cut
+//    off after its second step with 1 mm of residual where the reference converges;
+//    fuzz_7016 of profiles/r05_gpu_fuzz_tables.txt.)  A ray that neither converges nor
+//    reaches the floor runs to max_iter, as the reference's does;
 //  * the gradient of the LAST evaluation is returned and reused for the surface
 //    normal: the hit point moved by |f|/|f'| < tol since, which changes the
 //    normal by < curvature * tol.
@@ -1097,7 +1102,13 @@ OL_DEV void newton_iterate(const DevSurf<T>& s, cptr<T> c,
   T f = sag - zi;
   T af = m::abs(f);
   bool done = !(af >= s.cold->tol);                       // converged, or NaN
-  done = done || (it > 0 && !(af < T(0.5) * q.fprev));  // residual stopped halving
+#ifndef OL_NR_STALL_ULPS
+#define OL_NR_STALL_ULPS 1024  // (0: the rule of rounds 1-4, no floor -- A/B only)
+#endif
+  // residual stopped halving, and that close to the noise of the subtraction
+  const bool at_floor = OL_NR_STALL_ULPS == 0 ||
+      !(af > T(OL_NR_STALL_ULPS) * m::eps() * (m::abs(sag) + m::abs(zi)));
+  done = done || (it > 0 && at_floor && !(af < T(0.5) * q.fprev));
   T df = m::fma(fx, L, m::fma(fy, M, -N));
   T dfs = m::abs(df) > m::guard() ? df : m::guard();
   q.dt = q.dt - m::div(f, dfs);

@@ -89,6 +89,9 @@ VARIANTS = {
     # the fused OPD kernel with one ray per lane everywhere (round 5 default: two without a
     # Newton surface, launches of >= 2^20 rays)
     "opd_one": ["-DOL_OPD_TWO_RAYS=0"],
+    # Newton stop rule of rounds 1-4: a ray whose residual stops halving leaves at ANY level
+    # (round 5: only at the rounding floor of sag - z)
+    "old_stall": ["-DOL_NR_STALL_ULPS=0"],
 }
 
 
