@@ -26,6 +26,49 @@ from tests import _hostmath as hm
 from tests._util import assert_close_planes
 from tests.test_gpu_fuzz import random_system, random_nr_system, random_polarised_system
 from tests.test_hostmath_fuzz import _planes
+def _newton_triage(table, got, rec, tol, rays_in, pol):
+    with np.errstate(invalid="ignore"):
+        dev = np.abs(got - rec) / np.maximum(1.0, np.abs(rec))
+    differs = (np.nan_to_num(dev, nan=0.0) > max(tol, 1e-9)) | (np.isnan(got) != np.isnan(rec))
+    rays = np.nonzero(differs.any(axis=(0, 1)))[0]
+    nr_rows = np.nonzero(table.surfaces["max_iter"] > 0)[0]
+    unexplained = 0
+    for j in rays:
+        first = int(np.nonzero(differs[:, :, j].any(axis=1))[0][0])
+        # the Newton surfaces up to and including the first deviating row: the ray is "lost"
+        # from the first one the reference's hit is not on
+        lost = False
+        for s_i in nr_rows[nr_rows <= first]:
+            sf = table.surfaces[s_i]
+            Rm, o_ = np.array(sf["rot"]).reshape(3, 3), np.array(sf["origin"])
+            loc = Rm @ (rec[s_i, :3, j] - o_)
+            f_ = oracle.sag(table, int(s_i), float(loc[0]), float(loc[1])) - loc[2]
+            if not abs(f_) < 1e-3:
+                lost = True
+                break
+        if not lost:
+            # the reference did reach A root: is its choice stable?  The same ray moved by 1e-10
+            # of its start -- if the oracle's own hit at that row jumps, the iteration is
+            # chaotic there (a local minimum of f that Newton bounces off until it escapes to
+            # whichever root rounding decides: seed 68386, a switched-off ray whose reference
+            # hit lies BEHIND it, t = -264 mm, and the kernel's in front, t = +134)
+            one = {k: np.array([v[j]], dtype=np.float64) for k, v in rays_in.items()
+                   if isinstance(v, np.ndarray) and v.shape[:1] == (rec.shape[2],)}
+            base = oracle.trace(table, one, 0, record=True, polarized=pol)["record"][first, :3, 0]
+            for eps in (1e-10, -1e-10, 3e-10):
+                moved = dict(one)
+                moved["x"] = one["x"] + eps * max(1.0, abs(float(one["x"][0])))
+                hit = oracle.trace(table, moved, 0, record=True, polarized=pol)["record"][first, :3, 0]
+                if not np.all(np.abs(hit - base) < 1e-3):
+                    lost = True
+                    break
+        if not lost:
+            unexplained += 1
+    if unexplained == 0:
+        return "newton (the reference's own iteration lost the ray or is chaotic there: no root / folded-over asphere / local minimum of f)"
+    return f"UNKNOWN newton ({unexplained} of {len(rays)} deviating rays reached the surface in the reference)"
+
+
 bad=[]
 t0=time.time()
 lo,hi=int(sys.argv[1]),int(sys.argv[2])
@@ -65,7 +108,14 @@ for seed in range(lo,hi):
             except AssertionError:
                 rec_ok = False
             if has_nr_s:
-                why = "newton (chaotic far-field rays)"
+                # Round 5: not a label by default any more.  Every ray whose record deviates is
+                # followed to the FIRST Newton surface where it does: if the oracle's own hit is
+                # not on that surface (|sag(x, y) - z| > 1e-3 mm in its frame, or NaN) the
+                # reference's iteration lost the ray -- no root, or a folded-over asphere -- and
+                # what max_iter steps leave is rounding noise on both sides.  A ray the
+                # reference DID bring to the surface and the kernel did not is a defect (round 5
+                # found one: the stop rule) and is printed as UNKNOWN.
+                why = _newton_triage(table, got, want["record"], tol, rays, pol)
             elif not rec_ok and near_para and np.array_equal(np.isnan(got), np.isnan(want["record"])) \
                     and float(np.nanmax(np.abs(got - want["record"]))) < 1e-4:
                 why = "cancelling reference root (|1 + k N^2| small)"
@@ -101,5 +151,5 @@ print("seeds",lo,hi,"bad",len(bad),"time",time.time()-t0)
 import collections
 print(collections.Counter(b[2] for b in bad))
 for b in bad:
-    if b[2] == "UNKNOWN":
+    if b[2].startswith("UNKNOWN"):
         print(b)
