@@ -10,7 +10,11 @@ root formula on a paraboloid hit almost along the axis (the kernel's root is the
 beyond 45 degrees of incidence.  Round 4, seeds 30000-49999 (60000 systems, the kernel source of
 that round): 461 with a discrepancy -- 317 / 71 / 70 of those three kinds and 3 of a fourth:
 single rays, already switched off by an aperture, that graze a vertex plane (|N| ~ 1e-6 ... 1e-4)
-and land 1e5-6e6 mm off axis, where one ulp of N is 1e-3 mm.
+and land 1e5-6e6 mm off axis, where one ulp of N is 1e-3 mm.  Round 5: the Newton bin is triaged ray by
+ray (`_newton_triage`) instead of by "the system has a Newton surface"; that, and the GPU fuzz on
+new seeds, found converging rays the kernel's stop rule cut short (fixed: DESIGN 4.1 item 6).
+Seeds 30000-49999, 60000-99999 (180 000 systems) on the fixed source: 1384 with a discrepancy, none
+unknown (profiles/r05_host_long_fuzz.txt).
 
     python tools/host_long_fuzz.py 1000 1600
 """
@@ -32,9 +36,17 @@ def _newton_triage(table, got, rec, tol, rays_in, pol):
     differs = (np.nan_to_num(dev, nan=0.0) > max(tol, 1e-9)) | (np.isnan(got) != np.isnan(rec))
     rays = np.nonzero(differs.any(axis=(0, 1)))[0]
     nr_rows = np.nonzero(table.surfaces["max_iter"] > 0)[0]
-    unexplained = 0
+    unexplained = cancelling = 0
+    sk = table.surfaces
     for j in rays:
         first = int(np.nonzero(differs[:, :, j].any(axis=1))[0][0])
+        if sk["max_iter"][first] == 0 and sk["geom_kind"][first] == 1 \
+                and abs(float(sk["conic"][first]) + 1.0) < 0.6 \
+                and float(np.nanmax(dev[first, :, j])) < 1e-4:
+            # the first surface where this ray deviates is a near-parabolic CONIC of a system
+            # that happens to hold a Newton surface elsewhere: the reference's cancelling root
+            cancelling += 1
+            continue
         # the Newton surfaces up to and including the first deviating row: the ray is "lost"
         # from the first one the reference's hit is not on
         lost = False
@@ -64,6 +76,8 @@ def _newton_triage(table, got, rec, tol, rays_in, pol):
                     break
         if not lost:
             unexplained += 1
+    if unexplained == 0 and cancelling == len(rays):
+        return "cancelling reference root (|1 + k N^2| small)"
     if unexplained == 0:
         return "newton (the reference's own iteration lost the ray or is chaotic there: no root / folded-over asphere / local minimum of f)"
     return f"UNKNOWN newton ({unexplained} of {len(rays)} deviating rays reached the surface in the reference)"
