@@ -14,6 +14,15 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("rf", os.path.join(ROOT, "tests", "test_reference_fuzz.py"))
 rf = importlib.util.module_from_spec(spec); spec.loader.exec_module(rf)
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+if len(sys.argv) > 3 and sys.argv[3] == "kernel-source":
+    # round 5: the SAME families with the product's engine class on the host build of the kernel
+    # source (tests/_hostmath.py) in place of the oracle-backed stand-in: live reference vs kernel
+    # arithmetic, lens by lens (the tolerances are the oracle run's)
+    import tests._fake_engine as _fe
+    from tests import _hostmath as _hm
+    _cls = _hm.make_engine_class()
+    _fe.OracleEngine = lambda table, device="cpu": _cls(table, device)
+    print("# engine: host build of the kernel source")
 for name, extra in (("test_random_reference_lens_equals_packer_plus_oracle", ()),
                     ("test_standalone_tracer_on_random_lenses", ()),
                     ("test_standalone_spot_diagram_on_random_lenses", ("chief_ray",)),
