@@ -611,7 +611,15 @@ def _fused_fitted(self, field, wavelength):
     opd, pupil = eng.wavefront_opd_fitted(ref, r8[:7], px, py, want_pupil=True)
     host = ref.cpu()                                    # the one wait for the device
     front._finish_checks(eng)
-    eng.raise_for_fit_status(int(host[-1:].view(torch.int32)[0]))
+    from . import _capi
+    bits = int(host[-1:].view(torch.int32)[0])
+    if bits & _capi.FIT_SINGULAR and not bits & (_capi.FIT_NO_VALID | _capi.FIT_TOO_FEW):
+        # wavefront points that do not span space (a collimated beam: one plane): the device
+        # fit has no fourth pivot.  The reference's own code -- `lstsq` of its backend on the
+        # raw system, a rank-3 minimum-norm sphere -- runs instead, on the drop-in's trace.
+        _why("opd_fit", "rank-deficient wavefront points (singular device fit)")
+        return None
+    eng.raise_for_fit_status(bits)
     if kind == "best_fit" and not planar:
         self.center = tuple(float(v) for v in host[0:3])  # strategy.py:581
     _register(self.optic, front, table, (hx, hy, px, py, vig, w, 0))

@@ -36,7 +36,7 @@ struct FitState {
   double n_valid, unit_w, sw, c0[3], swd[3];        // C1
   double mean_d, thr, trim_on;                       // C2, C3
   double trimmed, sw_final, cen[3];                  // C4 (or C1 without trimming)
-  double m[3], sc[3], isc[3];                        // B1
+  double m[3], sc[3], isc[3], deficient;             // B1
   uint32_t ticket[kFitPasses];                       // blocks finished, per pass
 };
 static_assert(sizeof(FitState) <= kFitStateDoubles * sizeof(double), "FitState outgrew its slot");
@@ -148,12 +148,17 @@ OL_DEV void fit_centroid_done(const FitParams& p, FitState& st, const double* sw
   }
 }
 
-// 4 x 4 symmetric positive definite solve (Cholesky); false if a pivot is not positive
+// 4 x 4 symmetric positive definite solve (Cholesky); false if a pivot is not positive -- or,
+// round 5, not clearly positive: a pivot below 1e-10 of its diagonal entry is a direction the
+// points do not span (a tilted PLANE of wavefront points: a collimated beam), and what the
+// elimination leaves of it is rounding noise.  The caller then reports kFitSingular and the host
+// solves the raw system the way the reference does (SVD, minimum norm: wavefront.py).
 OL_DEV bool fit_solve4(double (&A)[4][4], double (&b)[4]) {
   for (int j = 0; j < 4; ++j) {
-    double d = A[j][j];
+    const double ajj = A[j][j];
+    double d = ajj;
     for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
-    if (!(d > 0.0)) return false;
+    if (!(d > 1e-10 * ajj)) return false;
     d = ::sqrt(d);
     A[j][j] = d;
     for (int i = j + 1; i < 4; ++i) {
@@ -250,10 +255,24 @@ OL_DEV void fit_finish(const FitParams& p, FitState& st, const double* s,
     st.n_valid = s[0];
     if (s[0] == 0.0) *status |= kFitNoValid;
     else if (s[0] < 4.0) *status |= kFitTooFew;
+    double var[3], vmax = 0.0;
+    st.deficient = 0.0;
     for (int k = 0; k < 3; ++k) {
       st.m[k] = s[1 + k] / s[0];
-      const double var = s[4 + k] / s[0] - st.m[k] * st.m[k];
-      st.sc[k] = var > 0.0 ? ::sqrt(var) : 1.0;  // a scale, not a statistic: any value > 0 works
+      var[k] = s[4 + k] / s[0] - st.m[k] * st.m[k];
+      if (var[k] > vmax) vmax = var[k];
+    }
+    for (int k = 0; k < 3; ++k) {
+      // Round 5: an axis along which the points do not spread (a collimated beam: the
+      // wavefront points of an afocal system lie in ONE plane, z = const to 1e-14) has a
+      // "variance" that is the cancellation noise of E[x^2] - m^2, ~eps m^2; scaled by its
+      // square root it would look like a fourth dimension and the sphere would be fitted to
+      // noise (radius 1e2 ... 1e13 where NumPy's rank-3 minimum-norm solution says 4.7).
+      // Such a cloud is reported as singular; the host follows the reference from there.
+      if (!p.planar && s[0] >= 4.0 && !(var[k] > 64.0 * 2.220446049250313e-16 *
+                                                      (st.m[k] * st.m[k] + vmax)))
+        st.deficient = 1.0;
+      st.sc[k] = var[k] > 0.0 ? ::sqrt(var[k]) : 1.0;  // a scale: any value > 0 works
       st.isc[k] = 1.0 / st.sc[k];
     }
   } else if constexpr (PASS == kPassB2) {
@@ -271,7 +290,7 @@ OL_DEV void fit_finish(const FitParams& p, FitState& st, const double* s,
       double A[4][4] = {{s[0], s[1], s[2], s[3]}, {s[1], s[4], s[5], s[6]},
                         {s[2], s[5], s[7], s[8]}, {s[3], s[6], s[8], s[9]}};
       double g[4] = {s[10], s[11], s[12], s[13]};
-      if (!fit_solve4(A, g)) {
+      if (st.deficient != 0.0 || !fit_solve4(A, g)) {
         *status |= kFitSingular;
         g[0] = g[1] = g[2] = g[3] = __builtin_nan("");
       }

@@ -18,6 +18,8 @@ from __future__ import annotations
 
 import math
 
+from . import _capi
+
 import numpy as np
 import torch
 
@@ -226,9 +228,48 @@ class Wavefront:
                                      planar=self.afocal)
         opd, pupil = t.engine.wavefront_opd_fitted(ref, r8[:7], px, py, want_pupil=True)
         R, bits = t.engine.fit_result(ref)
+        if bits & _capi.FIT_SINGULAR and self.strategy == "best_fit" and not self.afocal \
+                and not bits & (_capi.FIT_NO_VALID | _capi.FIT_TOO_FEW):
+            return self._best_fit_rank_deficient(r8, px, py, params)
         t.engine.raise_for_fit_status(bits)
         return WavefrontData(pupil[0], pupil[1], pupil[2], opd, r8[7].clone(),
                              math.inf if self.afocal else R)
+
+    def _best_fit_rank_deficient(self, r8, px, py, params) -> WavefrontData:
+        """The least-squares sphere through wavefront points that do not span space -- a
+        collimated beam: the points of an afocal system lie in one plane -- the way the
+        reference gets it (wavefront/strategy.py:556-582 on its NumPy backend):
+        `np.linalg.lstsq` of the RAW system `[x y z 1] c = |p|^2`, i.e. the rank-3 minimum-norm
+        solution of the SVD.  That sphere is an artefact of where the origin lies (4.7 mm of
+        radius for a flat wavefront, hundreds of waves of "OPD"), but it is what the reference
+        returns, so it is what this returns: the device fit reports the cloud as singular
+        (`ol_wavefront_fit`: its centred normal equations have no fourth pivot), the points
+        come back once, and the OPD map is taken on the device against the host's sphere
+        (`ol_wavefront_opd`), piston = the mean over the rays with intensity > 0
+        (strategy.py:331).  Rare by construction; `afocal=True` is the fit such a beam wants."""
+        import numpy as np
+        t = self.tracer
+        x, y, z, L, M, N, opd, inten = (v.double().cpu().numpy() for v in r8)
+        pxn, pyn = px.double().cpu().numpy(), py.double().cpu().numpy()
+        ni, half = float(params["n_image"]), float(params["half_epd"])
+        with np.errstate(all="ignore"):
+            opd_t = opd + (params["ux"] * (pxn * half) + params["uy"] * (pyn * half))
+            valid = (np.isfinite(x) & np.isfinite(y) & np.isfinite(z) & np.isfinite(L)
+                     & np.isfinite(M) & np.isfinite(N) & np.isfinite(opd_t) & (inten != 0))
+            pts = np.stack((x, y, z), axis=1)[valid] \
+                - (opd_t[valid] / ni)[:, None] * np.stack((L, M, N), axis=1)[valid]
+            A = np.concatenate([pts, np.ones((len(pts), 1))], axis=1)
+            c = np.linalg.lstsq(A, (pts ** 2).sum(axis=1), rcond=None)[0]
+            centre = c[:3] / 2
+            R = float(np.sqrt(c[3] + (centre ** 2).sum()))
+        sphere = dict(params, xc=float(centre[0]), yc=float(centre[1]), zc=float(centre[2]), R=R,
+                      opd_ref=0.0)
+        opd_w, pupil = t.engine.wavefront_opd(sphere, r8[:7], px, py, want_pupil=True)
+        alive = r8[7] > 0
+        if not bool(alive.any()):
+            raise ValueError("No valid rays with non-zero intensity for OPD calculation.")
+        opd_w = opd_w - opd_w[alive].mean()   # (piston - opd) / lambda, piston = mean(opd[i > 0])
+        return WavefrontData(pupil[0], pupil[1], pupil[2], opd_w, r8[7].clone(), R)
 
 
 class OPD(Wavefront):

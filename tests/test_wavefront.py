@@ -451,3 +451,88 @@ def test_fused_opd_two_rays_per_lane_is_bit_identical(name):
     finally:
         hip.lib.ol_set_tuning(_capi.TUNE_RAYS_PER_THREAD, 0)
         hip.close()
+
+
+# ----------------------------------------------------------------------------------
+# round 5: wavefront points that do not span space (found by the analyses fuzz on the fitted
+# strategies, tools/gpu_fuzz_analyses.py)
+# ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("where", WHERE)
+@pytest.mark.parametrize("name", ["fuzz_r05_flat_wavefront", "fuzz_r05_window"])
+def test_best_fit_sphere_of_a_collimated_beam_is_the_references(name, where):
+    """A system without power (air / air surfaces; a plane-parallel plate): the wavefront
+    points `p - (opd / n) d` of a field lie in ONE plane (z spread 1e-14 mm) and the sphere
+    through them is not determined.  The reference's NumPy backend returns the rank-3
+    minimum-norm solution of `lstsq([x y z 1], |p|^2)` (strategy.py:556-582): radius 4.68 /
+    4.72 mm, hundreds of waves of "OPD" -- an artefact, but its answer.  The device fit used to
+    scale the flat axis by the square root of its cancellation noise and fit a sphere to that
+    (radius 1e2 ... 1e13) or stop with "singular normal equations"; now it reports the cloud
+    as singular and the host follows the reference (`Wavefront._best_fit_rank_deficient`)."""
+    from tests._fake_engine import OracleEngine
+    from tests._util import load_case_table
+    table = load_case_table(name)
+    real = _real_tracer(table, where)
+    fake = tr.HipRayTracer(table, "cpu", dtype=torch.float64, engine=OracleEngine(table, "cpu"))
+    w = float(table.wavelengths[0])
+    try:
+        a = OPD(real, (0.0, 0.7), w, num_rays=5, strategy="best_fit_sphere")
+        b = OPD(fake, (0.0, 0.7), w, num_rays=5, strategy="best_fit_sphere")
+        assert 4.0 < b.data.radius < 5.0                       # the minimum-norm artefact
+        np.testing.assert_allclose(a.data.radius, b.data.radius, rtol=1e-9)
+        scale = float(b.data.opd.abs().max())
+        assert scale > 100.0
+        np.testing.assert_allclose(a.data.opd.cpu().numpy(), b.data.opd.numpy(), rtol=0,
+                                   atol=1e-8 * scale)
+        np.testing.assert_allclose(a.rms(), b.rms(), rtol=1e-8)
+        # the fits that such a beam wants are untouched: a plane, and the centroid sphere
+        for kw in (dict(strategy="best_fit_sphere", afocal=True), dict(strategy="centroid_sphere")):
+            a = OPD(real, (0.0, 0.7), w, num_rays=5, **kw)
+            b = OPD(fake, (0.0, 0.7), w, num_rays=5, **kw)
+            np.testing.assert_allclose(a.data.opd.cpu().numpy(), b.data.opd.numpy(), rtol=0,
+                                       atol=1e-7 * max(1.0, float(b.data.opd.abs().max())))
+    finally:
+        real.engine.close()
+
+
+@pytest.mark.parametrize("where", WHERE)
+def test_wavefront_fit_reports_a_tilted_plane_of_points_as_singular(where):
+    """`ol_wavefront_fit` (best fit, sphere) on points of a TILTED plane -- no axis is flat, the
+    scaled Gram matrix simply has no fourth pivot -- and on a cloud with one flat axis: the
+    FIT_SINGULAR bit; a proper spherical cap of the same size: no bit, centre and radius to
+    1e-9."""
+    from optiland_amd import _capi
+    table = load_system("cooke_generic")
+    real = _real_tracer(table, where)
+    eng, dev = real.engine, real.device
+    rng = np.random.default_rng(3)
+    n = 500
+    u, v = rng.uniform(-2, 2, n), rng.uniform(-2, 2, n)
+
+    def fit(points):
+        # rays at the points themselves, zero path: pts = p
+        planes = [torch.as_tensor(np.ascontiguousarray(c), dtype=torch.float64, device=dev)
+                  for c in (points[:, 0], points[:, 1], points[:, 2], np.zeros(n), np.zeros(n),
+                            np.ones(n), np.zeros(n), np.ones(n))]
+        zero = torch.zeros(n, dtype=torch.float64, device=dev)
+        ref = eng.wavefront_fit("best_fit", dict(n_image=1.0, wavelength_um=0.55, ux=0.0, uy=0.0,
+                                                 half_epd=1.0), planes, zero, zero,
+                                flavour="numpy")
+        host = ref.cpu()
+        return host[:4].numpy(), int(host[-1:].view(torch.int32)[0])
+
+    try:
+        origin = np.array([3.0, -2.0, 40.0])
+        e1, e2 = np.array([1.0, 0.2, 0.3]), np.array([-0.1, 1.0, 0.5])
+        tilted = origin + u[:, None] * e1 + v[:, None] * e2
+        assert fit(tilted)[1] & _capi.FIT_SINGULAR
+        flat = np.stack([u + 3.0, v - 2.0, np.full(n, 40.0)], axis=1)
+        assert fit(flat)[1] & _capi.FIT_SINGULAR
+        centre, R = np.array([3.0, -2.0, -60.0]), 100.0
+        cap = np.stack([u + 3.0, v - 2.0,
+                        centre[2] + np.sqrt(R * R - u * u - v * v)], axis=1)
+        got, bits = fit(cap)
+        assert bits == 0
+        np.testing.assert_allclose(got[:3], centre, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(got[3], R, rtol=1e-9)
+    finally:
+        eng.close()

@@ -69,8 +69,10 @@ def lost_alive_rays(table):
     return tuple(counts)
 
 
-worst = {"spot_rms": 0.0, "spot_geo": 0.0, "spot_centroid": 0.0, "ee": 0.0, "opd": 0.0}
-count = {"spot": 0, "ee": 0, "opd": 0, "raised_both": 0}
+worst = {"spot_rms": 0.0, "spot_geo": 0.0, "spot_centroid": 0.0, "ee": 0.0, "opd": 0.0,
+         "opd_centroid_sphere": 0.0, "opd_best_fit_sphere": 0.0}
+count = {"spot": 0, "ee": 0, "opd": 0, "opd_centroid_sphere": 0, "opd_best_fit_sphere": 0,
+         "raised_both": 0}
 bad = []
 
 
@@ -83,7 +85,7 @@ def both(fn, table):
         try:
             with np.errstate(all="ignore"):
                 out.append(fn(t))
-        except (ValueError, NotImplementedError) as e:
+        except (ValueError, NotImplementedError, RuntimeError) as e:
             out.append(e)
         finally:
             if real:
@@ -139,6 +141,24 @@ for path in sorted(glob.glob(os.path.join(ROOT, "fuzz_tables", "*.json"))):
             if e > 1e-5:
                 bad.append((name, "opd", e))
             count["opd"] += 1
+
+        # round 5: the fitted reference spheres (ol_wavefront_fit + ol_wavefront_opd_fitted on
+        # the real engine, oracle.wavefront_fit behind the stand-in)
+        for strat in ("centroid_sphere", "best_fit_sphere"):
+            def opd_fit(t, strat=strat):
+                o = OPD(t, (0.0, 0.7), float(table.wavelengths[0]), num_rays=5, strategy=strat)
+                return o.data.opd.double().cpu().numpy()
+            a, b = both(opd_fit, table)
+            if not (isinstance(a, Exception) or isinstance(b, Exception)) and np.isfinite(b).all() \
+                    and np.isfinite(a).all():
+                e = float(np.max(np.abs(a - b)) / max(1.0, float(np.abs(b).max())))
+                worst["opd_" + strat] = max(worst["opd_" + strat], e)
+                if e > (1e-4 if strat == "best_fit_sphere" else 1e-5):
+                    bad.append((name, "opd_" + strat, e))
+                count["opd_" + strat] += 1
+            elif isinstance(a, Exception) != isinstance(b, Exception):
+                bad.append((name, "opd_" + strat + " raised on one side only",
+                            str(a if isinstance(a, Exception) else b)[:80]))
 print("compared:", count)
 print("worst:", {k: f"{v:.3e}" for k, v in worst.items()})
 print("flagged:", len(bad))
