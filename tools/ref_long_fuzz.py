@@ -32,6 +32,8 @@ for name, extra in (("test_random_reference_lens_equals_packer_plus_oracle", ())
                     ("test_standalone_opd_on_random_lenses", ("best_fit_sphere",)),
                     ("test_standalone_encircled_energy_on_random_lenses", ()),
                     ("test_standalone_irradiance_on_random_lenses", ())):
+    if len(sys.argv) > 4 and sys.argv[4] not in name:
+        continue   # optional 4th argument: only the families whose name contains it
     fn = getattr(rf, name)
     bad, skipped = [], 0
     for seed in range(lo, hi):
