@@ -18,8 +18,9 @@ LIBNAME = "liboptiland_hip.so"
 # trace_kernel.hip is compiled twice -- fp32 and fp64 instantiations in separate
 # translation units -- so that the two halves (the bulk of the build) run in parallel
 SOURCES = ("trace_kernel_f32.hip", "trace_kernel_f64.hip", "aux_kernels.hip", "capi.hip")
-HEADERS = ("device_table.h", "trace_launch.h", "raygen_device.h", "wavefront_device.h",
-           "epilogue_device.h", "surface_math.h", "trace_kernel.hip")
+# every header under csrc/ (round 5: a hand-kept list had missed wavefront_fit_device.h since
+# round 4 -- an edit of that file alone left a stale aux_kernels.o behind) + the included .hip
+HEADERS = tuple(sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))) + ("trace_kernel.hip",)
 ARCH = "gfx950"
 
 

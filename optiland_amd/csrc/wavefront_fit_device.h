@@ -149,16 +149,21 @@ OL_DEV void fit_centroid_done(const FitParams& p, FitState& st, const double* sw
 }
 
 // 4 x 4 symmetric positive definite solve (Cholesky); false if a pivot is not positive -- or,
-// round 5, not clearly positive: a pivot below 1e-10 of its diagonal entry is a direction the
-// points do not span (a tilted PLANE of wavefront points: a collimated beam), and what the
-// elimination leaves of it is rounding noise.  The caller then reports kFitSingular and the host
-// solves the raw system the way the reference does (SVD, minimum norm: wavefront.py).
+// round 5, not clearly positive: below 1e-10 of the LARGEST diagonal entry.  In the scaled
+// coordinates every diagonal entry is ~n when the per-axis scales are right; a direction the
+// points do not span -- a tilted PLANE of wavefront points, or an axis that is flat to
+// rounding and was "scaled" by the square root of the cancellation noise of E[z^2] - m^2 --
+// leaves a pivot of ~1e-15 n, and what the elimination makes of it is noise.  The caller then
+// reports kFitSingular and the host solves the raw system the way the reference does (SVD,
+// minimum norm: wavefront.py).
 OL_DEV bool fit_solve4(double (&A)[4][4], double (&b)[4]) {
+  double dmax = 0.0;
+  for (int j = 0; j < 4; ++j)
+    if (A[j][j] > dmax) dmax = A[j][j];
   for (int j = 0; j < 4; ++j) {
-    const double ajj = A[j][j];
-    double d = ajj;
+    double d = A[j][j];
     for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
-    if (!(d > 1e-10 * ajj)) return false;
+    if (!(d > 1e-10 * dmax)) return false;
     d = ::sqrt(d);
     A[j][j] = d;
     for (int i = j + 1; i < 4; ++i) {

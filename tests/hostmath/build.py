@@ -19,8 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "optiland_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libol_hostmath.so")
-DEPS = ("surface_math.h", "raygen_device.h", "wavefront_device.h", "epilogue_device.h",
-        "device_table.h", "trace_launch.h", "capi.hip")
+# every header of the kernel source + the shim (a hand-kept list had missed
+# wavefront_fit_device.h, as optiland_amd/build.py's had)
+DEPS = tuple(sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))) + ("capi.hip",)
 
 
 def _cpu_has_fma() -> bool:

@@ -458,7 +458,8 @@ def test_fused_opd_two_rays_per_lane_is_bit_identical(name):
 # strategies, tools/gpu_fuzz_analyses.py)
 # ----------------------------------------------------------------------------------
 @pytest.mark.parametrize("where", WHERE)
-@pytest.mark.parametrize("name", ["fuzz_r05_flat_wavefront", "fuzz_r05_window"])
+@pytest.mark.parametrize("name", ["fuzz_r05_flat_wavefront", "fuzz_r05_window",
+                                  "fuzz_r05_flat_wavefront_b", "fuzz_r05_flat_wavefront_c"])
 def test_best_fit_sphere_of_a_collimated_beam_is_the_references(name, where):
     """A system without power (air / air surfaces; a plane-parallel plate): the wavefront
     points `p - (opd / n) d` of a field lie in ONE plane (z spread 1e-14 mm) and the sphere
@@ -478,6 +479,10 @@ def test_best_fit_sphere_of_a_collimated_beam_is_the_references(name, where):
         a = OPD(real, (0.0, 0.7), w, num_rays=5, strategy="best_fit_sphere")
         b = OPD(fake, (0.0, 0.7), w, num_rays=5, strategy="best_fit_sphere")
         assert 4.0 < b.data.radius < 5.0                       # the minimum-norm artefact
+        # (the _b / _c lenses are two of six that the DEVICE still got wrong after the first
+        # version of the fix: its block-wise sums leave a little more cancellation noise in
+        # E[z^2] - m^2 than a sequential host sum, past the variance test; the pivot test
+        # against the largest diagonal entry is what catches them)
         np.testing.assert_allclose(a.data.radius, b.data.radius, rtol=1e-9)
         scale = float(b.data.opd.abs().max())
         assert scale > 100.0
