@@ -479,10 +479,9 @@ def test_best_fit_sphere_of_a_collimated_beam_is_the_references(name, where):
         a = OPD(real, (0.0, 0.7), w, num_rays=5, strategy="best_fit_sphere")
         b = OPD(fake, (0.0, 0.7), w, num_rays=5, strategy="best_fit_sphere")
         assert 4.0 < b.data.radius < 5.0                       # the minimum-norm artefact
-        # (the _b / _c lenses are two of six that the DEVICE still got wrong after the first
-        # version of the fix: its block-wise sums leave a little more cancellation noise in
-        # E[z^2] - m^2 than a sequential host sum, past the variance test; the pivot test
-        # against the largest diagonal entry is what catches them)
+        # (_b / _c: two more of the eleven lenses of the fuzz -- the ones the MI355X run still
+        # showed wrong while a stale aux_kernels.o kept the device on the old fit; the build's
+        # header list had missed wavefront_fit_device.h)
         np.testing.assert_allclose(a.data.radius, b.data.radius, rtol=1e-9)
         scale = float(b.data.opd.abs().max())
         assert scale > 100.0
