@@ -1,0 +1,143 @@
+#!/usr/bin/env python
+"""CPU, build container only (round 5): the reference's OWN analysis classes on random lenses,
+with and without the drop-in.
+
+For every seed the lens of tests/test_reference_fuzz.py:build_random_lens is built twice through
+the reference's public API: once under the NumPy backend (the reference as it is), once under the
+torch backend (cpu, fp64) with `integration.enable(force=True)` and the product's engine class on
+the HOST build of the kernel source (tests/_hostmath.py) -- the seams of analysis_seams.py behind
+`SpotDiagram`, `EncircledEnergy`, `OPD` (chief ray, centroid, best fit; tilt removal), `FFTPSF`.
+Prints, per family, how many lenses were compared, the worst relative difference and every
+lens over 1e-6 (lenses with a Newton surface separately: the reference stops its iteration at
+1e-6 mm), plus which seams declined.
+
+    python tools/seam_fuzz.py 0 200
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests", "refshim"), "/root/reference"]
+warnings.filterwarnings("ignore")
+import importlib.util  # noqa: E402
+
+import optiland.backend as be  # noqa: E402
+
+be.set_backend("numpy")
+spec = importlib.util.spec_from_file_location(
+    "rf", os.path.join(ROOT, "tests", "test_reference_fuzz.py"))
+rf = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(rf)
+import optiland_amd.tracer as tr  # noqa: E402
+from optiland_amd import analysis_seams, integration  # noqa: E402
+from tests import _hostmath as hm  # noqa: E402
+
+_cls = hm.make_engine_class()
+tr._make_engine = lambda table, device: _cls(table, device)
+
+
+def _np(a):
+    return np.asarray(be.to_numpy(a), dtype=np.float64)
+
+
+def families(lens):
+    from optiland import analysis
+    from optiland.psf import FFTPSF
+    from optiland.wavefront import OPD
+    out = {}
+    w = lens.primary_wavelength
+
+    def spot():
+        s = analysis.SpotDiagram(lens, num_rings=5)
+        return np.array([[float(_np(v)) for v in f] for f in s.rms_spot_radius()] +
+                        [[float(_np(v)) for v in f] for f in s.geometric_spot_radius()])
+
+    def ee():
+        # (the curve itself is only formed while plotting, encircled_energy.py:135-168: the
+        # centroids and the hits it is formed from are compared)
+        e = analysis.EncircledEnergy(lens, num_rays=6, distribution="hexapolar", num_points=16)
+        cen = np.array([[float(_np(c[0])), float(_np(c[1]))] for c in e.centroid()]).ravel()
+        hits = np.concatenate([np.concatenate([_np(d.x), _np(d.y), _np(d.intensity)])
+                               for f in e.data for d in f])
+        return np.concatenate([cen, hits])
+
+    def opd(**kw):
+        return lambda: _np(OPD(lens, (0.0, 0.7), w, num_rays=5, **kw).data[((0.0, 0.7), w)].opd) \
+            if False else _np(OPD(lens, (0.0, 0.7), w, num_rays=5, **kw).get_data((0.0, 0.7), w).opd)
+
+    def psf():
+        return _np(FFTPSF(lens, (0.0, 0.5), w, num_rays=32, grid_size=64).psf)
+
+    todo = {"spot": spot, "ee": ee, "opd": opd(), "opd_centroid": opd(strategy="centroid"),
+            "opd_best_fit": opd(strategy="best_fit"), "opd_detrended": opd(remove_tilt=True),
+            "fftpsf": psf}
+    for k, fn in todo.items():
+        try:
+            with np.errstate(all="ignore"):
+                out[k] = fn()
+        except Exception as e:  # noqa: BLE001
+            out[k] = e
+    return out
+
+
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+stats = {}
+bad = []
+declined = {}
+for seed in range(lo, hi):
+    be.set_backend("numpy")
+    lens, _rng = rf.build_random_lens(seed, be)
+    if lens.polarization != "ignore":
+        continue
+    want = families(lens)
+    from optiland.geometries.newton_raphson import NewtonRaphsonGeometry
+    nr = sum(1 for s in lens.surface_group.surfaces
+             if isinstance(s.geometry, NewtonRaphsonGeometry))
+    be.set_backend("torch")
+    be.set_device("cpu")
+    be.set_precision("float64")
+    integration.enable(force=True, analyses=True)
+    for k in analysis_seams.STATS:
+        analysis_seams.STATS[k] = 0
+    try:
+        lens2, _ = rf.build_random_lens(seed, be)
+        got = families(lens2)
+        for k, v in analysis_seams.STATS.items():
+            if k.endswith("_fallback") and v:
+                declined[k] = declined.get(k, 0) + v
+    finally:
+        integration.disable()
+        be.set_backend("numpy")
+    for k in want:
+        a, b = got[k], want[k]
+        if isinstance(a, Exception) or isinstance(b, Exception):
+            # (both raising is agreement: the reference's two backends name the same failure
+            # differently -- max() of an empty spot is a ValueError in NumPy, a RuntimeError in torch)
+            if isinstance(a, Exception) != isinstance(b, Exception):
+                bad.append((seed, k, nr, "raised on one side: %r | %r" % (a, b)))
+            else:
+                stats.setdefault((k + " (both raise)", nr > 0), [0, 0.0])[0] += 1
+            continue
+        if a.shape != b.shape or not np.isfinite(b).all():
+            if a.shape != b.shape:
+                bad.append((seed, k, nr, f"shapes {a.shape} {b.shape}"))
+            continue
+        if not np.isfinite(a).all():
+            bad.append((seed, k, nr, "NaN with the drop-in only"))
+            continue
+        e = float(np.max(np.abs(a - b)) / max(1.0, float(np.abs(b).max())))
+        st = stats.setdefault((k, nr > 0), [0, 0.0])
+        st[0] += 1
+        st[1] = max(st[1], e)
+        if e > (1e-6 if nr == 0 else 2e-3):
+            bad.append((seed, k, nr, e))
+print("seeds", lo, hi)
+for (k, newton), (n, worst) in sorted(stats.items()):
+    print(f"  {k:14s} {'Newton lenses' if newton else 'conic lenses ':13s} compared {n:4d}  worst {worst:.3e}")
+print("seam fall-backs:", declined or "none")
+print("over 1e-6 (conic lenses) / 2e-3 (Newton lenses), or one-sided:", len(bad))
+for b_ in bad[:40]:
+    print("   ", b_)
