@@ -43,7 +43,10 @@ def _np(a):
     return np.asarray(be.to_numpy(a), dtype=np.float64)
 
 
-def families(lens):
+POLARISED = len(sys.argv) > 3 and sys.argv[3] == "polarised"   # only the polarised lenses: spot, ee
+
+
+def families(lens, polarised=False):
     from optiland import analysis
     from optiland.psf import FFTPSF
     from optiland.wavefront import OPD
@@ -74,6 +77,8 @@ def families(lens):
     todo = {"spot": spot, "ee": ee, "opd": opd(), "opd_centroid": opd(strategy="centroid"),
             "opd_best_fit": opd(strategy="best_fit"), "opd_detrended": opd(remove_tilt=True),
             "fftpsf": psf}
+    if polarised:  # (wavefronts of polarised systems are not part of the seams)
+        todo = {k: v for k, v in todo.items() if k in ("spot", "ee")}
     for k, fn in todo.items():
         try:
             with np.errstate(all="ignore"):
@@ -90,9 +95,12 @@ declined = {}
 for seed in range(lo, hi):
     be.set_backend("numpy")
     lens, _rng = rf.build_random_lens(seed, be)
-    if lens.polarization != "ignore":
+    polarised = lens.polarization != "ignore"
+    if polarised and not POLARISED:
         continue
-    want = families(lens)
+    if POLARISED and not polarised:
+        continue
+    want = families(lens, polarised)
     from optiland.geometries.newton_raphson import NewtonRaphsonGeometry
     nr = sum(1 for s in lens.surface_group.surfaces
              if isinstance(s.geometry, NewtonRaphsonGeometry))
@@ -104,7 +112,7 @@ for seed in range(lo, hi):
         analysis_seams.STATS[k] = 0
     try:
         lens2, _ = rf.build_random_lens(seed, be)
-        got = families(lens2)
+        got = families(lens2, polarised)
         for k, v in analysis_seams.STATS.items():
             if k.endswith("_fallback") and v:
                 declined[k] = declined.get(k, 0) + v
