@@ -74,11 +74,25 @@ def families(lens, polarised=False):
     def psf():
         return _np(FFTPSF(lens, (0.0, 0.5), w, num_rays=32, grid_size=64).psf)
 
-    todo = {"spot": spot, "ee": ee, "opd": opd(), "opd_centroid": opd(strategy="centroid"),
+    def trace():
+        r = lens.trace(0.3, -0.5, w, 5, "hexapolar")
+        rec = np.stack([_np(getattr(lens.surfaces, k))[1:] for k in ("x", "y", "z", "L", "M", "N", "intensity", "opd")])
+        return np.concatenate([np.nan_to_num(np.stack([_np(getattr(r, k)) for k in ("x", "y", "z", "L", "M", "N", "i", "opd")]), nan=-7.0).ravel(),
+                               np.nan_to_num(rec, nan=-7.0, posinf=-8.0, neginf=-9.0).ravel()])
+
+    def trace_generic():
+        rng_ = np.random.default_rng(5)
+        n = 64
+        hx, hy = be.array(rng_.uniform(-0.5, 0.5, n)), be.array(rng_.uniform(-1, 1, n))
+        rr, th = np.sqrt(rng_.random(n)) * 0.9, 2 * np.pi * rng_.random(n)
+        r = lens.trace_generic(hx, hy, be.array(rr * np.cos(th)), be.array(rr * np.sin(th)), w)
+        return np.nan_to_num(np.stack([_np(getattr(r, k)) for k in ("x", "y", "z", "L", "M", "N", "i", "opd")]), nan=-7.0).ravel()
+
+    todo = {"trace": trace, "trace_generic": trace_generic, "spot": spot, "ee": ee, "opd": opd(), "opd_centroid": opd(strategy="centroid"),
             "opd_best_fit": opd(strategy="best_fit"), "opd_detrended": opd(remove_tilt=True),
             "fftpsf": psf}
     if polarised:  # (wavefronts of polarised systems are not part of the seams)
-        todo = {k: v for k, v in todo.items() if k in ("spot", "ee")}
+        todo = {k: v for k, v in todo.items() if k in ("trace", "trace_generic", "spot", "ee")}
     for k, fn in todo.items():
         try:
             with np.errstate(all="ignore"):
