@@ -68,8 +68,7 @@ def families(lens, polarised=False):
         return np.concatenate([cen, hits])
 
     def opd(**kw):
-        return lambda: _np(OPD(lens, (0.0, 0.7), w, num_rays=5, **kw).data[((0.0, 0.7), w)].opd) \
-            if False else _np(OPD(lens, (0.0, 0.7), w, num_rays=5, **kw).get_data((0.0, 0.7), w).opd)
+        return lambda: _np(OPD(lens, (0.0, 0.7), w, num_rays=5, **kw).get_data((0.0, 0.7), w).opd)
 
     def psf():
         return _np(FFTPSF(lens, (0.0, 0.5), w, num_rays=32, grid_size=64).psf)
