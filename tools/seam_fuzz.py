@@ -31,6 +31,11 @@ spec = importlib.util.spec_from_file_location(
     "rf", os.path.join(ROOT, "tests", "test_reference_fuzz.py"))
 rf = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(rf)
+if os.environ.get("OL_FUZZ_KINDS"):
+    # e.g. OL_FUZZ_KINDS=standard: conic surfaces only (decentres, tilts, mirrors, apertures,
+    # coatings, finite objects as before) -- no Newton stop tolerance between the two sides, so
+    # every family is held to 1e-6
+    rf.KINDS = os.environ["OL_FUZZ_KINDS"].split(",")
 import optiland_amd.tracer as tr  # noqa: E402
 from optiland_amd import analysis_seams, integration  # noqa: E402
 from tests import _hostmath as hm  # noqa: E402
