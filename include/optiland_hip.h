@@ -201,6 +201,15 @@ typedef struct ol_system ol_system; /* opaque */
 #define OL_STATUS_PUPIL_RANGE 0x10u  /* a normalised pupil coordinate outside [-1, 1] */
 #define OL_STATUS_CHEBYSHEV_RANGE 0x4u /* |x/norm_x|>1 or |y/norm_y|>1
                                         (geometries/chebyshev.py:227-240)     */
+#define OL_STATUS_NAN_DIRECTION 0x20u /* ABI 10, INFORMATIONAL (no exception in the reference):
+                                        ol_trace / ol_trace_generate left a ray with a finite
+                                        position and a direction that is not a number -- total
+                                        internal reflection at the LAST traced surface.  The
+                                        reference's trace ends with `x += t L` by the last
+                                        thickness (real_ray_tracer.py:104-110), which turns such
+                                        a position into NaN even for t = 0; a caller that hands
+                                        out the final state as the reference's returned rays
+                                        applies that when (and only when) this bit is set.   */
 
 /* ---- trace flags --------------------------------------------------------- */
 #define OL_TRACE_WRITE_RAYS 0x1u   /* write the final ray state back into rays[] */

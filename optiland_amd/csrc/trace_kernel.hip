@@ -741,6 +741,17 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
     }
   }
 
+  // Round 5: total internal reflection at the LAST traced surface leaves a ray with a position
+  // and no direction.  The reference's trace then ends with `x += t L` (t = the last
+  // thickness, 0 in every sample), which makes that position NaN too; the drop-in applies that
+  // to the rays it RETURNS -- the recorded row keeps the position -- and needs to know when:
+  // an informational status bit instead of three extra elementwise passes per call.
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const Ray<T> q = LP::ray(r, k);
+    if (k < cnt && q.L != q.L && q.x == q.x) status |= kStatusNanDirection;
+  }
+
   if constexpr (SPOT) {
     // epilogue: masked moments of the final (global) state about (cx, cy),
     // into slot (workgroup % slots) of the caller's [slots][8] buffer -- the slots keep

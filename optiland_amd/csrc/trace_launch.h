@@ -76,6 +76,7 @@ constexpr uint32_t kSpotPolarizedOk = 0x8u;     // OL_SPOT_POLARIZED_OK (capi.hi
 constexpr uint32_t kSpotHitsLocal = 0x10u;      // OL_SPOT_HITS_LOCAL
 constexpr uint32_t kStatusFieldRange = 0x8u;    // OL_STATUS_FIELD_RANGE
 constexpr uint32_t kStatusPupilRange = 0x10u;   // OL_STATUS_PUPIL_RANGE
+constexpr uint32_t kStatusNanDirection = 0x20u;  // OL_STATUS_NAN_DIRECTION (informational)
 
 // normalised coordinates of one ray block (ol_raygen_inputs in working precision)
 template <typename T>

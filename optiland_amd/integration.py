@@ -38,6 +38,7 @@ import numpy as np
 import torch
 
 from . import fingerprint as _fp
+from . import system as _S
 from . import tracer as _tracer
 from .packer import UnsupportedSystem, pack_optic, pack_surfaces
 from .rays import prt_to_complex
@@ -767,6 +768,17 @@ def _make_tracer_class():
                     mine._prt, (mine._L0, mine._M0, mine._N0), mine._i0, table.polarization)
             if before_commit is not None:
                 before_commit()
+            if thick == 0.0 and front.last_status & _S.STATUS_NAN_DIRECTION:
+                # The reference's trace ends with `x += t L` by the last thickness
+                # (real_ray_tracer.py:104-110, homogeneous.py:40-42) even when that is 0 -- and
+                # 0 * NaN is NaN: a ray that was totally reflected at the last surface (a
+                # position, no direction) comes back WITHOUT a position, while the surface's
+                # recorded row keeps it.  The kernel says when there is such a ray
+                # (OL_STATUS_NAN_DIRECTION); only then do the returned rays get planes of their
+                # own for x, y, z.
+                out.x = out.x + 0.0 * out.L
+                out.y = out.y + 0.0 * out.M
+                out.z = out.z + 0.0 * out.N
             if lazy:
                 register_pending_record(self.optic, table, front.engine, front.dtype,
                                         front.last_fused_launch)

@@ -44,6 +44,7 @@ FIELD_ANGLE, FIELD_OBJECT_HEIGHT, FIELD_PARAXIAL_IMAGE_HEIGHT = 0, 1, 2
  APOD_TUKEY) = range(7)
 STATUS_FIELD_RANGE = 0x8
 STATUS_PUPIL_RANGE = 0x10
+STATUS_NAN_DIRECTION = 0x20  # informational: a ray ended with a position and no direction
 
 TRACE_WRITE_RAYS = 0x1
 TRACE_COMPACT = 0x2

@@ -162,6 +162,7 @@ class HipRayTracer:
         # the caller does `check_status()` itself -- integration.py overlaps its change
         # check of the live optic with the kernels this way
         self.defer_checks = False
+        self.last_status = 0   # the status word of the last `_finish_checks`
         self._pupil_cache = {}  # (distribution name, num_rays) -> device planes
         self.rebind(table)
 
@@ -229,8 +230,11 @@ class HipRayTracer:
         the trace kernel's own bits)."""
         status_t = getattr(eng, "_status", None)
         if status_t is None:  # engines that raise eagerly (tests' oracle stand-in)
+            self.last_status = 0
             return
-        eng.raise_for_status(int(status_t.item()))
+        # (kept: the informational bits -- STATUS_NAN_DIRECTION -- are the caller's to use)
+        self.last_status = int(status_t.item())
+        eng.raise_for_status(self.last_status)
 
     def _vig_factor(self, hx, hy):
         """FieldGroup.get_vig_factor (fields/field_group.py:93-122): nearest field

@@ -158,6 +158,7 @@ void trace_one(const TraceArgs<T>& a, int64_t i, uint32_t& status) {
       }
     }
   }
+  if (r[0].L != r[0].L && r[0].x == r[0].x) status |= kStatusNanDirection;  // (trace_kernel)
   if (a.flags & kTraceWriteRays) {
     const Ray<T> g = is_global ? r[0] : to_global<T>(last_traced, r[0]);
     a.rays[0][i] = g.x; a.rays[1][i] = g.y; a.rays[2][i] = g.z;
@@ -216,6 +217,8 @@ inline void trace_pair_gen(const TraceArgs<float>& a, int64_t i0, uint32_t& stat
     if (a.record && s >= rec_from && !(s == a.first && (a.flags & kTraceRow0IsInput)))
       put(nullptr, a.record_stride, a.record + (int64_t)(s - rec_from) * 8 * a.record_stride);
   }
+  for (int k = 0; k < cnt; ++k)
+    if (r[0].L[k] != r[0].L[k] && r[0].x[k] == r[0].x[k]) status |= kStatusNanDirection;
   if (a.flags & kTraceWriteRays) put(a.rays, 0, nullptr);
 }
 

@@ -74,3 +74,32 @@ def test_rim_rays_of_a_biconic_mirror_converge_like_the_reference(where):
     assert rim.sum() >= 3 and rim[j]
     alive = np.isfinite(want[1, 0]) & (want[1, 6] > 0)
     np.testing.assert_allclose(got[1][:, alive], want[1][:, alive], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("where", WHERE)
+def test_total_reflection_at_the_last_surface_is_reported(where):
+    """Round 5: OL_STATUS_NAN_DIRECTION -- informational, raises nothing: a ray left the last
+    traced surface with a position and no direction (total internal reflection there; a conic,
+    polarised lens of the seam fuzz kept as tests/golden/fuzz_r05_tir_at_last_surface.json).
+    The drop-in needs the bit to end `Optic.trace` the way the reference does, with `x += 0 L`
+    (tests/test_reference_integration.py::test_a_ray_without_a_direction…)."""
+    from optiland_amd import system as S
+    table = SystemTable.load(os.path.join(GOLDEN, "fuzz_r05_tir_at_last_surface.json"))
+    hip = _engine(table, where)
+    dev = hip.device
+    try:
+        d = torch.linspace(-0.9, 0.9, 41, dtype=torch.float64, device=dev)
+        px, py = (t.reshape(-1).contiguous() for t in torch.meshgrid(d, d, indexing="ij"))
+        n = px.numel()
+        prt = torch.empty((18 if table.needs_complex_prt else 9, n), dtype=torch.float64, device=dev)
+        for field, scale, expect in (((0.3, -0.5), 1.0, True), ((0.0, 0.0), 0.05, False)):
+            res = hip.trace_generate((px * scale).contiguous(), (py * scale).contiguous(), 0,
+                                     field=field, prt=prt, defer_status=True)
+            bits = int(hip._status.item())
+            hip.raise_for_status(bits)                      # ... and nothing is raised
+            last = res.record[-1, :, :n]
+            lost = torch.isnan(last[3]) & torch.isfinite(last[0])
+            assert bool(lost.any()) == expect, field
+            assert bool(bits & S.STATUS_NAN_DIRECTION) == expect, field
+    finally:
+        hip.close()
