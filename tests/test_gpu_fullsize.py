@@ -421,7 +421,7 @@ def test_config5_zernike_fresnel_polarised_full_size():
         assert np.nanmax(np.abs(p_got - p_want)) < 1e-4
         i_want, status = oracle.polarized_intensity(want["prt"], sub["L"], sub["M"], sub["N"],
                                                     sub["i"], table.polarization)
-        assert status == 0
+        assert (status & ~0x20) == 0  # (0x20: OL_STATUS_NAN_DIRECTION, informational)
         i_got = inten[idx].double().cpu().numpy()
         assert np.array_equal(np.isnan(i_got), np.isnan(i_want))
         np.testing.assert_allclose(i_got, i_want, rtol=1e-4, atol=1e-5)
@@ -509,7 +509,7 @@ def test_config5_zernike_fresnel_full_size_generating_kernel_with_epilogue(dtype
         assert np.nanmax(np.abs(p_got - p_want)) < tol
         i_want, status = oracle.polarized_intensity(want["prt"], sub["L"], sub["M"], sub["N"],
                                                     sub["i"], table.polarization)
-        assert status == 0
+        assert (status & ~0x20) == 0  # (0x20: OL_STATUS_NAN_DIRECTION, informational)
         i_got = res.updated_intensity[idx].double().cpu().numpy()
         assert np.array_equal(np.isnan(i_got), np.isnan(i_want))
         np.testing.assert_allclose(i_got, i_want, rtol=itol, atol=itol * 0.1)

@@ -113,7 +113,7 @@ def test_random_newton_raphson_system(seed, dtype):
     sysm = hm.HostMathSystem(table)
     got, status = sysm.trace(_planes(rays, dtype), 0, record=True)
     sysm.close()
-    assert status == 0
+    assert (status & ~0x20) == 0  # (0x20: OL_STATUS_NAN_DIRECTION, informational)
     tol = 1e-7 if dtype == np.float64 else 1e-4
     assert_close_planes(got.astype(np.float64), want["record"], tol, tol, f"nrfuzz{seed}")
 
@@ -135,7 +135,7 @@ def test_random_newton_raphson_system_polarised(seed, dtype):
         rays = _through_fp32(rays)
     n = rays["x"].size
     out = oracle.trace(table, rays, 0, record=True, polarized=True)
-    assert out["status"] == 0
+    assert (out["status"] & ~0x20) == 0
     sysm2 = hm.HostMathSystem(table)
     prt = np.empty((9, n), dtype=dtype)
     got, _ = sysm2.trace(_planes(rays, dtype), 0, record=True, prt=prt, prt_identity=True)
@@ -224,7 +224,7 @@ def test_random_polarised_system_update_intensity(seed, dtype):
     sysm.trace(planes, 0, record=True, prt=prt, prt_identity=True)
     iu, status = sysm.polarized_intensity(prt, k0, i0, table.polarization)
     sysm.close()
-    assert status == 0
+    assert (status & ~0x20) == 0  # (0x20: OL_STATUS_NAN_DIRECTION, informational)
     want_i, wstatus = oracle.polarized_intensity(out["prt"], rays["L"], rays["M"], rays["N"],
                                                  rays["i"], table.polarization)
     assert wstatus == 0
@@ -356,7 +356,7 @@ def test_random_fused_spot(seed, dtype):
         got, hits, status = sysm.trace_spot(px, py, 0, hx=f[0], hy=f[1], vx=v[0], vy=v[1],
                                             center=center, want_hits=True)
     sysm.close()
-    assert status == 0
+    assert (status & ~0x20) == 0  # (0x20: OL_STATUS_NAN_DIRECTION, informational)
     gx, gy, gi = (h.astype(np.float64) for h in hits)
     scale = _scale(table, wx, wy)
     assert want[0] > 0.05 * n, "bundle lost: the fuzz case tests nothing"
@@ -402,7 +402,7 @@ def test_fused_opd_equals_the_unfused_chain(case):
               "n_image": 1.0, "opd_ref": float(chief[7][0]), "ux": 0.01, "uy": -0.02,
               "half_epd": float(table.raygen["EPD"]) / 2, "wavelength_um": 0.55}
     opd, inten, pupil, mom, status = sysm.trace_opd(params, px, py, 0, field=field)
-    assert status == 0
+    assert (status & ~0x20) == 0  # (0x20: OL_STATUS_NAN_DIRECTION, informational)
     rays, _ = sysm.generate_rays(field[0], field[1], px, py)
     sysm.trace(rays, 0, record=False)
     want_opd, want_pupil = sysm.wavefront_opd(params, rays[:6] + [rays[7]], px, py)
