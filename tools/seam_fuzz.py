@@ -84,6 +84,17 @@ def families(lens, polarised=False):
         return np.concatenate([np.nan_to_num(np.stack([_np(getattr(r, k)) for k in ("x", "y", "z", "L", "M", "N", "i", "opd")]), nan=-7.0).ravel(),
                                np.nan_to_num(rec, nan=-7.0, posinf=-8.0, neginf=-9.0).ravel()])
 
+    def trace_distributions():
+        # (the deterministic samplers of distribution.py; "random" / "sobol" draw)
+        parts = []
+        for dist, n_ in (("uniform", 9), ("line_x", 11), ("line_y", 8), ("cross", 7), ("ring", 12),
+                         ("positive_line_x", 5), ("hexapolar", 1)):
+            r = lens.trace(-0.4, 0.6, w, n_, dist)
+            parts.append(np.nan_to_num(np.stack([_np(getattr(r, k)) for k in
+                                                 ("x", "y", "z", "L", "M", "N", "i", "opd")]),
+                                       nan=-7.0).ravel())
+        return np.concatenate(parts)
+
     def trace_generic():
         rng_ = np.random.default_rng(5)
         n = 64
@@ -92,11 +103,12 @@ def families(lens, polarised=False):
         r = lens.trace_generic(hx, hy, be.array(rr * np.cos(th)), be.array(rr * np.sin(th)), w)
         return np.nan_to_num(np.stack([_np(getattr(r, k)) for k in ("x", "y", "z", "L", "M", "N", "i", "opd")]), nan=-7.0).ravel()
 
-    todo = {"trace": trace, "trace_generic": trace_generic, "spot": spot, "ee": ee, "opd": opd(), "opd_centroid": opd(strategy="centroid"),
+    todo = {"trace": trace, "trace_distributions": trace_distributions,
+            "trace_generic": trace_generic, "spot": spot, "ee": ee, "opd": opd(), "opd_centroid": opd(strategy="centroid"),
             "opd_best_fit": opd(strategy="best_fit"), "opd_detrended": opd(remove_tilt=True),
             "fftpsf": psf}
     if polarised:  # (wavefronts of polarised systems are not part of the seams)
-        todo = {k: v for k, v in todo.items() if k in ("trace", "trace_generic", "spot", "ee")}
+        todo = {k: v for k, v in todo.items() if k in ("trace", "trace_distributions", "trace_generic", "spot", "ee")}
     for k, fn in todo.items():
         try:
             with np.errstate(all="ignore"):
