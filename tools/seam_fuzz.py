@@ -95,6 +95,30 @@ def families(lens, polarised=False):
                                        nan=-7.0).ravel())
         return np.concatenate(parts)
 
+    def sg_trace():
+        # the caller's own rays through SurfaceGroup.trace (in place), whole and with skip
+        rng_ = np.random.default_rng(9)
+        n = 48
+        rr, th = np.sqrt(rng_.random(n)) * 0.8, 2 * np.pi * rng_.random(n)
+        parts = []
+        for skip in (0, 2):
+            # (scalar field: with per-ray field ARRAYS the reference's torch backend fails in the
+            # object-space-telecentric branch of the aimer, `be.full_like(Px, z)`, by itself)
+            rays = lens.ray_tracer.ray_generator.generate_rays(0.2, -0.4, be.array(rr * np.cos(th)),
+                                                               be.array(rr * np.sin(th)), w)
+            if skip:
+                # (start where a trace of the first `skip` surfaces leaves the rays)
+                for surf in lens.surface_group.surfaces[:skip]:
+                    surf.trace(rays)
+            out = lens.surface_group.trace(rays, skip) if skip else lens.surface_group.trace(rays)
+            assert out is rays
+            parts.append(np.nan_to_num(np.stack([_np(getattr(rays, k)) for k in
+                                                 ("x", "y", "z", "L", "M", "N", "i", "opd")]),
+                                       nan=-7.0).ravel())
+            parts.append(np.nan_to_num(_np(lens.surfaces.x)[max(skip, 1):], nan=-7.0, posinf=-8.0,
+                                       neginf=-9.0).ravel())
+        return np.concatenate(parts)
+
     def trace_generic():
         rng_ = np.random.default_rng(5)
         n = 64
@@ -103,12 +127,12 @@ def families(lens, polarised=False):
         r = lens.trace_generic(hx, hy, be.array(rr * np.cos(th)), be.array(rr * np.sin(th)), w)
         return np.nan_to_num(np.stack([_np(getattr(r, k)) for k in ("x", "y", "z", "L", "M", "N", "i", "opd")]), nan=-7.0).ravel()
 
-    todo = {"trace": trace, "trace_distributions": trace_distributions,
+    todo = {"trace": trace, "sg_trace": sg_trace, "trace_distributions": trace_distributions,
             "trace_generic": trace_generic, "spot": spot, "ee": ee, "opd": opd(), "opd_centroid": opd(strategy="centroid"),
             "opd_best_fit": opd(strategy="best_fit"), "opd_detrended": opd(remove_tilt=True),
             "fftpsf": psf}
     if polarised:  # (wavefronts of polarised systems are not part of the seams)
-        todo = {k: v for k, v in todo.items() if k in ("trace", "trace_distributions", "trace_generic", "spot", "ee")}
+        todo = {k: v for k, v in todo.items() if k in ("trace", "sg_trace", "trace_distributions", "trace_generic", "spot", "ee")}
     for k, fn in todo.items():
         try:
             with np.errstate(all="ignore"):
