@@ -689,7 +689,14 @@ int ol_trace_opd_dev(const ol_system* sys, ol_dtype dt, int64_t n_rays,
  *              torch backend's be.mean, backend/torch_backend.py:969-989; numpy: NaN spreads)
  *   workspace  OL_WAVEFRONT_FIT_WORKSPACE_DOUBLES doubles of device memory (contents undefined)
  *   fit_status device word, WRITTEN: OL_FIT_NO_VALID / _TOO_FEW / _NO_ALIVE -- the three
- *              ValueErrors of strategy.py:387, 536, 334 -- or OL_FIT_SINGULAR
+ *              ValueErrors of strategy.py:387, 536, 334 -- or OL_FIT_SINGULAR: the wavefront
+ *              points do not span space (a collimated beam: ONE plane; a stigmatic image:
+ *              one point).  A direction whose variance is within 64 eps of (mean^2 + the
+ *              largest variance), or a Cholesky pivot below 1e-10 of the largest diagonal
+ *              entry.  The sphere is not determined; the reference's backend returns what
+ *              its lstsq makes of a rank-deficient system (NumPy: the minimum-norm solution
+ *              in RAW coordinates), and the caller follows it from the points themselves
+ *              (the centre / radius written here are NaN)
  * The sums are formed in a fixed order (bit-reproducible for a given n_rays).  The least-squares
  * fits solve their normal equations in centred, per-axis scaled coordinates.
  * ol_wavefront_opd_fitted is ol_wavefront_opd against such a reference, with the tilt added
