@@ -134,10 +134,15 @@ def families(lens, polarised=False):
             return np.concatenate([flat(v[k]) for k in v] or [np.zeros(0)])
         if isinstance(v, (list, tuple)):
             return np.concatenate([flat(x) for x in v] or [np.zeros(0)])
+        if hasattr(v, "intensity") and hasattr(v, "x"):      # SpotData
+            return flat((v.x, v.y, v.intensity))
         try:
             return np.nan_to_num(_np(v), nan=-7.0, posinf=-8.0, neginf=-9.0).ravel()
-        except Exception:  # noqa: BLE001 - a non-numeric leaf (names, enums)
-            return np.zeros(0)
+        except Exception:  # noqa: BLE001
+            try:
+                return np.nan_to_num(np.array([float(v)]), nan=-7.0, posinf=-8.0, neginf=-9.0)
+            except Exception:  # noqa: BLE001 - a non-numeric leaf (names, enums)
+                return np.zeros(0)
 
     # the reference's other consumers of Optic.trace / trace_generic (their own call patterns:
     # scalar and array coordinates, line distributions, the image surface moved between traces)
@@ -150,10 +155,10 @@ def families(lens, polarised=False):
         "RmsWavefrontErrorVsField": lambda: flat(analysis.RmsWavefrontErrorVsField(
             lens, num_fields=6, num_rays=5).data),
         "PupilAberration": lambda: flat(analysis.PupilAberration(lens, num_points=17).data),
+        # (moves the image surface between its traces: the change detector's business)
         "ThroughFocusSpot": lambda: flat([[[(d.x, d.y, d.intensity) for d in f] for f in step]
                                           for step in analysis.ThroughFocusSpotDiagram(
-                                              lens, delta_focus=0.05, num_steps=3, num_rings=3).data])
-        if hasattr(analysis, "ThroughFocusSpotDiagram") else np.zeros(0),
+                                              lens, delta_focus=0.05, num_steps=3, num_rings=3).results]),
     }
 
     todo = {"trace": trace, "sg_trace": sg_trace, "trace_distributions": trace_distributions,
