@@ -746,11 +746,16 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
   // thickness, 0 in every sample), which makes that position NaN too; the drop-in applies that
   // to the rays it RETURNS -- the recorded row keeps the position -- and needs to know when:
   // an informational status bit instead of three extra elementwise passes per call.
+#ifndef OL_NAN_DIRECTION_BIT
+#define OL_NAN_DIRECTION_BIT 1  // (0: A/B only -- the drop-in then misses such rays)
+#endif
+#if OL_NAN_DIRECTION_BIT
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
     const Ray<T> q = LP::ray(r, k);
     if (k < cnt && q.L != q.L && q.x == q.x) status |= kStatusNanDirection;
   }
+#endif
 
   if constexpr (SPOT) {
     // epilogue: masked moments of the final (global) state about (cx, cy),

@@ -92,6 +92,8 @@ VARIANTS = {
     # Newton stop rule of rounds 1-4: a ray whose residual stops halving leaves at ANY level
     # (round 5: only at the rounding floor of sag - z)
     "old_stall": ["-DOL_NR_STALL_ULPS=0"],
+    # without the end-of-trace test behind OL_STATUS_NAN_DIRECTION (two compares per ray)
+    "o_nobit": ["-DOL_NAN_DIRECTION_BIT=0"],
 }
 
 
