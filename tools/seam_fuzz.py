@@ -80,6 +80,18 @@ def families(lens, polarised=False):
     def psf():
         return _np(FFTPSF(lens, (0.0, 0.5), w, num_rays=32, grid_size=64).psf)
 
+    def trace_wavelengths():
+        # every wavelength of the lens in turn, twice round (the drop-in keeps one packed table
+        # and one device system per wavelength)
+        parts = []
+        for _round in range(2):
+            for wl in lens.wavelengths.get_wavelengths():
+                r = lens.trace(0.1, 0.8, wl, 4, "hexapolar")
+                parts.append(np.nan_to_num(np.stack([_np(getattr(r, k)) for k in
+                                                     ("x", "y", "z", "L", "M", "N", "i", "opd")]),
+                                           nan=-7.0).ravel())
+        return np.concatenate(parts)
+
     def trace():
         r = lens.trace(0.3, -0.5, w, 5, "hexapolar")
         rec = np.stack([_np(getattr(lens.surfaces, k))[1:] for k in ("x", "y", "z", "L", "M", "N", "intensity", "opd")])
@@ -162,14 +174,14 @@ def families(lens, polarised=False):
                                               lens, delta_focus=0.05, num_steps=3, num_rings=3).results]),
     }
 
-    todo = {"trace": trace, "sg_trace": sg_trace, "trace_distributions": trace_distributions,
+    todo = {"trace": trace, "trace_wavelengths": trace_wavelengths, "sg_trace": sg_trace, "trace_distributions": trace_distributions,
             "trace_generic": trace_generic, "spot": spot, "ee": ee, "opd": opd(), "opd_centroid": opd(strategy="centroid"),
             "opd_best_fit": opd(strategy="best_fit"), "opd_detrended": opd(remove_tilt=True),
             "fftpsf": psf}
     if OTHERS:
         todo = others
     if polarised:  # (wavefronts of polarised systems are not part of the seams)
-        todo = {k: v for k, v in todo.items() if k in ("trace", "sg_trace", "trace_distributions", "trace_generic", "spot", "ee")
+        todo = {k: v for k, v in todo.items() if k in ("trace", "trace_wavelengths", "sg_trace", "trace_distributions", "trace_generic", "spot", "ee")
                 or (OTHERS and not k.startswith("RmsWavefront"))}
     for k, fn in todo.items():
         try:
