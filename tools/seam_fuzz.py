@@ -80,6 +80,33 @@ def families(lens, polarised=False):
     def psf():
         return _np(FFTPSF(lens, (0.0, 0.5), w, num_rays=32, grid_size=64).psf)
 
+    def edit_loop():
+        # an optimiser's pattern: edit the prescription through the reference's updater, trace,
+        # edit, trace ... (the drop-in's change detector, re-packing and ol_system_update)
+        rng_ = np.random.default_rng(4242)
+        surfs = lens.surface_group.surfaces
+        parts = []
+        for _step in range(6):
+            kind = int(rng_.integers(0, 4))
+            idx = int(rng_.integers(1, len(surfs) - 1)) if len(surfs) > 2 else 1
+            g_ = surfs[idx].geometry
+            if kind == 0 and np.isfinite(float(_np(getattr(g_, "radius", np.inf)))):
+                lens.updater.set_radius(float(_np(g_.radius)) * (1 + 1e-3 * rng_.standard_normal()), idx)
+            elif kind == 1 and hasattr(g_, "k"):
+                lens.updater.set_conic(float(_np(g_.k)) + 1e-3 * rng_.standard_normal(), idx)
+            elif kind == 2:
+                th = float(_np(surfs[idx + 1].geometry.cs.z)) - float(_np(g_.cs.z)) if idx + 1 < len(surfs) else 0.0
+                if np.isfinite(th):
+                    lens.updater.set_thickness(th * (1 + 1e-3 * rng_.standard_normal()) + 1e-4, idx)
+            else:
+                lens.updater.scale_system(1.0 + 1e-3 * rng_.standard_normal())
+            r = lens.trace(0.2, 0.6, w, 3, "hexapolar")
+            parts.append(np.nan_to_num(np.stack([_np(getattr(r, k)) for k in
+                                                 ("x", "y", "z", "L", "M", "N", "i", "opd")]),
+                                       nan=-7.0).ravel())
+            parts.append(np.nan_to_num(_np(lens.surfaces.z)[1:], nan=-7.0, posinf=-8.0, neginf=-9.0).ravel())
+        return np.concatenate(parts)
+
     def trace_wavelengths():
         # every wavelength of the lens in turn, twice round (the drop-in keeps one packed table
         # and one device system per wavelength)
@@ -174,14 +201,15 @@ def families(lens, polarised=False):
                                               lens, delta_focus=0.05, num_steps=3, num_rings=3).results]),
     }
 
-    todo = {"trace": trace, "trace_wavelengths": trace_wavelengths, "sg_trace": sg_trace, "trace_distributions": trace_distributions,
+    todo = {"trace": trace, "trace_wavelengths": trace_wavelengths, "sg_trace": sg_trace, "edit_loop": edit_loop, "trace_distributions": trace_distributions,
             "trace_generic": trace_generic, "spot": spot, "ee": ee, "opd": opd(), "opd_centroid": opd(strategy="centroid"),
             "opd_best_fit": opd(strategy="best_fit"), "opd_detrended": opd(remove_tilt=True),
             "fftpsf": psf}
+    todo["edit_loop"] = todo.pop("edit_loop")   # last: it edits the lens
     if OTHERS:
         todo = others
     if polarised:  # (wavefronts of polarised systems are not part of the seams)
-        todo = {k: v for k, v in todo.items() if k in ("trace", "trace_wavelengths", "sg_trace", "trace_distributions", "trace_generic", "spot", "ee")
+        todo = {k: v for k, v in todo.items() if k in ("trace", "edit_loop", "trace_wavelengths", "sg_trace", "trace_distributions", "trace_generic", "spot", "ee")
                 or (OTHERS and not k.startswith("RmsWavefront"))}
     for k, fn in todo.items():
         try:
