@@ -107,6 +107,21 @@ def families(lens, polarised=False):
             parts.append(np.nan_to_num(_np(lens.surfaces.z)[1:], nan=-7.0, posinf=-8.0, neginf=-9.0).ravel())
         return np.concatenate(parts)
 
+    def aimed():
+        # iterative / robust ray aiming: the reference builds the rays (its aimers trace to the
+        # stop surface by surface), the surface loop enters the HIP path through SurfaceGroup.trace
+        parts = []
+        try:
+            for mode in ("iterative", "robust"):
+                lens.ray_tracer.set_aiming(mode, 10, 1e-9)
+                r = lens.trace(0.0, 0.7, w, 3, "hexapolar")
+                parts.append(np.nan_to_num(np.stack([_np(getattr(r, k)) for k in
+                                                     ("x", "y", "z", "L", "M", "N", "i", "opd")]),
+                                           nan=-7.0).ravel())
+        finally:
+            lens.ray_tracer.set_aiming("paraxial", 10, 1e-6)
+        return np.concatenate(parts)
+
     def trace_wavelengths():
         # every wavelength of the lens in turn, twice round (the drop-in keeps one packed table
         # and one device system per wavelength)
@@ -201,7 +216,8 @@ def families(lens, polarised=False):
                                               lens, delta_focus=0.05, num_steps=3, num_rings=3).results]),
     }
 
-    todo = {"trace": trace, "trace_wavelengths": trace_wavelengths, "sg_trace": sg_trace, "edit_loop": edit_loop, "trace_distributions": trace_distributions,
+    todo = {"trace": trace, "trace_wavelengths": trace_wavelengths, "aimed": aimed, "sg_trace": sg_trace,
+            "edit_loop": edit_loop, "trace_distributions": trace_distributions,
             "trace_generic": trace_generic, "spot": spot, "ee": ee, "opd": opd(), "opd_centroid": opd(strategy="centroid"),
             "opd_best_fit": opd(strategy="best_fit"), "opd_detrended": opd(remove_tilt=True),
             "fftpsf": psf}
@@ -209,7 +225,7 @@ def families(lens, polarised=False):
     if OTHERS:
         todo = others
     if polarised:  # (wavefronts of polarised systems are not part of the seams)
-        todo = {k: v for k, v in todo.items() if k in ("trace", "edit_loop", "trace_wavelengths", "sg_trace", "trace_distributions", "trace_generic", "spot", "ee")
+        todo = {k: v for k, v in todo.items() if k in ("trace", "aimed", "edit_loop", "trace_wavelengths", "sg_trace", "trace_distributions", "trace_generic", "spot", "ee")
                 or (OTHERS and not k.startswith("RmsWavefront"))}
     for k, fn in todo.items():
         try:
