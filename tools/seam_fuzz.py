@@ -1,17 +1,27 @@
 #!/usr/bin/env python
-"""CPU, build container only (round 5): the reference's OWN analysis classes on random lenses,
-with and without the drop-in.
+"""CPU, build container only (round 5): the reference's OWN classes on random lenses, with and
+without the drop-in.
 
 For every seed the lens of tests/test_reference_fuzz.py:build_random_lens is built twice through
 the reference's public API: once under the NumPy backend (the reference as it is), once under the
-torch backend (cpu, fp64) with `integration.enable(force=True)` and the product's engine class on
-the HOST build of the kernel source (tests/_hostmath.py) -- the seams of analysis_seams.py behind
-`SpotDiagram`, `EncircledEnergy`, `OPD` (chief ray, centroid, best fit; tilt removal), `FFTPSF`.
-Prints, per family, how many lenses were compared, the worst relative difference and every
-lens over 1e-6 (lenses with a Newton surface separately: the reference stops its iteration at
-1e-6 mm), plus which seams declined.
+torch backend (cpu) with `integration.enable(force=True)` and the product's engine class on the
+HOST build of the kernel source (tests/_hostmath.py).  Families:
+  trace, trace_generic (64-element field / pupil arrays), trace_distributions (every deterministic
+  pupil sampler), trace_wavelengths (every wavelength in turn, twice round), aimed (iterative and
+  robust ray aiming), sg_trace (the caller's own rays through SurfaceGroup.trace, whole and with
+  skip), edit_loop (edit through the updater / trace, six rounds), spot, ee (SpotDiagram,
+  EncircledEnergy), opd / opd_centroid / opd_best_fit / opd_detrended (OPD with each reference
+  strategy, tilt removal), fftpsf;
+  `others`: RayFan, PupilAberration, Distortion, GridDistortion, FieldCurvature,
+  RmsSpotSizeVsField, RmsWavefrontErrorVsField, ThroughFocusSpotDiagram.
+Prints, per family, how many lenses were compared, the worst relative difference (to the largest
+value of the reference's result), every lens over the limit -- 1e-6; wavefront families on lenses
+with a Newton surface 2e-3 (the reference stops its iteration at 1e-6 mm) -- and which seams
+declined.  Results and triage of every flag: profiles/r05_seam_fuzz.txt.
 
-    python tools/seam_fuzz.py 0 200
+    python tools/seam_fuzz.py LO HI [polarised] [others]
+    OL_FUZZ_KINDS=standard      conic surfaces only (no stop tolerance between the two sides)
+    OL_FUZZ_PRECISION=float32   the torch backend at float32 (limit 1e-4)
 """
 import os
 import sys
