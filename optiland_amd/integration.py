@@ -1043,6 +1043,14 @@ def _sg_run(group, eng, rays, planes, first, last, polarized):
         _carry_prt_planes(rays, prt)        # `p` is produced from the planes on first read
 
 
+def _unit_directions(rays, tol=1e-9) -> bool:
+    """All finite direction cosines of the bundle are unit vectors to `tol` (one small
+    reduction and one read-back; polarised caller-made bundles only)."""
+    L, M, N = (t.detach() for t in (rays.L, rays.M, rays.N))
+    off = (L * L + M * M + N * N - 1.0).abs()
+    return float(torch.nan_to_num(off, nan=0.0, posinf=0.0).max()) <= tol if off.numel() else True
+
+
 def _hip_surface_group_trace(group, rays, skip):
     """SurfaceGroup.trace on the HIP path, or None when the call is not eligible (the
     caller then runs the reference's own loop).  Mirrors surface_group.py:245-257:
@@ -1086,6 +1094,19 @@ def _hip_surface_group_trace(group, rays, skip):
         return None  # nothing but the object row would run fused
     if table.uses_polarization and not polarized:
         return None  # RealRays.update() ignores Jones matrices; keep that on the reference
+    if polarized and not _unit_directions(rays):
+        # Round 5 (tools/seam_fuzz.py, iterative / robust aiming on polarised lenses): the
+        # reference's iterative aimers hand out direction cosines that are not unit vectors
+        # (|k|^2 - 1 ~ 1e-3) and nothing renormalises them.  Its PRT algebra takes k as it
+        # comes -- O_in = (s, k0 x s, k0), O_out = (s, k1 x s, k1) stop being orthonormal and
+        # the matrix picks up factors |k0| |k1| (polarized_rays.py:136-202) -- while the
+        # kernel's rank-2 form of that update is the same matrix only for |k0| = 1 to
+        # rounding (surface_math.h: prt_apply_diag): 3e-3 of the PRT, 0.3 % of the returned
+        # intensity.  Such a bundle stays on the reference's own surface loop.  (Geometry does
+        # not care: the unpolarised traces of the same rays agree to 1e-10.)
+        from .analysis_seams import _why
+        _why("sg_trace", "polarised bundle whose direction cosines are not unit vectors")
+        return None
     eng, table = _sg_engine(group, table, rays.x.device)
 
     # SurfaceGroup.reset() (surface_group.py:373-380): every recorded attribute of every surface

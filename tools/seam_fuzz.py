@@ -22,6 +22,7 @@ declined.  Results and triage of every flag: profiles/r05_seam_fuzz.txt.
     python tools/seam_fuzz.py LO HI [polarised] [others]
     OL_FUZZ_KINDS=standard      conic surfaces only (no stop tolerance between the two sides)
     OL_FUZZ_PRECISION=float32   the torch backend at float32 (limit 1e-4)
+    OL_FUZZ_FAMILIES=a,b,...    only these families
 """
 import os
 import sys
@@ -63,7 +64,7 @@ OTHERS = "others" in sys.argv[3:]   # the reference's other analyses instead of 
 POLARISED = "polarised" in sys.argv[3:]   # only the polarised lenses: spot, ee
 
 
-def families(lens, polarised=False):
+def families(lens, polarised=False, only=None):
     from optiland import analysis
     from optiland.psf import FFTPSF
     from optiland.wavefront import OPD
@@ -237,6 +238,10 @@ def families(lens, polarised=False):
     if polarised:  # (wavefronts of polarised systems are not part of the seams)
         todo = {k: v for k, v in todo.items() if k in ("trace", "aimed", "edit_loop", "trace_wavelengths", "sg_trace", "trace_distributions", "trace_generic", "spot", "ee")
                 or (OTHERS and not k.startswith("RmsWavefront"))}
+    if only is None and os.environ.get("OL_FUZZ_FAMILIES"):
+        only = set(os.environ["OL_FUZZ_FAMILIES"].split(","))
+    if only:
+        todo = {k: v for k, v in todo.items() if k in only}
     for k, fn in todo.items():
         try:
             with np.errstate(all="ignore"):
@@ -312,5 +317,5 @@ for (k, newton), (n, worst) in sorted(stats.items()):
     print(f"  {k:14s} {'Newton lenses' if newton else 'conic lenses ':13s} compared {n:4d}  worst {worst:.3e}")
 print("seam fall-backs:", declined or "none")
 print("over 1e-6 (conic lenses) / 2e-3 (Newton lenses), or one-sided:", len(bad))
-for b_ in bad[:40]:
+for b_ in bad[:400]:
     print("   ", b_)
