@@ -371,6 +371,13 @@ class HipRayTracer:
         device generator does not cover)."""
         src = [self._dev(p) for p in planes]
         n = int(src[0].numel())
+        if self.table.polarization is not None and n:
+            # the PRT update of the kernels is the reference's only for unit direction cosines
+            # (surface_math.h: prt_apply_diag; DESIGN 0a): fail loudly instead of being 1e-3 off
+            off = (src[3] * src[3] + src[4] * src[4] + src[5] * src[5] - 1.0).abs()
+            if float(torch.nan_to_num(off, nan=0.0, posinf=0.0).max()) > 1e-6:
+                raise ValueError("trace_rays: a polarised trace needs unit direction cosines "
+                                 "(|L^2 + M^2 + N^2 - 1| <= 1e-6)")
         record, rays = self._alloc_state(n)
         for dst, s_ in zip(rays, src):
             dst.copy_(s_)

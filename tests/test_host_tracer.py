@@ -440,3 +440,20 @@ def test_few_waves_hint_follows_the_placed_windows():
     finally:
         E._PLACED_WINDOWS.clear()
         E._PLACED_WINDOWS.update(saved)
+
+
+def test_polarised_trace_rays_refuses_unnormalised_directions():
+    """Round 5: the kernels' PRT update equals the reference's only for unit direction cosines
+    (DESIGN 0a); the stand-alone `trace_rays` says so instead of returning a matrix 1e-3 off."""
+    from optiland_amd import load_system
+    from optiland_amd.tracer import HipRayTracer
+    from tests._fake_engine import OracleEngine
+    table = load_system("zernike_fresnel_fringe")
+    assert table.polarization is not None
+    t = HipRayTracer(table, "cpu", dtype=torch.float64, engine=OracleEngine(table, "cpu"))
+    n = 5
+    z = torch.full((n,), -10.0, dtype=torch.float64)
+    zero, one = torch.zeros(n, dtype=torch.float64), torch.ones(n, dtype=torch.float64)
+    t.trace_rays([zero, zero, z, zero, zero, one, one], 0.55)                    # unit: fine
+    with pytest.raises(ValueError, match="unit direction cosines"):
+        t.trace_rays([zero, zero, z, zero, zero, one * 1.0005, one], 0.55)
