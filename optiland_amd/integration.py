@@ -1043,12 +1043,16 @@ def _sg_run(group, eng, rays, planes, first, last, polarized):
         _carry_prt_planes(rays, prt)        # `p` is produced from the planes on first read
 
 
-def _unit_directions(rays, tol=1e-9) -> bool:
-    """All finite direction cosines of the bundle are unit vectors to `tol` (one small
-    reduction and one read-back; polarised caller-made bundles only)."""
+def _unit_directions(rays) -> bool:
+    """All finite direction cosines of the bundle are unit vectors -- to 1e-9 in float64, to
+    2e-6 in float32 (a correctly normalised float32 vector is off by ~1e-7; the aimers' bundles
+    by 1e-3).  One small reduction and one read-back; polarised caller-made bundles only."""
     L, M, N = (t.detach() for t in (rays.L, rays.M, rays.N))
     off = (L * L + M * M + N * N - 1.0).abs()
-    return float(torch.nan_to_num(off, nan=0.0, posinf=0.0).max()) <= tol if off.numel() else True
+    if not off.numel():
+        return True
+    tol = 1e-9 if L.dtype == torch.float64 else 2e-6
+    return float(torch.nan_to_num(off, nan=0.0, posinf=0.0).max()) <= tol
 
 
 def _hip_surface_group_trace(group, rays, skip):
