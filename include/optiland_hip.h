@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OL_ABI_VERSION 10
+#define OL_ABI_VERSION 11
 
 /* ---- error codes ------------------------------------------------------- */
 #define OL_OK 0
@@ -146,6 +146,19 @@ typedef enum ol_coating_kind {
                                        is ill conditioned (|1 + k| << 1: goldens generated with it
                                        encode its systematic error, e.g. tests/test_operand.py
                                        test_opd_diff_on_axis).  Default off: less accurate         */
+#define OL_SURF_REFERENCE_NEWTON 0x4u /* ABI 11, Newton-Raphson geometries only: the reference's
+                                       OWN stop rule.  NewtonRaphsonGeometry.distance
+                                       (geometries/newton_raphson.py:119-168) iterates the whole
+                                       batch in lockstep and stops when max_j |f_j| < tol, so every
+                                       ray of a trace call takes the SAME number K of updates
+                                       (max_iter when any ray of the batch is NaN), and the surface
+                                       normal is evaluated at the end point
+                                       (surfaces/standard_surface.py:200-258).  The default kernels
+                                       stop per ray and converge further (<= 1e-7 with the factory
+                                       tolerance; more with a user-set loose one).  K is a property
+                                       of the batch: it is found by ol_newton_count and handed to
+                                       ol_trace_ex in ol_trace_extras.newton_iterations; the fused
+                                       entry points refuse such a system (OL_EUNSUPPORTED)         */
 
 /* One traced surface.  All lengths in mm, angles already folded into rot[]. */
 typedef struct ol_surface_desc {
@@ -315,6 +328,17 @@ typedef struct ol_trace_extras {
    * NULL (or a NULL state): no epilogue.  The PRT planes are written either way.        */
   const ol_polarization_state* update_intensity_state;
   void* updated_intensity;
+  /* ABI 11, ranges with OL_SURF_REFERENCE_NEWTON surfaces (required there, ignored elsewhere).
+   * `newton_iterations`: DEVICE array of 2 * n_surfaces int32 (ol_system_num_surfaces), zeroed
+   * by the caller before the first ol_newton_count of a trace call: element s = the number of
+   * Newton updates every ray takes at surface s; element n_surfaces + s is raised (non-zero)
+   * by any launch that finds a ray NOT below the surface's tolerance after those updates
+   * although the count is below max_iter -- the caller then adds one to element s, clears the
+   * word and asks again (ol_newton_count with `verify`).  `newton_count_surface`: leave 0
+   * (ol_newton_count sets it).                                                             */
+  int32_t* newton_iterations;
+  int32_t newton_count_surface;
+  int32_t reserved2_;
 } ol_trace_extras;
 
 int ol_trace_ex(const ol_system* sys, ol_dtype dt, int64_t n_rays,
@@ -322,6 +346,24 @@ int ol_trace_ex(const ol_system* sys, ol_dtype dt, int64_t n_rays,
                 void* record, int64_t record_stride, void* prt,
                 int32_t first_surface, int32_t last_surface, uint32_t flags,
                 uint32_t* status, const ol_trace_extras* extras, void* stream);
+
+/* ABI 11.  The iteration count of ONE reference-rule Newton surface for this batch of rays
+ * (see OL_SURF_REFERENCE_NEWTON): the rays are traced from `first_surface` up to `surface` --
+ * nothing is recorded or written back; every Newton surface of the range before `surface`
+ * takes the count already in `iterations` -- and
+ *   verify == 0:  element `surface` of `iterations` becomes the maximum over the batch of each
+ *                 ray's first k with |f_k| < tol (max_iter for a ray that is NaN or never gets
+ *                 there): newton_raphson.py:148's break index, unless a ray that was below tol
+ *                 is above it again at that k;
+ *   verify != 0:  every ray takes exactly iterations[surface] updates and the violation word
+ *                 n_surfaces + surface is raised if the stop rule does not hold then.
+ * Call it for the reference-rule surfaces of a range in ascending order (each count depends on
+ * the ones before it), with the SAME rays, wavelength and first surface as the ol_trace_ex that
+ * follows; a sharded batch takes the maximum of element `surface` over its shards after every
+ * call (one int32 all-reduce).  Asynchronous on `stream`.                                   */
+int ol_newton_count(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const rays[8],
+                    int32_t wavelength_index, int32_t first_surface, int32_t surface,
+                    int32_t* iterations, int32_t verify, void* stream);
 
 /* Generate rays on device from normalised field/pupil coordinates: angle fields
  * (object at infinity or finite, fields/field_types/angle.py:17-58) and object-height

@@ -76,7 +76,10 @@ class TraceExtras(C.Structure):
     _fields_ = [("spot_slots", C.c_void_p), ("cx", C.c_double), ("cy", C.c_double),
                 ("record_first_surface", C.c_int32), ("reserved_", C.c_int32),
                 # ABI 7: update_intensity as an epilogue of ol_trace_generate
-                ("update_intensity_state", C.c_void_p), ("updated_intensity", C.c_void_p)]
+                ("update_intensity_state", C.c_void_p), ("updated_intensity", C.c_void_p),
+                # ABI 11: reference-Newton ranges (OL_SURF_REFERENCE_NEWTON, ol_newton_count)
+                ("newton_iterations", C.c_void_p), ("newton_count_surface", C.c_int32),
+                ("reserved2_", C.c_int32)]
 
 
 SPOT_SLOTS = 64
@@ -138,11 +141,12 @@ EXPORTS = (
     "ol_wavefront_fit",
     "ol_wavefront_opd_fitted",
     "ol_trace_spot_batch",
+    "ol_newton_count",
 )
 
 F32, F64 = 0, 1
 TUNE_RAYS_PER_THREAD, TUNE_COMPACT, TUNE_FIT_GRID, TUNE_RECORD_WG_CAP = 0, 1, 2, 3
-ABI_VERSION = 10
+ABI_VERSION = 11
 OPD_MOMENTS = 12  # kOpdMoments / ol_trace_opd
 WAVEFRONT_REFERENCE_DOUBLES = 16  # OL_WAVEFRONT_REFERENCE_DOUBLES
 WAVEFRONT_FIT_WORKSPACE_DOUBLES = 32832  # OL_WAVEFRONT_FIT_WORKSPACE_DOUBLES
@@ -255,6 +259,8 @@ def bind(lib, path: str = "?"):
                                       u32, vp, vp, vp]
     lib.ol_trace_spot_batch.restype = C.c_int
     lib.ol_trace_spot_batch.argtypes = [vp, C.c_int, i64, vp, vp, i32, vp, vp, i64, vp, vp, vp]
+    lib.ol_newton_count.restype = C.c_int
+    lib.ol_newton_count.argtypes = [vp, C.c_int, i64, C.POINTER(vp), i32, i32, i32, vp, i32, vp]
     lib.ol_pupil_points.restype = C.c_int
     lib.ol_pupil_points.argtypes = [i32, i32, C.c_int, i64, vp, vp, vp, vp, vp]
     lib.ol_math_probe.restype = C.c_int

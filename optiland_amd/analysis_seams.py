@@ -85,6 +85,12 @@ def _front(optic, wavelength, need_fp64=False, final_propagation=False, recorded
     if not table.raygen or polarised:
         _why("front", "no device ray generation" if not table.raygen else "polarised")
         return None  # reference-side ray generation / polarised epilogue: not fused
+    if table.reference_newton_surfaces():
+        # opt-in reference stop rule: the Newton iteration count is a property of each trace
+        # call's batch (engine._newton_counts) -- the reference's own analysis code runs on top
+        # of the drop-in's `Optic.trace`, which finds it
+        _why("front", "reference-rule Newton surfaces")
+        return None
     if float(table.last_thickness) != 0.0 and not final_propagation:
         _why("front", "last surface has a thickness")
         # `Optic.trace` propagates the rays on by the LAST surface's thickness
@@ -196,6 +202,11 @@ def _spot_grid(self):
     wls = [wp.value for wp in self.wavelengths]
     if not wls:
         return None
+    from . import integration as ig
+    if len(wls) > ig._MAX_ENGINES:
+        # one engine per wavelength is collected below and the tracer keeps _MAX_ENGINES of them:
+        # the ninth would evict -- and close -- the first before the launch
+        return None
     main = None      # the front whose geometry the launch reads; the others lend index rows
     cells, last = [], None
     for wi, w in enumerate(wls):
@@ -229,6 +240,8 @@ def _spot_grid(self):
 
     flags = (_capi.SPOT_HITS_LOCAL if tilted_local else 0) \
         | (_capi.SPOT_POLARIZED_OK if polarised else 0)
+    if any(getattr(c[2][7], "_handle", True) is None for c in cells):
+        return None   # an engine of the grid was closed in the meantime: the per-cell loop
     mom, hits = front.engine.trace_spot_batch(px, py, [c[2] for c in cells], hits=True,
                                               flags=flags)
     counts = mom[:, 0].cpu().numpy().astype(np.int64)   # the ONE read-back of the grid

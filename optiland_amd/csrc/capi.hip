@@ -245,7 +245,7 @@ struct Staged {
   std::vector<double> coeffs;
   std::vector<size_t> int_slots;  // coeffs entries uploaded as integer bit patterns
   std::vector<int32_t> interaction, coating, geom;
-  std::vector<uint8_t> polygon;
+  std::vector<uint8_t> polygon, ref_newton;
 };
 
 }  // namespace
@@ -260,6 +260,7 @@ struct ol_system {
   std::vector<int32_t> coating;
   std::vector<int32_t> geom;
   std::vector<uint8_t> polygon;  // surface uses a polygon aperture (top level or in a tree)
+  std::vector<uint8_t> ref_newton;  // OL_SURF_REFERENCE_NEWTON on a traced Newton-Raphson surface
   // false between the two in-place uploads of ol_system_update and for good if the second
   // one fails: the fp32 and fp64 tables (and the host copies) then describe different
   // prescriptions -- every entry point refuses such a system instead of tracing through it
@@ -352,11 +353,16 @@ void release(DeviceTable<T>& t) {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Which Newton kernel a traced range needs (trace_launch.h: launch_trace): 0 = none,
-// 3 / 4 = all of its Newton-Raphson surfaces are Zernike surfaces / even aspheres, else 1.
+// 3 / 4 = all of its Newton-Raphson surfaces are Zernike surfaces / even aspheres, 5 = the
+// reference's batch-global stop rule was asked for (OL_SURF_REFERENCE_NEWTON), else 1.
 // (A polygon aperture on a conic-only range also selects the generic kernel: polygons live
 // in the full kernels only.)
 int newton_family(const ol_system* sys, int32_t first, int32_t last) {
   bool any = false, polygon = false, all_zernike = true, all_even = true;
+  // OL_SURF_REFERENCE_NEWTON (opt-in, ABI 11) on any Newton surface of the range: the kernel
+  // family that iterates the batch in lockstep (surface_math.h: newton_reference)
+  for (int32_t s = first; s <= last; ++s)
+    if (sys->ref_newton[s]) return ol::kNrReference;
   for (int32_t s = first; s <= last; ++s) {
     polygon = polygon || sys->polygon[s];
     const int g = sys->geom[s];
@@ -421,9 +427,29 @@ int do_trace(const ol_system* sys, const DeviceTable<T>& tab, int64_t n, void* c
       alias = alias && (static_cast<T*>(rays[k]) == static_cast<T*>(record) + k * record_stride);
     if (alias) a.flags |= ol::kTraceRow0IsInput;
   }
-  hipError_t e = ol::launch_trace<T>(a, vec, newton_family(sys, first, last), stream);
+  const int family = newton_family(sys, first, last);
+  a.nr_iters = extras ? extras->newton_iterations : nullptr;
+  a.nr_count_at = extras && extras->newton_iterations ? extras->newton_count_surface : -1;
+  a.n_surf = sys->n_surf;
+  if (family == ol::kNrReference) {
+    if (!a.nr_iters)
+      return fail(OL_EINVAL, "ol_trace: a surface of the range carries OL_SURF_REFERENCE_NEWTON: "
+                             "pass ol_trace_extras.newton_iterations (see ol_newton_count)");
+    if (a.spot)
+      return fail(OL_EUNSUPPORTED, "ol_trace_ex: no spot epilogue on a reference-Newton range");
+  }
+  hipError_t e = ol::launch_trace<T>(a, vec, family, stream);
   if (e != hipSuccess) return fail(OL_EHIP, "trace launch failed: %s", hipGetErrorString(e));
   return OL_OK;
+}
+
+// the fused entry points (one launch: generate -> trace [-> reduce]) do not serve ranges whose
+// Newton iteration count is a property of the batch
+int refuse_reference_newton(const char* who, const ol_system* sys) {
+  if (newton_family(sys, 0, sys->n_surf - 1) != ol::kNrReference) return OL_OK;
+  return fail(OL_EUNSUPPORTED, "%s: the system carries OL_SURF_REFERENCE_NEWTON surfaces "
+                               "(reference stop rule): generate with ol_generate_rays, count "
+                               "with ol_newton_count, trace with ol_trace_ex", who);
 }
 
 // ol_raygen_inputs -> working precision; host-side part of the range validation
@@ -947,6 +973,11 @@ int stage_system(const char* who, const ol_surface_desc* surf, int32_t n_surf,
       }
       st.polygon.push_back(poly ? 1 : 0);
     }
+    st.ref_newton.push_back((surf[i].flags & OL_SURF_REFERENCE_NEWTON) &&
+                                    surf[i].geom_kind != OL_GEOM_PLANE &&
+                                    surf[i].geom_kind != OL_GEOM_STANDARD &&
+                                    surf[i].interaction != OL_INTERACT_RECORD_ONLY
+                                ? 1 : 0);
   }
   return OL_OK;
 }
@@ -956,6 +987,7 @@ void adopt_host_copies(ol_system* sys, Staged& st) {
   sys->coating.swap(st.coating);
   sys->geom.swap(st.geom);
   sys->polygon.swap(st.polygon);
+  sys->ref_newton.swap(st.ref_newton);
 }
 }  // namespace
 
@@ -1099,6 +1131,47 @@ int ol_trace_ex(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const r
                           prt, first_surface, last_surface, flags, status, extras, st);
 }
 
+int ol_newton_count(const ol_system* sys, ol_dtype dt, int64_t n_rays, void* const rays[8],
+                    int32_t wavelength_index, int32_t first_surface, int32_t surface,
+                    int32_t* iterations, int32_t verify, void* stream) {
+  if (!sys) return fail(OL_EINVAL, "ol_newton_count: system is NULL");
+  OL_CHECK_CONSISTENT(sys, "ol_newton_count");
+  if (dt != OL_F32 && dt != OL_F64)
+    return fail(OL_EINVAL, "ol_newton_count: bad dtype %d", (int)dt);
+  if (n_rays < 0) return fail(OL_EINVAL, "ol_newton_count: negative ray count");
+  if (first_surface < 0 || surface >= sys->n_surf || first_surface > surface)
+    return fail(OL_EINVAL, "ol_newton_count: surface range [%d, %d] outside [0, %d)",
+                first_surface, surface, sys->n_surf);
+  if (wavelength_index < 0 || wavelength_index >= sys->n_wl)
+    return fail(OL_EINVAL, "ol_newton_count: wavelength index %d outside [0, %d)",
+                wavelength_index, sys->n_wl);
+  if (!iterations) return fail(OL_EINVAL, "ol_newton_count: iterations is NULL");
+  if (!sys->ref_newton[surface])
+    return fail(OL_EINVAL, "ol_newton_count: surface %d is not a traced Newton-Raphson surface "
+                           "with OL_SURF_REFERENCE_NEWTON", surface);
+  if (n_rays == 0) return OL_OK;
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != sys->device)
+      return fail(OL_EINVAL, "ol_newton_count: current HIP device %d is not the system's "
+                             "device %d", cur, sys->device);
+  }
+  if (!rays) return fail(OL_EINVAL, "ol_newton_count: rays is NULL");
+  for (int k = 0; k < 8; ++k)
+    if (!rays[k]) return fail(OL_EINVAL, "ol_newton_count: rays[%d] is NULL", k);
+  // the geometry of a ray does not depend on its polarisation: the unpolarised kernel over
+  // [first_surface, surface], nothing recorded, nothing written back
+  ol_trace_extras ex{};
+  ex.newton_iterations = iterations;
+  ex.newton_count_surface = verify ? -1 : surface;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dt == OL_F32)
+    return do_trace<float>(sys, sys->f32, n_rays, rays, wavelength_index, nullptr, 0, nullptr,
+                           first_surface, surface, 0u, nullptr, &ex, st);
+  return do_trace<double>(sys, sys->f64, n_rays, rays, wavelength_index, nullptr, 0, nullptr,
+                          first_surface, surface, 0u, nullptr, &ex, st);
+}
+
 int ol_trace_generate(const ol_system* sys, ol_dtype dt, int64_t n_rays,
                       const ol_raygen_params* p, const ol_raygen_inputs* in,
                       int32_t wavelength_index, void* record, int64_t record_stride,
@@ -1106,6 +1179,7 @@ int ol_trace_generate(const ol_system* sys, ol_dtype dt, int64_t n_rays,
                       const ol_trace_extras* extras, void* stream) {
   if (!sys) return fail(OL_EINVAL, "ol_trace_generate: system is NULL");
   OL_CHECK_CONSISTENT(sys, "ol_trace_generate");
+  if (int rc = refuse_reference_newton("ol_trace_generate", sys)) return rc;
   if (dt != OL_F32 && dt != OL_F64)
     return fail(OL_EINVAL, "ol_trace_generate: bad dtype %d", (int)dt);
   if (!p || !in) return fail(OL_EINVAL, "ol_trace_generate: NULL argument");
@@ -1183,6 +1257,7 @@ int ol_trace_spot(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_ra
                   void* const hits[3], double* out7, uint32_t* status, void* stream) {
   if (!sys) return fail(OL_EINVAL, "ol_trace_spot: system is NULL");
   OL_CHECK_CONSISTENT(sys, "ol_trace_spot");
+  if (int rc = refuse_reference_newton("ol_trace_spot", sys)) return rc;
   if (dt != OL_F32 && dt != OL_F64) return fail(OL_EINVAL, "ol_trace_spot: bad dtype %d", (int)dt);
   if (!p || !in || !out7) return fail(OL_EINVAL, "ol_trace_spot: NULL argument");
   if (hits && (!hits[0] || !hits[1] || !hits[2]))
@@ -1217,6 +1292,7 @@ int ol_trace_spot_batch(const ol_system* sys, ol_dtype dt, int64_t n_rays, const
                         void* stream) {
   if (!sys) return fail(OL_EINVAL, "ol_trace_spot_batch: system is NULL");
   OL_CHECK_CONSISTENT(sys, "ol_trace_spot_batch");
+  if (int rc = refuse_reference_newton("ol_trace_spot_batch", sys)) return rc;
   if (dt != OL_F32 && dt != OL_F64)
     return fail(OL_EINVAL, "ol_trace_spot_batch: bad dtype %d", (int)dt);
   if (!p || !in || !out8 || (n_cells > 0 && !cells))
@@ -1387,6 +1463,7 @@ int ol_trace_opd(const ol_system* sys, ol_dtype dt, int64_t n_rays, const ol_ray
                  void* const pupil[3], double* moments12, uint32_t* status, void* stream) {
   if (!sys) return fail(OL_EINVAL, "ol_trace_opd: system is NULL");
   OL_CHECK_CONSISTENT(sys, "ol_trace_opd");
+  if (int rc = refuse_reference_newton("ol_trace_opd", sys)) return rc;
   if (dt != OL_F64)
     return fail(dt == OL_F32 ? OL_EUNSUPPORTED : OL_EINVAL,
                 "ol_trace_opd: wavefront work is fp64 only (dtype %d)", (int)dt);
@@ -1427,6 +1504,7 @@ static int opd_common_checks(const char* who, const ol_system* sys, ol_dtype dt,
   if (wavelength_index < 0 || wavelength_index >= sys->n_wl)
     return fail(OL_EINVAL, "%s: wavelength index %d outside [0, %d)", who, wavelength_index,
                 sys->n_wl);
+  if (int rc = refuse_reference_newton(who, sys)) return rc;
   for (int32_t s = 0; s < sys->n_surf; ++s)
     if (sys->coating[s] >= OL_COAT_FRESNEL)
       return fail(OL_EINVAL,

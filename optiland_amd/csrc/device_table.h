@@ -103,6 +103,16 @@ enum : int {
   kCoatNone = 0, kCoatSimple = 1, kCoatFresnel = 2, kCoatPolarizer = 3, kCoatRetarder = 4
 };
 
+// Newton-Raphson kernel families (template parameter NR of surface_step and of the kernels;
+// surface_math.h: nr_eval)
+constexpr int kNrNone = 0;       // conic-only range: no Newton code at all (lean kernel)
+constexpr int kNrGeneric = 1;    // every functor
+constexpr int kNrCompact = 2;    // every functor + wavefront straggler compaction (RPT > 1)
+constexpr int kNrZernike = 3;    // Zernike surfaces only (level form and one-polynomial form)
+constexpr int kNrEvenAsphere = 4;  // even aspheres only
+constexpr int kNrReference = 5;  // every functor + the reference's batch-global stop rule
+                                 // (OL_SURF_REFERENCE_NEWTON, opt-in: newton_reference)
+
 constexpr uint32_t kSurfRotated = 0x1u;     // this surface's own frame is rotated
 constexpr uint32_t kSurfRelRotated = 0x2u;  // transform from the previous frame rotates
 constexpr uint32_t kSurfRadiusInf = 0x4u;   // |R| = inf (standard.py:108-111 branch)

@@ -36,6 +36,11 @@ OL_DEV float exp(float x) { return ::expf(x); }
 OL_DEV int float_bits(float x) { int i; __builtin_memcpy(&i, &x, 4); return i; }
 OL_DEV long long double_bits(double x) { long long i; __builtin_memcpy(&i, &x, 8); return i; }
 OL_DEV bool wave_any(bool v) { return v; }  // a "wave" of one ray
+OL_DEV int wave_max(int v) { return v; }
+OL_DEV bool wave_leader() { return true; }
+OL_DEV void atomic_max_i32(int32_t* p, int32_t v) { if (v > *p) *p = v; }
+OL_DEV void atomic_or_i32(int32_t* p, int32_t v) { *p |= v; }
+OL_DEV int32_t load_i32(const int32_t* p) { return *p; }
 #else
 OL_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 OL_DEV float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -142,6 +147,25 @@ OL_DEV float exp(float x) { return __expf(x); }
 OL_DEV int float_bits(float x) { return __float_as_int(x); }
 OL_DEV long long double_bits(double x) { return __double_as_longlong(x); }
 OL_DEV bool wave_any(bool v) { return __any(v) != 0; }
+// (the reference-Newton launches only: maximum over the ACTIVE lanes of the wave, one lane of
+// them, and the two atomics their per-surface words take)
+OL_DEV int wave_max(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(v, off, 64);  // (a disabled source lane reads as 0; v >= 0)
+    v = o > v ? o : v;
+  }
+  return v;
+}
+OL_DEV bool wave_leader() {
+  const uint64_t m = __ballot(true);
+  return (int)__lane_id() == __builtin_ctzll(m);
+}
+OL_DEV void atomic_max_i32(int32_t* p, int32_t v) {
+  if (v > __atomic_load_n(p, __ATOMIC_RELAXED)) atomicMax(p, v);
+}
+OL_DEV void atomic_or_i32(int32_t* p, int32_t v) { atomicOr(p, v); }
+OL_DEV int32_t load_i32(const int32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 #endif
 }  // namespace hw
 
@@ -1032,11 +1056,7 @@ OL_DEV void toroidal_eval(const DevSurf<T>& s, cptr<T> c, T x,
 // the nine-way dispatch, BEFORE any Newton arithmetic (profiles/r02_nr_kernel_overhead.txt).
 // A traced range whose Newton surfaces all belong to one family runs an instantiation with
 // that family's functors only (capi.hip:newton_family picks it per launch).
-constexpr int kNrNone = 0;       // conic-only range: no Newton code at all (lean kernel)
-constexpr int kNrGeneric = 1;    // every functor
-constexpr int kNrCompact = 2;    // every functor + wavefront straggler compaction (RPT > 1)
-constexpr int kNrZernike = 3;    // Zernike surfaces only (level form and one-polynomial form)
-constexpr int kNrEvenAsphere = 4;  // even aspheres only
+// (the constants kNrNone ... kNrReference: device_table.h -- the launchers' callers name them)
 
 template <int NR = kNrGeneric, typename T>
 OL_DEV void nr_eval(const DevSurf<T>& s, cptr<T> c, T x, T y,
@@ -1116,6 +1136,86 @@ OL_DEV void newton_iterate(const DevSurf<T>& s, cptr<T> c,
   q.gx = fx;
   q.gy = fy;
   q.active = !done;
+}
+
+// OL_SURF_REFERENCE_NEWTON (opt-in, ABI 11; kernel family kNrReference): the reference's OWN
+// stop rule, for users who need its NUMBERS rather than the converged intersection.
+// newton_raphson.py:137-166 iterates the WHOLE batch in lockstep,
+//     for _ in range(max_iter):  f = sag(P + t D) - z;  if max_j |f_j| < tol: break;  t -= f / f'
+// so every ray of a trace call takes the SAME number K of updates: the first k at which all rays
+// are below tol, or max_iter -- also when any ray of the batch is NaN (be.max of an array with a
+// NaN is NaN, `NaN < tol` is False: a reference quirk, kept).  The surface normal is then
+// evaluated at the end point (standard_surface.py: `surface_normal(rays)` after the propagation),
+// not at the point of the last evaluation.  With the factory tolerance (1e-6) the per-ray rule
+// above lands within 1e-7 of this; with a user-set loose tolerance, or in what OPD / PSF
+// consumers make of 1e-7, the difference shows.
+// K is a property of the batch, so it is found by launches of its own (ol_newton_count): the
+// launch that has `count_at == surface` runs every ray to ITS first k with |f_k| < tol (NaN or
+// never: max_iter) and takes the maximum over the batch into iters[surface] -- a lower bound of
+// K that is K itself unless a ray that was below tol is above it again later (rounding noise of
+// the order of tol); every other launch takes exactly iters[surface] updates and, when that is
+// less than max_iter, checks the rule at the end point: a ray that is NOT below tol there raises
+// iters[n_surf + surface], and the host moves K up by one and asks again (engine.py).
+struct NrRefCtl {
+  int32_t* iters;    // [2 * n_surf]: K per surface, then the "rule violated at K" words
+  int32_t surface;   // the surface being traced
+  int32_t n_surf;
+  int32_t count_at;  // the surface whose K this launch determines, or -1
+};
+
+template <typename T>
+OL_DEV void newton_reference(const DevSurf<T>& s, cptr<T> c, const NrRefCtl& ctl, T t0,
+                             Ray<T>& r, T& t, T& gx, T& gy, uint32_t& status) {
+  using m = Math<T>;
+  const T L = r.L, M = r.M, N = r.N;
+  const T xb = m::fma(t0, L, r.x), yb = m::fma(t0, M, r.y), zb = m::fma(t0, N, r.z);
+  const T tol = s.cold->tol;
+  const int max_iter = s.max_iter;
+  const bool counting = ctl.surface == ctl.count_at;
+  int K = max_iter;
+  if (!counting) {
+    K = hw::load_i32(ctl.iters + ctl.surface);
+    K = K < 0 ? 0 : (K > max_iter ? max_iter : K);
+  }
+  T dt = T(0), sag, fx, fy;
+  int mine = max_iter;  // counting: this ray's first k with |f_k| < tol
+  bool active = true;
+  for (int it = 0; it < K; ++it) {
+    if (counting && !hw::wave_any(active)) break;
+    if (active) {
+      const T xi = m::fma(dt, L, xb), yi = m::fma(dt, M, yb), zi = m::fma(dt, N, zb);
+      nr_eval<kNrReference>(s, c, xi, yi, sag, fx, fy, status);
+      const T f = sag - zi;
+      if (counting) {
+        if (m::abs(f) < tol) {
+          mine = it;       // the batch may stop here as far as this ray is concerned
+          active = false;
+        } else if (f != f) {
+          active = false;  // NaN now, NaN for good: the batch runs to max_iter
+        }
+      }
+      if (active) {
+        const T df = m::fma(fx, L, m::fma(fy, M, -N));
+        const T dfs = m::abs(df) > m::guard() ? df : m::guard();
+        dt = dt - m::div(f, dfs);
+      }
+    }
+  }
+  if (counting) {
+    const int all = hw::wave_max(mine);
+    if (hw::wave_leader()) hw::atomic_max_i32(ctl.iters + ctl.surface, all);
+  }
+  r.x = m::fma(dt, L, xb);
+  r.y = m::fma(dt, M, yb);
+  r.z = m::fma(dt, N, zb);
+  t = t0 + dt;
+  // the normal at the END point -- and, for a K below max_iter, the rule that stopped the batch
+  nr_eval<kNrReference>(s, c, r.x, r.y, sag, gx, gy, status);
+  if (!counting && K < max_iter) {
+    const bool bad = !(m::abs(sag - r.z) < tol);
+    if (hw::wave_any(bad) && hw::wave_leader())
+      hw::atomic_or_i32(ctl.iters + ctl.n_surf + ctl.surface, 1);
+  }
 }
 
 // Wavefront straggler compaction (RPT > 1).  After the common iterations most
@@ -1754,10 +1854,11 @@ template <typename V, int RPT, int POLK, int NR, bool SHARE = false, typename H>
 OL_DEV void surface_step(const H& h, cptr<typename Math<V>::scalar> coeffs, bool from_global,
                          Ray<V> (&r)[RPT],
                          Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
-                         uint32_t& status, bool& prt_fresh) {
+                         uint32_t& status, bool& prt_fresh, const NrRefCtl* ref = nullptr) {
   using m = Math<V>;
   using T = typename m::scalar;
   static_assert(NR == 0 || m::lanes == 1, "the Newton-Raphson path is scalar");
+  static_assert(NR != kNrReference || RPT == 1, "reference-Newton launches: one ray per lane");
   {
     const DevSurf<T> s = h.surf();
     into_local_frame<V, RPT>(s, from_global, r);
@@ -1811,6 +1912,16 @@ OL_DEV void surface_step(const H& h, cptr<typename Math<V>::scalar> coeffs, bool
         conic_normal<V>(cv, kp1, r[k].x, r[k].y, r[k].z, nx[k], ny[k], nz[k]);
       }
     }
+  } else if constexpr (NR == kNrReference) {
+    const DevSurf<T> s = h.surf();
+    cptr<T> c = coeffs + s.coeff_off;
+    T gx, gy;
+    const T t0 = conic_distance<T, SHARE>(s, r[0].x, r[0].y, r[0].z, r[0].L, r[0].M, r[0].N);
+    newton_reference<T>(s, c, *ref, t0, r[0], t[0], gx, gy, status);
+    const T im = m::rsqrt(m::fma(gx, gx, m::fma(gy, gy, T(1))));
+    nx[0] = gx * im;
+    ny[0] = gy * im;
+    nz[0] = -im;
   } else if constexpr (NR != 0) {
     constexpr bool COMPACT = NR == kNrCompact;
     NewtonRay<T> q[RPT];
@@ -1915,9 +2026,9 @@ OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
                          cptr<typename Math<V>::scalar> coeffs, bool from_global,
                          Ray<V> (&r)[RPT],
                          Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
-                         uint32_t& status, bool& prt_fresh) {
+                         uint32_t& status, bool& prt_fresh, const NrRefCtl* ref = nullptr) {
   const SurfLoaded<typename Math<V>::scalar> h{s, o};
-  surface_step<V, RPT, POLK, NR, SHARE>(h, coeffs, from_global, r, P, status, prt_fresh);
+  surface_step<V, RPT, POLK, NR, SHARE>(h, coeffs, from_global, r, P, status, prt_fresh, ref);
 }
 
 // local -> global for the recorded state (coordinate_system.py:91-107)

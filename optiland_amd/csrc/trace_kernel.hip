@@ -427,7 +427,7 @@ template <typename T, int RPT, int POLK, int NR, bool GEN = false>  // GEN: any 
 struct WavesPerEu {
   static constexpr int value =
       (OL_POLNR_WAVES > 0 && sizeof(T) == 4 && RPT == 1 && POLK == 1 && NR != 0 &&
-       !(GEN && NR == 1))
+       NR != kNrReference && !(GEN && NR == 1))
           ? OL_POLNR_WAVES
           : ((OL_POLNR_WAVES_F64 > 0 && sizeof(T) == 8 && RPT == 1 && POLK == 1 && NR != 0)
                  ? OL_POLNR_WAVES_F64
@@ -681,8 +681,15 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
     if constexpr (kFetch) {
       const SurfFetched<T> h = fetched_surface<T, TraceArgs<T>>(s);
       if (refresh(h.hot)->interaction != kRecordOnly) {
-        surface_step<V, NV, POLK, NR, kShareRcp>(h, refresh(coeffs_c), is_global, r, P, status,
-                                               prt_fresh);
+        if constexpr (NR == kNrReference) {
+          const auto ka = kernargs<T, TraceArgs<T>>();
+          const NrRefCtl ctl{ka->a.nr_iters, s, ka->a.n_surf, ka->a.nr_count_at};
+          surface_step<V, NV, POLK, NR, kShareRcp>(h, refresh(coeffs_c), is_global, r, P, status,
+                                                 prt_fresh, &ctl);
+        } else {
+          surface_step<V, NV, POLK, NR, kShareRcp>(h, refresh(coeffs_c), is_global, r, P, status,
+                                                 prt_fresh);
+        }
         is_global = false;
         last_idx = s;
       }
@@ -706,8 +713,14 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
 #else
         const DevOptics<T> O = optics_tab[s * a.n_wl + a.wl];
 #endif
-        surface_step<V, NV, POLK, NR, kShareRcp>(S, O, coeffs_c, is_global, r, P, status,
-                                               prt_fresh);
+        if constexpr (NR == kNrReference) {
+          const NrRefCtl ctl{a.nr_iters, s, a.n_surf, a.nr_count_at};
+          surface_step<V, NV, POLK, NR, kShareRcp>(S, O, coeffs_c, is_global, r, P, status,
+                                                 prt_fresh, &ctl);
+        } else {
+          surface_step<V, NV, POLK, NR, kShareRcp>(S, O, coeffs_c, is_global, r, P, status,
+                                                 prt_fresh);
+        }
         is_global = false;
         last_traced = S;
       }
@@ -924,9 +937,11 @@ static hipError_t launch_nr(const TraceArgs<T>& a, hipStream_t stream) {
 #define OL_LAUNCH(R, P) OL_LAUNCH_S(R, P, false)
   if (a.spot != nullptr) {
     // the spot epilogue exists for unpolarised traces (the polarised intensity needs
-    // the update_intensity epilogue first)
-    if (polk != 0) return hipErrorInvalidValue;
-    if (rec) OL_LAUNCH_S(true, 0, true); else OL_LAUNCH_S(false, 0, true);
+    // the update_intensity epilogue first); not on reference-Newton ranges (capi.hip refuses)
+    if (polk != 0 || NR == kNrReference) return hipErrorInvalidValue;
+    if constexpr (NR != kNrReference) {
+      if (rec) OL_LAUNCH_S(true, 0, true); else OL_LAUNCH_S(false, 0, true);
+    }
     return hipGetLastError();
   }
   if (polk == 2) {
@@ -956,6 +971,9 @@ static hipError_t launch_rpt(const TraceArgs<T>& a, int nr, hipStream_t stream) 
       if (nr == kNrZernike) return launch_nr<T, 1, kNrZernike>(a, stream);
       if (nr == kNrEvenAsphere) return launch_nr<T, 1, kNrEvenAsphere>(a, stream);
     }
+    // the reference's batch-global Newton stop rule (opt-in): its own instantiations, so that
+    // every other kernel is what it was
+    if (nr == kNrReference) return launch_nr<T, 1, kNrReference>(a, stream);
   }
   return launch_nr<T, RPT, 1>(a, stream);
 }
@@ -1051,6 +1069,9 @@ template <typename T>
 hipError_t launch_trace_generate(const TraceArgs<T>& a_in, int nr_family, bool pair_ok,
                                  hipStream_t stream) {
   TraceArgs<T> a = a_in;
+  // (reference-Newton ranges generate and trace in two launches: the counting launches of
+  // ol_newton_count read the generated rays)
+  if (nr_family == kNrReference) return hipErrorInvalidValue;
   if (nr_family == kNrNone) return launch_gen_nr<T, 0>(a, pair_ok, stream);
   if (nr_family == kNrZernike) return launch_gen_nr<T, kNrZernike>(a, false, stream);
   if (nr_family == kNrEvenAsphere) return launch_gen_nr<T, kNrEvenAsphere>(a, false, stream);
@@ -1080,6 +1101,10 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool vector_ok, int nr_family,
   const int nr = nr_family == kNrNone
                      ? kNrNone
                      : ((a.flags & kTraceCompact) && tuning().compact ? kNrCompact : nr_family);
+  if (nr_family == kNrReference) {
+    if (a.nr_iters == nullptr) return hipErrorInvalidValue;
+    return launch_rpt<T, 1>(a, kNrReference, stream);
+  }
   if (!vector_ok || (a.prt && (a.flags & kTracePrtComplex)))
     return launch_rpt<T, 1>(a, nr == 2 ? 1 : nr, stream);
   // Defaults from interleaved A/B runs on MI355X (tools/ab_bench.py):

@@ -161,6 +161,12 @@ struct TraceArgs {
   // kernel (ol_trace_extras.updated_intensity, ABI 7); nullptr = none
   T* i_updated;
   PolFields<T> pf;
+  // reference-Newton launches (ABI 11, nr_family == kNrReference; surface_math.h NrRefCtl):
+  // the per-surface iteration counts (device, [2 * n_surf]) and the surface whose count THIS
+  // launch determines (-1: none)
+  int32_t* nr_iters;
+  int32_t nr_count_at;
+  int32_t n_surf;
 };
 
 // nr_family: 0 = no Newton-Raphson geometry in the traced range (lean kernel), 1 = generic

@@ -605,9 +605,9 @@ class HipSystem:
             if prt_identity:  # write-only PRT: starts from I inside the kernel
                 flags |= S.TRACE_PRT_IDENTITY
         ptrs = (C.c_void_p * 8)(*[t.data_ptr() for t in rays])
-        extras = None
+        extras = ex = None
         if rec_first != first:
-            extras = C.byref(_capi.TraceExtras(None, 0.0, 0.0, rec_first, 0))
+            ex = _capi.TraceExtras(None, 0.0, 0.0, rec_first, 0)
         if spot is not None:
             if rec_first != first:
                 raise ValueError("spot epilogue and record_first cannot be combined")
@@ -615,7 +615,20 @@ class HipSystem:
             if slots.dtype != torch.float64 or slots.numel() != 8 * _capi.SPOT_SLOTS \
                     or slots.device != self.device or not slots.is_contiguous():
                 raise ValueError("spot slots must come from alloc_spot_slots()")
-            extras = C.byref(_capi.TraceExtras(slots.data_ptr(), float(cx), float(cy), 0, 0))
+            ex = _capi.TraceExtras(slots.data_ptr(), float(cx), float(cy), 0, 0)
+        # opt-in reference stop rule (SURF_REFERENCE_NEWTON): the iteration counts of this batch
+        ref_newton = self.table.reference_newton_surfaces(first, last) if n else []
+        if ref_newton:
+            if spot is not None:
+                raise ValueError("the spot epilogue is not available on a range with "
+                                 "reference-rule Newton surfaces")
+            iters = self._newton_counts(ptrs, _DT[dtype], n, int(wavelength_index), int(first),
+                                        ref_newton)
+            if ex is None:
+                ex = _capi.TraceExtras(None, 0.0, 0.0, 0, 0)
+            ex.newton_iterations = iters.data_ptr()
+        if ex is not None:
+            extras = C.byref(ex)
         if check_status and zero_status:  # zero_status=False: keep bits set by ray generation
             self._status.zero_()
         with self._device_ctx():
@@ -635,12 +648,62 @@ class HipSystem:
         return TraceResult(n, rays, rec, prt, status, rec_first if rec is not None else first,
                            last)
 
+    # ---- reference-rule Newton surfaces (ABI 11; newton_raphson.py:137-166) -----------------
+    # `newton_count_hook(iters)`: called after every counting / verifying launch with the
+    # (2 S,) int32 device tensor -- a batch that is SHARDED over ranks takes the maximum over
+    # its shards there (distributed.py: one small all-reduce), because the reference's count is
+    # a property of the whole batch.
+    newton_count_hook = None
+
+    def _newton_counts(self, ptrs, dt: int, n: int, wl: int, first: int, surfaces):
+        """The (2 S,) int32 device tensor `ol_trace_extras.newton_iterations` of one trace call:
+        for every reference-rule Newton surface of the range, in order, the number K of updates
+        the reference's lockstep loop makes on THIS batch -- the first k at which every ray is
+        below the surface's tolerance, `max_iter` when a ray is NaN or never gets there."""
+        S_ = self.num_surfaces
+        iters = torch.zeros(2 * S_, dtype=torch.int32, device=self.device)
+        hook = self.newton_count_hook
+        stream = self._stream()
+
+        def launch(s, verify):
+            with self._device_ctx():
+                rc = self.lib.ol_newton_count(self._handle, dt, n, ptrs, wl, first, int(s),
+                                              iters.data_ptr(), 1 if verify else 0, stream)
+            self._check(rc, "ol_newton_count")
+            if hook is not None:
+                hook(iters)
+
+        for s in surfaces:
+            launch(s, False)
+        # A ray's first k below the tolerance bounds K from below; it IS K unless a ray that was
+        # below is above again at that k (rounding noise of the order of the tolerance).  One
+        # launch checks the rule at the counts found, for all surfaces at once; the rare repair
+        # moves the first offending count up by one and takes the later ones again.
+        max_iter = self.table.surfaces["max_iter"]
+        while True:
+            launch(surfaces[-1], True)
+            host = iters.cpu().numpy()   # (the one synchronisation of the chain)
+            bad = [s for s in surfaces if host[S_ + s] != 0 and host[s] < int(max_iter[s])]
+            if not bad:
+                return iters
+            s0 = bad[0]
+            iters[s0] += 1
+            later = [s for s in surfaces if s > s0]
+            for s in later:
+                iters[s] = 0
+            iters[S_:] = 0
+            for s in later:
+                launch(s, False)
+
     def can_trace_generate(self, field_planes: bool = False) -> bool:
         """`ol_trace_generate` serves this launch: the table carries generator scalars.  Per-ray
         field planes (`field_planes`) and apodized pupils are one launch too -- unpolarised
-        traces since ABI 8, polarised ones since ABI 10."""
+        traces since ABI 8, polarised ones since ABI 10.  Not with reference-rule Newton
+        surfaces: their counting launches read the generated rays (two launches)."""
         rg = self.table.raygen
         if not rg or not hasattr(self.lib, "ol_trace_generate"):
+            return False
+        if self.table.reference_newton_surfaces():
             return False
         if field_planes or int(rg.get("apod_kind", 0)) != 0:
             return (self.table.polarization is None and not self.table.uses_polarization) \
@@ -1183,6 +1246,13 @@ class HipSystem:
         if check_status:
             self._status.zero_()
         step = _capi.SPOT_BATCH_MAX_CELLS
+        for c in cells:
+            # a cell whose engine has been closed must not silently read THIS system's index
+            # rows (another wavelength's) through a NULL `optics_of`
+            if len(c) > 7 and c[7] is not None and getattr(c[7], "_handle", True) is None:
+                raise _capi.HipExtensionError("trace_spot_batch: a cell's engine is closed")
+        if getattr(self, "_handle", True) is None:
+            raise _capi.HipExtensionError("trace_spot_batch: this engine is closed")
         with self._device_ctx():
             for lo in range(0, k, step):
                 part = cells[lo: lo + step]

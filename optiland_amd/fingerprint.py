@@ -236,7 +236,7 @@ surface_token = _surface_token_native if _NATIVE is not None else _surface_token
 
 def _packing_options():
     from . import system as S
-    return bool(S.OPTIONS["reference_root"])
+    return (bool(S.OPTIONS["reference_root"]), bool(S.OPTIONS["reference_newton"]))
 
 
 def surfaces_token(surfaces, wavelength):

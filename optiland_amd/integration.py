@@ -1248,8 +1248,18 @@ def _set_reference_root(reference_root):
         _S.OPTIONS["reference_root"] = bool(reference_root)
 
 
+def _set_reference_newton(reference_newton):
+    """`reference_newton` of enable() / install(): None = leave as is
+    (OPTILAND_HIP_REFERENCE_NEWTON=1 seeds it); part of the tokens and cache keys like
+    `reference_root`."""
+    if reference_newton is not None:
+        from . import system as _S
+
+        _S.OPTIONS["reference_newton"] = bool(reference_newton)
+
+
 def enable(device=None, force=False, analyses=True, lazy_records=False, placed_records=None,
-           reference_root=None):
+           reference_root=None, reference_newton=None):
     """Route EVERY `Optic` (existing and future) through the HIP path.
 
     Patches `RealRayTracer.trace / trace_generic` (raytrace/real_ray_tracer.py:58-154)
@@ -1290,9 +1300,22 @@ def enable(device=None, force=False, analyses=True, lazy_records=False, placed_r
     is off by up to `eps |b| / |2a|` in the intersection distance, systematically, and its own
     golden `tests/test_operand.py::test_opd_diff_on_axis` (Hubble, on axis) encodes that: it
     passes through the drop-in with this option and misses by 4e-7 waves without it.
+
+    `reference_newton` (default off): Newton-Raphson surfaces (aspheres, polynomials, Zernike,
+    Chebyshev, biconic, toroidal) stop by the reference's OWN rule -- the whole batch of a trace
+    call iterates in lockstep and stops when `max_j |f_j| < tol`, `max_iter` updates when any ray
+    of the batch is NaN, and the normal is taken at the end point
+    (geometries/newton_raphson.py:137-166) -- instead of per ray.  The default converges
+    FURTHER than the reference (its rays are within 1e-7 of the reference's with the factory
+    tolerance); this option gives the reference's numbers, to rounding, also for a user-set
+    loose `tol` / small `max_iter` and in what OPD / PSF consumers make of 1e-7.  Costs one
+    counting launch per Newton surface and one verifying launch per trace call, and the fused
+    analysis kernels stand back for such optics (the reference's own analysis code then runs on
+    top of the drop-in's `Optic.trace`).
     """
     _set_record_pool(placed_records)
     _set_reference_root(reference_root)
+    _set_reference_newton(reference_newton)
     cls = _make_tracer_class()
     from optiland.raytrace.real_ray_tracer import RealRayTracer
 
@@ -1354,12 +1377,13 @@ def disable():
 
 
 def install(optic, device=None, force=False, analyses=True, lazy_records=False,
-            placed_records=None, reference_root=None):
+            placed_records=None, reference_root=None, reference_newton=None):
     """Replace `optic.ray_tracer` with the HIP tracer (keeps the aiming config).  `analyses`,
     `lazy_records`: see `enable()` -- the class-wide analysis seams only act on optics the
     drop-in serves."""
     _set_record_pool(placed_records)
     _set_reference_root(reference_root)
+    _set_reference_newton(reference_newton)
     cls = _make_tracer_class()
     if analyses:
         from . import analysis_seams

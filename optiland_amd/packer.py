@@ -328,6 +328,10 @@ def _pack_surface_local(is_object: bool, surf, wl):
     if getattr(im, "bsdf", None) is not None:
         raise UnsupportedSystem("BSDF scatter is not on the fused path")
     _pack_geometry(geom, row, coeffs)
+    if S.OPTIONS["reference_newton"] and int(row["geom_kind"]) not in (S.GEOM_PLANE,
+                                                                      S.GEOM_STANDARD):
+        # the reference's batch-global stop rule on this Newton-Raphson surface (opt-in)
+        row["flags"] |= S.SURF_REFERENCE_NEWTON
     _pack_aperture(surf.aperture, row, coeffs)
     _pack_coating(surf.coating, row, coeffs)
     if is_object:
@@ -418,7 +422,8 @@ def pack_surfaces(surfaces, wavelengths, name: str = "surfaces",
     surfaces = list(surfaces)
     unsupported: list = []
     wl = np.array([float(w) for w in np.atleast_1d(wavelengths)], dtype=np.float64)
-    wl_key = wl.tobytes() + (b"|reference_root" if S.OPTIONS["reference_root"] else b"")
+    wl_key = wl.tobytes() + (b"|reference_root" if S.OPTIONS["reference_root"] else b"") \
+        + (b"|reference_newton" if S.OPTIONS["reference_newton"] else b"")
     n_s = len(surfaces)
     use_cache = cache is not None and tokens is not None and len(tokens) == n_s
     if use_cache:

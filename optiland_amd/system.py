@@ -33,8 +33,11 @@ AP_OP_UNION, AP_OP_INTERSECTION, AP_OP_DIFFERENCE = 10, 11, 12
 COAT_NONE, COAT_SIMPLE, COAT_FRESNEL, COAT_POLARIZER, COAT_RETARDER = 0, 1, 2, 3, 4
 SURF_ROTATED = 0x1
 SURF_REFERENCE_ROOT = 0x2   # OL_SURF_REFERENCE_ROOT
-# packing options (process-wide; `integration.enable(reference_root=...)` sets them)
-OPTIONS = {"reference_root": os.environ.get("OPTILAND_HIP_REFERENCE_ROOT", "0") == "1"}
+SURF_REFERENCE_NEWTON = 0x4  # OL_SURF_REFERENCE_NEWTON
+# packing options (process-wide; `integration.enable(reference_root=..., reference_newton=...)`
+# sets them)
+OPTIONS = {"reference_root": os.environ.get("OPTILAND_HIP_REFERENCE_ROOT", "0") == "1",
+           "reference_newton": os.environ.get("OPTILAND_HIP_REFERENCE_NEWTON", "0") == "1"}
 
 STATUS_ZERNIKE_RANGE = 0x1
 STATUS_K_PARALLEL_X = 0x2
@@ -173,6 +176,23 @@ class SystemTable:
     def needs_complex_prt(self) -> bool:
         """Retarder coatings have a complex Jones matrix (jones.py:331-393)."""
         return bool(np.any(self.surfaces["coating_kind"] == COAT_RETARDER))
+
+    def reference_newton_surfaces(self, first: int = 0, last: int | None = None) -> list:
+        """Traced Newton-Raphson surfaces of [first, last] that carry SURF_REFERENCE_NEWTON (the
+        reference's batch-global stop rule, newton_raphson.py:137-166): their iteration count is
+        a property of the batch (`HipSystem._newton_counts`)."""
+        memo = self.__dict__.get("_ref_newton")
+        if memo is None:
+            s = self.surfaces
+            memo = self.__dict__["_ref_newton"] = [
+                int(i) for i in np.nonzero((s["flags"] & SURF_REFERENCE_NEWTON != 0)
+                                           & (s["geom_kind"] != GEOM_PLANE)
+                                           & (s["geom_kind"] != GEOM_STANDARD)
+                                           & (s["interaction"] != INTERACT_RECORD_ONLY))[0]]
+        if not memo:
+            return memo
+        last = self.num_surfaces - 1 if last is None else last
+        return [i for i in memo if first <= i <= last]
 
     def wavelength_index(self, wavelength: float) -> int:
         """Index of `wavelength` in the table (exact match on the packed value)."""

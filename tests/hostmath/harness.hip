@@ -139,7 +139,12 @@ void trace_one(const TraceArgs<T>& a, int64_t i, uint32_t& status) {
         // the Newton kernels hand surface_step table POINTERS and every phase re-reads its
         // fields (SurfFetched, device_table.h) -- same handle here
         const SurfFetched<T> h{a.surf + s, a.cold + s, a.optics + (s * a.n_wl + a.wl)};
-        surface_step<T, 1, POLK, NR>(h, a.coeffs, is_global, r, P, status, prt_fresh);
+        if constexpr (NR == kNrReference) {  // (trace_kernel: the batch's iteration counts)
+          const NrRefCtl ctl{a.nr_iters, s, a.n_surf, a.nr_count_at};
+          surface_step<T, 1, POLK, NR>(h, a.coeffs, is_global, r, P, status, prt_fresh, &ctl);
+        } else {
+          surface_step<T, 1, POLK, NR>(h, a.coeffs, is_global, r, P, status, prt_fresh);
+        }
       } else {
         const DevOptics<T> O = a.optics[s * a.n_wl + a.wl];
         surface_step<T, 1, POLK, NR>(S, O, a.coeffs, is_global, r, P, status, prt_fresh);
@@ -248,6 +253,9 @@ hipError_t launch_trace(const TraceArgs<T>& a, bool, int nr_family, hipStream_t)
     case kNrNone: return trace_nr<T, kNrNone>(a);
     case kNrZernike: return trace_nr<T, kNrZernike>(a);
     case kNrEvenAsphere: return trace_nr<T, kNrEvenAsphere>(a);
+    case kNrReference:
+      if (a.nr_iters == nullptr) return hipErrorInvalidValue;
+      return trace_nr<T, kNrReference>(a);
     default: return trace_nr<T, kNrGeneric>(a);
   }
 }
@@ -322,6 +330,7 @@ hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, bool pair
     case kNrNone: return gen_nr<T, kNrNone>(a, pair_ok);
     case kNrZernike: return gen_nr<T, kNrZernike>(a, false);
     case kNrEvenAsphere: return gen_nr<T, kNrEvenAsphere>(a, false);
+    case kNrReference: return hipErrorInvalidValue;  // (as the device launcher)
     default: return gen_nr<T, kNrGeneric>(a, false);
   }
 }

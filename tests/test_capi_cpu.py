@@ -41,7 +41,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.ol_abi_version() == _capi.ABI_VERSION == 10
+    assert lib.ol_abi_version() == _capi.ABI_VERSION == 11
 
 
 def test_struct_layouts_agree_with_the_c_compiler():

@@ -558,3 +558,120 @@ def test_spot_seams_on_a_polarised_optic_and_a_tilted_image_surface_on_device(be
                     np.testing.assert_allclose(i, iw, rtol=tol, atol=tol)
     finally:
         _off(be)
+
+
+# ---------------------------------------------------------------------------------------
+# round 6: the reference's own Newton stop rule on the device; every sample lens on the device
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tol,max_iter", [(1e-2, 1), (1e-3, 2), (None, None)])
+@pytest.mark.parametrize("name", ["AsphericSinglet", "ZernikeFresnelPolarized"])
+def test_reference_newton_rule_on_device(be, name, tol, max_iter):
+    """`enable(reference_newton=True)` (OL_SURF_REFERENCE_NEWTON, ABI 11): the batch-global
+    iteration count of newton_raphson.py:137-166 found by `ol_newton_count` launches on the
+    MI355X -- the reference's NUMBERS to 1e-12 where the per-ray default is up to 2e-3 away
+    (loose tolerance) -- through `Optic.trace` and through the `SurfaceGroup.trace` seam."""
+    from optiland_amd import integration
+
+    def build():
+        if name == "AsphericSinglet":
+            from optiland.samples.simple import AsphericSinglet
+            lens = AsphericSinglet()
+            lens.fields.add(y=8.0)
+        else:
+            lens = _live.zernike_fresnel("elliptical")
+        for s in lens.surfaces.surfaces:
+            g = s.geometry
+            if hasattr(g, "max_iter") and tol is not None:
+                g.tol, g.max_iter = tol, max_iter
+        return lens
+
+    def call(be, lens):
+        return _capture(be, lens, lens.trace(0.0, 1.0, 0.55, 12, "hexapolar"))
+
+    be.set_backend("numpy")
+    want = call(be, build())
+    results = {}
+    for option in (True, False):
+        be.set_backend("torch")
+        be.set_device("cuda")
+        be.set_precision("float64")
+        try:
+            lens = build()
+            comp = integration.install(lens, reference_newton=option)
+            results[option] = call(be, lens)
+            assert comp.last_path == "hip"
+        finally:
+            integration._set_reference_newton(False)
+            integration.disable()
+            be.set_device("cpu")
+            be.set_backend("numpy")
+    _compare(results[True], want, 1e-12, f"{name} reference Newton rule tol={tol}")
+    if tol is not None and name == "AsphericSinglet":
+        # (the case must be one where the two rules differ, or the test shows nothing)
+        diff = np.nanmax(np.abs(results[False]["surf"] - want["surf"]))
+        assert diff > 1e-7, diff
+    else:
+        _compare(results[False], want, 1e-6, f"{name} per-ray rule tol={tol}")
+
+
+def _sample_classes():
+    """Every Optic subclass defined in a module of `optiland.samples`."""
+    import importlib
+    import inspect
+    import pkgutil
+
+    import optiland.samples
+    from optiland.optic import Optic
+    out = []
+    for m in sorted(pkgutil.iter_modules(optiland.samples.__path__), key=lambda m: m.name):
+        mod = importlib.import_module(f"optiland.samples.{m.name}")
+        for cname, cls in sorted(vars(mod).items()):
+            if inspect.isclass(cls) and issubclass(cls, Optic) and cls.__module__ == mod.__name__:
+                out.append((f"{m.name}.{cname}", cls))
+    return out
+
+
+def test_every_sample_lens_through_the_live_drop_in_on_device(be):
+    """Every class of `optiland.samples` x every field x every wavelength, hexapolar pupil,
+    through `integration.install` on the MI355X against the NumPy backend in the same process
+    (blind spot 9: the sample goldens go through packed tables, not through the
+    live drop-in on the device)."""
+    from optiland_amd import integration
+    classes = _sample_classes()
+    assert len(classes) >= 25, len(classes)
+    worst, served = {}, {}
+    for label, cls in classes:
+        be.set_backend("numpy")
+        ref_lens = cls()
+        cells = [(fx, fy, float(w.value)) for fx, fy in ref_lens.fields.get_field_coords()
+                 for w in ref_lens.wavelengths.wavelengths]
+        wants = []
+        for hx, hy, w in cells:
+            wants.append(_capture(be, ref_lens, ref_lens.trace(hx, hy, w, 6, "hexapolar")))
+        be.set_backend("torch")
+        be.set_device("cuda")
+        be.set_precision("float64")
+        try:
+            lens = cls()
+            comp = integration.install(lens)
+            for (hx, hy, w), want in zip(cells, wants):
+                got = _capture(be, lens, lens.trace(hx, hy, w, 6, "hexapolar"))
+                served.setdefault(label, set()).add(comp.last_path)
+                nan_w = np.isnan(want["surf"])
+                assert np.array_equal(np.isnan(got["surf"]), nan_w), (label, hx, hy, w)
+                scale = max(1.0, np.nanmax(np.abs(want["surf"][:, :3]), initial=0.0))
+                d = np.abs(got["surf"] - want["surf"])
+                d[:, :3] /= scale
+                d[:, 7] /= scale
+                worst[label] = max(worst.get(label, 0.0), float(np.nanmax(d, initial=0.0)))
+        finally:
+            integration.disable()
+            be.set_precision("float64")
+            be.set_device("cpu")
+            be.set_backend("numpy")
+    bad = {k: v for k, v in worst.items() if v > 1e-6}
+    assert not bad, bad
+    # the drop-in -- not the reference's torch ops -- served them: the fused launch, or (wide-angle
+    # lenses: the reference's iterative aimer makes the rays) the SurfaceGroup.trace seam
+    assert all(p <= {"hip", "reference-rays"} for p in served.values()), served
+    assert sum("hip" in p for p in served.values()) >= len(classes) - 6, served
