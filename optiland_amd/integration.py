@@ -901,7 +901,9 @@ def _make_tracer_class():
         def trace_generic(self, Hx, Hy, Px, Py, wavelength):
             def original():
                 return _ORIGINALS["trace_generic"](self, Hx, Hy, Px, Py, wavelength)
-            if not self._eligible():
+            if not self._eligible() or _tracer.coordinates_unlike_the_reference(Hx, Hy, Px, Py):
+                # (lists, tuples, 2-D arrays: the reference's own method raises what the
+                # reference raises -- real_ray_tracer.py:120-194)
                 self.last_path = "reference"
                 return original()
             args = [_host_or_device(v) for v in (Hx, Hy, Px, Py)]
@@ -988,9 +990,12 @@ def _sg_planes(rays, force: bool):
     if any(not isinstance(t, torch.Tensor) for t in planes):
         return None
     dtype, dev, n = planes[0].dtype, planes[0].device, planes[0].numel()
+    # (one-dimensional planes of ONE length: a bundle whose planes disagree in shape -- what
+    # `trace_generic` builds from 2-D coordinate arrays, (3,3) intensities next to (9,)
+    # positions -- fails to broadcast in the reference's loop, and that loop is who says so)
     if dtype not in (torch.float32, torch.float64) or n == 0 \
-            or any(t.dtype != dtype or t.device != dev or t.numel() != n or t.requires_grad
-                   for t in planes):
+            or any(t.dtype != dtype or t.device != dev or t.ndim != 1 or t.numel() != n
+                   or t.requires_grad for t in planes):
         return None
     if not force and dev.type != "cuda":
         return None

@@ -131,6 +131,37 @@ def _size_mismatch_message(nhx, nhy, npx, npy):
     return None
 
 
+def coordinates_unlike_the_reference(*coords) -> bool:
+    """True when `trace_generic` of the reference does NOT accept these coordinate arguments
+    (real_ray_tracer.py:120-194): a Python list / tuple dies in `x >= -1` of
+    `_validate_normalized_coordinates` (:168-169, TypeError); an array of two or more dimensions
+    passes `_validate_array_size` untouched (:186-194) and fails to broadcast against the
+    flattened planes of the ray generator (ValueError) -- unless it is a single row."""
+    for v in coords:
+        if isinstance(v, (list, tuple)):
+            return True
+        shape = getattr(v, "shape", None)
+        if shape is not None and len(shape) >= 2:
+            return True
+    return False
+
+
+def _reject_unlike_the_reference(*coords):
+    """The standalone tracer's form of the above: the exceptions of the reference's NumPy
+    backend, same type and text (the live drop-in hands such calls to the reference's own
+    method instead, integration.py)."""
+    for v in coords:
+        if isinstance(v, (list, tuple)):
+            raise TypeError(f"'>=' not supported between instances of '{type(v).__name__}' "
+                            "and 'int'")
+    for v in coords:
+        shape = tuple(getattr(v, "shape", ()) or ())
+        if len(shape) >= 2 and not (len(shape) == 2 and shape[0] == 1):
+            dims = ",".join(str(int(k)) for k in shape)
+            raise ValueError(f"operands could not be broadcast together with shapes ({dims}) "
+                             f"({int(np.prod(shape))},) ")
+
+
 def _can_field_planes(can) -> bool:
     try:
         return bool(can(field_planes=True))
@@ -521,6 +552,7 @@ class HipRayTracer:
         """real_ray_tracer.py:120-154: caller-supplied per-ray coordinates; the
         pupil is pre-scaled by (1 - v) (:134-137, `OL_RAYGEN_PRESCALE_PUPIL`) and the
         polarised update_intensity epilogue is NOT applied."""
+        _reject_unlike_the_reference(Hx, Hy, Px, Py)
         self._validate_normalized_coordinates(Hx, Hy, "field")
         self._validate_normalized_coordinates(Px, Py, "pupil")
         sx, sy = self._as_scalar(Hx), self._as_scalar(Hy)

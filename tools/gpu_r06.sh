@@ -1,0 +1,125 @@
+#!/bin/bash
+# Round 6: ONE parameterised runner for the GPU box (`gpurun -- 'bash tools/gpu_r06.sh <leg> ...'`).
+# Every leg writes under gpurun_out/; what is judged is copied to profiles/ afterwards.
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; O=$R/gpurun_out; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+for leg in "$@"; do
+  echo "=== leg $leg ($(date +%T))"
+  case $leg in
+    regions)   # the map behind fast record blocks (tools/microbench/vmm_regions.hip)
+      timeout 420 tools/microbench/vmm_regions ${REGION_GIB:-240} > $O/r06_vmm_regions.txt 2>&1; echo "rc=$?" >> $O/r06_vmm_regions.txt
+      tail -5 $O/r06_vmm_regions.txt ;;
+    pairs)     # which two half-block pieces make a fast block (tools/microbench/vmm_pairs.hip)
+      timeout 420 tools/microbench/vmm_pairs ${PAIRS_GIB:-230} > $O/r06_vmm_pairs.txt 2>&1; echo "rc=$?" >> $O/r06_vmm_pairs.txt
+      tail -12 $O/r06_vmm_pairs.txt ;;
+    junctions) # the smallest arena whose junction makes a fast block (tools/microbench/vmm_junctions.hip)
+      timeout 300 tools/microbench/vmm_junctions > $O/r06_vmm_junctions.txt 2>&1; echo "rc=$?" >> $O/r06_vmm_junctions.txt
+      cat $O/r06_vmm_junctions.txt | cut -c1-400 ;;
+    split)     # a displacement between two groups of planes inside ONE allocation
+      timeout 300 tools/microbench/split_offset > $O/r06_split_offset.txt 2>&1; echo "rc=$?" >> $O/r06_split_offset.txt
+      grep -c . $O/r06_split_offset.txt ;;
+    pace)      # evenly paced stores against rows of 8 back to back (tools/microbench/pace_probe.hip)
+      timeout 300 tools/microbench/pace_probe > $O/r06_pace_probe.txt 2>&1; cat $O/r06_pace_probe.txt ;;
+    lottery)   # how often a junction of two pieces makes a fast block, by the pieces' sizes
+      timeout 600 tools/microbench/vmm_lottery ${LOTTERY_REPS:-6} > $O/r06_vmm_lottery.txt 2>&1; cat $O/r06_vmm_lottery.txt ;;
+    debugfs)   # can the box show where a buffer lies physically?
+      (mount -t debugfs none /sys/kernel/debug 2>&1; ls /sys/kernel/debug/dri/ 2>&1 | head; ls /sys/class/kfd/kfd/topology/nodes/ 2>&1;
+       cat /sys/module/amdgpu/version 2>&1; uname -r; cat /sys/class/drm/card*/device/mem_info_vram_total 2>&1 | head -3;
+       ls /sys/class/drm/card*/device/ 2>&1 | tr '\n' ' ' | head -c 3000; echo;
+       cat /sys/class/drm/card*/device/current_memory_partition /sys/class/drm/card*/device/current_compute_partition 2>&1 | head) > $O/r06_debugfs.txt 2>&1
+      head -40 $O/r06_debugfs.txt ;;
+    suite)     # the whole -m gpu suite (RCCL test included when OPTILAND_TEST_RCCL=1)
+      timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/r06_suite_${TAG:-0}.log 2>&1
+      echo "rc=$?" >> $O/r06_suite_${TAG:-0}.log; tail -4 $O/r06_suite_${TAG:-0}.log ;;
+    rccl_in_suite)  # the suite with the RCCL test on, the worker's phase stamps + stacks logged
+      export OPTILAND_TEST_RCCL=1 OPTILAND_TEST_RCCL_WAIT=${RCCL_WAIT:-150}
+      export OPTILAND_RCCL_WORKER_LOG=$O/r06_rccl_worker_${TAG:-0}.log
+      export NCCL_DEBUG=INFO NCCL_DEBUG_FILE=$O/r06_rccl_nccl_${TAG:-0}.%p.log
+      timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/r06_suite_rccl_${TAG:-0}.log 2>&1
+      echo "rc=$?" >> $O/r06_suite_rccl_${TAG:-0}.log; tail -6 $O/r06_suite_rccl_${TAG:-0}.log
+      unset NCCL_DEBUG NCCL_DEBUG_FILE OPTILAND_RCCL_WORKER_LOG ;;
+    rccl_alone)
+      OPTILAND_TEST_RCCL=1 OPTILAND_RCCL_WORKER_LOG=$O/r06_rccl_worker_alone.log timeout 400 \
+        python -m pytest tests/test_gpu_rccl_one_rank.py -m gpu -q -p no:cacheprovider > $O/r06_rccl_alone.log 2>&1
+      tail -3 $O/r06_rccl_alone.log ;;
+    window_pmc)
+      bash tools/gpu_window_pmc.sh > $O/r06_window_pmc.log 2>&1; tail -30 $O/r06_window_pmc.log ;;
+    ab)        # in-process A/B: ARMS=product,arith_r04 CONFIGS=dg_f64_gen,zf_f32_gen [ROUNDS=2] [AB_EXTRA=--placed]
+      timeout 600 python tools/ab_inproc.py --arms ${ARMS:-product} --configs ${CONFIGS:-dg_f32_gen} \
+        --rounds ${ROUNDS:-2} ${AB_EXTRA:-} >> $O/r06_ab_${TAG:-0}.txt 2>&1; tail -${AB_TAIL:-12} $O/r06_ab_${TAG:-0}.txt ;;
+    wgcap)     # resident-workgroup cap of the record launches: CAPS=0,2,3,4 CONFIGS=... [AB_EXTRA=--placed]
+      timeout 600 python tools/ab_wgcap.py --caps ${CAPS:-0,2,3,4} --configs ${CONFIGS:-dg_f32_gen,dg_f64_gen} \
+        --rounds ${ROUNDS:-2} ${AB_EXTRA:-} >> $O/r06_ab_wgcap_${TAG:-0}.txt 2>&1; tail -${AB_TAIL:-40} $O/r06_ab_wgcap_${TAG:-0}.txt ;;
+    kernel_table) # rocprofv3 duration + SQ counters per ray of the dominant kernel, final library
+      bash tools/gpu_kernel_table.sh $O/r06_kernel_table.txt > /dev/null 2>&1 <<'CFG'
+dg_f32_gen  |
+dg_f64_gen  | --dtype f64
+rc_f32_gen  | --workload rc_asphere
+zf_f32_gen  | --workload zernike_fresnel
+zf_f64_gen  | --workload zernike_fresnel --dtype f64
+dg_f64_spot | --mode spot --dtype f64
+dg_opd      | --mode opd
+CFG
+      python - <<'PY'
+import json
+print(f"{'tag':<12} {'kernel':<58} {'us':>8} {'VALU/ray':>9} {'SALU/ray':>9} {'SMEM/ray':>8} {'issue_ms':>8} {'movedGB':>8} {'TB/s':>6} {'frac':>6}")
+for ln in open("gpurun_out/r06_kernel_table.txt"):
+    if not ln.startswith('{'): continue
+    r=json.loads(ln)
+    print(f"{r['tag']:<12} {r.get('kernel','?')[:58]:<58} {r.get('avg_us',0):8.1f} {r.get('VALU_per_ray',0):9.0f} {r.get('SALU_per_ray',0):9.0f} {r.get('SMEM_per_ray',0):8.0f} {r.get('valu_issue_ms',0):8.3f} {r.get('moved_GB',0):8.3f} {r.get('TBps_moved',0):6.2f} {r.get('frac',0):6.3f}")
+PY
+      ;;
+    spotdiag)  # the reference's SpotDiagram through the seams: one launch per grid vs per cell
+      timeout 600 python tools/gpu_r06_spotdiag.py > $O/r06_spotdiag.txt 2>&1; tail -5 $O/r06_spotdiag.txt | cut -c1-600 ;;
+    prof)      # rocprofv3 stats + PMC passes of the BASELINE configurations (tools/collect_profiles.py r06)
+      rocm-smi --showserial > $O/r06_box.txt 2>&1
+      bash tools/gpu_prof.sh r06_dg_f32_gen > $O/r06_prof.log 2>&1
+      bash tools/gpu_prof.sh r06_dg_f64_gen --dtype f64 >> $O/r06_prof.log 2>&1
+      bash tools/gpu_prof.sh r06_rc_f32_gen --workload rc_asphere >> $O/r06_prof.log 2>&1
+      bash tools/gpu_prof.sh r06_zf_f32_gen --workload zernike_fresnel >> $O/r06_prof.log 2>&1
+      grep -h "trace_kernel" $O/prof_r06_*/summary.txt | head -8 ;;
+    benches)   # the other BASELINE configurations, steady state included (no baselines)
+      for cfg in "dg_f64:--dtype f64" "c4_f32:--workload rc_asphere" "c4_f64:--workload rc_asphere --dtype f64" \
+                 "c5_f32:--workload zernike_fresnel" "c5_f64:--workload zernike_fresnel --dtype f64" \
+                 "dg_f64_spot:--mode spot --dtype f64" "dg_opd:--mode opd"; do
+        tag=${cfg%%:*}; args=${cfg#*:}
+        python bench.py --steps 20 --warmup 5 --no-cpu-baseline --traffic committed $args \
+          > $O/r06_bench_$tag.json 2> $O/r06_bench_$tag.err
+        python - $O/r06_bench_$tag.json $tag <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    r = d["roofline"]; st = r.get("steady_state") or {}
+    print(f"{sys.argv[2]:12s} value {d['value']:.4g} kernel_ms {r['kernel_ms']:.4f} ({r['kernel_us_minmax']}) frac {r['frac']:.3f}"
+          f" steady {st.get('kernel_ms')} frac {st.get('frac')} placed {(r.get('record_placement') or {}).get('placed')}")
+except Exception as e:
+    print(sys.argv[2], "ERR", e)
+PY
+      done ;;
+    smoke)     # what the driver runs before its bench
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" > $O/r06_smoke.log 2>&1; tail -4 $O/r06_smoke.log ;;
+    exch)      # where the +0.05 ms per step of the reduce-first exchange go (one rank, RCCL)
+      for dbg in none alwayswait nocoll; do
+        OL_BENCH_EXCH_DEBUG=$dbg python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 \
+          bench.py --gpus 1 --force-exchange --steps 40 --warmup 10 --settle 0 --no-cpu-baseline --no-ref-baselines --traffic committed \
+          > $O/r06_exch_$dbg.json 2> $O/r06_exch_$dbg.err
+        python - $O/r06_exch_$dbg.json $dbg <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); e = d["exchange"]
+    print(f"{sys.argv[2]:8s} with {e['ms_per_step_with']:.4f} without {e['ms_per_step_without']:.4f} diff {e['exchange_ms_per_step']:.4f} kernel {d['roofline']['kernel_ms']:.4f}")
+except Exception as ex:
+    print(sys.argv[2], "ERR", ex)
+PY
+      done ;;
+    bench1rank) # the N > 1 launch form with ONE rank: RCCL init, barrier, exchange legs, placement
+      python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
+        bench.py --gpus 1 --force-exchange --steps 20 --warmup 5 --no-cpu-baseline --no-ref-baselines --traffic committed \
+        > $O/r06_bench_1rank_${TAG:-0}.json 2> $O/r06_bench_1rank_${TAG:-0}.err
+      tail -c 1200 $O/r06_bench_1rank_${TAG:-0}.json; tail -3 $O/r06_bench_1rank_${TAG:-0}.err ;;
+    bench)
+      python bench.py ${BENCH_ARGS:-} > $O/r06_bench_${TAG:-default}.json 2> $O/r06_bench_${TAG:-default}.err
+      tail -c 1500 $O/r06_bench_${TAG:-default}.json ;;
+    *) echo "unknown leg $leg" ;;
+  esac
+done

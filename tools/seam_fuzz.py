@@ -23,6 +23,9 @@ declined.  Results and triage of every flag: profiles/r05_seam_fuzz.txt.
     OL_FUZZ_KINDS=standard      conic surfaces only (no stop tolerance between the two sides)
     OL_FUZZ_PRECISION=float32   the torch backend at float32 (limit 1e-4)
     OL_FUZZ_FAMILIES=a,b,...    only these families
+    OL_FUZZ_REFERENCE_NEWTON=1  `enable(reference_newton=True)` (round 6): the reference's own
+                                batch-global Newton stop rule -- Newton lenses are then held to
+                                the conic lenses' limit, 1e-6, in every family
 """
 import os
 import sys
@@ -62,6 +65,7 @@ def _np(a):
 PRECISION = os.environ.get("OL_FUZZ_PRECISION", "float64")   # float32: the fp32 kernels (1e-4)
 OTHERS = "others" in sys.argv[3:]   # the reference's other analyses instead of the ten families
 POLARISED = "polarised" in sys.argv[3:]   # only the polarised lenses: spot, ee
+REFERENCE_NEWTON = os.environ.get("OL_FUZZ_REFERENCE_NEWTON", "0") == "1"
 
 
 def families(lens, polarised=False, only=None):
@@ -270,7 +274,7 @@ for seed in range(lo, hi):
     be.set_backend("torch")
     be.set_device("cpu")
     be.set_precision(PRECISION)
-    integration.enable(force=True, analyses=True)
+    integration.enable(force=True, analyses=True, reference_newton=REFERENCE_NEWTON)
     for k in analysis_seams.STATS:
         analysis_seams.STATS[k] = 0
     try:
@@ -307,7 +311,8 @@ for seed in range(lo, hi):
         st[1] = max(st[1], e)
         # ray-level families: 1e-6 whatever the lens (the Newton stop tolerance, 1e-6 mm, is 1e-8 of
         # these maps); wavefront families on Newton lenses: 2e-3 (1e-6 mm are 2e-3 waves per surface)
-        limit = 1e-6 if (nr == 0 or not k.startswith(("opd", "fftpsf", "RmsWavefront"))) else 2e-3
+        limit = 1e-6 if (nr == 0 or REFERENCE_NEWTON
+                         or not k.startswith(("opd", "fftpsf", "RmsWavefront"))) else 2e-3
         if PRECISION == "float32":
             limit = max(limit, 1e-4)       # BASELINE.json: fp32 within 1e-4
         if e > limit:
