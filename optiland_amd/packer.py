@@ -171,8 +171,10 @@ def _pack_geometry(geom, row, coeffs: list):
         row["max_iter"] = int(geom.max_iter)
         row["n_coeff"] = 2
         coeffs.extend([_f(geom.Ry), _f(geom.ky)])
+        _base_conic_is_the_profiles(name, geom, _f(geom.Rx), _f(geom.kx))
         return
     if name == "ToroidalGeometry":
+        _base_conic_is_the_profiles(name, geom, _f(geom.R_yz), 0.0)
         row["geom_kind"] = S.GEOM_TOROIDAL
         row["radius"] = _f(geom.R_yz)
         row["conic"] = 0.0  # base conic handed to NewtonRaphsonGeometry (toroidal.py:67-69)
@@ -198,6 +200,22 @@ def _pack_geometry(geom, row, coeffs: list):
             coeffs.extend([float(c), float(n), float(m), _f(z._norm_constant(n, m))])
         return
     raise UnsupportedSystem(f"geometry {name} is not on the fused path")
+
+
+def _base_conic_is_the_profiles(name, geom, radius, conic):
+    """Biconic / toroidal surfaces under the opt-in reference Newton rule: the kernels start the
+    iteration from the conic of the profile (Rx, kx / R_yz, 0), the reference from
+    `geometry.radius` / `geometry.k` (newton_raphson.py:119-135) -- the same numbers unless
+    `updater.set_radius / set_conic` moved the base apart from the profile
+    (optic_updater.py:38-70).  The converged intersection does not depend on the start; the
+    batch-global iteration COUNT does, so with that option such a surface goes to the
+    reference's own loop."""
+    if not S.OPTIONS["reference_newton"]:
+        return
+    r, k = _f(geom.radius), _f(geom.k)
+    if not ((r == radius or (math.isinf(r) and math.isinf(radius))) and k == conic):
+        raise UnsupportedSystem(f"{name}: base conic edited apart from the profile "
+                                "(reference Newton rule)")
 
 
 def _to_np(v):
@@ -589,8 +607,14 @@ def _raygen_fingerprint(optic, table: SystemTable):
     stop = tuple(bool(getattr(s, "is_stop", False)) for s in surfaces)
     fields = tuple((_f(f.x), _f(f.y), _f(f.vx), _f(f.vy)) for f in optic.fields.fields)
     mode = getattr(optic.ray_tracer, "ray_aiming_config", {}).get("mode", "paraxial")
+    # `SurfaceGroup.radii` (surface_group.py: geometry.radius of every surface) is what the
+    # paraxial tracer reads.  For a biconic / toroidal surface that is NOT the table's radius:
+    # the sag has its own Rx / R_yz and `updater.set_radius` moves `geometry.radius` alone
+    # (optic_updater.py:38-54, biconic.py:56-66, toroidal.py:67-82) -- the packed bytes stay
+    # what they were while EPL / EPD move (found by tools/seam_fuzz.py edit_loop, round 6)
+    radii = tuple(_f(getattr(s.geometry, "radius", math.inf)) for s in surfaces)
     return hash((
-        table.surfaces.tobytes(), table.coeffs.tobytes(), prim, idx, stop,
+        table.surfaces.tobytes(), table.coeffs.tobytes(), radii, prim, idx, stop,
         type(ap).__name__, None if ap is None else _f(ap.value),
         type(fd).__name__, fields, bool(optic.object_surface.is_infinite),
         bool(optic.obj_space_telecentric), _pack_apodization(optic.apodization), mode,
