@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include "trace_launch.h"
+#include "surface_math.h"  // Math<T>: the hardware reciprocal square root
 
 namespace ol {
 
@@ -36,19 +37,59 @@ OL_DEV T pol_state_term(T ar, T ai, T br, T bi, const T (&s)[3], const T (&p)[3]
   return acc;
 }
 
+// The same term for an incident state with REAL amplitudes (ai = bi = 0, a launch-uniform
+// fact: both states of the unpolarised mean -- E0 = s_hat and E0 = p_hat,
+// polarized_rays.py:122-133 -- and every linear state): Im E0 = 0 and half of the products
+// above are products with zero.  (They only differ where the matrix holds an infinity, which
+// 0 turns into NaN and this form leaves as it is.)  Round 6: the epilogue of the C5 launch was
+// 132 vector instructions per ray, a sixth of the kernel (profiles/r06_phase_costs_before.txt).
+template <typename T, bool CPLX>
+OL_DEV T pol_state_term_real(T ar, T br, const T (&s)[3], const T (&p)[3], const T (&P)[9],
+                             const T (&Q)[9]) {
+  const T er[3] = {ar * s[0] + br * p[0], ar * s[1] + br * p[1], ar * s[2] + br * p[2]};
+  T acc = T(0);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const T vr = P[3 * a] * er[0] + P[3 * a + 1] * er[1] + P[3 * a + 2] * er[2];
+    acc += vr * vr;
+    if (CPLX) {
+      const T vi = Q[3 * a] * er[0] + Q[3 * a + 1] * er[1] + Q[3 * a + 2] * er[2];
+      acc += vi * vi;
+    }
+  }
+  return acc;
+}
+
+// +-0 without a vector compare (the amplitudes are launch-uniform: scalar registers)
+OL_DEV bool amplitude_is_zero(float v) { return (hw::float_bits(v) & 0x7fffffff) == 0; }
+OL_DEV bool amplitude_is_zero(double v) {
+  return (hw::double_bits(v) & 0x7fffffffffffffffll) == 0;
+}
+
 template <typename T, bool CPLX>
 OL_DEV T pol_intensity_one(const PolFields<T>& f, T kx, T ky, T kz, const T (&P)[9],
                            const T (&Q)[9], T i0, uint32_t& flag) {
-  // p = k x x_hat = (0, kz, -ky), normalised; s = p x k
-  T nrm = sqrt(kz * kz + ky * ky);
-  if (nrm == T(0)) flag |= 0x2u;  // OL_STATUS_K_PARALLEL_X
-  const T p[3] = {T(0), kz / nrm, -ky / nrm};
-  const T s[3] = {p[1] * kz - p[2] * ky, p[2] * kx - p[0] * kz, p[0] * ky - p[1] * kx};
+  using m = Math<T>;
+  // p = k x x_hat = (0, kz, -ky), normalised; s = p x k.  One reciprocal square root for the
+  // norm (v_rsq_f32; fp64: the seed + refinement of Math<double>) instead of an IEEE square
+  // root and two IEEE quotients -- as the ray generator normalises the direction itself
+  const T n2 = m::fma(kz, kz, ky * ky);
+  if (n2 == T(0)) flag |= 0x2u;  // OL_STATUS_K_PARALLEL_X
+  const T inv = m::rsqrt(n2);
+  const T p[3] = {T(0), kz * inv, -(ky * inv)};
+  const T s[3] = {p[1] * kz - p[2] * ky, p[2] * kx, -(p[1] * kx)};
   // (the one or two incident states by CONSTANT index: a run-time index into the amplitude
   // arrays sends them to LDS / scratch)
-  T acc = pol_state_term<T, CPLX>(f.ar[0], f.ai[0], f.br[0], f.bi[0], s, p, P, Q);
-  if (f.nf > 1) acc += pol_state_term<T, CPLX>(f.ar[1], f.ai[1], f.br[1], f.bi[1], s, p, P, Q);
-  return acc * i0 / T(f.nf);
+  const bool real0 = amplitude_is_zero(f.ai[0]) && amplitude_is_zero(f.bi[0]);
+  T acc = real0 ? pol_state_term_real<T, CPLX>(f.ar[0], f.br[0], s, p, P, Q)
+                : pol_state_term<T, CPLX>(f.ar[0], f.ai[0], f.br[0], f.bi[0], s, p, P, Q);
+  if (f.nf > 1) {
+    const bool real1 = amplitude_is_zero(f.ai[1]) && amplitude_is_zero(f.bi[1]);
+    acc += real1 ? pol_state_term_real<T, CPLX>(f.ar[1], f.br[1], s, p, P, Q)
+                 : pol_state_term<T, CPLX>(f.ar[1], f.ai[1], f.br[1], f.bi[1], s, p, P, Q);
+  }
+  // (1 / nf: 1 or 1/2, exact)
+  return acc * i0 * (f.nf > 1 ? T(0.5) : T(1));
 }
 
 // analysis/spot_diagram/core.py:329-372, 440-481: what one image-plane hit adds to the

@@ -1521,12 +1521,57 @@ OL_DEV void prt_apply(Prt<T, POLK>& P, const PolBasis<T>& b, T k0x, T k0y,
 // (54 multiply-adds) instead of three products and a full recombination (75); s itself
 // is only needed to build p0 and p1.  Equal to the general form up to the rounding of
 // |k0|^2 - 1 (the reference never renormalises k either).
+// OL_PRT_PACKED (default on, fp32): the two updates below on PAIRS of matrix elements --
+// columns 0 and 1 of every row, and rows 0 and 1 of column 2 -- so that two of every three
+// multiply-adds issue as one v_pk_fma_f32 (v_pk_mul_f32): 57 -> 35 vector instructions for the
+// rank-2 update, 26 -> 16 for the first one (tools/phase_costs.py), in kernels that are bound by
+// vector issue.  Element for element the same operations in the same order as the scalar form
+// (which fp64, with no packed instructions, keeps): the same bits.  A/B knob.
+#ifndef OL_PRT_PACKED
+#define OL_PRT_PACKED 1
+#endif
+template <typename T>
+OL_DEV vec2<T> fma2(vec2<T> a, vec2<T> b, vec2<T> c) {
+  return __builtin_elementwise_fma(a, b, c);
+}
+template <typename T>
+OL_DEV vec2<T> splat2(T v) {
+  return vec2<T>{v, v};
+}
+
 template <typename T, int POLK>
 OL_DEV void prt_apply_diag(Prt<T, POLK>& P, const PolBasis<T>& b, T k0x,
                                                T k0y, T k0z, T k1x, T k1y, T k1z, T j0, T j1,
                                                T j2) {
   using m = Math<T>;
   constexpr int NP = POLK == 2 ? 2 : 1;
+  if constexpr (OL_PRT_PACKED && sizeof(T) == 4) {
+    using V2 = vec2<T>;
+    const V2 p0xy = {b.p0x, b.p0y}, p1xy = {b.p1x, b.p1y}, k0xy = {k0x, k0y}, k1xy = {k1x, k1y};
+    const V2 J0 = splat2(j0);
+    const V2 axy = fma2(splat2(j1), p1xy, -(J0 * p0xy));
+    const V2 bxy = fma2(splat2(j2), k1xy, -(J0 * k0xy));
+    const T az = m::fma(j1, b.p1z, -(j0 * b.p0z)), bz = m::fma(j2, k1z, -(j0 * k0z));
+    const V2 P0x = splat2(b.p0x), P0y = splat2(b.p0y), P0z = splat2(b.p0z);
+    const V2 K0x = splat2(k0x), K0y = splat2(k0y), K0z = splat2(k0z);
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      T* Q = P.m + 9 * c;
+      const V2 q0 = {Q[0], Q[1]}, q1 = {Q[3], Q[4]}, q2 = {Q[6], Q[7]}, c2 = {Q[2], Q[5]};
+      const V2 r1 = fma2(P0x, q0, fma2(P0y, q1, P0z * q2));
+      const V2 r2 = fma2(K0x, q0, fma2(K0y, q1, K0z * q2));
+      const T r1z = m::fma(b.p0x, Q[2], m::fma(b.p0y, Q[5], b.p0z * Q[8]));
+      const T r2z = m::fma(k0x, Q[2], m::fma(k0y, Q[5], k0z * Q[8]));
+      const V2 n0 = fma2(splat2(axy.x), r1, fma2(splat2(bxy.x), r2, J0 * q0));
+      const V2 n1 = fma2(splat2(axy.y), r1, fma2(splat2(bxy.y), r2, J0 * q1));
+      const V2 n2 = fma2(splat2(az), r1, fma2(splat2(bz), r2, J0 * q2));
+      const V2 nc = fma2(axy, splat2(r1z), fma2(bxy, splat2(r2z), J0 * c2));
+      Q[8] = m::fma(az, r1z, m::fma(bz, r2z, j0 * Q[8]));
+      Q[0] = n0.x; Q[1] = n0.y; Q[3] = n1.x; Q[4] = n1.y; Q[6] = n2.x; Q[7] = n2.y;
+      Q[2] = nc.x; Q[5] = nc.y;
+    }
+    return;
+  }
   const T ax = m::fma(j1, b.p1x, -(j0 * b.p0x)), ay = m::fma(j1, b.p1y, -(j0 * b.p0y)),
           az = m::fma(j1, b.p1z, -(j0 * b.p0z));
   const T bx = m::fma(j2, k1x, -(j0 * k0x)), by = m::fma(j2, k1y, -(j0 * k0y)),
@@ -1552,16 +1597,34 @@ OL_DEV void prt_first_diag(Prt<T, POLK>& P, const PolBasis<T>& b, T k0x,
                                                T k0y, T k0z, T k1x, T k1y, T k1z, T j0, T j1,
                                                T j2) {
   using m = Math<T>;
-  const T a[3] = {m::fma(j1, b.p1x, -(j0 * b.p0x)), m::fma(j1, b.p1y, -(j0 * b.p0y)),
-                  m::fma(j1, b.p1z, -(j0 * b.p0z))};
-  const T bb[3] = {m::fma(j2, k1x, -(j0 * k0x)), m::fma(j2, k1y, -(j0 * k0y)),
-                   m::fma(j2, k1z, -(j0 * k0z))};
-  const T p0[3] = {b.p0x, b.p0y, b.p0z}, k0[3] = {k0x, k0y, k0z};
+  if constexpr (OL_PRT_PACKED && sizeof(T) == 4) {
+    using V2 = vec2<T>;
+    const V2 p0xy = {b.p0x, b.p0y}, p1xy = {b.p1x, b.p1y}, k0xy = {k0x, k0y}, k1xy = {k1x, k1y};
+    const V2 J0 = splat2(j0);
+    const V2 axy = fma2(splat2(j1), p1xy, -(J0 * p0xy));
+    const V2 bxy = fma2(splat2(j2), k1xy, -(J0 * k0xy));
+    const T az = m::fma(j1, b.p1z, -(j0 * b.p0z)), bz = m::fma(j2, k1z, -(j0 * k0z));
+    // rows 0..2, columns (0, 1): a_i p0_xy + b_i k0_xy + (j0 on the diagonal)
+    const V2 n0 = fma2(splat2(axy.x), p0xy, fma2(splat2(bxy.x), k0xy, V2{j0, T(0)}));
+    const V2 n1 = fma2(splat2(axy.y), p0xy, fma2(splat2(bxy.y), k0xy, V2{T(0), j0}));
+    const V2 n2 = fma2(splat2(az), p0xy, fma2(splat2(bz), k0xy, V2{T(0), T(0)}));
+    // column 2, rows (0, 1): a_xy p0_z + b_xy k0_z
+    const V2 nc = fma2(axy, splat2(b.p0z), fma2(bxy, splat2(k0z), V2{T(0), T(0)}));
+    P.m[8] = m::fma(az, b.p0z, m::fma(bz, k0z, j0));
+    P.m[0] = n0.x; P.m[1] = n0.y; P.m[3] = n1.x; P.m[4] = n1.y; P.m[6] = n2.x; P.m[7] = n2.y;
+    P.m[2] = nc.x; P.m[5] = nc.y;
+  } else {
+    const T a[3] = {m::fma(j1, b.p1x, -(j0 * b.p0x)), m::fma(j1, b.p1y, -(j0 * b.p0y)),
+                    m::fma(j1, b.p1z, -(j0 * b.p0z))};
+    const T bb[3] = {m::fma(j2, k1x, -(j0 * k0x)), m::fma(j2, k1y, -(j0 * k0y)),
+                     m::fma(j2, k1z, -(j0 * k0z))};
+    const T p0[3] = {b.p0x, b.p0y, b.p0z}, k0[3] = {k0x, k0y, k0z};
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int e = 0; e < 3; ++e)
-      P.m[3 * i + e] = m::fma(a[i], p0[e], m::fma(bb[i], k0[e], i == e ? j0 : T(0)));
+      for (int e = 0; e < 3; ++e)
+        P.m[3 * i + e] = m::fma(a[i], p0[e], m::fma(bb[i], k0[e], i == e ? j0 : T(0)));
+  }
   if constexpr (POLK == 2) {
 #pragma unroll
     for (int e = 9; e < 18; ++e) P.m[e] = P.m[e] * T(0) + (P.m[0] * T(0));  // 0, NaN kept

@@ -453,6 +453,15 @@ struct WavesPerEu {
 // EPI (GEN == kGenUniform && POLK != 0 only): PolarizedRays.update_intensity as an epilogue
 // of the launch -- an instantiation of its own, so that launches without it keep their
 // register budget
+// LDS slots of the update_intensity epilogue (EPI): launch direction and `_i0` per lane, from
+// the generating prologue to the epilogue.  One object for both ends (a function-local
+// __shared__ array is a static of THIS function), allocated only in kernels that call it.
+template <typename T>
+__device__ __forceinline__ T (*epi_launch_slots())[kTraceBlock] {
+  __shared__ T slots[4][kTraceBlock];
+  return slots;
+}
+
 template <typename T, int RPT, bool RECORD, int POLK, int NR, bool SPOT, int GEN = 0,
           bool EPI = false>
 __global__ __launch_bounds__(kTraceBlock)
@@ -574,6 +583,20 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
       else q.i = T(1);
       q.opd = T(0);
       LP::put(r, k, q);
+      if constexpr (EPI) {
+        // what the update_intensity epilogue needs of the LAUNCH state -- the direction and
+        // `_i0` (polarized_rays.py:51-54) -- waits in LDS, one slot per lane (written and read
+        // by the same lane: no barrier).  Until round 6 the epilogue generated the ray a second
+        // time (32 vector instructions per ray in fp32 and the pupil / field planes read
+        // again, in a kernel bound by vector issue; profiles/r06_phase_costs_before.txt);
+        // LDS traffic goes down its own pipe and 4 KB of the CU's 160 KB were idle anyway.
+        static_assert(RPT == 1, "the update_intensity epilogue: one ray per lane");
+        T (*epi_launch)[kTraceBlock] = epi_launch_slots<T>();
+        epi_launch[0][threadIdx.x] = q.L;
+        epi_launch[1][threadIdx.x] = q.M;
+        epi_launch[2][threadIdx.x] = q.N;
+        epi_launch[3][threadIdx.x] = q.i;
+      }
     }
     if constexpr (POLK != 0) {
 #pragma unroll
@@ -850,29 +873,13 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
     // PolarizedRays.update_intensity (rays/polarized_rays.py:68-133) of the traced bundle, from
     // the matrix still in registers (ol_trace_extras.updated_intensity, ABI 7) -- instead of a
     // second launch that reads nine PRT planes, three direction planes and the intensity
-    // plane back.  The launch direction is GENERATED again from the pupil (and, when the launch
-    // has them, field) values (the same arithmetic on the same inputs: the same bits as row 0)
-    // rather than kept live through the surface loop; so is the initial intensity `_i0` -- 1,
-    // or the apodization of the pupil point (polarized_rays.py:51, ray_generator.py:81-85).
+    // plane back.  The launch direction and the initial intensity `_i0` -- 1, or the
+    // apodization of the pupil point (polarized_rays.py:51, ray_generator.py:81-85) -- come
+    // back from the LDS slots the prologue left them in (rounds 3-5 generated the ray again
+    // rather than keep four registers live through the surface loop).
     const auto ka = kernargs<T, TraceArgs<T>>();
     T* upd = ka->a.i_updated;
     {
-      const auto& in_ = ka->a.in;
-      T px = base.at(in_.px)[0], py = base.at(in_.py)[0];
-      T vx = in_.vx0, vy = in_.vy0, tx = in_.tx0, ty = in_.ty0, o[6];
-      const RaygenConsts<T> c = consts_of(&ka->a.rgc);
-      if (in_.hx != nullptr) {  // launch-uniform
-        const T hx = base.at(in_.hx)[0], hy = base.at(in_.hy)[0];
-        if (in_.vx != nullptr) {
-          vx = base.at(in_.vx)[0];
-          vy = base.at(in_.vy)[0];
-        }
-        raygen_field<T>(c, hx, hy, tx, ty);
-      }
-      uint32_t again = 0;  // (range bits were raised by the prologue already)
-      raygen_pupil<T>(in_.flags, vx, vy, px, py, again);
-      raygen_one<T>(c, tx, ty, px, py, vx, vy, o);
-      const T i0 = raygen_apodize<T>(c, px, py);
       PolFields<T> f;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -886,7 +893,10 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
         Pm[e] = P[0].m[e];
         Qm[e] = POLK == 2 ? P[0].m[POLK == 2 ? 9 + e : e] : T(0);
       }
-      base.at(upd)[0] = pol_intensity_one<T, POLK == 2>(f, o[3], o[4], o[5], Pm, Qm, i0, status);
+      T (*epi_launch)[kTraceBlock] = epi_launch_slots<T>();  // (the prologue's slots)
+      const T L0 = epi_launch[0][threadIdx.x], M0 = epi_launch[1][threadIdx.x],
+              N0 = epi_launch[2][threadIdx.x], i0 = epi_launch[3][threadIdx.x];
+      base.at(upd)[0] = pol_intensity_one<T, POLK == 2>(f, L0, M0, N0, Pm, Qm, i0, status);
     }
   }
   if (status && late.status) atomicOr(late.status, status);

@@ -38,6 +38,24 @@ def _newest(path: str) -> float:
     return m
 
 
+def make_writable(tree: str) -> None:
+    """u+w on every directory and file under `tree`.  /root/reference is read-only and
+    `shutil.copytree` keeps the modes: as root that went unnoticed, but the GPU box runs the
+    tests as an ordinary user, and a copy of the staged tests whose conftest.py is to be
+    rewritten (tools/gpu_ref_consumers.py) could not be (round 6)."""
+    for base, dirs, files in os.walk(tree):
+        for name in dirs + files:
+            path = os.path.join(base, name)
+            try:
+                os.chmod(path, os.stat(path).st_mode | 0o200)
+            except OSError:
+                pass
+    try:
+        os.chmod(tree, os.stat(tree).st_mode | 0o200)
+    except OSError:
+        pass
+
+
 def stage(src: str = "/root/reference", force: bool = False, verbose: bool = True) -> str | None:
     """Copy `src`/optiland to oracle/_ref/optiland.  Returns the staged root, or None
     when the reference is absent (the GPU box: the copy made here is already there)."""
@@ -49,6 +67,7 @@ def stage(src: str = "/root/reference", force: bool = False, verbose: bool = Tru
     if not force and os.path.isdir(out) and os.path.exists(stamp) \
             and os.path.isdir(os.path.join(DEST, "tests")) == os.path.isdir(os.path.join(src, "tests")) \
             and os.path.getmtime(stamp) >= _newest(pkg):
+        make_writable(DEST)
         return DEST
     if os.path.isdir(out):
         shutil.rmtree(out)
@@ -62,6 +81,7 @@ def stage(src: str = "/root/reference", force: bool = False, verbose: bool = Tru
             shutil.rmtree(tests_out)
         shutil.copytree(tests_src, tests_out,
                         ignore=shutil.ignore_patterns("__pycache__", "*.pyc", "gui"))
+    make_writable(DEST)
     with open(stamp, "w") as f:
         f.write(os.path.abspath(src) + "\n")
     if verbose:

@@ -252,6 +252,10 @@ def test_reference_suite_sweeps_the_hip_backend(tmp_path):
     dst = tmp_path / "tests"
     shutil.copytree(os.path.join(REF, "tests"), dst,
                     ignore=shutil.ignore_patterns("__pycache__", "zemax_files", "*.zmx"))
+    for base_, dirs_, files_ in os.walk(dst):   # (a read-only reference tree keeps its modes)
+        for name_ in dirs_ + files_:
+            os.chmod(os.path.join(base_, name_),
+                     os.stat(os.path.join(base_, name_)).st_mode | 0o200)
     conf = (dst / "conftest.py").read_text()
     conf = conf.replace(
         "import optiland.backend as be\n",
@@ -296,6 +300,10 @@ def test_reference_consumers_run_on_the_replaced_tracer(tmp_path, engine):
     dst = tmp_path / "tests"
     shutil.copytree(os.path.join(REF, "tests"), dst,
                     ignore=shutil.ignore_patterns("__pycache__"))
+    for base_, dirs_, files_ in os.walk(dst):   # (a read-only reference tree keeps its modes)
+        for name_ in dirs_ + files_:
+            os.chmod(os.path.join(base_, name_),
+                     os.stat(os.path.join(base_, name_)).st_mode | 0o200)
     counter = tmp_path / "hip_engines.txt"
     conf = (dst / "conftest.py").read_text()
     conf = conf.replace(

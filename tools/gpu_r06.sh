@@ -117,6 +117,31 @@ PY
         bench.py --gpus 1 --force-exchange --steps 20 --warmup 5 --no-cpu-baseline --no-ref-baselines --traffic committed \
         > $O/r06_bench_1rank_${TAG:-0}.json 2> $O/r06_bench_1rank_${TAG:-0}.err
       tail -c 1200 $O/r06_bench_1rank_${TAG:-0}.json; tail -3 $O/r06_bench_1rank_${TAG:-0}.err ;;
+    c5_valu)   # SQ_INSTS_VALU per ray of the C5 launch against the Newton iteration cap (tools/gpu_c5_valu.py)
+      OUTD=$O/prof_c5_valu; rm -rf $OUTD; mkdir -p $OUTD
+      (cd /tmp && TMPDIR=/tmp timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUTD/a -o c5 -- \
+        python $R/tools/gpu_c5_valu.py > $OUTD/a.log 2>&1)
+      python - <<PY
+import csv, glob
+names = [l.split("VARIANT ", 1)[1].strip() for l in open("$O/prof_c5_valu/a.log") if l.startswith("VARIANT ")]
+rows = []
+for f in glob.glob("$O/prof_c5_valu/a/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "trace_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "SQ_INSTS_VALU":
+            rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"].split("(")[0][9:], float(r["Counter_Value"])))
+rows.sort()
+L = 3
+with open("$O/r06_c5_valu_${TAG:-0}.txt", "w") as out:
+    for i, nm in enumerate(names):
+        grp = rows[i * L:(i + 1) * L]
+        if not grp:
+            continue
+        v = sum(g[2] for g in grp) / len(grp)
+        line = f"{nm:52s} {grp[0][1]:56s} VALU/ray {v * 64 / 1e7:8.1f}"
+        print(line)
+        out.write(line + "\n")
+PY
+      tail -2 $OUTD/a.log ;;
     bench)
       python bench.py ${BENCH_ARGS:-} > $O/r06_bench_${TAG:-default}.json 2> $O/r06_bench_${TAG:-default}.err
       tail -c 1500 $O/r06_bench_${TAG:-default}.json ;;

@@ -25,6 +25,9 @@ def run(dropin: bool, files=None):
     tmp = tempfile.mkdtemp(prefix="ol_ref_gpu_")
     dst = os.path.join(tmp, "tests")
     shutil.copytree(os.path.join(REF, "tests"), dst)
+    for _b, _d, _f in os.walk(dst):   # (the staged copy may be read-only; the box user is not root)
+        for _n in _d + _f:
+            os.chmod(os.path.join(_b, _n), os.stat(os.path.join(_b, _n)).st_mode | 0o200)
     conf = open(os.path.join(dst, "conftest.py")).read()
     conf = conf.replace('be.set_device("cpu")  # Use CPU for tests', 'be.set_device("cuda")')
     conf = conf.replace("be.grad_mode.enable()", "be.grad_mode.disable()")
