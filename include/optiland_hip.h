@@ -241,6 +241,21 @@ typedef struct ol_system ol_system; /* opaque */
                                       (an untouched dynamic-LDS request): fewer stores in
                                       flight write ~3 % faster there.  Results are
                                       identical; ignored by every other kernel.         */
+#define OL_TRACE_NONUNIT_K 0x20u   /* ABI 11, polarised ol_trace / ol_trace_ex launches: the
+                                      caller's word that the direction cosines of rays[] are
+                                      NOT unit vectors -- what the reference's iterative /
+                                      robust ray aimers hand out (|k|^2 - 1 ~ 1e-3,
+                                      rays/ray_aiming/iterative.py:339-366).  The reference's
+                                      PRT algebra takes k as it comes (its triads
+                                      (s, k0 x s, k0) are then not orthonormal,
+                                      rays/polarized_rays.py:136-202); with this flag the
+                                      kernels form the same matrices: the rank-2 update on
+                                      the normalised directions with the p and k amplitudes
+                                      scaled by |k0| |k1|.  Without it the update equals the
+                                      reference's only for |k| = 1 to rounding.  An uncoated
+                                      refracting surface between EQUAL indices is then not
+                                      the identity: the reference's s there is the rounding
+                                      noise of k0 x k1, the kernels take s = k0 x n.       */
 
 /* Polarisation state for the update_intensity epilogue
  * (rays/polarized_rays.py:122-133, rays/polarization_state.py:29-56).      */

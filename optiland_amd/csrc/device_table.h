@@ -113,6 +113,9 @@ constexpr int kNrEvenAsphere = 4;  // even aspheres only
 constexpr int kNrReference = 5;  // every functor + the reference's batch-global stop rule
                                  // (OL_SURF_REFERENCE_NEWTON, opt-in: newton_reference)
 
+// launch-uniform facts of a polarised trace (surface_math.h: interact)
+constexpr uint32_t kPolNonUnitK = 0x1u;     // OL_TRACE_NONUNIT_K: direction cosines not unit
+
 constexpr uint32_t kSurfRotated = 0x1u;     // this surface's own frame is rotated
 constexpr uint32_t kSurfRelRotated = 0x2u;  // transform from the previous frame rotates
 constexpr uint32_t kSurfRadiusInf = 0x4u;   // |R| = inf (standard.py:108-111 branch)

@@ -1714,9 +1714,10 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
                                          const V (&t)[RPT], const V (&nx)[RPT], const V (&ny)[RPT],
                                          const V (&nz)[RPT], Ray<V> (&r)[RPT],
                                          Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
-                                         bool& prt_fresh) {
+                                         bool& prt_fresh, uint32_t pol_flags = 0) {
   // prt_fresh (wave-uniform): the matrices still hold the identity a fresh trace starts
   // from -- the first real update then writes O_out J O_in instead of multiplying by it
+  // pol_flags (launch-uniform): kPolNonUnitK, see below
   using m = Math<V>;
   using T = typename m::scalar;
   static_assert(POLK == 0 || m::lanes == 1, "the polarised path is scalar");
@@ -1838,13 +1839,28 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
     // UNCOATED surface, whose interaction model calls rays.update() with the identity
     // Jones matrix (interactions/base.py:124-125).
     if (ck == kCoatSimple) return;
+    // kPolNonUnitK (OL_TRACE_NONUNIT_K, ABI 11; launch-uniform): the bundle's direction cosines
+    // are NOT unit vectors -- what the reference's iterative / robust ray aimers hand out
+    // (|k|^2 - 1 ~ 1e-3, rays/ray_aiming/iterative.py:339-366) and nothing renormalises.  Its
+    // PRT algebra takes k as it comes (polarized_rays.py:136-202): s = (k0 x k1) / |.| is a
+    // unit vector, p0 = k0 x s and p1 = k1 x s have the lengths |k0| and |k1|, and
+    //     O_out J O_in = j0 s s^T + j1 p1 p0^T + j2 k1 k0^T
+    //                  = j0 s s^T + |k0||k1| (j1 p1^ p0^^T + j2 k1^ k0^^T)     (^: normalised)
+    // -- the rank-2 form below on the NORMALISED directions with j1 and j2 scaled by |k0||k1|
+    // (exact; without the flag it is the same matrix only for |k| = 1 to rounding).  The
+    // Fresnel amplitudes read cos(aoi) = |n . k0| from k0 as it is, like the reference.
+    const bool nonunit = (pol_flags & kPolNonUnitK) != 0;
     // An uncoated refracting surface between equal indices (every image plane, dummy
     // surfaces) leaves the direction unchanged (u = 1 => k1 = k0), its Jones matrix is
     // the identity and O_out O_in = I for ANY orthonormal basis: P' = P.  The
     // reference still multiplies it out (and its s = k0 x k1 there is rounding noise);
     // here the update is skipped and only the NaN state of a lost ray is carried into
     // the matrix, as the reference's product would.
-    if (ck == kCoatNone && !reflect && o.u == T(1)) {
+    // (Not with kPolNonUnitK: the product is then s s^T + |k0|^2 (I - s s^T), which depends on
+    // a vector s the reference takes from the rounding noise of k0 x k1 -- the update below
+    // runs with s = k0 x n; callers that need the reference's numbers there hand such a
+    // surface to the reference itself, as integration.py does.)
+    if (ck == kCoatNone && !reflect && o.u == T(1) && !nonunit) {
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         const T poison = (r[k].L + r[k].M + r[k].N) * T(0);  // 0, or NaN for a lost ray
@@ -1860,8 +1876,17 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
       // real diagonal Jones matrix: rank-2 form of the update (prt_apply_diag)
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
-        const PolBasis<T> b = pol_basis(L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, nx[k],
-                                        ny[k], nz[k]);
+        T k0x = L0[k], k0y = M0[k], k0z = N0[k], k1x = r[k].L, k1y = r[k].M, k1z = r[k].N;
+        T jscale = T(1);
+        if (nonunit) {
+          const T q0 = m::fma(k0x, k0x, m::fma(k0y, k0y, k0z * k0z));
+          const T q1 = m::fma(k1x, k1x, m::fma(k1y, k1y, k1z * k1z));
+          const T i0 = m::rsqrt(q0), i1 = m::rsqrt(q1);
+          k0x *= i0; k0y *= i0; k0z *= i0;
+          k1x *= i1; k1y *= i1; k1z *= i1;
+          jscale = (q0 * i0) * (q1 * i1);  // |k0| |k1|
+        }
+        const PolBasis<T> b = pol_basis(k0x, k0y, k0z, k1x, k1y, k1z, nx[k], ny[k], nz[k]);
         T j0 = T(1), j1 = T(1), j2 = T(1);
         if (ck == kCoatFresnel) {
           // coatings.py:72-92 + jones.py:71-117 with cos(aoi) = min(|n.k0|, 1):
@@ -1880,20 +1905,36 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
             j1 = m::div(T(2) * nn * ci, m::fma(nn * nn, ci, root));
           }
         }
+        if (nonunit) {
+          j1 *= jscale;
+          j2 *= jscale;
+        }
         if (prt_fresh)
-          prt_first_diag<T, POLK>(P[k], b, L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, j0, j1,
-                                  j2);
+          prt_first_diag<T, POLK>(P[k], b, k0x, k0y, k0z, k1x, k1y, k1z, j0, j1, j2);
         else
-          prt_apply_diag<T, POLK>(P[k], b, L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, j0, j1,
-                                  j2);
+          prt_apply_diag<T, POLK>(P[k], b, k0x, k0y, k0z, k1x, k1y, k1z, j0, j1, j2);
       }
       prt_fresh = false;
       return;
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-      const PolBasis<T> b = pol_basis(L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, nx[k], ny[k],
-                                      nz[k]);
+      PolBasis<T> b;
+      if (nonunit) {
+        // polarizer / retarder: the reference's own (non-orthonormal) triads -- s from the
+        // normalised directions, p0 and p1 with the lengths |k0| and |k1| they have there;
+        // the axis projections of jones.py:157-170 and the product below then are its own
+        const T q0 = m::fma(L0[k], L0[k], m::fma(M0[k], M0[k], N0[k] * N0[k]));
+        const T q1 = m::fma(r[k].L, r[k].L, m::fma(r[k].M, r[k].M, r[k].N * r[k].N));
+        const T i0 = m::rsqrt(q0), i1 = m::rsqrt(q1);
+        b = pol_basis(L0[k] * i0, M0[k] * i0, N0[k] * i0, r[k].L * i1, r[k].M * i1, r[k].N * i1,
+                      nx[k], ny[k], nz[k]);
+        const T m0 = q0 * i0, m1 = q1 * i1;
+        b.p0x *= m0; b.p0y *= m0; b.p0z *= m0;
+        b.p1x *= m1; b.p1y *= m1; b.p1z *= m1;
+      } else {
+        b = pol_basis(L0[k], M0[k], N0[k], r[k].L, r[k].M, r[k].N, nx[k], ny[k], nz[k]);
+      }
       Jones<T> J;
       if (ck == kCoatPolarizer) {
         J = axis_jones(b, s.cold->axis, false, T(0), T(0));
@@ -1917,7 +1958,8 @@ template <typename V, int RPT, int POLK, int NR, bool SHARE = false, typename H>
 OL_DEV void surface_step(const H& h, cptr<typename Math<V>::scalar> coeffs, bool from_global,
                          Ray<V> (&r)[RPT],
                          Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
-                         uint32_t& status, bool& prt_fresh, const NrRefCtl* ref = nullptr) {
+                         uint32_t& status, bool& prt_fresh, const NrRefCtl* ref = nullptr,
+                         uint32_t pol_flags = 0) {
   using m = Math<V>;
   using T = typename m::scalar;
   static_assert(NR == 0 || m::lanes == 1, "the Newton-Raphson path is scalar");
@@ -2078,7 +2120,7 @@ OL_DEV void surface_step(const H& h, cptr<typename Math<V>::scalar> coeffs, bool
   {
     const DevSurf<T> s = h.surf();
     const DevOptics<T> o = h.optics();
-    interact<V, RPT, POLK, NR != 0>(s, o, coeffs, t, nx, ny, nz, r, P, prt_fresh);
+    interact<V, RPT, POLK, NR != 0>(s, o, coeffs, t, nx, ny, nz, r, P, prt_fresh, pol_flags);
   }
 }
 
@@ -2089,9 +2131,11 @@ OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
                          cptr<typename Math<V>::scalar> coeffs, bool from_global,
                          Ray<V> (&r)[RPT],
                          Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
-                         uint32_t& status, bool& prt_fresh, const NrRefCtl* ref = nullptr) {
+                         uint32_t& status, bool& prt_fresh, const NrRefCtl* ref = nullptr,
+                         uint32_t pol_flags = 0) {
   const SurfLoaded<typename Math<V>::scalar> h{s, o};
-  surface_step<V, RPT, POLK, NR, SHARE>(h, coeffs, from_global, r, P, status, prt_fresh, ref);
+  surface_step<V, RPT, POLK, NR, SHARE>(h, coeffs, from_global, r, P, status, prt_fresh, ref,
+                                        pol_flags);
 }
 
 // local -> global for the recorded state (coordinate_system.py:91-107)

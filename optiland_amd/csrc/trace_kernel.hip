@@ -701,6 +701,15 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
   const int first = a.first, last = a.last;
   const int rec_from = a.record_from > first ? a.record_from : first;
   for (int s = first; s <= last; ++s) {
+    // OL_TRACE_NONUNIT_K: polarised launches over the CALLER's rays only -- the generating
+    // prologue normalises its directions, so those kernels do not carry the branch at all
+    uint32_t polf = 0;
+    if constexpr (POLK != 0 && GEN == 0) {
+      uint32_t fl;
+      if constexpr (kFetchArgs) fl = kernargs<T, TraceArgs<T>>()->a.flags;
+      else fl = a.flags;
+      polf = (fl & kTraceNonUnitK) ? kPolNonUnitK : 0u;
+    }
     if constexpr (kFetch) {
       const SurfFetched<T> h = fetched_surface<T, TraceArgs<T>>(s);
       if (refresh(h.hot)->interaction != kRecordOnly) {
@@ -708,10 +717,10 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
           const auto ka = kernargs<T, TraceArgs<T>>();
           const NrRefCtl ctl{ka->a.nr_iters, s, ka->a.n_surf, ka->a.nr_count_at};
           surface_step<V, NV, POLK, NR, kShareRcp>(h, refresh(coeffs_c), is_global, r, P, status,
-                                                 prt_fresh, &ctl);
+                                                 prt_fresh, &ctl, polf);
         } else {
           surface_step<V, NV, POLK, NR, kShareRcp>(h, refresh(coeffs_c), is_global, r, P, status,
-                                                 prt_fresh);
+                                                 prt_fresh, nullptr, polf);
         }
         is_global = false;
         last_idx = s;
@@ -739,10 +748,10 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
         if constexpr (NR == kNrReference) {
           const NrRefCtl ctl{a.nr_iters, s, a.n_surf, a.nr_count_at};
           surface_step<V, NV, POLK, NR, kShareRcp>(S, O, coeffs_c, is_global, r, P, status,
-                                                 prt_fresh, &ctl);
+                                                 prt_fresh, &ctl, polf);
         } else {
           surface_step<V, NV, POLK, NR, kShareRcp>(S, O, coeffs_c, is_global, r, P, status,
-                                                 prt_fresh);
+                                                 prt_fresh, nullptr, polf);
         }
         is_global = false;
         last_traced = S;

@@ -17,6 +17,7 @@ constexpr uint32_t kTraceCompact = 0x2u;   // OL_TRACE_COMPACT
 constexpr uint32_t kTracePrtComplex = 0x4u;  // OL_TRACE_PRT_COMPLEX
 constexpr uint32_t kTracePrtIdentity = 0x8u;  // OL_TRACE_PRT_IDENTITY
 constexpr uint32_t kTraceFewWaves = 0x10u;    // OL_TRACE_FEW_WAVES
+constexpr uint32_t kTraceNonUnitK = 0x20u;    // OL_TRACE_NONUNIT_K (polarised ol_trace launches)
 constexpr uint32_t kTraceRow0IsInput = 0x100u;  // internal: rays[] ARE record row 0
 
 // GEN template parameter of trace_kernel: 0 = the rays come from eight planes; otherwise the

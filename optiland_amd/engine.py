@@ -552,7 +552,8 @@ class HipSystem:
               first: int = 0, last: int | None = None, write_rays: bool | None = None,
               check_status: bool = True, prt_identity: bool = False,
               defer_status: bool = False, zero_status: bool = True,
-              spot=None, record_first: int | None = None) -> TraceResult:
+              spot=None, record_first: int | None = None,
+              nonunit_directions: bool = False) -> TraceResult:
         """Launch the fused trace.
 
         rays: sequence of 8 contiguous 1-D device tensors (x,y,z,L,M,N,i,opd) of one
@@ -567,6 +568,10 @@ class HipSystem:
         then also accumulates the masked spot moments of the final state about
         (cx, cy) as an epilogue of the same kernel (`ol_trace_ex`); read them with
         `reduce_spot_slots(slots)`.
+        nonunit_directions (polarised traces, `OL_TRACE_NONUNIT_K`): the caller's direction
+        cosines are not unit vectors (the reference's iterative / robust aimers) -- the PRT
+        update then reproduces the reference's algebra on them as they are
+        (rays/polarized_rays.py:136-202).
         """
         rays = list(rays)
         if len(rays) != 8:
@@ -604,6 +609,8 @@ class HipSystem:
                 flags |= S.TRACE_PRT_COMPLEX
             if prt_identity:  # write-only PRT: starts from I inside the kernel
                 flags |= S.TRACE_PRT_IDENTITY
+            if nonunit_directions:
+                flags |= S.TRACE_NONUNIT_K
         ptrs = (C.c_void_p * 8)(*[t.data_ptr() for t in rays])
         extras = ex = None
         if rec_first != first:

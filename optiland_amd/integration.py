@@ -1002,8 +1002,10 @@ def _sg_planes(rays, force: bool):
     return planes
 
 
-def _sg_run(group, eng, rays, planes, first, last, polarized):
-    """One fused launch over surfaces[first..last]; rays and surfaces updated in place."""
+def _sg_run(group, eng, rays, planes, first, last, polarized, nonunit=False):
+    """One fused launch over surfaces[first..last]; rays and surfaces updated in place.
+    nonunit: a polarised bundle whose direction cosines are not unit vectors
+    (`OL_TRACE_NONUNIT_K`)."""
     n, dtype = planes[0].numel(), planes[0].dtype
     planes = [t.detach().reshape(-1).contiguous() for t in planes]
     prt = None
@@ -1024,7 +1026,8 @@ def _sg_run(group, eng, rays, planes, first, last, polarized):
                                                               device=p.device)]).contiguous()
         else:
             prt = (p.real if p.is_complex() else p).t().to(dtype).contiguous()  # (9, n)
-    res = eng.trace(planes, 0, record=True, prt=prt, first=first, last=last)
+    res = eng.trace(planes, 0, record=True, prt=prt, first=first, last=last,
+                    **({"nonunit_directions": True} if nonunit else {}))
     if _DEFER_VIEWS:
         register_pending_views(group, res)   # the traced surfaces' views: on first read
     else:
@@ -1103,19 +1106,25 @@ def _hip_surface_group_trace(group, rays, skip):
         return None  # nothing but the object row would run fused
     if table.uses_polarization and not polarized:
         return None  # RealRays.update() ignores Jones matrices; keep that on the reference
-    if polarized and not _unit_directions(rays):
-        # Round 5 (tools/seam_fuzz.py, iterative / robust aiming on polarised lenses): the
-        # reference's iterative aimers hand out direction cosines that are not unit vectors
-        # (|k|^2 - 1 ~ 1e-3) and nothing renormalises them.  Its PRT algebra takes k as it
-        # comes -- O_in = (s, k0 x s, k0), O_out = (s, k1 x s, k1) stop being orthonormal and
-        # the matrix picks up factors |k0| |k1| (polarized_rays.py:136-202) -- while the
-        # kernel's rank-2 form of that update is the same matrix only for |k0| = 1 to
-        # rounding (surface_math.h: prt_apply_diag): 3e-3 of the PRT, 0.3 % of the returned
-        # intensity.  Such a bundle stays on the reference's own surface loop.  (Geometry does
-        # not care: the unpolarised traces of the same rays agree to 1e-10.)
-        from .analysis_seams import _why
-        _why("sg_trace", "polarised bundle whose direction cosines are not unit vectors")
-        return None
+    nonunit = polarized and not _unit_directions(rays)
+    if nonunit:
+        # The reference's iterative / robust aimers hand out direction cosines that are not unit
+        # vectors (|k|^2 - 1 ~ 1e-3) and nothing renormalises them.  Its PRT algebra takes k as
+        # it comes -- O_in = (s, k0 x s, k0), O_out = (s, k1 x s, k1) stop being orthonormal
+        # and the matrix picks up factors |k0| |k1| (polarized_rays.py:136-202).  Round 5 left
+        # such bundles to the reference's surface loop (the rank-2 kernel form is that matrix
+        # only for |k| = 1: 3e-3 of the PRT); round 6: the kernels have the exact form
+        # (OL_TRACE_NONUNIT_K, surface_math.h: interact).  One kind of surface stays with the
+        # reference: an uncoated refracting surface between EQUAL indices (the image surface of
+        # every lens) -- there k1 = k0, the reference's s is the rounding noise of k0 x k1 (or
+        # its fallback axes when that noise is exactly zero) and the product
+        # s s^T + |k0|^2 (I - s s^T) depends on it at the 1e-3 level.
+        rows, opt = table.surfaces, table.optics[:, 0]
+        same = (opt["n1"] == opt["n2"]) & (rows["coating_kind"] == _S.COAT_NONE) \
+            & (rows["interaction"] == _S.INTERACT_REFRACT)
+        foreign = foreign | {int(i) for i in np.nonzero(same)[0] if i >= max(skip, 1)}
+        if len(foreign) >= n_s - skip - (1 if skip == 0 else 0):
+            return None
     eng, table = _sg_engine(group, table, rays.x.device)
 
     # SurfaceGroup.reset() (surface_group.py:373-380): every recorded attribute of every surface
@@ -1147,7 +1156,7 @@ def _hip_surface_group_trace(group, rays, skip):
         e = s
         while e + 1 < n_s and (e + 1) not in foreign:
             e += 1
-        _sg_run(group, eng, rays, planes, s, e, polarized)
+        _sg_run(group, eng, rays, planes, s, e, polarized, nonunit)
         s = e + 1
     return rays
 

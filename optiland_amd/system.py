@@ -54,6 +54,7 @@ TRACE_COMPACT = 0x2
 TRACE_FEW_WAVES = 0x10  # the record block is an ordinary allocation (not a placed window)
 TRACE_PRT_COMPLEX = 0x4
 TRACE_PRT_IDENTITY = 0x8
+TRACE_NONUNIT_K = 0x20  # OL_TRACE_NONUNIT_K: polarised bundle whose directions are not unit
 
 GEOM_NAMES = {
     GEOM_PLANE: "plane",

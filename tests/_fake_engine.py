@@ -29,7 +29,10 @@ class OracleEngine:
         pass
 
     def trace(self, rays, wavelength_index=0, record=True, prt=None, first=0, last=None,
-              write_rays=None, check_status=True, prt_identity=False):
+              write_rays=None, check_status=True, prt_identity=False,
+              nonunit_directions=False):
+        # (nonunit_directions: the oracle restates polarized_rays.py:136-202 literally -- k as
+        # it comes -- so it needs no word about it)
         self.calls += 1
         rays = list(rays)
         n = int(rays[0].numel())

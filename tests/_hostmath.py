@@ -82,7 +82,7 @@ class HostMathSystem:
         return self.table.num_surfaces
 
     def trace(self, rays, wavelength_index=0, record=True, prt=None, first=0, last=None,
-              write_rays=None, prt_identity=False):
+              write_rays=None, prt_identity=False, nonunit_directions=False):
         """rays: 8 contiguous 1-D arrays (x,y,z,L,M,N,i,opd) of one dtype.  Returns
         (record or None, status word); with write_rays the final state lands in `rays`."""
         rays = list(rays)
@@ -106,6 +106,8 @@ class HostMathSystem:
                 flags |= S.TRACE_PRT_COMPLEX
             if prt_identity:
                 flags |= S.TRACE_PRT_IDENTITY
+            if nonunit_directions:
+                flags |= S.TRACE_NONUNIT_K
         ptrs = (C.c_void_p * 8)(*[r.ctypes.data for r in rays])
         status = np.zeros(1, dtype=np.uint32)
         rc = self.lib.ol_trace_ex(

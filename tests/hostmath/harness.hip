@@ -135,19 +135,25 @@ void trace_one(const TraceArgs<T>& a, int64_t i, uint32_t& status) {
     static_cast<DevSurfHot<T>&>(S) = a.surf[s];
     S.cold = a.cold + s;
     if (S.interaction != kRecordOnly) {
+      // (trace_kernel: OL_TRACE_NONUNIT_K on polarised launches over the caller's rays)
+      const uint32_t polf =
+          (POLK != 0 && !GEN && (a.flags & kTraceNonUnitK)) ? kPolNonUnitK : 0u;
       if constexpr (NR != 0) {
         // the Newton kernels hand surface_step table POINTERS and every phase re-reads its
         // fields (SurfFetched, device_table.h) -- same handle here
         const SurfFetched<T> h{a.surf + s, a.cold + s, a.optics + (s * a.n_wl + a.wl)};
         if constexpr (NR == kNrReference) {  // (trace_kernel: the batch's iteration counts)
           const NrRefCtl ctl{a.nr_iters, s, a.n_surf, a.nr_count_at};
-          surface_step<T, 1, POLK, NR>(h, a.coeffs, is_global, r, P, status, prt_fresh, &ctl);
+          surface_step<T, 1, POLK, NR>(h, a.coeffs, is_global, r, P, status, prt_fresh, &ctl,
+                                       polf);
         } else {
-          surface_step<T, 1, POLK, NR>(h, a.coeffs, is_global, r, P, status, prt_fresh);
+          surface_step<T, 1, POLK, NR>(h, a.coeffs, is_global, r, P, status, prt_fresh, nullptr,
+                                       polf);
         }
       } else {
         const DevOptics<T> O = a.optics[s * a.n_wl + a.wl];
-        surface_step<T, 1, POLK, NR>(S, O, a.coeffs, is_global, r, P, status, prt_fresh);
+        surface_step<T, 1, POLK, NR>(S, O, a.coeffs, is_global, r, P, status, prt_fresh, nullptr,
+                                     polf);
       }
       is_global = false;
       last_traced = S;

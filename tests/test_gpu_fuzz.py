@@ -225,6 +225,46 @@ def random_polarised_system(seed):
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("seed", range(25))
+def test_random_polarised_system_with_directions_that_are_not_unit_vectors(seed, dtype):
+    """`OL_TRACE_NONUNIT_K` (ABI 11) on the device: the bundles of the reference's iterative /
+    robust aimers (|k|^2 - 1 ~ 1e-3) against the oracle, which restates
+    polarized_rays.py:136-202 with k as it comes.  The image plane (equal indices: the
+    reference's s is rounding noise there) is left out of the range, as integration.py leaves
+    it to the reference.  Host twin: tests/test_hostmath_fuzz.py."""
+    from oracle import oracle
+    from optiland_amd.engine import HipSystem
+    from optiland_amd.rays import prt_to_complex
+    table, rays = random_polarised_system(seed)
+    g = np.random.default_rng(99 + seed)
+    scale = 1.0 + 1e-3 * g.uniform(-1.0, 1.0, rays["x"].size)
+    rays = dict(rays)
+    for k in ("L", "M", "N"):
+        rays[k] = rays[k] * scale
+    if dtype == torch.float32:
+        rays = {k: v.astype(np.float32).astype(np.float64) for k, v in rays.items()}
+    n = rays["x"].size
+    last = table.num_surfaces - 2
+    out = oracle.trace(table, rays, 0, record=True, polarized=True, last=last)
+    hip = HipSystem(table, DEV)
+    try:
+        planes = [torch.tensor(rays[k], dtype=dtype, device=DEV) for k in PLANES[:7]]
+        planes.append(torch.zeros_like(planes[0]))
+        prt = torch.empty((18 if table.needs_complex_prt else 9, n), dtype=dtype, device=DEV)
+        res = hip.trace(planes, 0, record=True, prt=prt, prt_identity=True, last=last,
+                        nonunit_directions=True)
+        got = res.record[:, :, :n].double().cpu().numpy()
+        p = prt_to_complex(prt).cpu().numpy().astype(np.complex128)
+    finally:
+        hip.close()
+    tol = 1e-9 if dtype == torch.float64 else 1e-4
+    assert_close_planes(got, out["record"], tol, tol, f"polfuzz{seed}")
+    assert np.array_equal(np.isnan(p.real), np.isnan(out["prt"].real))
+    np.testing.assert_allclose(np.nan_to_num(p), np.nan_to_num(out["prt"]), rtol=0,
+                               atol=tol * 10)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("seed", range(25))
 def test_random_polarised_system(seed, dtype):
     """Rays, PRT matrices (real or complex planes) and the update_intensity epilogue of
     random coated systems against the oracle: fp64 1e-9, fp32 1e-4."""

@@ -606,12 +606,13 @@ def test_reference_newton_rule_on_device(be, name, tol, max_iter):
             be.set_device("cpu")
             be.set_backend("numpy")
     _compare(results[True], want, 1e-12, f"{name} reference Newton rule tol={tol}")
-    if tol is not None and name == "AsphericSinglet":
+    if tol is None:
+        # factory settings: the per-ray rule is within the contract too
+        _compare(results[False], want, 1e-6, f"{name} per-ray rule tol={tol}")
+    elif name == "AsphericSinglet":
         # (the case must be one where the two rules differ, or the test shows nothing)
         diff = np.nanmax(np.abs(results[False]["surf"] - want["surf"]))
         assert diff > 1e-7, diff
-    else:
-        _compare(results[False], want, 1e-6, f"{name} per-ray rule tol={tol}")
 
 
 def _sample_classes():

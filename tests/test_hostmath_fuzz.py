@@ -102,6 +102,53 @@ def test_random_polarised_system(seed, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("seed", range(25))
+def test_random_polarised_system_with_directions_that_are_not_unit_vectors(seed, dtype):
+    """`OL_TRACE_NONUNIT_K` (ABI 11): the bundles of the reference's iterative / robust aimers,
+    |k|^2 - 1 ~ 1e-3 (rays/ray_aiming/iterative.py:339-366).  The oracle restates
+    polarized_rays.py:136-202 literally -- k as it comes, triads that are not orthonormal --
+    and the kernels' rank-2 update on the normalised directions with the amplitudes scaled by
+    |k0| |k1| is the same matrix; without the flag the two differ by ~|k|^2 - 1.  Every
+    coating kind (the polarizer / retarder forms carry the lengths in p0 and p1).  The image
+    plane -- the one equal-index surface of these systems, where the reference's s is rounding
+    noise -- is left out of the range, as integration.py leaves it to the reference."""
+    from oracle import oracle
+    table, rays = random_polarised_system(seed)
+    g = np.random.default_rng(99 + seed)
+    scale = 1.0 + 1e-3 * g.uniform(-1.0, 1.0, rays["x"].size)
+    rays = dict(rays)
+    for k in ("L", "M", "N"):
+        rays[k] = rays[k] * scale
+    if dtype == np.float32:
+        rays = _through_fp32(rays)
+    n = rays["x"].size
+    last = table.num_surfaces - 2
+    out = oracle.trace(table, rays, 0, record=True, polarized=True, last=last)
+    sysm = hm.HostMathSystem(table)
+    shape = (18 if table.needs_complex_prt else 9, n)
+    prt, plain = np.empty(shape, dtype=dtype), np.empty(shape, dtype=dtype)
+    got, _ = sysm.trace(_planes(rays, dtype), 0, record=True, prt=prt, prt_identity=True,
+                        last=last, nonunit_directions=True)
+    sysm.trace(_planes(rays, dtype), 0, record=True, prt=plain, prt_identity=True, last=last)
+    sysm.close()
+    p, q = hm.prt_to_complex(prt), hm.prt_to_complex(plain)
+    tol = 1e-9 if dtype == np.float64 else 1e-4
+    assert_close_planes(got.astype(np.float64), out["record"], tol, tol, f"polfuzz{seed}")
+    assert np.array_equal(np.isnan(p.real), np.isnan(out["prt"].real))
+    np.testing.assert_allclose(np.nan_to_num(p), np.nan_to_num(out["prt"]), rtol=0, atol=tol * 10)
+    kinds = table.surfaces["coating_kind"][1:last + 1]
+    # the rank-2 form with an s-amplitude that is not zero (a Fresnel "mirror" between equal
+    # indices has j0 = j1 = 0, and the p and k terms are right with or without the flag)
+    coated = np.any(((kinds == S.COAT_FRESNEL) | (kinds == S.COAT_NONE))
+                    & (table.surfaces["interaction"][1:last + 1] == S.INTERACT_REFRACT))
+    # (... of a matrix that is not zero: a Fresnel "mirror" between equal indices reflects nothing)
+    alive = np.isfinite(out["prt"].real).any() and np.nanmin(np.abs(out["prt"]).max(axis=(1, 2))) > 0.1
+    if dtype == np.float64 and coated and alive:
+        # (the case shows something: without the flag the matrices are NOT the reference's)
+        assert np.nanmax(np.abs(q - out["prt"])) > 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("seed", range(28))
 def test_random_newton_raphson_system(seed, dtype):
     from oracle import oracle

@@ -1037,13 +1037,17 @@ def test_a_ray_without_a_direction_comes_back_without_a_position(hip_on_cpu, req
     assert np.isfinite(got_row["x"][lost]).all()                        # the record keeps it
 
 
-def test_polarised_bundle_with_unnormalised_directions_stays_on_the_reference(hip_on_cpu):
-    """Round 5 (tools/seam_fuzz.py, family `aimed`).  The reference's iterative / robust ray
-    aimers hand out direction cosines with |k|^2 - 1 ~ 1e-3, and nothing renormalises them.
-    Its PRT algebra takes k as it comes (polarized_rays.py:136-202: the triads stop being
-    orthonormal), the kernel's rank-2 form of the update equals it only for |k| = 1 to rounding
-    -- 0.3 % of the returned intensity on this lens.  `SurfaceGroup.trace` declines such a
-    polarised bundle; the result is the reference's, bit for bit with its own torch backend."""
+def test_polarised_bundle_with_unnormalised_directions_goes_through_the_kernel(hip_on_cpu):
+    """Found in round 5 (tools/seam_fuzz.py, family `aimed`), served by the kernels since round
+    6.  The reference's iterative / robust ray aimers hand out direction cosines with
+    |k|^2 - 1 ~ 1e-3, and nothing renormalises them.  Its PRT algebra takes k as it comes
+    (polarized_rays.py:136-202: the triads stop being orthonormal, every surface scales the
+    matrix by |k0| |k1|); the kernel's rank-2 update equals that only for |k| = 1 -- 0.3 % of
+    the returned intensity on this lens -- unless it is told (`OL_TRACE_NONUNIT_K`): then it
+    works on the normalised directions with the p and k amplitudes scaled by |k0| |k1|, which
+    is the same matrix.  `SurfaceGroup.trace` sets the flag for such a polarised bundle and
+    leaves only the equal-index image surface (s = rounding noise of k0 x k1 in the reference)
+    to the reference's own `Surface.trace`."""
     import importlib.util
     be = hip_on_cpu
     from optiland_amd import integration
@@ -1060,7 +1064,9 @@ def test_polarised_bundle_with_unnormalised_directions_stays_on_the_reference(hi
         r = lens.trace(0.0, 0.7, lens.primary_wavelength, 3, "hexapolar")
         k2 = _np(be, lens.surfaces.L)[0] ** 2 + _np(be, lens.surfaces.M)[0] ** 2 \
             + _np(be, lens.surfaces.N)[0] ** 2
-        return {k: _np(be, getattr(r, k)) for k in ("x", "y", "z", "L", "M", "N", "i", "opd")}, k2
+        out = {k: _np(be, getattr(r, k)) for k in ("x", "y", "z", "L", "M", "N", "i", "opd")}
+        out["p"] = np.asarray(be.to_numpy(r.p)).real.reshape(-1)
+        return out, k2
 
     for mode in ("iterative", "robust"):
         be.set_backend("numpy")
@@ -1070,10 +1076,14 @@ def test_polarised_bundle_with_unnormalised_directions_stays_on_the_reference(hi
         be.set_device("cpu")
         be.set_precision("float64")
         integration.enable(force=True)
+        served, declined = integration._SG["count"], integration._SG["fallbacks"]
         try:
             got, _ = run(mode)
         finally:
             integration.disable()
+        # the kernels traced the bundle (the aimers' own traces to the stop are unpolarised
+        # seam calls too: the counter moves by more than one), nothing fell back
+        assert integration._SG["count"] > served and integration._SG["fallbacks"] == declined
         for k in want:
-            np.testing.assert_allclose(got[k], want[k], rtol=0, atol=1e-12, equal_nan=True,
+            np.testing.assert_allclose(got[k], want[k], rtol=0, atol=1e-10, equal_nan=True,
                                        err_msg=f"{mode} {k}")
