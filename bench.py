@@ -937,18 +937,28 @@ def main():
             # clocks have settled, slower in the first 25 launches -- hence not the default
             # for a placed block (profiles/r05_ab_wgcap.txt)
             lib_, knob_ = hip.lib, 3  # OL_TUNE_RECORD_WG_CAP
+            try:
+                prev_cap = int(os.environ.get("OL_RECORD_WG_CAP", "0") or 0)
+            except ValueError:
+                prev_cap = 0
             if lib_.ol_set_tuning(knob_, 2) == 0:
-                cev = [(make_event(), make_event()) for _ in range(max(args.settle // 2, 30))]
-                for e0_, e1_ in cev:
-                    e0_.record()
-                    hip.trace_generate(px, py, wl, field=(0.0, hy), record=record, prt=prt,
-                                       zero_status=False, defer_status=True)
-                    e1_.record()
-                sync(device)
-                lib_.ol_set_tuning(knob_, 0)
+                try:
+                    cev = [(make_event(), make_event()) for _ in range(max(args.settle // 2, 30))]
+                    for e0_, e1_ in cev:
+                        e0_.record()
+                        hip.trace_generate(px, py, wl, field=(0.0, hy), record=record, prt=prt,
+                                           zero_status=False, defer_status=True)
+                        e1_.record()
+                    sync(device)
+                finally:
+                    lib_.ol_set_tuning(knob_, prev_cap)   # (what the environment had seeded)
                 ct = [a.elapsed_time(bb) for a, bb in cev]
                 ct = ct[-max(len(ct) // 3, 1):]
                 steady["kernel_ms_two_workgroups_per_cu"] = float(np.mean(ct))
+            # (round 6: the engine passes that cap by itself once it has seen this many launches
+            # in a row into one block -- `steady_state.kernel_ms` above already has it)
+            from optiland_amd import engine as _E
+            steady["hot_loop_after"] = int(_E._HOT_LOOP["after"])
         if placement is not None and placement.get("placed") and gen:
             # the same launch into an ORDINARY allocation (what a drop-in trace gets), for
             # comparison -- outside the reported region

@@ -547,6 +547,15 @@ int ol_math_probe(int32_t op, ol_dtype dt, int64_t n, const void* a, const void*
 int ol_stream_fill(void* dst, int64_t bytes, int32_t store_bytes, int32_t planes,
                    uint32_t pattern, void* stream);
 
+/* ABI 11.  Device memory of the library's OWN: the arenas in which the host side looks for
+ * fast record windows (engine.py: RecordPool, alloc_record_placed) come from here -- hipMalloc
+ * on the current device -- and go back with ol_arena_free (hipFree: waits for the device).
+ * Until round 6 they were blocks of the caller's caching allocator, and handing an arena
+ * back meant emptying THAT cache: the drop-in now never touches it.  OL_EHIP when the device
+ * cannot spare `bytes` (nothing is allocated; the caller goes without a pool).            */
+int ol_arena_alloc(int64_t bytes, void** out);
+int ol_arena_free(void* arena);
+
 /* Image-plane reductions for one ray block (analysis/spot_diagram/core.py:
  * 329-372): out[0..5] += {sum w, sum w x, sum w y, sum w x^2, sum w y^2,
  * count} with w = (i>0 ? 1 : 0) -- the masked centroid / RMS building blocks;

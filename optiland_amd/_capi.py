@@ -142,6 +142,8 @@ EXPORTS = (
     "ol_wavefront_opd_fitted",
     "ol_trace_spot_batch",
     "ol_newton_count",
+    "ol_arena_alloc",
+    "ol_arena_free",
 )
 
 F32, F64 = 0, 1
@@ -261,6 +263,10 @@ def bind(lib, path: str = "?"):
     lib.ol_trace_spot_batch.argtypes = [vp, C.c_int, i64, vp, vp, i32, vp, vp, i64, vp, vp, vp]
     lib.ol_newton_count.restype = C.c_int
     lib.ol_newton_count.argtypes = [vp, C.c_int, i64, C.POINTER(vp), i32, i32, i32, vp, i32, vp]
+    lib.ol_arena_alloc.restype = C.c_int
+    lib.ol_arena_alloc.argtypes = [i64, C.POINTER(vp)]
+    lib.ol_arena_free.restype = C.c_int
+    lib.ol_arena_free.argtypes = [vp]
     lib.ol_pupil_points.restype = C.c_int
     lib.ol_pupil_points.argtypes = [i32, i32, C.c_int, i64, vp, vp, vp, vp, vp]
     lib.ol_math_probe.restype = C.c_int

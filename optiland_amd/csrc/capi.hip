@@ -1714,6 +1714,28 @@ int ol_stream_fill(void* dst, int64_t bytes, int32_t store_bytes, int32_t planes
   return OL_OK;
 }
 
+int ol_arena_alloc(int64_t bytes, void** out) {
+  if (!out) return fail(OL_EINVAL, "ol_arena_alloc: out is NULL");
+  *out = nullptr;
+  if (bytes <= 0) return fail(OL_EINVAL, "ol_arena_alloc: %lld bytes", (long long)bytes);
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, (size_t)bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // (an out-of-memory answer is not a sticky error)
+    return fail(OL_EHIP, "ol_arena_alloc: %lld bytes: %s", (long long)bytes,
+                hipGetErrorString(e));
+  }
+  *out = p;
+  return OL_OK;
+}
+
+int ol_arena_free(void* arena) {
+  if (!arena) return OL_OK;
+  hipError_t e = hipFree(arena);
+  if (e != hipSuccess) return fail(OL_EHIP, "ol_arena_free: %s", hipGetErrorString(e));
+  return OL_OK;
+}
+
 int ol_spot_moments(ol_dtype dt, int64_t n_rays, const void* x, const void* y,
                     const void* intensity, double* out6, void* stream) {
   if (!x || !y || !intensity || !out6) return fail(OL_EINVAL, "ol_spot_moments: NULL argument");

@@ -56,6 +56,7 @@ OL_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 // square roots and two quotients per conic surface.
 // v_cmp_class masks: bit 2 -inf, 5 -0, 6 +0, 9 +inf
 constexpr int kClassZeroOrInf = 0x264;  // +-0 | +-inf
+constexpr int kClassDenormal = 0x090;   // +-denormal
 OL_DEV double rcp_f64(double x) {
   const double y0 = __builtin_amdgcn_rcp(x);
   double e = __builtin_fma(-x, y0, 1.0);
@@ -111,7 +112,9 @@ OL_DEV void div2_f64(double n1, double d1, double n2, double d2, double& q1, dou
   a = __builtin_fma(__builtin_fma(-d1, a, n1), i1, a);
   double b = n2 * i2;
   b = __builtin_fma(__builtin_fma(-d2, b, n2), i2, b);
-  const bool odd = __builtin_amdgcn_class(dd, kClassZeroOrInf);
+  // (... or a denormal: its reciprocal seed overflows and both quotients would be NaN where
+  // n1 / d1 and n2 / d2 are finite -- the product of two modest divisors can land there)
+  const bool odd = __builtin_amdgcn_class(dd, kClassZeroOrInf | kClassDenormal);
   if (__any(odd)) {
     const double sa = div_f64(n1, d1), sb = div_f64(n2, d2);
     a = odd ? sa : a;

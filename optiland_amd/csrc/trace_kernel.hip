@@ -936,8 +936,11 @@ static unsigned record_lds(const TraceArgs<T>& a, bool lean, bool generating) {
   if (cap == 0)
     cap = !lean ? 1 : sizeof(T) == 8 ? 3 : !(a.flags & kTraceFewWaves) ? 1 : generating ? 2 : 3;
   if (cap < 2) return 0;
+  // (63 KB at most: with the static LDS some variants carry -- the spot epilogue's partial sums,
+  // the update_intensity slots -- the request stays under the 64 KB a launch may ask for without
+  // a function attribute, and two blocks of 63 KB still keep a third off the CU)
   const unsigned want = 160u * 1024u / (unsigned)cap - 1024u;
-  return want > 64u * 1024u ? 64u * 1024u : want;
+  return want > 63u * 1024u ? 63u * 1024u : want;
 }
 
 template <typename T, int RPT, int NR>

@@ -8,8 +8,11 @@ from __future__ import annotations
 
 import collections
 import ctypes as C
+import logging
 import threading
 import os
+import time
+import weakref
 
 import numpy as np
 import torch
@@ -92,8 +95,97 @@ def _default_slots():
         return "auto"
 
 
+def _default_idle_s() -> float:
+    try:
+        return max(float(os.environ.get("OPTILAND_HIP_POOL_IDLE_S", "30")), 0.0)
+    except ValueError:
+        return 30.0
+
+
+# idle_s: a pool none of whose blocks is in a user's hands and that has not been asked for one
+# for this many seconds gives its arenas back to the device (0 = never).
 _POOL_CONFIG = {"slots": _default_slots(), "min_bytes": 256 << 20, "max_pools": 2,
-                "cooldown": 64}
+                "cooldown": 64, "idle_s": _default_idle_s()}
+_LOG = logging.getLogger("optiland_amd")
+
+
+class _Arena:
+    """Device memory of the library's OWN (`ol_arena_alloc`: hipMalloc), in which record windows
+    are looked for.  Not a block of torch's caching allocator: handing an arena back is one
+    hipFree and never touches the user's cache (until round 6 the arenas were torch tensors and
+    `torch.cuda.empty_cache()` was how they went back to the driver)."""
+
+    __slots__ = ("lib", "device", "ptr", "nbytes", "__weakref__")
+    live_bytes = 0          # all arenas of the process (`record_pool_stats`)
+    _lock = threading.Lock()
+
+    def __init__(self, lib, device, nbytes: int):
+        self.lib, self.device, self.nbytes, self.ptr = lib, device, int(nbytes), 0
+        out = C.c_void_p()
+        with torch.cuda.device(device):
+            rc = lib.ol_arena_alloc(int(nbytes), C.byref(out))
+        if rc != 0 or not out.value:
+            raise MemoryError(f"no arena of {nbytes >> 20} MiB on {device}")
+        self.ptr = int(out.value)
+        with _Arena._lock:
+            _Arena.live_bytes += self.nbytes
+
+    def data_ptr(self) -> int:
+        return self.ptr
+
+    def numel(self) -> int:
+        return self.nbytes
+
+    def view(self, offset: int, nbytes: int) -> torch.Tensor:
+        """uint8 tensor over [offset, offset + nbytes) whose storage keeps this arena alive."""
+        return torch.as_tensor(_ArenaView(self, self.ptr + int(offset), int(nbytes)),
+                               device=self.device)
+
+    def __del__(self):
+        ptr, self.ptr = self.ptr, 0
+        if not ptr:
+            return
+        try:
+            self.lib.ol_arena_free(C.c_void_p(ptr))
+            with _Arena._lock:
+                _Arena.live_bytes -= self.nbytes
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+class _ArenaView:
+    """CUDA-array-interface handle on a piece of an `_Arena`; torch keeps it (and through it
+    the arena) for as long as the storage made from it -- any view of it -- lives."""
+
+    __slots__ = ("arena", "ptr", "nbytes")
+
+    def __init__(self, arena, ptr, nbytes):
+        self.arena, self.ptr, self.nbytes = arena, ptr, nbytes
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False),
+                "strides": None, "version": 2}
+
+
+def _new_arena(hip, nbytes: int):
+    """An `_Arena` of `nbytes` on the system's device, or None when the device cannot spare it
+    (host-math engines of the tests, which have no hipMalloc behind them, use a tensor)."""
+    if not hasattr(hip.lib, "ol_arena_alloc") or hip.device.type != "cuda":
+        try:
+            return torch.empty(nbytes, dtype=torch.uint8, device=hip.device)
+        except RuntimeError:
+            return None
+    try:
+        return _Arena(hip.lib, hip.device, nbytes)
+    except MemoryError:
+        return None
+
+
+def _arena_view(arena, offset: int, nbytes: int) -> torch.Tensor:
+    if isinstance(arena, _Arena):
+        return arena.view(offset, nbytes)
+    return arena[offset: offset + nbytes]
 _RECORD_POOLS: "collections.OrderedDict" = collections.OrderedDict()  # key -> RecordPool (LRU)
 _POOL_LOCK = threading.RLock()  # pools are process-wide; traces may come from several threads
 _SHAPE_SEEN: dict = {}     # key -> requests so far ("auto": the second one builds the pool)
@@ -127,6 +219,46 @@ def _few_waves_flag(rec) -> int:
             if d == dev and lo <= ptr < lo + nb:
                 return 0
     return S.TRACE_FEW_WAVES
+
+
+# Hot loops (round 6).  The fp32 conic-only record-all kernels write a PLACED block 3.8 % faster
+# with at most two workgroups resident per CU -- once the part's clocks have settled; in the
+# first ~25 launches after an idle gap the same cap costs 11-13 % (profiles/r05_ab_wgcap.txt).
+# Round 5 therefore left it to the caller (`ol_set_tuning`).  The engine can see a loop itself:
+# launch after launch into the SAME block, enqueued without a pause.  From the `after`-th such
+# launch on the block is traced with `TRACE_FEW_WAVES` (the kernels' word for "two workgroups");
+# a gap of `gap_s` between two enqueues -- the device may have gone idle -- starts the count
+# again.  OPTILAND_HIP_HOT_LOOP=0 turns it off; =N sets `after`.
+def _hot_loop_after() -> int:
+    try:
+        return max(int(os.environ.get("OPTILAND_HIP_HOT_LOOP", "32")), 0)
+    except ValueError:
+        return 32
+
+
+_HOT_LOOP = {"after": _hot_loop_after(), "gap_s": 0.02}
+_HOT_BLOCKS: "collections.OrderedDict" = collections.OrderedDict()  # (dev, ptr) -> [count, last]
+
+
+def _hot_loop_flag(rec) -> int:
+    """`TRACE_FEW_WAVES` for a big record block that has been the target of `after` launches in
+    a row without an idle gap, else 0."""
+    after = _HOT_LOOP["after"]
+    if not after or rec is None or rec.numel() * rec.element_size() < _FEW_WAVES_MIN_BYTES:
+        return 0
+    key = (rec.device.index or 0, rec.data_ptr())
+    now = time.perf_counter()
+    ent = _HOT_BLOCKS.get(key)
+    if ent is None:
+        ent = _HOT_BLOCKS[key] = [0, now]
+        while len(_HOT_BLOCKS) > 8:
+            _HOT_BLOCKS.popitem(last=False)
+    elif now - ent[1] > _HOT_LOOP["gap_s"]:
+        ent[0] = 0
+    else:
+        ent[0] += 1
+    ent[1] = now
+    return S.TRACE_FEW_WAVES if ent[0] >= after else 0
 
 
 class _Lease:
@@ -166,8 +298,6 @@ class RecordPool:
 
     def __init__(self, hip, n: int, dtype, rows: int, slots: int = 2, arena_bytes=None,
                  min_gain: float = 0.04, max_arenas: int = 3):
-        import threading
-
         self.device, self.dtype, self.rows = hip.device, dtype, rows  # (`hip`: for the probe only)
         b = torch.empty((), dtype=dtype).element_size()
         self.stride = hip.record_stride(n, b)
@@ -175,18 +305,23 @@ class RecordPool:
         self.windows = []          # (arena, address)
         self.free = []
         self.lock = threading.RLock()  # (a lease's finaliser may run while this thread holds it)
+        self.last_used = time.monotonic()
         self.info = {"block_bytes": need, "slots_wanted": slots, "probes": 0, "arenas": 0}
         if arena_bytes is None:
             arena_bytes = max(3 * need, 40 << 30)
         coarse_ms, candidates, held = [], [], []
-        for _ in range(max(1, int(max_arenas))):
+        picked = []
+        # A small arena first (3 blocks: found or not in a tenth of the time and memory), then
+        # up to `max_arenas` of the full size; each is allocated while the earlier ones are held
+        # (a freed arena would come back at the same addresses).
+        sizes = ([3 * need] if arena_bytes > 3 * need else []) + [arena_bytes] * max(1, int(max_arenas))
+        for want in sizes:
             free, _total = torch.cuda.mem_get_info(hip.device)
-            size = min(arena_bytes, int(free * 0.45)) // (2 << 20) * (2 << 20)
+            size = min(want, int(free * 0.45)) // (2 << 20) * (2 << 20)
             if size < 2 * need:
                 break
-            try:
-                arena = torch.empty(size, dtype=torch.uint8, device=hip.device)
-            except RuntimeError:
+            arena = _new_arena(hip, size)
+            if arena is None:
                 break
             held.append(arena)
             times, offs, pad = hip._probe_windows(arena, size, need, b, rows * 8)
@@ -200,18 +335,27 @@ class RecordPool:
         self.info["arenas"] = len(held)
         if coarse_ms:
             med = float(np.median(coarse_ms))
-            picked = self._pick(candidates, med * (1.0 - min_gain), need, slots)
             self.info["probe_median_GBps"] = need / (med * 1e-3) / 1e9
             self.info["window_GBps"] = [need / (t * 1e-3) / 1e9 for t, _a, _o in picked]
             for _t, a, off in picked:
                 self.windows.append((held[a], held[a].data_ptr() + off))
                 _note_placed(hip.device, held[a].data_ptr() + off, need)
-            unused = len(held) - len({a for _t, a, _o in picked})
-            held = None  # (arenas without a window are released with this frame ...
-            if unused:
-                torch.cuda.empty_cache()  # ... and go back to the DRIVER, not to torch's cache)
+        # arenas without a window go back to the device with this frame (one hipFree each)
+        del held, candidates
         self.free = list(range(len(self.windows)))
         self.info["slots"] = len(self.windows)
+        self.info["arena_bytes_kept"] = sum({id(a): a.numel() for a, _p in self.windows}.values())
+        if self.windows:
+            _LOG.info("optiland_amd: record pool for %s blocks of %d MiB on %s keeps %d MiB of "
+                      "device memory (given back after %g s without use; "
+                      "HipSystem.enable_record_pool(0) or OPTILAND_HIP_PLACED_RECORDS=0 turns "
+                      "pools off)", len(self.windows), need >> 20, hip.device,
+                      self.info["arena_bytes_kept"] >> 20, _POOL_CONFIG["idle_s"])
+
+    def idle(self) -> bool:
+        """No block lent out (the windows' arenas may go)."""
+        with self.lock:
+            return len(self.free) == len(self.windows)
 
     @staticmethod
     def _pick(candidates, limit_ms, need, slots):
@@ -227,10 +371,12 @@ class RecordPool:
     def _give_back(self, index):
         with self.lock:
             self.free.append(index)
+            self.last_used = time.monotonic()
 
     def acquire(self):
         """A (rows, 8, stride) record block on a free window, or None when all are lent out."""
         with self.lock:
+            self.last_used = time.monotonic()
             if not self.free:
                 return None
             index = self.free.pop()
@@ -239,6 +385,60 @@ class RecordPool:
         flat = torch.as_tensor(lease, device=self.device)
         del lease  # (the tensor's storage holds the only reference now)
         return flat.view(self.dtype).view(self.rows, 8, self.stride)
+
+
+def release_record_pools(only_idle: bool = False) -> int:
+    """Drop the record pools of this process (their arenas go back to the device as soon as no
+    lent block holds them); `only_idle`: those with no block lent out and no request for
+    `idle_s` seconds.  Returns the number of pools dropped."""
+    now, limit, dropped = time.monotonic(), _POOL_CONFIG["idle_s"], 0
+    with _POOL_LOCK:
+        for key in list(_RECORD_POOLS):
+            pool = _RECORD_POOLS[key]
+            if only_idle and not (getattr(pool, "windows", None) and pool.idle()
+                                  and now - getattr(pool, "last_used", now) > limit):
+                continue
+            del _RECORD_POOLS[key]
+            _SHAPE_SEEN[key] = 1          # the next request of the shape is "the second" again
+            dropped += 1
+    return dropped
+
+
+def record_pool_stats() -> dict:
+    """What the placed-record machinery holds: `placed_bytes` = device memory of the library's
+    arenas (pools AND blocks of `alloc_record_placed` that are still alive), `pools` = one
+    entry per pooled shape."""
+    with _POOL_LOCK:
+        pools = [{"device": k[0], "rays": k[1], "dtype": str(k[2]).split(".")[-1], "rows": k[3],
+                  "slots": len(getattr(p, "windows", ())),
+                  "lent": len(getattr(p, "windows", ())) - len(getattr(p, "free", ())),
+                  "arena_bytes": getattr(p, "info", {}).get("arena_bytes_kept", 0)}
+                 for k, p in _RECORD_POOLS.items()]
+    return {"placed_bytes": int(_Arena.live_bytes), "pools": pools,
+            "idle_s": _POOL_CONFIG["idle_s"]}
+
+
+_SWEEPER = {"thread": None}
+
+
+def _start_sweeper() -> None:
+    """A daemon thread that gives idle pools back (a process that stops tracing never calls
+    `alloc_record` again, so nobody else would)."""
+    if _SWEEPER["thread"] is not None or not _POOL_CONFIG["idle_s"]:
+        return
+
+    def run():
+        while True:
+            time.sleep(max(_POOL_CONFIG["idle_s"] / 4.0, 0.05) if _POOL_CONFIG["idle_s"] else 5.0)
+            try:
+                if _POOL_CONFIG["idle_s"]:
+                    release_record_pools(only_idle=True)
+            except Exception:  # noqa: BLE001 - never take the process down from here
+                pass
+
+    t = threading.Thread(target=run, name="optiland_amd-pool-sweeper", daemon=True)
+    _SWEEPER["thread"] = t
+    t.start()
 
 
 class HipSystem:
@@ -421,6 +621,8 @@ class HipSystem:
         # r04_placement_attempts.txt: up to three are tried; those without one go straight back)
         pool = _RECORD_POOLS[key] = RecordPool(self, n, dtype, rows, 2 if auto else slots,
                                                arena_bytes=arena_bytes, max_arenas=3)
+        if getattr(pool, "windows", None):
+            _start_sweeper()
         return pool
 
     def alloc_record(self, n: int, dtype, rows: int | None = None) -> torch.Tensor:
@@ -432,7 +634,15 @@ class HipSystem:
             block = pool.acquire()
             if block is not None:
                 return block
-        return torch.empty((rows, 8, stride), dtype=dtype, device=self.device)
+        try:
+            return torch.empty((rows, 8, stride), dtype=dtype, device=self.device)
+        except torch.OutOfMemoryError:
+            # the device is full: the pools' arenas are the first thing to go
+            if not release_record_pools():
+                raise
+            import gc
+            gc.collect()
+            return torch.empty((rows, 8, stride), dtype=dtype, device=self.device)
 
     def _probe_windows(self, arena: torch.Tensor, size: int, need: int, b: int, planes: int):
         """(times [ms] by byte offset, the coarse offsets, pad): `ol_stream_fill` -- the record
@@ -513,9 +723,8 @@ class HipSystem:
             size = min(arena_bytes, int(free * 0.45)) // (2 << 20) * (2 << 20)
             if size < 2 * need:
                 break
-            try:
-                arena = torch.empty(size, dtype=torch.uint8, device=self.device)
-            except RuntimeError:  # out of memory after all
+            arena = _new_arena(self, size)   # (the library's own memory: never torch's cache)
+            if arena is None:
                 break
             held.append(arena)
             times, offs, pad = probe(arena, size)
@@ -537,14 +746,11 @@ class HipSystem:
                     probe_median_GBps=need / (med * 1e-3) / 1e9)
         placed = t_best <= med * (1.0 - min_gain)
         arena = held[which] if placed else None
-        discarded = len(held) - (1 if placed else 0)
-        del held
-        if discarded:
-            torch.cuda.empty_cache()  # arenas that were not chosen go back to the driver
+        del held   # arenas that were not chosen go back to the device (one hipFree each)
         if not placed:
             return self.alloc_record(n, dtype, rows), info
         info["placed"] = True
-        rec = arena[pad + off: pad + off + need].view(dtype).view(rows, 8, stride)
+        rec = _arena_view(arena, pad + off, need).view(dtype).view(rows, 8, stride)
         _note_placed(self.device, rec.data_ptr(), need)
         return rec, info
 
@@ -599,7 +805,8 @@ class HipSystem:
                 raise ValueError("record must be a contiguous (rows, 8, stride>=n) tensor")
         if write_rays is None:
             write_rays = rec is None
-        flags = (S.TRACE_WRITE_RAYS if write_rays else 0) | S.TRACE_COMPACT | _few_waves_flag(rec)
+        flags = (S.TRACE_WRITE_RAYS if write_rays else 0) | S.TRACE_COMPACT \
+            | _few_waves_flag(rec) | _hot_loop_flag(rec)
         if prt is not None:
             if prt.dtype != dtype or prt.dim() != 2 or prt.shape[0] not in (9, 18) \
                     or prt.shape[1] != n or not prt.is_contiguous():
@@ -754,7 +961,7 @@ class HipSystem:
                     or rec.shape[0] < rows or rec.shape[1] != 8 or rec.shape[2] < n \
                     or not rec.is_contiguous():
                 raise ValueError("record must be a contiguous (rows, 8, stride>=n) tensor")
-        tflags = _few_waves_flag(rec)
+        tflags = _few_waves_flag(rec) | _hot_loop_flag(rec)
         if prt is not None:
             if prt.dtype != dtype or prt.dim() != 2 or prt.shape[0] not in (9, 18) \
                     or prt.shape[1] != n or not prt.is_contiguous():

@@ -732,3 +732,61 @@ def test_resident_workgroup_cap_changes_nothing_but_time(dg, dtype, n):
         assert hip.lib.ol_set_tuning(_capi.TUNE_RECORD_WG_CAP, 9) != 0
     finally:
         hip.lib.ol_set_tuning(_capi.TUNE_RECORD_WG_CAP, 0)
+
+
+@pytest.mark.gpu
+def test_record_pool_is_a_good_citizen_of_the_device(dg):
+    """Round 6.  The pool's arenas are the library's own
+    hipMalloc blocks (`ol_arena_alloc`), so (a) `record_pool_stats()["placed_bytes"]` says what is
+    held, (b) arenas without a window went straight back -- at most the kept ones remain --
+    and torch's caching allocator was never emptied on the user's behalf, (c) a 20 GiB user
+    tensor allocated between two large traces still fits, (d) a pool nobody has used for
+    `idle_s` seconds gives everything back, and the loop that resumes gets a pool again on its
+    next trace but one."""
+    import gc
+    import time
+
+    from optiland_amd import engine as E
+    hip, table = dg
+    n, dtype = 2_000_000, torch.float32
+    px, py = _pupil(n, 63, dtype)
+    E.HipSystem.enable_record_pool(0)
+    gc.collect()
+    assert E.record_pool_stats()["placed_bytes"] == 0
+    keep = E._POOL_CONFIG["idle_s"]
+    E.HipSystem.enable_record_pool("auto")
+    try:
+        E._POOL_CONFIG["idle_s"] = 1.0
+        cached = torch.empty(64 << 20, dtype=torch.uint8, device=hip.device)
+        del cached                                    # a block in the USER's cache ...
+        reserved = torch.cuda.memory_reserved(hip.device)
+        first = hip.trace_generate(px, py, 0, field=(0.0, 0.7))         # one-off: plain
+        assert E.record_pool_stats()["placed_bytes"] == 0
+        second = hip.trace_generate(px, py, 0, field=(0.0, 0.7))        # a loop: the pool
+        stats = E.record_pool_stats()
+        free, total = torch.cuda.mem_get_info(hip.device)
+        if free + stats["placed_bytes"] >= total // 2:
+            assert len(stats["pools"]) == 1
+            kept = stats["pools"][0]["arena_bytes"]
+            assert stats["placed_bytes"] == kept            # probe arenas without a window: gone
+            assert kept <= 2 * (41 << 30)
+        assert torch.cuda.memory_reserved(hip.device) >= reserved   # ... is still there
+        user = torch.empty(20 << 30, dtype=torch.uint8, device=hip.device)   # (c)
+        third = hip.trace_generate(px, py, 0, field=(0.0, 0.7))
+        assert torch.equal(third.record[:, :, :n].nan_to_num(), first.record[:, :, :n].nan_to_num())
+        del user, first, second, third
+        gc.collect()
+        deadline = time.monotonic() + 20.0                # (d) the sweeper: idle_s / 4 steps
+        while E.record_pool_stats()["placed_bytes"] and time.monotonic() < deadline:
+            time.sleep(0.25)
+            E.release_record_pools(only_idle=True)
+        assert E.record_pool_stats()["placed_bytes"] == 0 and not E._RECORD_POOLS
+        again = hip.trace_generate(px, py, 0, field=(0.0, 0.7))         # "the second" again
+        if free + stats["placed_bytes"] >= total // 2:
+            assert len(E._RECORD_POOLS) == 1
+        del again
+    finally:
+        E._POOL_CONFIG["idle_s"] = keep
+        E.HipSystem.enable_record_pool(0)
+        gc.collect()
+        E.HipSystem.reset_record_pool()

@@ -7,6 +7,8 @@ field x pupil expansion order, vignetting handling, the polarised epilogue
 semantics (trace only) and the error texts.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -457,3 +459,100 @@ def test_polarised_trace_rays_refuses_unnormalised_directions():
     t.trace_rays([zero, zero, z, zero, zero, one, one], 0.55)                    # unit: fine
     with pytest.raises(ValueError, match="unit direction cosines"):
         t.trace_rays([zero, zero, z, zero, zero, one * 1.0005, one], 0.55)
+
+
+def test_hot_loop_hint_counts_launches_in_a_row(monkeypatch):
+    """Round 6: a big record block that is the target of launch after launch, enqueued without
+    a pause, is traced with `TRACE_FEW_WAVES` from the `after`-th launch on (two workgroups per
+    CU: faster once the clocks have settled, slower right after an idle gap --
+    profiles/r05_ab_wgcap.txt); an idle gap starts the count again; small blocks and
+    `after = 0` never."""
+    from optiland_amd import engine as E
+    from optiland_amd import system as S
+
+    class Block:
+        def __init__(self, ptr, nbytes):
+            self._ptr, self._n = ptr, nbytes
+            self.device = torch.device("cuda", 0)
+
+        def numel(self):
+            return self._n
+
+        def element_size(self):
+            return 1
+
+        def data_ptr(self):
+            return self._ptr
+
+    now = [100.0]
+    monkeypatch.setattr(E.time, "perf_counter", lambda: now[0])
+    monkeypatch.setitem(E._HOT_LOOP, "after", 4)
+    E._HOT_BLOCKS.clear()
+    try:
+        big, other, small = Block(1 << 40, 1 << 30), Block(2 << 40, 1 << 30), Block(3 << 40, 1 << 20)
+        got = []
+        for _ in range(7):
+            now[0] += 0.001
+            got.append(E._hot_loop_flag(big))
+        assert got == [0, 0, 0, 0] + [S.TRACE_FEW_WAVES] * 3      # launches 0..3 cold, then hot
+        assert E._hot_loop_flag(other) == 0 and E._hot_loop_flag(small) == 0
+        now[0] += 1.0                                              # the device may have gone idle
+        assert E._hot_loop_flag(big) == 0
+        for _ in range(4):
+            now[0] += 0.001
+            last = E._hot_loop_flag(big)
+        assert last == S.TRACE_FEW_WAVES
+        monkeypatch.setitem(E._HOT_LOOP, "after", 0)
+        assert E._hot_loop_flag(big) == 0
+        assert E._hot_loop_flag(None) == 0
+    finally:
+        E._HOT_BLOCKS.clear()
+
+
+def test_idle_record_pools_give_their_arenas_back():
+    """Round 6: a pool with no block lent out that nobody has asked for `idle_s` seconds is
+    dropped (`release_record_pools(only_idle=True)`, what the sweeper thread calls); the shape's
+    next request counts as "the second" again, so a loop that resumes gets its pool back at
+    once.  A pool with a block in a user's hands stays; an explicit release takes all."""
+    from optiland_amd import engine as E
+
+    class Pool:
+        def __init__(self, lent, age):
+            self.windows = [(None, 1), (None, 2)]
+            self.free = [0] if lent else [0, 1]
+            self.last_used = E.time.monotonic() - age
+            self.info = {"arena_bytes_kept": 7}
+
+        def idle(self):
+            return len(self.free) == len(self.windows)
+
+    E.HipSystem.reset_record_pool()
+    keep = E._POOL_CONFIG["idle_s"]
+    try:
+        E._POOL_CONFIG["idle_s"] = 10.0
+        E._RECORD_POOLS[(0, 1, torch.float32, 13)] = Pool(lent=False, age=100.0)   # idle: goes
+        E._RECORD_POOLS[(0, 2, torch.float32, 13)] = Pool(lent=True, age=100.0)    # lent: stays
+        E._RECORD_POOLS[(0, 3, torch.float32, 13)] = Pool(lent=False, age=1.0)     # recent: stays
+        stats = E.record_pool_stats()
+        assert [p["lent"] for p in stats["pools"]] == [0, 1, 0] and stats["idle_s"] == 10.0
+        assert E.release_record_pools(only_idle=True) == 1
+        assert [k[1] for k in E._RECORD_POOLS] == [2, 3]
+        assert E._SHAPE_SEEN[(0, 1, torch.float32, 13)] == 1
+        assert E.release_record_pools() == 2 and not E._RECORD_POOLS
+    finally:
+        E._POOL_CONFIG["idle_s"] = keep
+        E.HipSystem.reset_record_pool()
+
+
+def test_the_package_never_empties_the_users_allocator_cache():
+    """Round 6: arenas are the library's own hipMalloc blocks
+    (`ol_arena_alloc`); nothing under optiland_amd/ calls `torch.cuda.empty_cache()`."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "optiland_amd")
+    for base, _dirs, files in os.walk(root):
+        for name in files:
+            if name.endswith(".py"):
+                text = open(os.path.join(base, name)).read()
+                code = "\n".join(ln.split("#")[0] for ln in text.splitlines())
+                code = re.sub(r'"""[\s\S]*?"""', "", code)
+                assert "empty_cache(" not in code, os.path.join(base, name)

@@ -31,6 +31,19 @@ def variants():
         t.surfaces["max_iter"] = np.where(t.surfaces["geom_kind"] == S.GEOM_ZERNIKE, cap, 0)
         yield f"max_iter={cap}", t, None
     yield "max_iter=100 + update_intensity epilogue", copy.deepcopy(base), STATE
+    # one surface at a time switched to record-only (its surface_step is skipped, its row is
+    # still written): the dynamic cost of that surface INSIDE the real kernel -- spills, copies
+    # at the joins of the geometry / coating branches and all
+    for idx, what in ((1, "Zernike surface"), (2, "spherical surface"), (3, "image plane")):
+        t = copy.deepcopy(base)
+        t.surfaces["interaction"][idx] = S.INTERACT_RECORD_ONLY
+        yield f"surface {idx} ({what}) record-only", t, None
+    t = copy.deepcopy(base)
+    t.surfaces["coating_kind"][:] = S.COAT_NONE      # identity Jones: triads + PRT update, no Fresnel
+    yield "uncoated (polarised: identity Jones matrices)", t, None
+    t = copy.deepcopy(base)
+    t.surfaces["interaction"][1:] = S.INTERACT_RECORD_ONLY
+    yield "every surface record-only (prologue + rows + PRT stores)", t, None
 
 
 for dtype in (torch.float32, torch.float64):
@@ -49,3 +62,16 @@ for dtype in (torch.float32, torch.float64):
         print("VARIANT", str(dtype).split(".")[1], name, flush=True)
         hip.close()
         del rec, prt
+    # the same system without polarisation (coatings stripped, no PRT): what ALL of the
+    # polarised work costs -- another kernel (POLK = 0), same Newton family
+    t = copy.deepcopy(base)
+    t.surfaces["coating_kind"][:] = S.COAT_NONE
+    t.polarization = None
+    hip = HipSystem(t, dev)
+    rec = hip.alloc_record(n, dtype)
+    for _ in range(LAUNCHES):
+        hip.trace_generate(px, py, 0, field=(0.0, 1.0), record=rec, defer_status=True)
+    torch.cuda.synchronize()
+    print("VARIANT", str(dtype).split(".")[1], "unpolarised (no PRT at all)", flush=True)
+    hip.close()
+    del rec

@@ -142,6 +142,24 @@ with open("$O/r06_c5_valu_${TAG:-0}.txt", "w") as out:
         out.write(line + "\n")
 PY
       tail -2 $OUTD/a.log ;;
+    pcsamp)    # PC sampling of the C5 launch: where the issue slots really go (beta feature: every step time-boxed)
+      OUTD=$O/pcsamp_${TAG:-0}; rm -rf $OUTD; mkdir -p $OUTD
+      (timeout 60 rocprofv3-avail list --pc-sampling > $OUTD/avail.txt 2>&1; echo "rc=$?" >> $OUTD/avail.txt)
+      (cd /tmp && TMPDIR=/tmp timeout 240 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-method ${PCS_METHOD:-stochastic} \
+        --pc-sampling-unit ${PCS_UNIT:-cycles} --pc-sampling-interval ${PCS_INTERVAL:-1048576} --kernel-trace \
+        --output-format csv -d $OUTD/out -o c5 -- python $R/tools/gpu_c5_one.py > $OUTD/run.log 2>&1; echo "rc=$?" >> $OUTD/run.log)
+      tail -5 $OUTD/run.log; find $OUTD -type f | head; 
+      python - <<PY
+import csv, glob, collections
+for f in glob.glob("$O/pcsamp_${TAG:-0}/out/**/*pc_sampling*.csv", recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    print(f, len(rows), list(rows[0].keys()) if rows else None)
+PY
+      ;;
+    hot_loop)  # when the two-workgroup cap starts to pay in a loop (tools/gpu_hot_loop.py)
+      timeout 600 python tools/gpu_hot_loop.py > $O/r06_hot_loop_${TAG:-0}.txt 2>&1; cat $O/r06_hot_loop_${TAG:-0}.txt | tail -20 ;;
+    pool)      # the pool tests alone
+      timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -p no:cacheprovider -k "pool or placed" > $O/r06_pool_${TAG:-0}.log 2>&1; tail -5 $O/r06_pool_${TAG:-0}.log ;;
     bench)
       python bench.py ${BENCH_ARGS:-} > $O/r06_bench_${TAG:-default}.json 2> $O/r06_bench_${TAG:-default}.err
       tail -c 1500 $O/r06_bench_${TAG:-default}.json ;;
