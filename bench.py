@@ -651,7 +651,9 @@ def main():
     def make_record():
         if args.placement == "probe" and not args.plumbing_check \
                 and hasattr(hip, "alloc_record_placed"):
-            return hip.alloc_record_placed(n, dtype)
+            # (time-boxed: a rank whose arenas hold no fast window gives up after 2 s and
+            # writes into an ordinary block instead of keeping the others at the barrier)
+            return hip.alloc_record_placed(n, dtype, time_budget_s=2.0)
         return hip.alloc_record(n, dtype), None
 
     if args.mode == "record":
@@ -905,6 +907,17 @@ def main():
 
     kern_each = [a.elapsed_time(bb) for a, bb in evs]
     kern_ms = float(np.mean(kern_each)) if args.steps else float("nan")
+    # what every rank did, for rank 0's line (outside the timed region): its shard, where its
+    # record block lies and what its kernel took -- a slow rank is visible, not averaged away
+    mine = {"rank": rank, "rays": n, "kernel_ms": kern_ms,
+            "placement": None if placement is None else {
+                k: placement.get(k) for k in ("placed", "arenas_tried", "probes",
+                                              "probe_best_GBps", "probe_median_GBps",
+                                              "probe_seconds", "gave_up")}}
+    per_rank = [mine]
+    if have_pg:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     bw = device_bandwidth(device) if (rank == 0 and args.steps and not args.plumbing_check) \
         else None
     # Steady state, OUTSIDE the reported region: the same launch repeated until the part's
@@ -1052,6 +1065,7 @@ def main():
                                     ("double_gauss", "f32", 10_000_000)
                                     and args.mode in ("gen", "record") else None),
                 "rays_per_gpu": n,
+                "rays_per_rank": [r_["rays"] for r_ in per_rank],
                 "rays_total": job_rays,
                 "surfaces": S,
                 "mode": args.mode,
@@ -1097,6 +1111,8 @@ def main():
                 "kernel_us_each": [round(t * 1e3, 1) for t in kern_each[:64]],
                 "steady_state": steady,
                 "record_placement": placement,
+                "record_placement_ranks": [r_["placement"] for r_ in per_rank],
+                "kernel_ms_ranks": [r_["kernel_ms"] for r_ in per_rank],
                 "moved_bytes": moved_bytes,
                 "algorithmic_bytes": alg_bytes,
                 "achieved_algorithmic": alg_GBps,

@@ -193,6 +193,15 @@ __device__ __forceinline__ T vec_get(const typename VecOf<T, RPT>::type& v, int 
 #ifndef OL_SADDR
 #define OL_SADDR 1
 #endif
+// OL_RECORD_DIRECT (default on, round 6): record rows and PRT planes of the one-ray-per-lane
+// Newton / polarised kernels written without a copy of the ray and with scalar plane bases
+// (trace_kernel: the RECORD block and the PRT stores).  A/B knob.
+#ifndef OL_RECORD_DIRECT
+#define OL_RECORD_DIRECT 1
+#endif
+#ifndef OL_RECORD_ARGS_FRESH
+#define OL_RECORD_ARGS_FRESH 1
+#endif
 template <bool SADDR>
 struct RayIndexT {
   int64_t tile;   // wave-uniform
@@ -761,7 +770,10 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
       T* record;
       int64_t stride;
       uint32_t flags;
-      if constexpr (kFetchArgs) {
+      // (OL_RECORD_ARGS_FRESH: also in the polarised / Newton kernels that otherwise keep
+      // their arguments by value -- held across the surface body, the block's address and
+      // stride were SGPR-spilled and came back through 6-8 v_readlane per recorded row)
+      if constexpr (kFetchArgs || (OL_RECORD_ARGS_FRESH && RPT == 1 && (NR != 0 || POLK != 0))) {
         const auto ka = kernargs<T, TraceArgs<T>>();
         record = ka->a.record;
         stride = ka->a.record_stride;
@@ -775,6 +787,47 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
       if (s == first && (flags & kTraceRow0IsInput)) {
         // the caller generated the rays straight into row 0 of the record block
         // (the object surface only records its input): nothing to write
+      } else if constexpr (OL_RECORD_DIRECT && RPT == 1 && NV == 1 && (NR != 0 || POLK != 0)) {
+        // Round 6, the one-ray-per-lane Newton / polarised kernels (bound by vector issue): the
+        // row without a copy of the ray.  The state is global (before the first traced surface)
+        // or in the last traced surface's frame; unless that frame is rotated, global = local +
+        // origin -- three additions with a WAVE-UNIFORM offset that is -0 for a global state
+        // (x + -0 = x bit for bit, signed zeros and NaN included), and the other five planes go
+        // out of the ray's own registers.  Before: the selected frame's copy of all eight
+        // values was made first, ~10 moves per row on top of the 8 stores
+        // (profiles/r06_c5_valu.txt: 201 vector instructions per ray with NO surface traced).
+        bool rotated = false;
+        T ox = T(-0.0), oy = T(-0.0), oz = T(-0.0);
+        DevSurf<T> lt = last_traced;
+        if (!is_global) {
+          if constexpr (kFetch) lt = fetched_surface<T, TraceArgs<T>>(last_idx).surf();
+          rotated = (lt.flags & kSurfRotated) != 0;
+          if (!rotated) {
+            ox = lt.origin[0];
+            oy = lt.origin[1];
+            oz = lt.origin[2];
+          }
+        }
+        if (rotated) {
+          // (the marker keeps this rare tail from being MERGED with the one below: merged, the
+          // common path pays the copies into the registers the two tails would share)
+          Ray<T> g[1] = {to_global<T>(lt, r[0])};
+          asm volatile("s_nop 0 ; record row of a rotated frame");
+          store_rays<T, 1>(row, stride, base, cnt, g);
+          asm volatile("s_nop 0");
+        } else {
+          const T gx[1] = {r[0].x + ox}, gy[1] = {r[0].y + oy}, gz[1] = {r[0].z + oz};
+          const T dL[1] = {r[0].L}, dM[1] = {r[0].M}, dN[1] = {r[0].N}, di[1] = {r[0].i},
+                  dp[1] = {r[0].opd};
+          store_plane<T, 1>(row, base, cnt, gx);
+          store_plane<T, 1>(row + stride, base, cnt, gy);
+          store_plane<T, 1>(row + 2 * stride, base, cnt, gz);
+          store_plane<T, 1>(row + 3 * stride, base, cnt, dL);
+          store_plane<T, 1>(row + 4 * stride, base, cnt, dM);
+          store_plane<T, 1>(row + 5 * stride, base, cnt, dN);
+          store_plane<T, 1>(row + 6 * stride, base, cnt, di);
+          store_plane<T, 1>(row + 7 * stride, base, cnt, dp);
+        }
       } else {
         Ray<V> gv[NV];
         to_global_now(gv);
@@ -873,7 +926,14 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
     for (int e = 0; e < NPRT; ++e) {
 #pragma unroll
       for (int k = 0; k < RPT; ++k) tmp[k] = P[k].m[e];
-      store_plane<T, RPT>(late.prt + (int64_t)e * late.n, base, cnt, tmp);
+      // (the plane's base as a SCALAR pointer, said outright: left to itself the compiler
+      // folded e * n into the per-lane address -- a 64-bit multiply-add in vector registers
+      // for every one of the 9 / 18 stores, ~3.5 vector instructions each)
+      T* plane = late.prt + (int64_t)e * late.n;
+#if OL_RECORD_DIRECT
+      plane = refresh(plane);
+#endif
+      store_plane<T, RPT>(plane, base, cnt, tmp);
     }
   }
   if constexpr (EPI) {

@@ -683,7 +683,7 @@ class HipSystem:
 
     def alloc_record_placed(self, n: int, dtype, rows: int | None = None,
                             arena_bytes: int | None = None, min_gain: float = 0.04,
-                            max_arenas: int = 3):
+                            max_arenas: int = 3, time_budget_s: float | None = None):
         """A record block PLACED where this part writes it fastest -- for callers that reuse
         one block over many traces (`bench.py`, a sharded step loop, `GraphedTrace`).
 
@@ -700,7 +700,9 @@ class HipSystem:
         measured, profiles/r04_placement_attempts.txt): up to `max_arenas` are tried, each
         allocated while the earlier ones are still held; the others are released once the choice
         is made.  A plain allocation when no window is at least `min_gain` faster than
-        the median one.  Returns (record, info).  The view pins its arena: not for results
+        the median one.  `time_budget_s`: no further arena is tried once that much time has
+        gone into probing (`info["gave_up"]`; a sharded run does not wait for its slowest
+        rank's third arena).  Returns (record, info).  The view pins its arena: not for results
         that are handed to a user (those come from `alloc_record`, i.e. an ordinary
         allocation or, when `enable_record_pool` is on, a window LENT by a `RecordPool`)."""
         rows = self.num_surfaces if rows is None else rows
@@ -718,7 +720,12 @@ class HipSystem:
             return self._probe_windows(arena, size, need, b, rows * 8)
 
         held, coarse_ms, chosen, probes = [], [], None, 0
+        t_start = time.perf_counter()
         for _attempt in range(max(1, int(max_arenas))):
+            if held and time_budget_s is not None \
+                    and time.perf_counter() - t_start > float(time_budget_s):
+                info["gave_up"] = True
+                break
             free, _total = torch.cuda.mem_get_info(self.device)
             size = min(arena_bytes, int(free * 0.45)) // (2 << 20) * (2 << 20)
             if size < 2 * need:
@@ -745,6 +752,7 @@ class HipSystem:
                     probe_best_GBps=need / (t_best * 1e-3) / 1e9,
                     probe_median_GBps=need / (med * 1e-3) / 1e9)
         placed = t_best <= med * (1.0 - min_gain)
+        info["probe_seconds"] = time.perf_counter() - t_start
         arena = held[which] if placed else None
         del held   # arenas that were not chosen go back to the device (one hipFree each)
         if not placed:

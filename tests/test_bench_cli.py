@@ -101,3 +101,32 @@ def test_single_rank_line_has_the_contract_keys():
                   "roofline", "cpu_baseline"):
             assert k in d, (mode, k)
         assert d["config"]["mode"] == mode and d["vs_baseline"] is None
+
+
+def test_eight_rank_plumbing_check_shards_a_total_that_does_not_divide():
+    """The launch form the driver uses for its scaling record, at the node's full width: 8 ranks
+    (gloo, host build of the kernel source -- TEST ONLY), the strong-scaled C3 configuration
+    with a total the ranks do not divide, the literal all-gather of image-plane hits; and the
+    weak-scaled headline configuration with the reduce-first exchange.  Rank 0 prints exactly
+    one line; every rank's shard and placement are in it."""
+    import pytest
+    from tests import _hostmath
+    if not _hostmath.available():
+        pytest.skip("hipcc (used as host C++ compiler) missing")
+    out = _run(["--plumbing-check", "--gpus", "8", "--config", "c3", "--total-rays", "20003",
+                "--steps", "2", "--warmup", "1", "--exchange", "gather"])
+    assert out.returncode == 0, out.stderr[-1200:]
+    d = _json_line(out)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["dtype"] == "f64"
+    assert d["config"]["rays_total"] == 20003
+    shards = d["config"]["rays_per_rank"]
+    assert len(shards) == 8 and sum(shards) == 20003 and max(shards) - min(shards) <= 1
+    assert shards == sorted(shards, reverse=True)          # contiguous shards, the long ones first
+    assert "all-gather of image-plane hits" in d["exchange"]["kind"]
+    assert len(d["roofline"]["record_placement_ranks"]) == 8
+    out = _run(["--plumbing-check", "--gpus", "8", "--rays", "700", "--steps", "2",
+                "--warmup", "1"])
+    assert out.returncode == 0, out.stderr[-1200:]
+    d = _json_line(out)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["rays_total"] == 5600
+    assert d["config"]["rays_per_rank"] == [700] * 8 and "spot-moment" in d["exchange"]["kind"]
