@@ -101,8 +101,15 @@ def _front(optic, wavelength, need_fp64=False, final_propagation=False, recorded
         # else keeps the reference's own analysis code on top of the drop-in's trace.
         return None
     if need_fp64 and front.dtype != torch.float64:
-        _why("front", "fp32 wavefront")
-        return None
+        # a float32 backend (round 6): the wavefront kernels compute in fp64 and the seam hands
+        # the maps over in the backend's precision (`_out`).  (Until round 6 such an optic kept
+        # the reference's own fp32 chain: an OPD whose last two digits are rounding noise of
+        # path lengths 2e5 waves long.)
+        try:
+            front, table = comp._front_for(wavelength, wavefront_fp64=True)
+        except UnsupportedSystem as exc:
+            _why("front", f"unsupported system: {exc}")
+            return None
     if not hasattr(front.engine, "trace_spot"):
         return None
     comp.last_path = "hip"  # (introspection, as after an intercepted Optic.trace)
@@ -121,10 +128,24 @@ def _final_propagation(optic, table, wavelength) -> dict:
             "last_absorb": (4.0 * math.pi * k / float(wavelength)) * 1e3 if k > 0 else 0.0}
 
 
+def _out(front, t):
+    """A result of a fused wavefront launch in the precision the backend works in (a float32
+    backend is served by the fp64 kernels: `_front(need_fp64=True)`)."""
+    dt = getattr(front, "_hip_out_dtype", None)
+    if dt is None or not isinstance(t, torch.Tensor) or not t.is_floating_point():
+        return t
+    return t.to(dt)
+
+
 def _register(optic, front, table, launch):
     from . import integration as ig
 
-    ig.register_pending_record(optic, table, front.engine, front.dtype, launch)
+    dt = getattr(front, "_hip_out_dtype", None)
+    if dt is not None:
+        # (the surfaces' recorded arrays, if anybody reads them, are the backend's precision)
+        hx, hy, px, py, vig, w, flag = launch
+        launch = (hx, hy, px.to(dt), py.to(dt), vig, w, flag)
+    ig.register_pending_record(optic, table, front.engine, dt or front.dtype, launch)
 
 
 def _scalar(v):
@@ -430,6 +451,11 @@ def _fused_wavefront(self, field, wavelength):
     can_dev = getattr(front.engine, "can_wavefront_reference", None)
     if can_dev is not None and can_dev():
         return _fused_wavefront_device(self, front, table, hx, hy, w, dx, dy)
+    if getattr(front, "_hip_out_dtype", None) is not None:
+        # (an engine without the device-resident reference -- libraries before ABI 6, the
+        # tests' stand-in -- would take the chief ray from a float32 trace: not worth a sphere)
+        _why("opd", "fp32 wavefront on an engine without ol_wavefront_reference")
+        return None
     # 1. chief ray alone (strategy.py:176-179) -- through Optic.trace_generic, i.e. the
     # drop-in's own one-ray launch; kept on the strategy like the reference does
     self._chief_ray = chief = self.optic.trace_generic(hx, hy, Px=0.0, Py=0.0, wavelength=w)
@@ -466,9 +492,11 @@ def _fused_wavefront(self, field, wavelength):
     _register(self.optic, front, table, (hx, hy, px, py, front._vig_scalar(hx, hy), w, 0))
     from optiland.wavefront.wavefront_data import WavefrontData
 
-    data = WavefrontData(pupil_x=pupil[0], pupil_y=pupil[1], pupil_z=pupil[2], opd=opd,
-                         intensity=inten, radius=R)
+    data = WavefrontData(pupil_x=_out(front, pupil[0]), pupil_y=_out(front, pupil[1]),
+                         pupil_z=_out(front, pupil[2]), opd=_out(front, opd),
+                         intensity=_out(front, inten), radius=R)
     data._hip_fused = True  # lets the FFT-PSF seam recognise device data it can scatter
+    _keep_fp64(front, data, opd, inten)
     return data
 
 
@@ -537,10 +565,12 @@ def _fused_wavefront_device(self, front, table, hx, hy, w, dx, dy):
     # `radius`: the reference says float (strategy.py:248 `.item()`); here a 0-d device tensor
     # that becomes that float when somebody reads the attribute (the Huygens PSFs do,
     # psf/huygens_fresnel.py:283-300; OPD maps, Zernike fits and the FFT PSF never do)
-    data = _device_wavefront_data()(pupil_x=pupil[0], pupil_y=pupil[1], pupil_z=pupil[2],
-                                    opd=opd, intensity=inten,
+    data = _device_wavefront_data()(pupil_x=_out(front, pupil[0]), pupil_y=_out(front, pupil[1]),
+                                    pupil_z=_out(front, pupil[2]), opd=_out(front, opd),
+                                    intensity=_out(front, inten),
                                     radius=math.inf if planar else ref[3])
     data._hip_fused = True
+    _keep_fp64(front, data, opd, inten)
     return data
 
 
@@ -590,7 +620,7 @@ def _fused_fitted(self, field, wavelength):
     kind = _fitted_kind(type(self))
     if kind is None:
         return None
-    got = _front(self.optic, w, need_fp64=True)
+    got = _front(self.optic, w, need_fp64=True, final_propagation=True)
     if got is None:
         return None
     front, table = got
@@ -618,6 +648,17 @@ def _fused_fitted(self, field, wavelength):
     res = eng.trace_generate(px, py, wl, field=(hx, hy), vig=vig, record=True,
                              record_first=eng.num_surfaces - 1, defer_status=True)
     x, y, z, L, M, N, inten, opd_in = res.rows(res.last)
+    last = _final_propagation(self.optic, table, w)
+    if last:
+        # `Optic.trace` ends with a propagation by the last surface's thickness
+        # (real_ray_tracer.py:104-110, homogeneous.py:39-53): the fitted strategies read the
+        # RETURNED rays (strategy.py:319), i.e. positions moved on by t along the ray and the
+        # intensity after t of the last medium -- three elementwise operations on the recorded
+        # row (round 6; until then such an optic kept the reference's own chain)
+        t = last["last_thickness"]
+        x, y, z = x + t * L, y + t * M, z + t * N
+        if last["last_absorb"] > 0.0:
+            inten = inten * math.exp(-last["last_absorb"] * t)
     r8 = [x, y, z, L, M, N, opd_in, inten]
     ref = eng.wavefront_fit(kind, params, r8, px, py, trim_std=trim, flavour="torch",
                             planar=planar)
@@ -636,11 +677,20 @@ def _fused_fitted(self, field, wavelength):
     if kind == "best_fit" and not planar:
         self.center = tuple(float(v) for v in host[0:3])  # strategy.py:581
     _register(self.optic, front, table, (hx, hy, px, py, vig, w, 0))
-    data = _device_wavefront_data()(pupil_x=pupil[0], pupil_y=pupil[1], pupil_z=pupil[2],
-                                    opd=opd, intensity=inten,
+    data = _device_wavefront_data()(pupil_x=_out(front, pupil[0]), pupil_y=_out(front, pupil[1]),
+                                    pupil_z=_out(front, pupil[2]), opd=_out(front, opd),
+                                    intensity=_out(front, inten),
                                     radius=math.inf if planar else float(host[3]))
     data._hip_fused = True
+    _keep_fp64(front, data, opd, inten)
     return data
+
+
+def _keep_fp64(front, data, opd, inten):
+    """A float32 backend's map also keeps what the kernel computed (fp64): the FFT-PSF seam
+    scatters THAT into the padded grid (`_fused_pupils`) and rounds once, at the end."""
+    if getattr(front, "_hip_out_dtype", None) is not None:
+        data.__dict__["_hip_fp64"] = (opd, inten)
 
 
 _DEVICE_WAVEFRONT_DATA = None
@@ -723,10 +773,14 @@ def _fused_pupils(self, be):
     cell = cells.to(device=dev, dtype=torch.int32)
     before = (gsz - n) // 2
     padded, views = [], []
+    out_dt = getattr(front, "_hip_out_dtype", None)
     for d in datas:
-        if d.opd.numel() != cell.numel() or d.opd.dtype != torch.float64:
+        opd, inten = d.__dict__.get("_hip_fp64") or (d.opd, d.intensity)
+        if opd.numel() != cell.numel() or opd.dtype != torch.float64:
             return None
-        grid = front.engine.pupil_fill(d.opd.contiguous(), d.intensity.contiguous(), cell, n, gsz)
+        grid = front.engine.pupil_fill(opd.contiguous(), inten.contiguous(), cell, n, gsz)
+        if out_dt == torch.float32:
+            grid = grid.to(torch.complex64)   # (what `be.exp(1j * ...)` of a float32 backend is)
         padded.append(grid)
         views.append(grid[before:before + n, before:before + n])
     self._hip_padded = (padded, views)

@@ -149,6 +149,9 @@ class _Arena:
             self.lib.ol_arena_free(C.c_void_p(ptr))
             with _Arena._lock:
                 _Arena.live_bytes -= self.nbytes
+            # the windows that lay in it are no windows any more: the driver hands these
+            # addresses to the next allocation (torch's, typically), which is an ORDINARY block
+            _forget_placed(self.device, ptr, ptr + self.nbytes)
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
 
@@ -207,6 +210,14 @@ def _note_placed(device, ptr: int, nbytes: int) -> None:
         _PLACED_WINDOWS.move_to_end(key)
         while len(_PLACED_WINDOWS) > _PLACED_MAX:
             _PLACED_WINDOWS.popitem(last=False)
+
+
+def _forget_placed(device, lo: int, hi: int) -> None:
+    """Drop the placed windows that start in [lo, hi) on `device` (their arena has been freed)."""
+    dev = getattr(device, "index", None) or 0
+    with _PLACED_LOCK:
+        for key in [k for k in _PLACED_WINDOWS if k[0] == dev and lo <= k[1] < hi]:
+            del _PLACED_WINDOWS[key]
 
 
 def _few_waves_flag(rec) -> int:

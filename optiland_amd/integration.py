@@ -714,14 +714,22 @@ def _make_tracer_class():
             while len(self._hip_memo) > _MAX_MEMO:
                 self._hip_memo.popitem(last=False)
 
-        def _front_for(self, wavelength, tok=None, keep=None):
+        def _front_for(self, wavelength, tok=None, keep=None, wavefront_fp64=False):
             """The stand-alone device tracer (`tracer.HipRayTracer`) on the current table in
-            the backend's precision: it owns the whole device-side call sequence."""
+            the backend's precision: it owns the whole device-side call sequence.
+            `wavefront_fp64`: for the wavefront seams of a float32 backend -- a front that
+            computes in fp64 (an OPD in waves is a difference of path lengths 1e5 waves long:
+            the fused wavefront kernels are fp64 only) and says in
+            `_hip_out_dtype` what precision its results are handed over in."""
             eng, table, fronts = self._entry_for(wavelength, tok, keep)
             dtype = self._dtype()
-            front = fronts.get(dtype)
+            key = dtype
+            if wavefront_fp64 and dtype != torch.float64:
+                key, dtype = ("wavefront", dtype), torch.float64
+            front = fronts.get(key)
             if front is None:
-                front = fronts[dtype] = _tracer.HipRayTracer(table, dtype=dtype, engine=eng)
+                front = fronts[key] = _tracer.HipRayTracer(table, dtype=dtype, engine=eng)
+                front._hip_out_dtype = key[1] if isinstance(key, tuple) else None
             front.ray_aiming_config = self.ray_aiming_config
             front.lazy_records = self._hip_lazy
             return front, table

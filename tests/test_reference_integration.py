@@ -420,9 +420,9 @@ def test_trace_generic_input_matrix_matches_the_reference(hip_on_cpu):
     tensor pupil and the reverse, rays on the pupil rim -- gives the reference's result, and
     every range violation (field before pupil, NaN included) the reference's ValueError.
     Where the reference only fails by accident (size mismatch: a RuntimeError out of a
-    tensor op; empty input: `stack expects a non-empty TensorList`; numpy arrays / lists:
-    TypeError) the drop-in is a superset: a ValueError naming the problem, an empty result,
-    and the arrays accepted."""
+    tensor op; empty input: `stack expects a non-empty TensorList`; numpy arrays: TypeError)
+    the drop-in is a superset: a ValueError naming the problem, an empty result, and the arrays
+    accepted.  Python lists raise the reference's own TypeError."""
     import torch
     be = hip_on_cpu
     from optiland.samples.objectives import CookeTriplet
@@ -479,9 +479,14 @@ def test_trace_generic_input_matrix_matches_the_reference(hip_on_cpu):
     assert both[1] == "ValueError" and both[2].startswith("shape mismatch: objects cannot be")
     empty = run(hip_lens, (0.0, 0.5, T([]), T([])))
     assert empty[0] == "ok" and empty[1].size == 0
-    arr = run(hip_lens, (0.0, 0.5, np.array([0.1, -0.2]), [0.3, 0.2]))
+    # one-dimensional numpy arrays are taken (the NumPy backend's own input type) ...
+    arr = run(hip_lens, (0.0, 0.5, np.array([0.1, -0.2]), np.array([0.3, 0.2])))
     want = run(ref_lens, (0.0, 0.5, T([0.1, -0.2]), T([0.3, 0.2])))
     np.testing.assert_allclose(arr[1], want[1], rtol=1e-9)
+    # ... Python lists are NOT, like in the reference (round 6: rounds 2-5 flattened them; the
+    # reference dies in `x >= -1`, tests/test_trace_generic_validation.py)
+    lst = (0.0, 0.5, [0.1, -0.2], [0.3, 0.2])
+    assert run(hip_lens, lst) == run(ref_lens, lst) and run(hip_lens, lst)[1] == "TypeError"
 
 
 def test_dropin_keeps_device_tables_per_wavelength(hip_on_cpu):

@@ -16,6 +16,12 @@ sys.path.insert(0, ROOT)
 from optiland_amd import build as B  # noqa: E402
 
 VARIANTS = {
+    # round 6 (names start with "o": the ones .gpurunignore lets travel): this round's changes
+    # to the one-ray-per-lane Newton / polarised kernels switched off, together and one by one
+    "o6_off": ["-DOL_PRT_PACKED=0", "-DOL_RECORD_DIRECT=0", "-DOL_RECORD_ARGS_FRESH=0"],
+    "o6_prt_scalar": ["-DOL_PRT_PACKED=0"],
+    "o6_rec_copy": ["-DOL_RECORD_DIRECT=0"],
+    "o6_rec_args_held": ["-DOL_RECORD_ARGS_FRESH=0"],
     # BASELINE.json north_star: "surface coefficients staged in LDS" 
     "lds_table": ["-DOL_TABLE_IN_LDS=1"],
     # store flavour: plain stores for the one-ray-per-lane layout,

@@ -160,6 +160,14 @@ PY
       timeout 600 python tools/gpu_hot_loop.py > $O/r06_hot_loop_${TAG:-0}.txt 2>&1; cat $O/r06_hot_loop_${TAG:-0}.txt | tail -20 ;;
     pool)      # the pool tests alone
       timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -p no:cacheprovider -k "pool or placed" > $O/r06_pool_${TAG:-0}.log 2>&1; tail -5 $O/r06_pool_${TAG:-0}.log ;;
+    clock_transient)  # effective engine clock per launch (GRBM_GUI_ACTIVE / duration) + the part's own sysfs account
+      OUTD=$O/clock_transient_${TAG:-0}; rm -rf $OUTD; mkdir -p $OUTD
+      (cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUTD/a -o ct -- \
+        python $R/tools/gpu_clock_transient.py > $OUTD/run.log 2>&1; echo "rc=$?" >> $OUTD/run.log)
+      python $R/tools/clock_transient_report.py $OUTD > $O/r06_clock_transient_${TAG:-0}.txt 2>&1; head -60 $O/r06_clock_transient_${TAG:-0}.txt ;;
+    ab6)       # in-process A/B of this round's kernel changes: ARMS, CONFIGS [AB_EXTRA=--placed]
+      timeout 900 python tools/ab_inproc.py --arms ${ARMS:-product,o6_off} --configs ${CONFIGS:-zf_f32_gen,zf_f64_gen,rc_f32_gen} \
+        --rounds ${ROUNDS:-2} ${AB_EXTRA:-} >> $O/r06_ab_${TAG:-0}.txt 2>&1; tail -${AB_TAIL:-40} $O/r06_ab_${TAG:-0}.txt ;;
     bench)
       python bench.py ${BENCH_ARGS:-} > $O/r06_bench_${TAG:-default}.json 2> $O/r06_bench_${TAG:-default}.err
       tail -c 1500 $O/r06_bench_${TAG:-default}.json ;;
