@@ -48,7 +48,8 @@ from .packer import UnsupportedSystem
 _ORIG: dict = {}
 STATS = {"spot": 0, "spot_fallback": 0, "ee": 0, "ee_fallback": 0, "opd": 0, "opd_fallback": 0,
          "pupil": 0, "pupil_fallback": 0, "opd_init": 0, "opd_init_fallback": 0,
-         "dist": 0, "dist_fallback": 0, "opd_fit": 0, "opd_fit_fallback": 0, "spot_grid": 0}
+         "dist": 0, "dist_fallback": 0, "opd_fit": 0, "opd_fit_fallback": 0, "spot_grid": 0,
+         "spot_radius": 0}
 
 
 def _why(seam, reason):
@@ -248,7 +249,9 @@ def _spot_grid(self):
             return None
         wl, wv = front._wavelength_index(w)
         for fi, (hx, hy) in enumerate(fields):
-            front._validate_normalized_coordinates(hx, hy, "field")
+            if wi == 0 and not (-1.0 <= hx <= 1.0 and -1.0 <= hy <= 1.0):
+                # real_ray_tracer.py:156-173 (host scalars: decided here, once per field)
+                raise ValueError("Normalized field coordinates must be within (-1, 1)")
             vx, vy = front._vig_scalar(hx, hy)
             cells.append((fi, wi, (hx, hy, vx, vy, 0.0, 0.0, wl, front.engine), wv, front, table))
     from optiland.analysis.spot_diagram.core import SpotData
@@ -263,9 +266,21 @@ def _spot_grid(self):
         | (_capi.SPOT_POLARIZED_OK if polarised else 0)
     if any(getattr(c[2][7], "_handle", True) is None for c in cells):
         return None   # an engine of the grid was closed in the meantime: the per-cell loop
-    mom, hits = front.engine.trace_spot_batch(px, py, [c[2] for c in cells], hits=True,
-                                              flags=flags)
-    counts = mom[:, 0].cpu().numpy().astype(np.int64)   # the ONE read-back of the grid
+    eng = front.engine
+    status_t = getattr(eng, "_status", None)
+    if status_t is not None:
+        # the ONE read-back of the grid: the per-cell counts and the launch's status word in the
+        # same transfer (round 6: they were two synchronisations)
+        status_t.zero_()
+        mom, hits = eng.trace_spot_batch(px, py, [c[2] for c in cells], hits=True, flags=flags,
+                                         check_status=False)
+        both = torch.cat([mom[:, 0], status_t.to(torch.float64)]).cpu().numpy()
+        front.last_status = int(both[-1])
+        eng.raise_for_status(front.last_status)
+        counts = both[:-1].astype(np.int64)
+    else:   # (engines that raise eagerly: the tests' oracle stand-in)
+        mom, hits = eng.trace_spot_batch(px, py, [c[2] for c in cells], hits=True, flags=flags)
+        counts = mom[:, 0].cpu().numpy().astype(np.int64)
     xs, ys, ins = hits[:, 0, :n], hits[:, 1, :n], hits[:, 2, :n]
     clipped = masked and bool((counts != n).any())
     if clipped:
@@ -295,11 +310,74 @@ def _spot_grid(self):
         if fi == len(fields) - 1 and wi == len(wls) - 1:
             last = (fr, tb, (cell[0], cell[1], px, py, (cell[2], cell[3]), wv, 0))
     STATS["spot_grid"] += 1
+    # what `rms_spot_radius` / `geometric_spot_radius` need to work on the WHOLE grid at once
+    # (`_spot_radius`): the (cells, n) blocks the SpotData objects are views of -- only when
+    # every cell is such a view (nothing clipped, no local shift applied)
+    shifted = coordinates == "local" and not tilted_local and (ox != 0.0 or oy != 0.0)
+    self.__dict__["_hip_grid"] = None if (clipped or shifted or not masked) else {
+        "xs": xs, "ys": ys, "fields": len(fields), "wls": len(wls),
+        "objs": [[data[fi][wi] for wi in range(len(wls))] for fi in range(len(fields))]}
     if last is not None:
         # what the LAST Optic.trace() of the reference's loop would have left on the Surface
         # objects, produced on first read
         _register(self.optic, last[0], last[1], last[2])
     return data
+
+
+def _spot_radius(self, kind):
+    """core.py:342-370 (`geometric_spot_radius`, `rms_spot_radius`) for ALL cells of the grid in
+    one pass over the (cells, n) blocks `ol_trace_spot_batch` wrote -- when `self.data` still IS
+    what `_spot_grid` handed out.  The centres are the reference's own
+    (`_get_reference_centers`: chief rays through the drop-in, or centroids).  The reference's
+    form: a deep copy of every cell (`_center_spots`), then five elementwise launches per cell
+    -- ~100 launches for a 3 x 3 grid, 1.3 of the 2.9 ms of `SpotDiagram(400 rings)` +
+    `rms_spot_radius()` on the MI355X (profiles/r05_spotdiag.json)."""
+    g = self.__dict__.get("_hip_grid")
+    if g is None:
+        return None
+    data = self.data
+    F, W = g["fields"], g["wls"]
+    if len(data) != F or any(len(row) != W for row in data):
+        return None
+    for fi in range(F):
+        for wi in range(W):
+            sd, mine = data[fi][wi], g["objs"][fi][wi]
+            if sd is not mine or sd.x.data_ptr() != g["xs"][wi * F + fi].data_ptr() \
+                    or sd.y.data_ptr() != g["ys"][wi * F + fi].data_ptr() \
+                    or sd.x.numel() != g["xs"].shape[1]:
+                return None     # somebody replaced a cell or its arrays: the reference's code
+    centers = self._get_reference_centers(data)
+    cx = torch.stack([c[0].reshape(()) for c in centers]).to(g["xs"].dtype)
+    cy = torch.stack([c[1].reshape(()) for c in centers]).to(g["xs"].dtype)
+    n = g["xs"].shape[1]
+    dx = g["xs"].view(W, F, n) - cx.view(1, F, 1)     # (cells are wavelength-major)
+    dy = g["ys"].view(W, F, n) - cy.view(1, F, 1)
+    r2 = dx * dx + dy * dy
+    # (sqrt is monotone: the largest radius is the root of the largest squared radius)
+    out = torch.sqrt(r2.mean(dim=2) if kind == "rms" else r2.amax(dim=2))
+    rows = out.t().unbind(0)                          # per field: (W,) views
+    STATS["spot_radius"] += 1
+    return [list(row.unbind(0)) for row in rows]
+
+
+def _spot_rms_spot_radius(self):
+    out = None
+    if isinstance(getattr(self, "data", None), list):
+        try:
+            out = _spot_radius(self, "rms")
+        except (AttributeError, RuntimeError, TypeError):
+            out = None
+    return out if out is not None else _ORIG["spot_rms"](self)
+
+
+def _spot_geometric_spot_radius(self):
+    out = None
+    if isinstance(getattr(self, "data", None), list):
+        try:
+            out = _spot_radius(self, "geometric")
+        except (AttributeError, RuntimeError, TypeError):
+            out = None
+    return out if out is not None else _ORIG["spot_geo"](self)
 
 
 def _wavefront_generate_data(self):
@@ -902,6 +980,10 @@ _SEAMS = {
              "_spot_generate_field_data"),
     "spot_data": ("optiland.analysis.spot_diagram.core", "SpotDiagram", "_generate_data",
                   ("self",), "_spot_generate_data"),
+    "spot_rms": ("optiland.analysis.spot_diagram.core", "SpotDiagram", "rms_spot_radius",
+                 ("self",), "_spot_rms_spot_radius"),
+    "spot_geo": ("optiland.analysis.spot_diagram.core", "SpotDiagram", "geometric_spot_radius",
+                 ("self",), "_spot_geometric_spot_radius"),
     "ee": ("optiland.analysis.encircled_energy", "EncircledEnergy", "_generate_field_data",
            ("self", "field", "wavelength", "num_rays", "distribution", "coordinates"),
            "_ee_generate_field_data"),

@@ -953,3 +953,36 @@ def test_fitted_strategies_on_an_optic_whose_last_surface_has_a_thickness(seams,
     for a, b in zip(got[2:5], want[2:5]):
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-7)
     np.testing.assert_allclose(got[5], want[5], rtol=1e-9)
+
+
+@pytest.mark.parametrize("reference", ["chief_ray", "centroid"])
+def test_spot_radii_over_the_whole_grid_at_once(seams, reference, request):
+    """Round 6: `rms_spot_radius` / `geometric_spot_radius` of a
+    `SpotDiagram` whose data still are the blocks the grid launch wrote: one pass over the
+    (cells, n) blocks with the reference's own centres, instead of a deep copy and five
+    elementwise launches per cell.  Same numbers; a cell somebody replaced sends the call back
+    to the reference's own method."""
+    be, stats = seams
+    if "oracle" in request.node.name:
+        pytest.skip("the oracle-backed stand-in has no grid launch")
+    from optiland import analysis
+
+    def run(lens):
+        s = analysis.SpotDiagram(lens, num_rings=5, reference=reference)
+        return (np.array([[float(_np(be, v)) for v in f] for f in s.rms_spot_radius()]),
+                np.array([[float(_np(be, v)) for v in f] for f in s.geometric_spot_radius()]))
+
+    want = _numpy_reference(be, _cooke, run)
+    before = stats["spot_radius"]
+    got = run(_cooke())
+    assert stats["spot_radius"] == before + 2 and stats["spot_grid"] >= 1
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-11)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-11)
+    # a caller that edits the data gets the reference's own arithmetic on what it left there
+    s = analysis.SpotDiagram(_cooke(), num_rings=5, reference=reference)
+    cell = s.data[1][0]
+    s.data[1][0] = type(cell)(x=cell.x * 2.0, y=cell.y, intensity=cell.intensity)
+    before = stats["spot_radius"]
+    edited = s.rms_spot_radius()
+    assert stats["spot_radius"] == before
+    assert float(_np(be, edited[1][0])) > 1.2 * got[0][1][0]

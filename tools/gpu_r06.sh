@@ -70,7 +70,7 @@ for ln in open("gpurun_out/r06_kernel_table.txt"):
 PY
       ;;
     spotdiag)  # the reference's SpotDiagram through the seams: one launch per grid vs per cell
-      timeout 600 python tools/gpu_r06_spotdiag.py > $O/r06_spotdiag.txt 2>&1; tail -5 $O/r06_spotdiag.txt | cut -c1-600 ;;
+      timeout 600 python tools/gpu_spotdiag.py > $O/r06_spotdiag.txt 2>&1; tail -5 $O/r06_spotdiag.txt | cut -c1-600 ;;
     prof)      # rocprofv3 stats + PMC passes of the BASELINE configurations (tools/collect_profiles.py r06)
       rocm-smi --showserial > $O/r06_box.txt 2>&1
       bash tools/gpu_prof.sh r06_dg_f32_gen > $O/r06_prof.log 2>&1
@@ -168,6 +168,17 @@ PY
     ab6)       # in-process A/B of this round's kernel changes: ARMS, CONFIGS [AB_EXTRA=--placed]
       timeout 900 python tools/ab_inproc.py --arms ${ARMS:-product,o6_off} --configs ${CONFIGS:-zf_f32_gen,zf_f64_gen,rc_f32_gen} \
         --rounds ${ROUNDS:-2} ${AB_EXTRA:-} >> $O/r06_ab_${TAG:-0}.txt 2>&1; tail -${AB_TAIL:-40} $O/r06_ab_${TAG:-0}.txt ;;
+    cycles_ab) # GRBM_GUI_ACTIVE per launch of the product against a variant library: cycles, not time (the clock moves)
+      for arm in product ${VARIANT:-o6_off}; do
+        OUTD=$O/cycles_${arm}; rm -rf $OUTD; mkdir -p $OUTD
+        if [ $arm != product ]; then export OPTILAND_HIP_LIBRARY=$R/optiland_amd/lib/variant_${arm}.so; else unset OPTILAND_HIP_LIBRARY; fi
+        (cd /tmp && TMPDIR=/tmp CONFIGS=${CONFIGS:-zf_f32,zf_f64} ROUNDS=2 LAUNCHES=40 timeout 600 \
+          rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUTD/a -o ct -- \
+          python $R/tools/gpu_clock_transient.py > $OUTD/run.log 2>&1; echo "rc=$?" >> $OUTD/run.log)
+        python $R/tools/clock_transient_report.py $OUTD > $O/r06_cycles_${arm}.txt 2>&1
+        echo "--- $arm"; grep -A3 "^## " $O/r06_cycles_${arm}.txt | grep -v "^launch" | head -40
+        awk '/^## /{name=$2" "$3" "$4} /^ +3[0-9] /{print name, $0}' $O/r06_cycles_${arm}.txt | head -40
+      done; unset OPTILAND_HIP_LIBRARY ;;
     bench)
       python bench.py ${BENCH_ARGS:-} > $O/r06_bench_${TAG:-default}.json 2> $O/r06_bench_${TAG:-default}.err
       tail -c 1500 $O/r06_bench_${TAG:-default}.json ;;

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""GPU box, round 5: the reference's `SpotDiagram` / `EncircledEnergy` through the analysis seams,
+"""GPU box (rounds 5-6): the reference's `SpotDiagram` / `EncircledEnergy` through the analysis seams,
 the fields x wavelengths grid as ONE launch (`ol_trace_spot_batch`) against one launch per cell
 (round 4's seam): wall clock per construction, 6 and 400 rings, fp32 and fp64, and where the
-time of the small case goes (cProfile).  Writes gpurun_out/r05_spotdiag.json / .txt."""
+time of the small case goes (cProfile).  Writes gpurun_out/r06_spotdiag.json / .txt."""
 import cProfile
 import io
 import json
@@ -77,7 +77,7 @@ def main():
             print(s.getvalue()[:6000])
         integration.disable()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r05_spotdiag.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r06_spotdiag.json"), "w") as f:
         json.dump(doc, f, indent=1)
 
 
