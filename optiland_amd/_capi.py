@@ -233,7 +233,7 @@ def bind(lib, path: str = "?"):
     lib.ol_pupil_fill.argtypes = [i32, i64, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     have = lib.ol_abi_version()
     if have == 5 and os.environ.get("OPTILAND_HIP_ALLOW_ABI5") == "1":
-        # A/B runs against the round-2 library (tools/gpu_ab_r03.sh): ABI 5 lacks
+        # A/B runs against the round-2 library (tools/gpu_r06.sh cycles_ab / ab6): ABI 5 lacks
         # ol_trace_generate and the record_first_surface extra; the engine takes the
         # two-launch path when the symbol is missing
         return lib

@@ -202,6 +202,9 @@ __device__ __forceinline__ T vec_get(const typename VecOf<T, RPT>::type& v, int 
 #ifndef OL_RECORD_ARGS_FRESH
 #define OL_RECORD_ARGS_FRESH 1
 #endif
+#ifndef OL_PRT_SCALAR_BASE
+#define OL_PRT_SCALAR_BASE OL_RECORD_DIRECT
+#endif
 template <bool SADDR>
 struct RayIndexT {
   int64_t tile;   // wave-uniform
@@ -930,7 +933,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
       // folded e * n into the per-lane address -- a 64-bit multiply-add in vector registers
       // for every one of the 9 / 18 stores, ~3.5 vector instructions each)
       T* plane = late.prt + (int64_t)e * late.n;
-#if OL_RECORD_DIRECT
+#if OL_PRT_SCALAR_BASE
       plane = refresh(plane);
 #endif
       store_plane<T, RPT>(plane, base, cnt, tmp);

@@ -22,6 +22,12 @@ VARIANTS = {
     "o6_prt_scalar": ["-DOL_PRT_PACKED=0"],
     "o6_rec_copy": ["-DOL_RECORD_DIRECT=0"],
     "o6_rec_args_held": ["-DOL_RECORD_ARGS_FRESH=0"],
+    # the two halves of OL_RECORD_DIRECT apart: rows through a copy but scalar PRT plane bases,
+    # and the reverse
+    "o6_rows_copy_prt_scalar": ["-DOL_RECORD_DIRECT=0", "-DOL_PRT_SCALAR_BASE=1"],
+    "o6_rows_direct_prt_vector": ["-DOL_RECORD_DIRECT=1", "-DOL_PRT_SCALAR_BASE=0"],
+    "o6_rows_copy_prt_scalar_args_held": ["-DOL_RECORD_DIRECT=0", "-DOL_PRT_SCALAR_BASE=1",
+                                          "-DOL_RECORD_ARGS_FRESH=0"],
     # BASELINE.json north_star: "surface coefficients staged in LDS" 
     "lds_table": ["-DOL_TABLE_IN_LDS=1"],
     # store flavour: plain stores for the one-ray-per-lane layout,

@@ -24,7 +24,8 @@ LAUNCHES = int(os.environ.get("LAUNCHES", "40"))
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
 CONFIGS = [c for c in os.environ.get("CONFIGS", "dg_f64,dg_f32,zf_f32").split(",") if c]
 WORK = {"dg_f64": ("double_gauss", torch.float64), "dg_f32": ("double_gauss", torch.float32),
-        "zf_f32": ("zernike_fresnel", torch.float32), "zf_f64": ("zernike_fresnel", torch.float64)}
+        "zf_f32": ("zernike_fresnel", torch.float32), "zf_f64": ("zernike_fresnel", torch.float64),
+        "rc_f32": ("rc_asphere", torch.float32), "rc_f64": ("rc_asphere", torch.float64)}
 dev = torch.device("cuda", 0)
 n = 10_000_000
 samples, stop = [], threading.Event()

@@ -142,20 +142,6 @@ with open("$O/r06_c5_valu_${TAG:-0}.txt", "w") as out:
         out.write(line + "\n")
 PY
       tail -2 $OUTD/a.log ;;
-    pcsamp)    # PC sampling of the C5 launch: where the issue slots really go (beta feature: every step time-boxed)
-      OUTD=$O/pcsamp_${TAG:-0}; rm -rf $OUTD; mkdir -p $OUTD
-      (timeout 60 rocprofv3-avail list --pc-sampling > $OUTD/avail.txt 2>&1; echo "rc=$?" >> $OUTD/avail.txt)
-      (cd /tmp && TMPDIR=/tmp timeout 240 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-method ${PCS_METHOD:-stochastic} \
-        --pc-sampling-unit ${PCS_UNIT:-cycles} --pc-sampling-interval ${PCS_INTERVAL:-1048576} --kernel-trace \
-        --output-format csv -d $OUTD/out -o c5 -- python $R/tools/gpu_c5_one.py > $OUTD/run.log 2>&1; echo "rc=$?" >> $OUTD/run.log)
-      tail -5 $OUTD/run.log; find $OUTD -type f | head; 
-      python - <<PY
-import csv, glob, collections
-for f in glob.glob("$O/pcsamp_${TAG:-0}/out/**/*pc_sampling*.csv", recursive=True):
-    rows = list(csv.DictReader(open(f)))
-    print(f, len(rows), list(rows[0].keys()) if rows else None)
-PY
-      ;;
     hot_loop)  # when the two-workgroup cap starts to pay in a loop (tools/gpu_hot_loop.py)
       timeout 600 python tools/gpu_hot_loop.py > $O/r06_hot_loop_${TAG:-0}.txt 2>&1; cat $O/r06_hot_loop_${TAG:-0}.txt | tail -20 ;;
     pool)      # the pool tests alone
@@ -169,15 +155,30 @@ PY
       timeout 900 python tools/ab_inproc.py --arms ${ARMS:-product,o6_off} --configs ${CONFIGS:-zf_f32_gen,zf_f64_gen,rc_f32_gen} \
         --rounds ${ROUNDS:-2} ${AB_EXTRA:-} >> $O/r06_ab_${TAG:-0}.txt 2>&1; tail -${AB_TAIL:-40} $O/r06_ab_${TAG:-0}.txt ;;
     cycles_ab) # GRBM_GUI_ACTIVE per launch of the product against a variant library: cycles, not time (the clock moves)
-      for arm in product ${VARIANT:-o6_off}; do
+      for arm in product ${VARIANTS:-o6_off}; do
         OUTD=$O/cycles_${arm}; rm -rf $OUTD; mkdir -p $OUTD
         if [ $arm != product ]; then export OPTILAND_HIP_LIBRARY=$R/optiland_amd/lib/variant_${arm}.so; else unset OPTILAND_HIP_LIBRARY; fi
         (cd /tmp && TMPDIR=/tmp CONFIGS=${CONFIGS:-zf_f32,zf_f64} ROUNDS=2 LAUNCHES=40 timeout 600 \
           rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUTD/a -o ct -- \
           python $R/tools/gpu_clock_transient.py > $OUTD/run.log 2>&1; echo "rc=$?" >> $OUTD/run.log)
         python $R/tools/clock_transient_report.py $OUTD > $O/r06_cycles_${arm}.txt 2>&1
-        echo "--- $arm"; grep -A3 "^## " $O/r06_cycles_${arm}.txt | grep -v "^launch" | head -40
-        awk '/^## /{name=$2" "$3" "$4} /^ +3[0-9] /{print name, $0}' $O/r06_cycles_${arm}.txt | head -40
+        python - $O/r06_cycles_${arm}.txt $arm <<'PY'
+import re, sys
+import numpy as np
+cur, acc = None, {}
+for ln in open(sys.argv[1]):
+    m = re.match(r"## (\S+) round (\d+)", ln)
+    if m:
+        cur = m.group(1)
+        continue
+    m = re.match(r"\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+(\d+)\s+([\d.]+)", ln)
+    if m and cur and int(m.group(1)) >= 10:
+        acc.setdefault(cur, []).append((float(m.group(2)), float(m.group(4)), float(m.group(5))))
+for k, v in acc.items():
+    a = np.array(v)
+    print(f"{sys.argv[2]:18s} {k:7s} launches 10-39: event_ms {a[:, 0].mean():.4f}  engine cycles per launch and XCD "
+          f"{a[:, 1].mean() / 8:.4g}  clock {a[:, 2].mean() / 8:.0f} MHz")
+PY
       done; unset OPTILAND_HIP_LIBRARY ;;
     bench)
       python bench.py ${BENCH_ARGS:-} > $O/r06_bench_${TAG:-default}.json 2> $O/r06_bench_${TAG:-default}.err
