@@ -193,17 +193,26 @@ __device__ __forceinline__ T vec_get(const typename VecOf<T, RPT>::type& v, int 
 #ifndef OL_SADDR
 #define OL_SADDR 1
 #endif
-// OL_RECORD_DIRECT (default on, round 6): record rows and PRT planes of the one-ray-per-lane
-// Newton / polarised kernels written without a copy of the ray and with scalar plane bases
-// (trace_kernel: the RECORD block and the PRT stores).  A/B knob.
+// Round 6, three experiments on the one-ray-per-lane Newton / polarised kernels, judged in ENGINE
+// CYCLES per launch (GRBM_GUI_ACTIVE; profiles/r06_cycles.txt -- their times are at the mercy of
+// the clock the part's power management grants, profiles/r06_clock_transient_f64.txt):
+//   OL_RECORD_DIRECT      record rows written without a copy of the ray (three additions with a
+//                         wave-uniform offset, the other five planes out of the ray's own
+//                         registers): -35 vector instructions per ray and +3 % (C5 fp32), +5 %
+//                         (C4 fp32), +13 % (C5 fp64) CYCLES.  OFF.  The count is not the cost.
+//   OL_PRT_SCALAR_BASE    PRT plane bases pinned in scalar registers: -25 instructions, cycles
+//                         within +-1 %.  OFF (every pin is a scheduling barrier).
+//   OL_RECORD_ARGS_FRESH  record block address / stride re-read from the kernarg segment per row
+//                         instead of held (and SGPR-spilled) across the surface body: 10 fewer
+//                         spills, cycles within +-1 % (C4 -1.2 %).  ON.
 #ifndef OL_RECORD_DIRECT
-#define OL_RECORD_DIRECT 1
+#define OL_RECORD_DIRECT 0
 #endif
 #ifndef OL_RECORD_ARGS_FRESH
 #define OL_RECORD_ARGS_FRESH 1
 #endif
 #ifndef OL_PRT_SCALAR_BASE
-#define OL_PRT_SCALAR_BASE OL_RECORD_DIRECT
+#define OL_PRT_SCALAR_BASE 0
 #endif
 template <bool SADDR>
 struct RayIndexT {

@@ -238,7 +238,7 @@ def _few_waves_flag(rec) -> int:
 # Round 5 therefore left it to the caller (`ol_set_tuning`).  The engine can see a loop itself:
 # launch after launch into the SAME block, enqueued without a pause.  From the `after`-th such
 # launch on the block is traced with `TRACE_FEW_WAVES` (the kernels' word for "two workgroups");
-# a gap of `gap_s` between two enqueues -- the device may have gone idle -- starts the count
+# a gap of `gap_s` (5 ms) between two enqueues -- the device may have gone idle -- starts the count
 # again.  OPTILAND_HIP_HOT_LOOP=0 turns it off; =N sets `after`.
 def _hot_loop_after() -> int:
     try:
@@ -247,7 +247,7 @@ def _hot_loop_after() -> int:
         return 32
 
 
-_HOT_LOOP = {"after": _hot_loop_after(), "gap_s": 0.02}
+_HOT_LOOP = {"after": _hot_loop_after(), "gap_s": 0.005}
 _HOT_BLOCKS: "collections.OrderedDict" = collections.OrderedDict()  # (dev, ptr) -> [count, last]
 
 

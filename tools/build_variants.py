@@ -16,18 +16,15 @@ sys.path.insert(0, ROOT)
 from optiland_amd import build as B  # noqa: E402
 
 VARIANTS = {
-    # round 6 (names start with "o": the ones .gpurunignore lets travel): this round's changes
-    # to the one-ray-per-lane Newton / polarised kernels switched off, together and one by one
-    "o6_off": ["-DOL_PRT_PACKED=0", "-DOL_RECORD_DIRECT=0", "-DOL_RECORD_ARGS_FRESH=0"],
-    "o6_prt_scalar": ["-DOL_PRT_PACKED=0"],
-    "o6_rec_copy": ["-DOL_RECORD_DIRECT=0"],
+    # round 6 (names start with "o": the ones .gpurunignore lets travel): the three experiments
+    # on the one-ray-per-lane Newton / polarised kernels (trace_kernel.hip: OL_RECORD_DIRECT,
+    # OL_PRT_SCALAR_BASE, OL_RECORD_ARGS_FRESH) and the packed PRT updates, against the product
+    # (rows through a copy, per-lane PRT bases, fresh record arguments, packed PRT)
+    "o6_prt_unpacked": ["-DOL_PRT_PACKED=0"],
+    "o6_rows_direct": ["-DOL_RECORD_DIRECT=1"],
+    "o6_prt_scalar_base": ["-DOL_PRT_SCALAR_BASE=1"],
     "o6_rec_args_held": ["-DOL_RECORD_ARGS_FRESH=0"],
-    # the two halves of OL_RECORD_DIRECT apart: rows through a copy but scalar PRT plane bases,
-    # and the reverse
-    "o6_rows_copy_prt_scalar": ["-DOL_RECORD_DIRECT=0", "-DOL_PRT_SCALAR_BASE=1"],
-    "o6_rows_direct_prt_vector": ["-DOL_RECORD_DIRECT=1", "-DOL_PRT_SCALAR_BASE=0"],
-    "o6_rows_copy_prt_scalar_args_held": ["-DOL_RECORD_DIRECT=0", "-DOL_PRT_SCALAR_BASE=1",
-                                          "-DOL_RECORD_ARGS_FRESH=0"],
+    "o6_r05": ["-DOL_PRT_PACKED=0", "-DOL_RECORD_ARGS_FRESH=0"],
     # BASELINE.json north_star: "surface coefficients staged in LDS" 
     "lds_table": ["-DOL_TABLE_IN_LDS=1"],
     # store flavour: plain stores for the one-ray-per-lane layout,
