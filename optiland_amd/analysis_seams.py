@@ -63,7 +63,8 @@ def _why(seam, reason):
             f.write(f"{seam}: {reason} [{os.environ.get('PYTEST_CURRENT_TEST', '')}]\n")
 
 
-def _front(optic, wavelength, need_fp64=False, final_propagation=False, recorded_row=False):
+def _front(optic, wavelength, need_fp64=False, final_propagation=False, recorded_row=False,
+           polarised_ok=False):
     """(front, table) -- the stand-alone device tracer on the CURRENT packed table of
     `optic` -- when the fused analysis kernels apply to it, else None."""
     from . import integration as ig
@@ -83,7 +84,7 @@ def _front(optic, wavelength, need_fp64=False, final_propagation=False, recorded
         # the caller reads the RECORDED last row only (spot diagram, encircled energy): positions
         # and the geometric intensity, which no PRT matrix enters -- OL_SPOT_POLARIZED_OK, ABI 10
         polarised = False
-    if not table.raygen or polarised:
+    if not table.raygen or (polarised and not polarised_ok):
         _why("front", "no device ray generation" if not table.raygen else "polarised")
         return None  # reference-side ray generation / polarised epilogue: not fused
     if table.reference_newton_surfaces():
@@ -511,11 +512,13 @@ def _fused_wavefront(self, field, wavelength):
         return None
     if self.reference_type not in ("sphere", "plane"):
         return None
-    got = _front(self.optic, w, need_fp64=True, final_propagation=True)
+    got = _front(self.optic, w, need_fp64=True, final_propagation=True, polarised_ok=True)
     if got is None:
         return None
     front, table = got
     rg = table.raygen
+    if table.polarization is not None or table.uses_polarization:
+        return _fused_wavefront_polarised(self, front, table, hx, hy, w)
     if not hasattr(front.engine, "trace_opd"):
         return None
     if float(table.last_thickness) != 0.0 and not hasattr(
@@ -576,6 +579,71 @@ def _fused_wavefront(self, field, wavelength):
     data._hip_fused = True  # lets the FFT-PSF seam recognise device data it can scatter
     _keep_fp64(front, data, opd, inten)
     return data
+
+
+def _fused_wavefront_polarised(self, front, table, hx, hy, w):
+    """strategy.py:163-215 for a POLARISED optic (round 6: the last f4 decline).  The fused OPD
+    kernels carry no PRT matrix, so the two traces stay the drop-in's own polarised launches --
+    the chief ray through `Optic.trace_generic`, the bundle through `Optic.trace` (generate,
+    trace, PRT, `update_intensity` in ONE launch) -- and what follows them, the reference's chain
+    of ~25 elementwise operations over the bundle (path length to the reference sphere, tilt,
+    normalisation, pupil coordinates), is ONE `ol_wavefront_opd` launch on the returned planes.
+    `prt_matrix` / `E_exits` are the returned `PolarizedRays`' own, as in the reference."""
+    if getattr(front, "_hip_out_dtype", None) is not None or not hasattr(front.engine, "wavefront_opd"):
+        _why("opd", "polarised wavefront of a float32 backend")
+        return None
+    dist = self.distribution
+    dx, dy = getattr(dist, "x", None), getattr(dist, "y", None)
+    if dx is None or dy is None:
+        return None
+    rg = table.raygen
+    optic = self.optic
+    self._chief_ray = chief = optic.trace_generic(hx, hy, Px=0.0, Py=0.0, wavelength=w)
+    c = torch.stack([t.reshape(-1)[0] for t in (chief.x, chief.y, chief.z, chief.L, chief.M,
+                                                 chief.N, chief.opd)]).double().cpu().tolist()
+    xc, yc, zc, Lc, Mc, Nc, opd_c = c
+    n_image = rg.get("n_image")
+    if n_image is None:
+        n_image = _f(self.n_image)
+    ux, uy = _launch_plane_tilt(rg, hx, hy)
+    # (the rays `Optic.trace` returns HAVE crossed the last thickness: no last_thickness here)
+    params = dict(xc=xc, yc=yc, zc=zc, n_image=n_image, opd_ref=0.0, ux=ux, uy=uy,
+                  half_epd=rg["EPD"] / 2.0, wavelength_um=w)
+    if self.reference_type == "plane":
+        R = math.inf
+        params.update(R=0.0, nx=Lc, ny=Mc, nz=Nc)
+        t_back = 0.0
+    else:
+        pz = self.__dict__.get("_hip_pupil_z")
+        if pz is None or self.pupil_z is not self.__dict__.get("_hip_pupil_z_of"):
+            pz = _f(self.pupil_z)
+        R = math.sqrt(xc * xc + yc * yc + (zc - pz) ** 2)
+        params.update(R=R)
+        a_ = Lc * Lc + Mc * Mc + Nc * Nc
+        sq = math.sqrt(max(4.0 * a_ * R * R, 0.0))
+        t1, t2 = -sq / (2.0 * a_), sq / (2.0 * a_)
+        t_back = t2 if t1 < 0.0 else t1
+    params["opd_ref"] = opd_c - n_image * t_back
+    rays = optic.trace(hx, hy, w, None, dist)
+    planes = [getattr(rays, k) for k in ("x", "y", "z", "L", "M", "N", "opd")]
+    if any(not isinstance(t, torch.Tensor) or t.dtype != torch.float64 for t in planes):
+        return None
+    r7 = [t.detach().reshape(-1).contiguous() for t in planes]
+    px, py = front._dev(_as_input(dx)).contiguous(), front._dev(_as_input(dy)).contiguous()
+    if px.numel() != r7[0].numel():
+        return None
+    opd, pupil = front.engine.wavefront_opd(params, r7, px, py, want_pupil=True)
+    intensity = optic.surfaces.intensity[-1, :]          # strategy.py:188: the recorded last row
+    kwargs = {}
+    prt_matrix = getattr(rays, "p", None)
+    exit_fields = getattr(rays, "get_exit_fields", None)
+    if prt_matrix is not None and exit_fields:
+        kwargs["prt_matrix"] = prt_matrix
+        kwargs["E_exits"] = exit_fields(optic.polarization_state)
+    from optiland.wavefront.wavefront_data import WavefrontData
+
+    return WavefrontData(pupil_x=pupil[0], pupil_y=pupil[1], pupil_z=pupil[2], opd=opd,
+                         intensity=intensity, radius=R, **kwargs)
 
 
 class _LazyChiefRay:
