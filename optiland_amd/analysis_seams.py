@@ -347,9 +347,13 @@ def _spot_radius(self, kind):
                     or sd.y.data_ptr() != g["ys"][wi * F + fi].data_ptr() \
                     or sd.x.numel() != g["xs"].shape[1]:
                 return None     # somebody replaced a cell or its arrays: the reference's code
-    centers = self._get_reference_centers(data)
-    cx = torch.stack([c[0].reshape(()) for c in centers]).to(g["xs"].dtype)
-    cy = torch.stack([c[1].reshape(()) for c in centers]).to(g["xs"].dtype)
+    got = _chief_centers(self, F)
+    if got is not None:
+        cx, cy = got
+    else:
+        centers = self._get_reference_centers(data)
+        cx = torch.stack([c[0].reshape(()) for c in centers]).to(g["xs"].dtype)
+        cy = torch.stack([c[1].reshape(()) for c in centers]).to(g["xs"].dtype)
     n = g["xs"].shape[1]
     dx = g["xs"].view(W, F, n) - cx.view(1, F, 1)     # (cells are wavelength-major)
     dy = g["ys"].view(W, F, n) - cy.view(1, F, 1)
@@ -359,6 +363,49 @@ def _spot_radius(self, kind):
     rows = out.t().unbind(0)                          # per field: (W,) views
     STATS["spot_radius"] += 1
     return [list(row.unbind(0)) for row in rows]
+
+
+def _chief_centers(self, F):
+    """The stock `ChiefRayReference` (spot_diagram/reference.py:84-110, global coordinates): the
+    image-plane (x, y) of the chief ray of every field at the reference wavelength -- F calls of
+    `Optic.trace_generic(Px=0, Py=0)` there, ONE one-ray-per-cell `ol_trace_spot_batch` launch
+    here; what the LAST of those calls would have left on the optic's surfaces is registered as
+    a pending record, like every seam does.  None: any other strategy / coordinates / an optic
+    whose returned rays differ from the recorded row (a trailing thickness)."""
+    strat = getattr(self, "_reference_strategy", None)
+    try:
+        from optiland.analysis.spot_diagram.reference import ChiefRayReference
+    except ImportError:
+        return None
+    if type(strat) is not ChiefRayReference or self.coordinates != "global":
+        return None
+    fields = [(_scalar(fp.coord[0]), _scalar(fp.coord[1])) for fp in self.fields]
+    if len(fields) != F or any(hx is None or hy is None for hx, hy in fields):
+        return None
+    w = self.wavelengths[self._analysis_ref_wavelength_index].value
+    got = _front(self.optic, w, recorded_row=True)
+    if got is None:
+        return None
+    front, table = got
+    eng = front.engine
+    if not hasattr(eng, "trace_spot_batch") or float(table.last_thickness) != 0.0 \
+            or getattr(eng, "_status", None) is None:
+        return None
+    from . import _capi
+
+    wl, wv = front._wavelength_index(w)
+    zero = torch.zeros(1, dtype=front.dtype, device=eng.device)
+    cells = []
+    for hx, hy in fields:
+        front._validate_normalized_coordinates(hx, hy, "field")
+        vx, vy = front._vig_scalar(hx, hy)
+        cells.append((hx, hy, vx, vy, 0.0, 0.0, wl, eng))
+    flags = _capi.SPOT_POLARIZED_OK if table.polarization is not None else 0
+    _mom, hits = eng.trace_spot_batch(zero, zero, cells, hits=True, flags=flags,
+                                      check_status=False)
+    hx, hy = fields[-1]
+    _register(self.optic, front, table, (hx, hy, zero, zero, front._vig_scalar(hx, hy), wv, 0))
+    return hits[:, 0, 0], hits[:, 1, 0]
 
 
 def _spot_rms_spot_radius(self):

@@ -47,6 +47,11 @@ TAGS = {  # tag -> traffic key
     "r05_dg_f64_gen": "double_gauss:f64:gen",
     "r05_rc_f32_gen": "rc_asphere:f32:gen",
     "r05_zf_f32_gen": "zernike_fresnel:f32:gen",
+    # round 6 (tools/gpu_r06.sh prof): the final library
+    "r06_dg_f32_gen": "double_gauss:f32:gen",
+    "r06_dg_f64_gen": "double_gauss:f64:gen",
+    "r06_rc_f32_gen": "rc_asphere:f32:gen",
+    "r06_zf_f32_gen": "zernike_fresnel:f32:gen",
 }
 
 
