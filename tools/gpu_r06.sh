@@ -180,6 +180,8 @@ for k, v in acc.items():
           f"{a[:, 1].mean() / 8:.4g}  clock {a[:, 2].mean() / 8:.0f} MHz")
 PY
       done; unset OPTILAND_HIP_LIBRARY ;;
+    primed)    # is a block that has just been probed under sustained load "hot"? (tools/gpu_primed.py)
+      timeout 600 python tools/gpu_primed.py > $O/r06_primed_${TAG:-0}.txt 2>&1; tail -12 $O/r06_primed_${TAG:-0}.txt ;;
     bench)
       python bench.py ${BENCH_ARGS:-} > $O/r06_bench_${TAG:-default}.json 2> $O/r06_bench_${TAG:-default}.err
       tail -c 1500 $O/r06_bench_${TAG:-default}.json ;;
