@@ -676,3 +676,80 @@ def test_every_sample_lens_through_the_live_drop_in_on_device(be):
     # lenses: the reference's iterative aimer makes the rays) the SurfaceGroup.trace seam
     assert all(p <= {"hip", "reference-rays"} for p in served.values()), served
     assert sum("hip" in p for p in served.values()) >= len(classes) - 6, served
+
+
+# ---------------------------------------------------------------------------------------
+# round 6: the seams that stopped declining, on the device
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("strategy", ["chief_ray", "centroid_sphere", "best_fit_sphere"])
+def test_float32_backend_wavefront_on_device(be, strategy):
+    """A float32 backend's `Wavefront` / `FFTPSF` on the MI355X: served by the fp64 kernels, the
+    maps handed over in float32 and within 1e-3 waves of the fp64 NumPy reference (the float32
+    PRESCRIPTION alone moves an OPD by ~1e-4 waves)."""
+    import torch
+    from optiland.psf import FFTPSF
+    from optiland.samples.objectives import CookeTriplet
+    from optiland.wavefront import Wavefront
+
+    def run(lens):
+        w = Wavefront(lens, fields=[(0.0, 0.7)], wavelengths="primary", num_rays=9,
+                      distribution="hexapolar", strategy=strategy)
+        d = w.get_data((0.0, 0.7), lens.primary_wavelength)
+        psf = FFTPSF(lens, (0.0, 0.7), lens.primary_wavelength, num_rays=32, grid_size=64,
+                     strategy=strategy)
+        return d, psf.psf
+
+    be.set_backend("numpy")
+    want_d, want_psf = run(CookeTriplet())
+    want = {k: _np(be, getattr(want_d, k)) for k in ("opd", "intensity", "pupil_x", "pupil_y")}
+    want_psf = _np(be, want_psf)
+    stats = _on_device(be, "float32")
+    try:
+        d, psf = run(CookeTriplet())
+        assert stats["opd"] + stats["opd_fit"] >= 2
+        assert stats["opd_fallback"] == 0 and stats["opd_fit_fallback"] == 0
+        assert stats["pupil"] >= 1 and stats["pupil_fallback"] == 0
+        for k, v in want.items():
+            got = getattr(d, k)
+            assert got.dtype == torch.float32 and got.is_cuda, k
+            np.testing.assert_allclose(_np(be, got), v, rtol=1e-5,
+                                       atol=1e-3 if k == "opd" else 1e-5, err_msg=k)
+        assert psf.dtype == torch.float32
+        np.testing.assert_allclose(_np(be, psf), want_psf, rtol=0,
+                                   atol=2e-3 * float(want_psf.max()))
+    finally:
+        _off(be)
+
+
+@pytest.mark.parametrize("state", ["unpolarized", "elliptical"])
+def test_polarised_opd_map_and_spot_radii_on_device(be, state):
+    """The polarised OPD seam (the drop-in's polarised launches + one `ol_wavefront_opd`) and the
+    whole-grid spot radii with one-launch chief-ray centres, on the MI355X against NumPy."""
+    from optiland import analysis
+    from optiland.wavefront import Wavefront
+
+    def run(lens):
+        w = Wavefront(lens, fields=[(0.0, 1.0)], wavelengths="primary", num_rays=8,
+                      distribution="hexapolar")
+        d = w.get_data((0.0, 1.0), lens.primary_wavelength)
+        s = analysis.SpotDiagram(lens, num_rings=5)
+        return ([_np(be, getattr(d, k)) for k in ("opd", "intensity", "pupil_x", "pupil_y")],
+                np.asarray(be.to_numpy(d.prt_matrix)),
+                np.array([[float(_np(be, v)) for v in f] for f in s.rms_spot_radius()]),
+                np.array([[float(_np(be, v)) for v in f] for f in s.geometric_spot_radius()]))
+
+    be.set_backend("numpy")
+    want = run(_live.zernike_fresnel(state))
+    stats = _on_device(be, "float64")
+    try:
+        got = run(_live.zernike_fresnel(state))
+        assert stats["opd"] == 1 and stats["opd_fallback"] == 0
+        assert stats["spot_grid"] == 1 and stats["spot_radius"] == 2
+        np.testing.assert_allclose(got[0][0], want[0][0], rtol=0, atol=5e-3)   # Newton: 2e-3 waves
+        for a, b in zip(got[0][1:], want[0][1:]):
+            np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(got[1], want[1], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(got[2], want[2], rtol=1e-6)
+        np.testing.assert_allclose(got[3], want[3], rtol=1e-6)
+    finally:
+        _off(be)

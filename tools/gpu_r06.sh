@@ -182,6 +182,8 @@ PY
       done; unset OPTILAND_HIP_LIBRARY ;;
     primed)    # is a block that has just been probed under sustained load "hot"? (tools/gpu_primed.py)
       timeout 600 python tools/gpu_primed.py > $O/r06_primed_${TAG:-0}.txt 2>&1; tail -12 $O/r06_primed_${TAG:-0}.txt ;;
+    fuzz_tables) # kernel vs oracle on every table under fuzz_tables/ (tools/make_fuzz_tables.py LO HI, CPU, beforehand)
+      timeout 1500 python tools/gpu_fuzz_tables.py > $O/r06_fuzz_tables_${TAG:-0}.txt 2>&1; tail -15 $O/r06_fuzz_tables_${TAG:-0}.txt | cut -c1-250 ;;
     bench)
       python bench.py ${BENCH_ARGS:-} > $O/r06_bench_${TAG:-default}.json 2> $O/r06_bench_${TAG:-default}.err
       tail -c 1500 $O/r06_bench_${TAG:-default}.json ;;
