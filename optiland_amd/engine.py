@@ -117,7 +117,7 @@ class _Arena:
 
     __slots__ = ("lib", "device", "ptr", "nbytes", "__weakref__")
     live_bytes = 0          # all arenas of the process (`record_pool_stats`)
-    _lock = threading.Lock()
+    _lock = threading.RLock()   # (re-entrant: __del__ may run inside __init__'s critical section)
 
     def __init__(self, lib, device, nbytes: int):
         self.lib, self.device, self.nbytes, self.ptr = lib, device, int(nbytes), 0
@@ -199,7 +199,7 @@ _POOL_COOLDOWN: dict = {}  # device index -> big allocations left before another
 # arena has since been freed only costs that hint; a few dozen entries at most.
 _PLACED_WINDOWS: "collections.OrderedDict" = collections.OrderedDict()
 _PLACED_MAX = 64
-_PLACED_LOCK = threading.Lock()
+_PLACED_LOCK = threading.RLock()  # (re-entrant: an arena finalised by the garbage collector takes it too)
 _FEW_WAVES_MIN_BYTES = 256 << 20
 
 
