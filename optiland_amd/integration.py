@@ -601,6 +601,20 @@ def _make_tracer_class():
                 return be._backends[be.get_backend()]._config.get_precision()
             return torch.float64
 
+        def stats(self) -> dict:
+            """What the drop-in holds and did for this optic: `last_path` ("hip",
+            "reference-rays", "reference"), `packs` (tables really packed), `engines` (device
+            tables alive for it), and the process-wide record pools (`placed_bytes`: device
+            memory of the library's own arenas, `pools`: one entry per pooled block shape;
+            `engine.record_pool_stats()`)."""
+            from . import engine as _E
+
+            pools = _E.record_pool_stats()
+            return {"last_path": getattr(self, "last_path", None), "packs": self.pack_count,
+                    "engines": len(getattr(self, "_hip_engines", ()) or ()),
+                    "placed_bytes": pools["placed_bytes"], "pools": pools["pools"],
+                    "pool_idle_s": pools["idle_s"]}
+
         def invalidate(self):
             """Forget everything the change detector relies on: the token memo, the
             per-surface packed rows and the device scalars read back so far.  The next trace

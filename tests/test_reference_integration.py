@@ -489,6 +489,19 @@ def test_trace_generic_input_matrix_matches_the_reference(hip_on_cpu):
     assert run(hip_lens, lst) == run(ref_lens, lst) and run(hip_lens, lst)[1] == "TypeError"
 
 
+def test_tracer_stats_report_what_the_drop_in_holds(hip_on_cpu):
+    """Round 6: `tracer.stats()` -- the path of the last call, packs, device tables alive, and
+    the record pools' footprint (`placed_bytes`; 0 on the CPU engines of this suite)."""
+    from optiland.samples.objectives import CookeTriplet
+    from optiland_amd import integration
+    lens = CookeTriplet()
+    tracer = integration.install(lens, force=True)
+    lens.trace(0.0, 0.7, 0.55, 3, "hexapolar")
+    st = tracer.stats()
+    assert st["last_path"] == "hip" and st["packs"] == 1 and st["engines"] == 1
+    assert st["placed_bytes"] == 0 and st["pools"] == [] and st["pool_idle_s"] >= 0
+
+
 def test_dropin_keeps_device_tables_per_wavelength(hip_on_cpu):
     """Alternating wavelengths (what SpotDiagram does per field) reuses the device tables
     instead of re-creating one per call; a change of the prescription makes a new one."""
