@@ -147,6 +147,19 @@ class ShardedTracer:
         self.tracer = tracer
         self.group = group
         self.world, self.rank = _world(group)
+        # Reference-rule Newton surfaces (`reference_newton`, newton_raphson.py:137-166): the
+        # number of updates is a property of the WHOLE batch, so the counts of the shards are
+        # combined (MAX, 8 S bytes) after every counting launch.
+        eng = getattr(tracer, "engine", None)
+        if eng is not None and _exchanging(group):   # (only called when such surfaces exist)
+            eng.newton_count_hook = lambda iters: allreduce_max(iters, group)
+
+    def _no_reference_newton(self, what: str):
+        # the fused entry points generate the rays inside the launch; the counting launches of
+        # the reference's stop rule read them (capi: OL_ERR_UNSUPPORTED) -- say so here
+        if self.tracer.table.reference_newton_surfaces():
+            raise ValueError(f"{what}: not with reference-rule Newton surfaces "
+                             "(reference_newton); use trace_generic")
 
     def trace_spot(self, Hx: float, Hy: float, Px, Py, wavelength, center=(0.0, 0.0)):
         """Fused spot of ONE field point over a GLOBAL pupil list: this rank runs
@@ -156,6 +169,7 @@ class ShardedTracer:
         t = self.tracer
         if t.table.polarization is not None or t.table.uses_polarization:
             raise ValueError("trace_spot: fused spot reduction needs an unpolarised system")
+        self._no_reference_newton("trace_spot")
         px, py = t._dev(Px), t._dev(Py)
         lo, hi = shard_bounds(px.numel(), self.world, self.rank)
         wl, _ = t._wavelength_index(wavelength)
@@ -179,6 +193,9 @@ class ShardedTracer:
             x, y, i = rays.x, rays.y, rays.i
         else:  # more ranks than rays: nothing to launch, zero contribution below
             x = y = i = torch.empty(0, dtype=t.dtype, device=t.device)
+            empty = getattr(t.engine, "newton_counts_of_an_empty_shard", None)
+            if empty is not None:
+                empty()
         if exchange == "gather":
             out["hits"] = allgather_hits(x, y, i, n, self.group)
         elif exchange == "reduce":
@@ -210,6 +227,7 @@ class ShardedTracer:
         t = self.tracer
         if t.table.polarization is not None or t.table.uses_polarization:
             raise ValueError("trace_field: the spot epilogue needs an unpolarised system")
+        self._no_reference_newton("trace_field")
         px, py = t._dev(Px), t._dev(Py)
         lo, hi = shard_bounds(px.numel(), self.world, self.rank)
         wl, _ = t._wavelength_index(wavelength)

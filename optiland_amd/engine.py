@@ -899,10 +899,11 @@ class HipSystem:
         stream = self._stream()
 
         def launch(s, verify):
-            with self._device_ctx():
-                rc = self.lib.ol_newton_count(self._handle, dt, n, ptrs, wl, first, int(s),
-                                              iters.data_ptr(), 1 if verify else 0, stream)
-            self._check(rc, "ol_newton_count")
+            if n:   # (an EMPTY shard launches nothing and still takes part in the exchange)
+                with self._device_ctx():
+                    rc = self.lib.ol_newton_count(self._handle, dt, n, ptrs, wl, first, int(s),
+                                                  iters.data_ptr(), 1 if verify else 0, stream)
+                self._check(rc, "ol_newton_count")
             if hook is not None:
                 hook(iters)
 
@@ -927,6 +928,15 @@ class HipSystem:
             iters[S_:] = 0
             for s in later:
                 launch(s, False)
+
+    def newton_counts_of_an_empty_shard(self, first: int = 0, last: int | None = None):
+        """A rank whose shard of a batch is empty traces nothing, but the counting chain of the
+        other ranks exchanges after every launch (`newton_count_hook`): take part in exactly
+        those exchanges (the loop control is the same on every rank because it reads the
+        REDUCED counts)."""
+        surfaces = self.table.reference_newton_surfaces(first, last)
+        if surfaces and self.newton_count_hook is not None:
+            self._newton_counts(None, 0, 0, 0, int(first), surfaces)
 
     def can_trace_generate(self, field_planes: bool = False) -> bool:
         """`ol_trace_generate` serves this launch: the table carries generator scalars.  Per-ray

@@ -249,3 +249,98 @@ def test_two_rank_one_launch_field_step_equals_single_process():
         np.testing.assert_allclose(s["geometric_radius"],
                                    np.sqrt(np.max(x[m] ** 2 + (y[m] - 15.0) ** 2)), rtol=1e-12)
     assert results[0][4] == results[1][4]
+
+
+def _ref_newton_table():
+    """The packaged Zernike freeform with the reference's batch-global Newton stop rule switched
+    on and a loose tolerance, so that the number of updates depends on the rays of the batch."""
+    from optiland_amd import load_system
+    from optiland_amd.system import SURF_REFERENCE_NEWTON, GEOM_PLANE, GEOM_STANDARD
+    table = load_system("zernike_fresnel_fringe")
+    s = table.surfaces
+    newton = (s["geom_kind"] != GEOM_PLANE) & (s["geom_kind"] != GEOM_STANDARD)
+    assert newton.any()
+    s["flags"][newton] |= SURF_REFERENCE_NEWTON
+    s["tol"][newton] = 3e-4
+    table.__dict__.pop("_ref_newton", None)
+    assert table.reference_newton_surfaces()
+    return table
+
+
+def _ref_newton_rays(n):
+    """(Hx, Hy, Px, Py): near-axis rays first, the edge of the pupil at the edge of the field
+    last -- the first shard alone stops one update earlier than the whole batch."""
+    k = np.arange(n)
+    th = np.linspace(0.0, 2 * np.pi, n)
+    r = np.where(k < n // 2, 0.02, 0.95)
+    return np.zeros(n), np.where(k < n // 2, 0.0, 1.0), r * np.cos(th), r * np.sin(th)
+
+
+def _newton_worker(rank, world, port, q, n):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import optiland_amd.tracer as tr
+        from optiland_amd.distributed import ShardedTracer
+        from tests import _hostmath as hm
+        cls = hm.make_engine_class()
+        tr._make_engine = lambda table, device: cls(table, device)
+        table = _ref_newton_table()
+        t = tr.HipRayTracer(table, dtype=torch.float64)
+        st = ShardedTracer(t)
+        wl = float(table.wavelengths[0])
+        out = st.trace_generic(*_ref_newton_rays(n), wl, exchange="reduce")
+        rays = out["rays"]
+        got = None if rays is None else np.stack([np.asarray(getattr(rays, k))
+                                                  for k in ("x", "y", "z", "L", "M", "N", "opd")])
+        q.put((rank, out["lo"], out["hi"], got, out["spot"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("n", [400, 1])
+def test_reference_newton_counts_are_those_of_the_whole_batch_when_sharded(n):
+    """`reference_newton`: the reference's Newton loop makes the same number of updates for
+    every ray of a trace call (newton_raphson.py:137-166), so a batch sharded over ranks has to
+    take the maximum over its shards (`HipSystem.newton_count_hook`, one 8 S-byte MAX all-reduce
+    per counting launch).  World size 2 over gloo on the host build of the kernel source: the
+    shards concatenate to the single-process trace bit for bit -- the paraxial shard alone would
+    have stopped earlier -- and a rank without rays (n = 1) takes part in the exchanges."""
+    from tests import _hostmath as hm
+    if not hm.available():
+        pytest.skip("hipcc (used as host C++ compiler) missing")
+    cls = hm.make_engine_class()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_newton_worker, args=(r, world, port, q, n))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=200) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+
+    import optiland_amd.tracer as tr
+    table = _ref_newton_table()
+    eng = cls(table)
+    try:
+        t = tr.HipRayTracer(table, dtype=torch.float64, engine=eng)
+        wl = float(table.wavelengths[0])
+        rays = t.trace_generic(*_ref_newton_rays(n), wl)
+        want = np.stack([np.asarray(getattr(rays, k))
+                         for k in ("x", "y", "z", "L", "M", "N", "opd")])
+        if n > 1:   # the point of the exchange: the first shard ALONE stops earlier
+            lo, hi = results[0][1], results[0][2]
+            alone = t.trace_generic(*[a[lo:hi] for a in _ref_newton_rays(n)], wl)
+            assert not np.array_equal(np.asarray(alone.x), want[0, lo:hi])
+    finally:
+        eng.close()
+    got = np.concatenate([r[3] for r in results if r[3] is not None], axis=1)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want, equal_nan=True)
+    assert results[0][4] == results[1][4]
