@@ -245,7 +245,7 @@ struct Staged {
   std::vector<double> coeffs;
   std::vector<size_t> int_slots;  // coeffs entries uploaded as integer bit patterns
   std::vector<int32_t> interaction, coating, geom;
-  std::vector<uint8_t> polygon, ref_newton;
+  std::vector<uint8_t> polygon, ref_newton, no_pair;
 };
 
 }  // namespace
@@ -261,6 +261,9 @@ struct ol_system {
   std::vector<int32_t> geom;
   std::vector<uint8_t> polygon;  // surface uses a polygon aperture (top level or in a tree)
   std::vector<uint8_t> ref_newton;  // OL_SURF_REFERENCE_NEWTON on a traced Newton-Raphson surface
+  // the surface keeps a polarised Zernike launch off the two-rays-per-lane form
+  // (trace_kernel.hip: OL_POLZ_PAIR): a Zernike surface in the level form, a polarizer / retarder
+  std::vector<uint8_t> no_pair;
   // false between the two in-place uploads of ol_system_update and for good if the second
   // one fails: the fp32 and fp64 tables (and the host copies) then describe different
   // prescriptions -- every entry point refuses such a system instead of tracing through it
@@ -552,8 +555,15 @@ int do_trace_generate(const ol_system* sys, const DeviceTable<T>& tab, int64_t n
   if (rays_out)
     for (int k = 0; k < 8; ++k)
       pair_ok = pair_ok && reinterpret_cast<uintptr_t>(rays_out[k]) % 8 == 0;
-  hipError_t e = ol::launch_trace_generate<T>(a, newton_family(sys, 0, sys->n_surf - 1), pair_ok,
-                                              stream);
+  const int family = newton_family(sys, 0, sys->n_surf - 1);
+  if (family == ol::kNrZernike) {
+    // the polarised Zernike pair (fp32): polynomial-form Zernike surfaces, real diagonal Jones
+    // matrices, an even number of rays (the PRT planes are written with 8-byte lane accesses)
+    for (int32_t s = 0; s < sys->n_surf; ++s) pair_ok = pair_ok && !sys->no_pair[s];
+    pair_ok = pair_ok && prt && n % 2 == 0 && reinterpret_cast<uintptr_t>(prt) % 8 == 0 &&
+              reinterpret_cast<uintptr_t>(a.i_updated) % 8 == 0;
+  }
+  hipError_t e = ol::launch_trace_generate<T>(a, family, pair_ok, stream);
   if (e != hipSuccess) return fail(OL_EHIP, "trace launch failed: %s", hipGetErrorString(e));
   return OL_OK;
 }
@@ -973,6 +983,10 @@ int stage_system(const char* who, const ol_surface_desc* surf, int32_t n_surf,
       }
       st.polygon.push_back(poly ? 1 : 0);
     }
+    st.no_pair.push_back((surf[i].geom_kind == OL_GEOM_ZERNIKE && dev[i].geom != ol::kGeomZernikeMono) ||
+                                 surf[i].coating_kind == OL_COAT_POLARIZER ||
+                                 surf[i].coating_kind == OL_COAT_RETARDER
+                             ? 1 : 0);
     st.ref_newton.push_back((surf[i].flags & OL_SURF_REFERENCE_NEWTON) &&
                                     surf[i].geom_kind != OL_GEOM_PLANE &&
                                     surf[i].geom_kind != OL_GEOM_STANDARD &&
@@ -988,6 +1002,7 @@ void adopt_host_copies(ol_system* sys, Staged& st) {
   sys->geom.swap(st.geom);
   sys->polygon.swap(st.polygon);
   sys->ref_newton.swap(st.ref_newton);
+  sys->no_pair.swap(st.no_pair);
 }
 }  // namespace
 

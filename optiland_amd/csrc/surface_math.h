@@ -195,6 +195,8 @@ struct Math;
   static OL_DEV bool all(bool v) { return v; }                        \
   static OL_DEV bool mnot(bool m) { return !m; }                      \
   static OL_DEV bool mand(bool p, bool q) { return p && q; }          \
+  static OL_DEV bool mor(bool p, bool q) { return p || q; }           \
+  static OL_DEV bool any(bool p) { return p; }                        \
   static OL_DEV bool same(bool p, bool q) { return p == q; }          \
   static OL_DEV T select(bool m, T a, T b) { return m ? a : b; }      \
   static OL_DEV bool mselect(bool m, bool a, bool b) { return m ? a : b; }
@@ -288,6 +290,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct Mask2 {
   bool a, b;
 };
+#if !defined(__HIP_DEVICE_COMPILE__)
+// (host build of the kernel source: the ordering handle of refresh_after, device_table.h, on one
+// element -- x86 has no register constraint for an 8-byte float vector)
+template <typename P>
+OL_DEV P refresh_after(P p, f32x2& acc) {
+  float lo = acc.x;
+  asm volatile("" : "+r"(p), "+x"(lo));
+  acc.x = lo;
+  return p;
+}
+#endif
 
 template <>
 struct Math<f32x2> {
@@ -331,6 +344,8 @@ struct Math<f32x2> {
   static OL_DEV mask all(bool v) { return {v, v}; }
   static OL_DEV mask mnot(mask m) { return {!m.a, !m.b}; }
   static OL_DEV mask mand(mask p, mask q) { return {p.a && q.a, p.b && q.b}; }
+  static OL_DEV mask mor(mask p, mask q) { return {p.a || q.a, p.b || q.b}; }
+  static OL_DEV bool any(mask p) { return p.a || p.b; }
   static OL_DEV mask same(mask p, mask q) { return {p.a == q.a, p.b == q.b}; }
   static OL_DEV V select(mask m, V a, V b) {
     return V{m.a ? a.x : b.x, m.b ? a.y : b.y};
@@ -353,6 +368,13 @@ struct Ray {
 template <typename T, int POLK>
 struct Prt {
   T m[POLK == 2 ? 18 : 9];
+};
+// element type of the matrices a surface_step<V, ...> instantiation carries: V itself in a
+// polarised launch (one matrix per lane element), the scalar type in the unpolarised ones (their
+// callers hand over a stand-in that nothing reads)
+template <typename V, int POLK>
+struct PrtLane {
+  using type = typename std::conditional<POLK != 0, V, typename Math<V>::scalar>::type;
 };
 
 // Surface Jones matrix in the local (s, p) basis: 2x2 block A + iB, and the
@@ -931,6 +953,165 @@ OL_DEV void zernike_mono_eval(const DevSurf<T>& s, cptr<T> c, T x, T y, T& sag,
   zernike_finish(s, xn, yn, u, zsum, gx, gy, sag, fx, fy);
 }
 
+// ---- the polynomial form on a PAIR of fp32 rays (Math<f32x2>) ------------------------------
+// Configuration C5 on two rays per lane (trace_kernel.hip: OL_POLZ_PAIR).  Element for element
+// the operations of the scalar functions above, in the same order -- the same bits -- with the
+// multiply-adds of the two rays in ONE v_pk_fma_f32 / v_pk_mul_f32 each (square roots,
+// reciprocals, compares and selects stay one instruction per ray: there are no packed forms).
+// A branch on a ray's own values becomes a select; wave-uniform branches stay branches.  The
+// launcher sends only ranges whose Zernike surfaces all have the polynomial form here
+// (capi.hip: pair_polz_ok).
+OL_DEV void zernike_begin(const DevSurf<float>& s, f32x2 x, f32x2 y, f32x2& sag, f32x2& fx,
+                          f32x2& fy, f32x2& xn, f32x2& yn, f32x2& u, Mask2& out_of_range) {
+  using m = Math<f32x2>;
+  f32x2 r2 = m::fma(x, x, y * y);
+  f32x2 g = m::sqrt(m::fma(m::splat(-s.kp1 * s.cv * s.cv), r2, m::splat(1)));
+  sag = m::div(s.cv * r2, 1.0f + g);
+  f32x2 f = m::div(m::splat(s.cv), g);
+  fx = x * f;
+  fy = y * f;
+  const float inv = s.cold->inv_norm;
+  xn = x * inv;
+  yn = y * inv;
+  out_of_range = m::mor(m::gt(m::abs(xn), m::splat(1)), m::gt(m::abs(yn), m::splat(1)));
+  u = m::fma(xn, xn, yn * yn);
+}
+
+OL_DEV void zernike_finish(const DevSurf<float>& s, f32x2 xn, f32x2 yn, f32x2 u, f32x2 zsum,
+                           f32x2 gx, f32x2 gy, f32x2& sag, f32x2& fx, f32x2& fy) {
+  using m = Math<f32x2>;
+  const Mask2 near = m::lt(u, m::splat(1e-8f));
+  if (m::any(near)) {  // the reference's eps-regularised chain rule near / at the vertex
+    const float eps = m::guard();
+    const f32x2 Rr = m::fma(xn, gx, yn * gy);
+    const f32x2 Az = m::fma(xn, gy, -(yn * gx));
+    const f32x2 rho = m::sqrt(u);
+    const f32x2 d1 = m::select(m::gt(u, m::splat(0)), m::rcp(m::fma(m::splat(eps), rho, u)),
+                               m::splat(0));
+    const f32x2 d2 = m::rcp(u + eps);
+    const f32x2 hx = m::fma(Rr * d1, xn, -(Az * d2 * yn));
+    const f32x2 hy = m::fma(Rr * d1, yn, Az * d2 * xn);
+    gx = m::select(near, hx, gx);
+    gy = m::select(near, hy, gy);
+  }
+  const float inv = s.cold->inv_norm;
+  sag += zsum;
+  fx = m::fma(gx, m::splat(inv), fx);
+  fy = m::fma(gy, m::splat(inv), fy);
+}
+
+// (the gradient chains run per partial derivative ACROSS the two rays -- coefficient j of
+// d/dx_n, then of d/dy_n, each a broadcast scalar -- where the scalar form packs the two
+// partial derivatives of ONE ray: the same multiply-adds element for element)
+template <int N>
+OL_DEV void zernike_mono_two_blocks(cptr<float> c, f32x2 xn, f32x2 yn, f32x2& zsum, f32x2& gx,
+                                    f32x2& gy) {
+  using m = Math<f32x2>;
+  constexpr int NS = (N + 1) * (N + 2) / 2;
+  cptr<float> p = refresh(c);
+  int e = 0;
+  f32x2 P = m::splat(0);
+#pragma unroll
+  for (int i = N; i >= 0; --i) {
+    f32x2 q = m::splat(p[e++]);
+#pragma unroll
+    for (int j = N - i - 1; j >= 0; --j) q = m::fma(q, yn, m::splat(p[e++]));
+    P = i == N ? q : m::fma(P, xn, q);
+  }
+  cptr<float> g = refresh_after(c + NS, P);  // the gradient block: not before the sag chain ends
+  e = 0;
+  f32x2 Gx = m::splat(0), Gy = m::splat(0);
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    f32x2 qx = m::splat(g[e]), qy = m::splat(g[e + 1]);
+    e += 2;
+#pragma unroll
+    for (int j = N - 2 - i; j >= 0; --j) {
+      qx = qx * yn + m::splat(g[e]);
+      qy = qy * yn + m::splat(g[e + 1]);
+      e += 2;
+    }
+    Gx = i == N - 1 ? qx : Gx * xn + qx;
+    Gy = i == N - 1 ? qy : Gy * xn + qy;
+  }
+  zsum = P;
+  gx = Gx;
+  gy = Gy;
+}
+
+template <int LEN>
+OL_DEV f32x2 mono_row(cptr<float> p, f32x2 yn) {
+  using m = Math<f32x2>;
+  f32x2 q = m::splat(p[0]);
+#pragma unroll
+  for (int j = 1; j < LEN; ++j) q = m::fma(q, yn, m::splat(p[j]));
+  return q;
+}
+template <int LEN>
+OL_DEV void mono_row2(cptr<float> p, f32x2 yn, f32x2& qx, f32x2& qy) {
+  using m = Math<f32x2>;
+  qx = m::splat(p[0]);
+  qy = m::splat(p[1]);
+#pragma unroll
+  for (int j = 1; j < LEN; ++j) {
+    qx = qx * yn + m::splat(p[2 * j]);
+    qy = qy * yn + m::splat(p[2 * j + 1]);
+  }
+}
+
+OL_DEV void zernike_mono_loop(cptr<float> c, int N, f32x2 xn, f32x2 yn, f32x2& zsum, f32x2& gx,
+                              f32x2& gy) {
+  using m = Math<f32x2>;
+  cptr<float> p = c;
+  f32x2 P = m::splat(0);
+  for (int len = 1; len <= N + 1; ++len) {  // rows by descending power of x
+    f32x2 q;
+    switch (len) {
+#define OL_ROW(L) case L: q = mono_row<L>(p, yn); break;
+      OL_ROW(1) OL_ROW(2) OL_ROW(3) OL_ROW(4) OL_ROW(5) OL_ROW(6) OL_ROW(7) OL_ROW(8)
+#undef OL_ROW
+      default: q = mono_row<kZernMonoMaxRow>(p, yn); break;
+    }
+    p = refresh(p + len);
+    P = len == 1 ? q : m::fma(P, xn, q);
+  }
+  f32x2 Gx = m::splat(0), Gy = m::splat(0);
+  for (int len = 1; len <= N; ++len) {
+    f32x2 qx, qy;
+    switch (len) {
+#define OL_ROW(L) case L: mono_row2<L>(p, yn, qx, qy); break;
+      OL_ROW(1) OL_ROW(2) OL_ROW(3) OL_ROW(4) OL_ROW(5) OL_ROW(6) OL_ROW(7)
+#undef OL_ROW
+      default: mono_row2<kZernMonoMaxRow - 1>(p, yn, qx, qy); break;
+    }
+    p = refresh(p + 2 * len);
+    Gx = len == 1 ? qx : Gx * xn + qx;
+    Gy = len == 1 ? qy : Gy * xn + qy;
+  }
+  zsum = P;
+  gx = Gx;
+  gy = Gy;
+}
+
+// `report`: which rays of the pair may raise OL_STATUS_ZERNIKE_RANGE (the active ones)
+OL_DEV void zernike_mono_eval(const DevSurf<float>& s, cptr<float> c, f32x2 x, f32x2 y, f32x2& sag,
+                              f32x2& fx, f32x2& fy, Mask2 report, uint32_t& status) {
+  using m = Math<f32x2>;
+  f32x2 xn, yn, u, zsum, gx, gy;
+  Mask2 out;
+  zernike_begin(s, x, y, sag, fx, fy, xn, yn, u, out);
+  if (m::any(m::mand(out, report))) status |= 0x1u;  // OL_STATUS_ZERNIKE_RANGE
+  static_assert(OL_ZERN_MONO_F32_TWO_BLOCKS && OL_ZERN_MONO_SPLIT,
+                "the pair form has the two-block fixed-degree instances only");
+  switch (OL_ZERN_MONO_FIXED ? s.n_coeff : 0) {  // wave-uniform
+    case 2: zernike_mono_two_blocks<2>(c, xn, yn, zsum, gx, gy); break;
+    case 3: zernike_mono_two_blocks<3>(c, xn, yn, zsum, gx, gy); break;
+    case 4: zernike_mono_two_blocks<4>(c, xn, yn, zsum, gx, gy); break;
+    default: zernike_mono_loop(c, s.n_coeff, xn, yn, zsum, gx, gy); break;
+  }
+  zernike_finish(s, xn, yn, u, zsum, gx, gy, sag, fx, fy);
+}
+
 // chebyshev.py:126-225.  T_n by the three-term recurrence instead of
 // cos(n acos x); T_n'(x) = n U_{n-1}(x) instead of n sin(n acos x)/sqrt(1-x^2)
 // (identical for |x| < 1; at |x| == 1 the reference divides by zero).  As in the
@@ -1111,7 +1292,7 @@ OL_DEV void nr_eval(const DevSurf<T>& s, cptr<T> c, T x, T y,
 template <typename T>
 struct NewtonRay {
   T xb, yb, zb, dt, fprev, gx, gy;
-  bool active;
+  typename Math<T>::mask active;
 };
 
 template <int NR = kNrGeneric, typename T>
@@ -1139,6 +1320,33 @@ OL_DEV void newton_iterate(const DevSurf<T>& s, cptr<T> c,
   q.gx = fx;
   q.gy = fy;
   q.active = !done;
+}
+
+// One Newton step of a PAIR of fp32 rays on a polynomial-form Zernike surface (see the pair forms
+// of the evaluation above): both rays are evaluated, and what the scalar form skips for a ray
+// that has left the iteration is a select on `active` here -- per ray the same values.
+OL_DEV void newton_iterate(const DevSurf<float>& s, cptr<float> c, NewtonRay<f32x2>& q, f32x2 L,
+                           f32x2 M, f32x2 N, int it, uint32_t& status) {
+  using m = Math<f32x2>;
+  f32x2 xi = m::fma(q.dt, L, q.xb), yi = m::fma(q.dt, M, q.yb), zi = m::fma(q.dt, N, q.zb);
+  f32x2 sag, fx, fy;
+  zernike_mono_eval(s, c, xi, yi, sag, fx, fy, q.active, status);
+  f32x2 f = sag - zi;
+  f32x2 af = m::abs(f);
+  Mask2 done = m::mnot(m::ge(af, m::splat(s.cold->tol)));  // converged, or NaN
+  const Mask2 at_floor =
+      OL_NR_STALL_ULPS == 0
+          ? m::all(true)
+          : m::mnot(m::gt(af, (float(OL_NR_STALL_ULPS) * m::eps()) * (m::abs(sag) + m::abs(zi))));
+  done = m::mor(done, m::mand(m::all(it > 0), m::mand(at_floor, m::mnot(m::lt(af, 0.5f * q.fprev)))));
+  f32x2 df = m::fma(fx, L, m::fma(fy, M, -N));
+  f32x2 dfs = m::select(m::gt(m::abs(df), m::splat(m::guard())), df, m::splat(m::guard()));
+  const f32x2 dt = q.dt - m::div(f, dfs);
+  q.dt = m::select(q.active, dt, q.dt);
+  q.fprev = m::select(q.active, af, q.fprev);
+  q.gx = m::select(q.active, fx, q.gx);
+  q.gy = m::select(q.active, fy, q.gy);
+  q.active = m::mand(q.active, m::mnot(done));
 }
 
 // OL_SURF_REFERENCE_NEWTON (opt-in, ABI 11; kernel family kNrReference): the reference's OWN
@@ -1634,6 +1842,123 @@ OL_DEV void prt_first_diag(Prt<T, POLK>& P, const PolBasis<T>& b, T k0x,
   }
 }
 
+// ---- the polarised update of a PAIR of fp32 rays (Math<f32x2>; real diagonal Jones matrices) --
+// pol_basis / the Fresnel amplitudes / prt_first_diag / prt_apply_diag as above, element for
+// element in the same order (the rank-2 updates in the form the scalar code states for fp64,
+// which its packed fp32 form reproduces bit for bit): every multiply-add of the two rays is one
+// packed instruction, 27 + 6 per update and pair instead of 2 x 35.
+OL_DEV PolBasis<f32x2> pol_basis(f32x2 k0x, f32x2 k0y, f32x2 k0z, f32x2 k1x, f32x2 k1y, f32x2 k1z,
+                                 f32x2 nx, f32x2 ny, f32x2 nz) {
+  using m = Math<f32x2>;
+  const f32x2 zero = m::splat(0);
+  f32x2 sx = k0y * nz - k0z * ny, sy = k0z * nx - k0x * nz, sz = k0x * ny - k0y * nx;
+  {
+    f32x2 proj = m::fma(sx, k0x, m::fma(sy, k0y, sz * k0z));
+    sx = m::fma(-proj, k0x, sx);
+    sy = m::fma(-proj, k0y, sy);
+    sz = m::fma(-proj, k0z, sz);
+  }
+  f32x2 mag2 = m::fma(sx, sx, m::fma(sy, sy, sz * sz));
+  const Mask2 normal = m::eq(mag2, zero);
+  if (m::any(normal)) {
+    // normal incidence: polarized_rays.py:153-166 fallback axes
+    f32x2 px = zero, py = k0z, pz = -k0y;
+    const Mask2 second = m::mand(m::eq(py, zero), m::eq(pz, zero));
+    px = m::select(second, -k0z, px);
+    py = m::select(second, zero, py);
+    pz = m::select(second, k0x, pz);
+    const f32x2 fx = py * k0z - pz * k0y, fy = pz * k0x - px * k0z, fz = px * k0y - py * k0x;
+    sx = m::select(normal, fx, sx);
+    sy = m::select(normal, fy, sy);
+    sz = m::select(normal, fz, sz);
+    mag2 = m::select(normal, m::fma(fx, fx, m::fma(fy, fy, fz * fz)), mag2);
+  }
+  f32x2 im = m::rsqrt(mag2);
+  PolBasis<f32x2> b;
+  b.sx = sx * im;
+  b.sy = sy * im;
+  b.sz = sz * im;
+  b.p0x = k0y * b.sz - k0z * b.sy; b.p0y = k0z * b.sx - k0x * b.sz; b.p0z = k0x * b.sy - k0y * b.sx;
+  b.p1x = k1y * b.sz - k1z * b.sy; b.p1y = k1z * b.sx - k1x * b.sz; b.p1z = k1x * b.sy - k1y * b.sx;
+  return b;
+}
+
+OL_DEV void prt_apply_diag(Prt<f32x2, 1>& P, const PolBasis<f32x2>& b, f32x2 k0x, f32x2 k0y,
+                           f32x2 k0z, f32x2 k1x, f32x2 k1y, f32x2 k1z, f32x2 j0, f32x2 j1,
+                           f32x2 j2) {
+  using m = Math<f32x2>;
+  const f32x2 ax = m::fma(j1, b.p1x, -(j0 * b.p0x)), ay = m::fma(j1, b.p1y, -(j0 * b.p0y)),
+              az = m::fma(j1, b.p1z, -(j0 * b.p0z));
+  const f32x2 bx = m::fma(j2, k1x, -(j0 * k0x)), by = m::fma(j2, k1y, -(j0 * k0y)),
+              bz = m::fma(j2, k1z, -(j0 * k0z));
+  f32x2* Q = P.m;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const f32x2 r1 = m::fma(b.p0x, Q[e], m::fma(b.p0y, Q[3 + e], b.p0z * Q[6 + e]));
+    const f32x2 r2 = m::fma(k0x, Q[e], m::fma(k0y, Q[3 + e], k0z * Q[6 + e]));
+    Q[e] = m::fma(ax, r1, m::fma(bx, r2, j0 * Q[e]));
+    Q[3 + e] = m::fma(ay, r1, m::fma(by, r2, j0 * Q[3 + e]));
+    Q[6 + e] = m::fma(az, r1, m::fma(bz, r2, j0 * Q[6 + e]));
+  }
+}
+
+OL_DEV void prt_first_diag(Prt<f32x2, 1>& P, const PolBasis<f32x2>& b, f32x2 k0x, f32x2 k0y,
+                           f32x2 k0z, f32x2 k1x, f32x2 k1y, f32x2 k1z, f32x2 j0, f32x2 j1,
+                           f32x2 j2) {
+  using m = Math<f32x2>;
+  const f32x2 a[3] = {m::fma(j1, b.p1x, -(j0 * b.p0x)), m::fma(j1, b.p1y, -(j0 * b.p0y)),
+                      m::fma(j1, b.p1z, -(j0 * b.p0z))};
+  const f32x2 bb[3] = {m::fma(j2, k1x, -(j0 * k0x)), m::fma(j2, k1y, -(j0 * k0y)),
+                       m::fma(j2, k1z, -(j0 * k0z))};
+  const f32x2 p0[3] = {b.p0x, b.p0y, b.p0z}, k0[3] = {k0x, k0y, k0z};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+      P.m[3 * i + e] = m::fma(a[i], p0[e], m::fma(bb[i], k0[e], i == e ? j0 : m::splat(0)));
+}
+
+// interact()'s polarised tail for the pair: uncoated / Fresnel surfaces (the launcher keeps
+// ranges with polarizer or retarder coatings, and bundles with OL_TRACE_NONUNIT_K, on the
+// one-ray form)
+OL_DEV void polarise_pair(const DevSurf<float>& s, const DevOptics<float>& o, f32x2 L0, f32x2 M0,
+                          f32x2 N0, f32x2 adot, f32x2 nx, f32x2 ny, f32x2 nz, const Ray<f32x2>& r,
+                          Prt<f32x2, 1>& P, bool& prt_fresh) {
+  using m = Math<f32x2>;
+  const int ck = s.coating_kind;
+  const bool reflect = s.interaction == kReflect;
+  const float nn = o.nn;
+  if (ck == kCoatSimple) return;  // (never calls rays.update(): the matrix passes through)
+  if (ck == kCoatNone && !reflect && o.u == 1.0f) {  // identity update: only a lost ray's NaN
+    const f32x2 poison = (r.L + r.M + r.N) * 0.0f;
+    const Mask2 lost = m::ne(poison, poison);
+    if (m::any(lost)) {
+#pragma unroll
+      for (int e = 0; e < 9; ++e) P.m[e] = m::select(lost, P.m[e] + poison, P.m[e]);
+    }
+    return;
+  }
+  const f32x2 k0x = L0, k0y = M0, k0z = N0, k1x = r.L, k1y = r.M, k1z = r.N;
+  const PolBasis<f32x2> b = pol_basis(k0x, k0y, k0z, k1x, k1y, k1z, nx, ny, nz);
+  f32x2 j0 = m::splat(1), j1 = m::splat(1), j2 = m::splat(1);
+  if (ck == kCoatFresnel) {
+    const f32x2 one = m::splat(1);
+    f32x2 ci = m::select(m::lt(adot, one), adot, m::select(m::ge(adot, one), one, adot));
+    f32x2 root = m::sqrt(m::fma(m::splat(nn), m::splat(nn), m::fma(ci, ci, m::splat(-1))));
+    if (reflect) {
+      j0 = m::div(ci - root, ci + root);
+      j1 = -m::div(m::fma(m::splat(nn * nn), ci, -root), m::fma(m::splat(nn * nn), ci, root));
+      j2 = m::splat(-1);
+    } else {
+      j0 = m::div(2.0f * ci, ci + root);
+      j1 = m::div(2.0f * nn * ci, m::fma(m::splat(nn * nn), ci, root));
+    }
+  }
+  if (prt_fresh) prt_first_diag(P, b, k0x, k0y, k0z, k1x, k1y, k1z, j0, j1, j2);
+  else prt_apply_diag(P, b, k0x, k0y, k0z, k1x, k1y, k1z, j0, j1, j2);
+  prt_fresh = false;
+}
+
 // --------------------------------------------------------------------------
 // one surface for the RPT rays of a thread: standard_surface.py:200-248 (minus
 // record).  Phases run across the thread's rays so that independent chains
@@ -1716,14 +2041,15 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
                                          cptr<typename Math<V>::scalar> coeffs,
                                          const V (&t)[RPT], const V (&nx)[RPT], const V (&ny)[RPT],
                                          const V (&nz)[RPT], Ray<V> (&r)[RPT],
-                                         Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
+                                         Prt<typename PrtLane<V, POLK>::type, POLK> (&P)[POLK ? RPT : 1],
                                          bool& prt_fresh, uint32_t pol_flags = 0) {
   // prt_fresh (wave-uniform): the matrices still hold the identity a fresh trace starts
   // from -- the first real update then writes O_out J O_in instead of multiplying by it
   // pol_flags (launch-uniform): kPolNonUnitK, see below
   using m = Math<V>;
   using T = typename m::scalar;
-  static_assert(POLK == 0 || m::lanes == 1, "the polarised path is scalar");
+  static_assert(POLK == 0 || m::lanes == 1 || POLK == 1,
+                "the polarised path: scalar, or the real-matrix fp32 pair");
   const V zero = m::splat(0), one = m::splat(1);
   // homogeneous.py:44-53, standard_surface.py:244
   if (o.absorb > T(0)) {
@@ -1833,7 +2159,11 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
 #pragma unroll
     for (int k = 0; k < RPT; ++k) r[k].i = r[k].i * f;
   }
-  if constexpr (POLK != 0) {
+  if constexpr (POLK != 0 && m::lanes == 2) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+      polarise_pair(s, o, L0[k], M0[k], N0[k], adot[k], nx[k], ny[k], nz[k], r[k], P[k], prt_fresh);
+  } else if constexpr (POLK != 0) {
     const int ck = s.coating_kind;
     const bool reflect = s.interaction == kReflect;
     const T nn = o.nn;
@@ -1960,12 +2290,13 @@ OL_DEV void interact(const DevSurf<typename Math<V>::scalar>& s,
 template <typename V, int RPT, int POLK, int NR, bool SHARE = false, typename H>
 OL_DEV void surface_step(const H& h, cptr<typename Math<V>::scalar> coeffs, bool from_global,
                          Ray<V> (&r)[RPT],
-                         Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
+                         Prt<typename PrtLane<V, POLK>::type, POLK> (&P)[POLK ? RPT : 1],
                          uint32_t& status, bool& prt_fresh, const NrRefCtl* ref = nullptr,
                          uint32_t pol_flags = 0) {
   using m = Math<V>;
   using T = typename m::scalar;
-  static_assert(NR == 0 || m::lanes == 1, "the Newton-Raphson path is scalar");
+  static_assert(NR == 0 || m::lanes == 1 || NR == kNrZernike,
+                "the Newton-Raphson path: scalar, or the polynomial-Zernike fp32 pair");
   static_assert(NR != kNrReference || RPT == 1, "reference-Newton launches: one ray per lane");
   {
     const DevSurf<T> s = h.surf();
@@ -2030,6 +2361,68 @@ OL_DEV void surface_step(const H& h, cptr<typename Math<V>::scalar> coeffs, bool
     nx[0] = gx * im;
     ny[0] = gy * im;
     nz[0] = -im;
+  } else if constexpr (NR != 0 && m::lanes == 2) {
+    // the pair form (polynomial-form Zernike surfaces only: capi.hip, pair_polz_ok): the loop of
+    // the scalar branch below with both rays of a lane in one NewtonRay<f32x2>
+    NewtonRay<V> q[RPT];
+    int max_iter;
+    {
+      const DevSurf<T> s = h.surf();
+      max_iter = s.max_iter;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        t[k] = (s.flags & kSurfRadiusInf)
+                   ? flat_distance<V>(r[k].z, r[k].N)
+                   : curved_distance<V, SHARE>(s.cv, s.kp1, r[k].x, r[k].y, r[k].z, r[k].L, r[k].M,
+                                               r[k].N);
+        q[k].xb = m::fma(t[k], r[k].L, r[k].x);
+        q[k].yb = m::fma(t[k], r[k].M, r[k].y);
+        q[k].zb = m::fma(t[k], r[k].N, r[k].z);
+        q[k].dt = m::splat(0);
+        q[k].fprev = m::splat(0);
+        q[k].gx = q[k].gy = m::splat(0);
+        q[k].active = m::all(true);
+      }
+    }
+    int it = 0;
+    for (; it < max_iter; ++it) {
+      bool any = false;
+      const DevSurf<T> s = h.surf();
+      cptr<T> c = coeffs + s.coeff_off;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        if (m::any(q[k].active)) newton_iterate(s, c, q[k], r[k].L, r[k].M, r[k].N, it, status);
+        any = any || m::any(q[k].active);
+      }
+      if (!hw::wave_any(any)) {
+        ++it;
+        break;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      r[k].x = m::fma(q[k].dt, r[k].L, q[k].xb);
+      r[k].y = m::fma(q[k].dt, r[k].M, q[k].yb);
+      r[k].z = m::fma(q[k].dt, r[k].N, q[k].zb);
+      t[k] = t[k] + q[k].dt;
+    }
+    if (it == 0) {  // max_iter == 0: no evaluation happened, take the gradient here
+      const DevSurf<T> s = h.surf();
+      cptr<T> c = coeffs + s.coeff_off;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        V sag;
+        uint32_t st = 0;
+        zernike_mono_eval(s, c, r[k].x, r[k].y, sag, q[k].gx, q[k].gy, m::all(false), st);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const V im = m::rsqrt(m::fma(q[k].gx, q[k].gx, m::fma(q[k].gy, q[k].gy, m::splat(1))));
+      nx[k] = q[k].gx * im;
+      ny[k] = q[k].gy * im;
+      nz[k] = -im;
+    }
   } else if constexpr (NR != 0) {
     constexpr bool COMPACT = NR == kNrCompact;
     NewtonRay<T> q[RPT];
@@ -2133,7 +2526,7 @@ OL_DEV void surface_step(const DevSurf<typename Math<V>::scalar>& s,
                          const DevOptics<typename Math<V>::scalar>& o,
                          cptr<typename Math<V>::scalar> coeffs, bool from_global,
                          Ray<V> (&r)[RPT],
-                         Prt<typename Math<V>::scalar, POLK> (&P)[POLK ? RPT : 1],
+                         Prt<typename PrtLane<V, POLK>::type, POLK> (&P)[POLK ? RPT : 1],
                          uint32_t& status, bool& prt_fresh, const NrRefCtl* ref = nullptr,
                          uint32_t pol_flags = 0) {
   const SurfLoaded<typename Math<V>::scalar> h{s, o};

@@ -125,10 +125,24 @@ struct LanePack {
 #ifndef OL_PACKED_F32
 #define OL_PACKED_F32 1
 #endif
+#ifndef OL_POLZ_PACKED
+#define OL_POLZ_PACKED 1  // 0: the polarised Zernike pair on two SCALAR rays per lane (A/B knob)
+#endif
   static constexpr bool packed =
-      OL_PACKED_F32 && sizeof(T) == 4 && (RPT == 4 || RPT == 2) && POLK == 0 && NR == 0;
+      sizeof(T) == 4 && ((OL_PACKED_F32 && (RPT == 4 || RPT == 2) && POLK == 0 && NR == 0) ||
+                         (OL_POLZ_PACKED && RPT == 2 && POLK == 1 && NR == kNrZernike));
   using V = typename std::conditional<packed, f32x2, T>::type;
   static constexpr int NV = packed ? RPT / 2 : RPT;
+  // the PRT matrices of a polarised launch: one per lane ELEMENT (Prt<V>: a pair of matrices in
+  // the packed form); element e of ray k's matrix
+  using PT = typename PrtLane<V, POLK>::type;
+  using PrtArr = Prt<PT, POLK>[POLK ? NV : 1];
+  static __device__ __forceinline__ T pget(const PrtArr& P, int k, int e) {
+    if constexpr (packed && POLK != 0) return P[k / 2].m[e][k % 2]; else return P[k].m[e];
+  }
+  static __device__ __forceinline__ void pset(PrtArr& P, int k, int e, T x) {
+    if constexpr (packed && POLK != 0) P[k / 2].m[e][k % 2] = x; else P[k].m[e] = x;
+  }
   // ray k of the thread: element (k % lanes) of pack (k / lanes)
   static __device__ __forceinline__ T get(const V& v, int e) {
     if constexpr (packed) return v[e]; else return v;
@@ -444,10 +458,16 @@ __device__ __forceinline__ SurfFetched<T> fetched_surface_of(int s, const DevOpt
 #endif
 // (The generic-family kernel WITH the generator prologue does not fit 7 waves without two
 // dwords of scratch: it keeps the allocator's own choice.)
+// the polarised Zernike fp32 PAIR (OL_POLZ_PAIR): 108 VGPRs = 4 waves left to itself
+#ifndef OL_POLZ_PAIR_WAVES
+#define OL_POLZ_PAIR_WAVES 0
+#endif
 template <typename T, int RPT, int POLK, int NR, bool GEN = false>  // GEN: any generating form
 struct WavesPerEu {
   static constexpr int value =
-      (OL_POLNR_WAVES > 0 && sizeof(T) == 4 && RPT == 1 && POLK == 1 && NR != 0 &&
+      (OL_POLZ_PAIR_WAVES > 0 && sizeof(T) == 4 && RPT == 2 && POLK == 1 && NR == kNrZernike)
+          ? OL_POLZ_PAIR_WAVES
+      : (OL_POLNR_WAVES > 0 && sizeof(T) == 4 && RPT == 1 && POLK == 1 && NR != 0 &&
        NR != kNrReference && !(GEN && NR == 1))
           ? OL_POLNR_WAVES
           : ((OL_POLNR_WAVES_F64 > 0 && sizeof(T) == 8 && RPT == 1 && POLK == 1 && NR != 0)
@@ -477,9 +497,9 @@ struct WavesPerEu {
 // LDS slots of the update_intensity epilogue (EPI): launch direction and `_i0` per lane, from
 // the generating prologue to the epilogue.  One object for both ends (a function-local
 // __shared__ array is a static of THIS function), allocated only in kernels that call it.
-template <typename T>
-__device__ __forceinline__ T (*epi_launch_slots())[kTraceBlock] {
-  __shared__ T slots[4][kTraceBlock];
+template <typename T, int RPT = 1>
+__device__ __forceinline__ T (*epi_launch_slots())[kTraceBlock * RPT] {
+  __shared__ T slots[4][kTraceBlock * RPT];
   return slots;
 }
 
@@ -535,14 +555,15 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
   constexpr int NV = LP::NV;
   Ray<V> r[NV];
   constexpr int NPRT = POLK == 2 ? 18 : 9;  // PRT planes (real, then imaginary)
-  Prt<T, POLK> P[POLK ? RPT : 1];
+  typename LP::PrtArr P;  // (one matrix per ray; per PAIR of rays in the packed polarised form)
   uint32_t status = 0;
   if constexpr (GEN != 0) {
     // one ray per lane -- or, for the lean fp32 launch-uniform form, the packed PAIR of the
     // record-mode kernel (two rays generated one after the other, then traced as one f32x2)
-    static_assert(RPT == 1 || (RPT == 2 && GEN == kGenUniform && POLK == 0 && NR == 0 &&
-                               sizeof(T) == 4),
-                  "the generating prologue: one ray per lane, or the lean fp32 pair");
+    static_assert(RPT == 1 || (RPT == 2 && GEN == kGenUniform && sizeof(T) == 4 &&
+                               ((POLK == 0 && NR == 0) || (POLK == 1 && NR == kNrZernike))),
+                  "the generating prologue: one ray per lane, the lean fp32 pair, or the "
+                  "polarised Zernike fp32 pair (OL_POLZ_PAIR)");
     // POLARISED generating launches (round 5): ONE form, GEN == kGenUniform, that takes per-ray
     // field planes and an apodized pupil at RUN time (launch-uniform branches) -- the
     // prologue is nowhere near the register peak of a kernel that carries a PRT matrix through
@@ -611,17 +632,18 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
         // time (32 vector instructions per ray in fp32 and the pupil / field planes read
         // again, in a kernel bound by vector issue; profiles/r06_phase_costs_before.txt);
         // LDS traffic goes down its own pipe and 4 KB of the CU's 160 KB were idle anyway.
-        static_assert(RPT == 1, "the update_intensity epilogue: one ray per lane");
-        T (*epi_launch)[kTraceBlock] = epi_launch_slots<T>();
-        epi_launch[0][threadIdx.x] = q.L;
-        epi_launch[1][threadIdx.x] = q.M;
-        epi_launch[2][threadIdx.x] = q.N;
-        epi_launch[3][threadIdx.x] = q.i;
+        T (*epi_launch)[kTraceBlock * RPT] = epi_launch_slots<T, RPT>();
+        epi_launch[0][threadIdx.x * RPT + k] = q.L;
+        epi_launch[1][threadIdx.x * RPT + k] = q.M;
+        epi_launch[2][threadIdx.x * RPT + k] = q.N;
+        epi_launch[3][threadIdx.x * RPT + k] = q.i;
       }
     }
     if constexpr (POLK != 0) {
 #pragma unroll
-      for (int e = 0; e < NPRT; ++e) P[0].m[e] = (e == 0 || e == 4 || e == 8) ? T(1) : T(0);
+      for (int k = 0; k < RPT; ++k)
+#pragma unroll
+        for (int e = 0; e < NPRT; ++e) LP::pset(P, k, e, (e == 0 || e == 4 || e == 8) ? T(1) : T(0));
     }
   } else
   {
@@ -677,7 +699,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
         const bool ident = (a.flags & kTracePrtIdentity) != 0;  // PRT starts as I
 #pragma unroll
         for (int e = 0; e < NPRT; ++e)
-          P[k].m[e] = ident ? ((e == 0 || e == 4 || e == 8) ? T(1) : T(0)) : pin[e][k];
+          LP::pset(P, k, e, ident ? ((e == 0 || e == 4 || e == 8) ? T(1) : T(0)) : pin[e][k]);
       }
     }
   }
@@ -785,7 +807,8 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
       // (OL_RECORD_ARGS_FRESH: also in the polarised / Newton kernels that otherwise keep
       // their arguments by value -- held across the surface body, the block's address and
       // stride were SGPR-spilled and came back through 6-8 v_readlane per recorded row)
-      if constexpr (kFetchArgs || (OL_RECORD_ARGS_FRESH && RPT == 1 && (NR != 0 || POLK != 0))) {
+      if constexpr (kFetchArgs || (OL_RECORD_ARGS_FRESH && (NR != 0 || POLK != 0) &&
+                                   (RPT == 1 || GEN != 0))) {
         const auto ka = kernargs<T, TraceArgs<T>>();
         record = ka->a.record;
         stride = ka->a.record_stride;
@@ -937,7 +960,7 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
 #pragma unroll
     for (int e = 0; e < NPRT; ++e) {
 #pragma unroll
-      for (int k = 0; k < RPT; ++k) tmp[k] = P[k].m[e];
+      for (int k = 0; k < RPT; ++k) tmp[k] = LP::pget(P, k, e);
       // (the plane's base as a SCALAR pointer, said outright: left to itself the compiler
       // folded e * n into the per-lane address -- a 64-bit multiply-add in vector registers
       // for every one of the 9 / 18 stores, ~3.5 vector instructions each)
@@ -968,16 +991,25 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
         f.br[k] = ka->a.pf.br[k]; f.bi[k] = ka->a.pf.bi[k];
       }
       f.nf = ka->a.pf.nf;
-      T Pm[9], Qm[9];
+      T (*epi_launch)[kTraceBlock * RPT] = epi_launch_slots<T, RPT>();  // (the prologue's slots)
+      T upd_k[RPT];
 #pragma unroll
-      for (int e = 0; e < 9; ++e) {
-        Pm[e] = P[0].m[e];
-        Qm[e] = POLK == 2 ? P[0].m[POLK == 2 ? 9 + e : e] : T(0);
+      for (int k = 0; k < RPT; ++k) {
+        T Pm[9], Qm[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+          Pm[e] = LP::pget(P, k, e);
+          Qm[e] = POLK == 2 ? LP::pget(P, k, POLK == 2 ? 9 + e : e) : T(0);
+        }
+        const int slot = threadIdx.x * RPT + k;
+        const T L0 = epi_launch[0][slot], M0 = epi_launch[1][slot], N0 = epi_launch[2][slot],
+                i0 = epi_launch[3][slot];
+        uint32_t st_k = 0;
+        upd_k[k] = pol_intensity_one<T, POLK == 2>(f, L0, M0, N0, Pm, Qm, i0, st_k);
+        if (k < cnt) status |= st_k;
       }
-      T (*epi_launch)[kTraceBlock] = epi_launch_slots<T>();  // (the prologue's slots)
-      const T L0 = epi_launch[0][threadIdx.x], M0 = epi_launch[1][threadIdx.x],
-              N0 = epi_launch[2][threadIdx.x], i0 = epi_launch[3][threadIdx.x];
-      base.at(upd)[0] = pol_intensity_one<T, POLK == 2>(f, L0, M0, N0, Pm, Qm, i0, status);
+      if constexpr (RPT == 1) base.at(upd)[0] = upd_k[0];
+      else store_plane<T, RPT>(upd, base, cnt, upd_k);
     }
   }
   if (status && late.status) atomicOr(late.status, status);
@@ -1101,6 +1133,7 @@ static hipError_t launch_pair(const TraceArgs<T>& a, hipStream_t stream) {
 #ifndef OL_GEN_PAIR
 #define OL_GEN_PAIR 1
 #endif
+// (OL_POLZ_PAIR: trace_launch.h)
 template <typename T>
 static hipError_t launch_gen_pair(const TraceArgs<T>& a, hipStream_t stream) {
   const int64_t threads = (a.n + 1) / 2;
@@ -1125,6 +1158,27 @@ static hipError_t launch_gen_nr(const TraceArgs<T>& a, bool pair_ok, hipStream_t
     if (pair_ok && a.prt == nullptr && a.in.hx == nullptr && a.rgc.apod_kind == 0 &&
         (want == 3 || (want == 0 && OL_GEN_PAIR)))
       return launch_gen_pair<T>(a, stream);
+  }
+  if constexpr (sizeof(T) == 4 && NR == kNrZernike) {
+    // OL_POLZ_PAIR: the polarised Zernike fp32 launch (configuration C5) on TWO rays per lane
+    const int want = tuning().rays_per_thread;
+    if (pair_ok && a.prt != nullptr && !(a.flags & kTracePrtComplex) && a.spot == nullptr &&
+        a.n % 2 == 0 && reinterpret_cast<uintptr_t>(a.prt) % 8 == 0 &&
+        reinterpret_cast<uintptr_t>(a.i_updated) % 8 == 0 &&
+        (want == 3 || (want == 0 && OL_POLZ_PAIR))) {
+      const int64_t threads = (a.n + 1) / 2;
+      const int64_t blocks2 = (threads + kTraceBlock - 1) / kTraceBlock;
+      if (blocks2 == 0) return hipSuccess;
+      if (blocks2 > 0x7fffffffLL) return hipErrorInvalidValue;
+      const dim3 grid2((unsigned)blocks2), block2(kTraceBlock);
+      if (a.i_updated != nullptr)
+        hipLaunchKernelGGL((trace_kernel<T, 2, true, 1, NR, false, kGenUniform, true>), grid2,
+                           block2, 0, stream, a.surf, a.cold, a.optics, a.coeffs, a);
+      else
+        hipLaunchKernelGGL((trace_kernel<T, 2, true, 1, NR, false, kGenUniform, false>), grid2,
+                           block2, 0, stream, a.surf, a.cold, a.optics, a.coeffs, a);
+      return hipGetLastError();
+    }
   }
   const int64_t blocks = (a.n + kTraceBlock - 1) / kTraceBlock;
   if (blocks == 0) return hipSuccess;
@@ -1167,7 +1221,7 @@ hipError_t launch_trace_generate(const TraceArgs<T>& a_in, int nr_family, bool p
   // ol_newton_count read the generated rays)
   if (nr_family == kNrReference) return hipErrorInvalidValue;
   if (nr_family == kNrNone) return launch_gen_nr<T, 0>(a, pair_ok, stream);
-  if (nr_family == kNrZernike) return launch_gen_nr<T, kNrZernike>(a, false, stream);
+  if (nr_family == kNrZernike) return launch_gen_nr<T, kNrZernike>(a, pair_ok, stream);
   if (nr_family == kNrEvenAsphere) return launch_gen_nr<T, kNrEvenAsphere>(a, false, stream);
   return launch_gen_nr<T, 1>(a, false, stream);
 }

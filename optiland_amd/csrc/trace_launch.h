@@ -27,6 +27,15 @@ constexpr int kGenFieldPlanes = 2;  // + per-ray field planes hx, hy (and, if gi
 constexpr int kGenApod = 4;         // + pupil apodization as the initial intensity
 
 // process-wide tuning knobs (ol_set_tuning)
+// OL_POLZ_PAIR: the generating polarised Zernike fp32 launch (configuration C5) on TWO rays per
+// lane, traced as one f32x2 through surface_step<f32x2, 1, 1, kNrZernike> (surface_math.h: the
+// pair forms): every multiply-add of the two rays is one packed instruction, stores are 8 bytes
+// per lane.  Taken when capi.hip finds the launch eligible (pair_ok); ol_set_tuning
+// (OL_TUNE_RAYS_PER_THREAD: 1 = one ray per lane, 3 = pair) overrides the default for A/B runs.
+#ifndef OL_POLZ_PAIR
+#define OL_POLZ_PAIR 0
+#endif
+
 struct Tuning {
   int rays_per_thread = 0;  // 0 = default, 1 = one ray per lane, 2 = force vector
   int compact = 0;          // measured slower; opt-in (OL_TUNE_COMPACT)

@@ -234,6 +234,71 @@ inline void trace_pair_gen(const TraceArgs<float>& a, int64_t i0, uint32_t& stat
   if (a.flags & kTraceWriteRays) put(a.rays, 0, nullptr);
 }
 
+// trace_kernel<float, 2, true, 1, kNrZernike, false, kGenUniform, EPI> (OL_POLZ_PAIR: the polarised
+// Zernike fp32 launch on packed pairs): the general generating prologue per ray, then ONE f32x2
+// through surface_step<f32x2, 1, 1, kNrZernike> with a pair of PRT matrices -- what the device
+// instantiates.  (The launcher sends even ray counts only.)
+inline void trace_pair_gen_polz(const TraceArgs<float>& a, int64_t i0, uint32_t& status) {
+  using V = f32x2;
+  const int cnt = (a.n - i0) >= 2 ? 2 : 1;
+  Ray<V> r[1];
+  const RaygenIn<float>& in_ = a.in;
+  for (int k = 0; k < 2; ++k) {
+    const int64_t i = i0 + (k < cnt ? k : 0);
+    float tx = in_.tx0, ty = in_.ty0, vx = in_.vx0, vy = in_.vy0, o[6];
+    uint32_t st_k = 0;
+    if (in_.hx != nullptr) {
+      const float hx = in_.hx[i], hy = in_.hy[i];
+      if (in_.vx != nullptr) { vx = in_.vx[i]; vy = in_.vy[i]; }
+      if ((in_.flags & kRaygenCheckField) && (outside_unit(hx) || outside_unit(hy)))
+        st_k |= kStatusFieldRange;
+      raygen_field<float>(a.rgc, hx, hy, tx, ty);
+    }
+    float px = k < cnt ? in_.px[i] : 0.0f, py = k < cnt ? in_.py[i] : 0.0f;
+    raygen_pupil<float>(in_.flags, vx, vy, px, py, st_k);
+    if (k < cnt) status |= st_k;
+    raygen_one<float>(a.rgc, tx, ty, px, py, vx, vy, o);
+    r[0].x[k] = o[0]; r[0].y[k] = o[1]; r[0].z[k] = o[2];
+    r[0].L[k] = o[3]; r[0].M[k] = o[4]; r[0].N[k] = o[5];
+    r[0].i[k] = a.rgc.apod_kind != 0 ? raygen_apodize<float>(a.rgc, px, py) : 1.0f;
+    r[0].opd[k] = 0.0f;
+  }
+  Prt<V, 1> P[1];
+  for (int e = 0; e < 9; ++e) P[0].m[e] = V{(e % 4 == 0) ? 1.0f : 0.0f, (e % 4 == 0) ? 1.0f : 0.0f};
+  bool is_global = true, prt_fresh = true;
+  DevSurf<float> last_traced;
+  std::memset(static_cast<void*>(&last_traced), 0, sizeof(last_traced));
+  last_traced.cold = a.cold;
+  const int rec_from = a.record_from > a.first ? a.record_from : a.first;
+  auto put = [&](float* const plane[8], int64_t stride_or_zero, float* row) {
+    const Ray<V> g = is_global ? r[0] : to_global<V>(last_traced, r[0]);
+    const V f[8] = {g.x, g.y, g.z, g.L, g.M, g.N, g.i, g.opd};
+    for (int q = 0; q < 8; ++q)
+      for (int k = 0; k < cnt; ++k) {
+        if (row) row[q * stride_or_zero + i0 + k] = f[q][k];
+        else plane[q][i0 + k] = f[q][k];
+      }
+  };
+  for (int s = a.first; s <= a.last; ++s) {
+    DevSurf<float> S;
+    static_cast<DevSurfHot<float>&>(S) = a.surf[s];
+    S.cold = a.cold + s;
+    if (S.interaction != kRecordOnly) {
+      const SurfFetched<float> h{a.surf + s, a.cold + s, a.optics + (s * a.n_wl + a.wl)};
+      surface_step<V, 1, 1, kNrZernike>(h, a.coeffs, is_global, r, P, status, prt_fresh, nullptr, 0u);
+      is_global = false;
+      last_traced = S;
+    }
+    if (a.record && s >= rec_from && !(s == a.first && (a.flags & kTraceRow0IsInput)))
+      put(nullptr, a.record_stride, a.record + (int64_t)(s - rec_from) * 8 * a.record_stride);
+  }
+  for (int k = 0; k < cnt; ++k)
+    if (r[0].L[k] != r[0].L[k] && r[0].x[k] == r[0].x[k]) status |= kStatusNanDirection;
+  if (a.flags & kTraceWriteRays) put(a.rays, 0, nullptr);
+  for (int e = 0; e < 9; ++e)
+    for (int k = 0; k < cnt; ++k) a.prt[(int64_t)e * a.n + i0 + k] = P[0].m[e][k];
+}
+
 template <typename T, int POLK, int NR, bool GEN = false>
 void trace_all(const TraceArgs<T>& a) {
   uint32_t status = 0;
@@ -289,6 +354,18 @@ static hipError_t gen_nr(const TraceArgs<T>& a, bool pair_ok) {
       paired = true;
     }
   }
+  if constexpr (sizeof(T) == 4 && NR == kNrZernike) {
+    // the device's choice (trace_kernel.hip: launch_gen_nr): the polarised Zernike pair
+    const int want = tuning().rays_per_thread;
+    if (pair_ok && polk == 1 && a.spot == nullptr && a.n % 2 == 0 &&
+        (want == 3 || (want == 0 && OL_POLZ_PAIR))) {
+      uint32_t status = 0;
+      ++g_pair_launches;
+      for (int64_t i = 0; i < a.n; i += 2) trace_pair_gen_polz(a, i, status);
+      if (status && a.status) *a.status |= status;
+      paired = true;
+    }
+  }
   if (paired) {
   } else if (polk == 2) trace_all<T, 2, NR, true>(a);
   else if (polk == 1) trace_all<T, 1, NR, true>(a);
@@ -335,7 +412,7 @@ hipError_t launch_trace_generate(const TraceArgs<T>& a, int nr_family, bool pair
                                  hipStream_t) {
   switch (nr_family) {
     case kNrNone: return gen_nr<T, kNrNone>(a, pair_ok);
-    case kNrZernike: return gen_nr<T, kNrZernike>(a, false);
+    case kNrZernike: return gen_nr<T, kNrZernike>(a, pair_ok);
     case kNrEvenAsphere: return gen_nr<T, kNrEvenAsphere>(a, false);
     case kNrReference: return hipErrorInvalidValue;  // (as the device launcher)
     default: return gen_nr<T, kNrGeneric>(a, false);

@@ -711,3 +711,28 @@ def test_random_wavefront_opd(seed):
     assert np.isfinite(want).all()
     np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(want).max()))
     np.testing.assert_allclose(pupil, want_pupil, rtol=0, atol=1e-10 * abs(R))
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_polarised_zernike_pair_equals_the_one_ray_form(seed):
+    """Configuration C5's generating launch on PAIRS of fp32 rays (OL_POLZ_PAIR: two rays per
+    lane as one f32x2, csrc/surface_math.h "pair forms") against the one-ray-per-lane form of the
+    same launch ON THE DEVICE: record, PRT planes, updated intensity and status bit for bit, on
+    the shaken C5 systems of tests/test_polz_pair.py (the host twin)."""
+    from optiland_amd.engine import HipSystem
+    from tests import test_polz_pair as tp
+    table = tp.random_c5_table(seed)
+    rng = np.random.default_rng(seed)
+    hip = HipSystem(table, DEV)
+    try:
+        n = int(rng.choice([2, 254, 1000, 4098, 100_000]))
+        px, py = tp._pupil(n, rng, reach=1.0 if seed % 3 else 1.08)
+        px, py = px.to(DEV), py.to(DEV)
+        state = tp.POLARISED if seed % 2 else tp.STATE
+        kw = dict(field=(float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))),
+                  update_intensity=state if seed % 3 != 1 else None)
+        one = tp._launch(hip, px, py, 0, 1, **kw)
+        pair = tp._launch(hip, px, py, 0, 3, **kw)
+        tp.assert_same_bits(one, pair, f"seed {seed}")
+    finally:
+        hip.close()

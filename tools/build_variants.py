@@ -20,6 +20,11 @@ VARIANTS = {
     # on the one-ray-per-lane Newton / polarised kernels (trace_kernel.hip: OL_RECORD_DIRECT,
     # OL_PRT_SCALAR_BASE, OL_RECORD_ARGS_FRESH) and the packed PRT updates, against the product
     # (rows through a copy, per-lane PRT bases, fresh record arguments, packed PRT)
+    # the polarised Zernike fp32 pair (OL_POLZ_PAIR): occupancy requests (108 VGPRs = 4 waves by
+    # itself; 5 waves: 11 VGPRs to scratch, 6: 39), and the pair on two SCALAR rays per lane
+    "o6_pair_w5": ["-DOL_POLZ_PAIR_WAVES=5"],
+    "o6_pair_w6": ["-DOL_POLZ_PAIR_WAVES=6"],
+    "o6_pair_unpacked": ["-DOL_POLZ_PACKED=0"],
     "o6_prt_unpacked": ["-DOL_PRT_PACKED=0"],
     "o6_rows_direct": ["-DOL_RECORD_DIRECT=1"],
     "o6_prt_scalar_base": ["-DOL_PRT_SCALAR_BASE=1"],

@@ -180,6 +180,27 @@ for k, v in acc.items():
           f"{a[:, 1].mean() / 8:.4g}  clock {a[:, 2].mean() / 8:.0f} MHz")
 PY
       done; unset OPTILAND_HIP_LIBRARY ;;
+    polz_table) # SQ counters per ray of the C5 fp32 launch on one ray per lane (OL_TRACE_RPT=1) and on pairs (3)
+      for arm in 1 3; do
+        OL_TRACE_RPT=$arm bash tools/gpu_kernel_table.sh $O/r06_polz_table_$arm.txt > /dev/null 2>&1 <<'CFG'
+zf_f32_gen  | --workload zernike_fresnel
+CFG
+        cut -c1-900 $O/r06_polz_table_$arm.txt
+      done ;;
+    polz_pair) # C5 fp32 on two rays per lane: bits against the one-ray form, then arm against arm in one process
+      for arm in product ${VARIANTS:-}; do
+        if [ $arm != product ]; then export OPTILAND_HIP_LIBRARY=$R/optiland_amd/lib/variant_${arm}.so; else unset OPTILAND_HIP_LIBRARY; fi
+        timeout 900 python tools/gpu_polz_pair.py > $O/r06_polz_pair_${arm}.txt 2>&1; tail -${POLZ_TAIL:-24} $O/r06_polz_pair_${arm}.txt
+      done; unset OPTILAND_HIP_LIBRARY ;;
+    polz_cycles) # ... and in engine cycles per launch (GRBM_GUI_ACTIVE): OL_TRACE_RPT=1 (one ray per lane) against 3 (pair)
+      for arm in 1 3; do
+        OUTD=$O/polz_cycles_${arm}; rm -rf $OUTD; mkdir -p $OUTD
+        (cd /tmp && TMPDIR=/tmp OL_TRACE_RPT=$arm CONFIGS=zf_f32 ROUNDS=2 LAUNCHES=40 timeout 600 \
+          rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUTD/a -o ct -- \
+          python $R/tools/gpu_clock_transient.py > $OUTD/run.log 2>&1; echo "rc=$?" >> $OUTD/run.log)
+        python $R/tools/clock_transient_report.py $OUTD > $O/r06_polz_cycles_${arm}.txt 2>&1
+        grep -A44 "## zf_f32 round 1" $O/r06_polz_cycles_${arm}.txt | awk 'NR>12 && NF>=5 {t+=$2; c+=$4; k+=1} END {if (k) printf "rpt=%s launches 10+: event_ms %.4f  cycles per launch %.4g\n", "'$arm'", t/k, c/k}'
+      done ;;
     primed)    # is a block that has just been probed under sustained load "hot"? (tools/gpu_primed.py)
       timeout 600 python tools/gpu_primed.py > $O/r06_primed_${TAG:-0}.txt 2>&1; tail -12 $O/r06_primed_${TAG:-0}.txt ;;
     fuzz_tables) # kernel vs oracle on every table under fuzz_tables/ (tools/make_fuzz_tables.py LO HI, CPU, beforehand)
