@@ -1113,7 +1113,42 @@ _SEAMS = {
     "pad": ("optiland.psf.fft", "ScalarFFTPSF", "_pad_pupils", ("self",), "_fft_pad_pupils"),
     "dist_hex": ("optiland.distribution", "HexagonalDistribution", "generate_points",
                  ("self", "num_rings"), "_hexapolar_generate_points"),
+    "field_coords": ("optiland.fields.field_group", "FieldGroup", "get_field_coords", ("self",),
+                     "_memo_get_field_coords"),
 }
+def _memo_get_field_coords(self):
+    """`FieldGroup.get_field_coords()` (fields/field_group.py:124-139), remembered.  Every analysis
+    constructor asks for it (`utils.resolve_fields(optic, "all")`), and on the torch backend each
+    call is a dozen tiny device launches and 2 F + 1 device-to-host reads (`float(x / max_field)`
+    per coordinate): ~0.15 ms of a 0.5 ms `SpotDiagram(lens)`.  The answer is a pure function of
+    the fields' coordinates and of the backend's arithmetic: it is computed ONCE by the
+    reference's own code and handed out again while the (x, y) of every field -- plain Python
+    numbers -- and the backend / precision / device are what they were.  Tensors as field
+    coordinates (an optimisation variable): no memo."""
+    import optiland.backend as be
+
+    original = _ORIG["field_coords"]
+    vals = []
+    for f in self.fields:
+        x, y = f.x, f.y
+        if type(x) not in (int, float) or type(y) not in (int, float):
+            return original(self)
+        vals.append((x, y))
+    try:
+        cfg = be._backends[be.get_backend()]._config
+        key = (tuple(vals), be.get_backend(), cfg.get_precision(), str(cfg.get_device()))
+    except Exception:  # noqa: BLE001 - a backend without that configuration object: no memo
+        return original(self)
+    memo = self.__dict__.get("_hip_field_coords")
+    if memo is not None and memo[0] == key:
+        STATS["field_coords_memo"] = STATS.get("field_coords_memo", 0) + 1
+        return list(memo[1])
+    out = original(self)
+    if all(type(a) in (int, float) and type(b) in (int, float) for a, b in out):
+        self.__dict__["_hip_field_coords"] = (key, tuple(out))
+    return out
+
+
 # (dependent seams ..., the seam they need): the FFT-PSF pair scatters the OPD seam's device data
 _GROUPS = (("pupils", "pad", "opd"),)
 SKIPPED: dict = {}                      # key -> why the seam was not installed

@@ -1035,3 +1035,36 @@ def test_polarised_opd_map_through_the_seam(seams, state, reference_type, reques
     for a, b in zip(got[6], want[6]):
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-6)
     np.testing.assert_allclose(got[7], want[7], rtol=1e-9)
+
+
+def test_field_coordinates_are_remembered_until_a_field_or_the_backend_changes(seams):
+    """`FieldGroup.get_field_coords()` -- asked for by every analysis constructor, a dozen device
+    launches and 2 F + 1 read-backs on the torch backend -- is computed once by the reference's own
+    code and handed out again while the fields' (x, y) and the backend's arithmetic are what they
+    were (`analysis_seams._memo_get_field_coords`)."""
+    be, stats = seams
+    from optiland_amd import analysis_seams
+    original = analysis_seams._ORIG["field_coords"]
+    lens = _cooke()
+    fg = lens.fields
+    first = fg.get_field_coords()
+    assert first == original(fg) and stats.get("field_coords_memo", 0) == 0
+    again = fg.get_field_coords()
+    assert again == first and again is not first and stats["field_coords_memo"] == 1
+    again.append("mine")                                   # the caller's list is the caller's
+    assert fg.get_field_coords() == first
+    fg.fields[1].y = fg.fields[1].y * 0.5                  # an edited field
+    assert fg.get_field_coords() == original(fg) != first
+    n = stats["field_coords_memo"]
+    be.set_precision("float32")                            # other arithmetic: computed again
+    try:
+        assert fg.get_field_coords() == original(fg)
+        assert stats["field_coords_memo"] == n
+    finally:
+        be.set_precision("float64")
+    fg.fields[2].y = be.array(fg.fields[2].y)              # a tensor (a variable): no memo
+    n = stats["field_coords_memo"]
+    assert fg.get_field_coords() == original(fg) and fg.get_field_coords() == original(fg)
+    assert stats["field_coords_memo"] == n
+    import copy
+    assert copy.deepcopy(lens).fields.get_field_coords() == original(fg)

@@ -75,6 +75,26 @@ def main():
             pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28)
             doc["profile_6_rings_x50"] = s.getvalue()
             print(s.getvalue()[:6000])
+            for _ in range(3):
+                analysis.SpotDiagram(lens, num_rings=400).rms_spot_radius()
+            pr = cProfile.Profile()
+            pr.enable()
+            for _ in range(20):
+                analysis.SpotDiagram(lens, num_rings=400).rms_spot_radius()
+            pr.disable()
+            s = io.StringIO()
+            pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(40)
+            doc["profile_400_rings_rms_x20"] = s.getvalue()
+            print(s.getvalue()[:9000])
+            # ... and where the DEVICE time of one such call goes (kernels, by name)
+            from torch.profiler import ProfilerActivity, profile
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                for _ in range(5):
+                    analysis.SpotDiagram(lens, num_rings=400).rms_spot_radius()
+                torch.cuda.synchronize()
+            doc["device_400_rings_rms_x5"] = prof.key_averages().table(
+                sort_by="cuda_time_total", row_limit=14, max_name_column_width=60)
+            print(doc["device_400_rings_rms_x5"][:6000])
         integration.disable()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "r06_spotdiag.json"), "w") as f:
