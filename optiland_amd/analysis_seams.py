@@ -377,7 +377,7 @@ def _chief_centers(self, F):
         from optiland.analysis.spot_diagram.reference import ChiefRayReference
     except ImportError:
         return None
-    if type(strat) is not ChiefRayReference or self.coordinates != "global":
+    if type(strat) is not ChiefRayReference or self.coordinates not in ("global", "local"):
         return None
     fields = [(_scalar(fp.coord[0]), _scalar(fp.coord[1])) for fp in self.fields]
     if len(fields) != F or any(hx is None or hy is None for hx, hy in fields):
@@ -391,6 +391,14 @@ def _chief_centers(self, F):
     if not hasattr(eng, "trace_spot_batch") or float(table.last_thickness) != 0.0 \
             or getattr(eng, "_status", None) is None:
         return None
+    if self.coordinates == "local":
+        # reference.py:103-107 localises the hit to the image surface (`transform`:
+        # visualization/system/utils.py:17-47): for an untilted, undecentred image surface that
+        # is x - 0.0, y - 0.0 -- the global hit bit for bit.  Anything else: the reference's code.
+        img = table.surfaces[-1]
+        if bool(img["flags"] & 1) or float(img["origin"][0]) != 0.0 \
+                or float(img["origin"][1]) != 0.0:
+            return None
     from . import _capi
 
     wl, wv = front._wavelength_index(w)
