@@ -801,8 +801,10 @@ int ol_pupil_fill(ol_dtype dt, int64_t n_rays, const void* opd_waves, const void
  *   OL_TUNE_RAYS_PER_THREAD  0 = auto (16-byte vector of rays per lane for conic-only
  *                            ranges, one ray per lane when Newton surfaces are
  *                            present), 1 = one ray per lane, 2 = force the vector,
- *                            3 = fp32 lean ranges: one packed PAIR of rays per lane
- *                            (8-byte loads / stores; measured slower, kept for A/B)
+ *                            3 = fp32, one packed PAIR of rays per lane (8-byte loads /
+ *                            stores): ol_trace on lean ranges (measured slower, kept for
+ *                            A/B); ol_trace_generate of a polarised polynomial-Zernike range
+ *                            (configuration C5; same bits, same time: round 6, A/B only)
  *   OL_TUNE_COMPACT          1 = wavefront straggler compaction in the Newton loop
  *                            (needs the vector layout; default 0, measured slower)
  *   OL_TUNE_FIT_GRID         most blocks an ol_wavefront_fit pass is launched with (0 = the
