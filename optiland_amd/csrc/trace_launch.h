@@ -32,8 +32,12 @@ constexpr int kGenApod = 4;         // + pupil apodization as the initial intens
 // pair forms): every multiply-add of the two rays is one packed instruction, stores are 8 bytes
 // per lane.  Taken when capi.hip finds the launch eligible (pair_ok); ol_set_tuning
 // (OL_TUNE_RAYS_PER_THREAD: 1 = one ray per lane, 3 = pair) overrides the default for A/B runs.
+// Round 6, measured (profiles/r06_polz_*.txt): the same bits; 645 instead of 797 vector
+// instructions per ray and the SAME engine cycles at full clock (a packed instruction costs
+// 1.6-1.8 plain ones on gfx950, tools/microbench/valu_rate.hip); 2-5 % faster in the driver's
+// window and 1.5-3 % in steady state (three alternating bench runs, r06_c5_window.txt) -- ON.
 #ifndef OL_POLZ_PAIR
-#define OL_POLZ_PAIR 0
+#define OL_POLZ_PAIR 1
 #endif
 
 struct Tuning {
