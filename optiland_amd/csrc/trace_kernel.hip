@@ -590,6 +590,32 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
         raygen_field<T>(c, hx, hy, tx, ty);
       }
     }
+    // (two rays per lane: each ray its own field point / vignetting factors)
+    T txs[RPT], tys[RPT], vxs[RPT], vys[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      txs[k] = tx; tys[k] = ty; vxs[k] = vx; vys[k] = vy;
+    }
+    if constexpr (RPT > 1 && kGeneral) {
+      if (in_.hx != nullptr) {  // launch-uniform
+#pragma unroll
+        for (int k = 1; k < RPT; ++k) {
+          const int j = k < cnt ? k : 0;  // (a padding ray of the ragged tail repeats ray 0)
+          const T hx = base.at(in_.hx)[j], hy = base.at(in_.hy)[j];
+          vxs[k] = in_.vx0;
+          vys[k] = in_.vy0;
+          if (in_.vx != nullptr) {
+            vxs[k] = base.at(in_.vx)[j];
+            vys[k] = base.at(in_.vy)[j];
+          }
+          if (k < cnt && (in_.flags & kRaygenCheckField) && (outside_unit(hx) || outside_unit(hy)))
+            status |= kStatusFieldRange;
+          txs[k] = in_.tx0;
+          tys[k] = in_.ty0;
+          raygen_field<T>(c, hx, hy, txs[k], tys[k]);
+        }
+      }
+    }
     T pxs[RPT], pys[RPT];
     if constexpr (RPT == 1) {
       pxs[0] = base.at(in_.px)[0];
@@ -614,9 +640,9 @@ __attribute__((amdgpu_waves_per_eu(WavesPerEu<T, RPT, POLK, NR, GEN != 0 || EPI>
     for (int k = 0; k < RPT; ++k) {
       T px = pxs[k], py = pys[k];
       uint32_t st_k = 0;
-      raygen_pupil<T>(in_.flags, vx, vy, px, py, st_k);
+      raygen_pupil<T>(in_.flags, vxs[k], vys[k], px, py, st_k);
       if (k < cnt) status |= st_k;  // (a padding ray of the ragged tail reports nothing)
-      raygen_one<T>(c, tx, ty, px, py, vx, vy, o);
+      raygen_one<T>(c, txs[k], tys[k], px, py, vxs[k], vys[k], o);
       Ray<T> q;
       q.x = o[0]; q.y = o[1]; q.z = o[2];
       q.L = o[3]; q.M = o[4]; q.N = o[5];

@@ -736,3 +736,11 @@ def test_polarised_zernike_pair_equals_the_one_ray_form(seed):
         tp.assert_same_bits(one, pair, f"seed {seed}")
     finally:
         hip.close()
+
+
+def test_polarised_zernike_pair_with_field_planes_on_the_device():
+    """... and with per-ray field planes, vignetting planes and an apodized pupil: each ray of a
+    lane generated from ITS field point (tests/test_polz_pair.py: field_plane_cases)."""
+    from optiland_amd.engine import HipSystem
+    from tests import test_polz_pair as tp
+    tp.field_plane_cases(lambda table: HipSystem(table, DEV), DEV)
