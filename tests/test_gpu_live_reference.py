@@ -114,13 +114,15 @@ def test_optic_trace_on_device_matches_numpy_backend(be, name, precision):
     _compare(got, want, TOL[precision], f"{name} trace {precision}")
 
 
+@pytest.mark.parametrize("n", [3001, 3000], ids=["ragged", "even"])
 @pytest.mark.parametrize("precision", ["float64", "float32"])
 @pytest.mark.parametrize("name", _live.SYSTEMS)
-def test_optic_trace_generic_on_device_matches_numpy_backend(be, name, precision):
+def test_optic_trace_generic_on_device_matches_numpy_backend(be, name, precision, n):
     """Optic.trace_generic with per-ray field AND pupil arrays handed over as backend
-    arrays (device tensors on the HIP side)."""
+    arrays (device tensors on the HIP side).  n ragged on purpose -- and even: the fp32
+    polarised Zernike launch then runs two rays per lane (OL_POLZ_PAIR), each from its own
+    field point."""
     rng = np.random.default_rng(7)
-    n = 3001  # ragged on purpose
     r, th = np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
     P = (r * np.cos(th), r * np.sin(th))
     H = (np.zeros(n), rng.choice([0.0, 0.5, 1.0], n))
