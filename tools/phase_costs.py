@@ -341,19 +341,49 @@ INST(double)
 '''
 
 
+# What a vector instruction costs on gfx950, in units of a plain fp32 instruction on vector
+# registers (tools/microbench/valu_rate.hip, profiles/r06_valu_rate.txt: 8 waves per SIMD)
+PRICE = {"trans": 3.0, "pk_fma": 1.82, "pk": 1.6, "fma_f64": 1.87, "f64": 1.57, "cmp": 1.6,
+         "cndmask": 1.5, "lane": 1.56, "sgpr_operand": 1.56, "plain": 1.0}
+
+
+def price_of(s):
+    op = s.split()[0]
+    if re.match(r"v_(rcp|rsq|sqrt|exp|log|sin|cos)", op):
+        return PRICE["trans"]
+    if op.startswith("v_pk_fma"):
+        return PRICE["pk_fma"]
+    if op.startswith("v_pk_"):
+        return PRICE["pk"]
+    if op.endswith("_f64") or "_f64_" in op:
+        return PRICE["fma_f64"] if "fma" in op else PRICE["f64"]
+    if op.startswith("v_cmp"):
+        return PRICE["cmp"]
+    if op.startswith("v_cndmask"):
+        return PRICE["cndmask"]
+    if re.match(r"v_(readlane|writelane|readfirstlane)", op):
+        return PRICE["lane"]
+    operands = s.split(None, 1)[1] if " " in s else ""
+    if re.search(r"(^|[ ,\-|])s(\d+|\[\d+:\d+\])", operands):
+        return PRICE["sgpr_operand"]
+    return PRICE["plain"]
+
+
 def count(lines):
     v = tr = f64 = 0
+    price = 0.0
     for ln in lines:
         s = ln.strip()
         if not s.startswith("v_"):
             continue
         op = s.split()[0]
         v += 1
+        price += price_of(s.split(";")[0])
         if re.match(r"v_(rcp|rsq|sqrt|exp|log|sin|cos)", op):
             tr += 1
         if op.endswith("_f64") or "_f64_" in op:
             f64 += 1
-    return v, tr, f64
+    return v, tr, f64, price
 
 
 def compile_counts(src, defs, name):
@@ -409,8 +439,9 @@ def main():
     print("# vector instructions per ray of each phase (static = dynamic: branch-free), gfx950, "
           + (" ".join(defs) or "product knobs"))
     print(f"# {'phase':<48} " + " ".join(f"{t[1]:>26}" for t in types))
-    print(f"# {'':<48} " + " ".join(f"{'VALU (transc., fp64)':>26}" for _ in types))
-    per_surface = {t[0]: [0, 0, 0] for t in types}
+    print(f"# {'':<48} " + " ".join(f"{'VALU (transc., fp64) price':>26}" for _ in types))
+    per_surface = {t[0]: [0, 0, 0, 0.0] for t in types}
+    priced = {}
     for label, kern, base in rows:
         cells = []
         for t, _ in types:
@@ -418,22 +449,24 @@ def main():
             if k is None or b is None:
                 cells.append(f"{'-':>26}")
                 continue
-            v, tr, f64 = k[0] - b[0], k[1] - b[1], k[2] - b[2]
-            cells.append(f"{v:>12d} ({tr:d}, {f64:d})".rjust(26))
+            v, tr, f64, pr = k[0] - b[0], k[1] - b[1], k[2] - b[2], k[3] - b[3]
+            cells.append(f"{v:>8d} ({tr:d}, {f64:d}) {pr:6.0f}".rjust(26))
+            priced.setdefault(t, {})[label] = (v, pr)
             if label.startswith(("frame", "conic inter", "move to the hit + normal, sphere",
                                  "interact: OPD + radial")):
-                for q, x in enumerate((v, tr, f64)):
+                for q, x in enumerate((v, tr, f64, pr)):
                     per_surface[t][q] += x
         print(f"  {label:<48} " + " ".join(cells))
     print(f"  {'ONE spherical surface with a radial aperture':<48} " + " ".join(
-        f"{per_surface[t][0]:>12d} ({per_surface[t][1]:d}, {per_surface[t][2]:d})".rjust(26)
-        for t, _ in types))
-    print("# issue cycles per wave: full-rate VALU 4, transcendental (v_rcp / v_rsq / v_sqrt) 16;"
-          " fp64 FMA / MUL / ADD issue at half the fp32 rate on this part")
-    polarised(defs)
+        f"{per_surface[t][0]:>8d} ({per_surface[t][1]:d}, {per_surface[t][2]:d}) "
+        f"{per_surface[t][3]:6.0f}".rjust(26) for t, _ in types))
+    print("# last number of a cell = PRICE: issue cost in units of one plain fp32 instruction on "
+          "vector registers (1.13 ns per wave-instruction and SIMD at 8 waves, "
+          "profiles/r06_valu_rate.txt): " + ", ".join(f"{k} {v}" for k, v in PRICE.items()))
+    polarised(defs, priced)
 
 
-def polarised(defs):
+def polarised(defs, priced=None):
     """Round 6: where the vector instructions of the polarised Zernike kernel (configuration C5:
     raygen -> Zernike surface with a Fresnel coating -> spherical surface with a Fresnel coating
     -> image plane, every row recorded, update_intensity epilogue) go.  Static counts of branch-
@@ -463,8 +496,9 @@ def polarised(defs):
     print()
     print("# round 6: the polarised Zernike kernel (configuration C5), one ray per lane")
     print(f"# {'phase':<58} " + " ".join(f"{t:>26}" for t in types))
-    print(f"# {'':<58} " + " ".join(f"{'VALU (transc., fp64)':>26}" for _ in types))
+    print(f"# {'':<58} " + " ".join(f"{'VALU (transc., fp64) price':>26}" for _ in types))
     cost = {t: {} for t in types}
+    pcost = {t: {} for t in types}
     for label, kern, base, tag in rows:
         cells = []
         for t in types:
@@ -472,10 +506,11 @@ def polarised(defs):
             if k is None or b is None:
                 cells.append(f"{'-':>26}")
                 continue
-            v, tr, f64 = k[0] - b[0], k[1] - b[1], k[2] - b[2]
-            cells.append(f"{v:>12d} ({tr:d}, {f64:d})".rjust(26))
+            v, tr, f64, pr = k[0] - b[0], k[1] - b[1], k[2] - b[2], k[3] - b[3]
+            cells.append(f"{v:>8d} ({tr:d}, {f64:d}) {pr:6.0f}".rjust(26))
             if tag:
                 cost[t][tag] = cost[t].get(tag, 0) + v
+                pcost[t][tag] = pcost[t].get(tag, 0.0) + pr
         print(f"  {label:<58} " + " ".join(cells))
     # the budget of one C5 ray from these rows and the conic rows above (float: 3 / 32 / 13 for
     # frame change / intersection / hit + normal; double: 3 / 64 / 15), for K Newton evaluations
@@ -491,6 +526,28 @@ def polarised(defs):
                   f"{fr + c['Z']} + K x {c['I']} + spherical surface {fr + dist + hit + c['S']} + "
                   f"image plane {fr + 10 + plain} + 4 rows to global 12 + epilogue "
                   f"{c['R'] + c[epi]} = " + ", ".join(f"{v} (K = {k})" for k, v in tot.items()))
+    # the same budget PRICED (K = 2): what the launch costs in issue time, against the measured
+    # engine cycles (profiles/r06_cycles.txt: 5.3e5 per launch and XCD at 1e7 rays = 3470 per wave
+    # and SIMD slot; one price unit = 1.13 ns x the clock of the valu_rate run, ~2.4 cycles)
+    if priced:
+        names = {"fr": "frame change (unrotated: + offset)",
+                 "dist": "conic intersection (curved_distance)",
+                 "hit": "move to the hit + normal, sphere",
+                 "plain": "interact: OPD + Snell, no aperture",
+                 "glob": "local -> global of a recorded row (unrotated)"}
+        for t in types:
+            if t not in priced:
+                continue
+            q = {k: priced[t][v][1] for k, v in names.items()}
+            c = pcost[t]
+            fixed = (c["R"] + q["fr"] + c["Z"] + q["fr"] + q["dist"] + q["hit"] + c["S"] + q["fr"]
+                     + 10 + q["plain"] + 4 * q["glob"])
+            tot = fixed + 2 * c["I"] + c["R"] + c["P1"]
+            print(f"# {t}: the same ray PRICED (K = 2, polarised state): {tot:.0f} units = "
+                  f"{tot * 1.13:.0f} ns of issue per wave and SIMD slot at the valu_rate clock; "
+                  f"152.6 waves per SIMD at 1e7 rays: {tot * 1.13 * 152.6 * 1e-6:.3f} ms of vector "
+                  "issue per launch (stores, address arithmetic and spill reloads not in the "
+                  "phases: +~20 %)")
     return cost
 
 
