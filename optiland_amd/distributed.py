@@ -23,6 +23,8 @@ code over "gloo".
 
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -147,12 +149,23 @@ class ShardedTracer:
         self.tracer = tracer
         self.group = group
         self.world, self.rank = _world(group)
-        # Reference-rule Newton surfaces (`reference_newton`, newton_raphson.py:137-166): the
-        # number of updates is a property of the WHOLE batch, so the counts of the shards are
-        # combined (MAX, 8 S bytes) after every counting launch.
-        eng = getattr(tracer, "engine", None)
-        if eng is not None and _exchanging(group):   # (only called when such surfaces exist)
-            eng.newton_count_hook = lambda iters: allreduce_max(iters, group)
+
+    @contextlib.contextmanager
+    def _whole_batch_newton_counts(self):
+        """Reference-rule Newton surfaces (`reference_newton`, newton_raphson.py:137-166): the
+        number of updates is a property of the WHOLE batch, so the counts of the shards are
+        combined (MAX, 8 S bytes) after every counting launch -- while a SHARDED call runs: a
+        trace one rank makes by itself on the same engine must not wait for the others."""
+        eng = getattr(self.tracer, "engine", None)
+        if eng is None or not _exchanging(self.group) or not hasattr(eng, "newton_count_hook"):
+            yield    # (an engine stand-in without reference-rule Newton surfaces)
+            return
+        was = eng.newton_count_hook
+        eng.newton_count_hook = lambda iters: allreduce_max(iters, self.group)
+        try:
+            yield
+        finally:
+            eng.newton_count_hook = was
 
     def _no_reference_newton(self, what: str):
         # the fused entry points generate the rays inside the launch; the counting launches of
@@ -185,17 +198,18 @@ class ShardedTracer:
         n = max(a.numel() for a in arrs)
         lo, hi = shard_bounds(n, self.world, self.rank)
         out = {"rays": None, "lo": lo, "hi": hi, "n_total": n}
-        if hi > lo:
-            # one-element coordinates are broadcast over the GLOBAL list (n is the same on
-            # every rank because it is taken before slicing)
-            loc = [a.expand(hi - lo) if a.numel() == 1 else a[lo:hi] for a in arrs]
-            rays = out["rays"] = t.trace_generic(*loc, wavelength)
-            x, y, i = rays.x, rays.y, rays.i
-        else:  # more ranks than rays: nothing to launch, zero contribution below
-            x = y = i = torch.empty(0, dtype=t.dtype, device=t.device)
-            empty = getattr(t.engine, "newton_counts_of_an_empty_shard", None)
-            if empty is not None:
-                empty()
+        with self._whole_batch_newton_counts():
+            if hi > lo:
+                # one-element coordinates are broadcast over the GLOBAL list (n is the same on
+                # every rank because it is taken before slicing)
+                loc = [a.expand(hi - lo) if a.numel() == 1 else a[lo:hi] for a in arrs]
+                rays = out["rays"] = t.trace_generic(*loc, wavelength)
+                x, y, i = rays.x, rays.y, rays.i
+            else:  # more ranks than rays: nothing to launch, zero contribution below
+                x = y = i = torch.empty(0, dtype=t.dtype, device=t.device)
+                empty = getattr(t.engine, "newton_counts_of_an_empty_shard", None)
+                if empty is not None:
+                    empty()
         if exchange == "gather":
             out["hits"] = allgather_hits(x, y, i, n, self.group)
         elif exchange == "reduce":
