@@ -1101,9 +1101,10 @@ OL_DEV void zernike_mono_eval(const DevSurf<float>& s, cptr<float> c, f32x2 x, f
   Mask2 out;
   zernike_begin(s, x, y, sag, fx, fy, xn, yn, u, out);
   if (m::any(m::mand(out, report))) status |= 0x1u;  // OL_STATUS_ZERNIKE_RANGE
-  static_assert(OL_ZERN_MONO_F32_TWO_BLOCKS && OL_ZERN_MONO_SPLIT,
-                "the pair form has the two-block fixed-degree instances only");
-  switch (OL_ZERN_MONO_FIXED ? s.n_coeff : 0) {  // wave-uniform
+  // (the unrolled instances exist in the two-block form only; A/B builds that switch that form
+  // off run the loops -- the same multiply-adds in the same order)
+  constexpr bool kFixed = OL_ZERN_MONO_FIXED && OL_ZERN_MONO_F32_TWO_BLOCKS && OL_ZERN_MONO_SPLIT;
+  switch (kFixed ? s.n_coeff : 0) {  // wave-uniform
     case 2: zernike_mono_two_blocks<2>(c, xn, yn, zsum, gx, gy); break;
     case 3: zernike_mono_two_blocks<3>(c, xn, yn, zsum, gx, gy); break;
     case 4: zernike_mono_two_blocks<4>(c, xn, yn, zsum, gx, gy); break;

@@ -22,6 +22,7 @@ VARIANTS = {
     # (rows through a copy, per-lane PRT bases, fresh record arguments, packed PRT)
     # the polarised Zernike fp32 pair (OL_POLZ_PAIR): occupancy requests (108 VGPRs = 4 waves by
     # itself; 5 waves: 11 VGPRs to scratch, 6: 39), and the pair on two SCALAR rays per lane
+    "o6_pair_off": ["-DOL_POLZ_PAIR=0"],
     "o6_pair_w5": ["-DOL_POLZ_PAIR_WAVES=5"],
     "o6_pair_w6": ["-DOL_POLZ_PAIR_WAVES=6"],
     "o6_pair_unpacked": ["-DOL_POLZ_PACKED=0"],
