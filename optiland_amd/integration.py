@@ -430,6 +430,16 @@ def register_pending_record(optic, table, engine, dtype, launch):
                          _PendingRecord(optic, table, engine, dtype, launch), dtype)
 
 
+def forget_pending_record(optic):
+    """Drop a trace that was registered for `optic`'s surfaces and has not been RUN (a launch
+    whose status turned out bad after it was registered): nothing will try to produce it."""
+    if not _PENDING:
+        return
+    for surf in optic.surfaces.surfaces:
+        if isinstance(_PENDING.get(surf), _PendingRecord):
+            del _PENDING[surf]
+
+
 class _Volatile:
     """Holder of drop-in state that hangs on a REFERENCE object (`SurfaceGroup.__dict__`) and
     must not travel with it: change-detector tokens embed `id()`s, engines own device handles.

@@ -1068,3 +1068,26 @@ def test_field_coordinates_are_remembered_until_a_field_or_the_backend_changes(s
     assert stats["field_coords_memo"] == n
     import copy
     assert copy.deepcopy(lens).fields.get_field_coords() == original(fg)
+
+
+def test_encircled_energy_reads_the_status_once_per_grid_and_still_raises(seams):
+    """The encircled-energy cells need nothing of their launch on the host: inside the grid loop
+    no cell reads the status word back -- it accumulates in the engine and is read once when the
+    loop is over (`analysis_seams._image_hits` / `_spot_generate_data`).  A Zernike surface whose
+    normalisation radius the beam overfills still raises the reference's own error
+    (geometries/zernike.py:262-266), and a good lens after it is served as before."""
+    be, stats = seams
+    from optiland import analysis
+    from tests import _live
+
+    lens = _live.zernike_fresnel(polarization=None)
+    e = analysis.EncircledEnergy(lens, num_rays=7, distribution="random", num_points=16)
+    assert stats["ee"] == len(e.fields) * len(e.wavelengths) and stats["ee_fallback"] == 0
+    assert stats["spot_grid"] == 0      # ("random": a draw per cell, the reference's own loop)
+    bad = _live.zernike_fresnel(polarization=None)
+    bad.surfaces[1].geometry.norm_radius = 5.0          # EPD 20: rays leave the unit disc
+    with pytest.raises(ValueError, match="Zernike coordinates must be normalized"):
+        analysis.EncircledEnergy(bad, num_rays=7, distribution="random", num_points=16)
+    n = stats["ee"]
+    analysis.EncircledEnergy(lens, num_rays=7, distribution="random", num_points=16)
+    assert stats["ee"] > n and stats["ee_fallback"] == 0
