@@ -1153,7 +1153,33 @@ _SEAMS = {
                  ("self", "num_rings"), "_hexapolar_generate_points"),
     "field_coords": ("optiland.fields.field_group", "FieldGroup", "get_field_coords", ("self",),
                      "_memo_get_field_coords"),
+    "wf_init": ("optiland.wavefront.wavefront", "Wavefront", "__init__",
+                ("self", "optic", "fields", "wavelengths", "num_rays", "distribution", "strategy",
+                 "afocal", "remove_tilt", "kwargs"), "_wavefront_init"),
+    "fft_init": ("optiland.psf.fft", "ScalarFFTPSF", "__init__",
+                 ("self", "optic", "field", "wavelength", "num_rays", "grid_size", "strategy",
+                  "remove_tilt", "kwargs"), "_fft_init"),
 }
+def _constructor_scope(key):
+    """A constructor of the reference that only READS its optic -- `Wavefront.__init__`
+    (wavefront/wavefront.py:56-90: fields, strategy, the fields x wavelengths loop) and
+    `ScalarFFTPSF.__init__` (psf/fft.py:87-123: the same, then pupils and the transform) -- run
+    inside `integration.unchanged(optic)`: the change detector walks the optic once per
+    constructor instead of once per seam it passes through (strategy constructor, wavefront
+    data, pupil fill: 3-4 walks of ~0.06 ms in a 0.4-0.9 ms call, profiles/r06_seam_profile.txt)."""
+    def init(self, *args, **kwargs):
+        from . import integration as ig
+
+        optic = kwargs.get("optic", args[0] if args else None)
+        with ig.unchanged(optic):
+            return _ORIG[key](self, *args, **kwargs)
+    return init
+
+
+_wavefront_init = _constructor_scope("wf_init")
+_fft_init = _constructor_scope("fft_init")
+
+
 def _memo_get_field_coords(self):
     """`FieldGroup.get_field_coords()` (fields/field_group.py:124-139), remembered.  Every analysis
     constructor asks for it (`utils.resolve_fields(optic, "all")`), and on the torch backend each

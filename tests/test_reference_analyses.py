@@ -1091,3 +1091,37 @@ def test_encircled_energy_reads_the_status_once_per_grid_and_still_raises(seams)
     n = stats["ee"]
     analysis.EncircledEnergy(lens, num_rays=7, distribution="random", num_points=16)
     assert stats["ee"] > n and stats["ee_fallback"] == 0
+
+
+def test_wavefront_and_fft_psf_constructors_walk_the_optic_once(seams, monkeypatch):
+    """`Wavefront.__init__` / `ScalarFFTPSF.__init__` only read their optic: they run inside
+    `integration.unchanged(optic)`, so the strategy constructor, the wavefront data and the pupil
+    fill share ONE walk of the change detector -- and an edit between two constructors is seen."""
+    be, stats = seams
+    from optiland import wavefront
+    from optiland.psf import FFTPSF
+    from optiland_amd import fingerprint as fp
+    from optiland_amd import integration as ig
+    lens = _cooke()
+    walks = {"n": 0}
+    orig = fp.optic_token
+
+    def counting(*a, **k):
+        walks["n"] += 1
+        return orig(*a, **k)
+
+    monkeypatch.setattr(fp, "optic_token", counting)
+    wavefront.OPD(lens, (0, 1), 0.55, num_rays=16)       # (packs the optic: any number of walks)
+    for build in (lambda: wavefront.OPD(lens, (0, 1), 0.55, num_rays=16),
+                  lambda: wavefront.OPD(lens, (0, 1), 0.55, num_rays=16, strategy="best_fit_sphere"),
+                  lambda: FFTPSF(lens, (0, 1), 0.55, num_rays=32, grid_size=64)):
+        build()
+        walks["n"] = 0
+        build()
+        assert walks["n"] == 1, walks["n"]
+    comp = ig.hip_tracer_of(lens)
+    assert comp._hip_trusted is None and comp._hip_trust_depth == 0
+    before = _np(be, FFTPSF(lens, (0, 1), 0.55, num_rays=32, grid_size=64).psf)
+    lens.updater.set_radius(float(lens.surfaces[1].geometry.radius) * 1.05, 1)
+    after = _np(be, FFTPSF(lens, (0, 1), 0.55, num_rays=32, grid_size=64).psf)
+    assert np.abs(after - before).max() > 1e-6 * np.abs(before).max()
