@@ -1125,3 +1125,56 @@ def test_wavefront_and_fft_psf_constructors_walk_the_optic_once(seams, monkeypat
     lens.updater.set_radius(float(lens.surfaces[1].geometry.radius) * 1.05, 1)
     after = _np(be, FFTPSF(lens, (0, 1), 0.55, num_rays=32, grid_size=64).psf)
     assert np.abs(after - before).max() > 1e-6 * np.abs(before).max()
+
+
+def test_analyses_follow_field_and_prescription_edits(seams):
+    """Field coordinates edited in place, a field added, a radius and a thickness changed --
+    between analyses of ONE optic: the remembered field coordinates, the one-walk constructor
+    scopes and the whole-grid seams all have to notice.  Spot radii (local chief-ray and global
+    centroid references), an OPD map and an FFT PSF after every edit, against the NumPy backend."""
+    be, stats = seams
+    from optiland import analysis, wavefront
+    from optiland.psf import FFTPSF
+
+    def measure(lens):
+        out = []
+        s = analysis.SpotDiagram(lens, num_rings=4)
+        out += [_np(be, v) for f in s.rms_spot_radius() for v in f]
+        out += [_np(be, v) for f in s.geometric_spot_radius() for v in f]
+        s2 = analysis.SpotDiagram(lens, num_rings=4, coordinates="global", reference="centroid")
+        out += [_np(be, v) for f in s2.rms_spot_radius() for v in f]
+        o = wavefront.OPD(lens, (0, 1), 0.55, num_rays=16)
+        out.append(_np(be, list(o.data.values())[0].opd))
+        out.append(_np(be, FFTPSF(lens, (0, 0.7), 0.55, num_rays=32, grid_size=64).psf))
+        return out
+
+    def edit(lens, k):
+        if k == 0:
+            lens.fields.fields[1].y = 9.0
+        elif k == 1:
+            lens.fields.fields[2].x = 3.0
+        elif k == 2:
+            lens.fields.add(y=5.0)
+        elif k == 3:
+            lens.updater.set_radius(float(lens.surfaces[1].geometry.radius) * 1.03, 1)
+        elif k == 4:
+            lens.fields.fields[0].y = 1.0
+        else:
+            lens.updater.set_thickness(float(lens.surfaces[2].thickness) * 1.02, 2)
+
+    def run(lens):
+        states = [measure(lens)]
+        for k in range(6):
+            edit(lens, k)
+            states.append(measure(lens))
+        return states
+
+    want = _numpy_reference(be, _cooke, run)
+    got = run(_cooke())
+    assert stats["spot_fallback"] == stats["opd_fallback"] == stats["pupil_fallback"] == 0
+    assert stats["field_coords_memo"] > 0
+    assert stats["spot_radius"] > 0 or stats["spot_grid"] == 0   # (the oracle stand-in: per cell)
+    for step, (a, b) in enumerate(zip(got, want)):
+        for u, v in zip(a, b):
+            scale = max(float(np.abs(v).max()), 1e-30)
+            assert float(np.abs(u - v).max()) <= 1e-8 * scale, step
