@@ -291,6 +291,11 @@ def _newton_worker(rank, world, port, q, n):
         st = ShardedTracer(t)
         wl = float(table.wavelengths[0])
         out = st.trace_generic(*_ref_newton_rays(n), wl, exchange="reduce")
+        # (the exchange is installed for the sharded call only: a trace this rank makes by
+        # itself afterwards must not wait for the other ranks)
+        assert t.engine.newton_count_hook is None
+        if rank == 0:
+            t.trace_generic(*[a[:8] for a in _ref_newton_rays(max(n, 8))], wl)
         rays = out["rays"]
         got = None if rays is None else np.stack([np.asarray(getattr(rays, k))
                                                   for k in ("x", "y", "z", "L", "M", "N", "opd")])
