@@ -180,6 +180,22 @@ for k, v in acc.items():
           f"{a[:, 1].mean() / 8:.4g}  clock {a[:, 2].mean() / 8:.0f} MHz")
 PY
       done; unset OPTILAND_HIP_LIBRARY ;;
+    c5_window) # the driver's window (5 + 20 launches) of C5 fp32, one ray per lane against pairs, arms alternating
+      for rep in 1 2 3; do for arm in 1 3; do
+        OL_TRACE_RPT=$arm python bench.py --steps 20 --warmup 5 --no-cpu-baseline --traffic committed --workload zernike_fresnel > $O/c5w_${arm}_${rep}.json 2>/dev/null
+        python - $O/c5w_${arm}_${rep}.json $arm $rep <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+r = d["roofline"]; st = r.get("steady_state") or {}
+print(f"rpt={sys.argv[2]} rep={sys.argv[3]} ms_per_step {d['ms_per_step']:.4f} kernel_ms {r['kernel_ms']:.4f} {r['kernel_us_minmax']} frac {r['frac']:.3f} steady {st.get('kernel_ms')} {st.get('frac')}")
+PY
+      done; done ;;
+    polz_fuzz) # 1500 shaken C5 systems, pair form against one ray per lane, bits and status words
+      timeout 1200 python tools/gpu_polz_fuzz.py 2>&1 | tail -5 ;;
+    seam_profile) # wall time + cProfile of the reference's EE / OPD / FFTPSF / Optic.trace through the seams
+      timeout 600 python tools/gpu_seam_profile.py 2>&1 | grep "ms per call" ;;
+    valu_rate) # what a vector instruction costs (tools/microbench/valu_rate.hip, built beforehand)
+      timeout 200 tools/microbench/valu_rate > $O/r06_valu_rate.txt 2>&1; grep "SIMD 8" $O/r06_valu_rate.txt ;;
     polz_table) # SQ counters per ray of the C5 fp32 launch on one ray per lane (OL_TRACE_RPT=1) and on pairs (3)
       for arm in 1 3; do
         OL_TRACE_RPT=$arm bash tools/gpu_kernel_table.sh $O/r06_polz_table_$arm.txt > /dev/null 2>&1 <<'CFG'
