@@ -1109,12 +1109,48 @@ def _hexapolar_generate_points(self, num_rings=6):
     self.x, self.y = got
 
 
-# (No seam on `UniformDistribution.generate_points`: it is five array operations on the device
-# already, and its consumers build the SAME grid once more with the backend's own `linspace`
-# and rely on the two masks agreeing point for point (psf/fft.py:140-155) -- the torch
-# backend's `linspace` walks the upper half of the interval back from the end point and its
-# disc mask differs from NumPy's in a few rim points (25445 vs 25441 at 181 x 181).  The
-# stand-alone tracer's "uniform" keeps NumPy's arithmetic, as before.)
+# (No sampler of our own behind `UniformDistribution.generate_points`: its consumers build the
+# SAME grid once more with the backend's own `linspace` and rely on the two masks agreeing point
+# for point (psf/fft.py:140-155) -- the torch backend's `linspace` walks the upper half of the
+# interval back from the end point and its disc mask differs from NumPy's in a few rim points
+# (25445 vs 25441 at 181 x 181).  The stand-alone tracer's "uniform" keeps NumPy's arithmetic, as
+# before.  What the seam below does instead: REMEMBER the backend's own answer.)
+_UNIFORM_MEMO: dict = {}
+
+
+def _uniform_generate_points(self, num_points):
+    """distribution.py:176-186 on the torch backend: linspace, meshgrid, two squares, a sum, a
+    compare and two boolean selections (each a device-to-host read of the count) -- ~0.15 ms of
+    every `FFTPSF(...)` / uniform `OPD(...)` constructor for a grid that depends on `num_points`
+    and the backend's arithmetic alone.  The reference's own result is kept per (num_points,
+    backend, precision, device) and handed out as COPIES (two launches); autograd on, another
+    backend, a subclass: the reference's code."""
+    import optiland.backend as be
+    from optiland.distribution import UniformDistribution
+
+    original = _ORIG["dist_uniform"]
+    try:
+        if type(self) is not UniformDistribution or be.get_backend() != "torch":
+            return original(self, num_points)
+        cfg = be._backends["torch"]._config
+        if cfg.grad_mode.requires_grad:
+            return original(self, num_points)
+        key = (int(num_points), cfg.get_precision(), str(cfg.get_device()),
+               torch.cuda.current_device() if str(cfg.get_device()) == "cuda" else -1)
+    except Exception:  # noqa: BLE001 - a backend object without that configuration
+        return original(self, num_points)
+    hit = _UNIFORM_MEMO.get(key)
+    if hit is None:
+        original(self, num_points)
+        x, y = getattr(self, "x", None), getattr(self, "y", None)
+        if isinstance(x, torch.Tensor) and isinstance(y, torch.Tensor) and x.numel() <= (1 << 22):
+            if len(_UNIFORM_MEMO) >= 16:
+                _UNIFORM_MEMO.pop(next(iter(_UNIFORM_MEMO)))
+            _UNIFORM_MEMO[key] = (x.detach().clone(), y.detach().clone())
+        return None
+    STATS["uniform_memo"] = STATS.get("uniform_memo", 0) + 1
+    self.x, self.y = hit[0].clone(), hit[1].clone()
+    return None
 
 
 # --------------------------------------------------------------------------- (de)activate
@@ -1153,6 +1189,8 @@ _SEAMS = {
                  ("self", "num_rings"), "_hexapolar_generate_points"),
     "field_coords": ("optiland.fields.field_group", "FieldGroup", "get_field_coords", ("self",),
                      "_memo_get_field_coords"),
+    "dist_uniform": ("optiland.distribution", "UniformDistribution", "generate_points",
+                     ("self", "num_points"), "_uniform_generate_points"),
     "wf_init": ("optiland.wavefront.wavefront", "Wavefront", "__init__",
                 ("self", "optic", "fields", "wavelengths", "num_rays", "distribution", "strategy",
                  "afocal", "remove_tilt", "kwargs"), "_wavefront_init"),

@@ -1178,3 +1178,45 @@ def test_analyses_follow_field_and_prescription_edits(seams):
         for u, v in zip(a, b):
             scale = max(float(np.abs(v).max()), 1e-30)
             assert float(np.abs(u - v).max()) <= 1e-8 * scale, step
+
+
+def test_uniform_pupil_grid_is_remembered_per_size_and_backend_arithmetic(seams):
+    """`UniformDistribution.generate_points` (distribution.py:176-186): the backend's OWN grid --
+    the one its consumers' masks have to agree with -- computed once per (num_points, precision,
+    device) and handed out as copies; autograd on: the reference's code."""
+    be, stats = seams
+    from optiland import distribution
+    from optiland_amd import analysis_seams
+    analysis_seams._UNIFORM_MEMO.clear()
+    original = analysis_seams._ORIG["dist_uniform"]
+    a = distribution.create_distribution("uniform")
+    a.generate_points(33)
+    assert stats.get("uniform_memo", 0) == 0
+    b = distribution.create_distribution("uniform")
+    b.generate_points(33)
+    assert stats["uniform_memo"] == 1
+    ref = distribution.create_distribution("uniform")
+    original(ref, 33)
+    for d in (a, b):
+        assert np.array_equal(_np(be, d.x), _np(be, ref.x)) and np.array_equal(_np(be, d.y), _np(be, ref.y))
+    b.x *= 2.0                                  # a caller's copy is the caller's
+    c = distribution.create_distribution("uniform")
+    c.generate_points(33)
+    assert np.array_equal(_np(be, c.x), _np(be, ref.x))
+    c.generate_points(34)                       # another size: computed
+    assert c.x.shape != ref.x.shape and stats["uniform_memo"] == 2
+    be.set_precision("float32")
+    try:
+        n = stats["uniform_memo"]
+        d32 = distribution.create_distribution("uniform")
+        d32.generate_points(33)
+        assert stats["uniform_memo"] == n and d32.x.dtype != ref.x.dtype
+    finally:
+        be.set_precision("float64")
+    be.grad_mode.enable()
+    try:
+        n = stats["uniform_memo"]
+        distribution.create_distribution("uniform").generate_points(33)
+        assert stats["uniform_memo"] == n
+    finally:
+        be.grad_mode.disable()
